@@ -1,0 +1,507 @@
+"""CPU restatement (numpy) of the cgs-vmc batched VMC inner loop.  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: the reference (/root/reference/cgs_vmc) is Python on TensorFlow 1.x +
+Sonnet v1, neither of which can be imported here, and it ships no tests, golden vectors
+or fixtures.  This file follows the reference op for op (citations below are
+file:line under /root/reference/cgs_vmc) and is pinned instead by closed-form /
+exact-diagonalisation / autograd / finite-difference checks in tests/.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product path (cgs_vmc_amd) never does.
+
+Parameter vector layout (a9, wavefunctions.py:167-175 creation order of snt.Linear
+variables): [w_1 (N,H), b_1 (H), w_2 (H,H), b_2 (H), ..., w_out (H,1), b_out (1)],
+each row-major, w:[in,out].
+
+All functions take a `dtype` (np.float32 = the reference's arithmetic type;
+np.float64 = the high-precision twin used to state tolerances).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------- #
+# Activations (layers.py:13-21)
+# --------------------------------------------------------------------------- #
+NONLINEARITIES = {
+    'relu': lambda x: np.maximum(x, 0),
+    'exp': np.exp,
+    'cos': np.cos,
+    'tan': np.tan,
+    'tanh': np.tanh,
+    'sigmoid': lambda x: 1.0 / (1.0 + np.exp(-x)),
+    'identity': lambda x: x,
+}
+
+_NONLIN_DERIV = {
+    'relu': lambda z, a: (z > 0).astype(z.dtype),
+    'tanh': lambda z, a: 1 - a * a,
+    'sigmoid': lambda z, a: a * (1 - a),
+    'identity': lambda z, a: np.ones_like(z),
+    'exp': lambda z, a: a,
+    'cos': lambda z, a: -np.sin(z),
+    'tan': lambda z, a: 1 + a * a,
+}
+
+
+# --------------------------------------------------------------------------- #
+# Parameters
+# --------------------------------------------------------------------------- #
+def param_shapes(n_sites, layer_size, num_layers):
+  """Shapes of FullyConnectedNetwork variables in creation order.
+
+  wavefunctions.py:345-349: num_layers x [Linear(layer_size), act], Linear(1).
+  """
+  shapes = []
+  fan_in = n_sites
+  for _ in range(num_layers):
+    shapes += [(fan_in, layer_size), (layer_size,)]
+    fan_in = layer_size
+  shapes += [(fan_in, 1), (1,)]
+  return shapes
+
+
+def num_params(n_sites, layer_size, num_layers):
+  return int(sum(int(np.prod(s)) for s in param_shapes(n_sites, layer_size, num_layers)))
+
+
+def unpack(theta, n_sites, layer_size, num_layers):
+  """Splits a flat parameter vector into [(w, b), ...] (views)."""
+  out, off = [], 0
+  shapes = param_shapes(n_sites, layer_size, num_layers)
+  for k in range(0, len(shapes), 2):
+    ws, bs = shapes[k], shapes[k + 1]
+    nw, nb = int(np.prod(ws)), int(np.prod(bs))
+    w = theta[off:off + nw].reshape(ws); off += nw
+    b = theta[off:off + nb].reshape(bs); off += nb
+    out.append((w, b))
+  assert off == theta.size
+  return out
+
+
+def init_params(n_sites, layer_size, num_layers, rng):
+  """Sonnet-v1 snt.Linear default init restated: w ~ truncated normal (|x|<2 sigma)
+  with sigma = 1/sqrt(fan_in), b = 0 (third-party semantics)."""
+  parts = []
+  for shp in param_shapes(n_sites, layer_size, num_layers):
+    if len(shp) == 2:
+      sigma = 1.0 / np.sqrt(shp[0])
+      w = rng.standard_normal(shp)
+      bad = np.abs(w) > 2
+      while bad.any():
+        w[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(w) > 2
+      parts.append((w * sigma).ravel())
+    else:
+      parts.append(np.zeros(shp).ravel())
+  return np.concatenate(parts).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- #
+# Ansatz: FullyConnectedNetwork (wavefunctions.py:328-371) + exp shift (206-232)
+# --------------------------------------------------------------------------- #
+def fc_logit(theta, configs, layer_size, num_layers, nonlinearity='relu',
+             dtype=np.float32, return_acts=False):
+  """Pre-exp output of the network: squeeze(Linear(1)(act(Linear(...)))).
+
+  wavefunctions.py:345-349, 370-371.  `configs` [B,N] of +-1.
+  """
+  x = np.asarray(configs, dtype=dtype)
+  layers = unpack(np.asarray(theta, dtype=dtype), x.shape[1], layer_size, num_layers)
+  act = NONLINEARITIES[nonlinearity]
+  zs, acts = [], [x]
+  a = x
+  for (w, b) in layers[:-1]:
+    z = a @ w + b
+    a = act(z)
+    zs.append(z); acts.append(a)
+  w, b = layers[-1]
+  logit = (a @ w + b)[:, 0]
+  if return_acts:
+    return logit, zs, acts
+  return logit
+
+
+def fc_psi(theta, configs, layer_size, num_layers, shift=-10.0, nonlinearity='relu',
+           output_activation='exp', dtype=np.float32):
+  """psi = exp(logit - exp_norm_shift) (wavefunctions.py:350-353, 232); shift starts
+  at -10 (wavefunctions.py:209)."""
+  logit = fc_logit(theta, configs, layer_size, num_layers, nonlinearity, dtype)
+  if output_activation == 'exp':
+    with np.errstate(over='ignore'):
+      return np.exp(logit - dtype(shift))
+  return NONLINEARITIES[output_activation](logit)
+
+
+def update_norm(psi, shift, max_value=1e10):
+  """wavefunctions.py:261-288: if log(max psi) > log(max_value) the shift grows by the
+  excess, otherwise += 0."""
+  max_log = np.log(max_value)
+  log_max = np.log(np.max(psi))
+  if log_max > max_log:
+    return np.float32(shift + (log_max - max_log))
+  return np.float32(shift)
+
+
+def normalize_batch(psi, shift, max_value=1e10):
+  """wavefunctions.py:234-259."""
+  return np.float32(shift + (np.log(np.max(psi)) - np.log(max_value)))
+
+
+# --------------------------------------------------------------------------- #
+# Initial chains (utils.py:169-192)
+# --------------------------------------------------------------------------- #
+def random_configurations(n_sites, batch_size, rng):
+  """All +1, then n_sites//2 distinct random sites set to -1 by rejection; float32.
+  The reference is unseeded (np.random.RandomState()); here the caller owns `rng`
+  (np.random.RandomState-compatible .randint)."""
+  configurations = np.ones((batch_size, n_sites))
+  for i in range(batch_size):
+    pos = rng.randint(0, n_sites)
+    for _ in range(n_sites // 2):
+      while configurations[i, pos] != 1.0:
+        pos = rng.randint(0, n_sites)
+      configurations[i, pos] = -1.0
+  return configurations.astype(np.float32)
+
+
+# --------------------------------------------------------------------------- #
+# Counter-based RNG: Philox4x32-10 (Salmon et al., SC'11; Random123 v1.14 KAT pinned
+# in tests/test_oracle_rng.py).  The reference uses tf.random_uniform (unseeded), so
+# the generator is this build's own choice; the *use* of the uniforms follows
+# graph_builders.py:59-65,76-77.
+# --------------------------------------------------------------------------- #
+_PHILOX_M0 = np.uint64(0xD2511F53)
+_PHILOX_M1 = np.uint64(0xCD9E8D57)
+_PHILOX_W0 = np.uint32(0x9E3779B9)
+_PHILOX_W1 = np.uint32(0xBB67AE85)
+ACCEPT_BLOCK = 0xFFFFFFFF  # counter word 0 of the acceptance draw
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+  """Vectorised Philox4x32-10.  Inputs broadcastable uint32 arrays."""
+  c0, c1, c2, c3, k0, k1 = np.broadcast_arrays(
+      *[np.asarray(v, dtype=np.uint32) for v in (c0, c1, c2, c3, k0, k1)])
+  c0, c1, c2, c3, k0, k1 = [v.copy() for v in (c0, c1, c2, c3, k0, k1)]
+  mask = np.uint64(0xFFFFFFFF)
+  with np.errstate(over='ignore'):
+    for r in range(10):
+      p0 = _PHILOX_M0 * c0.astype(np.uint64)
+      p1 = _PHILOX_M1 * c2.astype(np.uint64)
+      hi0 = (p0 >> np.uint64(32)).astype(np.uint32); lo0 = (p0 & mask).astype(np.uint32)
+      hi1 = (p1 >> np.uint64(32)).astype(np.uint32); lo1 = (p1 & mask).astype(np.uint32)
+      c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+      if r < 9:
+        k0 = (k0 + _PHILOX_W0).astype(np.uint32)
+        k1 = (k1 + _PHILOX_W1).astype(np.uint32)
+  return c0, c1, c2, c3
+
+
+def u32_to_uniform(x):
+  """[0,1) float32 with 24 random bits (tf.random_uniform is [0,1) fp32)."""
+  return ((np.asarray(x, dtype=np.uint32) >> np.uint32(8)).astype(np.float32)
+          * np.float32(1.0 / 16777216.0))
+
+
+def step_uniforms(seed, chain_ids, step, n_sites):
+  """Uniforms of one mc_step: U[B,N] (site draws, graph_builders.py:59) and u[B]
+  (acceptance draw, graph_builders.py:76-77).
+
+  Counter = (block, global chain id, step_lo, step_hi), key = (seed_lo, seed_hi);
+  block b yields sites 4b..4b+3, block 0xFFFFFFFF word 0 the acceptance draw.
+  """
+  chain_ids = np.asarray(chain_ids, dtype=np.uint32)
+  nblk = (n_sites + 3) // 4
+  blocks = np.arange(nblk, dtype=np.uint32)[None, :]
+  k0 = np.uint32(seed & 0xFFFFFFFF); k1 = np.uint32((seed >> 32) & 0xFFFFFFFF)
+  s_lo = np.uint32(step & 0xFFFFFFFF); s_hi = np.uint32((step >> 32) & 0xFFFFFFFF)
+  r = philox4x32_10(blocks, chain_ids[:, None], s_lo, s_hi, k0, k1)
+  sites = np.stack(r, axis=-1).reshape(len(chain_ids), nblk * 4)[:, :n_sites]
+  ra = philox4x32_10(np.uint32(ACCEPT_BLOCK), chain_ids, s_lo, s_hi, k0, k1)
+  return u32_to_uniform(sites), u32_to_uniform(ra[0])
+
+
+# --------------------------------------------------------------------------- #
+# Metropolis exchange step (graph_builders.py:38-89)
+# --------------------------------------------------------------------------- #
+def propose_exchange(configs, site_uniforms):
+  """graph_builders.py:59-65: swap_choice = configs * u; the DOWN spin to raise is
+  argmin (most negative = down spin with the largest u), the UP spin to lower is
+  argmax.  np.argmin/argmax return the first index on ties like tf.argmin/argmax."""
+  swap_choice = np.asarray(configs, np.float32) * np.asarray(site_uniforms, np.float32)
+  return np.argmax(swap_choice, axis=1), np.argmin(swap_choice, axis=1)  # (i_up, i_dn)
+
+
+def mc_step(amp_fn, configs, i_up, i_dn, u_accept):
+  """One exchange proposal + Metropolis accept per chain, reference structure
+  (two forward passes, graph_builders.py:54-55 and 74).
+
+  amp_fn(configs)->psi.  Returns (new_configs, accept_mask, ratios).
+  accept = |psi'|/|psi| > sqrt(u)   (graph_builders.py:75-79, strict >).
+  """
+  configs = np.asarray(configs, np.float32)
+  rows = np.arange(configs.shape[0])
+  psi = amp_fn(configs)
+  updated = configs.copy()
+  np.add.at(updated, (rows, i_dn), np.float32(2.0))    # graph_builders.py:67-68
+  np.add.at(updated, (rows, i_up), np.float32(-2.0))   # graph_builders.py:70-71
+  new_psi = amp_fn(updated)
+  with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+    ratios = np.abs(new_psi) / np.abs(psi)
+  rnd = np.sqrt(np.asarray(u_accept, np.float32))
+  accept = ratios > rnd
+  out = configs.copy()
+  out[accept] = updated[accept]
+  return out, accept, ratios
+
+
+# --------------------------------------------------------------------------- #
+# Heisenberg operator (operators.py:128-287)
+# --------------------------------------------------------------------------- #
+def heisenberg_build(amp_fn, configs, bonds, j_x, j_z, dtype=np.float32):
+  """HeisenbergHamiltonian.build (operators.py:227-247): sum over bonds of
+  HeisenbergBond.build (operators.py:137-169).
+
+  Per bond: diag = 0.25*jz*s_i*s_j; off = 0.25*jx*2*[s_i*s_j<0]*psi(R with s_i,s_j
+  swapped).  The swapped forward runs on ALL rows and is masked afterwards.
+  j_x / j_z may be scalars (the reference) or per-bond arrays (extension D5).
+  """
+  x = np.asarray(configs, dtype=dtype)
+  nb = len(bonds)
+  jx = np.broadcast_to(np.asarray(j_x, dtype=dtype), (nb,))
+  jz = np.broadcast_to(np.asarray(j_z, dtype=dtype), (nb,))
+  diag = np.zeros(x.shape[0], dtype=dtype)
+  off = np.zeros(x.shape[0], dtype=dtype)
+  for k, (i, j) in enumerate(bonds):
+    si, sj = x[:, i], x[:, j]
+    upd = x.copy()
+    upd[:, i] += sj - si            # operators.py:162
+    upd[:, j] += si - sj            # operators.py:163
+    sz = si * sj                    # operators.py:165
+    mask = (sz < 0).astype(dtype)   # operators.py:166-167
+    perp = dtype(2.0) * mask * amp_fn(upd).astype(dtype)   # operators.py:168
+    diag += dtype(0.25) * jz[k] * sz
+    off += dtype(0.25) * jx[k] * perp
+  return diag, off
+
+
+def local_value(amp_fn, configs, bonds, j_x, j_z, psi=None, dtype=np.float32):
+  """operators.py:249-259: diag + off / psi."""
+  if psi is None:
+    psi = amp_fn(configs)
+  diag, off = heisenberg_build(amp_fn, configs, bonds, j_x, j_z, dtype)
+  return diag + off / np.asarray(psi, dtype)
+
+
+def apply_in_place(amp_fn, configs, bonds, j_x, j_z, psi=None, dtype=np.float32):
+  """operators.py:261-271: diag * psi + off."""
+  if psi is None:
+    psi = amp_fn(configs)
+  diag, off = heisenberg_build(amp_fn, configs, bonds, j_x, j_z, dtype)
+  return diag * np.asarray(psi, dtype) + off
+
+
+def constant_psi_local_energy(configs, bonds, j_x, j_z):
+  """Closed form for psi == const: 0.25*jz*(n_par - n_anti) + 0.5*jx*n_anti."""
+  x = np.asarray(configs, np.float64)
+  e = np.zeros(x.shape[0])
+  for (i, j) in bonds:
+    sz = x[:, i] * x[:, j]
+    e += 0.25 * j_z * sz + 0.5 * j_x * (sz < 0)
+  return e
+
+
+# --------------------------------------------------------------------------- #
+# d logit / d theta, batch-summed with weights (manual back-prop)
+# --------------------------------------------------------------------------- #
+def weighted_logit_grads(theta, configs, weights, layer_size, num_layers,
+                         nonlinearity='relu', dtype=np.float32):
+  """Returns sum_b weights[b, c] * d logit_b / d theta for every column c of
+  `weights` [B, C] -> [C, P].
+
+  This is tf.gradients(psi/stop_gradient(psi) * w, opt_v) of training.py:545-547 and
+  674-679: d(psi_b/psi_ng_b)/d theta = d logit_b / d theta for an exp output, and
+  tf.gradients sums over the batch.
+  """
+  x = np.asarray(configs, dtype=dtype)
+  w_b = np.asarray(weights, dtype=dtype)
+  if w_b.ndim == 1:
+    w_b = w_b[:, None]
+  th = np.asarray(theta, dtype=dtype)
+  layers = unpack(th, x.shape[1], layer_size, num_layers)
+  _, zs, acts = fc_logit(th, x, layer_size, num_layers, nonlinearity, dtype, True)
+  dact = _NONLIN_DERIV[nonlinearity]
+  n_cols = w_b.shape[1]
+  grads = [[] for _ in range(n_cols)]
+  # output layer
+  w_out, _ = layers[-1]
+  a_last = acts[-1]
+  for c in range(n_cols):
+    grads[c] = [(a_last * w_b[:, c:c + 1]).sum(0)[:, None], w_b[:, c].sum(keepdims=True)]
+  delta = np.broadcast_to(w_out[:, 0][None, :], a_last.shape).copy()  # d logit / d a_L
+  for l in range(num_layers - 1, -1, -1):
+    delta = delta * dact(zs[l], acts[l + 1])          # d logit / d z_l   [B,H]
+    a_prev = acts[l]
+    for c in range(n_cols):
+      dw = a_prev.T @ (delta * w_b[:, c:c + 1])
+      db = (delta * w_b[:, c:c + 1]).sum(0)
+      grads[c] = [dw, db] + grads[c]
+    if l > 0:
+      delta = delta @ layers[l][0].T
+  return np.stack([np.concatenate([g.ravel() for g in grads[c]]) for c in range(n_cols)])
+
+
+# --------------------------------------------------------------------------- #
+# EnergyGradient accumulators + gradient (training.py:539-567)
+# --------------------------------------------------------------------------- #
+class Accumulators:
+  """tf.metrics.mean / mean_tensor state (local variables).
+
+  mean(values): total += sum(values), count += size.
+  mean_tensor(values): total += values (elementwise), count += 1.
+  """
+
+  def __init__(self, n_params, dtype=np.float32):
+    self.dtype = dtype
+    self.n_params = n_params
+    self.reset()
+
+  def reset(self):
+    """training.py:568 / 707: tf.variables_initializer(tf.local_variables())."""
+    z = lambda: np.zeros(self.n_params, self.dtype)
+    self.g1_total, self.g2_total = z(), z()
+    self.g_count = self.dtype(0)
+    self.e_total = self.dtype(0); self.e_count = self.dtype(0)
+    self.r_total = self.dtype(0); self.r_count = self.dtype(0)
+
+  def mean_energy(self):
+    return self.e_total / self.e_count
+
+  def mean_ratio(self):
+    return self.r_total / self.r_count
+
+
+def energy_gradient_accumulate(acc, theta, configs, bonds, j_x, j_z, shift,
+                               layer_size, num_layers, dtype=np.float32):
+  """One `accumulate_gradients` run of EnergyGradientOptimizer (training.py:539-558)."""
+  amp = lambda c: fc_psi(theta, c, layer_size, num_layers, shift, dtype=dtype)
+  psi = amp(configs)
+  e_loc = local_value(amp, configs, bonds, j_x, j_z, psi, dtype)     # 542-543
+  ones = np.ones_like(e_loc)
+  g = weighted_logit_grads(theta, configs, np.stack([ones, e_loc], 1),
+                           layer_size, num_layers, dtype=dtype)      # 545-547
+  acc.g1_total += g[0]; acc.g2_total += g[1]; acc.g_count += 1        # 550-553
+  acc.e_total += e_loc.sum(dtype=dtype); acc.e_count += e_loc.size    # 555
+  return e_loc
+
+
+def energy_gradient(acc):
+  """training.py:560-564: mean(scaled) - mean(E) * mean(pure)."""
+  return acc.g2_total / acc.g_count - acc.mean_energy() * (acc.g1_total / acc.g_count)
+
+
+# --------------------------------------------------------------------------- #
+# LogOverlapImaginaryTimeSWO accumulators + gradient (training.py:652-699)
+# --------------------------------------------------------------------------- #
+def log_overlap_accumulate(acc, theta, theta_omega, configs, bonds, j_x, j_z, shift,
+                           shift_omega, beta, layer_size, num_layers, dtype=np.float32):
+  """One `accumulate_gradients` run of LogOverlapImaginaryTimeSWO.
+
+  The supervisor omega is a deepcopy with its OWN exp_norm_shift variable, created at
+  -10 and never updated (wavefunctions.py:177-204, 209; module_transfer_ops copies
+  trainables only, 300-325).
+  """
+  amp = lambda c: fc_psi(theta, c, layer_size, num_layers, shift, dtype=dtype)
+  amp_w = lambda c: fc_psi(theta_omega, c, layer_size, num_layers, shift_omega, dtype=dtype)
+  psi = amp(configs)                                                   # 661
+  psi_w = amp_w(configs)                                               # 662
+  h_psi_w = apply_in_place(amp_w, configs, bonds, j_x, j_z, psi_w, dtype)  # 664
+  ite = psi_w - dtype(beta) * h_psi_w                                  # 665-666
+  e_loc = h_psi_w / psi_w                                              # 667
+  ratio = ite / psi                                                    # 672
+  ones = np.ones_like(ratio)
+  g = weighted_logit_grads(theta, configs, np.stack([ones, ratio], 1),
+                           layer_size, num_layers, dtype=dtype)        # 674-679
+  acc.g1_total += g[0]; acc.g2_total += g[1]; acc.g_count += 1
+  acc.e_total += e_loc.sum(dtype=dtype); acc.e_count += e_loc.size     # 689
+  acc.r_total += ratio.sum(dtype=dtype); acc.r_count += ratio.size     # 690
+  return e_loc, ratio
+
+
+def log_overlap_gradient(acc):
+  """training.py:697-699: mean(log_grad) - mean(ratio_grad) / mean(ratio)."""
+  return acc.g1_total / acc.g_count - (acc.g2_total / acc.g_count) / acc.mean_ratio()
+
+
+# --------------------------------------------------------------------------- #
+# Optimizer (training.py:76-91; TF1 AdamOptimizer semantics)
+# --------------------------------------------------------------------------- #
+def piecewise_constant(x, boundaries, values):
+  """tf.train.piecewise_constant: values[0] if x <= b[0]; values[i] if
+  b[i-1] < x <= b[i]; values[-1] if x > b[-1]."""
+  for b, v in zip(boundaries, values):
+    if x <= b:
+      return v
+  return values[-1]
+
+
+class AdamState:
+  def __init__(self, n_params):
+    self.m = np.zeros(n_params, np.float32)
+    self.v = np.zeros(n_params, np.float32)
+    self.t = 0
+
+
+def adam_apply(state, theta, grad, lr, beta1=0.9, beta2=0.99, eps=1e-8):
+  """TF1 Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t*m/(sqrt(v)+eps)."""
+  state.t += 1
+  f = np.float32
+  lr_t = f(lr) * np.sqrt(f(1) - f(beta2) ** f(state.t)) / (f(1) - f(beta1) ** f(state.t))
+  g = np.asarray(grad, np.float32)
+  state.m = state.m + (g - state.m) * f(1 - beta1)
+  state.v = state.v + (g * g - state.v) * f(1 - beta2)
+  return (np.asarray(theta, np.float32)
+          - f(lr_t) * state.m / (np.sqrt(state.v) + f(eps))).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- #
+# Lattices (the build's own helpers; run_training.py:103-109 gives the 1-D default)
+# --------------------------------------------------------------------------- #
+def chain_bonds(n_sites):
+  """run_training.py:109 default: 1-D periodic chain."""
+  return [(i, (i + 1) % n_sites) for i in range(n_sites)]
+
+
+def torus_bonds(lx, ly, next_nearest=False):
+  """L_x x L_y periodic square lattice, each bond once; site = x + lx*y."""
+  bonds = []
+  for y in range(ly):
+    for x in range(lx):
+      s = x + lx * y
+      bonds.append((s, (x + 1) % lx + lx * y))
+      bonds.append((s, x + lx * ((y + 1) % ly)))
+  if next_nearest:
+    for y in range(ly):
+      for x in range(lx):
+        s = x + lx * y
+        bonds.append((s, (x + 1) % lx + lx * ((y + 1) % ly)))
+        bonds.append((s, (x - 1) % lx + lx * ((y + 1) % ly)))
+  return bonds
+
+
+# --------------------------------------------------------------------------- #
+# Loops with the reference's call structure (used as the timed CPU baseline)
+# --------------------------------------------------------------------------- #
+def run_sweeps(theta, configs, n_steps, seed, step0, layer_size, num_layers, shift=-10.0,
+               chain_offset=0, dtype=np.float32):
+  """n_steps mc_steps, one host-level call each with two forwards, as
+  training.py:608-609 / evaluation.py:138-139 drive graph_builders.py:38-89."""
+  amp = lambda c: fc_psi(theta, c, layer_size, num_layers, shift, dtype=dtype)
+  ids = np.arange(configs.shape[0], dtype=np.uint32) + np.uint32(chain_offset)
+  accepted = 0
+  for t in range(n_steps):
+    u_sites, u_acc = step_uniforms(seed, ids, step0 + t, configs.shape[1])
+    i_up, i_dn = propose_exchange(configs, u_sites)
+    configs, acc, _ = mc_step(amp, configs, i_up, i_dn, u_acc)
+    accepted += int(acc.sum())
+  return configs, accepted

@@ -1,0 +1,224 @@
+"""Pins the oracle (parity unpinned by the reference: it has no tests) with
+closed forms, exact diagonalisation, autograd and finite differences."""
+import itertools
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+import torch
+
+from oracle import vmc_oracle as vo
+
+
+def _setup(n=8, h=16, L=2, b=12, seed=0):
+  rng = np.random.default_rng(seed)
+  theta = vo.init_params(n, h, L, rng)
+  theta = theta + 0.05 * rng.standard_normal(theta.size).astype(np.float32)  # non-zero biases
+  cfg = vo.random_configurations(n, b, np.random.RandomState(seed))
+  return theta, cfg
+
+
+def test_param_count_and_order():
+  assert vo.num_params(100, 256, 3) == 157697      # config 3
+  assert vo.num_params(36, 128, 3) == 37889        # config 2
+  th = np.arange(vo.num_params(3, 2, 2), dtype=np.float32)
+  layers = vo.unpack(th, 3, 2, 2)
+  assert layers[0][0].shape == (3, 2) and layers[0][0][1, 0] == 2   # row-major w:[in,out]
+  assert layers[0][1].tolist() == [6, 7]
+  assert layers[2][0].shape == (2, 1) and layers[2][1].shape == (1,)
+
+
+def test_constant_psi_closed_form():
+  cfg = vo.random_configurations(16, 40, np.random.RandomState(3))
+  for bonds in (vo.chain_bonds(16), vo.torus_bonds(4, 4)):
+    for jx in (1.0, -1.0, 0.3):
+      amp = lambda c: np.full(c.shape[0], 3.7, np.float32)
+      e = vo.local_value(amp, cfg, bonds, jx, 1.0)
+      np.testing.assert_allclose(e, vo.constant_psi_local_energy(cfg, bonds, jx, 1.0), rtol=1e-6)
+
+
+def _ed_ground_state(n, bonds, jx, jz):
+  """Exact ground state in the Sz=0 sector, basis = all +-1 configs with n/2 downs."""
+  basis = [c for c in itertools.combinations(range(n), n // 2)]
+  index = {c: k for k, c in enumerate(basis)}
+  cfgs = np.ones((len(basis), n), np.float64)
+  for k, c in enumerate(basis):
+    cfgs[k, list(c)] = -1
+  rows, cols, vals = [], [], []
+  for k, c in enumerate(basis):
+    down = set(c)
+    d = 0.0
+    for (i, j) in bonds:
+      sz = cfgs[k, i] * cfgs[k, j]
+      d += 0.25 * jz * sz
+      if sz < 0:
+        nd = set(down)
+        if i in nd:
+          nd.remove(i); nd.add(j)
+        else:
+          nd.remove(j); nd.add(i)
+        rows.append(k); cols.append(index[tuple(sorted(nd))]); vals.append(0.5 * jx)
+    rows.append(k); cols.append(k); vals.append(d)
+  hmat = sp.csr_matrix((vals, (rows, cols)), shape=(len(basis),) * 2)
+  w, v = spla.eigsh(hmat, k=1, which='SA')
+  return w[0], v[:, 0], cfgs, index
+
+
+@pytest.mark.parametrize('n,bonds,jx', [
+    (8, vo.chain_bonds(8), 1.0),
+    (8, vo.chain_bonds(8), -1.0),
+    (12, vo.torus_bonds(4, 3), -1.0),
+])
+def test_ed_eigenstate_has_constant_local_energy(n, bonds, jx):
+  """Role of FullVector (wavefunctions.py:1001-1055): exact state => E_loc == E0."""
+  e0, vec, cfgs, index = _ed_ground_state(n, bonds, jx, 1.0)
+
+  def amp(c):
+    keys = [tuple(np.nonzero(row < 0)[0]) for row in np.asarray(c)]
+    return np.array([vec[index[k]] for k in keys])
+
+  sel = np.abs(vec) > 1e-6
+  e = vo.local_value(amp, cfgs[sel], bonds, jx, 1.0, dtype=np.float64)
+  np.testing.assert_allclose(e, e0, rtol=0, atol=1e-8)
+  if n == 8 and jx == 1.0:
+    np.testing.assert_allclose(e0, -3.651093408937176, atol=1e-9)  # 8-site Heisenberg ring
+
+
+def test_local_value_vs_apply_in_place():
+  theta, cfg = _setup()
+  amp = lambda c: vo.fc_psi(theta, c, 16, 2, dtype=np.float64)
+  bonds = vo.chain_bonds(8)
+  lv = vo.local_value(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64)
+  ap = vo.apply_in_place(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64)
+  np.testing.assert_allclose(ap / amp(cfg), lv, rtol=1e-12)
+
+
+def _torch_logit(theta_t, x, n, h, L):
+  off = 0
+  a = x
+  for l in range(L + 1):
+    fi = n if l == 0 else h
+    fo = h if l < L else 1
+    w = theta_t[off:off + fi * fo].reshape(fi, fo); off += fi * fo
+    b = theta_t[off:off + fo]; off += fo
+    a = a @ w + b
+    if l < L:
+      a = torch.relu(a)
+  return a[:, 0]
+
+
+def test_weighted_grads_vs_autograd_and_fd():
+  n, h, L = 8, 16, 2
+  theta, cfg = _setup(n, h, L, 12)
+  wts = np.random.default_rng(5).standard_normal((12, 2))
+  g = vo.weighted_logit_grads(theta, cfg, wts, h, L, dtype=np.float64)
+  tt = torch.tensor(theta.astype(np.float64), requires_grad=True)
+  x = torch.tensor(cfg.astype(np.float64))
+  for c in range(2):
+    out = (_torch_logit(tt, x, n, h, L) * torch.tensor(wts[:, c])).sum()
+    (ga,) = torch.autograd.grad(out, tt)
+    np.testing.assert_allclose(g[c], ga.numpy(), rtol=1e-10, atol=1e-12)
+  # central finite differences on a few coordinates
+  f = lambda th: (vo.fc_logit(th, cfg, h, L, dtype=np.float64) * wts[:, 0]).sum()
+  th64 = theta.astype(np.float64)
+  for k in (0, 5, n * h + 3, theta.size - 1, theta.size - 3):
+    e = np.zeros_like(th64); e[k] = 1e-6
+    fd = (f(th64 + e) - f(th64 - e)) / 2e-6
+    np.testing.assert_allclose(g[0][k], fd, rtol=1e-5, atol=1e-7)
+  # fp32 twin agrees to fp32 tolerance
+  g32 = vo.weighted_logit_grads(theta, cfg, wts, h, L, dtype=np.float32)
+  np.testing.assert_allclose(g32, g, rtol=2e-4, atol=2e-5)
+
+
+def test_energy_gradient_is_covariance():
+  """training.py:560-564 with tf.gradients' batch SUM: grad = B * Cov_b(E, O_k)."""
+  n, h, L = 8, 16, 2
+  theta, cfg = _setup(n, h, L, 32)
+  bonds = vo.chain_bonds(n)
+  acc = vo.Accumulators(theta.size, np.float64)
+  e = vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, h, L, np.float64)
+  grad = vo.energy_gradient(acc)
+  o = np.stack([vo.weighted_logit_grads(theta, cfg[b:b + 1], np.ones(1), h, L, dtype=np.float64)[0]
+                for b in range(32)])
+  cov = (e[:, None] * o).mean(0) - e.mean() * o.mean(0)
+  np.testing.assert_allclose(grad, 32 * cov, rtol=1e-9, atol=1e-12)
+
+
+def test_log_overlap_gradient_scale_invariance():
+  """grad = mean(G1) - mean(G2)/mean(ratio) must not depend on either shift."""
+  n, h, L = 8, 16, 2
+  theta, cfg = _setup(n, h, L, 16)
+  theta_w = theta + 0.01 * np.random.default_rng(9).standard_normal(theta.size).astype(np.float32)
+  bonds = vo.chain_bonds(n)
+  out = []
+  for s, sw in ((-10.0, -10.0), (-3.0, -10.0), (-10.0, 2.0)):
+    acc = vo.Accumulators(theta.size, np.float64)
+    vo.log_overlap_accumulate(acc, theta, theta_w, cfg, bonds, -1.0, 1.0, s, sw, 0.12, h, L,
+                              np.float64)
+    out.append(vo.log_overlap_gradient(acc))
+  np.testing.assert_allclose(out[0], out[1], rtol=1e-9, atol=1e-12)
+  np.testing.assert_allclose(out[0], out[2], rtol=1e-9, atol=1e-12)
+
+
+def test_adam_matches_torch_free_formula_and_piecewise_lr():
+  assert vo.piecewise_constant(0, [300, 600, 1000], [1e-3, 1e-4, 2e-5, 1e-5]) == 1e-3
+  assert vo.piecewise_constant(300, [300, 600, 1000], [1e-3, 1e-4, 2e-5, 1e-5]) == 1e-3
+  assert vo.piecewise_constant(301, [300, 600, 1000], [1e-3, 1e-4, 2e-5, 1e-5]) == 1e-4
+  assert vo.piecewise_constant(1001, [300, 600, 1000], [1e-3, 1e-4, 2e-5, 1e-5]) == 1e-5
+  st = vo.AdamState(3)
+  th = np.array([1.0, -2.0, 0.5], np.float32)
+  g = np.array([0.1, -0.3, 0.0], np.float32)
+  th1 = vo.adam_apply(st, th, g, 1e-3, 0.9, 0.99, 1e-8)
+  # first TF1 Adam step: m=(1-b1)g, v=(1-b2)g^2, lr_t=lr*sqrt(1-b2)/(1-b1)
+  lr_t = 1e-3 * np.sqrt(1 - 0.99) / (1 - 0.9)
+  exp = th - lr_t * (0.1 * g) / (np.sqrt(0.01 * g * g) + 1e-8)
+  np.testing.assert_allclose(th1, exp, rtol=1e-5)
+
+
+def test_update_norm_rule():
+  psi = np.array([1.0, 5e12], np.float32)
+  s = vo.update_norm(psi, -10.0)
+  np.testing.assert_allclose(s, -10 + np.log(5e12) - np.log(1e10), rtol=1e-6)
+  assert vo.update_norm(np.array([3.0], np.float32), -10.0) == np.float32(-10.0)
+
+
+def test_mc_step_conserves_sz_and_accept_rule():
+  n, h, L = 12, 16, 2
+  theta, cfg = _setup(n, h, L, 64)
+  amp = lambda c: vo.fc_psi(theta, c, h, L)
+  u, ua = vo.step_uniforms(11, np.arange(64), 0, n)
+  i_up, i_dn = vo.propose_exchange(cfg, u)
+  new, acc, ratios = vo.mc_step(amp, cfg, i_up, i_dn, ua)
+  assert (new.sum(1) == cfg.sum(1)).all()
+  assert np.array_equal(acc, ratios > np.sqrt(ua))
+  changed = (new != cfg).any(1)
+  assert np.array_equal(changed, acc)
+  # u = 0 always accepts (ratio > 0), u -> 1 with tiny ratio rejects
+  _, acc0, _ = vo.mc_step(amp, cfg, i_up, i_dn, np.zeros(64, np.float32))
+  assert acc0.all()
+
+
+def test_mc_sampling_reproduces_exact_energy():
+  """Statistical pin: sampling |psi|^2 of the exact ground state gives E0."""
+  n = 8
+  bonds = vo.chain_bonds(n)
+  e0, vec, cfgs, index = _ed_ground_state(n, bonds, -1.0, 1.0)
+  vec = np.abs(vec)
+
+  def amp(c):
+    keys = [tuple(np.nonzero(row < 0)[0]) for row in np.asarray(c)]
+    return np.array([vec[index[k]] for k in keys])
+
+  cfg = vo.random_configurations(n, 256, np.random.RandomState(1))
+  ids = np.arange(256)
+  for t in range(40):
+    u, ua = vo.step_uniforms(5, ids, t, n)
+    i_up, i_dn = vo.propose_exchange(cfg, u)
+    cfg, _, _ = vo.mc_step(amp, cfg, i_up, i_dn, ua)
+  e = vo.local_value(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64)
+  np.testing.assert_allclose(e, e0, atol=1e-8)   # zero-variance for an eigenstate
+  # and the sampled distribution is |psi|^2: compare <|S_0^z S_1^z|> with exact
+  szsz = (cfg[:, 0] * cfg[:, 1]).mean() / 4
+  exact = sum(vec[k] ** 2 * cfgs[k, 0] * cfgs[k, 1] for k in range(len(vec))) / 4
+  assert abs(szsz - exact) < 0.03

@@ -1,0 +1,39 @@
+"""Pins the oracle's Philox4x32-10 against the Random123 known-answer vectors."""
+import numpy as np
+
+from oracle import vmc_oracle as vo
+
+
+def _kat(ctr, key):
+  return [int(v) for v in vo.philox4x32_10(*[np.uint32(c) for c in ctr],
+                                           *[np.uint32(k) for k in key])]
+
+
+def test_philox_known_answers():
+  # Random123 kat_vectors: philox4x32 10
+  assert _kat((0, 0, 0, 0), (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+  assert _kat((0xffffffff,) * 4, (0xffffffff,) * 2) == [
+      0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+  assert _kat((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+              (0xa4093822, 0x299f31d0)) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_uniform_range_and_shapes():
+  u, ua = vo.step_uniforms(2024, np.arange(64), 7, 10)
+  assert u.shape == (64, 10) and ua.shape == (64,)
+  assert u.dtype == np.float32 and (u >= 0).all() and (u < 1).all()
+  # different chains / steps give different streams
+  u2, _ = vo.step_uniforms(2024, np.arange(64), 8, 10)
+  assert not np.array_equal(u, u2)
+  # chain-id keyed: a shard sees the same numbers as the full batch
+  u3, ua3 = vo.step_uniforms(2024, np.arange(32, 64), 7, 10)
+  assert np.array_equal(u3, u[32:]) and np.array_equal(ua3, ua[32:])
+
+
+def test_proposal_picks_one_up_one_down():
+  rng = np.random.RandomState(0)
+  cfg = vo.random_configurations(12, 50, rng)
+  u, _ = vo.step_uniforms(1, np.arange(50), 0, 12)
+  i_up, i_dn = vo.propose_exchange(cfg, u)
+  rows = np.arange(50)
+  assert (cfg[rows, i_up] == 1).all() and (cfg[rows, i_dn] == -1).all()
