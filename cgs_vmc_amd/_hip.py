@@ -1,0 +1,115 @@
+"""ctypes binding of libcgsvmc_hip.so (include/cgsvmc.h).
+
+There is no CPU fallback: if the shared library is missing or no GPU is present the
+product path raises.  Build with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C cgs_vmc_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_LIB_NAME = 'libcgsvmc_hip.so'
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+VMC_OK = 0
+VMC_ERR_INVALID = -1
+VMC_ERR_UNSUPPORTED = -2
+VMC_ERR_HIP = -3
+VMC_ERR_STATE = -4
+
+VMC_PSI, VMC_OMEGA = 0, 1
+VMC_MODE_ENERGY_GRADIENT, VMC_MODE_LOG_OVERLAP_ITSWO = 0, 1
+# layers.NONLINEARITIES ids (cgsvmc.h)
+ACT_IDS = {'relu': 0, 'exp': 1, 'cos': 2, 'tan': 3, 'tanh': 4, 'sigmoid': 5, 'identity': 6}
+
+
+class VmcDesc(C.Structure):
+  _fields_ = [
+      ('n_sites', C.c_int32), ('batch_size', C.c_int32), ('num_layers', C.c_int32),
+      ('layer_size', C.c_int32), ('nonlinearity', C.c_int32),
+      ('output_activation', C.c_int32), ('device', C.c_int32), ('chain_offset', C.c_int32),
+      ('seed', C.c_uint64), ('stream', C.c_void_p),
+  ]
+
+
+class HipLibraryError(RuntimeError):
+  """The HIP extension is missing or failed; the hot path has no fallback."""
+
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/cgsvmc.h declares
+SIGNATURES = {
+    'vmc_num_params': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'vmc_create': (C.c_int, [C.POINTER(VmcDesc), C.POINTER(_ctx)]),
+    'vmc_destroy': (None, [_ctx]),
+    'vmc_last_error': (C.c_char_p, [_ctx]),
+    'vmc_set_bonds': (C.c_int, [_ctx, C.c_int32, _ip, _fp, _fp]),
+    'vmc_set_params': (C.c_int, [_ctx, C.c_int, _fp]),
+    'vmc_get_params': (C.c_int, [_ctx, C.c_int, _fp]),
+    'vmc_transfer_params': (C.c_int, [_ctx]),
+    'vmc_set_configs': (C.c_int, [_ctx, _fp]),
+    'vmc_get_configs': (C.c_int, [_ctx, _fp]),
+    'vmc_set_shift': (C.c_int, [_ctx, C.c_int, C.c_float]),
+    'vmc_get_shift': (C.c_int, [_ctx, C.c_int, _fp]),
+    'vmc_amplitude': (C.c_int, [_ctx, C.c_int, _fp, C.c_int64, _fp, _fp]),
+    'vmc_mc_steps': (C.c_int, [_ctx, C.c_int64, C.POINTER(C.c_int64)]),
+    'vmc_mc_step_injected': (C.c_int, [_ctx, _ip, _ip, _fp, C.POINTER(C.c_uint8)]),
+    'vmc_debug_proposals': (C.c_int, [_ctx, C.c_uint64, _ip, _ip, _fp]),
+    'vmc_get_step_counter': (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
+    'vmc_set_step_counter': (C.c_int, [_ctx, C.c_uint64]),
+    'vmc_local_energy': (C.c_int, [_ctx, C.c_int, _fp, C.POINTER(C.c_double)]),
+    'vmc_local_energy_terms': (C.c_int, [_ctx, C.c_int, _fp, _fp]),
+    'vmc_accumulate': (C.c_int, [_ctx, C.c_int, C.c_float]),
+    'vmc_reset_accumulators': (C.c_int, [_ctx]),
+    'vmc_accumulators_devptr': (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    'vmc_get_accumulators': (C.c_int, [_ctx, _fp]),
+    'vmc_set_accumulators': (C.c_int, [_ctx, _fp]),
+    'vmc_apply_adam': (C.c_int, [_ctx, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.POINTER(C.c_double)]),
+    'vmc_get_gradient': (C.c_int, [_ctx, C.c_int, _fp]),
+    'vmc_mean_energy': (C.c_int, [_ctx, C.POINTER(C.c_double)]),
+    'vmc_get_adam_state': (C.c_int, [_ctx, _fp, _fp, C.POINTER(C.c_int64)]),
+    'vmc_set_adam_state': (C.c_int, [_ctx, _fp, _fp, C.c_int64]),
+    'vmc_update_norm': (C.c_int, [_ctx, C.c_float]),
+    'vmc_timing_enable': (C.c_int, [_ctx, C.c_int]),
+    'vmc_timing_reset': (C.c_int, [_ctx]),
+    'vmc_timing_get': (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    'vmc_last_connected_rows': (C.c_int, [_ctx, C.POINTER(C.c_int64)]),
+    'vmc_synchronize': (C.c_int, [_ctx]),
+    'vmc_debug_gemm': (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int64, C.c_int64,
+                                 C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp]),
+}
+
+_lib = None
+
+
+def library_path() -> str:
+  return _LIB_PATH
+
+
+def load():
+  """Loads the shared library and binds every declared symbol (no GPU needed)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(_LIB_PATH):
+    raise HipLibraryError(
+        '{} not found: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). '
+        'The VMC hot path has no CPU fallback.'.format(_LIB_PATH))
+  try:
+    lib = C.CDLL(_LIB_PATH)
+  except OSError as e:
+    raise HipLibraryError('cannot load {}: {}'.format(_LIB_PATH, e)) from e
+  for name, (res, args) in SIGNATURES.items():
+    try:
+      fn = getattr(lib, name)
+    except AttributeError as e:
+      raise HipLibraryError('{} does not export {}'.format(_LIB_PATH, name)) from e
+    fn.restype = res
+    fn.argtypes = args
+  _lib = lib
+  return lib

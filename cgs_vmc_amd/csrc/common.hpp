@@ -1,0 +1,132 @@
+// Shared device helpers and launcher declarations for libcgsvmc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define VMC_WAVE 64
+
+// --------------------------------------------------------------------------------------
+// Philox4x32-10 (counter-based RNG).  Counter = (block, global chain id, step_lo, step_hi),
+// key = (seed_lo, seed_hi); block b gives the site uniforms 4b..4b+3 of one mc_step
+// (graph_builders.py:59), block 0xFFFFFFFF word 0 the acceptance uniform (76-77).
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+
+__device__ __forceinline__ float u32_to_uniform(uint32_t x) {
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+#define VMC_ACCEPT_BLOCK 0xFFFFFFFFu
+
+// --------------------------------------------------------------------------------------
+// Device-side view of one parameter set, re-packed for the kernels (pack.hip).
+//   Hp       layer_size rounded up to a multiple of 64 (zero padded)
+//   w1p      [N][Hp]      first layer, row n = site n
+//   b1p      [Hp]
+//   bh       [L-1][Hp]    biases of the H x H layers
+//   p32      [L-1][Hp/32 (to)][Hp/32 (ti)][4 (q)][64 (lane)][4 (e)]
+//              = W[32ti + 8q + 4(lane>>5) + e][32to + (lane&31)]   (A operand, 32x32x2)
+//   p16      [L-1][Hp/16 (to)][Hp/16 (ti)][64 (lane)][4 (e)]
+//              = W[16ti + 4(lane>>4) + e][16to + (lane&15)]        (A operand, 16x16x4)
+//   woutp    [Hp], bout [1]
+// --------------------------------------------------------------------------------------
+struct PackedParams {
+  const float* w1p;
+  const float* b1p;
+  const float* bh;
+  const float* p32;
+  const float* p16;
+  const float* woutp;
+  const float* bout;
+};
+
+struct TailArgs {
+  PackedParams pp;
+  const float* z1;          // [n_base][Hp] cached first-layer pre-activations
+  const float* logit_base;  // [n_base] cached logits (ratio mode)
+  const int2* rowinfo;      // [n_rows] {chain, signed bond+1} or nullptr (row == chain)
+  const int2* bonds;        // [n_bonds] {i, j}
+  const float* half_jx;     // [n_bonds] 0.5 * j_x
+  const int* n_rows_dev;    // device row count (list mode) or nullptr
+  int n_rows;               // host row count / upper bound
+  int n_hidden;             // L-1
+  float* out;               // [n_rows]
+};
+
+struct SweepArgs {
+  PackedParams pp;
+  float* configs;           // [B][N] +-1, updated in place
+  float* z1;                // [B][Hp] cache out
+  float* logit;             // [B]     cache out
+  unsigned long long* accepted;  // device counter (atomicAdd)
+  const int* inj_up;        // injected proposals or nullptr
+  const int* inj_dn;
+  const float* inj_u;
+  unsigned char* acc_mask;  // [B] out (last step) or nullptr
+  int* dbg_up; int* dbg_dn; float* dbg_u;   // proposal dump (debug_proposals) or nullptr
+  int B, N, n_hidden;
+  int chain_offset;
+  uint32_t seed_lo, seed_hi;
+  unsigned long long step0;
+  long long n_steps;
+};
+
+// launchers (one per TU)
+hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp, int L,
+                       float* w1p, float* b1p, float* bh, float* p32, float* p16, float* woutp,
+                       float* bout);
+hipError_t launch_z1(hipStream_t s, const float* configs, const float* w1p, const float* b1p,
+                     float* z1, int rows, int N, int Hp);
+hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode);
+hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp);
+
+// bond list / local-energy reduction (eloc.hip)
+hipError_t launch_bond_list(hipStream_t s, const float* configs, const int2* bonds,
+                            const float* quarter_jz, int B, int N, int n_bonds, int* cnt,
+                            int* off, float* diag, int2* rowinfo);
+hipError_t launch_eloc_reduce(hipStream_t s, const int* off, const float* diag, const float* val,
+                              int B, float* offdiag, float* eloc);
+hipError_t launch_sum(hipStream_t s, const float* x, int n, double* out_sum);
+hipError_t launch_max(hipStream_t s, const float* x, int n, float* out_max);
+
+// gradient path (grad.hip)
+struct GemmArgs {
+  const float* A; long long sam, sak;   // A(m,k) = A[m*sam + k*sak]
+  const float* B; long long sbk, sbn;   // B(k,n) = B[k*sbk + n*sbn]
+  const float* kscale;                  // optional: B(k,n) *= kscale[k]
+  int M, N, K;
+  float* C; long long ldc;              // C(m,n) = C[m*ldc + n]
+  const float* bias;                    // epilogue 1: + bias[n] then relu
+  const float* mask;  long long ldmask; // epilogue 2: * (mask[m*ldmask+n] > 0)
+  int epilogue;                         // 0 none, 1 bias+relu, 2 mask, 3 accumulate (C += )
+  int splitk;                           // >= 1
+  float* workspace;                     // [splitk][M][N] when splitk > 1
+};
+hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
+hipError_t launch_relu_copy(hipStream_t s, const float* z, float* a, long long n);
+hipError_t launch_delta_out(hipStream_t s, const float* woutp, const float* aL, float* delta,
+                            int B, int Hp);
+// out[c] (+)= sum_b w[b] * X[b*ld + c], c < ncols (w may be null -> 1)
+hipError_t launch_wcolsum(hipStream_t s, const float* X, long long ld, const float* w, int B,
+                          int ncols, float* out, float* workspace);
+hipError_t launch_scalar_accum(hipStream_t s, const float* eloc, const float* ratio, int B,
+                               float* acc_scalars, int mode);
+hipError_t launch_itswo_ratio(hipStream_t s, const float* logit_psi, const float* logit_omega,
+                              const float* eloc_omega, float log_factor, float beta, int B,
+                              float* ratio);
+hipError_t launch_adam(hipStream_t s, float* theta, float* m, float* v, const float* acc, int P,
+                       int mode, float lr_t, float b1, float b2, float eps, float* grad_out);
+hipError_t launch_fill(hipStream_t s, float* x, float v, long long n);

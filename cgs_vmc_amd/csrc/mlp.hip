@@ -1,0 +1,519 @@
+// Amplitude kernels of the fully-connected ansatz (wavefunctions.py:328-371) for gfx950.
+//
+//   k_pack      re-packs the flat parameter vector into MFMA-fragment-major weight images
+//   k_z1        first layer on raw +-1 configurations: z1 = x W1 + b1
+//   k_tail32    layers 2..L + output dot for a list of rows, each row = cached z1 of a
+//               chain (+ optional rank-2 exchange update), v_mfma_f32_32x32x2_f32,
+//               activations never leave registers (transposed formulation, see below)
+//   k_sweep16   persistent Metropolis exchange sampler: n_steps x mc_step
+//               (graph_builders.py:38-89) in one launch, v_mfma_f32_16x16x4_f32
+//
+// Transposed formulation.  For a tile of samples j and hidden units i the kernels compute
+// Y^T = W^T X^T, i.e. the MFMA A operand is a weight fragment (A[i][k] = W[k][i]) and the
+// B operand is the activation fragment (B[k][j] = X[j][k]).  The 32x32 result then has the
+// sample on the lane (col = lane&31) and the hidden unit on the register
+// (row = (r&3) + 8(r>>2) + 4(lane>>5)), which is exactly the B-operand shape of the next
+// layer if its k index is visited in the order k(s, half) = 8(s>>2) + 4*half + (s&3): the
+// accumulator register s of input tile ti IS the B operand of k-step s.  The weight image
+// (p32 / p16) is stored in that k order, fragment-major, so every A-operand load is one
+// fully coalesced 1 KiB dwordx4 wave load.  The same holds for 16x16x4 with
+// k(r, g) = 4g + r.
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------ pack
+__global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, int L,
+                       float* __restrict__ w1p, float* __restrict__ b1p, float* __restrict__ bh,
+                       float* __restrict__ p32, float* __restrict__ p16,
+                       float* __restrict__ woutp, float* __restrict__ bout) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long off_b1 = (long long)N * H;
+  const long long off_h0 = off_b1 + H;                 // first H x H layer
+  const long long per_h = (long long)H * H + H;
+  const long long off_wout = off_h0 + (long long)(L - 1) * per_h;
+  const long long off_bout = off_wout + H;
+  const int HT = Hp / 32, NT = Hp / 16;
+  for (long long i = tid; i < (long long)N * Hp; i += stride) {
+    const int n = (int)(i / Hp), c = (int)(i % Hp);
+    w1p[i] = c < H ? theta[(long long)n * H + c] : 0.f;
+  }
+  for (long long i = tid; i < Hp; i += stride) {
+    b1p[i] = i < H ? theta[off_b1 + i] : 0.f;
+    woutp[i] = i < H ? theta[off_wout + i] : 0.f;
+    if (i == 0) bout[0] = theta[off_bout];
+  }
+  for (long long i = tid; i < (long long)(L - 1) * Hp; i += stride) {
+    const int l = (int)(i / Hp), c = (int)(i % Hp);
+    bh[i] = c < H ? theta[off_h0 + l * per_h + (long long)H * H + c] : 0.f;
+  }
+  const long long n32 = (long long)(L - 1) * Hp * Hp;
+  for (long long i = tid; i < n32; i += stride) {
+    long long r = i;
+    const int e = (int)(r & 3); r >>= 2;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int q = (int)(r & 3); r >>= 2;
+    const int ti = (int)(r % HT); r /= HT;
+    const int to = (int)(r % HT); r /= HT;
+    const int l = (int)r;
+    const int k = 32 * ti + 8 * q + 4 * (lane >> 5) + e;
+    const int n = 32 * to + (lane & 31);
+    p32[i] = (k < H && n < H) ? theta[off_h0 + l * per_h + (long long)k * H + n] : 0.f;
+  }
+  for (long long i = tid; i < n32; i += stride) {
+    long long r = i;
+    const int e = (int)(r & 3); r >>= 2;
+    const int lane = (int)(r & 63); r >>= 6;
+    const int ti = (int)(r % NT); r /= NT;
+    const int to = (int)(r % NT); r /= NT;
+    const int l = (int)r;
+    const int k = 16 * ti + 4 * (lane >> 4) + e;
+    const int n = 16 * to + (lane & 15);
+    p16[i] = (k < H && n < H) ? theta[off_h0 + l * per_h + (long long)k * H + n] : 0.f;
+  }
+}
+
+hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp, int L,
+                       float* w1p, float* b1p, float* bh, float* p32, float* p16, float* woutp,
+                       float* bout) {
+  hipLaunchKernelGGL(k_pack, dim3(512), dim3(256), 0, s, theta, N, H, Hp, L, w1p, b1p, bh, p32,
+                     p16, woutp, bout);
+  return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------- z1
+// z1[b][i] = b1[i] + sum_n x[b][n] W1[n][i].  8 rows per 256-thread block, spins in LDS.
+#define Z1_ROWS 8
+__global__ __launch_bounds__(256) void k_z1(const float* __restrict__ configs,
+                                            const float* __restrict__ w1p,
+                                            const float* __restrict__ b1p,
+                                            float* __restrict__ z1, int rows, int N, int Hp) {
+  extern __shared__ float s_x[];  // [Z1_ROWS][N]
+  const int row0 = blockIdx.x * Z1_ROWS;
+  for (int i = threadIdx.x; i < Z1_ROWS * N; i += 256) {
+    const int r = i / N, n = i % N;
+    s_x[i] = (row0 + r < rows) ? configs[(long long)(row0 + r) * N + n] : 0.f;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < Hp; c += 256) {
+    float acc[Z1_ROWS];
+    const float b = b1p[c];
+#pragma unroll
+    for (int r = 0; r < Z1_ROWS; ++r) acc[r] = b;
+    for (int n = 0; n < N; ++n) {
+      const float w = w1p[(long long)n * Hp + c];
+#pragma unroll
+      for (int r = 0; r < Z1_ROWS; ++r) acc[r] = fmaf(s_x[r * N + n], w, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < Z1_ROWS; ++r)
+      if (row0 + r < rows) z1[(long long)(row0 + r) * Hp + c] = acc[r];
+  }
+}
+
+hipError_t launch_z1(hipStream_t s, const float* configs, const float* w1p, const float* b1p,
+                     float* z1, int rows, int N, int Hp) {
+  if (rows <= 0) return hipSuccess;
+  const int grid = (rows + Z1_ROWS - 1) / Z1_ROWS;
+  hipLaunchKernelGGL(k_z1, dim3(grid), dim3(256), Z1_ROWS * N * sizeof(float), s, configs, w1p,
+                     b1p, z1, rows, N, Hp);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------- tail32
+// 256 threads = 4 waves; each wave owns 32 rows (lane&31) and all Hp hidden units
+// (HT tiles x 16 accumulator registers, split over the two lane halves).  No LDS, no
+// barriers.  RATIO mode writes 0.5*jx[bond]*exp(logit_row - logit_base[chain]).
+template <int HT, bool RATIO>
+__global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
+  constexpr int Hp = HT * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, j = lane & 31;
+  const int n_rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+  const int wrow0 = blockIdx.x * 128 + wave * 32;
+  if (wrow0 >= n_rows) return;  // wave-uniform; no barriers below
+  const int row = wrow0 + j;
+  const bool valid = row < n_rows;
+  int chain = 0, bs = 0;
+  if (valid) {
+    if (a.rowinfo) {
+      const int2 ri = a.rowinfo[row];
+      chain = ri.x; bs = ri.y;
+    } else {
+      chain = row;
+    }
+  }
+  // rank-2 exchange update of the first layer: z1' = z1 + coef (W1[i] - W1[j])
+  float coef = 0.f;
+  int bond = 0;
+  const float* wa = a.pp.w1p;
+  const float* wb = a.pp.w1p;
+  if (bs != 0) {
+    bond = (bs > 0 ? bs : -bs) - 1;
+    coef = bs > 0 ? -2.f : 2.f;           // -2 * s_i
+    const int2 ab = a.bonds[bond];
+    wa = a.pp.w1p + (long long)ab.x * Hp;
+    wb = a.pp.w1p + (long long)ab.y * Hp;
+  }
+  const float* zb = a.z1 + (long long)chain * Hp;
+
+  f32x16 in[HT];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int off = 32 * t + 8 * q + 4 * h;
+      const f32x4 z = *(const f32x4*)(zb + off);
+      const f32x4 x = *(const f32x4*)(wa + off);
+      const f32x4 y = *(const f32x4*)(wb + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) in[t][4 * q + e] = fmaxf(fmaf(coef, x[e] - y[e], z[e]), 0.f);
+    }
+  }
+
+  for (int l = 0; l < a.n_hidden; ++l) {
+    const f32x4* __restrict__ wp = (const f32x4*)(a.pp.p32 + (long long)l * Hp * Hp);
+    const float* __restrict__ bl = a.pp.bh + l * Hp;
+    f32x16 out[HT];
+#pragma unroll
+    for (int to = 0; to < HT; ++to) {
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *(const f32x4*)(bl + 32 * to + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * q + e] = b[e];
+      }
+#pragma unroll
+      for (int ti = 0; ti < HT; ++ti) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 w = wp[((to * HT + ti) * 4 + q) * 64 + lane];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], in[ti][4 * q + e], acc, 0, 0, 0);
+        }
+      }
+      out[to] = acc;
+    }
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) in[t][r] = fmaxf(out[t][r], 0.f);
+  }
+
+  float part = 0.f;
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 w = *(const f32x4*)(a.pp.woutp + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part = fmaf(in[t][4 * q + e], w[e], part);
+    }
+  }
+  const float other = __shfl_xor(part, 32);
+  // fixed order: (half 0) + (half 1)
+  const float logit = (h == 0 ? part + other : other + part) + a.pp.bout[0];
+  if (valid && h == 0) {
+    if (RATIO) {
+      a.out[row] = a.half_jx[bond] * expf(logit - a.logit_base[chain]);
+    } else {
+      a.out[row] = logit;
+    }
+  }
+}
+
+template <bool RATIO>
+static hipError_t launch_tail32_t(hipStream_t s, const TailArgs& a, int Hp) {
+  if (a.n_rows <= 0) return hipSuccess;
+  const dim3 grid((a.n_rows + 127) / 128), block(256);
+  switch (Hp / 32) {
+    case 2: hipLaunchKernelGGL((k_tail32<2, RATIO>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((k_tail32<4, RATIO>), grid, block, 0, s, a); break;
+    case 6: hipLaunchKernelGGL((k_tail32<6, RATIO>), grid, block, 0, s, a); break;
+    case 8: hipLaunchKernelGGL((k_tail32<8, RATIO>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode) {
+  return ratio_mode ? launch_tail32_t<true>(s, a, Hp) : launch_tail32_t<false>(s, a, Hp);
+}
+
+// --------------------------------------------------------------------------------- sweep16
+// One workgroup (4 waves) owns 16 chains for the whole launch.  Per mc_step:
+//   proposals (Philox, argmax/argmin of s*u over sites: graph_builders.py:59-65)
+//   z1' = z1 + 2 (W1[i_dn] - W1[i_up])            (rank-2 form of the forward at :74)
+//   layers 2..L by 16x16x4 MFMA, wave w owns output units [w*Hp/4, (w+1)*Hp/4)
+//   accept = exp(logit' - logit) > sqrt(u)        (graph_builders.py:75-79)
+// Chain state (spins, z1, logit) stays in LDS; z1 and logit are recomputed from the spins
+// at launch start and end so the cache written back never carries incremental drift.
+template <int NT>
+__global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
+  constexpr int Hp = NT * 16, TO = NT / 4, ZS = Hp + 4;
+  extern __shared__ float smem[];
+  const int N = a.N, Nst = (N + 3) & ~3;
+  float* s_spin = smem;                       // [16][Nst]
+  float* s_z1 = s_spin + 16 * Nst;            // [2][16][ZS]
+  float* s_x = s_z1 + 2 * 16 * ZS;            // [2][NT][64][4]
+  float* s_part = s_x + 2 * NT * 256;         // [4][16]
+  float* s_logit = s_part + 64;               // [16]
+  float* s_u = s_logit + 16;                  // [16]
+  int* s_iup = (int*)(s_u + 16);              // [16]
+  int* s_idn = s_iup + 16;                    // [16]
+  int* s_sel = s_idn + 16;                    // [16]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, j = lane & 15;
+  const int chain0 = blockIdx.x * 16;
+  const PackedParams& pp = a.pp;
+
+  for (int i = tid; i < 16 * Nst; i += 256) {
+    const int c = i / Nst, n = i % Nst, gc = chain0 + c;
+    float v = 0.f;
+    if (n < N) v = gc < a.B ? a.configs[(long long)gc * N + n] : ((n & 1) ? -1.f : 1.f);
+    s_spin[i] = v;
+  }
+  if (tid < 16) s_sel[tid] = 0;
+  __syncthreads();
+
+  // z1 from the spins (first layer, exact): thread -> (column, chain group)
+  auto z1_direct = [&]() {
+    constexpr int GROUPS = 256 / Hp > 0 ? 256 / Hp : 1;   // chain groups when Hp < 256
+    constexpr int CPG = 16 / GROUPS;
+    const int col = tid % Hp, grp = tid / Hp;
+    if (grp < GROUPS) {
+      float acc[CPG];
+      const float b = pp.b1p[col];
+#pragma unroll
+      for (int c = 0; c < CPG; ++c) acc[c] = b;
+      for (int n = 0; n < N; ++n) {
+        const float w = pp.w1p[(long long)n * Hp + col];
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) acc[c] = fmaf(s_spin[(grp * CPG + c) * Nst + n], w, acc[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < CPG; ++c) s_z1[(grp * CPG + c) * ZS + col] = acc[c];
+    }
+  };
+
+  f32x4 own[TO];  // relu'd activations of this wave's own output tiles (B-operand layout)
+
+  // builds the layer-2 input operand (and the candidate z1 when with_delta)
+  auto build = [&](bool with_delta) {
+    const int sel = s_sel[j];
+    const float* zc = s_z1 + sel * 16 * ZS + j * ZS;
+    float* zn = s_z1 + (sel ^ 1) * 16 * ZS + j * ZS;
+    const float* wa = pp.w1p;
+    const float* wb = pp.w1p;
+    if (with_delta) {
+      wa = pp.w1p + (long long)s_idn[j] * Hp;
+      wb = pp.w1p + (long long)s_iup[j] * Hp;
+    }
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+      const int t = wave * TO + to, col = 16 * t + 4 * g;
+      f32x4 z = *(const f32x4*)(zc + col);
+      if (with_delta) {
+        const f32x4 x = *(const f32x4*)(wa + col);
+        const f32x4 y = *(const f32x4*)(wb + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = fmaf(2.f, x[e] - y[e], z[e]);
+        *(f32x4*)(zn + col) = z;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(z[e], 0.f);
+      *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
+    }
+  };
+
+  // layers 2..L + output dot; returns nothing, leaves per-wave partial logits in s_part.
+  auto forward = [&]() {
+    int cur = 0;
+    for (int l = 0; l < a.n_hidden; ++l) {
+      __syncthreads();
+      const float* xin = s_x + cur * NT * 256;
+      f32x4 in[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) in[t] = *(const f32x4*)(xin + (t * 64 + lane) * 4);
+      f32x4 acc[TO];
+#pragma unroll
+      for (int to = 0; to < TO; ++to)
+        acc[to] = *(const f32x4*)(pp.bh + l * Hp + 16 * (wave * TO + to) + 4 * g);
+      const f32x4* __restrict__ wp = (const f32x4*)(pp.p16 + (long long)l * Hp * Hp);
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) {
+        f32x4 w[TO];
+#pragma unroll
+        for (int to = 0; to < TO; ++to) w[to] = wp[((wave * TO + to) * NT + ti) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int to = 0; to < TO; ++to)
+            acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[to][r], in[ti][r], acc[to], 0, 0, 0);
+      }
+      float* xout = s_x + (cur ^ 1) * NT * 256;
+#pragma unroll
+      for (int to = 0; to < TO; ++to) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(acc[to][e], 0.f);
+        if (l + 1 < a.n_hidden) *(f32x4*)(xout + ((wave * TO + to) * 64 + lane) * 4) = own[to];
+      }
+      cur ^= 1;
+    }
+    float part = 0.f;
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+      const f32x4 w = *(const f32x4*)(pp.woutp + 16 * (wave * TO + to) + 4 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part = fmaf(own[to][e], w[e], part);
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    if (g == 0) s_part[wave * 16 + j] = part;
+    __syncthreads();
+  };
+
+  auto logit_of = [&](int c) {
+    return ((s_part[c] + s_part[16 + c]) + (s_part[32 + c] + s_part[48 + c])) + pp.bout[0];
+  };
+
+  // ---- initial cache: z1 and logit of the current spins
+  z1_direct();
+  __syncthreads();
+  build(false);
+  forward();
+  if (tid < 16) s_logit[tid] = logit_of(tid);
+  __syncthreads();
+
+  const uint2 key = make_uint2(a.seed_lo, a.seed_hi);
+  const int nblk = (N + 3) >> 2;
+  unsigned int n_acc = 0;
+  const bool dbg = a.dbg_up != nullptr;
+  const long long n_iter = dbg ? 1 : a.n_steps;
+
+  for (long long it = 0; it < n_iter; ++it) {
+    const unsigned long long step = a.step0 + (unsigned long long)it;
+    // ---- proposals
+    if (a.inj_up) {
+      if (tid < 16) {
+        const int gc = chain0 + tid;
+        const bool ok = gc < a.B;
+        s_iup[tid] = ok ? a.inj_up[gc] : 0;
+        s_idn[tid] = ok ? a.inj_dn[gc] : 1;
+        s_u[tid] = ok ? a.inj_u[gc] : 2.f;
+      }
+    } else {
+      const int c = wave * 4 + g, sub = j;
+      const uint32_t gid = (uint32_t)(a.chain_offset + chain0 + c);
+      float vmax = -3.f, vmin = 3.f;
+      int imax = 0x7fffffff, imin = 0x7fffffff;
+      for (int blk = sub; blk < nblk; blk += 16) {
+        const uint4 r = philox4x32_10(
+            make_uint4((uint32_t)blk, gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
+        const f32x4 sp = *(const f32x4*)(s_spin + c * Nst + 4 * blk);
+        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = 4 * blk + e;
+          if (n < N) {
+            const float v = sp[e] * u32_to_uniform(rr[e]);
+            if (v > vmax) { vmax = v; imax = n; }
+            if (v < vmin) { vmin = v; imin = n; }
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        const float ov = __shfl_xor(vmax, m); const int oi = __shfl_xor(imax, m);
+        if (ov > vmax || (ov == vmax && oi < imax)) { vmax = ov; imax = oi; }
+        const float pv = __shfl_xor(vmin, m); const int pi = __shfl_xor(imin, m);
+        if (pv < vmin || (pv == vmin && pi < imin)) { vmin = pv; imin = pi; }
+      }
+      if (sub == 0) {
+        const uint4 r = philox4x32_10(
+            make_uint4(VMC_ACCEPT_BLOCK, gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
+        s_iup[c] = imax;   // argmax of s*u: the UP spin to lower   (graph_builders.py:64-65)
+        s_idn[c] = imin;   // argmin of s*u: the DOWN spin to raise (graph_builders.py:62-63)
+        s_u[c] = u32_to_uniform(r.x);
+      }
+    }
+    __syncthreads();
+    if (dbg) {
+      if (tid < 16 && chain0 + tid < a.B) {
+        a.dbg_up[chain0 + tid] = s_iup[tid];
+        a.dbg_dn[chain0 + tid] = s_idn[tid];
+        a.dbg_u[chain0 + tid] = s_u[tid];
+      }
+      break;
+    }
+    // ---- candidate amplitude
+    build(true);
+    forward();
+    // ---- Metropolis accept (graph_builders.py:75-88)
+    if (tid < 16) {
+      const int c = tid, gc = chain0 + c;
+      const float ln = logit_of(c);
+      const bool acc = (gc < a.B) && (expf(ln - s_logit[c]) > sqrtf(s_u[c]));
+      if (acc) {
+        s_logit[c] = ln;
+        s_spin[c * Nst + s_idn[c]] = 1.f;
+        s_spin[c * Nst + s_iup[c]] = -1.f;
+        s_sel[c] ^= 1;
+        ++n_acc;
+      }
+      if (a.acc_mask && gc < a.B) a.acc_mask[gc] = acc ? 1 : 0;
+    }
+    __syncthreads();
+  }
+
+  if (!dbg) {
+    // ---- exact cache for the final spins, then write back
+    __syncthreads();
+    if (tid < 16) s_sel[tid] = 0;
+    z1_direct();
+    __syncthreads();
+    build(false);
+    forward();
+    if (tid < 16 && chain0 + tid < a.B) a.logit[chain0 + tid] = logit_of(tid);
+    for (int i = tid; i < 16 * N; i += 256) {
+      const int c = i / N, n = i % N, gc = chain0 + c;
+      if (gc < a.B) a.configs[(long long)gc * N + n] = s_spin[c * Nst + n];
+    }
+    for (int i = tid; i < 16 * Hp; i += 256) {
+      const int c = i / Hp, col = i % Hp, gc = chain0 + c;
+      if (gc < a.B) a.z1[(long long)gc * Hp + col] = s_z1[c * ZS + col];
+    }
+    if (tid < 16 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);
+  }
+}
+
+static size_t sweep_lds_bytes(int N, int Hp) {
+  const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
+  return sizeof(float) * (size_t)(16 * Nst + 2 * 16 * ZS + 2 * NT * 256 + 64 + 16 + 16 + 48);
+}
+
+hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp) {
+  if (a.B <= 0) return hipSuccess;
+  const dim3 grid((a.B + 15) / 16), block(256);
+  const size_t lds = sweep_lds_bytes(a.N, Hp);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+#define SWEEP_CASE(NT_)                                                                       \
+  case NT_: {                                                                                 \
+    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT_>,                           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                            \
+    hipLaunchKernelGGL((k_sweep16<NT_>), grid, block, lds, s, a);                             \
+    break;                                                                                    \
+  }
+  switch (Hp / 16) {
+    SWEEP_CASE(4)
+    SWEEP_CASE(8)
+    SWEEP_CASE(12)
+    SWEEP_CASE(16)
+    default: return hipErrorInvalidValue;
+  }
+#undef SWEEP_CASE
+  return hipGetLastError();
+}

@@ -1,0 +1,758 @@
+// Host side of libcgsvmc_hip.so: the C ABI of include/cgsvmc.h on top of the gfx950
+// kernels in mlp.hip / eloc.hip / grad.hip.  One vmc_ctx per GPU, all work on ctx->stream.
+#include "../../include/cgsvmc.h"
+#include "common.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+struct ParamSet {
+  float* theta = nullptr;
+  float *w1p = nullptr, *b1p = nullptr, *bh = nullptr, *p32 = nullptr, *p16 = nullptr,
+        *woutp = nullptr, *bout = nullptr;
+  float* z1 = nullptr;     // [B][Hp] cache for the ctx's chains
+  float* logit = nullptr;  // [B]
+  float* eloc = nullptr;   // [B]
+  bool packed_valid = false, cache_valid = false, has_params = false;
+  float shift = -10.f;     // wavefunctions.py:209
+  PackedParams packed() const { return PackedParams{w1p, b1p, bh, p32, p16, woutp, bout}; }
+};
+
+struct TimedRegion {
+  std::string name;
+  hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct vmc_ctx {
+  vmc_desc d;
+  int N = 0, B = 0, L = 0, H = 0, Hp = 0;
+  long long P = 0;
+  hipStream_t stream = nullptr;
+  ParamSet ps[2];
+  float* configs = nullptr;
+  // Hamiltonian
+  int n_bonds = 0;
+  int2* bonds = nullptr;
+  float *half_jx = nullptr, *quarter_jz = nullptr;
+  int *cnt = nullptr, *off = nullptr;
+  float *diag = nullptr, *val = nullptr, *offdiag = nullptr;
+  int2* rowinfo = nullptr;
+  bool list_valid = false;
+  long long last_rows = 0;
+  // gradient path
+  std::vector<float*> act;   // L buffers [B][Hp]
+  float* delta[2] = {nullptr, nullptr};
+  float *ratio = nullptr, *ones = nullptr;
+  float *acc = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad_tmp = nullptr;
+  long long adam_t = 0;
+  float *gemm_ws = nullptr, *wcs_ws = nullptr;
+  int splitk = 16;
+  // scratch
+  unsigned long long* d_accepted = nullptr;
+  double* d_sum = nullptr;
+  float* d_max = nullptr;
+  float *tmp_cfg = nullptr, *tmp_z1 = nullptr, *tmp_out = nullptr;
+  long long tmp_rows = 0;
+  int *inj_up = nullptr, *inj_dn = nullptr;
+  float* inj_u = nullptr;
+  unsigned char* acc_mask = nullptr;
+  unsigned long long step = 0;
+  // timing
+  bool timing = false;
+  std::vector<TimedRegion> pending;
+  std::map<std::string, std::pair<double, long long>> timings;
+  std::string err;
+};
+
+namespace {
+
+int fail(vmc_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                  \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail((c), VMC_ERR_HIP,                                                      \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+  } while (0)
+
+#define CHECK_CTX(c) \
+  do { if (!(c)) return fail(nullptr, VMC_ERR_INVALID, "null ctx"); } while (0)
+
+#define PROPAGATE(expr) \
+  do { int rc_ = (expr); if (rc_ != VMC_OK) return rc_; } while (0)
+
+template <typename T>
+hipError_t dalloc(T** p, long long n) {
+  return hipMalloc((void**)p, (size_t)(n > 0 ? n : 1) * sizeof(T));
+}
+
+struct Timer {
+  vmc_ctx* c; bool on; TimedRegion r;
+  Timer(vmc_ctx* ctx, const char* name) : c(ctx), on(ctx->timing) {
+    if (on) {
+      r.name = name;
+      hipEventCreate(&r.start); hipEventCreate(&r.stop);
+      hipEventRecord(r.start, c->stream);
+    }
+  }
+  ~Timer() {
+    if (on) { hipEventRecord(r.stop, c->stream); c->pending.push_back(r); }
+  }
+};
+
+void drain_timings(vmc_ctx* c) {
+  for (auto& r : c->pending) {
+    hipEventSynchronize(r.stop);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.start, r.stop);
+    auto& t = c->timings[r.name];
+    t.first += ms; t.second += 1;
+    hipEventDestroy(r.start); hipEventDestroy(r.stop);
+  }
+  c->pending.clear();
+}
+
+long long off_w(const vmc_ctx* c, int l) {  // weight matrix of layer l (0 = first)
+  if (l == 0) return 0;
+  return (long long)c->N * c->H + c->H + (long long)(l - 1) * ((long long)c->H * c->H + c->H);
+}
+long long off_b(const vmc_ctx* c, int l) {
+  return l == 0 ? (long long)c->N * c->H : off_w(c, l) + (long long)c->H * c->H;
+}
+long long off_wout(const vmc_ctx* c) { return off_w(c, c->L); }
+long long off_bout(const vmc_ctx* c) { return off_wout(c) + c->H; }
+
+int ensure_packed(vmc_ctx* c, int which) {
+  ParamSet& p = c->ps[which];
+  if (!p.has_params) return fail(c, VMC_ERR_STATE, "parameters not set (vmc_set_params)");
+  if (p.packed_valid) return VMC_OK;
+  HIPCHK(c, launch_pack(c->stream, p.theta, c->N, c->H, c->Hp, c->L, p.w1p, p.b1p, p.bh, p.p32,
+                        p.p16, p.woutp, p.bout));
+  p.packed_valid = true;
+  return VMC_OK;
+}
+
+TailArgs tail_args(vmc_ctx* c, int which) {
+  TailArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pp = c->ps[which].packed();
+  a.bonds = c->bonds;
+  a.half_jx = c->half_jx;
+  a.n_hidden = c->L - 1;
+  return a;
+}
+
+// z1 / logit cache of parameter set `which` for the ctx's chains
+int ensure_cache(vmc_ctx* c, int which) {
+  PROPAGATE(ensure_packed(c, which));
+  ParamSet& p = c->ps[which];
+  if (p.cache_valid) return VMC_OK;
+  {
+    Timer t(c, "z1");
+    HIPCHK(c, launch_z1(c->stream, c->configs, p.w1p, p.b1p, p.z1, c->B, c->N, c->Hp));
+  }
+  {
+    Timer t(c, "tail_amp");
+    TailArgs a = tail_args(c, which);
+    a.z1 = p.z1; a.n_rows = c->B; a.out = p.logit;
+    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, false));
+  }
+  p.cache_valid = true;
+  return VMC_OK;
+}
+
+void invalidate_configs(vmc_ctx* c) {
+  c->ps[0].cache_valid = c->ps[1].cache_valid = false;
+  c->list_valid = false;
+}
+
+int ensure_list(vmc_ctx* c) {
+  if (c->n_bonds <= 0) return fail(c, VMC_ERR_STATE, "bonds not set (vmc_set_bonds)");
+  if (c->list_valid) return VMC_OK;
+  Timer t(c, "bond_list");
+  HIPCHK(c, launch_bond_list(c->stream, c->configs, c->bonds, c->quarter_jz, c->B, c->N,
+                             c->n_bonds, c->cnt, c->off, c->diag, c->rowinfo));
+  c->list_valid = true;
+  return VMC_OK;
+}
+
+// eloc[which] on device
+int local_energy_device(vmc_ctx* c, int which) {
+  PROPAGATE(ensure_cache(c, which));
+  PROPAGATE(ensure_list(c));
+  ParamSet& p = c->ps[which];
+  {
+    Timer t(c, "tail_eloc");
+    TailArgs a = tail_args(c, which);
+    a.z1 = p.z1; a.logit_base = p.logit; a.rowinfo = c->rowinfo;
+    a.n_rows_dev = c->off + c->B;
+    a.n_rows = (int)((long long)c->B * c->n_bonds);
+    a.out = c->val;
+    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, true));
+  }
+  {
+    Timer t(c, "eloc_reduce");
+    HIPCHK(c, launch_eloc_reduce(c->stream, c->off, c->diag, c->val, c->B, c->offdiag, p.eloc));
+  }
+  return VMC_OK;
+}
+
+int grow_tmp(vmc_ctx* c, long long rows) {
+  if (rows <= c->tmp_rows) return VMC_OK;
+  if (c->tmp_cfg) { hipFree(c->tmp_cfg); hipFree(c->tmp_z1); hipFree(c->tmp_out); }
+  HIPCHK(c, dalloc(&c->tmp_cfg, rows * c->N));
+  HIPCHK(c, dalloc(&c->tmp_z1, rows * c->Hp));
+  HIPCHK(c, dalloc(&c->tmp_out, rows));
+  c->tmp_rows = rows;
+  return VMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t vmc_num_params(int32_t n_sites, int32_t layer_size, int32_t num_layers) {
+  const int64_t N = n_sites, H = layer_size, L = num_layers;
+  return N * H + H + (L - 1) * (H * H + H) + H + 1;
+}
+
+const char* vmc_last_error(const vmc_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int vmc_create(const vmc_desc* d, vmc_ctx** out) {
+  if (!d || !out) return fail(nullptr, VMC_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (d->n_sites < 2 || d->batch_size < 1 || d->num_layers < 1 || d->layer_size < 1)
+    return fail(nullptr, VMC_ERR_INVALID, "n_sites >= 2, batch_size, num_layers, layer_size >= 1 required");
+  if (d->nonlinearity != VMC_ACT_RELU)
+    return fail(nullptr, VMC_ERR_UNSUPPORTED, "only nonlinearity='relu' has a HIP kernel");
+  if (d->output_activation != VMC_ACT_EXP)
+    return fail(nullptr, VMC_ERR_UNSUPPORTED, "only output_activation='exp' has a HIP kernel");
+  if (d->layer_size > 256)
+    return fail(nullptr, VMC_ERR_UNSUPPORTED, "fc_layer_size > 256 not supported by the register-resident kernels");
+  if (d->n_sites > 2048)
+    return fail(nullptr, VMC_ERR_UNSUPPORTED, "num_sites > 2048 not supported (LDS chain state)");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, VMC_ERR_HIP, "no HIP device available: the VMC hot path has no CPU fallback");
+  if (d->device < 0 || d->device >= ndev) return fail(nullptr, VMC_ERR_INVALID, "bad device ordinal");
+  if ((e = hipSetDevice(d->device)) != hipSuccess)
+    return fail(nullptr, VMC_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+
+  vmc_ctx* c = new vmc_ctx();
+  c->d = *d;
+  c->N = d->n_sites; c->B = d->batch_size; c->L = d->num_layers; c->H = d->layer_size;
+  c->Hp = (c->H + 63) / 64 * 64;
+  c->P = vmc_num_params(c->N, c->H, c->L);
+  c->stream = (hipStream_t)d->stream;
+  const long long B = c->B, N = c->N, Hp = c->Hp, P = c->P, L = c->L;
+#define CA(expr) do { hipError_t e2 = (expr); if (e2 != hipSuccess) { \
+    g_create_error = std::string(#expr) + ": " + hipGetErrorString(e2); vmc_destroy(c); return VMC_ERR_HIP; } } while (0)
+  for (int w = 0; w < 2; ++w) {
+    ParamSet& p = c->ps[w];
+    CA(dalloc(&p.theta, P));
+    CA(dalloc(&p.w1p, N * Hp)); CA(dalloc(&p.b1p, Hp)); CA(dalloc(&p.bh, (L - 1) * Hp));
+    CA(dalloc(&p.p32, (L - 1) * Hp * Hp)); CA(dalloc(&p.p16, (L - 1) * Hp * Hp));
+    CA(dalloc(&p.woutp, Hp)); CA(dalloc(&p.bout, 1));
+    CA(dalloc(&p.z1, B * Hp)); CA(dalloc(&p.logit, B)); CA(dalloc(&p.eloc, B));
+  }
+  CA(dalloc(&c->configs, B * N));
+  CA(hipMemsetAsync(c->configs, 0, B * N * sizeof(float), c->stream));
+  c->act.resize(L, nullptr);
+  for (int l = 0; l < L; ++l) {
+    CA(dalloc(&c->act[l], B * Hp));
+    CA(hipMemsetAsync(c->act[l], 0, B * Hp * sizeof(float), c->stream));
+  }
+  for (int i = 0; i < 2; ++i) {
+    CA(dalloc(&c->delta[i], B * Hp));
+    CA(hipMemsetAsync(c->delta[i], 0, B * Hp * sizeof(float), c->stream));
+  }
+  CA(dalloc(&c->ratio, B)); CA(dalloc(&c->ones, B));
+  CA(launch_fill(c->stream, c->ones, 1.f, B));
+  CA(dalloc(&c->acc, 2 * P + 8)); CA(dalloc(&c->adam_m, P)); CA(dalloc(&c->adam_v, P));
+  CA(dalloc(&c->grad_tmp, P));
+  CA(hipMemsetAsync(c->acc, 0, (2 * P + 8) * sizeof(float), c->stream));
+  CA(hipMemsetAsync(c->adam_m, 0, P * sizeof(float), c->stream));
+  CA(hipMemsetAsync(c->adam_v, 0, P * sizeof(float), c->stream));
+  const long long mmax = N > c->H ? N : c->H;
+  CA(dalloc(&c->gemm_ws, (long long)c->splitk * mmax * c->H));
+  CA(dalloc(&c->wcs_ws, 32 * Hp));
+  CA(dalloc(&c->d_accepted, 1)); CA(dalloc(&c->d_sum, 1)); CA(dalloc(&c->d_max, 1));
+  CA(dalloc(&c->inj_up, B)); CA(dalloc(&c->inj_dn, B)); CA(dalloc(&c->inj_u, B));
+  CA(dalloc(&c->acc_mask, B));
+  CA(dalloc(&c->cnt, B)); CA(dalloc(&c->off, B + 1)); CA(dalloc(&c->diag, B));
+  CA(dalloc(&c->offdiag, B));
+  CA(hipStreamSynchronize(c->stream));
+#undef CA
+  *out = c;
+  return VMC_OK;
+}
+
+void vmc_destroy(vmc_ctx* c) {
+  if (!c) return;
+  hipStreamSynchronize(c->stream);
+  drain_timings(c);
+  for (int w = 0; w < 2; ++w) {
+    ParamSet& p = c->ps[w];
+    float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p32, p.p16, p.woutp, p.bout, p.z1, p.logit, p.eloc};
+    for (float* q : ptrs) if (q) hipFree(q);
+  }
+  for (float* q : c->act) if (q) hipFree(q);
+  void* ptrs[] = {c->configs, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
+                  c->offdiag, c->rowinfo, c->delta[0], c->delta[1], c->ratio, c->ones, c->acc,
+                  c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->wcs_ws, c->d_accepted, c->d_sum,
+                  c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->inj_up, c->inj_dn, c->inj_u,
+                  c->acc_mask};
+  for (void* q : ptrs) if (q) hipFree(q);
+  delete c;
+}
+
+int vmc_set_bonds(vmc_ctx* c, int32_t n_bonds, const int32_t* ij, const float* j_x, const float* j_z) {
+  CHECK_CTX(c);
+  if (n_bonds < 1 || !ij || !j_x || !j_z) return fail(c, VMC_ERR_INVALID, "bad bond arguments");
+  std::vector<int2> b(n_bonds);
+  std::vector<float> hx(n_bonds), qz(n_bonds);
+  for (int k = 0; k < n_bonds; ++k) {
+    const int i = ij[2 * k], j = ij[2 * k + 1];
+    if (i < 0 || j < 0 || i >= c->N || j >= c->N || i == j)
+      return fail(c, VMC_ERR_INVALID, "bond site index out of range (or i == j)");
+    b[k] = make_int2(i, j);
+    hx[k] = 0.5f * j_x[k];     // 0.25 * jx * 2   (operators.py:168-169)
+    qz[k] = 0.25f * j_z[k];    // operators.py:169
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  void* old[] = {c->bonds, c->half_jx, c->quarter_jz, c->rowinfo, c->val};
+  for (void* q : old) if (q) hipFree(q);
+  c->bonds = nullptr; c->half_jx = c->quarter_jz = c->val = nullptr; c->rowinfo = nullptr;
+  c->n_bonds = n_bonds;
+  HIPCHK(c, dalloc(&c->bonds, n_bonds)); HIPCHK(c, dalloc(&c->half_jx, n_bonds));
+  HIPCHK(c, dalloc(&c->quarter_jz, n_bonds));
+  HIPCHK(c, dalloc(&c->rowinfo, (long long)c->B * n_bonds));
+  HIPCHK(c, dalloc(&c->val, (long long)c->B * n_bonds));
+  HIPCHK(c, hipMemcpy(c->bonds, b.data(), n_bonds * sizeof(int2), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->half_jx, hx.data(), n_bonds * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->quarter_jz, qz.data(), n_bonds * sizeof(float), hipMemcpyHostToDevice));
+  c->list_valid = false;
+  return VMC_OK;
+}
+
+int vmc_set_params(vmc_ctx* c, int which, const float* theta) {
+  CHECK_CTX(c);
+  if ((which != 0 && which != 1) || !theta) return fail(c, VMC_ERR_INVALID, "bad arguments");
+  HIPCHK(c, hipMemcpyAsync(c->ps[which].theta, theta, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->ps[which].has_params = true;
+  c->ps[which].packed_valid = c->ps[which].cache_valid = false;
+  return VMC_OK;
+}
+
+int vmc_get_params(vmc_ctx* c, int which, float* theta) {
+  CHECK_CTX(c);
+  if ((which != 0 && which != 1) || !theta) return fail(c, VMC_ERR_INVALID, "bad arguments");
+  if (!c->ps[which].has_params) return fail(c, VMC_ERR_STATE, "parameters not set");
+  HIPCHK(c, hipMemcpyAsync(theta, c->ps[which].theta, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_transfer_params(vmc_ctx* c) {
+  CHECK_CTX(c);
+  if (!c->ps[0].has_params) return fail(c, VMC_ERR_STATE, "parameters not set");
+  HIPCHK(c, hipMemcpyAsync(c->ps[1].theta, c->ps[0].theta, c->P * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  c->ps[1].has_params = true;
+  c->ps[1].packed_valid = c->ps[1].cache_valid = false;
+  return VMC_OK;
+}
+
+int vmc_set_configs(vmc_ctx* c, const float* configs) {
+  CHECK_CTX(c);
+  if (!configs) return fail(c, VMC_ERR_INVALID, "null configs");
+  const long long n = (long long)c->B * c->N;
+  for (long long i = 0; i < n; ++i)
+    if (configs[i] != 1.f && configs[i] != -1.f) return fail(c, VMC_ERR_INVALID, "configs must be +-1");
+  HIPCHK(c, hipMemcpyAsync(c->configs, configs, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  invalidate_configs(c);
+  return VMC_OK;
+}
+
+int vmc_get_configs(vmc_ctx* c, float* configs) {
+  CHECK_CTX(c);
+  if (!configs) return fail(c, VMC_ERR_INVALID, "null configs");
+  HIPCHK(c, hipMemcpyAsync(configs, c->configs, (long long)c->B * c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_set_shift(vmc_ctx* c, int which, float shift) {
+  CHECK_CTX(c);
+  if (which != 0 && which != 1) return fail(c, VMC_ERR_INVALID, "bad which");
+  c->ps[which].shift = shift;
+  return VMC_OK;
+}
+
+int vmc_get_shift(vmc_ctx* c, int which, float* shift) {
+  CHECK_CTX(c);
+  if ((which != 0 && which != 1) || !shift) return fail(c, VMC_ERR_INVALID, "bad arguments");
+  *shift = c->ps[which].shift;
+  return VMC_OK;
+}
+
+int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, float* logit, float* psi) {
+  CHECK_CTX(c);
+  if (which != 0 && which != 1) return fail(c, VMC_ERR_INVALID, "bad which");
+  if (n_rows < 0) return fail(c, VMC_ERR_INVALID, "n_rows < 0");
+  std::vector<float> host((size_t)n_rows);
+  if (!configs) {
+    if (n_rows != c->B) return fail(c, VMC_ERR_INVALID, "n_rows must equal batch_size when configs == NULL");
+    PROPAGATE(ensure_cache(c, which));
+    HIPCHK(c, hipMemcpyAsync(host.data(), c->ps[which].logit, n_rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  } else if (n_rows > 0) {
+    PROPAGATE(ensure_packed(c, which));
+    PROPAGATE(grow_tmp(c, n_rows));
+    HIPCHK(c, hipMemcpyAsync(c->tmp_cfg, configs, n_rows * c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    ParamSet& p = c->ps[which];
+    HIPCHK(c, launch_z1(c->stream, c->tmp_cfg, p.w1p, p.b1p, c->tmp_z1, (int)n_rows, c->N, c->Hp));
+    TailArgs a = tail_args(c, which);
+    a.z1 = c->tmp_z1; a.n_rows = (int)n_rows; a.out = c->tmp_out;
+    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, false));
+    HIPCHK(c, hipMemcpyAsync(host.data(), c->tmp_out, n_rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const float shift = c->ps[which].shift;
+  for (int64_t i = 0; i < n_rows; ++i) {
+    if (logit) logit[i] = host[i];
+    if (psi) psi[i] = expf(host[i] - shift);   // wavefunctions.py:232, 351
+  }
+  return VMC_OK;
+}
+
+static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int* dbg_up, int* dbg_dn,
+                     float* dbg_u, unsigned long long step0) {
+  PROPAGATE(ensure_packed(c, 0));
+  SweepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pp = c->ps[0].packed();
+  a.configs = c->configs; a.z1 = c->ps[0].z1; a.logit = c->ps[0].logit;
+  a.accepted = c->d_accepted;
+  if (injected) { a.inj_up = c->inj_up; a.inj_dn = c->inj_dn; a.inj_u = c->inj_u; a.acc_mask = c->acc_mask; }
+  if (dbg) { a.dbg_up = dbg_up; a.dbg_dn = dbg_dn; a.dbg_u = dbg_u; }
+  a.B = c->B; a.N = c->N; a.n_hidden = c->L - 1;
+  a.chain_offset = c->d.chain_offset;
+  a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
+  a.step0 = step0; a.n_steps = n_steps;
+  HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), c->stream));
+  {
+    Timer t(c, "sweep");
+    HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
+  }
+  return VMC_OK;
+}
+
+int vmc_mc_steps(vmc_ctx* c, int64_t n_steps, int64_t* accepted) {
+  CHECK_CTX(c);
+  if (n_steps < 0) return fail(c, VMC_ERR_INVALID, "n_steps < 0");
+  PROPAGATE(run_sweep(c, n_steps, false, false, nullptr, nullptr, nullptr, c->step));
+  c->step += (unsigned long long)n_steps;
+  c->ps[0].cache_valid = true;   // the sweep kernel writes back an exact z1/logit cache
+  c->ps[1].cache_valid = false;
+  c->list_valid = false;
+  if (accepted) {
+    unsigned long long h = 0;
+    HIPCHK(c, hipMemcpyAsync(&h, c->d_accepted, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *accepted = (int64_t)h;
+  }
+  return VMC_OK;
+}
+
+int vmc_mc_step_injected(vmc_ctx* c, const int32_t* i_up, const int32_t* i_dn, const float* u, uint8_t* accept_mask) {
+  CHECK_CTX(c);
+  if (!i_up || !i_dn || !u) return fail(c, VMC_ERR_INVALID, "null proposals");
+  for (int b = 0; b < c->B; ++b)
+    if (i_up[b] < 0 || i_up[b] >= c->N || i_dn[b] < 0 || i_dn[b] >= c->N)
+      return fail(c, VMC_ERR_INVALID, "proposal site out of range");
+  HIPCHK(c, hipMemcpyAsync(c->inj_up, i_up, c->B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->inj_dn, i_dn, c->B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->inj_u, u, c->B * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  PROPAGATE(run_sweep(c, 1, true, false, nullptr, nullptr, nullptr, c->step));
+  c->ps[0].cache_valid = true; c->ps[1].cache_valid = false; c->list_valid = false;
+  if (accept_mask)
+    HIPCHK(c, hipMemcpyAsync(accept_mask, c->acc_mask, c->B, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_debug_proposals(vmc_ctx* c, uint64_t step, int32_t* i_up, int32_t* i_dn, float* u) {
+  CHECK_CTX(c);
+  if (!i_up || !i_dn || !u) return fail(c, VMC_ERR_INVALID, "null outputs");
+  PROPAGATE(run_sweep(c, 0, false, true, c->inj_up, c->inj_dn, c->inj_u, step));
+  HIPCHK(c, hipMemcpyAsync(i_up, c->inj_up, c->B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(i_dn, c->inj_dn, c->B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(u, c->inj_u, c->B * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_get_step_counter(vmc_ctx* c, uint64_t* step) { CHECK_CTX(c); if (!step) return fail(c, VMC_ERR_INVALID, "null"); *step = c->step; return VMC_OK; }
+int vmc_set_step_counter(vmc_ctx* c, uint64_t step) { CHECK_CTX(c); c->step = step; return VMC_OK; }
+
+int vmc_local_energy(vmc_ctx* c, int which, float* eloc, double* mean) {
+  CHECK_CTX(c);
+  if (which != 0 && which != 1) return fail(c, VMC_ERR_INVALID, "bad which");
+  PROPAGATE(local_energy_device(c, which));
+  if (mean) HIPCHK(c, launch_sum(c->stream, c->ps[which].eloc, c->B, c->d_sum));
+  if (eloc) HIPCHK(c, hipMemcpyAsync(eloc, c->ps[which].eloc, c->B * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  int cnt_total = 0;
+  HIPCHK(c, hipMemcpyAsync(&cnt_total, c->off + c->B, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  double s = 0.0;
+  if (mean) HIPCHK(c, hipMemcpyAsync(&s, c->d_sum, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->last_rows = cnt_total;
+  if (mean) *mean = s / (double)c->B;
+  return VMC_OK;
+}
+
+int vmc_local_energy_terms(vmc_ctx* c, int which, float* diag, float* offdiag_over_psi) {
+  CHECK_CTX(c);
+  if (which != 0 && which != 1) return fail(c, VMC_ERR_INVALID, "bad which");
+  PROPAGATE(local_energy_device(c, which));
+  if (diag) HIPCHK(c, hipMemcpyAsync(diag, c->diag, c->B * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (offdiag_over_psi) HIPCHK(c, hipMemcpyAsync(offdiag_over_psi, c->offdiag, c->B * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_last_connected_rows(vmc_ctx* c, int64_t* rows) { CHECK_CTX(c); if (!rows) return fail(c, VMC_ERR_INVALID, "null"); *rows = c->last_rows; return VMC_OK; }
+
+// sum_b O_k(b) -> g1, sum_b w_b O_k(b) -> g2 for the psi parameter set
+static int gradient_sums(vmc_ctx* c, const float* w) {
+  ParamSet& p = c->ps[0];
+  const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->L;
+  float* g1 = c->acc;
+  float* g2 = c->acc + c->P;
+  Timer t(c, "grad");
+  // forward with saved activations (wavefunctions.py:345-349)
+  HIPCHK(c, launch_relu_copy(c->stream, p.z1, c->act[0], (long long)B * Hp));
+  for (int l = 1; l < L; ++l) {
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = c->act[l - 1]; g.sam = Hp; g.sak = 1;
+    g.B = p.theta + off_w(c, l); g.sbk = H; g.sbn = 1;
+    g.M = B; g.N = H; g.K = H; g.C = c->act[l]; g.ldc = Hp;
+    g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1;
+    HIPCHK(c, launch_gemm(c->stream, g));
+  }
+  // output layer: d logit / d w_out = a_L, d logit / d b_out = 1
+  HIPCHK(c, launch_wcolsum(c->stream, c->act[L - 1], Hp, nullptr, B, H, g1 + off_wout(c), c->wcs_ws));
+  HIPCHK(c, launch_wcolsum(c->stream, c->act[L - 1], Hp, w, B, H, g2 + off_wout(c), c->wcs_ws));
+  HIPCHK(c, launch_wcolsum(c->stream, c->ones, 1, nullptr, B, 1, g1 + off_bout(c), c->wcs_ws));
+  HIPCHK(c, launch_wcolsum(c->stream, w, 1, nullptr, B, 1, g2 + off_bout(c), c->wcs_ws));
+  // back-propagation of d logit / d z_l
+  int cur = 0;
+  HIPCHK(c, launch_delta_out(c->stream, p.woutp, c->act[L - 1], c->delta[cur], B, Hp));
+  for (int l = L - 1; l >= 0; --l) {
+    const float* delta = c->delta[cur];
+    for (int pass = 0; pass < 2; ++pass) {
+      float* gdst = pass == 0 ? g1 : g2;
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      if (l == 0) { g.A = c->configs; g.sam = 1; g.sak = N; g.M = N; }
+      else { g.A = c->act[l - 1]; g.sam = 1; g.sak = Hp; g.M = H; }
+      g.B = delta; g.sbk = Hp; g.sbn = 1; g.kscale = pass == 0 ? nullptr : w;
+      g.N = H; g.K = B; g.C = gdst + off_w(c, l); g.ldc = H; g.epilogue = 3;
+      g.splitk = c->splitk; g.workspace = c->gemm_ws;
+      HIPCHK(c, launch_gemm(c->stream, g));
+      HIPCHK(c, launch_wcolsum(c->stream, delta, Hp, pass == 0 ? nullptr : w, B, H, gdst + off_b(c, l), c->wcs_ws));
+    }
+    if (l > 0) {
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.A = delta; g.sam = Hp; g.sak = 1;
+      g.B = p.theta + off_w(c, l); g.sbk = 1; g.sbn = H;   // W_l^T
+      g.M = B; g.N = H; g.K = H; g.C = c->delta[cur ^ 1]; g.ldc = Hp;
+      g.mask = c->act[l - 1]; g.ldmask = Hp; g.epilogue = 2; g.splitk = 1;
+      HIPCHK(c, launch_gemm(c->stream, g));
+      cur ^= 1;
+    }
+  }
+  return VMC_OK;
+}
+
+int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
+  CHECK_CTX(c);
+  if (mode != VMC_MODE_ENERGY_GRADIENT && mode != VMC_MODE_LOG_OVERLAP_ITSWO)
+    return fail(c, VMC_ERR_INVALID, "bad mode");
+  const float* w = nullptr;
+  const float* e = nullptr;
+  if (mode == VMC_MODE_ENERGY_GRADIENT) {
+    PROPAGATE(local_energy_device(c, VMC_PSI));               // training.py:542-543
+    w = e = c->ps[0].eloc;
+  } else {
+    if (!c->ps[1].has_params) return fail(c, VMC_ERR_STATE, "supervisor parameters not set (vmc_transfer_params)");
+    PROPAGATE(local_energy_device(c, VMC_OMEGA));             // training.py:664, 667
+    PROPAGATE(ensure_cache(c, VMC_PSI));
+    HIPCHK(c, launch_itswo_ratio(c->stream, c->ps[0].logit, c->ps[1].logit, c->ps[1].eloc,
+                                 c->ps[0].shift - c->ps[1].shift, beta, c->B, c->ratio));
+    w = c->ratio; e = c->ps[1].eloc;
+  }
+  PROPAGATE(ensure_cache(c, VMC_PSI));
+  PROPAGATE(gradient_sums(c, w));
+  HIPCHK(c, launch_scalar_accum(c->stream, e, mode == 1 ? c->ratio : nullptr, c->B, c->acc + 2 * c->P, mode));
+  return VMC_OK;
+}
+
+int vmc_reset_accumulators(vmc_ctx* c) {
+  CHECK_CTX(c);
+  HIPCHK(c, hipMemsetAsync(c->acc, 0, (2 * c->P + 8) * sizeof(float), c->stream));
+  return VMC_OK;
+}
+
+int vmc_accumulators_devptr(vmc_ctx* c, void** dev_ptr, int64_t* n_floats) {
+  CHECK_CTX(c);
+  if (dev_ptr) *dev_ptr = c->acc;
+  if (n_floats) *n_floats = 2 * c->P + 8;
+  return VMC_OK;
+}
+
+int vmc_get_accumulators(vmc_ctx* c, float* host) {
+  CHECK_CTX(c);
+  if (!host) return fail(c, VMC_ERR_INVALID, "null");
+  HIPCHK(c, hipMemcpyAsync(host, c->acc, (2 * c->P + 8) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_set_accumulators(vmc_ctx* c, const float* host) {
+  CHECK_CTX(c);
+  if (!host) return fail(c, VMC_ERR_INVALID, "null");
+  HIPCHK(c, hipMemcpyAsync(c->acc, host, (2 * c->P + 8) * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_mean_energy(vmc_ctx* c, double* energy) {
+  CHECK_CTX(c);
+  if (!energy) return fail(c, VMC_ERR_INVALID, "null");
+  float sc[8];
+  HIPCHK(c, hipMemcpyAsync(sc, c->acc + 2 * c->P, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *energy = (double)(sc[0] / sc[1]);   // tf.metrics.mean value: total / count
+  return VMC_OK;
+}
+
+int vmc_get_gradient(vmc_ctx* c, int mode, float* grad) {
+  CHECK_CTX(c);
+  if (!grad || (mode != 0 && mode != 1)) return fail(c, VMC_ERR_INVALID, "bad arguments");
+  HIPCHK(c, launch_adam(c->stream, nullptr, nullptr, nullptr, c->acc, (int)c->P, mode, 0.f, 0.f, 0.f, 0.f, c->grad_tmp));
+  HIPCHK(c, hipMemcpyAsync(grad, c->grad_tmp, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_apply_adam(vmc_ctx* c, int mode, float lr, float beta1, float beta2, float eps, double* energy) {
+  CHECK_CTX(c);
+  if (mode != 0 && mode != 1) return fail(c, VMC_ERR_INVALID, "bad mode");
+  if (!c->ps[0].has_params) return fail(c, VMC_ERR_STATE, "parameters not set");
+  c->adam_t += 1;
+  const float t = (float)c->adam_t;
+  const float lr_t = lr * sqrtf(1.f - powf(beta2, t)) / (1.f - powf(beta1, t));
+  {
+    Timer tm(c, "adam");
+    HIPCHK(c, launch_adam(c->stream, c->ps[0].theta, c->adam_m, c->adam_v, c->acc, (int)c->P, mode, lr_t, beta1, beta2, eps, nullptr));
+  }
+  c->ps[0].packed_valid = c->ps[0].cache_valid = false;
+  if (energy) PROPAGATE(vmc_mean_energy(c, energy));
+  return VMC_OK;
+}
+
+int vmc_get_adam_state(vmc_ctx* c, float* m, float* v, int64_t* t) {
+  CHECK_CTX(c);
+  if (m) HIPCHK(c, hipMemcpyAsync(m, c->adam_m, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (v) HIPCHK(c, hipMemcpyAsync(v, c->adam_v, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (t) *t = c->adam_t;
+  return VMC_OK;
+}
+
+int vmc_set_adam_state(vmc_ctx* c, const float* m, const float* v, int64_t t) {
+  CHECK_CTX(c);
+  if (m) HIPCHK(c, hipMemcpyAsync(c->adam_m, m, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (v) HIPCHK(c, hipMemcpyAsync(c->adam_v, v, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->adam_t = t;
+  return VMC_OK;
+}
+
+int vmc_update_norm(vmc_ctx* c, float max_value) {
+  CHECK_CTX(c);
+  PROPAGATE(ensure_cache(c, VMC_PSI));
+  HIPCHK(c, launch_max(c->stream, c->ps[0].logit, c->B, c->d_max));
+  float mx = 0.f;
+  HIPCHK(c, hipMemcpyAsync(&mx, c->d_max, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // wavefunctions.py:280-288: log_max = log(reduce_max(psi)); where psi overflows float32 the
+  // reference yields inf; the logit-domain value is used there instead.
+  const float shift = c->ps[0].shift;
+  const float psi_max = expf(mx - shift);
+  const float log_max = (std::isfinite(psi_max) && psi_max > 0.f) ? logf(psi_max) : (mx - shift);
+  const float max_log = logf(max_value);
+  if (log_max > max_log) c->ps[0].shift = shift + (log_max - max_log);
+  return VMC_OK;
+}
+
+int vmc_timing_enable(vmc_ctx* c, int on) { CHECK_CTX(c); c->timing = on != 0; return VMC_OK; }
+
+int vmc_timing_reset(vmc_ctx* c) {
+  CHECK_CTX(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  drain_timings(c);
+  c->timings.clear();
+  return VMC_OK;
+}
+
+int vmc_timing_get(vmc_ctx* c, const char* name, double* ms, int64_t* launches) {
+  CHECK_CTX(c);
+  if (!name) return fail(c, VMC_ERR_INVALID, "null name");
+  drain_timings(c);
+  auto it = c->timings.find(name);
+  if (ms) *ms = it == c->timings.end() ? 0.0 : it->second.first;
+  if (launches) *launches = it == c->timings.end() ? 0 : it->second.second;
+  return VMC_OK;
+}
+
+int vmc_synchronize(vmc_ctx* c) { CHECK_CTX(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return VMC_OK; }
+
+int vmc_debug_gemm(vmc_ctx* c, int32_t M, int32_t N, int32_t K, const float* A, int64_t sam, int64_t sak,
+                   int64_t a_len, const float* B, int64_t sbk, int64_t sbn, int64_t b_len, float* C) {
+  CHECK_CTX(c);
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr, *ws = nullptr;
+  HIPCHK(c, dalloc(&dA, a_len)); HIPCHK(c, dalloc(&dB, b_len)); HIPCHK(c, dalloc(&dC, (long long)M * N));
+  HIPCHK(c, dalloc(&ws, 4LL * M * N));
+  HIPCHK(c, hipMemcpy(dA, A, a_len * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dB, B, b_len * sizeof(float), hipMemcpyHostToDevice));
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = dA; g.sam = sam; g.sak = sak; g.B = dB; g.sbk = sbk; g.sbn = sbn;
+  g.M = M; g.N = N; g.K = K; g.C = dC; g.ldc = N; g.epilogue = 0;
+  g.splitk = K >= 256 ? 4 : 1; g.workspace = ws;
+  HIPCHK(c, launch_gemm(c->stream, g));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(C, dC, (long long)M * N * sizeof(float), hipMemcpyDeviceToHost));
+  hipFree(dA); hipFree(dB); hipFree(dC); hipFree(ws);
+  return VMC_OK;
+}
+
+}  // extern "C"

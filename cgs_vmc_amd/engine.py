@@ -1,0 +1,272 @@
+"""VmcEngine: numpy-facing wrapper over one vmc_ctx (one GPU) of libcgsvmc_hip.so.
+
+This is the only module that talks to the C ABI; wavefunctions / operators /
+graph_builders / training / evaluation dispatch their op handles to it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _hip
+
+
+def _fptr(a: Optional[np.ndarray]):
+  if a is None:
+    return None
+  assert a.dtype == np.float32 and a.flags['C_CONTIGUOUS']
+  return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _iptr(a: np.ndarray):
+  assert a.dtype == np.int32 and a.flags['C_CONTIGUOUS']
+  return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class VmcEngine:
+  """Owns the device state of one shard of Markov chains and one ansatz."""
+
+  def __init__(self, n_sites: int, batch_size: int, num_layers: int, layer_size: int,
+               nonlinearity: str = 'relu', output_activation: str = 'exp', device: int = 0,
+               chain_offset: int = 0, seed: int = 2024, stream: int = 0):
+    self._lib = _hip.load()
+    self._ctx = C.c_void_p()
+    for name, act in (('nonlinearity', nonlinearity), ('output_activation', output_activation)):
+      if act not in _hip.ACT_IDS:
+        raise ValueError('unknown {} {!r}'.format(name, act))
+    desc = _hip.VmcDesc(n_sites, batch_size, num_layers, layer_size,
+                        _hip.ACT_IDS[nonlinearity], _hip.ACT_IDS[output_activation], device,
+                        chain_offset, seed, stream or None)
+    rc = self._lib.vmc_create(C.byref(desc), C.byref(self._ctx))
+    if rc != _hip.VMC_OK:
+      msg = self._lib.vmc_last_error(None).decode()
+      self._ctx = C.c_void_p()
+      self._raise(rc, msg)
+    self.n_sites, self.batch_size = n_sites, batch_size
+    self.num_layers, self.layer_size = num_layers, layer_size
+    self.chain_offset, self.seed, self.device = chain_offset, seed, device
+    self.num_params = int(self._lib.vmc_num_params(n_sites, layer_size, num_layers))
+    self.n_bonds = 0
+
+  # ------------------------------------------------------------------ plumbing
+  @staticmethod
+  def _raise(rc, msg):
+    if rc == _hip.VMC_ERR_INVALID:
+      raise ValueError(msg)
+    if rc == _hip.VMC_ERR_UNSUPPORTED:
+      raise NotImplementedError(msg)
+    raise _hip.HipLibraryError('libcgsvmc_hip error {}: {}'.format(rc, msg))
+
+  def _check(self, rc):
+    if rc != _hip.VMC_OK:
+      self._raise(rc, self._lib.vmc_last_error(self._ctx).decode())
+
+  def close(self):
+    if getattr(self, '_ctx', None) is not None and self._ctx.value:
+      self._lib.vmc_destroy(self._ctx)
+      self._ctx = C.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  # ------------------------------------------------------------------ state
+  def set_bonds(self, bonds: Sequence[Tuple[int, int]], j_x, j_z):
+    ij = np.ascontiguousarray(np.asarray(bonds, dtype=np.int32).reshape(-1, 2))
+    nb = ij.shape[0]
+    jx = np.ascontiguousarray(np.broadcast_to(np.asarray(j_x, np.float32), (nb,)))
+    jz = np.ascontiguousarray(np.broadcast_to(np.asarray(j_z, np.float32), (nb,)))
+    self._check(self._lib.vmc_set_bonds(self._ctx, nb, _iptr(ij), _fptr(jx), _fptr(jz)))
+    self.n_bonds = nb
+
+  def set_params(self, theta: np.ndarray, which: int = _hip.VMC_PSI):
+    theta = np.ascontiguousarray(theta, dtype=np.float32).ravel()
+    if theta.size != self.num_params:
+      raise ValueError('expected {} parameters, got {}'.format(self.num_params, theta.size))
+    self._check(self._lib.vmc_set_params(self._ctx, which, _fptr(theta)))
+
+  def get_params(self, which: int = _hip.VMC_PSI) -> np.ndarray:
+    theta = np.empty(self.num_params, np.float32)
+    self._check(self._lib.vmc_get_params(self._ctx, which, _fptr(theta)))
+    return theta
+
+  def transfer_params(self):
+    self._check(self._lib.vmc_transfer_params(self._ctx))
+
+  def set_configs(self, configs: np.ndarray):
+    configs = np.ascontiguousarray(configs, dtype=np.float32)
+    if configs.shape != (self.batch_size, self.n_sites):
+      raise ValueError('Size of existing variable does not match.')
+    self._check(self._lib.vmc_set_configs(self._ctx, _fptr(configs)))
+
+  def get_configs(self) -> np.ndarray:
+    out = np.empty((self.batch_size, self.n_sites), np.float32)
+    self._check(self._lib.vmc_get_configs(self._ctx, _fptr(out)))
+    return out
+
+  def set_shift(self, shift: float, which: int = _hip.VMC_PSI):
+    self._check(self._lib.vmc_set_shift(self._ctx, which, float(shift)))
+
+  def get_shift(self, which: int = _hip.VMC_PSI) -> float:
+    v = C.c_float()
+    self._check(self._lib.vmc_get_shift(self._ctx, which, C.byref(v)))
+    return float(v.value)
+
+  # ------------------------------------------------------------------ hot path
+  def amplitude(self, configs: Optional[np.ndarray] = None, which: int = _hip.VMC_PSI):
+    """Returns (logit, psi) on `configs` [M,N] or on the engine's chains."""
+    if configs is None:
+      n = self.batch_size
+      cp = None
+    else:
+      configs = np.ascontiguousarray(configs, dtype=np.float32)
+      if configs.ndim != 2 or configs.shape[1] != self.n_sites:
+        raise ValueError('Input tensor has wrong shape.')
+      n = configs.shape[0]
+      cp = _fptr(configs)
+    logit = np.empty(n, np.float32)
+    psi = np.empty(n, np.float32)
+    self._check(self._lib.vmc_amplitude(self._ctx, which, cp, n, _fptr(logit), _fptr(psi)))
+    return logit, psi
+
+  def mc_steps(self, n_steps: int, want_accepted: bool = True) -> int:
+    acc = C.c_int64(0)
+    self._check(self._lib.vmc_mc_steps(self._ctx, int(n_steps),
+                                       C.byref(acc) if want_accepted else None))
+    return int(acc.value)
+
+  def mc_step_injected(self, i_up, i_dn, u) -> np.ndarray:
+    i_up = np.ascontiguousarray(i_up, np.int32)
+    i_dn = np.ascontiguousarray(i_dn, np.int32)
+    u = np.ascontiguousarray(u, np.float32)
+    mask = np.empty(self.batch_size, np.uint8)
+    self._check(self._lib.vmc_mc_step_injected(
+        self._ctx, _iptr(i_up), _iptr(i_dn), _fptr(u), mask.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return mask.astype(bool)
+
+  def debug_proposals(self, step: int):
+    i_up = np.empty(self.batch_size, np.int32)
+    i_dn = np.empty(self.batch_size, np.int32)
+    u = np.empty(self.batch_size, np.float32)
+    self._check(self._lib.vmc_debug_proposals(self._ctx, int(step), _iptr(i_up), _iptr(i_dn),
+                                              _fptr(u)))
+    return i_up, i_dn, u
+
+  @property
+  def step_counter(self) -> int:
+    v = C.c_uint64()
+    self._check(self._lib.vmc_get_step_counter(self._ctx, C.byref(v)))
+    return int(v.value)
+
+  @step_counter.setter
+  def step_counter(self, step: int):
+    self._check(self._lib.vmc_set_step_counter(self._ctx, int(step)))
+
+  def local_energy(self, which: int = _hip.VMC_PSI, want_eloc: bool = True):
+    """Returns (eloc[B] or None, mean)."""
+    eloc = np.empty(self.batch_size, np.float32) if want_eloc else None
+    mean = C.c_double()
+    self._check(self._lib.vmc_local_energy(self._ctx, which, _fptr(eloc), C.byref(mean)))
+    return eloc, float(mean.value)
+
+  def local_energy_terms(self, which: int = _hip.VMC_PSI):
+    diag = np.empty(self.batch_size, np.float32)
+    off = np.empty(self.batch_size, np.float32)
+    self._check(self._lib.vmc_local_energy_terms(self._ctx, which, _fptr(diag), _fptr(off)))
+    return diag, off
+
+  def last_connected_rows(self) -> int:
+    v = C.c_int64()
+    self._check(self._lib.vmc_last_connected_rows(self._ctx, C.byref(v)))
+    return int(v.value)
+
+  def accumulate(self, mode: int, beta: float = 0.0):
+    self._check(self._lib.vmc_accumulate(self._ctx, mode, float(beta)))
+
+  def reset_accumulators(self):
+    self._check(self._lib.vmc_reset_accumulators(self._ctx))
+
+  def accumulators_devptr(self) -> Tuple[int, int]:
+    p = C.c_void_p()
+    n = C.c_int64()
+    self._check(self._lib.vmc_accumulators_devptr(self._ctx, C.byref(p), C.byref(n)))
+    return int(p.value), int(n.value)
+
+  def get_accumulators(self) -> np.ndarray:
+    out = np.empty(2 * self.num_params + 8, np.float32)
+    self._check(self._lib.vmc_get_accumulators(self._ctx, _fptr(out)))
+    return out
+
+  def set_accumulators(self, acc: np.ndarray):
+    acc = np.ascontiguousarray(acc, np.float32)
+    assert acc.size == 2 * self.num_params + 8
+    self._check(self._lib.vmc_set_accumulators(self._ctx, _fptr(acc)))
+
+  def apply_adam(self, mode: int, lr: float, beta1: float = 0.9, beta2: float = 0.99,
+                 eps: float = 1e-8) -> float:
+    e = C.c_double()
+    self._check(self._lib.vmc_apply_adam(self._ctx, mode, lr, beta1, beta2, eps, C.byref(e)))
+    return float(e.value)
+
+  def get_gradient(self, mode: int) -> np.ndarray:
+    g = np.empty(self.num_params, np.float32)
+    self._check(self._lib.vmc_get_gradient(self._ctx, mode, _fptr(g)))
+    return g
+
+  def mean_energy(self) -> float:
+    e = C.c_double()
+    self._check(self._lib.vmc_mean_energy(self._ctx, C.byref(e)))
+    return float(e.value)
+
+  def get_adam_state(self):
+    m = np.empty(self.num_params, np.float32)
+    v = np.empty(self.num_params, np.float32)
+    t = C.c_int64()
+    self._check(self._lib.vmc_get_adam_state(self._ctx, _fptr(m), _fptr(v), C.byref(t)))
+    return m, v, int(t.value)
+
+  def set_adam_state(self, m, v, t):
+    m = np.ascontiguousarray(m, np.float32)
+    v = np.ascontiguousarray(v, np.float32)
+    self._check(self._lib.vmc_set_adam_state(self._ctx, _fptr(m), _fptr(v), int(t)))
+
+  def update_norm(self, max_value: float = 1e10):
+    self._check(self._lib.vmc_update_norm(self._ctx, float(max_value)))
+
+  # ------------------------------------------------------------------ timing / debug
+  def timing_enable(self, on: bool = True):
+    self._check(self._lib.vmc_timing_enable(self._ctx, int(on)))
+
+  def timing_reset(self):
+    self._check(self._lib.vmc_timing_reset(self._ctx))
+
+  def timing_get(self, name: str) -> Tuple[float, int]:
+    ms = C.c_double()
+    n = C.c_int64()
+    self._check(self._lib.vmc_timing_get(self._ctx, name.encode(), C.byref(ms), C.byref(n)))
+    return float(ms.value), int(n.value)
+
+  def synchronize(self):
+    self._check(self._lib.vmc_synchronize(self._ctx))
+
+  def debug_gemm(self, a: np.ndarray, b: np.ndarray, trans_a=False, trans_b=False) -> np.ndarray:
+    """C = op(A) op(B) through the library's MFMA GEMM (test hook)."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    if trans_a:
+      k, m = a.shape; sam, sak = 1, m
+    else:
+      m, k = a.shape; sam, sak = k, 1
+    if trans_b:
+      n, k2 = b.shape; sbk, sbn = 1, k2
+    else:
+      k2, n = b.shape; sbk, sbn = n, 1
+    assert k == k2
+    c = np.empty((m, n), np.float32)
+    self._check(self._lib.vmc_debug_gemm(self._ctx, m, n, k, _fptr(a), sam, sak, a.size, _fptr(b),
+                                         sbk, sbn, b.size, _fptr(c)))
+    return c

@@ -1,0 +1,164 @@
+/*
+ * cgsvmc.h -- C ABI of libcgsvmc_hip.so: the MI355X (gfx950) implementation of the
+ * batched VMC inner loop of ClarkResearchGroup/cgs-vmc.
+ *
+ * The reference has no FFI: its boundary is the Python object API plus
+ * tf.Session.run(op) on op handles.  Each entry point below is what a
+ * ctypes binding for one of those op handles / object methods calls; the reference
+ * interface it replaces is cited as file:line under /root/reference/cgs_vmc.
+ *
+ * Conventions: every function returns 0 on success or a negative vmc_status; the
+ * message is available from vmc_last_error().  The caller owns all host buffers; the
+ * library owns all device memory.  Calls are synchronous with respect to the host on
+ * return unless stated otherwise (they are stream-ordered internally).  One vmc_ctx per
+ * GPU; a ctx is not thread-safe; distinct ctxs are independent.
+ *
+ * Parameter vector order (wavefunctions.py:167-175, creation order of the snt.Linear
+ * variables of FullyConnectedNetwork, wavefunctions.py:345-349):
+ *   w_1[N,H] b_1[H] w_2[H,H] b_2[H] ... w_L[H,H] b_L[H] w_out[H,1] b_out[1],
+ * every matrix row-major w[in][out]; P = N*H + H + (L-1)*(H*H + H) + H + 1 floats.
+ */
+#ifndef CGSVMC_H_
+#define CGSVMC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vmc_ctx vmc_ctx;
+
+typedef enum {
+  VMC_OK = 0,
+  VMC_ERR_INVALID = -1,     /* bad argument (ValueError in the reference API)      */
+  VMC_ERR_UNSUPPORTED = -2, /* ansatz shape / activation without a HIP kernel       */
+  VMC_ERR_HIP = -3,         /* HIP runtime failure                                  */
+  VMC_ERR_STATE = -4        /* call order (e.g. accumulate before set_bonds)        */
+} vmc_status;
+
+/* which parameter set: psi is the trained wavefunction, omega its frozen supervisor
+ * copy (copy.deepcopy(wavefunction), training.py:660). */
+enum { VMC_PSI = 0, VMC_OMEGA = 1 };
+
+/* accumulate / apply modes (training.GROUND_STATE_OPTIMIZERS, training.py:913-917) */
+enum { VMC_MODE_ENERGY_GRADIENT = 0, VMC_MODE_LOG_OVERLAP_ITSWO = 1 };
+
+/* layers.NONLINEARITIES ids (layers.py:13-21); only the ones with kernels are accepted */
+enum { VMC_ACT_RELU = 0, VMC_ACT_EXP = 1, VMC_ACT_IDENTITY = 6 };
+
+typedef struct {
+  int32_t n_sites;           /* hparams.num_sites                (utils.py:98)       */
+  int32_t batch_size;        /* chains owned by THIS ctx         (utils.py:135)      */
+  int32_t num_layers;        /* hparams.num_fc_layers            (utils.py:104)      */
+  int32_t layer_size;        /* hparams.fc_layer_size            (utils.py:105)      */
+  int32_t nonlinearity;      /* VMC_ACT_RELU                                        */
+  int32_t output_activation; /* VMC_ACT_EXP                                         */
+  int32_t device;            /* HIP device ordinal                                   */
+  int32_t chain_offset;      /* global id of local chain 0 (multi-GPU sharding)      */
+  uint64_t seed;             /* Philox key                                           */
+  void* stream;              /* hipStream_t to launch on, or NULL for the null stream*/
+} vmc_desc;
+
+/* Number of parameters P for a given shape (no ctx needed). */
+int64_t vmc_num_params(int32_t n_sites, int32_t layer_size, int32_t num_layers);
+
+/* FullyConnectedNetwork.__init__ + graph_builders.get_configs: allocates everything.
+ * wavefunctions.py:331-353, graph_builders.py:92-125. */
+int vmc_create(const vmc_desc* desc, vmc_ctx** out);
+void vmc_destroy(vmc_ctx* ctx);
+const char* vmc_last_error(const vmc_ctx* ctx); /* ctx may be NULL: last create error */
+
+/* HeisenbergHamiltonian(bonds, j_x, j_z), operators.py:215-225.  j_x / j_z are
+ * per-bond arrays of length n_bonds (constant arrays reproduce the reference). */
+int vmc_set_bonds(vmc_ctx* ctx, int32_t n_bonds, const int32_t* ij /*[n_bonds][2]*/,
+                  const float* j_x, const float* j_z);
+
+/* Variable assignment / read-back (tf.train.Saver restore/save, run_training.py:134-146;
+ * module_transfer_ops, wavefunctions.py:300-325). theta has P floats. */
+int vmc_set_params(vmc_ctx* ctx, int which, const float* theta);
+int vmc_get_params(vmc_ctx* ctx, int which, float* theta);
+int vmc_transfer_params(vmc_ctx* ctx); /* psi -> omega: TrainOpsSWO.update_supervisor */
+
+/* The CONFIGS variable, graph_builders.py:92-125: [batch_size][n_sites] float32 +-1. */
+int vmc_set_configs(vmc_ctx* ctx, const float* configs);
+int vmc_get_configs(vmc_ctx* ctx, float* configs);
+
+/* exp_norm_shift (wavefunctions.py:206-232), per parameter set. */
+int vmc_set_shift(vmc_ctx* ctx, int which, float shift);
+int vmc_get_shift(vmc_ctx* ctx, int which, float* shift);
+
+/* Wavefunction.__call__ (wavefunctions.py:355-371) on `configs` ([n_rows][n_sites],
+ * host) or, when configs == NULL, on the ctx's chains (n_rows must be batch_size).
+ * Writes the pre-exp logit and/or psi = exp(logit - shift); either may be NULL. */
+int vmc_amplitude(vmc_ctx* ctx, int which, const float* configs, int64_t n_rows,
+                  float* logit, float* psi);
+
+/* n_steps x session.run(mc_step): graph_builders.py:38-89, driven by training.py:608-609
+ * and evaluation.py:138-145.  One launch; chain state stays on the GPU.  *accepted (may be
+ * NULL) receives the total acceptance_count (graph_builders.py:86). */
+int vmc_mc_steps(vmc_ctx* ctx, int64_t n_steps, int64_t* accepted);
+
+/* Test hook: one mc_step with externally supplied proposals: site to lower i_up, site to
+ * raise i_dn, acceptance uniform u (all [batch_size]); accept_mask [batch_size] out. */
+int vmc_mc_step_injected(vmc_ctx* ctx, const int32_t* i_up, const int32_t* i_dn,
+                         const float* u, uint8_t* accept_mask);
+
+/* Test hook: the proposals the sampler would draw at absolute step `step` for the
+ * current chains (graph_builders.py:59-65), without moving. */
+int vmc_debug_proposals(vmc_ctx* ctx, uint64_t step, int32_t* i_up, int32_t* i_dn, float* u);
+int vmc_get_step_counter(vmc_ctx* ctx, uint64_t* step);
+int vmc_set_step_counter(vmc_ctx* ctx, uint64_t step);
+
+/* HeisenbergHamiltonian.local_value (operators.py:249-259) of parameter set `which` on
+ * the ctx's chains: eloc [batch_size] (may be NULL), *mean = mean over the batch
+ * (evaluation.py:102).  diag/offdiag_over_psi (may be NULL) are the two terms of
+ * HeisenbergHamiltonian.build (operators.py:227-247) with the off-diagonal one already
+ * divided by psi. */
+int vmc_local_energy(vmc_ctx* ctx, int which, float* eloc, double* mean);
+int vmc_local_energy_terms(vmc_ctx* ctx, int which, float* diag, float* offdiag_over_psi);
+
+/* TrainOps.accumulate_gradients: training.py:539-558 (mode ENERGY_GRADIENT) or
+ * training.py:661-695 (mode LOG_OVERLAP_ITSWO, beta = hparams.time_evolution_beta). */
+int vmc_accumulate(vmc_ctx* ctx, int mode, float beta);
+/* TrainOps.reset_gradients: tf.variables_initializer(tf.local_variables()). */
+int vmc_reset_accumulators(vmc_ctx* ctx);
+/* Accumulator buffer: [g1 (P) | g2 (P) | e_total e_count r_total r_count g_count 0 0 0]
+ * = 2P+8 floats.  The device pointer is exposed so the host can all-reduce it in place
+ * (RCCL via torch.distributed); *n_floats = 2P+8. */
+int vmc_accumulators_devptr(vmc_ctx* ctx, void** dev_ptr, int64_t* n_floats);
+int vmc_get_accumulators(vmc_ctx* ctx, float* host /*[2P+8]*/);
+int vmc_set_accumulators(vmc_ctx* ctx, const float* host /*[2P+8]*/);
+
+/* TrainOps.apply_gradients: gradient formula (training.py:560-564 or 697-699) + TF1
+ * Adam (training.py:84-91).  *energy (may be NULL) = TrainOps.metrics / .energy. */
+int vmc_apply_adam(vmc_ctx* ctx, int mode, float lr, float beta1, float beta2, float eps,
+                   double* energy);
+int vmc_get_gradient(vmc_ctx* ctx, int mode, float* grad /*[P]*/);
+int vmc_mean_energy(vmc_ctx* ctx, double* energy);
+int vmc_get_adam_state(vmc_ctx* ctx, float* m, float* v, int64_t* t);
+int vmc_set_adam_state(vmc_ctx* ctx, const float* m, const float* v, int64_t t);
+
+/* Wavefunction.update_norm (wavefunctions.py:261-288) on psi(chains). */
+int vmc_update_norm(vmc_ctx* ctx, float max_value);
+
+/* Per-kernel HIP-event timing on the ctx's stream (bench.py's roofline leg).
+ * names: "sweep", "tail_eloc", "tail_amp", "z1", "bond_list", "eloc_reduce", "grad",
+ * "adam".  ms = summed elapsed, launches = number of timed launches. */
+int vmc_timing_enable(vmc_ctx* ctx, int on);
+int vmc_timing_reset(vmc_ctx* ctx);
+int vmc_timing_get(vmc_ctx* ctx, const char* name, double* ms, int64_t* launches);
+/* rows the last local-energy call actually evaluated (antiparallel bonds) */
+int vmc_last_connected_rows(vmc_ctx* ctx, int64_t* rows);
+int vmc_synchronize(vmc_ctx* ctx);
+
+/* Test hook: C[M,N] = op(A) op(B) through the library's fp32 MFMA GEMM
+ * (A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; host buffers). */
+int vmc_debug_gemm(vmc_ctx* ctx, int32_t M, int32_t N, int32_t K, const float* A, int64_t sam,
+                   int64_t sak, int64_t a_len, const float* B, int64_t sbk, int64_t sbn,
+                   int64_t b_len, float* C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGSVMC_H_ */
