@@ -1,0 +1,120 @@
+"""Chain sharding across GPUs (absent from the reference, which is
+single-process).
+
+Markov chains are independent given theta (graph_builders.py:57-88 has no cross-row op), so
+rank r owns chains [r*B/G, (r+1)*B/G) and the only exchange is a SUM all-reduce of the
+accumulator buffer [g1 | g2 | e_total e_count r_total r_count g_count ...] (2P+8 floats) once
+per optimizer step, plus scalar MAX (update_norm) and SUM (acceptance / evaluation mean).
+Collectives go through torch.distributed: backend 'nccl' is RCCL over xGMI on ROCm; 'gloo'
+is used by the CPU tests.  Every rank then applies the identical Adam step.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def _dist():
+  import torch.distributed as dist
+  return dist
+
+
+def is_distributed() -> bool:
+  try:
+    dist = _dist()
+    return dist.is_available() and dist.is_initialized()
+  except Exception:  # pylint: disable=broad-except
+    return False
+
+
+def world_size() -> int:
+  return _dist().get_world_size() if is_distributed() else 1
+
+
+def rank() -> int:
+  return _dist().get_rank() if is_distributed() else 0
+
+
+def local_rank() -> int:
+  return int(os.environ.get('LOCAL_RANK', '0')) if is_distributed() else 0
+
+
+def init_from_env(backend: str = 'nccl'):
+  """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* when WORLD_SIZE > 1."""
+  if int(os.environ.get('WORLD_SIZE', '1')) <= 1 or is_distributed():
+    return
+  import torch
+  dist = _dist()
+  if backend == 'nccl':
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+  dist.init_process_group(backend=backend)
+
+
+def shard(batch_size: int):
+  """(local_batch, chain_offset) of this rank for a global batch."""
+  g, r = world_size(), rank()
+  if batch_size % g != 0:
+    raise ValueError('batch_size %d is not divisible by world size %d' % (batch_size, g))
+  local = batch_size // g
+  return local, r * local
+
+
+class _DevArray:
+  """__cuda_array_interface__ view of library-owned device memory (zero copy)."""
+
+  def __init__(self, ptr: int, n: int):
+    self.__cuda_array_interface__ = {
+        'shape': (n,), 'typestr': '<f4', 'data': (ptr, False), 'version': 2, 'strides': None}
+
+
+def accumulator_tensor(engine):
+  """torch view (device memory of the engine) of the accumulator buffer."""
+  import torch
+  ptr, n = engine.accumulators_devptr()
+  return torch.as_tensor(_DevArray(ptr, n), device=torch.device('cuda', engine.device))
+
+
+def allreduce_accumulators(engine):
+  """In-place SUM all-reduce of the engine's accumulator buffer over all ranks."""
+  if world_size() == 1:
+    return
+  engine.synchronize()                 # the library's stream -> visible to the collective
+  t = accumulator_tensor(engine)
+  _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
+  import torch
+  torch.cuda.current_stream(t.device).synchronize()
+
+
+def allreduce_array(values: np.ndarray, op: str = 'sum') -> np.ndarray:
+  """All-reduce of a small host array (float64) with SUM or MAX."""
+  values = np.asarray(values, np.float64)
+  if world_size() == 1:
+    return values
+  import torch
+  dist = _dist()
+  dev = torch.device('cuda', local_rank()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+  t = torch.as_tensor(values, dtype=torch.float64, device=dev).clone()
+  dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 'sum' else dist.ReduceOp.MAX)
+  return t.cpu().numpy()
+
+
+def allreduce_sum(value: float) -> float:
+  return float(allreduce_array(np.array([value]), 'sum')[0])
+
+
+def allreduce_max(value: float) -> float:
+  return float(allreduce_array(np.array([value]), 'max')[0])
+
+
+def reduce_accumulators_host(acc: np.ndarray) -> np.ndarray:
+  """SUM all-reduce of a host copy of an accumulator buffer (any backend; used by the gloo
+  tests and as the generic path)."""
+  if world_size() == 1:
+    return acc
+  import torch
+  dist = _dist()
+  dev = torch.device('cuda', local_rank()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+  t = torch.as_tensor(np.ascontiguousarray(acc, np.float32), device=dev).clone()
+  dist.all_reduce(t, op=dist.ReduceOp.SUM)
+  return t.cpu().numpy()

@@ -1,0 +1,360 @@
+"""Wavefunction interface and the fully-connected ansatz (mirror of
+cgs_vmc/wavefunctions.py, hot-path scope: SURVEY.md 8a rows a6-a10).
+
+A `Wavefunction` is a host-side description (shape, activations, parameter vector).  The
+arithmetic runs in libcgsvmc_hip.so: applying a wavefunction to the CONFIGS variable of
+graph_builders binds it to that variable's `VmcEngine` as parameter set psi (the first
+wavefunction bound) or omega (its deep copy, the LogOverlapITSWO supervisor).
+"""
+from __future__ import annotations
+
+import copy
+import inspect
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from . import _hip
+from . import layers
+from . import session as session_lib
+
+_name_counts: Dict[str, int] = {}
+
+
+def _unique_name(name: str) -> str:
+  """Sonnet module name uniquification: name, name_1, name_2, ..."""
+  n = _name_counts.get(name, 0)
+  _name_counts[name] = n + 1
+  return name if n == 0 else '%s_%d' % (name, n)
+
+
+def reset_name_scope():
+  _name_counts.clear()
+
+
+class Wavefunction:
+  """Wavefunction interface (wavefunctions.py:21-297)."""
+
+  def __init__(self, name: str = 'wavefunction'):
+    self._name = name
+    self._unique_name = _unique_name(name)
+    self._sub_wavefunctions: List['Wavefunction'] = []
+    self._exp_norm_shift = None
+    self._engine = None
+    self._which = None
+
+  # -- graph connection ----------------------------------------------------
+  def __call__(self, inputs) -> session_lib.Tensor:
+    return self._build(inputs)
+
+  def _build(self, inputs):
+    raise NotImplementedError
+
+  def __add__(self, other):
+    raise NotImplementedError('sum/diff/prod composites are outside the MI355X hot path '
+                              '(SURVEY.md 2: composites OUT OF SCOPE)')
+
+  __mul__ = __add__
+  __sub__ = __add__
+
+  def get_trainable_variables(self) -> List[session_lib.Variable]:
+    """wavefunctions.py:167-175: own variables in creation order, then sub-wavefunctions'."""
+    variables = list(self._own_variables())
+    for sub in self._sub_wavefunctions:
+      variables += sub.get_trainable_variables()
+    return variables
+
+  def _own_variables(self):
+    return []
+
+  def __deepcopy__(self, memo: Dict[int, Any]) -> 'Wavefunction':
+    """wavefunctions.py:177-204: same constructor arguments, fresh variables, name dc_<name>."""
+    id_self = id(self)
+    _copy = memo.get(id_self)
+    if _copy is not None:
+      return _copy
+    init_args = inspect.getfullargspec(self.__init__)[0]
+    init_args.remove('self')
+    init_args.remove('name')
+    init_values = {arg: copy.deepcopy(getattr(self, '_{}'.format(arg)), memo) for arg in init_args}
+    init_values['name'] = 'dc_{}'.format(getattr(self, '_unique_name'))
+    _copy = type(self)(**init_values)
+    memo[id_self] = _copy
+    return _copy
+
+  # -- normalisation -------------------------------------------------------
+  def add_exp_normalization(self, initial_exp_norm_shift: float = -10.):
+    """wavefunctions.py:206-232: non-trainable scalar shift, psi = exp(logit - shift)."""
+    self._exp_norm_shift = np.float32(initial_exp_norm_shift)
+
+  def normalize_batch(self, batch_of_amplitudes, max_value: float = 1e10):
+    """wavefunctions.py:234-259."""
+    if self._exp_norm_shift is None:
+      return None
+
+    def run():
+      psi = np.asarray(batch_of_amplitudes._run())
+      from . import parallel
+      log_max = np.log(parallel.allreduce_max(float(np.max(psi))))
+      self._set_shift(np.float32(self._get_shift() + (log_max - np.log(max_value))))
+    return session_lib.Op(run, 'normalize_batch')
+
+  def update_norm(self, batch_of_amplitudes, max_value: float = 1e10):
+    """wavefunctions.py:261-288."""
+    if self._exp_norm_shift is None:
+      return None
+    return session_lib.Op(lambda: self._update_norm(batch_of_amplitudes, max_value),
+                          'update_norm')
+
+  def _update_norm(self, batch_of_amplitudes, max_value):
+    raise NotImplementedError
+
+  def _get_shift(self):
+    return self._exp_norm_shift
+
+  def _set_shift(self, value):
+    self._exp_norm_shift = np.float32(value)
+
+  @classmethod
+  def from_hparams(cls, hparams, name: str = '') -> 'Wavefunction':
+    raise NotImplementedError
+
+
+def module_transfer_ops(source_module: Wavefunction, target_module: Wavefunction) -> session_lib.Op:
+  """wavefunctions.py:300-325: assign every trainable variable of source to target."""
+  def run():
+    if (source_module._engine is not None and source_module._engine is target_module._engine
+        and source_module._which == _hip.VMC_PSI and target_module._which == _hip.VMC_OMEGA):
+      source_module._engine.transfer_params()          # device-to-device
+      return
+    src = source_module.get_trainable_variables()
+    dst = target_module.get_trainable_variables()
+    for s, t in zip(src, dst):
+      t.load(s.eval())
+  return session_lib.Op(run, 'module_transfer')
+
+
+class FullyConnectedNetwork(Wavefunction):
+  """[Linear(layer_size), nonlinearity] x num_layers -> Linear(1) -> squeeze ->
+  (- exp_norm_shift) -> exp   (wavefunctions.py:328-388)."""
+
+  def __init__(self, num_layers: int, layer_size: int,
+               nonlinearity=layers.NONLINEARITIES['relu'],
+               output_activation=layers.NONLINEARITIES['exp'],
+               name: str = 'fully_connected_network'):
+    super(FullyConnectedNetwork, self).__init__(name=name)
+    self._num_layers = num_layers
+    self._layer_size = layer_size
+    self._nonlinearity = nonlinearity
+    self._output_activation = output_activation
+    if output_activation == layers.NONLINEARITIES['exp']:
+      self.add_exp_normalization()
+    self._n_sites: Optional[int] = None
+    self._theta: Optional[np.ndarray] = None     # host copy until bound to an engine
+    session_lib.get_default_graph().global_initializers.append(self._maybe_initialize)
+
+  # -- parameters ----------------------------------------------------------
+  def _shapes(self):
+    shapes, names = [], []
+    fan_in = self._n_sites
+    for l in range(self._num_layers + 1):
+      out = self._layer_size if l < self._num_layers else 1
+      lin = 'linear' if l == 0 else 'linear_%d' % l
+      names += ['%s/%s/w' % (self._unique_name, lin), '%s/%s/b' % (self._unique_name, lin)]
+      shapes += [(fan_in, out), (out,)]
+      fan_in = out
+    return names, shapes
+
+  @property
+  def num_params(self) -> int:
+    return int(sum(int(np.prod(s)) for s in self._shapes()[1]))
+
+  def _maybe_initialize(self):
+    if self._n_sites is not None and self._get_theta(allow_none=True) is None:
+      self.initialize()
+
+  def initialize(self, seed=None):
+    """snt.Linear defaults: w ~ truncated normal(sigma = 1/sqrt(fan_in)), b = 0."""
+    if self._n_sites is None:
+      raise ValueError('wavefunction is not connected to inputs yet')
+    rng = np.random.default_rng(seed)
+    parts = []
+    for shp in self._shapes()[1]:
+      if len(shp) == 2:
+        w = rng.standard_normal(shp)
+        bad = np.abs(w) > 2
+        while bad.any():
+          w[bad] = rng.standard_normal(int(bad.sum()))
+          bad = np.abs(w) > 2
+        parts.append((w / np.sqrt(shp[0])).ravel())
+      else:
+        parts.append(np.zeros(shp).ravel())
+    self._set_theta(np.concatenate(parts).astype(np.float32))
+
+  def _get_theta(self, allow_none=False):
+    if self._engine is not None and self._theta is None:
+      return self._engine.get_params(self._which)
+    if self._theta is None and not allow_none:
+      raise ValueError('Attempting to use uninitialized variables of %s' % self._unique_name)
+    return self._theta
+
+  def _set_theta(self, theta):
+    theta = np.ascontiguousarray(theta, np.float32)
+    if self._engine is not None:
+      self._engine.set_params(theta, self._which)
+      self._theta = None          # the device copy is authoritative from now on
+    else:
+      self._theta = theta
+
+  def _own_variables(self):
+    if self._n_sites is None:
+      raise ValueError('wavefunction %s has no variables before it is connected to inputs'
+                       % self._unique_name)
+    names, shapes = self._shapes()
+    out, off = [], 0
+    for name, shp in zip(names, shapes):
+      n = int(np.prod(shp))
+
+      def getter(off=off, n=n):
+        return self._get_theta()[off:off + n]
+
+      def setter(value, off=off, n=n):
+        theta = self._get_theta(allow_none=True)
+        if theta is None:
+          theta = np.zeros(self.num_params, np.float32)
+        theta = theta.copy()
+        theta[off:off + n] = np.asarray(value, np.float32).ravel()
+        self._set_theta(theta)
+
+      out.append(session_lib.Variable(name, shp, getter, setter, trainable=True))
+      off += n
+    return out
+
+  # -- engine binding ------------------------------------------------------
+  def _bind(self, configs_var):
+    """Connects this ansatz to the engine that owns `configs_var`."""
+    n_sites = configs_var.shape[1]
+    if self._n_sites is not None and self._n_sites != n_sites:
+      raise ValueError('Input tensor has wrong shape.')
+    self._n_sites = n_sites
+    engine = configs_var._get_engine(self)
+    if self._engine is engine:
+      return engine
+    if self._engine is not None:
+      raise ValueError('wavefunction %s is already bound to another CONFIGS variable'
+                       % self._unique_name)
+    which = configs_var._claim_slot(self)
+    host_theta = self._theta
+    self._engine, self._which = engine, which
+    if host_theta is not None:
+      engine.set_params(host_theta, which)
+      self._theta = None
+    if self._exp_norm_shift is not None:
+      engine.set_shift(float(self._exp_norm_shift), which)
+    return engine
+
+  def _get_shift(self):
+    if self._engine is not None:
+      return np.float32(self._engine.get_shift(self._which))
+    return self._exp_norm_shift
+
+  def _set_shift(self, value):
+    self._exp_norm_shift = np.float32(value)
+    if self._engine is not None:
+      self._engine.set_shift(float(value), self._which)
+
+  def _build(self, inputs) -> session_lib.Tensor:
+    """wavefunctions.py:355-371."""
+    from . import graph_builders
+    if isinstance(inputs, graph_builders.ConfigsVariable):
+      engine = self._bind(inputs)
+      return AmplitudeTensor(self, engine, None)
+    arr = np.asarray(inputs, np.float32)
+    if arr.ndim != 2 or (self._n_sites is not None and arr.shape[1] != self._n_sites):
+      raise ValueError('Input tensor has wrong shape.')
+    if self._engine is None:
+      raise ValueError('apply the wavefunction to the CONFIGS variable first '
+                       '(graph_builders.get_configs) so that it is bound to a GPU engine')
+    return AmplitudeTensor(self, self._engine, arr)
+
+  def _update_norm(self, batch_of_amplitudes, max_value):
+    from . import parallel
+    if (isinstance(batch_of_amplitudes, AmplitudeTensor) and batch_of_amplitudes.configs is None
+        and batch_of_amplitudes.wavefunction is self and parallel.world_size() == 1):
+      self._engine.update_norm(max_value)        # max-reduce on the GPU
+      return
+    psi = np.asarray(batch_of_amplitudes._run())
+    with np.errstate(divide='ignore'):
+      log_max = np.log(np.float32(parallel.allreduce_max(float(np.max(psi)))))
+    max_log = np.log(np.float32(max_value))
+    if log_max > max_log:
+      self._set_shift(np.float32(self._get_shift() + (log_max - max_log)))
+
+  @classmethod
+  def from_hparams(cls, hparams, name: str = '') -> 'Wavefunction':
+    """wavefunctions.py:373-388."""
+    fcnn_params = {
+        'num_layers': hparams.num_fc_layers,
+        'layer_size': hparams.fc_layer_size,
+        'output_activation': layers.NONLINEARITIES[hparams.output_activation],
+        'nonlinearity': layers.NONLINEARITIES[hparams.nonlinearity],
+    }
+    if name:
+      fcnn_params['name'] = name
+    return cls(**fcnn_params)
+
+
+class AmplitudeTensor(session_lib.Tensor):
+  """psi = wavefunction(inputs); evaluates to a float32 array [rows]."""
+
+  def __init__(self, wavefunction, engine, configs):
+    self.wavefunction = wavefunction
+    self.engine = engine
+    self.configs = configs
+    super(AmplitudeTensor, self).__init__(self._value, 'psi')
+
+  def _value(self):
+    return self.engine.amplitude(self.configs, self.wavefunction._which)[1]
+
+  def logits(self):
+    return self.engine.amplitude(self.configs, self.wavefunction._which)[0]
+
+
+class _OutOfScope(Wavefunction):
+  """Registered ansatz names whose kernels are not part of the MI355X hot path."""
+  _kind = ''
+
+  @classmethod
+  def from_hparams(cls, hparams, name: str = ''):
+    raise NotImplementedError(
+        "wavefunction_type '%s' is outside the MI355X hot path (SURVEY.md 2); only "
+        "'fully_connected' has HIP kernels" % cls._kind)
+
+
+def _stub(kind):
+  return type('OutOfScope_' + kind, (_OutOfScope,), {'_kind': kind})
+
+
+def build_wavefunction(hparams) -> Wavefunction:
+  """wavefunctions.py:1157-1196."""
+  wavefunction_type = hparams.wavefunction_type
+  if wavefunction_type in WAVEFUNCTION_TYPES:
+    return WAVEFUNCTION_TYPES[wavefunction_type].from_hparams(hparams)
+  if hparams.wavefunction_type in ('sum', 'diff', 'prod'):
+    raise NotImplementedError('composite wavefunctions are outside the MI355X hot path')
+  raise ValueError('Provided wavefunction_type is not registered.')
+
+
+WAVEFUNCTION_TYPES = {
+    'fully_connected': FullyConnectedNetwork,
+    'rbm': _stub('rbm'),
+    'conv_1d': _stub('conv_1d'),
+    'conv_2d': _stub('conv_2d'),
+    'mps': _stub('mps'),
+    'pbdg': _stub('pbdg'),
+    'fully_connected_nnb': _stub('fully_connected_nnb'),
+    'res_net_1d': _stub('res_net_1d'),
+    'res_net_2d': _stub('res_net_2d'),
+    'ed_vector': _stub('ed_vector'),
+    'gnn': _stub('gnn'),
+}
