@@ -1,0 +1,80 @@
+"""Evaluation of optimized wavefunctions (mirror of cgs_vmc/evaluation.py, hot-path scope:
+MonteCarloOperatorEvaluator)."""
+from __future__ import annotations
+
+from typing import Any, Dict, List, NamedTuple
+
+from . import graph_builders
+from . import operators
+from . import session as session_lib
+from .training import _run_mc_steps
+
+EvalOps = NamedTuple(
+    'EvaluationOps', [
+        ('value', session_lib.Op),
+        ('mc_step', session_lib.Op),
+        ('acceptance_rate', session_lib.Op),
+        ('placeholder_input', session_lib.Op),
+        ('wavefunction_value', session_lib.Op),
+    ]
+)
+"""Named tuple of tensors representing evaluation components."""
+
+
+class WavefunctionEvaluator():
+  """Parents class for wavefunction evaluators (evaluation.py:27-71)."""
+
+  def build_eval_ops(self, wavefunction, operator, hparams, shared_resources):
+    raise NotImplementedError
+
+  def run_evaluation(self, eval_ops, session, hparams, epoch_num: int) -> Any:
+    raise NotImplementedError
+
+
+class MonteCarloOperatorEvaluator(WavefunctionEvaluator):
+  """Operator evaluation by running MCMC (evaluation.py:74-152)."""
+
+  def build_eval_ops(self, wavefunction, operator, hparams,
+                     shared_resources: Dict[graph_builders.ResourceName, Any]) -> EvalOps:
+    """evaluation.py:77-110."""
+    batch_size = hparams.batch_size
+    n_sites = hparams.num_sites
+
+    configs = graph_builders.get_configs(shared_resources, batch_size, n_sites)
+    mc_step, acc_rate = graph_builders.get_monte_carlo_sampling(
+        shared_resources, configs, wavefunction)
+
+    value = operators.reduce_mean(operator.local_value(wavefunction, configs))
+    eval_ops = EvalOps(
+        value=value,
+        mc_step=mc_step,
+        acceptance_rate=acc_rate,
+        placeholder_input=None,
+        wavefunction_value=None,
+    )
+    return eval_ops
+
+  def run_evaluation(self, eval_ops: EvalOps, session, hparams, epoch_num: int) -> List[float]:
+    """evaluation.py:113-152: equilibrate, then alternate batch-mean local value and
+    num_monte_carlo_sweeps sweeps; returns num_evaluation_samples batch means."""
+    value = eval_ops.value
+    mc_step = eval_ops.mc_step
+    num_equilibration_sweeps = hparams.num_equilibration_sweeps
+    num_evaluation_samples = hparams.num_evaluation_samples
+    num_mc_steps = hparams.num_monte_carlo_sweeps * hparams.num_sites
+    _run_mc_steps(session, mc_step, num_equilibration_sweeps * hparams.num_sites)
+    values = []
+    self.acceptance_count = 0
+    for _ in range(0, num_evaluation_samples):
+      values.append(session.run(value))
+      _run_mc_steps(session, mc_step, num_mc_steps)
+      self.acceptance_count += getattr(mc_step, 'last_accepted', 0)
+    return values
+
+
+class VectorWavefunctionEvaluator(WavefunctionEvaluator):
+  """evaluation.py:155-246: dumps psi over a basis file.  Offline tool outside the hot path
+  (SURVEY.md 2); `Wavefunction.__call__` on an array gives the same amplitudes."""
+
+  def build_eval_ops(self, wavefunction, operator, hparams, shared_resources):
+    raise NotImplementedError('VectorWavefunctionEvaluator is outside the MI355X hot path')

@@ -82,6 +82,9 @@ def allreduce_accumulators(engine):
   engine.synchronize()                 # the library's stream -> visible to the collective
   t = accumulator_tensor(engine)
   _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
+  # mean_tensor's count is the number of accumulate CALLS (training.py:550-553), which every
+  # rank made in lock-step: undo the sum so that sharded == unsharded gradients
+  t[t.numel() - 4] /= world_size()
   import torch
   torch.cuda.current_stream(t.device).synchronize()
 
@@ -117,4 +120,5 @@ def reduce_accumulators_host(acc: np.ndarray) -> np.ndarray:
   dev = torch.device('cuda', local_rank()) if dist.get_backend() == 'nccl' else torch.device('cpu')
   t = torch.as_tensor(np.ascontiguousarray(acc, np.float32), device=dev).clone()
   dist.all_reduce(t, op=dist.ReduceOp.SUM)
+  t[t.numel() - 4] /= world_size()      # g_count: calls, not calls x ranks (see above)
   return t.cpu().numpy()

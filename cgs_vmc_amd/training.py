@@ -1,0 +1,306 @@
+"""Ground-state wavefunction optimizers (mirror of cgs_vmc/training.py, hot-path scope:
+EnergyGradientOptimizer and LogOverlapImaginaryTimeSWO).
+
+`build_opt_ops` returns the same NamedTuples of op handles as the reference; each handle is
+one call into libcgsvmc_hip.so (session.py).  `run_optimization_epoch` issues the same ops
+in the same order and count as training.py:589-623 / 731-763, except that the
+`num_sites * sweeps` consecutive `mc_step` runs go to the GPU as ONE persistent-kernel
+launch (`mc_step.run_many(n)`), which is the same Markov chain.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, NamedTuple
+
+import numpy as np
+
+from . import _hip
+from . import graph_builders
+from . import operators
+from . import parallel
+from . import session as session_lib
+from . import wavefunctions
+
+TrainOpsTraditional = NamedTuple(
+    'TrainingOpsTraditional', [
+        ('accumulate_gradients', session_lib.Op),
+        ('apply_gradients', session_lib.Op),
+        ('reset_gradients', session_lib.Op),
+        ('mc_step', session_lib.Op),
+        ('acc_rate', session_lib.Op),
+        ('metrics', session_lib.Op),
+        ('epoch_increment', session_lib.Op),
+        ('update_wf_norm', session_lib.Op),
+    ]
+)
+"""Organizes operations used to execute a training epoch traditional methods."""
+
+TrainOpsSWO = NamedTuple(
+    'TrainingOpsSWO', [
+        ('train_step', session_lib.Op),
+        ('accumulate_gradients', session_lib.Op),
+        ('apply_gradients', session_lib.Op),
+        ('reset_gradients', session_lib.Op),
+        ('mc_step', session_lib.Op),
+        ('acc_rate', session_lib.Op),
+        ('metrics', session_lib.Op),
+        ('energy', session_lib.Op),
+        ('update_supervisor', session_lib.Op),
+        ('update_normalization', session_lib.Op),
+        ('epoch_increment', session_lib.Op),
+        ('update_wf_norm', session_lib.Op),
+    ]
+)
+"""Organizes operations used by Supervised Wavefunction Optimizer SWO."""
+
+
+def piecewise_constant(x, boundaries, values):
+  """tf.train.piecewise_constant: values[0] if x <= b[0], values[i] if b[i-1] < x <= b[i],
+  values[-1] if x > b[-1]."""
+  if len(values) != len(boundaries) + 1:
+    raise ValueError('The length of boundaries should be 1 less than the length of values')
+  for b, v in zip(boundaries, values):
+    if x <= b:
+      return v
+  return values[-1]
+
+
+class AdamOptimizer:
+  """tf.train.AdamOptimizer(learning_rate, beta2=...) semantics: beta1 = 0.9, epsilon = 1e-8,
+  lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t), theta -= lr_t m / (sqrt(v) + epsilon)."""
+
+  def __init__(self, learning_rate_fn, beta1=0.9, beta2=0.999, epsilon=1e-8):
+    self._lr = learning_rate_fn
+    self.beta1, self.beta2, self.epsilon = beta1, beta2, epsilon
+
+  def learning_rate(self) -> float:
+    return float(self._lr())
+
+
+def _unsupported_optimizer(name):
+  def ctor(*args, **kwargs):
+    # training.py:91 passes beta2= to every optimizer class; in the reference this raises
+    # TypeError for everything but Adam (defect B2).  Same outcome here.
+    raise TypeError("__init__() got an unexpected keyword argument 'beta2' "
+                    "(optimizer '%s'; only 'adam' is usable, as in the reference)" % name)
+  return ctor
+
+
+OPTIMIZERS = {
+    'adam': AdamOptimizer,
+    'gradient': _unsupported_optimizer('gradient'),
+    'rms_prop': _unsupported_optimizer('rms_prop'),
+    'momentum': _unsupported_optimizer('momentum'),
+}
+
+
+def create_sgd_optimizer(hparams):
+  """Creates an optimizer as specified in hparams (training.py:76-91)."""
+  num_epochs = graph_builders.get_or_create_num_epochs()
+  learning_rates = list(hparams.learning_rates)
+  learning_rate_stops = list(hparams.learning_rate_stops)
+  learning_rate = lambda: piecewise_constant(num_epochs.value, learning_rate_stops, learning_rates)
+  return OPTIMIZERS[hparams.optimizer](learning_rate, beta2=hparams.beta2)
+
+
+class WavefunctionOptimizer():
+  """Parents class for ground state wavefunction optimizers (training.py:94-132)."""
+
+  def build_opt_ops(self, wavefunction, hamiltonian, hparams, shared_resources) -> NamedTuple:
+    raise NotImplementedError
+
+  def run_optimization_epoch(self, train_ops, session, hparams, epoch_number: int = 0):
+    raise NotImplementedError
+
+
+def _run_mc_steps(session, mc_step, n_steps):
+  """`for _ in range(n_steps): session.run(mc_step)` as one launch when possible."""
+  if n_steps <= 0:
+    return
+  if hasattr(mc_step, 'run_many'):
+    mc_step.run_many(n_steps)
+  else:
+    for _ in range(n_steps):
+      session.run(mc_step)
+
+
+class _AccumulatorState:
+  """The tf.metrics local variables of one optimizer graph, resident on the GPU."""
+
+  def __init__(self, engine):
+    self.engine = engine
+    self.reduced = False      # accumulators already summed over ranks
+    session_lib.get_default_graph().local_initializers.append(self.reset)
+
+  def reset(self):
+    self.engine.reset_accumulators()
+    self.reduced = False
+
+  def ensure_reduced(self):
+    if not self.reduced and parallel.world_size() > 1:
+      parallel.allreduce_accumulators(self.engine)
+    self.reduced = True
+
+
+def _common_ops(wavefunction, hamiltonian, hparams, shared_resources, mode):
+  batch_size = hparams.batch_size
+  n_sites = hparams.num_sites
+  configs = graph_builders.get_configs(shared_resources, batch_size, n_sites)
+  mc_step, acc_rate = graph_builders.get_monte_carlo_sampling(
+      shared_resources, configs, wavefunction)
+  engine = wavefunction._bind(configs)
+  configs._ensure_hamiltonian(hamiltonian)
+  psi = wavefunction(configs)
+  update_wf_norm = wavefunction.update_norm(psi)
+  state = _AccumulatorState(engine)
+  optimizer = create_sgd_optimizer(hparams)
+  beta = float(getattr(hparams, 'time_evolution_beta', 0.0))
+
+  def accumulate():
+    configs._ensure_hamiltonian(hamiltonian)
+    if state.reduced:
+      raise RuntimeError('accumulate_gradients after the accumulators were all-reduced; run '
+                         'reset_gradients first')
+    engine.accumulate(mode, beta)
+
+  def apply():
+    state.ensure_reduced()
+    engine.apply_adam(mode, optimizer.learning_rate(), optimizer.beta1, optimizer.beta2,
+                      optimizer.epsilon)
+
+  def mean_energy():
+    state.ensure_reduced()
+    return np.float32(engine.mean_energy())
+
+  num_epochs = graph_builders.get_or_create_num_epochs()
+
+  def increment():
+    num_epochs.value += 1
+    return num_epochs.value
+
+  return dict(
+      configs=configs, engine=engine,
+      accumulate_gradients=session_lib.Op(accumulate, 'accumulate_gradients'),
+      apply_gradients=session_lib.Op(apply, 'apply_gradients'),
+      reset_gradients=session_lib.Op(state.reset, 'reset_gradients'),
+      mc_step=mc_step, acc_rate=acc_rate,
+      mean_energy=session_lib.Tensor(mean_energy, 'mean_energy'),
+      epoch_increment=session_lib.Op(increment, 'epoch_increment'),
+      update_wf_norm=update_wf_norm,
+  )
+
+
+class EnergyGradientOptimizer(WavefunctionOptimizer):
+  """Wave-function optimization based on the reduced-variance energy gradient
+  (training.py:506-623)."""
+
+  def build_opt_ops(self, wavefunction, hamiltonian, hparams, shared_resources) -> NamedTuple:
+    """training.py:513-586.  accumulate_gradients adds sum_b O_k, sum_b E_b O_k (one
+    mean_tensor update each) and sum_b E_b; apply_gradients feeds
+    mean(E O) - mean(E) mean(O) to Adam."""
+    ops = _common_ops(wavefunction, hamiltonian, hparams, shared_resources,
+                      _hip.VMC_MODE_ENERGY_GRADIENT)
+    return TrainOpsTraditional(
+        accumulate_gradients=ops['accumulate_gradients'],
+        apply_gradients=ops['apply_gradients'],
+        reset_gradients=ops['reset_gradients'],
+        mc_step=ops['mc_step'],
+        acc_rate=ops['acc_rate'],
+        metrics=ops['mean_energy'],
+        epoch_increment=ops['epoch_increment'],
+        update_wf_norm=ops['update_wf_norm'],
+    )
+
+  def run_optimization_epoch(self, train_ops, session, hparams, epoch_number: int = 0
+                             ) -> np.float32:
+    """training.py:589-623."""
+    _run_mc_steps(session, train_ops.mc_step,
+                  hparams.num_equilibration_sweeps * hparams.num_sites)
+
+    if train_ops.update_wf_norm is not None:
+      session.run(train_ops.update_wf_norm)
+    session.run(train_ops.reset_gradients)
+    for _ in range(hparams.num_batches_per_epoch):
+      session.run(train_ops.accumulate_gradients)
+      _run_mc_steps(session, train_ops.mc_step,
+                    hparams.num_monte_carlo_sweeps * hparams.num_sites)
+
+    session.run(train_ops.apply_gradients)
+    energy = session.run(train_ops.metrics)
+    session.run(train_ops.reset_gradients)
+    session.run(train_ops.epoch_increment)
+    return energy
+
+
+class LogOverlapImaginaryTimeSWO(WavefunctionOptimizer):
+  """Imaginary-time SWO based on the log-overlap gradient formula (training.py:626-778)."""
+
+  def build_opt_ops(self, wavefunction, hamiltonian, hparams, shared_resources) -> NamedTuple:
+    """training.py:634-729.  The supervisor omega = copy.deepcopy(wavefunction) is the
+    engine's second parameter set; update_supervisor is a device-to-device copy."""
+    batch_size = hparams.batch_size
+    n_sites = hparams.num_sites
+    configs = graph_builders.get_configs(shared_resources, batch_size, n_sites)
+    # bind psi first so that it owns the sampling slot, then the supervisor copy
+    wavefunction._bind(configs)
+    wf_omega = copy.deepcopy(wavefunction)
+    wf_omega._bind(configs)
+    ops = _common_ops(wavefunction, hamiltonian, hparams, shared_resources,
+                      _hip.VMC_MODE_LOG_OVERLAP_ITSWO)
+    update_network = wavefunctions.module_transfer_ops(wavefunction, wf_omega)
+    self._wf_omega = wf_omega
+    return TrainOpsSWO(
+        train_step=None,
+        accumulate_gradients=ops['accumulate_gradients'],
+        apply_gradients=ops['apply_gradients'],
+        reset_gradients=ops['reset_gradients'],
+        mc_step=ops['mc_step'],
+        acc_rate=ops['acc_rate'],
+        metrics=None,
+        energy=ops['mean_energy'],
+        update_supervisor=update_network,
+        update_normalization=None,
+        epoch_increment=ops['epoch_increment'],
+        update_wf_norm=ops['update_wf_norm'],
+    )
+
+  def run_optimization_epoch(self, train_ops, session, hparams, epoch_number: int = 0
+                             ) -> np.float32:
+    """training.py:731-778."""
+    _run_mc_steps(session, train_ops.mc_step,
+                  hparams.num_equilibration_sweeps * hparams.num_sites)
+
+    if train_ops.update_wf_norm is not None:
+      session.run(train_ops.update_wf_norm)
+    session.run(train_ops.update_supervisor)
+    for _ in range(hparams.num_batches_per_epoch):
+      _run_mc_steps(session, train_ops.mc_step,
+                    hparams.num_monte_carlo_sweeps * hparams.num_sites)
+      session.run(train_ops.reset_gradients)
+      session.run(train_ops.accumulate_gradients)
+      session.run(train_ops.apply_gradients)
+    session.run(train_ops.epoch_increment)
+    energy = session.run(train_ops.energy)
+    return energy
+
+
+class ImaginaryTimeSWO(WavefunctionOptimizer):
+  """training.py:781-910.  In the reference `build_opt_ops` always raises AttributeError
+  (hparams.time_evolution_befta, training.py:812: defect B1), so there is no behaviour to
+  match; the same exception type is raised here."""
+
+  def build_opt_ops(self, wavefunction, hamiltonian, hparams, shared_resources):
+    raise AttributeError("'HParams' object has no attribute 'time_evolution_befta' "
+                         "(the reference's ITSWO is broken, training.py:812; use "
+                         "EnergyGradient or LogOverlapITSWO)")
+
+
+GROUND_STATE_OPTIMIZERS = {
+    'EnergyGradient': EnergyGradientOptimizer,
+    'LogOverlapITSWO': LogOverlapImaginaryTimeSWO,
+    'ITSWO': ImaginaryTimeSWO,
+}
+
+# run_supervised_training's optimizers (SWO, LogOverlapSWO, DualSamplingSWO, BasisIterSWO)
+# are outside the hot path named by BASELINE.json.
+SUPERVISED_OPTIMIZERS = {}

@@ -132,7 +132,7 @@ def _proto_scalar(typ, v):
 
 def _float_text(v: float) -> str:
   # protobuf text_format prints float fields with the shortest float32 round-trip repr
-  return repr(float(np.float32(v))) if np.isfinite(v) else str(v)
+  return str(np.float32(v))
 
 
 class HParamDefText:

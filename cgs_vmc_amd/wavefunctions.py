@@ -126,6 +126,7 @@ def module_transfer_ops(source_module: Wavefunction, target_module: Wavefunction
     if (source_module._engine is not None and source_module._engine is target_module._engine
         and source_module._which == _hip.VMC_PSI and target_module._which == _hip.VMC_OMEGA):
       source_module._engine.transfer_params()          # device-to-device
+      target_module._has_values, target_module._theta = True, None
       return
     src = source_module.get_trainable_variables()
     dst = target_module.get_trainable_variables()
@@ -151,6 +152,7 @@ class FullyConnectedNetwork(Wavefunction):
       self.add_exp_normalization()
     self._n_sites: Optional[int] = None
     self._theta: Optional[np.ndarray] = None     # host copy until bound to an engine
+    self._has_values = False                     # variables initialised / restored
     session_lib.get_default_graph().global_initializers.append(self._maybe_initialize)
 
   # -- parameters ----------------------------------------------------------
@@ -192,14 +194,17 @@ class FullyConnectedNetwork(Wavefunction):
     self._set_theta(np.concatenate(parts).astype(np.float32))
 
   def _get_theta(self, allow_none=False):
+    if not self._has_values:
+      if allow_none:
+        return None
+      raise ValueError('Attempting to use uninitialized variables of %s' % self._unique_name)
     if self._engine is not None and self._theta is None:
       return self._engine.get_params(self._which)
-    if self._theta is None and not allow_none:
-      raise ValueError('Attempting to use uninitialized variables of %s' % self._unique_name)
     return self._theta
 
   def _set_theta(self, theta):
     theta = np.ascontiguousarray(theta, np.float32)
+    self._has_values = True
     if self._engine is not None:
       self._engine.set_params(theta, self._which)
       self._theta = None          # the device copy is authoritative from now on

@@ -1,0 +1,216 @@
+"""GPU: the reference-API mirror (wavefunctions / operators / graph_builders / training /
+evaluation / run scripts) end to end, against epochs restated with the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vmc_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _fresh_graph(monkeypatch):
+  from cgs_vmc_amd import session, wavefunctions
+  session.reset_default_graph()
+  wavefunctions.reset_name_scope()
+  monkeypatch.setenv('CGS_VMC_SEED', '77')
+  monkeypatch.setenv('CGS_VMC_CONFIG_SEED', '5')
+  yield
+
+
+def _hparams(**kw):
+  from cgs_vmc_amd import utils
+  base = dict(wavefunction_type='fully_connected', num_sites=8, num_fc_layers=2, fc_layer_size=16,
+              batch_size=32, num_equilibration_sweeps=2, num_monte_carlo_sweeps=1,
+              num_batches_per_epoch=3, learning_rates=[1e-2, 1e-3], learning_rate_stops=[1])
+  base.update(kw)
+  return utils.create_hparams(**base)
+
+
+def _build(optimizer_name, hp, jx=-1.0):
+  from cgs_vmc_amd import operators, session, training, wavefunctions
+  from cgs_vmc_amd import lattice
+  wf = wavefunctions.build_wavefunction(hp)
+  ham = operators.HeisenbergHamiltonian(lattice.chain_bonds(hp.num_sites), jx, 1.)
+  opt = training.GROUND_STATE_OPTIMIZERS[optimizer_name]()
+  shared = {}
+  ops = opt.build_opt_ops(wavefunction=wf, hamiltonian=ham, hparams=hp, shared_resources=shared)
+  sess = session.Session()
+  sess.run([session.global_variables_initializer(), session.local_variables_initializer()])
+  return wf, ham, opt, ops, sess, shared
+
+
+def _oracle_sweeps(theta, cfg, n_steps, step0, hp):
+  return vo.run_sweeps(theta, cfg, n_steps, 77, step0, hp.fc_layer_size, hp.num_fc_layers,
+                       dtype=np.float64)[0]
+
+
+def test_energy_gradient_epoch_matches_oracle_epoch():
+  """training.py:589-623 executed by the HIP path == the same epoch restated with the oracle
+  (same Philox stream, same initial chains and parameters)."""
+  from cgs_vmc_amd import graph_builders
+  hp = _hparams()
+  wf, ham, opt, ops, sess, shared = _build('EnergyGradient', hp)
+  n, h, L, b = hp.num_sites, hp.fc_layer_size, hp.num_fc_layers, hp.batch_size
+  theta = wf._get_theta().copy()
+  cfg = shared[graph_builders.ResourceName.CONFIGS].eval()
+  bonds = ham._bonds_list
+  adam = vo.AdamState(theta.size)
+  step = 0
+  for epoch in range(2):
+    # --- oracle epoch
+    cfg = _oracle_sweeps(theta, cfg, hp.num_equilibration_sweeps * n, step, hp)
+    step += hp.num_equilibration_sweeps * n
+    acc = vo.Accumulators(theta.size, np.float64)
+    for _ in range(hp.num_batches_per_epoch):
+      vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, h, L, np.float64)
+      cfg = _oracle_sweeps(theta, cfg, hp.num_monte_carlo_sweeps * n, step, hp)
+      step += hp.num_monte_carlo_sweeps * n
+    lr = vo.piecewise_constant(epoch, hp.learning_rate_stops, hp.learning_rates)
+    theta = vo.adam_apply(adam, theta, vo.energy_gradient(acc), lr, 0.9, hp.beta2, 1e-8)
+    # --- HIP epoch
+    energy = opt.run_optimization_epoch(ops, sess, hp, epoch)
+    assert abs(energy - acc.mean_energy()) < 2e-4 * max(1, abs(acc.mean_energy()))
+    np.testing.assert_array_equal(shared[graph_builders.ResourceName.CONFIGS].eval(), cfg)
+    np.testing.assert_allclose(wf._get_theta(), theta, rtol=0, atol=5e-5)
+  assert sess.run(graph_builders.get_or_create_num_epochs()) == 2
+
+
+def test_log_overlap_itswo_epoch_matches_oracle_epoch():
+  """training.py:731-763 by the HIP path == the oracle restatement (supervisor refreshed once
+  per epoch, Adam applied every batch, energy = mean of the LAST batch)."""
+  from cgs_vmc_amd import graph_builders
+  hp = _hparams(num_batches_per_epoch=2)
+  wf, ham, opt, ops, sess, shared = _build('LogOverlapITSWO', hp)
+  n, h, L = hp.num_sites, hp.fc_layer_size, hp.num_fc_layers
+  theta = wf._get_theta().copy()
+  cfg = shared[graph_builders.ResourceName.CONFIGS].eval()
+  bonds = ham._bonds_list
+  adam = vo.AdamState(theta.size)
+  step = 0
+  for epoch in range(2):
+    cfg = _oracle_sweeps(theta, cfg, hp.num_equilibration_sweeps * n, step, hp)
+    step += hp.num_equilibration_sweeps * n
+    theta_w = theta.copy()                                   # update_supervisor
+    lr = vo.piecewise_constant(epoch, hp.learning_rate_stops, hp.learning_rates)
+    for _ in range(hp.num_batches_per_epoch):
+      cfg = _oracle_sweeps(theta, cfg, hp.num_monte_carlo_sweeps * n, step, hp)
+      step += hp.num_monte_carlo_sweeps * n
+      acc = vo.Accumulators(theta.size, np.float64)          # reset_gradients
+      vo.log_overlap_accumulate(acc, theta, theta_w, cfg, bonds, -1.0, 1.0, -10.0, -10.0,
+                                hp.time_evolution_beta, h, L, np.float64)
+      theta = vo.adam_apply(adam, theta, vo.log_overlap_gradient(acc), lr, 0.9, hp.beta2, 1e-8)
+    energy = opt.run_optimization_epoch(ops, sess, hp, epoch)
+    assert abs(energy - acc.mean_energy()) < 2e-4 * max(1, abs(acc.mean_energy()))
+    np.testing.assert_array_equal(shared[graph_builders.ResourceName.CONFIGS].eval(), cfg)
+    np.testing.assert_allclose(wf._get_theta(), theta, rtol=0, atol=1e-4)
+
+
+def test_tensor_handles_match_oracle():
+  """wavefunction(configs), Operator.build / local_value / apply_in_place as op handles."""
+  from cgs_vmc_amd import graph_builders
+  hp = _hparams()
+  wf, ham, opt, ops, sess, shared = _build('EnergyGradient', hp)
+  configs = shared[graph_builders.ResourceName.CONFIGS]
+  cfg = configs.eval()
+  theta = wf._get_theta()
+  h, L = hp.fc_layer_size, hp.num_fc_layers
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+  psi = sess.run(wf(configs))
+  np.testing.assert_allclose(psi, amp(cfg), rtol=3e-5)
+  np.testing.assert_allclose(sess.run(wf(cfg[:5])), amp(cfg[:5]), rtol=3e-5)
+  diag, off = sess.run(list(ham.build(wf, configs)))
+  dref, oref = vo.heisenberg_build(amp, cfg, ham._bonds_list, -1.0, 1.0, np.float64)
+  np.testing.assert_allclose(diag, dref, atol=1e-6)
+  np.testing.assert_allclose(off, oref, rtol=3e-4, atol=1e-3)
+  lv = sess.run(ham.local_value(wf, configs))
+  np.testing.assert_allclose(lv, dref + oref / amp(cfg), rtol=2e-4, atol=2e-4)
+  ap = sess.run(ham.apply_in_place(wf, configs))
+  np.testing.assert_allclose(ap, dref * amp(cfg) + oref, rtol=3e-4, atol=1e-3)
+  with pytest.raises(ValueError):
+    wf(np.ones((3, hp.num_sites + 1), np.float32))
+  # one mc_step through Session.run moves the chains and reports the acceptance count
+  sess.run(ops.mc_step)
+  acc = sess.run(ops.acc_rate)
+  assert 0 <= acc <= hp.batch_size
+  assert ((configs.eval() != cfg).any(1).sum()) == acc
+
+
+def test_evaluator_returns_batch_means():
+  from cgs_vmc_amd import evaluation, lattice, operators, session, wavefunctions
+  hp = _hparams(num_evaluation_samples=4)
+  wf = wavefunctions.build_wavefunction(hp)
+  ham = operators.HeisenbergHamiltonian(lattice.chain_bonds(hp.num_sites), -1.0, 1.)
+  ev = evaluation.MonteCarloOperatorEvaluator()
+  shared = {}
+  eops = ev.build_eval_ops(wavefunction=wf, operator=ham, hparams=hp, shared_resources=shared)
+  sess = session.Session()
+  sess.run(session.global_variables_initializer())
+  theta = wf._get_theta()
+  from cgs_vmc_amd import graph_builders
+  cfg = shared[graph_builders.ResourceName.CONFIGS].eval()
+  n, h, L = hp.num_sites, hp.fc_layer_size, hp.num_fc_layers
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+  cfg = _oracle_sweeps(theta, cfg, hp.num_equilibration_sweeps * n, 0, hp)
+  step = hp.num_equilibration_sweeps * n
+  ref = []
+  for _ in range(4):
+    ref.append(vo.local_value(amp, cfg, ham._bonds_list, -1.0, 1.0, dtype=np.float64).mean())
+    cfg = _oracle_sweeps(theta, cfg, n, step, hp)
+    step += n
+  vals = ev.run_evaluation(eops, sess, hp, epoch_num=0)
+  assert len(vals) == 4
+  np.testing.assert_allclose(vals, ref, rtol=2e-4, atol=2e-4)
+
+
+def test_run_training_and_energy_evaluation_cli(tmp_path, capsys):
+  """BASELINE config 1 (plumbing): 16-site chain and 4x4 torus via J.txt, B=64, 2x32 ansatz."""
+  from cgs_vmc_amd import lattice, run_energy_evaluation, run_training, session, wavefunctions
+  for name, bonds in (('chain', None), ('torus', lattice.torus_bonds(4, 4))):
+    session.reset_default_graph(); wavefunctions.reset_name_scope()
+    d = str(tmp_path / name)
+    os.makedirs(d)
+    if bonds:
+      lattice.write_bonds(d, bonds)
+    hp = ('batch_size=64,fc_layer_size=32,num_fc_layers=2,num_equilibration_sweeps=5,'
+          'num_batches_per_epoch=10,learning_rates=[0.003,0.001],learning_rate_stops=[100],'
+          'num_evaluation_samples=10')
+    run_training.main(['--checkpoint_dir', d, '--num_sites', '16', '--heisenberg_jx', '-1.0',
+                       '--wavefunction_type', 'fully_connected', '--optimizer', 'EnergyGradient',
+                       '--num_epochs', '12', '--hparams', hp])
+    metrics = [float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()]
+    assert len(metrics) == 12 and np.isfinite(metrics).all()
+    assert metrics[-1] < metrics[0] - 0.3            # the energy goes down
+    assert os.path.exists(os.path.join(d, 'hparams.pbtxt'))
+    assert os.path.exists(os.path.join(d, 'model_prior_11_epochs.npz'))
+    assert not os.path.exists(os.path.join(d, 'model_prior_0_epochs.npz'))     # max_to_keep=5
+    session.reset_default_graph(); wavefunctions.reset_name_scope()
+    mean, unc = run_energy_evaluation.main(['--checkpoint_dir', d, '--heisenberg_jx', '-1.0'])
+    out = capsys.readouterr().out
+    assert 'Energy: ' in out and ' +/- ' in out
+    # evaluation of the last checkpoint (parameters BEFORE epoch 11) ~ the energy of epoch 10/11
+    assert abs(mean - metrics[-1]) < 0.6
+
+
+def test_accumulator_device_view_for_rccl():
+  """parallel.accumulator_tensor: zero-copy torch view of the library's device buffer."""
+  import torch
+  from cgs_vmc_amd import _hip, parallel
+  from cgs_vmc_amd.engine import VmcEngine
+  n, h, L, b = 8, 16, 2, 32
+  eng = VmcEngine(n, b, L, h)
+  eng.set_params(vo.init_params(n, h, L, np.random.default_rng(0)))
+  eng.set_configs(vo.random_configurations(n, b, np.random.RandomState(0)))
+  eng.set_bonds(vo.chain_bonds(n), -1.0, 1.0)
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  eng.synchronize()
+  t = parallel.accumulator_tensor(eng)
+  assert t.is_cuda and t.dtype == torch.float32 and t.numel() == 2 * eng.num_params + 8
+  np.testing.assert_array_equal(t.cpu().numpy(), eng.get_accumulators())
+  t.mul_(2.0)                                   # in place on the library's memory
+  torch.cuda.synchronize()
+  np.testing.assert_array_equal(eng.get_accumulators(), t.cpu().numpy())
+  parallel.allreduce_accumulators(eng)          # world size 1: no-op
+  eng.close()
