@@ -106,22 +106,22 @@ hipError_t launch_max(hipStream_t s, const float* x, int n, float* out_max);
 struct GemmArgs {
   const float* A; long long sam, sak;   // A(m,k) = A[m*sam + k*sak]
   const float* B; long long sbk, sbn;   // B(k,n) = B[k*sbk + n*sbn]
-  const float* kscale;                  // optional: B(k,n) *= kscale[k]
+  const float* kscale;                  // optional: B(k,n) *= kscale[k] (dual: second product)
   int M, N, K;
   float* C; long long ldc;              // C(m,n) = C[m*ldc + n]
+  float* C2;                            // dual: destination of A (kscale (.) B)
+  int dual;                             // compute both A B -> C and A (kscale (.) B) -> C2
+  int ones_row;                         // row M-1 of A is an implicit row of ones
   const float* bias;                    // epilogue 1: + bias[n] then relu
   const float* mask;  long long ldmask; // epilogue 2: * (mask[m*ldmask+n] > 0)
   int epilogue;                         // 0 none, 1 bias+relu, 2 mask, 3 accumulate (C += )
   int splitk;                           // >= 1
-  float* workspace;                     // [splitk][M][N] when splitk > 1
+  float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
 };
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
 hipError_t launch_relu_copy(hipStream_t s, const float* z, float* a, long long n);
 hipError_t launch_delta_out(hipStream_t s, const float* woutp, const float* aL, float* delta,
                             int B, int Hp);
-// out[c] (+)= sum_b w[b] * X[b*ld + c], c < ncols (w may be null -> 1)
-hipError_t launch_wcolsum(hipStream_t s, const float* X, long long ld, const float* w, int B,
-                          int ncols, float* out, float* workspace);
 hipError_t launch_scalar_accum(hipStream_t s, const float* eloc, const float* ratio, int B,
                                float* acc_scalars, int mode);
 hipError_t launch_itswo_ratio(hipStream_t s, const float* logit_psi, const float* logit_omega,

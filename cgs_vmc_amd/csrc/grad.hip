@@ -5,15 +5,21 @@
 #include "common.hpp"
 
 // ----------------------------------------------------------------------------------- GEMM
-// C[M,N] = A[M,K] B[K,N] with arbitrary element strides, 64x64x16 block tile, 4 waves in a
-// 2x2 grid, one 32x32 v_mfma_f32_32x32x2_f32 accumulator per wave.  Optional split-K over
-// blockIdx.z into a workspace that k_gemm_reduce folds in z order.
+// C[M,N] = A[M,K] B[K,N] with arbitrary element strides on fp32 MFMA.
+//   64x64x32 block tile, 4 waves in a 2x2 grid, one (DUAL: two) 32x32 v_mfma_f32_32x32x2_f32
+//   accumulator(s) per wave; global -> register prefetch of tile k+1 while tile k is computed
+//   from LDS; dwordx4 global loads along whichever dimension has stride 1.
+//   ones_row : row M-1 of A is an implicit row of ones (folds the bias gradient, which sits
+//              right behind its weight matrix in the parameter vector, into the dW GEMM)
+//   DUAL     : second product A (kscale (.) B) -> C2 from the same tiles (the weighted sum
+//              sum_b w_b O_k next to sum_b O_k, training.py:545-547)
+//   split-K over blockIdx.z into a workspace that k_gemm_reduce folds in z order.
 #define GT 64
-#define GK 16
-#define GLD 65
+#define GK 32
+#define GLD 68
 
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int m, int n, float v) {
-  float* c = g.C + (long long)m * g.ldc + n;
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, int m, int n, float v) {
+  float* c = C + (long long)m * g.ldc + n;
   switch (g.epilogue) {
     case 1: *c = fmaxf(v + g.bias[n], 0.f); break;
     case 2: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? v : 0.f; break;
@@ -22,9 +28,74 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, int m, int n, f
   }
 }
 
+// One operand tile (64 along d, 32 along k) as 2 x float4 per thread.
+//   dfast (stride_d == 1): i-th vector = elements (d0 + 4*(t%16) + j, k0 + t/16 + 16 i)
+//   kfast (stride_k == 1): i-th vector = elements (d0 + t/8 + 32 i, k0 + 4*(t%8) + j)
+struct TileRegs { f32x4 v[2]; };
+
+__device__ __forceinline__ TileRegs load_tile(const float* __restrict__ P, long long sd,
+                                              long long sk, int d_extent, int kend, int d0,
+                                              int k0, bool kfast, int ones_d, int t) {
+  TileRegs r;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int d, k, dd, dk;
+    if (kfast) { d = d0 + (t >> 3) + 32 * i; k = k0 + 4 * (t & 7); dd = 0; dk = 1; }
+    else       { d = d0 + 4 * (t & 15); k = k0 + (t >> 4) + 16 * i; dd = 1; dk = 0; }
+    const float* p = P + (long long)d * sd + (long long)k * sk;
+    const bool inb = (d + 3 * dd < d_extent) && (k + 3 * dk < kend);
+    const long long sv = kfast ? sk : sd;
+    if (inb && sv == 1 && (((size_t)p) & 15) == 0) {
+      r.v[i] = *(const f32x4*)p;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int dj = d + j * dd, kj = k + j * dk;
+        r.v[i][j] = (dj < d_extent && kj < kend) ? P[(long long)dj * sd + (long long)kj * sk] : 0.f;
+      }
+    }
+    if (ones_d >= 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (d + j * dd == ones_d && k + j * dk < kend) r.v[i][j] = 1.f;
+    }
+  }
+  return r;
+}
+
+__device__ __forceinline__ void store_tile(float (*S)[GLD], const TileRegs& r, bool kfast, int t) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (kfast) {
+      const int d = (t >> 3) + 32 * i, k = 4 * (t & 7);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) S[k + j][d] = r.v[i][j];
+    } else {
+      const int d = 4 * (t & 15), k = (t >> 4) + 16 * i;
+      *(f32x4*)&S[k][d] = r.v[i];
+    }
+  }
+}
+
+__device__ __forceinline__ TileRegs scale_tile(const TileRegs& r, const float* __restrict__ ks,
+                                               int k0, int kend, bool kfast, int t) {
+  TileRegs o;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = kfast ? k0 + 4 * (t & 7) + j : k0 + (t >> 4) + 16 * i;
+      o.v[i][j] = k < kend ? r.v[i][j] * ks[k] : 0.f;
+    }
+  }
+  return o;
+}
+
+template <bool DUAL>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
-  __shared__ float As[GK][GLD];
-  __shared__ float Bs[GK][GLD];
+  __shared__ __attribute__((aligned(16))) float As[GK][GLD];
+  __shared__ __attribute__((aligned(16))) float Bs[GK][GLD];
+  __shared__ __attribute__((aligned(16))) float Bs2[DUAL ? GK : 1][GLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
@@ -33,69 +104,84 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
   const int kbeg = blockIdx.z * kc;
   const int kend = min(g.K, kbeg + kc);
   const bool a_kfast = (g.sak == 1), b_kfast = (g.sbk == 1);
+  const int a_extent = g.ones_row ? g.M - 1 : g.M;
+  const int ones_d = g.ones_row ? g.M - 1 : -1;
 
-  f32x16 acc;
+  f32x16 acc, acc2;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
 
+  TileRegs ra, rb;
+  if (kbeg < kend) {
+    ra = load_tile(g.A, g.sam, g.sak, a_extent, kend, m0, kbeg, a_kfast, ones_d, tid);
+    rb = load_tile(g.B, g.sbn, g.sbk, g.N, kend, n0, kbeg, b_kfast, -1, tid);
+  }
   for (int k0 = kbeg; k0 < kend; k0 += GK) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i;
-      int m, k;
-      if (a_kfast) { k = idx % GK; m = idx / GK; } else { m = idx % GT; k = idx / GT; }
-      const int gm = m0 + m, gk = k0 + k;
-      As[k][m] = (gm < g.M && gk < kend) ? g.A[(long long)gm * g.sam + (long long)gk * g.sak] : 0.f;
-      int n, kb;
-      if (b_kfast) { kb = idx % GK; n = idx / GK; } else { n = idx % GT; kb = idx / GT; }
-      const int gn = n0 + n, gkb = k0 + kb;
-      float bv = 0.f;
-      if (gn < g.N && gkb < kend) {
-        bv = g.B[(long long)gkb * g.sbk + (long long)gn * g.sbn];
-        if (g.kscale) bv *= g.kscale[gkb];
-      }
-      Bs[kb][n] = bv;
+    store_tile(As, ra, a_kfast, tid);
+    if (DUAL) {
+      store_tile(Bs, rb, b_kfast, tid);
+      store_tile(Bs2, scale_tile(rb, g.kscale, k0, kend, b_kfast, tid), b_kfast, tid);
+    } else if (g.kscale) {
+      store_tile(Bs, scale_tile(rb, g.kscale, k0, kend, b_kfast, tid), b_kfast, tid);
+    } else {
+      store_tile(Bs, rb, b_kfast, tid);
     }
     __syncthreads();
+    if (k0 + GK < kend) {   // prefetch the next tile while this one is multiplied
+      ra = load_tile(g.A, g.sam, g.sak, a_extent, kend, m0, k0 + GK, a_kfast, ones_d, tid);
+      rb = load_tile(g.B, g.sbn, g.sbk, g.N, kend, n0, k0 + GK, b_kfast, -1, tid);
+    }
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 2) {
       const float av = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
       const float bv = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      if (DUAL) {
+        const float bv2 = Bs2[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv2, acc2, 0, 0, 0);
+      }
     }
     __syncthreads();
   }
 
   const int n = n0 + wn * 32 + (lane & 31);
+  const long long mn = (long long)g.M * g.N;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (m < g.M && n < g.N) {
       if (g.splitk > 1) {
-        g.workspace[((long long)blockIdx.z * g.M + m) * g.N + n] = acc[r];
+        float* ws = g.workspace + (long long)blockIdx.z * (DUAL ? 2 : 1) * mn;
+        ws[(long long)m * g.N + n] = acc[r];
+        if (DUAL) ws[mn + (long long)m * g.N + n] = acc2[r];
       } else {
-        gemm_epilogue(g, m, n, acc[r]);
+        gemm_epilogue(g, g.C, m, n, acc[r]);
+        if (DUAL) gemm_epilogue(g, g.C2, m, n, acc2[r]);
       }
     }
   }
 }
 
 __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
-  const long long total = (long long)g.M * g.N;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+  const long long mn = (long long)g.M * g.N;
+  const int nd = g.dual ? 2 : 1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < mn * nd;
        i += (long long)gridDim.x * 256) {
+    const int d = (int)(i / mn);
+    const long long e = i % mn;
     float v = 0.f;
-    for (int z = 0; z < g.splitk; ++z) v += g.workspace[(long long)z * total + i];
-    gemm_epilogue(g, (int)(i / g.N), (int)(i % g.N), v);
+    for (int z = 0; z < g.splitk; ++z) v += g.workspace[((long long)z * nd + d) * mn + e];
+    gemm_epilogue(g, d ? g.C2 : g.C, (int)(e / g.N), (int)(e % g.N), v);
   }
 }
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
   const dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, g.splitk);
-  hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, s, g);
+  if (g.dual) hipLaunchKernelGGL(k_gemm<true>, grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(k_gemm<false>, grid, dim3(256), 0, s, g);
   if (g.splitk > 1) {
-    const long long total = (long long)g.M * g.N;
+    const long long total = (long long)g.M * g.N * (g.dual ? 2 : 1);
     const int blocks = (int)min((total + 255) / 256, (long long)2048);
     hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks), dim3(256), 0, s, g);
   }
@@ -142,38 +228,6 @@ hipError_t launch_delta_out(hipStream_t s, const float* woutp, const float* aL, 
   const long long n = (long long)B * Hp;
   const int blocks = (int)min((n + 255) / 256, (long long)4096);
   hipLaunchKernelGGL(k_delta_out, dim3(blocks), dim3(256), 0, s, woutp, aL, delta, B, Hp);
-  return hipGetLastError();
-}
-
-// weighted column sums: out[c] += sum_b w[b] X[b*ld + c]; two fixed-order stages
-#define WCS_CHUNKS 32
-__global__ __launch_bounds__(256) void k_wcolsum1(const float* __restrict__ X, long long ld,
-                                                  const float* __restrict__ w, int B, int ncols,
-                                                  float* __restrict__ ws) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int per = (B + WCS_CHUNKS - 1) / WCS_CHUNKS;
-  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
-  if (c >= ncols) return;
-  float acc = 0.f;
-  for (int b = b0; b < b1; ++b) acc = fmaf(w ? w[b] : 1.f, X[(long long)b * ld + c], acc);
-  ws[(long long)blockIdx.y * ncols + c] = acc;
-}
-
-__global__ __launch_bounds__(256) void k_wcolsum2(const float* __restrict__ ws, int ncols,
-                                                  float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncols) return;
-  float acc = 0.f;
-  for (int s = 0; s < WCS_CHUNKS; ++s) acc += ws[(long long)s * ncols + c];
-  out[c] += acc;
-}
-
-hipError_t launch_wcolsum(hipStream_t s, const float* X, long long ld, const float* w, int B,
-                          int ncols, float* out, float* workspace) {
-  const dim3 grid((ncols + 255) / 256, WCS_CHUNKS);
-  hipLaunchKernelGGL(k_wcolsum1, grid, dim3(256), 0, s, X, ld, w, B, ncols, workspace);
-  hipLaunchKernelGGL(k_wcolsum2, dim3((ncols + 255) / 256), dim3(256), 0, s, workspace, ncols,
-                     out);
   return hipGetLastError();
 }
 

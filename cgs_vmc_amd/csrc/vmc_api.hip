@@ -55,7 +55,7 @@ struct vmc_ctx {
   float *ratio = nullptr, *ones = nullptr;
   float *acc = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad_tmp = nullptr;
   long long adam_t = 0;
-  float *gemm_ws = nullptr, *wcs_ws = nullptr;
+  float* gemm_ws = nullptr;
   int splitk = 16;
   // scratch
   unsigned long long* d_accepted = nullptr;
@@ -291,8 +291,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(hipMemsetAsync(c->adam_m, 0, P * sizeof(float), c->stream));
   CA(hipMemsetAsync(c->adam_v, 0, P * sizeof(float), c->stream));
   const long long mmax = N > c->H ? N : c->H;
-  CA(dalloc(&c->gemm_ws, (long long)c->splitk * mmax * c->H));
-  CA(dalloc(&c->wcs_ws, 32 * Hp));
+  CA(dalloc(&c->gemm_ws, (long long)c->splitk * 2 * (mmax + 1) * c->H));
   CA(dalloc(&c->d_accepted, 1)); CA(dalloc(&c->d_sum, 1)); CA(dalloc(&c->d_max, 1));
   CA(dalloc(&c->inj_up, B)); CA(dalloc(&c->inj_dn, B)); CA(dalloc(&c->inj_u, B));
   CA(dalloc(&c->acc_mask, B));
@@ -316,7 +315,7 @@ void vmc_destroy(vmc_ctx* c) {
   for (float* q : c->act) if (q) hipFree(q);
   void* ptrs[] = {c->configs, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta[0], c->delta[1], c->ratio, c->ones, c->acc,
-                  c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->wcs_ws, c->d_accepted, c->d_sum,
+                  c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->d_accepted, c->d_sum,
                   c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->inj_up, c->inj_dn, c->inj_u,
                   c->acc_mask};
   for (void* q : ptrs) if (q) hipFree(q);
@@ -558,27 +557,28 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
     g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1;
     HIPCHK(c, launch_gemm(c->stream, g));
   }
-  // output layer: d logit / d w_out = a_L, d logit / d b_out = 1
-  HIPCHK(c, launch_wcolsum(c->stream, c->act[L - 1], Hp, nullptr, B, H, g1 + off_wout(c), c->wcs_ws));
-  HIPCHK(c, launch_wcolsum(c->stream, c->act[L - 1], Hp, w, B, H, g2 + off_wout(c), c->wcs_ws));
-  HIPCHK(c, launch_wcolsum(c->stream, c->ones, 1, nullptr, B, 1, g1 + off_bout(c), c->wcs_ws));
-  HIPCHK(c, launch_wcolsum(c->stream, w, 1, nullptr, B, 1, g2 + off_bout(c), c->wcs_ws));
+  // Every weight-gradient GEMM below is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows
+  // 0..K_in-1 give dW, the implicit ones row gives db (b_l sits right behind w_l in theta),
+  // the unscaled product goes to g1 and the w-scaled one to g2.
+  auto weight_grad = [&](const float* a, long long a_ld, int k_in, const float* delta,
+                         long long sbk, long long sbn, int n_out, long long off) -> int {
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = a; g.sam = 1; g.sak = a_ld; g.M = k_in + 1; g.ones_row = 1;
+    g.B = delta; g.sbk = sbk; g.sbn = sbn; g.kscale = w; g.dual = 1;
+    g.N = n_out; g.K = B; g.C = g1 + off; g.C2 = g2 + off; g.ldc = n_out; g.epilogue = 3;
+    g.splitk = c->splitk; g.workspace = c->gemm_ws;
+    HIPCHK(c, launch_gemm(c->stream, g));
+    return VMC_OK;
+  };
+  // output layer: d logit / d w_out = a_L, d logit / d b_out = 1  (delta = 1 for every b)
+  PROPAGATE(weight_grad(c->act[L - 1], Hp, H, c->ones, 1, 0, 1, off_wout(c)));
   // back-propagation of d logit / d z_l
   int cur = 0;
   HIPCHK(c, launch_delta_out(c->stream, p.woutp, c->act[L - 1], c->delta[cur], B, Hp));
   for (int l = L - 1; l >= 0; --l) {
     const float* delta = c->delta[cur];
-    for (int pass = 0; pass < 2; ++pass) {
-      float* gdst = pass == 0 ? g1 : g2;
-      GemmArgs g; memset(&g, 0, sizeof(g));
-      if (l == 0) { g.A = c->configs; g.sam = 1; g.sak = N; g.M = N; }
-      else { g.A = c->act[l - 1]; g.sam = 1; g.sak = Hp; g.M = H; }
-      g.B = delta; g.sbk = Hp; g.sbn = 1; g.kscale = pass == 0 ? nullptr : w;
-      g.N = H; g.K = B; g.C = gdst + off_w(c, l); g.ldc = H; g.epilogue = 3;
-      g.splitk = c->splitk; g.workspace = c->gemm_ws;
-      HIPCHK(c, launch_gemm(c->stream, g));
-      HIPCHK(c, launch_wcolsum(c->stream, delta, Hp, pass == 0 ? nullptr : w, B, H, gdst + off_b(c, l), c->wcs_ws));
-    }
+    if (l == 0) PROPAGATE(weight_grad(c->configs, N, N, delta, Hp, 1, H, off_w(c, 0)));
+    else PROPAGATE(weight_grad(c->act[l - 1], Hp, H, delta, Hp, 1, H, off_w(c, l)));
     if (l > 0) {
       GemmArgs g; memset(&g, 0, sizeof(g));
       g.A = delta; g.sam = Hp; g.sak = 1;

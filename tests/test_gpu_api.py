@@ -74,7 +74,10 @@ def test_energy_gradient_epoch_matches_oracle_epoch():
     energy = opt.run_optimization_epoch(ops, sess, hp, epoch)
     assert abs(energy - acc.mean_energy()) < 2e-4 * max(1, abs(acc.mean_energy()))
     np.testing.assert_array_equal(shared[graph_builders.ResourceName.CONFIGS].eval(), cfg)
-    np.testing.assert_allclose(wf._get_theta(), theta, rtol=0, atol=5e-5)
+    # b_out (last entry) has an identically-zero energy gradient (O_k == 1): its Adam step is
+    # rounding noise / (|noise| + eps) = +-lr in ANY fp32 implementation, so it is not compared;
+    # it only rescales psi and cancels in every ratio.
+    np.testing.assert_allclose(wf._get_theta()[:-1], theta[:-1], rtol=0, atol=5e-5)
   assert sess.run(graph_builders.get_or_create_num_epochs()) == 2
 
 
@@ -105,7 +108,7 @@ def test_log_overlap_itswo_epoch_matches_oracle_epoch():
     energy = opt.run_optimization_epoch(ops, sess, hp, epoch)
     assert abs(energy - acc.mean_energy()) < 2e-4 * max(1, abs(acc.mean_energy()))
     np.testing.assert_array_equal(shared[graph_builders.ResourceName.CONFIGS].eval(), cfg)
-    np.testing.assert_allclose(wf._get_theta(), theta, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(wf._get_theta()[:-1], theta[:-1], rtol=0, atol=1e-4)
 
 
 def test_tensor_handles_match_oracle():
