@@ -59,6 +59,7 @@ SIGNATURES = {
     'vmc_mc_steps': (C.c_int, [_ctx, C.c_int64, C.POINTER(C.c_int64)]),
     'vmc_mc_step_injected': (C.c_int, [_ctx, _ip, _ip, _fp, C.POINTER(C.c_uint8)]),
     'vmc_debug_proposals': (C.c_int, [_ctx, C.c_uint64, _ip, _ip, _fp]),
+    'vmc_debug_sweep_profile': (C.c_int, [_ctx, C.c_int64, C.POINTER(C.c_double)]),
     'vmc_get_step_counter': (C.c_int, [_ctx, C.POINTER(C.c_uint64)]),
     'vmc_set_step_counter': (C.c_int, [_ctx, C.c_uint64]),
     'vmc_local_energy': (C.c_int, [_ctx, C.c_int, _fp, C.POINTER(C.c_double)]),

@@ -13,15 +13,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // key = (seed_lo, seed_hi); block b gives the site uniforms 4b..4b+3 of one mc_step
 // (graph_builders.py:59), block 0xFFFFFFFF word 0 the acceptance uniform (76-77).
 // --------------------------------------------------------------------------------------
+// one Philox round (+ key bump); ten of them make Philox4x32-10
+__device__ __forceinline__ void philox_round(uint4& c, uint2& k) {
+  const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+  const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+  c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+  k.x += 0x9E3779B9u;
+  k.y += 0xBB67AE85u;
+}
+
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-    k.x += 0x9E3779B9u;
-    k.y += 0xBB67AE85u;
-  }
+  for (int r = 0; r < 10; ++r) philox_round(c, k);
   return c;
 }
 
@@ -77,6 +80,7 @@ struct SweepArgs {
   const float* inj_u;
   unsigned char* acc_mask;  // [B] out (last step) or nullptr
   int* dbg_up; int* dbg_dn; float* dbg_u;   // proposal dump (debug_proposals) or nullptr
+  unsigned long long* dbg_cycles;           // [grid][4 waves][8 phases] -> diagnostic STAMP build
   int B, N, n_hidden;
   int chain_offset;
   uint32_t seed_lo, seed_hi;

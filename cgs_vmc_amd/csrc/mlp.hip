@@ -19,6 +19,14 @@
 // fully coalesced 1 KiB dwordx4 wave load.  The same holds for 16x16x4 with
 // k(r, g) = 4g + r.
 #include "common.hpp"
+#include <type_traits>
+
+#ifndef SWEEP_RT
+#define SWEEP_RT 12   // resident k-tiles of the first H x H layer (sweep kernel)
+#endif
+#ifndef SWEEP_PF
+#define SWEEP_PF 4    // stages of the weight prefetch ring; (16 - SWEEP_RT) % SWEEP_PF == 0
+#endif
 
 // ------------------------------------------------------------------------------------ pack
 __global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, int L,
@@ -249,25 +257,69 @@ hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mo
 //   accept = exp(logit' - logit) > sqrt(u)        (graph_builders.py:75-79)
 // Chain state (spins, z1, logit) stays in LDS; z1 and logit are recomputed from the spins
 // at launch start and end so the cache written back never carries incremental drift.
-template <int NT>
+//
+// Weight traffic: the A-operand fragments of the first RT (= 12 of 16 at H = 256) k-tiles of
+// the FIRST H x H layer of this wave's output units are loaded once and stay in registers
+// (192 per lane) for the whole launch; everything else streams from L2 through a 4-stage
+// register ring whose loads are issued 3 k-tiles (1536 MFMA cycles) ahead of their use and
+// run across layer boundaries.
+// 16-lane (DPP row) all-reduce steps: lane^1, lane^2 (quad_perm), then row_half_mirror and
+// row_mirror, which combine the already-uniform quads / halves.  Pure VALU, no LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+#define DPP_XOR1 0xB1
+#define DPP_XOR2 0x4E
+#define DPP_HALF_MIRROR 0x141
+#define DPP_MIRROR 0x140
+
+// s_memtime stamp for the diagnostic instantiation (STAMP = true) only; the production kernel
+// (STAMP = false) executes none of it.
+__device__ __forceinline__ unsigned long long vmc_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+// W1L: the first-layer matrix W1 [N][Hp] also lives in LDS (when it fits), which turns the
+// rank-2 gather of two W1 rows per chain and step from an L2 round trip into LDS reads; the
+// accepted move is then folded into z1 lazily at the start of the next step instead of being
+// double-buffered.
+template <int NT, bool STAMP, bool W1L>
 __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
-  constexpr int Hp = NT * 16, TO = NT / 4, ZS = Hp + 4;
+  constexpr int Hp = NT * 16, TO = NT / 4, ZS = Hp + 4, W1S = Hp + 4, PF = SWEEP_PF;
+  constexpr int RT = NT < SWEEP_RT ? NT : SWEEP_RT;   // k-tiles of the first H x H layer kept in registers
   extern __shared__ float smem[];
   const int N = a.N, Nst = (N + 3) & ~3;
   float* s_spin = smem;                       // [16][Nst]
-  float* s_z1 = s_spin + 16 * Nst;            // [2][16][ZS]
-  float* s_x = s_z1 + 2 * 16 * ZS;            // [2][NT][64][4]
+  float* s_z1 = s_spin + 16 * Nst;            // [W1L ? 1 : 2][16][ZS]
+  float* s_x = s_z1 + (W1L ? 1 : 2) * 16 * ZS;  // [2][NT][64][4]
   float* s_part = s_x + 2 * NT * 256;         // [4][16]
   float* s_logit = s_part + 64;               // [16]
   float* s_u = s_logit + 16;                  // [16]
   int* s_iup = (int*)(s_u + 16);              // [16]
   int* s_idn = s_iup + 16;                    // [16]
   int* s_sel = s_idn + 16;                    // [16]
+  int* s_pup = s_sel + 16;                    // [16] previous step's proposal / accept flag
+  int* s_pdn = s_pup + 16;                    // [16]
+  int* s_pacc = s_pdn + 16;                   // [16]
+  float* s_wout = (float*)(s_pacc + 16);      // [Hp]
+  float* s_bias = s_wout + Hp;                // [n_hidden][Hp] biases of the H x H layers
+  float* s_w1 = s_bias + a.n_hidden * Hp;     // [N][W1S] (W1L only)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
   const int g = lane >> 4, j = lane & 15;
   const int chain0 = blockIdx.x * 16;
   const PackedParams& pp = a.pp;
+  const int n_hidden = a.n_hidden;
 
   for (int i = tid; i < 16 * Nst; i += 256) {
     const int c = i / Nst, n = i % Nst, gc = chain0 + c;
@@ -275,7 +327,27 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
     if (n < N) v = gc < a.B ? a.configs[(long long)gc * N + n] : ((n & 1) ? -1.f : 1.f);
     s_spin[i] = v;
   }
-  if (tid < 16) s_sel[tid] = 0;
+  if (tid < 16) { s_sel[tid] = 0; s_pacc[tid] = 0; s_pup[tid] = 0; s_pdn[tid] = 0; }
+  for (int i = tid; i < n_hidden * Hp; i += 256) s_bias[i] = pp.bh[i];
+  for (int i = tid; i < Hp; i += 256) s_wout[i] = pp.woutp[i];
+  if (W1L) {
+    for (int i = tid; i < N * (Hp / 4); i += 256) {
+      const int n = i / (Hp / 4), c4 = i % (Hp / 4);
+      *(f32x4*)(s_w1 + n * W1S + 4 * c4) = *(const f32x4*)(pp.w1p + (long long)n * Hp + 4 * c4);
+    }
+  }
+  const float bout = pp.bout[0];
+
+  // register-resident fragments of the first H x H layer
+  f32x4 wres[RT * TO];
+  if (n_hidden > 0) {
+    const f32x4* __restrict__ wp0 = (const f32x4*)pp.p16 + wave * TO * NT * 64;
+#pragma unroll
+    for (int ti = 0; ti < RT; ++ti)
+#pragma unroll
+      for (int to = 0; to < TO; ++to)
+        wres[ti * TO + to] = wp0[(to * NT + ti) * 64 + lane];
+  }
   __syncthreads();
 
   // z1 from the spins (first layer, exact): thread -> (column, chain group)
@@ -298,10 +370,174 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
     }
   };
 
+  const uint2 key = make_uint2(a.seed_lo, a.seed_hi);
+  const int nblk = (N + 3) >> 2;
+
+  // ---- proposals (graph_builders.py:59-65).  Lane (c = 4*wave + g, sub = j) owns the site
+  // blocks sub, sub+16, ... of chain c.  The Philox draws of step t+1 do not depend on the
+  // chain state, so they are computed one step ahead inside the MFMA phase of step t (UPRE
+  // blocks per lane, i.e. N <= 64*UPRE/... sites); only the argmax/argmin of s*u is left for
+  // the start of the step.
+  constexpr int UPRE = 2;                       // prefetched Philox blocks per lane
+  const bool use_pref = (nblk <= 16 * UPRE) && (a.inj_up == nullptr);
+  const int my_c = wave * 4 + g;
+  const uint32_t my_gid = (uint32_t)(a.chain_offset + chain0 + my_c);
+  float u_pre[4 * UPRE];
+  float u_pre_acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4 * UPRE; ++i) u_pre[i] = 0.f;
+
+  // Philox counters of this lane's two draws for `step`: A = site block j, B = site block
+  // j+16, or, when that block is beyond the lattice (always on lane 15 for N <= 124), the
+  // acceptance block (only lane 15's value is used).
+  const bool acc_in_b = (15 + 16 >= nblk);          // lane 15's block B is free
+  auto ctr_a = [&](unsigned long long step) {
+    return make_uint4((uint32_t)j, my_gid, (uint32_t)step, (uint32_t)(step >> 32));
+  };
+  auto ctr_b = [&](unsigned long long step) {
+    const uint32_t blk = (j + 16 < nblk) ? (uint32_t)(j + 16) : VMC_ACCEPT_BLOCK;
+    return make_uint4(blk, my_gid, (uint32_t)step, (uint32_t)(step >> 32));
+  };
+  auto finish_draw = [&](const uint4& ra, const uint4& rb, unsigned long long step) {
+    u_pre[0] = u32_to_uniform(ra.x); u_pre[1] = u32_to_uniform(ra.y);
+    u_pre[2] = u32_to_uniform(ra.z); u_pre[3] = u32_to_uniform(ra.w);
+    u_pre[4] = u32_to_uniform(rb.x); u_pre[5] = u32_to_uniform(rb.y);
+    u_pre[6] = u32_to_uniform(rb.z); u_pre[7] = u32_to_uniform(rb.w);
+    if (acc_in_b) {
+      u_pre_acc = u_pre[4];
+    } else {
+      const uint4 r = philox4x32_10(
+          make_uint4(VMC_ACCEPT_BLOCK, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
+      u_pre_acc = u32_to_uniform(r.x);
+    }
+  };
+  auto draw_all = [&](unsigned long long step) {     // un-overlapped form
+    finish_draw(philox4x32_10(ctr_a(step), key), philox4x32_10(ctr_b(step), key), step);
+  };
+
+  auto reduce_and_publish = [&](float vmax, int imax, float vmin, int imin, float uacc) {
+#define VMC_RED_STEP(CTRL)                                                            \
+    {                                                                                 \
+      const float ov = dpp_f<CTRL>(vmax); const int oi = dpp_i<CTRL>(imax);           \
+      if (ov > vmax || (ov == vmax && oi < imax)) { vmax = ov; imax = oi; }           \
+      const float pv = dpp_f<CTRL>(vmin); const int pi = dpp_i<CTRL>(imin);           \
+      if (pv < vmin || (pv == vmin && pi < imin)) { vmin = pv; imin = pi; }           \
+    }
+    VMC_RED_STEP(DPP_XOR1) VMC_RED_STEP(DPP_XOR2) VMC_RED_STEP(DPP_HALF_MIRROR) VMC_RED_STEP(DPP_MIRROR)
+#undef VMC_RED_STEP
+    if (j == 15) {
+      s_iup[my_c] = imax;   // argmax of s*u: the UP spin to lower   (graph_builders.py:64-65)
+      s_idn[my_c] = imin;   // argmin of s*u: the DOWN spin to raise (graph_builders.py:62-63)
+      s_u[my_c] = uacc;
+    }
+  };
+
+  // proposals of absolute step `step` into s_iup / s_idn / s_u
+  auto proposals = [&](unsigned long long step) {
+    if (a.inj_up) {
+      if (tid < 16) {
+        const int gc = chain0 + tid;
+        const bool ok = gc < a.B;
+        s_iup[tid] = ok ? a.inj_up[gc] : 0;
+        s_idn[tid] = ok ? a.inj_dn[gc] : 1;
+        s_u[tid] = ok ? a.inj_u[gc] : 2.f;
+      }
+      return;
+    }
+    float vmax = -3.f, vmin = 3.f;
+    int imax = 0x7fffffff, imin = 0x7fffffff;
+    if (use_pref) {       // uniforms were drawn during the previous step's MFMA phase
+#pragma unroll
+      for (int b = 0; b < UPRE; ++b) {
+        const int blk = j + 16 * b;
+        if (blk < nblk) {
+          const f32x4 sp = *(const f32x4*)(s_spin + my_c * Nst + 4 * blk);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = 4 * blk + e;
+            if (n < N) {
+              const float v = sp[e] * u_pre[4 * b + e];
+              if (v > vmax) { vmax = v; imax = n; }
+              if (v < vmin) { vmin = v; imin = n; }
+            }
+          }
+        }
+      }
+      reduce_and_publish(vmax, imax, vmin, imin, u_pre_acc);
+      return;
+    }
+    for (int blk = j; blk < nblk; blk += 16) {
+      const uint4 r = philox4x32_10(
+          make_uint4((uint32_t)blk, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
+      const f32x4 sp = *(const f32x4*)(s_spin + my_c * Nst + 4 * blk);
+      const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = 4 * blk + e;
+        if (n < N) {
+          const float v = sp[e] * u32_to_uniform(rr[e]);
+          if (v > vmax) { vmax = v; imax = n; }
+          if (v < vmin) { vmin = v; imin = n; }
+        }
+      }
+    }
+    float uacc = 0.f;
+    if (j == 15) {   // the lane with the fewest site blocks also draws the acceptance uniform
+      const uint4 r = philox4x32_10(
+          make_uint4(VMC_ACCEPT_BLOCK, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
+      uacc = u32_to_uniform(r.x);
+    }
+    reduce_and_publish(vmax, imax, vmin, imin, uacc);
+  };
+
+  if (a.dbg_up != nullptr) {   // debug_proposals: dump the draw of step0, do not move
+    if (use_pref) draw_all(a.step0);
+    proposals(a.step0);
+    __syncthreads();
+    if (tid < 16 && chain0 + tid < a.B) {
+      a.dbg_up[chain0 + tid] = s_iup[tid];
+      a.dbg_dn[chain0 + tid] = s_idn[tid];
+      a.dbg_u[chain0 + tid] = s_u[tid];
+    }
+    return;
+  }
+
   f32x4 own[TO];  // relu'd activations of this wave's own output tiles (B-operand layout)
 
   // builds the layer-2 input operand (and the candidate z1 when with_delta)
   auto build = [&](bool with_delta) {
+    if (W1L) {
+      // single z1 buffer; the previous step's accepted move is folded in first (each thread
+      // owns fixed elements of z1, so no barrier is needed for the read-modify-write)
+      float* zrow = s_z1 + j * ZS;
+      const bool pacc = s_pacc[j] != 0;
+      const float* px = s_w1 + s_pdn[j] * W1S;
+      const float* py = s_w1 + s_pup[j] * W1S;
+      const float* wa = s_w1 + (with_delta ? s_idn[j] : 0) * W1S;
+      const float* wb = s_w1 + (with_delta ? s_iup[j] : 0) * W1S;
+#pragma unroll
+      for (int to = 0; to < TO; ++to) {
+        const int t = wave * TO + to, col = 16 * t + 4 * g;
+        f32x4 z = *(const f32x4*)(zrow + col);
+        if (pacc) {
+          const f32x4 x = *(const f32x4*)(px + col);
+          const f32x4 y = *(const f32x4*)(py + col);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[e] = fmaf(2.f, x[e] - y[e], z[e]);
+          *(f32x4*)(zrow + col) = z;
+        }
+        if (with_delta) {
+          const f32x4 x = *(const f32x4*)(wa + col);
+          const f32x4 y = *(const f32x4*)(wb + col);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[e] = fmaf(2.f, x[e] - y[e], z[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(z[e], 0.f);
+        *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
+      }
+      return;
+    }
     const int sel = s_sel[j];
     const float* zc = s_z1 + sel * 16 * ZS + j * ZS;
     float* zn = s_z1 + (sel ^ 1) * 16 * ZS + j * ZS;
@@ -328,44 +564,103 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
     }
   };
 
-  // layers 2..L + output dot; returns nothing, leaves per-wave partial logits in s_part.
-  auto forward = [&]() {
-    int cur = 0;
-    for (int l = 0; l < a.n_hidden; ++l) {
-      __syncthreads();
-      const float* xin = s_x + cur * NT * 256;
-      f32x4 in[NT];
+  // layers 2..L + output dot; leaves per-wave partial logits in s_part.
+  // Weight stream = [(layer 0, ti = RT..NT-1), (layer 1, all ti), ...] through a PF-stage
+  // register ring; item q lives in stage q % PF and is issued PF-1 items ahead of its use.
+  auto forward = [&](unsigned long long next_step) {
+    f32x4 wb[PF][TO];
+    auto issue = [&](int l, int ti, int stage) {
+      // uniform (SGPR) base + one per-lane offset register
+      const f32x4* __restrict__ wp =
+          (const f32x4*)(pp.p16 + (long long)l * Hp * Hp) + (wave * TO * NT + ti) * 64;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) in[t] = *(const f32x4*)(xin + (t * 64 + lane) * 4);
+      for (int to = 0; to < TO; ++to) wb[stage][to] = wp[to * NT * 64 + lane];
+    };
+    // prologue of the ring.  Every issue below is unconditional (layer index clamped to the
+    // last layer) so that the compiler can count vmcnt exactly; a load issued under a runtime
+    // condition makes it wait for ALL outstanding loads at the next use.
+    const int l_last = n_hidden - 1;
+    if (RT < NT) {
+#pragma unroll
+      for (int st = 0; st < PF - 1; ++st) issue(0, RT + st, st);
+    } else {
+#pragma unroll
+      for (int st = 0; st < PF - 1; ++st) issue(min(1, l_last), st, st);
+    }
+    int cur = 0;
+    // FS = first streamed k-tile of the layer (RT for layer 0, 0 afterwards)
+    auto layer = [&](int l, auto fs_c) {
+      constexpr int FS = decltype(fs_c)::value;
+      __syncthreads();
+      const f32x4* xin = (const f32x4*)(s_x + cur * NT * 256) + lane;
       f32x4 acc[TO];
 #pragma unroll
       for (int to = 0; to < TO; ++to)
-        acc[to] = *(const f32x4*)(pp.bh + l * Hp + 16 * (wave * TO + to) + 4 * g);
-      const f32x4* __restrict__ wp = (const f32x4*)(pp.p16 + (long long)l * Hp * Hp);
+        acc[to] = *(const f32x4*)(s_bias + l * Hp + 16 * (wave * TO + to) + 4 * g);
+      // resident k-tiles: operands straight from registers.  The 20 Philox rounds of the NEXT
+      // step's two draws are cut into 2*FS pieces and pinned (sched_barrier) between groups of
+      // 2*TO MFMAs, so the VALU work issues in the shadow of the matrix pipe.
+      f32x4 inb[2];
+      inb[0] = xin[0];
+      uint4 ca = ctr_a(next_step), cb = ctr_b(next_step);
+      uint2 ka = key, kb = key;
+      constexpr int NPIECE = 2 * FS;
+      constexpr int RPP = NPIECE > 1 ? (20 + NPIECE - 2) / (NPIECE - 1) : 20;   // rounds / piece
+      auto piece = [&](int p) {
 #pragma unroll
-      for (int ti = 0; ti < NT; ++ti) {
-        f32x4 w[TO];
+        for (int q = p * RPP; q < (p + 1) * RPP && q < 20; ++q) {
+          if (q & 1) philox_round(cb, kb); else philox_round(ca, ka);
+        }
+      };
 #pragma unroll
-        for (int to = 0; to < TO; ++to) w[to] = wp[((wave * TO + to) * NT + ti) * 64 + lane];
+      for (int ti = 0; ti < FS; ++ti) {
+        if (ti + 1 < NT) inb[(ti + 1) & 1] = xin[(ti + 1) * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int to = 0; to < TO; ++to)
+            acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[ti * TO + to][r], inb[ti & 1][r],
+                                                           acc[to], 0, 0, 0);
+          if (r == 1) { piece(2 * ti); __builtin_amdgcn_sched_barrier(0); }
+          if (r == 3) { piece(2 * ti + 1); __builtin_amdgcn_sched_barrier(0); }
+        }
+      }
+      if (FS > 0) finish_draw(ca, cb, next_step);
+      // streamed k-tiles: weights PF-1 tiles ahead, activations one tile ahead
+      if (FS == 0) inb[0] = xin[0];
+#pragma unroll
+      for (int ti = FS; ti < NT; ++ti) {
+        const int tn = ti + PF - 1;
+        if (tn < NT) issue(l, tn, (tn - FS) % PF);
+        else issue(min(l + 1, l_last), tn - NT, (tn - FS) % PF);
+        if (ti + 1 < NT) inb[(ti + 1) & 1] = xin[(ti + 1) * 64];
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetches ahead of this tile's MFMAs
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int to = 0; to < TO; ++to)
-            acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[to][r], in[ti][r], acc[to], 0, 0, 0);
+            acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[(ti - FS) % PF][to][r],
+                                                           inb[ti & 1][r], acc[to], 0, 0, 0);
       }
       float* xout = s_x + (cur ^ 1) * NT * 256;
 #pragma unroll
       for (int to = 0; to < TO; ++to) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(acc[to][e], 0.f);
-        if (l + 1 < a.n_hidden) *(f32x4*)(xout + ((wave * TO + to) * 64 + lane) * 4) = own[to];
+        if (l + 1 < n_hidden) *(f32x4*)(xout + ((wave * TO + to) * 64 + lane) * 4) = own[to];
       }
       cur ^= 1;
-    }
+    };
+    layer(0, std::integral_constant<int, RT>{});
+    for (int l = 1; l < n_hidden; ++l) layer(l, std::integral_constant<int, 0>{});
+  };
+
+  // output dot of the last activations (own) -> per-wave partial logits in s_part
+  auto output_dot = [&]() {
     float part = 0.f;
 #pragma unroll
     for (int to = 0; to < TO; ++to) {
-      const f32x4 w = *(const f32x4*)(pp.woutp + 16 * (wave * TO + to) + 4 * g);
+      const f32x4 w = *(const f32x4*)(s_wout + 16 * (wave * TO + to) + 4 * g);
 #pragma unroll
       for (int e = 0; e < 4; ++e) part = fmaf(own[to][e], w[e], part);
     }
@@ -376,144 +671,113 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   };
 
   auto logit_of = [&](int c) {
-    return ((s_part[c] + s_part[16 + c]) + (s_part[32 + c] + s_part[48 + c])) + pp.bout[0];
+    return ((s_part[c] + s_part[16 + c]) + (s_part[32 + c] + s_part[48 + c])) + bout;
   };
 
-  // ---- initial cache: z1 and logit of the current spins
-  z1_direct();
-  __syncthreads();
-  build(false);
-  forward();
-  if (tid < 16) s_logit[tid] = logit_of(tid);
-  __syncthreads();
-
-  const uint2 key = make_uint2(a.seed_lo, a.seed_hi);
-  const int nblk = (N + 3) >> 2;
+  // it = -1: cache of the initial spins; 0..n_steps-1: mc_steps; n_steps: exact cache of the
+  // final spins (all three share one instance of build/forward)
   unsigned int n_acc = 0;
-  const bool dbg = a.dbg_up != nullptr;
-  const long long n_iter = dbg ? 1 : a.n_steps;
-
-  for (long long it = 0; it < n_iter; ++it) {
-    const unsigned long long step = a.step0 + (unsigned long long)it;
-    // ---- proposals
-    if (a.inj_up) {
-      if (tid < 16) {
-        const int gc = chain0 + tid;
-        const bool ok = gc < a.B;
-        s_iup[tid] = ok ? a.inj_up[gc] : 0;
-        s_idn[tid] = ok ? a.inj_dn[gc] : 1;
-        s_u[tid] = ok ? a.inj_u[gc] : 2.f;
-      }
+  unsigned long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+#define SWEEP_STAMP(k) \
+  if (STAMP) { const unsigned long long t1_ = vmc_stamp(); if (is_step) cyc[k] += t1_ - t0; t0 = t1_; }
+  for (long long it = -1; it <= a.n_steps; ++it) {
+    const bool is_step = it >= 0 && it < a.n_steps;
+    if (STAMP) t0 = vmc_stamp();
+    if (is_step) {
+      proposals(a.step0 + (unsigned long long)it);
     } else {
-      const int c = wave * 4 + g, sub = j;
-      const uint32_t gid = (uint32_t)(a.chain_offset + chain0 + c);
-      float vmax = -3.f, vmin = 3.f;
-      int imax = 0x7fffffff, imin = 0x7fffffff;
-      for (int blk = sub; blk < nblk; blk += 16) {
-        const uint4 r = philox4x32_10(
-            make_uint4((uint32_t)blk, gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
-        const f32x4 sp = *(const f32x4*)(s_spin + c * Nst + 4 * blk);
-        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = 4 * blk + e;
-          if (n < N) {
-            const float v = sp[e] * u32_to_uniform(rr[e]);
-            if (v > vmax) { vmax = v; imax = n; }
-            if (v < vmin) { vmin = v; imin = n; }
-          }
-        }
-      }
-#pragma unroll
-      for (int m = 1; m < 16; m <<= 1) {
-        const float ov = __shfl_xor(vmax, m); const int oi = __shfl_xor(imax, m);
-        if (ov > vmax || (ov == vmax && oi < imax)) { vmax = ov; imax = oi; }
-        const float pv = __shfl_xor(vmin, m); const int pi = __shfl_xor(imin, m);
-        if (pv < vmin || (pv == vmin && pi < imin)) { vmin = pv; imin = pi; }
-      }
-      if (sub == 0) {
-        const uint4 r = philox4x32_10(
-            make_uint4(VMC_ACCEPT_BLOCK, gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
-        s_iup[c] = imax;   // argmax of s*u: the UP spin to lower   (graph_builders.py:64-65)
-        s_idn[c] = imin;   // argmin of s*u: the DOWN spin to raise (graph_builders.py:62-63)
-        s_u[c] = u32_to_uniform(r.x);
-      }
+      if (tid < 16) { s_sel[tid] = 0; s_pacc[tid] = 0; }
+      z1_direct();
     }
+    SWEEP_STAMP(0)
     __syncthreads();
-    if (dbg) {
-      if (tid < 16 && chain0 + tid < a.B) {
-        a.dbg_up[chain0 + tid] = s_iup[tid];
-        a.dbg_dn[chain0 + tid] = s_idn[tid];
-        a.dbg_u[chain0 + tid] = s_u[tid];
-      }
-      break;
-    }
-    // ---- candidate amplitude
-    build(true);
-    forward();
-    // ---- Metropolis accept (graph_builders.py:75-88)
+    SWEEP_STAMP(1)
+    build(is_step);
+    SWEEP_STAMP(2)
+    const unsigned long long next_step = a.step0 + (unsigned long long)(it + 1);
+    const bool pre_here = use_pref && n_hidden > 0;
+    if (n_hidden > 0) forward(next_step);
+    if (use_pref && !pre_here) draw_all(next_step);
+    SWEEP_STAMP(3)
+    output_dot();
+    SWEEP_STAMP(4)
     if (tid < 16) {
       const int c = tid, gc = chain0 + c;
       const float ln = logit_of(c);
-      const bool acc = (gc < a.B) && (expf(ln - s_logit[c]) > sqrtf(s_u[c]));
-      if (acc) {
+      if (is_step) {
+        // Metropolis accept (graph_builders.py:75-88)
+        const bool acc = (gc < a.B) && (expf(ln - s_logit[c]) > sqrtf(s_u[c]));
+        if (acc) {
+          s_logit[c] = ln;
+          s_spin[c * Nst + s_idn[c]] = 1.f;
+          s_spin[c * Nst + s_iup[c]] = -1.f;
+          if (!W1L) s_sel[c] ^= 1;
+          ++n_acc;
+        }
+        if (W1L) { s_pacc[c] = acc ? 1 : 0; s_pup[c] = s_iup[c]; s_pdn[c] = s_idn[c]; }
+        if (a.acc_mask && gc < a.B) a.acc_mask[gc] = acc ? 1 : 0;
+      } else {
         s_logit[c] = ln;
-        s_spin[c * Nst + s_idn[c]] = 1.f;
-        s_spin[c * Nst + s_iup[c]] = -1.f;
-        s_sel[c] ^= 1;
-        ++n_acc;
       }
-      if (a.acc_mask && gc < a.B) a.acc_mask[gc] = acc ? 1 : 0;
     }
+    SWEEP_STAMP(5)
     __syncthreads();
+    SWEEP_STAMP(6)
+  }
+#undef SWEEP_STAMP
+  if (STAMP && a.dbg_cycles && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a.dbg_cycles[((long long)blockIdx.x * 4 + wave) * 8 + k] = cyc[k];
   }
 
-  if (!dbg) {
-    // ---- exact cache for the final spins, then write back
-    __syncthreads();
-    if (tid < 16) s_sel[tid] = 0;
-    z1_direct();
-    __syncthreads();
-    build(false);
-    forward();
-    if (tid < 16 && chain0 + tid < a.B) a.logit[chain0 + tid] = logit_of(tid);
-    for (int i = tid; i < 16 * N; i += 256) {
-      const int c = i / N, n = i % N, gc = chain0 + c;
-      if (gc < a.B) a.configs[(long long)gc * N + n] = s_spin[c * Nst + n];
-    }
-    for (int i = tid; i < 16 * Hp; i += 256) {
-      const int c = i / Hp, col = i % Hp, gc = chain0 + c;
-      if (gc < a.B) a.z1[(long long)gc * Hp + col] = s_z1[c * ZS + col];
-    }
-    if (tid < 16 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);
+  // write back chains and the exact cache
+  if (tid < 16 && chain0 + tid < a.B) a.logit[chain0 + tid] = s_logit[tid];
+  for (int i = tid; i < 16 * N; i += 256) {
+    const int c = i / N, n = i % N, gc = chain0 + c;
+    if (gc < a.B) a.configs[(long long)gc * N + n] = s_spin[c * Nst + n];
   }
+  for (int i = tid; i < 16 * Hp; i += 256) {
+    const int c = i / Hp, col = i % Hp, gc = chain0 + c;
+    if (gc < a.B) a.z1[(long long)gc * Hp + col] = s_z1[c * ZS + col];
+  }
+  if (tid < 16 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);
 }
 
-static size_t sweep_lds_bytes(int N, int Hp) {
+static size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l) {
   const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
-  return sizeof(float) * (size_t)(16 * Nst + 2 * 16 * ZS + 2 * NT * 256 + 64 + 16 + 16 + 48);
+  return sizeof(float) * (size_t)(16 * Nst + (w1l ? 1 : 2) * 16 * ZS + 2 * NT * 256 + 64 + 16 +
+                                  16 + 6 * 16 + Hp + n_hidden * Hp + (w1l ? N * (Hp + 4) : 0));
+}
+
+template <int NT>
+static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
+  const dim3 grid((a.B + 15) / 16), block(256);
+  const size_t lds_full = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, true);
+  const bool w1l = lds_full <= 160 * 1024;
+  const size_t lds = w1l ? lds_full : sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const void* fn;
+  if (a.dbg_cycles) fn = w1l ? (const void*)k_sweep16<NT, true, true> : (const void*)k_sweep16<NT, true, false>;
+  else fn = w1l ? (const void*)k_sweep16<NT, false, true> : (const void*)k_sweep16<NT, false, false>;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  if (a.dbg_cycles) {
+    if (w1l) hipLaunchKernelGGL((k_sweep16<NT, true, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((k_sweep16<NT, true, false>), grid, block, lds, s, a);
+  } else {
+    if (w1l) hipLaunchKernelGGL((k_sweep16<NT, false, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((k_sweep16<NT, false, false>), grid, block, lds, s, a);
+  }
+  return hipGetLastError();
 }
 
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp) {
   if (a.B <= 0) return hipSuccess;
-  const dim3 grid((a.B + 15) / 16), block(256);
-  const size_t lds = sweep_lds_bytes(a.N, Hp);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-#define SWEEP_CASE(NT_)                                                                       \
-  case NT_: {                                                                                 \
-    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT_>,                           \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return e;                                                            \
-    hipLaunchKernelGGL((k_sweep16<NT_>), grid, block, lds, s, a);                             \
-    break;                                                                                    \
-  }
   switch (Hp / 16) {
-    SWEEP_CASE(4)
-    SWEEP_CASE(8)
-    SWEEP_CASE(12)
-    SWEEP_CASE(16)
+    case 4: return launch_sweep16_t<4>(s, a);
+    case 8: return launch_sweep16_t<8>(s, a);
+    case 12: return launch_sweep16_t<12>(s, a);
+    case 16: return launch_sweep16_t<16>(s, a);
     default: return hipErrorInvalidValue;
   }
-#undef SWEEP_CASE
-  return hipGetLastError();
 }

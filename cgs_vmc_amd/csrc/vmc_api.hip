@@ -509,6 +509,37 @@ int vmc_debug_proposals(vmc_ctx* c, uint64_t step, int32_t* i_up, int32_t* i_dn,
   return VMC_OK;
 }
 
+int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
+  CHECK_CTX(c);
+  if (n_steps < 1 || !phase_cycles) return fail(c, VMC_ERR_INVALID, "bad arguments");
+  PROPAGATE(ensure_packed(c, 0));
+  const int grid = (c->B + 15) / 16;
+  unsigned long long* d = nullptr;
+  HIPCHK(c, dalloc(&d, (long long)grid * 32));
+  HIPCHK(c, hipMemsetAsync(d, 0, (size_t)grid * 32 * sizeof(unsigned long long), c->stream));
+  SweepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pp = c->ps[0].packed();
+  a.configs = c->configs; a.z1 = c->ps[0].z1; a.logit = c->ps[0].logit;
+  a.accepted = c->d_accepted; a.dbg_cycles = d;
+  a.B = c->B; a.N = c->N; a.n_hidden = c->L - 1; a.chain_offset = c->d.chain_offset;
+  a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
+  a.step0 = c->step; a.n_steps = n_steps;
+  HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
+  c->step += (unsigned long long)n_steps;
+  c->ps[0].cache_valid = true; c->ps[1].cache_valid = false; c->list_valid = false;
+  std::vector<unsigned long long> h((size_t)grid * 32);
+  HIPCHK(c, hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  hipFree(d);
+  for (int k = 0; k < 8; ++k) {
+    double s = 0.0;
+    for (int i = 0; i < grid * 4; ++i) s += (double)h[(size_t)i * 8 + k];
+    phase_cycles[k] = s / ((double)grid * 4.0 * (double)n_steps);
+  }
+  return VMC_OK;
+}
+
 int vmc_get_step_counter(vmc_ctx* c, uint64_t* step) { CHECK_CTX(c); if (!step) return fail(c, VMC_ERR_INVALID, "null"); *step = c->step; return VMC_OK; }
 int vmc_set_step_counter(vmc_ctx* c, uint64_t step) { CHECK_CTX(c); c->step = step; return VMC_OK; }
 

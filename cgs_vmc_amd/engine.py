@@ -156,6 +156,14 @@ class VmcEngine:
                                               _fptr(u)))
     return i_up, i_dn, u
 
+  def debug_sweep_profile(self, n_steps: int):
+    """Mean shader cycles per mc_step of the sweep kernel's phases (diagnostic build)."""
+    out = (C.c_double * 8)()
+    self._check(self._lib.vmc_debug_sweep_profile(self._ctx, int(n_steps), out))
+    names = ('proposals', 'barrier0', 'build_z1', 'hidden_layers', 'output_dot', 'accept',
+             'barrier1', 'unused')
+    return dict(zip(names, [float(x) for x in out]))
+
   @property
   def step_counter(self) -> int:
     v = C.c_uint64()
