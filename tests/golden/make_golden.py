@@ -1,0 +1,84 @@
+"""Generates tests/golden/vmc_small.npz from the numpy oracle (oracle/vmc_oracle.py).
+
+PROVENANCE: the reference (TensorFlow 1.x + Sonnet) cannot be imported in the build
+container, so NO vector in this file originates from the reference's code; they are the
+oracle's float64 outputs on fixed seeded inputs.  The oracle itself is pinned
+by tests/test_oracle_physics.py (closed forms, exact diagonalisation, autograd, finite
+differences) and tests/test_oracle_rng.py (Random123 known answers).
+
+  python tests/golden/make_golden.py        # rewrites vmc_small.npz
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import vmc_oracle as vo  # noqa: E402
+
+CASES = {
+    # name: (n_sites, H, L, B, bonds)
+    'chain16': (16, 32, 2, 64, vo.chain_bonds(16)),          # BASELINE config 1 (default chain)
+    'torus4x4': (16, 32, 2, 64, vo.torus_bonds(4, 4)),       # BASELINE config 1 (J.txt torus)
+    'torus6x6': (36, 64, 3, 48, vo.torus_bonds(6, 6)),       # BASELINE config 2 lattice, 3 layers
+}
+SEED, JX, JZ, BETA = 2024, -1.0, 1.0, 0.12
+
+
+def build_case(name):
+  n, h, L, b, bonds = CASES[name]
+  rng = np.random.default_rng(abs(hash(name)) % 1000 + 11) if False else np.random.default_rng(
+      {'chain16': 11, 'torus4x4': 12, 'torus6x6': 13}[name])
+  theta = vo.init_params(n, h, L, rng)
+  theta = (theta + 0.05 * rng.standard_normal(theta.size)).astype(np.float32)
+  theta_w = (theta + 0.02 * rng.standard_normal(theta.size)).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(7))
+  f64 = np.float64
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=f64)
+  out = dict(theta=theta, theta_omega=theta_w, configs=cfg,
+             bonds=np.asarray(bonds, np.int32), shape=np.array([n, h, L, b]),
+             seed=np.array([SEED]), couplings=np.array([JX, JZ, BETA]))
+  out['logit'] = vo.fc_logit(theta, cfg, h, L, dtype=f64)
+  diag, off = vo.heisenberg_build(amp, cfg, bonds, JX, JZ, f64)
+  out['diag'], out['offdiag_over_psi'] = diag, off / amp(cfg)
+  out['eloc'] = diag + off / amp(cfg)
+  # proposals + one injected step per listed absolute step
+  steps = np.array([0, 1, 5, 123456789012], np.uint64)
+  ups, dns, us, accs, ratios = [], [], [], [], []
+  for s in steps:
+    u_sites, u_acc = vo.step_uniforms(SEED, np.arange(b), int(s), n)
+    i_up, i_dn = vo.propose_exchange(cfg, u_sites)
+    _, acc, ratio = vo.mc_step(amp, cfg, i_up, i_dn, u_acc)
+    ups.append(i_up); dns.append(i_dn); us.append(u_acc); accs.append(acc); ratios.append(ratio)
+  out.update(steps=steps, i_up=np.array(ups, np.int32), i_dn=np.array(dns, np.int32),
+             u_accept=np.array(us, np.float32), accept=np.array(accs), ratio=np.array(ratios))
+  # 3 sweeps of the sampler from the oracle (chains after, for the statistically exact part
+  # of the trajectory see tests)
+  acc_eg = vo.Accumulators(theta.size, f64)
+  vo.energy_gradient_accumulate(acc_eg, theta, cfg, bonds, JX, JZ, -10.0, h, L, f64)
+  out['eg_g1'], out['eg_g2'] = acc_eg.g1_total, acc_eg.g2_total
+  out['eg_scalars'] = np.array([acc_eg.e_total, acc_eg.e_count, acc_eg.g_count])
+  out['eg_grad'] = vo.energy_gradient(acc_eg)
+  st = vo.AdamState(theta.size)
+  out['eg_theta_after_adam'] = vo.adam_apply(st, theta, out['eg_grad'], 1e-3, 0.9, 0.99, 1e-8)
+  acc_it = vo.Accumulators(theta.size, f64)
+  vo.log_overlap_accumulate(acc_it, theta, theta_w, cfg, bonds, JX, JZ, -9.0, -10.0, BETA, h, L, f64)
+  out['it_g1'], out['it_g2'] = acc_it.g1_total, acc_it.g2_total
+  out['it_scalars'] = np.array([acc_it.e_total, acc_it.e_count, acc_it.r_total, acc_it.r_count])
+  out['it_grad'] = vo.log_overlap_gradient(acc_it)
+  return out
+
+
+def main():
+  data = {}
+  for name in CASES:
+    for k, v in build_case(name).items():
+      data['{}/{}'.format(name, k)] = v
+  path = os.path.join(HERE, 'vmc_small.npz')
+  np.savez_compressed(path, **data)
+  print('wrote', path, os.path.getsize(path), 'bytes')
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,109 @@
+"""GPU: BASELINE.json's full-size configurations through size-independent properties
+(the oracle is too slow there, so it is only used on a few sampled chains)."""
+import numpy as np
+import pytest
+
+from oracle import vmc_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+FULL = {
+    'config2_6x6_h128_b1024': (6, 6, 3, 128, 1024),
+    'config3_10x10_h256_b4096': (10, 10, 3, 256, 4096),
+}
+
+
+def _setup(name, seed=2024, chains=None, offset=0):
+  import bench
+  from cgs_vmc_amd.engine import VmcEngine
+  lx, ly, L, h, b = FULL[name]
+  n = lx * ly
+  theta, cfg = bench.make_inputs(n, h, L, b, 0)
+  bonds = vo.torus_bonds(lx, ly)
+  if chains is not None:
+    cfg = cfg[offset:offset + chains]
+    b = chains
+  eng = VmcEngine(n, b, L, h, seed=seed, chain_offset=offset)
+  eng.set_params(theta)
+  eng.set_configs(cfg)
+  eng.set_bonds(bonds, -1.0, 1.0)
+  return eng, theta, cfg, bonds, (n, h, L, b)
+
+
+@pytest.mark.parametrize('name', sorted(FULL))
+def test_sweeps_conserve_sz_are_deterministic_and_shard_invariant(name):
+  eng, theta, cfg, bonds, (n, h, L, b) = _setup(name)
+  acc = eng.mc_steps(2 * n)
+  out = eng.get_configs()
+  assert (np.abs(out) == 1).all() and (out.sum(1) == cfg.sum(1)).all()
+  assert 0.02 < acc / (2.0 * n * b) < 0.98
+  # same seed, same inputs -> bit-identical chains, logits and energies
+  eng2, *_ = _setup(name)
+  eng2.mc_steps(2 * n)
+  np.testing.assert_array_equal(eng2.get_configs(), out)
+  np.testing.assert_array_equal(eng2.amplitude()[0], eng.amplitude()[0])
+  np.testing.assert_array_equal(eng2.local_energy()[0], eng.local_energy()[0])
+  # a shard (second half of the chains, RNG keyed by global chain id) walks the same chains
+  half, *_ = _setup(name, chains=b // 2, offset=b // 2)
+  half.mc_steps(2 * n)
+  np.testing.assert_array_equal(half.get_configs(), out[b // 2:])
+  # cache written back by the sweep kernel == amplitudes recomputed from the chains
+  logit_cached = eng.amplitude()[0]
+  logit_fresh = eng.amplitude(out)[0]
+  assert np.abs(logit_cached - logit_fresh).max() < 2e-5 * max(1.0, np.abs(logit_fresh).max())
+  # spot-check against the oracle (fp64) on 48 chains
+  idx = np.random.default_rng(0).choice(b, 48, replace=False)
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+  ref = vo.fc_logit(theta, out[idx], h, L, dtype=np.float64)
+  assert np.abs(logit_cached[idx] - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+  e_ref = vo.local_value(amp, out[idx], bonds, -1.0, 1.0, dtype=np.float64)
+  e = eng.local_energy()[0]
+  assert np.abs(e[idx] - e_ref).max() < 2e-4 * max(1.0, np.abs(e_ref).max())
+  for x in (eng, eng2, half):
+    x.close()
+
+
+@pytest.mark.parametrize('name', sorted(FULL))
+def test_constant_wavefunction_closed_form_at_full_size(name):
+  eng, theta, cfg, bonds, (n, h, L, b) = _setup(name)
+  eng.set_params(np.zeros_like(theta))
+  eng.set_bonds(bonds, 0.6, 1.0)
+  np.testing.assert_allclose(eng.local_energy()[0],
+                             vo.constant_psi_local_energy(cfg, bonds, 0.6, 1.0), rtol=1e-6)
+  eng.close()
+
+
+@pytest.mark.parametrize('name', sorted(FULL))
+def test_accumulators_are_additive_over_calls_and_shards(name):
+  from cgs_vmc_amd import _hip
+  eng, theta, cfg, bonds, (n, h, L, b) = _setup(name)
+  p = theta.size
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  one = eng.get_accumulators().astype(np.float64)
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)          # same chains again: totals double
+  two = eng.get_accumulators().astype(np.float64)
+  np.testing.assert_allclose(two[:2 * p], 2 * one[:2 * p], rtol=1e-6, atol=1e-6 * np.abs(one).max())
+  assert two[2 * p + 1] == 2 * b and two[2 * p + 4] == 2
+  # shards: sum of the two halves' accumulators == whole batch (fp32 re-association only)
+  parts = []
+  for off in (0, b // 2):
+    sh, *_ = _setup(name, chains=b // 2, offset=off)
+    sh.reset_accumulators()
+    sh.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+    parts.append(sh.get_accumulators().astype(np.float64))
+    sh.close()
+  tot = parts[0] + parts[1]
+  scale = np.abs(one[:2 * p]).max()
+  assert np.abs(tot[:2 * p] - one[:2 * p]).max() < 1e-4 * scale
+  assert abs(tot[2 * p] - one[2 * p]) < 1e-4 * abs(one[2 * p]) and tot[2 * p + 1] == b
+  # gradient against the oracle on a 64-chain subset engine (same code path, smaller batch)
+  sub, *_ = _setup(name, chains=64, offset=0)
+  sub.reset_accumulators()
+  sub.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  acc = vo.Accumulators(p, np.float64)
+  vo.energy_gradient_accumulate(acc, theta, cfg[:64], bonds, -1.0, 1.0, -10.0, h, L, np.float64)
+  g = sub.get_gradient(_hip.VMC_MODE_ENERGY_GRADIENT)
+  gref = vo.energy_gradient(acc)
+  assert np.abs(g - gref).max() < 2e-3 * np.abs(gref).max() + 2e-4
+  sub.close(); eng.close()

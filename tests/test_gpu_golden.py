@@ -1,0 +1,93 @@
+"""GPU: the HIP path against the committed golden vectors (tests/golden/vmc_small.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = ['chain16', 'torus4x4', 'torus6x6']
+
+
+def _load(name):
+  gold = np.load(os.path.join(HERE, 'golden', 'vmc_small.npz'))
+  return {k.split('/', 1)[1]: gold[k] for k in gold.files if k.startswith(name + '/')}
+
+
+def _engine(g):
+  from cgs_vmc_amd.engine import VmcEngine
+  n, h, L, b = [int(x) for x in g['shape']]
+  eng = VmcEngine(n, b, L, h, seed=int(g['seed'][0]))
+  eng.set_params(g['theta'])
+  eng.set_configs(g['configs'])
+  jx, jz, _ = g['couplings']
+  eng.set_bonds(g['bonds'], jx, jz)
+  return eng
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_amplitudes_and_local_energy(name):
+  g = _load(name)
+  eng = _engine(g)
+  logit, _ = eng.amplitude()
+  assert np.abs(logit - g['logit']).max() < 2e-5 * max(1.0, np.abs(g['logit']).max())
+  eloc, mean = eng.local_energy()
+  assert np.abs(eloc - g['eloc']).max() < 2e-4 * max(1.0, np.abs(g['eloc']).max())
+  diag, off = eng.local_energy_terms()
+  np.testing.assert_allclose(diag, g['diag'], atol=1e-5)
+  assert np.abs(off - g['offdiag_over_psi']).max() < 2e-4 * max(1.0, np.abs(g['offdiag_over_psi']).max())
+  assert abs(mean - g['eloc'].mean()) < 2e-4 * max(1.0, abs(g['eloc'].mean()))
+  eng.close()
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_proposals_and_accepts(name):
+  g = _load(name)
+  for k, step in enumerate(g['steps']):
+    eng = _engine(g)
+    i_up, i_dn, u = eng.debug_proposals(int(step))
+    np.testing.assert_array_equal(i_up, g['i_up'][k])          # integer work: bit-exact
+    np.testing.assert_array_equal(i_dn, g['i_dn'][k])
+    np.testing.assert_array_equal(u, g['u_accept'][k])
+    mask = eng.mc_step_injected(g['i_up'][k], g['i_dn'][k], g['u_accept'][k])
+    ratio = g['ratio'][k]
+    band = np.abs(ratio - np.sqrt(g['u_accept'][k].astype(np.float64))) < 1e-4 * np.maximum(ratio, 1e-30)
+    np.testing.assert_array_equal(mask[~band], g['accept'][k][~band])
+    eng.close()
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_gradient_accumulators_and_adam(name):
+  from cgs_vmc_amd import _hip
+  g = _load(name)
+  eng = _engine(g)
+  p = g['theta'].size
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  acc = eng.get_accumulators()
+  for got, ref in ((acc[:p], g['eg_g1']), (acc[p:2 * p], g['eg_g2'])):
+    assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max() + 1e-4
+  assert abs(acc[2 * p] - g['eg_scalars'][0]) < 2e-4 * max(1, abs(g['eg_scalars'][0]))
+  assert acc[2 * p + 1] == g['eg_scalars'][1] and acc[2 * p + 4] == g['eg_scalars'][2]
+  grad = eng.get_gradient(_hip.VMC_MODE_ENERGY_GRADIENT)
+  assert np.abs(grad - g['eg_grad']).max() < 2e-3 * np.abs(g['eg_grad']).max() + 2e-4
+  # the Adam step itself, from the golden gradient's accumulators (b_out excluded: its
+  # gradient is identically zero and Adam turns rounding noise into +-lr, see test_gpu_api)
+  eng.apply_adam(_hip.VMC_MODE_ENERGY_GRADIENT, 1e-3, 0.9, 0.99, 1e-8)
+  th = eng.get_params()
+  moved = np.abs(g['eg_grad']) > 50 * (2e-3 * np.abs(g['eg_grad']).max() + 2e-4)
+  np.testing.assert_allclose(th[:-1][moved[:-1]], g['eg_theta_after_adam'][:-1][moved[:-1]], atol=2e-5)
+  # LogOverlapITSWO accumulators
+  eng.set_params(g['theta'])
+  eng.set_params(g['theta_omega'], _hip.VMC_OMEGA)
+  eng.set_shift(-9.0)
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_LOG_OVERLAP_ITSWO, float(g['couplings'][2]))
+  acc = eng.get_accumulators()
+  for got, ref in ((acc[:p], g['it_g1']), (acc[p:2 * p], g['it_g2'])):
+    assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max() + 1e-4
+  assert abs(acc[2 * p] - g['it_scalars'][0]) < 2e-4 * max(1, abs(g['it_scalars'][0]))
+  assert abs(acc[2 * p + 2] - g['it_scalars'][2]) < 2e-4 * max(1, abs(g['it_scalars'][2]))
+  grad = eng.get_gradient(_hip.VMC_MODE_LOG_OVERLAP_ITSWO)
+  assert np.abs(grad - g['it_grad']).max() < 2e-3 * np.abs(g['it_grad']).max() + 2e-4
+  eng.close()
