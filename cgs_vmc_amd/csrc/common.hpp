@@ -66,6 +66,8 @@ struct TailArgs {
   const int* n_rows_dev;    // device row count (list mode) or nullptr
   int n_rows;               // host row count / upper bound
   int n_hidden;             // L-1
+  int n_sites;              // N (rows of W1)
+  int num_cus;              // CUs of the device (persistent grid size)
   float* out;               // [n_rows]
 };
 

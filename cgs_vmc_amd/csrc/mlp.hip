@@ -134,115 +134,272 @@ hipError_t launch_z1(hipStream_t s, const float* configs, const float* w1p, cons
 template <int HT, bool RATIO>
 __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
   constexpr int Hp = HT * 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // per-wave staging of the NEXT tile's first-layer activations: [wave][4*HT][64 lanes][4]
+  extern __shared__ float s_stage[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, j = lane & 31;
+  f32x4* stage = (f32x4*)s_stage + wave * (4 * HT) * 64 + lane;
   const int n_rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
-  const int wrow0 = blockIdx.x * 128 + wave * 32;
-  if (wrow0 >= n_rows) return;  // wave-uniform; no barriers below
-  const int row = wrow0 + j;
-  const bool valid = row < n_rows;
-  int chain = 0, bs = 0;
-  if (valid) {
-    if (a.rowinfo) {
-      const int2 ri = a.rowinfo[row];
-      chain = ri.x; bs = ri.y;
-    } else {
-      chain = row;
-    }
-  }
-  // rank-2 exchange update of the first layer: z1' = z1 + coef (W1[i] - W1[j])
-  float coef = 0.f;
-  int bond = 0;
-  const float* wa = a.pp.w1p;
-  const float* wb = a.pp.w1p;
-  if (bs != 0) {
-    bond = (bs > 0 ? bs : -bs) - 1;
-    coef = bs > 0 ? -2.f : 2.f;           // -2 * s_i
-    const int2 ab = a.bonds[bond];
-    wa = a.pp.w1p + (long long)ab.x * Hp;
-    wb = a.pp.w1p + (long long)ab.y * Hp;
-  }
-  const float* zb = a.z1 + (long long)chain * Hp;
+  const int n_hidden = a.n_hidden;   // >= 1 (L = 1 goes through k_tail0)
+  const float bout = a.pp.bout[0];
 
+  // weight-fragment ring: item i of a layer lives in stage i % RD and is issued RD-1 items
+  // ahead of its use, across (to, ti), layer AND tile boundaries (the last layer prefetches the
+  // first items of layer 0 for the wave's next tile).  Every issue is unconditional so that
+  // vmcnt is counted exactly.
+  constexpr int NI = 4 * HT * HT, RD = 8;
+  f32x4 ring[RD];
+  // uniform (SGPR) base + one 32-bit per-lane byte offset -> saddr addressing, no per-item
+  // 64-bit VGPR address (LICM otherwise keeps ~100 of them live across the persistent loop)
+  const unsigned lane_off = (unsigned)lane * 16u;
+  const char* p32c = (const char*)a.pp.p32;   // re-made opaque every tile, see below
+  auto issue = [&](int l, int item) {
+    const char* base = p32c + ((size_t)l * Hp * Hp + (size_t)item * 256) * sizeof(float);
+    return *(const f32x4*)(base + lane_off);
+  };
+#pragma unroll
+  for (int i = 0; i < RD - 1; ++i) ring[i] = issue(0, i);
+
+  // row descriptor of this lane in a tile: cached z1 row of the chain + rank-2 exchange update
+  // z1' = z1 + coef (W1[i] - W1[j])
+  struct Desc { const float* zb; const float* wa; const float* wb; float coef; int row, chain, bond; bool valid; };
+  auto describe = [&](int tile) {
+    Desc d;
+    d.row = tile * 128 + wave * 32 + j;
+    d.valid = d.row < n_rows;
+    d.chain = 0; d.bond = 0; d.coef = 0.f;
+    int bs = 0;
+    if (d.valid) {
+      if (a.rowinfo) {
+        const int2 ri = a.rowinfo[d.row];
+        d.chain = ri.x; bs = ri.y;
+      } else {
+        d.chain = d.row;
+      }
+    }
+    d.wa = a.pp.w1p;
+    d.wb = d.wa;
+    if (bs != 0) {
+      d.bond = (bs > 0 ? bs : -bs) - 1;
+      d.coef = bs > 0 ? -2.f : 2.f;           // -2 * s_i
+      const int2 ab = a.bonds[d.bond];
+      d.wa += (long long)ab.x * Hp;
+      d.wb += (long long)ab.y * Hp;
+    }
+    d.zb = a.z1 + (long long)d.chain * Hp;
+    return d;
+  };
+  auto finish_row = [&](const Desc& d, float part) {
+    const float other = __shfl_xor(part, 32);
+    // fixed order: (half 0) + (half 1)
+    const float logit = (h == 0 ? part + other : other + part) + bout;
+    if (d.valid && h == 0) {
+      if (RATIO) a.out[d.row] = a.half_jx[d.bond] * expf(logit - a.logit_base[d.chain]);
+      else a.out[d.row] = logit;
+    }
+  };
+
+  // persistent: workgroup b handles row tiles b, b + gridDim.x, ...  The first tile's rows
+  // are gathered here; every later tile's rows are gathered underneath the previous tile's
+  // last layer into `stage` (LDS) and only re-read here.
+  int tile = blockIdx.x;
+  if (tile * 128 + wave * 32 >= n_rows) return;   // wave-uniform; no barriers in this kernel
+  Desc cur = describe(tile);
   f32x16 in[HT];
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int off = 32 * t + 8 * q + 4 * h;
-      const f32x4 z = *(const f32x4*)(zb + off);
-      const f32x4 x = *(const f32x4*)(wa + off);
-      const f32x4 y = *(const f32x4*)(wb + off);
+      const f32x4 z = *(const f32x4*)(cur.zb + off);
+      const f32x4 x = *(const f32x4*)(cur.wa + off);
+      const f32x4 y = *(const f32x4*)(cur.wb + off);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) in[t][4 * q + e] = fmaxf(fmaf(coef, x[e] - y[e], z[e]), 0.f);
+      for (int e = 0; e < 4; ++e) in[t][4 * q + e] = fmaxf(fmaf(cur.coef, x[e] - y[e], z[e]), 0.f);
     }
   }
 
-  for (int l = 0; l < a.n_hidden; ++l) {
-    const f32x4* __restrict__ wp = (const f32x4*)(a.pp.p32 + (long long)l * Hp * Hp);
-    const float* __restrict__ bl = a.pp.bh + l * Hp;
-    f32x16 out[HT];
+  for (;;) {
+    const int next_tile = tile + gridDim.x;
+    const bool has_next = next_tile * 128 + wave * 32 < n_rows;   // wave-uniform
+    // bias / w_out loads are tile-invariant; an opaque zero keeps LICM from hoisting ~256
+    // values out of the persistent loop (which would spill them)
+    int opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
+    asm volatile("" : "+s"(p32c));   // same for the ~100 per-item weight addresses
+
+    // ---- all but the last H x H layer: in -> out -> in
+    for (int l = 0; l + 1 < n_hidden; ++l) {
+      const float* __restrict__ bl = a.pp.bh + l * Hp + opaque0;
+      f32x16 out[HT];
+      f32x4 bias[4];
 #pragma unroll
-    for (int to = 0; to < HT; ++to) {
-      f32x16 acc;
+      for (int q = 0; q < 4; ++q) bias[q] = *(const f32x4*)(bl + 8 * q + 4 * h);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b = *(const f32x4*)(bl + 32 * to + 8 * q + 4 * h);
+      for (int to = 0; to < HT; ++to) {
+        f32x16 acc;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * q + e] = b[e];
-      }
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int ti = 0; ti < HT; ++ti) {
+          for (int e = 0; e < 4; ++e) acc[4 * q + e] = bias[q][e];
+        if (to + 1 < HT) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 w = wp[((to * HT + ti) * 4 + q) * 64 + lane];
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], in[ti][4 * q + e], acc, 0, 0, 0);
+          for (int q = 0; q < 4; ++q) bias[q] = *(const f32x4*)(bl + 32 * (to + 1) + 8 * q + 4 * h);
         }
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int item = (to * HT + ti) * 4 + q, nxt = item + RD - 1;
+            if (nxt < NI) ring[nxt % RD] = issue(l, nxt);
+            else ring[nxt % RD] = issue(l + 1, nxt - NI);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch RD-1 items ahead
+            const f32x4 w = ring[item % RD];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], in[ti][4 * q + e], acc, 0, 0, 0);
+          }
+        }
+        out[to] = acc;
       }
-      out[to] = acc;
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) in[t][r] = fmaxf(out[t][r], 0.f);
     }
+
+    // ---- last H x H layer fused with the output dot.  The 4*HT items of output tile `to`
+    // are cut into 4 segments; segment sg gathers register group sg of the NEXT tile's unit
+    // tile `to` (3 float4 in flight: loads at the segment's first item, arithmetic + LDS store
+    // at its last), so the gather runs in the shadow of the matrix pipe.
+    const Desc nxt_d = describe(has_next ? next_tile : tile);
+    float part = 0.f;
+    {
+      const int l = n_hidden - 1;
+      const float* __restrict__ bl = a.pp.bh + l * Hp + opaque0;
+      const float* __restrict__ wop = a.pp.woutp + opaque0;
+      f32x4 bias[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bias[q] = *(const f32x4*)(bl + 8 * q + 4 * h);
+#pragma unroll
+      for (int to = 0; to < HT; ++to) {
+        f32x4 wo[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wo[q] = *(const f32x4*)(wop + 32 * to + 8 * q + 4 * h);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[4 * q + e] = bias[q][e];
+        if (to + 1 < HT) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bias[q] = *(const f32x4*)(bl + 32 * (to + 1) + 8 * q + 4 * h);
+        }
+        f32x4 gz, gx, gy;
+#pragma unroll
+        for (int ti = 0; ti < HT; ++ti) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int it_in_to = ti * 4 + q, sg = it_in_to / HT;
+            if (it_in_to % HT == 0) {
+              const int off = 32 * to + 8 * sg + 4 * h;
+              gz = *(const f32x4*)(nxt_d.zb + off);
+              gx = *(const f32x4*)(nxt_d.wa + off);
+              gy = *(const f32x4*)(nxt_d.wb + off);
+            }
+            const int item = (to * HT + ti) * 4 + q, nxt = item + RD - 1;
+            if (nxt < NI) ring[nxt % RD] = issue(l, nxt);
+            else ring[nxt % RD] = issue(0, nxt - NI);          // next tile's first layer
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4 w = ring[item % RD];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], in[ti][4 * q + e], acc, 0, 0, 0);
+            if (it_in_to % HT == HT - 1) {
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(nxt_d.coef, gx[e] - gy[e], gz[e]), 0.f);
+              stage[(to * 4 + sg) * 64] = v;
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part = fmaf(fmaxf(acc[4 * q + e], 0.f), wo[q][e], part);
+      }
+    }
+    finish_row(cur, part);
+    if (!has_next) break;
+    tile = next_tile;
+    cur = nxt_d;
+    // the wave re-reads what it wrote itself (same lane, same address): no barrier needed
 #pragma unroll
     for (int t = 0; t < HT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) in[t][r] = fmaxf(out[t][r], 0.f);
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = stage[(t * 4 + q) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) in[t][4 * q + e] = v[e];
+      }
   }
+}
 
-  float part = 0.f;
-#pragma unroll
-  for (int t = 0; t < HT; ++t) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 w = *(const f32x4*)(a.pp.woutp + 32 * t + 8 * q + 4 * h);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) part = fmaf(in[t][4 * q + e], w[e], part);
+// L = 1 (no H x H layer): logit = relu(z1') . w_out + b_out, one thread per row
+template <bool RATIO>
+__global__ __launch_bounds__(256) void k_tail0(TailArgs a, int Hp) {
+  const int n_rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
+  for (int row = blockIdx.x * 256 + threadIdx.x; row < n_rows; row += gridDim.x * 256) {
+    int chain = row, bs = 0;
+    if (a.rowinfo) { const int2 ri = a.rowinfo[row]; chain = ri.x; bs = ri.y; }
+    const float* zb = a.z1 + (long long)chain * Hp;
+    const float* wa = a.pp.w1p;
+    const float* wb = wa;
+    float coef = 0.f;
+    int bond = 0;
+    if (bs != 0) {
+      bond = (bs > 0 ? bs : -bs) - 1;
+      coef = bs > 0 ? -2.f : 2.f;
+      const int2 ab = a.bonds[bond];
+      wa += (long long)ab.x * Hp; wb += (long long)ab.y * Hp;
     }
+    float s = 0.f;
+    for (int i = 0; i < Hp; ++i)
+      s = fmaf(fmaxf(fmaf(coef, wa[i] - wb[i], zb[i]), 0.f), a.pp.woutp[i], s);
+    const float logit = s + a.pp.bout[0];
+    a.out[row] = RATIO ? a.half_jx[bond] * expf(logit - a.logit_base[chain]) : logit;
   }
-  const float other = __shfl_xor(part, 32);
-  // fixed order: (half 0) + (half 1)
-  const float logit = (h == 0 ? part + other : other + part) + a.pp.bout[0];
-  if (valid && h == 0) {
-    if (RATIO) {
-      a.out[row] = a.half_jx[bond] * expf(logit - a.logit_base[chain]);
-    } else {
-      a.out[row] = logit;
-    }
-  }
+}
+
+template <int HT, bool RATIO>
+static hipError_t launch_tail32_h(hipStream_t s, const TailArgs& a) {
+  const int tiles = (a.n_rows + 127) / 128;
+  const int persistent = a.num_cus > 0 ? a.num_cus : 256;   // 1 workgroup per CU (1 wave/SIMD)
+  const dim3 grid(tiles < persistent ? tiles : persistent), block(256);
+  const size_t lds = (size_t)4 * (4 * HT) * 64 * sizeof(f32x4);
+  hipError_t e = hipFuncSetAttribute((const void*)k_tail32<HT, RATIO>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_tail32<HT, RATIO>), grid, block, lds, s, a);
+  return hipGetLastError();
 }
 
 template <bool RATIO>
 static hipError_t launch_tail32_t(hipStream_t s, const TailArgs& a, int Hp) {
   if (a.n_rows <= 0) return hipSuccess;
-  const dim3 grid((a.n_rows + 127) / 128), block(256);
+  if (a.n_hidden == 0) {
+    const int blocks = (a.n_rows + 255) / 256;
+    hipLaunchKernelGGL((k_tail0<RATIO>), dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, s, a, Hp);
+    return hipGetLastError();
+  }
   switch (Hp / 32) {
-    case 2: hipLaunchKernelGGL((k_tail32<2, RATIO>), grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((k_tail32<4, RATIO>), grid, block, 0, s, a); break;
-    case 6: hipLaunchKernelGGL((k_tail32<6, RATIO>), grid, block, 0, s, a); break;
-    case 8: hipLaunchKernelGGL((k_tail32<8, RATIO>), grid, block, 0, s, a); break;
+    case 2: return launch_tail32_h<2, RATIO>(s, a);
+    case 4: return launch_tail32_h<4, RATIO>(s, a);
+    case 6: return launch_tail32_h<6, RATIO>(s, a);
+    case 8: return launch_tail32_h<8, RATIO>(s, a);
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 
 hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode) {

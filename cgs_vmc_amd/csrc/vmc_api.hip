@@ -57,6 +57,7 @@ struct vmc_ctx {
   long long adam_t = 0;
   float* gemm_ws = nullptr;
   int splitk = 16;
+  int num_cus = 256;
   // scratch
   unsigned long long* d_accepted = nullptr;
   double* d_sum = nullptr;
@@ -153,6 +154,8 @@ TailArgs tail_args(vmc_ctx* c, int which) {
   a.bonds = c->bonds;
   a.half_jx = c->half_jx;
   a.n_hidden = c->L - 1;
+  a.n_sites = c->N;
+  a.num_cus = c->num_cus;
   return a;
 }
 
@@ -261,6 +264,11 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   c->Hp = (c->H + 63) / 64 * 64;
   c->P = vmc_num_params(c->N, c->H, c->L);
   c->stream = (hipStream_t)d->stream;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0)
+      c->num_cus = prop.multiProcessorCount;
+  }
   const long long B = c->B, N = c->N, Hp = c->Hp, P = c->P, L = c->L;
 #define CA(expr) do { hipError_t e2 = (expr); if (e2 != hipSuccess) { \
     g_create_error = std::string(#expr) + ": " + hipGetErrorString(e2); vmc_destroy(c); return VMC_ERR_HIP; } } while (0)
@@ -268,7 +276,9 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     ParamSet& p = c->ps[w];
     CA(dalloc(&p.theta, P));
     CA(dalloc(&p.w1p, N * Hp)); CA(dalloc(&p.b1p, Hp)); CA(dalloc(&p.bh, (L - 1) * Hp));
-    CA(dalloc(&p.p32, (L - 1) * Hp * Hp)); CA(dalloc(&p.p16, (L - 1) * Hp * Hp));
+    CA(dalloc(&p.p32, (L > 1 ? L - 1 : 1) * Hp * Hp)); CA(dalloc(&p.p16, (L > 1 ? L - 1 : 1) * Hp * Hp));
+    CA(hipMemsetAsync(p.p32, 0, (size_t)(L > 1 ? L - 1 : 1) * Hp * Hp * sizeof(float), c->stream));
+    CA(hipMemsetAsync(p.p16, 0, (size_t)(L > 1 ? L - 1 : 1) * Hp * Hp * sizeof(float), c->stream));
     CA(dalloc(&p.woutp, Hp)); CA(dalloc(&p.bout, 1));
     CA(dalloc(&p.z1, B * Hp)); CA(dalloc(&p.logit, B)); CA(dalloc(&p.eloc, B));
   }
