@@ -449,7 +449,9 @@ __device__ __forceinline__ unsigned long long vmc_stamp() {
 // rank-2 gather of two W1 rows per chain and step from an L2 round trip into LDS reads; the
 // accepted move is then folded into z1 lazily at the start of the next step instead of being
 // double-buffered.
-template <int NT, bool STAMP, bool W1L>
+// FAST: the production path (Philox draws prefetched, no injected proposals, no debug dump);
+// the general instantiation keeps every path.
+template <int NT, bool STAMP, bool W1L, bool FAST>
 __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   constexpr int Hp = NT * 16, TO = NT / 4, ZS = Hp + 4, W1S = Hp + 4, PF = SWEEP_PF;
   constexpr int RT = NT < SWEEP_RT ? NT : SWEEP_RT;   // k-tiles of the first H x H layer kept in registers
@@ -467,7 +469,8 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   int* s_pup = s_sel + 16;                    // [16] previous step's proposal / accept flag
   int* s_pdn = s_pup + 16;                    // [16]
   int* s_pacc = s_pdn + 16;                   // [16]
-  float* s_wout = (float*)(s_pacc + 16);      // [Hp]
+  float* s_hlu = (float*)(s_pacc + 16);       // [16] 0.5 log(u_accept)
+  float* s_wout = s_hlu + 16;                 // [Hp]
   float* s_bias = s_wout + Hp;                // [n_hidden][Hp] biases of the H x H layers
   float* s_w1 = s_bias + a.n_hidden * Hp;     // [N][W1S] (W1L only)
 
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   // blocks per lane, i.e. N <= 64*UPRE/... sites); only the argmax/argmin of s*u is left for
   // the start of the step.
   constexpr int UPRE = 2;                       // prefetched Philox blocks per lane
-  const bool use_pref = (nblk <= 16 * UPRE) && (a.inj_up == nullptr);
+  const bool use_pref = FAST || ((nblk <= 16 * UPRE) && (a.inj_up == nullptr));
   const int my_c = wave * 4 + g;
   const uint32_t my_gid = (uint32_t)(a.chain_offset + chain0 + my_c);
   float u_pre[4 * UPRE];
@@ -586,18 +589,20 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
       s_iup[my_c] = imax;   // argmax of s*u: the UP spin to lower   (graph_builders.py:64-65)
       s_idn[my_c] = imin;   // argmin of s*u: the DOWN spin to raise (graph_builders.py:62-63)
       s_u[my_c] = uacc;
+      s_hlu[my_c] = 0.5f * __logf(uacc);
     }
   };
 
   // proposals of absolute step `step` into s_iup / s_idn / s_u
   auto proposals = [&](unsigned long long step) {
-    if (a.inj_up) {
+    if (!FAST && a.inj_up) {
       if (tid < 16) {
         const int gc = chain0 + tid;
         const bool ok = gc < a.B;
         s_iup[tid] = ok ? a.inj_up[gc] : 0;
         s_idn[tid] = ok ? a.inj_dn[gc] : 1;
         s_u[tid] = ok ? a.inj_u[gc] : 2.f;
+        s_hlu[tid] = 0.5f * __logf(s_u[tid]);
       }
       return;
     }
@@ -623,6 +628,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
       reduce_and_publish(vmax, imax, vmin, imin, u_pre_acc);
       return;
     }
+    if (FAST) return;
     for (int blk = j; blk < nblk; blk += 16) {
       const uint4 r = philox4x32_10(
           make_uint4((uint32_t)blk, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
     reduce_and_publish(vmax, imax, vmin, imin, uacc);
   };
 
-  if (a.dbg_up != nullptr) {   // debug_proposals: dump the draw of step0, do not move
+  if (!FAST && a.dbg_up != nullptr) {   // debug_proposals: dump the draw of step0, do not move
     if (use_pref) draw_all(a.step0);
     proposals(a.step0);
     __syncthreads();
@@ -660,6 +666,12 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   }
 
   f32x4 own[TO];  // relu'd activations of this wave's own output tiles (B-operand layout)
+
+  // diagnostic stamps (STAMP instantiation only)
+  unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+  bool stamp_on = false;
+#define SWEEP_STAMP(k) \
+  if (STAMP) { const unsigned long long t1_ = vmc_stamp(); if (stamp_on) cyc[k] += t1_ - t0; t0 = t1_; }
 
   // builds the layer-2 input operand (and the candidate z1 when with_delta)
   auto build = [&](bool with_delta) {
@@ -748,7 +760,9 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
     // FS = first streamed k-tile of the layer (RT for layer 0, 0 afterwards)
     auto layer = [&](int l, auto fs_c) {
       constexpr int FS = decltype(fs_c)::value;
+      SWEEP_STAMP(FS > 0 ? 7 : 11)
       __syncthreads();
+      SWEEP_STAMP(FS > 0 ? 8 : 12)
       const f32x4* xin = (const f32x4*)(s_x + cur * NT * 256) + lane;
       f32x4 acc[TO];
 #pragma unroll
@@ -783,6 +797,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
         }
       }
       if (FS > 0) finish_draw(ca, cb, next_step);
+      if (FS > 0) { SWEEP_STAMP(9) }
       // streamed k-tiles: weights PF-1 tiles ahead, activations one tile ahead
       if (FS == 0) inb[0] = xin[0];
 #pragma unroll
@@ -799,6 +814,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
             acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[(ti - FS) % PF][to][r],
                                                            inb[ti & 1][r], acc[to], 0, 0, 0);
       }
+      SWEEP_STAMP(FS > 0 ? 10 : 13)
       float* xout = s_x + (cur ^ 1) * NT * 256;
 #pragma unroll
       for (int to = 0; to < TO; ++to) {
@@ -807,6 +823,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
         if (l + 1 < n_hidden) *(f32x4*)(xout + ((wave * TO + to) * 64 + lane) * 4) = own[to];
       }
       cur ^= 1;
+      SWEEP_STAMP(FS > 0 ? 11 : 14)
     };
     layer(0, std::integral_constant<int, RT>{});
     for (int l = 1; l < n_hidden; ++l) layer(l, std::integral_constant<int, 0>{});
@@ -832,17 +849,46 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   };
 
   // it = -1: cache of the initial spins; 0..n_steps-1: mc_steps; n_steps: exact cache of the
-  // final spins (all three share one instance of build/forward)
+  // final spins (all three share one instance of build/forward).
+  // The outcome of iteration it-1 is resolved at the TOP of iteration it by the wave that owns
+  // the chain (chains 4w..4w+3 -> wave w, all 16 lanes of a group redundantly, lane j == 0
+  // writes): that wave is the only reader of the chain's spins in `proposals`, so no barrier
+  // is needed between the Metropolis accept and the next proposal.
   unsigned int n_acc = 0;
-  unsigned long long cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
-#define SWEEP_STAMP(k) \
-  if (STAMP) { const unsigned long long t1_ = vmc_stamp(); if (is_step) cyc[k] += t1_ - t0; t0 = t1_; }
+  int prev_kind = 0;   // 0 none, 1 refresh, 2 step
+  auto resolve = [&]() {
+    if (prev_kind == 0) return;
+    const int c = my_c, gc = chain0 + c;
+    const float ln = logit_of(c);
+    if (prev_kind == 2) {
+      // Metropolis accept (graph_builders.py:75-88)
+      // exp(dlogit) > sqrt(u)  <=>  dlogit > 0.5 log(u)  (monotone; u = 0 always accepts)
+      const bool acc = (gc < a.B) && ((ln - s_logit[c]) > s_hlu[c]);
+      if (j == 0) {
+        if (acc) {
+          s_logit[c] = ln;
+          s_spin[c * Nst + s_idn[c]] = 1.f;
+          s_spin[c * Nst + s_iup[c]] = -1.f;
+          if (!W1L) s_sel[c] ^= 1;
+          ++n_acc;
+        }
+        if (W1L) { s_pacc[c] = acc ? 1 : 0; s_pup[c] = s_iup[c]; s_pdn[c] = s_idn[c]; }
+        if (!FAST && a.acc_mask && gc < a.B) a.acc_mask[gc] = acc ? 1 : 0;
+      }
+    } else if (j == 0) {
+      s_logit[c] = ln;
+    }
+  };
   for (long long it = -1; it <= a.n_steps; ++it) {
     const bool is_step = it >= 0 && it < a.n_steps;
+    stamp_on = is_step;
     if (STAMP) t0 = vmc_stamp();
+    resolve();
+    SWEEP_STAMP(5)
     if (is_step) {
       proposals(a.step0 + (unsigned long long)it);
     } else {
+      __syncthreads();   // z1_direct reads every chain's (possibly just updated) spins
       if (tid < 16) { s_sel[tid] = 0; s_pacc[tid] = 0; }
       z1_direct();
     }
@@ -858,33 +904,15 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
     SWEEP_STAMP(3)
     output_dot();
     SWEEP_STAMP(4)
-    if (tid < 16) {
-      const int c = tid, gc = chain0 + c;
-      const float ln = logit_of(c);
-      if (is_step) {
-        // Metropolis accept (graph_builders.py:75-88)
-        const bool acc = (gc < a.B) && (expf(ln - s_logit[c]) > sqrtf(s_u[c]));
-        if (acc) {
-          s_logit[c] = ln;
-          s_spin[c * Nst + s_idn[c]] = 1.f;
-          s_spin[c * Nst + s_iup[c]] = -1.f;
-          if (!W1L) s_sel[c] ^= 1;
-          ++n_acc;
-        }
-        if (W1L) { s_pacc[c] = acc ? 1 : 0; s_pup[c] = s_iup[c]; s_pdn[c] = s_idn[c]; }
-        if (a.acc_mask && gc < a.B) a.acc_mask[gc] = acc ? 1 : 0;
-      } else {
-        s_logit[c] = ln;
-      }
-    }
-    SWEEP_STAMP(5)
-    __syncthreads();
-    SWEEP_STAMP(6)
+    prev_kind = is_step ? 2 : 1;
   }
+  stamp_on = false;
+  resolve();          // logit of the final refresh
+  __syncthreads();
 #undef SWEEP_STAMP
   if (STAMP && a.dbg_cycles && lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a.dbg_cycles[((long long)blockIdx.x * 4 + wave) * 8 + k] = cyc[k];
+    for (int k = 0; k < 16; ++k) a.dbg_cycles[((long long)blockIdx.x * 4 + wave) * 16 + k] = cyc[k];
   }
 
   // write back chains and the exact cache
@@ -897,13 +925,13 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
     const int c = i / Hp, col = i % Hp, gc = chain0 + c;
     if (gc < a.B) a.z1[(long long)gc * Hp + col] = s_z1[c * ZS + col];
   }
-  if (tid < 16 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);
+  if (j == 0 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);
 }
 
 static size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l) {
   const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
   return sizeof(float) * (size_t)(16 * Nst + (w1l ? 1 : 2) * 16 * ZS + 2 * NT * 256 + 64 + 16 +
-                                  16 + 6 * 16 + Hp + n_hidden * Hp + (w1l ? N * (Hp + 4) : 0));
+                                  16 + 7 * 16 + Hp + n_hidden * Hp + (w1l ? N * (Hp + 4) : 0));
 }
 
 template <int NT>
@@ -913,19 +941,24 @@ static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
   const bool w1l = lds_full <= 160 * 1024;
   const size_t lds = w1l ? lds_full : sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  const void* fn;
-  if (a.dbg_cycles) fn = w1l ? (const void*)k_sweep16<NT, true, true> : (const void*)k_sweep16<NT, true, false>;
-  else fn = w1l ? (const void*)k_sweep16<NT, false, true> : (const void*)k_sweep16<NT, false, false>;
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  const int nblk = (a.N + 3) / 4;
+  const bool fast = nblk <= 32 && a.inj_up == nullptr && a.dbg_up == nullptr;
+#define SWEEP_LAUNCH(ST, WL, FA)                                                              \
+  do {                                                                                        \
+    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, ST, WL, FA>,                \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                            \
+    hipLaunchKernelGGL((k_sweep16<NT, ST, WL, FA>), grid, block, lds, s, a);                  \
+    return hipGetLastError();                                                                 \
+  } while (0)
   if (a.dbg_cycles) {
-    if (w1l) hipLaunchKernelGGL((k_sweep16<NT, true, true>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((k_sweep16<NT, true, false>), grid, block, lds, s, a);
-  } else {
-    if (w1l) hipLaunchKernelGGL((k_sweep16<NT, false, true>), grid, block, lds, s, a);
-    else hipLaunchKernelGGL((k_sweep16<NT, false, false>), grid, block, lds, s, a);
+    if (!(w1l && fast)) return hipErrorInvalidValue;   // diagnostic build: production variant only
+    SWEEP_LAUNCH(true, true, true);
   }
-  return hipGetLastError();
+  if (w1l) { if (fast) SWEEP_LAUNCH(false, true, true); else SWEEP_LAUNCH(false, true, false); }
+  if (fast) SWEEP_LAUNCH(false, false, true);
+  SWEEP_LAUNCH(false, false, false);
+#undef SWEEP_LAUNCH
 }
 
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp) {

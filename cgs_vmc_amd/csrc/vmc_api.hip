@@ -525,8 +525,8 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   PROPAGATE(ensure_packed(c, 0));
   const int grid = (c->B + 15) / 16;
   unsigned long long* d = nullptr;
-  HIPCHK(c, dalloc(&d, (long long)grid * 32));
-  HIPCHK(c, hipMemsetAsync(d, 0, (size_t)grid * 32 * sizeof(unsigned long long), c->stream));
+  HIPCHK(c, dalloc(&d, (long long)grid * 64));
+  HIPCHK(c, hipMemsetAsync(d, 0, (size_t)grid * 64 * sizeof(unsigned long long), c->stream));
   SweepArgs a;
   memset(&a, 0, sizeof(a));
   a.pp = c->ps[0].packed();
@@ -538,13 +538,13 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
   c->step += (unsigned long long)n_steps;
   c->ps[0].cache_valid = true; c->ps[1].cache_valid = false; c->list_valid = false;
-  std::vector<unsigned long long> h((size_t)grid * 32);
+  std::vector<unsigned long long> h((size_t)grid * 64);
   HIPCHK(c, hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(d);
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < 16; ++k) {
     double s = 0.0;
-    for (int i = 0; i < grid * 4; ++i) s += (double)h[(size_t)i * 8 + k];
+    for (int i = 0; i < grid * 4; ++i) s += (double)h[(size_t)i * 16 + k];
     phase_cycles[k] = s / ((double)grid * 4.0 * (double)n_steps);
   }
   return VMC_OK;

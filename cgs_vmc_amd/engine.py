@@ -158,10 +158,12 @@ class VmcEngine:
 
   def debug_sweep_profile(self, n_steps: int):
     """Mean shader cycles per mc_step of the sweep kernel's phases (diagnostic build)."""
-    out = (C.c_double * 8)()
+    out = (C.c_double * 16)()
     self._check(self._lib.vmc_debug_sweep_profile(self._ctx, int(n_steps), out))
-    names = ('proposals', 'barrier0', 'build_z1', 'hidden_layers', 'output_dot', 'accept',
-             'barrier1', 'unused')
+    # 3 'hidden_tail' = what of the hidden layers is not covered by the sub-phases 7..14
+    names = ('proposals', 'barrier0', 'build_z1', 'hidden_tail', 'output_dot', 'accept',
+             'barrier1', 'l0_ring_prologue', 'l0_barrier', 'l0_resident_mfma',
+             'l0_streamed_mfma', 'l0_epilogue', 'l1_barrier', 'l1_mfma', 'l1_epilogue', 'unused')
     return dict(zip(names, [float(x) for x in out]))
 
   @property

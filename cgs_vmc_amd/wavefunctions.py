@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import copy
 import inspect
+import os
 from typing import Any, Dict, List, Optional
 
 import numpy as np
@@ -19,6 +20,12 @@ from . import layers
 from . import session as session_lib
 
 _name_counts: Dict[str, int] = {}
+_init_counter = [0]
+
+
+def _init_count() -> int:
+  _init_counter[0] += 1
+  return _init_counter[0] - 1
 
 
 def _unique_name(name: str) -> str:
@@ -30,6 +37,7 @@ def _unique_name(name: str) -> str:
 
 def reset_name_scope():
   _name_counts.clear()
+  _init_counter[0] = 0
 
 
 class Wavefunction:
@@ -173,7 +181,9 @@ class FullyConnectedNetwork(Wavefunction):
 
   def _maybe_initialize(self):
     if self._n_sites is not None and self._get_theta(allow_none=True) is None:
-      self.initialize()
+      # unseeded like the reference unless CGS_VMC_INIT_SEED is set (tests, reproducible runs)
+      seed = os.environ.get('CGS_VMC_INIT_SEED')
+      self.initialize(None if seed is None else int(seed) + _init_count())
 
   def initialize(self, seed=None):
     """snt.Linear defaults: w ~ truncated normal(sigma = 1/sqrt(fan_in)), b = 0."""

@@ -108,9 +108,9 @@ int vmc_mc_step_injected(vmc_ctx* ctx, const int32_t* i_up, const int32_t* i_dn,
  * current chains (graph_builders.py:59-65), without moving. */
 int vmc_debug_proposals(vmc_ctx* ctx, uint64_t step, int32_t* i_up, int32_t* i_dn, float* u);
 /* Diagnostic: runs n_steps mc_steps through the s_memtime-stamped instantiation of the sweep
- * kernel and returns the mean shader cycles per step of 7 phases (proposals, barrier, z1'
- * build, hidden layers, output dot, accept, barrier).  Never quote its run time. */
-int vmc_debug_sweep_profile(vmc_ctx* ctx, int64_t n_steps, double* phase_cycles /*[8]*/);
+ * kernel and returns the mean shader cycles per step of up to 16 phases (see
+ * engine.debug_sweep_profile for their names).  Never quote its run time. */
+int vmc_debug_sweep_profile(vmc_ctx* ctx, int64_t n_steps, double* phase_cycles /*[16]*/);
 int vmc_get_step_counter(vmc_ctx* ctx, uint64_t* step);
 int vmc_set_step_counter(vmc_ctx* ctx, uint64_t step);
 
