@@ -460,8 +460,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   float* s_spin = smem;                       // [16][Nst]
   float* s_z1 = s_spin + 16 * Nst;            // [W1L ? 1 : 2][16][ZS]
   float* s_x = s_z1 + (W1L ? 1 : 2) * 16 * ZS;  // [2][NT][64][4]
-  float* s_part = s_x + 2 * NT * 256;         // [4][16]
-  float* s_logit = s_part + 64;               // [16]
+  float* s_logit = s_x + 2 * NT * 256;        // [16]
   float* s_u = s_logit + 16;                  // [16]
   int* s_iup = (int*)(s_u + 16);              // [16]
   int* s_idn = s_iup + 16;                    // [16]
@@ -480,6 +479,10 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   const int chain0 = blockIdx.x * 16;
   const PackedParams& pp = a.pp;
   const int n_hidden = a.n_hidden;
+  // [4 waves][16 chains] partials of the output dot live in the operand buffer the LAST layer does
+  // not read (free from the barrier at that layer's top until the next step's build, which
+  // comes after every reader of s_part has passed barrier0)
+  float* s_part = s_x + (n_hidden == 0 ? 1 : (n_hidden & 1)) * NT * 256;
 
   for (int i = tid; i < 16 * Nst; i += 256) {
     const int c = i / Nst, n = i % Nst, gc = chain0 + c;
@@ -575,13 +578,17 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
     finish_draw(philox4x32_10(ctr_a(step), key), philox4x32_10(ctr_b(step), key), step);
   };
 
+  // branch-free (v_cndmask) argmax / argmin combine with the first-index tie rule of
+  // tf.argmax / tf.argmin
   auto reduce_and_publish = [&](float vmax, int imax, float vmin, int imin, float uacc) {
 #define VMC_RED_STEP(CTRL)                                                            \
     {                                                                                 \
       const float ov = dpp_f<CTRL>(vmax); const int oi = dpp_i<CTRL>(imax);           \
-      if (ov > vmax || (ov == vmax && oi < imax)) { vmax = ov; imax = oi; }           \
+      const bool tmax = (ov > vmax) | ((ov == vmax) & (oi < imax));                   \
+      vmax = tmax ? ov : vmax; imax = tmax ? oi : imax;                               \
       const float pv = dpp_f<CTRL>(vmin); const int pi = dpp_i<CTRL>(imin);           \
-      if (pv < vmin || (pv == vmin && pi < imin)) { vmin = pv; imin = pi; }           \
+      const bool tmin = (pv < vmin) | ((pv == vmin) & (pi < imin));                   \
+      vmin = tmin ? pv : vmin; imin = tmin ? pi : imin;                               \
     }
     VMC_RED_STEP(DPP_XOR1) VMC_RED_STEP(DPP_XOR2) VMC_RED_STEP(DPP_HALF_MIRROR) VMC_RED_STEP(DPP_MIRROR)
 #undef VMC_RED_STEP
@@ -592,6 +599,11 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
       s_hlu[my_c] = 0.5f * __logf(uacc);
     }
   };
+  // validity of this lane's 4*UPRE prefetched sites (bit k <-> site 4*(j+16*(k/4)) + k%4)
+  unsigned pre_valid = 0;
+#pragma unroll
+  for (int k = 0; k < 4 * UPRE; ++k)
+    if (4 * (j + 16 * (k / 4)) + (k % 4) < N) pre_valid |= 1u << k;
 
   // proposals of absolute step `step` into s_iup / s_idn / s_u
   auto proposals = [&](unsigned long long step) {
@@ -609,20 +621,20 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
     float vmax = -3.f, vmin = 3.f;
     int imax = 0x7fffffff, imin = 0x7fffffff;
     if (use_pref) {       // uniforms were drawn during the previous step's MFMA phase
+      // branch-free: out-of-lattice sites read (valid LDS) garbage and are masked to -3 / +3
 #pragma unroll
       for (int b = 0; b < UPRE; ++b) {
         const int blk = j + 16 * b;
-        if (blk < nblk) {
-          const f32x4 sp = *(const f32x4*)(s_spin + my_c * Nst + 4 * blk);
+        const f32x4 sp = *(const f32x4*)(s_spin + my_c * Nst + 4 * blk);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int n = 4 * blk + e;
-            if (n < N) {
-              const float v = sp[e] * u_pre[4 * b + e];
-              if (v > vmax) { vmax = v; imax = n; }
-              if (v < vmin) { vmin = v; imin = n; }
-            }
-          }
+        for (int e = 0; e < 4; ++e) {
+          const int n = 4 * blk + e;
+          const bool ok = (pre_valid >> (4 * b + e)) & 1u;
+          const float v = sp[e] * u_pre[4 * b + e];
+          const float vx = ok ? v : -3.f, vn = ok ? v : 3.f;
+          const bool tmax = vx > vmax, tmin = vn < vmin;
+          vmax = tmax ? vx : vmax; imax = tmax ? n : imax;
+          vmin = tmin ? vn : vmin; imin = tmin ? n : imin;
         }
       }
       reduce_and_publish(vmax, imax, vmin, imin, u_pre_acc);
@@ -677,32 +689,35 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   auto build = [&](bool with_delta) {
     if (W1L) {
       // single z1 buffer; the previous step's accepted move is folded in first (each thread
-      // owns fixed elements of z1, so no barrier is needed for the read-modify-write)
+      // owns fixed elements of z1, so no barrier is needed for the read-modify-write).
+      // Branch-free and with every LDS read issued before the first use: the phase costs one
+      // LDS round trip instead of three per output tile.
       float* zrow = s_z1 + j * ZS;
-      const bool pacc = s_pacc[j] != 0;
+      const float cp = s_pacc[j] != 0 ? 2.f : 0.f;
+      const float cd = with_delta ? 2.f : 0.f;
       const float* px = s_w1 + s_pdn[j] * W1S;
       const float* py = s_w1 + s_pup[j] * W1S;
       const float* wa = s_w1 + (with_delta ? s_idn[j] : 0) * W1S;
       const float* wb = s_w1 + (with_delta ? s_iup[j] : 0) * W1S;
+      f32x4 z[TO], x0[TO], y0[TO], x1[TO], y1[TO];
+#pragma unroll
+      for (int to = 0; to < TO; ++to) {
+        const int col = 16 * (wave * TO + to) + 4 * g;
+        z[to] = *(const f32x4*)(zrow + col);
+        x0[to] = *(const f32x4*)(px + col); y0[to] = *(const f32x4*)(py + col);
+        x1[to] = *(const f32x4*)(wa + col); y1[to] = *(const f32x4*)(wb + col);
+      }
 #pragma unroll
       for (int to = 0; to < TO; ++to) {
         const int t = wave * TO + to, col = 16 * t + 4 * g;
-        f32x4 z = *(const f32x4*)(zrow + col);
-        if (pacc) {
-          const f32x4 x = *(const f32x4*)(px + col);
-          const f32x4 y = *(const f32x4*)(py + col);
+        f32x4 zc;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) z[e] = fmaf(2.f, x[e] - y[e], z[e]);
-          *(f32x4*)(zrow + col) = z;
+        for (int e = 0; e < 4; ++e) {
+          z[to][e] = fmaf(cp, x0[to][e] - y0[to][e], z[to][e]);     // committed z1
+          zc[e] = fmaf(cd, x1[to][e] - y1[to][e], z[to][e]);        // candidate z1'
+          own[to][e] = fmaxf(zc[e], 0.f);
         }
-        if (with_delta) {
-          const f32x4 x = *(const f32x4*)(wa + col);
-          const f32x4 y = *(const f32x4*)(wb + col);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) z[e] = fmaf(2.f, x[e] - y[e], z[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(z[e], 0.f);
+        *(f32x4*)(zrow + col) = z[to];
         *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
       }
       return;
@@ -930,7 +945,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
 
 static size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l) {
   const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
-  return sizeof(float) * (size_t)(16 * Nst + (w1l ? 1 : 2) * 16 * ZS + 2 * NT * 256 + 64 + 16 +
+  return sizeof(float) * (size_t)(16 * Nst + (w1l ? 1 : 2) * 16 * ZS + 2 * NT * 256 + 16 +
                                   16 + 7 * 16 + Hp + n_hidden * Hp + (w1l ? N * (Hp + 4) : 0));
 }
 
