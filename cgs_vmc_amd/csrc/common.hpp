@@ -82,7 +82,8 @@ struct SweepArgs {
   const float* inj_u;
   unsigned char* acc_mask;  // [B] out (last step) or nullptr
   int* dbg_up; int* dbg_dn; float* dbg_u;   // proposal dump (debug_proposals) or nullptr
-  unsigned long long* dbg_cycles;           // [grid][4 waves][8 phases] -> diagnostic STAMP build
+  unsigned long long* dbg_cycles;           // [grid][4 waves][16 phases] -> diagnostic STAMP build
+  float* act_out;           // [L][B][Hp] activations of the final chains (gradient path) or nullptr
   int B, N, n_hidden;
   int chain_offset;
   uint32_t seed_lo, seed_hi;

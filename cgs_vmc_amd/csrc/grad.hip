@@ -9,8 +9,10 @@
 //   64x64x32 block tile, 4 waves in a 2x2 grid, one (DUAL: two) 32x32 v_mfma_f32_32x32x2_f32
 //   accumulator(s) per wave; global -> register prefetch of tile k+1 while tile k is computed
 //   from LDS; dwordx4 global loads along whichever dimension has stride 1.
-//   ones_row : row M-1 of A is an implicit row of ones (folds the bias gradient, which sits
-//              right behind its weight matrix in the parameter vector, into the dW GEMM)
+//   ones_row : C has one extra row M-1 = the column sums of B (the product with an implicit
+//              row of ones): the bias gradient, which sits right behind its weight matrix in the
+//              parameter vector.  It is accumulated on the VALU by the m-tile-0 workgroups from
+//              the B tile they have staged anyway, so the MFMA grid only covers M-1 rows.
 //   DUAL     : second product A (kscale (.) B) -> C2 from the same tiles (the weighted sum
 //              sum_b w_b O_k next to sum_b O_k, training.py:545-547)
 //   split-K over blockIdx.z into a workspace that k_gemm_reduce folds in z order.
@@ -105,7 +107,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
   const int kend = min(g.K, kbeg + kc);
   const bool a_kfast = (g.sak == 1), b_kfast = (g.sbk == 1);
   const int a_extent = g.ones_row ? g.M - 1 : g.M;
-  const int ones_d = g.ones_row ? g.M - 1 : -1;
+  const int ones_d = -1;
+  const bool do_colsum = g.ones_row && blockIdx.y == 0 && tid < GT;
+  float cs = 0.f, cs2 = 0.f;
 
   f32x16 acc, acc2;
 #pragma unroll
@@ -131,6 +135,13 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
       ra = load_tile(g.A, g.sam, g.sak, a_extent, kend, m0, k0 + GK, a_kfast, ones_d, tid);
       rb = load_tile(g.B, g.sbn, g.sbk, g.N, kend, n0, k0 + GK, b_kfast, -1, tid);
     }
+    if (do_colsum) {
+#pragma unroll
+      for (int kk = 0; kk < GK; ++kk) {
+        cs += Bs[kk][tid];
+        if (DUAL) cs2 += Bs2[kk][tid];
+      }
+    }
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 2) {
       const float av = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (m < g.M && n < g.N) {
+    if (m < a_extent && n < g.N) {
       if (g.splitk > 1) {
         float* ws = g.workspace + (long long)blockIdx.z * (DUAL ? 2 : 1) * mn;
         ws[(long long)m * g.N + n] = acc[r];
@@ -158,6 +169,17 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         gemm_epilogue(g, g.C, m, n, acc[r]);
         if (DUAL) gemm_epilogue(g, g.C2, m, n, acc2[r]);
       }
+    }
+  }
+  if (do_colsum && n0 + tid < g.N) {
+    const int m = g.M - 1, nn = n0 + tid;
+    if (g.splitk > 1) {
+      float* ws = g.workspace + (long long)blockIdx.z * (DUAL ? 2 : 1) * mn;
+      ws[(long long)m * g.N + nn] = cs;
+      if (DUAL) ws[mn + (long long)m * g.N + nn] = cs2;
+    } else {
+      gemm_epilogue(g, g.C, m, nn, cs);
+      if (DUAL) gemm_epilogue(g, g.C2, m, nn, cs2);
     }
   }
 }
@@ -177,7 +199,8 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
-  const dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, g.splitk);
+  const int m_rows = g.ones_row ? g.M - 1 : g.M;
+  const dim3 grid((g.N + GT - 1) / GT, (m_rows + GT - 1) / GT, g.splitk);
   if (g.dual) hipLaunchKernelGGL(k_gemm<true>, grid, dim3(256), 0, s, g);
   else hipLaunchKernelGGL(k_gemm<false>, grid, dim3(256), 0, s, g);
   if (g.splitk > 1) {

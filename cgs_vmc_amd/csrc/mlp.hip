@@ -686,6 +686,15 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   if (STAMP) { const unsigned long long t1_ = vmc_stamp(); if (stamp_on) cyc[k] += t1_ - t0; t0 = t1_; }
 
   // builds the layer-2 input operand (and the candidate z1 when with_delta)
+  bool save_acts = false;   // final refresh: also write the activations for the gradient path
+  auto save_own = [&](int l) {
+    if (chain0 + j < a.B) {
+      float* dst = a.act_out + ((long long)l * a.B + chain0 + j) * Hp;
+#pragma unroll
+      for (int to = 0; to < TO; ++to)
+        *(f32x4*)(dst + 16 * (wave * TO + to) + 4 * g) = own[to];
+    }
+  };
   auto build = [&](bool with_delta) {
     if (W1L) {
       // single z1 buffer; the previous step's accepted move is folded in first (each thread
@@ -720,6 +729,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
         *(f32x4*)(zrow + col) = z[to];
         *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
       }
+      if (save_acts) save_own(0);
       return;
     }
     const int sel = s_sel[j];
@@ -746,6 +756,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
       for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(z[e], 0.f);
       *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
     }
+    if (save_acts) save_own(0);
   };
 
   // layers 2..L + output dot; leaves per-wave partial logits in s_part.
@@ -837,6 +848,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
         for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(acc[to][e], 0.f);
         if (l + 1 < n_hidden) *(f32x4*)(xout + ((wave * TO + to) * 64 + lane) * 4) = own[to];
       }
+      if (save_acts) save_own(l + 1);
       cur ^= 1;
       SWEEP_STAMP(FS > 0 ? 11 : 14)
     };
@@ -896,6 +908,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   };
   for (long long it = -1; it <= a.n_steps; ++it) {
     const bool is_step = it >= 0 && it < a.n_steps;
+    save_acts = (it == a.n_steps) && (a.act_out != nullptr);
     stamp_on = is_step;
     if (STAMP) t0 = vmc_stamp();
     resolve();

@@ -50,7 +50,9 @@ struct vmc_ctx {
   bool list_valid = false;
   long long last_rows = 0;
   // gradient path
-  std::vector<float*> act;   // L buffers [B][Hp]
+  std::vector<float*> act;   // L views [B][Hp] into act_all
+  float* act_all = nullptr;  // [L][B][Hp]
+  bool acts_valid = false;   // act[] hold the activations of psi on the current chains
   float* delta[2] = {nullptr, nullptr};
   float *ratio = nullptr, *ones = nullptr;
   float *acc = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad_tmp = nullptr;
@@ -179,6 +181,7 @@ int ensure_cache(vmc_ctx* c, int which) {
 }
 
 void invalidate_configs(vmc_ctx* c) {
+  c->acts_valid = false;
   c->ps[0].cache_valid = c->ps[1].cache_valid = false;
   c->list_valid = false;
 }
@@ -285,10 +288,9 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(dalloc(&c->configs, B * N));
   CA(hipMemsetAsync(c->configs, 0, B * N * sizeof(float), c->stream));
   c->act.resize(L, nullptr);
-  for (int l = 0; l < L; ++l) {
-    CA(dalloc(&c->act[l], B * Hp));
-    CA(hipMemsetAsync(c->act[l], 0, B * Hp * sizeof(float), c->stream));
-  }
+  CA(dalloc(&c->act_all, L * B * Hp));
+  CA(hipMemsetAsync(c->act_all, 0, L * B * Hp * sizeof(float), c->stream));
+  for (int l = 0; l < L; ++l) c->act[l] = c->act_all + l * B * Hp;
   for (int i = 0; i < 2; ++i) {
     CA(dalloc(&c->delta[i], B * Hp));
     CA(hipMemsetAsync(c->delta[i], 0, B * Hp * sizeof(float), c->stream));
@@ -322,7 +324,7 @@ void vmc_destroy(vmc_ctx* c) {
     float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p32, p.p16, p.woutp, p.bout, p.z1, p.logit, p.eloc};
     for (float* q : ptrs) if (q) hipFree(q);
   }
-  for (float* q : c->act) if (q) hipFree(q);
+  if (c->act_all) hipFree(c->act_all);
   void* ptrs[] = {c->configs, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta[0], c->delta[1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->d_accepted, c->d_sum,
@@ -368,6 +370,7 @@ int vmc_set_params(vmc_ctx* c, int which, const float* theta) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->ps[which].has_params = true;
   c->ps[which].packed_valid = c->ps[which].cache_valid = false;
+  if (which == VMC_PSI) c->acts_valid = false;
   return VMC_OK;
 }
 
@@ -466,6 +469,8 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   a.chain_offset = c->d.chain_offset;
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = step0; a.n_steps = n_steps;
+  a.act_out = dbg ? nullptr : c->act_all;
+  c->acts_valid = !dbg;
   HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), c->stream));
   {
     Timer t(c, "sweep");
@@ -535,6 +540,7 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   a.B = c->B; a.N = c->N; a.n_hidden = c->L - 1; a.chain_offset = c->d.chain_offset;
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = c->step; a.n_steps = n_steps;
+  c->acts_valid = false;
   HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
   c->step += (unsigned long long)n_steps;
   c->ps[0].cache_valid = true; c->ps[1].cache_valid = false; c->list_valid = false;
@@ -588,9 +594,10 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
   float* g1 = c->acc;
   float* g2 = c->acc + c->P;
   Timer t(c, "grad");
-  // forward with saved activations (wavefunctions.py:345-349)
-  HIPCHK(c, launch_relu_copy(c->stream, p.z1, c->act[0], (long long)B * Hp));
-  for (int l = 1; l < L; ++l) {
+  // forward with saved activations (wavefunctions.py:345-349); after a sweep launch the kernel
+  // has already left them in act[] (exact refresh of the final chains)
+  if (!c->acts_valid) HIPCHK(c, launch_relu_copy(c->stream, p.z1, c->act[0], (long long)B * Hp));
+  for (int l = 1; l < L && !c->acts_valid; ++l) {
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.A = c->act[l - 1]; g.sam = Hp; g.sak = 1;
     g.B = p.theta + off_w(c, l); g.sbk = H; g.sbn = 1;
@@ -716,6 +723,7 @@ int vmc_apply_adam(vmc_ctx* c, int mode, float lr, float beta1, float beta2, flo
     HIPCHK(c, launch_adam(c->stream, c->ps[0].theta, c->adam_m, c->adam_v, c->acc, (int)c->P, mode, lr_t, beta1, beta2, eps, nullptr));
   }
   c->ps[0].packed_valid = c->ps[0].cache_valid = false;
+  c->acts_valid = false;
   if (energy) PROPAGATE(vmc_mean_energy(c, energy));
   return VMC_OK;
 }
