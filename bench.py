@@ -231,10 +231,24 @@ def main():
         v['executed_tflops'] = v['flops_executed'] / (v['ms_avg'] * 1e-3) / 1e12
         v['executed_frac'] = v['executed_tflops'] / FP32_MFMA_PEAK_TFLOPS
       key = 'k_sweep16' if dom == 'sweep' else 'k_tail32(eloc)'
+      # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command
+      # (profiles/r1_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc runs; see
+      # tools/collect_profiles.sh); null when no matching profile is present
+      traffic = None
+      tpath = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
+      if os.path.exists(tpath) and args.workload == 'heisenberg10x10_fc3x256_b4096':
+        try:
+          prof = json.load(open(tpath))
+          for name, rec in prof.items():
+            if name.startswith(key.split('(')[0]) and rec.get('hbm_read_bytes') is not None:
+              traffic = rec['hbm_read_bytes'] + (rec.get('hbm_write_bytes') or 0)
+              per_kernel[key]['pmc'] = {k: rec[k] for k in ('mfma_util', 'clock_ghz', 'median_us')}
+        except Exception:  # pylint: disable=broad-except
+          traffic = None
       out['roofline'] = {
           'kernel': key, 'bound': 'mfma', 'achieved': per_kernel[key]['achieved'],
           'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': per_kernel[key]['frac'],
-          'traffic': None,
+          'traffic': traffic,
           'note': 'achieved = nominal algorithmic flops (SURVEY.md 8d) / HIP-event kernel time; '
                   'executed_* counts the flops actually issued (antiparallel bonds only, rank-2 '
                   'first layer)',
