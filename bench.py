@@ -86,7 +86,7 @@ def cpu_baseline(n, h, L, bonds, theta, cfg, seconds_budget=25.0):
   except Exception:  # pylint: disable=broad-except
     threads = os.cpu_count() or 1
   # bounded sample: a slice of the chains, one full step (accumulate + sweep) on it
-  bs = min(cfg.shape[0], 1024)
+  bs = min(cfg.shape[0], 4096)
   sub = cfg[:bs].copy()
   acc = vo.Accumulators(theta.size, np.float32)
   t0 = time.perf_counter()
@@ -159,7 +159,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
       torch.distributed.barrier()
-    torch.cuda.synchronize()
+      torch.cuda.synchronize()
 
   eng.reset_accumulators()
   for _ in range(args.warmup):

@@ -37,7 +37,17 @@ def rank() -> int:
 
 
 def local_rank() -> int:
-  return int(os.environ.get('LOCAL_RANK', '0')) if is_distributed() else 0
+  """Device ordinal of this rank (LOCAL_RANK, folded onto the visible devices so that the
+  2-rank gloo test can share one GPU)."""
+  if not is_distributed():
+    return 0
+  lr = int(os.environ.get('LOCAL_RANK', '0'))
+  try:
+    import torch
+    n = torch.cuda.device_count()
+    return lr % n if n > 0 else lr
+  except Exception:  # pylint: disable=broad-except
+    return lr
 
 
 def init_from_env(backend: str = 'nccl'):
@@ -46,6 +56,7 @@ def init_from_env(backend: str = 'nccl'):
     return
   import torch
   dist = _dist()
+  backend = os.environ.get('CGS_VMC_DIST_BACKEND', backend)   # 'gloo' for single-GPU tests
   if backend == 'nccl':
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
   dist.init_process_group(backend=backend)
@@ -78,6 +89,10 @@ def accumulator_tensor(engine):
 def allreduce_accumulators(engine):
   """In-place SUM all-reduce of the engine's accumulator buffer over all ranks."""
   if world_size() == 1:
+    return
+  if _dist().get_backend() != 'nccl':
+    # gloo (tests, CPU rendezvous): stage through the host
+    engine.set_accumulators(reduce_accumulators_host(engine.get_accumulators()))
     return
   engine.synchronize()                 # the library's stream -> visible to the collective
   t = accumulator_tensor(engine)
