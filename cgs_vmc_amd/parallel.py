@@ -79,11 +79,20 @@ class _DevArray:
         'shape': (n,), 'typestr': '<f4', 'data': (ptr, False), 'version': 2, 'strides': None}
 
 
+_acc_views = {}
+
+
 def accumulator_tensor(engine):
-  """torch view (device memory of the engine) of the accumulator buffer."""
+  """torch view (device memory of the engine) of the accumulator buffer; cached per buffer."""
   import torch
   ptr, n = engine.accumulators_devptr()
-  return torch.as_tensor(_DevArray(ptr, n), device=torch.device('cuda', engine.device))
+  key = (engine.device, ptr, n)
+  t = _acc_views.get(key)
+  if t is None:
+    t = torch.as_tensor(_DevArray(ptr, n), device=torch.device('cuda', engine.device))
+    _acc_views.clear()          # one live engine per process is the normal case
+    _acc_views[key] = t
+  return t
 
 
 def allreduce_accumulators(engine):
@@ -94,14 +103,21 @@ def allreduce_accumulators(engine):
     # gloo (tests, CPU rendezvous): stage through the host
     engine.set_accumulators(reduce_accumulators_host(engine.get_accumulators()))
     return
-  engine.synchronize()                 # the library's stream -> visible to the collective
+  # Stream ordering, no host sync: the library launches on the legacy null stream, which is
+  # torch's current (default) stream; the RCCL collective waits for that stream before it
+  # starts and makes it wait for the result (torch.distributed semantics for async_op=False).
+  # CGS_VMC_SAFE_SYNC=1 adds explicit host synchronisation on both sides.
+  safe = os.environ.get('CGS_VMC_SAFE_SYNC', '0') == '1'
+  if safe:
+    engine.synchronize()
   t = accumulator_tensor(engine)
   _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
   # mean_tensor's count is the number of accumulate CALLS (training.py:550-553), which every
   # rank made in lock-step: undo the sum so that sharded == unsharded gradients
   t[t.numel() - 4] /= world_size()
-  import torch
-  torch.cuda.current_stream(t.device).synchronize()
+  if safe:
+    import torch
+    torch.cuda.current_stream(t.device).synchronize()
 
 
 def allreduce_array(values: np.ndarray, op: str = 'sum') -> np.ndarray:
