@@ -906,7 +906,20 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
       s_logit[c] = ln;
     }
   };
-  for (long long it = -1; it <= a.n_steps; ++it) {
+  long long it_first = -1;
+  if (a.cache_in_valid && a.n_steps > 0) {
+    // the previous launch left an exact z1 / logit cache for these very chains: load it
+    // instead of recomputing it (saves one of the two refresh passes per launch)
+    for (int i = tid; i < 16 * Hp; i += 256) {
+      const int c = i / Hp, col = i % Hp, gc = chain0 + c;
+      s_z1[c * ZS + col] = gc < a.B ? a.z1[(long long)gc * Hp + col] : 0.f;
+    }
+    if (tid < 16) s_logit[tid] = chain0 + tid < a.B ? a.logit[chain0 + tid] : 0.f;
+    if (use_pref) draw_all(a.step0);
+    __syncthreads();
+    it_first = 0;
+  }
+  for (long long it = it_first; it <= a.n_steps; ++it) {
     const bool is_step = it >= 0 && it < a.n_steps;
     save_acts = (it == a.n_steps) && (a.act_out != nullptr);
     stamp_on = is_step;

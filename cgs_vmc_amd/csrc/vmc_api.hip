@@ -470,6 +470,7 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = step0; a.n_steps = n_steps;
   a.act_out = dbg ? nullptr : c->act_all;
+  a.cache_in_valid = (!dbg && !injected && c->ps[0].cache_valid) ? 1 : 0;
   c->acts_valid = !dbg;
   HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), c->stream));
   {
