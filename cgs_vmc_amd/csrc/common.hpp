@@ -83,6 +83,7 @@ struct SweepArgs {
   unsigned char* acc_mask;  // [B] out (last step) or nullptr
   int* dbg_up; int* dbg_dn; float* dbg_u;   // proposal dump (debug_proposals) or nullptr
   unsigned long long* dbg_cycles;           // [grid][4 waves][16 phases] -> diagnostic STAMP build
+  int waves;                // waves per workgroup of the sweep kernel (4 or 8)
   int cache_in_valid;       // z1 / logit already hold the exact cache of `configs`
   float* act_out;           // [L][B][Hp] activations of the final chains (gradient path) or nullptr
   int B, N, n_hidden;

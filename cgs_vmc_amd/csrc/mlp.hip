@@ -451,9 +451,14 @@ __device__ __forceinline__ unsigned long long vmc_stamp() {
 // double-buffered.
 // FAST: the production path (Philox draws prefetched, no injected proposals, no debug dump);
 // the general instantiation keeps every path.
-template <int NT, bool STAMP, bool W1L, bool FAST>
-__global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
-  constexpr int Hp = NT * 16, TO = NT / 4, ZS = Hp + 4, W1S = Hp + 4, PF = SWEEP_PF;
+// NW: waves per workgroup (4 or 8).  With 8 waves (2 per SIMD) each wave owns NT/8 output
+// tiles; the two co-resident waves hide each other's vmcnt / LDS stalls inside the layers.
+// Proposals, accept and the Philox chains stay on waves 0-3 (4 chains each).
+template <int NT, int NW, bool STAMP, bool W1L, bool FAST>
+__global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
+  static_assert(NT % NW == 0, "output tiles must divide over the waves");
+  constexpr int NTH = NW * 64;
+  constexpr int Hp = NT * 16, TO = NT / NW, ZS = Hp + 4, W1S = Hp + 4, PF = SWEEP_PF;
   constexpr int RT = NT < SWEEP_RT ? NT : SWEEP_RT;   // k-tiles of the first H x H layer kept in registers
   extern __shared__ float smem[];
   const int N = a.N, Nst = (N + 3) & ~3;
@@ -484,17 +489,17 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   // comes after every reader of s_part has passed barrier0)
   float* s_part = s_x + (n_hidden == 0 ? 1 : (n_hidden & 1)) * NT * 256;
 
-  for (int i = tid; i < 16 * Nst; i += 256) {
+  for (int i = tid; i < 16 * Nst; i += NTH) {
     const int c = i / Nst, n = i % Nst, gc = chain0 + c;
     float v = 0.f;
     if (n < N) v = gc < a.B ? a.configs[(long long)gc * N + n] : ((n & 1) ? -1.f : 1.f);
     s_spin[i] = v;
   }
   if (tid < 16) { s_sel[tid] = 0; s_pacc[tid] = 0; s_pup[tid] = 0; s_pdn[tid] = 0; }
-  for (int i = tid; i < n_hidden * Hp; i += 256) s_bias[i] = pp.bh[i];
-  for (int i = tid; i < Hp; i += 256) s_wout[i] = pp.woutp[i];
+  for (int i = tid; i < n_hidden * Hp; i += NTH) s_bias[i] = pp.bh[i];
+  for (int i = tid; i < Hp; i += NTH) s_wout[i] = pp.woutp[i];
   if (W1L) {
-    for (int i = tid; i < N * (Hp / 4); i += 256) {
+    for (int i = tid; i < N * (Hp / 4); i += NTH) {
       const int n = i / (Hp / 4), c4 = i % (Hp / 4);
       *(f32x4*)(s_w1 + n * W1S + 4 * c4) = *(const f32x4*)(pp.w1p + (long long)n * Hp + 4 * c4);
     }
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
 
   // z1 from the spins (first layer, exact): thread -> (column, chain group)
   auto z1_direct = [&]() {
-    constexpr int GROUPS = 256 / Hp > 0 ? 256 / Hp : 1;   // chain groups when Hp < 256
+    constexpr int GROUPS = NTH / Hp > 0 ? NTH / Hp : 1;   // chain groups when Hp < NTH
     constexpr int CPG = 16 / GROUPS;
     const int col = tid % Hp, grp = tid / Hp;
     if (grp < GROUPS) {
@@ -607,6 +612,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
 
   // proposals of absolute step `step` into s_iup / s_idn / s_u
   auto proposals = [&](unsigned long long step) {
+    if (NW > 4 && wave >= 4) return;   // chains 4w..4w+3 belong to waves 0-3
     if (!FAST && a.inj_up) {
       if (tid < 16) {
         const int gc = chain0 + tid;
@@ -867,12 +873,14 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
     }
     part += __shfl_xor(part, 16);
     part += __shfl_xor(part, 32);
-    if (g == 0) s_part[wave * 16 + j] = part;
+    if (g == 0) s_part[wave * 16 + j] = part;   // NW partials per chain
     __syncthreads();
   };
 
-  auto logit_of = [&](int c) {
-    return ((s_part[c] + s_part[16 + c]) + (s_part[32 + c] + s_part[48 + c])) + bout;
+  auto logit_of = [&](int c) {   // fixed summation order over the NW per-wave partials
+    float t = (s_part[c] + s_part[16 + c]) + (s_part[32 + c] + s_part[48 + c]);
+    if (NW == 8) t += (s_part[64 + c] + s_part[80 + c]) + (s_part[96 + c] + s_part[112 + c]);
+    return t + bout;
   };
 
   // it = -1: cache of the initial spins; 0..n_steps-1: mc_steps; n_steps: exact cache of the
@@ -884,7 +892,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   unsigned int n_acc = 0;
   int prev_kind = 0;   // 0 none, 1 refresh, 2 step
   auto resolve = [&]() {
-    if (prev_kind == 0) return;
+    if (prev_kind == 0 || (NW > 4 && wave >= 4)) return;
     const int c = my_c, gc = chain0 + c;
     const float ln = logit_of(c);
     if (prev_kind == 2) {
@@ -910,7 +918,7 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
   if (a.cache_in_valid && a.n_steps > 0) {
     // the previous launch left an exact z1 / logit cache for these very chains: load it
     // instead of recomputing it (saves one of the two refresh passes per launch)
-    for (int i = tid; i < 16 * Hp; i += 256) {
+    for (int i = tid; i < 16 * Hp; i += NTH) {
       const int c = i / Hp, col = i % Hp, gc = chain0 + c;
       s_z1[c * ZS + col] = gc < a.B ? a.z1[(long long)gc * Hp + col] : 0.f;
     }
@@ -953,20 +961,20 @@ __global__ __launch_bounds__(256) void k_sweep16(SweepArgs a) {
 #undef SWEEP_STAMP
   if (STAMP && a.dbg_cycles && lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) a.dbg_cycles[((long long)blockIdx.x * 4 + wave) * 16 + k] = cyc[k];
+    for (int k = 0; k < 16; ++k) a.dbg_cycles[((long long)blockIdx.x * NW + wave) * 16 + k] = cyc[k];
   }
 
   // write back chains and the exact cache
   if (tid < 16 && chain0 + tid < a.B) a.logit[chain0 + tid] = s_logit[tid];
-  for (int i = tid; i < 16 * N; i += 256) {
+  for (int i = tid; i < 16 * N; i += NTH) {
     const int c = i / N, n = i % N, gc = chain0 + c;
     if (gc < a.B) a.configs[(long long)gc * N + n] = s_spin[c * Nst + n];
   }
-  for (int i = tid; i < 16 * Hp; i += 256) {
+  for (int i = tid; i < 16 * Hp; i += NTH) {
     const int c = i / Hp, col = i % Hp, gc = chain0 + c;
     if (gc < a.B) a.z1[(long long)gc * Hp + col] = s_z1[c * ZS + col];
   }
-  if (j == 0 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);
+  if (j == 0 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);   // waves 0-3 only
 }
 
 static size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l) {
@@ -975,9 +983,9 @@ static size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l) {
                                   16 + 7 * 16 + Hp + n_hidden * Hp + (w1l ? N * (Hp + 4) : 0));
 }
 
-template <int NT>
+template <int NT, int NW>
 static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
-  const dim3 grid((a.B + 15) / 16), block(256);
+  const dim3 grid((a.B + 15) / 16), block(NW * 64);
   const size_t lds_full = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, true);
   const bool w1l = lds_full <= 160 * 1024;
   const size_t lds = w1l ? lds_full : sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false);
@@ -986,10 +994,10 @@ static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
   const bool fast = nblk <= 32 && a.inj_up == nullptr && a.dbg_up == nullptr;
 #define SWEEP_LAUNCH(ST, WL, FA)                                                              \
   do {                                                                                        \
-    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, ST, WL, FA>,                \
+    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, NW, ST, WL, FA>,                \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                            \
-    hipLaunchKernelGGL((k_sweep16<NT, ST, WL, FA>), grid, block, lds, s, a);                  \
+    hipLaunchKernelGGL((k_sweep16<NT, NW, ST, WL, FA>), grid, block, lds, s, a);                  \
     return hipGetLastError();                                                                 \
   } while (0)
   if (a.dbg_cycles) {
@@ -1005,10 +1013,10 @@ static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp) {
   if (a.B <= 0) return hipSuccess;
   switch (Hp / 16) {
-    case 4: return launch_sweep16_t<4>(s, a);
-    case 8: return launch_sweep16_t<8>(s, a);
-    case 12: return launch_sweep16_t<12>(s, a);
-    case 16: return launch_sweep16_t<16>(s, a);
+    case 4: return launch_sweep16_t<4, 4>(s, a);
+    case 8: return launch_sweep16_t<8, 4>(s, a);
+    case 12: return launch_sweep16_t<12, 4>(s, a);
+    case 16: return a.waves == 8 ? launch_sweep16_t<16, 8>(s, a) : launch_sweep16_t<16, 4>(s, a);
     default: return hipErrorInvalidValue;
   }
 }

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -60,6 +61,7 @@ struct vmc_ctx {
   float* gemm_ws = nullptr;
   int splitk = 16;
   int num_cus = 256;
+  int sweep_waves = 8;       // waves per sweep workgroup at Hp = 256 (CGS_VMC_SWEEP_WAVES=4|8)
   // scratch
   unsigned long long* d_accepted = nullptr;
   double* d_sum = nullptr;
@@ -267,6 +269,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   c->Hp = (c->H + 63) / 64 * 64;
   c->P = vmc_num_params(c->N, c->H, c->L);
   c->stream = (hipStream_t)d->stream;
+  if (const char* e = getenv("CGS_VMC_SWEEP_WAVES")) c->sweep_waves = atoi(e) == 8 ? 8 : 4;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -469,6 +472,7 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   a.chain_offset = c->d.chain_offset;
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = step0; a.n_steps = n_steps;
+  a.waves = c->sweep_waves;
   a.act_out = dbg ? nullptr : c->act_all;
   a.cache_in_valid = (!dbg && !injected && c->ps[0].cache_valid) ? 1 : 0;
   c->acts_valid = !dbg;
@@ -531,13 +535,13 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   PROPAGATE(ensure_packed(c, 0));
   const int grid = (c->B + 15) / 16;
   unsigned long long* d = nullptr;
-  HIPCHK(c, dalloc(&d, (long long)grid * 64));
-  HIPCHK(c, hipMemsetAsync(d, 0, (size_t)grid * 64 * sizeof(unsigned long long), c->stream));
+  HIPCHK(c, dalloc(&d, (long long)grid * 128));
+  HIPCHK(c, hipMemsetAsync(d, 0, (size_t)grid * 128 * sizeof(unsigned long long), c->stream));
   SweepArgs a;
   memset(&a, 0, sizeof(a));
   a.pp = c->ps[0].packed();
   a.configs = c->configs; a.z1 = c->ps[0].z1; a.logit = c->ps[0].logit;
-  a.accepted = c->d_accepted; a.dbg_cycles = d;
+  a.accepted = c->d_accepted; a.dbg_cycles = d; a.waves = c->sweep_waves;
   a.B = c->B; a.N = c->N; a.n_hidden = c->L - 1; a.chain_offset = c->d.chain_offset;
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = c->step; a.n_steps = n_steps;
@@ -545,14 +549,14 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
   c->step += (unsigned long long)n_steps;
   c->ps[0].cache_valid = true; c->ps[1].cache_valid = false; c->list_valid = false;
-  std::vector<unsigned long long> h((size_t)grid * 64);
+  std::vector<unsigned long long> h((size_t)grid * 128);
   HIPCHK(c, hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(d);
   for (int k = 0; k < 16; ++k) {
     double s = 0.0;
-    for (int i = 0; i < grid * 4; ++i) s += (double)h[(size_t)i * 16 + k];
-    phase_cycles[k] = s / ((double)grid * 4.0 * (double)n_steps);
+    for (int i = 0; i < grid * c->sweep_waves; ++i) s += (double)h[(size_t)i * 16 + k];
+    phase_cycles[k] = s / ((double)grid * c->sweep_waves * (double)n_steps);
   }
   return VMC_OK;
 }
