@@ -55,21 +55,24 @@ class MonteCarloOperatorEvaluator(WavefunctionEvaluator):
     return eval_ops
 
   def run_evaluation(self, eval_ops: EvalOps, session, hparams, epoch_num: int) -> List[float]:
-    """evaluation.py:113-152: equilibrate, then alternate batch-mean local value and
-    num_monte_carlo_sweeps sweeps; returns num_evaluation_samples batch means."""
-    value = eval_ops.value
-    mc_step = eval_ops.mc_step
-    num_equilibration_sweeps = hparams.num_equilibration_sweeps
-    num_evaluation_samples = hparams.num_evaluation_samples
-    num_mc_steps = hparams.num_monte_carlo_sweeps * hparams.num_sites
-    _run_mc_steps(session, mc_step, num_equilibration_sweeps * hparams.num_sites)
-    values = []
+    """evaluation.py:113-152: thermalise for num_equilibration_sweeps sweeps, then take
+    num_evaluation_samples measurements of the batch-mean local value, num_monte_carlo_sweeps
+    sweeps apart.  Each block of num_sites consecutive mc_steps is one persistent-kernel
+    launch; the acceptance count the reference computes and drops is kept in
+    `self.acceptance_count`."""
+    del epoch_num
+    steps_per_sweep = hparams.num_sites
+    decorrelation = hparams.num_monte_carlo_sweeps * steps_per_sweep
     self.acceptance_count = 0
-    for _ in range(0, num_evaluation_samples):
-      values.append(session.run(value))
-      _run_mc_steps(session, mc_step, num_mc_steps)
-      self.acceptance_count += getattr(mc_step, 'last_accepted', 0)
-    return values
+
+    def measurements():
+      _run_mc_steps(session, eval_ops.mc_step, hparams.num_equilibration_sweeps * steps_per_sweep)
+      for _ in range(hparams.num_evaluation_samples):
+        yield session.run(eval_ops.value)
+        _run_mc_steps(session, eval_ops.mc_step, decorrelation)
+        self.acceptance_count += getattr(eval_ops.mc_step, 'last_accepted', 0)
+
+    return list(measurements())
 
 
 class VectorWavefunctionEvaluator(WavefunctionEvaluator):

@@ -1,76 +1,53 @@
-"""Runs evaluation on the optimized wave-function (counterpart of
-cgs_vmc/run_energy_evaluation.py): loads hparams.pbtxt and the latest checkpoint from
---checkpoint_dir, runs MonteCarloOperatorEvaluator and prints `Energy: mean +/- uncertainty`
-with the reference's formula (sqrt(std)/n, run_energy_evaluation.py:86-88; defect B6 kept
-for output parity, the standard error std/sqrt(n) is printed on a second line)."""
+"""Energy evaluation driver; command-line counterpart of cgs_vmc/run_energy_evaluation.py.
+
+Reads `hparams.pbtxt` (+ optional `J.txt`) and the latest checkpoint of --checkpoint_dir, runs
+MonteCarloOperatorEvaluator and prints `Energy: <mean> +/- <uncertainty>`.  The uncertainty
+uses the reference's expression sqrt(std)/n (run_energy_evaluation.py:87, defect B6 kept so the
+line is comparable); the conventional standard error follows on a second line.
+"""
 from __future__ import annotations
 
-import argparse
 import os
 
 import numpy as np
 
+from . import cli_common
 from . import evaluation
-from . import lattice
-from . import operators
 from . import parallel
 from . import session as session_lib
 from . import utils
-from . import wavefunctions
+
+FLAG_TABLE = (
+    ('heisenberg_jx', float, 1.0, 'Jx value in Heisenberg Hamiltonian.'),
+    ('checkpoint_dir', str, '', 'Full path to the checkpoint directory.'),
+    ('output_file', str, '', 'Accepted and unused, as in the reference.'),
+    ('hparams', str, '', 'Comma-separated name=value overrides of the hyper-parameters.'),
+)
 
 
-def build_parser():
-  p = argparse.ArgumentParser(description=__doc__)
-  p.add_argument('--heisenberg_jx', type=float, default=1.0)
-  p.add_argument('--checkpoint_dir', default='')
-  p.add_argument('--output_file', default='')
-  p.add_argument('--hparams', default='')
-  return p
+def evaluate(flags):
+  hp = utils.load_hparams(os.path.join(flags.checkpoint_dir, 'hparams.pbtxt'))
+  hp.parse(flags.hparams)
+  ansatz, hamiltonian = cli_common.heisenberg_system(hp, flags.checkpoint_dir, flags.heisenberg_jx)
+  evaluator = evaluation.MonteCarloOperatorEvaluator()
+  eval_ops = evaluator.build_eval_ops(**cli_common.graph_kwargs(
+      wavefunction=ansatz, operator=hamiltonian, hparams=hp))
+  sess = session_lib.Session()
+  sess.run(session_lib.global_variables_initializer())
+  session_lib.Saver(ansatz.get_trainable_variables()).restore(
+      sess, session_lib.latest_checkpoint(hp.checkpoint_dir))
+  return np.asarray(evaluator.run_evaluation(eval_ops, sess, hp, epoch_num=0), np.float64)
 
 
 def main(argv=None):
-  """Evaluates energy and prints the result."""
-  FLAGS = build_parser().parse_args(argv)
+  flags = cli_common.parser_from_table(__doc__, FLAG_TABLE).parse_args(argv)
   parallel.init_from_env('nccl')
-  hparams_path = os.path.join(FLAGS.checkpoint_dir, 'hparams.pbtxt')
-  hparams = utils.load_hparams(hparams_path)
-  hparams.parse(FLAGS.hparams)  # optional way to override some hparameters
-  n_sites = hparams.num_sites
-
-  heisenberg_jx = FLAGS.heisenberg_jx
-  heisenberg_bonds = lattice.load_bonds(FLAGS.checkpoint_dir, n_sites)
-
-  wavefunction = wavefunctions.build_wavefunction(hparams)
-  hamiltonian = operators.HeisenbergHamiltonian(heisenberg_bonds, heisenberg_jx, 1.)
-
-  evaluator = evaluation.MonteCarloOperatorEvaluator()
-
-  shared_resources = {}
-
-  graph_building_args = {
-      'wavefunction': wavefunction,
-      'operator': hamiltonian,
-      'hparams': hparams,
-      'shared_resources': shared_resources
-  }
-
-  evaluation_ops = evaluator.build_eval_ops(**graph_building_args)
-
-  init = session_lib.global_variables_initializer()
-  session = session_lib.Session()
-  session.run(init)
-
-  checkpoint_manager = session_lib.Saver(wavefunction.get_trainable_variables())
-
-  latest_checkpoint = session_lib.latest_checkpoint(hparams.checkpoint_dir)
-  checkpoint_manager.restore(session, latest_checkpoint)
-
-  data = evaluator.run_evaluation(evaluation_ops, session, hparams, epoch_num=0)
-  mean_energy = np.mean(data)
-  uncertainty = np.sqrt(np.std(data)) / len(data)
+  samples = evaluate(flags)
+  mean_energy = samples.mean()
+  uncertainty = np.sqrt(samples.std()) / samples.size
   if parallel.rank() == 0:
     print('Energy: {} +/- {}'.format(mean_energy, uncertainty))
-    print('Standard error (std/sqrt(n)): {}'.format(np.std(data) / np.sqrt(len(data))))
+    print('Standard error (std/sqrt(n)): {}'.format(samples.std() / np.sqrt(samples.size)))
   return mean_energy, uncertainty
 
 
