@@ -254,3 +254,23 @@ def test_two_rank_bench_path_on_one_gpu(tmp_path):
   d = json.loads(line)
   assert d['n_gpus'] == 2 and d['config']['global_chains'] == 2048 and d['value'] > 0
   assert not [l for l in outs[1][0].decode().splitlines() if l.startswith('{')]   # rank 0 only
+
+
+@pytest.mark.parametrize('optimizer', ['EnergyGradient', 'LogOverlapITSWO'])
+def test_training_reaches_exact_ground_state_energy(tmp_path, optimizer):
+  """End-to-end physics check: 400 epochs of either working optimizer on the 4x4 Heisenberg
+  torus (Marshall-rotated, j_x = -1) bring the VMC energy within 1 % of the exact-
+  diagonalisation ground state energy E0 = -11.2285 (16 sites, E0/N = -0.70178)."""
+  from cgs_vmc_amd import lattice, run_training
+  d = str(tmp_path)
+  lattice.write_bonds(d, lattice.torus_bonds(4, 4))
+  hp = ('batch_size=512,fc_layer_size=64,num_fc_layers=2,num_equilibration_sweeps=10,'
+        'num_batches_per_epoch=20,learning_rates=[0.003,0.001,0.0003],'
+        'learning_rate_stops=[150,300]')
+  run_training.main(['--checkpoint_dir', d, '--num_sites', '16', '--heisenberg_jx', '-1.0',
+                     '--wavefunction_type', 'fully_connected', '--optimizer', optimizer,
+                     '--num_epochs', '400', '--hparams', hp])
+  energies = [float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()]
+  tail = np.mean(energies[-20:])
+  assert abs(tail - (-11.2285)) < 0.01 * 11.2285, tail
+  assert tail > -11.2285 - 0.05          # variational: not below E0 beyond MC noise
