@@ -150,9 +150,10 @@ def main():
 
   def step():
     eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
-    if world > 1:
-      parallel.allreduce_accumulators(eng)
+    # the sweep does not touch the accumulators: the RCCL all-reduce runs underneath it
+    pending = parallel.allreduce_accumulators_begin(eng)
     eng.mc_steps(n, want_accepted=False)
+    pending.wait()
 
   def barrier():
     eng.synchronize()

@@ -120,6 +120,33 @@ def allreduce_accumulators(engine):
     torch.cuda.current_stream(t.device).synchronize()
 
 
+class _PendingReduce:
+  """Handle of an in-flight accumulator all-reduce (see allreduce_accumulators_begin)."""
+
+  def __init__(self, work, tensor):
+    self.work, self.tensor = work, tensor
+
+  def wait(self):
+    """Orders the current stream after the collective (no host sync) and restores g_count."""
+    if self.work is not None:
+      self.work.wait()
+      self.tensor[self.tensor.numel() - 4] /= world_size()
+      self.work = None
+
+
+def allreduce_accumulators_begin(engine) -> _PendingReduce:
+  """Starts the SUM all-reduce of the accumulator buffer on RCCL's stream and returns at
+  once, so that work which does not touch the accumulators (the next MC sweep) overlaps with
+  it; call .wait() before the accumulators are read or written again."""
+  if world_size() == 1:
+    return _PendingReduce(None, None)
+  if _dist().get_backend() != 'nccl':
+    allreduce_accumulators(engine)
+    return _PendingReduce(None, None)
+  t = accumulator_tensor(engine)
+  return _PendingReduce(_dist().all_reduce(t, op=_dist().ReduceOp.SUM, async_op=True), t)
+
+
 def allreduce_array(values: np.ndarray, op: str = 'sum') -> np.ndarray:
   """All-reduce of a small host array (float64) with SUM or MAX."""
   values = np.asarray(values, np.float64)
