@@ -128,6 +128,10 @@ struct GemmArgs {
   float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
 };
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
+// `count` dual / ones-row GEMMs (device array of GemmArgs, all with the same splitk and their
+// own workspace) in one launch + one reduction launch; max_m counts MFMA rows (M - 1)
+hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
+                               int max_n, int splitk);
 hipError_t launch_relu_copy(hipStream_t s, const float* z, float* a, long long n);
 hipError_t launch_delta_out(hipStream_t s, const float* woutp, const float* aL, float* delta,
                             int B, int Hp);

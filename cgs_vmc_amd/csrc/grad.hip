@@ -94,21 +94,21 @@ __device__ __forceinline__ TileRegs scale_tile(const TileRegs& r, const float* _
 }
 
 template <bool DUAL>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+__device__ __forceinline__ void gemm_block(const GemmArgs& g, int bx, int by, int bz) {
   __shared__ __attribute__((aligned(16))) float As[GK][GLD];
   __shared__ __attribute__((aligned(16))) float Bs[GK][GLD];
   __shared__ __attribute__((aligned(16))) float Bs2[DUAL ? GK : 1][GLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int m0 = by * GT, n0 = bx * GT;
   int kc = (g.K + g.splitk - 1) / g.splitk;
   kc = (kc + GK - 1) / GK * GK;
-  const int kbeg = blockIdx.z * kc;
+  const int kbeg = bz * kc;
   const int kend = min(g.K, kbeg + kc);
   const bool a_kfast = (g.sak == 1), b_kfast = (g.sbk == 1);
   const int a_extent = g.ones_row ? g.M - 1 : g.M;
   const int ones_d = -1;
-  const bool do_colsum = g.ones_row && blockIdx.y == 0 && tid < GT;
+  const bool do_colsum = g.ones_row && by == 0 && tid < GT;
   float cs = 0.f, cs2 = 0.f;
 
   f32x16 acc, acc2;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (m < a_extent && n < g.N) {
       if (g.splitk > 1) {
-        float* ws = g.workspace + (long long)blockIdx.z * (DUAL ? 2 : 1) * mn;
+        float* ws = g.workspace + (long long)bz * (DUAL ? 2 : 1) * mn;
         ws[(long long)m * g.N + n] = acc[r];
         if (DUAL) ws[mn + (long long)m * g.N + n] = acc2[r];
       } else {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
   if (do_colsum && n0 + tid < g.N) {
     const int m = g.M - 1, nn = n0 + tid;
     if (g.splitk > 1) {
-      float* ws = g.workspace + (long long)blockIdx.z * (DUAL ? 2 : 1) * mn;
+      float* ws = g.workspace + (long long)bz * (DUAL ? 2 : 1) * mn;
       ws[(long long)m * g.N + nn] = cs;
       if (DUAL) ws[mn + (long long)m * g.N + nn] = cs2;
     } else {
@@ -182,6 +182,40 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
       if (DUAL) gemm_epilogue(g, g.C2, m, nn, cs2);
     }
   }
+}
+
+template <bool DUAL>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+  gemm_block<DUAL>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent dual GEMMs (one per layer's weight gradient) in ONE launch:
+// blockIdx.z = problem * splitk + split.  With ~4 workgroups co-resident per CU the global
+// load latency of one is hidden behind the MFMAs of the others.
+__global__ __launch_bounds__(256) void k_gemm_batched(const GemmArgs* __restrict__ batch,
+                                                      int splitk) {
+  const GemmArgs g = batch[blockIdx.z / splitk];
+  const int m_rows = g.ones_row ? g.M - 1 : g.M;
+  if ((int)blockIdx.x * GT >= g.N || (int)blockIdx.y * GT >= m_rows) return;   // block-uniform
+  gemm_block<true>(g, blockIdx.x, blockIdx.y, blockIdx.z % splitk);
+}
+
+__device__ __forceinline__ void gemm_reduce_body(const GemmArgs& g, long long start,
+                                                 long long stride) {
+  const long long mn = (long long)g.M * g.N;
+  const int nd = g.dual ? 2 : 1;
+  for (long long i = start; i < mn * nd; i += stride) {
+    const int d = (int)(i / mn);
+    const long long e = i % mn;
+    float v = 0.f;
+    for (int z = 0; z < g.splitk; ++z) v += g.workspace[((long long)z * nd + d) * mn + e];
+    gemm_epilogue(g, d ? g.C2 : g.C, (int)(e / g.N), (int)(e % g.N), v);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_reduce_batched(const GemmArgs* __restrict__ batch) {
+  const GemmArgs g = batch[blockIdx.y];
+  gemm_reduce_body(g, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
 }
 
 __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
@@ -208,6 +242,17 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
     const int blocks = (int)min((total + 255) / 256, (long long)2048);
     hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks), dim3(256), 0, s, g);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
+                               int max_n, int splitk) {
+  if (count <= 0) return hipSuccess;
+  const dim3 grid((max_n + GT - 1) / GT, (max_m + GT - 1) / GT, count * splitk);
+  hipLaunchKernelGGL(k_gemm_batched, grid, dim3(256), 0, s, dev_batch, splitk);
+  const long long total = 2LL * (max_m + 1) * max_n;
+  const int blocks = (int)min((total + 255) / 256, (long long)512);
+  hipLaunchKernelGGL(k_gemm_reduce_batched, dim3(blocks, count), dim3(256), 0, s, dev_batch);
   return hipGetLastError();
 }
 

@@ -54,7 +54,10 @@ struct vmc_ctx {
   std::vector<float*> act;   // L views [B][Hp] into act_all
   float* act_all = nullptr;  // [L][B][Hp]
   bool acts_valid = false;   // act[] hold the activations of psi on the current chains
-  float* delta[2] = {nullptr, nullptr};
+  std::vector<float*> delta;   // L views [B][Hp] into delta_all: d logit / d z_l
+  float* delta_all = nullptr;
+  GemmArgs* d_batch[2] = {nullptr, nullptr};   // weight-gradient GEMM tables (w = eloc / ratio)
+  bool batch_ready[2] = {false, false};
   float *ratio = nullptr, *ones = nullptr;
   float *acc = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad_tmp = nullptr;
   long long adam_t = 0;
@@ -294,10 +297,11 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(dalloc(&c->act_all, L * B * Hp));
   CA(hipMemsetAsync(c->act_all, 0, L * B * Hp * sizeof(float), c->stream));
   for (int l = 0; l < L; ++l) c->act[l] = c->act_all + l * B * Hp;
-  for (int i = 0; i < 2; ++i) {
-    CA(dalloc(&c->delta[i], B * Hp));
-    CA(hipMemsetAsync(c->delta[i], 0, B * Hp * sizeof(float), c->stream));
-  }
+  c->delta.resize(L, nullptr);
+  CA(dalloc(&c->delta_all, L * B * Hp));
+  CA(hipMemsetAsync(c->delta_all, 0, L * B * Hp * sizeof(float), c->stream));
+  for (int l = 0; l < L; ++l) c->delta[l] = c->delta_all + l * B * Hp;
+  for (int i = 0; i < 2; ++i) CA(dalloc(&c->d_batch[i], L + 1));
   CA(dalloc(&c->ratio, B)); CA(dalloc(&c->ones, B));
   CA(launch_fill(c->stream, c->ones, 1.f, B));
   CA(dalloc(&c->acc, 2 * P + 8)); CA(dalloc(&c->adam_m, P)); CA(dalloc(&c->adam_v, P));
@@ -306,7 +310,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(hipMemsetAsync(c->adam_m, 0, P * sizeof(float), c->stream));
   CA(hipMemsetAsync(c->adam_v, 0, P * sizeof(float), c->stream));
   const long long mmax = N > c->H ? N : c->H;
-  CA(dalloc(&c->gemm_ws, (long long)c->splitk * 2 * (mmax + 1) * c->H));
+  CA(dalloc(&c->gemm_ws, (long long)(L + 1) * c->splitk * 2 * (mmax + 1) * c->H));
   CA(dalloc(&c->d_accepted, 1)); CA(dalloc(&c->d_sum, 1)); CA(dalloc(&c->d_max, 1));
   CA(dalloc(&c->inj_up, B)); CA(dalloc(&c->inj_dn, B)); CA(dalloc(&c->inj_u, B));
   CA(dalloc(&c->acc_mask, B));
@@ -329,7 +333,7 @@ void vmc_destroy(vmc_ctx* c) {
   }
   if (c->act_all) hipFree(c->act_all);
   void* ptrs[] = {c->configs, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
-                  c->offdiag, c->rowinfo, c->delta[0], c->delta[1], c->ratio, c->ones, c->acc,
+                  c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0], c->d_batch[1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->d_accepted, c->d_sum,
                   c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->inj_up, c->inj_dn, c->inj_u,
                   c->acc_mask};
@@ -610,38 +614,41 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
     g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1;
     HIPCHK(c, launch_gemm(c->stream, g));
   }
-  // Every weight-gradient GEMM below is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows
-  // 0..K_in-1 give dW, the implicit ones row gives db (b_l sits right behind w_l in theta),
-  // the unscaled product goes to g1 and the w-scaled one to g2.
-  auto weight_grad = [&](const float* a, long long a_ld, int k_in, const float* delta,
-                         long long sbk, long long sbn, int n_out, long long off) -> int {
+  // back-propagation of d logit / d z_l: delta[L-1] = w_out (.) relu', then W_l^T chains
+  HIPCHK(c, launch_delta_out(c->stream, p.woutp, c->act[L - 1], c->delta[L - 1], B, Hp));
+  for (int l = L - 1; l > 0; --l) {
     GemmArgs g; memset(&g, 0, sizeof(g));
-    g.A = a; g.sam = 1; g.sak = a_ld; g.M = k_in + 1; g.ones_row = 1;
-    g.B = delta; g.sbk = sbk; g.sbn = sbn; g.kscale = w; g.dual = 1;
-    g.N = n_out; g.K = B; g.C = g1 + off; g.C2 = g2 + off; g.ldc = n_out; g.epilogue = 3;
-    g.splitk = c->splitk; g.workspace = c->gemm_ws;
+    g.A = c->delta[l]; g.sam = Hp; g.sak = 1;
+    g.B = p.theta + off_w(c, l); g.sbk = 1; g.sbn = H;   // W_l^T
+    g.M = B; g.N = H; g.K = H; g.C = c->delta[l - 1]; g.ldc = Hp;
+    g.mask = c->act[l - 1]; g.ldmask = Hp; g.epilogue = 2; g.splitk = 1;
     HIPCHK(c, launch_gemm(c->stream, g));
-    return VMC_OK;
-  };
-  // output layer: d logit / d w_out = a_L, d logit / d b_out = 1  (delta = 1 for every b)
-  PROPAGATE(weight_grad(c->act[L - 1], Hp, H, c->ones, 1, 0, 1, off_wout(c)));
-  // back-propagation of d logit / d z_l
-  int cur = 0;
-  HIPCHK(c, launch_delta_out(c->stream, p.woutp, c->act[L - 1], c->delta[cur], B, Hp));
-  for (int l = L - 1; l >= 0; --l) {
-    const float* delta = c->delta[cur];
-    if (l == 0) PROPAGATE(weight_grad(c->configs, N, N, delta, Hp, 1, H, off_w(c, 0)));
-    else PROPAGATE(weight_grad(c->act[l - 1], Hp, H, delta, Hp, 1, H, off_w(c, l)));
-    if (l > 0) {
-      GemmArgs g; memset(&g, 0, sizeof(g));
-      g.A = delta; g.sam = Hp; g.sak = 1;
-      g.B = p.theta + off_w(c, l); g.sbk = 1; g.sbn = H;   // W_l^T
-      g.M = B; g.N = H; g.K = H; g.C = c->delta[cur ^ 1]; g.ldc = Hp;
-      g.mask = c->act[l - 1]; g.ldmask = Hp; g.epilogue = 2; g.splitk = 1;
-      HIPCHK(c, launch_gemm(c->stream, g));
-      cur ^= 1;
-    }
   }
+  // Every weight-gradient GEMM is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows 0..K_in-1
+  // give dW, the implicit ones row gives db (b_l sits right behind w_l in theta), the unscaled
+  // product goes to g1 and the w-scaled one to g2.  All L+1 of them run as ONE batched launch
+  // (+ one reduction launch); the argument table is built once per weight vector `w`.
+  const int slot = (w == c->ratio) ? 1 : 0;
+  if (!c->batch_ready[slot]) {
+    std::vector<GemmArgs> tab;
+    const long long ws_stride = (long long)c->splitk * 2 * ((N > H ? N : H) + 1) * H;
+    auto add = [&](const float* a, long long a_ld, int k_in, const float* delta, long long sbk,
+                   long long sbn, int n_out, long long off) {
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.A = a; g.sam = 1; g.sak = a_ld; g.M = k_in + 1; g.ones_row = 1;
+      g.B = delta; g.sbk = sbk; g.sbn = sbn; g.kscale = w; g.dual = 1;
+      g.N = n_out; g.K = B; g.C = g1 + off; g.C2 = g2 + off; g.ldc = n_out; g.epilogue = 3;
+      g.splitk = c->splitk; g.workspace = c->gemm_ws + (long long)tab.size() * ws_stride;
+      tab.push_back(g);
+    };
+    // output layer: d logit / d w_out = a_L, d logit / d b_out = 1  (delta = 1 for every b)
+    add(c->act[L - 1], Hp, H, c->ones, 1, 0, 1, off_wout(c));
+    for (int l = L - 1; l > 0; --l) add(c->act[l - 1], Hp, H, c->delta[l], Hp, 1, H, off_w(c, l));
+    add(c->configs, N, N, c->delta[0], Hp, 1, H, off_w(c, 0));
+    HIPCHK(c, hipMemcpy(c->d_batch[slot], tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
+    c->batch_ready[slot] = true;
+  }
+  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot], L + 1, N > H ? N : H, H, c->splitk));
   return VMC_OK;
 }
 
