@@ -60,7 +60,7 @@ struct TailArgs {
   PackedParams pp;
   const float* z1;          // [n_base][Hp] cached first-layer pre-activations
   const float* logit_base;  // [n_base] cached logits (ratio mode)
-  const int2* rowinfo;      // [n_rows] {chain, signed bond+1} or nullptr (row == chain)
+  const int2* rowinfo;      // [n_rows] {chain, signed bond+1 or 0}; never null (launch_iota_rows)
   const int2* bonds;        // [n_bonds] {i, j}
   const float* half_jx;     // [n_bonds] 0.5 * j_x
   const int* n_rows_dev;    // device row count (list mode) or nullptr
@@ -100,6 +100,7 @@ hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp, 
 hipError_t launch_z1(hipStream_t s, const float* configs, const float* w1p, const float* b1p,
                      float* z1, int rows, int N, int Hp);
 hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode);
+hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n);
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp);
 
 // bond list / local-energy reduction (eloc.hip)

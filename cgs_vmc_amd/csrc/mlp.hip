@@ -164,29 +164,20 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
   // row descriptor of this lane in a tile: cached z1 row of the chain + rank-2 exchange update
   // z1' = z1 + coef (W1[i] - W1[j])
   struct Desc { const float* zb; const float* wa; const float* wb; float coef; int row, chain, bond; bool valid; };
+  // branch-free (every load unconditional, indices clamped): the waitcnt pass can then count
+  // vmcnt exactly, which lets the three dependent loads be issued a whole tile ahead
   auto describe = [&](int tile) {
     Desc d;
     d.row = tile * 128 + wave * 32 + j;
     d.valid = d.row < n_rows;
-    d.chain = 0; d.bond = 0; d.coef = 0.f;
-    int bs = 0;
-    if (d.valid) {
-      if (a.rowinfo) {
-        const int2 ri = a.rowinfo[d.row];
-        d.chain = ri.x; bs = ri.y;
-      } else {
-        d.chain = d.row;
-      }
-    }
-    d.wa = a.pp.w1p;
-    d.wb = d.wa;
-    if (bs != 0) {
-      d.bond = (bs > 0 ? bs : -bs) - 1;
-      d.coef = bs > 0 ? -2.f : 2.f;           // -2 * s_i
-      const int2 ab = a.bonds[d.bond];
-      d.wa += (long long)ab.x * Hp;
-      d.wb += (long long)ab.y * Hp;
-    }
+    const int2 ri = a.rowinfo[d.valid ? d.row : n_rows - 1];   // {chain, +-(bond+1) or 0}
+    d.chain = ri.x;
+    const int bs = ri.y;
+    d.bond = (bs > 0 ? bs : -bs) - (bs != 0 ? 1 : 0);
+    d.coef = bs > 0 ? -2.f : (bs < 0 ? 2.f : 0.f);          // -2 * s_i, 0 for a plain row
+    const int2 ab = a.bonds[d.bond];
+    d.wa = a.pp.w1p + (long long)ab.x * Hp;
+    d.wb = a.pp.w1p + (long long)ab.y * Hp;
     d.zb = a.z1 + (long long)d.chain * Hp;
     return d;
   };
@@ -228,6 +219,9 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
     int opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
     asm volatile("" : "+s"(p32c));   // same for the ~100 per-item weight addresses
+    // next tile's row descriptors: three dependent loads, issued here so that their latency
+    // hides under this tile's layers
+    const Desc nxt_d = describe(has_next ? next_tile : tile);
 
     // ---- all but the last H x H layer: in -> out -> in
     for (int l = 0; l + 1 < n_hidden; ++l) {
@@ -273,7 +267,6 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
     // are cut into 4 segments; segment sg gathers register group sg of the NEXT tile's unit
     // tile `to` (3 float4 in flight: loads at the segment's first item, arithmetic + LDS store
     // at its last), so the gather runs in the shadow of the matrix pipe.
-    const Desc nxt_d = describe(has_next ? next_tile : tile);
     float part = 0.f;
     {
       const int l = n_hidden - 1;
@@ -344,6 +337,19 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
         for (int e = 0; e < 4; ++e) in[t][4 * q + e] = v[e];
       }
   }
+}
+
+// rowinfo of a plain batch of rows: row r = chain r, no exchange update
+__global__ void k_iota_rows(int2* __restrict__ dst, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    dst[i] = make_int2(i, 0);
+}
+
+hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n) {
+  if (n <= 0) return hipSuccess;
+  const int blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_iota_rows, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, s, dst, n);
+  return hipGetLastError();
 }
 
 // L = 1 (no H x H layer): logit = relu(z1') . w_out + b_out, one thread per row

@@ -48,6 +48,9 @@ struct vmc_ctx {
   int *cnt = nullptr, *off = nullptr;
   float *diag = nullptr, *val = nullptr, *offdiag = nullptr;
   int2* rowinfo = nullptr;
+  int2* bond_dummy = nullptr;   // {0,0}: stands in for the bond table before vmc_set_bonds
+  int2* rowinfo_id = nullptr;   // identity list {r, 0} for plain rows (cache refresh)
+  int2* tmp_rowinfo = nullptr;
   bool list_valid = false;
   long long last_rows = 0;
   // gradient path
@@ -158,7 +161,7 @@ TailArgs tail_args(vmc_ctx* c, int which) {
   TailArgs a;
   memset(&a, 0, sizeof(a));
   a.pp = c->ps[which].packed();
-  a.bonds = c->bonds;
+  a.bonds = c->bonds ? c->bonds : c->bond_dummy;   // the kernel loads bonds[0] unconditionally
   a.half_jx = c->half_jx;
   a.n_hidden = c->L - 1;
   a.n_sites = c->N;
@@ -178,7 +181,7 @@ int ensure_cache(vmc_ctx* c, int which) {
   {
     Timer t(c, "tail_amp");
     TailArgs a = tail_args(c, which);
-    a.z1 = p.z1; a.n_rows = c->B; a.out = p.logit;
+    a.z1 = p.z1; a.n_rows = c->B; a.out = p.logit; a.rowinfo = c->rowinfo_id;
     HIPCHK(c, launch_tail32(c->stream, a, c->Hp, false));
   }
   p.cache_valid = true;
@@ -224,7 +227,9 @@ int local_energy_device(vmc_ctx* c, int which) {
 
 int grow_tmp(vmc_ctx* c, long long rows) {
   if (rows <= c->tmp_rows) return VMC_OK;
-  if (c->tmp_cfg) { hipFree(c->tmp_cfg); hipFree(c->tmp_z1); hipFree(c->tmp_out); }
+  if (c->tmp_cfg) { hipFree(c->tmp_cfg); hipFree(c->tmp_z1); hipFree(c->tmp_out); hipFree(c->tmp_rowinfo); }
+  HIPCHK(c, dalloc(&c->tmp_rowinfo, rows));
+  HIPCHK(c, launch_iota_rows(c->stream, c->tmp_rowinfo, (int)rows));
   HIPCHK(c, dalloc(&c->tmp_cfg, rows * c->N));
   HIPCHK(c, dalloc(&c->tmp_z1, rows * c->Hp));
   HIPCHK(c, dalloc(&c->tmp_out, rows));
@@ -315,6 +320,8 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(dalloc(&c->inj_up, B)); CA(dalloc(&c->inj_dn, B)); CA(dalloc(&c->inj_u, B));
   CA(dalloc(&c->acc_mask, B));
   CA(dalloc(&c->cnt, B)); CA(dalloc(&c->off, B + 1)); CA(dalloc(&c->diag, B));
+  CA(dalloc(&c->rowinfo_id, B)); CA(launch_iota_rows(c->stream, c->rowinfo_id, (int)B));
+  CA(dalloc(&c->bond_dummy, 1)); CA(hipMemsetAsync(c->bond_dummy, 0, sizeof(int2), c->stream));
   CA(dalloc(&c->offdiag, B));
   CA(hipStreamSynchronize(c->stream));
 #undef CA
@@ -335,7 +342,7 @@ void vmc_destroy(vmc_ctx* c) {
   void* ptrs[] = {c->configs, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0], c->d_batch[1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->d_accepted, c->d_sum,
-                  c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->inj_up, c->inj_dn, c->inj_u,
+                  c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->tmp_rowinfo, c->rowinfo_id, c->bond_dummy, c->inj_up, c->inj_dn, c->inj_u,
                   c->acc_mask};
   for (void* q : ptrs) if (q) hipFree(q);
   delete c;
@@ -449,7 +456,7 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
     ParamSet& p = c->ps[which];
     HIPCHK(c, launch_z1(c->stream, c->tmp_cfg, p.w1p, p.b1p, c->tmp_z1, (int)n_rows, c->N, c->Hp));
     TailArgs a = tail_args(c, which);
-    a.z1 = c->tmp_z1; a.n_rows = (int)n_rows; a.out = c->tmp_out;
+    a.z1 = c->tmp_z1; a.n_rows = (int)n_rows; a.out = c->tmp_out; a.rowinfo = c->tmp_rowinfo;
     HIPCHK(c, launch_tail32(c->stream, a, c->Hp, false));
     HIPCHK(c, hipMemcpyAsync(host.data(), c->tmp_out, n_rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   }
