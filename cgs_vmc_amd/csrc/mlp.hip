@@ -22,10 +22,10 @@
 #include <type_traits>
 
 #ifndef SWEEP_RT
-#define SWEEP_RT 12   // resident k-tiles of the first H x H layer (sweep kernel)
+#define SWEEP_RT 14   // resident k-tiles of the first H x H layer (sweep kernel)
 #endif
 #ifndef SWEEP_PF
-#define SWEEP_PF 4    // stages of the weight prefetch ring; (16 - SWEEP_RT) % SWEEP_PF == 0
+#define SWEEP_PF 2    // stages of the weight prefetch ring; (16 - SWEEP_RT) % SWEEP_PF == 0
 #endif
 
 // ------------------------------------------------------------------------------------ pack
