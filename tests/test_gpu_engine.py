@@ -22,6 +22,8 @@ SHAPES = [
     (10, 80, 3, 37, 'chain'),      # reference default fc_layer_size=80 -> padded to 128
     (12, 200, 1, 48, 'chain'),     # single layer, H padded to 256
     (20, 256, 4, 130, 'chain'),    # config-5-like depth
+    (150, 256, 6, 20, 'chain'),    # config-5 ansatz; N > 128: general (non-prefetch) sampler path,
+                                   # W1 does not fit LDS next to the chain state
 ]
 
 
@@ -130,7 +132,7 @@ def test_constant_wavefunction_closed_form():
   eng.close()
 
 
-@pytest.mark.parametrize('n,h,L,b,kind', SHAPES[:4])
+@pytest.mark.parametrize('n,h,L,b,kind', SHAPES[:4] + SHAPES[-1:])
 def test_proposals_bit_exact(n, h, L, b, kind):
   eng, theta, cfg, _ = _make(n, h, L, b, kind)
   for step in (0, 1, 12345678901):
@@ -158,7 +160,7 @@ def test_chain_offset_keys_rng_by_global_id():
   full.close(); half.close()
 
 
-@pytest.mark.parametrize('n,h,L,b,kind', SHAPES[:5])
+@pytest.mark.parametrize('n,h,L,b,kind', SHAPES[:5] + SHAPES[-1:])
 def test_injected_mc_step_matches_oracle(n, h, L, b, kind):
   eng, theta, cfg, _ = _make(n, h, L, b, kind)
   amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
@@ -183,10 +185,11 @@ def test_injected_mc_step_matches_oracle(n, h, L, b, kind):
   eng.close()
 
 
-def test_sampler_trajectory_follows_oracle():
+@pytest.mark.parametrize('n,h,L,b', [(16, 32, 2, 64),      # prefetched-draw sampler, W1 in LDS
+                                     (150, 64, 2, 40)])    # N > 128: general sampler path
+def test_sampler_trajectory_follows_oracle(n, h, L, b):
   """vmc_mc_steps with its own Philox stream reproduces the oracle's chains step by step
   (chains whose accept test falls in the tolerance band are excluded from then on)."""
-  n, h, L, b = 16, 32, 2, 64
   eng, theta, cfg, _ = _make(n, h, L, b, 'chain')
   amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
   cur = cfg.copy()
