@@ -97,8 +97,6 @@ struct SweepArgs {
 hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp, int L,
                        float* w1p, float* b1p, float* bh, float* p32, float* p16, float* woutp,
                        float* bout);
-hipError_t launch_z1(hipStream_t s, const float* configs, const float* w1p, const float* b1p,
-                     float* z1, int rows, int N, int Hp);
 hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode);
 hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n);
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp);
@@ -124,7 +122,7 @@ struct GemmArgs {
   int ones_row;                         // row M-1 of A is an implicit row of ones
   const float* bias;                    // epilogue 1: + bias[n] then relu
   const float* mask;  long long ldmask; // epilogue 2: * (mask[m*ldmask+n] > 0)
-  int epilogue;                         // 0 none, 1 bias+relu, 2 mask, 3 accumulate (C += )
+  int epilogue;                         // 0 none, 1 bias+relu, 2 mask, 3 accumulate (C += ), 4 bias
   int splitk;                           // >= 1
   float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
 };

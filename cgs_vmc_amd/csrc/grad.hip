@@ -26,6 +26,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, int m
     case 1: *c = fmaxf(v + g.bias[n], 0.f); break;
     case 2: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? v : 0.f; break;
     case 3: *c += v; break;
+    case 4: *c = v + g.bias[n]; break;
     default: *c = v; break;
   }
 }

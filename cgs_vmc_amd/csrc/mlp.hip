@@ -1,7 +1,8 @@
 // Amplitude kernels of the fully-connected ansatz (wavefunctions.py:328-371) for gfx950.
 //
 //   k_pack      re-packs the flat parameter vector into MFMA-fragment-major weight images
-//   k_z1        first layer on raw +-1 configurations: z1 = x W1 + b1
+//   (the first layer on raw +-1 configurations, z1 = x W1 + b1, runs through the LDS-tiled
+//    MFMA GEMM of grad.hip; see first_layer() in vmc_api.hip)
 //   k_tail32    layers 2..L + output dot for a list of rows, each row = cached z1 of a
 //               chain (+ optional rank-2 exchange update), v_mfma_f32_32x32x2_f32,
 //               activations never leave registers (transposed formulation, see below)
@@ -85,45 +86,6 @@ hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp, 
                        float* bout) {
   hipLaunchKernelGGL(k_pack, dim3(512), dim3(256), 0, s, theta, N, H, Hp, L, w1p, b1p, bh, p32,
                      p16, woutp, bout);
-  return hipGetLastError();
-}
-
-// -------------------------------------------------------------------------------------- z1
-// z1[b][i] = b1[i] + sum_n x[b][n] W1[n][i].  8 rows per 256-thread block, spins in LDS.
-#define Z1_ROWS 8
-__global__ __launch_bounds__(256) void k_z1(const float* __restrict__ configs,
-                                            const float* __restrict__ w1p,
-                                            const float* __restrict__ b1p,
-                                            float* __restrict__ z1, int rows, int N, int Hp) {
-  extern __shared__ float s_x[];  // [Z1_ROWS][N]
-  const int row0 = blockIdx.x * Z1_ROWS;
-  for (int i = threadIdx.x; i < Z1_ROWS * N; i += 256) {
-    const int r = i / N, n = i % N;
-    s_x[i] = (row0 + r < rows) ? configs[(long long)(row0 + r) * N + n] : 0.f;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < Hp; c += 256) {
-    float acc[Z1_ROWS];
-    const float b = b1p[c];
-#pragma unroll
-    for (int r = 0; r < Z1_ROWS; ++r) acc[r] = b;
-    for (int n = 0; n < N; ++n) {
-      const float w = w1p[(long long)n * Hp + c];
-#pragma unroll
-      for (int r = 0; r < Z1_ROWS; ++r) acc[r] = fmaf(s_x[r * N + n], w, acc[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < Z1_ROWS; ++r)
-      if (row0 + r < rows) z1[(long long)(row0 + r) * Hp + c] = acc[r];
-  }
-}
-
-hipError_t launch_z1(hipStream_t s, const float* configs, const float* w1p, const float* b1p,
-                     float* z1, int rows, int N, int Hp) {
-  if (rows <= 0) return hipSuccess;
-  const int grid = (rows + Z1_ROWS - 1) / Z1_ROWS;
-  hipLaunchKernelGGL(k_z1, dim3(grid), dim3(256), Z1_ROWS * N * sizeof(float), s, configs, w1p,
-                     b1p, z1, rows, N, Hp);
   return hipGetLastError();
 }
 

@@ -169,6 +169,19 @@ TailArgs tail_args(vmc_ctx* c, int which) {
   return a;
 }
 
+// First layer of raw configurations on the matrix cores: z1[rows,Hp] = X[rows,N] W1p[N,Hp] + b1
+// through the LDS-tiled fp32-MFMA GEMM (64x64x32 tiles of spins and weights staged in LDS,
+// dwordx4 loads of the configuration batch).  wavefunctions.py:345-349, first snt.Linear.
+int first_layer(vmc_ctx* c, const ParamSet& p, const float* configs, float* z1, int rows) {
+  GemmArgs g; memset(&g, 0, sizeof(g));
+  g.A = configs; g.sam = c->N; g.sak = 1;
+  g.B = p.w1p; g.sbk = c->Hp; g.sbn = 1;
+  g.M = rows; g.N = c->Hp; g.K = c->N; g.C = z1; g.ldc = c->Hp;
+  g.bias = p.b1p; g.epilogue = 4; g.splitk = 1;
+  HIPCHK(c, launch_gemm(c->stream, g));
+  return VMC_OK;
+}
+
 // z1 / logit cache of parameter set `which` for the ctx's chains
 int ensure_cache(vmc_ctx* c, int which) {
   PROPAGATE(ensure_packed(c, which));
@@ -176,7 +189,7 @@ int ensure_cache(vmc_ctx* c, int which) {
   if (p.cache_valid) return VMC_OK;
   {
     Timer t(c, "z1");
-    HIPCHK(c, launch_z1(c->stream, c->configs, p.w1p, p.b1p, p.z1, c->B, c->N, c->Hp));
+    PROPAGATE(first_layer(c, p, c->configs, p.z1, c->B));
   }
   {
     Timer t(c, "tail_amp");
@@ -454,7 +467,7 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
     PROPAGATE(grow_tmp(c, n_rows));
     HIPCHK(c, hipMemcpyAsync(c->tmp_cfg, configs, n_rows * c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     ParamSet& p = c->ps[which];
-    HIPCHK(c, launch_z1(c->stream, c->tmp_cfg, p.w1p, p.b1p, c->tmp_z1, (int)n_rows, c->N, c->Hp));
+    PROPAGATE(first_layer(c, p, c->tmp_cfg, c->tmp_z1, (int)n_rows));
     TailArgs a = tail_args(c, which);
     a.z1 = c->tmp_z1; a.n_rows = (int)n_rows; a.out = c->tmp_out; a.rowinfo = c->tmp_rowinfo;
     HIPCHK(c, launch_tail32(c->stream, a, c->Hp, false));
