@@ -22,6 +22,9 @@
 #include "common.hpp"
 #include <type_traits>
 
+#ifndef TAIL_RD
+#define TAIL_RD 8     // stages of k_tail32's weight-fragment ring (items of 4 MFMAs each)
+#endif
 #ifndef SWEEP_RT
 #define SWEEP_RT 14   // resident k-tiles of the first H x H layer (sweep kernel)
 #endif
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
   // ahead of its use, across (to, ti), layer AND tile boundaries (the last layer prefetches the
   // first items of layer 0 for the wave's next tile).  Every issue is unconditional so that
   // vmcnt is counted exactly.
-  constexpr int NI = 4 * HT * HT, RD = 8;
+  constexpr int NI = 4 * HT * HT, RD = TAIL_RD;
   f32x4 ring[RD];
   // uniform (SGPR) base + one 32-bit per-lane byte offset -> saddr addressing, no per-item
   // 64-bit VGPR address (LICM otherwise keeps ~100 of them live across the persistent loop)

@@ -274,3 +274,43 @@ def test_training_reaches_exact_ground_state_energy(tmp_path, optimizer):
   tail = np.mean(energies[-20:])
   assert abs(tail - (-11.2285)) < 0.01 * 11.2285, tail
   assert tail > -11.2285 - 0.05          # variational: not below E0 beyond MC noise
+
+
+def test_resume_training_restores_latest_checkpoint(tmp_path):
+  """--resume_training (run_training.py:141-143): the second run starts from the parameters of
+  the latest checkpoint (the ones PRIOR to the first run's last epoch) and keeps appending to
+  metrics.txt."""
+  from cgs_vmc_amd import run_training, session, wavefunctions
+  d = str(tmp_path)
+  hp = ('batch_size=64,fc_layer_size=32,num_fc_layers=2,num_equilibration_sweeps=3,'
+        'num_batches_per_epoch=5')
+  common = ['--checkpoint_dir', d, '--num_sites', '16', '--heisenberg_jx', '-1.0',
+            '--wavefunction_type', 'fully_connected', '--optimizer', 'EnergyGradient',
+            '--hparams', hp]
+  run_training.main(common + ['--num_epochs', '4'])
+  first = np.load(os.path.join(d, 'model_prior_3_epochs.npz'))
+  session.reset_default_graph(); wavefunctions.reset_name_scope()
+  run_training.main(common + ['--num_epochs', '2', '--resume_training'])
+  # the resumed run wrote its own 'prior to epoch 0' checkpoint = the restored parameters
+  resumed = np.load(os.path.join(d, 'model_prior_0_epochs.npz'))
+  assert sorted(first.files) == sorted(resumed.files) and len(first.files) == 6
+  for k in first.files:
+    np.testing.assert_array_equal(first[k], resumed[k])
+  metrics = open(os.path.join(d, 'metrics.txt')).read().split()
+  assert len(metrics) == 6
+
+
+def test_update_norm_keeps_psi_finite_during_training():
+  """Wavefunction.update_norm through the op handle: after the shift update max psi <= 1e10
+  and ratios (sampling, local energy) are unchanged."""
+  from cgs_vmc_amd import graph_builders
+  hp = _hparams()
+  wf, ham, opt, ops, sess, shared = _build('EnergyGradient', hp)
+  configs = shared[graph_builders.ResourceName.CONFIGS]
+  e_before = sess.run(ham.local_value(wf, configs))
+  wf._set_shift(-45.0)                              # psi = exp(logit + 45) ~ 3e19 > 1e10
+  assert sess.run(wf(configs)).max() > 1e10
+  sess.run(ops.update_wf_norm)
+  psi = sess.run(wf(configs))
+  assert np.isfinite(psi).all() and abs(psi.max() - 1e10) < 1e-3 * 1e10
+  np.testing.assert_allclose(sess.run(ham.local_value(wf, configs)), e_before, rtol=1e-6)
