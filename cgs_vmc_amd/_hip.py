@@ -75,6 +75,10 @@ SIGNATURES = {
     'vmc_mean_energy': (C.c_int, [_ctx, C.POINTER(C.c_double)]),
     'vmc_get_adam_state': (C.c_int, [_ctx, _fp, _fp, C.POINTER(C.c_int64)]),
     'vmc_set_adam_state': (C.c_int, [_ctx, _fp, _fp, C.c_int64]),
+    'vmc_epoch_energy_gradient': (C.c_int, [_ctx, C.c_int64, C.c_int32, C.c_int64, C.c_float]),
+    'vmc_epoch_log_overlap': (C.c_int, [_ctx, C.c_float, C.c_int64, C.c_int32, C.c_int64, C.c_float,
+                                        C.c_float, C.c_float, C.c_float, C.c_float,
+                                        C.POINTER(C.c_double)]),
     'vmc_update_norm': (C.c_int, [_ctx, C.c_float]),
     'vmc_timing_enable': (C.c_int, [_ctx, C.c_int]),
     'vmc_timing_reset': (C.c_int, [_ctx]),

@@ -795,6 +795,38 @@ int vmc_update_norm(vmc_ctx* c, float max_value) {
   return VMC_OK;
 }
 
+int vmc_epoch_energy_gradient(vmc_ctx* c, int64_t n_eq_steps, int32_t n_batches, int64_t n_mc_steps,
+                              float max_value) {
+  CHECK_CTX(c);
+  if (n_eq_steps < 0 || n_batches < 0 || n_mc_steps < 0) return fail(c, VMC_ERR_INVALID, "negative count");
+  PROPAGATE(vmc_mc_steps(c, n_eq_steps, nullptr));                       // training.py:608-609
+  if (max_value > 0.f) PROPAGATE(vmc_update_norm(c, max_value));          // training.py:611-612
+  PROPAGATE(vmc_reset_accumulators(c));                                   // training.py:613
+  for (int b = 0; b < n_batches; ++b) {                                   // training.py:614-617
+    PROPAGATE(vmc_accumulate(c, VMC_MODE_ENERGY_GRADIENT, 0.f));
+    PROPAGATE(vmc_mc_steps(c, n_mc_steps, nullptr));
+  }
+  return VMC_OK;
+}
+
+int vmc_epoch_log_overlap(vmc_ctx* c, float beta, int64_t n_eq_steps, int32_t n_batches,
+                          int64_t n_mc_steps, float max_value, float lr, float beta1, float beta2,
+                          float eps, double* energy) {
+  CHECK_CTX(c);
+  if (n_eq_steps < 0 || n_batches < 0 || n_mc_steps < 0) return fail(c, VMC_ERR_INVALID, "negative count");
+  PROPAGATE(vmc_mc_steps(c, n_eq_steps, nullptr));                       // training.py:750-751
+  if (max_value > 0.f) PROPAGATE(vmc_update_norm(c, max_value));          // training.py:753-754
+  PROPAGATE(vmc_transfer_params(c));                                      // training.py:755
+  for (int b = 0; b < n_batches; ++b) {                                   // training.py:756-761
+    PROPAGATE(vmc_mc_steps(c, n_mc_steps, nullptr));
+    PROPAGATE(vmc_reset_accumulators(c));
+    PROPAGATE(vmc_accumulate(c, VMC_MODE_LOG_OVERLAP_ITSWO, beta));
+    PROPAGATE(vmc_apply_adam(c, VMC_MODE_LOG_OVERLAP_ITSWO, lr, beta1, beta2, eps, nullptr));
+  }
+  if (energy) PROPAGATE(vmc_mean_energy(c, energy));                      // training.py:763
+  return VMC_OK;
+}
+
 int vmc_timing_enable(vmc_ctx* c, int on) { CHECK_CTX(c); c->timing = on != 0; return VMC_OK; }
 
 int vmc_timing_reset(vmc_ctx* c) {

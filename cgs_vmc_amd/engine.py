@@ -244,6 +244,22 @@ class VmcEngine:
     v = np.ascontiguousarray(v, np.float32)
     self._check(self._lib.vmc_set_adam_state(self._ctx, _fptr(m), _fptr(v), int(t)))
 
+  def epoch_energy_gradient(self, n_eq_steps: int, n_batches: int, n_mc_steps: int,
+                            max_value: float = 1e10):
+    """training.py:608-617 in one host call (everything before apply_gradients)."""
+    self._check(self._lib.vmc_epoch_energy_gradient(self._ctx, int(n_eq_steps), int(n_batches),
+                                                    int(n_mc_steps), float(max_value)))
+
+  def epoch_log_overlap(self, beta: float, n_eq_steps: int, n_batches: int, n_mc_steps: int,
+                        max_value: float, lr: float, beta1: float, beta2: float,
+                        eps: float) -> float:
+    """training.py:750-763 in one host call; returns the energy of the last batch."""
+    e = C.c_double()
+    self._check(self._lib.vmc_epoch_log_overlap(self._ctx, float(beta), int(n_eq_steps),
+                                                int(n_batches), int(n_mc_steps), float(max_value),
+                                                lr, beta1, beta2, eps, C.byref(e)))
+    return float(e.value)
+
   def update_norm(self, max_value: float = 1e10):
     self._check(self._lib.vmc_update_norm(self._ctx, float(max_value)))
 

@@ -179,7 +179,8 @@ def _common_ops(wavefunction, hamiltonian, hparams, shared_resources, mode):
     return num_epochs.value
 
   return dict(
-      configs=configs, engine=engine,
+      configs=configs, engine=engine, state=state, optimizer=optimizer, beta=beta,
+      hamiltonian=hamiltonian,
       accumulate_gradients=session_lib.Op(accumulate, 'accumulate_gradients'),
       apply_gradients=session_lib.Op(apply, 'apply_gradients'),
       reset_gradients=session_lib.Op(state.reset, 'reset_gradients'),
@@ -200,7 +201,8 @@ class EnergyGradientOptimizer(WavefunctionOptimizer):
     mean(E O) - mean(E) mean(O) to Adam."""
     ops = _common_ops(wavefunction, hamiltonian, hparams, shared_resources,
                       _hip.VMC_MODE_ENERGY_GRADIENT)
-    return TrainOpsTraditional(
+    self._fused = ops            # whole-epoch fast path (SURVEY.md 8f-1), see below
+    self._train_ops = TrainOpsTraditional(
         accumulate_gradients=ops['accumulate_gradients'],
         apply_gradients=ops['apply_gradients'],
         reset_gradients=ops['reset_gradients'],
@@ -210,20 +212,36 @@ class EnergyGradientOptimizer(WavefunctionOptimizer):
         epoch_increment=ops['epoch_increment'],
         update_wf_norm=ops['update_wf_norm'],
     )
+    return self._train_ops
 
   def run_optimization_epoch(self, train_ops, session, hparams, epoch_number: int = 0
                              ) -> np.float32:
-    """training.py:589-623."""
-    _run_mc_steps(session, train_ops.mc_step,
-                  hparams.num_equilibration_sweeps * hparams.num_sites)
-
-    if train_ops.update_wf_norm is not None:
-      session.run(train_ops.update_wf_norm)
-    session.run(train_ops.reset_gradients)
-    for _ in range(hparams.num_batches_per_epoch):
-      session.run(train_ops.accumulate_gradients)
-      _run_mc_steps(session, train_ops.mc_step,
-                    hparams.num_monte_carlo_sweeps * hparams.num_sites)
+    """training.py:589-623.  When `train_ops` are the handles this object built, the sampling /
+    accumulation part of the epoch is ONE call into the library (vmc_epoch_energy_gradient:
+    same ops, same order, no Python round trip per op); foreign handles run op by op."""
+    n_eq = hparams.num_equilibration_sweeps * hparams.num_sites
+    n_mc = hparams.num_monte_carlo_sweeps * hparams.num_sites
+    if train_ops is getattr(self, '_train_ops', None):
+      fused = self._fused
+      fused['configs']._ensure_hamiltonian(fused['hamiltonian'])
+      if parallel.world_size() == 1:
+        fused['engine'].epoch_energy_gradient(
+            n_eq, hparams.num_batches_per_epoch, n_mc,
+            1e10 if train_ops.update_wf_norm is not None else 0.0)
+      else:   # update_norm needs the max over all ranks: keep it as its own op
+        _run_mc_steps(session, train_ops.mc_step, n_eq)
+        if train_ops.update_wf_norm is not None:
+          session.run(train_ops.update_wf_norm)
+        fused['engine'].epoch_energy_gradient(0, hparams.num_batches_per_epoch, n_mc, 0.0)
+      fused['state'].reduced = False
+    else:
+      _run_mc_steps(session, train_ops.mc_step, n_eq)
+      if train_ops.update_wf_norm is not None:
+        session.run(train_ops.update_wf_norm)
+      session.run(train_ops.reset_gradients)
+      for _ in range(hparams.num_batches_per_epoch):
+        session.run(train_ops.accumulate_gradients)
+        _run_mc_steps(session, train_ops.mc_step, n_mc)
 
     session.run(train_ops.apply_gradients)
     energy = session.run(train_ops.metrics)
@@ -249,7 +267,8 @@ class LogOverlapImaginaryTimeSWO(WavefunctionOptimizer):
                       _hip.VMC_MODE_LOG_OVERLAP_ITSWO)
     update_network = wavefunctions.module_transfer_ops(wavefunction, wf_omega)
     self._wf_omega = wf_omega
-    return TrainOpsSWO(
+    self._fused = ops
+    self._train_ops = TrainOpsSWO(
         train_step=None,
         accumulate_gradients=ops['accumulate_gradients'],
         apply_gradients=ops['apply_gradients'],
@@ -263,10 +282,25 @@ class LogOverlapImaginaryTimeSWO(WavefunctionOptimizer):
         epoch_increment=ops['epoch_increment'],
         update_wf_norm=ops['update_wf_norm'],
     )
+    return self._train_ops
 
   def run_optimization_epoch(self, train_ops, session, hparams, epoch_number: int = 0
                              ) -> np.float32:
-    """training.py:731-778."""
+    """training.py:731-778.  Single process + own handles: the whole epoch is one call into
+    the library (vmc_epoch_log_overlap, same op order)."""
+    if train_ops is getattr(self, '_train_ops', None) and parallel.world_size() == 1:
+      fused = self._fused
+      fused['configs']._ensure_hamiltonian(fused['hamiltonian'])
+      opt = fused['optimizer']
+      energy = fused['engine'].epoch_log_overlap(
+          fused['beta'], hparams.num_equilibration_sweeps * hparams.num_sites,
+          hparams.num_batches_per_epoch, hparams.num_monte_carlo_sweeps * hparams.num_sites,
+          1e10 if train_ops.update_wf_norm is not None else 0.0,
+          opt.learning_rate(), opt.beta1, opt.beta2, opt.epsilon)
+      self._wf_omega._has_values, self._wf_omega._theta = True, None
+      fused['state'].reduced = True
+      session.run(train_ops.epoch_increment)
+      return np.float32(energy)
     _run_mc_steps(session, train_ops.mc_step,
                   hparams.num_equilibration_sweeps * hparams.num_sites)
 

@@ -143,6 +143,20 @@ int vmc_mean_energy(vmc_ctx* ctx, double* energy);
 int vmc_get_adam_state(vmc_ctx* ctx, float* m, float* v, int64_t* t);
 int vmc_set_adam_state(vmc_ctx* ctx, const float* m, const float* v, int64_t t);
 
+/* Whole-epoch entry points: the op sequences of run_optimization_epoch in
+ * ONE host call, no Python round trip per op.
+ * EnergyGradient (training.py:608-617): n_eq_steps mc_steps, update_norm (skipped when
+ * max_value <= 0), reset, n_batches x [accumulate, n_mc_steps mc_steps].  apply_gradients is
+ * left to the caller (the multi-GPU all-reduce sits in between).
+ * LogOverlapITSWO (training.py:750-763): n_eq_steps mc_steps, update_norm, update_supervisor,
+ * n_batches x [n_mc_steps mc_steps, reset, accumulate, Adam]; *energy = mean of the last batch.
+ * Single-GPU only (Adam needs the reduced accumulators every batch). */
+int vmc_epoch_energy_gradient(vmc_ctx* ctx, int64_t n_eq_steps, int32_t n_batches,
+                              int64_t n_mc_steps, float max_value);
+int vmc_epoch_log_overlap(vmc_ctx* ctx, float beta, int64_t n_eq_steps, int32_t n_batches,
+                          int64_t n_mc_steps, float max_value, float lr, float beta1, float beta2,
+                          float eps, double* energy);
+
 /* Wavefunction.update_norm (wavefunctions.py:261-288) on psi(chains). */
 int vmc_update_norm(vmc_ctx* ctx, float max_value);
 
