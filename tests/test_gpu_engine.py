@@ -328,3 +328,40 @@ def test_error_behaviour():
   with pytest.raises(Exception):
     eng.local_energy()                                     # no params / bonds yet
   eng.close()
+
+
+@pytest.mark.parametrize('n,h,L,b,bonds', [
+    (9, 32, 2, 1, [(0, 1)]),                      # one chain, odd site count (4 down spins), one bond
+    (2, 16, 1, 3, [(0, 1)]),                      # smallest lattice the kernels accept
+    (33, 64, 2, 17, [(i, (i + 2) % 33) for i in range(33)]),   # N not a multiple of 4, odd batch
+])
+def test_edge_shapes(n, h, L, b, bonds):
+  """Ragged / minimal shapes through every kernel: amplitudes, local energy, proposals, a few
+  sweeps, gradient accumulators."""
+  from cgs_vmc_amd import _hip
+  from cgs_vmc_amd.engine import VmcEngine
+  rng = np.random.default_rng(4)
+  theta = vo.init_params(n, h, L, rng)
+  theta += (0.05 * rng.standard_normal(theta.size)).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(2))
+  eng = VmcEngine(n, b, L, h, seed=11)
+  eng.set_params(theta); eng.set_configs(cfg); eng.set_bonds(bonds, -1.0, 1.0)
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+  _close(eng.amplitude()[0], vo.fc_logit(theta, cfg, h, L, dtype=np.float64), 2e-5)
+  _close(eng.local_energy()[0], vo.local_value(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64), 2e-4)
+  u_sites, u_acc = vo.step_uniforms(11, np.arange(b), 0, n)
+  i_up_ref, i_dn_ref = vo.propose_exchange(cfg, u_sites)
+  i_up, i_dn, u = eng.debug_proposals(0)
+  np.testing.assert_array_equal(i_up, i_up_ref); np.testing.assert_array_equal(i_dn, i_dn_ref)
+  np.testing.assert_array_equal(u, u_acc)
+  eng.mc_steps(3 * n)
+  got = eng.get_configs()
+  assert (np.abs(got) == 1).all() and (got.sum(1) == cfg.sum(1)).all()
+  _close(eng.amplitude()[0], vo.fc_logit(theta, got, h, L, dtype=np.float64), 2e-5)
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.energy_gradient_accumulate(acc, theta, got, bonds, -1.0, 1.0, -10.0, h, L, np.float64)
+  eng.reset_accumulators(); eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  a = eng.get_accumulators(); p = theta.size
+  for g, r in ((a[:p], acc.g1_total), (a[p:2 * p], acc.g2_total)):
+    assert np.abs(g - r).max() < 2e-3 * np.abs(r).max() + 1e-4
+  eng.close()
