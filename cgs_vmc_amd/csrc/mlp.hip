@@ -93,9 +93,11 @@ hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp, 
 }
 
 // ---------------------------------------------------------------------------------- tail32
-// 256 threads = 4 waves; each wave owns 32 rows (lane&31) and all Hp hidden units
-// (HT tiles x 16 accumulator registers, split over the two lane halves).  No LDS, no
-// barriers.  RATIO mode writes 0.5*jx[bond]*exp(logit_row - logit_base[chain]).
+// Persistent: one 256-thread workgroup per CU walks the row tiles b, b + gridDim.x, ...; each of
+// its 4 waves owns 32 rows (lane&31) of a tile and all Hp hidden units (HT tiles x 16
+// accumulator registers, split over the two lane halves).  No barriers; LDS is only a per-wave
+// staging area for the next tile's gathered first-layer activations.  RATIO mode writes
+// 0.5*jx[bond]*exp(logit_row - logit_base[chain]).
 template <int HT, bool RATIO>
 __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
   constexpr int Hp = HT * 32;
@@ -378,19 +380,19 @@ hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mo
 }
 
 // --------------------------------------------------------------------------------- sweep16
-// One workgroup (4 waves) owns 16 chains for the whole launch.  Per mc_step:
+// One workgroup (NW = 4 or 8 waves) owns 16 chains for the whole launch.  Per mc_step:
 //   proposals (Philox, argmax/argmin of s*u over sites: graph_builders.py:59-65)
 //   z1' = z1 + 2 (W1[i_dn] - W1[i_up])            (rank-2 form of the forward at :74)
-//   layers 2..L by 16x16x4 MFMA, wave w owns output units [w*Hp/4, (w+1)*Hp/4)
-//   accept = exp(logit' - logit) > sqrt(u)        (graph_builders.py:75-79)
+//   layers 2..L by 16x16x4 MFMA, wave w owns output units [w*Hp/NW, (w+1)*Hp/NW)
+//   accept = exp(logit' - logit) > sqrt(u)        (graph_builders.py:75-79), evaluated as
+//            logit' - logit > 0.5 log u by the wave that owns the chain
 // Chain state (spins, z1, logit) stays in LDS; z1 and logit are recomputed from the spins
 // at launch start and end so the cache written back never carries incremental drift.
 //
-// Weight traffic: the A-operand fragments of the first RT (= 12 of 16 at H = 256) k-tiles of
-// the FIRST H x H layer of this wave's output units are loaded once and stay in registers
-// (192 per lane) for the whole launch; everything else streams from L2 through a 4-stage
-// register ring whose loads are issued 3 k-tiles (1536 MFMA cycles) ahead of their use and
-// run across layer boundaries.
+// Weight traffic: the A-operand fragments of the first RT (= 14 of 16 at H = 256) k-tiles of
+// the FIRST H x H layer of this wave's output units are loaded once and stay in registers for
+// the whole launch; everything else streams from L2 through a PF-stage register ring whose
+// loads are issued PF-1 k-tiles ahead of their use and run across layer boundaries.
 // 16-lane (DPP row) all-reduce steps: lane^1, lane^2 (quad_perm), then row_half_mirror and
 // row_mirror, which combine the already-uniform quads / halves.  Pure VALU, no LDS crossbar.
 template <int CTRL>
