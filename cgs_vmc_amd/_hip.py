@@ -79,6 +79,19 @@ SIGNATURES = {
     'vmc_epoch_log_overlap': (C.c_int, [_ctx, C.c_float, C.c_int64, C.c_int32, C.c_int64, C.c_float,
                                         C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.POINTER(C.c_double)]),
+    'vmc_sr_reserve': (C.c_int, [_ctx, C.c_int32]),
+    'vmc_sr_num_stored': (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
+    'vmc_sr_begin': (C.c_int, [_ctx, C.POINTER(C.c_double)]),
+    'vmc_sr_matvec_partial': (C.c_int, [_ctx]),
+    'vmc_sr_buffer_devptr': (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    'vmc_sr_get_buffer': (C.c_int, [_ctx, _fp]),
+    'vmc_sr_set_buffer': (C.c_int, [_ctx, _fp]),
+    'vmc_sr_cg_update': (C.c_int, [_ctx, C.c_float, C.POINTER(C.c_double)]),
+    'vmc_sr_solve': (C.c_int, [_ctx, C.c_float, C.c_float, C.c_int32, C.POINTER(C.c_int32),
+                               C.POINTER(C.c_double)]),
+    'vmc_sr_get_solution': (C.c_int, [_ctx, _fp]),
+    'vmc_sr_apply': (C.c_int, [_ctx, C.c_float, C.POINTER(C.c_double)]),
+    'vmc_sr_debug_matvec': (C.c_int, [_ctx, _fp, C.c_float, _fp]),
     'vmc_update_norm': (C.c_int, [_ctx, C.c_float]),
     'vmc_timing_enable': (C.c_int, [_ctx, C.c_int]),
     'vmc_timing_reset': (C.c_int, [_ctx]),

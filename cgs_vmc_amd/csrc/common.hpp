@@ -122,7 +122,8 @@ struct GemmArgs {
   int ones_row;                         // row M-1 of A is an implicit row of ones
   const float* bias;                    // epilogue 1: + bias[n] then relu
   const float* mask;  long long ldmask; // epilogue 2: * (mask[m*ldmask+n] > 0)
-  int epilogue;                         // 0 none, 1 bias+relu, 2 mask, 3 accumulate (C += ), 4 bias
+  int epilogue;                         // 0 none, 1 bias+relu, 2 mask, 3 accumulate (C += ), 4 bias,
+                                        // 5 mask (.) (v + bias), 6 mask (.) (C + v + bias)
   int splitk;                           // >= 1
   float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
 };
@@ -130,7 +131,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
 // `count` dual / ones-row GEMMs (device array of GemmArgs, all with the same splitk and their
 // own workspace) in one launch + one reduction launch; max_m counts MFMA rows (M - 1)
 hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
-                               int max_n, int splitk);
+                               int max_n, int splitk, bool dual = true);
 hipError_t launch_relu_copy(hipStream_t s, const float* z, float* a, long long n);
 hipError_t launch_delta_out(hipStream_t s, const float* woutp, const float* aL, float* delta,
                             int B, int Hp);
@@ -142,3 +143,15 @@ hipError_t launch_itswo_ratio(hipStream_t s, const float* logit_psi, const float
 hipError_t launch_adam(hipStream_t s, float* theta, float* m, float* v, const float* acc, int P,
                        int mode, float lr_t, float b1, float b2, float eps, float* grad_out);
 hipError_t launch_fill(hipStream_t s, float* x, float v, long long n);
+
+// stochastic reconfiguration (sr.hip)
+hipError_t launch_jvp_out(hipStream_t s, const float* tang, const float* act, const float* wout,
+                          const float* vout, const float* vbout, int B, int H, int Hp, float* t);
+hipError_t launch_sum_into(hipStream_t s, const float* t, int B, float* dst);
+hipError_t launch_sr_rhs(hipStream_t s, const float* acc, int P, float* x, float* r, float* p,
+                         double* partial, double* sc);
+hipError_t launch_sr_q(hipStream_t s, const float* u, const float* acc, int P, const float* p,
+                       float lambda, float* q, double* partial, double* sc);
+hipError_t launch_sr_step(hipStream_t s, double* sc, int cur, int P, float* p, const float* q,
+                          float* x, float* r, double* partial);
+hipError_t launch_sr_apply(hipStream_t s, float* theta, const float* x, float lr, int P);

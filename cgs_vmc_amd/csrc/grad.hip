@@ -27,6 +27,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, int m
     case 2: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? v : 0.f; break;
     case 3: *c += v; break;
     case 4: *c = v + g.bias[n]; break;
+    case 5: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? v + g.bias[n] : 0.f; break;
+    case 6: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? *c + v + g.bias[n] : 0.f; break;
     default: *c = v; break;
   }
 }
@@ -193,12 +195,13 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 // Several independent dual GEMMs (one per layer's weight gradient) in ONE launch:
 // blockIdx.z = problem * splitk + split.  With ~4 workgroups co-resident per CU the global
 // load latency of one is hidden behind the MFMAs of the others.
+template <bool DUAL>
 __global__ __launch_bounds__(256) void k_gemm_batched(const GemmArgs* __restrict__ batch,
                                                       int splitk) {
   const GemmArgs g = batch[blockIdx.z / splitk];
   const int m_rows = g.ones_row ? g.M - 1 : g.M;
   if ((int)blockIdx.x * GT >= g.N || (int)blockIdx.y * GT >= m_rows) return;   // block-uniform
-  gemm_block<true>(g, blockIdx.x, blockIdx.y, blockIdx.z % splitk);
+  gemm_block<DUAL>(g, blockIdx.x, blockIdx.y, blockIdx.z % splitk);
 }
 
 __device__ __forceinline__ void gemm_reduce_body(const GemmArgs& g, long long start,
@@ -247,11 +250,12 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
 }
 
 hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
-                               int max_n, int splitk) {
+                               int max_n, int splitk, bool dual) {
   if (count <= 0) return hipSuccess;
   const dim3 grid((max_n + GT - 1) / GT, (max_m + GT - 1) / GT, count * splitk);
-  hipLaunchKernelGGL(k_gemm_batched, grid, dim3(256), 0, s, dev_batch, splitk);
-  const long long total = 2LL * (max_m + 1) * max_n;
+  if (dual) hipLaunchKernelGGL(k_gemm_batched<true>, grid, dim3(256), 0, s, dev_batch, splitk);
+  else hipLaunchKernelGGL(k_gemm_batched<false>, grid, dim3(256), 0, s, dev_batch, splitk);
+  const long long total = (dual ? 2LL : 1LL) * (max_m + 1) * max_n;
   const int blocks = (int)min((total + 255) / 256, (long long)512);
   hipLaunchKernelGGL(k_gemm_reduce_batched, dim3(blocks, count), dim3(256), 0, s, dev_batch);
   return hipGetLastError();

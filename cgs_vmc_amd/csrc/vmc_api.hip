@@ -68,6 +68,14 @@ struct vmc_ctx {
   int splitk = 16;
   int num_cus = 256;
   int sweep_waves = 8;       // waves per sweep workgroup at Hp = 256 (CGS_VMC_SWEEP_WAVES=4|8)
+  // stochastic reconfiguration (extension, sr.hip): sample store + CG vectors
+  int sr_cap = 0, sr_n = 0, sr_iter = 0;
+  float *sr_cfg = nullptr, *sr_act = nullptr, *sr_delta = nullptr;   // [cap][B][N], [cap][L][B][Hp] x2
+  float *sr_tang = nullptr, *sr_t = nullptr;                          // [2][B][Hp], [B]
+  float *sr_u = nullptr, *sr_x = nullptr, *sr_r = nullptr, *sr_p = nullptr, *sr_q = nullptr;
+  double *sr_partial = nullptr, *sr_sc = nullptr;
+  GemmArgs* sr_batch = nullptr;                                       // [cap][L+1]
+  bool sr_begun = false;
   // scratch
   unsigned long long* d_accepted = nullptr;
   double* d_sum = nullptr;
@@ -358,6 +366,9 @@ void vmc_destroy(vmc_ctx* c) {
                   c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->tmp_rowinfo, c->rowinfo_id, c->bond_dummy, c->inj_up, c->inj_dn, c->inj_u,
                   c->acc_mask};
   for (void* q : ptrs) if (q) hipFree(q);
+  void* sr[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_tang, c->sr_t, c->sr_u, c->sr_x, c->sr_r,
+                c->sr_p, c->sr_q, c->sr_partial, c->sr_sc, c->sr_batch};
+  for (void* q : sr) if (q) hipFree(q);
   delete c;
 }
 
@@ -672,6 +683,19 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
   return VMC_OK;
 }
 
+// SR sample store: the chains of this accumulate call with their activations a_l and
+// back-propagated d logit / d z_l, which gradient_sums has just left in act[] / delta[]
+static int sr_record(vmc_ctx* c) {
+  if (c->sr_n >= c->sr_cap)
+    return fail(c, VMC_ERR_STATE, "SR sample store full: vmc_sr_reserve fewer batches than accumulate calls");
+  const long long B = c->B, N = c->N, Hp = c->Hp, L = c->L, k = c->sr_n;
+  HIPCHK(c, hipMemcpyAsync(c->sr_cfg + k * B * N, c->configs, B * N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->sr_act + k * L * B * Hp, c->act_all, L * B * Hp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->sr_delta + k * L * B * Hp, c->delta_all, L * B * Hp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  c->sr_n += 1;
+  return VMC_OK;
+}
+
 int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   CHECK_CTX(c);
   if (mode != VMC_MODE_ENERGY_GRADIENT && mode != VMC_MODE_LOG_OVERLAP_ITSWO)
@@ -692,12 +716,14 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   PROPAGATE(ensure_cache(c, VMC_PSI));
   PROPAGATE(gradient_sums(c, w));
   HIPCHK(c, launch_scalar_accum(c->stream, e, mode == 1 ? c->ratio : nullptr, c->B, c->acc + 2 * c->P, mode));
+  if (c->sr_cap > 0 && mode == VMC_MODE_ENERGY_GRADIENT) PROPAGATE(sr_record(c));
   return VMC_OK;
 }
 
 int vmc_reset_accumulators(vmc_ctx* c) {
   CHECK_CTX(c);
   HIPCHK(c, hipMemsetAsync(c->acc, 0, (2 * c->P + 8) * sizeof(float), c->stream));
+  c->sr_n = 0; c->sr_begun = false;
   return VMC_OK;
 }
 
@@ -824,6 +850,199 @@ int vmc_epoch_log_overlap(vmc_ctx* c, float beta, int64_t n_eq_steps, int32_t n_
     PROPAGATE(vmc_apply_adam(c, VMC_MODE_LOG_OVERLAP_ITSWO, lr, beta1, beta2, eps, nullptr));
   }
   if (energy) PROPAGATE(vmc_mean_energy(c, energy));                      // training.py:763
+  return VMC_OK;
+}
+
+// ------------------------------------------------------------------ stochastic reconfiguration
+int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
+  CHECK_CTX(c);
+  if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_batch};
+  for (void* q : old) if (q) hipFree(q);
+  c->sr_cfg = c->sr_act = c->sr_delta = nullptr; c->sr_batch = nullptr;
+  c->sr_cap = 0; c->sr_n = 0; c->sr_begun = false;
+  if (n_batches == 0) return VMC_OK;
+  const long long B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->L, P = c->P;
+  HIPCHK(c, dalloc(&c->sr_cfg, n_batches * B * N));
+  HIPCHK(c, dalloc(&c->sr_act, n_batches * L * B * Hp));
+  HIPCHK(c, dalloc(&c->sr_delta, n_batches * L * B * Hp));
+  HIPCHK(c, dalloc(&c->sr_batch, (long long)n_batches * (L + 1)));
+  if (!c->sr_u) {
+    HIPCHK(c, dalloc(&c->sr_tang, 2 * B * Hp)); HIPCHK(c, dalloc(&c->sr_t, B));
+    HIPCHK(c, hipMemsetAsync(c->sr_tang, 0, 2 * B * Hp * sizeof(float), c->stream));
+    HIPCHK(c, dalloc(&c->sr_u, P + 1)); HIPCHK(c, dalloc(&c->sr_x, P)); HIPCHK(c, dalloc(&c->sr_r, P));
+    HIPCHK(c, dalloc(&c->sr_p, P)); HIPCHK(c, dalloc(&c->sr_q, P));
+    HIPCHK(c, dalloc(&c->sr_partial, 256)); HIPCHK(c, dalloc(&c->sr_sc, 4));
+    HIPCHK(c, hipMemsetAsync(c->sr_x, 0, P * sizeof(float), c->stream));
+  }
+  // weighted-sum GEMM tables, one per slot: u += [a_{l-1} | 1]^T [t (.) delta_l]
+  std::vector<GemmArgs> tab;
+  const long long ws_stride = (long long)c->splitk * 2 * ((N > H ? N : H) + 1) * H;
+  for (long long k = 0; k < n_batches; ++k) {
+    const float* act = c->sr_act + k * L * B * Hp;
+    const float* del = c->sr_delta + k * L * B * Hp;
+    int slot = 0;
+    auto add = [&](const float* a, long long a_ld, int k_in, const float* delta, long long sbk,
+                   long long sbn, int n_out, long long off) {
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.A = a; g.sam = 1; g.sak = a_ld; g.M = k_in + 1; g.ones_row = 1;
+      g.B = delta; g.sbk = sbk; g.sbn = sbn; g.kscale = c->sr_t; g.dual = 0;
+      g.N = n_out; g.K = (int)B; g.C = c->sr_u + off; g.ldc = n_out; g.epilogue = 3;
+      g.splitk = c->splitk; g.workspace = c->gemm_ws + (long long)(slot++) * ws_stride;
+      tab.push_back(g);
+    };
+    add(act + (L - 1) * B * Hp, Hp, (int)H, c->ones, 1, 0, 1, off_wout(c));
+    for (int l = (int)L - 1; l > 0; --l) add(act + (l - 1) * B * Hp, Hp, (int)H, del + l * B * Hp, Hp, 1, (int)H, off_w(c, l));
+    add(c->sr_cfg + k * B * N, N, (int)N, del, Hp, 1, (int)H, off_w(c, 0));
+  }
+  HIPCHK(c, hipMemcpy(c->sr_batch, tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
+  c->sr_cap = n_batches;
+  return VMC_OK;
+}
+
+int vmc_sr_num_stored(vmc_ctx* c, int32_t* n) {
+  CHECK_CTX(c);
+  if (!n) return fail(c, VMC_ERR_INVALID, "null");
+  *n = c->sr_n;
+  return VMC_OK;
+}
+
+static int sr_read_rr(vmc_ctx* c, int idx, double* rr) {
+  if (!rr) return VMC_OK;
+  HIPCHK(c, hipMemcpyAsync(rr, c->sr_sc + idx, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_sr_begin(vmc_ctx* c, double* rr0) {
+  CHECK_CTX(c);
+  if (c->sr_cap <= 0) return fail(c, VMC_ERR_STATE, "vmc_sr_reserve first");
+  if (c->sr_n <= 0) return fail(c, VMC_ERR_STATE, "no samples recorded (vmc_accumulate in ENERGY_GRADIENT mode)");
+  HIPCHK(c, launch_sr_rhs(c->stream, c->acc, (int)c->P, c->sr_x, c->sr_r, c->sr_p, c->sr_partial, c->sr_sc));
+  c->sr_iter = 0; c->sr_begun = true;
+  return sr_read_rr(c, 0, rr0);
+}
+
+// u[0..P) = sum over this rank's stored samples of (O_b . p) O_b,  u[P] = sum (O_b . p)
+int vmc_sr_matvec_partial(vmc_ctx* c) {
+  CHECK_CTX(c);
+  if (!c->sr_begun) return fail(c, VMC_ERR_STATE, "vmc_sr_begin first");
+  const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->L;
+  const float* theta = c->ps[0].theta;
+  const float* v = c->sr_p;
+  Timer t(c, "sr_matvec");
+  HIPCHK(c, hipMemsetAsync(c->sr_u, 0, (c->P + 1) * sizeof(float), c->stream));
+  for (long long k = 0; k < c->sr_n; ++k) {
+    const float* cfg = c->sr_cfg + k * B * N;
+    const float* act = c->sr_act + k * (long long)L * B * Hp;
+    float* tang[2] = {c->sr_tang, c->sr_tang + (long long)B * Hp};
+    {  // adot_1 = relu'(z_1) (.) (X V_1 + v_b1)
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.A = cfg; g.sam = N; g.sak = 1; g.B = v + off_w(c, 0); g.sbk = H; g.sbn = 1;
+      g.M = B; g.N = H; g.K = N; g.C = tang[0]; g.ldc = Hp;
+      g.bias = v + off_b(c, 0); g.mask = act; g.ldmask = Hp; g.epilogue = 5; g.splitk = 1;
+      HIPCHK(c, launch_gemm(c->stream, g));
+    }
+    for (int l = 1; l < L; ++l) {  // adot_{l+1} = relu' (.) (adot_l W_l + a_l V_l + v_bl)
+      float* src = tang[(l - 1) & 1];
+      float* dst = tang[l & 1];
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.A = src; g.sam = Hp; g.sak = 1; g.B = theta + off_w(c, l); g.sbk = H; g.sbn = 1;
+      g.M = B; g.N = H; g.K = H; g.C = dst; g.ldc = Hp; g.epilogue = 0; g.splitk = 1;
+      HIPCHK(c, launch_gemm(c->stream, g));
+      g.A = act + (long long)(l - 1) * B * Hp; g.B = v + off_w(c, l);
+      g.bias = v + off_b(c, l); g.mask = act + (long long)l * B * Hp; g.ldmask = Hp; g.epilogue = 6;
+      HIPCHK(c, launch_gemm(c->stream, g));
+    }
+    HIPCHK(c, launch_jvp_out(c->stream, tang[(L - 1) & 1], act + (long long)(L - 1) * B * Hp,
+                             theta + off_wout(c), v + off_wout(c), v + off_bout(c), B, H, Hp, c->sr_t));
+    HIPCHK(c, launch_sum_into(c->stream, c->sr_t, B, c->sr_u + c->P));
+    HIPCHK(c, launch_gemm_batched(c->stream, c->sr_batch + k * (L + 1), L + 1, N > H ? N : H, H, c->splitk, false));
+  }
+  return VMC_OK;
+}
+
+int vmc_sr_buffer_devptr(vmc_ctx* c, void** dev_ptr, int64_t* n_floats) {
+  CHECK_CTX(c);
+  if (!c->sr_u) return fail(c, VMC_ERR_STATE, "vmc_sr_reserve first");
+  if (dev_ptr) *dev_ptr = c->sr_u;
+  if (n_floats) *n_floats = c->P + 1;
+  return VMC_OK;
+}
+
+int vmc_sr_get_buffer(vmc_ctx* c, float* host) {
+  CHECK_CTX(c);
+  if (!host || !c->sr_u) return fail(c, VMC_ERR_INVALID, "null / vmc_sr_reserve first");
+  HIPCHK(c, hipMemcpyAsync(host, c->sr_u, (c->P + 1) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_sr_set_buffer(vmc_ctx* c, const float* host) {
+  CHECK_CTX(c);
+  if (!host || !c->sr_u) return fail(c, VMC_ERR_INVALID, "null / vmc_sr_reserve first");
+  HIPCHK(c, hipMemcpyAsync(c->sr_u, host, (c->P + 1) * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_sr_cg_update(vmc_ctx* c, float diag_shift, double* rr) {
+  CHECK_CTX(c);
+  if (!c->sr_begun) return fail(c, VMC_ERR_STATE, "vmc_sr_begin first");
+  const int cur = c->sr_iter & 1;
+  HIPCHK(c, launch_sr_q(c->stream, c->sr_u, c->acc, (int)c->P, c->sr_p, diag_shift, c->sr_q, c->sr_partial, c->sr_sc));
+  HIPCHK(c, launch_sr_step(c->stream, c->sr_sc, cur, (int)c->P, c->sr_p, c->sr_q, c->sr_x, c->sr_r, c->sr_partial));
+  c->sr_iter += 1;
+  return sr_read_rr(c, cur ^ 1, rr);
+}
+
+int vmc_sr_solve(vmc_ctx* c, float diag_shift, float tol, int32_t max_iter, int32_t* iters, double* rel_residual) {
+  CHECK_CTX(c);
+  if (max_iter < 0 || tol < 0.f) return fail(c, VMC_ERR_INVALID, "bad CG arguments");
+  double rr0 = 0.0, rr = 0.0;
+  PROPAGATE(vmc_sr_begin(c, &rr0));
+  rr = rr0;
+  int it = 0;
+  while (it < max_iter && rr > (double)tol * (double)tol * rr0 && rr0 > 0.0) {
+    PROPAGATE(vmc_sr_matvec_partial(c));
+    PROPAGATE(vmc_sr_cg_update(c, diag_shift, &rr));
+    ++it;
+  }
+  if (iters) *iters = it;
+  if (rel_residual) *rel_residual = rr0 > 0.0 ? sqrt(rr / rr0) : 0.0;
+  return VMC_OK;
+}
+
+int vmc_sr_get_solution(vmc_ctx* c, float* x) {
+  CHECK_CTX(c);
+  if (!x || !c->sr_x) return fail(c, VMC_ERR_INVALID, "null / vmc_sr_reserve first");
+  HIPCHK(c, hipMemcpyAsync(x, c->sr_x, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return VMC_OK;
+}
+
+int vmc_sr_apply(vmc_ctx* c, float lr, double* energy) {
+  CHECK_CTX(c);
+  if (!c->sr_begun) return fail(c, VMC_ERR_STATE, "vmc_sr_begin / vmc_sr_solve first");
+  HIPCHK(c, launch_sr_apply(c->stream, c->ps[0].theta, c->sr_x, lr, (int)c->P));
+  c->ps[0].packed_valid = c->ps[0].cache_valid = false;
+  c->acts_valid = false;
+  c->sr_begun = false;
+  if (energy) PROPAGATE(vmc_mean_energy(c, energy));
+  return VMC_OK;
+}
+
+int vmc_sr_debug_matvec(vmc_ctx* c, const float* v, float diag_shift, float* out) {
+  CHECK_CTX(c);
+  if (!v || !out) return fail(c, VMC_ERR_INVALID, "null");
+  PROPAGATE(vmc_sr_begin(c, nullptr));
+  HIPCHK(c, hipMemcpyAsync(c->sr_p, v, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  PROPAGATE(vmc_sr_matvec_partial(c));
+  HIPCHK(c, launch_sr_q(c->stream, c->sr_u, c->acc, (int)c->P, c->sr_p, diag_shift, c->sr_q, c->sr_partial, c->sr_sc));
+  HIPCHK(c, hipMemcpyAsync(out, c->sr_q, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->sr_begun = false;
   return VMC_OK;
 }
 

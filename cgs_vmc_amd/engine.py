@@ -263,6 +263,71 @@ class VmcEngine:
   def update_norm(self, max_value: float = 1e10):
     self._check(self._lib.vmc_update_norm(self._ctx, float(max_value)))
 
+  # ------------------------------------------------------------------ stochastic reconfiguration
+  # Extension named by the north star, absent from the reference (see include/cgsvmc.h).
+  def sr_reserve(self, n_batches: int):
+    """Sample store for `n_batches` accumulate calls; switches recording on (0 = off)."""
+    self._check(self._lib.vmc_sr_reserve(self._ctx, int(n_batches)))
+
+  def sr_num_stored(self) -> int:
+    n = C.c_int32()
+    self._check(self._lib.vmc_sr_num_stored(self._ctx, C.byref(n)))
+    return int(n.value)
+
+  def sr_begin(self) -> float:
+    rr = C.c_double()
+    self._check(self._lib.vmc_sr_begin(self._ctx, C.byref(rr)))
+    return float(rr.value)
+
+  def sr_matvec_partial(self):
+    self._check(self._lib.vmc_sr_matvec_partial(self._ctx))
+
+  def sr_buffer_devptr(self) -> Tuple[int, int]:
+    p = C.c_void_p()
+    n = C.c_int64()
+    self._check(self._lib.vmc_sr_buffer_devptr(self._ctx, C.byref(p), C.byref(n)))
+    return int(p.value), int(n.value)
+
+  def sr_get_buffer(self) -> np.ndarray:
+    out = np.empty(self.num_params + 1, np.float32)
+    self._check(self._lib.vmc_sr_get_buffer(self._ctx, _fptr(out)))
+    return out
+
+  def sr_set_buffer(self, buf: np.ndarray):
+    buf = np.ascontiguousarray(buf, np.float32)
+    assert buf.size == self.num_params + 1
+    self._check(self._lib.vmc_sr_set_buffer(self._ctx, _fptr(buf)))
+
+  def sr_cg_update(self, diag_shift: float) -> float:
+    rr = C.c_double()
+    self._check(self._lib.vmc_sr_cg_update(self._ctx, float(diag_shift), C.byref(rr)))
+    return float(rr.value)
+
+  def sr_solve(self, diag_shift: float, tol: float, max_iter: int) -> Tuple[int, float]:
+    """(S + diag_shift I) x = f by matrix-free CG on this GPU -> (iterations, |r|/|f|)."""
+    it = C.c_int32()
+    res = C.c_double()
+    self._check(self._lib.vmc_sr_solve(self._ctx, float(diag_shift), float(tol), int(max_iter),
+                                       C.byref(it), C.byref(res)))
+    return int(it.value), float(res.value)
+
+  def sr_get_solution(self) -> np.ndarray:
+    x = np.empty(self.num_params, np.float32)
+    self._check(self._lib.vmc_sr_get_solution(self._ctx, _fptr(x)))
+    return x
+
+  def sr_apply(self, lr: float) -> float:
+    e = C.c_double()
+    self._check(self._lib.vmc_sr_apply(self._ctx, float(lr), C.byref(e)))
+    return float(e.value)
+
+  def sr_debug_matvec(self, v: np.ndarray, diag_shift: float = 0.0) -> np.ndarray:
+    v = np.ascontiguousarray(v, np.float32)
+    assert v.size == self.num_params
+    out = np.empty(self.num_params, np.float32)
+    self._check(self._lib.vmc_sr_debug_matvec(self._ctx, _fptr(v), float(diag_shift), _fptr(out)))
+    return out
+
   # ------------------------------------------------------------------ timing / debug
   def timing_enable(self, on: bool = True):
     self._check(self._lib.vmc_timing_enable(self._ctx, int(on)))

@@ -147,6 +147,38 @@ def allreduce_accumulators_begin(engine) -> _PendingReduce:
   return _PendingReduce(_dist().all_reduce(t, op=_dist().ReduceOp.SUM, async_op=True), t)
 
 
+def allreduce_sr_buffer(engine):
+  """In-place SUM all-reduce of the SR matrix-vector buffer (P+1 floats, vmc_sr_buffer_devptr)."""
+  if world_size() == 1:
+    return
+  import torch
+  if _dist().get_backend() != 'nccl':     # gloo (tests): stage through the host
+    h = torch.from_numpy(np.ascontiguousarray(engine.sr_get_buffer(), np.float32))
+    _dist().all_reduce(h, op=_dist().ReduceOp.SUM)
+    engine.sr_set_buffer(h.numpy())
+    return
+  ptr, n = engine.sr_buffer_devptr()
+  t = torch.as_tensor(_DevArray(ptr, n), device=torch.device('cuda', engine.device))
+  _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
+
+
+def sr_solve(engine, diag_shift: float, tol: float, max_iter: int):
+  """Matrix-free CG for (S + diag_shift I) x = f with the chains (and therefore the stored
+  samples) sharded over ranks: one P+1-float SUM all-reduce per iteration; every rank runs the
+  identical recurrence on the reduced vectors.  Returns (iterations, |r| / |f|).  The
+  accumulators must already be all-reduced (vmc_sr_begin reads f and <O> from them)."""
+  if world_size() == 1:
+    return engine.sr_solve(diag_shift, tol, max_iter)
+  rr0 = rr = engine.sr_begin()
+  it = 0
+  while it < max_iter and rr0 > 0.0 and rr > tol * tol * rr0:
+    engine.sr_matvec_partial()
+    allreduce_sr_buffer(engine)
+    rr = engine.sr_cg_update(diag_shift)
+    it += 1
+  return it, (float(np.sqrt(rr / rr0)) if rr0 > 0.0 else 0.0)
+
+
 def allreduce_array(values: np.ndarray, op: str = 'sum') -> np.ndarray:
   """All-reduce of a small host array (float64) with SUM or MAX."""
   values = np.asarray(values, np.float64)

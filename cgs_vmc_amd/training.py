@@ -142,7 +142,7 @@ class _AccumulatorState:
     self.reduced = True
 
 
-def _common_ops(wavefunction, hamiltonian, hparams, shared_resources, mode):
+def _common_ops(wavefunction, hamiltonian, hparams, shared_resources, mode, apply_fn=None):
   batch_size = hparams.batch_size
   n_sites = hparams.num_sites
   configs = graph_builders.get_configs(shared_resources, batch_size, n_sites)
@@ -165,8 +165,11 @@ def _common_ops(wavefunction, hamiltonian, hparams, shared_resources, mode):
 
   def apply():
     state.ensure_reduced()
-    engine.apply_adam(mode, optimizer.learning_rate(), optimizer.beta1, optimizer.beta2,
-                      optimizer.epsilon)
+    if apply_fn is not None:
+      apply_fn(engine, optimizer)
+    else:
+      engine.apply_adam(mode, optimizer.learning_rate(), optimizer.beta1, optimizer.beta2,
+                        optimizer.epsilon)
 
   def mean_energy():
     state.ensure_reduced()
@@ -195,12 +198,15 @@ class EnergyGradientOptimizer(WavefunctionOptimizer):
   """Wave-function optimization based on the reduced-variance energy gradient
   (training.py:506-623)."""
 
+  def _apply_fn(self, hparams):
+    return None
+
   def build_opt_ops(self, wavefunction, hamiltonian, hparams, shared_resources) -> NamedTuple:
     """training.py:513-586.  accumulate_gradients adds sum_b O_k, sum_b E_b O_k (one
     mean_tensor update each) and sum_b E_b; apply_gradients feeds
     mean(E O) - mean(E) mean(O) to Adam."""
     ops = _common_ops(wavefunction, hamiltonian, hparams, shared_resources,
-                      _hip.VMC_MODE_ENERGY_GRADIENT)
+                      _hip.VMC_MODE_ENERGY_GRADIENT, self._apply_fn(hparams))
     self._fused = ops            # whole-epoch fast path (SURVEY.md 8f-1), see below
     self._train_ops = TrainOpsTraditional(
         accumulate_gradients=ops['accumulate_gradients'],
@@ -248,6 +254,32 @@ class EnergyGradientOptimizer(WavefunctionOptimizer):
     session.run(train_ops.reset_gradients)
     session.run(train_ops.epoch_increment)
     return energy
+
+
+class StochasticReconfigurationOptimizer(EnergyGradientOptimizer):
+  """EXTENSION (named by the north star; the reference has no SR): the same ops, op order and
+  accumulators as EnergyGradientOptimizer, but apply_gradients solves
+  (S + sr_diag_shift I) x = <E O> - <E><O> over every sample of the epoch by matrix-free
+  conjugate gradients on the GPU (csrc/sr.hip; one P-vector all-reduce per iteration when the
+  chains are sharded) and steps theta -= learning_rate x.  hparams: sr_diag_shift,
+  sr_cg_tolerance, sr_cg_max_iterations (defaults 0.01, 1e-3, 100) and the usual
+  learning_rates schedule (SR wants a larger rate than Adam, e.g. 0.05)."""
+
+  def _apply_fn(self, hparams):
+    shift = float(getattr(hparams, 'sr_diag_shift', 0.01))
+    tol = float(getattr(hparams, 'sr_cg_tolerance', 1e-3))
+    max_iter = int(getattr(hparams, 'sr_cg_max_iterations', 100))
+    self.last_cg = (0, 0.0)
+
+    def apply(engine, optimizer):
+      self.last_cg = parallel.sr_solve(engine, shift, tol, max_iter)
+      engine.sr_apply(optimizer.learning_rate())
+    return apply
+
+  def build_opt_ops(self, wavefunction, hamiltonian, hparams, shared_resources) -> NamedTuple:
+    train_ops = super().build_opt_ops(wavefunction, hamiltonian, hparams, shared_resources)
+    self._fused['engine'].sr_reserve(hparams.num_batches_per_epoch)
+    return train_ops
 
 
 class LogOverlapImaginaryTimeSWO(WavefunctionOptimizer):
@@ -333,6 +365,7 @@ GROUND_STATE_OPTIMIZERS = {
     'EnergyGradient': EnergyGradientOptimizer,
     'LogOverlapITSWO': LogOverlapImaginaryTimeSWO,
     'ITSWO': ImaginaryTimeSWO,
+    'StochasticReconfiguration': StochasticReconfigurationOptimizer,   # extension, see class
 }
 
 # run_supervised_training's optimizers (SWO, LogOverlapSWO, DualSamplingSWO, BasisIterSWO)

@@ -238,6 +238,10 @@ def create_hparams(**kwargs: Any) -> HParams:
       optimizer='adam',
       beta2=0.99,
       num_evaluation_samples=100,
+      # extension (not in the reference): StochasticReconfiguration optimizer, training.py here
+      sr_diag_shift=0.01,
+      sr_cg_tolerance=1e-3,
+      sr_cg_max_iterations=100,
   )
   hparams.override_from_dict(kwargs)
   return hparams

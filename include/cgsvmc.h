@@ -157,12 +157,40 @@ int vmc_epoch_log_overlap(vmc_ctx* ctx, float beta, int64_t n_eq_steps, int32_t 
                           int64_t n_mc_steps, float max_value, float lr, float beta1, float beta2,
                           float eps, double* energy);
 
+/* Stochastic reconfiguration -- EXTENSION: named by the north star, absent from the reference
+ * (training.py has only the plain energy gradient + Adam), so these entries replace no reference
+ * interface; they sit where TrainOpsTraditional.apply_gradients (training.py:560-567) sits.
+ *   S = <O O^T> - <O><O>^T, f = <E O> - <E><O>, (S + diag_shift I) x = f, theta -= lr x
+ * over every sample of the vmc_accumulate(ENERGY_GRADIENT) calls since the last reset.
+ * vmc_sr_reserve(n) allocates the sample store for n accumulate calls (chains, activations,
+ * back-propagated deltas: 2 L B Hp + B N floats each) and switches recording on; 0 frees it.
+ * Matrix-free conjugate gradients: vmc_sr_begin (x = 0, r = p = f from the accumulators, which
+ * must already be all-reduced), then per iteration vmc_sr_matvec_partial (this rank's
+ * sum_b (O_b . p) O_b into the P+1-float buffer of vmc_sr_buffer_devptr, last float =
+ * sum_b O_b . p; SUM all-reduce it across ranks) and vmc_sr_cg_update (*rr = |r|^2 after the
+ * step).  vmc_sr_solve runs the loop on one GPU until |r| <= tol |f| or max_iter.
+ * vmc_sr_apply does theta -= lr x; *energy = TrainOps.metrics as in vmc_apply_adam. */
+int vmc_sr_reserve(vmc_ctx* ctx, int32_t n_batches);
+int vmc_sr_num_stored(vmc_ctx* ctx, int32_t* n);
+int vmc_sr_begin(vmc_ctx* ctx, double* rr0);
+int vmc_sr_matvec_partial(vmc_ctx* ctx);
+int vmc_sr_buffer_devptr(vmc_ctx* ctx, void** dev_ptr, int64_t* n_floats);
+int vmc_sr_get_buffer(vmc_ctx* ctx, float* host /*[P+1]*/);   /* host staging (non-RCCL backends) */
+int vmc_sr_set_buffer(vmc_ctx* ctx, const float* host /*[P+1]*/);
+int vmc_sr_cg_update(vmc_ctx* ctx, float diag_shift, double* rr);
+int vmc_sr_solve(vmc_ctx* ctx, float diag_shift, float tol, int32_t max_iter, int32_t* iters,
+                 double* rel_residual);
+int vmc_sr_get_solution(vmc_ctx* ctx, float* x /*[P]*/);
+int vmc_sr_apply(vmc_ctx* ctx, float lr, double* energy);
+/* test hook: out = (S + diag_shift I) v over the stored samples (single rank) */
+int vmc_sr_debug_matvec(vmc_ctx* ctx, const float* v /*[P]*/, float diag_shift, float* out);
+
 /* Wavefunction.update_norm (wavefunctions.py:261-288) on psi(chains). */
 int vmc_update_norm(vmc_ctx* ctx, float max_value);
 
 /* Per-kernel HIP-event timing on the ctx's stream (bench.py's roofline leg).
  * names: "sweep", "tail_eloc", "tail_amp", "z1", "bond_list", "eloc_reduce", "grad",
- * "adam".  ms = summed elapsed, launches = number of timed launches. */
+ * "adam", "sr_matvec".  ms = summed elapsed, launches = number of timed launches. */
 int vmc_timing_enable(vmc_ctx* ctx, int on);
 int vmc_timing_reset(vmc_ctx* ctx);
 int vmc_timing_get(vmc_ctx* ctx, const char* name, double* ms, int64_t* launches);

@@ -401,6 +401,73 @@ def energy_gradient(acc):
 
 
 # --------------------------------------------------------------------------- #
+# Stochastic reconfiguration (EXTENSION named by the north star; NOT in the reference:
+# training.py only has the plain gradient + Adam).  fp64 explicit-S restatement of what
+# cgs_vmc_amd/csrc/sr.hip solves matrix-free; it is the only oracle this path has.
+# --------------------------------------------------------------------------- #
+def per_sample_logit_grads(theta, configs, layer_size, num_layers, nonlinearity='relu',
+                           dtype=np.float64):
+  """O[b, k] = d logit_b / d theta_k  -> [B, P] (same back-prop as weighted_logit_grads,
+  kept per sample)."""
+  x = np.asarray(configs, dtype=dtype)
+  th = np.asarray(theta, dtype=dtype)
+  layers = unpack(th, x.shape[1], layer_size, num_layers)
+  _, zs, acts = fc_logit(th, x, layer_size, num_layers, nonlinearity, dtype, True)
+  dact = _NONLIN_DERIV[nonlinearity]
+  b = x.shape[0]
+  pieces = [acts[-1], np.ones((b, 1), dtype)]
+  delta = np.broadcast_to(layers[-1][0][:, 0][None, :], acts[-1].shape).copy()
+  for l in range(num_layers - 1, -1, -1):
+    delta = delta * dact(zs[l], acts[l + 1])
+    dw = (acts[l][:, :, None] * delta[:, None, :]).reshape(b, -1)
+    pieces = [dw, delta.copy()] + pieces
+    if l > 0:
+      delta = delta @ layers[l][0].T
+  return np.concatenate(pieces, axis=1)
+
+
+def sr_system(o, e_loc):
+  """S = <O O^T> - <O><O>^T and f = <E O> - <E><O> over the samples (rows of o)."""
+  o = np.asarray(o, np.float64)
+  e = np.asarray(e_loc, np.float64)
+  n = o.shape[0]
+  o_mean = o.mean(0)
+  s = o.T @ o / n - np.outer(o_mean, o_mean)
+  f = o.T @ e / n - e.mean() * o_mean
+  return s, f
+
+
+def sr_solve(o, e_loc, diag_shift):
+  """x with (S + diag_shift I) x = f (dense solve)."""
+  s, f = sr_system(o, e_loc)
+  return np.linalg.solve(s + diag_shift * np.eye(s.shape[0]), f)
+
+
+def sr_conjugate_gradient(o, e_loc, diag_shift, tol, max_iter):
+  """The same CG recurrence as the HIP path (x0 = 0, stop at |r| <= tol |f|), with the
+  matrix-free product S v = O^T (O v) / n - <O> mean(O v).  Returns (x, iterations)."""
+  o = np.asarray(o, np.float64)
+  e = np.asarray(e_loc, np.float64)
+  n = o.shape[0]
+  o_mean = o.mean(0)
+  f = o.T @ e / n - e.mean() * o_mean
+  x = np.zeros_like(f); r = f.copy(); p = f.copy()
+  rr0 = rr = r @ r
+  it = 0
+  while it < max_iter and rr > tol * tol * rr0 and rr0 > 0:
+    t = o @ p
+    q = o.T @ t / n - o_mean * t.mean() + diag_shift * p
+    alpha = rr / (p @ q)
+    x += alpha * p
+    r -= alpha * q
+    rr_new = r @ r
+    p = r + (rr_new / rr) * p
+    rr = rr_new
+    it += 1
+  return x, it
+
+
+# --------------------------------------------------------------------------- #
 # LogOverlapImaginaryTimeSWO accumulators + gradient (training.py:652-699)
 # --------------------------------------------------------------------------- #
 def log_overlap_accumulate(acc, theta, theta_omega, configs, bonds, j_x, j_z, shift,

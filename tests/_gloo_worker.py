@@ -14,6 +14,39 @@ from cgs_vmc_amd import parallel  # noqa: E402
 from oracle import vmc_oracle as vo  # noqa: E402
 
 
+class _OracleSrEngine:
+  """numpy stand-in for VmcEngine's SR entry points (the recurrence of csrc/sr.hip in fp64) so
+  that parallel.sr_solve's sharded CG loop runs without a GPU."""
+
+  def __init__(self, o_local, n_total, f, o_mean):
+    self.o, self.n, self.f, self.o_mean = o_local, n_total, f, o_mean
+
+  def sr_begin(self):
+    self.x = np.zeros_like(self.f); self.r = self.f.copy(); self.p = self.f.copy()
+    self.rr = float(self.r @ self.r)
+    return self.rr
+
+  def sr_matvec_partial(self):
+    t = self.o @ self.p
+    self.buf = np.concatenate([self.o.T @ t, [t.sum()]])
+
+  def sr_get_buffer(self):
+    return self.buf.astype(np.float32)
+
+  def sr_set_buffer(self, buf):
+    self.buf = np.asarray(buf, np.float64)
+
+  def sr_cg_update(self, lam):
+    q = self.buf[:-1] / self.n - self.o_mean * (self.buf[-1] / self.n) + lam * self.p
+    alpha = self.rr / float(self.p @ q)
+    self.x += alpha * self.p
+    self.r -= alpha * q
+    rr_new = float(self.r @ self.r)
+    self.p = self.r + (rr_new / self.rr) * self.p
+    self.rr = rr_new
+    return rr_new
+
+
 def main():
   parallel.init_from_env('gloo')
   assert parallel.is_distributed() and parallel.world_size() == 2
@@ -57,6 +90,17 @@ def main():
   g_red = red[p:2 * p] / red[2 * p + 4] - (red[2 * p] / red[2 * p + 1]) * red[:p] / red[2 * p + 4]
   g_ref = vo.energy_gradient(acc_full)
   np.testing.assert_allclose(g_red, g_ref, rtol=2e-3, atol=2e-4)
+
+  # stochastic reconfiguration: samples sharded by chain, one P+1 all-reduce per CG iteration
+  o_full = vo.per_sample_logit_grads(theta, full, h, L)
+  e_full = vo.local_value(lambda c: vo.fc_psi(theta, c, h, L, -10.0, dtype=np.float64), full,
+                          bonds, -1.0, 1.0, dtype=np.float64)
+  _, f = vo.sr_system(o_full, e_full)
+  fake = _OracleSrEngine(o_full[offset:offset + local], b, f, o_full.mean(0))
+  iters, res = parallel.sr_solve(fake, 0.01, 1e-5, 500)
+  x_ref = vo.sr_solve(o_full, e_full, 0.01)
+  assert res <= 1e-5 and 0 < iters < 500, (iters, res)
+  assert np.abs(fake.x - x_ref).max() <= 1e-3 * np.abs(x_ref).max(), np.abs(fake.x - x_ref).max()
 
   assert parallel.allreduce_max(float(rank) + 0.5) == 1.5
   assert parallel.allreduce_sum(float(rank) + 1.0) == 3.0

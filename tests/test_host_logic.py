@@ -84,7 +84,9 @@ def test_piecewise_constant_and_optimizer_factory():
 
 
 def test_registries_and_errors():
-  assert set(training.GROUND_STATE_OPTIMIZERS) == {'EnergyGradient', 'LogOverlapITSWO', 'ITSWO'}
+  # the reference's three (training.py:913-917) + the SR extension named by the north star
+  assert set(training.GROUND_STATE_OPTIMIZERS) == {
+      'EnergyGradient', 'LogOverlapITSWO', 'ITSWO', 'StochasticReconfiguration'}
   assert set(wavefunctions.WAVEFUNCTION_TYPES) == {
       'fully_connected', 'rbm', 'conv_1d', 'conv_2d', 'mps', 'pbdg', 'fully_connected_nnb',
       'res_net_1d', 'res_net_2d', 'ed_vector', 'gnn'}
