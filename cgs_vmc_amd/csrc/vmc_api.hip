@@ -70,11 +70,11 @@ struct vmc_ctx {
   int sweep_waves = 8;       // waves per sweep workgroup at Hp = 256 (CGS_VMC_SWEEP_WAVES=4|8)
   // stochastic reconfiguration (extension, sr.hip): sample store + CG vectors
   int sr_cap = 0, sr_n = 0, sr_iter = 0;
-  float *sr_cfg = nullptr, *sr_act = nullptr, *sr_delta = nullptr;   // [cap][B][N], [cap][L][B][Hp] x2
-  float *sr_tang = nullptr, *sr_t = nullptr;                          // [2][B][Hp], [B]
+  float *sr_cfg = nullptr, *sr_act = nullptr, *sr_delta = nullptr;   // [cap B][N], [L][cap B][Hp] x2
+  float *sr_tang = nullptr, *sr_t = nullptr, *sr_ones = nullptr;      // [2][cap B][Hp], [cap B] x2
   float *sr_u = nullptr, *sr_x = nullptr, *sr_r = nullptr, *sr_p = nullptr, *sr_q = nullptr;
   double *sr_partial = nullptr, *sr_sc = nullptr;
-  GemmArgs* sr_batch = nullptr;                                       // [cap][L+1]
+  GemmArgs* sr_batch = nullptr;                                       // [L+1]
   bool sr_begun = false;
   // scratch
   unsigned long long* d_accepted = nullptr;
@@ -367,7 +367,7 @@ void vmc_destroy(vmc_ctx* c) {
                   c->acc_mask};
   for (void* q : ptrs) if (q) hipFree(q);
   void* sr[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_tang, c->sr_t, c->sr_u, c->sr_x, c->sr_r,
-                c->sr_p, c->sr_q, c->sr_partial, c->sr_sc, c->sr_batch};
+                c->sr_p, c->sr_q, c->sr_partial, c->sr_sc, c->sr_batch, c->sr_ones};
   for (void* q : sr) if (q) hipFree(q);
   delete c;
 }
@@ -688,10 +688,14 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
 static int sr_record(vmc_ctx* c) {
   if (c->sr_n >= c->sr_cap)
     return fail(c, VMC_ERR_STATE, "SR sample store full: vmc_sr_reserve fewer batches than accumulate calls");
-  const long long B = c->B, N = c->N, Hp = c->Hp, L = c->L, k = c->sr_n;
+  const long long B = c->B, N = c->N, Hp = c->Hp, L = c->L, k = c->sr_n, R = (long long)c->sr_cap * B;
   HIPCHK(c, hipMemcpyAsync(c->sr_cfg + k * B * N, c->configs, B * N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->sr_act + k * L * B * Hp, c->act_all, L * B * Hp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->sr_delta + k * L * B * Hp, c->delta_all, L * B * Hp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  // layer-major store [L][cap * B][Hp]: every layer's rows of ALL stored batches are contiguous,
+  // so the CG matrix-vector product runs each GEMM once over all samples
+  HIPCHK(c, hipMemcpy2DAsync(c->sr_act + k * B * Hp, R * Hp * sizeof(float), c->act_all, B * Hp * sizeof(float),
+                             B * Hp * sizeof(float), L, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(c->sr_delta + k * B * Hp, R * Hp * sizeof(float), c->delta_all, B * Hp * sizeof(float),
+                             B * Hp * sizeof(float), L, hipMemcpyDeviceToDevice, c->stream));
   c->sr_n += 1;
   return VMC_OK;
 }
@@ -858,46 +862,51 @@ int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   CHECK_CTX(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_batch};
+  void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_tang, c->sr_t, c->sr_ones};
   for (void* q : old) if (q) hipFree(q);
-  c->sr_cfg = c->sr_act = c->sr_delta = nullptr; c->sr_batch = nullptr;
+  c->sr_cfg = c->sr_act = c->sr_delta = c->sr_tang = c->sr_t = c->sr_ones = nullptr;
   c->sr_cap = 0; c->sr_n = 0; c->sr_begun = false;
   if (n_batches == 0) return VMC_OK;
-  const long long B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->L, P = c->P;
-  HIPCHK(c, dalloc(&c->sr_cfg, n_batches * B * N));
-  HIPCHK(c, dalloc(&c->sr_act, n_batches * L * B * Hp));
-  HIPCHK(c, dalloc(&c->sr_delta, n_batches * L * B * Hp));
-  HIPCHK(c, dalloc(&c->sr_batch, (long long)n_batches * (L + 1)));
+  const long long B = c->B, N = c->N, Hp = c->Hp, L = c->L, P = c->P, R = (long long)n_batches * B;
+  if (R > 0x7fffffffLL / Hp) return fail(c, VMC_ERR_UNSUPPORTED, "SR sample store too large (rows * Hp >= 2^31)");
+  HIPCHK(c, dalloc(&c->sr_cfg, R * N));
+  HIPCHK(c, dalloc(&c->sr_act, L * R * Hp));
+  HIPCHK(c, dalloc(&c->sr_delta, L * R * Hp));
+  HIPCHK(c, dalloc(&c->sr_tang, 2 * R * Hp)); HIPCHK(c, dalloc(&c->sr_t, R)); HIPCHK(c, dalloc(&c->sr_ones, R));
+  HIPCHK(c, hipMemsetAsync(c->sr_tang, 0, 2 * R * Hp * sizeof(float), c->stream));
+  HIPCHK(c, launch_fill(c->stream, c->sr_ones, 1.f, R));
   if (!c->sr_u) {
-    HIPCHK(c, dalloc(&c->sr_tang, 2 * B * Hp)); HIPCHK(c, dalloc(&c->sr_t, B));
-    HIPCHK(c, hipMemsetAsync(c->sr_tang, 0, 2 * B * Hp * sizeof(float), c->stream));
+    HIPCHK(c, dalloc(&c->sr_batch, L + 1));
     HIPCHK(c, dalloc(&c->sr_u, P + 1)); HIPCHK(c, dalloc(&c->sr_x, P)); HIPCHK(c, dalloc(&c->sr_r, P));
     HIPCHK(c, dalloc(&c->sr_p, P)); HIPCHK(c, dalloc(&c->sr_q, P));
     HIPCHK(c, dalloc(&c->sr_partial, 256)); HIPCHK(c, dalloc(&c->sr_sc, 4));
     HIPCHK(c, hipMemsetAsync(c->sr_x, 0, P * sizeof(float), c->stream));
   }
-  // weighted-sum GEMM tables, one per slot: u += [a_{l-1} | 1]^T [t (.) delta_l]
+  c->sr_cap = n_batches;
+  return VMC_OK;
+}
+
+// weighted-sum GEMM table over the rows recorded so far: u += [a_{l-1} | 1]^T [t (.) delta_l]
+static int sr_build_table(vmc_ctx* c) {
+  const long long B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->L;
+  const long long R = (long long)c->sr_cap * B, rows = (long long)c->sr_n * B;
   std::vector<GemmArgs> tab;
   const long long ws_stride = (long long)c->splitk * 2 * ((N > H ? N : H) + 1) * H;
-  for (long long k = 0; k < n_batches; ++k) {
-    const float* act = c->sr_act + k * L * B * Hp;
-    const float* del = c->sr_delta + k * L * B * Hp;
-    int slot = 0;
-    auto add = [&](const float* a, long long a_ld, int k_in, const float* delta, long long sbk,
-                   long long sbn, int n_out, long long off) {
-      GemmArgs g; memset(&g, 0, sizeof(g));
-      g.A = a; g.sam = 1; g.sak = a_ld; g.M = k_in + 1; g.ones_row = 1;
-      g.B = delta; g.sbk = sbk; g.sbn = sbn; g.kscale = c->sr_t; g.dual = 0;
-      g.N = n_out; g.K = (int)B; g.C = c->sr_u + off; g.ldc = n_out; g.epilogue = 3;
-      g.splitk = c->splitk; g.workspace = c->gemm_ws + (long long)(slot++) * ws_stride;
-      tab.push_back(g);
-    };
-    add(act + (L - 1) * B * Hp, Hp, (int)H, c->ones, 1, 0, 1, off_wout(c));
-    for (int l = (int)L - 1; l > 0; --l) add(act + (l - 1) * B * Hp, Hp, (int)H, del + l * B * Hp, Hp, 1, (int)H, off_w(c, l));
-    add(c->sr_cfg + k * B * N, N, (int)N, del, Hp, 1, (int)H, off_w(c, 0));
-  }
-  HIPCHK(c, hipMemcpy(c->sr_batch, tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
-  c->sr_cap = n_batches;
+  auto add = [&](const float* a, long long a_ld, int k_in, const float* delta, long long sbk,
+                 long long sbn, int n_out, long long off) {
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = a; g.sam = 1; g.sak = a_ld; g.M = k_in + 1; g.ones_row = 1;
+    g.B = delta; g.sbk = sbk; g.sbn = sbn; g.kscale = c->sr_t; g.dual = 0;
+    g.N = n_out; g.K = (int)rows; g.C = c->sr_u + off; g.ldc = n_out; g.epilogue = 3;
+    g.splitk = c->splitk; g.workspace = c->gemm_ws + (long long)tab.size() * ws_stride;
+    tab.push_back(g);
+  };
+  add(c->sr_act + (L - 1) * R * Hp, Hp, (int)H, c->sr_ones, 1, 0, 1, off_wout(c));
+  for (int l = (int)L - 1; l > 0; --l)
+    add(c->sr_act + (l - 1) * R * Hp, Hp, (int)H, c->sr_delta + l * R * Hp, Hp, 1, (int)H, off_w(c, l));
+  add(c->sr_cfg, N, (int)N, c->sr_delta, Hp, 1, (int)H, off_w(c, 0));
+  HIPCHK(c, hipMemcpyAsync(c->sr_batch, tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // tab is a stack object
   return VMC_OK;
 }
 
@@ -919,6 +928,7 @@ int vmc_sr_begin(vmc_ctx* c, double* rr0) {
   CHECK_CTX(c);
   if (c->sr_cap <= 0) return fail(c, VMC_ERR_STATE, "vmc_sr_reserve first");
   if (c->sr_n <= 0) return fail(c, VMC_ERR_STATE, "no samples recorded (vmc_accumulate in ENERGY_GRADIENT mode)");
+  PROPAGATE(sr_build_table(c));
   HIPCHK(c, launch_sr_rhs(c->stream, c->acc, (int)c->P, c->sr_x, c->sr_r, c->sr_p, c->sr_partial, c->sr_sc));
   c->sr_iter = 0; c->sr_begun = true;
   return sr_read_rr(c, 0, rr0);
@@ -929,37 +939,35 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
   CHECK_CTX(c);
   if (!c->sr_begun) return fail(c, VMC_ERR_STATE, "vmc_sr_begin first");
   const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->L;
+  const long long R = (long long)c->sr_cap * B;   // row stride between layers of the store
+  const int rows = c->sr_n * B;                   // all recorded samples in one pass
   const float* theta = c->ps[0].theta;
   const float* v = c->sr_p;
   Timer t(c, "sr_matvec");
   HIPCHK(c, hipMemsetAsync(c->sr_u, 0, (c->P + 1) * sizeof(float), c->stream));
-  for (long long k = 0; k < c->sr_n; ++k) {
-    const float* cfg = c->sr_cfg + k * B * N;
-    const float* act = c->sr_act + k * (long long)L * B * Hp;
-    float* tang[2] = {c->sr_tang, c->sr_tang + (long long)B * Hp};
-    {  // adot_1 = relu'(z_1) (.) (X V_1 + v_b1)
-      GemmArgs g; memset(&g, 0, sizeof(g));
-      g.A = cfg; g.sam = N; g.sak = 1; g.B = v + off_w(c, 0); g.sbk = H; g.sbn = 1;
-      g.M = B; g.N = H; g.K = N; g.C = tang[0]; g.ldc = Hp;
-      g.bias = v + off_b(c, 0); g.mask = act; g.ldmask = Hp; g.epilogue = 5; g.splitk = 1;
-      HIPCHK(c, launch_gemm(c->stream, g));
-    }
-    for (int l = 1; l < L; ++l) {  // adot_{l+1} = relu' (.) (adot_l W_l + a_l V_l + v_bl)
-      float* src = tang[(l - 1) & 1];
-      float* dst = tang[l & 1];
-      GemmArgs g; memset(&g, 0, sizeof(g));
-      g.A = src; g.sam = Hp; g.sak = 1; g.B = theta + off_w(c, l); g.sbk = H; g.sbn = 1;
-      g.M = B; g.N = H; g.K = H; g.C = dst; g.ldc = Hp; g.epilogue = 0; g.splitk = 1;
-      HIPCHK(c, launch_gemm(c->stream, g));
-      g.A = act + (long long)(l - 1) * B * Hp; g.B = v + off_w(c, l);
-      g.bias = v + off_b(c, l); g.mask = act + (long long)l * B * Hp; g.ldmask = Hp; g.epilogue = 6;
-      HIPCHK(c, launch_gemm(c->stream, g));
-    }
-    HIPCHK(c, launch_jvp_out(c->stream, tang[(L - 1) & 1], act + (long long)(L - 1) * B * Hp,
-                             theta + off_wout(c), v + off_wout(c), v + off_bout(c), B, H, Hp, c->sr_t));
-    HIPCHK(c, launch_sum_into(c->stream, c->sr_t, B, c->sr_u + c->P));
-    HIPCHK(c, launch_gemm_batched(c->stream, c->sr_batch + k * (L + 1), L + 1, N > H ? N : H, H, c->splitk, false));
+  float* tang[2] = {c->sr_tang, c->sr_tang + R * Hp};
+  {  // adot_1 = relu'(z_1) (.) (X V_1 + v_b1)
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = c->sr_cfg; g.sam = N; g.sak = 1; g.B = v + off_w(c, 0); g.sbk = H; g.sbn = 1;
+    g.M = rows; g.N = H; g.K = N; g.C = tang[0]; g.ldc = Hp;
+    g.bias = v + off_b(c, 0); g.mask = c->sr_act; g.ldmask = Hp; g.epilogue = 5; g.splitk = 1;
+    HIPCHK(c, launch_gemm(c->stream, g));
   }
+  for (int l = 1; l < L; ++l) {  // adot_{l+1} = relu' (.) (adot_l W_l + a_l V_l + v_bl)
+    float* src = tang[(l - 1) & 1];
+    float* dst = tang[l & 1];
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = src; g.sam = Hp; g.sak = 1; g.B = theta + off_w(c, l); g.sbk = H; g.sbn = 1;
+    g.M = rows; g.N = H; g.K = H; g.C = dst; g.ldc = Hp; g.epilogue = 0; g.splitk = 1;
+    HIPCHK(c, launch_gemm(c->stream, g));
+    g.A = c->sr_act + (long long)(l - 1) * R * Hp; g.B = v + off_w(c, l);
+    g.bias = v + off_b(c, l); g.mask = c->sr_act + (long long)l * R * Hp; g.ldmask = Hp; g.epilogue = 6;
+    HIPCHK(c, launch_gemm(c->stream, g));
+  }
+  HIPCHK(c, launch_jvp_out(c->stream, tang[(L - 1) & 1], c->sr_act + (long long)(L - 1) * R * Hp,
+                           theta + off_wout(c), v + off_wout(c), v + off_bout(c), rows, H, Hp, c->sr_t));
+  HIPCHK(c, launch_sum_into(c->stream, c->sr_t, rows, c->sr_u + c->P));
+  HIPCHK(c, launch_gemm_batched(c->stream, c->sr_batch, L + 1, N > H ? N : H, H, c->splitk, false));
   return VMC_OK;
 }
 

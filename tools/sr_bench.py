@@ -1,0 +1,41 @@
+"""Times the stochastic-reconfiguration solve at BASELINE config 3 (10x10 torus, FC 3x256,
+4096 chains): one epoch slice of `n_store` accumulate calls, then CG iterations.
+Usage: python tools/sr_bench.py [n_store] [cg_iters]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from cgs_vmc_amd.engine import VmcEngine  # noqa: E402
+
+n_store = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+n, h, L, b = 100, 256, 3, 4096
+theta, cfg = bench.make_inputs(n, h, L, b, 0)
+eng = VmcEngine(n, b, L, h)
+eng.set_params(theta); eng.set_configs(cfg)
+eng.set_bonds(bench.torus_bonds(10, 10, False), -1.0, 1.0)
+eng.sr_reserve(n_store)
+eng.mc_steps(10 * n)
+eng.reset_accumulators()
+for _ in range(n_store):
+  eng.accumulate(0)
+  eng.mc_steps(n)
+eng.sr_solve(0.01, 0.0, 3)          # warm-up
+eng.timing_enable(True); eng.timing_reset()
+eng.synchronize(); t0 = time.perf_counter()
+it, res = eng.sr_solve(0.01, 0.0, iters)
+eng.synchronize(); t1 = time.perf_counter()
+ms, launches = eng.timing_get('sr_matvec')
+f_amp = 2 * (n * h + (L - 1) * h * h + h)
+# per stored sample and CG iteration: tangent pass (2 F_amp: adot W and a V products) + one
+# weighted weight-gradient pass (1 F_amp)
+flops = 3.0 * f_amp * b * n_store
+print(json.dumps({
+    'n_store': n_store, 'samples': n_store * b, 'cg_iters': it, 'rel_residual': res,
+    'wall_ms_per_iter': (t1 - t0) * 1e3 / max(it, 1),
+    'matvec_ms': ms / max(launches, 1), 'matvec_ms_per_batch': ms / max(launches, 1) / n_store,
+    'matvec_tflops': flops / (ms / max(launches, 1) * 1e-3) / 1e12,
+}))
