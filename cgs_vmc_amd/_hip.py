@@ -20,6 +20,8 @@ VMC_ERR_STATE = -4
 
 VMC_PSI, VMC_OMEGA = 0, 1
 VMC_MODE_ENERGY_GRADIENT, VMC_MODE_LOG_OVERLAP_ITSWO = 0, 1
+# wavefunctions.WAVEFUNCTION_TYPES with kernels (cgsvmc.h VMC_ANSATZ_*)
+ANSATZ_IDS = {'fully_connected': 0, 'rbm': 1}
 # layers.NONLINEARITIES ids (cgsvmc.h)
 ACT_IDS = {'relu': 0, 'exp': 1, 'cos': 2, 'tan': 3, 'tanh': 4, 'sigmoid': 5, 'identity': 6}
 
@@ -29,6 +31,7 @@ class VmcDesc(C.Structure):
       ('n_sites', C.c_int32), ('batch_size', C.c_int32), ('num_layers', C.c_int32),
       ('layer_size', C.c_int32), ('nonlinearity', C.c_int32),
       ('output_activation', C.c_int32), ('device', C.c_int32), ('chain_offset', C.c_int32),
+      ('ansatz', C.c_int32), ('reserved', C.c_int32),
       ('seed', C.c_uint64), ('stream', C.c_void_p),
   ]
 
@@ -44,6 +47,7 @@ _ctx = C.c_void_p
 # name -> (restype, argtypes); every symbol include/cgsvmc.h declares
 SIGNATURES = {
     'vmc_num_params': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    'vmc_num_params_ansatz': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'vmc_create': (C.c_int, [C.POINTER(VmcDesc), C.POINTER(_ctx)]),
     'vmc_destroy': (None, [_ctx]),
     'vmc_last_error': (C.c_char_p, [_ctx]),

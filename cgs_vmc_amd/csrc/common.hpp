@@ -45,6 +45,9 @@ __device__ __forceinline__ float u32_to_uniform(uint32_t x) {
 //   p16      [L-1][Hp/16 (to)][Hp/16 (ti)][64 (lane)][4 (e)]
 //              = W[16ti + 4(lane>>4) + e][16to + (lane&15)]        (A operand, 16x16x4)
 //   woutp    [Hp], bout [1]
+// RBM ansatz (RestrictedBoltzmannNetwork, wavefunctions.py:391-452): same image with one more
+// H x H layer whose output goes through log cosh instead of relu; woutp = ones, bout = the
+// onsite bias, won [N] = the onsite weights (x . w_on is added to the logit).
 // --------------------------------------------------------------------------------------
 struct PackedParams {
   const float* w1p;
@@ -54,11 +57,28 @@ struct PackedParams {
   const float* p16;
   const float* woutp;
   const float* bout;
+  const float* won;   // [N] onsite weights (RBM) or nullptr
 };
+
+// offsets of the pieces of the flat parameter vector (both ansatz types), see vmc_api.hip
+struct ParamLayout {
+  long long off_w1, off_b1;   // first layer [N,H], [H]
+  long long off_h0;           // first H x H layer; layer l at off_h0 + l (H*H + H): w then b
+  long long off_wout, off_bout;  // FC: w_out [H], b_out;  RBM: off_wout = -1, off_bout = b_on
+  long long off_won;          // RBM: onsite weights [N]; FC: -1
+  int n_hh;                   // number of H x H layers (FC: L-1, RBM: L)
+};
+
+// log cosh(z) = |z| + log(1 + exp(-2|z|)) - log 2 (finite for every z, unlike log(cosh(z)))
+__device__ __forceinline__ float vmc_logcosh(float z) {
+  const float a = fabsf(z);
+  return a + __logf(1.f + __expf(-2.f * a)) - 0.69314718056f;
+}
 
 struct TailArgs {
   PackedParams pp;
   const float* z1;          // [n_base][Hp] cached first-layer pre-activations
+  const float* on_base;     // [n_base] cached onsite term x . w_on (RBM) or nullptr
   const float* logit_base;  // [n_base] cached logits (ratio mode)
   const int2* rowinfo;      // [n_rows] {chain, signed bond+1 or 0}; never null (launch_iota_rows)
   const int2* bonds;        // [n_bonds] {i, j}
@@ -67,6 +87,7 @@ struct TailArgs {
   int n_rows;               // host row count / upper bound
   int n_hidden;             // L-1
   int n_sites;              // N (rows of W1)
+  int n_units;              // H (unpadded layer size; the RBM sum skips the padded units)
   int num_cus;              // CUs of the device (persistent grid size)
   float* out;               // [n_rows]
 };
@@ -76,6 +97,8 @@ struct SweepArgs {
   float* configs;           // [B][N] +-1, updated in place
   float* z1;                // [B][Hp] cache out
   float* logit;             // [B]     cache out
+  float* onsite;            // [B]     cache out: x . w_on (RBM) or nullptr
+  int rbm;                  // 1: RestrictedBoltzmannNetwork epilogue (log cosh + onsite term)
   unsigned long long* accepted;  // device counter (atomicAdd)
   const int* inj_up;        // injected proposals or nullptr
   const int* inj_dn;
@@ -94,10 +117,12 @@ struct SweepArgs {
 };
 
 // launchers (one per TU)
-hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp, int L,
-                       float* w1p, float* b1p, float* bh, float* p32, float* p16, float* woutp,
-                       float* bout);
-hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode);
+hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp,
+                       const ParamLayout& lay, float* w1p, float* b1p, float* bh, float* p32,
+                       float* p16, float* woutp, float* bout, float* won);
+hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm);
+hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, int rows, int N,
+                         float* out);
 hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n);
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp);
 
@@ -123,7 +148,7 @@ struct GemmArgs {
   const float* bias;                    // epilogue 1: + bias[n] then relu
   const float* mask;  long long ldmask; // epilogue 2: * (mask[m*ldmask+n] > 0)
   int epilogue;                         // 0 none, 1 bias+relu, 2 mask, 3 accumulate (C += ), 4 bias,
-                                        // 5 mask (.) (v + bias), 6 mask (.) (C + v + bias)
+                                        // 5 mask (.) (v + bias), 6 mask (.) (C + v + bias), 7 tanh(v + bias)
   int splitk;                           // >= 1
   float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
 };
@@ -133,6 +158,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
 hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
                                int max_n, int splitk, bool dual = true);
 hipError_t launch_relu_copy(hipStream_t s, const float* z, float* a, long long n);
+hipError_t launch_tanh_copy(hipStream_t s, const float* z, float* a, long long n);
 hipError_t launch_delta_out(hipStream_t s, const float* woutp, const float* aL, float* delta,
                             int B, int Hp);
 hipError_t launch_scalar_accum(hipStream_t s, const float* eloc, const float* ratio, int B,

@@ -28,6 +28,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, int m
     case 3: *c += v; break;
     case 4: *c = v + g.bias[n]; break;
     case 5: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? v + g.bias[n] : 0.f; break;
+    case 7: *c = tanhf(v + g.bias[n]); break;
     case 6: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? *c + v + g.bias[n] : 0.f; break;
     default: *c = v; break;
   }
@@ -271,6 +272,18 @@ __global__ void k_relu_copy(const float* __restrict__ z, float* __restrict__ a, 
 hipError_t launch_relu_copy(hipStream_t s, const float* z, float* a, long long n) {
   const int blocks = (int)min((n + 255) / 256, (long long)4096);
   hipLaunchKernelGGL(k_relu_copy, dim3(blocks), dim3(256), 0, s, z, a, n);
+  return hipGetLastError();
+}
+
+__global__ void k_tanh_copy(const float* __restrict__ z, float* __restrict__ a, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    a[i] = tanhf(z[i]);
+}
+
+hipError_t launch_tanh_copy(hipStream_t s, const float* z, float* a, long long n) {
+  const int blocks = (int)min((n + 255) / 256, (long long)4096);
+  hipLaunchKernelGGL(k_tanh_copy, dim3(blocks), dim3(256), 0, s, z, a, n);
   return hipGetLastError();
 }
 

@@ -33,32 +33,34 @@
 #endif
 
 // ------------------------------------------------------------------------------------ pack
-__global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, int L,
+__global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, ParamLayout lay,
                        float* __restrict__ w1p, float* __restrict__ b1p, float* __restrict__ bh,
                        float* __restrict__ p32, float* __restrict__ p16,
-                       float* __restrict__ woutp, float* __restrict__ bout) {
+                       float* __restrict__ woutp, float* __restrict__ bout,
+                       float* __restrict__ won) {
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  const long long off_b1 = (long long)N * H;
-  const long long off_h0 = off_b1 + H;                 // first H x H layer
+  const long long off_h0 = lay.off_h0;
   const long long per_h = (long long)H * H + H;
-  const long long off_wout = off_h0 + (long long)(L - 1) * per_h;
-  const long long off_bout = off_wout + H;
+  const int n_hh = lay.n_hh;
   const int HT = Hp / 32, NT = Hp / 16;
   for (long long i = tid; i < (long long)N * Hp; i += stride) {
     const int n = (int)(i / Hp), c = (int)(i % Hp);
-    w1p[i] = c < H ? theta[(long long)n * H + c] : 0.f;
+    w1p[i] = c < H ? theta[lay.off_w1 + (long long)n * H + c] : 0.f;
   }
   for (long long i = tid; i < Hp; i += stride) {
-    b1p[i] = i < H ? theta[off_b1 + i] : 0.f;
-    woutp[i] = i < H ? theta[off_wout + i] : 0.f;
-    if (i == 0) bout[0] = theta[off_bout];
+    b1p[i] = i < H ? theta[lay.off_b1 + i] : 0.f;
+    // RBM: the output "dot" is a plain sum over the H log cosh values
+    woutp[i] = i < H ? (lay.off_wout >= 0 ? theta[lay.off_wout + i] : 1.f) : 0.f;
+    if (i == 0) bout[0] = theta[lay.off_bout];
   }
-  for (long long i = tid; i < (long long)(L - 1) * Hp; i += stride) {
+  if (lay.off_won >= 0)
+    for (long long i = tid; i < N; i += stride) won[i] = theta[lay.off_won + i];
+  for (long long i = tid; i < (long long)n_hh * Hp; i += stride) {
     const int l = (int)(i / Hp), c = (int)(i % Hp);
     bh[i] = c < H ? theta[off_h0 + l * per_h + (long long)H * H + c] : 0.f;
   }
-  const long long n32 = (long long)(L - 1) * Hp * Hp;
+  const long long n32 = (long long)n_hh * Hp * Hp;
   for (long long i = tid; i < n32; i += stride) {
     long long r = i;
     const int e = (int)(r & 3); r >>= 2;
@@ -84,11 +86,33 @@ __global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, in
   }
 }
 
-hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp, int L,
-                       float* w1p, float* b1p, float* bh, float* p32, float* p16, float* woutp,
-                       float* bout) {
-  hipLaunchKernelGGL(k_pack, dim3(512), dim3(256), 0, s, theta, N, H, Hp, L, w1p, b1p, bh, p32,
-                     p16, woutp, bout);
+hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp,
+                       const ParamLayout& lay, float* w1p, float* b1p, float* bh, float* p32,
+                       float* p16, float* woutp, float* bout, float* won) {
+  hipLaunchKernelGGL(k_pack, dim3(512), dim3(256), 0, s, theta, N, H, Hp, lay, w1p, b1p, bh, p32,
+                     p16, woutp, bout, won);
+  return hipGetLastError();
+}
+
+// onsite term of the RBM ansatz (wavefunctions.py:436): out[r] = x_r . w_on, one wave per row
+// (the bias b_on travels as `bout`)
+__global__ __launch_bounds__(256) void k_onsite(const float* __restrict__ configs,
+                                                const float* __restrict__ won, int rows, int N,
+                                                float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int n = lane; n < N; n += 64) s = fmaf(configs[(long long)r * N + n], won[n], s);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) out[r] = s;
+}
+
+hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, int rows, int N,
+                         float* out) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_onsite, dim3((rows + 3) / 4), dim3(256), 0, s, configs, won, rows, N, out);
   return hipGetLastError();
 }
 
@@ -98,7 +122,9 @@ hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp, 
 // accumulator registers, split over the two lane halves).  No barriers; LDS is only a per-wave
 // staging area for the next tile's gathered first-layer activations.  RATIO mode writes
 // 0.5*jx[bond]*exp(logit_row - logit_base[chain]).
-template <int HT, bool RATIO>
+// RBM: the last H x H layer's epilogue is sum_h log cosh(z_h) instead of relu(z) . w_out, and the
+// onsite term x . w_on of the row (chain's cached value + the rank-2 exchange update) is added.
+template <int HT, bool RATIO, bool RBM>
 __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
   constexpr int Hp = HT * 32;
   // per-wave staging of the NEXT tile's first-layer activations: [wave][4*HT][64 lanes][4]
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
 
   // row descriptor of this lane in a tile: cached z1 row of the chain + rank-2 exchange update
   // z1' = z1 + coef (W1[i] - W1[j])
-  struct Desc { const float* zb; const float* wa; const float* wb; float coef; int row, chain, bond; bool valid; };
+  struct Desc { const float* zb; const float* wa; const float* wb; float coef, on; int row, chain, bond; bool valid; };
   // branch-free (every load unconditional, indices clamped): the waitcnt pass can then count
   // vmcnt exactly, which lets the three dependent loads be issued a whole tile ahead
   auto describe = [&](int tile) {
@@ -146,12 +172,15 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
     d.wa = a.pp.w1p + (long long)ab.x * Hp;
     d.wb = a.pp.w1p + (long long)ab.y * Hp;
     d.zb = a.z1 + (long long)d.chain * Hp;
+    d.on = 0.f;
+    if (RBM) d.on = fmaf(d.coef, a.pp.won[ab.x] - a.pp.won[ab.y], a.on_base[d.chain]);
     return d;
   };
   auto finish_row = [&](const Desc& d, float part) {
     const float other = __shfl_xor(part, 32);
     // fixed order: (half 0) + (half 1)
-    const float logit = (h == 0 ? part + other : other + part) + bout;
+    float logit = (h == 0 ? part + other : other + part) + bout;
+    if (RBM) logit += d.on;
     if (d.valid && h == 0) {
       if (RATIO) a.out[d.row] = a.half_jx[d.bond] * expf(logit - a.logit_base[d.chain]);
       else a.out[d.row] = logit;
@@ -245,8 +274,10 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
 #pragma unroll
       for (int to = 0; to < HT; ++to) {
         f32x4 wo[4];
+        if (!RBM) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wo[q] = *(const f32x4*)(wop + 32 * to + 8 * q + 4 * h);
+          for (int q = 0; q < 4; ++q) wo[q] = *(const f32x4*)(wop + 32 * to + 8 * q + 4 * h);
+        }
         f32x16 acc;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -287,7 +318,10 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) part = fmaf(fmaxf(acc[4 * q + e], 0.f), wo[q][e], part);
+          for (int e = 0; e < 4; ++e) {
+            if (RBM) part += (32 * to + 8 * q + 4 * h + e < a.n_units) ? vmc_logcosh(acc[4 * q + e]) : 0.f;
+            else part = fmaf(fmaxf(acc[4 * q + e], 0.f), wo[q][e], part);
+          }
       }
     }
     finish_row(cur, part);
@@ -319,8 +353,9 @@ hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n) {
   return hipGetLastError();
 }
 
-// L = 1 (no H x H layer): logit = relu(z1') . w_out + b_out, one thread per row
-template <bool RATIO>
+// no H x H layer: logit = relu(z1') . w_out + b_out (FC, L = 1) or sum log cosh(z1') + onsite
+// (RBM, num_layers = 0: the classic restricted Boltzmann machine), one thread per row
+template <bool RATIO, bool RBM>
 __global__ __launch_bounds__(256) void k_tail0(TailArgs a, int Hp) {
   const int n_rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
   for (int row = blockIdx.x * 256 + threadIdx.x; row < n_rows; row += gridDim.x * 256) {
@@ -329,54 +364,60 @@ __global__ __launch_bounds__(256) void k_tail0(TailArgs a, int Hp) {
     const float* zb = a.z1 + (long long)chain * Hp;
     const float* wa = a.pp.w1p;
     const float* wb = wa;
-    float coef = 0.f;
+    float coef = 0.f, on = RBM ? a.on_base[chain] : 0.f;
     int bond = 0;
     if (bs != 0) {
       bond = (bs > 0 ? bs : -bs) - 1;
       coef = bs > 0 ? -2.f : 2.f;
       const int2 ab = a.bonds[bond];
       wa += (long long)ab.x * Hp; wb += (long long)ab.y * Hp;
+      if (RBM) on = fmaf(coef, a.pp.won[ab.x] - a.pp.won[ab.y], on);
     }
     float s = 0.f;
-    for (int i = 0; i < Hp; ++i)
-      s = fmaf(fmaxf(fmaf(coef, wa[i] - wb[i], zb[i]), 0.f), a.pp.woutp[i], s);
-    const float logit = s + a.pp.bout[0];
+    if (RBM) {
+      for (int i = 0; i < a.n_units; ++i) s += vmc_logcosh(fmaf(coef, wa[i] - wb[i], zb[i]));
+    } else {
+      for (int i = 0; i < Hp; ++i)
+        s = fmaf(fmaxf(fmaf(coef, wa[i] - wb[i], zb[i]), 0.f), a.pp.woutp[i], s);
+    }
+    const float logit = s + a.pp.bout[0] + on;
     a.out[row] = RATIO ? a.half_jx[bond] * expf(logit - a.logit_base[chain]) : logit;
   }
 }
 
-template <int HT, bool RATIO>
+template <int HT, bool RATIO, bool RBM>
 static hipError_t launch_tail32_h(hipStream_t s, const TailArgs& a) {
   const int tiles = (a.n_rows + 127) / 128;
   const int persistent = a.num_cus > 0 ? a.num_cus : 256;   // 1 workgroup per CU (1 wave/SIMD)
   const dim3 grid(tiles < persistent ? tiles : persistent), block(256);
   const size_t lds = (size_t)4 * (4 * HT) * 64 * sizeof(f32x4);
-  hipError_t e = hipFuncSetAttribute((const void*)k_tail32<HT, RATIO>,
+  hipError_t e = hipFuncSetAttribute((const void*)k_tail32<HT, RATIO, RBM>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_tail32<HT, RATIO>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((k_tail32<HT, RATIO, RBM>), grid, block, lds, s, a);
   return hipGetLastError();
 }
 
-template <bool RATIO>
+template <bool RATIO, bool RBM>
 static hipError_t launch_tail32_t(hipStream_t s, const TailArgs& a, int Hp) {
   if (a.n_rows <= 0) return hipSuccess;
   if (a.n_hidden == 0) {
     const int blocks = (a.n_rows + 255) / 256;
-    hipLaunchKernelGGL((k_tail0<RATIO>), dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, s, a, Hp);
+    hipLaunchKernelGGL((k_tail0<RATIO, RBM>), dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, s, a, Hp);
     return hipGetLastError();
   }
   switch (Hp / 32) {
-    case 2: return launch_tail32_h<2, RATIO>(s, a);
-    case 4: return launch_tail32_h<4, RATIO>(s, a);
-    case 6: return launch_tail32_h<6, RATIO>(s, a);
-    case 8: return launch_tail32_h<8, RATIO>(s, a);
+    case 2: return launch_tail32_h<2, RATIO, RBM>(s, a);
+    case 4: return launch_tail32_h<4, RATIO, RBM>(s, a);
+    case 6: return launch_tail32_h<6, RATIO, RBM>(s, a);
+    case 8: return launch_tail32_h<8, RATIO, RBM>(s, a);
     default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode) {
-  return ratio_mode ? launch_tail32_t<true>(s, a, Hp) : launch_tail32_t<false>(s, a, Hp);
+hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm) {
+  if (rbm) return ratio_mode ? launch_tail32_t<true, true>(s, a, Hp) : launch_tail32_t<false, true>(s, a, Hp);
+  return ratio_mode ? launch_tail32_t<true, false>(s, a, Hp) : launch_tail32_t<false, false>(s, a, Hp);
 }
 
 // --------------------------------------------------------------------------------- sweep16
@@ -427,7 +468,9 @@ __device__ __forceinline__ unsigned long long vmc_stamp() {
 // NW: waves per workgroup (4 or 8).  With 8 waves (2 per SIMD) each wave owns NT/8 output
 // tiles; the two co-resident waves hide each other's vmcnt / LDS stalls inside the layers.
 // Proposals, accept and the Philox chains stay on waves 0-3 (4 chains each).
-template <int NT, int NW, bool STAMP, bool W1L, bool FAST>
+// RBM: RestrictedBoltzmannNetwork epilogue: the last layer's units go through log cosh (its
+// output "dot" is against ones) and the onsite term x . w_on is tracked per chain in LDS.
+template <int NT, int NW, bool STAMP, bool W1L, bool FAST, bool RBM = false>
 __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   static_assert(NT % NW == 0, "output tiles must divide over the waves");
   constexpr int NTH = NW * 64;
@@ -449,7 +492,9 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   float* s_hlu = (float*)(s_pacc + 16);       // [16] 0.5 log(u_accept)
   float* s_wout = s_hlu + 16;                 // [Hp]
   float* s_bias = s_wout + Hp;                // [n_hidden][Hp] biases of the H x H layers
-  float* s_w1 = s_bias + a.n_hidden * Hp;     // [N][W1S] (W1L only)
+  float* s_won = s_bias + a.n_hidden * Hp;    // [Nst] onsite weights (RBM only)
+  float* s_on = s_won + (RBM ? Nst : 0);      // [16] x . w_on of the committed chains (RBM only)
+  float* s_w1 = s_on + (RBM ? 16 : 0);        // [N][W1S] (W1L only)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
@@ -471,6 +516,9 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   if (tid < 16) { s_sel[tid] = 0; s_pacc[tid] = 0; s_pup[tid] = 0; s_pdn[tid] = 0; }
   for (int i = tid; i < n_hidden * Hp; i += NTH) s_bias[i] = pp.bh[i];
   for (int i = tid; i < Hp; i += NTH) s_wout[i] = pp.woutp[i];
+  if (RBM) {
+    for (int i = tid; i < Nst; i += NTH) s_won[i] = i < N ? pp.won[i] : 0.f;
+  }
   if (W1L) {
     for (int i = tid; i < N * (Hp / 4); i += NTH) {
       const int n = i / (Hp / 4), c4 = i % (Hp / 4);
@@ -508,6 +556,14 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
       }
 #pragma unroll
       for (int c = 0; c < CPG; ++c) s_z1[(grp * CPG + c) * ZS + col] = acc[c];
+    }
+  };
+  // exact onsite term of the committed spins (RBM): one thread per chain
+  auto onsite_direct = [&]() {
+    if (RBM && tid < 16) {
+      float acc = 0.f;
+      for (int n = 0; n < N; ++n) acc = fmaf(s_spin[tid * Nst + n], s_won[n], acc);
+      s_on[tid] = acc;
     }
   };
 
@@ -657,6 +713,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   }
 
   f32x4 own[TO];  // relu'd activations of this wave's own output tiles (B-operand layout)
+  f32x4 zlast[TO];  // RBM: pre-activations of the last layer (the gradient path wants tanh of them)
 
   // diagnostic stamps (STAMP instantiation only)
   unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
@@ -670,8 +727,24 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
     if (chain0 + j < a.B) {
       float* dst = a.act_out + ((long long)l * a.B + chain0 + j) * Hp;
 #pragma unroll
-      for (int to = 0; to < TO; ++to)
-        *(f32x4*)(dst + 16 * (wave * TO + to) + 4 * g) = own[to];
+      for (int to = 0; to < TO; ++to) {
+        f32x4 v = own[to];
+        if (RBM && l == n_hidden) {   // d sum log cosh(z) / d z = tanh(z): the last layer's delta
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = tanhf(zlast[to][e]);
+        }
+        *(f32x4*)(dst + 16 * (wave * TO + to) + 4 * g) = v;
+      }
+    }
+  };
+  // last-stage activation: relu (FC; the dot with w_out follows) or log cosh (RBM, w_out = 1)
+  auto finish_own = [&](int to, const f32x4& z, bool last) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(z[e], 0.f);
+    if (RBM && last) {
+      zlast[to] = z;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) own[to][e] = vmc_logcosh(z[e]);
     }
   };
   auto build = [&](bool with_delta) {
@@ -703,8 +776,8 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
         for (int e = 0; e < 4; ++e) {
           z[to][e] = fmaf(cp, x0[to][e] - y0[to][e], z[to][e]);     // committed z1
           zc[e] = fmaf(cd, x1[to][e] - y1[to][e], z[to][e]);        // candidate z1'
-          own[to][e] = fmaxf(zc[e], 0.f);
         }
+        finish_own(to, zc, n_hidden == 0);
         *(f32x4*)(zrow + col) = z[to];
         *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
       }
@@ -731,8 +804,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
         for (int e = 0; e < 4; ++e) z[e] = fmaf(2.f, x[e] - y[e], z[e]);
         *(f32x4*)(zn + col) = z;
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(z[e], 0.f);
+      finish_own(to, z, n_hidden == 0);
       *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
     }
     if (save_acts) save_own(0);
@@ -823,8 +895,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
       float* xout = s_x + (cur ^ 1) * NT * 256;
 #pragma unroll
       for (int to = 0; to < TO; ++to) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(acc[to][e], 0.f);
+        finish_own(to, acc[to], l + 1 == n_hidden);
         if (l + 1 < n_hidden) *(f32x4*)(xout + ((wave * TO + to) * 64 + lane) * 4) = own[to];
       }
       if (save_acts) save_own(l + 1);
@@ -867,7 +938,13 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   auto resolve = [&]() {
     if (prev_kind == 0 || (NW > 4 && wave >= 4)) return;
     const int c = my_c, gc = chain0 + c;
-    const float ln = logit_of(c);
+    float ln = logit_of(c);
+    float on_new = 0.f;
+    if (RBM) {   // onsite term of the evaluated configuration: committed value (+ exchange update)
+      on_new = s_on[c];
+      if (prev_kind == 2) on_new += 2.f * (s_won[s_idn[c]] - s_won[s_iup[c]]);
+      ln += on_new;
+    }
     if (prev_kind == 2) {
       // Metropolis accept (graph_builders.py:75-88)
       // exp(dlogit) > sqrt(u)  <=>  dlogit > 0.5 log(u)  (monotone; u = 0 always accepts)
@@ -875,6 +952,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
       if (j == 0) {
         if (acc) {
           s_logit[c] = ln;
+          if (RBM) s_on[c] = on_new;
           s_spin[c * Nst + s_idn[c]] = 1.f;
           s_spin[c * Nst + s_iup[c]] = -1.f;
           if (!W1L) s_sel[c] ^= 1;
@@ -896,6 +974,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
       s_z1[c * ZS + col] = gc < a.B ? a.z1[(long long)gc * Hp + col] : 0.f;
     }
     if (tid < 16) s_logit[tid] = chain0 + tid < a.B ? a.logit[chain0 + tid] : 0.f;
+    onsite_direct();
     if (use_pref) draw_all(a.step0);
     __syncthreads();
     it_first = 0;
@@ -913,6 +992,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
       __syncthreads();   // z1_direct reads every chain's (possibly just updated) spins
       if (tid < 16) { s_sel[tid] = 0; s_pacc[tid] = 0; }
       z1_direct();
+      onsite_direct();
     }
     SWEEP_STAMP(0)
     __syncthreads();
@@ -939,6 +1019,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
 
   // write back chains and the exact cache
   if (tid < 16 && chain0 + tid < a.B) a.logit[chain0 + tid] = s_logit[tid];
+  if (RBM && tid < 16 && chain0 + tid < a.B) a.onsite[chain0 + tid] = s_on[tid];
   for (int i = tid; i < 16 * N; i += NTH) {
     const int c = i / N, n = i % N, gc = chain0 + c;
     if (gc < a.B) a.configs[(long long)gc * N + n] = s_spin[c * Nst + n];
@@ -950,32 +1031,33 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   if (j == 0 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);   // waves 0-3 only
 }
 
-static size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l) {
+static size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool rbm) {
   const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
   return sizeof(float) * (size_t)(16 * Nst + (w1l ? 1 : 2) * 16 * ZS + 2 * NT * 256 + 16 +
-                                  16 + 7 * 16 + Hp + n_hidden * Hp + (w1l ? N * (Hp + 4) : 0));
+                                  16 + 7 * 16 + Hp + n_hidden * Hp + (rbm ? Nst + 16 : 0) +
+                                  (w1l ? N * (Hp + 4) : 0));
 }
 
-template <int NT, int NW>
+template <int NT, int NW, bool RBM>
 static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
   const dim3 grid((a.B + 15) / 16), block(NW * 64);
-  const size_t lds_full = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, true);
+  const size_t lds_full = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, true, RBM);
   const bool w1l = lds_full <= 160 * 1024;
-  const size_t lds = w1l ? lds_full : sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false);
+  const size_t lds = w1l ? lds_full : sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false, RBM);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int nblk = (a.N + 3) / 4;
   const bool fast = nblk <= 32 && a.inj_up == nullptr && a.dbg_up == nullptr;
 #define SWEEP_LAUNCH(ST, WL, FA)                                                              \
   do {                                                                                        \
-    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, NW, ST, WL, FA>,                \
+    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, NW, ST, WL, FA, RBM>,       \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                            \
-    hipLaunchKernelGGL((k_sweep16<NT, NW, ST, WL, FA>), grid, block, lds, s, a);                  \
+    hipLaunchKernelGGL((k_sweep16<NT, NW, ST, WL, FA, RBM>), grid, block, lds, s, a);         \
     return hipGetLastError();                                                                 \
   } while (0)
   if (a.dbg_cycles) {
-    if (!(w1l && fast)) return hipErrorInvalidValue;   // diagnostic build: production variant only
-    SWEEP_LAUNCH(true, true, true);
+    if (!(w1l && fast) || RBM) return hipErrorInvalidValue;   // diagnostic build: production variant only
+    if constexpr (!RBM) SWEEP_LAUNCH(true, true, true);
   }
   if (w1l) { if (fast) SWEEP_LAUNCH(false, true, true); else SWEEP_LAUNCH(false, true, false); }
   if (fast) SWEEP_LAUNCH(false, false, true);
@@ -985,11 +1067,20 @@ static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
 
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp) {
   if (a.B <= 0) return hipSuccess;
+  if (a.rbm) {
+    switch (Hp / 16) {
+      case 4: return launch_sweep16_t<4, 4, true>(s, a);
+      case 8: return launch_sweep16_t<8, 4, true>(s, a);
+      case 12: return launch_sweep16_t<12, 4, true>(s, a);
+      case 16: return a.waves == 8 ? launch_sweep16_t<16, 8, true>(s, a) : launch_sweep16_t<16, 4, true>(s, a);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (Hp / 16) {
-    case 4: return launch_sweep16_t<4, 4>(s, a);
-    case 8: return launch_sweep16_t<8, 4>(s, a);
-    case 12: return launch_sweep16_t<12, 4>(s, a);
-    case 16: return a.waves == 8 ? launch_sweep16_t<16, 8>(s, a) : launch_sweep16_t<16, 4>(s, a);
+    case 4: return launch_sweep16_t<4, 4, false>(s, a);
+    case 8: return launch_sweep16_t<8, 4, false>(s, a);
+    case 12: return launch_sweep16_t<12, 4, false>(s, a);
+    case 16: return a.waves == 8 ? launch_sweep16_t<16, 8, false>(s, a) : launch_sweep16_t<16, 4, false>(s, a);
     default: return hipErrorInvalidValue;
   }
 }

@@ -18,13 +18,14 @@ std::string g_create_error;
 struct ParamSet {
   float* theta = nullptr;
   float *w1p = nullptr, *b1p = nullptr, *bh = nullptr, *p32 = nullptr, *p16 = nullptr,
-        *woutp = nullptr, *bout = nullptr;
+        *woutp = nullptr, *bout = nullptr, *won = nullptr;
   float* z1 = nullptr;     // [B][Hp] cache for the ctx's chains
+  float* onsite = nullptr; // [B] cached x . w_on (RBM)
   float* logit = nullptr;  // [B]
   float* eloc = nullptr;   // [B]
   bool packed_valid = false, cache_valid = false, has_params = false;
   float shift = -10.f;     // wavefunctions.py:209
-  PackedParams packed() const { return PackedParams{w1p, b1p, bh, p32, p16, woutp, bout}; }
+  PackedParams packed() const { return PackedParams{w1p, b1p, bh, p32, p16, woutp, bout, won}; }
 };
 
 struct TimedRegion {
@@ -37,6 +38,10 @@ struct TimedRegion {
 struct vmc_ctx {
   vmc_desc d;
   int N = 0, B = 0, L = 0, H = 0, Hp = 0;
+  bool rbm = false;        // RestrictedBoltzmannNetwork instead of FullyConnectedNetwork
+  int n_hh = 0;            // H x H layers: L - 1 (FC) or L (RBM)
+  int A = 0;               // activation buffers = n_hh + 1
+  ParamLayout lay;
   long long P = 0;
   hipStream_t stream = nullptr;
   ParamSet ps[2];
@@ -80,7 +85,7 @@ struct vmc_ctx {
   unsigned long long* d_accepted = nullptr;
   double* d_sum = nullptr;
   float* d_max = nullptr;
-  float *tmp_cfg = nullptr, *tmp_z1 = nullptr, *tmp_out = nullptr;
+  float *tmp_cfg = nullptr, *tmp_z1 = nullptr, *tmp_out = nullptr, *tmp_on = nullptr;
   long long tmp_rows = 0;
   int *inj_up = nullptr, *inj_dn = nullptr;
   float* inj_u = nullptr;
@@ -146,21 +151,36 @@ void drain_timings(vmc_ctx* c) {
 }
 
 long long off_w(const vmc_ctx* c, int l) {  // weight matrix of layer l (0 = first)
-  if (l == 0) return 0;
-  return (long long)c->N * c->H + c->H + (long long)(l - 1) * ((long long)c->H * c->H + c->H);
+  if (l == 0) return c->lay.off_w1;
+  return c->lay.off_h0 + (long long)(l - 1) * ((long long)c->H * c->H + c->H);
 }
-long long off_b(const vmc_ctx* c, int l) {
-  return l == 0 ? (long long)c->N * c->H : off_w(c, l) + (long long)c->H * c->H;
+long long off_b(const vmc_ctx* c, int l) {  // biases sit right behind their weights
+  return l == 0 ? c->lay.off_b1 : off_w(c, l) + (long long)c->H * c->H;
 }
-long long off_wout(const vmc_ctx* c) { return off_w(c, c->L); }
-long long off_bout(const vmc_ctx* c) { return off_wout(c) + c->H; }
+long long off_wout(const vmc_ctx* c) { return c->lay.off_wout; }
+long long off_bout(const vmc_ctx* c) { return c->lay.off_bout; }
+
+ParamLayout make_layout(bool rbm, long long N, long long H, long long L) {
+  ParamLayout lay;
+  if (rbm) {   // w_on[N] b_on | w_1 b_1 | (w b) x L        (see include/cgsvmc.h)
+    lay.off_won = 0; lay.off_bout = N; lay.off_wout = -1;
+    lay.off_w1 = N + 1; lay.off_b1 = lay.off_w1 + N * H; lay.off_h0 = lay.off_b1 + H;
+    lay.n_hh = (int)L;
+  } else {     // w_1 b_1 | (w b) x (L-1) | w_out b_out
+    lay.off_w1 = 0; lay.off_b1 = N * H; lay.off_h0 = lay.off_b1 + H;
+    lay.n_hh = (int)L - 1;
+    lay.off_wout = lay.off_h0 + (L - 1) * (H * H + H); lay.off_bout = lay.off_wout + H;
+    lay.off_won = -1;
+  }
+  return lay;
+}
 
 int ensure_packed(vmc_ctx* c, int which) {
   ParamSet& p = c->ps[which];
   if (!p.has_params) return fail(c, VMC_ERR_STATE, "parameters not set (vmc_set_params)");
   if (p.packed_valid) return VMC_OK;
-  HIPCHK(c, launch_pack(c->stream, p.theta, c->N, c->H, c->Hp, c->L, p.w1p, p.b1p, p.bh, p.p32,
-                        p.p16, p.woutp, p.bout));
+  HIPCHK(c, launch_pack(c->stream, p.theta, c->N, c->H, c->Hp, c->lay, p.w1p, p.b1p, p.bh, p.p32,
+                        p.p16, p.woutp, p.bout, p.won));
   p.packed_valid = true;
   return VMC_OK;
 }
@@ -171,8 +191,10 @@ TailArgs tail_args(vmc_ctx* c, int which) {
   a.pp = c->ps[which].packed();
   a.bonds = c->bonds ? c->bonds : c->bond_dummy;   // the kernel loads bonds[0] unconditionally
   a.half_jx = c->half_jx;
-  a.n_hidden = c->L - 1;
+  a.n_hidden = c->n_hh;
   a.n_sites = c->N;
+  a.n_units = c->H;
+  a.on_base = c->ps[which].onsite;
   a.num_cus = c->num_cus;
   return a;
 }
@@ -198,12 +220,13 @@ int ensure_cache(vmc_ctx* c, int which) {
   {
     Timer t(c, "z1");
     PROPAGATE(first_layer(c, p, c->configs, p.z1, c->B));
+    if (c->rbm) HIPCHK(c, launch_onsite(c->stream, c->configs, p.won, c->B, c->N, p.onsite));
   }
   {
     Timer t(c, "tail_amp");
     TailArgs a = tail_args(c, which);
     a.z1 = p.z1; a.n_rows = c->B; a.out = p.logit; a.rowinfo = c->rowinfo_id;
-    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, false));
+    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, false, c->rbm));
   }
   p.cache_valid = true;
   return VMC_OK;
@@ -237,7 +260,7 @@ int local_energy_device(vmc_ctx* c, int which) {
     a.n_rows_dev = c->off + c->B;
     a.n_rows = (int)((long long)c->B * c->n_bonds);
     a.out = c->val;
-    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, true));
+    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, true, c->rbm));
   }
   {
     Timer t(c, "eloc_reduce");
@@ -248,7 +271,8 @@ int local_energy_device(vmc_ctx* c, int which) {
 
 int grow_tmp(vmc_ctx* c, long long rows) {
   if (rows <= c->tmp_rows) return VMC_OK;
-  if (c->tmp_cfg) { hipFree(c->tmp_cfg); hipFree(c->tmp_z1); hipFree(c->tmp_out); hipFree(c->tmp_rowinfo); }
+  if (c->tmp_cfg) { hipFree(c->tmp_cfg); hipFree(c->tmp_z1); hipFree(c->tmp_out); hipFree(c->tmp_rowinfo); hipFree(c->tmp_on); }
+  HIPCHK(c, dalloc(&c->tmp_on, rows));
   HIPCHK(c, dalloc(&c->tmp_rowinfo, rows));
   HIPCHK(c, launch_iota_rows(c->stream, c->tmp_rowinfo, (int)rows));
   HIPCHK(c, dalloc(&c->tmp_cfg, rows * c->N));
@@ -267,6 +291,12 @@ int64_t vmc_num_params(int32_t n_sites, int32_t layer_size, int32_t num_layers) 
   return N * H + H + (L - 1) * (H * H + H) + H + 1;
 }
 
+int64_t vmc_num_params_ansatz(int32_t ansatz, int32_t n_sites, int32_t layer_size, int32_t num_layers) {
+  const int64_t N = n_sites, H = layer_size, L = num_layers;
+  if (ansatz == VMC_ANSATZ_RBM) return N + 1 + N * H + H + L * (H * H + H);
+  return vmc_num_params(n_sites, layer_size, num_layers);
+}
+
 const char* vmc_last_error(const vmc_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
@@ -274,8 +304,11 @@ const char* vmc_last_error(const vmc_ctx* ctx) {
 int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (!d || !out) return fail(nullptr, VMC_ERR_INVALID, "null argument");
   *out = nullptr;
-  if (d->n_sites < 2 || d->batch_size < 1 || d->num_layers < 1 || d->layer_size < 1)
-    return fail(nullptr, VMC_ERR_INVALID, "n_sites >= 2, batch_size, num_layers, layer_size >= 1 required");
+  if (d->ansatz != VMC_ANSATZ_FULLY_CONNECTED && d->ansatz != VMC_ANSATZ_RBM)
+    return fail(nullptr, VMC_ERR_UNSUPPORTED, "only the fully_connected and rbm ansatz types have HIP kernels");
+  const bool rbm = d->ansatz == VMC_ANSATZ_RBM;
+  if (d->n_sites < 2 || d->batch_size < 1 || d->num_layers < (rbm ? 0 : 1) || d->layer_size < 1)
+    return fail(nullptr, VMC_ERR_INVALID, "n_sites >= 2, batch_size, layer_size >= 1, num_layers >= 1 (rbm: >= 0) required");
   if (d->nonlinearity != VMC_ACT_RELU)
     return fail(nullptr, VMC_ERR_UNSUPPORTED, "only nonlinearity='relu' has a HIP kernel");
   if (d->output_activation != VMC_ACT_EXP)
@@ -296,7 +329,10 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   c->d = *d;
   c->N = d->n_sites; c->B = d->batch_size; c->L = d->num_layers; c->H = d->layer_size;
   c->Hp = (c->H + 63) / 64 * 64;
-  c->P = vmc_num_params(c->N, c->H, c->L);
+  c->rbm = rbm;
+  c->lay = make_layout(rbm, c->N, c->H, c->L);
+  c->n_hh = c->lay.n_hh; c->A = c->n_hh + 1;
+  c->P = vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
   c->stream = (hipStream_t)d->stream;
   if (const char* e = getenv("CGS_VMC_SWEEP_WAVES")) c->sweep_waves = atoi(e) == 8 ? 8 : 4;
   {
@@ -304,16 +340,19 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0)
       c->num_cus = prop.multiProcessorCount;
   }
-  const long long B = c->B, N = c->N, Hp = c->Hp, P = c->P, L = c->L;
+  const long long B = c->B, N = c->N, Hp = c->Hp, P = c->P, L = c->A, NH = c->n_hh;   // L: activation buffers
 #define CA(expr) do { hipError_t e2 = (expr); if (e2 != hipSuccess) { \
     g_create_error = std::string(#expr) + ": " + hipGetErrorString(e2); vmc_destroy(c); return VMC_ERR_HIP; } } while (0)
   for (int w = 0; w < 2; ++w) {
     ParamSet& p = c->ps[w];
     CA(dalloc(&p.theta, P));
-    CA(dalloc(&p.w1p, N * Hp)); CA(dalloc(&p.b1p, Hp)); CA(dalloc(&p.bh, (L - 1) * Hp));
-    CA(dalloc(&p.p32, (L > 1 ? L - 1 : 1) * Hp * Hp)); CA(dalloc(&p.p16, (L > 1 ? L - 1 : 1) * Hp * Hp));
-    CA(hipMemsetAsync(p.p32, 0, (size_t)(L > 1 ? L - 1 : 1) * Hp * Hp * sizeof(float), c->stream));
-    CA(hipMemsetAsync(p.p16, 0, (size_t)(L > 1 ? L - 1 : 1) * Hp * Hp * sizeof(float), c->stream));
+    CA(dalloc(&p.w1p, N * Hp)); CA(dalloc(&p.b1p, Hp)); CA(dalloc(&p.bh, NH * Hp));
+    CA(dalloc(&p.p32, (NH > 0 ? NH : 1) * Hp * Hp)); CA(dalloc(&p.p16, (NH > 0 ? NH : 1) * Hp * Hp));
+    CA(hipMemsetAsync(p.p32, 0, (size_t)(NH > 0 ? NH : 1) * Hp * Hp * sizeof(float), c->stream));
+    CA(hipMemsetAsync(p.p16, 0, (size_t)(NH > 0 ? NH : 1) * Hp * Hp * sizeof(float), c->stream));
+    CA(dalloc(&p.won, N)); CA(dalloc(&p.onsite, B));
+    CA(hipMemsetAsync(p.won, 0, N * sizeof(float), c->stream));
+    CA(hipMemsetAsync(p.onsite, 0, B * sizeof(float), c->stream));
     CA(dalloc(&p.woutp, Hp)); CA(dalloc(&p.bout, 1));
     CA(dalloc(&p.z1, B * Hp)); CA(dalloc(&p.logit, B)); CA(dalloc(&p.eloc, B));
   }
@@ -356,14 +395,14 @@ void vmc_destroy(vmc_ctx* c) {
   drain_timings(c);
   for (int w = 0; w < 2; ++w) {
     ParamSet& p = c->ps[w];
-    float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p32, p.p16, p.woutp, p.bout, p.z1, p.logit, p.eloc};
+    float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p32, p.p16, p.woutp, p.bout, p.z1, p.logit, p.eloc, p.won, p.onsite};
     for (float* q : ptrs) if (q) hipFree(q);
   }
   if (c->act_all) hipFree(c->act_all);
   void* ptrs[] = {c->configs, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0], c->d_batch[1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->d_accepted, c->d_sum,
-                  c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->tmp_rowinfo, c->rowinfo_id, c->bond_dummy, c->inj_up, c->inj_dn, c->inj_u,
+                  c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->tmp_on, c->tmp_rowinfo, c->rowinfo_id, c->bond_dummy, c->inj_up, c->inj_dn, c->inj_u,
                   c->acc_mask};
   for (void* q : ptrs) if (q) hipFree(q);
   void* sr[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_tang, c->sr_t, c->sr_u, c->sr_x, c->sr_r,
@@ -479,9 +518,10 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
     HIPCHK(c, hipMemcpyAsync(c->tmp_cfg, configs, n_rows * c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     ParamSet& p = c->ps[which];
     PROPAGATE(first_layer(c, p, c->tmp_cfg, c->tmp_z1, (int)n_rows));
+    if (c->rbm) HIPCHK(c, launch_onsite(c->stream, c->tmp_cfg, p.won, (int)n_rows, c->N, c->tmp_on));
     TailArgs a = tail_args(c, which);
-    a.z1 = c->tmp_z1; a.n_rows = (int)n_rows; a.out = c->tmp_out; a.rowinfo = c->tmp_rowinfo;
-    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, false));
+    a.z1 = c->tmp_z1; a.on_base = c->tmp_on; a.n_rows = (int)n_rows; a.out = c->tmp_out; a.rowinfo = c->tmp_rowinfo;
+    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, false, c->rbm));
     HIPCHK(c, hipMemcpyAsync(host.data(), c->tmp_out, n_rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -500,10 +540,11 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   memset(&a, 0, sizeof(a));
   a.pp = c->ps[0].packed();
   a.configs = c->configs; a.z1 = c->ps[0].z1; a.logit = c->ps[0].logit;
+  a.onsite = c->ps[0].onsite; a.rbm = c->rbm ? 1 : 0;
   a.accepted = c->d_accepted;
   if (injected) { a.inj_up = c->inj_up; a.inj_dn = c->inj_dn; a.inj_u = c->inj_u; a.acc_mask = c->acc_mask; }
   if (dbg) { a.dbg_up = dbg_up; a.dbg_dn = dbg_dn; a.dbg_u = dbg_u; }
-  a.B = c->B; a.N = c->N; a.n_hidden = c->L - 1;
+  a.B = c->B; a.N = c->N; a.n_hidden = c->n_hh;
   a.chain_offset = c->d.chain_offset;
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = step0; a.n_steps = n_steps;
@@ -567,6 +608,7 @@ int vmc_debug_proposals(vmc_ctx* c, uint64_t step, int32_t* i_up, int32_t* i_dn,
 int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   CHECK_CTX(c);
   if (n_steps < 1 || !phase_cycles) return fail(c, VMC_ERR_INVALID, "bad arguments");
+  if (c->rbm) return fail(c, VMC_ERR_UNSUPPORTED, "the diagnostic sweep build exists for fully_connected only");
   PROPAGATE(ensure_packed(c, 0));
   const int grid = (c->B + 15) / 16;
   unsigned long long* d = nullptr;
@@ -577,7 +619,7 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   a.pp = c->ps[0].packed();
   a.configs = c->configs; a.z1 = c->ps[0].z1; a.logit = c->ps[0].logit;
   a.accepted = c->d_accepted; a.dbg_cycles = d; a.waves = c->sweep_waves;
-  a.B = c->B; a.N = c->N; a.n_hidden = c->L - 1; a.chain_offset = c->d.chain_offset;
+  a.B = c->B; a.N = c->N; a.n_hidden = c->n_hh; a.chain_offset = c->d.chain_offset;
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = c->step; a.n_steps = n_steps;
   c->acts_valid = false;
@@ -630,24 +672,32 @@ int vmc_last_connected_rows(vmc_ctx* c, int64_t* rows) { CHECK_CTX(c); if (!rows
 // sum_b O_k(b) -> g1, sum_b w_b O_k(b) -> g2 for the psi parameter set
 static int gradient_sums(vmc_ctx* c, const float* w) {
   ParamSet& p = c->ps[0];
-  const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->L;
+  const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, NH = c->n_hh;
   float* g1 = c->acc;
   float* g2 = c->acc + c->P;
   Timer t(c, "grad");
-  // forward with saved activations (wavefunctions.py:345-349); after a sweep launch the kernel
-  // has already left them in act[] (exact refresh of the final chains)
-  if (!c->acts_valid) HIPCHK(c, launch_relu_copy(c->stream, p.z1, c->act[0], (long long)B * Hp));
-  for (int l = 1; l < L && !c->acts_valid; ++l) {
+  // forward with saved activations (wavefunctions.py:345-349 / 418-420); after a sweep launch
+  // the kernel has already left them in act[] (exact refresh of the final chains).
+  // act[l] = relu(z_{l+1}); RBM: the last one is tanh(z_last) = d sum log cosh / d z_last
+  if (!c->acts_valid) {
+    if (c->rbm && NH == 0) HIPCHK(c, launch_tanh_copy(c->stream, p.z1, c->act[0], (long long)B * Hp));
+    else HIPCHK(c, launch_relu_copy(c->stream, p.z1, c->act[0], (long long)B * Hp));
+  }
+  for (int l = 1; l <= NH && !c->acts_valid; ++l) {
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.A = c->act[l - 1]; g.sam = Hp; g.sak = 1;
     g.B = p.theta + off_w(c, l); g.sbk = H; g.sbn = 1;
     g.M = B; g.N = H; g.K = H; g.C = c->act[l]; g.ldc = Hp;
-    g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1;
+    g.bias = p.theta + off_b(c, l); g.epilogue = (c->rbm && l == NH) ? 7 : 1; g.splitk = 1;
     HIPCHK(c, launch_gemm(c->stream, g));
   }
-  // back-propagation of d logit / d z_l: delta[L-1] = w_out (.) relu', then W_l^T chains
-  HIPCHK(c, launch_delta_out(c->stream, p.woutp, c->act[L - 1], c->delta[L - 1], B, Hp));
-  for (int l = L - 1; l > 0; --l) {
+  // back-propagation of d logit / d z_l: FC delta[NH] = w_out (.) relu'; RBM delta[NH] = tanh(z)
+  // (which IS act[NH]); then the W_l^T chain through the relu masks
+  if (c->rbm)
+    HIPCHK(c, hipMemcpyAsync(c->delta[NH], c->act[NH], (size_t)B * Hp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  else
+    HIPCHK(c, launch_delta_out(c->stream, p.woutp, c->act[NH], c->delta[NH], B, Hp));
+  for (int l = NH; l > 0; --l) {
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.A = c->delta[l]; g.sam = Hp; g.sak = 1;
     g.B = p.theta + off_w(c, l); g.sbk = 1; g.sbn = H;   // W_l^T
@@ -657,7 +707,7 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
   }
   // Every weight-gradient GEMM is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows 0..K_in-1
   // give dW, the implicit ones row gives db (b_l sits right behind w_l in theta), the unscaled
-  // product goes to g1 and the w-scaled one to g2.  All L+1 of them run as ONE batched launch
+  // product goes to g1 and the w-scaled one to g2.  All NH+2 of them run as ONE batched launch
   // (+ one reduction launch); the argument table is built once per weight vector `w`.
   const int slot = (w == c->ratio) ? 1 : 0;
   if (!c->batch_ready[slot]) {
@@ -672,14 +722,16 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
       g.splitk = c->splitk; g.workspace = c->gemm_ws + (long long)tab.size() * ws_stride;
       tab.push_back(g);
     };
-    // output layer: d logit / d w_out = a_L, d logit / d b_out = 1  (delta = 1 for every b)
-    add(c->act[L - 1], Hp, H, c->ones, 1, 0, 1, off_wout(c));
-    for (int l = L - 1; l > 0; --l) add(c->act[l - 1], Hp, H, c->delta[l], Hp, 1, H, off_w(c, l));
+    if (c->rbm)   // onsite layer: d logit / d w_on = x, d logit / d b_on = 1
+      add(c->configs, N, N, c->ones, 1, 0, 1, c->lay.off_won);
+    else          // output layer: d logit / d w_out = a_L, d logit / d b_out = 1
+      add(c->act[NH], Hp, H, c->ones, 1, 0, 1, off_wout(c));
+    for (int l = NH; l > 0; --l) add(c->act[l - 1], Hp, H, c->delta[l], Hp, 1, H, off_w(c, l));
     add(c->configs, N, N, c->delta[0], Hp, 1, H, off_w(c, 0));
     HIPCHK(c, hipMemcpy(c->d_batch[slot], tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
     c->batch_ready[slot] = true;
   }
-  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot], L + 1, N > H ? N : H, H, c->splitk));
+  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot], NH + 2, N > H ? N : H, H, c->splitk));
   return VMC_OK;
 }
 
@@ -688,7 +740,7 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
 static int sr_record(vmc_ctx* c) {
   if (c->sr_n >= c->sr_cap)
     return fail(c, VMC_ERR_STATE, "SR sample store full: vmc_sr_reserve fewer batches than accumulate calls");
-  const long long B = c->B, N = c->N, Hp = c->Hp, L = c->L, k = c->sr_n, R = (long long)c->sr_cap * B;
+  const long long B = c->B, N = c->N, Hp = c->Hp, L = c->A, k = c->sr_n, R = (long long)c->sr_cap * B;
   HIPCHK(c, hipMemcpyAsync(c->sr_cfg + k * B * N, c->configs, B * N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   // layer-major store [L][cap * B][Hp]: every layer's rows of ALL stored batches are contiguous,
   // so the CG matrix-vector product runs each GEMM once over all samples
@@ -861,13 +913,15 @@ int vmc_epoch_log_overlap(vmc_ctx* c, float beta, int64_t n_eq_steps, int32_t n_
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   CHECK_CTX(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
+  if (c->rbm && n_batches > 0)
+    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration is implemented for the fully_connected ansatz only");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_tang, c->sr_t, c->sr_ones};
   for (void* q : old) if (q) hipFree(q);
   c->sr_cfg = c->sr_act = c->sr_delta = c->sr_tang = c->sr_t = c->sr_ones = nullptr;
   c->sr_cap = 0; c->sr_n = 0; c->sr_begun = false;
   if (n_batches == 0) return VMC_OK;
-  const long long B = c->B, N = c->N, Hp = c->Hp, L = c->L, P = c->P, R = (long long)n_batches * B;
+  const long long B = c->B, N = c->N, Hp = c->Hp, L = c->A, P = c->P, R = (long long)n_batches * B;
   if (R > 0x7fffffffLL / Hp) return fail(c, VMC_ERR_UNSUPPORTED, "SR sample store too large (rows * Hp >= 2^31)");
   HIPCHK(c, dalloc(&c->sr_cfg, R * N));
   HIPCHK(c, dalloc(&c->sr_act, L * R * Hp));
@@ -888,7 +942,7 @@ int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
 
 // weighted-sum GEMM table over the rows recorded so far: u += [a_{l-1} | 1]^T [t (.) delta_l]
 static int sr_build_table(vmc_ctx* c) {
-  const long long B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->L;
+  const long long B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->A;
   const long long R = (long long)c->sr_cap * B, rows = (long long)c->sr_n * B;
   std::vector<GemmArgs> tab;
   const long long ws_stride = (long long)c->splitk * 2 * ((N > H ? N : H) + 1) * H;
@@ -938,7 +992,7 @@ int vmc_sr_begin(vmc_ctx* c, double* rr0) {
 int vmc_sr_matvec_partial(vmc_ctx* c) {
   CHECK_CTX(c);
   if (!c->sr_begun) return fail(c, VMC_ERR_STATE, "vmc_sr_begin first");
-  const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->L;
+  const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->A;
   const long long R = (long long)c->sr_cap * B;   // row stride between layers of the store
   const int rows = c->sr_n * B;                   // all recorded samples in one pass
   const float* theta = c->ps[0].theta;

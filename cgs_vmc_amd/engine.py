@@ -30,15 +30,18 @@ class VmcEngine:
 
   def __init__(self, n_sites: int, batch_size: int, num_layers: int, layer_size: int,
                nonlinearity: str = 'relu', output_activation: str = 'exp', device: int = 0,
-               chain_offset: int = 0, seed: int = 2024, stream: int = 0):
+               chain_offset: int = 0, seed: int = 2024, stream: int = 0,
+               ansatz: str = 'fully_connected'):
     self._lib = _hip.load()
     self._ctx = C.c_void_p()
     for name, act in (('nonlinearity', nonlinearity), ('output_activation', output_activation)):
       if act not in _hip.ACT_IDS:
         raise ValueError('unknown {} {!r}'.format(name, act))
+    if ansatz not in _hip.ANSATZ_IDS:
+      raise NotImplementedError('ansatz {!r} has no HIP kernels'.format(ansatz))
     desc = _hip.VmcDesc(n_sites, batch_size, num_layers, layer_size,
                         _hip.ACT_IDS[nonlinearity], _hip.ACT_IDS[output_activation], device,
-                        chain_offset, seed, stream or None)
+                        chain_offset, _hip.ANSATZ_IDS[ansatz], 0, seed, stream or None)
     rc = self._lib.vmc_create(C.byref(desc), C.byref(self._ctx))
     if rc != _hip.VMC_OK:
       msg = self._lib.vmc_last_error(None).decode()
@@ -47,7 +50,9 @@ class VmcEngine:
     self.n_sites, self.batch_size = n_sites, batch_size
     self.num_layers, self.layer_size = num_layers, layer_size
     self.chain_offset, self.seed, self.device = chain_offset, seed, device
-    self.num_params = int(self._lib.vmc_num_params(n_sites, layer_size, num_layers))
+    self.ansatz = ansatz
+    self.num_params = int(self._lib.vmc_num_params_ansatz(_hip.ANSATZ_IDS[ansatz], n_sites,
+                                                          layer_size, num_layers))
     self.n_bonds = 0
 
   # ------------------------------------------------------------------ plumbing

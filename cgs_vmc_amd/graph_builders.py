@@ -88,11 +88,13 @@ class ConfigsVariable:
           num_layers=wavefunction._num_layers, layer_size=wavefunction._layer_size,
           nonlinearity=wavefunction._nonlinearity.name,
           output_activation=wavefunction._output_activation.name,
-          device=parallel.local_rank(), chain_offset=self.chain_offset, seed=seed)
+          device=parallel.local_rank(), chain_offset=self.chain_offset, seed=seed,
+          ansatz=wavefunction._ansatz)
       self._engine.set_configs(self._host_value)
     else:
       e = self._engine
-      if (e.num_layers, e.layer_size) != (wavefunction._num_layers, wavefunction._layer_size):
+      if (e.ansatz, e.num_layers, e.layer_size) != (
+          wavefunction._ansatz, wavefunction._num_layers, wavefunction._layer_size):
         raise ValueError('a CONFIGS variable serves one ansatz shape (psi and its deep copy)')
     return self._engine
 

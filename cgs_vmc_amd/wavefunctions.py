@@ -146,6 +146,7 @@ def module_transfer_ops(source_module: Wavefunction, target_module: Wavefunction
 class FullyConnectedNetwork(Wavefunction):
   """[Linear(layer_size), nonlinearity] x num_layers -> Linear(1) -> squeeze ->
   (- exp_norm_shift) -> exp   (wavefunctions.py:328-388)."""
+  _ansatz = 'fully_connected'     # engine kernel family (include/cgsvmc.h VMC_ANSATZ_*)
 
   def __init__(self, num_layers: int, layer_size: int,
                nonlinearity=layers.NONLINEARITIES['relu'],
@@ -319,6 +320,50 @@ class FullyConnectedNetwork(Wavefunction):
     return cls(**fcnn_params)
 
 
+class RestrictedBoltzmannNetwork(FullyConnectedNetwork):
+  """Extended restricted Boltzmann machine (wavefunctions.py:391-452):
+  psi = exp(onsite(x) + sum_h log cosh(Linear(H)([Linear(H), nonlinearity] x num_layers (x)))_h
+            - exp_norm_shift),  onsite = Linear(1).
+  num_layers = 0 is the classic RBM.  Same engine, same kernels as the fully-connected ansatz
+  with a log-cosh output epilogue and the rank-2 onsite update (csrc/mlp.hip, RBM variants)."""
+  _ansatz = 'rbm'
+
+  def __init__(self, num_layers: int, layer_size: int,
+               nonlinearity=layers.NONLINEARITIES['relu'],
+               name: str = 'restricted_boltzmann_network'):
+    super(RestrictedBoltzmannNetwork, self).__init__(
+        num_layers=num_layers, layer_size=layer_size, nonlinearity=nonlinearity,
+        output_activation=layers.NONLINEARITIES['exp'], name=name)
+
+  def _shapes(self):
+    """Creation order of the snt.Linear variables: Sonnet v1 creates them when a module is first
+    connected, and _build (wavefunctions.py:436-437) connects the onsite layer -- the LAST
+    module constructed, hence `linear_{num_layers+1}` -- before the Sequential."""
+    n, h, L = self._n_sites, self._layer_size, self._num_layers
+    u = self._unique_name
+    names = ['%s/linear_%d/w' % (u, L + 1), '%s/linear_%d/b' % (u, L + 1)]
+    shapes = [(n, 1), (1,)]
+    fan_in = n
+    for l in range(L + 1):
+      lin = 'linear' if l == 0 else 'linear_%d' % l
+      names += ['%s/%s/w' % (u, lin), '%s/%s/b' % (u, lin)]
+      shapes += [(fan_in, h), (h,)]
+      fan_in = h
+    return names, shapes
+
+  @classmethod
+  def from_hparams(cls, hparams, name: str = '') -> 'Wavefunction':
+    """wavefunctions.py:440-452."""
+    rbm_params = {
+        'num_layers': hparams.num_fc_layers,
+        'layer_size': hparams.fc_layer_size,
+        'nonlinearity': layers.NONLINEARITIES[hparams.nonlinearity],
+    }
+    if name:
+      rbm_params['name'] = name
+    return cls(**rbm_params)
+
+
 class AmplitudeTensor(session_lib.Tensor):
   """psi = wavefunction(inputs); evaluates to a float32 array [rows]."""
 
@@ -343,7 +388,7 @@ class _OutOfScope(Wavefunction):
   def from_hparams(cls, hparams, name: str = ''):
     raise NotImplementedError(
         "wavefunction_type '%s' is outside the MI355X hot path (SURVEY.md 2); only "
-        "'fully_connected' has HIP kernels" % cls._kind)
+        "'fully_connected' and 'rbm' have HIP kernels" % cls._kind)
 
 
 def _stub(kind):
@@ -362,7 +407,7 @@ def build_wavefunction(hparams) -> Wavefunction:
 
 WAVEFUNCTION_TYPES = {
     'fully_connected': FullyConnectedNetwork,
-    'rbm': _stub('rbm'),
+    'rbm': RestrictedBoltzmannNetwork,
     'conv_1d': _stub('conv_1d'),
     'conv_2d': _stub('conv_2d'),
     'mps': _stub('mps'),

@@ -17,6 +17,10 @@
  * variables of FullyConnectedNetwork, wavefunctions.py:345-349):
  *   w_1[N,H] b_1[H] w_2[H,H] b_2[H] ... w_L[H,H] b_L[H] w_out[H,1] b_out[1],
  * every matrix row-major w[in][out]; P = N*H + H + (L-1)*(H*H + H) + H + 1 floats.
+ * RestrictedBoltzmannNetwork (wavefunctions.py:391-452; Sonnet creates the variables when the
+ * module is first connected, so the onsite layer of _build line 436 comes first):
+ *   w_on[N,1] b_on[1] w_1[N,H] b_1[H] w_2[H,H] b_2[H] ... w_{L+1}[H,H] b_{L+1}[H],
+ * P = N + 1 + N*H + H + L*(H*H + H) floats (L = num_fc_layers >= 0 relu layers).
  */
 #ifndef CGSVMC_H_
 #define CGSVMC_H_
@@ -44,6 +48,9 @@ enum { VMC_PSI = 0, VMC_OMEGA = 1 };
 /* accumulate / apply modes (training.GROUND_STATE_OPTIMIZERS, training.py:913-917) */
 enum { VMC_MODE_ENERGY_GRADIENT = 0, VMC_MODE_LOG_OVERLAP_ITSWO = 1 };
 
+/* wavefunctions.WAVEFUNCTION_TYPES with kernels (wavefunctions.py:1157-1170) */
+enum { VMC_ANSATZ_FULLY_CONNECTED = 0, VMC_ANSATZ_RBM = 1 };
+
 /* layers.NONLINEARITIES ids (layers.py:13-21); only the ones with kernels are accepted */
 enum { VMC_ACT_RELU = 0, VMC_ACT_EXP = 1, VMC_ACT_IDENTITY = 6 };
 
@@ -56,12 +63,16 @@ typedef struct {
   int32_t output_activation; /* VMC_ACT_EXP                                         */
   int32_t device;            /* HIP device ordinal                                   */
   int32_t chain_offset;      /* global id of local chain 0 (multi-GPU sharding)      */
+  int32_t ansatz;            /* VMC_ANSATZ_*: hparams.wavefunction_type              */
+  int32_t reserved;          /* 0                                                    */
   uint64_t seed;             /* Philox key                                           */
   void* stream;              /* hipStream_t to launch on, or NULL for the null stream*/
 } vmc_desc;
 
 /* Number of parameters P for a given shape (no ctx needed). */
 int64_t vmc_num_params(int32_t n_sites, int32_t layer_size, int32_t num_layers);
+int64_t vmc_num_params_ansatz(int32_t ansatz, int32_t n_sites, int32_t layer_size,
+                              int32_t num_layers);
 
 /* FullyConnectedNetwork.__init__ + graph_builders.get_configs: allocates everything.
  * wavefunctions.py:331-353, graph_builders.py:92-125. */

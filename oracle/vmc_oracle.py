@@ -98,6 +98,116 @@ def init_params(n_sites, layer_size, num_layers, rng):
 
 
 # --------------------------------------------------------------------------- #
+# Ansatz: RestrictedBoltzmannNetwork (wavefunctions.py:391-452)
+# --------------------------------------------------------------------------- #
+def rbm_param_shapes(n_sites, layer_size, num_layers):
+  """Variables in creation order.  Sonnet v1 creates a Linear's variables when the module is
+  first connected; _build connects the onsite layer first (wavefunctions.py:436), then the
+  Sequential of num_layers x [Linear(H), act] + Linear(H) (wavefunctions.py:414-419)."""
+  shapes = [(n_sites, 1), (1,)]
+  fan_in = n_sites
+  for _ in range(num_layers + 1):
+    shapes += [(fan_in, layer_size), (layer_size,)]
+    fan_in = layer_size
+  return shapes
+
+
+def rbm_num_params(n_sites, layer_size, num_layers):
+  return int(sum(int(np.prod(s)) for s in rbm_param_shapes(n_sites, layer_size, num_layers)))
+
+
+def rbm_unpack(theta, n_sites, layer_size, num_layers):
+  out, off = [], 0
+  shapes = rbm_param_shapes(n_sites, layer_size, num_layers)
+  for k in range(0, len(shapes), 2):
+    ws, bs = shapes[k], shapes[k + 1]
+    nw, nb = int(np.prod(ws)), int(np.prod(bs))
+    w = theta[off:off + nw].reshape(ws); off += nw
+    b = theta[off:off + nb].reshape(bs); off += nb
+    out.append((w, b))
+  assert off == theta.size
+  return out      # [onsite, layer_1, ..., layer_{L+1}]
+
+
+def rbm_init_params(n_sites, layer_size, num_layers, rng):
+  """snt.Linear default init (see init_params)."""
+  parts = []
+  for shp in rbm_param_shapes(n_sites, layer_size, num_layers):
+    if len(shp) == 2:
+      w = rng.standard_normal(shp)
+      bad = np.abs(w) > 2
+      while bad.any():
+        w[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(w) > 2
+      parts.append((w / np.sqrt(shp[0])).ravel())
+    else:
+      parts.append(np.zeros(shp).ravel())
+  return np.concatenate(parts).astype(np.float32)
+
+
+def rbm_logit(theta, configs, layer_size, num_layers, nonlinearity='relu', dtype=np.float32,
+              return_acts=False):
+  """onsite + sum_h log(cosh(z_h)) before the exp-normalisation shift
+  (wavefunctions.py:414-420, 436-438).  log cosh is evaluated in its overflow-free form
+  |z| + log1p(exp(-2|z|)) - log 2, which equals tf.log(tf.cosh(z)) wherever that is finite."""
+  x = np.asarray(configs, dtype=dtype)
+  layers = rbm_unpack(np.asarray(theta, dtype=dtype), x.shape[1], layer_size, num_layers)
+  act = NONLINEARITIES[nonlinearity]
+  (w_on, b_on), hidden = layers[0], layers[1:]
+  onsite = (x @ w_on + b_on)[:, 0]                         # tf.squeeze(Linear(1)(inputs))
+  zs, acts = [], [x]
+  a = x
+  for (w, b) in hidden[:-1]:
+    z = a @ w + b
+    a = act(z)
+    zs.append(z); acts.append(a)
+  w, b = hidden[-1]
+  z_last = a @ w + b
+  az = np.abs(z_last)
+  logcosh = az + np.log1p(np.exp(-2 * az)) - dtype(np.log(2.0))
+  logit = onsite + logcosh.sum(1, dtype=dtype)
+  if return_acts:
+    return logit, zs, acts, z_last
+  return logit
+
+
+def rbm_psi(theta, configs, layer_size, num_layers, shift=-10.0, nonlinearity='relu',
+            output_activation='exp', dtype=np.float32):
+  """psi = exp(onsite + (sum log cosh - shift)) (wavefunctions.py:419-420, 438)."""
+  logit = rbm_logit(theta, configs, layer_size, num_layers, nonlinearity, dtype)
+  with np.errstate(over='ignore'):
+    return np.exp(logit - dtype(shift))
+
+
+def rbm_weighted_logit_grads(theta, configs, weights, layer_size, num_layers,
+                             nonlinearity='relu', dtype=np.float32):
+  """sum_b weights[b, c] * d logit_b / d theta -> [C, P] in rbm_param_shapes order."""
+  x = np.asarray(configs, dtype=dtype)
+  w_b = np.asarray(weights, dtype=dtype)
+  if w_b.ndim == 1:
+    w_b = w_b[:, None]
+  th = np.asarray(theta, dtype=dtype)
+  layers = rbm_unpack(th, x.shape[1], layer_size, num_layers)
+  hidden = layers[1:]
+  _, zs, acts, z_last = rbm_logit(th, x, layer_size, num_layers, nonlinearity, dtype, True)
+  dact = _NONLIN_DERIV[nonlinearity]
+  out = []
+  for c in range(w_b.shape[1]):
+    wc = w_b[:, c:c + 1]
+    grads = []
+    delta = np.tanh(z_last)                                # d sum log cosh / d z_last
+    for l in range(num_layers, -1, -1):
+      grads = [acts[l].T @ (delta * wc), (delta * wc).sum(0)] + grads
+      if l > 0:
+        delta = (delta @ hidden[l][0].T) * dact(zs[l - 1], acts[l])
+    grads = [x.T @ wc, wc.sum(0)] + grads                  # onsite w, b
+    out.append(np.concatenate([g.ravel() for g in grads]))
+  return np.stack(out)
+
+
+
+
+# --------------------------------------------------------------------------- #
 # Ansatz: FullyConnectedNetwork (wavefunctions.py:328-371) + exp shift (206-232)
 # --------------------------------------------------------------------------- #
 def fc_logit(theta, configs, layer_size, num_layers, nonlinearity='relu',
@@ -382,14 +492,17 @@ class Accumulators:
 
 
 def energy_gradient_accumulate(acc, theta, configs, bonds, j_x, j_z, shift,
-                               layer_size, num_layers, dtype=np.float32):
+                               layer_size, num_layers, dtype=np.float32,
+                               ansatz='fully_connected'):
   """One `accumulate_gradients` run of EnergyGradientOptimizer (training.py:539-558)."""
-  amp = lambda c: fc_psi(theta, c, layer_size, num_layers, shift, dtype=dtype)
+  psi_fn = ANSATZ[ansatz][0]
+  grads_fn = ANSATZ[ansatz][2] or weighted_logit_grads
+  amp = lambda c: psi_fn(theta, c, layer_size, num_layers, shift, dtype=dtype)
   psi = amp(configs)
   e_loc = local_value(amp, configs, bonds, j_x, j_z, psi, dtype)     # 542-543
   ones = np.ones_like(e_loc)
-  g = weighted_logit_grads(theta, configs, np.stack([ones, e_loc], 1),
-                           layer_size, num_layers, dtype=dtype)      # 545-547
+  g = grads_fn(theta, configs, np.stack([ones, e_loc], 1),
+               layer_size, num_layers, dtype=dtype)                  # 545-547
   acc.g1_total += g[0]; acc.g2_total += g[1]; acc.g_count += 1        # 550-553
   acc.e_total += e_loc.sum(dtype=dtype); acc.e_count += e_loc.size    # 555
   return e_loc
@@ -471,15 +584,18 @@ def sr_conjugate_gradient(o, e_loc, diag_shift, tol, max_iter):
 # LogOverlapImaginaryTimeSWO accumulators + gradient (training.py:652-699)
 # --------------------------------------------------------------------------- #
 def log_overlap_accumulate(acc, theta, theta_omega, configs, bonds, j_x, j_z, shift,
-                           shift_omega, beta, layer_size, num_layers, dtype=np.float32):
+                           shift_omega, beta, layer_size, num_layers, dtype=np.float32,
+                           ansatz='fully_connected'):
   """One `accumulate_gradients` run of LogOverlapImaginaryTimeSWO.
 
   The supervisor omega is a deepcopy with its OWN exp_norm_shift variable, created at
   -10 and never updated (wavefunctions.py:177-204, 209; module_transfer_ops copies
   trainables only, 300-325).
   """
-  amp = lambda c: fc_psi(theta, c, layer_size, num_layers, shift, dtype=dtype)
-  amp_w = lambda c: fc_psi(theta_omega, c, layer_size, num_layers, shift_omega, dtype=dtype)
+  psi_fn = ANSATZ[ansatz][0]
+  grads_fn = ANSATZ[ansatz][2] or weighted_logit_grads
+  amp = lambda c: psi_fn(theta, c, layer_size, num_layers, shift, dtype=dtype)
+  amp_w = lambda c: psi_fn(theta_omega, c, layer_size, num_layers, shift_omega, dtype=dtype)
   psi = amp(configs)                                                   # 661
   psi_w = amp_w(configs)                                               # 662
   h_psi_w = apply_in_place(amp_w, configs, bonds, j_x, j_z, psi_w, dtype)  # 664
@@ -487,8 +603,8 @@ def log_overlap_accumulate(acc, theta, theta_omega, configs, bonds, j_x, j_z, sh
   e_loc = h_psi_w / psi_w                                              # 667
   ratio = ite / psi                                                    # 672
   ones = np.ones_like(ratio)
-  g = weighted_logit_grads(theta, configs, np.stack([ones, ratio], 1),
-                           layer_size, num_layers, dtype=dtype)        # 674-679
+  g = grads_fn(theta, configs, np.stack([ones, ratio], 1),
+               layer_size, num_layers, dtype=dtype)                    # 674-679
   acc.g1_total += g[0]; acc.g2_total += g[1]; acc.g_count += 1
   acc.e_total += e_loc.sum(dtype=dtype); acc.e_count += e_loc.size     # 689
   acc.r_total += ratio.sum(dtype=dtype); acc.r_count += ratio.size     # 690
@@ -560,10 +676,10 @@ def torus_bonds(lx, ly, next_nearest=False):
 # Loops with the reference's call structure (used as the timed CPU baseline)
 # --------------------------------------------------------------------------- #
 def run_sweeps(theta, configs, n_steps, seed, step0, layer_size, num_layers, shift=-10.0,
-               chain_offset=0, dtype=np.float32):
+               chain_offset=0, dtype=np.float32, ansatz='fully_connected'):
   """n_steps mc_steps, one host-level call each with two forwards, as
   training.py:608-609 / evaluation.py:138-139 drive graph_builders.py:38-89."""
-  amp = lambda c: fc_psi(theta, c, layer_size, num_layers, shift, dtype=dtype)
+  amp = lambda c: ANSATZ[ansatz][0](theta, c, layer_size, num_layers, shift, dtype=dtype)
   ids = np.arange(configs.shape[0], dtype=np.uint32) + np.uint32(chain_offset)
   accepted = 0
   for t in range(n_steps):
@@ -572,3 +688,10 @@ def run_sweeps(theta, configs, n_steps, seed, step0, layer_size, num_layers, shi
     configs, acc, _ = mc_step(amp, configs, i_up, i_dn, u_acc)
     accepted += int(acc.sum())
   return configs, accepted
+
+
+# ansatz name -> (psi, logit, weighted grads, init, num_params); `ansatz=` of the functions below
+ANSATZ = {
+    'fully_connected': (fc_psi, fc_logit, None, init_params, num_params),
+    'rbm': (rbm_psi, rbm_logit, rbm_weighted_logit_grads, rbm_init_params, rbm_num_params),
+}

@@ -1,0 +1,197 @@
+"""GPU parity of the RestrictedBoltzmannNetwork ansatz (wavefunctions.py:391-452; the RBM
+variants of k_tail32 / k_tail0 / k_sweep16 and the generalised gradient chain) against the numpy
+oracle, through the C ABI.  Same tolerances as tests/test_gpu_engine.py:
+  logits 2e-5 * max(1, |logit|), local energies 2e-4 * max(1, |E|), gradient sums
+  2e-3 * ||.||_inf + 1e-4, accept masks bit-exact outside |ratio - sqrt(u)| < 1e-4 ratio.
+"""
+import numpy as np
+import pytest
+
+from oracle import vmc_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+RBM_SHAPES = [
+    # n_sites, H, num_layers (relu layers before the cosh layer), B, bonds
+    (16, 32, 2, 64, 'torus4x4'),
+    (12, 40, 0, 48, 'chain'),       # classic RBM: no H x H layer (k_tail0 / n_hidden = 0)
+    (10, 80, 1, 37, 'chain'),       # padded H, ragged batch
+    (36, 128, 1, 200, 'torus6x6'),
+    (20, 256, 2, 130, 'chain'),     # 8-wave sampler
+    (100, 256, 2, 48, 'torus10x10'),  # config-3 lattice: W1 does not fit LDS next to 2 bias rows
+]
+
+
+def _bonds(kind, n):
+  if kind == 'chain':
+    return vo.chain_bonds(n)
+  lx = int(kind[5:].split('x')[0])
+  return vo.torus_bonds(lx, n // lx)
+
+
+def _make(n, h, L, b, kind, seed=0):
+  from cgs_vmc_amd.engine import VmcEngine
+  rng = np.random.default_rng(seed)
+  theta = vo.rbm_init_params(n, h, L, rng)
+  theta += (0.05 * rng.standard_normal(theta.size)).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(seed + 1))
+  bonds = _bonds(kind, n)
+  eng = VmcEngine(n, b, L, h, seed=2024, ansatz='rbm')
+  assert eng.num_params == theta.size == vo.rbm_num_params(n, h, L)
+  eng.set_params(theta)
+  eng.set_configs(cfg)
+  eng.set_bonds(bonds, -1.0, 1.0)
+  return eng, theta, cfg, bonds
+
+
+def _close(a, b, rel, floor=1.0):
+  a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+  tol = rel * np.maximum(floor, np.abs(b))
+  bad = np.abs(a - b) > tol
+  assert not bad.any(), 'max err {} at {} (tol {})'.format(
+      np.abs(a - b).max(), np.argmax(np.abs(a - b)), tol[np.argmax(np.abs(a - b))])
+
+
+@pytest.mark.parametrize('n,h,L,b,kind', RBM_SHAPES)
+def test_rbm_amplitude_and_local_energy(n, h, L, b, kind):
+  eng, theta, cfg, bonds = _make(n, h, L, b, kind)
+  ref = vo.rbm_logit(theta, cfg, h, L, dtype=np.float64)
+  logit, psi = eng.amplitude(cfg)
+  _close(logit, ref, 2e-5)
+  _close(eng.amplitude()[0], ref, 2e-5)              # cached path
+  np.testing.assert_allclose(psi, np.exp(logit.astype(np.float32) + np.float32(10.0)), rtol=1e-6)
+  c2 = vo.random_configurations(n, 129, np.random.RandomState(9))
+  _close(eng.amplitude(c2)[0], vo.rbm_logit(theta, c2, h, L, dtype=np.float64), 2e-5)
+  amp = lambda c: vo.rbm_psi(theta, c, h, L, dtype=np.float64)
+  for jx in (-1.0, 1.0):
+    eng.set_bonds(bonds, jx, 1.0)
+    _close(eng.local_energy()[0], vo.local_value(amp, cfg, bonds, jx, 1.0, dtype=np.float64), 2e-4)
+  eng.close()
+
+
+@pytest.mark.parametrize('n,h,L,b,kind', RBM_SHAPES)
+def test_rbm_injected_mc_step_and_cache(n, h, L, b, kind):
+  eng, theta, cfg, _ = _make(n, h, L, b, kind)
+  amp = lambda c: vo.rbm_psi(theta, c, h, L, dtype=np.float64)
+  cur = cfg
+  for step in range(5):
+    u_sites, u_acc = vo.step_uniforms(99, np.arange(b), step, n)
+    i_up, i_dn = vo.propose_exchange(cur, u_sites)
+    _, acc_ref, ratios = vo.mc_step(amp, cur, i_up, i_dn, u_acc)
+    mask = eng.mc_step_injected(i_up, i_dn, u_acc)
+    band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
+    assert np.array_equal(mask[~band], acc_ref[~band])
+    expect = cur.copy()
+    rows = np.arange(b)[mask]
+    expect[rows, i_dn[mask]] = 1.0
+    expect[rows, i_up[mask]] = -1.0
+    got = eng.get_configs()
+    np.testing.assert_array_equal(got, expect)
+    cur = got
+    _close(eng.amplitude()[0], vo.rbm_logit(theta, cur, h, L, dtype=np.float64), 2e-5)
+  eng.close()
+
+
+@pytest.mark.parametrize('n,h,L,b,kind', RBM_SHAPES[:3])
+def test_rbm_sampler_trajectory_follows_oracle(n, h, L, b, kind):
+  eng, theta, cfg, bonds = _make(n, h, L, b, kind)
+  amp = lambda c: vo.rbm_psi(theta, c, h, L, dtype=np.float64)
+  cur = cfg.copy()
+  ok = np.ones(b, bool)
+  for step in range(10):
+    u_sites, u_acc = vo.step_uniforms(2024, np.arange(b), step, n)
+    i_up, i_dn = vo.propose_exchange(cur, u_sites)
+    cur, acc, ratios = vo.mc_step(amp, cur, i_up, i_dn, u_acc)
+    ok &= ~(np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30))
+  eng.mc_steps(10)                                   # one persistent launch
+  got = eng.get_configs()
+  np.testing.assert_array_equal(got[ok], cur[ok])
+  assert ok.sum() > b // 2
+  # the written-back cache (z1, onsite, logit) is exact for the final chains
+  _close(eng.amplitude()[0], vo.rbm_logit(theta, got, h, L, dtype=np.float64), 2e-5)
+  amp_e = vo.local_value(amp, got, bonds, -1.0, 1.0, dtype=np.float64)
+  _close(eng.local_energy()[0], amp_e, 2e-4)
+  eng.close()
+
+
+@pytest.mark.parametrize('n,h,L,b,kind', RBM_SHAPES)
+def test_rbm_energy_gradient_accumulators(n, h, L, b, kind):
+  from cgs_vmc_amd import _hip
+  eng, theta, cfg, bonds = _make(n, h, L, b, kind)
+  acc = vo.Accumulators(theta.size, np.float64)
+  eng.reset_accumulators()
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, h, L, np.float64,
+                                ansatz='rbm')
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)       # activations recomputed by the GEMM chain
+  # second batch: after a sweep launch the sampler hands the activations over
+  eng.mc_steps(3)
+  cur = eng.get_configs()
+  vo.energy_gradient_accumulate(acc, theta, cur, bonds, -1.0, 1.0, -10.0, h, L, np.float64,
+                                ansatz='rbm')
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  got = eng.get_accumulators()
+  p = theta.size
+  for name, g, r in (('g1', got[:p], acc.g1_total), ('g2', got[p:2 * p], acc.g2_total)):
+    tol = 2e-3 * np.abs(r).max() + 1e-4
+    assert np.abs(g - r).max() < tol, (name, np.abs(g - r).max(), tol)
+  sc = got[2 * p:]
+  assert abs(sc[0] - acc.e_total) < 2e-4 * max(1, abs(acc.e_total))
+  grad_ref = vo.energy_gradient(acc)
+  grad = eng.get_gradient(_hip.VMC_MODE_ENERGY_GRADIENT)
+  assert np.abs(grad - grad_ref).max() < 2e-3 * np.abs(grad_ref).max() + 2e-4
+  st = vo.AdamState(p)
+  th_ref = vo.adam_apply(st, theta, grad, 1e-3, 0.9, 0.99, 1e-8)
+  eng.apply_adam(_hip.VMC_MODE_ENERGY_GRADIENT, 1e-3, 0.9, 0.99, 1e-8)
+  np.testing.assert_allclose(eng.get_params(), th_ref, rtol=0, atol=2e-6)
+  _close(eng.amplitude()[0], vo.rbm_logit(eng.get_params(), cur, h, L, dtype=np.float64), 2e-5)
+  eng.close()
+
+
+def test_rbm_log_overlap_itswo_accumulators():
+  from cgs_vmc_amd import _hip
+  n, h, L, b = 16, 32, 1, 64
+  eng, theta, cfg, bonds = _make(n, h, L, b, 'torus4x4')
+  eng.transfer_params()
+  rng = np.random.default_rng(8)
+  theta2 = theta + (0.02 * rng.standard_normal(theta.size)).astype(np.float32)
+  eng.set_params(theta2)
+  eng.set_shift(-9.0)
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.log_overlap_accumulate(acc, theta2, theta, cfg, bonds, -1.0, 1.0, -9.0, -10.0, 0.12, h, L,
+                            np.float64, ansatz='rbm')
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_LOG_OVERLAP_ITSWO, 0.12)
+  grad_ref = vo.log_overlap_gradient(acc)
+  grad = eng.get_gradient(_hip.VMC_MODE_LOG_OVERLAP_ITSWO)
+  assert np.abs(grad - grad_ref).max() < 2e-3 * np.abs(grad_ref).max() + 2e-4
+  eng.close()
+
+
+def test_rbm_through_run_training_and_evaluation(tmp_path):
+  """--wavefunction_type=rbm through the run_training / run_energy_evaluation counterparts:
+  variable names follow Sonnet's (onsite layer = linear_{L+1}), the energy of the 4x4 torus
+  drops well below the Neel-state value within 150 epochs and stays variational."""
+  import os
+  from cgs_vmc_amd import lattice, run_energy_evaluation, run_training, session as session_lib
+  from cgs_vmc_amd import wavefunctions
+  session_lib.reset_default_graph()
+  wavefunctions.reset_name_scope()
+  os.environ.update(CGS_VMC_SEED='77', CGS_VMC_CONFIG_SEED='5', CGS_VMC_INIT_SEED='31')
+  d = str(tmp_path)
+  lattice.write_bonds(d, lattice.torus_bonds(4, 4))
+  hp = ('batch_size=512,fc_layer_size=32,num_fc_layers=1,num_equilibration_sweeps=10,'
+        'num_batches_per_epoch=10,learning_rates=[0.003,0.001],learning_rate_stops=[100]')
+  run_training.main(['--checkpoint_dir', d, '--num_sites', '16', '--heisenberg_jx', '-1.0',
+                     '--wavefunction_type', 'rbm', '--optimizer', 'EnergyGradient',
+                     '--num_epochs', '150', '--hparams', hp])
+  energies = [float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()]
+  tail = np.mean(energies[-10:])
+  assert -11.2285 - 0.05 < tail < -10.5, (tail, energies[::15])
+  ck = session_lib.latest_checkpoint(d)
+  names = set(np.load(ck + '.npz').files)
+  assert 'restricted_boltzmann_network/linear_2/w' in names      # onsite layer (L + 1 = 2)
+  assert 'restricted_boltzmann_network/linear/w' in names
+  session_lib.reset_default_graph()
+  wavefunctions.reset_name_scope()
+  run_energy_evaluation.main(['--checkpoint_dir', d, '--heisenberg_jx', '-1.0',
+                              '--hparams', 'num_evaluation_samples=5'])
