@@ -70,7 +70,48 @@ def build_case(name):
   return out
 
 
+RBM_CASES = {
+    # name: (n_sites, H, num_layers, B, bonds) of RestrictedBoltzmannNetwork
+    'rbm_torus4x4': (16, 32, 1, 64, vo.torus_bonds(4, 4)),
+    'rbm_classic_chain12': (12, 24, 0, 40, vo.chain_bonds(12)),   # num_layers = 0
+}
+
+
+def build_rbm_case(name):
+  """Same quantities as build_case for the rbm ansatz (tests/golden/rbm_small.npz)."""
+  n, h, L, b, bonds = RBM_CASES[name]
+  rng = np.random.default_rng({'rbm_torus4x4': 21, 'rbm_classic_chain12': 22}[name])
+  theta = vo.rbm_init_params(n, h, L, rng)
+  theta = (theta + 0.05 * rng.standard_normal(theta.size)).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(7))
+  f64 = np.float64
+  amp = lambda c: vo.rbm_psi(theta, c, h, L, dtype=f64)
+  out = dict(theta=theta, configs=cfg, bonds=np.asarray(bonds, np.int32),
+             shape=np.array([n, h, L, b]), seed=np.array([SEED]), couplings=np.array([JX, JZ, BETA]))
+  out['logit'] = vo.rbm_logit(theta, cfg, h, L, dtype=f64)
+  out['eloc'] = vo.local_value(amp, cfg, bonds, JX, JZ, dtype=f64)
+  u_sites, u_acc = vo.step_uniforms(SEED, np.arange(b), 3, n)
+  i_up, i_dn = vo.propose_exchange(cfg, u_sites)
+  _, acc, ratio = vo.mc_step(amp, cfg, i_up, i_dn, u_acc)
+  out.update(i_up=i_up.astype(np.int32), i_dn=i_dn.astype(np.int32), u_accept=u_acc, accept=acc,
+             ratio=ratio)
+  acc_eg = vo.Accumulators(theta.size, f64)
+  vo.energy_gradient_accumulate(acc_eg, theta, cfg, bonds, JX, JZ, -10.0, h, L, f64, ansatz='rbm')
+  out['eg_g1'], out['eg_g2'] = acc_eg.g1_total, acc_eg.g2_total
+  out['eg_grad'] = vo.energy_gradient(acc_eg)
+  return out
+
+
 def main():
+  rbm = {}
+  for name in RBM_CASES:
+    for k, v in build_rbm_case(name).items():
+      rbm['{}/{}'.format(name, k)] = v
+  path = os.path.join(HERE, 'rbm_small.npz')
+  np.savez_compressed(path, **rbm)
+  print('wrote', path, os.path.getsize(path), 'bytes')
+  if '--rbm-only' in sys.argv:
+    return
   data = {}
   for name in CASES:
     for k, v in build_case(name).items():

@@ -21,3 +21,15 @@ def test_oracle_reproduces_golden_file():
         np.testing.assert_allclose(g, v, rtol=1e-12, atol=1e-12, err_msg='{}/{}'.format(name, k))
       else:
         np.testing.assert_array_equal(g, v, err_msg='{}/{}'.format(name, k))
+
+
+def test_oracle_reproduces_rbm_golden_file():
+  gold = np.load(os.path.join(HERE, 'golden', 'rbm_small.npz'))
+  for name in make_golden.RBM_CASES:
+    fresh = make_golden.build_rbm_case(name)
+    for k, v in fresh.items():
+      g = gold['{}/{}'.format(name, k)]
+      if np.issubdtype(np.asarray(v).dtype, np.floating):
+        np.testing.assert_allclose(g, v, rtol=1e-12, atol=1e-12, err_msg='{}/{}'.format(name, k))
+      else:
+        np.testing.assert_array_equal(g, v, err_msg='{}/{}'.format(name, k))

@@ -91,3 +91,31 @@ def test_gradient_accumulators_and_adam(name):
   grad = eng.get_gradient(_hip.VMC_MODE_LOG_OVERLAP_ITSWO)
   assert np.abs(grad - g['it_grad']).max() < 2e-3 * np.abs(g['it_grad']).max() + 2e-4
   eng.close()
+
+
+@pytest.mark.parametrize('name', ['rbm_torus4x4', 'rbm_classic_chain12'])
+def test_rbm_golden(name):
+  from cgs_vmc_amd.engine import VmcEngine
+  gold = np.load(os.path.join(HERE, 'golden', 'rbm_small.npz'))
+  g = {k.split('/', 1)[1]: gold[k] for k in gold.files if k.startswith(name + '/')}
+  n, h, L, b = [int(x) for x in g['shape']]
+  eng = VmcEngine(n, b, L, h, seed=int(g['seed'][0]), ansatz='rbm')
+  eng.set_params(g['theta']); eng.set_configs(g['configs'])
+  jx, jz, _ = g['couplings']
+  eng.set_bonds(g['bonds'], jx, jz)
+  logit, _ = eng.amplitude()
+  assert np.abs(logit - g['logit']).max() < 2e-5 * max(1.0, np.abs(g['logit']).max())
+  eloc, _ = eng.local_energy()
+  assert np.abs(eloc - g['eloc']).max() < 2e-4 * max(1.0, np.abs(g['eloc']).max())
+  i_up, i_dn, u = eng.debug_proposals(3)
+  np.testing.assert_array_equal(i_up, g['i_up'])
+  np.testing.assert_array_equal(i_dn, g['i_dn'])
+  np.testing.assert_array_equal(u, g['u_accept'])
+  eng.reset_accumulators()
+  eng.accumulate(0)
+  grad = eng.get_gradient(0)
+  assert np.abs(grad - g['eg_grad']).max() < 2e-3 * np.abs(g['eg_grad']).max() + 2e-4
+  mask = eng.mc_step_injected(g['i_up'], g['i_dn'], g['u_accept'])
+  band = np.abs(g['ratio'] - np.sqrt(g['u_accept'].astype(np.float64))) < 1e-4 * np.maximum(g['ratio'], 1e-30)
+  np.testing.assert_array_equal(mask[~band], g['accept'][~band])
+  eng.close()

@@ -222,3 +222,50 @@ def test_mc_sampling_reproduces_exact_energy():
   szsz = (cfg[:, 0] * cfg[:, 1]).mean() / 4
   exact = sum(vec[k] ** 2 * cfgs[k, 0] * cfgs[k, 1] for k in range(len(vec))) / 4
   assert abs(szsz - exact) < 0.03
+
+
+# ------------------------------------------------------------------ RBM ansatz (wavefunctions.py:391-452)
+def test_rbm_logit_is_onsite_plus_sum_log_cosh():
+  rng = np.random.default_rng(0)
+  for (n, h, L, b) in [(8, 6, 2, 20), (8, 6, 0, 20), (10, 5, 1, 7)]:
+    th = vo.rbm_init_params(n, h, L, rng).astype(np.float64)
+    th += 0.2 * rng.standard_normal(th.size)
+    assert th.size == vo.rbm_num_params(n, h, L) == n + 1 + n * h + h + L * (h * h + h)
+    cfg = vo.random_configurations(n, b, np.random.RandomState(1)).astype(np.float64)
+    lay = vo.rbm_unpack(th, n, h, L)
+    a = cfg
+    for (w, bias) in lay[1:-1]:
+      a = np.maximum(a @ w + bias, 0)
+    z = a @ lay[-1][0] + lay[-1][1]
+    ref = (cfg @ lay[0][0] + lay[0][1])[:, 0] + np.log(np.cosh(z)).sum(1)
+    np.testing.assert_allclose(vo.rbm_logit(th, cfg, h, L, dtype=np.float64), ref, rtol=1e-13, atol=1e-13)
+    # overflow-free where log(cosh(z)) itself overflows
+    big = th.copy(); big[-h:] = 800.0
+    assert np.isfinite(vo.rbm_logit(big, cfg, h, L, dtype=np.float64)).all()
+
+
+def test_rbm_weighted_grads_match_finite_differences():
+  rng = np.random.default_rng(1)
+  for (n, h, L, b) in [(8, 6, 2, 12), (8, 6, 0, 12)]:
+    th = vo.rbm_init_params(n, h, L, rng).astype(np.float64)
+    th += 0.2 * rng.standard_normal(th.size)
+    cfg = vo.random_configurations(n, b, np.random.RandomState(2))
+    w = rng.standard_normal((b, 2))
+    g = vo.rbm_weighted_logit_grads(th, cfg, w, h, L, dtype=np.float64)
+    eps = 1e-6
+    for k in range(th.size):
+      tp = th.copy(); tp[k] += eps
+      tm = th.copy(); tm[k] -= eps
+      fd = (vo.rbm_logit(tp, cfg, h, L, dtype=np.float64)
+            - vo.rbm_logit(tm, cfg, h, L, dtype=np.float64)) / (2 * eps)
+      assert abs(fd @ w[:, 0] - g[0, k]) < 1e-7 and abs(fd @ w[:, 1] - g[1, k]) < 1e-7
+
+
+def test_rbm_zero_parameters_give_constant_psi_closed_form():
+  n, h, L, b = 16, 8, 1, 32
+  theta = np.zeros(vo.rbm_num_params(n, h, L), np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(3))
+  bonds = vo.torus_bonds(4, 4)
+  amp = lambda c: vo.rbm_psi(theta, c, h, L, dtype=np.float64)
+  np.testing.assert_allclose(vo.local_value(amp, cfg, bonds, 0.7, 1.0, dtype=np.float64),
+                             vo.constant_psi_local_energy(cfg, bonds, 0.7, 1.0), rtol=1e-12)
