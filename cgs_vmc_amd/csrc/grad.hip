@@ -19,6 +19,9 @@
 #define GT 64
 #define GK 32
 #define GLD 68
+#ifndef GEMM_DEEP_MAX_WGS
+#define GEMM_DEEP_MAX_WGS 512    // grids up to 2 workgroups per CU take the 2-stage pipeline
+#endif
 
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, int m, int n, float v) {
   float* c = C + (long long)m * g.ldc + n;
@@ -97,7 +100,35 @@ __device__ __forceinline__ TileRegs scale_tile(const TileRegs& r, const float* _
   return o;
 }
 
-template <bool DUAL>
+// kscale values of one B tile.  dfast tile: element (i, j) has k = k0 + t/16 + 16 i -> s[i];
+// kfast tile: k = k0 + 4 (t%8) + j -> s[j]
+struct ScaleRegs { f32x4 s; };
+
+__device__ __forceinline__ ScaleRegs load_scale(const float* __restrict__ ks, int k0, int kend,
+                                                bool kfast, int t) {
+  ScaleRegs o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = kfast ? k0 + 4 * (t & 7) + j : k0 + (t >> 4) + 16 * (j & 1);
+    o.s[j] = ks[k < kend ? k : kend - 1];
+  }
+  return o;
+}
+
+__device__ __forceinline__ TileRegs apply_scale(const TileRegs& r, const ScaleRegs& sc, bool kfast) {
+  TileRegs o;   // out-of-range k were loaded as 0 already
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (kfast) o.v[i] = r.v[i] * sc.s;
+    else o.v[i] = r.v[i] * sc.s[i];
+  }
+  return o;
+}
+
+// NS = register stages of the global -> LDS pipeline: 1 (lean: 5 / 3 waves per SIMD; used when
+// the grid oversubscribes the CUs, so co-resident workgroups hide the latency) or 2 (tile t+2
+// in flight while tile t is multiplied; used for small grids where nothing else can).
+template <bool DUAL, int NS>
 __device__ __forceinline__ void gemm_block(const GemmArgs& g, int bx, int by, int bz) {
   __shared__ __attribute__((aligned(16))) float As[GK][GLD];
   __shared__ __attribute__((aligned(16))) float Bs[GK][GLD];
@@ -111,34 +142,38 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, int bx, int by, in
   const int kend = min(g.K, kbeg + kc);
   const bool a_kfast = (g.sak == 1), b_kfast = (g.sbk == 1);
   const int a_extent = g.ones_row ? g.M - 1 : g.M;
-  const int ones_d = -1;
   const bool do_colsum = g.ones_row && by == 0 && tid < GT;
+  const bool scaled = g.kscale != nullptr;
   float cs = 0.f, cs2 = 0.f;
 
   f32x16 acc, acc2;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
 
-  TileRegs ra, rb;
-  if (kbeg < kend) {
-    ra = load_tile(g.A, g.sam, g.sak, a_extent, kend, m0, kbeg, a_kfast, ones_d, tid);
-    rb = load_tile(g.B, g.sbn, g.sbk, g.N, kend, n0, kbeg, b_kfast, -1, tid);
-  }
-  for (int k0 = kbeg; k0 < kend; k0 += GK) {
-    store_tile(As, ra, a_kfast, tid);
+  // Tile t+NS is requested right after tile t has gone to LDS, i.e. NS compute phases (16 MFMAs
+  // per wave each, twice that for DUAL) before it is needed.  The requests are unconditional
+  // (tile index clamped) so that vmcnt is counted exactly.
+  const int T = kbeg < kend ? (kend - kbeg + GK - 1) / GK : 0;
+  TileRegs ra[NS], rb[NS];
+  ScaleRegs rs[NS];
+  auto request = [&](int t, TileRegs& a, TileRegs& b, ScaleRegs& sc) {
+    const int k0 = kbeg + min(t, T - 1) * GK;
+    a = load_tile(g.A, g.sam, g.sak, a_extent, kend, m0, k0, a_kfast, -1, tid);
+    b = load_tile(g.B, g.sbn, g.sbk, g.N, kend, n0, k0, b_kfast, -1, tid);
+    if (scaled) sc = load_scale(g.kscale, k0, kend, b_kfast, tid);
+  };
+  auto stage = [&](int t, TileRegs& a, TileRegs& b, ScaleRegs& sc) {
+    store_tile(As, a, a_kfast, tid);
     if (DUAL) {
-      store_tile(Bs, rb, b_kfast, tid);
-      store_tile(Bs2, scale_tile(rb, g.kscale, k0, kend, b_kfast, tid), b_kfast, tid);
-    } else if (g.kscale) {
-      store_tile(Bs, scale_tile(rb, g.kscale, k0, kend, b_kfast, tid), b_kfast, tid);
+      store_tile(Bs, b, b_kfast, tid);
+      store_tile(Bs2, apply_scale(b, sc, b_kfast), b_kfast, tid);
+    } else if (scaled) {
+      store_tile(Bs, apply_scale(b, sc, b_kfast), b_kfast, tid);
     } else {
-      store_tile(Bs, rb, b_kfast, tid);
+      store_tile(Bs, b, b_kfast, tid);
     }
     __syncthreads();
-    if (k0 + GK < kend) {   // prefetch the next tile while this one is multiplied
-      ra = load_tile(g.A, g.sam, g.sak, a_extent, kend, m0, k0 + GK, a_kfast, ones_d, tid);
-      rb = load_tile(g.B, g.sbn, g.sbk, g.N, kend, n0, k0 + GK, b_kfast, -1, tid);
-    }
+    request(t + NS, a, b, sc);
     if (do_colsum) {
 #pragma unroll
       for (int kk = 0; kk < GK; ++kk) {
@@ -157,6 +192,15 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, int bx, int by, in
       }
     }
     __syncthreads();
+  };
+  if (T > 0) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) request(i, ra[i], rb[i], rs[i]);
+    for (int t = 0; t < T; t += NS) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+        if (i == 0 || t + i < T) stage(t + i, ra[i], rb[i], rs[i]);
+    }
   }
 
   const int n = n0 + wn * 32 + (lane & 31);
@@ -188,21 +232,21 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, int bx, int by, in
   }
 }
 
-template <bool DUAL>
+template <bool DUAL, int NS>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
-  gemm_block<DUAL>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+  gemm_block<DUAL, NS>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Several independent dual GEMMs (one per layer's weight gradient) in ONE launch:
 // blockIdx.z = problem * splitk + split.  With ~4 workgroups co-resident per CU the global
 // load latency of one is hidden behind the MFMAs of the others.
-template <bool DUAL>
+template <bool DUAL, int NS>
 __global__ __launch_bounds__(256) void k_gemm_batched(const GemmArgs* __restrict__ batch,
                                                       int splitk) {
   const GemmArgs g = batch[blockIdx.z / splitk];
   const int m_rows = g.ones_row ? g.M - 1 : g.M;
   if ((int)blockIdx.x * GT >= g.N || (int)blockIdx.y * GT >= m_rows) return;   // block-uniform
-  gemm_block<DUAL>(g, blockIdx.x, blockIdx.y, blockIdx.z % splitk);
+  gemm_block<DUAL, NS>(g, blockIdx.x, blockIdx.y, blockIdx.z % splitk);
 }
 
 __device__ __forceinline__ void gemm_reduce_body(const GemmArgs& g, long long start,
@@ -240,8 +284,14 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
   const int m_rows = g.ones_row ? g.M - 1 : g.M;
   const dim3 grid((g.N + GT - 1) / GT, (m_rows + GT - 1) / GT, g.splitk);
-  if (g.dual) hipLaunchKernelGGL(k_gemm<true>, grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL(k_gemm<false>, grid, dim3(256), 0, s, g);
+  const bool deep = (long long)grid.x * grid.y * grid.z <= GEMM_DEEP_MAX_WGS;
+  if (g.dual) {
+    if (deep) hipLaunchKernelGGL((k_gemm<true, 2>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm<true, 1>), grid, dim3(256), 0, s, g);
+  } else {
+    if (deep) hipLaunchKernelGGL((k_gemm<false, 2>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((k_gemm<false, 1>), grid, dim3(256), 0, s, g);
+  }
   if (g.splitk > 1) {
     const long long total = (long long)g.M * g.N * (g.dual ? 2 : 1);
     const int blocks = (int)min((total + 255) / 256, (long long)2048);
@@ -254,8 +304,14 @@ hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int cou
                                int max_n, int splitk, bool dual) {
   if (count <= 0) return hipSuccess;
   const dim3 grid((max_n + GT - 1) / GT, (max_m + GT - 1) / GT, count * splitk);
-  if (dual) hipLaunchKernelGGL(k_gemm_batched<true>, grid, dim3(256), 0, s, dev_batch, splitk);
-  else hipLaunchKernelGGL(k_gemm_batched<false>, grid, dim3(256), 0, s, dev_batch, splitk);
+  const bool deep = (long long)grid.x * grid.y * grid.z <= GEMM_DEEP_MAX_WGS;
+  if (dual) {
+    if (deep) hipLaunchKernelGGL((k_gemm_batched<true, 2>), grid, dim3(256), 0, s, dev_batch, splitk);
+    else hipLaunchKernelGGL((k_gemm_batched<true, 1>), grid, dim3(256), 0, s, dev_batch, splitk);
+  } else {
+    if (deep) hipLaunchKernelGGL((k_gemm_batched<false, 2>), grid, dim3(256), 0, s, dev_batch, splitk);
+    else hipLaunchKernelGGL((k_gemm_batched<false, 1>), grid, dim3(256), 0, s, dev_batch, splitk);
+  }
   const long long total = (dual ? 2LL : 1LL) * (max_m + 1) * max_n;
   const int blocks = (int)min((total + 255) / 256, (long long)512);
   hipLaunchKernelGGL(k_gemm_reduce_batched, dim3(blocks, count), dim3(256), 0, s, dev_batch);
