@@ -142,23 +142,28 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
   // first items of layer 0 for the wave's next tile).  Every issue is unconditional so that
   // vmcnt is counted exactly.
   constexpr int NI = 4 * HT * HT, RD = TAIL_RD;
+  static_assert(NI % RD == 0, "ring slots continue across layers only if RD divides the items per layer");
   f32x4 ring[RD];
   // uniform (SGPR) base + one 32-bit per-lane byte offset -> saddr addressing, no per-item
   // 64-bit VGPR address (LICM otherwise keeps ~100 of them live across the persistent loop)
   const unsigned lane_off = (unsigned)lane * 16u;
   const char* p32c = (const char*)a.pp.p32;   // re-made opaque every tile, see below
+  // p32c passes through an opaque asm every tile, after which the compiler no longer knows it
+  // is a GLOBAL pointer; without the address-space cast the ring becomes flat_load, whose
+  // completion order is not tracked, i.e. s_waitcnt vmcnt(0) at every use.
+  typedef const __attribute__((address_space(1))) char* gchar_p;
+  typedef const __attribute__((address_space(1))) f32x4* gf32x4_p;
   auto issue = [&](int l, int item) {
-    const char* base = p32c + ((size_t)l * Hp * Hp + (size_t)item * 256) * sizeof(float);
-    return *(const f32x4*)(base + lane_off);
+    gchar_p base = (gchar_p)p32c + ((size_t)l * Hp * Hp + (size_t)item * 256) * sizeof(float);
+    return *(gf32x4_p)(base + lane_off);
   };
 #pragma unroll
   for (int i = 0; i < RD - 1; ++i) ring[i] = issue(0, i);
 
   // row descriptor of this lane in a tile: cached z1 row of the chain + rank-2 exchange update
   // z1' = z1 + coef (W1[i] - W1[j])
-  struct Desc { const float* zb; const float* wa; const float* wb; float coef, on; int row, chain, bond; bool valid; };
-  // branch-free (every load unconditional, indices clamped): the waitcnt pass can then count
-  // vmcnt exactly, which lets the three dependent loads be issued a whole tile ahead
+  struct Desc { const float* zb; const float* wa; const float* wb; float coef, on, lbase, hjx; int row, chain, bond, valid; };
+  // (used for the first two tiles of a wave only; later descriptors are built in the loop)
   auto describe = [&](int tile) {
     Desc d;
     d.row = tile * 128 + wave * 32 + j;
@@ -174,6 +179,8 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
     d.zb = a.z1 + (long long)d.chain * Hp;
     d.on = 0.f;
     if (RBM) d.on = fmaf(d.coef, a.pp.won[ab.x] - a.pp.won[ab.y], a.on_base[d.chain]);
+    d.lbase = RATIO ? a.logit_base[d.chain] : 0.f;
+    d.hjx = RATIO ? a.half_jx[d.bond] : 0.f;
     return d;
   };
   auto finish_row = [&](const Desc& d, float part) {
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
     float logit = (h == 0 ? part + other : other + part) + bout;
     if (RBM) logit += d.on;
     if (d.valid && h == 0) {
-      if (RATIO) a.out[d.row] = a.half_jx[d.bond] * expf(logit - a.logit_base[d.chain]);
+      if (RATIO) a.out[d.row] = d.hjx * expf(logit - d.lbase);   // loaded with the descriptor
       else a.out[d.row] = logit;
     }
   };
@@ -193,6 +200,9 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
   int tile = blockIdx.x;
   if (tile * 128 + wave * 32 >= n_rows) return;   // wave-uniform; no barriers in this kernel
   Desc cur = describe(tile);
+  // descriptor of the NEXT tile; inside the loop the one after that is built in three pipelined
+  // steps spread over the last layer (straight-line code: every wait is an exact vmcnt)
+  Desc nxt_d = describe((tile + (int)gridDim.x) * 128 + wave * 32 < n_rows ? tile + (int)gridDim.x : tile);
   f32x16 in[HT];
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
@@ -215,9 +225,11 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
     int opaque0 = 0;
     asm volatile("" : "+s"(opaque0));
     asm volatile("" : "+s"(p32c));   // same for the ~100 per-item weight addresses
-    // next tile's row descriptors: three dependent loads, issued here so that their latency
-    // hides under this tile's layers
-    const Desc nxt_d = describe(has_next ? next_tile : tile);
+    // descriptor of the tile after next (rowinfo -> bond table -> W1 row pointers): built in the
+    // last layer below, one dependent step at a time
+    Desc nn_d = nxt_d;
+    int2 nn_ri = make_int2(0, 0), nn_ab = make_int2(0, 0);
+    float nn_onb = 0.f;
 
     // ---- all but the last H x H layer: in -> out -> in
     for (int l = 0; l + 1 < n_hidden; ++l) {
@@ -300,6 +312,28 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
               gy = *(const f32x4*)(nxt_d.wb + off);
             }
             const int item = (to * HT + ti) * 4 + q, nxt = item + RD - 1;
+            if (item == 0) {                      // step A: rowinfo of the tile after next
+              nn_d.row = (next_tile + (int)gridDim.x) * 128 + wave * 32 + j;
+              nn_d.valid = nn_d.row < n_rows;
+              nn_ri = a.rowinfo[nn_d.valid ? nn_d.row : n_rows - 1];
+            }
+            if (item == NI / 4) {                 // step B: chain / bond -> bond table, z1 row
+              nn_d.chain = nn_ri.x;
+              const int bs = nn_ri.y;
+              nn_d.bond = (bs > 0 ? bs : -bs) - (bs != 0 ? 1 : 0);
+              nn_d.coef = bs > 0 ? -2.f : (bs < 0 ? 2.f : 0.f);
+              nn_ab = a.bonds[nn_d.bond];
+              nn_d.zb = a.z1 + (long long)nn_d.chain * Hp;
+              if (RBM) nn_onb = a.on_base[nn_d.chain];
+              nn_d.lbase = RATIO ? a.logit_base[nn_d.chain] : 0.f;
+              nn_d.hjx = RATIO ? a.half_jx[nn_d.bond] : 0.f;
+            }
+            if (item == NI / 2) {                 // step C: W1 rows of the exchanged sites
+              nn_d.wa = a.pp.w1p + (long long)nn_ab.x * Hp;
+              nn_d.wb = a.pp.w1p + (long long)nn_ab.y * Hp;
+              nn_d.on = 0.f;
+              if (RBM) nn_d.on = fmaf(nn_d.coef, a.pp.won[nn_ab.x] - a.pp.won[nn_ab.y], nn_onb);
+            }
             if (nxt < NI) ring[nxt % RD] = issue(l, nxt);
             else ring[nxt % RD] = issue(0, nxt - NI);          // next tile's first layer
             __builtin_amdgcn_sched_barrier(0);
@@ -328,6 +362,7 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
     if (!has_next) break;
     tile = next_tile;
     cur = nxt_d;
+    nxt_d = nn_d;
     // the wave re-reads what it wrote itself (same lane, same address): no barrier needed
 #pragma unroll
     for (int t = 0; t < HT; ++t)
