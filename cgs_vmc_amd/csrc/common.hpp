@@ -148,7 +148,7 @@ struct GemmArgs {
   const float* bias;                    // epilogue 1: + bias[n] then relu
   const float* mask;  long long ldmask; // epilogue 2: * (mask[m*ldmask+n] > 0)
   int epilogue;                         // 0 none, 1 bias+relu, 2 mask, 3 accumulate (C += ), 4 bias,
-                                        // 5 mask (.) (v + bias), 6 mask (.) (C + v + bias), 7 tanh(v + bias)
+                                        // 5 mask (.) (v + bias), 6 mask (.) (C + v + bias), 7 tanh(v + bias), 8 C + v + bias
   int splitk;                           // >= 1
   float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
 };
@@ -173,6 +173,9 @@ hipError_t launch_fill(hipStream_t s, float* x, float v, long long n);
 // stochastic reconfiguration (sr.hip)
 hipError_t launch_jvp_out(hipStream_t s, const float* tang, const float* act, const float* wout,
                           const float* vout, const float* vbout, int B, int H, int Hp, float* t);
+hipError_t launch_jvp_out_rbm(hipStream_t s, const float* tang, const float* act,
+                              const float* cfg, const float* von, const float* vbon, int B, int H,
+                              int Hp, int N, float* t);
 hipError_t launch_sum_into(hipStream_t s, const float* t, int B, float* dst);
 hipError_t launch_sr_rhs(hipStream_t s, const float* acc, int P, float* x, float* r, float* p,
                          double* partial, double* sc);

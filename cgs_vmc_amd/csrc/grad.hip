@@ -19,9 +19,6 @@
 #define GT 64
 #define GK 32
 #define GLD 68
-#ifndef GEMM_DEEP_MAX_WGS
-#define GEMM_DEEP_MAX_WGS 512    // grids up to 2 workgroups per CU take the 2-stage pipeline
-#endif
 
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, int m, int n, float v) {
   float* c = C + (long long)m * g.ldc + n;
@@ -32,6 +29,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, int m
     case 4: *c = v + g.bias[n]; break;
     case 5: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? v + g.bias[n] : 0.f; break;
     case 7: *c = tanhf(v + g.bias[n]); break;
+    case 8: *c = *c + v + g.bias[n]; break;
     case 6: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? *c + v + g.bias[n] : 0.f; break;
     default: *c = v; break;
   }
@@ -125,10 +123,9 @@ __device__ __forceinline__ TileRegs apply_scale(const TileRegs& r, const ScaleRe
   return o;
 }
 
-// NS = register stages of the global -> LDS pipeline: 1 (lean: 5 / 3 waves per SIMD; used when
-// the grid oversubscribes the CUs, so co-resident workgroups hide the latency) or 2 (tile t+2
-// in flight while tile t is multiplied; used for small grids where nothing else can).
-template <bool DUAL, int NS>
+// (A second register stage -- tile t+2 in flight while tile t is multiplied -- was measured and
+// gives nothing: 19.7 vs 18.2 us on the 256-workgroup back-prop GEMMs; NS stays 1.)
+template <bool DUAL, int NS = 1>
 __device__ __forceinline__ void gemm_block(const GemmArgs& g, int bx, int by, int bz) {
   __shared__ __attribute__((aligned(16))) float As[GK][GLD];
   __shared__ __attribute__((aligned(16))) float Bs[GK][GLD];
@@ -232,7 +229,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, int bx, int by, in
   }
 }
 
-template <bool DUAL, int NS>
+template <bool DUAL, int NS = 1>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
   gemm_block<DUAL, NS>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
@@ -240,7 +237,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 // Several independent dual GEMMs (one per layer's weight gradient) in ONE launch:
 // blockIdx.z = problem * splitk + split.  With ~4 workgroups co-resident per CU the global
 // load latency of one is hidden behind the MFMAs of the others.
-template <bool DUAL, int NS>
+template <bool DUAL, int NS = 1>
 __global__ __launch_bounds__(256) void k_gemm_batched(const GemmArgs* __restrict__ batch,
                                                       int splitk) {
   const GemmArgs g = batch[blockIdx.z / splitk];
@@ -284,14 +281,8 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
   const int m_rows = g.ones_row ? g.M - 1 : g.M;
   const dim3 grid((g.N + GT - 1) / GT, (m_rows + GT - 1) / GT, g.splitk);
-  const bool deep = (long long)grid.x * grid.y * grid.z <= GEMM_DEEP_MAX_WGS;
-  if (g.dual) {
-    if (deep) hipLaunchKernelGGL((k_gemm<true, 2>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((k_gemm<true, 1>), grid, dim3(256), 0, s, g);
-  } else {
-    if (deep) hipLaunchKernelGGL((k_gemm<false, 2>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((k_gemm<false, 1>), grid, dim3(256), 0, s, g);
-  }
+  if (g.dual) hipLaunchKernelGGL((k_gemm<true>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((k_gemm<false>), grid, dim3(256), 0, s, g);
   if (g.splitk > 1) {
     const long long total = (long long)g.M * g.N * (g.dual ? 2 : 1);
     const int blocks = (int)min((total + 255) / 256, (long long)2048);
@@ -304,14 +295,8 @@ hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int cou
                                int max_n, int splitk, bool dual) {
   if (count <= 0) return hipSuccess;
   const dim3 grid((max_n + GT - 1) / GT, (max_m + GT - 1) / GT, count * splitk);
-  const bool deep = (long long)grid.x * grid.y * grid.z <= GEMM_DEEP_MAX_WGS;
-  if (dual) {
-    if (deep) hipLaunchKernelGGL((k_gemm_batched<true, 2>), grid, dim3(256), 0, s, dev_batch, splitk);
-    else hipLaunchKernelGGL((k_gemm_batched<true, 1>), grid, dim3(256), 0, s, dev_batch, splitk);
-  } else {
-    if (deep) hipLaunchKernelGGL((k_gemm_batched<false, 2>), grid, dim3(256), 0, s, dev_batch, splitk);
-    else hipLaunchKernelGGL((k_gemm_batched<false, 1>), grid, dim3(256), 0, s, dev_batch, splitk);
-  }
+  if (dual) hipLaunchKernelGGL((k_gemm_batched<true>), grid, dim3(256), 0, s, dev_batch, splitk);
+  else hipLaunchKernelGGL((k_gemm_batched<false>), grid, dim3(256), 0, s, dev_batch, splitk);
   const long long total = (dual ? 2LL : 1LL) * (max_m + 1) * max_n;
   const int blocks = (int)min((total + 255) / 256, (long long)512);
   hipLaunchKernelGGL(k_gemm_reduce_batched, dim3(blocks, count), dim3(256), 0, s, dev_batch);

@@ -54,6 +54,31 @@ hipError_t launch_jvp_out(hipStream_t s, const float* tang, const float* act, co
   return hipGetLastError();
 }
 
+// RBM: t_b = zdot_last[b] . tanh(z_last[b]) + x_b . v_on + v_bon   (act holds tanh(z_last))
+__global__ __launch_bounds__(256) void k_jvp_out_rbm(const float* __restrict__ tang,
+                                                     const float* __restrict__ act,
+                                                     const float* __restrict__ cfg,
+                                                     const float* __restrict__ von,
+                                                     const float* __restrict__ vbon, int B, int H,
+                                                     int Hp, int N, float* __restrict__ t) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float s = 0.f;
+  for (int h = lane; h < H; h += 64) s = fmaf(tang[(long long)b * Hp + h], act[(long long)b * Hp + h], s);
+  for (int n = lane; n < N; n += 64) s = fmaf(cfg[(long long)b * N + n], von[n], s);
+  s = wave_sum_f(s);
+  if (lane == 0) t[b] = s + vbon[0];
+}
+
+hipError_t launch_jvp_out_rbm(hipStream_t s, const float* tang, const float* act,
+                              const float* cfg, const float* von, const float* vbon, int B, int H,
+                              int Hp, int N, float* t) {
+  hipLaunchKernelGGL(k_jvp_out_rbm, dim3((B + 3) / 4), dim3(256), 0, s, tang, act, cfg, von, vbon,
+                     B, H, Hp, N, t);
+  return hipGetLastError();
+}
+
 // dst[0] += sum_b t[b]  (single block, fixed order)
 __global__ __launch_bounds__(1024) void k_sum_into(const float* __restrict__ t, int B,
                                                    float* __restrict__ dst) {

@@ -913,8 +913,6 @@ int vmc_epoch_log_overlap(vmc_ctx* c, float beta, int64_t n_eq_steps, int32_t n_
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   CHECK_CTX(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
-  if (c->rbm && n_batches > 0)
-    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration is implemented for the fully_connected ansatz only");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_tang, c->sr_t, c->sr_ones};
   for (void* q : old) if (q) hipFree(q);
@@ -955,7 +953,8 @@ static int sr_build_table(vmc_ctx* c) {
     g.splitk = c->splitk; g.workspace = c->gemm_ws + (long long)tab.size() * ws_stride;
     tab.push_back(g);
   };
-  add(c->sr_act + (L - 1) * R * Hp, Hp, (int)H, c->sr_ones, 1, 0, 1, off_wout(c));
+  if (c->rbm) add(c->sr_cfg, N, (int)N, c->sr_ones, 1, 0, 1, c->lay.off_won);        // onsite layer
+  else add(c->sr_act + (L - 1) * R * Hp, Hp, (int)H, c->sr_ones, 1, 0, 1, off_wout(c));
   for (int l = (int)L - 1; l > 0; --l)
     add(c->sr_act + (l - 1) * R * Hp, Hp, (int)H, c->sr_delta + l * R * Hp, Hp, 1, (int)H, off_w(c, l));
   add(c->sr_cfg, N, (int)N, c->sr_delta, Hp, 1, (int)H, off_w(c, 0));
@@ -1000,11 +999,14 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
   Timer t(c, "sr_matvec");
   HIPCHK(c, hipMemsetAsync(c->sr_u, 0, (c->P + 1) * sizeof(float), c->stream));
   float* tang[2] = {c->sr_tang, c->sr_tang + R * Hp};
+  // RBM: the last linear layer has no relu (its output goes through log cosh), so its tangent is
+  // not masked; sr_act's last slot holds tanh(z_last) = d logit / d z_last
   {  // adot_1 = relu'(z_1) (.) (X V_1 + v_b1)
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.A = c->sr_cfg; g.sam = N; g.sak = 1; g.B = v + off_w(c, 0); g.sbk = H; g.sbn = 1;
     g.M = rows; g.N = H; g.K = N; g.C = tang[0]; g.ldc = Hp;
-    g.bias = v + off_b(c, 0); g.mask = c->sr_act; g.ldmask = Hp; g.epilogue = 5; g.splitk = 1;
+    g.bias = v + off_b(c, 0); g.mask = c->sr_act; g.ldmask = Hp;
+    g.epilogue = (c->rbm && L == 1) ? 4 : 5; g.splitk = 1;
     HIPCHK(c, launch_gemm(c->stream, g));
   }
   for (int l = 1; l < L; ++l) {  // adot_{l+1} = relu' (.) (adot_l W_l + a_l V_l + v_bl)
@@ -1015,11 +1017,16 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
     g.M = rows; g.N = H; g.K = H; g.C = dst; g.ldc = Hp; g.epilogue = 0; g.splitk = 1;
     HIPCHK(c, launch_gemm(c->stream, g));
     g.A = c->sr_act + (long long)(l - 1) * R * Hp; g.B = v + off_w(c, l);
-    g.bias = v + off_b(c, l); g.mask = c->sr_act + (long long)l * R * Hp; g.ldmask = Hp; g.epilogue = 6;
+    g.bias = v + off_b(c, l); g.mask = c->sr_act + (long long)l * R * Hp; g.ldmask = Hp;
+    g.epilogue = (c->rbm && l == L - 1) ? 8 : 6;
     HIPCHK(c, launch_gemm(c->stream, g));
   }
-  HIPCHK(c, launch_jvp_out(c->stream, tang[(L - 1) & 1], c->sr_act + (long long)(L - 1) * R * Hp,
-                           theta + off_wout(c), v + off_wout(c), v + off_bout(c), rows, H, Hp, c->sr_t));
+  if (c->rbm)
+    HIPCHK(c, launch_jvp_out_rbm(c->stream, tang[(L - 1) & 1], c->sr_act + (long long)(L - 1) * R * Hp,
+                                 c->sr_cfg, v + c->lay.off_won, v + off_bout(c), rows, H, Hp, N, c->sr_t));
+  else
+    HIPCHK(c, launch_jvp_out(c->stream, tang[(L - 1) & 1], c->sr_act + (long long)(L - 1) * R * Hp,
+                             theta + off_wout(c), v + off_wout(c), v + off_bout(c), rows, H, Hp, c->sr_t));
   HIPCHK(c, launch_sum_into(c->stream, c->sr_t, rows, c->sr_u + c->P));
   HIPCHK(c, launch_gemm_batched(c->stream, c->sr_batch, L + 1, N > H ? N : H, H, c->splitk, false));
   return VMC_OK;

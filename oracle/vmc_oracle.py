@@ -539,6 +539,14 @@ def per_sample_logit_grads(theta, configs, layer_size, num_layers, nonlinearity=
   return np.concatenate(pieces, axis=1)
 
 
+def rbm_per_sample_logit_grads(theta, configs, layer_size, num_layers, nonlinearity='relu',
+                               dtype=np.float64):
+  """O[b, k] for the rbm ansatz (one-hot weights through rbm_weighted_logit_grads; small cases)."""
+  b = np.asarray(configs).shape[0]
+  return rbm_weighted_logit_grads(theta, configs, np.eye(b, dtype=dtype), layer_size, num_layers,
+                                  nonlinearity, dtype)
+
+
 def sr_system(o, e_loc):
   """S = <O O^T> - <O><O>^T and f = <E O> - <E><O> over the samples (rows of o)."""
   o = np.asarray(o, np.float64)

@@ -174,3 +174,43 @@ def test_sr_optimizer_through_run_training(tmp_path):
   tail = np.mean(energies[-10:])
   assert abs(tail - (-11.2285)) < 0.02 * 11.2285, (tail, energies[::10])
   assert tail > -11.2285 - 0.05
+
+
+@pytest.mark.parametrize('n,h,L,b,kind,n_store', [(16, 32, 1, 64, 'torus4x4', 3),
+                                                  (12, 40, 0, 48, 'chain', 2),      # classic RBM
+                                                  (10, 24, 2, 37, 'chain', 2)])
+def test_sr_rbm_matvec_and_solution(n, h, L, b, kind, n_store):
+  """SR over the RestrictedBoltzmannNetwork: unmasked tangent of the cosh layer, tanh output
+  factor, onsite parameters."""
+  from cgs_vmc_amd.engine import VmcEngine
+  rng = np.random.default_rng(4)
+  theta = vo.rbm_init_params(n, h, L, rng)
+  theta += (0.05 * rng.standard_normal(theta.size)).astype(np.float32)
+  bonds = _bonds(kind, n)
+  eng = VmcEngine(n, b, L, h, seed=2024, ansatz='rbm')
+  eng.set_params(theta)
+  eng.set_bonds(bonds, -1.0, 1.0)
+  eng.sr_reserve(n_store)
+  eng.reset_accumulators()
+  cfgs, elocs = [], []
+  for k in range(n_store):
+    cfg = vo.random_configurations(n, b, np.random.RandomState(30 + k))
+    eng.set_configs(cfg)
+    if k == 1:
+      eng.mc_steps(2)                    # activations handed over by the sampler for this batch
+      cfg = eng.get_configs()
+    eng.accumulate(0)
+    cfgs.append(cfg)
+    elocs.append(eng.local_energy()[0])
+  o = vo.rbm_per_sample_logit_grads(theta, np.concatenate(cfgs, 0), h, L)
+  e = np.concatenate(elocs, 0).astype(np.float64)
+  s_mat, _ = vo.sr_system(o, e)
+  v = rng.standard_normal(theta.size).astype(np.float32)
+  ref = s_mat @ v.astype(np.float64) + 0.01 * v
+  got = eng.sr_debug_matvec(v, 0.01)
+  assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()
+  x_ref = vo.sr_solve(o, e, 1e-2)
+  iters, res = eng.sr_solve(1e-2, 1e-6, 2000)
+  x = eng.sr_get_solution()
+  assert res <= 1e-4 and np.abs(x - x_ref).max() <= 2e-3 * np.abs(x_ref).max(), (iters, res)
+  eng.close()
