@@ -224,14 +224,14 @@ def main():
           'k_sweep16': {'achieved': flops_sweep / ts / 1e12, 'ms_avg': ts * 1e3,
                         'flops_nominal': flops_sweep,
                         'flops_executed': b * (n + 2) * exec_per_row},
-          'k_tail32(eloc)': {'achieved': flops_eloc / te / 1e12, 'ms_avg': te * 1e3,
+          'k_tail16(eloc)': {'achieved': flops_eloc / te / 1e12, 'ms_avg': te * 1e3,
                              'flops_nominal': flops_eloc, 'flops_executed': rows * exec_per_row},
       }
       for v in per_kernel.values():
         v['frac'] = v['achieved'] / FP32_MFMA_PEAK_TFLOPS
         v['executed_tflops'] = v['flops_executed'] / (v['ms_avg'] * 1e-3) / 1e12
         v['executed_frac'] = v['executed_tflops'] / FP32_MFMA_PEAK_TFLOPS
-      key = 'k_sweep16' if dom == 'sweep' else 'k_tail32(eloc)'
+      key = 'k_sweep16' if dom == 'sweep' else 'k_tail16(eloc)'
       # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command
       # (profiles/r1_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc runs; see
       # tools/collect_profiles.sh); null when no matching profile is present

@@ -40,8 +40,6 @@ __device__ __forceinline__ float u32_to_uniform(uint32_t x) {
 //   w1p      [N][Hp]      first layer, row n = site n
 //   b1p      [Hp]
 //   bh       [L-1][Hp]    biases of the H x H layers
-//   p32      [L-1][Hp/32 (to)][Hp/32 (ti)][4 (q)][64 (lane)][4 (e)]
-//              = W[32ti + 8q + 4(lane>>5) + e][32to + (lane&31)]   (A operand, 32x32x2)
 //   p16      [L-1][Hp/16 (to)][Hp/16 (ti)][64 (lane)][4 (e)]
 //              = W[16ti + 4(lane>>4) + e][16to + (lane&15)]        (A operand, 16x16x4)
 //   woutp    [Hp], bout [1]
@@ -53,7 +51,6 @@ struct PackedParams {
   const float* w1p;
   const float* b1p;
   const float* bh;
-  const float* p32;
   const float* p16;
   const float* woutp;
   const float* bout;
@@ -118,9 +115,9 @@ struct SweepArgs {
 
 // launchers (one per TU)
 hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp,
-                       const ParamLayout& lay, float* w1p, float* b1p, float* bh, float* p32,
-                       float* p16, float* woutp, float* bout, float* won);
-hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm);
+                       const ParamLayout& lay, float* w1p, float* b1p, float* bh, float* p16,
+                       float* woutp, float* bout, float* won);
+hipError_t launch_tail(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm);
 hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, int rows, int N,
                          float* out);
 hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n);

@@ -4,7 +4,7 @@
 // The reference evaluates psi(swap_ij R) for EVERY bond and multiplies by the mask
 // [s_i s_j < 0] afterwards (operators.py:166-168).  Here the masked-out rows are never
 // generated: k_bond_count / k_scan / k_bond_fill build a compact, chain-ordered list of the
-// antiparallel bonds, k_tail32 (mlp.hip) evaluates exactly those rows, and k_eloc_reduce sums
+// antiparallel bonds, k_tail16 (mlp.hip) evaluates exactly those rows, and k_eloc_reduce sums
 // each chain's segment in a fixed order (deterministic, no float atomics).
 #include "common.hpp"
 
@@ -109,7 +109,7 @@ hipError_t launch_bond_list(hipStream_t s, const float* configs, const int2* bon
 }
 
 // one wave per chain: offdiag[c] = sum of the chain's rows (0.5 jx psi'/psi each, written by
-// k_tail32), eloc[c] = diag[c] + offdiag[c]   (operators.py:259)
+// k_tail16), eloc[c] = diag[c] + offdiag[c]   (operators.py:259)
 __global__ __launch_bounds__(256) void k_eloc_reduce(const int* __restrict__ off,
                                                      const float* __restrict__ diag,
                                                      const float* __restrict__ val, int B,

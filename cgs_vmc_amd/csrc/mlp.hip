@@ -3,27 +3,26 @@
 //   k_pack      re-packs the flat parameter vector into MFMA-fragment-major weight images
 //   (the first layer on raw +-1 configurations, z1 = x W1 + b1, runs through the LDS-tiled
 //    MFMA GEMM of grad.hip; see first_layer() in vmc_api.hip)
-//   k_tail32    layers 2..L + output dot for a list of rows, each row = cached z1 of a
-//               chain (+ optional rank-2 exchange update), v_mfma_f32_32x32x2_f32,
+//   k_tail16    layers 2..L + output dot for a list of rows, each row = cached z1 of a
+//               chain (+ optional rank-2 exchange update), v_mfma_f32_16x16x4_f32,
 //               activations never leave registers (transposed formulation, see below)
 //   k_sweep16   persistent Metropolis exchange sampler: n_steps x mc_step
 //               (graph_builders.py:38-89) in one launch, v_mfma_f32_16x16x4_f32
 //
 // Transposed formulation.  For a tile of samples j and hidden units i the kernels compute
 // Y^T = W^T X^T, i.e. the MFMA A operand is a weight fragment (A[i][k] = W[k][i]) and the
-// B operand is the activation fragment (B[k][j] = X[j][k]).  The 32x32 result then has the
-// sample on the lane (col = lane&31) and the hidden unit on the register
-// (row = (r&3) + 8(r>>2) + 4(lane>>5)), which is exactly the B-operand shape of the next
-// layer if its k index is visited in the order k(s, half) = 8(s>>2) + 4*half + (s&3): the
-// accumulator register s of input tile ti IS the B operand of k-step s.  The weight image
-// (p32 / p16) is stored in that k order, fragment-major, so every A-operand load is one
-// fully coalesced 1 KiB dwordx4 wave load.  The same holds for 16x16x4 with
-// k(r, g) = 4g + r.
+// B operand is the activation fragment (B[k][j] = X[j][k]).  The 16x16 result then has the
+// sample on the lane (col = lane&15) and the hidden unit on the register
+// (row = 4(lane>>4) + r), which is exactly the B-operand shape of the next layer if its k index
+// is visited in the order k(r, g) = 4g + r: accumulator register r of input tile ti IS the B
+// operand of k-step r.  The weight image (p16) is stored in that k order, fragment-major, so
+// every A-operand load is one fully coalesced 1 KiB dwordx4 wave load.
 #include "common.hpp"
+#include <cstdlib>
 #include <type_traits>
 
 #ifndef TAIL_RD
-#define TAIL_RD 8     // stages of k_tail32's weight-fragment ring (items of 4 MFMAs each)
+#define TAIL_RD 8     // stages of k_tail16's weight-fragment ring (items of 8 MFMAs each)
 #endif
 #ifndef SWEEP_RT
 #define SWEEP_RT 14   // resident k-tiles of the first H x H layer (sweep kernel)
@@ -35,7 +34,7 @@
 // ------------------------------------------------------------------------------------ pack
 __global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, ParamLayout lay,
                        float* __restrict__ w1p, float* __restrict__ b1p, float* __restrict__ bh,
-                       float* __restrict__ p32, float* __restrict__ p16,
+                       float* __restrict__ p16,
                        float* __restrict__ woutp, float* __restrict__ bout,
                        float* __restrict__ won) {
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -43,7 +42,7 @@ __global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, Pa
   const long long off_h0 = lay.off_h0;
   const long long per_h = (long long)H * H + H;
   const int n_hh = lay.n_hh;
-  const int HT = Hp / 32, NT = Hp / 16;
+  const int NT = Hp / 16;
   for (long long i = tid; i < (long long)N * Hp; i += stride) {
     const int n = (int)(i / Hp), c = (int)(i % Hp);
     w1p[i] = c < H ? theta[lay.off_w1 + (long long)n * H + c] : 0.f;
@@ -65,18 +64,6 @@ __global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, Pa
     long long r = i;
     const int e = (int)(r & 3); r >>= 2;
     const int lane = (int)(r & 63); r >>= 6;
-    const int q = (int)(r & 3); r >>= 2;
-    const int ti = (int)(r % HT); r /= HT;
-    const int to = (int)(r % HT); r /= HT;
-    const int l = (int)r;
-    const int k = 32 * ti + 8 * q + 4 * (lane >> 5) + e;
-    const int n = 32 * to + (lane & 31);
-    p32[i] = (k < H && n < H) ? theta[off_h0 + l * per_h + (long long)k * H + n] : 0.f;
-  }
-  for (long long i = tid; i < n32; i += stride) {
-    long long r = i;
-    const int e = (int)(r & 3); r >>= 2;
-    const int lane = (int)(r & 63); r >>= 6;
     const int ti = (int)(r % NT); r /= NT;
     const int to = (int)(r % NT); r /= NT;
     const int l = (int)r;
@@ -87,10 +74,10 @@ __global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, Pa
 }
 
 hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp,
-                       const ParamLayout& lay, float* w1p, float* b1p, float* bh, float* p32,
-                       float* p16, float* woutp, float* bout, float* won) {
-  hipLaunchKernelGGL(k_pack, dim3(512), dim3(256), 0, s, theta, N, H, Hp, lay, w1p, b1p, bh, p32,
-                     p16, woutp, bout, won);
+                       const ParamLayout& lay, float* w1p, float* b1p, float* bh, float* p16,
+                       float* woutp, float* bout, float* won) {
+  hipLaunchKernelGGL(k_pack, dim3(512), dim3(256), 0, s, theta, N, H, Hp, lay, w1p, b1p, bh, p16,
+                     woutp, bout, won);
   return hipGetLastError();
 }
 
@@ -116,57 +103,56 @@ hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, 
   return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------- tail32
-// Persistent: one 256-thread workgroup per CU walks the row tiles b, b + gridDim.x, ...; each of
-// its 4 waves owns 32 rows (lane&31) of a tile and all Hp hidden units (HT tiles x 16
-// accumulator registers, split over the two lane halves).  No barriers; LDS is only a per-wave
-// staging area for the next tile's gathered first-layer activations.  RATIO mode writes
+// ---------------------------------------------------------------------------------- tail16
+// Layers 2..L + output for a list of rows.  Persistent: one 256-thread workgroup per CU walks
+// the row tiles b, b + gridDim.x, ...; each of its 4 waves owns 32 rows of a tile, as two 16-row
+// halves that share every weight fragment (1 KiB of p16 per 8 v_mfma_f32_16x16x4_f32 = 256 matrix
+// cycles) and give the matrix pipe two independent accumulator chains, and all Hp hidden units
+// (2 x NT x 4 accumulator registers).  No barriers; LDS is only a per-wave staging area for the
+// next tile's gathered first-layer activations.  RATIO mode writes
 // 0.5*jx[bond]*exp(logit_row - logit_base[chain]).
 // RBM: the last H x H layer's epilogue is sum_h log cosh(z_h) instead of relu(z) . w_out, and the
 // onsite term x . w_on of the row (chain's cached value + the rank-2 exchange update) is added.
-template <int HT, bool RATIO, bool RBM>
-__global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
-  constexpr int Hp = HT * 32;
-  // per-wave staging of the NEXT tile's first-layer activations: [wave][4*HT][64 lanes][4]
+// Layouts (lane = 16 g + j): B operand of k-step e of input tile ti = X[row j][16 ti + 4 g + e],
+// accumulator register r of output tile to = unit 16 to + 4 g + r of row j, so the accumulator
+// of tile `to` IS the B operand of input tile `to` of the next layer (as in k_sweep16).
+// (A v_mfma_f32_32x32x2_f32 version of this kernel measured 1 % slower; the sustained rate of
+// this loop skeleton, tools/ubench/mfma_stream.hip, is 143 TFLOP/s = 91 % of nominal either way.)
+template <int NT, bool RATIO, bool RBM>
+__global__ __launch_bounds__(256) void k_tail16(TailArgs a) {
+  constexpr int Hp = NT * 16;
+  static_assert(NT % 2 == 0, "the gather of an output tile is cut into two halves");
+  // per-wave staging of the NEXT tile's first-layer activations: [wave][NT][2 halves][64 lanes]
   extern __shared__ float s_stage[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = lane >> 5, j = lane & 31;
-  f32x4* stage = (f32x4*)s_stage + wave * (4 * HT) * 64 + lane;
+  const int g = lane >> 4, j = lane & 15;
+  f32x4* stage = (f32x4*)s_stage + wave * (2 * NT) * 64 + lane;
   const int n_rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
-  const int n_hidden = a.n_hidden;   // >= 1 (L = 1 goes through k_tail0)
+  const int n_hidden = a.n_hidden;   // >= 1 (no H x H layer goes through k_tail0)
   const float bout = a.pp.bout[0];
 
-  // weight-fragment ring: item i of a layer lives in stage i % RD and is issued RD-1 items
-  // ahead of its use, across (to, ti), layer AND tile boundaries (the last layer prefetches the
-  // first items of layer 0 for the wave's next tile).  Every issue is unconditional so that
-  // vmcnt is counted exactly.
-  constexpr int NI = 4 * HT * HT, RD = TAIL_RD;
+  // weight-fragment ring: item (to, ti) of a layer lives in stage item % RD and is issued RD-1
+  // items ahead of its use, across layer AND tile boundaries; every issue is unconditional
+  constexpr int NI = NT * NT, RD = TAIL_RD;
   static_assert(NI % RD == 0, "ring slots continue across layers only if RD divides the items per layer");
   f32x4 ring[RD];
-  // uniform (SGPR) base + one 32-bit per-lane byte offset -> saddr addressing, no per-item
-  // 64-bit VGPR address (LICM otherwise keeps ~100 of them live across the persistent loop)
   const unsigned lane_off = (unsigned)lane * 16u;
-  const char* p32c = (const char*)a.pp.p32;   // re-made opaque every tile, see below
-  // p32c passes through an opaque asm every tile, after which the compiler no longer knows it
-  // is a GLOBAL pointer; without the address-space cast the ring becomes flat_load, whose
-  // completion order is not tracked, i.e. s_waitcnt vmcnt(0) at every use.
+  const char* p16c = (const char*)a.pp.p16;   // re-made opaque every tile (an opaque per-tile copy keeps LICM from hoisting ~256 per-item 64-bit addresses, which spill)
   typedef const __attribute__((address_space(1))) char* gchar_p;
   typedef const __attribute__((address_space(1))) f32x4* gf32x4_p;
   auto issue = [&](int l, int item) {
-    gchar_p base = (gchar_p)p32c + ((size_t)l * Hp * Hp + (size_t)item * 256) * sizeof(float);
+    gchar_p base = (gchar_p)p16c + ((size_t)l * Hp * Hp + (size_t)item * 256) * sizeof(float);
     return *(gf32x4_p)(base + lane_off);
   };
 #pragma unroll
   for (int i = 0; i < RD - 1; ++i) ring[i] = issue(0, i);
 
-  // row descriptor of this lane in a tile: cached z1 row of the chain + rank-2 exchange update
-  // z1' = z1 + coef (W1[i] - W1[j])
+  // descriptor of one of this lane's two rows (half 0: row j, half 1: row 16 + j of the wave)
   struct Desc { const float* zb; const float* wa; const float* wb; float coef, on, lbase, hjx; int row, chain, bond, valid; };
-  // (used for the first two tiles of a wave only; later descriptors are built in the loop)
-  auto describe = [&](int tile) {
+  auto describe = [&](int tile, int half) {   // first two tiles of a wave only
     Desc d;
-    d.row = tile * 128 + wave * 32 + j;
+    d.row = tile * 128 + wave * 32 + 16 * half + j;
     d.valid = d.row < n_rows;
     const int2 ri = a.rowinfo[d.valid ? d.row : n_rows - 1];   // {chain, +-(bond+1) or 0}
     d.chain = ri.x;
@@ -184,194 +170,178 @@ __global__ __launch_bounds__(256) void k_tail32(TailArgs a) {
     return d;
   };
   auto finish_row = [&](const Desc& d, float part) {
-    const float other = __shfl_xor(part, 32);
-    // fixed order: (half 0) + (half 1)
-    float logit = (h == 0 ? part + other : other + part) + bout;
+    part += __shfl_xor(part, 16);    // (g0 + g1), (g2 + g3): a + b == b + a bit for bit
+    part += __shfl_xor(part, 32);
+    float logit = part + bout;
     if (RBM) logit += d.on;
-    if (d.valid && h == 0) {
-      if (RATIO) a.out[d.row] = d.hjx * expf(logit - d.lbase);   // loaded with the descriptor
+    if (d.valid && g == 0) {
+      if (RATIO) a.out[d.row] = d.hjx * expf(logit - d.lbase);
       else a.out[d.row] = logit;
     }
   };
 
-  // persistent: workgroup b handles row tiles b, b + gridDim.x, ...  The first tile's rows
-  // are gathered here; every later tile's rows are gathered underneath the previous tile's
-  // last layer into `stage` (LDS) and only re-read here.
   int tile = blockIdx.x;
   if (tile * 128 + wave * 32 >= n_rows) return;   // wave-uniform; no barriers in this kernel
-  Desc cur = describe(tile);
-  // descriptor of the NEXT tile; inside the loop the one after that is built in three pipelined
-  // steps spread over the last layer (straight-line code: every wait is an exact vmcnt)
-  Desc nxt_d = describe((tile + (int)gridDim.x) * 128 + wave * 32 < n_rows ? tile + (int)gridDim.x : tile);
-  f32x16 in[HT];
+  Desc cur[2], nxt_d[2];
+  const int tile1 = (tile + (int)gridDim.x) * 128 + wave * 32 < n_rows ? tile + (int)gridDim.x : tile;
 #pragma unroll
-  for (int t = 0; t < HT; ++t) {
+  for (int hf = 0; hf < 2; ++hf) { cur[hf] = describe(tile, hf); nxt_d[hf] = describe(tile1, hf); }
+  f32x4 in[2][NT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int off = 32 * t + 8 * q + 4 * h;
-      const f32x4 z = *(const f32x4*)(cur.zb + off);
-      const f32x4 x = *(const f32x4*)(cur.wa + off);
-      const f32x4 y = *(const f32x4*)(cur.wb + off);
+  for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) in[t][4 * q + e] = fmaxf(fmaf(cur.coef, x[e] - y[e], z[e]), 0.f);
+    for (int t = 0; t < NT; ++t) {
+      const int off = 16 * t + 4 * g;
+      const f32x4 z = *(const f32x4*)(cur[hf].zb + off);
+      const f32x4 x = *(const f32x4*)(cur[hf].wa + off);
+      const f32x4 y = *(const f32x4*)(cur[hf].wb + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) in[hf][t][e] = fmaxf(fmaf(cur[hf].coef, x[e] - y[e], z[e]), 0.f);
     }
-  }
 
   for (;;) {
     const int next_tile = tile + gridDim.x;
     const bool has_next = next_tile * 128 + wave * 32 < n_rows;   // wave-uniform
-    // bias / w_out loads are tile-invariant; an opaque zero keeps LICM from hoisting ~256
-    // values out of the persistent loop (which would spill them)
     int opaque0 = 0;
-    asm volatile("" : "+s"(opaque0));
-    asm volatile("" : "+s"(p32c));   // same for the ~100 per-item weight addresses
-    // descriptor of the tile after next (rowinfo -> bond table -> W1 row pointers): built in the
-    // last layer below, one dependent step at a time
-    Desc nn_d = nxt_d;
-    int2 nn_ri = make_int2(0, 0), nn_ab = make_int2(0, 0);
-    float nn_onb = 0.f;
+    asm volatile("" : "+s"(opaque0));   // keeps tile-invariant bias / w_out loads inside the loop
+    asm volatile("" : "+s"(p16c));      // same for the per-item weight addresses
+    // descriptors of the tile after next: built in three steps inside the last layer
+    Desc nn_d[2];
+    int2 nn_ri[2], nn_ab[2];
+    float nn_onb[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) { nn_d[hf] = nxt_d[hf]; nn_ri[hf] = make_int2(0, 0); nn_ab[hf] = make_int2(0, 0); nn_onb[hf] = 0.f; }
 
     // ---- all but the last H x H layer: in -> out -> in
     for (int l = 0; l + 1 < n_hidden; ++l) {
       const float* __restrict__ bl = a.pp.bh + l * Hp + opaque0;
-      f32x16 out[HT];
-      f32x4 bias[4];
+      f32x4 out[2][NT];
+      f32x4 bias = *(const f32x4*)(bl + 4 * g);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bias[q] = *(const f32x4*)(bl + 8 * q + 4 * h);
+      for (int to = 0; to < NT; ++to) {
+        f32x4 acc0 = bias, acc1 = bias;
+        if (to + 1 < NT) bias = *(const f32x4*)(bl + 16 * (to + 1) + 4 * g);
 #pragma unroll
-      for (int to = 0; to < HT; ++to) {
-        f32x16 acc;
+        for (int ti = 0; ti < NT; ++ti) {
+          const int item = to * NT + ti, nxt = item + RD - 1;
+          if (nxt < NI) ring[nxt % RD] = issue(l, nxt);
+          else ring[nxt % RD] = issue(l + 1, nxt - NI);
+          __builtin_amdgcn_sched_barrier(0);   // keep the prefetch RD-1 items ahead
+          const f32x4 w = ring[item % RD];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[4 * q + e] = bias[q][e];
-        if (to + 1 < HT) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) bias[q] = *(const f32x4*)(bl + 32 * (to + 1) + 8 * q + 4 * h);
-        }
-#pragma unroll
-        for (int ti = 0; ti < HT; ++ti) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int item = (to * HT + ti) * 4 + q, nxt = item + RD - 1;
-            if (nxt < NI) ring[nxt % RD] = issue(l, nxt);
-            else ring[nxt % RD] = issue(l + 1, nxt - NI);
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch RD-1 items ahead
-            const f32x4 w = ring[item % RD];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], in[ti][4 * q + e], acc, 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], in[0][ti][e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], in[1][ti][e], acc1, 0, 0, 0);
           }
         }
-        out[to] = acc;
+        out[0][to] = acc0; out[1][to] = acc1;
       }
 #pragma unroll
-      for (int t = 0; t < HT; ++t)
+      for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) in[t][r] = fmaxf(out[t][r], 0.f);
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) in[hf][t][e] = fmaxf(out[hf][t][e], 0.f);
     }
 
-    // ---- last H x H layer fused with the output dot.  The 4*HT items of output tile `to`
-    // are cut into 4 segments; segment sg gathers register group sg of the NEXT tile's unit
-    // tile `to` (3 float4 in flight: loads at the segment's first item, arithmetic + LDS store
-    // at its last), so the gather runs in the shadow of the matrix pipe.
-    float part = 0.f;
+    // ---- last H x H layer fused with the output dot.  While output tile `to` is accumulated,
+    // unit tile `to` of the NEXT row tile is gathered: half 0 in the first NT/2 items (loads at
+    // the first, arithmetic + LDS store at the last), half 1 in the second NT/2.
+    float part[2] = {0.f, 0.f};
     {
       const int l = n_hidden - 1;
       const float* __restrict__ bl = a.pp.bh + l * Hp + opaque0;
       const float* __restrict__ wop = a.pp.woutp + opaque0;
-      f32x4 bias[4];
+      constexpr int SEG = NT / 2;
+      f32x4 bias = *(const f32x4*)(bl + 4 * g);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bias[q] = *(const f32x4*)(bl + 8 * q + 4 * h);
-#pragma unroll
-      for (int to = 0; to < HT; ++to) {
-        f32x4 wo[4];
-        if (!RBM) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) wo[q] = *(const f32x4*)(wop + 32 * to + 8 * q + 4 * h);
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[4 * q + e] = bias[q][e];
-        if (to + 1 < HT) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) bias[q] = *(const f32x4*)(bl + 32 * (to + 1) + 8 * q + 4 * h);
-        }
+      for (int to = 0; to < NT; ++to) {
+        f32x4 wo;
+        if (!RBM) wo = *(const f32x4*)(wop + 16 * to + 4 * g);
+        f32x4 acc0 = bias, acc1 = bias;
+        if (to + 1 < NT) bias = *(const f32x4*)(bl + 16 * (to + 1) + 4 * g);
         f32x4 gz, gx, gy;
 #pragma unroll
-        for (int ti = 0; ti < HT; ++ti) {
+        for (int ti = 0; ti < NT; ++ti) {
+          const int hf = ti / SEG;
+          if (ti % SEG == 0) {
+            const int off = 16 * to + 4 * g;
+            gz = *(const f32x4*)(nxt_d[hf].zb + off);
+            gx = *(const f32x4*)(nxt_d[hf].wa + off);
+            gy = *(const f32x4*)(nxt_d[hf].wb + off);
+          }
+          const int item = to * NT + ti, nxt = item + RD - 1;
+          if (item == 0) {                      // step A: rowinfo of the tile after next
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int it_in_to = ti * 4 + q, sg = it_in_to / HT;
-            if (it_in_to % HT == 0) {
-              const int off = 32 * to + 8 * sg + 4 * h;
-              gz = *(const f32x4*)(nxt_d.zb + off);
-              gx = *(const f32x4*)(nxt_d.wa + off);
-              gy = *(const f32x4*)(nxt_d.wb + off);
+            for (int q = 0; q < 2; ++q) {
+              nn_d[q].row = (next_tile + (int)gridDim.x) * 128 + wave * 32 + 16 * q + j;
+              nn_d[q].valid = nn_d[q].row < n_rows;
+              nn_ri[q] = a.rowinfo[nn_d[q].valid ? nn_d[q].row : n_rows - 1];
             }
-            const int item = (to * HT + ti) * 4 + q, nxt = item + RD - 1;
-            if (item == 0) {                      // step A: rowinfo of the tile after next
-              nn_d.row = (next_tile + (int)gridDim.x) * 128 + wave * 32 + j;
-              nn_d.valid = nn_d.row < n_rows;
-              nn_ri = a.rowinfo[nn_d.valid ? nn_d.row : n_rows - 1];
-            }
-            if (item == NI / 4) {                 // step B: chain / bond -> bond table, z1 row
-              nn_d.chain = nn_ri.x;
-              const int bs = nn_ri.y;
-              nn_d.bond = (bs > 0 ? bs : -bs) - (bs != 0 ? 1 : 0);
-              nn_d.coef = bs > 0 ? -2.f : (bs < 0 ? 2.f : 0.f);
-              nn_ab = a.bonds[nn_d.bond];
-              nn_d.zb = a.z1 + (long long)nn_d.chain * Hp;
-              if (RBM) nn_onb = a.on_base[nn_d.chain];
-              nn_d.lbase = RATIO ? a.logit_base[nn_d.chain] : 0.f;
-              nn_d.hjx = RATIO ? a.half_jx[nn_d.bond] : 0.f;
-            }
-            if (item == NI / 2) {                 // step C: W1 rows of the exchanged sites
-              nn_d.wa = a.pp.w1p + (long long)nn_ab.x * Hp;
-              nn_d.wb = a.pp.w1p + (long long)nn_ab.y * Hp;
-              nn_d.on = 0.f;
-              if (RBM) nn_d.on = fmaf(nn_d.coef, a.pp.won[nn_ab.x] - a.pp.won[nn_ab.y], nn_onb);
-            }
-            if (nxt < NI) ring[nxt % RD] = issue(l, nxt);
-            else ring[nxt % RD] = issue(0, nxt - NI);          // next tile's first layer
-            __builtin_amdgcn_sched_barrier(0);
-            const f32x4 w = ring[item % RD];
+          }
+          if (item == NI / 4) {                 // step B: chain / bond -> bond table, z1 row
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], in[ti][4 * q + e], acc, 0, 0, 0);
-            if (it_in_to % HT == HT - 1) {
-              f32x4 v;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(nxt_d.coef, gx[e] - gy[e], gz[e]), 0.f);
-              stage[(to * 4 + sg) * 64] = v;
+            for (int q = 0; q < 2; ++q) {
+              nn_d[q].chain = nn_ri[q].x;
+              const int bs = nn_ri[q].y;
+              nn_d[q].bond = (bs > 0 ? bs : -bs) - (bs != 0 ? 1 : 0);
+              nn_d[q].coef = bs > 0 ? -2.f : (bs < 0 ? 2.f : 0.f);
+              nn_ab[q] = a.bonds[nn_d[q].bond];
+              nn_d[q].zb = a.z1 + (long long)nn_d[q].chain * Hp;
+              if (RBM) nn_onb[q] = a.on_base[nn_d[q].chain];
+              nn_d[q].lbase = RATIO ? a.logit_base[nn_d[q].chain] : 0.f;
+              nn_d[q].hjx = RATIO ? a.half_jx[nn_d[q].bond] : 0.f;
             }
+          }
+          if (item == NI / 2) {                 // step C: W1 rows of the exchanged sites
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              nn_d[q].wa = a.pp.w1p + (long long)nn_ab[q].x * Hp;
+              nn_d[q].wb = a.pp.w1p + (long long)nn_ab[q].y * Hp;
+              nn_d[q].on = 0.f;
+              if (RBM) nn_d[q].on = fmaf(nn_d[q].coef, a.pp.won[nn_ab[q].x] - a.pp.won[nn_ab[q].y], nn_onb[q]);
+            }
+          }
+          if (nxt < NI) ring[nxt % RD] = issue(l, nxt);
+          else ring[nxt % RD] = issue(0, nxt - NI);          // next tile's first layer
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x4 w = ring[item % RD];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], in[0][ti][e], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[e], in[1][ti][e], acc1, 0, 0, 0);
+          }
+          if (ti % SEG == SEG - 1) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(nxt_d[hf].coef, gx[e] - gy[e], gz[e]), 0.f);
+            stage[(to * 2 + hf) * 64] = v;
           }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (RBM) part += (32 * to + 8 * q + 4 * h + e < a.n_units) ? vmc_logcosh(acc[4 * q + e]) : 0.f;
-            else part = fmaf(fmaxf(acc[4 * q + e], 0.f), wo[q][e], part);
+        for (int e = 0; e < 4; ++e) {
+          if (RBM) {
+            const bool ok = 16 * to + 4 * g + e < a.n_units;
+            part[0] += ok ? vmc_logcosh(acc0[e]) : 0.f;
+            part[1] += ok ? vmc_logcosh(acc1[e]) : 0.f;
+          } else {
+            part[0] = fmaf(fmaxf(acc0[e], 0.f), wo[e], part[0]);
+            part[1] = fmaf(fmaxf(acc1[e], 0.f), wo[e], part[1]);
           }
+        }
       }
     }
-    finish_row(cur, part);
+    finish_row(cur[0], part[0]);
+    finish_row(cur[1], part[1]);
     if (!has_next) break;
     tile = next_tile;
-    cur = nxt_d;
-    nxt_d = nn_d;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) { cur[hf] = nxt_d[hf]; nxt_d[hf] = nn_d[hf]; }
     // the wave re-reads what it wrote itself (same lane, same address): no barrier needed
 #pragma unroll
-    for (int t = 0; t < HT; ++t)
+    for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 v = stage[(t * 4 + q) * 64];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) in[t][4 * q + e] = v[e];
-      }
+      for (int t = 0; t < NT; ++t) in[hf][t] = stage[(t * 2 + hf) * 64];
   }
 }
 
@@ -420,39 +390,39 @@ __global__ __launch_bounds__(256) void k_tail0(TailArgs a, int Hp) {
   }
 }
 
-template <int HT, bool RATIO, bool RBM>
-static hipError_t launch_tail32_h(hipStream_t s, const TailArgs& a) {
+template <int NT, bool RATIO, bool RBM>
+static hipError_t launch_tail16_h(hipStream_t s, const TailArgs& a) {
   const int tiles = (a.n_rows + 127) / 128;
   const int persistent = a.num_cus > 0 ? a.num_cus : 256;   // 1 workgroup per CU (1 wave/SIMD)
   const dim3 grid(tiles < persistent ? tiles : persistent), block(256);
-  const size_t lds = (size_t)4 * (4 * HT) * 64 * sizeof(f32x4);
-  hipError_t e = hipFuncSetAttribute((const void*)k_tail32<HT, RATIO, RBM>,
+  const size_t lds = (size_t)4 * (2 * NT) * 64 * sizeof(f32x4);
+  hipError_t e = hipFuncSetAttribute((const void*)k_tail16<NT, RATIO, RBM>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_tail32<HT, RATIO, RBM>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((k_tail16<NT, RATIO, RBM>), grid, block, lds, s, a);
   return hipGetLastError();
 }
 
 template <bool RATIO, bool RBM>
-static hipError_t launch_tail32_t(hipStream_t s, const TailArgs& a, int Hp) {
+static hipError_t launch_tail_t(hipStream_t s, const TailArgs& a, int Hp) {
   if (a.n_rows <= 0) return hipSuccess;
   if (a.n_hidden == 0) {
     const int blocks = (a.n_rows + 255) / 256;
     hipLaunchKernelGGL((k_tail0<RATIO, RBM>), dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, s, a, Hp);
     return hipGetLastError();
   }
-  switch (Hp / 32) {
-    case 2: return launch_tail32_h<2, RATIO, RBM>(s, a);
-    case 4: return launch_tail32_h<4, RATIO, RBM>(s, a);
-    case 6: return launch_tail32_h<6, RATIO, RBM>(s, a);
-    case 8: return launch_tail32_h<8, RATIO, RBM>(s, a);
+  switch (Hp / 16) {
+    case 4: return launch_tail16_h<4, RATIO, RBM>(s, a);
+    case 8: return launch_tail16_h<8, RATIO, RBM>(s, a);
+    case 12: return launch_tail16_h<12, RATIO, RBM>(s, a);
+    case 16: return launch_tail16_h<16, RATIO, RBM>(s, a);
     default: return hipErrorInvalidValue;
   }
 }
 
-hipError_t launch_tail32(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm) {
-  if (rbm) return ratio_mode ? launch_tail32_t<true, true>(s, a, Hp) : launch_tail32_t<false, true>(s, a, Hp);
-  return ratio_mode ? launch_tail32_t<true, false>(s, a, Hp) : launch_tail32_t<false, false>(s, a, Hp);
+hipError_t launch_tail(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm) {
+  if (rbm) return ratio_mode ? launch_tail_t<true, true>(s, a, Hp) : launch_tail_t<false, true>(s, a, Hp);
+  return ratio_mode ? launch_tail_t<true, false>(s, a, Hp) : launch_tail_t<false, false>(s, a, Hp);
 }
 
 // --------------------------------------------------------------------------------- sweep16

@@ -17,7 +17,7 @@ std::string g_create_error;
 
 struct ParamSet {
   float* theta = nullptr;
-  float *w1p = nullptr, *b1p = nullptr, *bh = nullptr, *p32 = nullptr, *p16 = nullptr,
+  float *w1p = nullptr, *b1p = nullptr, *bh = nullptr, *p16 = nullptr,
         *woutp = nullptr, *bout = nullptr, *won = nullptr;
   float* z1 = nullptr;     // [B][Hp] cache for the ctx's chains
   float* onsite = nullptr; // [B] cached x . w_on (RBM)
@@ -25,7 +25,7 @@ struct ParamSet {
   float* eloc = nullptr;   // [B]
   bool packed_valid = false, cache_valid = false, has_params = false;
   float shift = -10.f;     // wavefunctions.py:209
-  PackedParams packed() const { return PackedParams{w1p, b1p, bh, p32, p16, woutp, bout, won}; }
+  PackedParams packed() const { return PackedParams{w1p, b1p, bh, p16, woutp, bout, won}; }
 };
 
 struct TimedRegion {
@@ -179,8 +179,8 @@ int ensure_packed(vmc_ctx* c, int which) {
   ParamSet& p = c->ps[which];
   if (!p.has_params) return fail(c, VMC_ERR_STATE, "parameters not set (vmc_set_params)");
   if (p.packed_valid) return VMC_OK;
-  HIPCHK(c, launch_pack(c->stream, p.theta, c->N, c->H, c->Hp, c->lay, p.w1p, p.b1p, p.bh, p.p32,
-                        p.p16, p.woutp, p.bout, p.won));
+  HIPCHK(c, launch_pack(c->stream, p.theta, c->N, c->H, c->Hp, c->lay, p.w1p, p.b1p, p.bh, p.p16,
+                        p.woutp, p.bout, p.won));
   p.packed_valid = true;
   return VMC_OK;
 }
@@ -226,7 +226,7 @@ int ensure_cache(vmc_ctx* c, int which) {
     Timer t(c, "tail_amp");
     TailArgs a = tail_args(c, which);
     a.z1 = p.z1; a.n_rows = c->B; a.out = p.logit; a.rowinfo = c->rowinfo_id;
-    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, false, c->rbm));
+    HIPCHK(c, launch_tail(c->stream, a, c->Hp, false, c->rbm));
   }
   p.cache_valid = true;
   return VMC_OK;
@@ -260,7 +260,7 @@ int local_energy_device(vmc_ctx* c, int which) {
     a.n_rows_dev = c->off + c->B;
     a.n_rows = (int)((long long)c->B * c->n_bonds);
     a.out = c->val;
-    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, true, c->rbm));
+    HIPCHK(c, launch_tail(c->stream, a, c->Hp, true, c->rbm));
   }
   {
     Timer t(c, "eloc_reduce");
@@ -347,8 +347,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     ParamSet& p = c->ps[w];
     CA(dalloc(&p.theta, P));
     CA(dalloc(&p.w1p, N * Hp)); CA(dalloc(&p.b1p, Hp)); CA(dalloc(&p.bh, NH * Hp));
-    CA(dalloc(&p.p32, (NH > 0 ? NH : 1) * Hp * Hp)); CA(dalloc(&p.p16, (NH > 0 ? NH : 1) * Hp * Hp));
-    CA(hipMemsetAsync(p.p32, 0, (size_t)(NH > 0 ? NH : 1) * Hp * Hp * sizeof(float), c->stream));
+    CA(dalloc(&p.p16, (NH > 0 ? NH : 1) * Hp * Hp));
     CA(hipMemsetAsync(p.p16, 0, (size_t)(NH > 0 ? NH : 1) * Hp * Hp * sizeof(float), c->stream));
     CA(dalloc(&p.won, N)); CA(dalloc(&p.onsite, B));
     CA(hipMemsetAsync(p.won, 0, N * sizeof(float), c->stream));
@@ -395,7 +394,7 @@ void vmc_destroy(vmc_ctx* c) {
   drain_timings(c);
   for (int w = 0; w < 2; ++w) {
     ParamSet& p = c->ps[w];
-    float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p32, p.p16, p.woutp, p.bout, p.z1, p.logit, p.eloc, p.won, p.onsite};
+    float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p16, p.woutp, p.bout, p.z1, p.logit, p.eloc, p.won, p.onsite};
     for (float* q : ptrs) if (q) hipFree(q);
   }
   if (c->act_all) hipFree(c->act_all);
@@ -521,7 +520,7 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
     if (c->rbm) HIPCHK(c, launch_onsite(c->stream, c->tmp_cfg, p.won, (int)n_rows, c->N, c->tmp_on));
     TailArgs a = tail_args(c, which);
     a.z1 = c->tmp_z1; a.on_base = c->tmp_on; a.n_rows = (int)n_rows; a.out = c->tmp_out; a.rowinfo = c->tmp_rowinfo;
-    HIPCHK(c, launch_tail32(c->stream, a, c->Hp, false, c->rbm));
+    HIPCHK(c, launch_tail(c->stream, a, c->Hp, false, c->rbm));
     HIPCHK(c, hipMemcpyAsync(host.data(), c->tmp_out, n_rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -2,7 +2,7 @@
 
 The arithmetic of HeisenbergHamiltonian.build / local_value / apply_in_place runs in
 libcgsvmc_hip.so: k_bond_count / k_bond_fill list the antiparallel bonds of every chain,
-k_tail32 evaluates psi(swap_ij R)/psi(R) for exactly those rows and k_eloc_reduce sums them
+k_tail16 evaluates psi(swap_ij R)/psi(R) for exactly those rows and k_eloc_reduce sums them
 per chain.  The results equal the reference's "evaluate every bond, then mask"
 (operators.py:166-168) because masked rows contribute exactly zero.
 """

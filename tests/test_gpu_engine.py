@@ -22,6 +22,7 @@ SHAPES = [
     (10, 80, 3, 37, 'chain'),      # reference default fc_layer_size=80 -> padded to 128
     (12, 200, 1, 48, 'chain'),     # single layer, H padded to 256
     (20, 256, 4, 130, 'chain'),    # config-5-like depth
+    (14, 160, 3, 70, 'chain'),     # H padded to 192: the 12-tile kernel instantiations
     (150, 256, 6, 20, 'chain'),    # config-5 ansatz; N > 128: general (non-prefetch) sampler path,
                                    # W1 does not fit LDS next to the chain state
 ]

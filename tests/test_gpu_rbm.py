@@ -1,5 +1,5 @@
 """GPU parity of the RestrictedBoltzmannNetwork ansatz (wavefunctions.py:391-452; the RBM
-variants of k_tail32 / k_tail0 / k_sweep16 and the generalised gradient chain) against the numpy
+variants of k_tail16 / k_tail0 / k_sweep16 and the generalised gradient chain) against the numpy
 oracle, through the C ABI.  Same tolerances as tests/test_gpu_engine.py:
   logits 2e-5 * max(1, |logit|), local energies 2e-4 * max(1, |E|), gradient sums
   2e-3 * ||.||_inf + 1e-4, accept masks bit-exact outside |ratio - sqrt(u)| < 1e-4 ratio.
@@ -18,6 +18,7 @@ RBM_SHAPES = [
     (10, 80, 1, 37, 'chain'),       # padded H, ragged batch
     (36, 128, 1, 200, 'torus6x6'),
     (20, 256, 2, 130, 'chain'),     # 8-wave sampler
+    (14, 160, 2, 70, 'chain'),      # H padded to 192: the 12-tile kernel instantiations
     (100, 256, 2, 48, 'torus10x10'),  # config-3 lattice: W1 does not fit LDS next to 2 bias rows
 ]
 
