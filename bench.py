@@ -149,6 +149,9 @@ def main():
   eng.mc_steps(10 * n, want_accepted=False)        # 10 warm-up sweeps
 
   def step():
+    # one optimizer-step slice: fresh accumulators (training.py:613 / 758), gradient accumulate,
+    # accumulator all-reduce (multi-GPU), one MC sweep
+    eng.reset_accumulators()
     eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
     # the sweep does not touch the accumulators: the RCCL all-reduce runs underneath it
     pending = parallel.allreduce_accumulators_begin(eng)
@@ -205,8 +208,9 @@ def main():
         'config': {'workload': args.workload, 'lattice': '{}x{} torus'.format(lx, ly),
                    'n_sites': n, 'n_bonds': nb, 'ansatz': 'fully_connected {}x{} relu/exp'.format(L, h),
                    'chains_per_gpu': b, 'global_chains': world * b,
-                   'step': 'accumulate_gradients (E_loc + grad sums) + 1 MC sweep'
-                           + (' + RCCL all-reduce' if world > 1 else ''),
+                   'step': 'reset + accumulate_gradients (E_loc + grad sums) + 1 MC sweep'
+                           + (' + RCCL accumulator all-reduce (overlapped with the sweep)'
+                              if world > 1 else ''),
                    'parallelism': 'chains sharded x{}'.format(world)},
         'mean_energy_per_site': mean_e / n,
         'connected_rows_last_eloc': rows,
@@ -252,7 +256,8 @@ def main():
           'traffic': traffic,
           'note': 'achieved = nominal algorithmic flops (SURVEY.md 8d) / HIP-event kernel time; '
                   'executed_* counts the flops actually issued (antiparallel bonds only, rank-2 '
-                  'first layer)',
+                  'first layer); sustained fp32-MFMA rate of the streaming loop skeleton on '
+                  'this part is 141-144 TFLOP/s (tools/ubench/mfma_stream.hip, DESIGN.md 4)',
           'per_kernel': per_kernel,
       }
     if not args.no_cpu_baseline:
