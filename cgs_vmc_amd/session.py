@@ -141,14 +141,22 @@ class Saver:
     self._kept: List[str] = []
 
   def save(self, session: Session, save_path: str) -> str:
+    """Writes `<save_path>.npz` keyed by the TF variable names, or -- with
+    CGS_VMC_CHECKPOINT_FORMAT=tf -- a TensorFlow V2 bundle (`.index` + `.data-00000-of-00001`,
+    cgs_vmc_amd/tf_checkpoint.py) that the reference's tf.train.Saver can restore."""
     del session
     arrays = {v.name: v.eval() for v in self._vars}
-    np.savez(save_path + '.npz', **arrays)
+    if os.environ.get('CGS_VMC_CHECKPOINT_FORMAT', 'npz') == 'tf':
+      from . import tf_checkpoint
+      tf_checkpoint.write_bundle(save_path, arrays)
+    else:
+      np.savez(save_path + '.npz', **arrays)
     self._kept.append(save_path)
     if self._max_to_keep and len(self._kept) > self._max_to_keep:
       old = self._kept.pop(0)
-      if os.path.exists(old + '.npz'):
-        os.remove(old + '.npz')
+      for suffix in ('.npz', '.index', '.data-00000-of-00001'):
+        if os.path.exists(old + suffix):
+          os.remove(old + suffix)
     directory = os.path.dirname(save_path)
     with open(os.path.join(directory, 'checkpoint'), 'w') as f:
       f.write('model_checkpoint_path: "%s"\n' % os.path.basename(save_path))
@@ -160,7 +168,13 @@ class Saver:
     del session
     if save_path is None:
       raise ValueError("Can't load save_path when it is None.")
-    data = np.load(save_path + '.npz')
+    if os.path.exists(save_path + '.npz'):
+      data = np.load(save_path + '.npz')
+    else:   # a checkpoint written by the reference's tf.train.Saver (run_training.py:134-146)
+      from . import tf_checkpoint
+      if not tf_checkpoint.bundle_exists(save_path):
+        raise FileNotFoundError('no checkpoint %s(.npz | .index)' % save_path)
+      data = tf_checkpoint.read_bundle(save_path)
     for v in self._vars:
       if v.name not in data:
         raise KeyError('variable %s not found in checkpoint %s' % (v.name, save_path))
@@ -179,4 +193,4 @@ def latest_checkpoint(checkpoint_dir: str) -> Optional[str]:
   path = m.group(1)
   if not os.path.isabs(path):
     path = os.path.join(checkpoint_dir, path)
-  return path if os.path.exists(path + '.npz') else None
+  return path if (os.path.exists(path + '.npz') or os.path.exists(path + '.index')) else None

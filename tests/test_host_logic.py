@@ -203,3 +203,64 @@ def test_hamiltonian_holds_per_bond_couplings():
   h = operators.HeisenbergHamiltonian([(0, 1), [1, 2]], -1.0, 1.0)
   assert h._bonds_list == [(0, 1), (1, 2)]
   np.testing.assert_array_equal(h._j_x, [-1, -1]); np.testing.assert_array_equal(h._j_z, [1, 1])
+
+
+def test_tf_v2_checkpoint_bundle_round_trip(tmp_path):
+  """cgs_vmc_amd/tf_checkpoint.py: CRC32C known answer, table framing invariants, and a
+  writer -> reader round trip with the variable names a reference checkpoint carries."""
+  import struct
+  from cgs_vmc_amd import tf_checkpoint as tfc
+  assert tfc.crc32c(b'123456789') == 0xE3069283          # RFC 3720 / Castagnoli check value
+  assert tfc.masked_crc32c(b'') == (((0 >> 15) | (0 << 17)) + 0xa282ead8) & 0xFFFFFFFF
+  rng = np.random.default_rng(0)
+  tensors = {
+      'fully_connected_network/linear/w': rng.standard_normal((16, 32)).astype(np.float32),
+      'fully_connected_network/linear/b': np.zeros(32, np.float32),
+      'fully_connected_network/linear_1/w': rng.standard_normal((32, 1)).astype(np.float32),
+      'fully_connected_network/linear_1/b': rng.standard_normal(1).astype(np.float32),
+      'num_epochs': np.array(17, np.int32),                  # scalar: empty shape
+      'beta1_power': np.array(0.5, np.float64),
+  }
+  for i in range(40):                                        # more than one restart interval
+    tensors['extra/v_%02d' % i] = rng.integers(-5, 5, (3, i + 1)).astype(np.int64)
+  prefix = str(tmp_path / 'model_prior_3_epochs')
+  tfc.write_bundle(prefix, tensors)
+  assert tfc.bundle_exists(prefix) and os.path.exists(prefix + '.data-00000-of-00001')
+  raw = open(prefix + '.index', 'rb').read()
+  assert struct.unpack('<Q', raw[-8:])[0] == 0xdb4775248b80fb57 and len(raw) > 48
+  back = tfc.read_bundle(prefix)
+  assert set(back) == set(tensors)
+  for k, v in tensors.items():
+    assert back[k].dtype == v.dtype and back[k].shape == v.shape
+    np.testing.assert_array_equal(back[k], v)
+  # corruption is detected
+  data = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read())
+  data[5] ^= 0xFF
+  open(prefix + '.data-00000-of-00001', 'wb').write(bytes(data))
+  with pytest.raises(ValueError, match='CRC32C'):
+    tfc.read_bundle(prefix)
+  assert tfc.read_bundle(prefix, verify=False).keys() == tensors.keys()
+
+
+def test_saver_restores_a_tf_bundle(tmp_path, monkeypatch):
+  """Saver.restore / latest_checkpoint accept the reference's V2 bundle next to the .npz form."""
+  from cgs_vmc_amd import session as session_lib
+  vals = {'a/w': np.arange(6, dtype=np.float32).reshape(2, 3), 'a/b': np.ones(3, np.float32)}
+  store = {k: np.zeros_like(v) for k, v in vals.items()}
+  def var(name):
+    return session_lib.Variable(name, vals[name].shape, lambda: store[name],
+                                lambda value: store.__setitem__(name, np.asarray(value, np.float32).reshape(vals[name].shape)),
+                                trainable=True)
+  variables = [var('a/w'), var('a/b')]
+  for k in vals:
+    store[k] = vals[k].copy()
+  monkeypatch.setenv('CGS_VMC_CHECKPOINT_FORMAT', 'tf')
+  saver = session_lib.Saver(variables)
+  path = saver.save(None, str(tmp_path / 'model_prior_0_epochs'))
+  assert os.path.exists(path + '.index') and not os.path.exists(path + '.npz')
+  assert session_lib.latest_checkpoint(str(tmp_path)) == path
+  for k in vals:
+    store[k] = np.zeros_like(vals[k])
+  saver.restore(None, path)
+  for k in vals:
+    np.testing.assert_array_equal(store[k], vals[k])
