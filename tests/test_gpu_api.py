@@ -314,3 +314,17 @@ def test_update_norm_keeps_psi_finite_during_training():
   psi = sess.run(wf(configs))
   assert np.isfinite(psi).all() and abs(psi.max() - 1e10) < 1e-3 * 1e10
   np.testing.assert_allclose(sess.run(ham.local_value(wf, configs)), e_before, rtol=1e-6)
+
+
+def test_rccl_single_rank_allreduce_on_library_buffer():
+  """RCCL itself on this box (1 rank): see tests/_rccl_worker.py."""
+  import socket
+  import subprocess
+  import sys
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
+             LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  p = subprocess.run([sys.executable, os.path.join(root, 'tests', '_rccl_worker.py')], env=env,
+                     stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+  assert p.returncode == 0 and b'rccl ok' in p.stdout, p.stdout.decode()[-3000:]
