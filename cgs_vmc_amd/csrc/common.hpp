@@ -122,6 +122,7 @@ hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, 
                          float* out);
 hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n);
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp);
+size_t sweep_lds_required(int N, int Hp, int n_hidden, bool rbm);
 
 // bond list / local-energy reduction (eloc.hip)
 hipError_t launch_bond_list(hipStream_t s, const float* configs, const int2* bonds,

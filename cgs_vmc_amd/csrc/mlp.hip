@@ -1043,6 +1043,11 @@ static size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool rbm) {
                                   (w1l ? N * (Hp + 4) : 0));
 }
 
+// LDS the sampler needs at least (W1 streamed from L2); vmc_create rejects shapes beyond 160 KiB
+size_t sweep_lds_required(int N, int Hp, int n_hidden, bool rbm) {
+  return sweep_lds_bytes(N, Hp, n_hidden, false, rbm);
+}
+
 template <int NT, int NW, bool RBM>
 static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
   const dim3 grid((a.B + 15) / 16), block(NW * 64);

@@ -315,8 +315,17 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     return fail(nullptr, VMC_ERR_UNSUPPORTED, "only output_activation='exp' has a HIP kernel");
   if (d->layer_size > 256)
     return fail(nullptr, VMC_ERR_UNSUPPORTED, "fc_layer_size > 256 not supported by the register-resident kernels");
-  if (d->n_sites > 2048)
-    return fail(nullptr, VMC_ERR_UNSUPPORTED, "num_sites > 2048 not supported (LDS chain state)");
+  {  // the sampler keeps 16 chains' spins, z1 and operands in LDS (160 KiB per CU)
+    const int hp = (d->layer_size + 63) / 64 * 64;
+    const int n_hh = rbm ? d->num_layers : d->num_layers - 1;
+    const size_t need = sweep_lds_required(d->n_sites, hp, n_hh, rbm);
+    if (need > 160 * 1024) {
+      char msg[200];
+      snprintf(msg, sizeof(msg), "num_sites = %d with %d hidden units needs %zu bytes of LDS for the sampler's "
+               "chain state (limit 163840)", d->n_sites, d->layer_size, need);
+      return fail(nullptr, VMC_ERR_UNSUPPORTED, msg);
+    }
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0)

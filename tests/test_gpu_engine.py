@@ -366,3 +366,23 @@ def test_edge_shapes(n, h, L, b, bonds):
   for g, r in ((a[:p], acc.g1_total), (a[p:2 * p], acc.g2_total)):
     assert np.abs(g - r).max() < 2e-3 * np.abs(r).max() + 1e-4
   eng.close()
+
+
+def test_lattice_size_limit_is_checked_at_create_and_large_lattices_run():
+  """The sampler keeps 16 chains' state in LDS: shapes beyond 160 KiB are refused at vmc_create
+  (NotImplementedError), the largest that fit run and match the oracle."""
+  from cgs_vmc_amd.engine import VmcEngine
+  with pytest.raises(NotImplementedError, match='LDS'):
+    VmcEngine(2048, 16, 3, 256)
+  n, h, L, b = 1400, 256, 3, 16              # 159 KiB of chain state
+  rng = np.random.default_rng(0)
+  theta = vo.init_params(n, h, L, rng)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(1))
+  eng = VmcEngine(n, b, L, h, seed=3)
+  eng.set_params(theta); eng.set_configs(cfg)
+  _close(eng.amplitude()[0], vo.fc_logit(theta, cfg, h, L, dtype=np.float64), 2e-5)
+  acc = eng.mc_steps(20)
+  got = eng.get_configs()
+  assert 0 <= acc <= 20 * b and (np.abs(got) == 1).all() and (got.sum(1) == cfg.sum(1)).all()
+  _close(eng.amplitude()[0], vo.fc_logit(theta, got, h, L, dtype=np.float64), 2e-5)
+  eng.close()
