@@ -42,6 +42,8 @@ __device__ __forceinline__ float u32_to_uniform(uint32_t x) {
 //   bh       [L-1][Hp]    biases of the H x H layers
 //   p16      [L-1][Hp/16 (to)][Hp/16 (ti)][64 (lane)][4 (e)]
 //              = W[16ti + 4(lane>>4) + e][16to + (lane&15)]        (A operand, 16x16x4)
+//   p16t     same shape, = W[16to + (lane&15)][16ti + 4(lane>>4) + e]: the transposed image of
+//            the back-propagation chain (k_backprop16)
 //   woutp    [Hp], bout [1]
 // RBM ansatz (RestrictedBoltzmannNetwork, wavefunctions.py:391-452): same image with one more
 // H x H layer whose output goes through log cosh instead of relu; woutp = ones, bout = the
@@ -116,7 +118,11 @@ struct SweepArgs {
 // launchers (one per TU)
 hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp,
                        const ParamLayout& lay, float* w1p, float* b1p, float* bh, float* p16,
-                       float* woutp, float* bout, float* won);
+                       float* p16t, float* woutp, float* bout, float* won);
+// d logit / d z_l of every layer: act_all / delta_all are [n_hidden + 1][B][Hp]
+hipError_t launch_backprop16(hipStream_t s, const float* act_all, float* delta_all,
+                             const float* p16t, const float* woutp, int B, int Hp, int n_hidden,
+                             bool rbm);
 hipError_t launch_tail(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm);
 hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, int rows, int N,
                          float* out);
@@ -144,8 +150,8 @@ struct GemmArgs {
   int dual;                             // compute both A B -> C and A (kscale (.) B) -> C2
   int ones_row;                         // row M-1 of A is an implicit row of ones
   const float* bias;                    // epilogue 1: + bias[n] then relu
-  const float* mask;  long long ldmask; // epilogue 2: * (mask[m*ldmask+n] > 0)
-  int epilogue;                         // 0 none, 1 bias+relu, 2 mask, 3 accumulate (C += ), 4 bias,
+  const float* mask;  long long ldmask; // epilogues 5 / 6: * (mask[m*ldmask+n] > 0)
+  int epilogue;                         // 0 none, 1 bias+relu, 3 accumulate (C += ), 4 bias,
                                         // 5 mask (.) (v + bias), 6 mask (.) (C + v + bias), 7 tanh(v + bias), 8 C + v + bias
   int splitk;                           // >= 1
   float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
@@ -157,8 +163,6 @@ hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int cou
                                int max_n, int splitk, bool dual = true);
 hipError_t launch_relu_copy(hipStream_t s, const float* z, float* a, long long n);
 hipError_t launch_tanh_copy(hipStream_t s, const float* z, float* a, long long n);
-hipError_t launch_delta_out(hipStream_t s, const float* woutp, const float* aL, float* delta,
-                            int B, int Hp);
 hipError_t launch_scalar_accum(hipStream_t s, const float* eloc, const float* ratio, int B,
                                float* acc_scalars, int mode);
 hipError_t launch_itswo_ratio(hipStream_t s, const float* logit_psi, const float* logit_omega,

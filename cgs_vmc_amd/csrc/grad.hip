@@ -1,6 +1,6 @@
 // Gradient-accumulator path: the two tf.gradients calls of training.py:545-547 / 674-679
 // (sum_b O_k(b) and sum_b w_b O_k(b), O_k = d logit / d theta_k) as an explicit
-// forward / back-prop / weight-gradient GEMM chain on fp32 MFMA, plus the accumulator,
+// forward / back-prop (k_backprop16, mlp.hip) / weight-gradient GEMM chain on fp32 MFMA, plus the accumulator,
 // ratio and Adam element-wise kernels.  All reductions are fixed-order (no float atomics).
 #include "common.hpp"
 
@@ -24,7 +24,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, int m
   float* c = C + (long long)m * g.ldc + n;
   switch (g.epilogue) {
     case 1: *c = fmaxf(v + g.bias[n], 0.f); break;
-    case 2: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? v : 0.f; break;
     case 3: *c += v; break;
     case 4: *c = v + g.bias[n]; break;
     case 5: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? v + g.bias[n] : 0.f; break;
@@ -338,23 +337,6 @@ hipError_t launch_fill(hipStream_t s, float* x, float v, long long n) {
   if (n <= 0) return hipSuccess;
   const int blocks = (int)min((n + 255) / 256, (long long)4096);
   hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, x, v, n);
-  return hipGetLastError();
-}
-
-// delta_L[b][i] = d logit_b / d z_L[b][i] = w_out[i] * relu'(z_L) (a_L > 0 <=> z_L > 0)
-__global__ void k_delta_out(const float* __restrict__ woutp, const float* __restrict__ aL,
-                            float* __restrict__ delta, int B, int Hp) {
-  const long long n = (long long)B * Hp;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x)
-    delta[i] = aL[i] > 0.f ? woutp[i % Hp] : 0.f;
-}
-
-hipError_t launch_delta_out(hipStream_t s, const float* woutp, const float* aL, float* delta,
-                            int B, int Hp) {
-  const long long n = (long long)B * Hp;
-  const int blocks = (int)min((n + 255) / 256, (long long)4096);
-  hipLaunchKernelGGL(k_delta_out, dim3(blocks), dim3(256), 0, s, woutp, aL, delta, B, Hp);
   return hipGetLastError();
 }
 

@@ -34,7 +34,7 @@
 // ------------------------------------------------------------------------------------ pack
 __global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, ParamLayout lay,
                        float* __restrict__ w1p, float* __restrict__ b1p, float* __restrict__ bh,
-                       float* __restrict__ p16,
+                       float* __restrict__ p16, float* __restrict__ p16t,
                        float* __restrict__ woutp, float* __restrict__ bout,
                        float* __restrict__ won) {
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,14 +70,16 @@ __global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, Pa
     const int k = 16 * ti + 4 * (lane >> 4) + e;
     const int n = 16 * to + (lane & 15);
     p16[i] = (k < H && n < H) ? theta[off_h0 + l * per_h + (long long)k * H + n] : 0.f;
+    // transposed image for the back-propagation chain: A[i = n][k] = W[n][k]
+    p16t[i] = (k < H && n < H) ? theta[off_h0 + l * per_h + (long long)n * H + k] : 0.f;
   }
 }
 
 hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp,
                        const ParamLayout& lay, float* w1p, float* b1p, float* bh, float* p16,
-                       float* woutp, float* bout, float* won) {
+                       float* p16t, float* woutp, float* bout, float* won) {
   hipLaunchKernelGGL(k_pack, dim3(512), dim3(256), 0, s, theta, N, H, Hp, lay, w1p, b1p, bh, p16,
-                     woutp, bout, won);
+                     p16t, woutp, bout, won);
   return hipGetLastError();
 }
 
@@ -423,6 +425,108 @@ static hipError_t launch_tail_t(hipStream_t s, const TailArgs& a, int Hp) {
 hipError_t launch_tail(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm) {
   if (rbm) return ratio_mode ? launch_tail_t<true, true>(s, a, Hp) : launch_tail_t<false, true>(s, a, Hp);
   return ratio_mode ? launch_tail_t<true, false>(s, a, Hp) : launch_tail_t<false, false>(s, a, Hp);
+}
+
+// ------------------------------------------------------------------------------- backprop16
+// d logit / d z_l for every layer (training.py:545-547 asks tf.gradients for it), 16 chains per
+// workgroup like the sampler: delta_last = w_out (.) relu'(a_last) (FC) or tanh(z_last) (RBM,
+// already in the last activation slot), then delta_{l-1} = (delta_l W_l^T) (.) relu'(a_{l-1})
+// on 16x16x4 MFMA with the transposed weight image p16t; the operand of the next layer goes
+// through LDS (one barrier per layer), the result to global memory row-major for the
+// weight-gradient GEMMs.  One pass per accumulate call: 2 x 128 MFMAs per wave at H = 256.
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict__ act_all,
+                                                        float* __restrict__ delta_all,
+                                                        const float* __restrict__ p16t,
+                                                        const float* __restrict__ woutp, int B,
+                                                        int n_hidden, int rbm) {
+  constexpr int Hp = NT * 16, TO = NT / NW, PF = 4;
+  static_assert(NT % NW == 0 && NT % PF == 0, "tiles divide over waves and the prefetch ring");
+  __shared__ __attribute__((aligned(16))) float s_x[2 * NT * 256];   // [2][NT][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, j = lane & 15;
+  const int chain = blockIdx.x * 16 + j;
+  const bool ok = chain < B;
+  const long long row = (long long)(ok ? chain : 0) * Hp;
+  const long long layer_stride = (long long)B * Hp;
+
+  // last layer's delta for this wave's own unit tiles
+  {
+    const float* a_last = act_all + n_hidden * layer_stride + row;
+    float* d_last = delta_all + n_hidden * layer_stride + row;
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+      const int t = wave * TO + to, col = 16 * t + 4 * g;
+      const f32x4 a = *(const f32x4*)(a_last + col);
+      f32x4 d;
+      if (rbm) d = a;
+      else {
+        const f32x4 w = *(const f32x4*)(woutp + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? w[e] : 0.f;
+      }
+      if (!ok) d = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok) *(f32x4*)(d_last + col) = d;
+      *(f32x4*)(s_x + (t * 64 + lane) * 4) = d;
+    }
+  }
+  int cur = 0;
+  for (int l = n_hidden; l > 0; --l) {
+    __syncthreads();
+    const f32x4* __restrict__ wp = (const f32x4*)(p16t + (long long)(l - 1) * Hp * Hp) + lane;
+    const f32x4* xin = (const f32x4*)(s_x + cur * NT * 256) + lane;
+    const float* a_prev = act_all + (l - 1) * layer_stride + row;
+    f32x4 mask[TO];
+#pragma unroll
+    for (int to = 0; to < TO; ++to) mask[to] = *(const f32x4*)(a_prev + 16 * (wave * TO + to) + 4 * g);
+    f32x4 acc[TO], wb[PF][TO];
+#pragma unroll
+    for (int to = 0; to < TO; ++to) acc[to] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < PF - 1; ++st)
+#pragma unroll
+      for (int to = 0; to < TO; ++to) wb[st][to] = wp[((wave * TO + to) * NT + st) * 64];
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+      const int tn = ti + PF - 1 < NT ? ti + PF - 1 : NT - 1;   // clamped: unconditional issue
+#pragma unroll
+      for (int to = 0; to < TO; ++to) wb[(ti + PF - 1) % PF][to] = wp[((wave * TO + to) * NT + tn) * 64];
+      const f32x4 b = xin[ti * 64];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int to = 0; to < TO; ++to)
+          acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ti % PF][to][r], b[r], acc[to], 0, 0, 0);
+    }
+    float* d_prev = delta_all + (l - 1) * layer_stride + row;
+    float* xout = s_x + (cur ^ 1) * NT * 256;
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+      const int t = wave * TO + to;
+      f32x4 d;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = (ok && mask[to][e] > 0.f) ? acc[to][e] : 0.f;
+      if (ok) *(f32x4*)(d_prev + 16 * t + 4 * g) = d;
+      *(f32x4*)(xout + (t * 64 + lane) * 4) = d;
+    }
+    cur ^= 1;
+  }
+}
+
+hipError_t launch_backprop16(hipStream_t s, const float* act_all, float* delta_all,
+                             const float* p16t, const float* woutp, int B, int Hp, int n_hidden,
+                             bool rbm) {
+  if (B <= 0) return hipSuccess;
+  const dim3 grid((B + 15) / 16);
+  switch (Hp / 16) {
+    case 4: hipLaunchKernelGGL((k_backprop16<4, 4>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, rbm ? 1 : 0); break;
+    case 8: hipLaunchKernelGGL((k_backprop16<8, 4>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, rbm ? 1 : 0); break;
+    case 12: hipLaunchKernelGGL((k_backprop16<12, 4>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, rbm ? 1 : 0); break;
+    case 16: hipLaunchKernelGGL((k_backprop16<16, 8>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, rbm ? 1 : 0); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 // --------------------------------------------------------------------------------- sweep16

@@ -17,7 +17,7 @@ std::string g_create_error;
 
 struct ParamSet {
   float* theta = nullptr;
-  float *w1p = nullptr, *b1p = nullptr, *bh = nullptr, *p16 = nullptr,
+  float *w1p = nullptr, *b1p = nullptr, *bh = nullptr, *p16 = nullptr, *p16t = nullptr,
         *woutp = nullptr, *bout = nullptr, *won = nullptr;
   float* z1 = nullptr;     // [B][Hp] cache for the ctx's chains
   float* onsite = nullptr; // [B] cached x . w_on (RBM)
@@ -70,7 +70,7 @@ struct vmc_ctx {
   float *acc = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad_tmp = nullptr;
   long long adam_t = 0;
   float* gemm_ws = nullptr;
-  int splitk = 16;
+  int splitk = 16;           // upper bound (workspace size); see pick_splitk
   int num_cus = 256;
   int sweep_waves = 8;       // waves per sweep workgroup at Hp = 256 (CGS_VMC_SWEEP_WAVES=4|8)
   // stochastic reconfiguration (extension, sr.hip): sample store + CG vectors
@@ -160,6 +160,15 @@ long long off_b(const vmc_ctx* c, int l) {  // biases sit right behind their wei
 long long off_wout(const vmc_ctx* c) { return c->lay.off_wout; }
 long long off_bout(const vmc_ctx* c) { return c->lay.off_bout; }
 
+// split-K of the weight-gradient GEMMs (K = number of samples): ~512 samples per split, measured
+// best at K = 4096 (8 splits: 0.086 ms for the whole gradient path against 0.097 at 16, 0.109 at 4)
+int pick_splitk(const vmc_ctx* c, long long k) {
+  long long s = k / 512;
+  if (s < 4) s = 4;
+  if (s > c->splitk) s = c->splitk;
+  return (int)s;
+}
+
 ParamLayout make_layout(bool rbm, long long N, long long H, long long L) {
   ParamLayout lay;
   if (rbm) {   // w_on[N] b_on | w_1 b_1 | (w b) x L        (see include/cgsvmc.h)
@@ -180,7 +189,7 @@ int ensure_packed(vmc_ctx* c, int which) {
   if (!p.has_params) return fail(c, VMC_ERR_STATE, "parameters not set (vmc_set_params)");
   if (p.packed_valid) return VMC_OK;
   HIPCHK(c, launch_pack(c->stream, p.theta, c->N, c->H, c->Hp, c->lay, p.w1p, p.b1p, p.bh, p.p16,
-                        p.woutp, p.bout, p.won));
+                        p.p16t, p.woutp, p.bout, p.won));
   p.packed_valid = true;
   return VMC_OK;
 }
@@ -357,6 +366,8 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     CA(dalloc(&p.theta, P));
     CA(dalloc(&p.w1p, N * Hp)); CA(dalloc(&p.b1p, Hp)); CA(dalloc(&p.bh, NH * Hp));
     CA(dalloc(&p.p16, (NH > 0 ? NH : 1) * Hp * Hp));
+    CA(dalloc(&p.p16t, (NH > 0 ? NH : 1) * Hp * Hp));
+    CA(hipMemsetAsync(p.p16t, 0, (size_t)(NH > 0 ? NH : 1) * Hp * Hp * sizeof(float), c->stream));
     CA(hipMemsetAsync(p.p16, 0, (size_t)(NH > 0 ? NH : 1) * Hp * Hp * sizeof(float), c->stream));
     CA(dalloc(&p.won, N)); CA(dalloc(&p.onsite, B));
     CA(hipMemsetAsync(p.won, 0, N * sizeof(float), c->stream));
@@ -403,7 +414,7 @@ void vmc_destroy(vmc_ctx* c) {
   drain_timings(c);
   for (int w = 0; w < 2; ++w) {
     ParamSet& p = c->ps[w];
-    float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p16, p.woutp, p.bout, p.z1, p.logit, p.eloc, p.won, p.onsite};
+    float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p16, p.p16t, p.woutp, p.bout, p.z1, p.logit, p.eloc, p.won, p.onsite};
     for (float* q : ptrs) if (q) hipFree(q);
   }
   if (c->act_all) hipFree(c->act_all);
@@ -700,19 +711,9 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
     HIPCHK(c, launch_gemm(c->stream, g));
   }
   // back-propagation of d logit / d z_l: FC delta[NH] = w_out (.) relu'; RBM delta[NH] = tanh(z)
-  // (which IS act[NH]); then the W_l^T chain through the relu masks
-  if (c->rbm)
-    HIPCHK(c, hipMemcpyAsync(c->delta[NH], c->act[NH], (size_t)B * Hp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-  else
-    HIPCHK(c, launch_delta_out(c->stream, p.woutp, c->act[NH], c->delta[NH], B, Hp));
-  for (int l = NH; l > 0; --l) {
-    GemmArgs g; memset(&g, 0, sizeof(g));
-    g.A = c->delta[l]; g.sam = Hp; g.sak = 1;
-    g.B = p.theta + off_w(c, l); g.sbk = 1; g.sbn = H;   // W_l^T
-    g.M = B; g.N = H; g.K = H; g.C = c->delta[l - 1]; g.ldc = Hp;
-    g.mask = c->act[l - 1]; g.ldmask = Hp; g.epilogue = 2; g.splitk = 1;
-    HIPCHK(c, launch_gemm(c->stream, g));
-  }
+  // (which IS act[NH]); then the W_l^T chain through the relu masks -- one launch, 16 chains per
+  // workgroup, transposed weight fragments on 16x16x4 MFMA (k_backprop16)
+  HIPCHK(c, launch_backprop16(c->stream, c->act_all, c->delta_all, p.p16t, p.woutp, B, Hp, NH, c->rbm));
   // Every weight-gradient GEMM is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows 0..K_in-1
   // give dW, the implicit ones row gives db (b_l sits right behind w_l in theta), the unscaled
   // product goes to g1 and the w-scaled one to g2.  All NH+2 of them run as ONE batched launch
@@ -727,7 +728,7 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
       g.A = a; g.sam = 1; g.sak = a_ld; g.M = k_in + 1; g.ones_row = 1;
       g.B = delta; g.sbk = sbk; g.sbn = sbn; g.kscale = w; g.dual = 1;
       g.N = n_out; g.K = B; g.C = g1 + off; g.C2 = g2 + off; g.ldc = n_out; g.epilogue = 3;
-      g.splitk = c->splitk; g.workspace = c->gemm_ws + (long long)tab.size() * ws_stride;
+      g.splitk = pick_splitk(c, B); g.workspace = c->gemm_ws + (long long)tab.size() * ws_stride;
       tab.push_back(g);
     };
     if (c->rbm)   // onsite layer: d logit / d w_on = x, d logit / d b_on = 1
@@ -739,7 +740,7 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
     HIPCHK(c, hipMemcpy(c->d_batch[slot], tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
     c->batch_ready[slot] = true;
   }
-  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot], NH + 2, N > H ? N : H, H, c->splitk));
+  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot], NH + 2, N > H ? N : H, H, pick_splitk(c, B)));
   return VMC_OK;
 }
 
@@ -958,7 +959,7 @@ static int sr_build_table(vmc_ctx* c) {
     g.A = a; g.sam = 1; g.sak = a_ld; g.M = k_in + 1; g.ones_row = 1;
     g.B = delta; g.sbk = sbk; g.sbn = sbn; g.kscale = c->sr_t; g.dual = 0;
     g.N = n_out; g.K = (int)rows; g.C = c->sr_u + off; g.ldc = n_out; g.epilogue = 3;
-    g.splitk = c->splitk; g.workspace = c->gemm_ws + (long long)tab.size() * ws_stride;
+    g.splitk = pick_splitk(c, rows); g.workspace = c->gemm_ws + (long long)tab.size() * ws_stride;
     tab.push_back(g);
   };
   if (c->rbm) add(c->sr_cfg, N, (int)N, c->sr_ones, 1, 0, 1, c->lay.off_won);        // onsite layer
@@ -1036,7 +1037,7 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
     HIPCHK(c, launch_jvp_out(c->stream, tang[(L - 1) & 1], c->sr_act + (long long)(L - 1) * R * Hp,
                              theta + off_wout(c), v + off_wout(c), v + off_bout(c), rows, H, Hp, c->sr_t));
   HIPCHK(c, launch_sum_into(c->stream, c->sr_t, rows, c->sr_u + c->P));
-  HIPCHK(c, launch_gemm_batched(c->stream, c->sr_batch, L + 1, N > H ? N : H, H, c->splitk, false));
+  HIPCHK(c, launch_gemm_batched(c->stream, c->sr_batch, L + 1, N > H ? N : H, H, pick_splitk(c, (long long)c->sr_n * B), false));
   return VMC_OK;
 }
 
