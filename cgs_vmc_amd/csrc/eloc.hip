@@ -42,30 +42,30 @@ __global__ __launch_bounds__(256) void k_bond_count(const float* __restrict__ co
   if (lane == 0) { cnt[c] = n; diag[c] = d; }
 }
 
-// single block: off[c] = sum_{c' < c} cnt[c'], off[B] = total
+// single block: off[c] = sum_{c' < c} cnt[c'], off[B] = total.  Thread t owns the contiguous
+// slice [t*per, (t+1)*per): serial sum, wave-level inclusive scan of the 64 slice totals by
+// shuffles, the 16 wave totals through LDS, then the slice is written out (two barriers in all).
 __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ cnt, int B,
                                                int* __restrict__ off) {
-  __shared__ int s[1024];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < B; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < B ? cnt[i] : 0;
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-      const int t = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
-      __syncthreads();
-      s[threadIdx.x] += t;
-      __syncthreads();
-    }
-    if (i < B) off[i] = carry + s[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += s[1023];
-    __syncthreads();
+  __shared__ int s_wave[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int per = (B + 1023) / 1024;
+  const int beg = min(t * per, B), end = min(beg + per, B);
+  int total = 0;
+  for (int i = beg; i < end; ++i) total += cnt[i];
+  int incl = total;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
   }
-  if (threadIdx.x == 0) off[B] = carry;
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += s_wave[w];
+  int run = base + incl - total;          // exclusive prefix of this thread's slice
+  for (int i = beg; i < end; ++i) { off[i] = run; run += cnt[i]; }
+  if (t == 1023) off[B] = base + incl;
 }
 
 // one wave per chain: rowinfo[off[c] + p] = {c, +-(bond+1)}, sign = sign of s_i, bonds in
