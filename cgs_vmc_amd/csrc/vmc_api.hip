@@ -92,8 +92,9 @@ struct vmc_ctx {
   unsigned char* acc_mask = nullptr;
   unsigned long long step = 0;
   // timing
-  bool timing = false;
+  int timing = 0;            // 0 off, 1 every region, 2 the two roofline kernels only
   std::vector<TimedRegion> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
   std::map<std::string, std::pair<double, long long>> timings;
   std::string err;
 };
@@ -124,12 +125,39 @@ hipError_t dalloc(T** p, long long n) {
   return hipMalloc((void**)p, (size_t)(n > 0 ? n : 1) * sizeof(T));
 }
 
+// Per-kernel timing: event pairs come from a pool (creating two events per region costs more
+// than recording them); regions whose stop event has completed are folded into the totals and
+// their events recycled without blocking.
+static void account(vmc_ctx* c, const TimedRegion& r) {
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, r.start, r.stop);
+  auto& t = c->timings[r.name];
+  t.first += ms; t.second += 1;
+  c->event_pool.emplace_back(r.start, r.stop);
+}
+
+static void harvest_finished(vmc_ctx* c) {
+  size_t done = 0;
+  while (done < c->pending.size() && hipEventQuery(c->pending[done].stop) == hipSuccess) {
+    account(c, c->pending[done]);
+    ++done;
+  }
+  if (done) c->pending.erase(c->pending.begin(), c->pending.begin() + done);
+}
+
 struct Timer {
   vmc_ctx* c; bool on; TimedRegion r;
-  Timer(vmc_ctx* ctx, const char* name) : c(ctx), on(ctx->timing) {
+  Timer(vmc_ctx* ctx, const char* name)
+      : c(ctx), on(ctx->timing == 1 || (ctx->timing == 2 && (!strcmp(name, "sweep") || !strcmp(name, "tail_eloc")))) {
     if (on) {
       r.name = name;
-      hipEventCreate(&r.start); hipEventCreate(&r.stop);
+      if (c->event_pool.empty()) harvest_finished(c);
+      if (c->event_pool.empty()) {
+        hipEventCreate(&r.start); hipEventCreate(&r.stop);
+      } else {
+        r.start = c->event_pool.back().first; r.stop = c->event_pool.back().second;
+        c->event_pool.pop_back();
+      }
       hipEventRecord(r.start, c->stream);
     }
   }
@@ -141,11 +169,7 @@ struct Timer {
 void drain_timings(vmc_ctx* c) {
   for (auto& r : c->pending) {
     hipEventSynchronize(r.stop);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, r.start, r.stop);
-    auto& t = c->timings[r.name];
-    t.first += ms; t.second += 1;
-    hipEventDestroy(r.start); hipEventDestroy(r.stop);
+    account(c, r);
   }
   c->pending.clear();
 }
@@ -412,6 +436,7 @@ void vmc_destroy(vmc_ctx* c) {
   if (!c) return;
   hipStreamSynchronize(c->stream);
   drain_timings(c);
+  for (auto& e : c->event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   for (int w = 0; w < 2; ++w) {
     ParamSet& p = c->ps[w];
     float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p16, p.p16t, p.woutp, p.bout, p.z1, p.logit, p.eloc, p.won, p.onsite};
@@ -1124,7 +1149,16 @@ int vmc_sr_debug_matvec(vmc_ctx* c, const float* v, float diag_shift, float* out
   return VMC_OK;
 }
 
-int vmc_timing_enable(vmc_ctx* c, int on) { CHECK_CTX(c); c->timing = on != 0; return VMC_OK; }
+int vmc_timing_enable(vmc_ctx* c, int on) {
+  CHECK_CTX(c);
+  c->timing = on < 0 || on > 2 ? 1 : on;
+  while (c->timing && c->event_pool.size() < 64) {   // enough for a dozen steps in flight
+    hipEvent_t a, b;
+    HIPCHK(c, hipEventCreate(&a)); HIPCHK(c, hipEventCreate(&b));
+    c->event_pool.emplace_back(a, b);
+  }
+  return VMC_OK;
+}
 
 int vmc_timing_reset(vmc_ctx* c) {
   CHECK_CTX(c);

@@ -334,7 +334,8 @@ class VmcEngine:
     return out
 
   # ------------------------------------------------------------------ timing / debug
-  def timing_enable(self, on: bool = True):
+  def timing_enable(self, on=True):
+    """True / 1: every region; 2: only the two roofline kernels (sweep, tail_eloc); False: off."""
     self._check(self._lib.vmc_timing_enable(self._ctx, int(on)))
 
   def timing_reset(self):

@@ -199,7 +199,9 @@ int vmc_sr_debug_matvec(vmc_ctx* ctx, const float* v /*[P]*/, float diag_shift, 
 /* Wavefunction.update_norm (wavefunctions.py:261-288) on psi(chains). */
 int vmc_update_norm(vmc_ctx* ctx, float max_value);
 
-/* Per-kernel HIP-event timing on the ctx's stream (bench.py's roofline leg).
+/* Per-kernel HIP-event timing on the ctx's stream (bench.py's roofline leg).  on = 1 times
+ * every region, on = 2 only "sweep" and "tail_eloc" (each recorded event drains the pipeline
+ * between two kernels, ~3.5 us: ten of them per step cost 1.8 % of the step they measure).
  * names: "sweep", "tail_eloc", "tail_amp", "z1", "bond_list", "eloc_reduce", "grad",
  * "adam", "sr_matvec".  ms = summed elapsed, launches = number of timed launches. */
 int vmc_timing_enable(vmc_ctx* ctx, int on);
