@@ -628,10 +628,20 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   if (RBM) {
     for (int i = tid; i < Nst; i += NTH) s_won[i] = i < N ? pp.won[i] : 0.f;
   }
-  if (W1L) {
-    for (int i = tid; i < N * (Hp / 4); i += NTH) {
-      const int n = i / (Hp / 4), c4 = i % (Hp / 4);
-      *(f32x4*)(s_w1 + n * W1S + 4 * c4) = *(const f32x4*)(pp.w1p + (long long)n * Hp + 4 * c4);
+  if (W1L) {   // 8 loads in flight per thread: the copy costs one L2 round trip per 8 vectors
+    const int total = N * (Hp / 4);
+    for (int base = tid; base < total; base += 8 * NTH) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = min(base + u * NTH, total - 1);
+        v[u] = *(const f32x4*)(pp.w1p + (long long)(i / (Hp / 4)) * Hp + 4 * (i % (Hp / 4)));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * NTH;
+        if (i < total) *(f32x4*)(s_w1 + (i / (Hp / 4)) * W1S + 4 * (i % (Hp / 4))) = v[u];
+      }
     }
   }
   const float bout = pp.bout[0];
@@ -658,10 +668,28 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
       const float b = pp.b1p[col];
 #pragma unroll
       for (int c = 0; c < CPG; ++c) acc[c] = b;
-      for (int n = 0; n < N; ++n) {
-        const float w = pp.w1p[(long long)n * Hp + col];
+      if (W1L) {   // W1 is LDS-resident: no global round trip per site
+        for (int n = 0; n < N; ++n) {
+          const float w = s_w1[n * W1S + col];
 #pragma unroll
-        for (int c = 0; c < CPG; ++c) acc[c] = fmaf(s_spin[(grp * CPG + c) * Nst + n], w, acc[c]);
+          for (int c = 0; c < CPG; ++c) acc[c] = fmaf(s_spin[(grp * CPG + c) * Nst + n], w, acc[c]);
+        }
+      } else {     // stream W1 from L2 eight rows at a time (all eight loads in flight together)
+        int n = 0;
+        for (; n + 8 <= N; n += 8) {
+          float w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) w[u] = pp.w1p[(long long)(n + u) * Hp + col];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) acc[c] = fmaf(s_spin[(grp * CPG + c) * Nst + n + u], w[u], acc[c]);
+        }
+        for (; n < N; ++n) {
+          const float w = pp.w1p[(long long)n * Hp + col];
+#pragma unroll
+          for (int c = 0; c < CPG; ++c) acc[c] = fmaf(s_spin[(grp * CPG + c) * Nst + n], w, acc[c]);
+        }
       }
 #pragma unroll
       for (int c = 0; c < CPG; ++c) s_z1[(grp * CPG + c) * ZS + col] = acc[c];
@@ -1078,9 +1106,11 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   if (a.cache_in_valid && a.n_steps > 0) {
     // the previous launch left an exact z1 / logit cache for these very chains: load it
     // instead of recomputing it (saves one of the two refresh passes per launch)
-    for (int i = tid; i < 16 * Hp; i += NTH) {
-      const int c = i / Hp, col = i % Hp, gc = chain0 + c;
-      s_z1[c * ZS + col] = gc < a.B ? a.z1[(long long)gc * Hp + col] : 0.f;
+    for (int i = tid; i < 16 * (Hp / 4); i += NTH) {   // 16-byte loads, <= 2 per thread
+      const int c = i / (Hp / 4), c4 = i % (Hp / 4), gc = chain0 + c;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (gc < a.B) v = *(const f32x4*)(a.z1 + (long long)gc * Hp + 4 * c4);
+      *(f32x4*)(s_z1 + c * ZS + 4 * c4) = v;
     }
     if (tid < 16) s_logit[tid] = chain0 + tid < a.B ? a.logit[chain0 + tid] : 0.f;
     onsite_direct();
@@ -1133,9 +1163,9 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
     const int c = i / N, n = i % N, gc = chain0 + c;
     if (gc < a.B) a.configs[(long long)gc * N + n] = s_spin[c * Nst + n];
   }
-  for (int i = tid; i < 16 * Hp; i += NTH) {
-    const int c = i / Hp, col = i % Hp, gc = chain0 + c;
-    if (gc < a.B) a.z1[(long long)gc * Hp + col] = s_z1[c * ZS + col];
+  for (int i = tid; i < 16 * (Hp / 4); i += NTH) {
+    const int c = i / (Hp / 4), c4 = i % (Hp / 4), gc = chain0 + c;
+    if (gc < a.B) *(f32x4*)(a.z1 + (long long)gc * Hp + 4 * c4) = *(const f32x4*)(s_z1 + c * ZS + 4 * c4);
   }
   if (j == 0 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);   // waves 0-3 only
 }

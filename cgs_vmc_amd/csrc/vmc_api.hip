@@ -578,7 +578,7 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
 }
 
 static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int* dbg_up, int* dbg_dn,
-                     float* dbg_u, unsigned long long step0) {
+                     float* dbg_u, unsigned long long step0, bool count_accepted = false) {
   PROPAGATE(ensure_packed(c, 0));
   SweepArgs a;
   memset(&a, 0, sizeof(a));
@@ -596,7 +596,8 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   a.act_out = dbg ? nullptr : c->act_all;
   a.cache_in_valid = (!dbg && !injected && c->ps[0].cache_valid) ? 1 : 0;
   c->acts_valid = !dbg;
-  HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), c->stream));
+  // the device counter is only zeroed when the caller will read it back
+  if (count_accepted) HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), c->stream));
   {
     Timer t(c, "sweep");
     HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
@@ -607,7 +608,7 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
 int vmc_mc_steps(vmc_ctx* c, int64_t n_steps, int64_t* accepted) {
   CHECK_CTX(c);
   if (n_steps < 0) return fail(c, VMC_ERR_INVALID, "n_steps < 0");
-  PROPAGATE(run_sweep(c, n_steps, false, false, nullptr, nullptr, nullptr, c->step));
+  PROPAGATE(run_sweep(c, n_steps, false, false, nullptr, nullptr, nullptr, c->step, accepted != nullptr));
   c->step += (unsigned long long)n_steps;
   c->ps[0].cache_valid = true;   // the sweep kernel writes back an exact z1/logit cache
   c->ps[1].cache_valid = false;
