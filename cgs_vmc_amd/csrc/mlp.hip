@@ -382,7 +382,13 @@ __global__ __launch_bounds__(256) void k_tail0(TailArgs a, int Hp) {
     }
     float s = 0.f;
     if (RBM) {
-      for (int i = 0; i < a.n_units; ++i) s += vmc_logcosh(fmaf(coef, wa[i] - wb[i], zb[i]));
+      // the logit is a sum of H positive terms (~ H / 2): accumulate in double so that
+      // logit' - logit keeps its digits (this kernel is not hot)
+      double sd = 0.0;
+      for (int i = 0; i < a.n_units; ++i) {
+        sd += (double)vmc_logcosh(fmaf(coef, wa[i] - wb[i], zb[i]));
+      }
+      s = (float)sd;
     } else {
       for (int i = 0; i < Hp; ++i)
         s = fmaf(fmaxf(fmaf(coef, wa[i] - wb[i], zb[i]), 0.f), a.pp.woutp[i], s);

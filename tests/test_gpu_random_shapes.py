@@ -1,0 +1,78 @@
+"""GPU parity on seeded random shapes (both ansatz types): lattice size, hidden width, depth,
+batch and bond graph with per-bond couplings are drawn at random, so padding (H not a multiple
+of 16 / 64), ragged batches, odd N, tiny H and irregular bond lists all get exercised.
+Tolerances as in tests/test_gpu_engine.py."""
+import numpy as np
+import pytest
+
+from oracle import vmc_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _draw(seed):
+  rng = np.random.default_rng(1000 + seed)
+  ansatz = 'rbm' if seed % 3 == 2 else 'fully_connected'
+  n = int(rng.integers(4, 61))
+  h = int(rng.choice([1, 3, 16, 17, 40, 64, 65, 100, 128, 129, 200, 255, 256]))
+  L = int(rng.integers(0, 4)) if ansatz == 'rbm' else int(rng.integers(1, 5))
+  b = int(rng.integers(1, 151))
+  n_b = int(rng.integers(1, 3 * n))
+  bonds = []
+  while len(bonds) < n_b:
+    i, j = (int(x) for x in rng.integers(0, n, 2))
+    if i != j:
+      bonds.append((i, j))
+  jx = rng.uniform(-1.5, 1.5, n_b).astype(np.float32)
+  jz = rng.uniform(-1.0, 1.5, n_b).astype(np.float32)
+  return ansatz, n, h, L, b, bonds, jx, jz, rng
+
+
+@pytest.mark.parametrize('seed', range(60))
+def test_random_shape_matches_oracle(seed):
+  from cgs_vmc_amd import _hip
+  from cgs_vmc_amd.engine import VmcEngine
+  ansatz, n, h, L, b, bonds, jx, jz, rng = _draw(seed)
+  rbm = ansatz == 'rbm'
+  theta = (vo.rbm_init_params if rbm else vo.init_params)(n, h, L, rng)
+  theta = (theta + 0.05 * rng.standard_normal(theta.size)).astype(np.float32)
+  logit_fn = vo.rbm_logit if rbm else vo.fc_logit
+  psi_fn = vo.rbm_psi if rbm else vo.fc_psi
+  cfg = vo.random_configurations(n, b, np.random.RandomState(seed))
+  eng = VmcEngine(n, b, L, h, seed=11, ansatz=ansatz)
+  eng.set_params(theta); eng.set_configs(cfg); eng.set_bonds(bonds, jx, jz)
+  tag = (ansatz, n, h, L, b, len(bonds))
+
+  def close(a, ref, rel):
+    a = np.asarray(a, np.float64); ref = np.asarray(ref, np.float64)
+    err = np.abs(a - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() <= rel, (tag, float(err.max()))
+
+  close(eng.amplitude()[0], logit_fn(theta, cfg, h, L, dtype=np.float64), 2e-5)
+  amp = lambda c: psi_fn(theta, c, h, L, dtype=np.float64)
+  close(eng.local_energy()[0], vo.local_value(amp, cfg, bonds, jx, jz, dtype=np.float64), 3e-4)
+  # gradient accumulators
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, jx, jz, -10.0, h, L, np.float64,
+                                ansatz=ansatz)
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  got = eng.get_accumulators()
+  p = theta.size
+  for g, r in ((got[:p], acc.g1_total), (got[p:2 * p], acc.g2_total)):
+    assert np.abs(g - r).max() < 2e-3 * np.abs(r).max() + 2e-4, tag
+  # one injected Metropolis step + exact cache afterwards
+  u_sites, u_acc = vo.step_uniforms(5, np.arange(b), seed, n)
+  i_up, i_dn = vo.propose_exchange(cfg, u_sites)
+  _, acc_ref, ratios = vo.mc_step(amp, cfg, i_up, i_dn, u_acc)
+  mask = eng.mc_step_injected(i_up, i_dn, u_acc)
+  band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
+  assert np.array_equal(mask[~band], acc_ref[~band]), tag
+  got_cfg = eng.get_configs()
+  close(eng.amplitude()[0], logit_fn(theta, got_cfg, h, L, dtype=np.float64), 2e-5)
+  # a short free-running sweep keeps Sz and the cache exact
+  eng.mc_steps(2 * n)
+  got_cfg = eng.get_configs()
+  assert (np.abs(got_cfg) == 1).all() and (got_cfg.sum(1) == cfg.sum(1)).all(), tag
+  close(eng.amplitude()[0], logit_fn(theta, got_cfg, h, L, dtype=np.float64), 2e-5)
+  eng.close()
