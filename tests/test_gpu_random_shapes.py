@@ -76,3 +76,54 @@ def test_random_shape_matches_oracle(seed):
   assert (np.abs(got_cfg) == 1).all() and (got_cfg.sum(1) == cfg.sum(1)).all(), tag
   close(eng.amplitude()[0], logit_fn(theta, got_cfg, h, L, dtype=np.float64), 2e-5)
   eng.close()
+
+
+@pytest.mark.parametrize('seed', range(20))
+def test_random_shape_itswo_and_sr(seed):
+  """LogOverlapITSWO accumulators and the SR matrix-vector product on small random shapes
+  (dense S is affordable there)."""
+  from cgs_vmc_amd import _hip
+  from cgs_vmc_amd.engine import VmcEngine
+  rng = np.random.default_rng(5000 + seed)
+  rbm = seed % 2 == 1
+  ansatz = 'rbm' if rbm else 'fully_connected'
+  n = int(rng.integers(4, 21)); h = int(rng.choice([2, 7, 16, 33, 48]))
+  L = int(rng.integers(0, 3)) if rbm else int(rng.integers(1, 4))
+  b = int(rng.integers(2, 61))
+  bonds = [(i, (i + 1) % n) for i in range(n)] + [(0, n // 2)]
+  theta = (vo.rbm_init_params if rbm else vo.init_params)(n, h, L, rng)
+  theta = (theta + 0.05 * rng.standard_normal(theta.size)).astype(np.float32)
+  theta_w = (theta + 0.02 * rng.standard_normal(theta.size)).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(seed))
+  tag = (ansatz, n, h, L, b)
+  eng = VmcEngine(n, b, L, h, seed=3, ansatz=ansatz)
+  eng.set_bonds(bonds, -1.0, 1.0)
+  # ITSWO: omega = theta_w frozen, psi = theta
+  eng.set_params(theta_w); eng.set_configs(cfg)
+  eng.transfer_params()
+  eng.set_params(theta); eng.set_shift(-9.5)
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.log_overlap_accumulate(acc, theta, theta_w, cfg, bonds, -1.0, 1.0, -9.5, -10.0, 0.12, h, L,
+                            np.float64, ansatz=ansatz)
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_LOG_OVERLAP_ITSWO, 0.12)
+  g_ref = vo.log_overlap_gradient(acc)
+  g = eng.get_gradient(_hip.VMC_MODE_LOG_OVERLAP_ITSWO)
+  assert np.abs(g - g_ref).max() < 2e-3 * np.abs(g_ref).max() + 2e-4, tag
+  # SR matvec over two recorded batches
+  eng.set_shift(-10.0)
+  eng.sr_reserve(2)
+  eng.reset_accumulators()
+  cfgs, elocs = [], []
+  for k in range(2):
+    c = vo.random_configurations(n, b, np.random.RandomState(100 + seed + k))
+    eng.set_configs(c); eng.accumulate(0)
+    cfgs.append(c); elocs.append(eng.local_energy()[0])
+  grads = vo.rbm_per_sample_logit_grads if rbm else vo.per_sample_logit_grads
+  o = grads(theta, np.concatenate(cfgs, 0), h, L)
+  s_mat, _ = vo.sr_system(o, np.concatenate(elocs, 0).astype(np.float64))
+  v = rng.standard_normal(theta.size).astype(np.float32)
+  ref = s_mat @ v.astype(np.float64) + 0.01 * v
+  got = eng.sr_debug_matvec(v, 0.01)
+  assert np.abs(got - ref).max() <= 3e-4 * np.abs(ref).max(), tag
+  eng.close()
