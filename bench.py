@@ -146,7 +146,9 @@ def main():
   eng.set_params(theta)
   eng.set_configs(cfg)
   eng.set_bonds(bonds, -1.0, 1.0)
-  eng.mc_steps(10 * n, want_accepted=False)        # 10 warm-up sweeps
+  for _ in range(10):                              # 10 warm-up sweeps, one launch each
+    eng.mc_steps(n, want_accepted=False)           # (every k_sweep16 launch of a run is one sweep, so
+                                                   # rocprofv3's per-kernel average is per sweep)
 
   def step():
     # one optimizer-step slice: fresh accumulators (training.py:613 / 758), gradient accumulate,
