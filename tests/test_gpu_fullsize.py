@@ -107,3 +107,29 @@ def test_accumulators_are_additive_over_calls_and_shards(name):
   gref = vo.energy_gradient(acc)
   assert np.abs(g - gref).max() < 2e-3 * np.abs(gref).max() + 2e-4
   sub.close(); eng.close()
+
+
+@pytest.mark.parametrize('name', sorted(FULL))
+def test_full_size_engine_matches_oracle_on_sampled_chains(name):
+  """The full-size engine (all chains resident, production kernels and tile counts) against the
+  fp64 oracle on every 64th chain: logits, local energies, and -- after a sweep of the whole
+  batch -- the same quantities on the moved chains."""
+  eng, theta, cfg, bonds, (n, h, L, b) = _setup(name)
+  pick = np.arange(0, b, 64)
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+
+  def check(configs):
+    sub = configs[pick]
+    ref_logit = vo.fc_logit(theta, sub, h, L, dtype=np.float64)
+    ref_eloc = vo.local_value(amp, sub, bonds, -1.0, 1.0, dtype=np.float64)
+    logit = eng.amplitude()[0][pick]
+    eloc = eng.local_energy()[0][pick]
+    assert np.abs(logit - ref_logit).max() <= 2e-5 * max(1.0, np.abs(ref_logit).max())
+    assert np.abs(eloc - ref_eloc).max() <= 2e-4 * max(1.0, np.abs(ref_eloc).max())
+
+  check(cfg)
+  eng.mc_steps(n)
+  moved = eng.get_configs()
+  assert (moved != cfg).any()
+  check(moved)
+  eng.close()
