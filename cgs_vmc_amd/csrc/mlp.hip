@@ -607,9 +607,12 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   float* s_hlu = (float*)(s_pacc + 16);       // [16] 0.5 log(u_accept)
   float* s_wout = s_hlu + 16;                 // [Hp]
   float* s_bias = s_wout + Hp;                // [n_hidden][Hp] biases of the H x H layers
-  float* s_won = s_bias + a.n_hidden * Hp;    // [Nst] onsite weights (RBM only)
-  float* s_on = s_won + (RBM ? Nst : 0);      // [16] x . w_on of the committed chains (RBM only)
+  // RBM onsite weights: with W1 in LDS they live in the first padding float of each W1 row
+  // (s_w1[n * W1S + Hp]), otherwise in their own [Nst] array
+  float* s_won = s_bias + a.n_hidden * Hp;
+  float* s_on = s_won + ((RBM && !W1L) ? Nst : 0);   // [16] x . w_on of the committed chains (RBM only)
   float* s_w1 = s_on + (RBM ? 16 : 0);        // [N][W1S] (W1L only)
+  auto won_at = [&](int n) { return W1L ? s_w1[n * W1S + Hp] : s_won[n]; };
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
@@ -632,7 +635,8 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   for (int i = tid; i < n_hidden * Hp; i += NTH) s_bias[i] = pp.bh[i];
   for (int i = tid; i < Hp; i += NTH) s_wout[i] = pp.woutp[i];
   if (RBM) {
-    for (int i = tid; i < Nst; i += NTH) s_won[i] = i < N ? pp.won[i] : 0.f;
+    if (W1L) { for (int i = tid; i < N; i += NTH) s_w1[i * W1S + Hp] = pp.won[i]; }
+    else { for (int i = tid; i < Nst; i += NTH) s_won[i] = i < N ? pp.won[i] : 0.f; }
   }
   if (W1L) {   // 8 loads in flight per thread: the copy costs one L2 round trip per 8 vectors
     const int total = N * (Hp / 4);
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   auto onsite_direct = [&]() {
     if (RBM && tid < 16) {
       float acc = 0.f;
-      for (int n = 0; n < N; ++n) acc = fmaf(s_spin[tid * Nst + n], s_won[n], acc);
+      for (int n = 0; n < N; ++n) acc = fmaf(s_spin[tid * Nst + n], won_at(n), acc);
       s_on[tid] = acc;
     }
   };
@@ -1085,7 +1089,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
     float on_new = 0.f;
     if (RBM) {   // onsite term of the evaluated configuration: committed value (+ exchange update)
       on_new = s_on[c];
-      if (prev_kind == 2) on_new += 2.f * (s_won[s_idn[c]] - s_won[s_iup[c]]);
+      if (prev_kind == 2) on_new += 2.f * (won_at(s_idn[c]) - won_at(s_iup[c]));
       ln += on_new;
     }
     if (prev_kind == 2) {
@@ -1179,7 +1183,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
 static size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool rbm) {
   const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
   return sizeof(float) * (size_t)(16 * Nst + (w1l ? 1 : 2) * 16 * ZS + 2 * NT * 256 + 16 +
-                                  16 + 7 * 16 + Hp + n_hidden * Hp + (rbm ? Nst + 16 : 0) +
+                                  16 + 7 * 16 + Hp + n_hidden * Hp + (rbm ? (w1l ? 0 : Nst) + 16 : 0) +
                                   (w1l ? N * (Hp + 4) : 0));
 }
 
