@@ -71,6 +71,7 @@ SIGNATURES = {
     'vmc_accumulate': (C.c_int, [_ctx, C.c_int, C.c_float]),
     'vmc_reset_accumulators': (C.c_int, [_ctx]),
     'vmc_accumulators_devptr': (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    'vmc_allreduce_accumulators': (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
     'vmc_get_accumulators': (C.c_int, [_ctx, _fp]),
     'vmc_set_accumulators': (C.c_int, [_ctx, _fp]),
     'vmc_apply_adam': (C.c_int, [_ctx, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -173,6 +173,7 @@ hipError_t launch_itswo_ratio(hipStream_t s, const float* logit_psi, const float
 hipError_t launch_adam(hipStream_t s, float* theta, float* m, float* v, const float* acc, int P,
                        int mode, float lr_t, float b1, float b2, float eps, float* grad_out);
 hipError_t launch_fill(hipStream_t s, float* x, float v, long long n);
+hipError_t launch_scale_one(hipStream_t s, float* x, float f);
 
 // stochastic reconfiguration (sr.hip)
 hipError_t launch_jvp_out(hipStream_t s, const float* tang, const float* act, const float* wout,

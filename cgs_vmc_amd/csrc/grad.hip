@@ -327,6 +327,13 @@ hipError_t launch_tanh_copy(hipStream_t s, const float* z, float* a, long long n
   return hipGetLastError();
 }
 
+__global__ void k_scale_one(float* x, float f) { x[0] *= f; }
+
+hipError_t launch_scale_one(hipStream_t s, float* x, float f) {
+  hipLaunchKernelGGL(k_scale_one, dim3(1), dim3(1), 0, s, x, f);
+  return hipGetLastError();
+}
+
 __global__ void k_fill(float* __restrict__ x, float v, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x)

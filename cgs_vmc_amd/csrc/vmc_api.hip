@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -822,6 +823,28 @@ int vmc_accumulators_devptr(vmc_ctx* c, void** dev_ptr, int64_t* n_floats) {
   CHECK_CTX(c);
   if (dev_ptr) *dev_ptr = c->acc;
   if (n_floats) *n_floats = 2 * c->P + 8;
+  return VMC_OK;
+}
+
+// In-place SUM all-reduce of the accumulator buffer over an existing RCCL communicator, for hosts
+// without torch.distributed.  librccl is resolved at the first call (dlopen), so the library
+// itself does not depend on it; comm == NULL is the single-rank no-op.  g_count (number of
+// accumulate calls, identical on every rank) is divided back by the world size so that sharded
+// and unsharded gradients agree (see cgs_vmc_amd/parallel.py).
+int vmc_allreduce_accumulators(vmc_ctx* c, void* nccl_comm, int32_t world_size) {
+  CHECK_CTX(c);
+  if (!nccl_comm || world_size <= 1) return VMC_OK;
+  typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  static allreduce_fn fn = nullptr;
+  if (!fn) {
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (h) fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+    if (!fn) return fail(c, VMC_ERR_UNSUPPORTED, "librccl.so / ncclAllReduce not found");
+  }
+  const int rc = fn(c->acc, c->acc, (size_t)(2 * c->P + 8), /*ncclFloat32*/ 7, /*ncclSum*/ 0, nccl_comm, c->stream);
+  if (rc != 0) return fail(c, VMC_ERR_HIP, "ncclAllReduce failed with code " + std::to_string(rc));
+  HIPCHK(c, launch_scale_one(c->stream, c->acc + 2 * c->P + 4, 1.f / (float)world_size));
   return VMC_OK;
 }
 

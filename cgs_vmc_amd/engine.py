@@ -211,6 +211,11 @@ class VmcEngine:
     self._check(self._lib.vmc_accumulators_devptr(self._ctx, C.byref(p), C.byref(n)))
     return int(p.value), int(n.value)
 
+  def allreduce_accumulators_rccl(self, nccl_comm: int, world_size: int):
+    """SUM all-reduce of the accumulator buffer over an existing RCCL communicator handle (the
+    C-ABI path for hosts without torch.distributed; parallel.py uses torch's process group)."""
+    self._check(self._lib.vmc_allreduce_accumulators(self._ctx, C.c_void_p(nccl_comm), int(world_size)))
+
   def get_accumulators(self) -> np.ndarray:
     out = np.empty(2 * self.num_params + 8, np.float32)
     self._check(self._lib.vmc_get_accumulators(self._ctx, _fptr(out)))

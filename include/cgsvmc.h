@@ -142,6 +142,10 @@ int vmc_reset_accumulators(vmc_ctx* ctx);
  * = 2P+8 floats.  The device pointer is exposed so the host can all-reduce it in place
  * (RCCL via torch.distributed); *n_floats = 2P+8. */
 int vmc_accumulators_devptr(vmc_ctx* ctx, void** dev_ptr, int64_t* n_floats);
+/* The same all-reduce for hosts without torch.distributed: nccl_comm is an existing ncclComm_t of
+ * RCCL (NULL or world_size <= 1: no-op); stream-ordered on the ctx's stream, g_count corrected.
+ * librccl is resolved with dlopen at the first call. */
+int vmc_allreduce_accumulators(vmc_ctx* ctx, void* nccl_comm, int32_t world_size);
 int vmc_get_accumulators(vmc_ctx* ctx, float* host /*[2P+8]*/);
 int vmc_set_accumulators(vmc_ctx* ctx, const float* host /*[2P+8]*/);
 

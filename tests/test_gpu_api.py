@@ -328,3 +328,42 @@ def test_rccl_single_rank_allreduce_on_library_buffer():
   p = subprocess.run([sys.executable, os.path.join(root, 'tests', '_rccl_worker.py')], env=env,
                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
   assert p.returncode == 0 and b'rccl ok' in p.stdout, p.stdout.decode()[-3000:]
+
+
+def test_cabi_allreduce_over_an_rccl_communicator():
+  """vmc_allreduce_accumulators with a communicator made directly on librccl (1 rank): the
+  collective runs on the engine's stream; SUM over one rank is the identity and g_count is
+  divided by the world size the caller states."""
+  import ctypes as C
+  from cgs_vmc_amd.engine import VmcEngine
+  rccl = C.CDLL('librccl.so')
+
+  class UniqueId(C.Structure):
+    _fields_ = [('internal', C.c_char * 128)]
+
+  uid = UniqueId()
+  assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+  comm = C.c_void_p()
+  rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+  assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+  try:
+    n, h, L, b = 16, 32, 2, 64
+    rng = np.random.default_rng(0)
+    eng = VmcEngine(n, b, L, h, seed=5)
+    eng.set_params(vo.init_params(n, h, L, rng))
+    eng.set_configs(vo.random_configurations(n, b, np.random.RandomState(1)))
+    eng.set_bonds(vo.torus_bonds(4, 4), -1.0, 1.0)
+    eng.reset_accumulators()
+    eng.accumulate(0)
+    before = eng.get_accumulators()
+    eng.allreduce_accumulators_rccl(0, 8)                       # NULL communicator: no-op
+    np.testing.assert_array_equal(eng.get_accumulators(), before)
+    eng.allreduce_accumulators_rccl(comm.value, 2)             # really calls ncclAllReduce
+    after = eng.get_accumulators()
+    expect = before.copy()
+    expect[-4] /= 2                                            # g_count / stated world size
+    np.testing.assert_array_equal(after, expect)
+    eng.close()
+  finally:
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
