@@ -58,9 +58,11 @@ class HeisenbergHamiltonian(Operator):
     engine = self._engine_for(wavefunction, inputs)
 
     def diag():
+      inputs._ensure_hamiltonian(self)      # another operator may have been evaluated in between
       return engine.local_energy_terms(wavefunction._which)[0]
 
     def offdiag():
+      inputs._ensure_hamiltonian(self)
       d, o = engine.local_energy_terms(wavefunction._which)
       return o * engine.amplitude(None, wavefunction._which)[1]
     return session_lib.Tensor(diag, 'sz_elements'), session_lib.Tensor(offdiag, 's_perp_terms')
@@ -85,6 +87,17 @@ class HeisenbergHamiltonian(Operator):
   def apply(self, wavefunction):
     raise NotImplementedError('TransformedWavefunction (operators.py:90-125) is used by no '
                               'driver and is outside the MI355X hot path')
+
+
+class HeisenbergBond(HeisenbergHamiltonian):
+  """S_i . S_j on one bond (operators.py:128-169): `build` returns
+  (0.25 j_z s_i s_j, 0.25 j_x 2 [s_i s_j < 0] psi(R with i and j exchanged)).  It is the
+  one-bond case of the Hamiltonian kernels (the connected-row list then has at most one row per
+  chain)."""
+
+  def __init__(self, bond: Tuple[int, int], j_x, j_z):
+    super(HeisenbergBond, self).__init__([bond], j_x, j_z)
+    self._bond = (int(bond[0]), int(bond[1]))
 
 
 class LocalValueTensor(session_lib.Tensor):

@@ -367,3 +367,33 @@ def test_cabi_allreduce_over_an_rccl_communicator():
   finally:
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
+
+
+def test_heisenberg_bond_operator_and_interleaved_operators():
+  """operators.HeisenbergBond (operators.py:128-169) as the one-bond case, evaluated in turn
+  with the full Hamiltonian on the same CONFIGS variable (each handle re-applies its own bond
+  set when it is run)."""
+  from cgs_vmc_amd import graph_builders, operators
+  hp = _hparams()
+  wf, ham, opt, ops, sess, shared = _build('EnergyGradient', hp)
+  configs = shared[graph_builders.ResourceName.CONFIGS]
+  cfg = configs.eval()
+  theta = wf._get_theta()
+  h, L = hp.fc_layer_size, hp.num_fc_layers
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+  bond = operators.HeisenbergBond((2, 7), 0.8, 1.3)
+  t_bond = bond.build(wf, configs)
+  t_ham = ham.build(wf, configs)
+  lv_ham = ham.local_value(wf, configs)
+  for _ in range(2):                                   # interleaved evaluation
+    d1, o1 = sess.run(list(t_bond))
+    dref, oref = vo.heisenberg_build(amp, cfg, [(2, 7)], 0.8, 1.3, np.float64)
+    np.testing.assert_allclose(d1, dref, atol=1e-6)
+    np.testing.assert_allclose(o1, oref, rtol=3e-4, atol=1e-3)
+    d2, o2 = sess.run(list(t_ham))
+    dref2, oref2 = vo.heisenberg_build(amp, cfg, ham._bonds_list, -1.0, 1.0, np.float64)
+    np.testing.assert_allclose(d2, dref2, atol=1e-6)
+    np.testing.assert_allclose(o2, oref2, rtol=3e-4, atol=1e-3)
+    np.testing.assert_allclose(sess.run(lv_ham), dref2 + oref2 / amp(cfg), rtol=2e-4, atol=2e-4)
+  np.testing.assert_allclose(sess.run(bond.local_value(wf, configs)), dref + oref / amp(cfg),
+                             rtol=2e-4, atol=2e-4)

@@ -264,3 +264,11 @@ def test_saver_restores_a_tf_bundle(tmp_path, monkeypatch):
   saver.restore(None, path)
   for k in vals:
     np.testing.assert_array_equal(store[k], vals[k])
+
+
+def test_heisenberg_bond_is_the_one_bond_hamiltonian():
+  """operators.HeisenbergBond (operators.py:128-135): constructor signature and bond bookkeeping
+  (its kernels are covered by tests/test_gpu_api.py)."""
+  b = operators.HeisenbergBond((3, 5), 0.5, 2.0)
+  assert isinstance(b, operators.Operator) and b._bond == (3, 5)
+  assert b._bonds_list == [(3, 5)] and b._j_x.tolist() == [0.5] and b._j_z.tolist() == [2.0]
