@@ -145,7 +145,10 @@ def main():
   eng = VmcEngine(n, b, L, h, device=dev, chain_offset=chain_offset, seed=2024)
   eng.set_params(theta)
   eng.set_configs(cfg)
-  eng.set_bonds(bonds, -1.0, 1.0)
+  j = np.ones(nb, np.float32)
+  if nnn:
+    j[nb // 2:] = 0.5                               # J1 = 1 on the NN bonds, J2 = 0.5 on the NNN bonds
+  eng.set_bonds(bonds, -j, j)
   for _ in range(10):                              # 10 warm-up sweeps, one launch each
     eng.mc_steps(n, want_accepted=False)           # (every k_sweep16 launch of a run is one sweep, so
                                                    # rocprofv3's per-kernel average is per sweep)

@@ -95,7 +95,10 @@ struct TailArgs {
 
 struct SweepArgs {
   PackedParams pp;
-  float* configs;           // [B][N] +-1, updated in place
+  const float* configs_in;  // [B][N] +-1 chains at launch start
+  const float* z1_in;       // [B][Hp] exact cache of configs_in (read when cache_in_valid)
+  const float* logit_in;    // [B]
+  float* configs;           // [B][N] chains at launch end (may alias configs_in)
   float* z1;                // [B][Hp] cache out
   float* logit;             // [B]     cache out
   float* onsite;            // [B]     cache out: x . w_on (RBM) or nullptr
@@ -108,6 +111,7 @@ struct SweepArgs {
   int* dbg_up; int* dbg_dn; float* dbg_u;   // proposal dump (debug_proposals) or nullptr
   unsigned long long* dbg_cycles;           // [grid][4 waves][16 phases] -> diagnostic STAMP build
   int waves;                // waves per workgroup of the sweep kernel (4 or 8)
+  int no_w1l;               // 1: never hold W1 in LDS (the two-workgroups-per-CU variant)
   int cache_in_valid;       // z1 / logit already hold the exact cache of `configs`
   float* act_out;           // [L][B][Hp] activations of the final chains (gradient path) or nullptr
   int B, N, n_hidden;

@@ -585,12 +585,17 @@ __device__ __forceinline__ unsigned long long vmc_stamp() {
 // Proposals, accept and the Philox chains stay on waves 0-3 (4 chains each).
 // RBM: RestrictedBoltzmannNetwork epilogue: the last layer's units go through log cosh (its
 // output "dot" is against ones) and the onsite term x . w_on is tracked per chain in LDS.
-template <int NT, int NW, bool STAMP, bool W1L, bool FAST, bool RBM = false>
-__global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
+// RTP: k-tiles of the first H x H layer whose fragments stay in registers (14 with 8 waves; the
+// 4-wave variant of H = 256 owns 4 output tiles per wave and keeps fewer so that it fits 256
+// registers, i.e. two workgroups per CU).
+// UPRE: Philox site blocks per lane drawn one step ahead (2: N <= 128 sites, 4: N <= 256).
+template <int NT, int NW, int RTP, bool STAMP, bool W1L, bool FAST, int UPRE, bool RBM = false>
+__global__ __launch_bounds__(NW * 64, NT == 16 ? 2 : 1) void k_sweep16(SweepArgs a) {
   static_assert(NT % NW == 0, "output tiles must divide over the waves");
   constexpr int NTH = NW * 64;
   constexpr int Hp = NT * 16, TO = NT / NW, ZS = Hp + 4, W1S = Hp + 4, PF = SWEEP_PF;
-  constexpr int RT = NT < SWEEP_RT ? NT : SWEEP_RT;   // k-tiles of the first H x H layer kept in registers
+  constexpr int RT = NT < RTP ? NT : RTP;   // k-tiles of the first H x H layer kept in registers
+  static_assert((NT - RT) % PF == 0, "the streamed k-tiles of layer 0 must fill whole ring turns");
   extern __shared__ float smem[];
   const int N = a.N, Nst = (N + 3) & ~3;
   float* s_spin = smem;                       // [16][Nst]
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   for (int i = tid; i < 16 * Nst; i += NTH) {
     const int c = i / Nst, n = i % Nst, gc = chain0 + c;
     float v = 0.f;
-    if (n < N) v = gc < a.B ? a.configs[(long long)gc * N + n] : ((n & 1) ? -1.f : 1.f);
+    if (n < N) v = gc < a.B ? a.configs_in[(long long)gc * N + n] : ((n & 1) ? -1.f : 1.f);
     s_spin[i] = v;
   }
   if (tid < 16) { s_sel[tid] = 0; s_pacc[tid] = 0; s_pup[tid] = 0; s_pdn[tid] = 0; }
@@ -722,7 +727,10 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
   // chain state, so they are computed one step ahead inside the MFMA phase of step t (UPRE
   // blocks per lane, i.e. N <= 64*UPRE/... sites); only the argmax/argmin of s*u is left for
   // the start of the step.
-  constexpr int UPRE = 2;                       // prefetched Philox blocks per lane
+  // ND draws per lane and step: the UPRE site blocks j, j+16, ... and the acceptance block.  With
+  // UPRE = 2 the acceptance draw rides in lane 15's second slot when that block is beyond the
+  // lattice (N <= 124), so ND = 2; with UPRE = 4 it has a slot of its own (ND = 5).
+  constexpr int ND = UPRE == 2 ? 2 : UPRE + 1;
   const bool use_pref = FAST || ((nblk <= 16 * UPRE) && (a.inj_up == nullptr));
   const int my_c = wave * 4 + g;
   const uint32_t my_gid = (uint32_t)(a.chain_offset + chain0 + my_c);
@@ -731,24 +739,23 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
 #pragma unroll
   for (int i = 0; i < 4 * UPRE; ++i) u_pre[i] = 0.f;
 
-  // Philox counters of this lane's two draws for `step`: A = site block j, B = site block
-  // j+16, or, when that block is beyond the lattice (always on lane 15 for N <= 124), the
-  // acceptance block (only lane 15's value is used).
-  const bool acc_in_b = (15 + 16 >= nblk);          // lane 15's block B is free
-  auto ctr_a = [&](unsigned long long step) {
-    return make_uint4((uint32_t)j, my_gid, (uint32_t)step, (uint32_t)(step >> 32));
-  };
-  auto ctr_b = [&](unsigned long long step) {
-    const uint32_t blk = (j + 16 < nblk) ? (uint32_t)(j + 16) : VMC_ACCEPT_BLOCK;
+  const bool acc_in_b = (15 + 16 >= nblk);          // UPRE = 2: lane 15's second slot is free
+  auto ctr_of = [&](int d, unsigned long long step) {
+    uint32_t blk = (uint32_t)(j + 16 * d);
+    if (d >= UPRE) blk = VMC_ACCEPT_BLOCK;
+    else if (ND == UPRE && d == UPRE - 1 && j + 16 * d >= nblk) blk = VMC_ACCEPT_BLOCK;
     return make_uint4(blk, my_gid, (uint32_t)step, (uint32_t)(step >> 32));
   };
-  auto finish_draw = [&](const uint4& ra, const uint4& rb, unsigned long long step) {
-    u_pre[0] = u32_to_uniform(ra.x); u_pre[1] = u32_to_uniform(ra.y);
-    u_pre[2] = u32_to_uniform(ra.z); u_pre[3] = u32_to_uniform(ra.w);
-    u_pre[4] = u32_to_uniform(rb.x); u_pre[5] = u32_to_uniform(rb.y);
-    u_pre[6] = u32_to_uniform(rb.z); u_pre[7] = u32_to_uniform(rb.w);
-    if (acc_in_b) {
-      u_pre_acc = u_pre[4];
+  auto finish_draw = [&](const uint4 (&cs)[ND], unsigned long long step) {
+#pragma unroll
+    for (int d = 0; d < UPRE; ++d) {
+      u_pre[4 * d + 0] = u32_to_uniform(cs[d].x); u_pre[4 * d + 1] = u32_to_uniform(cs[d].y);
+      u_pre[4 * d + 2] = u32_to_uniform(cs[d].z); u_pre[4 * d + 3] = u32_to_uniform(cs[d].w);
+    }
+    if (ND > UPRE) {
+      u_pre_acc = u32_to_uniform(cs[ND - 1].x);
+    } else if (acc_in_b) {
+      u_pre_acc = u_pre[4 * (UPRE - 1)];
     } else {
       const uint4 r = philox4x32_10(
           make_uint4(VMC_ACCEPT_BLOCK, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
@@ -756,7 +763,10 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
     }
   };
   auto draw_all = [&](unsigned long long step) {     // un-overlapped form
-    finish_draw(philox4x32_10(ctr_a(step), key), philox4x32_10(ctr_b(step), key), step);
+    uint4 cs[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) cs[d] = philox4x32_10(ctr_of(d, step), key);
+    finish_draw(cs, step);
   };
 
   // branch-free (v_cndmask) argmax / argmin combine with the first-index tie rule of
@@ -997,14 +1007,18 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
       // 2*TO MFMAs, so the VALU work issues in the shadow of the matrix pipe.
       f32x4 inb[2];
       inb[0] = xin[0];
-      uint4 ca = ctr_a(next_step), cb = ctr_b(next_step);
-      uint2 ka = key, kb = key;
-      constexpr int NPIECE = 2 * FS;
-      constexpr int RPP = NPIECE > 1 ? (20 + NPIECE - 2) / (NPIECE - 1) : 20;   // rounds / piece
+      uint4 cs[ND];
+      uint2 ks[ND];
+#pragma unroll
+      for (int d = 0; d < ND; ++d) { cs[d] = ctr_of(d, next_step); ks[d] = key; }
+      constexpr int NPIECE = 2 * FS, NROUND = 10 * ND;
+      constexpr int RPP = NPIECE > 1 ? (NROUND + NPIECE - 2) / (NPIECE - 1) : NROUND;   // rounds / piece
       auto piece = [&](int p) {
 #pragma unroll
-        for (int q = p * RPP; q < (p + 1) * RPP && q < 20; ++q) {
-          if (q & 1) philox_round(cb, kb); else philox_round(ca, ka);
+        for (int q = p * RPP; q < (p + 1) * RPP && q < NROUND; ++q) {
+#pragma unroll
+          for (int d = 0; d < ND; ++d)
+            if (q % ND == d) philox_round(cs[d], ks[d]);
         }
       };
 #pragma unroll
@@ -1020,7 +1034,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
           if (r == 3) { piece(2 * ti + 1); __builtin_amdgcn_sched_barrier(0); }
         }
       }
-      if (FS > 0) finish_draw(ca, cb, next_step);
+      if (FS > 0) finish_draw(cs, next_step);
       if (FS > 0) { SWEEP_STAMP(9) }
       // streamed k-tiles: weights PF-1 tiles ahead, activations one tile ahead
       if (FS == 0) inb[0] = xin[0];
@@ -1119,10 +1133,10 @@ __global__ __launch_bounds__(NW * 64) void k_sweep16(SweepArgs a) {
     for (int i = tid; i < 16 * (Hp / 4); i += NTH) {   // 16-byte loads, <= 2 per thread
       const int c = i / (Hp / 4), c4 = i % (Hp / 4), gc = chain0 + c;
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (gc < a.B) v = *(const f32x4*)(a.z1 + (long long)gc * Hp + 4 * c4);
+      if (gc < a.B) v = *(const f32x4*)(a.z1_in + (long long)gc * Hp + 4 * c4);
       *(f32x4*)(s_z1 + c * ZS + 4 * c4) = v;
     }
-    if (tid < 16) s_logit[tid] = chain0 + tid < a.B ? a.logit[chain0 + tid] : 0.f;
+    if (tid < 16) s_logit[tid] = chain0 + tid < a.B ? a.logit_in[chain0 + tid] : 0.f;
     onsite_direct();
     if (use_pref) draw_all(a.step0);
     __syncthreads();
@@ -1192,49 +1206,63 @@ size_t sweep_lds_required(int N, int Hp, int n_hidden, bool rbm) {
   return sweep_lds_bytes(N, Hp, n_hidden, false, rbm);
 }
 
-template <int NT, int NW, bool RBM>
+template <int NT, int NW, int RTP, bool RBM>
 static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
   const dim3 grid((a.B + 15) / 16), block(NW * 64);
   const size_t lds_full = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, true, RBM);
-  const bool w1l = lds_full <= 160 * 1024;
+  const bool w1l = lds_full <= 160 * 1024 && !a.no_w1l;
   const size_t lds = w1l ? lds_full : sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false, RBM);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int nblk = (a.N + 3) / 4;
-  const bool fast = nblk <= 32 && a.inj_up == nullptr && a.dbg_up == nullptr;
-#define SWEEP_LAUNCH(ST, WL, FA)                                                              \
+  const bool plain = a.inj_up == nullptr && a.dbg_up == nullptr;
+  const bool fast2 = nblk <= 32 && plain, fast4 = nblk <= 64 && plain;
+#define SWEEP_LAUNCH(ST, WL, FA, UP)                                                          \
   do {                                                                                        \
-    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, NW, ST, WL, FA, RBM>,       \
+    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, NW, RTP, ST, WL, FA, UP, RBM>, \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                            \
-    hipLaunchKernelGGL((k_sweep16<NT, NW, ST, WL, FA, RBM>), grid, block, lds, s, a);         \
+    hipLaunchKernelGGL((k_sweep16<NT, NW, RTP, ST, WL, FA, UP, RBM>), grid, block, lds, s, a); \
     return hipGetLastError();                                                                 \
   } while (0)
   if (a.dbg_cycles) {
-    if (!(w1l && fast) || RBM) return hipErrorInvalidValue;   // diagnostic build: production variant only
-    if constexpr (!RBM) SWEEP_LAUNCH(true, true, true);
+    if (!(w1l && fast2) || RBM || NW != 8) return hipErrorInvalidValue;   // diagnostic build: production variant only
+    if constexpr (!RBM && NW == 8) SWEEP_LAUNCH(true, true, true, 2);
   }
-  if (w1l) { if (fast) SWEEP_LAUNCH(false, true, true); else SWEEP_LAUNCH(false, true, false); }
-  if (fast) SWEEP_LAUNCH(false, false, true);
-  SWEEP_LAUNCH(false, false, false);
+  if (w1l) {
+    if (fast2) SWEEP_LAUNCH(false, true, true, 2);
+    if (fast4) SWEEP_LAUNCH(false, true, true, 4);
+    SWEEP_LAUNCH(false, true, false, 2);
+  }
+  if (fast2) SWEEP_LAUNCH(false, false, true, 2);
+  if (fast4) SWEEP_LAUNCH(false, false, true, 4);
+  SWEEP_LAUNCH(false, false, false, 2);
 #undef SWEEP_LAUNCH
+}
+
+// H = 256: 8 waves with 14 resident k-tiles (one workgroup per CU), or 4 waves with RT4
+// resident k-tiles at <= 256 registers, so that two workgroups share a CU and each one's serial
+// phases (proposal, z1' build, accept) run under the other's MFMAs
+#ifndef SWEEP_RT4
+#define SWEEP_RT4 8
+#endif
+template <bool RBM>
+static hipError_t launch_sweep16_r(hipStream_t s, const SweepArgs& a, int Hp) {
+  switch (Hp / 16) {
+#ifndef VMC_QUICK   // development builds (-DVMC_QUICK) only instantiate H = 256, fully_connected
+    case 4: return launch_sweep16_t<4, 4, SWEEP_RT, RBM>(s, a);
+    case 8: return launch_sweep16_t<8, 4, SWEEP_RT, RBM>(s, a);
+    case 12: return launch_sweep16_t<12, 4, SWEEP_RT, RBM>(s, a);
+#endif
+    case 16: return a.waves == 8 ? launch_sweep16_t<16, 8, SWEEP_RT, RBM>(s, a)
+                                 : launch_sweep16_t<16, 4, SWEEP_RT4, RBM>(s, a);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp) {
   if (a.B <= 0) return hipSuccess;
-  if (a.rbm) {
-    switch (Hp / 16) {
-      case 4: return launch_sweep16_t<4, 4, true>(s, a);
-      case 8: return launch_sweep16_t<8, 4, true>(s, a);
-      case 12: return launch_sweep16_t<12, 4, true>(s, a);
-      case 16: return a.waves == 8 ? launch_sweep16_t<16, 8, true>(s, a) : launch_sweep16_t<16, 4, true>(s, a);
-      default: return hipErrorInvalidValue;
-    }
-  }
-  switch (Hp / 16) {
-    case 4: return launch_sweep16_t<4, 4, false>(s, a);
-    case 8: return launch_sweep16_t<8, 4, false>(s, a);
-    case 12: return launch_sweep16_t<12, 4, false>(s, a);
-    case 16: return a.waves == 8 ? launch_sweep16_t<16, 8, false>(s, a) : launch_sweep16_t<16, 4, false>(s, a);
-    default: return hipErrorInvalidValue;
-  }
+#ifndef VMC_QUICK
+  if (a.rbm) return launch_sweep16_r<true>(s, a, Hp);
+#endif
+  return launch_sweep16_r<false>(s, a, Hp);
 }

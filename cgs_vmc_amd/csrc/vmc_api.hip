@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -23,6 +24,8 @@ struct ParamSet {
   float* z1 = nullptr;     // [B][Hp] cache for the ctx's chains
   float* onsite = nullptr; // [B] cached x . w_on (RBM)
   float* logit = nullptr;  // [B]
+  // psi only: the buffers the NEXT sampler launch writes (see vmc_ctx::configs_alt)
+  float *z1_alt = nullptr, *onsite_alt = nullptr, *logit_alt = nullptr;
   float* eloc = nullptr;   // [B]
   bool packed_valid = false, cache_valid = false, has_params = false;
   float shift = -10.f;     // wavefunctions.py:209
@@ -47,6 +50,23 @@ struct vmc_ctx {
   hipStream_t stream = nullptr;
   ParamSet ps[2];
   float* configs = nullptr;
+  // Double-buffered chain state.  A sampler launch reads {configs, z1, logit} and writes
+  // {configs_alt, z1_alt, logit_alt, onsite_alt, act_alt}; the two sets are swapped on the host
+  // right after the launch.  accumulate(R_t) on `stream` and sweep(R_t -> R_t+1) on
+  // `sweep_stream` therefore touch disjoint buffers and run concurrently (training.py:614-617:
+  // the two ops of a batch iteration are independent given the chains R_t).
+  float* configs_alt = nullptr;
+  float* act_alt = nullptr;
+  int parity = 0;                 // which physical buffer set is current (GEMM tables are per set)
+  hipStream_t sweep_stream = nullptr;   // private non-blocking stream of the sampler
+  bool overlap = true;            // CGS_VMC_OVERLAP=0: everything on `stream`
+  hipEvent_t ev_mark = nullptr;   // recorded on `stream` at the start of the latest accumulate
+  hipEvent_t ev_now = nullptr;    // scratch: "everything enqueued on `stream` so far"
+  hipEvent_t ev_sweep_done = nullptr;
+  bool sweep_pending = false;     // a sampler launch on sweep_stream that `stream` has not waited for
+  bool token = false;             // the latest entry point was an accumulate the next sweep may overtake
+  bool expect_sweep = false;      // the previous accumulate was overtaken by a sweep: leave it CUs
+  bool acc_since_sweep = false;   // a gradient accumulate may follow: the sampler hands over activations
   // Hamiltonian
   int n_bonds = 0;
   int2* bonds = nullptr;
@@ -65,8 +85,8 @@ struct vmc_ctx {
   bool acts_valid = false;   // act[] hold the activations of psi on the current chains
   std::vector<float*> delta;   // L views [B][Hp] into delta_all: d logit / d z_l
   float* delta_all = nullptr;
-  GemmArgs* d_batch[2] = {nullptr, nullptr};   // weight-gradient GEMM tables (w = eloc / ratio)
-  bool batch_ready[2] = {false, false};
+  GemmArgs* d_batch[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // weight-gradient GEMM tables [w = eloc / ratio][parity]
+  bool batch_ready[2][2] = {{false, false}, {false, false}};
   float *ratio = nullptr, *ones = nullptr;
   float *acc = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad_tmp = nullptr;
   long long adam_t = 0;
@@ -74,6 +94,7 @@ struct vmc_ctx {
   int splitk = 16;           // upper bound (workspace size); see pick_splitk
   int num_cus = 256;
   int sweep_waves = 8;       // waves per sweep workgroup at Hp = 256 (CGS_VMC_SWEEP_WAVES=4|8)
+  int sweep_no_w1l = 0;      // CGS_VMC_SWEEP_W1L=0: W1 stays in L2 (smaller LDS footprint)
   // stochastic reconfiguration (extension, sr.hip): sample store + CG vectors
   int sr_cap = 0, sr_n = 0, sr_iter = 0;
   float *sr_cfg = nullptr, *sr_act = nullptr, *sr_delta = nullptr;   // [cap B][N], [L][cap B][Hp] x2
@@ -115,11 +136,61 @@ int fail(vmc_ctx* c, int code, const std::string& msg) {
                   std::string(#expr) + ": " + hipGetErrorString(e_));                    \
   } while (0)
 
-#define CHECK_CTX(c) \
-  do { if (!(c)) return fail(nullptr, VMC_ERR_INVALID, "null ctx"); } while (0)
+// Every entry point runs on the ctx's device whatever the calling thread's current device is
+// (HIP's current device is per thread), and restores the caller's device on return.
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess) prev = cur;
+  }
+  ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// entry points that only touch the accumulators / scalars / host state
+#define CHECK_CTX(c)                                                      \
+  if (!(c)) return fail(nullptr, VMC_ERR_INVALID, "null ctx");            \
+  DeviceGuard device_guard_((c)->d.device)
+
+// every other entry point: the work it enqueues on `stream` may depend on the chains, so
+// `stream` first waits for a sampler launch still in flight on sweep_stream
+#define ENTER(c)                                                          \
+  CHECK_CTX(c);                                                           \
+  (c)->token = false;                                                     \
+  do { int rc_join_ = join_sweep(c); if (rc_join_ != VMC_OK) return rc_join_; } while (0)
 
 #define PROPAGATE(expr) \
   do { int rc_ = (expr); if (rc_ != VMC_OK) return rc_; } while (0)
+
+// CUs a sampler launch occupies (8 waves at 255 registers, or LDS, fill a CU per workgroup)
+int sweep_cus(const vmc_ctx* c) { return (c->B + 15) / 16; }
+
+// The sampler may overtake the accumulate enqueued just before it when it leaves the local-energy
+// kernel at least a quarter of the CUs; with one 16-chain tile per CU (config 3) there is nothing
+// to share and the launch stays on `stream`.
+bool can_overlap(const vmc_ctx* c) {
+  return c->overlap && sweep_cus(c) <= (3 * c->num_cus) / 4;
+}
+
+int join_sweep(vmc_ctx* c) {
+  if (c->sweep_pending) {
+    hipError_t e = hipStreamWaitEvent(c->stream, c->ev_sweep_done, 0);
+    if (e != hipSuccess) return fail(c, VMC_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+    c->sweep_pending = false;
+  }
+  return VMC_OK;
+}
+
+void swap_chain_buffers(vmc_ctx* c) {
+  ParamSet& p = c->ps[0];
+  std::swap(c->configs, c->configs_alt);
+  std::swap(p.z1, p.z1_alt); std::swap(p.logit, p.logit_alt); std::swap(p.onsite, p.onsite_alt);
+  std::swap(c->act_all, c->act_alt);
+  for (size_t l = 0; l < c->act.size(); ++l) c->act[l] = c->act_all + (long long)l * c->B * c->Hp;
+  c->parity ^= 1;
+}
 
 template <typename T>
 hipError_t dalloc(T** p, long long n) {
@@ -147,9 +218,9 @@ static void harvest_finished(vmc_ctx* c) {
 }
 
 struct Timer {
-  vmc_ctx* c; bool on; TimedRegion r;
-  Timer(vmc_ctx* ctx, const char* name)
-      : c(ctx), on(ctx->timing == 1 || (ctx->timing == 2 && (!strcmp(name, "sweep") || !strcmp(name, "tail_eloc")))) {
+  vmc_ctx* c; hipStream_t st; bool on; TimedRegion r;
+  Timer(vmc_ctx* ctx, const char* name, hipStream_t stream = nullptr, bool own_stream = false)
+      : c(ctx), st(own_stream ? stream : ctx->stream), on(ctx->timing == 1 || (ctx->timing == 2 && (!strcmp(name, "sweep") || !strcmp(name, "tail_eloc")))) {
     if (on) {
       r.name = name;
       if (c->event_pool.empty()) harvest_finished(c);
@@ -159,11 +230,11 @@ struct Timer {
         r.start = c->event_pool.back().first; r.stop = c->event_pool.back().second;
         c->event_pool.pop_back();
       }
-      hipEventRecord(r.start, c->stream);
+      hipEventRecord(r.start, st);
     }
   }
   ~Timer() {
-    if (on) { hipEventRecord(r.stop, c->stream); c->pending.push_back(r); }
+    if (on) { hipEventRecord(r.stop, st); c->pending.push_back(r); }
   }
 };
 
@@ -294,6 +365,9 @@ int local_energy_device(vmc_ctx* c, int which) {
     a.n_rows_dev = c->off + c->B;
     a.n_rows = (int)((long long)c->B * c->n_bonds);
     a.out = c->val;
+    // a sampler launch is expected to overtake this accumulate: its workgroups need a whole
+    // CU each, so the persistent grid leaves them free
+    if (c->expect_sweep && can_overlap(c)) a.num_cus = c->num_cus - sweep_cus(c);
     HIPCHK(c, launch_tail(c->stream, a, c->Hp, true, c->rbm));
   }
   {
@@ -378,6 +452,8 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   c->P = vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
   c->stream = (hipStream_t)d->stream;
   if (const char* e = getenv("CGS_VMC_SWEEP_WAVES")) c->sweep_waves = atoi(e) == 8 ? 8 : 4;
+  if (const char* e = getenv("CGS_VMC_SWEEP_W1L")) c->sweep_no_w1l = atoi(e) == 0 ? 1 : 0;
+  if (const char* e = getenv("CGS_VMC_OVERLAP")) c->overlap = atoi(e) != 0;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -399,18 +475,28 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     CA(hipMemsetAsync(p.onsite, 0, B * sizeof(float), c->stream));
     CA(dalloc(&p.woutp, Hp)); CA(dalloc(&p.bout, 1));
     CA(dalloc(&p.z1, B * Hp)); CA(dalloc(&p.logit, B)); CA(dalloc(&p.eloc, B));
+    if (w == 0) {
+      CA(dalloc(&p.z1_alt, B * Hp)); CA(dalloc(&p.logit_alt, B)); CA(dalloc(&p.onsite_alt, B));
+      CA(hipMemsetAsync(p.onsite_alt, 0, B * sizeof(float), c->stream));
+    }
   }
-  CA(dalloc(&c->configs, B * N));
+  CA(dalloc(&c->configs, B * N)); CA(dalloc(&c->configs_alt, B * N));
   CA(hipMemsetAsync(c->configs, 0, B * N * sizeof(float), c->stream));
+  CA(hipMemsetAsync(c->configs_alt, 0, B * N * sizeof(float), c->stream));
   c->act.resize(L, nullptr);
-  CA(dalloc(&c->act_all, L * B * Hp));
+  CA(dalloc(&c->act_all, L * B * Hp)); CA(dalloc(&c->act_alt, L * B * Hp));
   CA(hipMemsetAsync(c->act_all, 0, L * B * Hp * sizeof(float), c->stream));
+  CA(hipMemsetAsync(c->act_alt, 0, L * B * Hp * sizeof(float), c->stream));
+  CA(hipStreamCreateWithFlags(&c->sweep_stream, hipStreamNonBlocking));
+  CA(hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming));
+  CA(hipEventCreateWithFlags(&c->ev_now, hipEventDisableTiming));
+  CA(hipEventCreateWithFlags(&c->ev_sweep_done, hipEventDisableTiming));
   for (int l = 0; l < L; ++l) c->act[l] = c->act_all + l * B * Hp;
   c->delta.resize(L, nullptr);
   CA(dalloc(&c->delta_all, L * B * Hp));
   CA(hipMemsetAsync(c->delta_all, 0, L * B * Hp * sizeof(float), c->stream));
   for (int l = 0; l < L; ++l) c->delta[l] = c->delta_all + l * B * Hp;
-  for (int i = 0; i < 2; ++i) CA(dalloc(&c->d_batch[i], L + 1));
+  for (int i = 0; i < 4; ++i) CA(dalloc(&c->d_batch[i / 2][i % 2], L + 1));
   CA(dalloc(&c->ratio, B)); CA(dalloc(&c->ones, B));
   CA(launch_fill(c->stream, c->ones, 1.f, B));
   CA(dalloc(&c->acc, 2 * P + 8)); CA(dalloc(&c->adam_m, P)); CA(dalloc(&c->adam_v, P));
@@ -435,17 +521,23 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
 
 void vmc_destroy(vmc_ctx* c) {
   if (!c) return;
+  DeviceGuard device_guard_(c->d.device);
+  if (c->sweep_stream) hipStreamSynchronize(c->sweep_stream);
   hipStreamSynchronize(c->stream);
   drain_timings(c);
+  if (c->sweep_stream) hipStreamDestroy(c->sweep_stream);
+  for (hipEvent_t e : {c->ev_mark, c->ev_now, c->ev_sweep_done}) if (e) hipEventDestroy(e);
   for (auto& e : c->event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   for (int w = 0; w < 2; ++w) {
     ParamSet& p = c->ps[w];
-    float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p16, p.p16t, p.woutp, p.bout, p.z1, p.logit, p.eloc, p.won, p.onsite};
+    float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p16, p.p16t, p.woutp, p.bout, p.z1, p.logit, p.eloc, p.won, p.onsite,
+                     p.z1_alt, p.logit_alt, p.onsite_alt};
     for (float* q : ptrs) if (q) hipFree(q);
   }
   if (c->act_all) hipFree(c->act_all);
-  void* ptrs[] = {c->configs, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
-                  c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0], c->d_batch[1], c->ratio, c->ones, c->acc,
+  if (c->act_alt) hipFree(c->act_alt);
+  void* ptrs[] = {c->configs, c->configs_alt, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
+                  c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->d_accepted, c->d_sum,
                   c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->tmp_on, c->tmp_rowinfo, c->rowinfo_id, c->bond_dummy, c->inj_up, c->inj_dn, c->inj_u,
                   c->acc_mask};
@@ -457,7 +549,7 @@ void vmc_destroy(vmc_ctx* c) {
 }
 
 int vmc_set_bonds(vmc_ctx* c, int32_t n_bonds, const int32_t* ij, const float* j_x, const float* j_z) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (n_bonds < 1 || !ij || !j_x || !j_z) return fail(c, VMC_ERR_INVALID, "bad bond arguments");
   std::vector<int2> b(n_bonds);
   std::vector<float> hx(n_bonds), qz(n_bonds);
@@ -486,7 +578,7 @@ int vmc_set_bonds(vmc_ctx* c, int32_t n_bonds, const int32_t* ij, const float* j
 }
 
 int vmc_set_params(vmc_ctx* c, int which, const float* theta) {
-  CHECK_CTX(c);
+  ENTER(c);
   if ((which != 0 && which != 1) || !theta) return fail(c, VMC_ERR_INVALID, "bad arguments");
   HIPCHK(c, hipMemcpyAsync(c->ps[which].theta, theta, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -497,7 +589,7 @@ int vmc_set_params(vmc_ctx* c, int which, const float* theta) {
 }
 
 int vmc_get_params(vmc_ctx* c, int which, float* theta) {
-  CHECK_CTX(c);
+  ENTER(c);
   if ((which != 0 && which != 1) || !theta) return fail(c, VMC_ERR_INVALID, "bad arguments");
   if (!c->ps[which].has_params) return fail(c, VMC_ERR_STATE, "parameters not set");
   HIPCHK(c, hipMemcpyAsync(theta, c->ps[which].theta, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -506,7 +598,7 @@ int vmc_get_params(vmc_ctx* c, int which, float* theta) {
 }
 
 int vmc_transfer_params(vmc_ctx* c) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!c->ps[0].has_params) return fail(c, VMC_ERR_STATE, "parameters not set");
   HIPCHK(c, hipMemcpyAsync(c->ps[1].theta, c->ps[0].theta, c->P * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   c->ps[1].has_params = true;
@@ -515,7 +607,7 @@ int vmc_transfer_params(vmc_ctx* c) {
 }
 
 int vmc_set_configs(vmc_ctx* c, const float* configs) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!configs) return fail(c, VMC_ERR_INVALID, "null configs");
   const long long n = (long long)c->B * c->N;
   for (long long i = 0; i < n; ++i)
@@ -527,7 +619,7 @@ int vmc_set_configs(vmc_ctx* c, const float* configs) {
 }
 
 int vmc_get_configs(vmc_ctx* c, float* configs) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!configs) return fail(c, VMC_ERR_INVALID, "null configs");
   HIPCHK(c, hipMemcpyAsync(configs, c->configs, (long long)c->B * c->N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -549,7 +641,7 @@ int vmc_get_shift(vmc_ctx* c, int which, float* shift) {
 }
 
 int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, float* logit, float* psi) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (which != 0 && which != 1) return fail(c, VMC_ERR_INVALID, "bad which");
   if (n_rows < 0) return fail(c, VMC_ERR_INVALID, "n_rows < 0");
   std::vector<float> host((size_t)n_rows);
@@ -578,14 +670,19 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
   return VMC_OK;
 }
 
+// One sampler launch: reads the current chain buffers, writes the alternate set, swaps.
+//   overtake: the launch goes to sweep_stream and only waits for `dep` (an event on `stream`)
 static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int* dbg_up, int* dbg_dn,
-                     float* dbg_u, unsigned long long step0, bool count_accepted = false) {
+                     float* dbg_u, unsigned long long step0, bool count_accepted = false,
+                     bool overtake = false, hipEvent_t dep = nullptr) {
   PROPAGATE(ensure_packed(c, 0));
+  ParamSet& p = c->ps[0];
   SweepArgs a;
   memset(&a, 0, sizeof(a));
-  a.pp = c->ps[0].packed();
-  a.configs = c->configs; a.z1 = c->ps[0].z1; a.logit = c->ps[0].logit;
-  a.onsite = c->ps[0].onsite; a.rbm = c->rbm ? 1 : 0;
+  a.pp = p.packed();
+  a.configs_in = c->configs; a.z1_in = p.z1; a.logit_in = p.logit;
+  a.configs = c->configs_alt; a.z1 = p.z1_alt; a.logit = p.logit_alt;
+  a.onsite = p.onsite_alt; a.rbm = c->rbm ? 1 : 0;
   a.accepted = c->d_accepted;
   if (injected) { a.inj_up = c->inj_up; a.inj_dn = c->inj_dn; a.inj_u = c->inj_u; a.acc_mask = c->acc_mask; }
   if (dbg) { a.dbg_up = dbg_up; a.dbg_dn = dbg_dn; a.dbg_u = dbg_u; }
@@ -593,15 +690,28 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   a.chain_offset = c->d.chain_offset;
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = step0; a.n_steps = n_steps;
-  a.waves = c->sweep_waves;
-  a.act_out = dbg ? nullptr : c->act_all;
-  a.cache_in_valid = (!dbg && !injected && c->ps[0].cache_valid) ? 1 : 0;
-  c->acts_valid = !dbg;
+  a.waves = c->sweep_waves; a.no_w1l = c->sweep_no_w1l;
+  // the activations of the final chains are handed to the gradient path only when a gradient
+  // accumulate has been seen since the previous launch (equilibration / evaluation sweeps skip
+  // the [L][B][Hp] write-back; gradient_sums then recomputes them)
+  const bool hand_over = !dbg && (injected || c->acc_since_sweep || c->sr_cap > 0);
+  a.act_out = hand_over ? c->act_alt : nullptr;
+  a.cache_in_valid = (!dbg && !injected && p.cache_valid) ? 1 : 0;
+  hipStream_t st = overtake ? c->sweep_stream : c->stream;
+  if (overtake) HIPCHK(c, hipStreamWaitEvent(st, dep, 0));
   // the device counter is only zeroed when the caller will read it back
-  if (count_accepted) HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), c->stream));
+  if (count_accepted) HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), st));
   {
-    Timer t(c, "sweep");
-    HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
+    Timer t(c, "sweep", st, true);
+    HIPCHK(c, launch_sweep16(st, a, c->Hp));
+  }
+  if (dbg) return VMC_OK;               // the proposal dump writes nothing back
+  swap_chain_buffers(c);
+  c->acts_valid = hand_over;
+  c->acc_since_sweep = false;
+  if (overtake) {
+    HIPCHK(c, hipEventRecord(c->ev_sweep_done, st));
+    c->sweep_pending = true;
   }
   return VMC_OK;
 }
@@ -609,22 +719,40 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
 int vmc_mc_steps(vmc_ctx* c, int64_t n_steps, int64_t* accepted) {
   CHECK_CTX(c);
   if (n_steps < 0) return fail(c, VMC_ERR_INVALID, "n_steps < 0");
-  PROPAGATE(run_sweep(c, n_steps, false, false, nullptr, nullptr, nullptr, c->step, accepted != nullptr));
+  // training.py:614-617: accumulate_gradients and the following mc_steps only share the chains
+  // R_t, which the sampler reads and never writes in place, so the launch need not wait for the
+  // accumulate that was enqueued just before it: it waits for the event recorded when that
+  // accumulate STARTED.  Anything else in between (or a re-pack of the parameters) makes it wait
+  // for everything enqueued so far.
+  const bool after_acc = c->token && c->ps[0].packed_valid;
+  c->token = false;
+  const bool overtake = can_overlap(c);
+  hipEvent_t dep = c->ev_mark;
+  if (overtake && !after_acc) {
+    PROPAGATE(ensure_packed(c, 0));
+    HIPCHK(c, hipEventRecord(c->ev_now, c->stream));
+    dep = c->ev_now;
+  }
+  if (!overtake) PROPAGATE(join_sweep(c));
+  c->expect_sweep = overtake && after_acc;
+  PROPAGATE(run_sweep(c, n_steps, false, false, nullptr, nullptr, nullptr, c->step, accepted != nullptr,
+                      overtake, dep));
   c->step += (unsigned long long)n_steps;
   c->ps[0].cache_valid = true;   // the sweep kernel writes back an exact z1/logit cache
   c->ps[1].cache_valid = false;
   c->list_valid = false;
   if (accepted) {
+    hipStream_t st = overtake ? c->sweep_stream : c->stream;
     unsigned long long h = 0;
-    HIPCHK(c, hipMemcpyAsync(&h, c->d_accepted, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(&h, c->d_accepted, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
     *accepted = (int64_t)h;
   }
   return VMC_OK;
 }
 
 int vmc_mc_step_injected(vmc_ctx* c, const int32_t* i_up, const int32_t* i_dn, const float* u, uint8_t* accept_mask) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!i_up || !i_dn || !u) return fail(c, VMC_ERR_INVALID, "null proposals");
   for (int b = 0; b < c->B; ++b)
     if (i_up[b] < 0 || i_up[b] >= c->N || i_dn[b] < 0 || i_dn[b] >= c->N)
@@ -641,7 +769,7 @@ int vmc_mc_step_injected(vmc_ctx* c, const int32_t* i_up, const int32_t* i_dn, c
 }
 
 int vmc_debug_proposals(vmc_ctx* c, uint64_t step, int32_t* i_up, int32_t* i_dn, float* u) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!i_up || !i_dn || !u) return fail(c, VMC_ERR_INVALID, "null outputs");
   PROPAGATE(run_sweep(c, 0, false, true, c->inj_up, c->inj_dn, c->inj_u, step));
   HIPCHK(c, hipMemcpyAsync(i_up, c->inj_up, c->B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -652,7 +780,7 @@ int vmc_debug_proposals(vmc_ctx* c, uint64_t step, int32_t* i_up, int32_t* i_dn,
 }
 
 int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (n_steps < 1 || !phase_cycles) return fail(c, VMC_ERR_INVALID, "bad arguments");
   if (c->rbm) return fail(c, VMC_ERR_UNSUPPORTED, "the diagnostic sweep build exists for fully_connected only");
   PROPAGATE(ensure_packed(c, 0));
@@ -663,13 +791,15 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   SweepArgs a;
   memset(&a, 0, sizeof(a));
   a.pp = c->ps[0].packed();
-  a.configs = c->configs; a.z1 = c->ps[0].z1; a.logit = c->ps[0].logit;
-  a.accepted = c->d_accepted; a.dbg_cycles = d; a.waves = c->sweep_waves;
+  a.configs_in = c->configs; a.z1_in = c->ps[0].z1; a.logit_in = c->ps[0].logit;
+  a.configs = c->configs_alt; a.z1 = c->ps[0].z1_alt; a.logit = c->ps[0].logit_alt;
+  a.accepted = c->d_accepted; a.dbg_cycles = d; a.waves = 8;
   a.B = c->B; a.N = c->N; a.n_hidden = c->n_hh; a.chain_offset = c->d.chain_offset;
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = c->step; a.n_steps = n_steps;
-  c->acts_valid = false;
   HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
+  swap_chain_buffers(c);
+  c->acts_valid = false;
   c->step += (unsigned long long)n_steps;
   c->ps[0].cache_valid = true; c->ps[1].cache_valid = false; c->list_valid = false;
   std::vector<unsigned long long> h((size_t)grid * 128);
@@ -688,7 +818,7 @@ int vmc_get_step_counter(vmc_ctx* c, uint64_t* step) { CHECK_CTX(c); if (!step) 
 int vmc_set_step_counter(vmc_ctx* c, uint64_t step) { CHECK_CTX(c); c->step = step; return VMC_OK; }
 
 int vmc_local_energy(vmc_ctx* c, int which, float* eloc, double* mean) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (which != 0 && which != 1) return fail(c, VMC_ERR_INVALID, "bad which");
   PROPAGATE(local_energy_device(c, which));
   if (mean) HIPCHK(c, launch_sum(c->stream, c->ps[which].eloc, c->B, c->d_sum));
@@ -704,7 +834,7 @@ int vmc_local_energy(vmc_ctx* c, int which, float* eloc, double* mean) {
 }
 
 int vmc_local_energy_terms(vmc_ctx* c, int which, float* diag, float* offdiag_over_psi) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (which != 0 && which != 1) return fail(c, VMC_ERR_INVALID, "bad which");
   PROPAGATE(local_energy_device(c, which));
   if (diag) HIPCHK(c, hipMemcpyAsync(diag, c->diag, c->B * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -745,8 +875,8 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
   // give dW, the implicit ones row gives db (b_l sits right behind w_l in theta), the unscaled
   // product goes to g1 and the w-scaled one to g2.  All NH+2 of them run as ONE batched launch
   // (+ one reduction launch); the argument table is built once per weight vector `w`.
-  const int slot = (w == c->ratio) ? 1 : 0;
-  if (!c->batch_ready[slot]) {
+  const int slot = (w == c->ratio) ? 1 : 0, par = c->parity;
+  if (!c->batch_ready[slot][par]) {
     std::vector<GemmArgs> tab;
     const long long ws_stride = (long long)c->splitk * 2 * ((N > H ? N : H) + 1) * H;
     auto add = [&](const float* a, long long a_ld, int k_in, const float* delta, long long sbk,
@@ -764,10 +894,10 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
       add(c->act[NH], Hp, H, c->ones, 1, 0, 1, off_wout(c));
     for (int l = NH; l > 0; --l) add(c->act[l - 1], Hp, H, c->delta[l], Hp, 1, H, off_w(c, l));
     add(c->configs, N, N, c->delta[0], Hp, 1, H, off_w(c, 0));
-    HIPCHK(c, hipMemcpy(c->d_batch[slot], tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
-    c->batch_ready[slot] = true;
+    HIPCHK(c, hipMemcpy(c->d_batch[slot][par], tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
+    c->batch_ready[slot][par] = true;
   }
-  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot], NH + 2, N > H ? N : H, H, pick_splitk(c, B)));
+  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot][par], NH + 2, N > H ? N : H, H, pick_splitk(c, B)));
   return VMC_OK;
 }
 
@@ -789,11 +919,16 @@ static int sr_record(vmc_ctx* c) {
 }
 
 int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (mode != VMC_MODE_ENERGY_GRADIENT && mode != VMC_MODE_LOG_OVERLAP_ITSWO)
     return fail(c, VMC_ERR_INVALID, "bad mode");
   const float* w = nullptr;
   const float* e = nullptr;
+  // everything this call enqueues comes after ev_mark; a sampler launch that follows directly
+  // may start as soon as ev_mark has passed (vmc_mc_steps).  If this call has to rebuild the
+  // psi cache the sampler reads, the launch must wait for all of it instead.
+  const bool cache_was_valid = c->ps[0].cache_valid && c->ps[0].packed_valid;
+  HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));
   if (mode == VMC_MODE_ENERGY_GRADIENT) {
     PROPAGATE(local_energy_device(c, VMC_PSI));               // training.py:542-543
     w = e = c->ps[0].eloc;
@@ -809,6 +944,8 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   PROPAGATE(gradient_sums(c, w));
   HIPCHK(c, launch_scalar_accum(c->stream, e, mode == 1 ? c->ratio : nullptr, c->B, c->acc + 2 * c->P, mode));
   if (c->sr_cap > 0 && mode == VMC_MODE_ENERGY_GRADIENT) PROPAGATE(sr_record(c));
+  c->acc_since_sweep = true;
+  c->token = cache_was_valid;
   return VMC_OK;
 }
 
@@ -884,7 +1021,7 @@ int vmc_get_gradient(vmc_ctx* c, int mode, float* grad) {
 }
 
 int vmc_apply_adam(vmc_ctx* c, int mode, float lr, float beta1, float beta2, float eps, double* energy) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (mode != 0 && mode != 1) return fail(c, VMC_ERR_INVALID, "bad mode");
   if (!c->ps[0].has_params) return fail(c, VMC_ERR_STATE, "parameters not set");
   c->adam_t += 1;
@@ -919,7 +1056,7 @@ int vmc_set_adam_state(vmc_ctx* c, const float* m, const float* v, int64_t t) {
 }
 
 int vmc_update_norm(vmc_ctx* c, float max_value) {
-  CHECK_CTX(c);
+  ENTER(c);
   PROPAGATE(ensure_cache(c, VMC_PSI));
   HIPCHK(c, launch_max(c->stream, c->ps[0].logit, c->B, c->d_max));
   float mx = 0.f;
@@ -937,12 +1074,13 @@ int vmc_update_norm(vmc_ctx* c, float max_value) {
 
 int vmc_epoch_energy_gradient(vmc_ctx* c, int64_t n_eq_steps, int32_t n_batches, int64_t n_mc_steps,
                               float max_value) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (n_eq_steps < 0 || n_batches < 0 || n_mc_steps < 0) return fail(c, VMC_ERR_INVALID, "negative count");
   PROPAGATE(vmc_mc_steps(c, n_eq_steps, nullptr));                       // training.py:608-609
   if (max_value > 0.f) PROPAGATE(vmc_update_norm(c, max_value));          // training.py:611-612
   PROPAGATE(vmc_reset_accumulators(c));                                   // training.py:613
   for (int b = 0; b < n_batches; ++b) {                                   // training.py:614-617
+    c->expect_sweep = n_mc_steps > 0;
     PROPAGATE(vmc_accumulate(c, VMC_MODE_ENERGY_GRADIENT, 0.f));
     PROPAGATE(vmc_mc_steps(c, n_mc_steps, nullptr));
   }
@@ -952,7 +1090,7 @@ int vmc_epoch_energy_gradient(vmc_ctx* c, int64_t n_eq_steps, int32_t n_batches,
 int vmc_epoch_log_overlap(vmc_ctx* c, float beta, int64_t n_eq_steps, int32_t n_batches,
                           int64_t n_mc_steps, float max_value, float lr, float beta1, float beta2,
                           float eps, double* energy) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (n_eq_steps < 0 || n_batches < 0 || n_mc_steps < 0) return fail(c, VMC_ERR_INVALID, "negative count");
   PROPAGATE(vmc_mc_steps(c, n_eq_steps, nullptr));                       // training.py:750-751
   if (max_value > 0.f) PROPAGATE(vmc_update_norm(c, max_value));          // training.py:753-754
@@ -969,7 +1107,7 @@ int vmc_epoch_log_overlap(vmc_ctx* c, float beta, int64_t n_eq_steps, int32_t n_
 
 // ------------------------------------------------------------------ stochastic reconfiguration
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_tang, c->sr_t, c->sr_ones};
@@ -1036,7 +1174,7 @@ static int sr_read_rr(vmc_ctx* c, int idx, double* rr) {
 }
 
 int vmc_sr_begin(vmc_ctx* c, double* rr0) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (c->sr_cap <= 0) return fail(c, VMC_ERR_STATE, "vmc_sr_reserve first");
   if (c->sr_n <= 0) return fail(c, VMC_ERR_STATE, "no samples recorded (vmc_accumulate in ENERGY_GRADIENT mode)");
   PROPAGATE(sr_build_table(c));
@@ -1047,7 +1185,7 @@ int vmc_sr_begin(vmc_ctx* c, double* rr0) {
 
 // u[0..P) = sum over this rank's stored samples of (O_b . p) O_b,  u[P] = sum (O_b . p)
 int vmc_sr_matvec_partial(vmc_ctx* c) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!c->sr_begun) return fail(c, VMC_ERR_STATE, "vmc_sr_begin first");
   const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->A;
   const long long R = (long long)c->sr_cap * B;   // row stride between layers of the store
@@ -1099,7 +1237,7 @@ int vmc_sr_buffer_devptr(vmc_ctx* c, void** dev_ptr, int64_t* n_floats) {
 }
 
 int vmc_sr_get_buffer(vmc_ctx* c, float* host) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!host || !c->sr_u) return fail(c, VMC_ERR_INVALID, "null / vmc_sr_reserve first");
   HIPCHK(c, hipMemcpyAsync(host, c->sr_u, (c->P + 1) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1107,7 +1245,7 @@ int vmc_sr_get_buffer(vmc_ctx* c, float* host) {
 }
 
 int vmc_sr_set_buffer(vmc_ctx* c, const float* host) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!host || !c->sr_u) return fail(c, VMC_ERR_INVALID, "null / vmc_sr_reserve first");
   HIPCHK(c, hipMemcpyAsync(c->sr_u, host, (c->P + 1) * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1115,7 +1253,7 @@ int vmc_sr_set_buffer(vmc_ctx* c, const float* host) {
 }
 
 int vmc_sr_cg_update(vmc_ctx* c, float diag_shift, double* rr) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!c->sr_begun) return fail(c, VMC_ERR_STATE, "vmc_sr_begin first");
   const int cur = c->sr_iter & 1;
   HIPCHK(c, launch_sr_q(c->stream, c->sr_u, c->acc, (int)c->P, c->sr_p, diag_shift, c->sr_q, c->sr_partial, c->sr_sc));
@@ -1125,7 +1263,7 @@ int vmc_sr_cg_update(vmc_ctx* c, float diag_shift, double* rr) {
 }
 
 int vmc_sr_solve(vmc_ctx* c, float diag_shift, float tol, int32_t max_iter, int32_t* iters, double* rel_residual) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (max_iter < 0 || tol < 0.f) return fail(c, VMC_ERR_INVALID, "bad CG arguments");
   double rr0 = 0.0, rr = 0.0;
   PROPAGATE(vmc_sr_begin(c, &rr0));
@@ -1142,7 +1280,7 @@ int vmc_sr_solve(vmc_ctx* c, float diag_shift, float tol, int32_t max_iter, int3
 }
 
 int vmc_sr_get_solution(vmc_ctx* c, float* x) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!x || !c->sr_x) return fail(c, VMC_ERR_INVALID, "null / vmc_sr_reserve first");
   HIPCHK(c, hipMemcpyAsync(x, c->sr_x, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1150,7 +1288,7 @@ int vmc_sr_get_solution(vmc_ctx* c, float* x) {
 }
 
 int vmc_sr_apply(vmc_ctx* c, float lr, double* energy) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!c->sr_begun) return fail(c, VMC_ERR_STATE, "vmc_sr_begin / vmc_sr_solve first");
   HIPCHK(c, launch_sr_apply(c->stream, c->ps[0].theta, c->sr_x, lr, (int)c->P));
   c->ps[0].packed_valid = c->ps[0].cache_valid = false;
@@ -1161,7 +1299,7 @@ int vmc_sr_apply(vmc_ctx* c, float lr, double* energy) {
 }
 
 int vmc_sr_debug_matvec(vmc_ctx* c, const float* v, float diag_shift, float* out) {
-  CHECK_CTX(c);
+  ENTER(c);
   if (!v || !out) return fail(c, VMC_ERR_INVALID, "null");
   PROPAGATE(vmc_sr_begin(c, nullptr));
   HIPCHK(c, hipMemcpyAsync(c->sr_p, v, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -1202,11 +1340,16 @@ int vmc_timing_get(vmc_ctx* c, const char* name, double* ms, int64_t* launches) 
   return VMC_OK;
 }
 
-int vmc_synchronize(vmc_ctx* c) { CHECK_CTX(c); HIPCHK(c, hipStreamSynchronize(c->stream)); return VMC_OK; }
+int vmc_synchronize(vmc_ctx* c) {
+  ENTER(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->sweep_stream));
+  return VMC_OK;
+}
 
 int vmc_debug_gemm(vmc_ctx* c, int32_t M, int32_t N, int32_t K, const float* A, int64_t sam, int64_t sak,
                    int64_t a_len, const float* B, int64_t sbk, int64_t sbn, int64_t b_len, float* C) {
-  CHECK_CTX(c);
+  ENTER(c);
   float *dA = nullptr, *dB = nullptr, *dC = nullptr, *ws = nullptr;
   HIPCHK(c, dalloc(&dA, a_len)); HIPCHK(c, dalloc(&dB, b_len)); HIPCHK(c, dalloc(&dC, (long long)M * N));
   HIPCHK(c, dalloc(&ws, 4LL * M * N));

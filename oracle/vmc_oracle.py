@@ -414,10 +414,12 @@ def apply_in_place(amp_fn, configs, bonds, j_x, j_z, psi=None, dtype=np.float32)
 def constant_psi_local_energy(configs, bonds, j_x, j_z):
   """Closed form for psi == const: 0.25*jz*(n_par - n_anti) + 0.5*jx*n_anti."""
   x = np.asarray(configs, np.float64)
+  jx = np.broadcast_to(np.asarray(j_x, np.float64), (len(bonds),))
+  jz = np.broadcast_to(np.asarray(j_z, np.float64), (len(bonds),))
   e = np.zeros(x.shape[0])
-  for (i, j) in bonds:
+  for k, (i, j) in enumerate(bonds):
     sz = x[:, i] * x[:, j]
-    e += 0.25 * j_z * sz + 0.5 * j_x * (sz < 0)
+    e += 0.25 * jz[k] * sz + 0.5 * jx[k] * (sz < 0)
   return e
 
 

@@ -187,7 +187,10 @@ def test_injected_mc_step_matches_oracle(n, h, L, b, kind):
 
 
 @pytest.mark.parametrize('n,h,L,b', [(16, 32, 2, 64),      # prefetched-draw sampler, W1 in LDS
-                                     (150, 64, 2, 40)])    # N > 128: general sampler path
+                                     (150, 64, 2, 40),     # 128 < N <= 256: four prefetched site blocks per lane
+                                     (256, 64, 2, 24),     # N = 256: every lane's four blocks are sites
+                                     (252, 256, 3, 20),    # H = 256 (8 waves), W1 streamed from L2
+                                     (300, 64, 2, 24)])    # N > 256: general sampler path
 def test_sampler_trajectory_follows_oracle(n, h, L, b):
   """vmc_mc_steps with its own Philox stream reproduces the oracle's chains step by step
   (chains whose accept test falls in the tolerance band are excluded from then on)."""

@@ -7,26 +7,40 @@ from oracle import vmc_oracle as vo
 
 pytestmark = pytest.mark.gpu
 
+# name: (lx, ly, next-nearest bonds too, L, H, chains per GPU)
 FULL = {
-    'config2_6x6_h128_b1024': (6, 6, 3, 128, 1024),
-    'config3_10x10_h256_b4096': (10, 10, 3, 256, 4096),
+    'config2_6x6_h128_b1024': (6, 6, False, 3, 128, 1024),
+    'config3_10x10_h256_b4096': (10, 10, False, 3, 256, 4096),
+    # BASELINE config 5, one GPU's shard: NN + NNN bonds with per-bond couplings J1 = 1, J2 = 0.5
+    'config5_16x16_j1j2_h256_L6_b1024': (16, 16, True, 6, 256, 1024),
 }
+
+
+def _couplings(name, bonds, jx_sign=-1.0):
+  """(j_x, j_z) of the workload: scalars for the NN lattices, per-bond arrays for J1-J2."""
+  if not FULL[name][2]:
+    return jx_sign, 1.0
+  nb = len(bonds)
+  j = np.concatenate([np.ones(nb // 2), 0.5 * np.ones(nb // 2)]).astype(np.float32)
+  return jx_sign * j, j
 
 
 def _setup(name, seed=2024, chains=None, offset=0):
   import bench
   from cgs_vmc_amd.engine import VmcEngine
-  lx, ly, L, h, b = FULL[name]
+  lx, ly, nnn, L, h, b = FULL[name]
   n = lx * ly
   theta, cfg = bench.make_inputs(n, h, L, b, 0)
-  bonds = vo.torus_bonds(lx, ly)
+  bonds = vo.torus_bonds(lx, ly, nnn)
+  if nnn:
+    assert len(bonds) == 4 * n
   if chains is not None:
     cfg = cfg[offset:offset + chains]
     b = chains
   eng = VmcEngine(n, b, L, h, seed=seed, chain_offset=offset)
   eng.set_params(theta)
   eng.set_configs(cfg)
-  eng.set_bonds(bonds, -1.0, 1.0)
+  eng.set_bonds(bonds, *_couplings(name, bonds))
   return eng, theta, cfg, bonds, (n, h, L, b)
 
 
@@ -36,7 +50,8 @@ def test_sweeps_conserve_sz_are_deterministic_and_shard_invariant(name):
   acc = eng.mc_steps(2 * n)
   out = eng.get_configs()
   assert (np.abs(out) == 1).all() and (out.sum(1) == cfg.sum(1)).all()
-  assert 0.02 < acc / (2.0 * n * b) < 0.98
+  # (the deep random-init network of config 5 is nearly flat: almost every move is accepted)
+  assert 0.02 < acc / (2.0 * n * b) < (0.98 if L <= 3 else 1.0) and (out != cfg).any()
   # same seed, same inputs -> bit-identical chains, logits and energies
   eng2, *_ = _setup(name)
   eng2.mc_steps(2 * n)
@@ -56,7 +71,7 @@ def test_sweeps_conserve_sz_are_deterministic_and_shard_invariant(name):
   amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
   ref = vo.fc_logit(theta, out[idx], h, L, dtype=np.float64)
   assert np.abs(logit_cached[idx] - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
-  e_ref = vo.local_value(amp, out[idx], bonds, -1.0, 1.0, dtype=np.float64)
+  e_ref = vo.local_value(amp, out[idx], bonds, *_couplings(name, bonds), dtype=np.float64)
   e = eng.local_energy()[0]
   assert np.abs(e[idx] - e_ref).max() < 2e-4 * max(1.0, np.abs(e_ref).max())
   for x in (eng, eng2, half):
@@ -67,9 +82,10 @@ def test_sweeps_conserve_sz_are_deterministic_and_shard_invariant(name):
 def test_constant_wavefunction_closed_form_at_full_size(name):
   eng, theta, cfg, bonds, (n, h, L, b) = _setup(name)
   eng.set_params(np.zeros_like(theta))
-  eng.set_bonds(bonds, 0.6, 1.0)
+  jx, jz = _couplings(name, bonds, jx_sign=0.6)
+  eng.set_bonds(bonds, jx, jz)
   np.testing.assert_allclose(eng.local_energy()[0],
-                             vo.constant_psi_local_energy(cfg, bonds, 0.6, 1.0), rtol=1e-6)
+                             vo.constant_psi_local_energy(cfg, bonds, jx, jz), rtol=1e-6, atol=1e-5)
   eng.close()
 
 
@@ -102,7 +118,8 @@ def test_accumulators_are_additive_over_calls_and_shards(name):
   sub.reset_accumulators()
   sub.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
   acc = vo.Accumulators(p, np.float64)
-  vo.energy_gradient_accumulate(acc, theta, cfg[:64], bonds, -1.0, 1.0, -10.0, h, L, np.float64)
+  jx, jz = _couplings(name, bonds)
+  vo.energy_gradient_accumulate(acc, theta, cfg[:64], bonds, jx, jz, -10.0, h, L, np.float64)
   g = sub.get_gradient(_hip.VMC_MODE_ENERGY_GRADIENT)
   gref = vo.energy_gradient(acc)
   assert np.abs(g - gref).max() < 2e-3 * np.abs(gref).max() + 2e-4
@@ -121,7 +138,7 @@ def test_full_size_engine_matches_oracle_on_sampled_chains(name):
   def check(configs):
     sub = configs[pick]
     ref_logit = vo.fc_logit(theta, sub, h, L, dtype=np.float64)
-    ref_eloc = vo.local_value(amp, sub, bonds, -1.0, 1.0, dtype=np.float64)
+    ref_eloc = vo.local_value(amp, sub, bonds, *_couplings(name, bonds), dtype=np.float64)
     logit = eng.amplitude()[0][pick]
     eloc = eng.local_energy()[0][pick]
     assert np.abs(logit - ref_logit).max() <= 2e-5 * max(1.0, np.abs(ref_logit).max())
