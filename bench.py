@@ -15,12 +15,23 @@ and, for N > 1, the RCCL all-reduce of the accumulator buffer (2P+8 floats).
 second, whole job.  mc_sweeps_per_sec counts batch sweeps as the reference does (one sweep =
 num_sites mc_steps on the whole batch); local_energy_evals_per_sec = chains x steps / time
 spent in the local-energy kernels.
+
+Protocol: W warm-up steps, then the timed region of EXACTLY K steps (barrier +
+synchronize on both sides, max over ranks) is repeated REPS = 5 times back to back and the
+MEDIAN repetition is reported (`repetitions_ms_per_step` lists all five).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N ranks of
+itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) before it
+touches the GPU, relays rank 0's JSON line and exits non-zero if any rank fails.  Under
+torch.distributed.run the ranks already exist and `--gpus` must equal WORLD_SIZE.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +43,7 @@ if ROOT not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
 HBM_PEAK_GBS = 8000.0
+REPS = 5                        # repetitions of the timed region; the median is reported
 
 WORKLOADS = {
     # name: (lx, ly, next_nearest, L, H, B per GPU)
@@ -49,6 +61,15 @@ def f_amp(n, h, L):
 def torus_bonds(lx, ly, nnn):
   from cgs_vmc_amd import lattice
   return lattice.torus_bonds(lx, ly, nnn)
+
+
+def couplings(n_bonds, nnn):
+  """(j_x, j_z) per bond: antiferromagnet in the Marshall-rotated frame (j_x = -J, j_z = J);
+  J1 = 1 on the nearest-neighbour bonds, J2 = 0.5 on the next-nearest ones (config 5)."""
+  j = np.ones(n_bonds, np.float32)
+  if nnn:
+    j[n_bonds // 2:] = 0.5
+  return -j, j
 
 
 def make_inputs(n, h, L, b, chain_offset):
@@ -74,61 +95,146 @@ def make_inputs(n, h, L, b, chain_offset):
   return theta, cfg
 
 
-def cpu_baseline(n, h, L, bonds, theta, cfg, seconds_budget=25.0):
-  """Times the oracle (numpy restatement with the reference's call structure: one host call
-  per mc_step with two forwards, 1 + n_bonds full-batch forwards per local energy, two
-  back-prop passes per accumulate) on a bounded sample of the same workload."""
-  from oracle import vmc_oracle as vo
+# ----------------------------------------------------------------------------- CPU baseline
+def _blas_info():
   try:
     import threadpoolctl
     info = threadpoolctl.threadpool_info()
-    threads = max([i.get('num_threads', 1) for i in info] or [1])
+    blas = [i for i in info if i.get('user_api') == 'blas'] or info
+    return (max([i.get('num_threads', 1) for i in blas] or [1]),
+            ', '.join(sorted({'{} {}'.format(i.get('internal_api', '?'), i.get('version', ''))
+                              for i in blas})))
   except Exception:  # pylint: disable=broad-except
-    threads = os.cpu_count() or 1
-  # bounded sample: a slice of the chains, one full step (accumulate + sweep) on it
-  bs = min(cfg.shape[0], 4096)
-  sub = cfg[:bs].copy()
+    return os.cpu_count() or 1, 'unknown'
+
+
+def _cpu_step_seconds(vo, theta, cfg, bonds, jx, jz, h, L, n, mc_steps_timed):
+  """One step of the reference's structure on `cfg`: accumulate_gradients + one sweep (the
+  sweep is timed on `mc_steps_timed` of its n mc_steps and scaled)."""
   acc = vo.Accumulators(theta.size, np.float32)
   t0 = time.perf_counter()
-  vo.energy_gradient_accumulate(acc, theta, sub, bonds, -1.0, 1.0, -10.0, h, L, np.float32)
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, jx, jz, -10.0, h, L, np.float32)
   t_acc = time.perf_counter() - t0
   t0 = time.perf_counter()
-  n_steps = n
-  # stop early if the sweep alone would blow the budget
-  done = 0
-  cur = sub
-  while done < n_steps:
-    cur, _ = vo.run_sweeps(theta, cur, 10, 2024, done, h, L)
-    done += 10
-    if time.perf_counter() - t0 > seconds_budget:
-      break
-  t_sweep = (time.perf_counter() - t0) * (n_steps / done)
-  step_s = t_acc + t_sweep
-  return {
-      'value': bs / step_s, 'unit': 'chain-evals/s', 'cores': int(threads), 'kind': 'port',
-      'sample': '{} chains x 1 step (accumulate {:.2f}s + sweep {:.2f}s, {} of {} mc_steps '
-                'timed); numpy fp32 restatement of the reference algorithm (TF1 unavailable)'
-                .format(bs, t_acc, t_sweep, done, n_steps),
-      'mc_sweeps_per_sec_batch{}'.format(bs): 1.0 / t_sweep,
-      'local_energy_evals_per_sec': bs / t_acc,
-  }
+  vo.run_sweeps(theta, cfg, mc_steps_timed, 2024, 0, h, L)
+  t_sweep = (time.perf_counter() - t0) * (n / float(mc_steps_timed))
+  return t_acc, t_sweep
 
 
+def cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg):
+  """Times the oracle (numpy fp32 restatement with the reference's call structure: one host
+  call per mc_step with two forwards, 1 + n_bonds full-batch forwards per local energy, two
+  back-prop passes per accumulate; no rank-2 update, no bond skipping) on a bounded sample of
+  the same workload: median of 3 repetitions, with all BLAS threads and single-threaded."""
+  from oracle import vmc_oracle as vo
+  threads, blas = _blas_info()
+  flops_per_chain_step = (1 + len(bonds) + 2 * n) * f_amp(n, h, L)
+  out = {'unit': 'chain-evals/s', 'kind': 'port', 'cores': int(threads), 'blas': blas,
+         'host_cpu_count': os.cpu_count()}
+
+  def measure(bs, mc_steps_timed, reps):
+    sub = np.ascontiguousarray(cfg[:bs])
+    runs = [_cpu_step_seconds(vo, theta, sub, bonds, jx, jz, h, L, n, mc_steps_timed)
+            for _ in range(reps)]
+    runs.sort(key=lambda r: r[0] + r[1])
+    return runs[len(runs) // 2]
+
+  # all cores: a batch large enough for the BLAS to thread (2048 chains on a many-core host,
+  # 512 on a small one); ~10-20 s in total
+  bs_all = min(cfg.shape[0], 2048 if threads >= 32 else 512)
+  steps_all = max(4, min(n, 20))
+  measure(min(bs_all, 64), 2, 1)                       # page in BLAS, first-touch
+  t_acc, t_sweep = measure(bs_all, steps_all, 3)
+  out['value'] = bs_all / (t_acc + t_sweep)
+  out['mc_sweeps_per_sec_per_chain'] = 1.0 / t_sweep * bs_all
+  out['local_energy_evals_per_sec'] = bs_all / t_acc
+  out['sample'] = ('median of 3: {} chains x 1 step = accumulate_gradients ({:.2f} s) + sweep '
+                   '({:.2f} s scaled from {} of {} mc_steps); numpy fp32 restatement of the '
+                   'reference algorithm (TensorFlow 1.x unavailable), {} BLAS threads'
+                   .format(bs_all, t_acc, t_sweep, steps_all, n, threads))
+  # single thread: 64 chains
+  try:
+    import threadpoolctl
+    with threadpoolctl.threadpool_limits(limits=1):
+      bs_1 = min(cfg.shape[0], 64)
+      steps_1 = max(2, min(n, 10))
+      a1, s1 = measure(bs_1, steps_1, 3)
+    out['single_thread'] = {
+        'value': bs_1 / (a1 + s1), 'unit': 'chain-evals/s', 'cores': 1,
+        'gflops': flops_per_chain_step * bs_1 / (a1 + s1) / 1e9,
+        'sample': 'median of 3: {} chains x 1 step (accumulate {:.2f} s + sweep {:.2f} s scaled '
+                  'from {} of {} mc_steps)'.format(bs_1, a1, s1, steps_1, n)}
+  except Exception as e:  # pylint: disable=broad-except
+    out['single_thread'] = {'error': repr(e)}
+  out['all_threads'] = {'value': out['value'], 'cores': int(threads), 'sample': out['sample']}
+  st = out['single_thread']
+  if 'value' in st and st['value'] > out['value']:
+    # small batches that stay in one core's cache beat the threaded BLAS on this host: the
+    # reported baseline is the faster of the two configurations
+    out['value'], out['cores'], out['sample'] = st['value'], 1, st['sample'] + '; numpy fp32 restatement of the reference algorithm (TensorFlow 1.x unavailable)'
+  out['gflops'] = flops_per_chain_step * out['value'] / 1e9
+  return out
+
+
+# ----------------------------------------------------------------------------- rank launcher
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  return port
+
+
+def spawn_ranks(n_ranks):
+  """Starts `n_ranks` copies of this script (one per GPU) and relays rank 0's output.  Runs
+  before this process has made any GPU / HIP call: the children are fresh processes."""
+  port = os.environ.get('MASTER_PORT') or str(_free_port())
+  procs = []
+  for r in range(n_ranks):
+    env = dict(os.environ)
+    env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(n_ranks),
+                'LOCAL_WORLD_SIZE': str(n_ranks), 'MASTER_ADDR': '127.0.0.1',
+                'MASTER_PORT': port, 'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')})
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                  env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+  out0, _ = procs[0].communicate()
+  codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+  sys.stdout.write(out0.decode())
+  sys.stdout.flush()
+  bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+  if bad:
+    sys.stderr.write('bench.py: ranks failed (rank, exit code): {}\n'.format(bad))
+    return 1
+  return 0
+
+
+# ----------------------------------------------------------------------------- main
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=20)
-  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--steps', type=int, default=100)
+  ap.add_argument('--warmup', type=int, default=10)
   ap.add_argument('--workload', default='heisenberg10x10_fc3x256_b4096', choices=sorted(WORKLOADS))
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-timing', action='store_true', help='disable per-kernel HIP events')
+  ap.add_argument('--reps', type=int, default=REPS, help='repetitions of the timed region (median reported)')
   args = ap.parse_args()
+
+  if args.gpus < 1:
+    ap.error('--gpus must be >= 1')
+  env_world = os.environ.get('WORLD_SIZE')
+  if env_world is None and args.gpus > 1:
+    sys.exit(spawn_ranks(args.gpus))          # no GPU call has been made in this process
+  world = int(env_world or '1')
+  if world != args.gpus:
+    sys.stderr.write('bench.py: --gpus {} but WORLD_SIZE={}; start {} ranks (or drop WORLD_SIZE and '
+                     'let bench.py start them)\n'.format(args.gpus, world, args.gpus))
+    sys.exit(2)
 
   import torch
   from cgs_vmc_amd import _hip, parallel
   from cgs_vmc_amd.engine import VmcEngine
 
-  world = int(os.environ.get('WORLD_SIZE', '1'))
   if world > 1:
     parallel.init_from_env('nccl')
   rank = parallel.rank()
@@ -139,16 +245,14 @@ def main():
   n = lx * ly
   bonds = torus_bonds(lx, ly, nnn)
   nb = len(bonds)
+  jx, jz = couplings(nb, nnn)
   chain_offset = rank * b
   theta, cfg = make_inputs(n, h, L, b, chain_offset)
 
   eng = VmcEngine(n, b, L, h, device=dev, chain_offset=chain_offset, seed=2024)
   eng.set_params(theta)
   eng.set_configs(cfg)
-  j = np.ones(nb, np.float32)
-  if nnn:
-    j[nb // 2:] = 0.5                               # J1 = 1 on the NN bonds, J2 = 0.5 on the NNN bonds
-  eng.set_bonds(bonds, -j, j)
+  eng.set_bonds(bonds, jx, jz)
   for _ in range(10):                              # 10 warm-up sweeps, one launch each
     eng.mc_steps(n, want_accepted=False)           # (every k_sweep16 launch of a run is one sweep, so
                                                    # rocprofv3's per-kernel average is per sweep)
@@ -174,19 +278,23 @@ def main():
   for _ in range(args.warmup):
     step()
   eng.reset_accumulators()
-  # HIP events on the library's stream: inside the timed region only around the two roofline
+  # HIP events on the library's streams: inside the timed region only around the two roofline
   # kernels (every recorded event drains the pipeline between two kernels, ~3.5 us); the small
   # kernels are timed in a few extra steps after the timed region
   eng.timing_enable(0 if args.no_timing else 2)
   eng.timing_reset()
-  barrier()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    step()
-  barrier()
-  elapsed = time.perf_counter() - t0
-  if world > 1:
-    elapsed = parallel.allreduce_max(elapsed)
+  rep_s = []
+  for _ in range(max(1, args.reps)):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+      elapsed = parallel.allreduce_max(elapsed)
+    rep_s.append(elapsed)
+  elapsed = sorted(rep_s)[len(rep_s) // 2]
   eng.timing_enable(False)
   main_timings = {name: eng.timing_get(name) for name in ('sweep', 'tail_eloc')}
   if not args.no_timing:
@@ -197,7 +305,16 @@ def main():
     barrier()
     eng.timing_enable(False)
 
-  rows = eng.last_connected_rows()
+  # the RCCL all-reduce alone (blocking), for the record
+  allreduce_ms = None
+  if world > 1:
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(10):
+      parallel.allreduce_accumulators(eng)
+    barrier()
+    allreduce_ms = parallel.allreduce_max(1e3 * (time.perf_counter() - t0) / 10)
+
   eng.local_energy(want_eloc=False)
   rows = eng.last_connected_rows()
   mean_e = eng.mean_energy()
@@ -210,15 +327,25 @@ def main():
 
   if rank == 0:
     fa = f_amp(n, h, L)
+    hp = (h + 63) // 64 * 64
+    n_hh = L - 1
+    mfma_per_row = 2 * n_hh * hp * hp               # H x H layers of one amplitude, on MFMA
+    p = n * h + h + n_hh * (h * h + h) + h + 1
     flops_eloc = b * (1 + nb) * fa                  # nominal per E_loc batch
     flops_sweep = b * n * fa                        # nominal per sweep
-    exec_per_row = fa - 2 * n * h                   # rank-2 first layer: layer-1 GEMM skipped
+    # executed on the matrix cores: one row per mc_step + the exact refresh of the final
+    # chains (sweep); one row per antiparallel bond (local energy); delta chain + the dual
+    # weight-gradient GEMMs (gradient sums)
+    exec_sweep = b * (n + 1) * mfma_per_row
+    exec_eloc = rows * mfma_per_row
+    exec_grad = b * (n_hh * 2 * hp * hp + 4 * (n * h + n_hh * h * h + h))
+    ms_step = 1e3 * elapsed / args.steps
     out = {
         'metric': 'mc_sweep+local_energy_evals_per_sec',
         'value': world * b * args.steps / elapsed,
         'unit': 'chain-evals/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * elapsed / args.steps,
+        'ms_per_step': ms_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': args.workload, 'lattice': '{}x{} torus'.format(lx, ly),
@@ -228,10 +355,15 @@ def main():
                            + (' + RCCL accumulator all-reduce (overlapped with the sweep)'
                               if world > 1 else ''),
                    'parallelism': 'chains sharded x{}'.format(world)},
+        'repetitions': len(rep_s), 'statistic': 'median',
+        'repetitions_ms_per_step': [1e3 * t / args.steps for t in rep_s],
         'mean_energy_per_site': mean_e / n,
         'connected_rows_last_eloc': rows,
         'kernels': timings,
     }
+    if world > 1:
+      out['rccl'] = {'ranks': world, 'allreduce_floats': 2 * p + 8,
+                     'allreduce_ms_blocking': allreduce_ms}
     if 'sweep' in timings and 'tail_eloc' in timings:
       ts = timings['sweep']['ms_avg'] * 1e-3
       te = timings['tail_eloc']['ms_avg'] * 1e-3
@@ -243,47 +375,55 @@ def main():
       out['local_energy_evals_per_sec'] = world * b / t_eloc_call
       dom = 'sweep' if timings['sweep']['ms_total'] >= timings['tail_eloc']['ms_total'] else 'tail_eloc'
       per_kernel = {
-          'k_sweep16': {'achieved': flops_sweep / ts / 1e12, 'ms_avg': ts * 1e3,
-                        'flops_nominal': flops_sweep,
-                        'flops_executed': b * (n + 2) * exec_per_row},
-          'k_tail16(eloc)': {'achieved': flops_eloc / te / 1e12, 'ms_avg': te * 1e3,
-                             'flops_nominal': flops_eloc, 'flops_executed': rows * exec_per_row},
+          'k_sweep16': {'ms_avg': ts * 1e3, 'flops_executed': exec_sweep, 'flops_nominal': flops_sweep},
+          'k_tail16(eloc)': {'ms_avg': te * 1e3, 'flops_executed': exec_eloc, 'flops_nominal': flops_eloc},
       }
       for v in per_kernel.values():
+        t = v['ms_avg'] * 1e-3
+        v['achieved'] = v['flops_executed'] / t / 1e12         # TFLOP/s issued to the matrix cores
         v['frac'] = v['achieved'] / FP32_MFMA_PEAK_TFLOPS
-        v['executed_tflops'] = v['flops_executed'] / (v['ms_avg'] * 1e-3) / 1e12
-        v['executed_frac'] = v['executed_tflops'] / FP32_MFMA_PEAK_TFLOPS
+        v['algorithmic_tflops'] = v['flops_nominal'] / t / 1e12   # SURVEY 8d count / time; not a roofline fraction
       key = 'k_sweep16' if dom == 'sweep' else 'k_tail16(eloc)'
       # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command
-      # (profiles/r1_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc runs; see
+      # (profiles/*_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc runs; see
       # tools/collect_profiles.sh); null when no matching profile is present
       traffic = None
-      tpath = os.path.join(ROOT, 'profiles', 'r1_traffic.json')
-      if os.path.exists(tpath) and args.workload == 'heisenberg10x10_fc3x256_b4096':
+      pmc = None
+      tag = {'heisenberg10x10_fc3x256_b4096': 'r2', 'heisenberg16x16j1j2_fc6x256_b1024': 'r2_config5'}.get(args.workload)
+      tpath = os.path.join(ROOT, 'profiles', '{}_traffic.json'.format(tag))
+      if tag and os.path.exists(tpath):
         try:
           prof = json.load(open(tpath))
           for name, rec in prof.items():
             if name.startswith(key.split('(')[0]) and rec.get('hbm_read_bytes') is not None:
               traffic = rec['hbm_read_bytes'] + (rec.get('hbm_write_bytes') or 0)
-              per_kernel[key]['pmc'] = {k: rec[k] for k in ('mfma_util', 'clock_ghz', 'median_us')}
+              pmc = {k: rec[k] for k in ('mfma_util', 'clock_ghz', 'median_us') if k in rec}
+              pmc['source'] = 'profiles/{}_traffic.json'.format(tag)
         except Exception:  # pylint: disable=broad-except
           traffic = None
+      nominal = per_kernel[key]['algorithmic_tflops']
       out['roofline'] = {
           'kernel': key, 'bound': 'mfma', 'achieved': per_kernel[key]['achieved'],
           'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': per_kernel[key]['frac'],
           'traffic': traffic,
-          'note': 'achieved = nominal algorithmic flops (SURVEY.md 8d) / HIP-event kernel time; '
-                  'executed_* counts the flops actually issued (antiparallel bonds only, rank-2 '
-                  'first layer); sustained fp32-MFMA rate of the streaming loop skeleton on '
-                  'this part is 141-144 TFLOP/s (tools/ubench/mfma_stream.hip, DESIGN.md 4)',
+          'nominal_achieved': nominal, 'nominal_frac': nominal / FP32_MFMA_PEAK_TFLOPS,
+          'step_frac': (exec_sweep + exec_eloc + exec_grad) / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+          'pmc': pmc,
+          'note': 'achieved / frac = flops ISSUED to the matrix cores (antiparallel bonds only, '
+                  'rank-2 first layer) / HIP-event kernel time / peak at the 2.4 GHz peak clock; it '
+                  'equals rocprofv3 MFMA-busy x (measured clock / 2.4 GHz).  nominal_* = SURVEY.md '
+                  '8d algorithmic count (includes the first-layer GEMM and the masked parallel '
+                  'bonds that are never executed) / the same time: a throughput, not a utilisation. '
+                  'step_frac = executed flops of the whole step / ms_per_step / peak.',
           'per_kernel': per_kernel,
       }
     if not args.no_cpu_baseline:
       try:
-        out['cpu_baseline'] = cpu_baseline(n, h, L, bonds, theta, cfg)
+        out['cpu_baseline'] = cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg)
       except Exception as e:  # pylint: disable=broad-except
         out['cpu_baseline'] = {'error': repr(e)}
     print(json.dumps(out))
+    sys.stdout.flush()
   eng.close()
   if world > 1:
     torch.distributed.barrier()

@@ -108,10 +108,36 @@ SIGNATURES = {
 }
 
 _lib = None
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+_STAMP_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libcgsvmc_hip.stamp')
+# the files the library is built from, in the order csrc/Makefile hashes them
+_SOURCES = ('vmc_api.hip', 'mlp.hip', 'sweep_fc.hip', 'sweep_rbm.hip', 'eloc.hip', 'grad.hip', 'sr.hip',
+            'conv.hip', 'common.hpp', 'sweep16.hpp',
+            os.path.join('..', '..', 'include', 'cgsvmc.h'))
 
 
 def library_path() -> str:
   return _LIB_PATH
+
+
+def source_hash() -> str:
+  """sha256 over the library's sources (same byte stream as `cat ... | sha256sum` in the
+  Makefile)."""
+  import hashlib
+  h = hashlib.sha256()
+  for name in _SOURCES:
+    with open(os.path.join(_CSRC, name), 'rb') as f:
+      h.update(f.read())
+  return h.hexdigest()
+
+
+def stamp_matches() -> bool:
+  """True when libcgsvmc_hip.so was linked from exactly the sources in the tree."""
+  try:
+    with open(_STAMP_PATH) as f:
+      return f.read().split()[0] == source_hash()
+  except (OSError, IndexError):
+    return False
 
 
 def load():
@@ -123,6 +149,10 @@ def load():
     raise HipLibraryError(
         '{} not found: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). '
         'The VMC hot path has no CPU fallback.'.format(_LIB_PATH))
+  if not stamp_matches():
+    raise HipLibraryError(
+        '{} was not built from the sources in {} (stamp mismatch): rebuild it with '
+        '__graft_entry__.build() or `make -C cgs_vmc_amd/csrc`.'.format(_LIB_PATH, _CSRC))
   try:
     lib = C.CDLL(_LIB_PATH)
   except OSError as e:

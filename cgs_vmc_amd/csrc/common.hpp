@@ -142,6 +142,7 @@ hipError_t launch_bond_list(hipStream_t s, const float* configs, const int2* bon
                             int* off, float* diag, int2* rowinfo);
 hipError_t launch_eloc_reduce(hipStream_t s, const int* off, const float* diag, const float* val,
                               int B, float* offdiag, float* eloc);
+hipError_t launch_check_pm1(hipStream_t s, const float* x, long long n, int* flag);
 hipError_t launch_sum(hipStream_t s, const float* x, int n, double* out_sum);
 hipError_t launch_max(hipStream_t s, const float* x, int n, float* out_max);
 

@@ -173,3 +173,22 @@ hipError_t launch_max(hipStream_t s, const float* x, int n, float* out_max) {
   hipLaunchKernelGGL(k_max, dim3(1), dim3(1024), 0, s, x, n, out_max);
   return hipGetLastError();
 }
+
+// vmc_set_configs: every entry must be exactly +1 or -1 (the sampler's argmax/argmin proposal
+// and the bond mask assume it); flag != 0 on violation
+__global__ void k_check_pm1(const float* __restrict__ x, long long n, int* __restrict__ flag) {
+  int bad = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    bad |= (v != 1.f && v != -1.f) ? 1 : 0;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+hipError_t launch_check_pm1(hipStream_t s, const float* x, long long n, int* flag) {
+  hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+  if (e != hipSuccess) return e;
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_check_pm1, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, x, n, flag);
+  return hipGetLastError();
+}

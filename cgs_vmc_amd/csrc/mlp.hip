@@ -24,12 +24,6 @@
 #ifndef TAIL_RD
 #define TAIL_RD 8     // stages of k_tail16's weight-fragment ring (items of 8 MFMAs each)
 #endif
-#ifndef SWEEP_RT
-#define SWEEP_RT 14   // resident k-tiles of the first H x H layer (sweep kernel)
-#endif
-#ifndef SWEEP_PF
-#define SWEEP_PF 2    // stages of the weight prefetch ring; (16 - SWEEP_RT) % SWEEP_PF == 0
-#endif
 
 // ------------------------------------------------------------------------------------ pack
 __global__ void k_pack(const float* __restrict__ theta, int N, int H, int Hp, ParamLayout lay,
@@ -535,734 +529,3 @@ hipError_t launch_backprop16(hipStream_t s, const float* act_all, float* delta_a
   return hipGetLastError();
 }
 
-// --------------------------------------------------------------------------------- sweep16
-// One workgroup (NW = 4 or 8 waves) owns 16 chains for the whole launch.  Per mc_step:
-//   proposals (Philox, argmax/argmin of s*u over sites: graph_builders.py:59-65)
-//   z1' = z1 + 2 (W1[i_dn] - W1[i_up])            (rank-2 form of the forward at :74)
-//   layers 2..L by 16x16x4 MFMA, wave w owns output units [w*Hp/NW, (w+1)*Hp/NW)
-//   accept = exp(logit' - logit) > sqrt(u)        (graph_builders.py:75-79), evaluated as
-//            logit' - logit > 0.5 log u by the wave that owns the chain
-// Chain state (spins, z1, logit) stays in LDS; z1 and logit are recomputed from the spins
-// at launch start and end so the cache written back never carries incremental drift.
-//
-// Weight traffic: the A-operand fragments of the first RT (= 14 of 16 at H = 256) k-tiles of
-// the FIRST H x H layer of this wave's output units are loaded once and stay in registers for
-// the whole launch; everything else streams from L2 through a PF-stage register ring whose
-// loads are issued PF-1 k-tiles ahead of their use and run across layer boundaries.
-// 16-lane (DPP row) all-reduce steps: lane^1, lane^2 (quad_perm), then row_half_mirror and
-// row_mirror, which combine the already-uniform quads / halves.  Pure VALU, no LDS crossbar.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
-}
-#define DPP_XOR1 0xB1
-#define DPP_XOR2 0x4E
-#define DPP_HALF_MIRROR 0x141
-#define DPP_MIRROR 0x140
-
-// s_memtime stamp for the diagnostic instantiation (STAMP = true) only; the production kernel
-// (STAMP = false) executes none of it.
-__device__ __forceinline__ unsigned long long vmc_stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-
-// W1L: the first-layer matrix W1 [N][Hp] also lives in LDS (when it fits), which turns the
-// rank-2 gather of two W1 rows per chain and step from an L2 round trip into LDS reads; the
-// accepted move is then folded into z1 lazily at the start of the next step instead of being
-// double-buffered.
-// FAST: the production path (Philox draws prefetched, no injected proposals, no debug dump);
-// the general instantiation keeps every path.
-// NW: waves per workgroup (4 or 8).  With 8 waves (2 per SIMD) each wave owns NT/8 output
-// tiles; the two co-resident waves hide each other's vmcnt / LDS stalls inside the layers.
-// Proposals, accept and the Philox chains stay on waves 0-3 (4 chains each).
-// RBM: RestrictedBoltzmannNetwork epilogue: the last layer's units go through log cosh (its
-// output "dot" is against ones) and the onsite term x . w_on is tracked per chain in LDS.
-// RTP: k-tiles of the first H x H layer whose fragments stay in registers (14 with 8 waves; the
-// 4-wave variant of H = 256 owns 4 output tiles per wave and keeps fewer so that it fits 256
-// registers, i.e. two workgroups per CU).
-// UPRE: Philox site blocks per lane drawn one step ahead (2: N <= 128 sites, 4: N <= 256).
-template <int NT, int NW, int RTP, bool STAMP, bool W1L, bool FAST, int UPRE, bool RBM = false>
-__global__ __launch_bounds__(NW * 64, NT == 16 ? 2 : 1) void k_sweep16(SweepArgs a) {
-  static_assert(NT % NW == 0, "output tiles must divide over the waves");
-  constexpr int NTH = NW * 64;
-  constexpr int Hp = NT * 16, TO = NT / NW, ZS = Hp + 4, W1S = Hp + 4, PF = SWEEP_PF;
-  constexpr int RT = NT < RTP ? NT : RTP;   // k-tiles of the first H x H layer kept in registers
-  static_assert((NT - RT) % PF == 0, "the streamed k-tiles of layer 0 must fill whole ring turns");
-  extern __shared__ float smem[];
-  const int N = a.N, Nst = (N + 3) & ~3;
-  float* s_spin = smem;                       // [16][Nst]
-  float* s_z1 = s_spin + 16 * Nst;            // [W1L ? 1 : 2][16][ZS]
-  float* s_x = s_z1 + (W1L ? 1 : 2) * 16 * ZS;  // [2][NT][64][4]
-  float* s_logit = s_x + 2 * NT * 256;        // [16]
-  float* s_u = s_logit + 16;                  // [16]
-  int* s_iup = (int*)(s_u + 16);              // [16]
-  int* s_idn = s_iup + 16;                    // [16]
-  int* s_sel = s_idn + 16;                    // [16]
-  int* s_pup = s_sel + 16;                    // [16] previous step's proposal / accept flag
-  int* s_pdn = s_pup + 16;                    // [16]
-  int* s_pacc = s_pdn + 16;                   // [16]
-  float* s_hlu = (float*)(s_pacc + 16);       // [16] 0.5 log(u_accept)
-  float* s_wout = s_hlu + 16;                 // [Hp]
-  float* s_bias = s_wout + Hp;                // [n_hidden][Hp] biases of the H x H layers
-  // RBM onsite weights: with W1 in LDS they live in the first padding float of each W1 row
-  // (s_w1[n * W1S + Hp]), otherwise in their own [Nst] array
-  float* s_won = s_bias + a.n_hidden * Hp;
-  float* s_on = s_won + ((RBM && !W1L) ? Nst : 0);   // [16] x . w_on of the committed chains (RBM only)
-  float* s_w1 = s_on + (RBM ? 16 : 0);        // [N][W1S] (W1L only)
-  auto won_at = [&](int n) { return W1L ? s_w1[n * W1S + Hp] : s_won[n]; };
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR
-  const int g = lane >> 4, j = lane & 15;
-  const int chain0 = blockIdx.x * 16;
-  const PackedParams& pp = a.pp;
-  const int n_hidden = a.n_hidden;
-  // [4 waves][16 chains] partials of the output dot live in the operand buffer the LAST layer does
-  // not read (free from the barrier at that layer's top until the next step's build, which
-  // comes after every reader of s_part has passed barrier0)
-  float* s_part = s_x + (n_hidden == 0 ? 1 : (n_hidden & 1)) * NT * 256;
-
-  for (int i = tid; i < 16 * Nst; i += NTH) {
-    const int c = i / Nst, n = i % Nst, gc = chain0 + c;
-    float v = 0.f;
-    if (n < N) v = gc < a.B ? a.configs_in[(long long)gc * N + n] : ((n & 1) ? -1.f : 1.f);
-    s_spin[i] = v;
-  }
-  if (tid < 16) { s_sel[tid] = 0; s_pacc[tid] = 0; s_pup[tid] = 0; s_pdn[tid] = 0; }
-  for (int i = tid; i < n_hidden * Hp; i += NTH) s_bias[i] = pp.bh[i];
-  for (int i = tid; i < Hp; i += NTH) s_wout[i] = pp.woutp[i];
-  if (RBM) {
-    if (W1L) { for (int i = tid; i < N; i += NTH) s_w1[i * W1S + Hp] = pp.won[i]; }
-    else { for (int i = tid; i < Nst; i += NTH) s_won[i] = i < N ? pp.won[i] : 0.f; }
-  }
-  if (W1L) {   // 8 loads in flight per thread: the copy costs one L2 round trip per 8 vectors
-    const int total = N * (Hp / 4);
-    for (int base = tid; base < total; base += 8 * NTH) {
-      f32x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = min(base + u * NTH, total - 1);
-        v[u] = *(const f32x4*)(pp.w1p + (long long)(i / (Hp / 4)) * Hp + 4 * (i % (Hp / 4)));
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = base + u * NTH;
-        if (i < total) *(f32x4*)(s_w1 + (i / (Hp / 4)) * W1S + 4 * (i % (Hp / 4))) = v[u];
-      }
-    }
-  }
-  const float bout = pp.bout[0];
-
-  // register-resident fragments of the first H x H layer
-  f32x4 wres[RT * TO];
-  if (n_hidden > 0) {
-    const f32x4* __restrict__ wp0 = (const f32x4*)pp.p16 + wave * TO * NT * 64;
-#pragma unroll
-    for (int ti = 0; ti < RT; ++ti)
-#pragma unroll
-      for (int to = 0; to < TO; ++to)
-        wres[ti * TO + to] = wp0[(to * NT + ti) * 64 + lane];
-  }
-  __syncthreads();
-
-  // z1 from the spins (first layer, exact): thread -> (column, chain group)
-  auto z1_direct = [&]() {
-    constexpr int GROUPS = NTH / Hp > 0 ? NTH / Hp : 1;   // chain groups when Hp < NTH
-    constexpr int CPG = 16 / GROUPS;
-    const int col = tid % Hp, grp = tid / Hp;
-    if (grp < GROUPS) {
-      float acc[CPG];
-      const float b = pp.b1p[col];
-#pragma unroll
-      for (int c = 0; c < CPG; ++c) acc[c] = b;
-      if (W1L) {   // W1 is LDS-resident: no global round trip per site
-        for (int n = 0; n < N; ++n) {
-          const float w = s_w1[n * W1S + col];
-#pragma unroll
-          for (int c = 0; c < CPG; ++c) acc[c] = fmaf(s_spin[(grp * CPG + c) * Nst + n], w, acc[c]);
-        }
-      } else {     // stream W1 from L2 eight rows at a time (all eight loads in flight together)
-        int n = 0;
-        for (; n + 8 <= N; n += 8) {
-          float w[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) w[u] = pp.w1p[(long long)(n + u) * Hp + col];
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int c = 0; c < CPG; ++c) acc[c] = fmaf(s_spin[(grp * CPG + c) * Nst + n + u], w[u], acc[c]);
-        }
-        for (; n < N; ++n) {
-          const float w = pp.w1p[(long long)n * Hp + col];
-#pragma unroll
-          for (int c = 0; c < CPG; ++c) acc[c] = fmaf(s_spin[(grp * CPG + c) * Nst + n], w, acc[c]);
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < CPG; ++c) s_z1[(grp * CPG + c) * ZS + col] = acc[c];
-    }
-  };
-  // exact onsite term of the committed spins (RBM): one thread per chain
-  auto onsite_direct = [&]() {
-    if (RBM && tid < 16) {
-      float acc = 0.f;
-      for (int n = 0; n < N; ++n) acc = fmaf(s_spin[tid * Nst + n], won_at(n), acc);
-      s_on[tid] = acc;
-    }
-  };
-
-  const uint2 key = make_uint2(a.seed_lo, a.seed_hi);
-  const int nblk = (N + 3) >> 2;
-
-  // ---- proposals (graph_builders.py:59-65).  Lane (c = 4*wave + g, sub = j) owns the site
-  // blocks sub, sub+16, ... of chain c.  The Philox draws of step t+1 do not depend on the
-  // chain state, so they are computed one step ahead inside the MFMA phase of step t (UPRE
-  // blocks per lane, i.e. N <= 64*UPRE/... sites); only the argmax/argmin of s*u is left for
-  // the start of the step.
-  // ND draws per lane and step: the UPRE site blocks j, j+16, ... and the acceptance block.  With
-  // UPRE = 2 the acceptance draw rides in lane 15's second slot when that block is beyond the
-  // lattice (N <= 124), so ND = 2; with UPRE = 4 it has a slot of its own (ND = 5).
-  constexpr int ND = UPRE == 2 ? 2 : UPRE + 1;
-  const bool use_pref = FAST || ((nblk <= 16 * UPRE) && (a.inj_up == nullptr));
-  const int my_c = wave * 4 + g;
-  const uint32_t my_gid = (uint32_t)(a.chain_offset + chain0 + my_c);
-  float u_pre[4 * UPRE];
-  float u_pre_acc = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4 * UPRE; ++i) u_pre[i] = 0.f;
-
-  const bool acc_in_b = (15 + 16 >= nblk);          // UPRE = 2: lane 15's second slot is free
-  auto ctr_of = [&](int d, unsigned long long step) {
-    uint32_t blk = (uint32_t)(j + 16 * d);
-    if (d >= UPRE) blk = VMC_ACCEPT_BLOCK;
-    else if (ND == UPRE && d == UPRE - 1 && j + 16 * d >= nblk) blk = VMC_ACCEPT_BLOCK;
-    return make_uint4(blk, my_gid, (uint32_t)step, (uint32_t)(step >> 32));
-  };
-  auto finish_draw = [&](const uint4 (&cs)[ND], unsigned long long step) {
-#pragma unroll
-    for (int d = 0; d < UPRE; ++d) {
-      u_pre[4 * d + 0] = u32_to_uniform(cs[d].x); u_pre[4 * d + 1] = u32_to_uniform(cs[d].y);
-      u_pre[4 * d + 2] = u32_to_uniform(cs[d].z); u_pre[4 * d + 3] = u32_to_uniform(cs[d].w);
-    }
-    if (ND > UPRE) {
-      u_pre_acc = u32_to_uniform(cs[ND - 1].x);
-    } else if (acc_in_b) {
-      u_pre_acc = u_pre[4 * (UPRE - 1)];
-    } else {
-      const uint4 r = philox4x32_10(
-          make_uint4(VMC_ACCEPT_BLOCK, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
-      u_pre_acc = u32_to_uniform(r.x);
-    }
-  };
-  auto draw_all = [&](unsigned long long step) {     // un-overlapped form
-    uint4 cs[ND];
-#pragma unroll
-    for (int d = 0; d < ND; ++d) cs[d] = philox4x32_10(ctr_of(d, step), key);
-    finish_draw(cs, step);
-  };
-
-  // branch-free (v_cndmask) argmax / argmin combine with the first-index tie rule of
-  // tf.argmax / tf.argmin
-  auto reduce_and_publish = [&](float vmax, int imax, float vmin, int imin, float uacc) {
-#define VMC_RED_STEP(CTRL)                                                            \
-    {                                                                                 \
-      const float ov = dpp_f<CTRL>(vmax); const int oi = dpp_i<CTRL>(imax);           \
-      const bool tmax = (ov > vmax) | ((ov == vmax) & (oi < imax));                   \
-      vmax = tmax ? ov : vmax; imax = tmax ? oi : imax;                               \
-      const float pv = dpp_f<CTRL>(vmin); const int pi = dpp_i<CTRL>(imin);           \
-      const bool tmin = (pv < vmin) | ((pv == vmin) & (pi < imin));                   \
-      vmin = tmin ? pv : vmin; imin = tmin ? pi : imin;                               \
-    }
-    VMC_RED_STEP(DPP_XOR1) VMC_RED_STEP(DPP_XOR2) VMC_RED_STEP(DPP_HALF_MIRROR) VMC_RED_STEP(DPP_MIRROR)
-#undef VMC_RED_STEP
-    if (j == 15) {
-      s_iup[my_c] = imax;   // argmax of s*u: the UP spin to lower   (graph_builders.py:64-65)
-      s_idn[my_c] = imin;   // argmin of s*u: the DOWN spin to raise (graph_builders.py:62-63)
-      s_u[my_c] = uacc;
-      s_hlu[my_c] = 0.5f * __logf(uacc);
-    }
-  };
-  // validity of this lane's 4*UPRE prefetched sites (bit k <-> site 4*(j+16*(k/4)) + k%4)
-  unsigned pre_valid = 0;
-#pragma unroll
-  for (int k = 0; k < 4 * UPRE; ++k)
-    if (4 * (j + 16 * (k / 4)) + (k % 4) < N) pre_valid |= 1u << k;
-
-  // proposals of absolute step `step` into s_iup / s_idn / s_u
-  auto proposals = [&](unsigned long long step) {
-    if (NW > 4 && wave >= 4) return;   // chains 4w..4w+3 belong to waves 0-3
-    if (!FAST && a.inj_up) {
-      if (tid < 16) {
-        const int gc = chain0 + tid;
-        const bool ok = gc < a.B;
-        s_iup[tid] = ok ? a.inj_up[gc] : 0;
-        s_idn[tid] = ok ? a.inj_dn[gc] : 1;
-        s_u[tid] = ok ? a.inj_u[gc] : 2.f;
-        s_hlu[tid] = 0.5f * __logf(s_u[tid]);
-      }
-      return;
-    }
-    float vmax = -3.f, vmin = 3.f;
-    int imax = 0x7fffffff, imin = 0x7fffffff;
-    if (use_pref) {       // uniforms were drawn during the previous step's MFMA phase
-      // branch-free: out-of-lattice sites read (valid LDS) garbage and are masked to -3 / +3
-#pragma unroll
-      for (int b = 0; b < UPRE; ++b) {
-        const int blk = j + 16 * b;
-        const f32x4 sp = *(const f32x4*)(s_spin + my_c * Nst + 4 * blk);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int n = 4 * blk + e;
-          const bool ok = (pre_valid >> (4 * b + e)) & 1u;
-          const float v = sp[e] * u_pre[4 * b + e];
-          const float vx = ok ? v : -3.f, vn = ok ? v : 3.f;
-          const bool tmax = vx > vmax, tmin = vn < vmin;
-          vmax = tmax ? vx : vmax; imax = tmax ? n : imax;
-          vmin = tmin ? vn : vmin; imin = tmin ? n : imin;
-        }
-      }
-      reduce_and_publish(vmax, imax, vmin, imin, u_pre_acc);
-      return;
-    }
-    if (FAST) return;
-    for (int blk = j; blk < nblk; blk += 16) {
-      const uint4 r = philox4x32_10(
-          make_uint4((uint32_t)blk, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
-      const f32x4 sp = *(const f32x4*)(s_spin + my_c * Nst + 4 * blk);
-      const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = 4 * blk + e;
-        if (n < N) {
-          const float v = sp[e] * u32_to_uniform(rr[e]);
-          if (v > vmax) { vmax = v; imax = n; }
-          if (v < vmin) { vmin = v; imin = n; }
-        }
-      }
-    }
-    float uacc = 0.f;
-    if (j == 15) {   // the lane with the fewest site blocks also draws the acceptance uniform
-      const uint4 r = philox4x32_10(
-          make_uint4(VMC_ACCEPT_BLOCK, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
-      uacc = u32_to_uniform(r.x);
-    }
-    reduce_and_publish(vmax, imax, vmin, imin, uacc);
-  };
-
-  if (!FAST && a.dbg_up != nullptr) {   // debug_proposals: dump the draw of step0, do not move
-    if (use_pref) draw_all(a.step0);
-    proposals(a.step0);
-    __syncthreads();
-    if (tid < 16 && chain0 + tid < a.B) {
-      a.dbg_up[chain0 + tid] = s_iup[tid];
-      a.dbg_dn[chain0 + tid] = s_idn[tid];
-      a.dbg_u[chain0 + tid] = s_u[tid];
-    }
-    return;
-  }
-
-  f32x4 own[TO];  // relu'd activations of this wave's own output tiles (B-operand layout)
-  f32x4 zlast[TO];  // RBM: pre-activations of the last layer (the gradient path wants tanh of them)
-
-  // diagnostic stamps (STAMP instantiation only)
-  unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
-  bool stamp_on = false;
-#define SWEEP_STAMP(k) \
-  if (STAMP) { const unsigned long long t1_ = vmc_stamp(); if (stamp_on) cyc[k] += t1_ - t0; t0 = t1_; }
-
-  // builds the layer-2 input operand (and the candidate z1 when with_delta)
-  bool save_acts = false;   // final refresh: also write the activations for the gradient path
-  auto save_own = [&](int l) {
-    if (chain0 + j < a.B) {
-      float* dst = a.act_out + ((long long)l * a.B + chain0 + j) * Hp;
-#pragma unroll
-      for (int to = 0; to < TO; ++to) {
-        f32x4 v = own[to];
-        if (RBM && l == n_hidden) {   // d sum log cosh(z) / d z = tanh(z): the last layer's delta
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = tanhf(zlast[to][e]);
-        }
-        *(f32x4*)(dst + 16 * (wave * TO + to) + 4 * g) = v;
-      }
-    }
-  };
-  // last-stage activation: relu (FC; the dot with w_out follows) or log cosh (RBM, w_out = 1)
-  auto finish_own = [&](int to, const f32x4& z, bool last) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(z[e], 0.f);
-    if (RBM && last) {
-      zlast[to] = z;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) own[to][e] = vmc_logcosh(z[e]);
-    }
-  };
-  auto build = [&](bool with_delta) {
-    if (W1L) {
-      // single z1 buffer; the previous step's accepted move is folded in first (each thread
-      // owns fixed elements of z1, so no barrier is needed for the read-modify-write).
-      // Branch-free and with every LDS read issued before the first use: the phase costs one
-      // LDS round trip instead of three per output tile.
-      float* zrow = s_z1 + j * ZS;
-      const float cp = s_pacc[j] != 0 ? 2.f : 0.f;
-      const float cd = with_delta ? 2.f : 0.f;
-      const float* px = s_w1 + s_pdn[j] * W1S;
-      const float* py = s_w1 + s_pup[j] * W1S;
-      const float* wa = s_w1 + (with_delta ? s_idn[j] : 0) * W1S;
-      const float* wb = s_w1 + (with_delta ? s_iup[j] : 0) * W1S;
-      f32x4 z[TO], x0[TO], y0[TO], x1[TO], y1[TO];
-#pragma unroll
-      for (int to = 0; to < TO; ++to) {
-        const int col = 16 * (wave * TO + to) + 4 * g;
-        z[to] = *(const f32x4*)(zrow + col);
-        x0[to] = *(const f32x4*)(px + col); y0[to] = *(const f32x4*)(py + col);
-        x1[to] = *(const f32x4*)(wa + col); y1[to] = *(const f32x4*)(wb + col);
-      }
-#pragma unroll
-      for (int to = 0; to < TO; ++to) {
-        const int t = wave * TO + to, col = 16 * t + 4 * g;
-        f32x4 zc;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          z[to][e] = fmaf(cp, x0[to][e] - y0[to][e], z[to][e]);     // committed z1
-          zc[e] = fmaf(cd, x1[to][e] - y1[to][e], z[to][e]);        // candidate z1'
-        }
-        finish_own(to, zc, n_hidden == 0);
-        *(f32x4*)(zrow + col) = z[to];
-        *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
-      }
-      if (save_acts) save_own(0);
-      return;
-    }
-    const int sel = s_sel[j];
-    const float* zc = s_z1 + sel * 16 * ZS + j * ZS;
-    float* zn = s_z1 + (sel ^ 1) * 16 * ZS + j * ZS;
-    const float* wa = pp.w1p;
-    const float* wb = pp.w1p;
-    if (with_delta) {
-      wa = pp.w1p + (long long)s_idn[j] * Hp;
-      wb = pp.w1p + (long long)s_iup[j] * Hp;
-    }
-#pragma unroll
-    for (int to = 0; to < TO; ++to) {
-      const int t = wave * TO + to, col = 16 * t + 4 * g;
-      f32x4 z = *(const f32x4*)(zc + col);
-      if (with_delta) {
-        const f32x4 x = *(const f32x4*)(wa + col);
-        const f32x4 y = *(const f32x4*)(wb + col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) z[e] = fmaf(2.f, x[e] - y[e], z[e]);
-        *(f32x4*)(zn + col) = z;
-      }
-      finish_own(to, z, n_hidden == 0);
-      *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
-    }
-    if (save_acts) save_own(0);
-  };
-
-  // layers 2..L + output dot; leaves per-wave partial logits in s_part.
-  // Weight stream = [(layer 0, ti = RT..NT-1), (layer 1, all ti), ...] through a PF-stage
-  // register ring; item q lives in stage q % PF and is issued PF-1 items ahead of its use.
-  auto forward = [&](unsigned long long next_step) {
-    f32x4 wb[PF][TO];
-    auto issue = [&](int l, int ti, int stage) {
-      // uniform (SGPR) base + one per-lane offset register
-      const f32x4* __restrict__ wp =
-          (const f32x4*)(pp.p16 + (long long)l * Hp * Hp) + (wave * TO * NT + ti) * 64;
-#pragma unroll
-      for (int to = 0; to < TO; ++to) wb[stage][to] = wp[to * NT * 64 + lane];
-    };
-    // prologue of the ring.  Every issue below is unconditional (layer index clamped to the
-    // last layer) so that the compiler can count vmcnt exactly; a load issued under a runtime
-    // condition makes it wait for ALL outstanding loads at the next use.
-    const int l_last = n_hidden - 1;
-    if (RT < NT) {
-#pragma unroll
-      for (int st = 0; st < PF - 1; ++st) issue(0, RT + st, st);
-    } else {
-#pragma unroll
-      for (int st = 0; st < PF - 1; ++st) issue(min(1, l_last), st, st);
-    }
-    int cur = 0;
-    // FS = first streamed k-tile of the layer (RT for layer 0, 0 afterwards)
-    auto layer = [&](int l, auto fs_c) {
-      constexpr int FS = decltype(fs_c)::value;
-      SWEEP_STAMP(FS > 0 ? 7 : 11)
-      __syncthreads();
-      SWEEP_STAMP(FS > 0 ? 8 : 12)
-      const f32x4* xin = (const f32x4*)(s_x + cur * NT * 256) + lane;
-      f32x4 acc[TO];
-#pragma unroll
-      for (int to = 0; to < TO; ++to)
-        acc[to] = *(const f32x4*)(s_bias + l * Hp + 16 * (wave * TO + to) + 4 * g);
-      // resident k-tiles: operands straight from registers.  The 20 Philox rounds of the NEXT
-      // step's two draws are cut into 2*FS pieces and pinned (sched_barrier) between groups of
-      // 2*TO MFMAs, so the VALU work issues in the shadow of the matrix pipe.
-      f32x4 inb[2];
-      inb[0] = xin[0];
-      uint4 cs[ND];
-      uint2 ks[ND];
-#pragma unroll
-      for (int d = 0; d < ND; ++d) { cs[d] = ctr_of(d, next_step); ks[d] = key; }
-      constexpr int NPIECE = 2 * FS, NROUND = 10 * ND;
-      constexpr int RPP = NPIECE > 1 ? (NROUND + NPIECE - 2) / (NPIECE - 1) : NROUND;   // rounds / piece
-      auto piece = [&](int p) {
-#pragma unroll
-        for (int q = p * RPP; q < (p + 1) * RPP && q < NROUND; ++q) {
-#pragma unroll
-          for (int d = 0; d < ND; ++d)
-            if (q % ND == d) philox_round(cs[d], ks[d]);
-        }
-      };
-#pragma unroll
-      for (int ti = 0; ti < FS; ++ti) {
-        if (ti + 1 < NT) inb[(ti + 1) & 1] = xin[(ti + 1) * 64];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-          for (int to = 0; to < TO; ++to)
-            acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[ti * TO + to][r], inb[ti & 1][r],
-                                                           acc[to], 0, 0, 0);
-          if (r == 1) { piece(2 * ti); __builtin_amdgcn_sched_barrier(0); }
-          if (r == 3) { piece(2 * ti + 1); __builtin_amdgcn_sched_barrier(0); }
-        }
-      }
-      if (FS > 0) finish_draw(cs, next_step);
-      if (FS > 0) { SWEEP_STAMP(9) }
-      // streamed k-tiles: weights PF-1 tiles ahead, activations one tile ahead
-      if (FS == 0) inb[0] = xin[0];
-#pragma unroll
-      for (int ti = FS; ti < NT; ++ti) {
-        const int tn = ti + PF - 1;
-        if (tn < NT) issue(l, tn, (tn - FS) % PF);
-        else issue(min(l + 1, l_last), tn - NT, (tn - FS) % PF);
-        if (ti + 1 < NT) inb[(ti + 1) & 1] = xin[(ti + 1) * 64];
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetches ahead of this tile's MFMAs
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int to = 0; to < TO; ++to)
-            acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[(ti - FS) % PF][to][r],
-                                                           inb[ti & 1][r], acc[to], 0, 0, 0);
-      }
-      SWEEP_STAMP(FS > 0 ? 10 : 13)
-      float* xout = s_x + (cur ^ 1) * NT * 256;
-#pragma unroll
-      for (int to = 0; to < TO; ++to) {
-        finish_own(to, acc[to], l + 1 == n_hidden);
-        if (l + 1 < n_hidden) *(f32x4*)(xout + ((wave * TO + to) * 64 + lane) * 4) = own[to];
-      }
-      if (save_acts) save_own(l + 1);
-      cur ^= 1;
-      SWEEP_STAMP(FS > 0 ? 11 : 14)
-    };
-    layer(0, std::integral_constant<int, RT>{});
-    for (int l = 1; l < n_hidden; ++l) layer(l, std::integral_constant<int, 0>{});
-  };
-
-  // output dot of the last activations (own) -> per-wave partial logits in s_part
-  auto output_dot = [&]() {
-    float part = 0.f;
-#pragma unroll
-    for (int to = 0; to < TO; ++to) {
-      const f32x4 w = *(const f32x4*)(s_wout + 16 * (wave * TO + to) + 4 * g);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) part = fmaf(own[to][e], w[e], part);
-    }
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
-    if (g == 0) s_part[wave * 16 + j] = part;   // NW partials per chain
-    __syncthreads();
-  };
-
-  auto logit_of = [&](int c) {   // fixed summation order over the NW per-wave partials
-    float t = (s_part[c] + s_part[16 + c]) + (s_part[32 + c] + s_part[48 + c]);
-    if (NW == 8) t += (s_part[64 + c] + s_part[80 + c]) + (s_part[96 + c] + s_part[112 + c]);
-    return t + bout;
-  };
-
-  // it = -1: cache of the initial spins; 0..n_steps-1: mc_steps; n_steps: exact cache of the
-  // final spins (all three share one instance of build/forward).
-  // The outcome of iteration it-1 is resolved at the TOP of iteration it by the wave that owns
-  // the chain (chains 4w..4w+3 -> wave w, all 16 lanes of a group redundantly, lane j == 0
-  // writes): that wave is the only reader of the chain's spins in `proposals`, so no barrier
-  // is needed between the Metropolis accept and the next proposal.
-  unsigned int n_acc = 0;
-  int prev_kind = 0;   // 0 none, 1 refresh, 2 step
-  auto resolve = [&]() {
-    if (prev_kind == 0 || (NW > 4 && wave >= 4)) return;
-    const int c = my_c, gc = chain0 + c;
-    float ln = logit_of(c);
-    float on_new = 0.f;
-    if (RBM) {   // onsite term of the evaluated configuration: committed value (+ exchange update)
-      on_new = s_on[c];
-      if (prev_kind == 2) on_new += 2.f * (won_at(s_idn[c]) - won_at(s_iup[c]));
-      ln += on_new;
-    }
-    if (prev_kind == 2) {
-      // Metropolis accept (graph_builders.py:75-88)
-      // exp(dlogit) > sqrt(u)  <=>  dlogit > 0.5 log(u)  (monotone; u = 0 always accepts)
-      const bool acc = (gc < a.B) && ((ln - s_logit[c]) > s_hlu[c]);
-      if (j == 0) {
-        if (acc) {
-          s_logit[c] = ln;
-          if (RBM) s_on[c] = on_new;
-          s_spin[c * Nst + s_idn[c]] = 1.f;
-          s_spin[c * Nst + s_iup[c]] = -1.f;
-          if (!W1L) s_sel[c] ^= 1;
-          ++n_acc;
-        }
-        if (W1L) { s_pacc[c] = acc ? 1 : 0; s_pup[c] = s_iup[c]; s_pdn[c] = s_idn[c]; }
-        if (!FAST && a.acc_mask && gc < a.B) a.acc_mask[gc] = acc ? 1 : 0;
-      }
-    } else if (j == 0) {
-      s_logit[c] = ln;
-    }
-  };
-  long long it_first = -1;
-  if (a.cache_in_valid && a.n_steps > 0) {
-    // the previous launch left an exact z1 / logit cache for these very chains: load it
-    // instead of recomputing it (saves one of the two refresh passes per launch)
-    for (int i = tid; i < 16 * (Hp / 4); i += NTH) {   // 16-byte loads, <= 2 per thread
-      const int c = i / (Hp / 4), c4 = i % (Hp / 4), gc = chain0 + c;
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (gc < a.B) v = *(const f32x4*)(a.z1_in + (long long)gc * Hp + 4 * c4);
-      *(f32x4*)(s_z1 + c * ZS + 4 * c4) = v;
-    }
-    if (tid < 16) s_logit[tid] = chain0 + tid < a.B ? a.logit_in[chain0 + tid] : 0.f;
-    onsite_direct();
-    if (use_pref) draw_all(a.step0);
-    __syncthreads();
-    it_first = 0;
-  }
-  for (long long it = it_first; it <= a.n_steps; ++it) {
-    const bool is_step = it >= 0 && it < a.n_steps;
-    save_acts = (it == a.n_steps) && (a.act_out != nullptr);
-    stamp_on = is_step;
-    if (STAMP) t0 = vmc_stamp();
-    resolve();
-    SWEEP_STAMP(5)
-    if (is_step) {
-      proposals(a.step0 + (unsigned long long)it);
-    } else {
-      __syncthreads();   // z1_direct reads every chain's (possibly just updated) spins
-      if (tid < 16) { s_sel[tid] = 0; s_pacc[tid] = 0; }
-      z1_direct();
-      onsite_direct();
-    }
-    SWEEP_STAMP(0)
-    __syncthreads();
-    SWEEP_STAMP(1)
-    build(is_step);
-    SWEEP_STAMP(2)
-    const unsigned long long next_step = a.step0 + (unsigned long long)(it + 1);
-    const bool pre_here = use_pref && n_hidden > 0;
-    if (n_hidden > 0) forward(next_step);
-    if (use_pref && !pre_here) draw_all(next_step);
-    SWEEP_STAMP(3)
-    output_dot();
-    SWEEP_STAMP(4)
-    prev_kind = is_step ? 2 : 1;
-  }
-  stamp_on = false;
-  resolve();          // logit of the final refresh
-  __syncthreads();
-#undef SWEEP_STAMP
-  if (STAMP && a.dbg_cycles && lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a.dbg_cycles[((long long)blockIdx.x * NW + wave) * 16 + k] = cyc[k];
-  }
-
-  // write back chains and the exact cache
-  if (tid < 16 && chain0 + tid < a.B) a.logit[chain0 + tid] = s_logit[tid];
-  if (RBM && tid < 16 && chain0 + tid < a.B) a.onsite[chain0 + tid] = s_on[tid];
-  for (int i = tid; i < 16 * N; i += NTH) {
-    const int c = i / N, n = i % N, gc = chain0 + c;
-    if (gc < a.B) a.configs[(long long)gc * N + n] = s_spin[c * Nst + n];
-  }
-  for (int i = tid; i < 16 * (Hp / 4); i += NTH) {
-    const int c = i / (Hp / 4), c4 = i % (Hp / 4), gc = chain0 + c;
-    if (gc < a.B) *(f32x4*)(a.z1 + (long long)gc * Hp + 4 * c4) = *(const f32x4*)(s_z1 + c * ZS + 4 * c4);
-  }
-  if (j == 0 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);   // waves 0-3 only
-}
-
-static size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool rbm) {
-  const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
-  return sizeof(float) * (size_t)(16 * Nst + (w1l ? 1 : 2) * 16 * ZS + 2 * NT * 256 + 16 +
-                                  16 + 7 * 16 + Hp + n_hidden * Hp + (rbm ? (w1l ? 0 : Nst) + 16 : 0) +
-                                  (w1l ? N * (Hp + 4) : 0));
-}
-
-// LDS the sampler needs at least (W1 streamed from L2); vmc_create rejects shapes beyond 160 KiB
-size_t sweep_lds_required(int N, int Hp, int n_hidden, bool rbm) {
-  return sweep_lds_bytes(N, Hp, n_hidden, false, rbm);
-}
-
-template <int NT, int NW, int RTP, bool RBM>
-static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
-  const dim3 grid((a.B + 15) / 16), block(NW * 64);
-  const size_t lds_full = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, true, RBM);
-  const bool w1l = lds_full <= 160 * 1024 && !a.no_w1l;
-  const size_t lds = w1l ? lds_full : sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false, RBM);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  const int nblk = (a.N + 3) / 4;
-  const bool plain = a.inj_up == nullptr && a.dbg_up == nullptr;
-  const bool fast2 = nblk <= 32 && plain, fast4 = nblk <= 64 && plain;
-#define SWEEP_LAUNCH(ST, WL, FA, UP)                                                          \
-  do {                                                                                        \
-    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, NW, RTP, ST, WL, FA, UP, RBM>, \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return e;                                                            \
-    hipLaunchKernelGGL((k_sweep16<NT, NW, RTP, ST, WL, FA, UP, RBM>), grid, block, lds, s, a); \
-    return hipGetLastError();                                                                 \
-  } while (0)
-  if (a.dbg_cycles) {
-    if (!(w1l && fast2) || RBM || NW != 8) return hipErrorInvalidValue;   // diagnostic build: production variant only
-    if constexpr (!RBM && NW == 8) SWEEP_LAUNCH(true, true, true, 2);
-  }
-  if (w1l) {
-    if (fast2) SWEEP_LAUNCH(false, true, true, 2);
-    if (fast4) SWEEP_LAUNCH(false, true, true, 4);
-    SWEEP_LAUNCH(false, true, false, 2);
-  }
-  if (fast2) SWEEP_LAUNCH(false, false, true, 2);
-  if (fast4) SWEEP_LAUNCH(false, false, true, 4);
-  SWEEP_LAUNCH(false, false, false, 2);
-#undef SWEEP_LAUNCH
-}
-
-// H = 256: 8 waves with 14 resident k-tiles (one workgroup per CU), or 4 waves with RT4
-// resident k-tiles at <= 256 registers, so that two workgroups share a CU and each one's serial
-// phases (proposal, z1' build, accept) run under the other's MFMAs
-#ifndef SWEEP_RT4
-#define SWEEP_RT4 8
-#endif
-template <bool RBM>
-static hipError_t launch_sweep16_r(hipStream_t s, const SweepArgs& a, int Hp) {
-  switch (Hp / 16) {
-#ifndef VMC_QUICK   // development builds (-DVMC_QUICK) only instantiate H = 256, fully_connected
-    case 4: return launch_sweep16_t<4, 4, SWEEP_RT, RBM>(s, a);
-    case 8: return launch_sweep16_t<8, 4, SWEEP_RT, RBM>(s, a);
-    case 12: return launch_sweep16_t<12, 4, SWEEP_RT, RBM>(s, a);
-#endif
-    case 16: return a.waves == 8 ? launch_sweep16_t<16, 8, SWEEP_RT, RBM>(s, a)
-                                 : launch_sweep16_t<16, 4, SWEEP_RT4, RBM>(s, a);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp) {
-  if (a.B <= 0) return hipSuccess;
-#ifndef VMC_QUICK
-  if (a.rbm) return launch_sweep16_r<true>(s, a, Hp);
-#endif
-  return launch_sweep16_r<false>(s, a, Hp);
-}

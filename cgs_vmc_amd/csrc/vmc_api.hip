@@ -451,7 +451,6 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   c->n_hh = c->lay.n_hh; c->A = c->n_hh + 1;
   c->P = vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
   c->stream = (hipStream_t)d->stream;
-  if (const char* e = getenv("CGS_VMC_SWEEP_WAVES")) c->sweep_waves = atoi(e) == 8 ? 8 : 4;
   if (const char* e = getenv("CGS_VMC_SWEEP_W1L")) c->sweep_no_w1l = atoi(e) == 0 ? 1 : 0;
   if (const char* e = getenv("CGS_VMC_OVERLAP")) c->overlap = atoi(e) != 0;
   {
@@ -610,9 +609,15 @@ int vmc_set_configs(vmc_ctx* c, const float* configs) {
   ENTER(c);
   if (!configs) return fail(c, VMC_ERR_INVALID, "null configs");
   const long long n = (long long)c->B * c->N;
-  for (long long i = 0; i < n; ++i)
-    if (configs[i] != 1.f && configs[i] != -1.f) return fail(c, VMC_ERR_INVALID, "configs must be +-1");
-  HIPCHK(c, hipMemcpyAsync(c->configs, configs, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  // staged in the alternate chain buffer (free between sampler launches), validated on the
+  // device, and only then made current: a rejected batch leaves the chains untouched
+  HIPCHK(c, hipMemcpyAsync(c->configs_alt, configs, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, launch_check_pm1(c->stream, c->configs_alt, n, c->cnt));
+  int bad = 0;
+  HIPCHK(c, hipMemcpyAsync(&bad, c->cnt, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (bad) return fail(c, VMC_ERR_INVALID, "configs must be +-1");
+  HIPCHK(c, hipMemcpyAsync(c->configs, c->configs_alt, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   invalidate_configs(c);
   return VMC_OK;

@@ -49,6 +49,25 @@ def get_or_create_num_epochs() -> _Counter:
   return g.named['num_epochs']
 
 
+def sampler_seed() -> int:
+  """Key of the sampler's counter-based RNG for a new set of chains.  The reference draws
+  from unseeded tf.random_uniform (graph_builders.py:59, 76), so repeated runs -- and
+  repeated evaluations inside one process -- are independent samples: unless CGS_VMC_SEED
+  pins it, every call returns fresh entropy drawn on rank 0 and shared with every rank (the
+  chains of all ranks must use one key: it is combined with the global chain id).  The key is
+  printed so that a run can be reproduced."""
+  pinned = os.environ.get('CGS_VMC_SEED')
+  if pinned is not None:
+    return int(pinned)
+  fresh = int.from_bytes(os.urandom(6), 'little')      # < 2^48: exact in float64
+  if parallel.world_size() > 1:
+    fresh = int(parallel.allreduce_array(
+        np.array([float(fresh) if parallel.rank() == 0 else 0.0]))[0])
+  if parallel.rank() == 0:
+    print('sampler seed (CGS_VMC_SEED to reproduce): {}'.format(fresh), flush=True)
+  return fresh
+
+
 class ConfigsVariable:
   """Non-trainable variable of logical shape [batch_size, n_sites] holding the chains.
 
@@ -82,7 +101,7 @@ class ConfigsVariable:
   def _get_engine(self, wavefunction):
     if self._engine is None:
       from .engine import VmcEngine
-      seed = int(os.environ.get('CGS_VMC_SEED', '2024'))
+      seed = sampler_seed()
       self._engine = VmcEngine(
           n_sites=self.shape[1], batch_size=self.local_batch,
           num_layers=wavefunction._num_layers, layer_size=wavefunction._layer_size,

@@ -83,8 +83,13 @@ def main(argv=None):
   hp = hparams_from_flags(flags)
   cli_common.ensure_directory(flags.checkpoint_dir)
   pbtxt = os.path.join(hp.checkpoint_dir, 'hparams.pbtxt')
-  if os.path.exists(pbtxt) and not flags.override:
+  # rank 0 alone looks at the file system and every rank follows its verdict: a slower rank
+  # must not mistake the file rank 0 is about to write for a pre-existing one
+  exists = os.path.exists(pbtxt) if parallel.rank() == 0 else False
+  if parallel.allreduce_max(1.0 if exists else 0.0) > 0.5 and not flags.override:
     print('Hparams file already exists')
+    if parallel.is_distributed():
+      parallel._dist().destroy_process_group()
     sys.exit()
   if parallel.rank() == 0:
     with open(pbtxt, 'w') as out:

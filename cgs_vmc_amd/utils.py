@@ -258,15 +258,19 @@ def load_hparams(hparams_path: str) -> HParams:
 
 
 def random_configurations(n_sites: int, batch_size: int = 1, seed=None) -> np.ndarray:
-  """Random configurations in the Sz=0 sector (utils.py:169-192): all +1, then n_sites//2
-  distinct random sites set to -1 by rejection.  Unseeded like the reference unless `seed`
-  is given."""
-  configurations = np.ones((batch_size, n_sites))
-  rnd = np.random.RandomState(seed)
-  for i in range(0, batch_size):
-    pos = rnd.randint(0, n_sites)
-    for _ in range(0, n_sites // 2):
-      while configurations[i, pos] != 1.0:
-        pos = rnd.randint(0, n_sites)
-      configurations[i, pos] = -1.0
-  return configurations.astype(np.float32)
+  """Random Sz = 0 chains (utils.py:169-192): every row starts all-up and gets n_sites // 2
+  distinct sites lowered; a candidate site that is already down is redrawn.  The draws come
+  from RandomState(seed).randint in the reference's order (unseeded, like the reference, when
+  `seed` is None), so a seeded call reproduces the reference's chains."""
+  draw = np.random.RandomState(seed).randint
+  n_down = n_sites // 2
+  chains = np.ones((batch_size, n_sites), np.float32)
+  for row in chains:
+    site, lowered = draw(0, n_sites), 0
+    while lowered < n_down:
+      if row[site] > 0:
+        row[site] = -1.0
+        lowered += 1
+      else:
+        site = draw(0, n_sites)
+  return chains

@@ -76,19 +76,16 @@ class Wavefunction:
     return []
 
   def __deepcopy__(self, memo: Dict[int, Any]) -> 'Wavefunction':
-    """wavefunctions.py:177-204: same constructor arguments, fresh variables, name dc_<name>."""
-    id_self = id(self)
-    _copy = memo.get(id_self)
-    if _copy is not None:
-      return _copy
-    init_args = inspect.getfullargspec(self.__init__)[0]
-    init_args.remove('self')
-    init_args.remove('name')
-    init_values = {arg: copy.deepcopy(getattr(self, '_{}'.format(arg)), memo) for arg in init_args}
-    init_values['name'] = 'dc_{}'.format(getattr(self, '_unique_name'))
-    _copy = type(self)(**init_values)
-    memo[id_self] = _copy
-    return _copy
+    """wavefunctions.py:177-204: a twin built from the same constructor arguments (deep-copied,
+    so sub-wavefunctions get twins too) with fresh variables under the name dc_<name>."""
+    twin = memo.get(id(self))
+    if twin is None:
+      ctor = inspect.signature(type(self).__init__).parameters
+      kwargs = {arg: copy.deepcopy(getattr(self, '_' + arg), memo)
+                for arg in ctor if arg not in ('self', 'name')}
+      twin = type(self)(name='dc_' + self._unique_name, **kwargs)
+      memo[id(self)] = twin
+    return twin
 
   # -- normalisation -------------------------------------------------------
   def add_exp_normalization(self, initial_exp_norm_shift: float = -10.):
@@ -101,11 +98,30 @@ class Wavefunction:
       return None
 
     def run():
-      psi = np.asarray(batch_of_amplitudes._run())
-      from . import parallel
-      log_max = np.log(parallel.allreduce_max(float(np.max(psi))))
-      self._set_shift(np.float32(self._get_shift() + (log_max - np.log(max_value))))
+      log_max = self._global_log_max(batch_of_amplitudes)
+      self._set_shift(np.float32(self._get_shift() + (log_max - np.log(np.float32(max_value)))))
     return session_lib.Op(run, 'normalize_batch')
+
+  def _global_log_max(self, batch_of_amplitudes) -> np.float32:
+    """log(max_b psi_b) over ALL ranks (wavefunctions.py:250, 283).  For this ansatz's own
+    amplitudes the max is taken over the logits and `log(exp(max_logit - shift))` is evaluated
+    once, as vmc_update_norm does: where psi overflows float32 the reference's value is inf;
+    the logit-domain value max_logit - shift is used there, on every path (single GPU, sharded,
+    op-by-op), so that sharded and unsharded runs agree."""
+    from . import parallel
+    own = (isinstance(batch_of_amplitudes, AmplitudeTensor)
+           and batch_of_amplitudes.wavefunction is self and self._exp_norm_shift is not None)
+    if own:
+      top = np.float32(parallel.allreduce_max(float(np.max(batch_of_amplitudes.logits()))))
+      gap = np.float32(top - np.float32(self._get_shift()))
+      with np.errstate(over='ignore'):
+        psi_max = np.exp(gap, dtype=np.float32)
+      if np.isfinite(psi_max) and psi_max > 0:
+        return np.float32(np.log(psi_max))
+      return gap
+    psi = np.asarray(batch_of_amplitudes._run())
+    with np.errstate(divide='ignore'):
+      return np.float32(np.log(np.float32(parallel.allreduce_max(float(np.max(psi))))))
 
   def update_norm(self, batch_of_amplitudes, max_value: float = 1e10):
     """wavefunctions.py:261-288."""
@@ -299,9 +315,7 @@ class FullyConnectedNetwork(Wavefunction):
         and batch_of_amplitudes.wavefunction is self and parallel.world_size() == 1):
       self._engine.update_norm(max_value)        # max-reduce on the GPU
       return
-    psi = np.asarray(batch_of_amplitudes._run())
-    with np.errstate(divide='ignore'):
-      log_max = np.log(np.float32(parallel.allreduce_max(float(np.max(psi)))))
+    log_max = self._global_log_max(batch_of_amplitudes)
     max_log = np.log(np.float32(max_value))
     if log_max > max_log:
       self._set_shift(np.float32(self._get_shift() + (log_max - max_log)))

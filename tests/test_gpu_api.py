@@ -230,30 +230,32 @@ def test_accumulator_device_view_for_rccl():
 
 
 def test_two_rank_bench_path_on_one_gpu(tmp_path):
-  """bench.py's N > 1 path (sharded chains, accumulator all-reduce, max-over-ranks timing) with
-  two ranks sharing this GPU over gloo.  RCCL itself needs >= 2 GPUs and is exercised by the
-  driver's scaling runs; everything around the collective is covered here."""
+  """`python bench.py --gpus 2` with NO rank environment: bench.py starts the two ranks itself
+  (sharded chains, accumulator all-reduce, max-over-ranks timing); they share this GPU over gloo.
+  RCCL itself needs >= 2 GPUs and is exercised by the driver's scaling runs; everything around
+  the collective is covered here."""
   import json
-  import socket
   import subprocess
   import sys
-  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  procs = []
-  for rank in range(2):
-    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2',
-               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CGS_VMC_DIST_BACKEND='gloo')
-    procs.append(subprocess.Popen(
-        [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup',
-         '1', '--no-cpu-baseline', '--workload', 'heisenberg6x6_fc3x128_b1024'],
-        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
-  outs = [p.communicate(timeout=600) for p in procs]
-  for p, (o, e) in zip(procs, outs):
-    assert p.returncode == 0, e.decode()[-2000:]
-  line = [l for l in outs[0][0].decode().splitlines() if l.startswith('{')][-1]
-  d = json.loads(line)
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+  env['CGS_VMC_DIST_BACKEND'] = 'gloo'
+  p = subprocess.run(
+      [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup',
+       '1', '--reps', '2', '--no-cpu-baseline', '--workload', 'heisenberg6x6_fc3x128_b1024'],
+      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+  assert p.returncode == 0, p.stderr.decode()[-2000:]
+  lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+  assert len(lines) == 1                      # rank 0 only
+  d = json.loads(lines[0])
   assert d['n_gpus'] == 2 and d['config']['global_chains'] == 2048 and d['value'] > 0
-  assert not [l for l in outs[1][0].decode().splitlines() if l.startswith('{')]   # rank 0 only
+  assert d['rccl']['ranks'] == 2 and d['rccl']['allreduce_floats'] == 2 * 37889 + 8
+  # a rank count that contradicts the environment is refused instead of silently mislabelled
+  bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'],
+                       env=dict(env, WORLD_SIZE='1', RANK='0'), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+  assert bad.returncode == 2 and b'WORLD_SIZE' in bad.stderr
 
 
 @pytest.mark.parametrize('optimizer', ['EnergyGradient', 'LogOverlapITSWO'])

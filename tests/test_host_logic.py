@@ -272,3 +272,15 @@ def test_heisenberg_bond_is_the_one_bond_hamiltonian():
   b = operators.HeisenbergBond((3, 5), 0.5, 2.0)
   assert isinstance(b, operators.Operator) and b._bond == (3, 5)
   assert b._bonds_list == [(3, 5)] and b._j_x.tolist() == [0.5] and b._j_z.tolist() == [2.0]
+
+
+def test_bench_refuses_a_rank_count_that_contradicts_the_environment():
+  """`--gpus N` must equal WORLD_SIZE when ranks already exist (a mislabelled
+  single-rank run); checked before anything touches the GPU, so it runs on CPU."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, WORLD_SIZE='1', RANK='0')
+  p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4'], env=env,
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+  assert p.returncode == 2 and b'WORLD_SIZE=1' in p.stderr and not p.stdout.strip()

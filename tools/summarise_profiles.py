@@ -1,7 +1,7 @@
-"""Summarises gpurun_out/r1_prof (tools/collect_profiles.sh) into profiles/:
-  r1_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (copied)
-  r1_pmc_summary.txt    per-kernel medians of the PMC passes
-  r1_traffic.json       HBM bytes per launch of the hot kernels (FETCH_SIZE x 2 per the gfx950
+"""Summarises gpurun_out/<tag>_prof (tools/collect_profiles.sh <tag> [workload]) into profiles/:
+  <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (copied)
+  <tag>_pmc_summary.txt    per-kernel medians of the PMC passes
+  <tag>_traffic.json       HBM bytes per launch of the hot kernels (FETCH_SIZE x 2 per the gfx950
                         correction of MI355X_MICROARCH.md + WRITE_SIZE, KB units -> bytes),
                         MFMA utilisation and clock; bench.py reads it for roofline.traffic
 """
@@ -14,8 +14,9 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, 'gpurun_out', 'r1_prof')
-DST = os.path.join(ROOT, 'profiles')
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+SRC = os.path.join(ROOT, 'gpurun_out', TAG + '_prof')
+DST = os.path.join(ROOT, 'gpurun_out', TAG + '_summary') if os.environ.get('GRAFT_REPO_ROOT') else os.path.join(ROOT, 'profiles')
 
 
 def medians(path):
@@ -39,7 +40,7 @@ def medians(path):
 def main():
   os.makedirs(DST, exist_ok=True)
   for f in glob.glob(SRC + '/stats/**/*kernel_stats.csv', recursive=True):
-    shutil.copy(f, os.path.join(DST, 'r1_kernel_stats.csv'))
+    shutil.copy(f, os.path.join(DST, TAG + '_kernel_stats.csv'))
   sq = medians(SRC + '/pmc_sq')
   fe = medians(SRC + '/pmc_fetch')
   wr = medians(SRC + '/pmc_write')
@@ -69,10 +70,10 @@ def main():
           'hbm_write_bytes': None if w_kb is None else 1024 * w_kb,
           'median_us': s['median_ns'] / 1e3, 'clock_ghz': clock, 'mfma_util': util,
       }
-  open(os.path.join(DST, 'r1_pmc_summary.txt'), 'w').write('\n'.join(lines) + '\n')
-  json.dump(traffic, open(os.path.join(DST, 'r1_traffic.json'), 'w'), indent=1, sort_keys=True)
+  open(os.path.join(DST, TAG + '_pmc_summary.txt'), 'w').write('\n'.join(lines) + '\n')
+  json.dump(traffic, open(os.path.join(DST, TAG + '_traffic.json'), 'w'), indent=1, sort_keys=True)
   if os.path.exists(SRC + '/bench.json'):
-    shutil.copy(SRC + '/bench.json', os.path.join(DST, 'r1_bench.json'))
+    shutil.copy(SRC + '/bench.json', os.path.join(DST, TAG + '_bench.json'))
   print('\n'.join(lines[:60]))
 
 
