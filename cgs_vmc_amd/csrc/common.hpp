@@ -76,6 +76,90 @@ __device__ __forceinline__ float vmc_logcosh(float z) {
   return a + __logf(1.f + __expf(-2.f * a)) - 0.69314718056f;
 }
 
+// --------------------------------------------------------------------------------------
+// layers.NONLINEARITIES (layers.py:13-21), ids of include/cgsvmc.h VMC_ACT_*.
+// Hidden activations are template parameters of the fused kernels (relu is the tuned path); the
+// output activation only touches scalars per row and is a run-time id.
+// cos / sin go through the hardware v_cos_f32 / v_sin_f32 after an fp32 range reduction
+// (|error| ~ 1e-6 for |z| < ~50, stated with the tolerance of the activation tests); exp / tanh
+// use the ocml device functions.
+// --------------------------------------------------------------------------------------
+#define VMC_ACT_RELU_ 0
+#define VMC_ACT_EXP_ 1
+#define VMC_ACT_COS_ 2
+#define VMC_ACT_TAN_ 3
+#define VMC_ACT_TANH_ 4
+#define VMC_ACT_SIGMOID_ 5
+#define VMC_ACT_IDENTITY_ 6
+
+template <int ACT>
+__device__ __forceinline__ float vmc_act(float z) {
+  if (ACT == VMC_ACT_RELU_) return fmaxf(z, 0.f);
+  if (ACT == VMC_ACT_EXP_) return expf(z);
+  if (ACT == VMC_ACT_COS_) return __cosf(z);
+  if (ACT == VMC_ACT_TAN_) return __sinf(z) / __cosf(z);
+  if (ACT == VMC_ACT_TANH_) return tanhf(z);
+  if (ACT == VMC_ACT_SIGMOID_) return 1.f / (1.f + expf(-z));
+  return z;
+}
+
+// f'(z) from the activation value a = f(z); the cosine needs sin z, which the producers of the
+// activations store next to them (`dact` arrays) instead
+template <int ACT>
+__device__ __forceinline__ float vmc_dact_from_a(float a) {
+  if (ACT == VMC_ACT_RELU_) return a > 0.f ? 1.f : 0.f;
+  if (ACT == VMC_ACT_EXP_) return a;
+  if (ACT == VMC_ACT_TAN_) return 1.f + a * a;
+  if (ACT == VMC_ACT_TANH_) return 1.f - a * a;
+  if (ACT == VMC_ACT_SIGMOID_) return a * (1.f - a);
+  return 1.f;   // identity (cos: see dact arrays)
+}
+
+__device__ __forceinline__ float vmc_act_rt(int act, float z) {
+  switch (act) {
+    case VMC_ACT_RELU_: return vmc_act<VMC_ACT_RELU_>(z);
+    case VMC_ACT_EXP_: return vmc_act<VMC_ACT_EXP_>(z);
+    case VMC_ACT_COS_: return vmc_act<VMC_ACT_COS_>(z);
+    case VMC_ACT_TAN_: return vmc_act<VMC_ACT_TAN_>(z);
+    case VMC_ACT_TANH_: return vmc_act<VMC_ACT_TANH_>(z);
+    case VMC_ACT_SIGMOID_: return vmc_act<VMC_ACT_SIGMOID_>(z);
+    default: return z;
+  }
+}
+
+__device__ __forceinline__ float vmc_dact_rt(int act, float z, float a) {
+  switch (act) {
+    case VMC_ACT_RELU_: return z > 0.f ? 1.f : 0.f;
+    case VMC_ACT_EXP_: return a;
+    case VMC_ACT_COS_: return -__sinf(z);
+    case VMC_ACT_TAN_: return 1.f + a * a;
+    case VMC_ACT_TANH_: return 1.f - a * a;
+    case VMC_ACT_SIGMOID_: return a * (1.f - a);
+    default: return 1.f;
+  }
+}
+
+// Output activation g (wavefunctions.py:350-353).  exp: psi = exp(x - shift), every ratio is
+// exp(x' - x); any other g: psi = g(x) with no shift and ratios are taken in the linear domain.
+//   ratio psi'/psi (signed, local energy: operators.py:259)
+__device__ __forceinline__ float vmc_out_ratio(int oact, float x_new, float x_old) {
+  if (oact == VMC_ACT_EXP_) return expf(x_new - x_old);
+  return vmc_act_rt(oact, x_new) / vmc_act_rt(oact, x_old);
+}
+//   Metropolis test |psi'| / |psi| > sqrt(u) (graph_builders.py:75-79); half_log_u = 0.5 log u
+__device__ __forceinline__ bool vmc_out_accept(int oact, float x_new, float x_old, float u,
+                                               float half_log_u) {
+  if (oact == VMC_ACT_EXP_) return (x_new - x_old) > half_log_u;
+  const float pn = fabsf(vmc_act_rt(oact, x_new)), po = fabsf(vmc_act_rt(oact, x_old));
+  return pn / po > sqrtf(u);     // 0/0 = nan > . is false, x/0 = inf accepts: as the reference
+}
+//   (1/psi) d psi / d x: the per-sample factor of O_k (training.py:545: grad of psi / stop_gradient(psi))
+__device__ __forceinline__ float vmc_out_dlog(int oact, float x) {
+  if (oact == VMC_ACT_EXP_) return 1.f;
+  const float a = vmc_act_rt(oact, x);
+  return vmc_dact_rt(oact, x, a) / a;
+}
+
 struct TailArgs {
   PackedParams pp;
   const float* z1;          // [n_base][Hp] cached first-layer pre-activations
@@ -90,6 +174,8 @@ struct TailArgs {
   int n_sites;              // N (rows of W1)
   int n_units;              // H (unpadded layer size; the RBM sum skips the padded units)
   int num_cus;              // CUs of the device (persistent grid size)
+  int act;                  // hidden activation id (selects the instantiation)
+  int oact;                 // output activation id (ratio mode: exp -> log domain, else linear)
   float* out;               // [n_rows]
 };
 
@@ -110,6 +196,8 @@ struct SweepArgs {
   unsigned char* acc_mask;  // [B] out (last step) or nullptr
   int* dbg_up; int* dbg_dn; float* dbg_u;   // proposal dump (debug_proposals) or nullptr
   unsigned long long* dbg_cycles;           // [grid][4 waves][16 phases] -> diagnostic STAMP build
+  int act, oact;            // hidden / output activation ids
+  float* dact_out;          // [L][B][Hp] f'(z) of the final chains (cosine only) or nullptr
   int waves;                // waves per workgroup of the sweep kernel (4 or 8)
   int no_w1l;               // 1: never hold W1 in LDS (the two-workgroups-per-CU variant)
   int cache_in_valid;       // z1 / logit already hold the exact cache of `configs`
@@ -126,9 +214,11 @@ hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp,
                        const ParamLayout& lay, float* w1p, float* b1p, float* bh, float* p16,
                        float* p16t, float* woutp, float* bout, float* won);
 // d logit / d z_l of every layer: act_all / delta_all are [n_hidden + 1][B][Hp]
+// act: hidden activation id; dact_all: f'(z) arrays (cosine only) or nullptr; oscale: [B]
+// (1/psi) d psi / d x of a non-exp output activation or nullptr
 hipError_t launch_backprop16(hipStream_t s, const float* act_all, float* delta_all,
                              const float* p16t, const float* woutp, int B, int Hp, int n_hidden,
-                             bool rbm);
+                             bool rbm, int act, const float* dact_all, const float* oscale);
 hipError_t launch_tail(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm);
 hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, int rows, int N,
                          float* out);
@@ -156,10 +246,12 @@ struct GemmArgs {
   float* C2;                            // dual: destination of A (kscale (.) B)
   int dual;                             // compute both A B -> C and A (kscale (.) B) -> C2
   int ones_row;                         // row M-1 of A is an implicit row of ones
-  const float* bias;                    // epilogue 1: + bias[n] then relu
-  const float* mask;  long long ldmask; // epilogues 5 / 6: * (mask[m*ldmask+n] > 0)
-  int epilogue;                         // 0 none, 1 bias+relu, 3 accumulate (C += ), 4 bias,
-                                        // 5 mask (.) (v + bias), 6 mask (.) (C + v + bias), 7 tanh(v + bias), 8 C + v + bias
+  const float* bias;                    // epilogue 1: f(v + bias[n]), f = hidden activation `act`
+  const float* mask;  long long ldmask; // epilogues 5 / 6: * f'(z) read off mask = f(z) (relu: mask > 0)
+  int act;                              // hidden activation id of epilogues 1 / 5 / 6
+  float* dact_out;                      // epilogue 1: also store f'(z) (layout of C) or nullptr
+  int epilogue;                         // 0 none, 1 f(v + bias), 3 accumulate (C += ), 4 bias,
+                                        // 5 f' (.) (v + bias), 6 f' (.) (C + v + bias), 7 tanh(v + bias), 8 C + v + bias
   int splitk;                           // >= 1
   float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
 };
@@ -168,13 +260,14 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
 // own workspace) in one launch + one reduction launch; max_m counts MFMA rows (M - 1)
 hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
                                int max_n, int splitk, bool dual = true);
-hipError_t launch_relu_copy(hipStream_t s, const float* z, float* a, long long n);
+hipError_t launch_act_copy(hipStream_t s, const float* z, float* a, float* dact, long long n, int act);
+hipError_t launch_out_scale(hipStream_t s, const float* x, float* oscale, int B, int oact);
 hipError_t launch_tanh_copy(hipStream_t s, const float* z, float* a, long long n);
 hipError_t launch_scalar_accum(hipStream_t s, const float* eloc, const float* ratio, int B,
                                float* acc_scalars, int mode);
 hipError_t launch_itswo_ratio(hipStream_t s, const float* logit_psi, const float* logit_omega,
                               const float* eloc_omega, float log_factor, float beta, int B,
-                              float* ratio);
+                              float* ratio, int oact);
 hipError_t launch_adam(hipStream_t s, float* theta, float* m, float* v, const float* acc, int P,
                        int mode, float lr_t, float b1, float b2, float eps, float* grad_out);
 hipError_t launch_fill(hipStream_t s, float* x, float v, long long n);

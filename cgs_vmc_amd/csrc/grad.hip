@@ -23,13 +23,20 @@
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, int m, int n, float v) {
   float* c = C + (long long)m * g.ldc + n;
   switch (g.epilogue) {
-    case 1: *c = fmaxf(v + g.bias[n], 0.f); break;
+    case 1: {   // hidden layer: a = f(z) (and f'(z) next to it where the activation needs z: cosine)
+      const float z = v + g.bias[n];
+      const float a = vmc_act_rt(g.act, z);
+      *c = a;
+      if (g.dact_out) g.dact_out[(long long)m * g.ldc + n] = vmc_dact_rt(g.act, z, a);
+      break;
+    }
     case 3: *c += v; break;
     case 4: *c = v + g.bias[n]; break;
-    case 5: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? v + g.bias[n] : 0.f; break;
+    // tangent pass: f'(z) (.) (...), f' read off the stored activation a = f(z)
+    case 5: *c = vmc_dact_rt(g.act, g.mask[(long long)m * g.ldmask + n], g.mask[(long long)m * g.ldmask + n]) * (v + g.bias[n]); break;
     case 7: *c = tanhf(v + g.bias[n]); break;
     case 8: *c = *c + v + g.bias[n]; break;
-    case 6: *c = g.mask[(long long)m * g.ldmask + n] > 0.f ? *c + v + g.bias[n] : 0.f; break;
+    case 6: *c = vmc_dact_rt(g.act, g.mask[(long long)m * g.ldmask + n], g.mask[(long long)m * g.ldmask + n]) * (*c + v + g.bias[n]); break;
     default: *c = v; break;
   }
 }
@@ -303,15 +310,31 @@ hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int cou
 }
 
 // ---------------------------------------------------------------------------- element-wise
-__global__ void k_relu_copy(const float* __restrict__ z, float* __restrict__ a, long long n) {
+// a = f(z) (and, where given, f'(z)): the first activation of the gradient path's own forward
+__global__ void k_act_copy(const float* __restrict__ z, float* __restrict__ a,
+                           float* __restrict__ dact, long long n, int act) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x)
-    a[i] = fmaxf(z[i], 0.f);
+       i += (long long)gridDim.x * blockDim.x) {
+    const float v = vmc_act_rt(act, z[i]);
+    a[i] = v;
+    if (dact) dact[i] = vmc_dact_rt(act, z[i], v);
+  }
 }
 
-hipError_t launch_relu_copy(hipStream_t s, const float* z, float* a, long long n) {
+hipError_t launch_act_copy(hipStream_t s, const float* z, float* a, float* dact, long long n, int act) {
   const int blocks = (int)min((n + 255) / 256, (long long)4096);
-  hipLaunchKernelGGL(k_relu_copy, dim3(blocks), dim3(256), 0, s, z, a, n);
+  hipLaunchKernelGGL(k_act_copy, dim3(blocks), dim3(256), 0, s, z, a, dact, n, act);
+  return hipGetLastError();
+}
+
+// per-sample factors of a non-exp output activation g: psi = g(x), oscale = g'(x) / g(x)
+__global__ void k_out_scale(const float* __restrict__ x, float* __restrict__ oscale, int B, int oact) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) oscale[i] = vmc_out_dlog(oact, x[i]);
+}
+
+hipError_t launch_out_scale(hipStream_t s, const float* x, float* oscale, int B, int oact) {
+  hipLaunchKernelGGL(k_out_scale, dim3((B + 255) / 256), dim3(256), 0, s, x, oscale, B, oact);
   return hipGetLastError();
 }
 
@@ -382,18 +405,22 @@ hipError_t launch_scalar_accum(hipStream_t s, const float* eloc, const float* ra
 
 // ratio_b = (psi_w - beta H psi_w)/psi  (training.py:665-672)
 //         = exp(logit_w - logit_psi + shift_psi - shift_w) * (1 - beta * E_loc^w)
+// (a non-exp output activation g has no shift: psi_w / psi = g(x_w) / g(x_psi))
 __global__ void k_itswo_ratio(const float* __restrict__ lp, const float* __restrict__ lw,
                               const float* __restrict__ ew, float log_factor, float beta, int B,
-                              float* __restrict__ ratio) {
+                              float* __restrict__ ratio, int oact) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) ratio[i] = expf(lw[i] - lp[i] + log_factor) * (1.f - beta * ew[i]);
+  if (i >= B) return;
+  const float amp = oact == VMC_ACT_EXP_ ? expf(lw[i] - lp[i] + log_factor)
+                                         : vmc_act_rt(oact, lw[i]) / vmc_act_rt(oact, lp[i]);
+  ratio[i] = amp * (1.f - beta * ew[i]);
 }
 
 hipError_t launch_itswo_ratio(hipStream_t s, const float* logit_psi, const float* logit_omega,
                               const float* eloc_omega, float log_factor, float beta, int B,
-                              float* ratio) {
+                              float* ratio, int oact) {
   hipLaunchKernelGGL(k_itswo_ratio, dim3((B + 255) / 256), dim3(256), 0, s, logit_psi,
-                     logit_omega, eloc_omega, log_factor, beta, B, ratio);
+                     logit_omega, eloc_omega, log_factor, beta, B, ratio, oact);
   return hipGetLastError();
 }
 

@@ -70,7 +70,8 @@ __device__ __forceinline__ unsigned long long vmc_stamp() {
 // 4-wave variant of H = 256 owns 4 output tiles per wave and keeps fewer so that it fits 256
 // registers, i.e. two workgroups per CU).
 // UPRE: Philox site blocks per lane drawn one step ahead (2: N <= 128 sites, 4: N <= 256).
-template <int NT, int NW, int RTP, bool STAMP, bool W1L, bool FAST, int UPRE, bool RBM = false>
+// ACT: hidden activation (layers.NONLINEARITIES id); relu is the tuned path.
+template <int NT, int NW, int RTP, bool STAMP, bool W1L, bool FAST, int UPRE, bool RBM, int ACT>
 __global__ __launch_bounds__(NW * 64, NT == 16 ? (RTP == 0 ? SWEEP_OCC0 : 2) : 1) void k_sweep16(SweepArgs a) {
   static_assert(NT % NW == 0, "output tiles must divide over the waves");
   constexpr int NTH = NW * 64;
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(NW * 64, NT == 16 ? (RTP == 0 ? SWEEP_OCC0 : 2) : 1
 
   f32x4 own[TO];  // relu'd activations of this wave's own output tiles (B-operand layout)
   f32x4 zlast[TO];  // RBM: pre-activations of the last layer (the gradient path wants tanh of them)
+  f32x4 zown[TO];   // cosine: pre-activations of `own` (the gradient path wants -sin of them)
 
   // diagnostic stamps (STAMP instantiation only)
   unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
@@ -372,13 +374,20 @@ __global__ __launch_bounds__(NW * 64, NT == 16 ? (RTP == 0 ? SWEEP_OCC0 : 2) : 1
           for (int e = 0; e < 4; ++e) v[e] = tanhf(zlast[to][e]);
         }
         *(f32x4*)(dst + 16 * (wave * TO + to) + 4 * g) = v;
+        if (ACT == VMC_ACT_COS_ && a.dact_out && !(RBM && l == n_hidden)) {   // f'(z) = -sin z
+          f32x4 d;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[e] = -__sinf(zown[to][e]);
+          *(f32x4*)(a.dact_out + ((long long)l * a.B + chain0 + j) * Hp + 16 * (wave * TO + to) + 4 * g) = d;
+        }
       }
     }
   };
   // last-stage activation: relu (FC; the dot with w_out follows) or log cosh (RBM, w_out = 1)
   auto finish_own = [&](int to, const f32x4& z, bool last) {
+    if (ACT == VMC_ACT_COS_) zown[to] = z;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) own[to][e] = fmaxf(z[e], 0.f);
+    for (int e = 0; e < 4; ++e) own[to][e] = vmc_act<ACT>(z[e]);
     if (RBM && last) {
       zlast[to] = z;
 #pragma unroll
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(NW * 64, NT == 16 ? (RTP == 0 ? SWEEP_OCC0 : 2) : 1
     if (prev_kind == 2) {
       // Metropolis accept (graph_builders.py:75-88)
       // exp(dlogit) > sqrt(u)  <=>  dlogit > 0.5 log(u)  (monotone; u = 0 always accepts)
-      const bool acc = (gc < a.B) && ((ln - s_logit[c]) > s_hlu[c]);
+      const bool acc = (gc < a.B) && vmc_out_accept(a.oact, ln, s_logit[c], s_u[c], s_hlu[c]);
       if (j == 0) {
         if (acc) {
           s_logit[c] = ln;
@@ -691,7 +700,7 @@ static inline size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool
                                   (w1l ? N * (Hp + 4) : 0));
 }
 
-template <int NT, int NW, int RTP, bool RBM>
+template <int NT, int NW, int RTP, bool RBM, int ACT>
 static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
   const dim3 grid((a.B + 15) / 16), block(NW * 64);
   const size_t lds_full = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, true, RBM);
@@ -703,23 +712,27 @@ static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
   const bool fast2 = nblk <= 32 && plain, fast4 = nblk <= 64 && plain;
 #define SWEEP_LAUNCH(ST, WL, FA, UP)                                                          \
   do {                                                                                        \
-    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, NW, RTP, ST, WL, FA, UP, RBM>, \
+    hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, NW, RTP, ST, WL, FA, UP, RBM, ACT>, \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                            \
-    hipLaunchKernelGGL((k_sweep16<NT, NW, RTP, ST, WL, FA, UP, RBM>), grid, block, lds, s, a); \
+    hipLaunchKernelGGL((k_sweep16<NT, NW, RTP, ST, WL, FA, UP, RBM, ACT>), grid, block, lds, s, a); \
     return hipGetLastError();                                                                 \
   } while (0)
+  constexpr bool TUNED = ACT == VMC_ACT_RELU_;   // other activations only get the general variant
   if (a.dbg_cycles) {
-    if (!(w1l && fast2) || RBM || NT != 16) return hipErrorInvalidValue;   // diagnostic build: production variant only
-    if constexpr (!RBM && NT == 16) SWEEP_LAUNCH(true, true, true, 2);
+    if (!(w1l && fast2) || RBM || NT != 16 || !TUNED) return hipErrorInvalidValue;   // diagnostic build: production variant only
+    if constexpr (!RBM && NT == 16 && TUNED) SWEEP_LAUNCH(true, true, true, 2);
   }
-  if (w1l) {
-    if (fast2) SWEEP_LAUNCH(false, true, true, 2);
-    if (fast4) SWEEP_LAUNCH(false, true, true, 4);
-    SWEEP_LAUNCH(false, true, false, 2);
+  if constexpr (TUNED) {
+    if (w1l) {
+      if (fast2) SWEEP_LAUNCH(false, true, true, 2);
+      if (fast4) SWEEP_LAUNCH(false, true, true, 4);
+    } else {
+      if (fast2) SWEEP_LAUNCH(false, false, true, 2);
+      if (fast4) SWEEP_LAUNCH(false, false, true, 4);
+    }
   }
-  if (fast2) SWEEP_LAUNCH(false, false, true, 2);
-  if (fast4) SWEEP_LAUNCH(false, false, true, 4);
+  if (w1l) SWEEP_LAUNCH(false, true, false, 2);
   SWEEP_LAUNCH(false, false, false, 2);
 #undef SWEEP_LAUNCH
 }
@@ -729,15 +742,15 @@ static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
 // registers) was measured in round 2 and dropped: it spills 80-160 VGPRs at any number of
 // resident tiles and ran 1.42 ms per sweep against 1.14 ms alone, 2.92 against 2.18 ms with two
 // workgroups per CU (8192 chains), 7.1 against 6.1 ms at config 5.
-template <bool RBM>
+template <bool RBM, int ACT>
 static hipError_t launch_sweep16_r(hipStream_t s, const SweepArgs& a, int Hp) {
   switch (Hp / 16) {
 #ifndef VMC_QUICK   // development builds (-DVMC_QUICK) only instantiate H = 256, fully_connected
-    case 4: return launch_sweep16_t<4, 4, SWEEP_RT, RBM>(s, a);
-    case 8: return launch_sweep16_t<8, 4, SWEEP_RT, RBM>(s, a);
-    case 12: return launch_sweep16_t<12, 4, SWEEP_RT, RBM>(s, a);
+    case 4: return launch_sweep16_t<4, 4, SWEEP_RT, RBM, ACT>(s, a);
+    case 8: return launch_sweep16_t<8, 4, SWEEP_RT, RBM, ACT>(s, a);
+    case 12: return launch_sweep16_t<12, 4, SWEEP_RT, RBM, ACT>(s, a);
 #endif
-    case 16: return launch_sweep16_t<16, 8, SWEEP_RT, RBM>(s, a);
+    case 16: return launch_sweep16_t<16, 8, SWEEP_RT, RBM, ACT>(s, a);
     default: return hipErrorInvalidValue;
   }
 }

@@ -43,6 +43,10 @@ struct vmc_ctx {
   vmc_desc d;
   int N = 0, B = 0, L = 0, H = 0, Hp = 0;
   bool rbm = false;        // RestrictedBoltzmannNetwork instead of FullyConnectedNetwork
+  int hact = VMC_ACT_RELU_;  // hidden activation (layers.NONLINEARITIES id)
+  int oact = VMC_ACT_EXP_;   // output activation; exp: psi = exp(x - shift), else psi = g(x), no shift
+  float* oscale = nullptr;   // [B] (1/psi) d psi / d x of a non-exp output activation
+  float *dact_all = nullptr, *dact_alt = nullptr;   // [L][B][Hp] f'(z) next to act_all (cosine only)
   int n_hh = 0;            // H x H layers: L - 1 (FC) or L (RBM)
   int A = 0;               // activation buffers = n_hh + 1
   ParamLayout lay;
@@ -188,6 +192,7 @@ void swap_chain_buffers(vmc_ctx* c) {
   std::swap(c->configs, c->configs_alt);
   std::swap(p.z1, p.z1_alt); std::swap(p.logit, p.logit_alt); std::swap(p.onsite, p.onsite_alt);
   std::swap(c->act_all, c->act_alt);
+  std::swap(c->dact_all, c->dact_alt);
   for (size_t l = 0; l < c->act.size(); ++l) c->act[l] = c->act_all + (long long)l * c->B * c->Hp;
   c->parity ^= 1;
 }
@@ -301,6 +306,7 @@ TailArgs tail_args(vmc_ctx* c, int which) {
   a.n_units = c->H;
   a.on_base = c->ps[which].onsite;
   a.num_cus = c->num_cus;
+  a.act = c->hact; a.oact = c->oact;
   return a;
 }
 
@@ -390,6 +396,19 @@ int grow_tmp(vmc_ctx* c, long long rows) {
   return VMC_OK;
 }
 
+// layers.NONLINEARITIES on the host (the psi values vmc_amplitude hands back)
+float host_activation(int act, float x) {
+  switch (act) {
+    case VMC_ACT_RELU_: return x > 0.f ? x : 0.f;
+    case VMC_ACT_EXP_: return expf(x);
+    case VMC_ACT_COS_: return cosf(x);
+    case VMC_ACT_TAN_: return tanf(x);
+    case VMC_ACT_TANH_: return tanhf(x);
+    case VMC_ACT_SIGMOID_: return 1.f / (1.f + expf(-x));
+    default: return x;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -417,10 +436,10 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   const bool rbm = d->ansatz == VMC_ANSATZ_RBM;
   if (d->n_sites < 2 || d->batch_size < 1 || d->num_layers < (rbm ? 0 : 1) || d->layer_size < 1)
     return fail(nullptr, VMC_ERR_INVALID, "n_sites >= 2, batch_size, layer_size >= 1, num_layers >= 1 (rbm: >= 0) required");
-  if (d->nonlinearity != VMC_ACT_RELU)
-    return fail(nullptr, VMC_ERR_UNSUPPORTED, "only nonlinearity='relu' has a HIP kernel");
-  if (d->output_activation != VMC_ACT_EXP)
-    return fail(nullptr, VMC_ERR_UNSUPPORTED, "only output_activation='exp' has a HIP kernel");
+  if (d->nonlinearity < 0 || d->nonlinearity > 6 || d->output_activation < 0 || d->output_activation > 6)
+    return fail(nullptr, VMC_ERR_INVALID, "unknown activation id (layers.NONLINEARITIES has 7 entries)");
+  if (rbm && d->output_activation != VMC_ACT_EXP)
+    return fail(nullptr, VMC_ERR_INVALID, "the rbm ansatz has no output_activation: it is always exp (wavefunctions.py:419-420)");
   if (d->layer_size > 256)
     return fail(nullptr, VMC_ERR_UNSUPPORTED, "fc_layer_size > 256 not supported by the register-resident kernels");
   {  // the sampler keeps 16 chains' spins, z1 and operands in LDS (160 KiB per CU)
@@ -447,6 +466,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   c->N = d->n_sites; c->B = d->batch_size; c->L = d->num_layers; c->H = d->layer_size;
   c->Hp = (c->H + 63) / 64 * 64;
   c->rbm = rbm;
+  c->hact = d->nonlinearity; c->oact = d->output_activation;
   c->lay = make_layout(rbm, c->N, c->H, c->L);
   c->n_hh = c->lay.n_hh; c->A = c->n_hh + 1;
   c->P = vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
@@ -496,8 +516,14 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(hipMemsetAsync(c->delta_all, 0, L * B * Hp * sizeof(float), c->stream));
   for (int l = 0; l < L; ++l) c->delta[l] = c->delta_all + l * B * Hp;
   for (int i = 0; i < 4; ++i) CA(dalloc(&c->d_batch[i / 2][i % 2], L + 1));
-  CA(dalloc(&c->ratio, B)); CA(dalloc(&c->ones, B));
+  CA(dalloc(&c->ratio, B)); CA(dalloc(&c->ones, B)); CA(dalloc(&c->oscale, B));
   CA(launch_fill(c->stream, c->ones, 1.f, B));
+  CA(launch_fill(c->stream, c->oscale, 1.f, B));
+  if (c->hact == VMC_ACT_COS_) {
+    CA(dalloc(&c->dact_all, L * B * Hp)); CA(dalloc(&c->dact_alt, L * B * Hp));
+    CA(hipMemsetAsync(c->dact_all, 0, L * B * Hp * sizeof(float), c->stream));
+    CA(hipMemsetAsync(c->dact_alt, 0, L * B * Hp * sizeof(float), c->stream));
+  }
   CA(dalloc(&c->acc, 2 * P + 8)); CA(dalloc(&c->adam_m, P)); CA(dalloc(&c->adam_v, P));
   CA(dalloc(&c->grad_tmp, P));
   CA(hipMemsetAsync(c->acc, 0, (2 * P + 8) * sizeof(float), c->stream));
@@ -535,6 +561,7 @@ void vmc_destroy(vmc_ctx* c) {
   }
   if (c->act_all) hipFree(c->act_all);
   if (c->act_alt) hipFree(c->act_alt);
+  for (float* q : {c->oscale, c->dact_all, c->dact_alt}) if (q) hipFree(q);
   void* ptrs[] = {c->configs, c->configs_alt, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->d_accepted, c->d_sum,
@@ -670,7 +697,8 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
   const float shift = c->ps[which].shift;
   for (int64_t i = 0; i < n_rows; ++i) {
     if (logit) logit[i] = host[i];
-    if (psi) psi[i] = expf(host[i] - shift);   // wavefunctions.py:232, 351
+    // wavefunctions.py:350-353: exp(x - shift) (232), or the output activation itself, no shift
+    if (psi) psi[i] = c->oact == VMC_ACT_EXP_ ? expf(host[i] - shift) : host_activation(c->oact, host[i]);
   }
   return VMC_OK;
 }
@@ -696,11 +724,13 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = step0; a.n_steps = n_steps;
   a.waves = c->sweep_waves; a.no_w1l = c->sweep_no_w1l;
+  a.act = c->hact; a.oact = c->oact;
   // the activations of the final chains are handed to the gradient path only when a gradient
   // accumulate has been seen since the previous launch (equilibration / evaluation sweeps skip
   // the [L][B][Hp] write-back; gradient_sums then recomputes them)
   const bool hand_over = !dbg && (injected || c->acc_since_sweep || c->sr_cap > 0);
   a.act_out = hand_over ? c->act_alt : nullptr;
+  a.dact_out = hand_over ? c->dact_alt : nullptr;
   a.cache_in_valid = (!dbg && !injected && p.cache_valid) ? 1 : 0;
   hipStream_t st = overtake ? c->sweep_stream : c->stream;
   if (overtake) HIPCHK(c, hipStreamWaitEvent(st, dep, 0));
@@ -798,7 +828,7 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   a.pp = c->ps[0].packed();
   a.configs_in = c->configs; a.z1_in = c->ps[0].z1; a.logit_in = c->ps[0].logit;
   a.configs = c->configs_alt; a.z1 = c->ps[0].z1_alt; a.logit = c->ps[0].logit_alt;
-  a.accepted = c->d_accepted; a.dbg_cycles = d; a.waves = 8;
+  a.accepted = c->d_accepted; a.dbg_cycles = d; a.waves = 8; a.act = c->hact; a.oact = c->oact;
   a.B = c->B; a.N = c->N; a.n_hidden = c->n_hh; a.chain_offset = c->d.chain_offset;
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = c->step; a.n_steps = n_steps;
@@ -862,7 +892,7 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
   // act[l] = relu(z_{l+1}); RBM: the last one is tanh(z_last) = d sum log cosh / d z_last
   if (!c->acts_valid) {
     if (c->rbm && NH == 0) HIPCHK(c, launch_tanh_copy(c->stream, p.z1, c->act[0], (long long)B * Hp));
-    else HIPCHK(c, launch_relu_copy(c->stream, p.z1, c->act[0], (long long)B * Hp));
+    else HIPCHK(c, launch_act_copy(c->stream, p.z1, c->act[0], c->dact_all, (long long)B * Hp, c->hact));
   }
   for (int l = 1; l <= NH && !c->acts_valid; ++l) {
     GemmArgs g; memset(&g, 0, sizeof(g));
@@ -870,12 +900,17 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
     g.B = p.theta + off_w(c, l); g.sbk = H; g.sbn = 1;
     g.M = B; g.N = H; g.K = H; g.C = c->act[l]; g.ldc = Hp;
     g.bias = p.theta + off_b(c, l); g.epilogue = (c->rbm && l == NH) ? 7 : 1; g.splitk = 1;
+    g.act = c->hact;
+    if (c->dact_all && g.epilogue == 1) g.dact_out = c->dact_all + (long long)l * B * Hp;
     HIPCHK(c, launch_gemm(c->stream, g));
   }
+  // psi = g(x) with a non-exp output activation: O_k carries the per-sample factor g'(x) / g(x)
+  if (c->oact != VMC_ACT_EXP_) HIPCHK(c, launch_out_scale(c->stream, p.logit, c->oscale, B, c->oact));
   // back-propagation of d logit / d z_l: FC delta[NH] = w_out (.) relu'; RBM delta[NH] = tanh(z)
   // (which IS act[NH]); then the W_l^T chain through the relu masks -- one launch, 16 chains per
   // workgroup, transposed weight fragments on 16x16x4 MFMA (k_backprop16)
-  HIPCHK(c, launch_backprop16(c->stream, c->act_all, c->delta_all, p.p16t, p.woutp, B, Hp, NH, c->rbm));
+  HIPCHK(c, launch_backprop16(c->stream, c->act_all, c->delta_all, p.p16t, p.woutp, B, Hp, NH, c->rbm, c->hact,
+                              c->dact_all, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr));
   // Every weight-gradient GEMM is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows 0..K_in-1
   // give dW, the implicit ones row gives db (b_l sits right behind w_l in theta), the unscaled
   // product goes to g1 and the w-scaled one to g2.  All NH+2 of them run as ONE batched launch
@@ -896,7 +931,7 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
     if (c->rbm)   // onsite layer: d logit / d w_on = x, d logit / d b_on = 1
       add(c->configs, N, N, c->ones, 1, 0, 1, c->lay.off_won);
     else          // output layer: d logit / d w_out = a_L, d logit / d b_out = 1
-      add(c->act[NH], Hp, H, c->ones, 1, 0, 1, off_wout(c));
+      add(c->act[NH], Hp, H, c->oscale, 1, 0, 1, off_wout(c));   // oscale == 1 for the exp output
     for (int l = NH; l > 0; --l) add(c->act[l - 1], Hp, H, c->delta[l], Hp, 1, H, off_w(c, l));
     add(c->configs, N, N, c->delta[0], Hp, 1, H, off_w(c, 0));
     HIPCHK(c, hipMemcpy(c->d_batch[slot][par], tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
@@ -942,7 +977,7 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
     PROPAGATE(local_energy_device(c, VMC_OMEGA));             // training.py:664, 667
     PROPAGATE(ensure_cache(c, VMC_PSI));
     HIPCHK(c, launch_itswo_ratio(c->stream, c->ps[0].logit, c->ps[1].logit, c->ps[1].eloc,
-                                 c->ps[0].shift - c->ps[1].shift, beta, c->B, c->ratio));
+                                 c->ps[0].shift - c->ps[1].shift, beta, c->B, c->ratio, c->oact));
     w = c->ratio; e = c->ps[1].eloc;
   }
   PROPAGATE(ensure_cache(c, VMC_PSI));
@@ -1062,6 +1097,7 @@ int vmc_set_adam_state(vmc_ctx* c, const float* m, const float* v, int64_t t) {
 
 int vmc_update_norm(vmc_ctx* c, float max_value) {
   ENTER(c);
+  if (c->oact != VMC_ACT_EXP_) return VMC_OK;   // wavefunctions.py:276-277: no exp_norm_shift, nothing to do
   PROPAGATE(ensure_cache(c, VMC_PSI));
   HIPCHK(c, launch_max(c->stream, c->ps[0].logit, c->B, c->d_max));
   float mx = 0.f;
@@ -1114,6 +1150,8 @@ int vmc_epoch_log_overlap(vmc_ctx* c, float beta, int64_t n_eq_steps, int32_t n_
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   ENTER(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
+  if (n_batches > 0 && (c->oact != VMC_ACT_EXP_ || c->hact == VMC_ACT_COS_))
+    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation and every hidden activation except cos");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_tang, c->sr_t, c->sr_ones};
   for (void* q : old) if (q) hipFree(q);
@@ -1207,7 +1245,7 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
     g.A = c->sr_cfg; g.sam = N; g.sak = 1; g.B = v + off_w(c, 0); g.sbk = H; g.sbn = 1;
     g.M = rows; g.N = H; g.K = N; g.C = tang[0]; g.ldc = Hp;
     g.bias = v + off_b(c, 0); g.mask = c->sr_act; g.ldmask = Hp;
-    g.epilogue = (c->rbm && L == 1) ? 4 : 5; g.splitk = 1;
+    g.epilogue = (c->rbm && L == 1) ? 4 : 5; g.splitk = 1; g.act = c->hact;
     HIPCHK(c, launch_gemm(c->stream, g));
   }
   for (int l = 1; l < L; ++l) {  // adot_{l+1} = relu' (.) (adot_l W_l + a_l V_l + v_bl)
@@ -1219,7 +1257,7 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
     HIPCHK(c, launch_gemm(c->stream, g));
     g.A = c->sr_act + (long long)(l - 1) * R * Hp; g.B = v + off_w(c, l);
     g.bias = v + off_b(c, l); g.mask = c->sr_act + (long long)l * R * Hp; g.ldmask = Hp;
-    g.epilogue = (c->rbm && l == L - 1) ? 8 : 6;
+    g.epilogue = (c->rbm && l == L - 1) ? 8 : 6; g.act = c->hact;
     HIPCHK(c, launch_gemm(c->stream, g));
   }
   if (c->rbm)

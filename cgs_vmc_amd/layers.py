@@ -1,7 +1,10 @@
 """Activation registry (mirror of cgs_vmc/layers.py:13-21).
 
 In the reference the values are TensorFlow functions; here they are named tokens that
-the engine maps to kernel epilogues (cgsvmc.h VMC_ACT_*).  The periodic-conv / residual /
+the engine maps to kernel epilogues (cgsvmc.h VMC_ACT_*): all seven are available as the hidden
+nonlinearity (template parameter of the fused row / sampler kernels; relu is the tuned path) and
+as the output activation (exp works in the log domain with exp_norm_shift, any other g gives
+psi = g(x) and linear-domain ratios).  The periodic-conv / residual /
 MPS / graph-conv building blocks of layers.py serve only ansaetze outside the hot path
  and are not provided.
 """

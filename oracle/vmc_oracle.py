@@ -426,8 +426,18 @@ def constant_psi_local_energy(configs, bonds, j_x, j_z):
 # --------------------------------------------------------------------------- #
 # d logit / d theta, batch-summed with weights (manual back-prop)
 # --------------------------------------------------------------------------- #
+def output_dlog(logit, output_activation, dtype):
+  """(1/psi) d psi / d x for psi = g(x): the factor tf.gradients(psi / stop_gradient(psi))
+  (training.py:545) puts in front of d x / d theta.  1 for the exp output."""
+  if output_activation == 'exp':
+    return np.ones_like(logit)
+  g = NONLINEARITIES[output_activation](logit)
+  with np.errstate(divide='ignore', invalid='ignore'):
+    return (_NONLIN_DERIV[output_activation](logit, g) / g).astype(dtype)
+
+
 def weighted_logit_grads(theta, configs, weights, layer_size, num_layers,
-                         nonlinearity='relu', dtype=np.float32):
+                         nonlinearity='relu', dtype=np.float32, output_activation='exp'):
   """Returns sum_b weights[b, c] * d logit_b / d theta for every column c of
   `weights` [B, C] -> [C, P].
 
@@ -441,7 +451,9 @@ def weighted_logit_grads(theta, configs, weights, layer_size, num_layers,
     w_b = w_b[:, None]
   th = np.asarray(theta, dtype=dtype)
   layers = unpack(th, x.shape[1], layer_size, num_layers)
-  _, zs, acts = fc_logit(th, x, layer_size, num_layers, nonlinearity, dtype, True)
+  logit, zs, acts = fc_logit(th, x, layer_size, num_layers, nonlinearity, dtype, True)
+  # a non-exp output activation g: d (psi/psi_ng) = (g'(x)/g(x)) d x, a per-sample factor
+  w_b = w_b * output_dlog(logit, output_activation, dtype)[:, None]
   dact = _NONLIN_DERIV[nonlinearity]
   n_cols = w_b.shape[1]
   grads = [[] for _ in range(n_cols)]
@@ -493,18 +505,27 @@ class Accumulators:
     return self.r_total / self.r_count
 
 
+def _act_kwargs(ansatz, nonlinearity, output_activation):
+  kw = {'nonlinearity': nonlinearity}
+  if ansatz == 'fully_connected':
+    kw['output_activation'] = output_activation
+  return kw
+
+
 def energy_gradient_accumulate(acc, theta, configs, bonds, j_x, j_z, shift,
                                layer_size, num_layers, dtype=np.float32,
-                               ansatz='fully_connected'):
+                               ansatz='fully_connected', nonlinearity='relu',
+                               output_activation='exp'):
   """One `accumulate_gradients` run of EnergyGradientOptimizer (training.py:539-558)."""
   psi_fn = ANSATZ[ansatz][0]
   grads_fn = ANSATZ[ansatz][2] or weighted_logit_grads
-  amp = lambda c: psi_fn(theta, c, layer_size, num_layers, shift, dtype=dtype)
+  kw = _act_kwargs(ansatz, nonlinearity, output_activation)
+  amp = lambda c: psi_fn(theta, c, layer_size, num_layers, shift, dtype=dtype, **kw)
   psi = amp(configs)
   e_loc = local_value(amp, configs, bonds, j_x, j_z, psi, dtype)     # 542-543
   ones = np.ones_like(e_loc)
   g = grads_fn(theta, configs, np.stack([ones, e_loc], 1),
-               layer_size, num_layers, dtype=dtype)                  # 545-547
+               layer_size, num_layers, dtype=dtype, **kw)            # 545-547
   acc.g1_total += g[0]; acc.g2_total += g[1]; acc.g_count += 1        # 550-553
   acc.e_total += e_loc.sum(dtype=dtype); acc.e_count += e_loc.size    # 555
   return e_loc
@@ -595,7 +616,8 @@ def sr_conjugate_gradient(o, e_loc, diag_shift, tol, max_iter):
 # --------------------------------------------------------------------------- #
 def log_overlap_accumulate(acc, theta, theta_omega, configs, bonds, j_x, j_z, shift,
                            shift_omega, beta, layer_size, num_layers, dtype=np.float32,
-                           ansatz='fully_connected'):
+                           ansatz='fully_connected', nonlinearity='relu',
+                           output_activation='exp'):
   """One `accumulate_gradients` run of LogOverlapImaginaryTimeSWO.
 
   The supervisor omega is a deepcopy with its OWN exp_norm_shift variable, created at
@@ -604,8 +626,9 @@ def log_overlap_accumulate(acc, theta, theta_omega, configs, bonds, j_x, j_z, sh
   """
   psi_fn = ANSATZ[ansatz][0]
   grads_fn = ANSATZ[ansatz][2] or weighted_logit_grads
-  amp = lambda c: psi_fn(theta, c, layer_size, num_layers, shift, dtype=dtype)
-  amp_w = lambda c: psi_fn(theta_omega, c, layer_size, num_layers, shift_omega, dtype=dtype)
+  kw = _act_kwargs(ansatz, nonlinearity, output_activation)
+  amp = lambda c: psi_fn(theta, c, layer_size, num_layers, shift, dtype=dtype, **kw)
+  amp_w = lambda c: psi_fn(theta_omega, c, layer_size, num_layers, shift_omega, dtype=dtype, **kw)
   psi = amp(configs)                                                   # 661
   psi_w = amp_w(configs)                                               # 662
   h_psi_w = apply_in_place(amp_w, configs, bonds, j_x, j_z, psi_w, dtype)  # 664
@@ -614,7 +637,7 @@ def log_overlap_accumulate(acc, theta, theta_omega, configs, bonds, j_x, j_z, sh
   ratio = ite / psi                                                    # 672
   ones = np.ones_like(ratio)
   g = grads_fn(theta, configs, np.stack([ones, ratio], 1),
-               layer_size, num_layers, dtype=dtype)                    # 674-679
+               layer_size, num_layers, dtype=dtype, **kw)              # 674-679
   acc.g1_total += g[0]; acc.g2_total += g[1]; acc.g_count += 1
   acc.e_total += e_loc.sum(dtype=dtype); acc.e_count += e_loc.size     # 689
   acc.r_total += ratio.sum(dtype=dtype); acc.r_count += ratio.size     # 690
@@ -686,10 +709,12 @@ def torus_bonds(lx, ly, next_nearest=False):
 # Loops with the reference's call structure (used as the timed CPU baseline)
 # --------------------------------------------------------------------------- #
 def run_sweeps(theta, configs, n_steps, seed, step0, layer_size, num_layers, shift=-10.0,
-               chain_offset=0, dtype=np.float32, ansatz='fully_connected'):
+               chain_offset=0, dtype=np.float32, ansatz='fully_connected', nonlinearity='relu',
+               output_activation='exp'):
   """n_steps mc_steps, one host-level call each with two forwards, as
   training.py:608-609 / evaluation.py:138-139 drive graph_builders.py:38-89."""
-  amp = lambda c: ANSATZ[ansatz][0](theta, c, layer_size, num_layers, shift, dtype=dtype)
+  kw = _act_kwargs(ansatz, nonlinearity, output_activation)
+  amp = lambda c: ANSATZ[ansatz][0](theta, c, layer_size, num_layers, shift, dtype=dtype, **kw)
   ids = np.arange(configs.shape[0], dtype=np.uint32) + np.uint32(chain_offset)
   accepted = 0
   for t in range(n_steps):

@@ -316,10 +316,8 @@ def test_update_norm_rule():
 
 def test_error_behaviour():
   from cgs_vmc_amd.engine import VmcEngine
-  with pytest.raises(NotImplementedError):
-    VmcEngine(16, 8, 2, 32, nonlinearity='tanh')
-  with pytest.raises(NotImplementedError):
-    VmcEngine(16, 8, 2, 512)
+  with pytest.raises(ValueError):
+    VmcEngine(16, 8, 2, 32, nonlinearity='swish')         # not in layers.NONLINEARITIES
   with pytest.raises(ValueError):
     VmcEngine(16, 0, 2, 32)
   eng = VmcEngine(16, 8, 2, 32)

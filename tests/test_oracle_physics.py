@@ -131,6 +131,42 @@ def test_weighted_grads_vs_autograd_and_fd():
   np.testing.assert_allclose(g32, g, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('act,oact', [('tanh', 'exp'), ('sigmoid', 'tanh'), ('cos', 'sigmoid'),
+                                      ('relu', 'identity'), ('identity', 'cos'), ('tan', 'exp')])
+def test_general_activation_grads_vs_autograd(act, oact):
+  """Every layers.NONLINEARITIES entry as hidden / output activation: the oracle's weighted
+  gradients equal torch.autograd of sum_b w_b psi_b / stop_gradient(psi_b) (training.py:545)."""
+  n, h, L = 8, 16, 2
+  theta, cfg = _setup(n, h, L, 12)
+  theta = (0.4 * theta).astype(np.float32); theta[-1] = 0.7
+  wts = np.random.default_rng(6).standard_normal((12, 2))
+  g = vo.weighted_logit_grads(theta, cfg, wts, h, L, nonlinearity=act, dtype=np.float64,
+                              output_activation=oact)
+  tf = {'relu': torch.relu, 'exp': torch.exp, 'cos': torch.cos, 'tan': torch.tan,
+        'tanh': torch.tanh, 'sigmoid': torch.sigmoid, 'identity': lambda v: v}
+  tt = torch.tensor(theta.astype(np.float64), requires_grad=True)
+  a = torch.tensor(cfg.astype(np.float64))
+  off = 0
+  fan = n
+  for l in range(L + 1):
+    out = h if l < L else 1
+    w = tt[off:off + fan * out].reshape(fan, out); off += fan * out
+    b = tt[off:off + out]; off += out
+    a = a @ w + b
+    if l < L:
+      a = tf[act](a)
+    fan = out
+  x = a[:, 0]
+  psi = torch.exp(x + 10.0) if oact == 'exp' else tf[oact](x)
+  np.testing.assert_allclose(psi.detach().numpy(),
+                             vo.fc_psi(theta, cfg, h, L, nonlinearity=act, output_activation=oact,
+                                       dtype=np.float64), rtol=1e-12)
+  for c in range(2):
+    (ga,) = torch.autograd.grad(((psi / psi.detach()) * torch.tensor(wts[:, c])).sum(), tt,
+                                retain_graph=True)
+    np.testing.assert_allclose(g[c], ga.numpy(), rtol=1e-9, atol=1e-11)
+
+
 def test_energy_gradient_is_covariance():
   """training.py:560-564 with tf.gradients' batch SUM: grad = B * Cov_b(E, O_k)."""
   n, h, L = 8, 16, 2

@@ -18,3 +18,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1
 python3 $ROOT/bench.py --workload $WL > $OUT/bench.json 2> $OUT/bench.err
 cd $ROOT && python3 tools/summarise_profiles.py $TAG
+# raw counter dumps are large; the summaries under gpurun_out/<tag>_summary are what is kept
+rm -rf $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/stats
