@@ -21,7 +21,8 @@ VMC_ERR_STATE = -4
 VMC_PSI, VMC_OMEGA = 0, 1
 VMC_MODE_ENERGY_GRADIENT, VMC_MODE_LOG_OVERLAP_ITSWO = 0, 1
 # wavefunctions.WAVEFUNCTION_TYPES with kernels (cgsvmc.h VMC_ANSATZ_*)
-ANSATZ_IDS = {'fully_connected': 0, 'rbm': 1}
+ANSATZ_IDS = {'fully_connected': 0, 'rbm': 1, 'conv_2d': 2, 'res_net_2d': 3}
+CONV_ANSATZ = ('conv_2d', 'res_net_2d')
 # layers.NONLINEARITIES ids (cgsvmc.h)
 ACT_IDS = {'relu': 0, 'exp': 1, 'cos': 2, 'tan': 3, 'tanh': 4, 'sigmoid': 5, 'identity': 6}
 
@@ -33,6 +34,8 @@ class VmcDesc(C.Structure):
       ('output_activation', C.c_int32), ('device', C.c_int32), ('chain_offset', C.c_int32),
       ('ansatz', C.c_int32), ('reserved', C.c_int32),
       ('seed', C.c_uint64), ('stream', C.c_void_p),
+      ('kernel_size', C.c_int32), ('size_x', C.c_int32), ('size_y', C.c_int32),
+      ('reserved2', C.c_int32),
   ]
 
 
@@ -48,6 +51,7 @@ _ctx = C.c_void_p
 SIGNATURES = {
     'vmc_num_params': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     'vmc_num_params_ansatz': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'vmc_num_params_conv': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'vmc_create': (C.c_int, [C.POINTER(VmcDesc), C.POINTER(_ctx)]),
     'vmc_destroy': (None, [_ctx]),
     'vmc_last_error': (C.c_char_p, [_ctx]),
@@ -112,7 +116,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 _STAMP_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libcgsvmc_hip.stamp')
 # the files the library is built from, in the order csrc/Makefile hashes them
 _SOURCES = ('vmc_api.hip', 'mlp.hip', 'eloc.hip', 'grad.hip', 'sr.hip', 'conv.hip', 'act_tail.hip',
-            'act_sweep.hip', 'common.hpp', 'tail16.hpp', 'sweep16.hpp',
+            'act_sweep.hip', 'common.hpp', 'tail16.hpp', 'sweep16.hpp', 'conv.hpp',
             os.path.join('..', '..', 'include', 'cgsvmc.h'))
 
 

@@ -1,0 +1,109 @@
+// Convolutional ansatz types (Conv2DNetwork, wavefunctions.py:531-615; ResNet2D, 710-809; on
+// layers.Conv2dPeriodic / ResBlock2d, layers.py:89-229) for gfx950: shared descriptors and
+// launcher declarations.  Kernels: conv.hip.  DESIGN.md 4 "Convolutional ansatz".
+#pragma once
+#include "common.hpp"
+
+#define CONV_MAX_LAYERS 32
+#define CONV_FP 16          // channel tile: num_conv_filters <= 16, zero padded to 16
+
+// Geometry of one network.  A feature map of one sample is stored -- in LDS and in the HBM tapes
+// alike -- channel-group major: [4 groups][GS dwords], element (site, channel c) at
+// (c / 4) * GS + 4 * site + c % 4, with GS >= 4 N a multiple of 64 dwords so that the 16-lane
+// groups of ds_read_b128 / ds_write_b128 fall on distinct banks.
+struct ConvGeom {
+  int K;        // kernel_size
+  int D1, D2;   // size_x, size_y: inputs are reshaped to [-1, size_x, size_y, 1] (wavefunctions.py:596)
+  int N;        // D1 * D2
+  int F;        // num_conv_filters
+  int n_conv;   // number of Conv2dPeriodic modules: num_conv_layers, or 1 + 2 num_resnet_blocks
+  int resnet;   // 0: Conv2DNetwork, 1: ResNet2D
+  int hact;     // hidden activation id of Conv2DNetwork (ResNet2D: selu, layers.py:226)
+  int GS;       // dwords per channel group of a feature map (see above)
+  int lo, hi;   // periodic padding in front / behind: (K-1)/2 and K/2 on both axes (layers.py:132-141)
+};
+
+// One packed parameter set (k_conv_pack):
+//   w0   [Q0][64]           first convolution (1 input channel), taps are the k index:
+//                           lane (m, g) of k-step q = W0[tap 4q+g][0][cout m]
+//   wf   [n_conv-1][K*K][64][4]  forward fragments of convolutions 1..: lane (m, g), element e =
+//                           W[tap][cin 4g+e][cout m]        (A operand of v_mfma_f32_16x16x4_f32)
+//   wb   same shape: the transposed convolution, lane (m, g), e = W[K*K-1-tap][cin m][cout 4g+e]
+//   bias [n_conv][16]
+struct ConvParams {
+  const float* w0;
+  const float* wf;
+  const float* wb;
+  const float* bias;
+};
+
+struct ConvRowsArgs {
+  ConvGeom g;
+  ConvParams p;
+  const float* configs;     // [n_base][N] +-1
+  const int2* rowinfo;      // [n_rows] {chain, +-(bond+1) or 0}
+  const int2* bonds;        // [n_bonds]
+  const float* half_jx;     // [n_bonds]
+  const float* logit_base;  // [n_base] (ratio mode)
+  const int* n_rows_dev;    // device row count or nullptr
+  int n_rows;               // host row count / upper bound
+  int ratio;                // 1: out = half_jx[bond] * psi'/psi, 0: out = logit
+  int oact;
+  int G;                    // samples per pass (LDS resident)
+  float* out;               // [n_rows]
+  float* tape;              // [n_conv-1][n_rows][4 GS] inputs of convolutions 1.. (gradient path) or nullptr
+  long long tape_stride;    // floats between the tapes of consecutive convolutions
+};
+
+struct ConvSweepArgs {
+  ConvGeom g;
+  ConvParams p;
+  const float* configs_in;  // [B][N]
+  const float* logit_in;    // [B] (read when cache_in_valid)
+  float* configs;           // [B][N] out
+  float* logit;             // [B] out
+  unsigned long long* accepted;
+  const int* inj_up; const int* inj_dn; const float* inj_u;
+  unsigned char* acc_mask;
+  int* dbg_up; int* dbg_dn; float* dbg_u;
+  int oact;
+  int cache_in_valid;
+  int B, G;
+  int chain_offset;
+  uint32_t seed_lo, seed_hi;
+  unsigned long long step0;
+  long long n_steps;
+};
+
+struct ConvBackArgs {
+  ConvGeom g;
+  ConvParams p;
+  const float* tape;        // [n_conv-1][B][4 GS]
+  long long tape_stride;
+  const float* oscale;      // [B] (1/psi) d psi / d logit (1 for the exp output)
+  float* delta;             // [n_conv][B][4 GS]  d logit / d (output of convolution l)
+  long long delta_stride;
+  int B, G;
+};
+
+struct ConvDwArgs {
+  ConvGeom g;
+  const float* configs;     // [B][N]
+  const float* tape;  long long tape_stride;
+  const float* delta; long long delta_stride;
+  const float* w;           // [B] weights of the second (scaled) sum
+  int B;
+  int n_slices;             // sample slices = gridDim.x
+  float* ws;                // [n_slices][n_conv][2][(K*K*16 + 1) * 16] partial sums
+  float* g1; float* g2;     // accumulators (theta layout), += on reduce
+};
+
+size_t conv_rows_lds(const ConvGeom& g, int G);
+int conv_pick_group(const ConvGeom& g, int waves);
+long long conv_num_params(int n_conv, int F, int K);
+hipError_t launch_conv_pack(hipStream_t s, const float* theta, const ConvGeom& g, float* w0,
+                            float* wf, float* wb, float* bias);
+hipError_t launch_conv_rows(hipStream_t s, const ConvRowsArgs& a, int num_cus);
+hipError_t launch_conv_sweep(hipStream_t s, const ConvSweepArgs& a);
+hipError_t launch_conv_back(hipStream_t s, const ConvBackArgs& a, int num_cus);
+hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a);

@@ -2,6 +2,7 @@
 // kernels in mlp.hip / eloc.hip / grad.hip.  One vmc_ctx per GPU, all work on ctx->stream.
 #include "../../include/cgsvmc.h"
 #include "common.hpp"
+#include "conv.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -27,6 +28,8 @@ struct ParamSet {
   // psi only: the buffers the NEXT sampler launch writes (see vmc_ctx::configs_alt)
   float *z1_alt = nullptr, *onsite_alt = nullptr, *logit_alt = nullptr;
   float* eloc = nullptr;   // [B]
+  // convolutional ansatz types: fragment images of conv.hpp ConvParams
+  float *cw0 = nullptr, *cwf = nullptr, *cwb = nullptr, *cbias = nullptr;
   bool packed_valid = false, cache_valid = false, has_params = false;
   float shift = -10.f;     // wavefunctions.py:209
   PackedParams packed() const { return PackedParams{w1p, b1p, bh, p16, woutp, bout, won}; }
@@ -43,6 +46,15 @@ struct vmc_ctx {
   vmc_desc d;
   int N = 0, B = 0, L = 0, H = 0, Hp = 0;
   bool rbm = false;        // RestrictedBoltzmannNetwork instead of FullyConnectedNetwork
+  // Conv2DNetwork / ResNet2D (conv.hip).  The dense-ansatz members below keep harmless minimal
+  // shapes (H = filters, Hp = 64, no H x H layer); acts_valid tells whether the forward tapes
+  // hold the inputs of every convolution for psi on the current chains.
+  bool conv = false;
+  ConvGeom cg;
+  int cG = 1, cGs = 1;     // samples per workgroup pass of the row / backward kernels, of the sampler
+  float *ctape = nullptr, *cdelta = nullptr, *cws = nullptr;
+  long long ctape_stride = 0, cdelta_stride = 0;
+  int c_slices = 64;       // sample slices of the weight-gradient kernel
   int hact = VMC_ACT_RELU_;  // hidden activation (layers.NONLINEARITIES id)
   int oact = VMC_ACT_EXP_;   // output activation; exp: psi = exp(x - shift), else psi = g(x), no shift
   float* oscale = nullptr;   // [B] (1/psi) d psi / d x of a non-exp output activation
@@ -289,6 +301,11 @@ int ensure_packed(vmc_ctx* c, int which) {
   ParamSet& p = c->ps[which];
   if (!p.has_params) return fail(c, VMC_ERR_STATE, "parameters not set (vmc_set_params)");
   if (p.packed_valid) return VMC_OK;
+  if (c->conv) {
+    HIPCHK(c, launch_conv_pack(c->stream, p.theta, c->cg, p.cw0, p.cwf, p.cwb, p.cbias));
+    p.packed_valid = true;
+    return VMC_OK;
+  }
   HIPCHK(c, launch_pack(c->stream, p.theta, c->N, c->H, c->Hp, c->lay, p.w1p, p.b1p, p.bh, p.p16,
                         p.p16t, p.woutp, p.bout, p.won));
   p.packed_valid = true;
@@ -310,6 +327,26 @@ TailArgs tail_args(vmc_ctx* c, int which) {
   return a;
 }
 
+ConvParams conv_params(const ParamSet& p) { return ConvParams{p.cw0, p.cwf, p.cwb, p.cbias}; }
+
+// Conv2DNetwork / ResNet2D forward (wavefunctions.py:596-598, 790-792) of parameter set `which` on
+// the rows of a row list over `configs`: logits (ratio == false) or 0.5 jx psi'/psi of the
+// bond-exchanged configurations.  with_tape: the inputs of every convolution go to c->ctape.
+int conv_rows(vmc_ctx* c, int which, const float* configs, const int2* rowinfo, int rows,
+              const int* rows_dev, bool ratio, float* out, bool with_tape) {
+  ConvRowsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = c->cg; a.p = conv_params(c->ps[which]);
+  a.configs = configs; a.rowinfo = rowinfo;
+  a.bonds = c->bonds ? c->bonds : c->bond_dummy; a.half_jx = c->half_jx;
+  a.logit_base = c->ps[which].logit;
+  a.n_rows_dev = rows_dev; a.n_rows = rows; a.ratio = ratio ? 1 : 0; a.oact = c->oact;
+  a.G = c->cG; a.out = out;
+  a.tape = with_tape ? c->ctape : nullptr; a.tape_stride = c->ctape_stride;
+  HIPCHK(c, launch_conv_rows(c->stream, a, c->num_cus));
+  return VMC_OK;
+}
+
 // First layer of raw configurations on the matrix cores: z1[rows,Hp] = X[rows,N] W1p[N,Hp] + b1
 // through the LDS-tiled fp32-MFMA GEMM (64x64x32 tiles of spins and weights staged in LDS,
 // dwordx4 loads of the configuration batch).  wavefunctions.py:345-349, first snt.Linear.
@@ -328,6 +365,13 @@ int ensure_cache(vmc_ctx* c, int which) {
   PROPAGATE(ensure_packed(c, which));
   ParamSet& p = c->ps[which];
   if (p.cache_valid) return VMC_OK;
+  if (c->conv) {
+    Timer t(c, "tail_amp");
+    PROPAGATE(conv_rows(c, which, c->configs, c->rowinfo_id, c->B, nullptr, false, p.logit, which == VMC_PSI));
+    if (which == VMC_PSI) c->acts_valid = true;
+    p.cache_valid = true;
+    return VMC_OK;
+  }
   {
     Timer t(c, "z1");
     PROPAGATE(first_layer(c, p, c->configs, p.z1, c->B));
@@ -364,7 +408,11 @@ int local_energy_device(vmc_ctx* c, int which) {
   PROPAGATE(ensure_cache(c, which));
   PROPAGATE(ensure_list(c));
   ParamSet& p = c->ps[which];
-  {
+  if (c->conv) {
+    Timer t(c, "tail_eloc");
+    PROPAGATE(conv_rows(c, which, c->configs, c->rowinfo, (int)((long long)c->B * c->n_bonds), c->off + c->B,
+                        true, c->val, false));
+  } else {
     Timer t(c, "tail_eloc");
     TailArgs a = tail_args(c, which);
     a.z1 = p.z1; a.logit_base = p.logit; a.rowinfo = c->rowinfo;
@@ -424,6 +472,11 @@ int64_t vmc_num_params_ansatz(int32_t ansatz, int32_t n_sites, int32_t layer_siz
   return vmc_num_params(n_sites, layer_size, num_layers);
 }
 
+int64_t vmc_num_params_conv(int32_t ansatz, int32_t num_layers, int32_t num_filters, int32_t kernel_size) {
+  const int n_conv = ansatz == VMC_ANSATZ_RES_NET_2D ? 1 + 2 * num_layers : num_layers;
+  return conv_num_params(n_conv, num_filters, kernel_size);
+}
+
 const char* vmc_last_error(const vmc_ctx* ctx) {
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
@@ -431,18 +484,43 @@ const char* vmc_last_error(const vmc_ctx* ctx) {
 int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (!d || !out) return fail(nullptr, VMC_ERR_INVALID, "null argument");
   *out = nullptr;
-  if (d->ansatz != VMC_ANSATZ_FULLY_CONNECTED && d->ansatz != VMC_ANSATZ_RBM)
-    return fail(nullptr, VMC_ERR_UNSUPPORTED, "only the fully_connected and rbm ansatz types have HIP kernels");
+  if (d->ansatz < VMC_ANSATZ_FULLY_CONNECTED || d->ansatz > VMC_ANSATZ_RES_NET_2D)
+    return fail(nullptr, VMC_ERR_UNSUPPORTED, "only the fully_connected, rbm, conv_2d and res_net_2d ansatz types have HIP kernels");
   const bool rbm = d->ansatz == VMC_ANSATZ_RBM;
-  if (d->n_sites < 2 || d->batch_size < 1 || d->num_layers < (rbm ? 0 : 1) || d->layer_size < 1)
-    return fail(nullptr, VMC_ERR_INVALID, "n_sites >= 2, batch_size, layer_size >= 1, num_layers >= 1 (rbm: >= 0) required");
+  const bool conv = d->ansatz == VMC_ANSATZ_CONV_2D || d->ansatz == VMC_ANSATZ_RES_NET_2D;
+  const bool resnet = d->ansatz == VMC_ANSATZ_RES_NET_2D;
+  if (d->n_sites < 2 || d->batch_size < 1 || d->num_layers < ((rbm || resnet) ? 0 : 1) || d->layer_size < 1)
+    return fail(nullptr, VMC_ERR_INVALID, "n_sites >= 2, batch_size, layer_size >= 1, num_layers >= 1 (rbm, res_net_2d: >= 0) required");
+  ConvGeom cg;
+  memset(&cg, 0, sizeof(cg));
+  if (conv) {
+    // Conv2DNetwork reshapes its input to [-1, size_x, size_y, 1] (wavefunctions.py:596-597)
+    if (d->size_x < 1 || d->size_y < 1 || (long long)d->size_x * d->size_y != d->n_sites)
+      return fail(nullptr, VMC_ERR_INVALID, "size_x * size_y must equal num_sites");
+    if (d->kernel_size < 1 || d->kernel_size > 6)
+      return fail(nullptr, VMC_ERR_UNSUPPORTED, "kernel_size 1..6 supported by the convolution kernels (weights are register resident)");
+    if (d->layer_size > CONV_FP)
+      return fail(nullptr, VMC_ERR_UNSUPPORTED, "num_conv_filters > 16 not supported by the convolution kernels");
+    if (d->size_x < d->kernel_size / 2 || d->size_y < d->kernel_size / 2 || d->size_x > 1023 || d->size_y > 1023)
+      return fail(nullptr, VMC_ERR_UNSUPPORTED, "lattice sides must be in [kernel_size / 2, 1023]");
+    if (!resnet && d->nonlinearity == VMC_ACT_COS)
+      return fail(nullptr, VMC_ERR_UNSUPPORTED, "the cos nonlinearity is not offered by the convolution kernels");
+    cg.K = d->kernel_size; cg.D1 = d->size_x; cg.D2 = d->size_y; cg.N = d->n_sites; cg.F = d->layer_size;
+    cg.n_conv = resnet ? 1 + 2 * d->num_layers : d->num_layers;
+    cg.resnet = resnet ? 1 : 0; cg.hact = d->nonlinearity;
+    cg.GS = (4 * cg.N + 63) / 64 * 64;
+    cg.lo = (cg.K - 1) / 2; cg.hi = cg.K / 2;
+    if (cg.n_conv > CONV_MAX_LAYERS) return fail(nullptr, VMC_ERR_UNSUPPORTED, "too many convolutions");
+    if (conv_rows_lds(cg, 1) > 160 * 1024)
+      return fail(nullptr, VMC_ERR_UNSUPPORTED, "lattice too large: the feature maps of one sample must fit the 160 KiB of LDS");
+  }
   if (d->nonlinearity < 0 || d->nonlinearity > 6 || d->output_activation < 0 || d->output_activation > 6)
     return fail(nullptr, VMC_ERR_INVALID, "unknown activation id (layers.NONLINEARITIES has 7 entries)");
   if (rbm && d->output_activation != VMC_ACT_EXP)
     return fail(nullptr, VMC_ERR_INVALID, "the rbm ansatz has no output_activation: it is always exp (wavefunctions.py:419-420)");
-  if (d->layer_size > 256)
+  if (!conv && d->layer_size > 256)
     return fail(nullptr, VMC_ERR_UNSUPPORTED, "fc_layer_size > 256 not supported by the register-resident kernels");
-  {  // the sampler keeps 16 chains' spins, z1 and operands in LDS (160 KiB per CU)
+  if (!conv) {  // the sampler keeps 16 chains' spins, z1 and operands in LDS (160 KiB per CU)
     const int hp = (d->layer_size + 63) / 64 * 64;
     const int n_hh = rbm ? d->num_layers : d->num_layers - 1;
     const size_t need = sweep_lds_required(d->n_sites, hp, n_hh, rbm);
@@ -466,13 +544,16 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   c->N = d->n_sites; c->B = d->batch_size; c->L = d->num_layers; c->H = d->layer_size;
   c->Hp = (c->H + 63) / 64 * 64;
   c->rbm = rbm;
+  c->conv = conv; c->cg = cg;
+  if (conv) { c->L = 1; c->Hp = 64; c->overlap = false; }   // minimal dense-side shapes (unused)
   c->hact = d->nonlinearity; c->oact = d->output_activation;
   c->lay = make_layout(rbm, c->N, c->H, c->L);
   c->n_hh = c->lay.n_hh; c->A = c->n_hh + 1;
-  c->P = vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
+  c->P = conv ? vmc_num_params_conv(d->ansatz, d->num_layers, d->layer_size, d->kernel_size)
+              : vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
   c->stream = (hipStream_t)d->stream;
   if (const char* e = getenv("CGS_VMC_SWEEP_W1L")) c->sweep_no_w1l = atoi(e) == 0 ? 1 : 0;
-  if (const char* e = getenv("CGS_VMC_OVERLAP")) c->overlap = atoi(e) != 0;
+  if (const char* e = getenv("CGS_VMC_OVERLAP")) c->overlap = !conv && atoi(e) != 0;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -538,6 +619,21 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(dalloc(&c->rowinfo_id, B)); CA(launch_iota_rows(c->stream, c->rowinfo_id, (int)B));
   CA(dalloc(&c->bond_dummy, 1)); CA(hipMemsetAsync(c->bond_dummy, 0, sizeof(int2), c->stream));
   CA(dalloc(&c->offdiag, B));
+  if (conv) {
+    const long long KK = (long long)cg.K * cg.K, nl = cg.n_conv > 1 ? cg.n_conv - 1 : 1;
+    for (int w = 0; w < 2; ++w) {
+      ParamSet& p = c->ps[w];
+      CA(dalloc(&p.cw0, (KK + 3) / 4 * 64)); CA(dalloc(&p.cwf, nl * KK * 256)); CA(dalloc(&p.cwb, nl * KK * 256));
+      CA(dalloc(&p.cbias, (long long)cg.n_conv * 16));
+    }
+    c->cG = conv_pick_group(cg, 8);
+    if (c->cG > B) c->cG = (int)B;
+    c->cGs = (int)(B / c->num_cus); if (c->cGs < 1) c->cGs = 1; if (c->cGs > c->cG) c->cGs = c->cG;
+    c->ctape_stride = B * 4 * cg.GS; c->cdelta_stride = B * 4 * cg.GS;
+    CA(dalloc(&c->ctape, nl * c->ctape_stride)); CA(dalloc(&c->cdelta, (long long)cg.n_conv * c->cdelta_stride));
+    c->c_slices = B < 64 ? (int)B : 64;
+    CA(dalloc(&c->cws, (long long)c->c_slices * cg.n_conv * 2 * (KK * 16 + 1) * 16));
+  }
   CA(hipStreamSynchronize(c->stream));
 #undef CA
   *out = c;
@@ -556,12 +652,12 @@ void vmc_destroy(vmc_ctx* c) {
   for (int w = 0; w < 2; ++w) {
     ParamSet& p = c->ps[w];
     float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p16, p.p16t, p.woutp, p.bout, p.z1, p.logit, p.eloc, p.won, p.onsite,
-                     p.z1_alt, p.logit_alt, p.onsite_alt};
+                     p.z1_alt, p.logit_alt, p.onsite_alt, p.cw0, p.cwf, p.cwb, p.cbias};
     for (float* q : ptrs) if (q) hipFree(q);
   }
   if (c->act_all) hipFree(c->act_all);
   if (c->act_alt) hipFree(c->act_alt);
-  for (float* q : {c->oscale, c->dact_all, c->dact_alt}) if (q) hipFree(q);
+  for (float* q : {c->oscale, c->dact_all, c->dact_alt, c->ctape, c->cdelta, c->cws}) if (q) hipFree(q);
   void* ptrs[] = {c->configs, c->configs_alt, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->d_accepted, c->d_sum,
@@ -686,11 +782,15 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
     PROPAGATE(grow_tmp(c, n_rows));
     HIPCHK(c, hipMemcpyAsync(c->tmp_cfg, configs, n_rows * c->N * sizeof(float), hipMemcpyHostToDevice, c->stream));
     ParamSet& p = c->ps[which];
-    PROPAGATE(first_layer(c, p, c->tmp_cfg, c->tmp_z1, (int)n_rows));
-    if (c->rbm) HIPCHK(c, launch_onsite(c->stream, c->tmp_cfg, p.won, (int)n_rows, c->N, c->tmp_on));
-    TailArgs a = tail_args(c, which);
-    a.z1 = c->tmp_z1; a.on_base = c->tmp_on; a.n_rows = (int)n_rows; a.out = c->tmp_out; a.rowinfo = c->tmp_rowinfo;
-    HIPCHK(c, launch_tail(c->stream, a, c->Hp, false, c->rbm));
+    if (c->conv) {
+      PROPAGATE(conv_rows(c, which, c->tmp_cfg, c->tmp_rowinfo, (int)n_rows, nullptr, false, c->tmp_out, false));
+    } else {
+      PROPAGATE(first_layer(c, p, c->tmp_cfg, c->tmp_z1, (int)n_rows));
+      if (c->rbm) HIPCHK(c, launch_onsite(c->stream, c->tmp_cfg, p.won, (int)n_rows, c->N, c->tmp_on));
+      TailArgs a = tail_args(c, which);
+      a.z1 = c->tmp_z1; a.on_base = c->tmp_on; a.n_rows = (int)n_rows; a.out = c->tmp_out; a.rowinfo = c->tmp_rowinfo;
+      HIPCHK(c, launch_tail(c->stream, a, c->Hp, false, c->rbm));
+    }
     HIPCHK(c, hipMemcpyAsync(host.data(), c->tmp_out, n_rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -728,7 +828,7 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   // the activations of the final chains are handed to the gradient path only when a gradient
   // accumulate has been seen since the previous launch (equilibration / evaluation sweeps skip
   // the [L][B][Hp] write-back; gradient_sums then recomputes them)
-  const bool hand_over = !dbg && (injected || c->acc_since_sweep || c->sr_cap > 0);
+  const bool hand_over = !c->conv && !dbg && (injected || c->acc_since_sweep || c->sr_cap > 0);
   a.act_out = hand_over ? c->act_alt : nullptr;
   a.dact_out = hand_over ? c->dact_alt : nullptr;
   a.cache_in_valid = (!dbg && !injected && p.cache_valid) ? 1 : 0;
@@ -736,7 +836,20 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   if (overtake) HIPCHK(c, hipStreamWaitEvent(st, dep, 0));
   // the device counter is only zeroed when the caller will read it back
   if (count_accepted) HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), st));
-  {
+  if (c->conv) {
+    ConvSweepArgs s;
+    memset(&s, 0, sizeof(s));
+    s.g = c->cg; s.p = conv_params(p);
+    s.configs_in = c->configs; s.logit_in = p.logit; s.configs = c->configs_alt; s.logit = p.logit_alt;
+    s.accepted = c->d_accepted;
+    s.inj_up = a.inj_up; s.inj_dn = a.inj_dn; s.inj_u = a.inj_u; s.acc_mask = a.acc_mask;
+    s.dbg_up = a.dbg_up; s.dbg_dn = a.dbg_dn; s.dbg_u = a.dbg_u;
+    s.oact = c->oact; s.cache_in_valid = a.cache_in_valid; s.B = c->B; s.G = c->cGs;
+    s.chain_offset = a.chain_offset; s.seed_lo = a.seed_lo; s.seed_hi = a.seed_hi;
+    s.step0 = step0; s.n_steps = n_steps;
+    Timer t(c, "sweep", st, true);
+    HIPCHK(c, launch_conv_sweep(st, s));
+  } else {
     Timer t(c, "sweep", st, true);
     HIPCHK(c, launch_sweep16(st, a, c->Hp));
   }
@@ -817,7 +930,7 @@ int vmc_debug_proposals(vmc_ctx* c, uint64_t step, int32_t* i_up, int32_t* i_dn,
 int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   ENTER(c);
   if (n_steps < 1 || !phase_cycles) return fail(c, VMC_ERR_INVALID, "bad arguments");
-  if (c->rbm) return fail(c, VMC_ERR_UNSUPPORTED, "the diagnostic sweep build exists for fully_connected only");
+  if (c->rbm || c->conv) return fail(c, VMC_ERR_UNSUPPORTED, "the diagnostic sweep build exists for fully_connected only");
   PROPAGATE(ensure_packed(c, 0));
   const int grid = (c->B + 15) / 16;
   unsigned long long* d = nullptr;
@@ -887,6 +1000,27 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
   float* g1 = c->acc;
   float* g2 = c->acc + c->P;
   Timer t(c, "grad");
+  if (c->conv) {
+    // forward tapes (the inputs of every convolution), d logit / d (output of every convolution)
+    // back through the transposed convolutions, then the weight-gradient correlations
+    if (!c->acts_valid) {
+      PROPAGATE(conv_rows(c, VMC_PSI, c->configs, c->rowinfo_id, B, nullptr, false, p.logit, true));
+      c->acts_valid = true;
+    }
+    if (c->oact != VMC_ACT_EXP_) HIPCHK(c, launch_out_scale(c->stream, p.logit, c->oscale, B, c->oact));
+    ConvBackArgs bk;
+    memset(&bk, 0, sizeof(bk));
+    bk.g = c->cg; bk.p = conv_params(p); bk.tape = c->ctape; bk.tape_stride = c->ctape_stride;
+    bk.oscale = c->oscale; bk.delta = c->cdelta; bk.delta_stride = c->cdelta_stride; bk.B = B; bk.G = c->cG;
+    HIPCHK(c, launch_conv_back(c->stream, bk, c->num_cus));
+    ConvDwArgs dw;
+    memset(&dw, 0, sizeof(dw));
+    dw.g = c->cg; dw.configs = c->configs; dw.tape = c->ctape; dw.tape_stride = c->ctape_stride;
+    dw.delta = c->cdelta; dw.delta_stride = c->cdelta_stride; dw.w = w; dw.B = B;
+    dw.n_slices = c->c_slices; dw.ws = c->cws; dw.g1 = g1; dw.g2 = g2;
+    HIPCHK(c, launch_conv_dw(c->stream, dw));
+    return VMC_OK;
+  }
   // forward with saved activations (wavefunctions.py:345-349 / 418-420); after a sweep launch
   // the kernel has already left them in act[] (exact refresh of the final chains).
   // act[l] = relu(z_{l+1}); RBM: the last one is tanh(z_last) = d sum log cosh / d z_last
@@ -1150,6 +1284,8 @@ int vmc_epoch_log_overlap(vmc_ctx* c, float beta, int64_t n_eq_steps, int32_t n_
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   ENTER(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
+  if (n_batches > 0 && c->conv)
+    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the fully_connected and rbm ansatz types");
   if (n_batches > 0 && (c->oact != VMC_ACT_EXP_ || c->hact == VMC_ACT_COS_))
     return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation and every hidden activation except cos");
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -31,7 +31,11 @@ class VmcEngine:
   def __init__(self, n_sites: int, batch_size: int, num_layers: int, layer_size: int,
                nonlinearity: str = 'relu', output_activation: str = 'exp', device: int = 0,
                chain_offset: int = 0, seed: int = 2024, stream: int = 0,
-               ansatz: str = 'fully_connected'):
+               ansatz: str = 'fully_connected', kernel_size: int = 0, size_x: int = 0,
+               size_y: int = 0):
+    """Dense ansatz types: num_layers / layer_size = num_fc_layers / fc_layer_size.  Convolutional
+    ones ('conv_2d', 'res_net_2d'): num_layers = num_conv_layers or num_resnet_blocks, layer_size =
+    num_conv_filters, plus kernel_size and the lattice size_x x size_y (= n_sites)."""
     self._lib = _hip.load()
     self._ctx = C.c_void_p()
     for name, act in (('nonlinearity', nonlinearity), ('output_activation', output_activation)):
@@ -41,7 +45,8 @@ class VmcEngine:
       raise NotImplementedError('ansatz {!r} has no HIP kernels'.format(ansatz))
     desc = _hip.VmcDesc(n_sites, batch_size, num_layers, layer_size,
                         _hip.ACT_IDS[nonlinearity], _hip.ACT_IDS[output_activation], device,
-                        chain_offset, _hip.ANSATZ_IDS[ansatz], 0, seed, stream or None)
+                        chain_offset, _hip.ANSATZ_IDS[ansatz], 0, seed, stream or None,
+                        kernel_size, size_x, size_y, 0)
     rc = self._lib.vmc_create(C.byref(desc), C.byref(self._ctx))
     if rc != _hip.VMC_OK:
       msg = self._lib.vmc_last_error(None).decode()
@@ -51,8 +56,13 @@ class VmcEngine:
     self.num_layers, self.layer_size = num_layers, layer_size
     self.chain_offset, self.seed, self.device = chain_offset, seed, device
     self.ansatz = ansatz
-    self.num_params = int(self._lib.vmc_num_params_ansatz(_hip.ANSATZ_IDS[ansatz], n_sites,
-                                                          layer_size, num_layers))
+    self.kernel_size, self.size_x, self.size_y = kernel_size, size_x, size_y
+    if ansatz in _hip.CONV_ANSATZ:
+      self.num_params = int(self._lib.vmc_num_params_conv(_hip.ANSATZ_IDS[ansatz], num_layers,
+                                                          layer_size, kernel_size))
+    else:
+      self.num_params = int(self._lib.vmc_num_params_ansatz(_hip.ANSATZ_IDS[ansatz], n_sites,
+                                                            layer_size, num_layers))
     self.n_bonds = 0
 
   # ------------------------------------------------------------------ plumbing

@@ -80,6 +80,7 @@ class ConfigsVariable:
     self.local_batch, self.chain_offset = parallel.shard(batch_size)
     self._seed = seed
     self._engine = None
+    self._engine_spec = None
     self._slots = {}
     self._hamiltonian = None
     self._host_value = utils.random_configurations(
@@ -104,17 +105,12 @@ class ConfigsVariable:
       seed = sampler_seed()
       self._engine = VmcEngine(
           n_sites=self.shape[1], batch_size=self.local_batch,
-          num_layers=wavefunction._num_layers, layer_size=wavefunction._layer_size,
-          nonlinearity=wavefunction._nonlinearity.name,
-          output_activation=wavefunction._output_activation.name,
           device=parallel.local_rank(), chain_offset=self.chain_offset, seed=seed,
-          ansatz=wavefunction._ansatz)
+          **wavefunction._engine_spec())
+      self._engine_spec = wavefunction._engine_spec()
       self._engine.set_configs(self._host_value)
-    else:
-      e = self._engine
-      if (e.ansatz, e.num_layers, e.layer_size) != (
-          wavefunction._ansatz, wavefunction._num_layers, wavefunction._layer_size):
-        raise ValueError('a CONFIGS variable serves one ansatz shape (psi and its deep copy)')
+    elif self._engine_spec != wavefunction._engine_spec():
+      raise ValueError('a CONFIGS variable serves one ansatz shape (psi and its deep copy)')
     return self._engine
 
   def _claim_slot(self, wavefunction) -> int:

@@ -263,6 +263,12 @@ class FullyConnectedNetwork(Wavefunction):
     return out
 
   # -- engine binding ------------------------------------------------------
+  def _engine_spec(self):
+    """Keyword arguments that describe this ansatz to VmcEngine / vmc_create."""
+    return dict(ansatz=self._ansatz, num_layers=self._num_layers, layer_size=self._layer_size,
+                nonlinearity=self._nonlinearity.name,
+                output_activation=self._output_activation.name)
+
   def _bind(self, configs_var):
     """Connects this ansatz to the engine that owns `configs_var`."""
     n_sites = configs_var.shape[1]
@@ -378,6 +384,126 @@ class RestrictedBoltzmannNetwork(FullyConnectedNetwork):
     return cls(**rbm_params)
 
 
+class Conv2DNetwork(FullyConnectedNetwork):
+  """[Conv2dPeriodic(num_filters, kernel_size), nonlinearity] x (num_layers - 1),
+  Conv2dPeriodic, reduce_sum over sites and channels, (- exp_norm_shift), exp
+  (wavefunctions.py:531-615; layers.Conv2dPeriodic, layers.py:89-160).  Inputs are reshaped to
+  [-1, size_x, size_y, 1]; the kernels are the periodic implicit-GEMM family of csrc/conv.hip."""
+  _ansatz = 'conv_2d'
+
+  def __init__(self, num_layers: int, num_filters: int, kernel_size: int, size_x: int,
+               size_y: int, nonlinearity=layers.NONLINEARITIES['relu'],
+               output_activation=layers.NONLINEARITIES['exp'], name: str = 'conv_2d_network'):
+    super(Conv2DNetwork, self).__init__(
+        num_layers=num_layers, layer_size=num_filters, nonlinearity=nonlinearity,
+        output_activation=output_activation, name=name)
+    self._num_filters = num_filters
+    self._kernel_size = kernel_size
+    self._size_x = size_x
+    self._size_y = size_y
+
+  def _conv_scopes(self):
+    """Variable scopes of the snt.Conv2D modules in connection order."""
+    return ['conv_2d_periodic' if l == 0 else 'conv_2d_periodic_%d' % l
+            for l in range(self._num_layers)]
+
+  def _shapes(self):
+    if self._n_sites != self._size_x * self._size_y:
+      raise ValueError('Input tensor has wrong shape.')        # tf.reshape fails in the reference
+    k, f, u = self._kernel_size, self._num_filters, self._unique_name
+    names, shapes, cin = [], [], 1
+    for scope in self._conv_scopes():
+      names += ['%s/%s/conv_2d/w' % (u, scope), '%s/%s/conv_2d/b' % (u, scope)]
+      shapes += [(k, k, cin, f), (f,)]
+      cin = f
+    return names, shapes
+
+  def initialize(self, seed=None):
+    """snt.Conv2D defaults: w ~ truncated normal(sigma = 1/sqrt(k*k*in_channels)), b = 0."""
+    if self._n_sites is None:
+      raise ValueError('wavefunction is not connected to inputs yet')
+    rng = np.random.default_rng(seed)
+    parts = []
+    for shp in self._shapes()[1]:
+      if len(shp) == 4:
+        w = rng.standard_normal(shp)
+        bad = np.abs(w) > 2
+        while bad.any():
+          w[bad] = rng.standard_normal(int(bad.sum()))
+          bad = np.abs(w) > 2
+        parts.append((w / np.sqrt(shp[0] * shp[1] * shp[2])).ravel())
+      else:
+        parts.append(np.zeros(shp).ravel())
+    self._set_theta(np.concatenate(parts).astype(np.float32))
+
+  def _engine_spec(self):
+    spec = super(Conv2DNetwork, self)._engine_spec()
+    spec.update(kernel_size=self._kernel_size, size_x=self._size_x, size_y=self._size_y)
+    return spec
+
+  @classmethod
+  def from_hparams(cls, hparams, name: str = '') -> 'Wavefunction':
+    """wavefunctions.py:600-615."""
+    conv_2d_params = {
+        'num_layers': hparams.num_conv_layers,
+        'num_filters': hparams.num_conv_filters,
+        'kernel_size': hparams.kernel_size,
+        'size_x': hparams.size_x,
+        'size_y': hparams.size_y,
+        'output_activation': layers.NONLINEARITIES[hparams.output_activation],
+        'nonlinearity': layers.NONLINEARITIES[hparams.nonlinearity],
+    }
+    if name:
+      conv_2d_params['name'] = name
+    return cls(**conv_2d_params)
+
+
+class ResNet2D(Conv2DNetwork):
+  """Conv2dPeriodic, then num_blocks x ResBlock2d (x + conv(selu(conv(x)))), reduce_sum,
+  (- exp_norm_shift), exp   (wavefunctions.py:710-809; layers.ResBlock2d, layers.py:163-229).
+  The reference only has the plain block for 2D (bottleneck=True names a class layers.py does not
+  define) and a block only type-checks at stride 1, so those are the supported settings."""
+  _ansatz = 'res_net_2d'
+
+  def __init__(self, num_blocks: int, num_filters: int, kernel_size: int, conv_stride: int,
+               size_x: int, size_y: int, bottleneck: bool = False,
+               output_activation=layers.NONLINEARITIES['exp'], name: str = 'res_net_2d'):
+    if bottleneck:
+      raise AttributeError("module 'layers' has no attribute 'BottleneckResBlock2d'")
+    if conv_stride != 1:
+      raise ValueError('Inputs shape is not compatable with filters.')   # layers.py:218-219
+    super(ResNet2D, self).__init__(
+        num_layers=num_blocks, num_filters=num_filters, kernel_size=kernel_size, size_x=size_x,
+        size_y=size_y, nonlinearity=layers.NONLINEARITIES['relu'],
+        output_activation=output_activation, name=name)
+    self._num_blocks = num_blocks
+    self._conv_stride = conv_stride
+    self._bottleneck = bottleneck
+
+  def _conv_scopes(self):
+    scopes = ['conv_2d_periodic']
+    for blk in range(self._num_blocks):
+      block = 'res_block_2d' if blk == 0 else 'res_block_2d_%d' % blk
+      scopes += ['%s/first_conv' % block, '%s/second_conv' % block]
+    return scopes
+
+  @classmethod
+  def from_hparams(cls, hparams, name: str = '') -> 'Wavefunction':
+    """wavefunctions.py:794-809."""
+    res_net_2d_params = {
+        'num_blocks': hparams.num_resnet_blocks,
+        'num_filters': hparams.num_conv_filters,
+        'kernel_size': hparams.kernel_size,
+        'conv_stride': hparams.conv_strides,
+        'size_x': hparams.size_x,
+        'size_y': hparams.size_y,
+        'output_activation': layers.NONLINEARITIES[hparams.output_activation],
+    }
+    if name:
+      res_net_2d_params['name'] = name
+    return cls(**res_net_2d_params)
+
+
 class AmplitudeTensor(session_lib.Tensor):
   """psi = wavefunction(inputs); evaluates to a float32 array [rows]."""
 
@@ -402,7 +528,7 @@ class _OutOfScope(Wavefunction):
   def from_hparams(cls, hparams, name: str = ''):
     raise NotImplementedError(
         "wavefunction_type '%s' is outside the MI355X hot path (SURVEY.md 2); only "
-        "'fully_connected' and 'rbm' have HIP kernels" % cls._kind)
+        "'fully_connected', 'rbm', 'conv_2d' and 'res_net_2d' have HIP kernels" % cls._kind)
 
 
 def _stub(kind):
@@ -423,12 +549,12 @@ WAVEFUNCTION_TYPES = {
     'fully_connected': FullyConnectedNetwork,
     'rbm': RestrictedBoltzmannNetwork,
     'conv_1d': _stub('conv_1d'),
-    'conv_2d': _stub('conv_2d'),
+    'conv_2d': Conv2DNetwork,
     'mps': _stub('mps'),
     'pbdg': _stub('pbdg'),
     'fully_connected_nnb': _stub('fully_connected_nnb'),
     'res_net_1d': _stub('res_net_1d'),
-    'res_net_2d': _stub('res_net_2d'),
+    'res_net_2d': ResNet2D,
     'ed_vector': _stub('ed_vector'),
     'gnn': _stub('gnn'),
 }

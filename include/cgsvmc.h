@@ -21,6 +21,11 @@
  * module is first connected, so the onsite layer of _build line 436 comes first):
  *   w_on[N,1] b_on[1] w_1[N,H] b_1[H] w_2[H,H] b_2[H] ... w_{L+1}[H,H] b_{L+1}[H],
  * P = N + 1 + N*H + H + L*(H*H + H) floats (L = num_fc_layers >= 0 relu layers).
+ * Conv2DNetwork (wavefunctions.py:531-615) and ResNet2D (wavefunctions.py:710-809): one snt.Conv2D
+ * per layers.Conv2dPeriodic in connection order -- conv_2d: num_conv_layers of them; res_net_2d:
+ * the initial convolution, then first_conv, second_conv of every ResBlock2d (layers.py:200-201) --
+ * each w[k][k][in_channels][F] (row-major) followed by b[F]; in_channels = 1 for the first, F after;
+ * P = k*k*F + F + (n_conv - 1)*(k*k*F*F + F).
  */
 #ifndef CGSVMC_H_
 #define CGSVMC_H_
@@ -49,30 +54,42 @@ enum { VMC_PSI = 0, VMC_OMEGA = 1 };
 enum { VMC_MODE_ENERGY_GRADIENT = 0, VMC_MODE_LOG_OVERLAP_ITSWO = 1 };
 
 /* wavefunctions.WAVEFUNCTION_TYPES with kernels (wavefunctions.py:1157-1170) */
-enum { VMC_ANSATZ_FULLY_CONNECTED = 0, VMC_ANSATZ_RBM = 1 };
+enum { VMC_ANSATZ_FULLY_CONNECTED = 0, VMC_ANSATZ_RBM = 1, VMC_ANSATZ_CONV_2D = 2,
+       VMC_ANSATZ_RES_NET_2D = 3 };
 
-/* layers.NONLINEARITIES ids (layers.py:13-21); only the ones with kernels are accepted */
-enum { VMC_ACT_RELU = 0, VMC_ACT_EXP = 1, VMC_ACT_IDENTITY = 6 };
+/* layers.NONLINEARITIES ids (layers.py:13-21).  Every id is accepted as hidden and as output
+ * activation of the dense ansatz types; the convolutional ones take every hidden id but cos. */
+enum { VMC_ACT_RELU = 0, VMC_ACT_EXP = 1, VMC_ACT_COS = 2, VMC_ACT_TAN = 3, VMC_ACT_TANH = 4,
+       VMC_ACT_SIGMOID = 5, VMC_ACT_IDENTITY = 6 };
 
 typedef struct {
   int32_t n_sites;           /* hparams.num_sites                (utils.py:98)       */
   int32_t batch_size;        /* chains owned by THIS ctx         (utils.py:135)      */
-  int32_t num_layers;        /* hparams.num_fc_layers            (utils.py:104)      */
-  int32_t layer_size;        /* hparams.fc_layer_size            (utils.py:105)      */
-  int32_t nonlinearity;      /* VMC_ACT_RELU                                        */
-  int32_t output_activation; /* VMC_ACT_EXP                                         */
+  int32_t num_layers;        /* hparams.num_fc_layers (utils.py:104); conv_2d: num_conv_layers
+                                (108); res_net_2d: num_resnet_blocks (114)                     */
+  int32_t layer_size;        /* hparams.fc_layer_size (utils.py:105); convolutional ansatz types:
+                                num_conv_filters (111), at most 16                             */
+  int32_t nonlinearity;      /* VMC_ACT_*: hparams.nonlinearity  (utils.py:128)      */
+  int32_t output_activation; /* VMC_ACT_*: hparams.output_activation (utils.py:129)  */
   int32_t device;            /* HIP device ordinal                                   */
   int32_t chain_offset;      /* global id of local chain 0 (multi-GPU sharding)      */
   int32_t ansatz;            /* VMC_ANSATZ_*: hparams.wavefunction_type              */
   int32_t reserved;          /* 0                                                    */
   uint64_t seed;             /* Philox key                                           */
   void* stream;              /* hipStream_t to launch on, or NULL for the null stream*/
+  /* convolutional ansatz types only (ignored otherwise) */
+  int32_t kernel_size;       /* hparams.kernel_size (utils.py:110), 1..6             */
+  int32_t size_x, size_y;    /* hparams.size_x, size_y (utils.py:99-100); n_sites = size_x*size_y */
+  int32_t reserved2;         /* 0                                                    */
 } vmc_desc;
 
 /* Number of parameters P for a given shape (no ctx needed). */
 int64_t vmc_num_params(int32_t n_sites, int32_t layer_size, int32_t num_layers);
 int64_t vmc_num_params_ansatz(int32_t ansatz, int32_t n_sites, int32_t layer_size,
                               int32_t num_layers);
+/* convolutional ansatz types: layer_size = num_conv_filters, num_layers as in vmc_desc */
+int64_t vmc_num_params_conv(int32_t ansatz, int32_t num_layers, int32_t num_filters,
+                            int32_t kernel_size);
 
 /* FullyConnectedNetwork.__init__ + graph_builders.get_configs: allocates everything.
  * wavefunctions.py:331-353, graph_builders.py:92-125. */

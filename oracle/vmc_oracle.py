@@ -208,6 +208,223 @@ def rbm_weighted_logit_grads(theta, configs, weights, layer_size, num_layers,
 
 
 # --------------------------------------------------------------------------- #
+# Ansatz: Conv2DNetwork (wavefunctions.py:531-615) and ResNet2D (wavefunctions.py:710-809) on
+# layers.Conv2dPeriodic / layers.ResBlock2d (layers.py:89-229).
+#
+# Geometry argument `geom` = (num_filters, kernel_size, size_x, size_y); it travels in the
+# `layer_size` slot of the ANSATZ call signature.  `num_layers` is hparams.num_conv_layers
+# (conv_2d) or hparams.num_resnet_blocks (res_net_2d).
+#
+# Third-party semantics restated (Sonnet v1 snt.Conv2D, TF1 tf.nn.conv2d / tf.nn.selu; sources
+# not under /root/reference): w has shape [k, k, in_channels, out_channels], b [out_channels];
+# tf.nn.conv2d is a cross-correlation; default initialisers are truncated normal with
+# sigma = 1/sqrt(k*k*in_channels) for w and zeros for b; variables are created w then b when the
+# module is first connected; selu(x) = 1.0507009873554805 * (x if x > 0 else
+# 1.6732632423543772 * (exp(x) - 1)).
+# --------------------------------------------------------------------------- #
+SELU_SCALE = 1.0507009873554804934193349852946
+SELU_ALPHA = 1.6732632423543772848170429916717
+
+
+def selu(x):
+  with np.errstate(over='ignore'):
+    return x.dtype.type(SELU_SCALE) * np.where(
+        x > 0, x, x.dtype.type(SELU_ALPHA) * (np.exp(np.minimum(x, 0)) - 1))
+
+
+def selu_deriv(x):
+  return x.dtype.type(SELU_SCALE) * np.where(
+      x > 0, x.dtype.type(1), x.dtype.type(SELU_ALPHA) * np.exp(np.minimum(x, 0)))
+
+
+def conv_layer_channels(ansatz, num_layers, num_filters):
+  """(in_channels, out_channels) of every Conv2dPeriodic in creation order.
+  conv_2d: num_layers convolutions (wavefunctions.py:572-575); res_net_2d: the initial
+  convolution, then first_conv / second_conv of each block (wavefunctions.py:766-772,
+  layers.py:200-201)."""
+  n_conv = num_layers if ansatz == 'conv_2d' else 1 + 2 * num_layers
+  return [(1 if l == 0 else num_filters, num_filters) for l in range(n_conv)]
+
+
+def conv_param_shapes(ansatz, geom, num_layers):
+  f, k = geom[0], geom[1]
+  shapes = []
+  for cin, cout in conv_layer_channels(ansatz, num_layers, f):
+    shapes += [(k, k, cin, cout), (cout,)]
+  return shapes
+
+
+def conv_num_params(ansatz, geom, num_layers):
+  return int(sum(int(np.prod(s)) for s in conv_param_shapes(ansatz, geom, num_layers)))
+
+
+def conv_unpack(theta, ansatz, geom, num_layers):
+  out, off = [], 0
+  shapes = conv_param_shapes(ansatz, geom, num_layers)
+  for i in range(0, len(shapes), 2):
+    nw, nb = int(np.prod(shapes[i])), int(np.prod(shapes[i + 1]))
+    w = theta[off:off + nw].reshape(shapes[i]); off += nw
+    b = theta[off:off + nb]; off += nb
+    out.append((w, b))
+  assert off == theta.size
+  return out
+
+
+def conv_init_params(ansatz, geom, num_layers, rng):
+  """snt.Conv2D default init: truncated normal, sigma = 1/sqrt(k*k*in_channels); b = 0."""
+  parts = []
+  for shp in conv_param_shapes(ansatz, geom, num_layers):
+    if len(shp) == 4:
+      w = rng.standard_normal(shp)
+      bad = np.abs(w) > 2
+      while bad.any():
+        w[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(w) > 2
+      parts.append((w / np.sqrt(shp[0] * shp[1] * shp[2])).ravel())
+    else:
+      parts.append(np.zeros(shp).ravel())
+  return np.concatenate(parts).astype(np.float32)
+
+
+def periodic_pad_2d(x, k):
+  """layers.Conv2dPeriodic._pad_input (layers.py:118-148) on x [B, D1, D2, C]: axis 2 gets
+  (k-1)//2 columns of the far end in front and k//2 of the near end behind, then axis 1 the
+  same (odd k: (k-1)/2 both; even k: k/2 - 1 in front and k/2 behind)."""
+  lo = (k - 1) // 2 if k % 2 == 1 else k // 2 - 1
+  hi = (k - 1) // 2 if k % 2 == 1 else k // 2
+  d1, d2 = x.shape[1], x.shape[2]
+  left = x[:, :, d2 - lo:]
+  right = x[:, :, :hi]
+  wp = np.concatenate([left, x, right], axis=2)
+  bot = wp[:, d1 - lo:]
+  top = wp[:, :hi]
+  return np.concatenate([bot, wp, top], axis=1)
+
+
+def conv2d_periodic(x, w, b):
+  """Conv2dPeriodic._build (layers.py:151-160): snt.Conv2D(VALID, stride 1) of the padded
+  input = cross-correlation out[a1,a2,o] = b[o] + sum w[d1,d2,c,o] pad[a1+d1, a2+d2, c]."""
+  k = w.shape[0]
+  pad = periodic_pad_2d(x, k)
+  bsz, d1, d2 = x.shape[0], x.shape[1], x.shape[2]
+  out = np.zeros((bsz, d1, d2, w.shape[3]), x.dtype)
+  for i in range(k):
+    for j in range(k):
+      out += pad[:, i:i + d1, j:j + d2, :] @ w[i, j]
+  return out + b
+
+
+def conv2d_periodic_backward(x, w, delta):
+  """(d/dx, d/dw, d/db) of sum(conv2d_periodic(x, w, b) * delta)."""
+  k = w.shape[0]
+  lo = (k - 1) // 2
+  dx = np.zeros_like(x)
+  dw = np.zeros_like(w)
+  for i in range(k):
+    for j in range(k):
+      # pad[a1+i, a2+j] = x[(a1+i-lo) mod D1, (a2+j-lo) mod D2]
+      xs = np.roll(x, (-(i - lo), -(j - lo)), axis=(1, 2))
+      dw[i, j] = np.tensordot(xs, delta, axes=([0, 1, 2], [0, 1, 2]))
+      dx += np.roll(delta @ w[i, j].T, (i - lo, j - lo), axis=(1, 2))
+  return dx, dw, delta.sum((0, 1, 2))
+
+
+def conv_forward(theta, configs, ansatz, geom, num_layers, nonlinearity='relu',
+                 dtype=np.float32, return_tape=False):
+  """Pre-output-activation scalar of Conv2DNetwork / ResNet2D: reduce_sum over sites and
+  channels of the last feature map (wavefunctions.py:569, 577; 760, 773)."""
+  f, k, sx, sy = geom
+  x = np.asarray(configs, dtype=dtype).reshape(-1, sx, sy, 1)   # wavefunctions.py:596-597
+  layers_ = conv_unpack(np.asarray(theta, dtype=dtype), ansatz, geom, num_layers)
+  tape = []   # per convolution: (input, pre-activation output)
+  if ansatz == 'conv_2d':
+    act = NONLINEARITIES[nonlinearity]
+    a = x
+    for l, (w, b) in enumerate(layers_):
+      z = conv2d_periodic(a, w, b)
+      tape.append((a, z))
+      a = act(z) if l + 1 != len(layers_) else z            # wavefunctions.py:574-575
+    last = a
+  elif ansatz == 'res_net_2d':
+    w, b = layers_[0]
+    h = conv2d_periodic(x, w, b)                             # initial_conv, no activation
+    tape.append((x, h))
+    for blk in range(num_layers):                            # layers.py:226-228
+      (w1, b1), (w2, b2) = layers_[1 + 2 * blk], layers_[2 + 2 * blk]
+      u = conv2d_periodic(h, w1, b1)
+      t = selu(u)
+      v = conv2d_periodic(t, w2, b2)
+      tape.append((h, u)); tape.append((t, v))
+      h = v + h
+    last = h
+  else:
+    raise ValueError(ansatz)
+  logit = last.reshape(last.shape[0], -1).sum(1, dtype=dtype)
+  if return_tape == 'scale':       # sum |entries|: the rounding scale of an fp32 evaluation of the sum
+    return logit, np.abs(last).reshape(last.shape[0], -1).sum(1)
+  if return_tape:
+    return logit, tape, layers_
+  return logit
+
+
+def _conv_psi(ansatz):
+  def psi(theta, configs, geom, num_layers, shift=-10.0, nonlinearity='relu',
+          output_activation='exp', dtype=np.float32):
+    logit = conv_forward(theta, configs, ansatz, geom, num_layers, nonlinearity, dtype)
+    if output_activation == 'exp':                           # wavefunctions.py:576-579
+      with np.errstate(over='ignore'):
+        return np.exp(logit - dtype(shift))
+    return NONLINEARITIES[output_activation](logit)
+  return psi
+
+
+def _conv_logit(ansatz):
+  def logit(theta, configs, geom, num_layers, nonlinearity='relu', dtype=np.float32):
+    return conv_forward(theta, configs, ansatz, geom, num_layers, nonlinearity, dtype)
+  return logit
+
+
+def _conv_weighted_grads(ansatz):
+  def grads(theta, configs, weights, geom, num_layers, nonlinearity='relu', dtype=np.float32,
+            output_activation='exp'):
+    """sum_b weights[b, c] * d logit_b / d theta -> [C, P] (manual back-propagation)."""
+    w_b = np.asarray(weights, dtype=dtype)
+    if w_b.ndim == 1:
+      w_b = w_b[:, None]
+    logit, tape, layers_ = conv_forward(theta, configs, ansatz, geom, num_layers, nonlinearity,
+                                        dtype, True)
+    w_b = w_b * output_dlog(logit, output_activation, dtype)[:, None]
+    out = []
+    for c in range(w_b.shape[1]):
+      wc = w_b[:, c][:, None, None, None]
+      grads_ = [None] * len(layers_)
+      if ansatz == 'conv_2d':
+        dact = _NONLIN_DERIV[nonlinearity]
+        delta = np.broadcast_to(wc, tape[-1][1].shape).astype(dtype)   # d logit / d z_last = 1
+        for l in range(len(layers_) - 1, -1, -1):
+          a_in, _ = tape[l]
+          dx, dw, db = conv2d_periodic_backward(a_in, layers_[l][0], delta)
+          grads_[l] = (dw, db)
+          if l > 0:
+            z_prev = tape[l - 1][1]
+            delta = dx * dact(z_prev, NONLINEARITIES[nonlinearity](z_prev))
+      else:
+        dh = np.broadcast_to(wc, tape[-1][1].shape).astype(dtype)
+        for blk in range(num_layers - 1, -1, -1):
+          (h_in, u), (t, _) = tape[1 + 2 * blk], tape[2 + 2 * blk]
+          dt, dw2, db2 = conv2d_periodic_backward(t, layers_[2 + 2 * blk][0], dh)
+          du = dt * selu_deriv(u)
+          dhin, dw1, db1 = conv2d_periodic_backward(h_in, layers_[1 + 2 * blk][0], du)
+          grads_[2 + 2 * blk] = (dw2, db2); grads_[1 + 2 * blk] = (dw1, db1)
+          dh = dh + dhin
+        _, dw0, db0 = conv2d_periodic_backward(tape[0][0], layers_[0][0], dh)
+        grads_[0] = (dw0, db0)
+      out.append(np.concatenate([np.concatenate([g[0].ravel(), g[1].ravel()]) for g in grads_]))
+    return np.stack(out)
+  return grads
+
+
+# --------------------------------------------------------------------------- #
 # Ansatz: FullyConnectedNetwork (wavefunctions.py:328-371) + exp shift (206-232)
 # --------------------------------------------------------------------------- #
 def fc_logit(theta, configs, layer_size, num_layers, nonlinearity='relu',
@@ -507,7 +724,7 @@ class Accumulators:
 
 def _act_kwargs(ansatz, nonlinearity, output_activation):
   kw = {'nonlinearity': nonlinearity}
-  if ansatz == 'fully_connected':
+  if ansatz in ('fully_connected', 'conv_2d', 'res_net_2d'):
     kw['output_activation'] = output_activation
   return kw
 
@@ -729,4 +946,12 @@ def run_sweeps(theta, configs, n_steps, seed, step0, layer_size, num_layers, shi
 ANSATZ = {
     'fully_connected': (fc_psi, fc_logit, None, init_params, num_params),
     'rbm': (rbm_psi, rbm_logit, rbm_weighted_logit_grads, rbm_init_params, rbm_num_params),
+    # convolutional ansatz types: the `layer_size` slot carries geom = (filters, kernel, sx, sy)
+    'conv_2d': (_conv_psi('conv_2d'), _conv_logit('conv_2d'), _conv_weighted_grads('conv_2d'),
+                lambda geom, num_layers, rng: conv_init_params('conv_2d', geom, num_layers, rng),
+                lambda geom, num_layers: conv_num_params('conv_2d', geom, num_layers)),
+    'res_net_2d': (_conv_psi('res_net_2d'), _conv_logit('res_net_2d'),
+                   _conv_weighted_grads('res_net_2d'),
+                   lambda geom, num_layers, rng: conv_init_params('res_net_2d', geom, num_layers, rng),
+                   lambda geom, num_layers: conv_num_params('res_net_2d', geom, num_layers)),
 }

@@ -94,8 +94,33 @@ def test_registries_and_errors():
   hp = utils.create_hparams(wavefunction_type='bogus')
   with pytest.raises(ValueError, match='not registered'):
     wavefunctions.build_wavefunction(hp)
-  hp.set_hparam('wavefunction_type', 'conv_2d')
+  hp.set_hparam('wavefunction_type', 'conv_1d')
   with pytest.raises(NotImplementedError):
+    wavefunctions.build_wavefunction(hp)
+  # the two convolutional types with kernels: constructor arguments and Sonnet variable names
+  hp.set_hparam('wavefunction_type', 'conv_2d')
+  hp.set_hparam('size_x', 4); hp.set_hparam('size_y', 6); hp.set_hparam('num_conv_layers', 3)
+  wf = wavefunctions.build_wavefunction(hp)
+  assert isinstance(wf, wavefunctions.Conv2DNetwork)
+  wf._n_sites = 24
+  names, shapes = wf._shapes()
+  assert names[:4] == ['conv_2d_network/conv_2d_periodic/conv_2d/w', 'conv_2d_network/conv_2d_periodic/conv_2d/b',
+                       'conv_2d_network/conv_2d_periodic_1/conv_2d/w', 'conv_2d_network/conv_2d_periodic_1/conv_2d/b']
+  assert shapes == [(5, 5, 1, 16), (16,), (5, 5, 16, 16), (16,), (5, 5, 16, 16), (16,)]
+  assert wf._engine_spec() == dict(ansatz='conv_2d', num_layers=3, layer_size=16, nonlinearity='relu',
+                                   output_activation='exp', kernel_size=5, size_x=4, size_y=6)
+  hp.set_hparam('wavefunction_type', 'res_net_2d')
+  wf = wavefunctions.build_wavefunction(hp)
+  wf._n_sites = 24
+  names, shapes = wf._shapes()
+  assert names[2] == 'res_net_2d/res_block_2d/first_conv/conv_2d/w'
+  assert names[-1] == 'res_net_2d/res_block_2d_1/second_conv/conv_2d/b' and len(shapes) == 10
+  import copy as _copy
+  twin = _copy.deepcopy(wf)
+  assert isinstance(twin, wavefunctions.ResNet2D) and twin._unique_name == 'dc_res_net_2d'
+  assert twin._engine_spec() == wf._engine_spec()
+  hp.set_hparam('conv_strides', 2)
+  with pytest.raises(ValueError):
     wavefunctions.build_wavefunction(hp)
   with pytest.raises(AttributeError):   # defect B1 of the reference: ITSWO cannot be built
     training.GROUND_STATE_OPTIMIZERS['ITSWO']().build_opt_ops(None, None, hp, {})

@@ -305,3 +305,78 @@ def test_rbm_zero_parameters_give_constant_psi_closed_form():
   amp = lambda c: vo.rbm_psi(theta, c, h, L, dtype=np.float64)
   np.testing.assert_allclose(vo.local_value(amp, cfg, bonds, 0.7, 1.0, dtype=np.float64),
                              vo.constant_psi_local_energy(cfg, bonds, 0.7, 1.0), rtol=1e-12)
+
+
+# --------------------------------------------------------------------------- #
+# Convolutional ansatz types (wavefunctions.py:531-615, 710-809; layers.py:89-229)
+# --------------------------------------------------------------------------- #
+def _torch_periodic_conv(x, w, b):
+  """Independent restatement with explicit concat padding (layers.py:118-148) + torch conv2d."""
+  import torch
+  k = w.shape[0]
+  lo = (k - 1) // 2 if k % 2 else k // 2 - 1
+  hi = (k - 1) // 2 if k % 2 else k // 2
+  xp = torch.cat([x[..., x.shape[3] - lo:], x, x[..., :hi]], 3)
+  xp = torch.cat([xp[:, :, xp.shape[2] - lo:], xp, xp[:, :, :hi]], 2)
+  return torch.nn.functional.conv2d(xp, w.permute(3, 2, 0, 1), b)
+
+
+@pytest.mark.parametrize('ansatz,L', [('conv_2d', 3), ('res_net_2d', 2)])
+@pytest.mark.parametrize('k', [2, 3, 4, 5])
+def test_conv_oracle_against_torch_autograd(ansatz, L, k):
+  import torch
+  geom = (6, k, 4, 6)
+  rng = np.random.default_rng(1)
+  th = vo.conv_init_params(ansatz, geom, L, rng).astype(np.float64)
+  th += 0.05 * rng.standard_normal(th.size)
+  cfg = vo.random_configurations(24, 5, np.random.RandomState(2))
+  logit = vo.conv_forward(th, cfg, ansatz, geom, L, 'tanh', np.float64)
+  x = torch.tensor(cfg, dtype=torch.float64).reshape(-1, 4, 6, 1).permute(0, 3, 1, 2)
+  tl = [(torch.tensor(w, requires_grad=True), torch.tensor(b.copy(), requires_grad=True))
+        for w, b in vo.conv_unpack(th, ansatz, geom, L)]
+  if ansatz == 'conv_2d':
+    a = x
+    for l, (w, b) in enumerate(tl):
+      a = _torch_periodic_conv(a, w, b)
+      if l + 1 != len(tl):
+        a = torch.tanh(a)
+  else:
+    a = _torch_periodic_conv(x, *tl[0])
+    for blk in range(L):
+      a = a + _torch_periodic_conv(torch.selu(_torch_periodic_conv(a, *tl[1 + 2 * blk])), *tl[2 + 2 * blk])
+  t_logit = a.sum((1, 2, 3))
+  np.testing.assert_allclose(logit, t_logit.detach().numpy(), rtol=0, atol=1e-12)
+  wts = torch.tensor(rng.standard_normal(5))
+  (t_logit * wts).sum().backward()
+  tg = np.concatenate([np.concatenate([w.grad.numpy().ravel(), b.grad.numpy().ravel()]) for w, b in tl])
+  g = vo.ANSATZ[ansatz][2](th, cfg, wts.numpy(), geom, L, nonlinearity='tanh', dtype=np.float64)[0]
+  np.testing.assert_allclose(g, tg, rtol=0, atol=1e-11 * max(1.0, np.abs(tg).max()))
+
+
+def test_conv_even_kernel_padding_is_asymmetric():
+  """layers.py:137-141: an even kernel pads k/2 - 1 in front and k/2 behind on both axes (the 1-D
+  module does the opposite, layers.py:69-72): a delta kernel at tap (0, 0) of a 2 x 2 kernel
+  reads the site itself, tap (1, 1) the site one step up in both axes."""
+  x = np.arange(12, dtype=np.float64).reshape(1, 3, 4, 1)
+  for tap, shift in (((0, 0), (0, 0)), ((1, 1), (-1, -1)), ((0, 1), (0, -1))):
+    w = np.zeros((2, 2, 1, 1)); w[tap] = 1.0
+    out = vo.conv2d_periodic(x, w, np.zeros(1))
+    np.testing.assert_array_equal(out[0, :, :, 0], np.roll(x[0, :, :, 0], shift, axis=(0, 1)))
+  w = np.zeros((3, 3, 1, 1)); w[0, 0] = 1.0       # odd kernel: one site back in both axes
+  np.testing.assert_array_equal(vo.conv2d_periodic(x, w, np.zeros(1))[0, :, :, 0],
+                                np.roll(x[0, :, :, 0], (1, 1), axis=(0, 1)))
+
+
+def test_conv_zero_weights_closed_form_and_exchange_symmetry():
+  """All-zero kernels: logit = N * sum(b_last) (conv_2d); a translation of the lattice leaves the
+  amplitude unchanged (periodic convolutions + global sum)."""
+  geom, L = (4, 3, 4, 4), 2
+  th = np.zeros(vo.conv_num_params('conv_2d', geom, L))
+  th[-4:] = [0.1, 0.2, 0.3, 0.4]
+  cfg = vo.random_configurations(16, 3, np.random.RandomState(0))
+  np.testing.assert_allclose(vo.conv_forward(th, cfg, 'conv_2d', geom, L, dtype=np.float64), 16 * 1.0)
+  for ansatz in ('conv_2d', 'res_net_2d'):
+    th = vo.conv_init_params(ansatz, geom, L, np.random.default_rng(4)).astype(np.float64)
+    a = vo.conv_forward(th, cfg, ansatz, geom, L, dtype=np.float64)
+    shifted = np.roll(cfg.reshape(-1, 4, 4), (1, 2), axis=(1, 2)).reshape(-1, 16)
+    np.testing.assert_allclose(vo.conv_forward(th, shifted, ansatz, geom, L, dtype=np.float64), a, atol=1e-12)
