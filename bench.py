@@ -46,16 +46,36 @@ HBM_PEAK_GBS = 8000.0
 REPS = 5                        # repetitions of the timed region; the median is reported
 
 WORKLOADS = {
-    # name: (lx, ly, next_nearest, L, H, B per GPU)
+    # name: (lx, ly, next_nearest, L, H, B per GPU[, ansatz, kernel_size])
+    # convolutional ansatz types: L = num_conv_layers / num_resnet_blocks,
+    # H = num_conv_filters, hparams defaults of utils.py:108-114
     'heisenberg10x10_fc3x256_b4096': (10, 10, False, 3, 256, 4096),
     'heisenberg6x6_fc3x128_b1024': (6, 6, False, 3, 128, 1024),
     'heisenberg16x16j1j2_fc6x256_b1024': (16, 16, True, 6, 256, 1024),
+    'heisenberg10x10_conv5x16k5_b4096': (10, 10, False, 5, 16, 4096, 'conv_2d', 5),
+    'heisenberg10x10_resnet2x16k5_b4096': (10, 10, False, 2, 16, 4096, 'res_net_2d', 5),
+    'heisenberg16x16j1j2_conv5x16k5_b1024': (16, 16, True, 5, 16, 1024, 'conv_2d', 5),
 }
 
 
-def f_amp(n, h, L):
-  """flops per amplitude, SURVEY.md 8: 2 (N H + (L-1) H^2 + H)."""
+def f_amp(n, h, L, ansatz='fully_connected', k=0):
+  """flops per amplitude.  Dense: SURVEY.md 8, 2 (N H + (L-1) H^2 + H).  Convolutional: every
+  one of the n_conv periodic convolutions is N sites x k^2 taps x Cin x F multiply-adds
+  (Cin = 1 for the first), plus the N F-term sum."""
+  if ansatz in ('conv_2d', 'res_net_2d'):
+    n_conv = L if ansatz == 'conv_2d' else 1 + 2 * L
+    return 2 * n * (k * k * h + (n_conv - 1) * k * k * h * h) + n * h
   return 2 * (n * h + (L - 1) * h * h + h)
+
+
+def mfma_flops_per_amp(n, h, L, ansatz, k):
+  """flops one amplitude ISSUES to the matrix cores."""
+  if ansatz in ('conv_2d', 'res_net_2d'):
+    # 16-channel tiles (filters zero padded), taps of the first convolution padded to 4
+    n_conv = L if ansatz == 'conv_2d' else 1 + 2 * L
+    return 2 * n * 16 * (4 * ((k * k + 3) // 4) + (n_conv - 1) * k * k * 16)
+  hp = (h + 63) // 64 * 64
+  return 2 * (L - 1) * hp * hp
 
 
 def torus_bonds(lx, ly, nnn):
@@ -72,21 +92,24 @@ def couplings(n_bonds, nnn):
   return -j, j
 
 
-def make_inputs(n, h, L, b, chain_offset):
+def make_inputs(n, h, L, b, chain_offset, ansatz='fully_connected', k=0):
   """Synthetic inputs per BASELINE.md: truncated-normal weights (default_rng(1234)), random
   Sz=0 chains keyed by global chain id (default_rng(4321 + global id))."""
   rng = np.random.default_rng(1234)
   parts = []
-  fan_in = n
-  for l in range(L + 1):
-    out = h if l < L else 1
-    w = rng.standard_normal((fan_in, out))
+  if ansatz in ('conv_2d', 'res_net_2d'):     # snt.Conv2D: sigma = 1/sqrt(k k Cin), b = 0
+    n_conv = L if ansatz == 'conv_2d' else 1 + 2 * L
+    shapes = [(k, k, 1 if l == 0 else h, h) for l in range(n_conv)]
+  else:
+    shapes = [(n if l == 0 else h, h if l < L else 1) for l in range(L + 1)]
+  for shp in shapes:
+    fan_in = int(np.prod(shp[:-1]))
+    w = rng.standard_normal(shp)
     bad = np.abs(w) > 2
     while bad.any():
       w[bad] = rng.standard_normal(int(bad.sum()))
       bad = np.abs(w) > 2
-    parts += [(w / np.sqrt(fan_in)).ravel(), np.zeros(out)]
-    fan_in = out
+    parts += [(w / np.sqrt(fan_in)).ravel(), np.zeros(shp[-1])]
   theta = np.concatenate(parts).astype(np.float32)
   cfg = np.ones((b, n), np.float32)
   for i in range(b):
@@ -108,41 +131,44 @@ def _blas_info():
     return os.cpu_count() or 1, 'unknown'
 
 
-def _cpu_step_seconds(vo, theta, cfg, bonds, jx, jz, h, L, n, mc_steps_timed):
+def _cpu_step_seconds(vo, theta, cfg, bonds, jx, jz, h, L, n, mc_steps_timed, ansatz='fully_connected'):
   """One step of the reference's structure on `cfg`: accumulate_gradients + one sweep (the
-  sweep is timed on `mc_steps_timed` of its n mc_steps and scaled)."""
+  sweep is timed on `mc_steps_timed` of its n mc_steps and scaled).  `h` is the layer size, or
+  the oracle's geometry tuple for the convolutional ansatz types."""
   acc = vo.Accumulators(theta.size, np.float32)
   t0 = time.perf_counter()
-  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, jx, jz, -10.0, h, L, np.float32)
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, jx, jz, -10.0, h, L, np.float32, ansatz=ansatz)
   t_acc = time.perf_counter() - t0
   t0 = time.perf_counter()
-  vo.run_sweeps(theta, cfg, mc_steps_timed, 2024, 0, h, L)
+  vo.run_sweeps(theta, cfg, mc_steps_timed, 2024, 0, h, L, ansatz=ansatz)
   t_sweep = (time.perf_counter() - t0) * (n / float(mc_steps_timed))
   return t_acc, t_sweep
 
 
-def cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg):
+def cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg, ansatz='fully_connected', k=0, lx=0, ly=0):
   """Times the oracle (numpy fp32 restatement with the reference's call structure: one host
   call per mc_step with two forwards, 1 + n_bonds full-batch forwards per local energy, two
   back-prop passes per accumulate; no rank-2 update, no bond skipping) on a bounded sample of
   the same workload: median of 3 repetitions, with all BLAS threads and single-threaded."""
   from oracle import vmc_oracle as vo
   threads, blas = _blas_info()
-  flops_per_chain_step = (1 + len(bonds) + 2 * n) * f_amp(n, h, L)
+  flops_per_chain_step = (1 + len(bonds) + 2 * n) * f_amp(n, h, L, ansatz, k)
+  conv = ansatz in ('conv_2d', 'res_net_2d')
+  shape = (h, k, ly, lx) if conv else h        # oracle geometry: (filters, kernel, size_x, size_y)
   out = {'unit': 'chain-evals/s', 'kind': 'port', 'cores': int(threads), 'blas': blas,
          'host_cpu_count': os.cpu_count()}
 
   def measure(bs, mc_steps_timed, reps):
     sub = np.ascontiguousarray(cfg[:bs])
-    runs = [_cpu_step_seconds(vo, theta, sub, bonds, jx, jz, h, L, n, mc_steps_timed)
+    runs = [_cpu_step_seconds(vo, theta, sub, bonds, jx, jz, shape, L, n, mc_steps_timed, ansatz)
             for _ in range(reps)]
     runs.sort(key=lambda r: r[0] + r[1])
     return runs[len(runs) // 2]
 
   # all cores: a batch large enough for the BLAS to thread (2048 chains on a many-core host,
   # 512 on a small one); ~10-20 s in total
-  bs_all = min(cfg.shape[0], 2048 if threads >= 32 else 512)
-  steps_all = max(4, min(n, 20))
+  bs_all = min(cfg.shape[0], (2048 if threads >= 32 else 512) // (8 if conv else 1))
+  steps_all = max(4, min(n, 20)) // (4 if conv else 1)
   measure(min(bs_all, 64), 2, 1)                       # page in BLAS, first-touch
   t_acc, t_sweep = measure(bs_all, steps_all, 3)
   out['value'] = bs_all / (t_acc + t_sweep)
@@ -156,8 +182,8 @@ def cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg):
   try:
     import threadpoolctl
     with threadpoolctl.threadpool_limits(limits=1):
-      bs_1 = min(cfg.shape[0], 64)
-      steps_1 = max(2, min(n, 10))
+      bs_1 = min(cfg.shape[0], 16 if conv else 64)
+      steps_1 = max(2, min(n, 4 if conv else 10))
       a1, s1 = measure(bs_1, steps_1, 3)
     out['single_thread'] = {
         'value': bs_1 / (a1 + s1), 'unit': 'chain-evals/s', 'cores': 1,
@@ -241,15 +267,20 @@ def main():
   dev = parallel.local_rank()
   torch.cuda.set_device(dev)
 
-  lx, ly, nnn, L, h, b = WORKLOADS[args.workload]
+  lx, ly, nnn, L, h, b = WORKLOADS[args.workload][:6]
+  ansatz, ksz = (WORKLOADS[args.workload][6:] + ('fully_connected', 0))[:2]
+  conv = ansatz in ('conv_2d', 'res_net_2d')
   n = lx * ly
   bonds = torus_bonds(lx, ly, nnn)
   nb = len(bonds)
   jx, jz = couplings(nb, nnn)
   chain_offset = rank * b
-  theta, cfg = make_inputs(n, h, L, b, chain_offset)
+  theta, cfg = make_inputs(n, h, L, b, chain_offset, ansatz, ksz)
 
-  eng = VmcEngine(n, b, L, h, device=dev, chain_offset=chain_offset, seed=2024)
+  # lattice.torus_bonds: site = x + lx * y, so the reshape [-1, size_x, size_y, 1] of the
+  # convolutional ansatz (wavefunctions.py:596) has size_x = ly, size_y = lx
+  eng = VmcEngine(n, b, L, h, device=dev, chain_offset=chain_offset, seed=2024, ansatz=ansatz,
+                  kernel_size=ksz, size_x=ly if conv else 0, size_y=lx if conv else 0)
   eng.set_params(theta)
   eng.set_configs(cfg)
   eng.set_bonds(bonds, jx, jz)
@@ -326,11 +357,11 @@ def main():
       timings[name] = {'ms_total': ms, 'launches': cnt, 'ms_avg': ms / cnt}
 
   if rank == 0:
-    fa = f_amp(n, h, L)
+    fa = f_amp(n, h, L, ansatz, ksz)
     hp = (h + 63) // 64 * 64
     n_hh = L - 1
-    mfma_per_row = 2 * n_hh * hp * hp               # H x H layers of one amplitude, on MFMA
-    p = n * h + h + n_hh * (h * h + h) + h + 1
+    mfma_per_row = mfma_flops_per_amp(n, h, L, ansatz, ksz)   # H x H layers / convolutions of one amplitude, on MFMA
+    p = eng.num_params
     flops_eloc = b * (1 + nb) * fa                  # nominal per E_loc batch
     flops_sweep = b * n * fa                        # nominal per sweep
     # executed on the matrix cores: one row per mc_step + the exact refresh of the final
@@ -339,6 +370,9 @@ def main():
     exec_sweep = b * (n + 1) * mfma_per_row
     exec_eloc = rows * mfma_per_row
     exec_grad = b * (n_hh * 2 * hp * hp + 4 * (n * h + n_hh * h * h + h))
+    if conv:      # taped forward + transposed convolutions + the two correlation sums
+      exec_sweep = b * n * mfma_per_row
+      exec_grad = 4 * b * mfma_per_row
     ms_step = 1e3 * elapsed / args.steps
     out = {
         'metric': 'mc_sweep+local_energy_evals_per_sec',
@@ -349,7 +383,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': args.workload, 'lattice': '{}x{} torus'.format(lx, ly),
-                   'n_sites': n, 'n_bonds': nb, 'ansatz': 'fully_connected {}x{} relu/exp'.format(L, h),
+                   'n_sites': n, 'n_bonds': nb, 'ansatz': ('{} {} x {} filters, kernel {}, relu/exp'.format(ansatz, L, h, ksz) if conv
+                              else 'fully_connected {}x{} relu/exp'.format(L, h)),
                    'chains_per_gpu': b, 'global_chains': world * b,
                    'step': 'reset + accumulate_gradients (E_loc + grad sums) + 1 MC sweep'
                            + (' + RCCL accumulator all-reduce (overlapped with the sweep)'
@@ -374,22 +409,24 @@ def main():
       out['mc_sweeps_per_sec'] = world / ts
       out['local_energy_evals_per_sec'] = world * b / t_eloc_call
       dom = 'sweep' if timings['sweep']['ms_total'] >= timings['tail_eloc']['ms_total'] else 'tail_eloc'
+      k_sweep, k_eloc = ('k_conv_sweep', 'k_conv_rows(eloc)') if conv else ('k_sweep16', 'k_tail16(eloc)')
       per_kernel = {
-          'k_sweep16': {'ms_avg': ts * 1e3, 'flops_executed': exec_sweep, 'flops_nominal': flops_sweep},
-          'k_tail16(eloc)': {'ms_avg': te * 1e3, 'flops_executed': exec_eloc, 'flops_nominal': flops_eloc},
+          k_sweep: {'ms_avg': ts * 1e3, 'flops_executed': exec_sweep, 'flops_nominal': flops_sweep},
+          k_eloc: {'ms_avg': te * 1e3, 'flops_executed': exec_eloc, 'flops_nominal': flops_eloc},
       }
       for v in per_kernel.values():
         t = v['ms_avg'] * 1e-3
         v['achieved'] = v['flops_executed'] / t / 1e12         # TFLOP/s issued to the matrix cores
         v['frac'] = v['achieved'] / FP32_MFMA_PEAK_TFLOPS
         v['algorithmic_tflops'] = v['flops_nominal'] / t / 1e12   # SURVEY 8d count / time; not a roofline fraction
-      key = 'k_sweep16' if dom == 'sweep' else 'k_tail16(eloc)'
+      key = k_sweep if dom == 'sweep' else k_eloc
       # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command
       # (profiles/*_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc runs; see
       # tools/collect_profiles.sh); null when no matching profile is present
       traffic = None
       pmc = None
-      tag = {'heisenberg10x10_fc3x256_b4096': 'r2', 'heisenberg16x16j1j2_fc6x256_b1024': 'r2_config5'}.get(args.workload)
+      tag = {'heisenberg10x10_fc3x256_b4096': 'r2', 'heisenberg16x16j1j2_fc6x256_b1024': 'r2_config5',
+             'heisenberg10x10_conv5x16k5_b4096': 'r2_conv', 'heisenberg16x16j1j2_conv5x16k5_b1024': 'r2_conv16'}.get(args.workload)
       tpath = os.path.join(ROOT, 'profiles', '{}_traffic.json'.format(tag))
       if tag and os.path.exists(tpath):
         try:
@@ -419,7 +456,7 @@ def main():
       }
     if not args.no_cpu_baseline:
       try:
-        out['cpu_baseline'] = cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg)
+        out['cpu_baseline'] = cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg, ansatz, ksz, lx, ly)
       except Exception as e:  # pylint: disable=broad-except
         out['cpu_baseline'] = {'error': repr(e)}
     print(json.dumps(out))
