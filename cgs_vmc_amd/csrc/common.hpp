@@ -287,3 +287,15 @@ hipError_t launch_sr_q(hipStream_t s, const float* u, const float* acc, int P, c
 hipError_t launch_sr_step(hipStream_t s, double* sc, int cur, int P, float* p, const float* q,
                           float* x, float* r, double* partial);
 hipError_t launch_sr_apply(hipStream_t s, float* theta, const float* x, float lr, int P);
+// large-tile GEMMs of the SR matrix-vector product (srmm.hip)
+hipError_t launch_sr_rowdot(hipStream_t s, const float* A, long long lda, const float* V,
+                            long long ldv, const float* vb, const float* D, long long ldd, float* t,
+                            int M, int N, int K, bool first);
+int sr_wsum_slices(int R, int num_cus);
+hipError_t launch_sr_wsum(hipStream_t s, const float* A, long long lda, const float* D,
+                          long long ldd, const float* t, float* ws, float* out, int M, int N, int R,
+                          int slices);
+hipError_t launch_sr_row_linear(hipStream_t s, const float* x, long long ldx, const float* v,
+                                const float* vb, int R, int K, float* t);
+hipError_t launch_sr_colsum(hipStream_t s, const float* x, long long ldx, const float* t, int R,
+                            int K, float* ws, int slices, float* u, float* tsum);

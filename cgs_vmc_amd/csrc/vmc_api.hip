@@ -76,6 +76,7 @@ struct vmc_ctx {
   int parity = 0;                 // which physical buffer set is current (GEMM tables are per set)
   hipStream_t sweep_stream = nullptr;   // private non-blocking stream of the sampler
   bool overlap = true;            // CGS_VMC_OVERLAP=0: everything on `stream`
+  bool overlap_full = false;      // CGS_VMC_OVERLAP=2: overtake even when the sampler fills every CU
   hipEvent_t ev_mark = nullptr;   // recorded on `stream` at the start of the latest accumulate
   hipEvent_t ev_now = nullptr;    // scratch: "everything enqueued on `stream` so far"
   hipEvent_t ev_sweep_done = nullptr;
@@ -114,7 +115,7 @@ struct vmc_ctx {
   // stochastic reconfiguration (extension, sr.hip): sample store + CG vectors
   int sr_cap = 0, sr_n = 0, sr_iter = 0;
   float *sr_cfg = nullptr, *sr_act = nullptr, *sr_delta = nullptr;   // [cap B][N], [L][cap B][Hp] x2
-  float *sr_tang = nullptr, *sr_t = nullptr, *sr_ones = nullptr;      // [2][cap B][Hp], [cap B] x2
+  float *sr_ws = nullptr, *sr_t = nullptr, *sr_ones = nullptr;        // [slices][(max(N,H)+1) H], [cap B] x2
   float *sr_u = nullptr, *sr_x = nullptr, *sr_r = nullptr, *sr_p = nullptr, *sr_q = nullptr;
   double *sr_partial = nullptr, *sr_sc = nullptr;
   GemmArgs* sr_batch = nullptr;                                       // [L+1]
@@ -187,7 +188,7 @@ int sweep_cus(const vmc_ctx* c) { return (c->B + 15) / 16; }
 // kernel at least a quarter of the CUs; with one 16-chain tile per CU (config 3) there is nothing
 // to share and the launch stays on `stream`.
 bool can_overlap(const vmc_ctx* c) {
-  return c->overlap && sweep_cus(c) <= (3 * c->num_cus) / 4;
+  return c->overlap && (c->overlap_full || sweep_cus(c) <= (3 * c->num_cus) / 4);
 }
 
 int join_sweep(vmc_ctx* c) {
@@ -421,7 +422,8 @@ int local_energy_device(vmc_ctx* c, int which) {
     a.out = c->val;
     // a sampler launch is expected to overtake this accumulate: its workgroups need a whole
     // CU each, so the persistent grid leaves them free
-    if (c->expect_sweep && can_overlap(c)) a.num_cus = c->num_cus - sweep_cus(c);
+    if (c->expect_sweep && can_overlap(c) && c->num_cus - sweep_cus(c) >= c->num_cus / 4)
+      a.num_cus = c->num_cus - sweep_cus(c);
     HIPCHK(c, launch_tail(c->stream, a, c->Hp, true, c->rbm));
   }
   {
@@ -553,7 +555,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
               : vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
   c->stream = (hipStream_t)d->stream;
   if (const char* e = getenv("CGS_VMC_SWEEP_W1L")) c->sweep_no_w1l = atoi(e) == 0 ? 1 : 0;
-  if (const char* e = getenv("CGS_VMC_OVERLAP")) c->overlap = !conv && atoi(e) != 0;
+  if (const char* e = getenv("CGS_VMC_OVERLAP")) { c->overlap = !conv && atoi(e) != 0; c->overlap_full = atoi(e) == 2; }
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -628,7 +630,16 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     }
     c->cG = conv_pick_group(cg, 8);
     if (c->cG > B) c->cG = (int)B;
-    c->cGs = (int)(B / c->num_cus); if (c->cGs < 1) c->cGs = 1; if (c->cGs > c->cG) c->cGs = c->cG;
+    {  // sampler: chains per workgroup that minimise (rounds of workgroups over the CUs) x (tile
+       // rounds of one forward pass); one workgroup per CU at a time (LDS)
+      long long best_cost = -1;
+      for (int G = 1; G <= 64 && conv_rows_lds(cg, G) <= 160 * 1024 && G <= B; ++G) {
+        const long long wgs = (B + G - 1) / G, wg_rounds = (wgs + c->num_cus - 1) / c->num_cus;
+        const long long tiles = ((long long)G * cg.N + 15) / 16, tile_rounds = (tiles + 7) / 8;
+        const long long cost = wg_rounds * tile_rounds;
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; c->cGs = G; }
+      }
+    }
     c->ctape_stride = B * 4 * cg.GS; c->cdelta_stride = B * 4 * cg.GS;
     CA(dalloc(&c->ctape, nl * c->ctape_stride)); CA(dalloc(&c->cdelta, (long long)cg.n_conv * c->cdelta_stride));
     c->c_slices = B < 64 ? (int)B : 64;
@@ -664,7 +675,7 @@ void vmc_destroy(vmc_ctx* c) {
                   c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->tmp_on, c->tmp_rowinfo, c->rowinfo_id, c->bond_dummy, c->inj_up, c->inj_dn, c->inj_u,
                   c->acc_mask};
   for (void* q : ptrs) if (q) hipFree(q);
-  void* sr[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_tang, c->sr_t, c->sr_u, c->sr_x, c->sr_r,
+  void* sr[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_u, c->sr_x, c->sr_r,
                 c->sr_p, c->sr_q, c->sr_partial, c->sr_sc, c->sr_batch, c->sr_ones};
   for (void* q : sr) if (q) hipFree(q);
   delete c;
@@ -1289,9 +1300,9 @@ int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   if (n_batches > 0 && (c->oact != VMC_ACT_EXP_ || c->hact == VMC_ACT_COS_))
     return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation and every hidden activation except cos");
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_tang, c->sr_t, c->sr_ones};
+  void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_ones};
   for (void* q : old) if (q) hipFree(q);
-  c->sr_cfg = c->sr_act = c->sr_delta = c->sr_tang = c->sr_t = c->sr_ones = nullptr;
+  c->sr_cfg = c->sr_act = c->sr_delta = c->sr_ws = c->sr_t = c->sr_ones = nullptr;
   c->sr_cap = 0; c->sr_n = 0; c->sr_begun = false;
   if (n_batches == 0) return VMC_OK;
   const long long B = c->B, N = c->N, Hp = c->Hp, L = c->A, P = c->P, R = (long long)n_batches * B;
@@ -1299,8 +1310,8 @@ int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   HIPCHK(c, dalloc(&c->sr_cfg, R * N));
   HIPCHK(c, dalloc(&c->sr_act, L * R * Hp));
   HIPCHK(c, dalloc(&c->sr_delta, L * R * Hp));
-  HIPCHK(c, dalloc(&c->sr_tang, 2 * R * Hp)); HIPCHK(c, dalloc(&c->sr_t, R)); HIPCHK(c, dalloc(&c->sr_ones, R));
-  HIPCHK(c, hipMemsetAsync(c->sr_tang, 0, 2 * R * Hp * sizeof(float), c->stream));
+  HIPCHK(c, dalloc(&c->sr_ws, (long long)sr_wsum_slices((int)R, c->num_cus) * ((N > c->H ? N : c->H) + 1) * c->H));
+  HIPCHK(c, dalloc(&c->sr_t, R)); HIPCHK(c, dalloc(&c->sr_ones, R));
   HIPCHK(c, launch_fill(c->stream, c->sr_ones, 1.f, R));
   if (!c->sr_u) {
     HIPCHK(c, dalloc(&c->sr_batch, L + 1));
@@ -1328,11 +1339,10 @@ static int sr_build_table(vmc_ctx* c) {
     g.splitk = pick_splitk(c, rows); g.workspace = c->gemm_ws + (long long)tab.size() * ws_stride;
     tab.push_back(g);
   };
+  // only the N = 1 layer goes through the batched GEMM (u += [a | 1]^T [t]); the H-wide layers
+  // run on the large-tile kernels of srmm.hip
   if (c->rbm) add(c->sr_cfg, N, (int)N, c->sr_ones, 1, 0, 1, c->lay.off_won);        // onsite layer
   else add(c->sr_act + (L - 1) * R * Hp, Hp, (int)H, c->sr_ones, 1, 0, 1, off_wout(c));
-  for (int l = (int)L - 1; l > 0; --l)
-    add(c->sr_act + (l - 1) * R * Hp, Hp, (int)H, c->sr_delta + l * R * Hp, Hp, 1, (int)H, off_w(c, l));
-  add(c->sr_cfg, N, (int)N, c->sr_delta, Hp, 1, (int)H, off_w(c, 0));
   HIPCHK(c, hipMemcpyAsync(c->sr_batch, tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // tab is a stack object
   return VMC_OK;
@@ -1369,41 +1379,36 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
   const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->A;
   const long long R = (long long)c->sr_cap * B;   // row stride between layers of the store
   const int rows = c->sr_n * B;                   // all recorded samples in one pass
-  const float* theta = c->ps[0].theta;
   const float* v = c->sr_p;
   Timer t(c, "sr_matvec");
   HIPCHK(c, hipMemsetAsync(c->sr_u, 0, (c->P + 1) * sizeof(float), c->stream));
-  float* tang[2] = {c->sr_tang, c->sr_tang + R * Hp};
-  // RBM: the last linear layer has no relu (its output goes through log cosh), so its tangent is
-  // not masked; sr_act's last slot holds tanh(z_last) = d logit / d z_last
-  {  // adot_1 = relu'(z_1) (.) (X V_1 + v_b1)
-    GemmArgs g; memset(&g, 0, sizeof(g));
-    g.A = c->sr_cfg; g.sam = N; g.sak = 1; g.B = v + off_w(c, 0); g.sbk = H; g.sbn = 1;
-    g.M = rows; g.N = H; g.K = N; g.C = tang[0]; g.ldc = Hp;
-    g.bias = v + off_b(c, 0); g.mask = c->sr_act; g.ldmask = Hp;
-    g.epilogue = (c->rbm && L == 1) ? 4 : 5; g.splitk = 1; g.act = c->hact;
-    HIPCHK(c, launch_gemm(c->stream, g));
-  }
-  for (int l = 1; l < L; ++l) {  // adot_{l+1} = relu' (.) (adot_l W_l + a_l V_l + v_bl)
-    float* src = tang[(l - 1) & 1];
-    float* dst = tang[l & 1];
-    GemmArgs g; memset(&g, 0, sizeof(g));
-    g.A = src; g.sam = Hp; g.sak = 1; g.B = theta + off_w(c, l); g.sbk = H; g.sbn = 1;
-    g.M = rows; g.N = H; g.K = H; g.C = dst; g.ldc = Hp; g.epilogue = 0; g.splitk = 1;
-    HIPCHK(c, launch_gemm(c->stream, g));
-    g.A = c->sr_act + (long long)(l - 1) * R * Hp; g.B = v + off_w(c, l);
-    g.bias = v + off_b(c, l); g.mask = c->sr_act + (long long)l * R * Hp; g.ldmask = Hp;
-    g.epilogue = (c->rbm && l == L - 1) ? 8 : 6; g.act = c->hact;
-    HIPCHK(c, launch_gemm(c->stream, g));
+  // t_b = O_b . p = sum_l delta_l[b] . (a_{l-1}[b] V_l + v_l) + (output / onsite layer term)
+  for (int l = 0; l < L; ++l) {
+    const float* a_in = l == 0 ? c->sr_cfg : c->sr_act + (long long)(l - 1) * R * Hp;
+    HIPCHK(c, launch_sr_rowdot(c->stream, a_in, l == 0 ? N : Hp, v + off_w(c, l), H, v + off_b(c, l),
+                               c->sr_delta + (long long)l * R * Hp, Hp, c->sr_t, rows, H, l == 0 ? N : H,
+                               l == 0));
   }
   if (c->rbm)
-    HIPCHK(c, launch_jvp_out_rbm(c->stream, tang[(L - 1) & 1], c->sr_act + (long long)(L - 1) * R * Hp,
-                                 c->sr_cfg, v + c->lay.off_won, v + off_bout(c), rows, H, Hp, N, c->sr_t));
+    HIPCHK(c, launch_sr_row_linear(c->stream, c->sr_cfg, N, v + c->lay.off_won, v + off_bout(c), rows, N, c->sr_t));
   else
-    HIPCHK(c, launch_jvp_out(c->stream, tang[(L - 1) & 1], c->sr_act + (long long)(L - 1) * R * Hp,
-                             theta + off_wout(c), v + off_wout(c), v + off_bout(c), rows, H, Hp, c->sr_t));
-  HIPCHK(c, launch_sum_into(c->stream, c->sr_t, rows, c->sr_u + c->P));
-  HIPCHK(c, launch_gemm_batched(c->stream, c->sr_batch, L + 1, N > H ? N : H, H, pick_splitk(c, (long long)c->sr_n * B), false));
+    HIPCHK(c, launch_sr_row_linear(c->stream, c->sr_act + (long long)(L - 1) * R * Hp, Hp, v + off_wout(c),
+                                   v + off_bout(c), rows, H, c->sr_t));
+  // u = sum_b t_b O_b: per layer [a_{l-1} | 1]^T (t (.) delta_l), written in the theta layout
+  const int slices = sr_wsum_slices(rows, c->num_cus);
+  for (int l = 0; l < L; ++l) {
+    const float* a_in = l == 0 ? c->sr_cfg : c->sr_act + (long long)(l - 1) * R * Hp;
+    HIPCHK(c, launch_sr_wsum(c->stream, a_in, l == 0 ? N : Hp, c->sr_delta + (long long)l * R * Hp, Hp, c->sr_t,
+                             c->sr_ws, c->sr_u + off_w(c, l), l == 0 ? N : H, H, rows, slices));
+  }
+  // the N = 1 layer (w_out, b_out of fully_connected; w_on, b_on of rbm: weights then bias in
+  // theta) and sum_b t_b in one column-sum pass
+  if (c->rbm)
+    HIPCHK(c, launch_sr_colsum(c->stream, c->sr_cfg, N, c->sr_t, rows, N, c->sr_ws, slices,
+                               c->sr_u + c->lay.off_won, c->sr_u + c->P));
+  else
+    HIPCHK(c, launch_sr_colsum(c->stream, c->sr_act + (long long)(L - 1) * R * Hp, Hp, c->sr_t, rows, H,
+                               c->sr_ws, slices, c->sr_u + off_wout(c), c->sr_u + c->P));
   return VMC_OK;
 }
 

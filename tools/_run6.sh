@@ -1,0 +1,10 @@
+cd /root/repo
+mkdir -p gpurun_out/r2h
+python tools/prof_sweep.py > gpurun_out/r2h/prof_sweep.txt 2>&1; cat gpurun_out/r2h/prof_sweep.txt
+for wl in heisenberg10x10_conv5x16k5_b4096 heisenberg16x16j1j2_conv5x16k5_b1024; do
+  timeout -k 10 300 python bench.py --workload $wl --steps 5 --warmup 1 --reps 3 --no-cpu-baseline > gpurun_out/r2h/bench_$wl.json 2> gpurun_out/r2h/bench_$wl.err || { echo "bench $wl failed"; tail -5 gpurun_out/r2h/bench_$wl.err; exit 1; }
+  python -c "
+import json,sys
+d=json.load(open('gpurun_out/r2h/bench_$wl.json')); print('$wl', round(d['ms_per_step'],3), {k:round(v['ms_avg'],4) for k,v in d['kernels'].items()}, {k:round(v['frac'],3) for k,v in d['roofline']['per_kernel'].items()})
+"
+done
