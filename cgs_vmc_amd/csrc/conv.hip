@@ -10,9 +10,15 @@
 // register r, which is the layout the next layer reads, so the epilogue is one ds_write_b128.
 // Feature maps of the G samples a workgroup has in flight never leave LDS between layers.
 #include "conv.hpp"
+#include <type_traits>
 
-#define CONV_WAVES 8
+// 4 waves per workgroup (one per SIMD) and two workgroups per CU: the two co-resident workgroups are
+// never in step, so the serial phases of one (row staging behind dependent global loads, the
+// per-layer weight-fragment reload, barriers, the final reduction) run under the MFMAs of the
+// other.  One 8-wave workgroup per CU measured 0.64 of the fp32-MFMA peak on the same loops.
+#define CONV_WAVES 4
 #define CONV_THREADS (CONV_WAVES * 64)
+#define CONV_LDS_PER_WG (80 * 1024)   // two workgroups share the 160 KiB of a CU
 #define SELU_SCALE_F 1.0507009873554805f
 #define SELU_ALPHA_F 1.6732632423543772f
 
@@ -60,6 +66,12 @@ struct ConvSmem {
   unsigned* pinfo;  // [G N] pack_pos
   int* row_chain;   // [G] chain (or row) of each slot, -1 = empty
   float* red;       // [G] reduced logits
+  // periodic neighbour tables, built once per kernel (the wrap arithmetic costs ~15 VALU
+  // instructions per tap column / row and tile otherwise): rtab[dir][a1][d] = 4 D2 ((a1 + d - lo)
+  // mod D1), ctab[dir][a2][d] = 4 ((a2 + d - lo) mod D2) in floats, lo = g.lo (dir 0: forward) or
+  // g.hi (dir 1: transposed convolution); rows of 8 ints
+  int* rtab;        // [2][D1][8]
+  int* ctab;        // [2][D2][8]
 };
 
 __device__ __forceinline__ int conv_xs_stride(const ConvGeom& g) { return (g.N + 3) & ~3; }
@@ -72,7 +84,15 @@ __device__ __forceinline__ ConvSmem conv_carve(float* base, const ConvGeom& g, i
   s.pinfo = (unsigned*)(s.xs + (size_t)G * conv_xs_stride(g));
   s.row_chain = (int*)(s.pinfo + (size_t)G * g.N);
   s.red = (float*)(s.row_chain + G);
+  s.rtab = (int*)(s.red + 6 * G);       // red, cur_logit, prop[2], prop_u of the sampler + spare
+  s.ctab = s.rtab + 2 * g.D1 * 8;
   return s;
+}
+
+__device__ __forceinline__ int wrap(int v, int d) {
+  v += v < 0 ? d : 0;
+  v -= v >= d ? d : 0;
+  return v;
 }
 
 __device__ __forceinline__ void conv_build_pinfo(const ConvSmem& sm, const ConvGeom& g, int G) {
@@ -81,12 +101,13 @@ __device__ __forceinline__ void conv_build_pinfo(const ConvSmem& sm, const ConvG
     const int a1 = site / g.D2, a2 = site - a1 * g.D2;
     sm.pinfo[q] = pack_pos(s, a1, a2);
   }
-}
-
-__device__ __forceinline__ int wrap(int v, int d) {
-  v += v < 0 ? d : 0;
-  v -= v >= d ? d : 0;
-  return v;
+  for (int i = threadIdx.x; i < 2 * (g.D1 + g.D2) * 8; i += blockDim.x) {
+    const bool is_r = i < 2 * g.D1 * 8;
+    const int j = is_r ? i : i - 2 * g.D1 * 8, D = is_r ? g.D1 : g.D2;
+    const int dir = j / (D * 8), a = (j / 8) % D, d = j & 7;
+    const int w = wrap(a + min(d, g.K - 1) - (dir ? g.hi : g.lo), D);
+    (is_r ? sm.rtab : sm.ctab)[j] = is_r ? 4 * g.D2 * w : 4 * w;
+  }
 }
 
 // First convolution (one input channel, layers.py:151-160 on the reshaped spins): the k index of
@@ -108,8 +129,8 @@ __device__ __forceinline__ void conv_first(const ConvSmem& sm, float* out, const
   for (int q = 0; q < Q0; ++q) {
     int tap = 4 * q + gl;
     tap = tap < K * K ? tap : 0;          // the weight of a tap beyond K*K is zero
-    d1[q] = tap / K - g.lo;
-    d2[q] = tap % K - g.lo;
+    d1[q] = tap / K;
+    d2[q] = tap % K;
   }
   for (int t = wave; t < n_tiles; t += CONV_WAVES) {
     const int q = t * 16 + pl;
@@ -118,11 +139,11 @@ __device__ __forceinline__ void conv_first(const ConvSmem& sm, float* out, const
     const int a2 = info & 1023, a1 = (info >> 10) & 1023, s = info >> 20;
     const float* xs = sm.xs + s * xs_stride;
     f32x4 acc = bias;
+    float bx[Q0];
 #pragma unroll
-    for (int qq = 0; qq < Q0; ++qq) {
-      const float b = xs[wrap(a1 + d1[qq], g.D1) * g.D2 + wrap(a2 + d2[qq], g.D2)];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[qq], b, acc, 0, 0, 0);
-    }
+    for (int qq = 0; qq < Q0; ++qq) bx[qq] = xs[(sm.rtab[a1 * 8 + d1[qq]] + sm.ctab[a2 * 8 + d2[qq]]) >> 2];
+#pragma unroll
+    for (int qq = 0; qq < Q0; ++qq) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[qq], bx[qq], acc, 0, 0, 0);
     if (ep == EP_ACT) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] = vmc_act_rt(g.hact, acc[r]);
@@ -143,7 +164,7 @@ __device__ __forceinline__ void conv_first(const ConvSmem& sm, float* out, const
 template <int K>
 __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, float* out,
                                            const ConvGeom& g, const float* wfrag, const float* bias16,
-                                           int lo, int G, int ep, int wave, int lane,
+                                           int dir, int G, int ep, int wave, int lane,
                                            const float* tape_in, float* tape_out) {
   const int pl = lane & 15, gl = lane >> 4;
   f32x4 w[K * K];
@@ -152,48 +173,83 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
   if (bias16) bias = *(const f32x4*)(bias16 + 4 * gl);
   const int n_pos = G * g.N, n_tiles = (n_pos + 15) >> 4;
-  for (int t = wave; t < n_tiles; t += CONV_WAVES) {
-    const int q = t * 16 + pl;
-    const bool valid = q < n_pos;
-    const unsigned info = sm.pinfo[valid ? q : n_pos - 1];
-    const int a2 = info & 1023, a1 = (info >> 10) & 1023, s = info >> 20;
-    const float* base = in + (size_t)s * 4 * g.GS + gl * g.GS;
-    int roff[K], coff[K];
+  // Two adjacent position tiles at a time: two independent accumulator chains that share every
+  // weight fragment.
+  auto tiles = [&](int t0, auto nt_c) {
+    constexpr int NTL = decltype(nt_c)::value;
+    bool valid[NTL]; int a1[NTL], a2[NTL], sl[NTL];
+    const float* base[NTL];
+    int roff[NTL][K], coff[NTL][K];
 #pragma unroll
-    for (int d = 0; d < K; ++d) {
-      roff[d] = wrap(a1 + d - lo, g.D1) * g.D2;
-      coff[d] = wrap(a2 + d - lo, g.D2);
+    for (int h = 0; h < NTL; ++h) {
+      const int q = (t0 + h) * 16 + pl;
+      valid[h] = q < n_pos;
+      const unsigned info = sm.pinfo[valid[h] ? q : n_pos - 1];
+      a2[h] = info & 1023; a1[h] = (info >> 10) & 1023; sl[h] = info >> 20;
+      base[h] = in + (size_t)sl[h] * 4 * g.GS + gl * g.GS;
+      const int* rt = sm.rtab + (dir * g.D1 + a1[h]) * 8;
+      const int* ct = sm.ctab + (dir * g.D2 + a2[h]) * 8;
+#pragma unroll
+      for (int d = 0; d < K; ++d) { roff[h][d] = rt[d]; coff[h][d] = ct[d]; }
     }
-    f32x4 acc = bias;
+    f32x4 acc[NTL];
+#pragma unroll
+    for (int h = 0; h < NTL; ++h) acc[h] = bias;
+    // B operands two taps ahead of the MFMAs that consume them (3-stage register ring per tile;
+    // the sched_barrier keeps the compiler from sinking the reads back next to their use, which
+    // would expose one LDS round trip per tap)
+    f32x4 bq[NTL][3];
+#pragma unroll
+    for (int h = 0; h < NTL; ++h) {
+      bq[h][0] = *(const f32x4*)(base[h] + roff[h][0] + coff[h][0]);
+      if (K * K > 1) bq[h][1] = *(const f32x4*)(base[h] + roff[h][K > 1 ? 1 / K : 0] + coff[h][K > 1 ? 1 % K : 0]);
+    }
 #pragma unroll
     for (int tap = 0; tap < K * K; ++tap) {
-      const f32x4 b = *(const f32x4*)(base + 4 * (roff[tap / K] + coff[tap % K]));
+      if (tap + 2 < K * K) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][e], b[e], acc, 0, 0, 0);
+        for (int h = 0; h < NTL; ++h)
+          bq[h][(tap + 2) % 3] = *(const f32x4*)(base[h] + roff[h][(tap + 2) / K] + coff[h][(tap + 2) % K]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int h = 0; h < NTL; ++h)
+          acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][e], bq[h][tap % 3][e], acc[h], 0, 0, 0);
     }
-    const int site = a1 * g.D2 + a2;
-    float* dst = out + (size_t)s * 4 * g.GS + gl * g.GS + 4 * site;
-    const int row = sm.row_chain[s];
-    const long long trow = ((long long)(row >= 0 ? row : 0) * 4 + gl) * g.GS + 4 * site;
-    if (ep == EP_ACT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = vmc_act_rt(g.hact, acc[r]);
-    } else if (ep == EP_SELU) {
+    for (int h = 0; h < NTL; ++h) {
+      const int site = a1[h] * g.D2 + a2[h];
+      float* dst = out + (size_t)sl[h] * 4 * g.GS + gl * g.GS + 4 * site;
+      const int row = sm.row_chain[sl[h]];
+      const long long trow = ((long long)(row >= 0 ? row : 0) * 4 + gl) * g.GS + 4 * site;
+      f32x4 v = acc[h];
+      if (ep == EP_ACT) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = selu_f(acc[r]);
-    } else if (ep == EP_RESADD || ep == EP_BACK_ADD) {
-      const f32x4 old = *(const f32x4*)dst;
-      acc += old;
-    } else if (ep == EP_BACK_DACT || ep == EP_BACK_SELU) {
-      const f32x4 a = *(const f32x4*)(tape_in + trow);
+        for (int r = 0; r < 4; ++r) v[r] = vmc_act_rt(g.hact, v[r]);
+      } else if (ep == EP_SELU) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[r] *= ep == EP_BACK_SELU ? selu_deriv_from_t(a[r]) : dact_from_a_rt(g.hact, a[r]);
+        for (int r = 0; r < 4; ++r) v[r] = selu_f(v[r]);
+      } else if (ep == EP_RESADD || ep == EP_BACK_ADD) {
+        const f32x4 old = *(const f32x4*)dst;
+        v += old;
+      } else if (ep == EP_BACK_DACT || ep == EP_BACK_SELU) {
+        const f32x4 a = *(const f32x4*)(tape_in + trow);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          v[r] *= ep == EP_BACK_SELU ? selu_deriv_from_t(a[r]) : dact_from_a_rt(g.hact, a[r]);
+      }
+      if (valid[h]) {
+        *(f32x4*)dst = v;
+        if (tape_out && row >= 0) *(f32x4*)(tape_out + trow) = v;
+      }
     }
-    if (valid) {
-      *(f32x4*)dst = acc;
-      if (tape_out && row >= 0) *(f32x4*)(tape_out + trow) = acc;
-    }
+  };
+  // a wave's tiles in pairs (2w, 2w+1), (2w + 2 NW, ...); an odd last tile runs alone
+  for (int t0 = 2 * wave; t0 < n_tiles; t0 += 2 * CONV_WAVES) {
+    if (t0 + 1 < n_tiles) tiles(t0, std::integral_constant<int, 2>{});
+    else tiles(t0, std::integral_constant<int, 1>{});
   }
 }
 
@@ -212,7 +268,7 @@ __device__ __forceinline__ void conv_forward(const ConvSmem& sm, const ConvGeom&
     float* in = sm.buf0; float* out = sm.buf1;
     for (int l = 1; l < g.n_conv; ++l) {
       const bool is_last = l + 1 == g.n_conv;
-      conv_layer<K>(sm, in, out, g, p.wf + (size_t)(l - 1) * K * K * 256, p.bias + 16 * l, g.lo, G,
+      conv_layer<K>(sm, in, out, g, p.wf + (size_t)(l - 1) * K * K * 256, p.bias + 16 * l, 0, G,
                     is_last ? EP_LINEAR : EP_ACT, wave, lane, nullptr,
                     (tape && !is_last) ? tape + (long long)l * tape_stride : nullptr);
       __syncthreads();
@@ -226,11 +282,11 @@ __device__ __forceinline__ void conv_forward(const ConvSmem& sm, const ConvGeom&
     __syncthreads();
     for (int l = 1; l + 1 < g.n_conv; l += 2) {
       conv_layer<K>(sm, sm.buf0, sm.buf1, g, p.wf + (size_t)(l - 1) * K * K * 256, p.bias + 16 * l,
-                    g.lo, G, EP_SELU, wave, lane, nullptr,
+                    0, G, EP_SELU, wave, lane, nullptr,
                     tape ? tape + (long long)l * tape_stride : nullptr);
       __syncthreads();
       conv_layer<K>(sm, sm.buf1, sm.buf0, g, p.wf + (size_t)l * K * K * 256, p.bias + 16 * (l + 1),
-                    g.lo, G, EP_RESADD, wave, lane, nullptr,
+                    0, G, EP_RESADD, wave, lane, nullptr,
                     (tape && l + 2 < g.n_conv) ? tape + (long long)(l + 1) * tape_stride : nullptr);
       __syncthreads();
     }
@@ -254,7 +310,7 @@ __device__ __forceinline__ void conv_forward(const ConvSmem& sm, const ConvGeom&
 // sites exchanged (operators.py:162-163), or the chain itself (bond 0).  Persistent: workgroup b
 // takes the row groups b, b + gridDim.x, ... of G rows each.
 template <int K>
-__global__ __launch_bounds__(CONV_THREADS) void k_conv_rows(ConvRowsArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_rows(ConvRowsArgs a) {
   extern __shared__ float s_conv[];
   const ConvGeom& g = a.g;
   const int G = a.G;
@@ -310,7 +366,7 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv_rows(ConvRowsArgs a) {
 // forward of the proposed configuration (a K x K receptive field grows past the lattice after a few
 // layers, so there is no incremental shortcut).
 template <int K>
-__global__ __launch_bounds__(CONV_THREADS) void k_conv_sweep(ConvSweepArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_sweep(ConvSweepArgs a) {
   extern __shared__ float s_conv[];
   const ConvGeom& g = a.g;
   const int G = a.G;
@@ -429,7 +485,7 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv_sweep(ConvSweepArgs a) {
 // D += convT_{2k+1}(delta_{2k+1}); delta_0 = D.  convT is the same tile loop with the flipped,
 // transposed fragment image and the padding roles exchanged.
 template <int K>
-__global__ __launch_bounds__(CONV_THREADS) void k_conv_back(ConvBackArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_back(ConvBackArgs a) {
   extern __shared__ float s_conv[];
   const ConvGeom& g = a.g;
   const int G = a.G;
@@ -457,7 +513,7 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv_back(ConvBackArgs a) {
     if (!g.resnet) {
       float* in = sm.buf0; float* out = sm.buf1;
       for (int l = n - 1; l >= 1; --l) {
-        conv_layer<K>(sm, in, out, g, a.p.wb + (size_t)(l - 1) * K * K * 256, nullptr, g.hi, G,
+        conv_layer<K>(sm, in, out, g, a.p.wb + (size_t)(l - 1) * K * K * 256, nullptr, 1, G,
                       EP_BACK_DACT, wave, lane, a.tape + (long long)(l - 1) * a.tape_stride,
                       a.delta + (long long)(l - 1) * a.delta_stride);
         __syncthreads();
@@ -475,11 +531,11 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv_back(ConvBackArgs a) {
                   a.delta[(long long)l * a.delta_stride + ((long long)row * 4 + gq) * g.GS + i] = d[gq * g.GS + i];
           }
         }
-        conv_layer<K>(sm, sm.buf0, sm.buf1, g, a.p.wb + (size_t)(l - 1) * K * K * 256, nullptr, g.hi, G,
+        conv_layer<K>(sm, sm.buf0, sm.buf1, g, a.p.wb + (size_t)(l - 1) * K * K * 256, nullptr, 1, G,
                       EP_BACK_SELU, wave, lane, a.tape + (long long)(l - 1) * a.tape_stride,
                       a.delta + (long long)(l - 1) * a.delta_stride);
         __syncthreads();
-        conv_layer<K>(sm, sm.buf1, sm.buf0, g, a.p.wb + (size_t)(l - 2) * K * K * 256, nullptr, g.hi, G,
+        conv_layer<K>(sm, sm.buf1, sm.buf0, g, a.p.wb + (size_t)(l - 2) * K * K * 256, nullptr, 1, G,
                       EP_BACK_ADD, wave, lane, nullptr, l == 2 ? a.delta : nullptr);
         __syncthreads();
       }
@@ -496,10 +552,11 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv_back(ConvBackArgs a) {
 // index of the MFMA (4 positions per instruction): A = input at the tap-shifted position (lane =
 // cin), B = delta (lane = cout), and a second accumulator takes w_b * delta.  Partial sums go to
 // ws[slice][layer]; k_conv_dw_reduce adds the slices in a fixed order into the accumulators.
+#define DW_WAVES 8   // the weight-gradient kernel splits the taps over 8 waves (1 workgroup per CU)
 template <int K>
-__global__ __launch_bounds__(CONV_THREADS) void k_conv_dw(ConvDwArgs a) {
+__global__ __launch_bounds__(DW_WAVES * 64) void k_conv_dw(ConvDwArgs a) {
   constexpr int KK = K * K;
-  constexpr int TPW = (KK + CONV_WAVES - 1) / CONV_WAVES;        // taps per wave
+  constexpr int TPW = (KK + DW_WAVES - 1) / DW_WAVES;        // taps per wave
   constexpr int T0 = (KK + 15) / 16;                             // tap tiles of the first layer
   extern __shared__ float s_dw[];
   const ConvGeom& g = a.g;
@@ -515,7 +572,7 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv_dw(ConvDwArgs a) {
   f32x4 acc1[TPW], acc2[TPW];
 #pragma unroll
   for (int i = 0; i < TPW; ++i) { acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i] = acc1[i]; }
-  f32x4 bacc1 = {0.f, 0.f, 0.f, 0.f}, bacc2 = bacc1;   // bias: A = ones (wave CONV_WAVES-1)
+  f32x4 bacc1 = {0.f, 0.f, 0.f, 0.f}, bacc2 = bacc1;   // bias: A = ones (wave DW_WAVES-1)
   for (int i = threadIdx.x; i < (Np - g.N) * 16; i += blockDim.x) {   // zero the padded positions once
     s_dl[g.N * 16 + i] = 0.f;
     if (l > 0) s_in[g.N * 16 + i] = 0.f;
@@ -548,19 +605,19 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv_dw(ConvDwArgs a) {
         // A = spin at the tap-shifted position, lane m = tap 16 tt + m: tap tiles over waves
 #pragma unroll
         for (int tt = 0; tt < T0; ++tt) {
-          if ((tt % CONV_WAVES) == wave) {
+          if ((tt % DW_WAVES) == wave) {
             int tap = 16 * tt + ml;
             tap = tap < KK ? tap : 0;
             const int n1 = wrap(a1 + tap / K - g.lo, g.D1), n2 = wrap(a2 + tap % K - g.lo, g.D2);
             const float av = pv ? s_in[n1 * g.D2 + n2] : 0.f;
-            acc1[tt / CONV_WAVES] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv, acc1[tt / CONV_WAVES], 0, 0, 0);
-            acc2[tt / CONV_WAVES] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv2, acc2[tt / CONV_WAVES], 0, 0, 0);
+            acc1[tt / DW_WAVES] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv, acc1[tt / DW_WAVES], 0, 0, 0);
+            acc2[tt / DW_WAVES] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv2, acc2[tt / DW_WAVES], 0, 0, 0);
           }
         }
       } else {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-          const int tap = wave + i * CONV_WAVES;       // wave-uniform
+          const int tap = wave + i * DW_WAVES;       // wave-uniform
           if (tap < KK) {
             const int n1 = wrap(a1 + tap / K - g.lo, g.D1), n2 = wrap(a2 + tap % K - g.lo, g.D2);
             const float av = pv ? s_in[(n1 * g.D2 + n2) * 16 + ml] : 0.f;
@@ -569,7 +626,7 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv_dw(ConvDwArgs a) {
           }
         }
       }
-      if (wave == CONV_WAVES - 1) {
+      if (wave == DW_WAVES - 1) {
         bacc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv, bacc1, 0, 0, 0);
         bacc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv2, bacc2, 0, 0, 0);
       }
@@ -582,19 +639,19 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv_dw(ConvDwArgs a) {
   if (l == 0) {
 #pragma unroll
     for (int tt = 0; tt < T0; ++tt)
-      if ((tt % CONV_WAVES) == wave)
+      if ((tt % DW_WAVES) == wave)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int tap = 16 * tt + 4 * gl + r;        // accumulator row = tap
           if (tap < KK) {
-            w1[(size_t)tap * 16 * 16 + ml] = acc1[tt / CONV_WAVES][r];   // cin 0
-            w2[(size_t)tap * 16 * 16 + ml] = acc2[tt / CONV_WAVES][r];
+            w1[(size_t)tap * 16 * 16 + ml] = acc1[tt / DW_WAVES][r];   // cin 0
+            w2[(size_t)tap * 16 * 16 + ml] = acc2[tt / DW_WAVES][r];
           }
         }
   } else {
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-      const int tap = wave + i * CONV_WAVES;
+      const int tap = wave + i * DW_WAVES;
       if (tap < KK)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -603,7 +660,7 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv_dw(ConvDwArgs a) {
         }
     }
   }
-  if (wave == CONV_WAVES - 1 && gl == 0) {
+  if (wave == DW_WAVES - 1 && gl == 0) {
     w1[(size_t)KK * 16 * 16 + ml] = bacc1[0];
     w2[(size_t)KK * 16 * 16 + ml] = bacc2[0];
   }
@@ -675,10 +732,10 @@ __global__ void k_conv_pack(const float* __restrict__ theta, ConvGeom g, float* 
 }
 
 template <typename Kern, typename Args>
-hipError_t launch_k(Kern kern, dim3 grid, size_t lds, hipStream_t s, const Args& a) {
+hipError_t launch_k(Kern kern, dim3 grid, size_t lds, hipStream_t s, const Args& a, int threads = CONV_THREADS) {
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, grid, dim3(CONV_THREADS), lds, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, a);
   return hipGetLastError();
 }
 
@@ -695,10 +752,16 @@ hipError_t launch_k(Kern kern, dim3 grid, size_t lds, hipStream_t s, const Args&
 
 }  // namespace
 
+// LDS budget of one workgroup: half a CU when a sample's feature maps allow two workgroups per CU
+size_t conv_lds_cap(const ConvGeom& g) {
+  return conv_rows_lds(g, 1) <= CONV_LDS_PER_WG ? (size_t)CONV_LDS_PER_WG : (size_t)160 * 1024;
+}
+int conv_waves() { return CONV_WAVES; }
+
 size_t conv_rows_lds(const ConvGeom& g, int G) {
   const size_t xs = (size_t)((g.N + 3) & ~3);
   // buf0, buf1, xs, pinfo, row_chain, red + the sampler's cur_logit, prop, prop_u
-  return ((size_t)G * 8 * g.GS + (size_t)G * xs + (size_t)G * g.N + (size_t)G * 6 + 16) * sizeof(float);
+  return ((size_t)G * 8 * g.GS + (size_t)G * xs + (size_t)G * g.N + (size_t)G * 7 + 16 * (size_t)(g.D1 + g.D2) + 16) * sizeof(float);
 }
 
 // samples per pass: the group size (<= 64, LDS <= 160 KiB) whose position tiles divide most evenly
@@ -706,7 +769,7 @@ size_t conv_rows_lds(const ConvGeom& g, int G) {
 int conv_pick_group(const ConvGeom& g, int waves) {
   int best = 1; double best_eff = -1.0;
   for (int G = 1; G <= 64; ++G) {
-    if (conv_rows_lds(g, G) > 160 * 1024) break;
+    if (conv_rows_lds(g, G) > conv_lds_cap(g)) break;
     const int tiles = (G * g.N + 15) / 16;
     const int rounds = (tiles + waves - 1) / waves;
     const double eff = (double)G * g.N / 16.0 / ((double)rounds * waves);
@@ -729,8 +792,9 @@ hipError_t launch_conv_pack(hipStream_t s, const float* theta, const ConvGeom& g
 hipError_t launch_conv_rows(hipStream_t s, const ConvRowsArgs& a, int num_cus) {
   if (a.n_rows <= 0) return hipSuccess;
   const int groups = (a.n_rows + a.G - 1) / a.G;
-  const dim3 grid(groups < num_cus ? groups : num_cus);
   const size_t lds = conv_rows_lds(a.g, a.G);
+  const int slots = num_cus * (lds <= CONV_LDS_PER_WG ? 2 : 1);      // co-resident workgroups
+  const dim3 grid(groups < slots ? groups : slots);
   CONV_DISPATCH_K(a.g.K, return launch_k(k_conv_rows<KK_>, grid, lds, s, a));
   return hipSuccess;
 }
@@ -744,8 +808,9 @@ hipError_t launch_conv_sweep(hipStream_t s, const ConvSweepArgs& a) {
 
 hipError_t launch_conv_back(hipStream_t s, const ConvBackArgs& a, int num_cus) {
   const int groups = (a.B + a.G - 1) / a.G;
-  const dim3 grid(groups < num_cus ? groups : num_cus);
   const size_t lds = conv_rows_lds(a.g, a.G);
+  const int slots = num_cus * (lds <= CONV_LDS_PER_WG ? 2 : 1);
+  const dim3 grid(groups < slots ? groups : slots);
   CONV_DISPATCH_K(a.g.K, return launch_k(k_conv_back<KK_>, grid, lds, s, a));
   return hipSuccess;
 }
@@ -754,7 +819,7 @@ hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a) {
   const dim3 grid(a.n_slices, a.g.n_conv);
   const size_t lds = (size_t)((a.g.N + 3) & ~3) * 32 * sizeof(float);
   CONV_DISPATCH_K(a.g.K, {
-    hipError_t e = launch_k(k_conv_dw<KK_>, grid, lds, s, a);
+    hipError_t e = launch_k(k_conv_dw<KK_>, grid, lds, s, a, DW_WAVES * 64);
     if (e != hipSuccess) return e;
   });
   hipLaunchKernelGGL(k_conv_dw_reduce, dim3(32), dim3(256), 0, s, a, a.g.K * a.g.K);

@@ -628,15 +628,16 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
       CA(dalloc(&p.cw0, (KK + 3) / 4 * 64)); CA(dalloc(&p.cwf, nl * KK * 256)); CA(dalloc(&p.cwb, nl * KK * 256));
       CA(dalloc(&p.cbias, (long long)cg.n_conv * 16));
     }
-    c->cG = conv_pick_group(cg, 8);
+    const int nw = conv_waves();
+    c->cG = conv_pick_group(cg, nw);
     if (c->cG > B) c->cG = (int)B;
-    {  // sampler: chains per workgroup that minimise (rounds of workgroups over the CUs) x (tile
-       // rounds of one forward pass); one workgroup per CU at a time (LDS)
+    {  // sampler: chains per workgroup that minimise (workgroups per CU) x (tile rounds of one
+       // forward pass) -- the MFMA time of the busiest CU per mc_step
       long long best_cost = -1;
-      for (int G = 1; G <= 64 && conv_rows_lds(cg, G) <= 160 * 1024 && G <= B; ++G) {
-        const long long wgs = (B + G - 1) / G, wg_rounds = (wgs + c->num_cus - 1) / c->num_cus;
-        const long long tiles = ((long long)G * cg.N + 15) / 16, tile_rounds = (tiles + 7) / 8;
-        const long long cost = wg_rounds * tile_rounds;
+      for (int G = 1; G <= 64 && conv_rows_lds(cg, G) <= conv_lds_cap(cg) && G <= B; ++G) {
+        const long long wgs = (B + G - 1) / G, per_cu = (wgs + c->num_cus - 1) / c->num_cus;
+        const long long tiles = ((long long)G * cg.N + 15) / 16, tile_rounds = (tiles + nw - 1) / nw;
+        const long long cost = per_cu * tile_rounds;
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; c->cGs = G; }
       }
     }
