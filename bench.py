@@ -52,6 +52,7 @@ WORKLOADS = {
     'heisenberg10x10_fc3x256_b4096': (10, 10, False, 3, 256, 4096),
     'heisenberg6x6_fc3x128_b1024': (6, 6, False, 3, 128, 1024),
     'heisenberg16x16j1j2_fc6x256_b1024': (16, 16, True, 6, 256, 1024),
+    'heisenberg10x10_fc3x512_b4096': (10, 10, False, 3, 512, 4096),   # > 256 units: general path (wide.hip)
     'heisenberg10x10_conv5x16k5_b4096': (10, 10, False, 5, 16, 4096, 'conv_2d', 5),
     'heisenberg10x10_resnet2x16k5_b4096': (10, 10, False, 2, 16, 4096, 'res_net_2d', 5),
     'heisenberg16x16j1j2_conv5x16k5_b1024': (16, 16, True, 5, 16, 1024, 'conv_2d', 5),

@@ -299,3 +299,20 @@ hipError_t launch_sr_row_linear(hipStream_t s, const float* x, long long ldx, co
                                 const float* vb, int R, int K, float* t);
 hipError_t launch_sr_colsum(hipStream_t s, const float* x, long long ldx, const float* t, int R,
                             int K, float* ws, int slices, float* u, float* tsum);
+
+// fully_connected with fc_layer_size > 256: the general path through materialised rows (wide.hip)
+hipError_t launch_wide_rows_act(hipStream_t s, const float* z1, const float* w1p, const int2* rowinfo,
+                                const int2* bonds, long long row0, int n_rows, int Hp, int act, float* out);
+hipError_t launch_wide_out(hipStream_t s, const float* a, const float* wout, const float* bout, int n_rows,
+                           int H, int Hp, const int2* rowinfo, long long row0, const float* half_jx,
+                           const float* logit_base, int oact, bool ratio, float* out);
+hipError_t launch_wide_propose(hipStream_t s, const float* configs, int B, int N, uint32_t seed_lo,
+                               uint32_t seed_hi, int chain_offset, unsigned long long step, const int* inj_up,
+                               const int* inj_dn, const float* inj_u, int* iup, int* idn, float* u);
+hipError_t launch_wide_build(hipStream_t s, const float* z1, const float* w1p, const int* iup, const int* idn,
+                             int B, int Hp, int act, float* zc, float* a0);
+hipError_t launch_wide_accept(hipStream_t s, float* configs, float* z1, const float* zc, float* logit,
+                              const float* lnew, const int* iup, const int* idn, const float* u, int B, int N,
+                              int Hp, int oact, unsigned long long* accepted, unsigned char* acc_mask);
+hipError_t launch_wide_delta_last(hipStream_t s, const float* a_last, const float* wout, const float* oscale,
+                                  int B, int H, int Hp, int act, float* delta);

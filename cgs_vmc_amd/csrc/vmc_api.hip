@@ -55,6 +55,11 @@ struct vmc_ctx {
   float *ctape = nullptr, *cdelta = nullptr, *cws = nullptr;
   long long ctape_stride = 0, cdelta_stride = 0;
   int c_slices = 64;       // sample slices of the weight-gradient kernel
+  // fully_connected with more than 256 hidden units: general path (wide.hip)
+  bool wide = false;
+  long long wrows = 0;     // rows of the two activation row buffers
+  float *wbuf[2] = {nullptr, nullptr}, *wide_zc = nullptr, *wide_lnew = nullptr, *wide_u = nullptr, *wide_zero = nullptr;
+  int *wide_iup = nullptr, *wide_idn = nullptr;
   int hact = VMC_ACT_RELU_;  // hidden activation (layers.NONLINEARITIES id)
   int oact = VMC_ACT_EXP_;   // output activation; exp: psi = exp(x - shift), else psi = g(x), no shift
   float* oscale = nullptr;   // [B] (1/psi) d psi / d x of a non-exp output activation
@@ -361,6 +366,30 @@ int first_layer(vmc_ctx* c, const ParamSet& p, const float* configs, float* z1, 
   return VMC_OK;
 }
 
+// fc_layer_size > 256: rows {chain, bond} of a row list over the cached z1 -> logits / ratios,
+// `wrows` rows at a time: rank-2 first layer written out, H x H layers as GEMMs, output dot
+int wide_forward(vmc_ctx* c, int which, const float* z1, const int2* rowinfo, long long n_rows, bool ratio,
+                 float* out) {
+  ParamSet& p = c->ps[which];
+  const int H = c->H, Hp = c->Hp, NH = c->n_hh;
+  for (long long row0 = 0; row0 < n_rows; row0 += c->wrows) {
+    const int rows = (int)(n_rows - row0 < c->wrows ? n_rows - row0 : c->wrows);
+    HIPCHK(c, launch_wide_rows_act(c->stream, z1, p.w1p, rowinfo, c->bonds ? c->bonds : c->bond_dummy, row0, rows,
+                                   Hp, c->hact, c->wbuf[0]));
+    for (int l = 1; l <= NH; ++l) {
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.A = c->wbuf[(l - 1) & 1]; g.sam = Hp; g.sak = 1;
+      g.B = p.theta + off_w(c, l); g.sbk = H; g.sbn = 1;
+      g.M = rows; g.N = H; g.K = H; g.C = c->wbuf[l & 1]; g.ldc = Hp;
+      g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1; g.act = c->hact;
+      HIPCHK(c, launch_gemm(c->stream, g));
+    }
+    HIPCHK(c, launch_wide_out(c->stream, c->wbuf[NH & 1], p.woutp, p.bout, rows, H, Hp, rowinfo, row0, c->half_jx,
+                              p.logit, c->oact, ratio, out));
+  }
+  return VMC_OK;
+}
+
 // z1 / logit cache of parameter set `which` for the ctx's chains
 int ensure_cache(vmc_ctx* c, int which) {
   PROPAGATE(ensure_packed(c, which));
@@ -378,7 +407,10 @@ int ensure_cache(vmc_ctx* c, int which) {
     PROPAGATE(first_layer(c, p, c->configs, p.z1, c->B));
     if (c->rbm) HIPCHK(c, launch_onsite(c->stream, c->configs, p.won, c->B, c->N, p.onsite));
   }
-  {
+  if (c->wide) {
+    Timer t(c, "tail_amp");
+    PROPAGATE(wide_forward(c, which, p.z1, c->rowinfo_id, c->B, false, p.logit));
+  } else {
     Timer t(c, "tail_amp");
     TailArgs a = tail_args(c, which);
     a.z1 = p.z1; a.n_rows = c->B; a.out = p.logit; a.rowinfo = c->rowinfo_id;
@@ -413,6 +445,12 @@ int local_energy_device(vmc_ctx* c, int which) {
     Timer t(c, "tail_eloc");
     PROPAGATE(conv_rows(c, which, c->configs, c->rowinfo, (int)((long long)c->B * c->n_bonds), c->off + c->B,
                         true, c->val, false));
+  } else if (c->wide) {
+    Timer t(c, "tail_eloc");
+    int n_rows = 0;      // the GEMM grids need the row count on the host
+    HIPCHK(c, hipMemcpyAsync(&n_rows, c->off + c->B, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    PROPAGATE(wide_forward(c, which, p.z1, c->rowinfo, n_rows, true, c->val));
   } else {
     Timer t(c, "tail_eloc");
     TailArgs a = tail_args(c, which);
@@ -520,9 +558,10 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     return fail(nullptr, VMC_ERR_INVALID, "unknown activation id (layers.NONLINEARITIES has 7 entries)");
   if (rbm && d->output_activation != VMC_ACT_EXP)
     return fail(nullptr, VMC_ERR_INVALID, "the rbm ansatz has no output_activation: it is always exp (wavefunctions.py:419-420)");
-  if (!conv && d->layer_size > 256)
-    return fail(nullptr, VMC_ERR_UNSUPPORTED, "fc_layer_size > 256 not supported by the register-resident kernels");
-  if (!conv) {  // the sampler keeps 16 chains' spins, z1 and operands in LDS (160 KiB per CU)
+  const bool wide = !conv && d->layer_size > 256;
+  if (wide && (rbm || d->nonlinearity == VMC_ACT_COS || d->layer_size > 4096))
+    return fail(nullptr, VMC_ERR_UNSUPPORTED, "fc_layer_size > 256 is supported for fully_connected (any nonlinearity but cos, at most 4096 units)");
+  if (!conv && !wide) {  // the sampler keeps 16 chains' spins, z1 and operands in LDS (160 KiB per CU)
     const int hp = (d->layer_size + 63) / 64 * 64;
     const int n_hh = rbm ? d->num_layers : d->num_layers - 1;
     const size_t need = sweep_lds_required(d->n_sites, hp, n_hh, rbm);
@@ -548,6 +587,8 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   c->rbm = rbm;
   c->conv = conv; c->cg = cg;
   if (conv) { c->L = 1; c->Hp = 64; c->overlap = false; }   // minimal dense-side shapes (unused)
+  c->wide = wide;
+  if (wide) c->overlap = false;
   c->hact = d->nonlinearity; c->oact = d->output_activation;
   c->lay = make_layout(rbm, c->N, c->H, c->L);
   c->n_hh = c->lay.n_hh; c->A = c->n_hh + 1;
@@ -555,7 +596,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
               : vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
   c->stream = (hipStream_t)d->stream;
   if (const char* e = getenv("CGS_VMC_SWEEP_W1L")) c->sweep_no_w1l = atoi(e) == 0 ? 1 : 0;
-  if (const char* e = getenv("CGS_VMC_OVERLAP")) { c->overlap = !conv && atoi(e) != 0; c->overlap_full = atoi(e) == 2; }
+  if (const char* e = getenv("CGS_VMC_OVERLAP")) { c->overlap = !conv && !wide && atoi(e) != 0; c->overlap_full = atoi(e) == 2; }
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -621,6 +662,13 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(dalloc(&c->rowinfo_id, B)); CA(launch_iota_rows(c->stream, c->rowinfo_id, (int)B));
   CA(dalloc(&c->bond_dummy, 1)); CA(hipMemsetAsync(c->bond_dummy, 0, sizeof(int2), c->stream));
   CA(dalloc(&c->offdiag, B));
+  if (wide) {
+    c->wrows = B > 131072 ? B : 131072;
+    CA(dalloc(&c->wbuf[0], c->wrows * Hp)); CA(dalloc(&c->wbuf[1], c->wrows * Hp));
+    CA(dalloc(&c->wide_zc, B * Hp)); CA(dalloc(&c->wide_lnew, B)); CA(dalloc(&c->wide_u, B));
+    CA(dalloc(&c->wide_iup, B)); CA(dalloc(&c->wide_idn, B)); CA(dalloc(&c->wide_zero, Hp));
+    CA(hipMemsetAsync(c->wide_zero, 0, Hp * sizeof(float), c->stream));
+  }
   if (conv) {
     const long long KK = (long long)cg.K * cg.K, nl = cg.n_conv > 1 ? cg.n_conv - 1 : 1;
     for (int w = 0; w < 2; ++w) {
@@ -669,7 +717,9 @@ void vmc_destroy(vmc_ctx* c) {
   }
   if (c->act_all) hipFree(c->act_all);
   if (c->act_alt) hipFree(c->act_alt);
-  for (float* q : {c->oscale, c->dact_all, c->dact_alt, c->ctape, c->cdelta, c->cws}) if (q) hipFree(q);
+  for (float* q : {c->oscale, c->dact_all, c->dact_alt, c->ctape, c->cdelta, c->cws, c->wbuf[0], c->wbuf[1],
+                   c->wide_zc, c->wide_lnew, c->wide_u, c->wide_zero}) if (q) hipFree(q);
+  for (int* q : {c->wide_iup, c->wide_idn}) if (q) hipFree(q);
   void* ptrs[] = {c->configs, c->configs_alt, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->d_accepted, c->d_sum,
@@ -796,6 +846,9 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
     ParamSet& p = c->ps[which];
     if (c->conv) {
       PROPAGATE(conv_rows(c, which, c->tmp_cfg, c->tmp_rowinfo, (int)n_rows, nullptr, false, c->tmp_out, false));
+    } else if (c->wide) {
+      PROPAGATE(first_layer(c, p, c->tmp_cfg, c->tmp_z1, (int)n_rows));
+      PROPAGATE(wide_forward(c, which, c->tmp_z1, c->tmp_rowinfo, n_rows, false, c->tmp_out));
     } else {
       PROPAGATE(first_layer(c, p, c->tmp_cfg, c->tmp_z1, (int)n_rows));
       if (c->rbm) HIPCHK(c, launch_onsite(c->stream, c->tmp_cfg, p.won, (int)n_rows, c->N, c->tmp_on));
@@ -817,10 +870,56 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
 
 // One sampler launch: reads the current chain buffers, writes the alternate set, swaps.
 //   overtake: the launch goes to sweep_stream and only waits for `dep` (an event on `stream`)
+// fc_layer_size > 256: one mc_step = proposals, candidate first layer, H x H GEMMs, output dot,
+// accept -- a handful of launches per step, chain state updated in place
+static int run_sweep_wide(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int* dbg_up, int* dbg_dn,
+                          float* dbg_u, unsigned long long step0, bool count_accepted) {
+  ParamSet& p = c->ps[0];
+  const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, NH = c->n_hh;
+  const uint32_t seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull), seed_hi = (uint32_t)(c->d.seed >> 32);
+  if (dbg) {
+    HIPCHK(c, launch_wide_propose(c->stream, c->configs, B, N, seed_lo, seed_hi, c->d.chain_offset, step0, nullptr,
+                                  nullptr, nullptr, dbg_up, dbg_dn, dbg_u));
+    return VMC_OK;
+  }
+  PROPAGATE(ensure_cache(c, VMC_PSI));
+  if (count_accepted) HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), c->stream));
+  Timer t(c, "sweep");
+  for (long long st = 0; st < n_steps; ++st) {
+    if (st > 0 && st % 128 == 0) {   // z1 is updated incrementally: re-derive it from the spins now and then
+      p.cache_valid = false;
+      PROPAGATE(ensure_cache(c, VMC_PSI));
+    }
+    HIPCHK(c, launch_wide_propose(c->stream, c->configs, B, N, seed_lo, seed_hi, c->d.chain_offset,
+                                  step0 + (unsigned long long)st, injected ? c->inj_up : nullptr,
+                                  injected ? c->inj_dn : nullptr, injected ? c->inj_u : nullptr, c->wide_iup,
+                                  c->wide_idn, c->wide_u));
+    HIPCHK(c, launch_wide_build(c->stream, p.z1, p.w1p, c->wide_iup, c->wide_idn, B, Hp, c->hact, c->wide_zc,
+                                c->wbuf[0]));
+    for (int l = 1; l <= NH; ++l) {
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.A = c->wbuf[(l - 1) & 1]; g.sam = Hp; g.sak = 1;
+      g.B = p.theta + off_w(c, l); g.sbk = H; g.sbn = 1;
+      g.M = B; g.N = H; g.K = H; g.C = c->wbuf[l & 1]; g.ldc = Hp;
+      g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1; g.act = c->hact;
+      HIPCHK(c, launch_gemm(c->stream, g));
+    }
+    HIPCHK(c, launch_wide_out(c->stream, c->wbuf[NH & 1], p.woutp, p.bout, B, H, Hp, c->rowinfo_id, 0, c->half_jx,
+                              p.logit, c->oact, false, c->wide_lnew));
+    HIPCHK(c, launch_wide_accept(c->stream, c->configs, p.z1, c->wide_zc, p.logit, c->wide_lnew, c->wide_iup,
+                                 c->wide_idn, c->wide_u, B, N, Hp, c->oact, c->d_accepted,
+                                 injected ? c->acc_mask : nullptr));
+  }
+  c->acts_valid = false;
+  c->acc_since_sweep = false;
+  return VMC_OK;
+}
+
 static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int* dbg_up, int* dbg_dn,
                      float* dbg_u, unsigned long long step0, bool count_accepted = false,
                      bool overtake = false, hipEvent_t dep = nullptr) {
   PROPAGATE(ensure_packed(c, 0));
+  if (c->wide) return run_sweep_wide(c, n_steps, injected, dbg, dbg_up, dbg_dn, dbg_u, step0, count_accepted);
   ParamSet& p = c->ps[0];
   SweepArgs a;
   memset(&a, 0, sizeof(a));
@@ -898,7 +997,8 @@ int vmc_mc_steps(vmc_ctx* c, int64_t n_steps, int64_t* accepted) {
   PROPAGATE(run_sweep(c, n_steps, false, false, nullptr, nullptr, nullptr, c->step, accepted != nullptr,
                       overtake, dep));
   c->step += (unsigned long long)n_steps;
-  c->ps[0].cache_valid = true;   // the sweep kernel writes back an exact z1/logit cache
+  c->ps[0].cache_valid = !c->wide;   // the sweep kernel writes back an exact z1/logit cache (the general
+                                     // wide path keeps an incrementally updated one: recomputed on demand)
   c->ps[1].cache_valid = false;
   c->list_valid = false;
   if (accepted) {
@@ -921,7 +1021,7 @@ int vmc_mc_step_injected(vmc_ctx* c, const int32_t* i_up, const int32_t* i_dn, c
   HIPCHK(c, hipMemcpyAsync(c->inj_dn, i_dn, c->B * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->inj_u, u, c->B * sizeof(float), hipMemcpyHostToDevice, c->stream));
   PROPAGATE(run_sweep(c, 1, true, false, nullptr, nullptr, nullptr, c->step));
-  c->ps[0].cache_valid = true; c->ps[1].cache_valid = false; c->list_valid = false;
+  c->ps[0].cache_valid = !c->wide; c->ps[1].cache_valid = false; c->list_valid = false;
   if (accept_mask)
     HIPCHK(c, hipMemcpyAsync(accept_mask, c->acc_mask, c->B, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -942,7 +1042,7 @@ int vmc_debug_proposals(vmc_ctx* c, uint64_t step, int32_t* i_up, int32_t* i_dn,
 int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   ENTER(c);
   if (n_steps < 1 || !phase_cycles) return fail(c, VMC_ERR_INVALID, "bad arguments");
-  if (c->rbm || c->conv) return fail(c, VMC_ERR_UNSUPPORTED, "the diagnostic sweep build exists for fully_connected only");
+  if (c->rbm || c->conv || c->wide) return fail(c, VMC_ERR_UNSUPPORTED, "the diagnostic sweep build exists for fully_connected (<= 256 units) only");
   PROPAGATE(ensure_packed(c, 0));
   const int grid = (c->B + 15) / 16;
   unsigned long long* d = nullptr;
@@ -1055,6 +1155,19 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
   // back-propagation of d logit / d z_l: FC delta[NH] = w_out (.) relu'; RBM delta[NH] = tanh(z)
   // (which IS act[NH]); then the W_l^T chain through the relu masks -- one launch, 16 chains per
   // workgroup, transposed weight fragments on 16x16x4 MFMA (k_backprop16)
+  if (c->wide) {
+    // delta_NH = w_out (.) f'(z_NH); delta_{l-1} = f'(z_{l-1}) (.) (delta_l W_l^T) on the generic GEMM
+    HIPCHK(c, launch_wide_delta_last(c->stream, c->act[NH], p.woutp, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr,
+                                     B, H, Hp, c->hact, c->delta[NH]));
+    for (int l = NH; l >= 1; --l) {
+      GemmArgs g; memset(&g, 0, sizeof(g));
+      g.A = c->delta[l]; g.sam = Hp; g.sak = 1;
+      g.B = p.theta + off_w(c, l); g.sbk = 1; g.sbn = H;          // B(k = out, n = in) = W_l[in][out]
+      g.M = B; g.N = H; g.K = H; g.C = c->delta[l - 1]; g.ldc = Hp;
+      g.bias = c->wide_zero; g.mask = c->act[l - 1]; g.ldmask = Hp; g.epilogue = 5; g.splitk = 1; g.act = c->hact;
+      HIPCHK(c, launch_gemm(c->stream, g));
+    }
+  } else
   HIPCHK(c, launch_backprop16(c->stream, c->act_all, c->delta_all, p.p16t, p.woutp, B, Hp, NH, c->rbm, c->hact,
                               c->dact_all, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr));
   // Every weight-gradient GEMM is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows 0..K_in-1
@@ -1296,8 +1409,8 @@ int vmc_epoch_log_overlap(vmc_ctx* c, float beta, int64_t n_eq_steps, int32_t n_
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   ENTER(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
-  if (n_batches > 0 && c->conv)
-    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the fully_connected and rbm ansatz types");
+  if (n_batches > 0 && (c->conv || c->wide))
+    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the fully_connected (<= 256 units) and rbm ansatz types");
   if (n_batches > 0 && (c->oact != VMC_ACT_EXP_ || c->hact == VMC_ACT_COS_))
     return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation and every hidden activation except cos");
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -1,0 +1,133 @@
+"""GPU parity of fully_connected with fc_layer_size > 256 (utils.py:105 allows any size): the
+general path of csrc/wide.hip (materialised rows + the library's fp32-MFMA GEMM, a few launches per
+mc_step) against the numpy oracle, through the C ABI.  Tolerances as tests/test_gpu_engine.py:
+logits 2e-5 * max(1, |logit|), local energies 2e-4 * max(1, |E|), gradient sums
+2e-3 * ||.||_inf + 1e-4, accept masks bit-exact outside |ratio - sqrt(u)| < 1e-4 ratio, proposals
+bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import vmc_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+WIDE_SHAPES = [
+    # n_sites, H, num_layers, B, bonds, nonlinearity
+    (16, 320, 2, 40, 'torus4x4', 'relu'),
+    (36, 512, 3, 64, 'torus6x6', 'relu'),
+    (12, 300, 1, 23, 'chain', 'tanh'),        # no H x H layer, H not a multiple of 64
+    (20, 264, 2, 17, 'chain', 'sigmoid'),
+]
+
+
+def _bonds(kind, n):
+  if kind == 'chain':
+    return vo.chain_bonds(n)
+  lx = int(kind[5:].split('x')[0])
+  return vo.torus_bonds(lx, n // lx)
+
+
+def _make(n, h, L, b, kind, nonlin, seed=0):
+  from cgs_vmc_amd.engine import VmcEngine
+  rng = np.random.default_rng(seed)
+  theta = vo.init_params(n, h, L, rng)
+  theta += (0.02 * rng.standard_normal(theta.size)).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(seed + 1))
+  bonds = _bonds(kind, n)
+  eng = VmcEngine(n, b, L, h, nonlinearity=nonlin, seed=2024)
+  assert eng.num_params == theta.size
+  eng.set_params(theta); eng.set_configs(cfg); eng.set_bonds(bonds, -1.0, 1.0)
+  return eng, theta, cfg, bonds
+
+
+def _close(a, b, rel, floor=1.0):
+  a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+  tol = rel * np.maximum(floor, np.abs(b))
+  assert (np.abs(a - b) <= tol).all(), 'max err {} (tol {})'.format(np.abs(a - b).max(), tol.min())
+
+
+@pytest.mark.parametrize('n,h,L,b,kind,nonlin', WIDE_SHAPES)
+def test_wide_amplitude_local_energy_and_sampler(n, h, L, b, kind, nonlin):
+  eng, theta, cfg, bonds = _make(n, h, L, b, kind, nonlin)
+  logit_ref = lambda c: vo.fc_logit(theta, c, h, L, nonlinearity=nonlin, dtype=np.float64)
+  amp = lambda c: vo.fc_psi(theta, c, h, L, nonlinearity=nonlin, dtype=np.float64)
+  _close(eng.amplitude(cfg)[0], logit_ref(cfg), 2e-5)
+  _close(eng.amplitude()[0], logit_ref(cfg), 2e-5)
+  for jx in (-1.0, 1.0):
+    eng.set_bonds(bonds, jx, 1.0)
+    _close(eng.local_energy()[0], vo.local_value(amp, cfg, bonds, jx, 1.0, dtype=np.float64), 2e-4)
+  u_sites, u_acc = vo.step_uniforms(2024, np.arange(b), 5, n)
+  i_up, i_dn = vo.propose_exchange(cfg, u_sites)
+  g_up, g_dn, g_u = eng.debug_proposals(5)
+  np.testing.assert_array_equal(g_up, i_up); np.testing.assert_array_equal(g_dn, i_dn)
+  np.testing.assert_array_equal(g_u, u_acc)
+  cur = cfg
+  for step in range(3):
+    u_sites, u_acc = vo.step_uniforms(99, np.arange(b), step, n)
+    i_up, i_dn = vo.propose_exchange(cur, u_sites)
+    _, acc_ref, ratios = vo.mc_step(amp, cur, i_up, i_dn, u_acc)
+    mask = eng.mc_step_injected(i_up, i_dn, u_acc)
+    band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
+    assert np.array_equal(mask[~band], acc_ref[~band])
+    expect = cur.copy()
+    rows = np.arange(b)[mask]
+    expect[rows, i_dn[mask]] = 1.0
+    expect[rows, i_up[mask]] = -1.0
+    got = eng.get_configs()
+    np.testing.assert_array_equal(got, expect)
+    cur = got
+    _close(eng.amplitude()[0], logit_ref(cur), 2e-5)
+  eng.step_counter = 0
+  ok = np.ones(b, bool)
+  ref = cur.copy()
+  for step in range(8):
+    u_sites, u_acc = vo.step_uniforms(2024, np.arange(b), step, n)
+    i_up, i_dn = vo.propose_exchange(ref, u_sites)
+    ref, acc, ratios = vo.mc_step(amp, ref, i_up, i_dn, u_acc)
+    ok &= ~(np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30))
+  accepted = eng.mc_steps(8)
+  got = eng.get_configs()
+  np.testing.assert_array_equal(got[ok], ref[ok])
+  assert ok.sum() > b // 2 and 0 <= accepted <= 8 * b
+  _close(eng.local_energy()[0], vo.local_value(amp, got, bonds, 1.0, 1.0, dtype=np.float64), 2e-4)
+  eng.close()
+
+
+@pytest.mark.parametrize('n,h,L,b,kind,nonlin', WIDE_SHAPES)
+def test_wide_energy_gradient_accumulators(n, h, L, b, kind, nonlin):
+  from cgs_vmc_amd import _hip
+  eng, theta, cfg, bonds = _make(n, h, L, b, kind, nonlin)
+  acc = vo.Accumulators(theta.size, np.float64)
+  eng.reset_accumulators()
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, h, L, np.float64,
+                                nonlinearity=nonlin)
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  eng.mc_steps(3)
+  cur = eng.get_configs()
+  vo.energy_gradient_accumulate(acc, theta, cur, bonds, -1.0, 1.0, -10.0, h, L, np.float64,
+                                nonlinearity=nonlin)
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  got = eng.get_accumulators()
+  p = theta.size
+  for name, g, r in (('g1', got[:p], acc.g1_total), ('g2', got[p:2 * p], acc.g2_total)):
+    tol = 2e-3 * np.abs(r).max() + 1e-4
+    assert np.abs(g - r).max() < tol, (name, np.abs(g - r).max(), tol)
+  grad_ref = vo.energy_gradient(acc)
+  grad = eng.get_gradient(_hip.VMC_MODE_ENERGY_GRADIENT)
+  assert np.abs(grad - grad_ref).max() < 2e-3 * np.abs(grad_ref).max() + 2e-4
+  eng.apply_adam(_hip.VMC_MODE_ENERGY_GRADIENT, 1e-3, 0.9, 0.99, 1e-8)
+  th = eng.get_params()
+  _close(eng.amplitude()[0], vo.fc_logit(th, cur, h, L, nonlinearity=nonlin, dtype=np.float64), 2e-5)
+  eng.close()
+
+
+def test_wide_limits():
+  from cgs_vmc_amd.engine import VmcEngine
+  with pytest.raises(NotImplementedError):
+    VmcEngine(16, 8, 2, 320, ansatz='rbm')
+  with pytest.raises(NotImplementedError):
+    VmcEngine(16, 8, 2, 320, nonlinearity='cos')
+  eng = VmcEngine(16, 8, 2, 320)
+  with pytest.raises(NotImplementedError):
+    eng.sr_reserve(2)
+  eng.close()
