@@ -10,6 +10,7 @@
 // register r, which is the layout the next layer reads, so the epilogue is one ds_write_b128.
 // Feature maps of the G samples a workgroup has in flight never leave LDS between layers.
 #include "conv.hpp"
+#include <cstdlib>
 #include <type_traits>
 
 // 4 waves per workgroup (one per SIMD) and two workgroups per CU: the two co-resident workgroups are
@@ -754,6 +755,8 @@ hipError_t launch_k(Kern kern, dim3 grid, size_t lds, hipStream_t s, const Args&
 
 // LDS budget of one workgroup: half a CU when a sample's feature maps allow two workgroups per CU
 size_t conv_lds_cap(const ConvGeom& g) {
+  static const int one_per_cu = getenv("CGS_VMC_CONV_WG_PER_CU") ? atoi(getenv("CGS_VMC_CONV_WG_PER_CU")) == 1 : 0;
+  if (one_per_cu) return (size_t)160 * 1024;      // experiment: one workgroup with twice the samples
   return conv_rows_lds(g, 1) <= CONV_LDS_PER_WG ? (size_t)CONV_LDS_PER_WG : (size_t)160 * 1024;
 }
 int conv_waves() { return CONV_WAVES; }

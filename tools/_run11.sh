@@ -1,7 +1,8 @@
 set -e
 cd /root/repo
-bash tools/collect_profiles.sh r2 heisenberg10x10_fc3x256_b4096 > gpurun_out/collect_r2.log 2>&1
-bash tools/collect_profiles.sh r2_config5 heisenberg16x16j1j2_fc6x256_b1024 > gpurun_out/collect_r2_config5.log 2>&1
+mkdir -p gpurun_out
 bash tools/collect_profiles.sh r2_conv heisenberg10x10_conv5x16k5_b4096 > gpurun_out/collect_r2_conv.log 2>&1
 bash tools/collect_profiles.sh r2_conv16 heisenberg16x16j1j2_conv5x16k5_b1024 > gpurun_out/collect_r2_conv16.log 2>&1
+timeout -k 10 300 python bench.py --workload heisenberg10x10_resnet2x16k5_b4096 --steps 20 --warmup 2 > gpurun_out/bench_resnet.json 2> gpurun_out/bench_resnet.err
+timeout -k 10 300 python bench.py --workload heisenberg10x10_fc3x512_b4096 --steps 5 --warmup 1 --reps 3 --no-cpu-baseline > gpurun_out/bench_wide.json 2> gpurun_out/bench_wide.err
 ls gpurun_out/*_summary
