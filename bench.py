@@ -455,7 +455,7 @@ def main():
                   'step_frac = executed flops of the whole step / ms_per_step / peak.',
           'per_kernel': per_kernel,
       }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
       try:
         out['cpu_baseline'] = cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg, ansatz, ksz, lx, ly)
       except Exception as e:  # pylint: disable=broad-except
