@@ -68,8 +68,8 @@ struct ConvSmem {
   int* row_chain;   // [G] chain (or row) of each slot, -1 = empty
   float* red;       // [G] reduced logits
   // periodic neighbour tables, built once per kernel (the wrap arithmetic costs ~15 VALU
-  // instructions per tap column / row and tile otherwise): rtab[dir][a1][d] = 4 D2 ((a1 + d - lo)
-  // mod D1), ctab[dir][a2][d] = 4 ((a2 + d - lo) mod D2) in floats, lo = g.lo (dir 0: forward) or
+  // instructions per tap column / row and tile otherwise): rtab[dir][a1][d] = 16 D2 ((a1 + d - lo)
+  // mod D1), ctab[dir][a2][d] = 16 ((a2 + d - lo) mod D2) in bytes (one v_add3 per tap and tile), lo = g.lo (dir 0: forward) or
   // g.hi (dir 1: transposed convolution); rows of 8 ints
   int* rtab;        // [2][D1][8]
   int* ctab;        // [2][D2][8]
@@ -107,7 +107,7 @@ __device__ __forceinline__ void conv_build_pinfo(const ConvSmem& sm, const ConvG
     const int j = is_r ? i : i - 2 * g.D1 * 8, D = is_r ? g.D1 : g.D2;
     const int dir = j / (D * 8), a = (j / 8) % D, d = j & 7;
     const int w = wrap(a + min(d, g.K - 1) - (dir ? g.hi : g.lo), D);
-    (is_r ? sm.rtab : sm.ctab)[j] = is_r ? 4 * g.D2 * w : 4 * w;
+    (is_r ? sm.rtab : sm.ctab)[j] = is_r ? 16 * g.D2 * w : 16 * w;     // byte offsets
   }
 }
 
@@ -142,7 +142,7 @@ __device__ __forceinline__ void conv_first(const ConvSmem& sm, float* out, const
     f32x4 acc = bias;
     float bx[Q0];
 #pragma unroll
-    for (int qq = 0; qq < Q0; ++qq) bx[qq] = xs[(sm.rtab[a1 * 8 + d1[qq]] + sm.ctab[a2 * 8 + d2[qq]]) >> 2];
+    for (int qq = 0; qq < Q0; ++qq) bx[qq] = xs[(sm.rtab[a1 * 8 + d1[qq]] + sm.ctab[a2 * 8 + d2[qq]]) >> 4];
 #pragma unroll
     for (int qq = 0; qq < Q0; ++qq) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[qq], bx[qq], acc, 0, 0, 0);
     if (ep == EP_ACT) {
@@ -179,7 +179,7 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
   auto tiles = [&](int t0, auto nt_c) {
     constexpr int NTL = decltype(nt_c)::value;
     bool valid[NTL]; int a1[NTL], a2[NTL], sl[NTL];
-    const float* base[NTL];
+    const char* base[NTL];
     int roff[NTL][K], coff[NTL][K];
 #pragma unroll
     for (int h = 0; h < NTL; ++h) {
@@ -187,7 +187,7 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
       valid[h] = q < n_pos;
       const unsigned info = sm.pinfo[valid[h] ? q : n_pos - 1];
       a2[h] = info & 1023; a1[h] = (info >> 10) & 1023; sl[h] = info >> 20;
-      base[h] = in + (size_t)sl[h] * 4 * g.GS + gl * g.GS;
+      base[h] = (const char*)(in + (size_t)sl[h] * 4 * g.GS + gl * g.GS);
       const int* rt = sm.rtab + (dir * g.D1 + a1[h]) * 8;
       const int* ct = sm.ctab + (dir * g.D2 + a2[h]) * 8;
 #pragma unroll
@@ -224,7 +224,7 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
       const int site = a1[h] * g.D2 + a2[h];
       float* dst = out + (size_t)sl[h] * 4 * g.GS + gl * g.GS + 4 * site;
       const int row = sm.row_chain[sl[h]];
-      const long long trow = ((long long)(row >= 0 ? row : 0) * 4 + gl) * g.GS + 4 * site;
+      const unsigned trow = (unsigned)((row >= 0 ? row : 0) * 4 + gl) * (unsigned)g.GS + 4u * site;   // < 2^31: checked on the host
       f32x4 v = acc[h];
       if (ep == EP_ACT) {
 #pragma unroll

@@ -551,6 +551,8 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     cg.GS = (4 * cg.N + 63) / 64 * 64;
     cg.lo = (cg.K - 1) / 2; cg.hi = cg.K / 2;
     if (cg.n_conv > CONV_MAX_LAYERS) return fail(nullptr, VMC_ERR_UNSUPPORTED, "too many convolutions");
+    if ((long long)d->batch_size * 4 * cg.GS >= (1LL << 31))
+      return fail(nullptr, VMC_ERR_UNSUPPORTED, "batch_size x lattice too large for the 32-bit tape offsets of the convolution kernels");
     if (conv_rows_lds(cg, 1) > 160 * 1024)
       return fail(nullptr, VMC_ERR_UNSUPPORTED, "lattice too large: the feature maps of one sample must fit the 160 KiB of LDS");
   }

@@ -11,7 +11,7 @@ def summarise(path):
   dur = defaultdict(dict)
   for f in glob.glob(path + '/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-      k = r['Kernel_Name'].split('(')[0]
+      k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0]
       per[k][r['Counter_Name']].append(float(r['Counter_Value']))
       dur[k][r['Dispatch_Id']] = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
   return per, dur
