@@ -21,8 +21,8 @@ VMC_ERR_STATE = -4
 VMC_PSI, VMC_OMEGA = 0, 1
 VMC_MODE_ENERGY_GRADIENT, VMC_MODE_LOG_OVERLAP_ITSWO = 0, 1
 # wavefunctions.WAVEFUNCTION_TYPES with kernels (cgsvmc.h VMC_ANSATZ_*)
-ANSATZ_IDS = {'fully_connected': 0, 'rbm': 1, 'conv_2d': 2, 'res_net_2d': 3}
-CONV_ANSATZ = ('conv_2d', 'res_net_2d')
+ANSATZ_IDS = {'fully_connected': 0, 'rbm': 1, 'conv_2d': 2, 'res_net_2d': 3, 'conv_1d': 4, 'res_net_1d': 5}
+CONV_ANSATZ = ('conv_2d', 'res_net_2d', 'conv_1d', 'res_net_1d')
 # layers.NONLINEARITIES ids (cgsvmc.h)
 ACT_IDS = {'relu': 0, 'exp': 1, 'cos': 2, 'tan': 3, 'tanh': 4, 'sigmoid': 5, 'identity': 6}
 

@@ -106,18 +106,19 @@ __device__ __forceinline__ void conv_build_pinfo(const ConvSmem& sm, const ConvG
     const bool is_r = i < 2 * g.D1 * 8;
     const int j = is_r ? i : i - 2 * g.D1 * 8, D = is_r ? g.D1 : g.D2;
     const int dir = j / (D * 8), a = (j / 8) % D, d = j & 7;
-    const int w = wrap(a + min(d, g.K - 1) - (dir ? g.hi : g.lo), D);
+    const int lo = is_r ? (dir ? g.hi : g.lo) : (dir ? g.hi2 : g.lo2);
+    const int w = ((a + min(d, (is_r ? g.K : g.KW) - 1) - lo) % D + D) % D;
     (is_r ? sm.rtab : sm.ctab)[j] = is_r ? 16 * g.D2 * w : 16 * w;     // byte offsets
   }
 }
 
 // First convolution (one input channel, layers.py:151-160 on the reshaped spins): the k index of
 // the MFMA runs over the taps, four per instruction.
-template <int K>
+template <int K, int KW>
 __device__ __forceinline__ void conv_first(const ConvSmem& sm, float* out, const ConvGeom& g,
                                            const ConvParams& p, int G, int ep, int wave, int lane,
                                            float* tape_out, long long tape_rows) {
-  constexpr int Q0 = (K * K + 3) / 4;
+  constexpr int Q0 = (K * KW + 3) / 4;
   const int pl = lane & 15, gl = lane >> 4;
   float w0[Q0];
 #pragma unroll
@@ -129,9 +130,9 @@ __device__ __forceinline__ void conv_first(const ConvSmem& sm, float* out, const
 #pragma unroll
   for (int q = 0; q < Q0; ++q) {
     int tap = 4 * q + gl;
-    tap = tap < K * K ? tap : 0;          // the weight of a tap beyond K*K is zero
-    d1[q] = tap / K;
-    d2[q] = tap % K;
+    tap = tap < K * KW ? tap : 0;         // the weight of a tap beyond K*KW is zero
+    d1[q] = tap / KW;
+    d2[q] = tap % KW;
   }
   for (int t = wave; t < n_tiles; t += CONV_WAVES) {
     const int q = t * 16 + pl;
@@ -162,15 +163,15 @@ __device__ __forceinline__ void conv_first(const ConvSmem& sm, float* out, const
 
 // One 16-channel convolution over the G resident samples: in -> out (LDS).  `wfrag` is the layer's
 // fragment image ([K*K][64] f32x4, forward or transposed), `lo` the padding in front.
-template <int K>
+template <int K, int KW>
 __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, float* out,
                                            const ConvGeom& g, const float* wfrag, const float* bias16,
                                            int dir, int G, int ep, int wave, int lane,
                                            const float* tape_in, float* tape_out) {
   const int pl = lane & 15, gl = lane >> 4;
-  f32x4 w[K * K];
+  f32x4 w[K * KW];
 #pragma unroll
-  for (int t = 0; t < K * K; ++t) w[t] = *(const f32x4*)(wfrag + ((size_t)t * 64 + lane) * 4);
+  for (int t = 0; t < K * KW; ++t) w[t] = *(const f32x4*)(wfrag + ((size_t)t * 64 + lane) * 4);
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
   if (bias16) bias = *(const f32x4*)(bias16 + 4 * gl);
   const int n_pos = G * g.N, n_tiles = (n_pos + 15) >> 4;
@@ -180,7 +181,7 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
     constexpr int NTL = decltype(nt_c)::value;
     bool valid[NTL]; int a1[NTL], a2[NTL], sl[NTL];
     const char* base[NTL];
-    int roff[NTL][K], coff[NTL][K];
+    int roff[NTL][K], coff[NTL][KW];
 #pragma unroll
     for (int h = 0; h < NTL; ++h) {
       const int q = (t0 + h) * 16 + pl;
@@ -191,7 +192,9 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
       const int* rt = sm.rtab + (dir * g.D1 + a1[h]) * 8;
       const int* ct = sm.ctab + (dir * g.D2 + a2[h]) * 8;
 #pragma unroll
-      for (int d = 0; d < K; ++d) { roff[h][d] = rt[d]; coff[h][d] = ct[d]; }
+      for (int d = 0; d < K; ++d) roff[h][d] = rt[d];
+#pragma unroll
+      for (int d = 0; d < KW; ++d) coff[h][d] = ct[d];
     }
     f32x4 acc[NTL];
 #pragma unroll
@@ -203,14 +206,14 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
 #pragma unroll
     for (int h = 0; h < NTL; ++h) {
       bq[h][0] = *(const f32x4*)(base[h] + roff[h][0] + coff[h][0]);
-      if (K * K > 1) bq[h][1] = *(const f32x4*)(base[h] + roff[h][K > 1 ? 1 / K : 0] + coff[h][K > 1 ? 1 % K : 0]);
+      if (K * KW > 1) bq[h][1] = *(const f32x4*)(base[h] + roff[h][K * KW > 1 ? 1 / KW : 0] + coff[h][K * KW > 1 ? 1 % KW : 0]);
     }
 #pragma unroll
-    for (int tap = 0; tap < K * K; ++tap) {
-      if (tap + 2 < K * K) {
+    for (int tap = 0; tap < K * KW; ++tap) {
+      if (tap + 2 < K * KW) {
 #pragma unroll
         for (int h = 0; h < NTL; ++h)
-          bq[h][(tap + 2) % 3] = *(const f32x4*)(base[h] + roff[h][(tap + 2) / K] + coff[h][(tap + 2) % K]);
+          bq[h][(tap + 2) % 3] = *(const f32x4*)(base[h] + roff[h][(tap + 2) / KW] + coff[h][(tap + 2) % KW]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -256,20 +259,20 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
 
 // Whole forward of the G resident samples: spins (sm.xs) -> sm.red[s] = sum over sites and
 // channels of the last feature map (wavefunctions.py:569, 760).  Barriers inside.
-template <int K>
+template <int K, int KW>
 __device__ __forceinline__ void conv_forward(const ConvSmem& sm, const ConvGeom& g,
                                              const ConvParams& p, int G, int wave, int lane,
                                              float* tape, long long tape_stride) {
   float* last;
   if (!g.resnet) {
     // [Conv2dPeriodic, nonlinearity] x (n-1), Conv2dPeriodic            (wavefunctions.py:572-575)
-    conv_first<K>(sm, sm.buf0, g, p, G, g.n_conv > 1 ? EP_ACT : EP_LINEAR, wave, lane,
+    conv_first<K, KW>(sm, sm.buf0, g, p, G, g.n_conv > 1 ? EP_ACT : EP_LINEAR, wave, lane,
                   (tape && g.n_conv > 1) ? tape : nullptr, 0);
     __syncthreads();
     float* in = sm.buf0; float* out = sm.buf1;
     for (int l = 1; l < g.n_conv; ++l) {
       const bool is_last = l + 1 == g.n_conv;
-      conv_layer<K>(sm, in, out, g, p.wf + (size_t)(l - 1) * K * K * 256, p.bias + 16 * l, 0, G,
+      conv_layer<K, KW>(sm, in, out, g, p.wf + (size_t)(l - 1) * K * KW * 256, p.bias + 16 * l, 0, G,
                     is_last ? EP_LINEAR : EP_ACT, wave, lane, nullptr,
                     (tape && !is_last) ? tape + (long long)l * tape_stride : nullptr);
       __syncthreads();
@@ -279,14 +282,14 @@ __device__ __forceinline__ void conv_forward(const ConvSmem& sm, const ConvGeom&
   } else {
     // initial_conv, then blocks h <- h + conv2(selu(conv1(h)))          (wavefunctions.py:766-772)
     // tape slot l-1 holds the input of convolution l: h before block k at slot 2k, selu(..) at 2k+1
-    conv_first<K>(sm, sm.buf0, g, p, G, EP_LINEAR, wave, lane, g.n_conv > 1 ? tape : nullptr, 0);
+    conv_first<K, KW>(sm, sm.buf0, g, p, G, EP_LINEAR, wave, lane, g.n_conv > 1 ? tape : nullptr, 0);
     __syncthreads();
     for (int l = 1; l + 1 < g.n_conv; l += 2) {
-      conv_layer<K>(sm, sm.buf0, sm.buf1, g, p.wf + (size_t)(l - 1) * K * K * 256, p.bias + 16 * l,
+      conv_layer<K, KW>(sm, sm.buf0, sm.buf1, g, p.wf + (size_t)(l - 1) * K * KW * 256, p.bias + 16 * l,
                     0, G, EP_SELU, wave, lane, nullptr,
                     tape ? tape + (long long)l * tape_stride : nullptr);
       __syncthreads();
-      conv_layer<K>(sm, sm.buf1, sm.buf0, g, p.wf + (size_t)l * K * K * 256, p.bias + 16 * (l + 1),
+      conv_layer<K, KW>(sm, sm.buf1, sm.buf0, g, p.wf + (size_t)l * K * KW * 256, p.bias + 16 * (l + 1),
                     0, G, EP_RESADD, wave, lane, nullptr,
                     (tape && l + 2 < g.n_conv) ? tape + (long long)(l + 1) * tape_stride : nullptr);
       __syncthreads();
@@ -310,7 +313,7 @@ __device__ __forceinline__ void conv_forward(const ConvSmem& sm, const ConvGeom&
 // Amplitudes of a list of rows {chain, bond}: the chain's configuration with the bond's two
 // sites exchanged (operators.py:162-163), or the chain itself (bond 0).  Persistent: workgroup b
 // takes the row groups b, b + gridDim.x, ... of G rows each.
-template <int K>
+template <int K, int KW>
 __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_rows(ConvRowsArgs a) {
   extern __shared__ float s_conv[];
   const ConvGeom& g = a.g;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_rows(ConvRowsArgs a) {
     }
     __syncthreads();
     float* tape = a.tape;
-    conv_forward<K>(sm, g, a.p, G, wave, lane, tape, a.tape_stride);
+    conv_forward<K, KW>(sm, g, a.p, G, wave, lane, tape, a.tape_stride);
     for (int s = threadIdx.x; s < G; s += blockDim.x) {
       const int row = grp * G + s;
       if (row < n_rows) {
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_rows(ConvRowsArgs a) {
 // A workgroup owns G chains; their spins and current logits stay in LDS.  Every proposal is a full
 // forward of the proposed configuration (a K x K receptive field grows past the lattice after a few
 // layers, so there is no incremental shortcut).
-template <int K>
+template <int K, int KW>
 __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_sweep(ConvSweepArgs a) {
   extern __shared__ float s_conv[];
   const ConvGeom& g = a.g;
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_sweep(ConvSweepArgs a)
   if (a.cache_in_valid) {
     for (int s = threadIdx.x; s < G; s += blockDim.x) cur_logit[s] = a.logit_in[min(chain0 + s, a.B - 1)];
   } else {
-    conv_forward<K>(sm, g, a.p, G, wave, lane, nullptr, 0);
+    conv_forward<K, KW>(sm, g, a.p, G, wave, lane, nullptr, 0);
     for (int s = threadIdx.x; s < G; s += blockDim.x) cur_logit[s] = sm.red[s];
   }
   __syncthreads();
@@ -448,7 +451,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_sweep(ConvSweepArgs a)
     }
     if (a.dbg_up) break;
     __syncthreads();
-    conv_forward<K>(sm, g, a.p, G, wave, lane, nullptr, 0);
+    conv_forward<K, KW>(sm, g, a.p, G, wave, lane, nullptr, 0);
     for (int s = threadIdx.x; s < G; s += blockDim.x) {
       const int c = chain0 + s;
       const float x_new = sm.red[s], x_old = cur_logit[s], u = prop_u[s];
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_sweep(ConvSweepArgs a)
 // per block (last first) delta_{2k+2} = D, delta_{2k+1} = selu'(t_k) (.) convT_{2k+2}(D),
 // D += convT_{2k+1}(delta_{2k+1}); delta_0 = D.  convT is the same tile loop with the flipped,
 // transposed fragment image and the padding roles exchanged.
-template <int K>
+template <int K, int KW>
 __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_back(ConvBackArgs a) {
   extern __shared__ float s_conv[];
   const ConvGeom& g = a.g;
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_back(ConvBackArgs a) {
     if (!g.resnet) {
       float* in = sm.buf0; float* out = sm.buf1;
       for (int l = n - 1; l >= 1; --l) {
-        conv_layer<K>(sm, in, out, g, a.p.wb + (size_t)(l - 1) * K * K * 256, nullptr, 1, G,
+        conv_layer<K, KW>(sm, in, out, g, a.p.wb + (size_t)(l - 1) * K * KW * 256, nullptr, 1, G,
                       EP_BACK_DACT, wave, lane, a.tape + (long long)(l - 1) * a.tape_stride,
                       a.delta + (long long)(l - 1) * a.delta_stride);
         __syncthreads();
@@ -532,11 +535,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_back(ConvBackArgs a) {
                   a.delta[(long long)l * a.delta_stride + ((long long)row * 4 + gq) * g.GS + i] = d[gq * g.GS + i];
           }
         }
-        conv_layer<K>(sm, sm.buf0, sm.buf1, g, a.p.wb + (size_t)(l - 1) * K * K * 256, nullptr, 1, G,
+        conv_layer<K, KW>(sm, sm.buf0, sm.buf1, g, a.p.wb + (size_t)(l - 1) * K * KW * 256, nullptr, 1, G,
                       EP_BACK_SELU, wave, lane, a.tape + (long long)(l - 1) * a.tape_stride,
                       a.delta + (long long)(l - 1) * a.delta_stride);
         __syncthreads();
-        conv_layer<K>(sm, sm.buf1, sm.buf0, g, a.p.wb + (size_t)(l - 2) * K * K * 256, nullptr, 1, G,
+        conv_layer<K, KW>(sm, sm.buf1, sm.buf0, g, a.p.wb + (size_t)(l - 2) * K * KW * 256, nullptr, 1, G,
                       EP_BACK_ADD, wave, lane, nullptr, l == 2 ? a.delta : nullptr);
         __syncthreads();
       }
@@ -554,9 +557,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_back(ConvBackArgs a) {
 // cin), B = delta (lane = cout), and a second accumulator takes w_b * delta.  Partial sums go to
 // ws[slice][layer]; k_conv_dw_reduce adds the slices in a fixed order into the accumulators.
 #define DW_WAVES 8   // the weight-gradient kernel splits the taps over 8 waves (1 workgroup per CU)
-template <int K>
+template <int K, int KW>
 __global__ __launch_bounds__(DW_WAVES * 64) void k_conv_dw(ConvDwArgs a) {
-  constexpr int KK = K * K;
+  constexpr int KK = K * KW;
   constexpr int TPW = (KK + DW_WAVES - 1) / DW_WAVES;        // taps per wave
   constexpr int T0 = (KK + 15) / 16;                             // tap tiles of the first layer
   extern __shared__ float s_dw[];
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void k_conv_dw(ConvDwArgs a) {
           if ((tt % DW_WAVES) == wave) {
             int tap = 16 * tt + ml;
             tap = tap < KK ? tap : 0;
-            const int n1 = wrap(a1 + tap / K - g.lo, g.D1), n2 = wrap(a2 + tap % K - g.lo, g.D2);
+            const int n1 = wrap(a1 + tap / KW - g.lo, g.D1), n2 = wrap(a2 + tap % KW - g.lo2, g.D2);
             const float av = pv ? s_in[n1 * g.D2 + n2] : 0.f;
             acc1[tt / DW_WAVES] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv, acc1[tt / DW_WAVES], 0, 0, 0);
             acc2[tt / DW_WAVES] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv2, acc2[tt / DW_WAVES], 0, 0, 0);
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(DW_WAVES * 64) void k_conv_dw(ConvDwArgs a) {
         for (int i = 0; i < TPW; ++i) {
           const int tap = wave + i * DW_WAVES;       // wave-uniform
           if (tap < KK) {
-            const int n1 = wrap(a1 + tap / K - g.lo, g.D1), n2 = wrap(a2 + tap % K - g.lo, g.D2);
+            const int n1 = wrap(a1 + tap / KW - g.lo, g.D1), n2 = wrap(a2 + tap % KW - g.lo2, g.D2);
             const float av = pv ? s_in[(n1 * g.D2 + n2) * 16 + ml] : 0.f;
             acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv, acc1[i], 0, 0, 0);
             acc2[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv2, acc2[i], 0, 0, 0);
@@ -702,7 +705,7 @@ __global__ void k_conv_dw_reduce(ConvDwArgs a, int KK) {
 // theta (snt.Conv2D order: per convolution w[K][K][cin][F], b[F]) -> fragment images
 __global__ void k_conv_pack(const float* __restrict__ theta, ConvGeom g, float* w0, float* wf,
                             float* wb, float* bias) {
-  const int KK = g.K * g.K, Q0 = (KK + 3) / 4;
+  const int KK = g.K * g.KW, Q0 = (KK + 3) / 4;
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
   const long long p0 = (long long)KK * g.F + g.F;                 // parameters of convolution 0
@@ -740,15 +743,21 @@ hipError_t launch_k(Kern kern, dim3 grid, size_t lds, hipStream_t s, const Args&
   return hipGetLastError();
 }
 
-#define CONV_DISPATCH_K(K_, CALL)                        \
-  switch (K_) {                                          \
-    case 1: { constexpr int KK_ = 1; CALL; } break;      \
-    case 2: { constexpr int KK_ = 2; CALL; } break;      \
-    case 3: { constexpr int KK_ = 3; CALL; } break;      \
-    case 4: { constexpr int KK_ = 4; CALL; } break;      \
-    case 5: { constexpr int KK_ = 5; CALL; } break;      \
-    case 6: { constexpr int KK_ = 6; CALL; } break;      \
-    default: return hipErrorInvalidValue;                \
+// (kernel_size, taps along axis 2): square kernels (Conv2dPeriodic) and k x 1 (Conv1dPeriodic)
+#define CONV_DISPATCH_K(G_, CALL)                                                       \
+  switch ((G_).KW == 1 ? -(G_).K : (G_).K) {                                            \
+    case 1: case -1: { constexpr int KK_ = 1, KW_ = 1; CALL; } break;                    \
+    case 2: { constexpr int KK_ = 2, KW_ = 2; CALL; } break;                            \
+    case 3: { constexpr int KK_ = 3, KW_ = 3; CALL; } break;                            \
+    case 4: { constexpr int KK_ = 4, KW_ = 4; CALL; } break;                            \
+    case 5: { constexpr int KK_ = 5, KW_ = 5; CALL; } break;                            \
+    case 6: { constexpr int KK_ = 6, KW_ = 6; CALL; } break;                            \
+    case -2: { constexpr int KK_ = 2, KW_ = 1; CALL; } break;                           \
+    case -3: { constexpr int KK_ = 3, KW_ = 1; CALL; } break;                           \
+    case -4: { constexpr int KK_ = 4, KW_ = 1; CALL; } break;                           \
+    case -5: { constexpr int KK_ = 5, KW_ = 1; CALL; } break;                           \
+    case -6: { constexpr int KK_ = 6, KW_ = 1; CALL; } break;                           \
+    default: return hipErrorInvalidValue;                                               \
   }
 
 }  // namespace
@@ -781,8 +790,8 @@ int conv_pick_group(const ConvGeom& g, int waves) {
   return best;
 }
 
-long long conv_num_params(int n_conv, int F, int K) {
-  const long long KK = (long long)K * K;
+long long conv_num_params(int n_conv, int F, int taps) {
+  const long long KK = taps;
   return KK * F + F + (long long)(n_conv - 1) * (KK * F * F + F);
 }
 
@@ -798,14 +807,14 @@ hipError_t launch_conv_rows(hipStream_t s, const ConvRowsArgs& a, int num_cus) {
   const size_t lds = conv_rows_lds(a.g, a.G);
   const int slots = num_cus * (lds <= CONV_LDS_PER_WG ? 2 : 1);      // co-resident workgroups
   const dim3 grid(groups < slots ? groups : slots);
-  CONV_DISPATCH_K(a.g.K, return launch_k(k_conv_rows<KK_>, grid, lds, s, a));
+  CONV_DISPATCH_K(a.g, return launch_k(k_conv_rows<KK_, KW_>, grid, lds, s, a));
   return hipSuccess;
 }
 
 hipError_t launch_conv_sweep(hipStream_t s, const ConvSweepArgs& a) {
   const dim3 grid((a.B + a.G - 1) / a.G);
   const size_t lds = conv_rows_lds(a.g, a.G);
-  CONV_DISPATCH_K(a.g.K, return launch_k(k_conv_sweep<KK_>, grid, lds, s, a));
+  CONV_DISPATCH_K(a.g, return launch_k(k_conv_sweep<KK_, KW_>, grid, lds, s, a));
   return hipSuccess;
 }
 
@@ -814,17 +823,17 @@ hipError_t launch_conv_back(hipStream_t s, const ConvBackArgs& a, int num_cus) {
   const size_t lds = conv_rows_lds(a.g, a.G);
   const int slots = num_cus * (lds <= CONV_LDS_PER_WG ? 2 : 1);
   const dim3 grid(groups < slots ? groups : slots);
-  CONV_DISPATCH_K(a.g.K, return launch_k(k_conv_back<KK_>, grid, lds, s, a));
+  CONV_DISPATCH_K(a.g, return launch_k(k_conv_back<KK_, KW_>, grid, lds, s, a));
   return hipSuccess;
 }
 
 hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a) {
   const dim3 grid(a.n_slices, a.g.n_conv);
   const size_t lds = (size_t)((a.g.N + 3) & ~3) * 32 * sizeof(float);
-  CONV_DISPATCH_K(a.g.K, {
-    hipError_t e = launch_k(k_conv_dw<KK_>, grid, lds, s, a, DW_WAVES * 64);
+  CONV_DISPATCH_K(a.g, {
+    hipError_t e = launch_k(k_conv_dw<KK_, KW_>, grid, lds, s, a, DW_WAVES * 64);
     if (e != hipSuccess) return e;
   });
-  hipLaunchKernelGGL(k_conv_dw_reduce, dim3(32), dim3(256), 0, s, a, a.g.K * a.g.K);
+  hipLaunchKernelGGL(k_conv_dw_reduce, dim3(32), dim3(256), 0, s, a, a.g.K * a.g.KW);
   return hipGetLastError();
 }

@@ -20,13 +20,16 @@ struct ConvGeom {
   int resnet;   // 0: Conv2DNetwork, 1: ResNet2D
   int hact;     // hidden activation id of Conv2DNetwork (ResNet2D: selu, layers.py:226)
   int GS;       // dwords per channel group of a feature map (see above)
-  int lo, hi;   // periodic padding in front / behind: (K-1)/2 and K/2 on both axes (layers.py:132-141)
+  int lo, hi;   // periodic padding in front / behind along axis 1: (K-1)/2 and K/2 (layers.py:132-141);
+                // the 1-D modules pad K/2 in front and K-1-K/2 behind (layers.py:66-72)
+  int KW;       // taps along axis 2: K (Conv2dPeriodic) or 1 (Conv1dPeriodic on an [N, 1] lattice)
+  int lo2, hi2; // the same padding for axis 2 (0 for the 1-D modules)
 };
 
 // One packed parameter set (k_conv_pack):
 //   w0   [Q0][64]           first convolution (1 input channel), taps are the k index:
 //                           lane (m, g) of k-step q = W0[tap 4q+g][0][cout m]
-//   wf   [n_conv-1][K*K][64][4]  forward fragments of convolutions 1..: lane (m, g), element e =
+//   wf   [n_conv-1][K*KW][64][4] forward fragments of convolutions 1..: lane (m, g), element e =
 //                           W[tap][cin 4g+e][cout m]        (A operand of v_mfma_f32_16x16x4_f32)
 //   wb   same shape: the transposed convolution, lane (m, g), e = W[K*K-1-tap][cin m][cout 4g+e]
 //   bias [n_conv][16]
@@ -102,7 +105,7 @@ size_t conv_rows_lds(const ConvGeom& g, int G);
 size_t conv_lds_cap(const ConvGeom& g);   // LDS budget of one workgroup (two per CU when a sample fits)
 int conv_waves();                         // waves per workgroup of the conv kernels
 int conv_pick_group(const ConvGeom& g, int waves);
-long long conv_num_params(int n_conv, int F, int K);
+long long conv_num_params(int n_conv, int F, int taps);
 hipError_t launch_conv_pack(hipStream_t s, const float* theta, const ConvGeom& g, float* w0,
                             float* wf, float* wb, float* bias);
 hipError_t launch_conv_rows(hipStream_t s, const ConvRowsArgs& a, int num_cus);

@@ -513,8 +513,10 @@ int64_t vmc_num_params_ansatz(int32_t ansatz, int32_t n_sites, int32_t layer_siz
 }
 
 int64_t vmc_num_params_conv(int32_t ansatz, int32_t num_layers, int32_t num_filters, int32_t kernel_size) {
-  const int n_conv = ansatz == VMC_ANSATZ_RES_NET_2D ? 1 + 2 * num_layers : num_layers;
-  return conv_num_params(n_conv, num_filters, kernel_size);
+  const bool resnet = ansatz == VMC_ANSATZ_RES_NET_2D || ansatz == VMC_ANSATZ_RES_NET_1D;
+  const bool one_d = ansatz == VMC_ANSATZ_CONV_1D || ansatz == VMC_ANSATZ_RES_NET_1D;
+  const int n_conv = resnet ? 1 + 2 * num_layers : num_layers;
+  return conv_num_params(n_conv, num_filters, one_d ? kernel_size : kernel_size * kernel_size);
 }
 
 const char* vmc_last_error(const vmc_ctx* ctx) {
@@ -524,32 +526,39 @@ const char* vmc_last_error(const vmc_ctx* ctx) {
 int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (!d || !out) return fail(nullptr, VMC_ERR_INVALID, "null argument");
   *out = nullptr;
-  if (d->ansatz < VMC_ANSATZ_FULLY_CONNECTED || d->ansatz > VMC_ANSATZ_RES_NET_2D)
-    return fail(nullptr, VMC_ERR_UNSUPPORTED, "only the fully_connected, rbm, conv_2d and res_net_2d ansatz types have HIP kernels");
+  if (d->ansatz < VMC_ANSATZ_FULLY_CONNECTED || d->ansatz > VMC_ANSATZ_RES_NET_1D)
+    return fail(nullptr, VMC_ERR_UNSUPPORTED, "only the fully_connected, rbm, conv_1d/2d and res_net_1d/2d ansatz types have HIP kernels");
   const bool rbm = d->ansatz == VMC_ANSATZ_RBM;
-  const bool conv = d->ansatz == VMC_ANSATZ_CONV_2D || d->ansatz == VMC_ANSATZ_RES_NET_2D;
-  const bool resnet = d->ansatz == VMC_ANSATZ_RES_NET_2D;
+  const bool conv = d->ansatz >= VMC_ANSATZ_CONV_2D;
+  const bool resnet = d->ansatz == VMC_ANSATZ_RES_NET_2D || d->ansatz == VMC_ANSATZ_RES_NET_1D;
+  const bool one_d = d->ansatz == VMC_ANSATZ_CONV_1D || d->ansatz == VMC_ANSATZ_RES_NET_1D;
   if (d->n_sites < 2 || d->batch_size < 1 || d->num_layers < ((rbm || resnet) ? 0 : 1) || d->layer_size < 1)
     return fail(nullptr, VMC_ERR_INVALID, "n_sites >= 2, batch_size, layer_size >= 1, num_layers >= 1 (rbm, res_net_2d: >= 0) required");
   ConvGeom cg;
   memset(&cg, 0, sizeof(cg));
   if (conv) {
-    // Conv2DNetwork reshapes its input to [-1, size_x, size_y, 1] (wavefunctions.py:596-597)
-    if (d->size_x < 1 || d->size_y < 1 || (long long)d->size_x * d->size_y != d->n_sites)
+    // Conv2DNetwork reshapes its input to [-1, size_x, size_y, 1] (wavefunctions.py:596-597);
+    // Conv1DNetwork expands [B, N] to [B, N, 1] (wavefunctions.py:511): an N x 1 lattice here
+    const int sx = one_d ? d->n_sites : d->size_x, sy = one_d ? 1 : d->size_y;
+    if (sx < 1 || sy < 1 || (long long)sx * sy != d->n_sites)
       return fail(nullptr, VMC_ERR_INVALID, "size_x * size_y must equal num_sites");
     if (d->kernel_size < 1 || d->kernel_size > 6)
       return fail(nullptr, VMC_ERR_UNSUPPORTED, "kernel_size 1..6 supported by the convolution kernels (weights are register resident)");
     if (d->layer_size > CONV_FP)
       return fail(nullptr, VMC_ERR_UNSUPPORTED, "num_conv_filters > 16 not supported by the convolution kernels");
-    if (d->size_x < d->kernel_size / 2 || d->size_y < d->kernel_size / 2 || d->size_x > 1023 || d->size_y > 1023)
+    if (sx < d->kernel_size / 2 || (!one_d && sy < d->kernel_size / 2) || sx > 1023 || sy > 1023)
       return fail(nullptr, VMC_ERR_UNSUPPORTED, "lattice sides must be in [kernel_size / 2, 1023]");
     if (!resnet && d->nonlinearity == VMC_ACT_COS)
       return fail(nullptr, VMC_ERR_UNSUPPORTED, "the cos nonlinearity is not offered by the convolution kernels");
-    cg.K = d->kernel_size; cg.D1 = d->size_x; cg.D2 = d->size_y; cg.N = d->n_sites; cg.F = d->layer_size;
+    cg.K = d->kernel_size; cg.D1 = sx; cg.D2 = sy; cg.N = d->n_sites; cg.F = d->layer_size;
     cg.n_conv = resnet ? 1 + 2 * d->num_layers : d->num_layers;
     cg.resnet = resnet ? 1 : 0; cg.hact = d->nonlinearity;
     cg.GS = (4 * cg.N + 63) / 64 * 64;
-    cg.lo = (cg.K - 1) / 2; cg.hi = cg.K / 2;
+    if (one_d) {   // layers.py:66-72: k/2 in front, k - 1 - k/2 behind (odd k: (k-1)/2 both)
+      cg.KW = 1; cg.lo = cg.K / 2; cg.hi = cg.K - 1 - cg.lo; cg.lo2 = cg.hi2 = 0;
+    } else {       // layers.py:132-141: (k-1)/2 in front, k/2 behind, both axes
+      cg.KW = cg.K; cg.lo = cg.lo2 = (cg.K - 1) / 2; cg.hi = cg.hi2 = cg.K / 2;
+    }
     if (cg.n_conv > CONV_MAX_LAYERS) return fail(nullptr, VMC_ERR_UNSUPPORTED, "too many convolutions");
     if ((long long)d->batch_size * 4 * cg.GS >= (1LL << 31))
       return fail(nullptr, VMC_ERR_UNSUPPORTED, "batch_size x lattice too large for the 32-bit tape offsets of the convolution kernels");
@@ -672,7 +681,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     CA(hipMemsetAsync(c->wide_zero, 0, Hp * sizeof(float), c->stream));
   }
   if (conv) {
-    const long long KK = (long long)cg.K * cg.K, nl = cg.n_conv > 1 ? cg.n_conv - 1 : 1;
+    const long long KK = (long long)cg.K * cg.KW, nl = cg.n_conv > 1 ? cg.n_conv - 1 : 1;
     for (int w = 0; w < 2; ++w) {
       ParamSet& p = c->ps[w];
       CA(dalloc(&p.cw0, (KK + 3) / 4 * 64)); CA(dalloc(&p.cwf, nl * KK * 256)); CA(dalloc(&p.cwb, nl * KK * 256));

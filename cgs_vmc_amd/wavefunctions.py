@@ -504,6 +504,115 @@ class ResNet2D(Conv2DNetwork):
     return cls(**res_net_2d_params)
 
 
+class Conv1DNetwork(Conv2DNetwork):
+  """[Conv1dPeriodic(num_filters, kernel_size), nonlinearity] x (num_layers - 1), Conv1dPeriodic,
+  reduce_sum over sites and channels, (- exp_norm_shift), exp   (wavefunctions.py:455-527;
+  layers.Conv1dPeriodic, layers.py:24-86).  Inputs are expanded to [B, N, 1]; the kernels are those
+  of the 2-D types on an N x 1 lattice with k x 1 taps and the 1-D padding rule (an even kernel
+  pads k/2 in front and k/2 - 1 behind, layers.py:66-72 -- the mirror image of the 2-D module)."""
+  _ansatz = 'conv_1d'
+
+  def __init__(self, num_layers: int, num_filters: int, kernel_size: int,
+               nonlinearity=layers.NONLINEARITIES['relu'],
+               output_activation=layers.NONLINEARITIES['exp'], name: str = 'conv_1d_network'):
+    super(Conv1DNetwork, self).__init__(
+        num_layers=num_layers, num_filters=num_filters, kernel_size=kernel_size, size_x=0, size_y=1,
+        nonlinearity=nonlinearity, output_activation=output_activation, name=name)
+
+  def _conv_scopes(self):
+    return ['conv_1d_periodic' if l == 0 else 'conv_1d_periodic_%d' % l
+            for l in range(self._num_layers)]
+
+  def _shapes(self):
+    k, f, u = self._kernel_size, self._num_filters, self._unique_name
+    names, shapes, cin = [], [], 1
+    for scope in self._conv_scopes():
+      names += ['%s/%s/conv_1d/w' % (u, scope), '%s/%s/conv_1d/b' % (u, scope)]
+      shapes += [(k, cin, f), (f,)]
+      cin = f
+    return names, shapes
+
+  def initialize(self, seed=None):
+    """snt.Conv1D defaults: w ~ truncated normal(sigma = 1/sqrt(k*in_channels)), b = 0."""
+    if self._n_sites is None:
+      raise ValueError('wavefunction is not connected to inputs yet')
+    rng = np.random.default_rng(seed)
+    parts = []
+    for shp in self._shapes()[1]:
+      if len(shp) == 3:
+        w = rng.standard_normal(shp)
+        bad = np.abs(w) > 2
+        while bad.any():
+          w[bad] = rng.standard_normal(int(bad.sum()))
+          bad = np.abs(w) > 2
+        parts.append((w / np.sqrt(shp[0] * shp[1])).ravel())
+      else:
+        parts.append(np.zeros(shp).ravel())
+    self._set_theta(np.concatenate(parts).astype(np.float32))
+
+  def _engine_spec(self):
+    spec = FullyConnectedNetwork._engine_spec(self)
+    spec.update(kernel_size=self._kernel_size, size_x=0, size_y=0)
+    return spec
+
+  @classmethod
+  def from_hparams(cls, hparams, name: str = '') -> 'Wavefunction':
+    """wavefunctions.py:513-527."""
+    conv_1d_params = {
+        'num_layers': hparams.num_conv_layers,
+        'num_filters': hparams.num_conv_filters,
+        'kernel_size': hparams.kernel_size,
+        'output_activation': layers.NONLINEARITIES[hparams.output_activation],
+        'nonlinearity': layers.NONLINEARITIES[hparams.nonlinearity],
+    }
+    if name:
+      conv_1d_params['name'] = name
+    return cls(**conv_1d_params)
+
+
+class ResNet1D(Conv1DNetwork):
+  """Conv1dPeriodic, then num_blocks x ResBlock1d (x + conv(selu(conv(x))), layers.py:290-293),
+  reduce_sum, (- exp_norm_shift), exp   (wavefunctions.py:618-707).  Plain blocks at stride 1 are
+  supported (a strided block does not type-check against its shortcut, layers.py:281-282;
+  bottleneck blocks are outside the MI355X hot path)."""
+  _ansatz = 'res_net_1d'
+
+  def __init__(self, num_blocks: int, num_filters: int, kernel_size: int, conv_stride: int,
+               bottleneck: bool = False, output_activation=layers.NONLINEARITIES['exp'],
+               name: str = 'res_net_1d'):
+    if bottleneck:
+      raise NotImplementedError('BottleneckResBlock1d is outside the MI355X hot path')
+    if conv_stride != 1:
+      raise ValueError('Inputs shape is not compatable with filters.')
+    super(ResNet1D, self).__init__(
+        num_layers=num_blocks, num_filters=num_filters, kernel_size=kernel_size,
+        nonlinearity=layers.NONLINEARITIES['relu'], output_activation=output_activation, name=name)
+    self._num_blocks = num_blocks
+    self._conv_stride = conv_stride
+    self._bottleneck = bottleneck
+
+  def _conv_scopes(self):
+    scopes = ['conv_1d_periodic']
+    for blk in range(self._num_blocks):
+      block = 'res_block_1d' if blk == 0 else 'res_block_1d_%d' % blk
+      scopes += ['%s/first_conv' % block, '%s/second_conv' % block]
+    return scopes
+
+  @classmethod
+  def from_hparams(cls, hparams, name: str = '') -> 'Wavefunction':
+    """wavefunctions.py:692-707."""
+    res_net_1d_params = {
+        'num_blocks': hparams.num_resnet_blocks,
+        'num_filters': hparams.num_conv_filters,
+        'kernel_size': hparams.kernel_size,
+        'conv_stride': hparams.conv_strides,
+        'output_activation': layers.NONLINEARITIES[hparams.output_activation],
+    }
+    if name:
+      res_net_1d_params['name'] = name
+    return cls(**res_net_1d_params)
+
+
 class AmplitudeTensor(session_lib.Tensor):
   """psi = wavefunction(inputs); evaluates to a float32 array [rows]."""
 
@@ -528,7 +637,8 @@ class _OutOfScope(Wavefunction):
   def from_hparams(cls, hparams, name: str = ''):
     raise NotImplementedError(
         "wavefunction_type '%s' is outside the MI355X hot path (SURVEY.md 2); only "
-        "'fully_connected', 'rbm', 'conv_2d' and 'res_net_2d' have HIP kernels" % cls._kind)
+        "'fully_connected', 'rbm', 'conv_1d', 'conv_2d', 'res_net_1d' and 'res_net_2d' have HIP "
+        "kernels" % cls._kind)
 
 
 def _stub(kind):
@@ -548,12 +658,12 @@ def build_wavefunction(hparams) -> Wavefunction:
 WAVEFUNCTION_TYPES = {
     'fully_connected': FullyConnectedNetwork,
     'rbm': RestrictedBoltzmannNetwork,
-    'conv_1d': _stub('conv_1d'),
+    'conv_1d': Conv1DNetwork,
     'conv_2d': Conv2DNetwork,
     'mps': _stub('mps'),
     'pbdg': _stub('pbdg'),
     'fully_connected_nnb': _stub('fully_connected_nnb'),
-    'res_net_1d': _stub('res_net_1d'),
+    'res_net_1d': ResNet1D,
     'res_net_2d': ResNet2D,
     'ed_vector': _stub('ed_vector'),
     'gnn': _stub('gnn'),

@@ -26,6 +26,9 @@
  * the initial convolution, then first_conv, second_conv of every ResBlock2d (layers.py:200-201) --
  * each w[k][k][in_channels][F] (row-major) followed by b[F]; in_channels = 1 for the first, F after;
  * P = k*k*F + F + (n_conv - 1)*(k*k*F*F + F).
+ * Conv1DNetwork (wavefunctions.py:455-527) and ResNet1D (wavefunctions.py:618-707): the same with
+ * snt.Conv1D variables w[k][in_channels][F], b[F] per layers.Conv1dPeriodic;
+ * P = k*F + F + (n_conv - 1)*(k*F*F + F).
  */
 #ifndef CGSVMC_H_
 #define CGSVMC_H_
@@ -55,7 +58,7 @@ enum { VMC_MODE_ENERGY_GRADIENT = 0, VMC_MODE_LOG_OVERLAP_ITSWO = 1 };
 
 /* wavefunctions.WAVEFUNCTION_TYPES with kernels (wavefunctions.py:1157-1170) */
 enum { VMC_ANSATZ_FULLY_CONNECTED = 0, VMC_ANSATZ_RBM = 1, VMC_ANSATZ_CONV_2D = 2,
-       VMC_ANSATZ_RES_NET_2D = 3 };
+       VMC_ANSATZ_RES_NET_2D = 3, VMC_ANSATZ_CONV_1D = 4, VMC_ANSATZ_RES_NET_1D = 5 };
 
 /* layers.NONLINEARITIES ids (layers.py:13-21).  Every id is accepted as hidden and as output
  * activation of the dense ansatz types; the convolutional ones take every hidden id but cos. */
@@ -81,7 +84,8 @@ typedef struct {
   void* stream;              /* hipStream_t to launch on, or NULL for the null stream*/
   /* convolutional ansatz types only (ignored otherwise) */
   int32_t kernel_size;       /* hparams.kernel_size (utils.py:110), 1..6             */
-  int32_t size_x, size_y;    /* hparams.size_x, size_y (utils.py:99-100); n_sites = size_x*size_y */
+  int32_t size_x, size_y;    /* hparams.size_x, size_y (utils.py:99-100); n_sites = size_x*size_y
+                                (ignored by the 1-D types: the chain has n_sites sites)          */
   int32_t reserved2;         /* 0                                                    */
 } vmc_desc;
 

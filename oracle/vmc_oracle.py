@@ -237,20 +237,32 @@ def selu_deriv(x):
       x > 0, x.dtype.type(1), x.dtype.type(SELU_ALPHA) * np.exp(np.minimum(x, 0)))
 
 
+# The 1-D types -- Conv1DNetwork (wavefunctions.py:455-527) and ResNet1D (wavefunctions.py:618-707)
+# on layers.Conv1dPeriodic / ResBlock1d (layers.py:24-86, 229-293) -- are the same networks on a
+# [N, 1] "lattice" with k x 1 kernels (snt.Conv1D variables w[k, in, out], b[out]) and the 1-D
+# padding rule, which for an even kernel is the mirror image of the 2-D one (layers.py:66-72:
+# k/2 in front, k/2 - 1 behind).  geom = (filters, kernel, N, 1).
+CONV_1D = ('conv_1d', 'res_net_1d')
+CONV_PLAIN = ('conv_1d', 'conv_2d')
+
+
 def conv_layer_channels(ansatz, num_layers, num_filters):
-  """(in_channels, out_channels) of every Conv2dPeriodic in creation order.
-  conv_2d: num_layers convolutions (wavefunctions.py:572-575); res_net_2d: the initial
-  convolution, then first_conv / second_conv of each block (wavefunctions.py:766-772,
-  layers.py:200-201)."""
-  n_conv = num_layers if ansatz == 'conv_2d' else 1 + 2 * num_layers
+  """(in_channels, out_channels) of every periodic convolution in creation order.
+  conv_*: num_layers convolutions (wavefunctions.py:572-575, 487-490); res_net_*: the initial
+  convolution, then first_conv / second_conv of each block (wavefunctions.py:766-772, 659-667;
+  layers.py:200-201, 265-266)."""
+  n_conv = num_layers if ansatz in CONV_PLAIN else 1 + 2 * num_layers
   return [(1 if l == 0 else num_filters, num_filters) for l in range(n_conv)]
 
 
 def conv_param_shapes(ansatz, geom, num_layers):
+  """Kernels as [k1, k2, in, out] (k2 = 1 for the 1-D types: the flat order equals snt.Conv1D's
+  [k, in, out])."""
   f, k = geom[0], geom[1]
+  k2 = 1 if ansatz in CONV_1D else k
   shapes = []
   for cin, cout in conv_layer_channels(ansatz, num_layers, f):
-    shapes += [(k, k, cin, cout), (cout,)]
+    shapes += [(k, k2, cin, cout), (cout,)]
   return shapes
 
 
@@ -301,31 +313,44 @@ def periodic_pad_2d(x, k):
   return np.concatenate([bot, wp, top], axis=1)
 
 
+def periodic_pad_1d(x, k):
+  """layers.Conv1dPeriodic._pad_input (layers.py:51-74) on x [B, N, 1, C] (axis 1): (k-1)/2 on both
+  sides for odd k; for even k, k/2 in front and k/2 - 1 behind."""
+  lo = (k - 1) // 2 if k % 2 == 1 else k // 2
+  hi = (k - 1) // 2 if k % 2 == 1 else k // 2 - 1
+  n = x.shape[1]
+  return np.concatenate([x[:, n - lo:], x, x[:, :hi]], axis=1)
+
+
 def conv2d_periodic(x, w, b):
-  """Conv2dPeriodic._build (layers.py:151-160): snt.Conv2D(VALID, stride 1) of the padded
-  input = cross-correlation out[a1,a2,o] = b[o] + sum w[d1,d2,c,o] pad[a1+d1, a2+d2, c]."""
-  k = w.shape[0]
-  pad = periodic_pad_2d(x, k)
+  """Conv2dPeriodic._build (layers.py:151-160) / Conv1dPeriodic._build (layers.py:77-86):
+  snt.Conv2D / Conv1D (VALID, stride 1) of the padded input = cross-correlation
+  out[a1,a2,o] = b[o] + sum w[d1,d2,c,o] pad[a1+d1, a2+d2, c].  A kernel of shape [k, 1, ., .]
+  is the 1-D module acting along axis 1."""
+  k1, k2 = w.shape[0], w.shape[1]
+  pad = periodic_pad_2d(x, k1) if k2 == k1 and x.shape[2] > 1 or k2 > 1 else periodic_pad_1d(x, k1)
   bsz, d1, d2 = x.shape[0], x.shape[1], x.shape[2]
   out = np.zeros((bsz, d1, d2, w.shape[3]), x.dtype)
-  for i in range(k):
-    for j in range(k):
+  for i in range(k1):
+    for j in range(k2):
       out += pad[:, i:i + d1, j:j + d2, :] @ w[i, j]
   return out + b
 
 
 def conv2d_periodic_backward(x, w, delta):
   """(d/dx, d/dw, d/db) of sum(conv2d_periodic(x, w, b) * delta)."""
-  k = w.shape[0]
-  lo = (k - 1) // 2
+  k1, k2 = w.shape[0], w.shape[1]
+  one_d = k2 == 1 and x.shape[2] == 1
+  lo1 = k1 // 2 if one_d else (k1 - 1) // 2       # padding in front (even 1-D kernels: k/2)
+  lo2 = 0 if one_d else (k2 - 1) // 2
   dx = np.zeros_like(x)
   dw = np.zeros_like(w)
-  for i in range(k):
-    for j in range(k):
-      # pad[a1+i, a2+j] = x[(a1+i-lo) mod D1, (a2+j-lo) mod D2]
-      xs = np.roll(x, (-(i - lo), -(j - lo)), axis=(1, 2))
+  for i in range(k1):
+    for j in range(k2):
+      # pad[a1+i, a2+j] = x[(a1+i-lo1) mod D1, (a2+j-lo2) mod D2]
+      xs = np.roll(x, (-(i - lo1), -(j - lo2)), axis=(1, 2))
       dw[i, j] = np.tensordot(xs, delta, axes=([0, 1, 2], [0, 1, 2]))
-      dx += np.roll(delta @ w[i, j].T, (i - lo, j - lo), axis=(1, 2))
+      dx += np.roll(delta @ w[i, j].T, (i - lo1, j - lo2), axis=(1, 2))
   return dx, dw, delta.sum((0, 1, 2))
 
 
@@ -334,10 +359,10 @@ def conv_forward(theta, configs, ansatz, geom, num_layers, nonlinearity='relu',
   """Pre-output-activation scalar of Conv2DNetwork / ResNet2D: reduce_sum over sites and
   channels of the last feature map (wavefunctions.py:569, 577; 760, 773)."""
   f, k, sx, sy = geom
-  x = np.asarray(configs, dtype=dtype).reshape(-1, sx, sy, 1)   # wavefunctions.py:596-597
+  x = np.asarray(configs, dtype=dtype).reshape(-1, sx, sy, 1)   # wavefunctions.py:596-597 (1-D: expand_dims, :511)
   layers_ = conv_unpack(np.asarray(theta, dtype=dtype), ansatz, geom, num_layers)
   tape = []   # per convolution: (input, pre-activation output)
-  if ansatz == 'conv_2d':
+  if ansatz in CONV_PLAIN:
     act = NONLINEARITIES[nonlinearity]
     a = x
     for l, (w, b) in enumerate(layers_):
@@ -345,7 +370,7 @@ def conv_forward(theta, configs, ansatz, geom, num_layers, nonlinearity='relu',
       tape.append((a, z))
       a = act(z) if l + 1 != len(layers_) else z            # wavefunctions.py:574-575
     last = a
-  elif ansatz == 'res_net_2d':
+  elif ansatz in ('res_net_2d', 'res_net_1d'):
     w, b = layers_[0]
     h = conv2d_periodic(x, w, b)                             # initial_conv, no activation
     tape.append((x, h))
@@ -398,7 +423,7 @@ def _conv_weighted_grads(ansatz):
     for c in range(w_b.shape[1]):
       wc = w_b[:, c][:, None, None, None]
       grads_ = [None] * len(layers_)
-      if ansatz == 'conv_2d':
+      if ansatz in CONV_PLAIN:
         dact = _NONLIN_DERIV[nonlinearity]
         delta = np.broadcast_to(wc, tape[-1][1].shape).astype(dtype)   # d logit / d z_last = 1
         for l in range(len(layers_) - 1, -1, -1):
@@ -724,7 +749,7 @@ class Accumulators:
 
 def _act_kwargs(ansatz, nonlinearity, output_activation):
   kw = {'nonlinearity': nonlinearity}
-  if ansatz in ('fully_connected', 'conv_2d', 'res_net_2d'):
+  if ansatz in ('fully_connected', 'conv_2d', 'res_net_2d', 'conv_1d', 'res_net_1d'):
     kw['output_activation'] = output_activation
   return kw
 
@@ -954,4 +979,11 @@ ANSATZ = {
                    _conv_weighted_grads('res_net_2d'),
                    lambda geom, num_layers, rng: conv_init_params('res_net_2d', geom, num_layers, rng),
                    lambda geom, num_layers: conv_num_params('res_net_2d', geom, num_layers)),
+    'conv_1d': (_conv_psi('conv_1d'), _conv_logit('conv_1d'), _conv_weighted_grads('conv_1d'),
+                lambda geom, num_layers, rng: conv_init_params('conv_1d', geom, num_layers, rng),
+                lambda geom, num_layers: conv_num_params('conv_1d', geom, num_layers)),
+    'res_net_1d': (_conv_psi('res_net_1d'), _conv_logit('res_net_1d'),
+                   _conv_weighted_grads('res_net_1d'),
+                   lambda geom, num_layers, rng: conv_init_params('res_net_1d', geom, num_layers, rng),
+                   lambda geom, num_layers: conv_num_params('res_net_1d', geom, num_layers)),
 }

@@ -31,6 +31,17 @@ CONV_SHAPES = [
     ('res_net_2d', 4, 4, 0, 6, 3, 8, 'relu'),       # no block: the initial convolution alone
     ('res_net_2d', 10, 10, 2, 16, 5, 24, 'relu'),   # hparams defaults (utils.py:114) on 10 x 10
 ]
+ONE_D = [
+    # Conv1DNetwork / ResNet1D (wavefunctions.py:455-527, 618-707): N x 1 lattice, k x 1 taps
+    ('conv_1d', 12, 1, 3, 16, 5, 20, 'relu'),
+    ('conv_1d', 10, 1, 2, 8, 4, 17, 'tanh'),        # even kernel: k/2 in front, k/2 - 1 behind (layers.py:66-72)
+    ('conv_1d', 40, 1, 5, 16, 5, 24, 'relu'),       # hparams defaults (utils.py:98, 108-111)
+    ('conv_1d', 9, 1, 2, 5, 2, 11, 'sigmoid'),
+    ('res_net_1d', 12, 1, 2, 16, 5, 20, 'relu'),
+    ('res_net_1d', 24, 1, 1, 12, 6, 13, 'relu'),
+    ('res_net_1d', 40, 1, 2, 16, 3, 16, 'relu'),
+]
+CONV_SHAPES = CONV_SHAPES + ONE_D
 BIG = [
     ('conv_2d', 16, 16, 5, 16, 5, 12, 'relu'),
     ('res_net_2d', 16, 16, 2, 16, 5, 10, 'relu'),
@@ -46,7 +57,8 @@ def _make(ansatz, sx, sy, L, f, k, b, nonlin, seed=0, output_activation='exp', n
   theta = vo.conv_init_params(ansatz, geom, L, rng)
   theta += (noise * rng.standard_normal(theta.size)).astype(np.float32)   # non-zero biases
   cfg = vo.random_configurations(n, b, np.random.RandomState(seed + 1))
-  bonds = vo.torus_bonds(sy, sx)       # site = a2 + size_y * a1 (row-major reshape)
+  # site = a2 + size_y * a1 (row-major reshape); the 1-D types live on the periodic chain
+  bonds = vo.chain_bonds(n) if ansatz in vo.CONV_1D else vo.torus_bonds(sy, sx)
   eng = VmcEngine(n, b, L, f, nonlinearity=nonlin, output_activation=output_activation, seed=2024,
                   ansatz=ansatz, kernel_size=k, size_x=sx, size_y=sy)
   assert eng.num_params == theta.size == vo.conv_num_params(ansatz, geom, L)
@@ -284,3 +296,24 @@ def test_conv_through_run_training_and_evaluation(tmp_path):
     wavefunctions.reset_name_scope()
     run_energy_evaluation.main(['--checkpoint_dir', d, '--heisenberg_jx', '-1.0',
                                 '--hparams', 'num_evaluation_samples=5'])
+
+
+def test_conv_1d_through_run_training(tmp_path):
+  """--wavefunction_type=conv_1d on the reference's default lattice, the periodic chain
+  (run_training.py:103-109: no J.txt): 16 sites, E0 = -7.1423 (exact diagonalisation)."""
+  import os
+  from cgs_vmc_amd import run_training, session as session_lib, wavefunctions
+  session_lib.reset_default_graph()
+  wavefunctions.reset_name_scope()
+  os.environ.update(CGS_VMC_SEED='77', CGS_VMC_CONFIG_SEED='5', CGS_VMC_INIT_SEED='31')
+  d = str(tmp_path)
+  hp = ('batch_size=256,num_conv_layers=3,num_conv_filters=8,kernel_size=4,num_equilibration_sweeps=10,'
+        'num_batches_per_epoch=8,learning_rates=[0.003,0.001],learning_rate_stops=[60]')
+  run_training.main(['--checkpoint_dir', d, '--num_sites', '16', '--heisenberg_jx', '-1.0',
+                     '--wavefunction_type', 'conv_1d', '--optimizer', 'EnergyGradient',
+                     '--num_epochs', '80', '--hparams', hp])
+  energies = [float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()]
+  tail = np.mean(energies[-10:])
+  assert -7.1423 - 0.05 < tail < -6.0, (tail, energies[::10])
+  ck = session_lib.latest_checkpoint(d)
+  assert 'conv_1d_network/conv_1d_periodic_2/conv_1d/w' in set(np.load(ck + '.npz').files)

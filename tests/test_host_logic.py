@@ -94,9 +94,21 @@ def test_registries_and_errors():
   hp = utils.create_hparams(wavefunction_type='bogus')
   with pytest.raises(ValueError, match='not registered'):
     wavefunctions.build_wavefunction(hp)
-  hp.set_hparam('wavefunction_type', 'conv_1d')
+  hp.set_hparam('wavefunction_type', 'mps')
   with pytest.raises(NotImplementedError):
     wavefunctions.build_wavefunction(hp)
+  hp.set_hparam('wavefunction_type', 'conv_1d')
+  wf1 = wavefunctions.build_wavefunction(hp)
+  wf1._n_sites = 12
+  assert wf1._shapes() == (
+      ['conv_1d_network/conv_1d_periodic%s/conv_1d/%s' % (sfx, v) for sfx in ('', '_1', '_2', '_3', '_4')
+       for v in ('w', 'b')],
+      [(5, 1, 16), (16,)] + [(5, 16, 16), (16,)] * 4)
+  assert wf1._engine_spec()['ansatz'] == 'conv_1d' and wf1._engine_spec()['kernel_size'] == 5
+  hp.set_hparam('wavefunction_type', 'res_net_1d')
+  wf1 = wavefunctions.build_wavefunction(hp)
+  wf1._n_sites = 12
+  assert wf1._shapes()[0][2] == 'res_net_1d/res_block_1d/first_conv/conv_1d/w' and len(wf1._shapes()[1]) == 10
   # the two convolutional types with kernels: constructor arguments and Sonnet variable names
   hp.set_hparam('wavefunction_type', 'conv_2d')
   hp.set_hparam('size_x', 4); hp.set_hparam('size_y', 6); hp.set_hparam('num_conv_layers', 3)

@@ -380,3 +380,45 @@ def test_conv_zero_weights_closed_form_and_exchange_symmetry():
     a = vo.conv_forward(th, cfg, ansatz, geom, L, dtype=np.float64)
     shifted = np.roll(cfg.reshape(-1, 4, 4), (1, 2), axis=(1, 2)).reshape(-1, 16)
     np.testing.assert_allclose(vo.conv_forward(th, shifted, ansatz, geom, L, dtype=np.float64), a, atol=1e-12)
+
+
+@pytest.mark.parametrize('ansatz,L', [('conv_1d', 3), ('res_net_1d', 2)])
+@pytest.mark.parametrize('k', [2, 3, 4, 5])
+def test_conv1d_oracle_against_torch_autograd(ansatz, L, k):
+  """Conv1DNetwork / ResNet1D (wavefunctions.py:455-527, 618-707) against explicit concat padding
+  (layers.py:51-74: an even kernel pads k/2 in front and k/2 - 1 behind) + torch conv1d + autograd."""
+  import torch
+  n, geom = 12, (6, k, 12, 1)
+  rng = np.random.default_rng(1)
+  th = vo.conv_init_params(ansatz, geom, L, rng).astype(np.float64)
+  th += 0.05 * rng.standard_normal(th.size)
+  cfg = vo.random_configurations(n, 5, np.random.RandomState(2))
+  logit = vo.conv_forward(th, cfg, ansatz, geom, L, 'tanh', np.float64)
+  x = torch.tensor(cfg, dtype=torch.float64).reshape(-1, 1, n)
+  tl = [(torch.tensor(w[:, 0], requires_grad=True), torch.tensor(b.copy(), requires_grad=True))
+        for w, b in vo.conv_unpack(th, ansatz, geom, L)]
+
+  def pconv(x, w, b):
+    kk = w.shape[0]
+    lo = (kk - 1) // 2 if kk % 2 else kk // 2
+    hi = (kk - 1) // 2 if kk % 2 else kk // 2 - 1
+    xp = torch.cat([x[..., x.shape[2] - lo:], x, x[..., :hi]], 2)
+    return torch.nn.functional.conv1d(xp, w.permute(2, 1, 0), b)
+
+  if ansatz == 'conv_1d':
+    a = x
+    for l, (w, b) in enumerate(tl):
+      a = pconv(a, w, b)
+      if l + 1 != len(tl):
+        a = torch.tanh(a)
+  else:
+    a = pconv(x, *tl[0])
+    for blk in range(L):
+      a = a + pconv(torch.selu(pconv(a, *tl[1 + 2 * blk])), *tl[2 + 2 * blk])
+  t_logit = a.sum((1, 2))
+  np.testing.assert_allclose(logit, t_logit.detach().numpy(), rtol=0, atol=1e-12)
+  wts = torch.tensor(rng.standard_normal(5))
+  (t_logit * wts).sum().backward()
+  tg = np.concatenate([np.concatenate([w.grad.numpy().ravel(), b.grad.numpy().ravel()]) for w, b in tl])
+  g = vo.ANSATZ[ansatz][2](th, cfg, wts.numpy(), geom, L, nonlinearity='tanh', dtype=np.float64)[0]
+  np.testing.assert_allclose(g, tg, rtol=0, atol=1e-11 * max(1.0, np.abs(tg).max()))
