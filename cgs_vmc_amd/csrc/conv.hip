@@ -250,10 +250,17 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
       }
     }
   };
-  // a wave's tiles in pairs (2w, 2w+1), (2w + 2 NW, ...); an odd last tile runs alone
+  // a wave's tiles in pairs (2w, 2w+1), (2w + 2 NW, ...); an odd last tile runs alone.  With more
+  // than 25 taps (6 x 6: 144 weight registers) the pair's second accumulator set would spill, so
+  // those kernels take the two tiles one after the other.
+  constexpr bool PAIR = K * KW <= 25;
   for (int t0 = 2 * wave; t0 < n_tiles; t0 += 2 * CONV_WAVES) {
-    if (t0 + 1 < n_tiles) tiles(t0, std::integral_constant<int, 2>{});
-    else tiles(t0, std::integral_constant<int, 1>{});
+    if (PAIR && t0 + 1 < n_tiles) {
+      tiles(t0, std::integral_constant<int, 2>{});
+    } else {
+      tiles(t0, std::integral_constant<int, 1>{});
+      if (!PAIR && t0 + 1 < n_tiles) tiles(t0 + 1, std::integral_constant<int, 1>{});
+    }
   }
 }
 
