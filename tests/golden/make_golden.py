@@ -102,7 +102,55 @@ def build_rbm_case(name):
   return out
 
 
+CONV_CASES = {
+    # name: (ansatz, geom = (filters, kernel, size_x, size_y), num_layers / blocks, B, bonds, nonlinearity)
+    'conv2d_4x4': ('conv_2d', (8, 3, 4, 4), 2, 32, vo.torus_bonds(4, 4), 'relu'),
+    'conv2d_6x4_even': ('conv_2d', (16, 4, 6, 4), 3, 24, vo.torus_bonds(4, 6), 'tanh'),
+    'resnet2d_4x4': ('res_net_2d', (8, 3, 4, 4), 1, 32, vo.torus_bonds(4, 4), 'relu'),
+    'conv1d_12_even': ('conv_1d', (8, 4, 12, 1), 3, 24, vo.chain_bonds(12), 'relu'),
+    'resnet1d_12': ('res_net_1d', (16, 5, 12, 1), 2, 24, vo.chain_bonds(12), 'relu'),
+}
+
+
+def build_conv_case(name):
+  """Same quantities as build_rbm_case for the convolutional ansatz types
+  (tests/golden/conv_small.npz); `scale` = sum |last feature map|, the fp32 summation scale the
+  logit tolerance is stated on."""
+  ansatz, geom, L, b, bonds, nonlin = CONV_CASES[name]
+  n = geom[2] * geom[3]
+  rng = np.random.default_rng(31 + sorted(CONV_CASES).index(name))
+  theta = vo.conv_init_params(ansatz, geom, L, rng)
+  theta = (theta + 0.03 * rng.standard_normal(theta.size)).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(7))
+  f64 = np.float64
+  amp = lambda c: vo.ANSATZ[ansatz][0](theta, c, geom, L, nonlinearity=nonlin, dtype=f64)
+  out = dict(theta=theta, configs=cfg, bonds=np.asarray(bonds, np.int32),
+             shape=np.array(list(geom) + [L, b]), seed=np.array([SEED]), couplings=np.array([JX, JZ, BETA]))
+  out['logit'], out['scale'] = vo.conv_forward(theta, cfg, ansatz, geom, L, nonlin, f64, return_tape='scale')
+  out['eloc'] = vo.local_value(amp, cfg, bonds, JX, JZ, dtype=f64)
+  u_sites, u_acc = vo.step_uniforms(SEED, np.arange(b), 3, n)
+  i_up, i_dn = vo.propose_exchange(cfg, u_sites)
+  _, acc, ratio = vo.mc_step(amp, cfg, i_up, i_dn, u_acc)
+  out.update(i_up=i_up.astype(np.int32), i_dn=i_dn.astype(np.int32), u_accept=u_acc, accept=acc,
+             ratio=ratio)
+  acc_eg = vo.Accumulators(theta.size, f64)
+  vo.energy_gradient_accumulate(acc_eg, theta, cfg, bonds, JX, JZ, -10.0, geom, L, f64, ansatz=ansatz,
+                                nonlinearity=nonlin)
+  out['eg_g1'], out['eg_g2'] = acc_eg.g1_total, acc_eg.g2_total
+  out['eg_grad'] = vo.energy_gradient(acc_eg)
+  return out
+
+
 def main():
+  conv = {}
+  for name in CONV_CASES:
+    for k, v in build_conv_case(name).items():
+      conv['{}/{}'.format(name, k)] = v
+  path = os.path.join(HERE, 'conv_small.npz')
+  np.savez_compressed(path, **conv)
+  print('wrote', path, os.path.getsize(path), 'bytes')
+  if '--conv-only' in sys.argv:
+    return
   rbm = {}
   for name in RBM_CASES:
     for k, v in build_rbm_case(name).items():

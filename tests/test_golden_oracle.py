@@ -33,3 +33,15 @@ def test_oracle_reproduces_rbm_golden_file():
         np.testing.assert_allclose(g, v, rtol=1e-12, atol=1e-12, err_msg='{}/{}'.format(name, k))
       else:
         np.testing.assert_array_equal(g, v, err_msg='{}/{}'.format(name, k))
+
+
+def test_oracle_reproduces_conv_golden_file():
+  gold = np.load(os.path.join(HERE, 'golden', 'conv_small.npz'))
+  for name in make_golden.CONV_CASES:
+    fresh = make_golden.build_conv_case(name)
+    for k, v in fresh.items():
+      g = gold['{}/{}'.format(name, k)]
+      if np.issubdtype(np.asarray(v).dtype, np.floating):
+        np.testing.assert_allclose(g, v, rtol=1e-11, atol=1e-11, err_msg='{}/{}'.format(name, k))
+      else:
+        np.testing.assert_array_equal(g, v, err_msg='{}/{}'.format(name, k))

@@ -119,3 +119,36 @@ def test_rbm_golden(name):
   band = np.abs(g['ratio'] - np.sqrt(g['u_accept'].astype(np.float64))) < 1e-4 * np.maximum(g['ratio'], 1e-30)
   np.testing.assert_array_equal(mask[~band], g['accept'][~band])
   eng.close()
+
+
+@pytest.mark.parametrize('name', ['conv2d_4x4', 'conv2d_6x4_even', 'resnet2d_4x4', 'conv1d_12_even', 'resnet1d_12'])
+def test_conv_golden(name):
+  """Convolutional ansatz types against tests/golden/conv_small.npz (tolerances of
+  tests/test_gpu_conv.py: logits on the fp32 summation scale)."""
+  from cgs_vmc_amd.engine import VmcEngine
+  gold = np.load(os.path.join(HERE, 'golden', 'conv_small.npz'))
+  g = {k.split('/', 1)[1]: gold[k] for k in gold.files if k.startswith(name + '/')}
+  f, k, sx, sy, L, b = [int(x) for x in g['shape']]
+  ansatz = {'conv2d': 'conv_2d', 'resnet2d': 'res_net_2d', 'conv1d': 'conv_1d', 'resnet1d': 'res_net_1d'}[name.split('_')[0]]
+  nonlin = 'tanh' if name == 'conv2d_6x4_even' else 'relu'
+  eng = VmcEngine(sx * sy, b, L, f, nonlinearity=nonlin, seed=int(g['seed'][0]), ansatz=ansatz, kernel_size=k,
+                  size_x=sx, size_y=sy)
+  eng.set_params(g['theta']); eng.set_configs(g['configs'])
+  jx, jz, _ = g['couplings']
+  eng.set_bonds(g['bonds'], jx, jz)
+  logit, _ = eng.amplitude()
+  assert (np.abs(logit - g['logit']) <= 1e-6 * g['scale'] + 2e-5).all()
+  eloc, _ = eng.local_energy()
+  assert np.abs(eloc - g['eloc']).max() < 2e-4 * max(1.0, np.abs(g['eloc']).max())
+  i_up, i_dn, u = eng.debug_proposals(3)
+  np.testing.assert_array_equal(i_up, g['i_up'])
+  np.testing.assert_array_equal(i_dn, g['i_dn'])
+  np.testing.assert_array_equal(u, g['u_accept'])
+  eng.reset_accumulators()
+  eng.accumulate(0)
+  grad = eng.get_gradient(0)
+  assert np.abs(grad - g['eg_grad']).max() < 2e-3 * np.abs(g['eg_grad']).max() + 2e-4
+  mask = eng.mc_step_injected(g['i_up'], g['i_dn'], g['u_accept'])
+  band = np.abs(g['ratio'] - np.sqrt(g['u_accept'].astype(np.float64))) < 1e-4 * np.maximum(g['ratio'], 1e-30)
+  np.testing.assert_array_equal(mask[~band], g['accept'][~band])
+  eng.close()
