@@ -200,7 +200,77 @@ def cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg, ansatz='fully_connected', k
     # reported baseline is the faster of the two configurations
     out['value'], out['cores'], out['sample'] = st['value'], 1, st['sample'] + '; numpy fp32 restatement of the reference algorithm (TensorFlow 1.x unavailable)'
   out['gflops'] = flops_per_chain_step * out['value'] / 1e9
+  if not conv:
+    try:
+      out['torch_cpu'] = torch_cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg,
+                                            bs=min(cfg.shape[0], 256), mc_steps_timed=max(2, min(n, 10)))
+    except Exception as e:  # pylint: disable=broad-except
+      out['torch_cpu'] = {'error': repr(e)}
   return out
+
+
+def torch_cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg, bs=256, mc_steps_timed=10):
+  """The same reference structure on torch-CPU tensors (fully_connected only): 1 + n_bonds
+  full-batch forwards and two autograd backward passes per accumulate (training.py:542-547), two
+  forwards per mc_step (graph_builders.py:54-55, 74); median of 3 on `bs` chains."""
+  import torch
+  torch.manual_seed(0)
+  th = torch.tensor(theta)
+  shapes, off, params = [], 0, []
+  fan = n
+  for l in range(L + 1):
+    out = h if l < L else 1
+    w = th[off:off + fan * out].reshape(fan, out).clone().requires_grad_(True); off += fan * out
+    b = th[off:off + out].clone().requires_grad_(True); off += out
+    params += [w, b]; fan = out
+  def logit(x):
+    a = x
+    for l in range(L):
+      a = torch.relu(a @ params[2 * l] + params[2 * l + 1])
+    return (a @ params[2 * L] + params[2 * L + 1])[:, 0]
+  x0 = torch.tensor(np.ascontiguousarray(cfg[:bs]))
+  ij = torch.tensor(np.asarray(bonds, np.int64))
+  hx = torch.tensor(0.5 * np.asarray(jx, np.float32)); qz = torch.tensor(0.25 * np.asarray(jz, np.float32))
+  def accumulate():
+    with torch.no_grad():
+      psi = torch.exp(logit(x0) + 10.0)
+      diag = torch.zeros(bs); offd = torch.zeros(bs)
+      for k in range(ij.shape[0]):
+        i, j = int(ij[k, 0]), int(ij[k, 1])
+        si, sj = x0[:, i], x0[:, j]
+        upd = x0.clone(); upd[:, i] = sj; upd[:, j] = si
+        sz = si * sj
+        offd += hx[k] * (sz < 0).float() * torch.exp(logit(upd) + 10.0)
+        diag += qz[k] * sz
+      eloc = diag + offd / psi
+    lg = logit(x0)
+    g1 = torch.autograd.grad(lg.sum(), params, retain_graph=True)
+    g2 = torch.autograd.grad((lg * eloc).sum(), params)
+    return g1, g2
+  def sweep(steps):
+    x = x0.clone()
+    rows = torch.arange(bs)
+    with torch.no_grad():
+      for _ in range(steps):
+        u = torch.rand(bs, n)
+        sc = x * u
+        i_up, i_dn = sc.argmax(1), sc.argmin(1)
+        psi = torch.exp(logit(x) + 10.0)
+        upd = x.clone(); upd[rows, i_dn] += 2.0; upd[rows, i_up] -= 2.0
+        ratio = torch.exp(logit(upd) + 10.0).abs() / psi.abs()
+        acc = ratio > torch.rand(bs).sqrt()
+        x[acc] = upd[acc]
+  runs = []
+  for _ in range(3):
+    t0 = time.perf_counter(); accumulate(); t_acc = time.perf_counter() - t0
+    t0 = time.perf_counter(); sweep(mc_steps_timed); t_sw = (time.perf_counter() - t0) * (n / float(mc_steps_timed))
+    runs.append((t_acc, t_sw))
+  runs.sort(key=lambda r: r[0] + r[1])
+  t_acc, t_sw = runs[1]
+  return {'value': bs / (t_acc + t_sw), 'unit': 'chain-evals/s', 'cores': int(torch.get_num_threads()),
+          'sample': 'median of 3: {} chains x 1 step (accumulate {:.2f} s + sweep {:.2f} s scaled from {} of {} '
+                    'mc_steps); torch {} CPU tensors, {} threads'.format(bs, t_acc, t_sw, mc_steps_timed, n,
+                                                                        torch.__version__, torch.get_num_threads())}
 
 
 # ----------------------------------------------------------------------------- rank launcher
