@@ -202,8 +202,16 @@ def cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg, ansatz='fully_connected', k
   out['gflops'] = flops_per_chain_step * out['value'] / 1e9
   if not conv:
     try:
-      out['torch_cpu'] = torch_cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg,
-                                            bs=min(cfg.shape[0], 256), mc_steps_timed=max(2, min(n, 10)))
+      import torch
+      default_threads = torch.get_num_threads()
+      variants = {}
+      for nt in (1, default_threads):      # one core and torch's default intra-op pool
+        torch.set_num_threads(nt)
+        variants['threads_{}'.format(nt)] = torch_cpu_baseline(
+            n, h, L, bonds, jx, jz, theta, cfg, bs=min(cfg.shape[0], 64 if nt == 1 else 256),
+            mc_steps_timed=max(2, min(n, 10)))
+      torch.set_num_threads(default_threads)
+      out['torch_cpu'] = variants
     except Exception as e:  # pylint: disable=broad-except
       out['torch_cpu'] = {'error': repr(e)}
   return out
