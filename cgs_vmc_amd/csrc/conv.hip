@@ -1,5 +1,6 @@
-// Convolutional ansatz kernels (Conv2DNetwork / ResNet2D, wavefunctions.py:531-615, 710-809) for
-// gfx950.  See DESIGN.md 4 "Convolutional ansatz".
+// Convolutional ansatz kernels (Conv2DNetwork / ResNet2D, wavefunctions.py:531-615, 710-809, and
+// their 1-D siblings Conv1DNetwork / ResNet1D, 455-527, 618-707, as k x 1 taps on an N x 1 lattice)
+// for gfx950.  See DESIGN.md 4 "Convolutional ansatz types".
 //
 // A periodic convolution with <= 16 channels is an implicit GEMM whose output tile is exactly one
 // v_mfma_f32_16x16x4_f32 tile: 16 output channels x 16 lattice positions, reduced over
@@ -16,7 +17,7 @@
 // 4 waves per workgroup (one per SIMD) and two workgroups per CU: the two co-resident workgroups are
 // never in step, so the serial phases of one (row staging behind dependent global loads, the
 // per-layer weight-fragment reload, barriers, the final reduction) run under the MFMAs of the
-// other.  One 8-wave workgroup per CU measured 0.64 of the fp32-MFMA peak on the same loops.
+// other (one 4-wave workgroup per CU: 0.58 of the fp32-MFMA peak against 0.72 for two).
 #define CONV_WAVES 4
 #define CONV_THREADS (CONV_WAVES * 64)
 #define CONV_LDS_PER_WG (80 * 1024)   // two workgroups share the 160 KiB of a CU
