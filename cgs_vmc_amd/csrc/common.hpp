@@ -200,6 +200,7 @@ struct SweepArgs {
   float* dact_out;          // [L][B][Hp] f'(z) of the final chains (cosine only) or nullptr
   int waves;                // waves per workgroup of the sweep kernel (4 or 8)
   int no_w1l;               // 1: never hold W1 in LDS (the two-workgroups-per-CU variant)
+  int co;                   // 1: the co-resident variant k_sweep16_co (H = 256, relu, N <= 128; ignored otherwise)
   int cache_in_valid;       // z1 / logit already hold the exact cache of `configs`
   float* act_out;           // [L][B][Hp] activations of the final chains (gradient path) or nullptr
   int B, N, n_hidden;
@@ -224,6 +225,10 @@ hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, 
                          float* out);
 hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n);
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp);
+// the CU-sharing pair (tail_co.hip / k_sweep16_co): LDS footprints and the row kernel's launcher
+size_t tail_co_lds_bytes(int n_hidden);
+size_t sweep_co_lds_bytes(int N, int n_hidden);
+hipError_t launch_tail_co(hipStream_t s, const TailArgs& a, size_t lds_bytes);
 size_t sweep_lds_required(int N, int Hp, int n_hidden, bool rbm);
 
 // bond list / local-energy reduction (eloc.hip)

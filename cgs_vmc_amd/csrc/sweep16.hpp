@@ -12,6 +12,15 @@
 #ifndef SWEEP_OCC0
 #define SWEEP_OCC0 4    // waves per SIMD the all-streamed (RTP = 0) H = 256 variant is compiled for
 #endif
+#ifndef SWEEP_RT_CO
+#define SWEEP_RT_CO 0     // resident k-tiles of the co-resident variant k_sweep16_co
+#endif
+#ifndef SWEEP_VGPR_CO
+#define SWEEP_VGPR_CO 100 // its register budget (two waves per SIMD + one wave of k_tail_co <= 512)
+#endif
+#ifndef SWEEP_CO_PRIO
+#define SWEEP_CO_PRIO 3
+#endif
 #ifndef SWEEP_PF
 #define SWEEP_PF 2    // stages of the weight prefetch ring; (16 - SWEEP_RT) % SWEEP_PF == 0
 #endif
@@ -72,7 +81,7 @@ __device__ __forceinline__ unsigned long long vmc_stamp() {
 // UPRE: Philox site blocks per lane drawn one step ahead (2: N <= 128 sites, 4: N <= 256).
 // ACT: hidden activation (layers.NONLINEARITIES id); relu is the tuned path.
 template <int NT, int NW, int RTP, bool STAMP, bool W1L, bool FAST, int UPRE, bool RBM, int ACT>
-__global__ __launch_bounds__(NW * 64, NT == 16 ? (RTP == 0 ? SWEEP_OCC0 : 2) : 1) void k_sweep16(SweepArgs a) {
+__device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   static_assert(NT % NW == 0, "output tiles must divide over the waves");
   constexpr int NTH = NW * 64;
   constexpr int Hp = NT * 16, TO = NT / NW, ZS = Hp + 4, W1S = Hp + 4, PF = SWEEP_PF;
@@ -693,6 +702,24 @@ __global__ __launch_bounds__(NW * 64, NT == 16 ? (RTP == 0 ? SWEEP_OCC0 : 2) : 1
   if (j == 0 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);   // waves 0-3 only
 }
 
+template <int NT, int NW, int RTP, bool STAMP, bool W1L, bool FAST, int UPRE, bool RBM, int ACT>
+__global__ __launch_bounds__(NW * 64, NT == 16 ? (RTP == 0 ? SWEEP_OCC0 : 2) : 1) void k_sweep16(SweepArgs a) {
+  sweep16_body<NT, NW, RTP, STAMP, W1L, FAST, UPRE, RBM, ACT>(a);
+}
+
+// The co-resident variant (H = 256, production path only): SWEEP_RT_CO resident k-tiles, W1 in
+// L2 and at most SWEEP_VGPR_CO registers, so that its two waves per SIMD leave 512 - 2 x
+// SWEEP_VGPR_CO registers of every SIMD -- and half the LDS -- to one wave of k_tail_co
+// (tail_co.hpp), which evaluates local energies in the matrix-pipe time the sampler's serial
+// phases leave idle.
+template <int ACT>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(SWEEP_VGPR_CO)))
+void k_sweep16_co(SweepArgs a) {
+  // the sampler's mc_step is the critical path of the pair: its waves issue ahead of k_tail_co's
+  __builtin_amdgcn_s_setprio(SWEEP_CO_PRIO);
+  sweep16_body<16, 8, SWEEP_RT_CO, false, false, true, 2, false, ACT>(a);
+}
+
 static inline size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool rbm) {
   const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
   return sizeof(float) * (size_t)(16 * Nst + (w1l ? 1 : 2) * 16 * ZS + 2 * NT * 256 + 16 +
@@ -719,6 +746,16 @@ static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
     return hipGetLastError();                                                                 \
   } while (0)
   constexpr bool TUNED = ACT == VMC_ACT_RELU_;   // other activations only get the general variant
+  if constexpr (TUNED && NT == 16 && NW == 8 && !RBM) {
+    if (a.co && fast2 && !a.dbg_cycles) {   // co-resident variant: W1 in L2, capped registers
+      const size_t lds_co = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false, false);
+      hipError_t e = hipFuncSetAttribute((const void*)k_sweep16_co<ACT>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_co);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((k_sweep16_co<ACT>), grid, block, lds_co, s, a);
+      return hipGetLastError();
+    }
+  }
   if (a.dbg_cycles) {
     if (!(w1l && fast2) || RBM || NT != 16 || !TUNED) return hipErrorInvalidValue;   // diagnostic build: production variant only
     if constexpr (!RBM && NT == 16 && TUNED) SWEEP_LAUNCH(true, true, true, 2);

@@ -117,6 +117,9 @@ struct vmc_ctx {
   int num_cus = 256;
   int sweep_waves = 8;       // waves per sweep workgroup at Hp = 256 (CGS_VMC_SWEEP_WAVES=4|8)
   int sweep_no_w1l = 0;      // CGS_VMC_SWEEP_W1L=0: W1 stays in L2 (smaller LDS footprint)
+  int sweep_co = 0;          // CGS_VMC_SWEEP_CO=1: force the co-resident sampler variant (diagnostic)
+  bool co = false;           // sampler and local-energy kernel share every CU (k_sweep16_co + k_tail_co)
+  size_t co_lds = 0;         // padded LDS request of k_tail_co (> half a CU: never two of them per CU)
   // stochastic reconfiguration (extension, sr.hip): sample store + CG vectors
   int sr_cap = 0, sr_n = 0, sr_iter = 0;
   float *sr_cfg = nullptr, *sr_act = nullptr, *sr_delta = nullptr;   // [cap B][N], [L][cap B][Hp] x2
@@ -192,8 +195,13 @@ int sweep_cus(const vmc_ctx* c) { return (c->B + 15) / 16; }
 // The sampler may overtake the accumulate enqueued just before it when it leaves the local-energy
 // kernel at least a quarter of the CUs; with one 16-chain tile per CU (config 3) there is nothing
 // to share and the launch stays on `stream`.
+// ... unless the CU-sharing pair applies (c->co): k_sweep16_co and k_tail_co are sized so that one
+// workgroup of each is resident per CU, and the row kernel's MFMAs fill the sampler's serial phases.
+bool co_active(const vmc_ctx* c) {
+  return c->overlap && c->co && sweep_cus(c) > (3 * c->num_cus) / 4;
+}
 bool can_overlap(const vmc_ctx* c) {
-  return c->overlap && (c->overlap_full || sweep_cus(c) <= (3 * c->num_cus) / 4);
+  return c->overlap && (c->overlap_full || co_active(c) || sweep_cus(c) <= (3 * c->num_cus) / 4);
 }
 
 int join_sweep(vmc_ctx* c) {
@@ -462,7 +470,11 @@ int local_energy_device(vmc_ctx* c, int which) {
     // CU each, so the persistent grid leaves them free
     if (c->expect_sweep && can_overlap(c) && c->num_cus - sweep_cus(c) >= c->num_cus / 4)
       a.num_cus = c->num_cus - sweep_cus(c);
-    HIPCHK(c, launch_tail(c->stream, a, c->Hp, true, c->rbm));
+    if (c->expect_sweep && co_active(c) && which == 0) {
+      HIPCHK(c, launch_tail_co(c->stream, a, c->co_lds));   // shares each CU with the overtaking sampler
+    } else {
+      HIPCHK(c, launch_tail(c->stream, a, c->Hp, true, c->rbm));
+    }
   }
   {
     Timer t(c, "eloc_reduce");
@@ -607,6 +619,25 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
               : vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
   c->stream = (hipStream_t)d->stream;
   if (const char* e = getenv("CGS_VMC_SWEEP_W1L")) c->sweep_no_w1l = atoi(e) == 0 ? 1 : 0;
+  if (const char* e = getenv("CGS_VMC_SWEEP_CO")) c->sweep_co = atoi(e) != 0 ? 1 : 0;
+  {
+    // the CU-sharing pair: fully_connected, relu, H = 256, N <= 128 (the prefetched-Philox sampler),
+    // and both LDS footprints (in 1280-byte granules) fit one CU with the row kernel above half of it
+    const bool shape = !conv && !wide && !c->rbm && c->hact == VMC_ACT_RELU_ && c->Hp == 256 &&
+                       c->n_hh >= 1 && c->N <= 128;
+    if (shape) {
+      const size_t gran = 1280, cu = 160 * 1024;
+      const size_t sw = (sweep_co_lds_bytes(c->N, c->n_hh) + gran - 1) / gran * gran;
+      size_t tl = tail_co_lds_bytes(c->n_hh);
+      if (tl < cu / 2 + gran) tl = cu / 2 + gran;
+      tl = (tl + gran - 1) / gran * gran;
+      c->co = sw + tl <= cu;
+      c->co_lds = tl;
+    }
+    // measured slower than the separate kernels at config 3 (2.07 vs 2.04 ms): opt-in only
+    const char* e = getenv("CGS_VMC_CO");
+    c->co = c->co && e && atoi(e) != 0;
+  }
   if (const char* e = getenv("CGS_VMC_OVERLAP")) { c->overlap = !conv && !wide && atoi(e) != 0; c->overlap_full = atoi(e) == 2; }
   {
     hipDeviceProp_t prop;
@@ -946,6 +977,7 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = step0; a.n_steps = n_steps;
   a.waves = c->sweep_waves; a.no_w1l = c->sweep_no_w1l;
+  a.co = (c->sweep_co || (overtake && co_active(c) && c->expect_sweep)) ? 1 : 0;
   a.act = c->hact; a.oact = c->oact;
   // the activations of the final chains are handed to the gradient path only when a gradient
   // accumulate has been seen since the previous launch (equilibration / evaluation sweeps skip
