@@ -469,26 +469,29 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   // layers 2..L + output dot; leaves per-wave partial logits in s_part.
   // Weight stream = [(layer 0, ti = RT..NT-1), (layer 1, all ti), ...] through a PF-stage
   // register ring; item q lives in stage q % PF and is issued PF-1 items ahead of its use.
+  // The ring lives across mc_steps: the last PF-1 issues of a pass fetch the first streamed
+  // fragments of the NEXT pass (the weights do not change during a launch), so a pass neither
+  // ends on a wait for fragments nobody reads nor starts with an exposed prologue.
+  f32x4 wb[PF][TO];
+  auto issue = [&](int l, int ti, int stage) {
+    // uniform (SGPR) base + one per-lane offset register
+    const f32x4* __restrict__ wp =
+        (const f32x4*)(pp.p16 + (long long)l * Hp * Hp) + (wave * TO * NT + ti) * 64;
+#pragma unroll
+    for (int to = 0; to < TO; ++to) wb[stage][to] = wp[to * NT * 64 + lane];
+  };
+  const int l_last = n_hidden - 1;
+  // first stream item of a pass: layer 0's first streamed k-tile, or (all of layer 0 resident)
+  // layer 1's first k-tile
+  const int ring_l0 = RT < NT ? 0 : min(1, l_last);
+  constexpr int ring_t0 = RT < NT ? RT : 0;
+  if (n_hidden > 0) {
+#pragma unroll
+    for (int st = 0; st < PF - 1; ++st) issue(ring_l0, ring_t0 + st, st);
+  }
   auto forward = [&](unsigned long long next_step) {
-    f32x4 wb[PF][TO];
-    auto issue = [&](int l, int ti, int stage) {
-      // uniform (SGPR) base + one per-lane offset register
-      const f32x4* __restrict__ wp =
-          (const f32x4*)(pp.p16 + (long long)l * Hp * Hp) + (wave * TO * NT + ti) * 64;
-#pragma unroll
-      for (int to = 0; to < TO; ++to) wb[stage][to] = wp[to * NT * 64 + lane];
-    };
-    // prologue of the ring.  Every issue below is unconditional (layer index clamped to the
-    // last layer) so that the compiler can count vmcnt exactly; a load issued under a runtime
-    // condition makes it wait for ALL outstanding loads at the next use.
-    const int l_last = n_hidden - 1;
-    if (RT < NT) {
-#pragma unroll
-      for (int st = 0; st < PF - 1; ++st) issue(0, RT + st, st);
-    } else {
-#pragma unroll
-      for (int st = 0; st < PF - 1; ++st) issue(min(1, l_last), st, st);
-    }
+    // Every issue below is unconditional so that the compiler can count vmcnt exactly; a load
+    // issued under a runtime condition makes it wait for ALL outstanding loads at the next use.
     int cur = 0;
     // FS = first streamed k-tile of the layer (RT for layer 0, 0 afterwards)
     auto layer = [&](int l, auto fs_c, auto first_c) {
@@ -544,7 +547,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       for (int ti = FS; ti < NT; ++ti) {
         const int tn = ti + PF - 1;
         if (tn < NT) issue(l, tn, (tn - FS) % PF);
-        else issue(min(l + 1, l_last), tn - NT, (tn - FS) % PF);
+        else issue(l < l_last ? l + 1 : ring_l0, l < l_last ? tn - NT : ring_t0 + tn - NT, (tn - FS) % PF);
         if (ti + 1 < NT) inb[(ti + 1) & 1] = xin[(ti + 1) * 64];
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetches ahead of this tile's MFMAs
 #pragma unroll
