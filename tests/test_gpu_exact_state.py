@@ -1,0 +1,62 @@
+"""GPU known-answer test that does not go through the oracle's restatement of the network: a
+fully_connected ansatz whose parameters are solved (tests/exact_states.py, fp64 ED + least squares)
+so that psi IS the Heisenberg ground state on the whole Sz = 0 sector.  Then, on the HIP path:
+E_loc(R) == E0 for every configuration before and after sampling, the covariance gradient vanishes,
+and the sampler's stationary distribution reproduces the exact nearest-neighbour correlation."""
+import numpy as np
+import pytest
+
+from oracle import vmc_oracle as vo
+from tests.exact_states import exact_fc_eigenstate
+
+pytestmark = pytest.mark.gpu
+
+
+# (8 sites, 2 x 128): one H x H layer on the 4-wave kernels; (10 sites, 3 x 256): the config-3 kernels
+@pytest.mark.parametrize('n,h,L', [(8, 128, 2), (10, 256, 3)])
+def test_exact_eigenstate_on_the_hip_path(n, h, L):
+  from cgs_vmc_amd import _hip
+  from cgs_vmc_amd.engine import VmcEngine
+  bonds = vo.chain_bonds(n)
+  theta, e0, cfgs, vec = exact_fc_eigenstate(n, bonds, h, L)
+  b = len(cfgs)                                   # 70 / 252: every configuration of the sector once
+  eng = VmcEngine(n, b, L, h, seed=5)
+  eng.set_params(theta)
+  eng.set_shift(0.0)
+  eng.set_configs(cfgs)
+  eng.set_bonds(bonds, -1.0, 1.0)
+
+  logit = eng.amplitude()[0]
+  assert np.abs(logit - np.log(vec)).max() < 2e-4
+  e = eng.local_energy()[0]
+  assert np.abs(e - e0).max() < 2e-3              # fp32 evaluation of an fp64-exact eigenstate
+
+  # zero-variance principle (training.py:560-564): <E O> - <E><O> = 0 when E_loc is constant
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  g = eng.get_gradient(_hip.VMC_MODE_ENERGY_GRADIENT)
+  acc = eng.get_accumulators()
+  p = theta.size
+  scale = np.abs(acc[p:2 * p]).max() / b          # |mean of E_loc O_k|, the size of either term
+  assert np.abs(g).max() < 2e-3 * scale
+  assert abs(eng.mean_energy() - e0) < 2e-3
+
+  # sampling: E_loc stays E0 on every chain, and the chains sample |psi|^2: the exact
+  # nearest-neighbour correlation <s_i s_i+1> = sum_R psi(R)^2 s_i s_i+1 (translation invariant)
+  exact = float(np.mean([(vec ** 2 * cfgs[:, i] * cfgs[:, j]).sum() for (i, j) in bonds]))
+  eng.mc_steps(20 * n)
+  snaps = 150
+  corr = 0.0
+  for _ in range(snaps):
+    eng.mc_steps(n)
+    c = eng.get_configs()
+    corr += np.mean([np.mean(c[:, i] * c[:, j]) for (i, j) in bonds])
+  corr /= snaps
+  # b * snaps * n bond samples, strongly correlated within a configuration: ~ b * snaps independent
+  sigma = 1.0 / np.sqrt(b * snaps)
+  assert abs(corr - exact) < 5 * sigma, (corr, exact)
+  e = eng.local_energy()[0]
+  assert np.abs(e - e0).max() < 2e-3
+  out = eng.get_configs()
+  assert (out.sum(1) == 0).all()
+  eng.close()

@@ -9,6 +9,7 @@ import scipy.sparse.linalg as spla
 import torch
 
 from oracle import vmc_oracle as vo
+from tests.exact_states import ed_ground_state as _ed_ground_state, exact_fc_eigenstate
 
 
 def _setup(n=8, h=16, L=2, b=12, seed=0):
@@ -36,33 +37,6 @@ def test_constant_psi_closed_form():
       amp = lambda c: np.full(c.shape[0], 3.7, np.float32)
       e = vo.local_value(amp, cfg, bonds, jx, 1.0)
       np.testing.assert_allclose(e, vo.constant_psi_local_energy(cfg, bonds, jx, 1.0), rtol=1e-6)
-
-
-def _ed_ground_state(n, bonds, jx, jz):
-  """Exact ground state in the Sz=0 sector, basis = all +-1 configs with n/2 downs."""
-  basis = [c for c in itertools.combinations(range(n), n // 2)]
-  index = {c: k for k, c in enumerate(basis)}
-  cfgs = np.ones((len(basis), n), np.float64)
-  for k, c in enumerate(basis):
-    cfgs[k, list(c)] = -1
-  rows, cols, vals = [], [], []
-  for k, c in enumerate(basis):
-    down = set(c)
-    d = 0.0
-    for (i, j) in bonds:
-      sz = cfgs[k, i] * cfgs[k, j]
-      d += 0.25 * jz * sz
-      if sz < 0:
-        nd = set(down)
-        if i in nd:
-          nd.remove(i); nd.add(j)
-        else:
-          nd.remove(j); nd.add(i)
-        rows.append(k); cols.append(index[tuple(sorted(nd))]); vals.append(0.5 * jx)
-    rows.append(k); cols.append(k); vals.append(d)
-  hmat = sp.csr_matrix((vals, (rows, cols)), shape=(len(basis),) * 2)
-  w, v = spla.eigsh(hmat, k=1, which='SA')
-  return w[0], v[:, 0], cfgs, index
 
 
 @pytest.mark.parametrize('n,bonds,jx', [
@@ -422,3 +396,23 @@ def test_conv1d_oracle_against_torch_autograd(ansatz, L, k):
   tg = np.concatenate([np.concatenate([w.grad.numpy().ravel(), b.grad.numpy().ravel()]) for w, b in tl])
   g = vo.ANSATZ[ansatz][2](th, cfg, wts.numpy(), geom, L, nonlinearity='tanh', dtype=np.float64)[0]
   np.testing.assert_allclose(g, tg, rtol=0, atol=1e-11 * max(1.0, np.abs(tg).max()))
+
+
+@pytest.mark.parametrize('n,h,L', [(8, 128, 2), (10, 256, 3)])
+def test_exact_fc_eigenstate_has_constant_local_energy_and_zero_gradient(n, h, L):
+  """A FullyConnectedNetwork that equals the ED ground state (tests/exact_states.py): E_loc == E0 on
+  the whole sector, and the energy gradient <E O> - <E><O> (training.py:560-564) vanishes."""
+  bonds = vo.chain_bonds(n)
+  theta, e0, cfgs, vec = exact_fc_eigenstate(n, bonds, h, L)
+  amp64 = lambda c: vo.fc_psi(theta.astype(np.float64), c, h, L, shift=0.0, dtype=np.float64)
+  e64 = vo.local_value(amp64, cfgs.astype(np.float64), bonds, -1.0, 1.0, dtype=np.float64)
+  assert np.abs(e64 - e0).max() < 1e-4          # fp32-rounded parameters, fp64 arithmetic
+  amp32 = lambda c: vo.fc_psi(theta, c, h, L, shift=0.0)
+  e32 = vo.local_value(amp32, cfgs, bonds, -1.0, 1.0)
+  assert np.abs(e32 - e0).max() < 2e-3          # fp32 arithmetic
+  # zero-variance principle: with E_loc constant the covariance gradient is zero whatever the sampling
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.energy_gradient_accumulate(acc, theta, cfgs, bonds, -1.0, 1.0, 0.0, h, L, dtype=np.float64)
+  g = vo.energy_gradient(acc)
+  scale = np.abs(acc.g2_total / acc.g_count).max()
+  assert np.abs(g).max() < 1e-4 * scale
