@@ -41,6 +41,18 @@ def test_exact_eigenstate_on_the_hip_path(n, h, L):
   assert np.abs(g).max() < 2e-3 * scale
   assert abs(eng.mean_energy() - e0) < 2e-3
 
+  # imaginary-time target of an eigenstate is the eigenstate: with omega = psi the ratio
+  # (1 - beta H) omega / psi = 1 - beta E0 is constant and the log-overlap gradient
+  # (training.py:652-729) vanishes for any set of samples
+  eng.transfer_params()
+  eng.set_shift(0.0, _hip.VMC_OMEGA)
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_LOG_OVERLAP_ITSWO, 0.12)
+  g = eng.get_gradient(_hip.VMC_MODE_LOG_OVERLAP_ITSWO)
+  acc = eng.get_accumulators()
+  scale = np.abs(acc[:p]).max() / b               # |mean of O_k|
+  assert np.abs(g).max() < 2e-3 * scale
+
   # sampling: E_loc stays E0 on every chain, and the chains sample |psi|^2: the exact
   # nearest-neighbour correlation <s_i s_i+1> = sum_R psi(R)^2 s_i s_i+1 (translation invariant)
   exact = float(np.mean([(vec ** 2 * cfgs[:, i] * cfgs[:, j]).sum() for (i, j) in bonds]))
