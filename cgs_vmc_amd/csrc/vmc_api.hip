@@ -777,6 +777,9 @@ void vmc_destroy(vmc_ctx* c) {
 int vmc_set_bonds(vmc_ctx* c, int32_t n_bonds, const int32_t* ij, const float* j_x, const float* j_z) {
   ENTER(c);
   if (n_bonds < 1 || !ij || !j_x || !j_z) return fail(c, VMC_ERR_INVALID, "bad bond arguments");
+  // connected rows are indexed with 32-bit integers (at most one row per chain and bond)
+  if ((long long)c->B * n_bonds > 0x7fffffffLL - c->B)
+    return fail(c, VMC_ERR_UNSUPPORTED, "batch_size x n_bonds does not fit the 32-bit row index");
   std::vector<int2> b(n_bonds);
   std::vector<float> hx(n_bonds), qz(n_bonds);
   for (int k = 0; k < n_bonds; ++k) {
