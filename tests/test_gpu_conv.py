@@ -317,3 +317,63 @@ def test_conv_1d_through_run_training(tmp_path):
   assert -7.1423 - 0.05 < tail < -6.0, (tail, energies[::10])
   ck = session_lib.latest_checkpoint(d)
   assert 'conv_1d_network/conv_1d_periodic_2/conv_1d/w' in set(np.load(ck + '.npz').files)
+
+
+def _random_conv_shapes(count, seed=2025):
+  """Seeded random geometries inside the limits vmc_create states (kernel 1..6, <= 16 filters,
+  lattice sides >= kernel // 2): every padding parity, ragged batches, k larger than a side."""
+  rng = np.random.default_rng(seed)
+  # (tan and exp hidden units are covered by CONV_SHAPES at controlled magnitudes: near a pole of
+  # tan the fp32 error of the pre-activation is amplified without bound)
+  acts = ['relu', 'tanh', 'sigmoid', 'identity']
+  shapes = []
+  while len(shapes) < count:
+    ansatz = ['conv_2d', 'res_net_2d', 'conv_1d', 'res_net_1d'][int(rng.integers(4))]
+    k = int(rng.integers(1, 7))
+    if ansatz in vo.CONV_1D:
+      sx, sy = int(rng.integers(max(2, k // 2), 33)), 1
+    else:
+      sx, sy = int(rng.integers(max(2, k // 2), 9)), int(rng.integers(max(2, k // 2), 9))
+    if (sx * sy) % 2 or sx * sy < 4:
+      continue
+    resnet = ansatz.startswith('res_net')
+    L = int(rng.integers(0, 3)) if resnet else int(rng.integers(1, 5))
+    f = int(rng.integers(1, 17))
+    b = int(rng.integers(1, 41))
+    nonlin = 'relu' if resnet else acts[int(rng.integers(len(acts)))]
+    shapes.append((ansatz, sx, sy, L, f, k, b, nonlin))
+  return shapes
+
+
+RANDOM_SHAPES = _random_conv_shapes(36)
+
+
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', RANDOM_SHAPES,
+                         ids=['{}-{}x{}-L{}-F{}-K{}-B{}-{}'.format(*s) for s in RANDOM_SHAPES])
+def test_conv_random_shapes(ansatz, sx, sy, L, f, k, b, nonlin):
+  """Amplitudes, local energies, one injected mc_step and the gradient sums on random geometries."""
+  from cgs_vmc_amd import _hip
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin, seed=b + 7 * k)
+  n = sx * sy
+  psi_fn = vo.ANSATZ[ansatz][0]
+  amp = lambda c: psi_fn(theta, c, geom, L, nonlinearity=nonlin, dtype=np.float64)
+  _logits_close(eng.amplitude()[0], theta, cfg, ansatz, geom, L, nonlin)
+  e_ref = vo.local_value(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64)
+  _close(eng.local_energy()[0], e_ref, 2e-4)
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, geom, L, np.float64,
+                                ansatz=ansatz, nonlinearity=nonlin)
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  got = eng.get_accumulators()
+  p = theta.size
+  for name, g, r in (('g1', got[:p], acc.g1_total), ('g2', got[p:2 * p], acc.g2_total)):
+    tol = 2e-3 * np.abs(r).max() + 1e-4
+    assert np.abs(g - r).max() < tol, (name, np.abs(g - r).max(), tol, int(np.argmax(np.abs(g - r))))
+  u_sites, u_acc = vo.step_uniforms(5, np.arange(b), 0, n)
+  i_up, i_dn = vo.propose_exchange(cfg, u_sites)
+  _, acc_ref, ratios = vo.mc_step(amp, cfg, i_up, i_dn, u_acc)
+  mask = eng.mc_step_injected(i_up, i_dn, u_acc)
+  band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
+  assert np.array_equal(mask[~band], acc_ref[~band])
+  eng.close()
