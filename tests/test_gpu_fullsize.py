@@ -186,3 +186,62 @@ def test_cu_sharing_pair_matches_separate_kernels(monkeypatch):
   amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
   e_ref = vo.local_value(amp, out1[idx], bonds, *_couplings(name, bonds), dtype=np.float64)
   assert np.abs(e1[idx] - e_ref).max() < 2e-4 * max(1.0, np.abs(e_ref).max())
+
+
+# the convolutional bench workloads (bench.py WORKLOADS) at their full sizes
+FULL_CONV = {
+    'conv10x10_5x16k5_b4096': ('conv_2d', 10, 10, False, 5, 16, 5, 4096),
+    'resnet10x10_2x16k5_b4096': ('res_net_2d', 10, 10, False, 2, 16, 5, 4096),
+    'conv16x16j1j2_5x16k5_b1024': ('conv_2d', 16, 16, True, 5, 16, 5, 1024),
+}
+
+
+@pytest.mark.parametrize('name', sorted(FULL_CONV))
+def test_conv_workloads_full_size_properties(name):
+  """Sz conservation, bit reproducibility, shard invariance, exact logit cache and oracle spot checks
+  (logits, local energies) on sampled chains of the full-size convolutional workloads."""
+  import bench
+  from cgs_vmc_amd.engine import VmcEngine
+  ansatz, lx, ly, nnn, L, f, k, b = FULL_CONV[name]
+  n = lx * ly
+  geom = (f, k, ly, lx)                  # site = x + lx * y: size_x = ly, size_y = lx (bench.py)
+  theta, cfg = bench.make_inputs(n, f, L, b, 0, ansatz, k)
+  bonds = vo.torus_bonds(lx, ly, nnn)
+  if nnn:
+    jz = np.concatenate([np.ones(len(bonds) // 2), 0.5 * np.ones(len(bonds) // 2)]).astype(np.float32)
+    jx = -jz
+  else:
+    jx, jz = -1.0, 1.0
+
+  def make(chains=None, offset=0):
+    c = cfg if chains is None else cfg[offset:offset + chains]
+    eng = VmcEngine(n, len(c), L, f, seed=2024, chain_offset=offset, ansatz=ansatz, kernel_size=k,
+                    size_x=ly, size_y=lx)
+    eng.set_params(theta); eng.set_configs(c); eng.set_bonds(bonds, jx, jz)
+    return eng
+
+  steps = n // 2
+  eng = make()
+  acc = eng.mc_steps(steps)
+  out = eng.get_configs()
+  assert (np.abs(out) == 1).all() and (out.sum(1) == cfg.sum(1)).all() and (out != cfg).any()
+  assert 0 < acc <= steps * b
+  eng2 = make()
+  eng2.mc_steps(steps)
+  np.testing.assert_array_equal(eng2.get_configs(), out)
+  np.testing.assert_array_equal(eng2.local_energy()[0], eng.local_energy()[0])
+  half = make(chains=b // 4, offset=b // 2)
+  half.mc_steps(steps)
+  np.testing.assert_array_equal(half.get_configs(), out[b // 2:b // 2 + b // 4])
+  idx = np.random.default_rng(0).choice(b, 12, replace=False)
+  logit_cached = eng.amplitude()[0]
+  ref, scale = vo.conv_forward(theta, out[idx], ansatz, geom, L, 'relu', np.float64, return_tape='scale')
+  assert (np.abs(logit_cached[idx] - ref) <= 1e-6 * scale + 2e-5).all()
+  assert (np.abs(eng.amplitude(out[idx])[0] - ref) <= 1e-6 * scale + 2e-5).all()
+  psi_fn = vo.ANSATZ[ansatz][0]
+  amp = lambda c: psi_fn(theta, c, geom, L, nonlinearity='relu', dtype=np.float64)
+  e_ref = vo.local_value(amp, out[idx], bonds, jx, jz, dtype=np.float64)
+  e = eng.local_energy()[0]
+  assert np.abs(e[idx] - e_ref).max() < 2e-4 * max(1.0, np.abs(e_ref).max())
+  for x in (eng, eng2, half):
+    x.close()
