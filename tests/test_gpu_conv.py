@@ -377,3 +377,30 @@ def test_conv_random_shapes(ansatz, sx, sy, L, f, k, b, nonlin):
   band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
   assert np.array_equal(mask[~band], acc_ref[~band])
   eng.close()
+
+
+@pytest.mark.parametrize('wf_type,e0', [('conv_2d', -11.2285), ('res_net_1d', -7.1423)])
+def test_conv_log_overlap_itswo_training_entry(tmp_path, wf_type, e0):
+  """--optimizer=LogOverlapITSWO with a convolutional ansatz (vmc_epoch_log_overlap on the conv
+  kernels): 40 epochs approach the exact ground-state energy of the 4x4 torus / the 16-site ring
+  from above; stochastic reconfiguration (an extension for the dense types) says so."""
+  import os
+  from cgs_vmc_amd import lattice, run_training, session as session_lib, wavefunctions
+  session_lib.reset_default_graph()
+  wavefunctions.reset_name_scope()
+  os.environ.update(CGS_VMC_SEED='77', CGS_VMC_CONFIG_SEED='5', CGS_VMC_INIT_SEED='31')
+  d = str(tmp_path)
+  lattice.write_bonds(d, lattice.chain_bonds(16) if wf_type.endswith('1d') else lattice.torus_bonds(4, 4))
+  hp = ('batch_size=256,size_x=4,size_y=4,num_conv_layers=2,num_resnet_blocks=1,num_conv_filters=8,'
+        'kernel_size=3,num_equilibration_sweeps=10,num_batches_per_epoch=8,'
+        'learning_rates=[0.003,0.001],learning_rate_stops=[60]')
+  args = ['--checkpoint_dir', d, '--num_sites', '16', '--heisenberg_jx', '-1.0',
+          '--wavefunction_type', wf_type, '--num_epochs', '40', '--hparams', hp]
+  run_training.main(args + ['--optimizer', 'LogOverlapITSWO'])
+  energies = [float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()]
+  tail = np.mean(energies[-5:])
+  assert e0 - 0.05 < tail < 0.95 * e0, (wf_type, tail, energies[::8])
+  session_lib.reset_default_graph()
+  wavefunctions.reset_name_scope()
+  with pytest.raises(NotImplementedError):
+    run_training.main(args + ['--optimizer', 'StochasticReconfiguration'])
