@@ -18,6 +18,12 @@
 #ifndef SWEEP_VGPR_CO
 #define SWEEP_VGPR_CO 100 // its register budget (two waves per SIMD + one wave of k_tail_co <= 512)
 #endif
+#ifndef SWEEP_RT_WIDE
+#define SWEEP_RT_WIDE 2      // resident k-tiles of the 384- and 512-unit variants
+#endif
+#ifndef SWEEP_SCALAR_NT
+#define SWEEP_SCALAR_NT 16   // layers wider than this many tiles keep the weight base address scalar (see issue())
+#endif
 #ifndef SWEEP_CO_PRIO
 #define SWEEP_CO_PRIO 3
 #endif
@@ -473,12 +479,19 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   // fragments of the NEXT pass (the weights do not change during a launch), so a pass neither
   // ends on a wait for fragments nobody reads nor starts with an exposed prologue.
   f32x4 wb[PF][TO];
+  typedef const __attribute__((address_space(1))) char* gchar_p;
+  typedef const __attribute__((address_space(1))) f32x4* gf32x4_p;
+  const unsigned lane_off16 = (unsigned)lane * 16u;
+  const char* p16w = (const char*)pp.p16 + (size_t)wave * TO * NT * 256 * sizeof(float);
   auto issue = [&](int l, int ti, int stage) {
     // uniform (SGPR) base + one per-lane offset register
-    const f32x4* __restrict__ wp =
-        (const f32x4*)(pp.p16 + (long long)l * Hp * Hp) + (wave * TO * NT + ti) * 64;
+    const char* lb = p16w + (size_t)l * Hp * Hp * sizeof(float);
+    if (NT > SWEEP_SCALAR_NT) asm volatile("" : "+s"(lb));   // keep it scalar: per-item 64-bit lane addresses would be hoisted and spill
 #pragma unroll
-    for (int to = 0; to < TO; ++to) wb[stage][to] = wp[to * NT * 64 + lane];
+    for (int to = 0; to < TO; ++to) {
+      gchar_p base = (gchar_p)lb + (size_t)(to * NT + ti) * 256 * sizeof(float);
+      wb[stage][to] = *(gf32x4_p)(base + lane_off16);
+    }
   };
   const int l_last = n_hidden - 1;
   // first stream item of a pass: layer 0's first streamed k-tile, or (all of layer 0 resident)
@@ -734,7 +747,8 @@ template <int NT, int NW, int RTP, bool RBM, int ACT>
 static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
   const dim3 grid((a.B + 15) / 16), block(NW * 64);
   const size_t lds_full = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, true, RBM);
-  const bool w1l = lds_full <= 160 * 1024 && !a.no_w1l;
+  // (more than 256 units: W1 alone would need > 160 KiB; those variants are not instantiated)
+  const bool w1l = NT <= 16 && lds_full <= 160 * 1024 && !a.no_w1l;
   const size_t lds = w1l ? lds_full : sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false, RBM);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int nblk = (a.N + 3) / 4;
@@ -764,15 +778,20 @@ static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
     if constexpr (!RBM && NT == 16 && TUNED) SWEEP_LAUNCH(true, true, true, 2);
   }
   if constexpr (TUNED) {
-    if (w1l) {
-      if (fast2) SWEEP_LAUNCH(false, true, true, 2);
-      if (fast4) SWEEP_LAUNCH(false, true, true, 4);
-    } else {
+    if constexpr (NT <= 16) {
+      if (w1l) {
+        if (fast2) SWEEP_LAUNCH(false, true, true, 2);
+        if (fast4) SWEEP_LAUNCH(false, true, true, 4);
+      }
+    }
+    if (!w1l) {
       if (fast2) SWEEP_LAUNCH(false, false, true, 2);
       if (fast4) SWEEP_LAUNCH(false, false, true, 4);
     }
   }
-  if (w1l) SWEEP_LAUNCH(false, true, false, 2);
+  if constexpr (NT <= 16) {
+    if (w1l) SWEEP_LAUNCH(false, true, false, 2);
+  }
   SWEEP_LAUNCH(false, false, false, 2);
 #undef SWEEP_LAUNCH
 }
@@ -791,6 +810,14 @@ static hipError_t launch_sweep16_r(hipStream_t s, const SweepArgs& a, int Hp) {
     case 12: return launch_sweep16_t<12, 4, SWEEP_RT, RBM, ACT>(s, a);
 #endif
     case 16: return launch_sweep16_t<16, 8, SWEEP_RT, RBM, ACT>(s, a);
+#ifndef VMC_QUICK
+    // 257 .. 512 units (fully_connected, relu): wave w owns 3 or 4 output tiles, W1 in L2, the
+    // weight stream addressed from a scalar base (SWEEP_SCALAR_NT)
+    case 24: if constexpr (!RBM && ACT == VMC_ACT_RELU_) return launch_sweep16_t<24, 8, SWEEP_RT_WIDE, RBM, ACT>(s, a);
+             return hipErrorInvalidValue;
+    case 32: if constexpr (!RBM && ACT == VMC_ACT_RELU_) return launch_sweep16_t<32, 8, SWEEP_RT_WIDE, RBM, ACT>(s, a);
+             return hipErrorInvalidValue;
+#endif
     default: return hipErrorInvalidValue;
   }
 }

@@ -18,6 +18,11 @@
 // owns output units 64 w .. 64 w + 63 (TO = 4 tiles) of both halves: 8 accumulator tiles; the B
 // operands of a layer come from LDS (as in the sampler), the A fragments stream from L2 through a
 // two-stage register ring (one k-tile = 4 KiB per wave = 32 MFMAs ahead).  One barrier per layer.
+//
+// The same body, without the register cap and for 24 or 32 unit tiles per row (384 / 512 hidden
+// units: TO = 6 / 8 tiles per wave), is the row kernel of the wide fully_connected path
+// (k_tail_lds; local energies and plain logits), where k_tail16's register-resident activations
+// (2 x NT x 4 registers twice) no longer fit.
 #include "common.hpp"
 
 #ifndef TAILCO_VGPR
@@ -25,11 +30,13 @@
 #endif
 
 namespace {
-constexpr int NT = 16, Hp = 256, NW = 4, TO = 4;
-constexpr int XBUF = 2 * NT * 256;   // floats of one operand buffer [2 halves][NT][64 lanes][4]
+constexpr int NW = 4;
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(TAILCO_VGPR)))
-void k_tail_co(TailArgs a) {
+template <int NT, bool RATIO>
+__device__ __forceinline__ void tail_lds_body(const TailArgs& a) {
+  constexpr int Hp = NT * 16, TO = NT / NW;
+  constexpr int XBUF = 2 * NT * 256;   // floats of one operand buffer [2 halves][NT][64 lanes][4]
+  static_assert(NT % NW == 0 && TO % 2 == 0, "unit tiles divide over the waves in pairs");
   extern __shared__ float smem[];
   const int n_hidden = a.n_hidden;
   float* s_x = smem;                     // [2][2][NT][64][4]
@@ -81,8 +88,10 @@ void k_tail_co(TailArgs a) {
       const float* wa = pp.w1p + (long long)ab.x * Hp;
       const float* wb = pp.w1p + (long long)ab.y * Hp;
       if (wave == 0 && g == hf) {
-        s_meta[(16 * hf + j) * 2] = a.half_jx[bond];
-        s_meta[(16 * hf + j) * 2 + 1] = a.logit_base[ri.x];
+        if (RATIO) {
+          s_meta[(16 * hf + j) * 2] = a.half_jx[bond];
+          s_meta[(16 * hf + j) * 2 + 1] = a.logit_base[ri.x];
+        }
       }
 #pragma unroll
       for (int t0 = 0; t0 < TO; t0 += 2) {   // two unit tiles at a time: 24 registers in flight
@@ -163,16 +172,40 @@ void k_tail_co(TailArgs a) {
       const int row = tile * 32 + 16 * g + j;
       const float logit = ((s_part[(0 * 2 + g) * 16 + j] + s_part[(1 * 2 + g) * 16 + j]) +
                            (s_part[(2 * 2 + g) * 16 + j] + s_part[(3 * 2 + g) * 16 + j])) + bout;
-      if (row < n_rows)
-        a.out[row] = s_meta[(16 * g + j) * 2] * vmc_out_ratio(oact, logit, s_meta[(16 * g + j) * 2 + 1]);
+      if (row < n_rows) {
+        if (RATIO) a.out[row] = s_meta[(16 * g + j) * 2] * vmc_out_ratio(oact, logit, s_meta[(16 * g + j) * 2 + 1]);
+        else a.out[row] = logit;
+      }
     }
   }
 }
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(TAILCO_VGPR)))
+void k_tail_co(TailArgs a) { tail_lds_body<16, true>(a); }
+
+template <int NT, bool RATIO>
+__global__ __launch_bounds__(256) void k_tail_lds(TailArgs a) { tail_lds_body<NT, RATIO>(a); }
+
+size_t tail_lds_bytes_t(int nt, int n_hidden) {
+  return sizeof(float) * (size_t)(2 * (2 * nt * 256) + NW * 32 + 64 + n_hidden * nt * 16 + nt * 16);
+}
+
+template <int NT, bool RATIO>
+hipError_t launch_tail_lds_t(hipStream_t s, const TailArgs& a) {
+  const size_t lds = tail_lds_bytes_t(NT, a.n_hidden);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  const int tiles = (a.n_rows + 31) / 32;
+  const int persistent = a.num_cus > 0 ? a.num_cus : 256;
+  const dim3 grid(tiles < persistent ? tiles : persistent), block(256);
+  hipError_t e = hipFuncSetAttribute((const void*)k_tail_lds<NT, RATIO>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_tail_lds<NT, RATIO>), grid, block, lds, s, a);
+  return hipGetLastError();
+}
 }  // namespace
 
-size_t tail_co_lds_bytes(int n_hidden) {
-  return sizeof(float) * (size_t)(2 * XBUF + NW * 32 + 64 + n_hidden * Hp + Hp);
-}
+size_t tail_co_lds_bytes(int n_hidden) { return tail_lds_bytes_t(16, n_hidden); }
 
 // lds_bytes >= tail_co_lds_bytes(n_hidden): the caller pads it beyond half a CU's LDS so that two
 // of these workgroups never share a CU (the second one would take the sampler's place)
@@ -188,4 +221,17 @@ hipError_t launch_tail_co(hipStream_t s, const TailArgs& a, size_t lds_bytes) {
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_tail_co, grid, block, lds_bytes, s, a);
   return hipGetLastError();
+}
+
+// fully_connected (relu) with 384 or 512 padded units and at least one H x H layer: 0.5 jx psi'/psi
+// of the rows of a row list (ratio) or their logits
+bool tail_lds_supported(int Hp, int n_hidden) {
+  return (Hp == 384 || Hp == 512) && n_hidden >= 1 && tail_lds_bytes_t(Hp / 16, n_hidden) <= 160 * 1024;
+}
+
+hipError_t launch_tail_lds(hipStream_t s, const TailArgs& a, int Hp, bool ratio) {
+  if (a.n_rows <= 0) return hipSuccess;
+  if (!tail_lds_supported(Hp, a.n_hidden)) return hipErrorInvalidValue;
+  if (Hp == 384) return ratio ? launch_tail_lds_t<24, true>(s, a) : launch_tail_lds_t<24, false>(s, a);
+  return ratio ? launch_tail_lds_t<32, true>(s, a) : launch_tail_lds_t<32, false>(s, a);
 }

@@ -57,6 +57,10 @@ struct vmc_ctx {
   int c_slices = 64;       // sample slices of the weight-gradient kernel
   // fully_connected with more than 256 hidden units: general path (wide.hip)
   bool wide = false;
+  // ... except relu networks of at most 512 units with an H x H layer: their sampler and row kernel
+  // are instantiations of the fused kernels (k_sweep16<24|32>, k_tail_lds); only the gradient path
+  // stays on the general GEMMs.  CGS_VMC_WIDE_FAST=0 forces the general path.
+  bool wide_fast = false;
   long long wrows = 0;     // rows of the two activation row buffers
   float *wbuf[2] = {nullptr, nullptr}, *wide_zc = nullptr, *wide_lnew = nullptr, *wide_u = nullptr, *wide_zero = nullptr;
   int *wide_iup = nullptr, *wide_idn = nullptr;
@@ -380,6 +384,13 @@ int wide_forward(vmc_ctx* c, int which, const float* z1, const int2* rowinfo, lo
                  float* out) {
   ParamSet& p = c->ps[which];
   const int H = c->H, Hp = c->Hp, NH = c->n_hh;
+  if (c->wide_fast) {
+    TailArgs a = tail_args(c, which);
+    a.z1 = z1; a.logit_base = p.logit; a.rowinfo = rowinfo;
+    a.n_rows = (int)n_rows; a.out = out;
+    HIPCHK(c, launch_tail_lds(c->stream, a, Hp, ratio));
+    return VMC_OK;
+  }
   for (long long row0 = 0; row0 < n_rows; row0 += c->wrows) {
     const int rows = (int)(n_rows - row0 < c->wrows ? n_rows - row0 : c->wrows);
     HIPCHK(c, launch_wide_rows_act(c->stream, z1, p.w1p, rowinfo, c->bonds ? c->bonds : c->bond_dummy, row0, rows,
@@ -453,6 +464,14 @@ int local_energy_device(vmc_ctx* c, int which) {
     Timer t(c, "tail_eloc");
     PROPAGATE(conv_rows(c, which, c->configs, c->rowinfo, (int)((long long)c->B * c->n_bonds), c->off + c->B,
                         true, c->val, false));
+  } else if (c->wide && c->wide_fast) {
+    Timer t(c, "tail_eloc");
+    TailArgs a = tail_args(c, which);
+    a.z1 = p.z1; a.logit_base = p.logit; a.rowinfo = c->rowinfo;
+    a.n_rows_dev = c->off + c->B;                 // the row count stays on the device
+    a.n_rows = (int)((long long)c->B * c->n_bonds);
+    a.out = c->val;
+    HIPCHK(c, launch_tail_lds(c->stream, a, c->Hp, true));
   } else if (c->wide) {
     Timer t(c, "tail_eloc");
     int n_rows = 0;      // the GEMM grids need the row count on the host
@@ -614,6 +633,15 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (wide) c->overlap = false;
   c->hact = d->nonlinearity; c->oact = d->output_activation;
   c->lay = make_layout(rbm, c->N, c->H, c->L);
+  if (wide && c->H <= 512 && c->hact == VMC_ACT_RELU_ && c->L >= 2) {
+    const int hp = (c->H + 127) / 128 * 128;     // 8 waves x whole 16-unit tiles
+    const char* e = getenv("CGS_VMC_WIDE_FAST");
+    if (!(e && atoi(e) == 0) && tail_lds_supported(hp, (int)c->L - 1) &&
+        sweep_lds_required(c->N, hp, (int)c->L - 1, false) <= 160 * 1024) {
+      c->wide_fast = true;
+      c->Hp = hp;
+    }
+  }
   c->n_hh = c->lay.n_hh; c->A = c->n_hh + 1;
   c->P = conv ? vmc_num_params_conv(d->ansatz, d->num_layers, d->layer_size, d->kernel_size)
               : vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
@@ -964,7 +992,8 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
                      float* dbg_u, unsigned long long step0, bool count_accepted = false,
                      bool overtake = false, hipEvent_t dep = nullptr) {
   PROPAGATE(ensure_packed(c, 0));
-  if (c->wide) return run_sweep_wide(c, n_steps, injected, dbg, dbg_up, dbg_dn, dbg_u, step0, count_accepted);
+  if (c->wide && !c->wide_fast)
+    return run_sweep_wide(c, n_steps, injected, dbg, dbg_up, dbg_dn, dbg_u, step0, count_accepted);
   ParamSet& p = c->ps[0];
   SweepArgs a;
   memset(&a, 0, sizeof(a));
@@ -1043,7 +1072,7 @@ int vmc_mc_steps(vmc_ctx* c, int64_t n_steps, int64_t* accepted) {
   PROPAGATE(run_sweep(c, n_steps, false, false, nullptr, nullptr, nullptr, c->step, accepted != nullptr,
                       overtake, dep));
   c->step += (unsigned long long)n_steps;
-  c->ps[0].cache_valid = !c->wide;   // the sweep kernel writes back an exact z1/logit cache (the general
+  c->ps[0].cache_valid = !c->wide || c->wide_fast;   // the sweep kernel writes back an exact z1/logit cache (the general
                                      // wide path keeps an incrementally updated one: recomputed on demand)
   c->ps[1].cache_valid = false;
   c->list_valid = false;
@@ -1067,7 +1096,7 @@ int vmc_mc_step_injected(vmc_ctx* c, const int32_t* i_up, const int32_t* i_dn, c
   HIPCHK(c, hipMemcpyAsync(c->inj_dn, i_dn, c->B * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->inj_u, u, c->B * sizeof(float), hipMemcpyHostToDevice, c->stream));
   PROPAGATE(run_sweep(c, 1, true, false, nullptr, nullptr, nullptr, c->step));
-  c->ps[0].cache_valid = !c->wide; c->ps[1].cache_valid = false; c->list_valid = false;
+  c->ps[0].cache_valid = !c->wide || c->wide_fast; c->ps[1].cache_valid = false; c->list_valid = false;
   if (accept_mask)
     HIPCHK(c, hipMemcpyAsync(accept_mask, c->acc_mask, c->B, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -13,6 +13,8 @@ FULL = {
     'config3_10x10_h256_b4096': (10, 10, False, 3, 256, 4096),
     # BASELINE config 5, one GPU's shard: NN + NNN bonds with per-bond couplings J1 = 1, J2 = 0.5
     'config5_16x16_j1j2_h256_L6_b1024': (16, 16, True, 6, 256, 1024),
+    # bench.py's 512-unit workload: k_sweep16<32> / k_tail_lds<32>
+    'wide_10x10_h512_b4096': (10, 10, False, 3, 512, 4096),
 }
 
 

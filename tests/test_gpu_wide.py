@@ -1,6 +1,8 @@
-"""GPU parity of fully_connected with fc_layer_size > 256 (utils.py:105 allows any size): the
+"""GPU parity of fully_connected with fc_layer_size > 256 (utils.py:105 allows any size) against the
+numpy oracle, through the C ABI: relu networks of at most 512 units with an H x H layer run the fused
+sampler / row kernels padded to 384 or 512 units (k_sweep16<24|32>, k_tail_lds), everything else the
 general path of csrc/wide.hip (materialised rows + the library's fp32-MFMA GEMM, a few launches per
-mc_step) against the numpy oracle, through the C ABI.  Tolerances as tests/test_gpu_engine.py:
+mc_step).  Tolerances as tests/test_gpu_engine.py:
 logits 2e-5 * max(1, |logit|), local energies 2e-4 * max(1, |E|), gradient sums
 2e-3 * ||.||_inf + 1e-4, accept masks bit-exact outside |ratio - sqrt(u)| < 1e-4 ratio, proposals
 bit-exact."""
@@ -17,6 +19,11 @@ WIDE_SHAPES = [
     (36, 512, 3, 64, 'torus6x6', 'relu'),
     (12, 300, 1, 23, 'chain', 'tanh'),        # no H x H layer, H not a multiple of 64
     (20, 264, 2, 17, 'chain', 'sigmoid'),
+    (10, 384, 3, 50, 'chain', 'relu'),        # exactly 24 unit tiles, two H x H layers
+    (24, 500, 2, 33, 'chain', 'relu'),        # padded to 512, ragged batch
+    (150, 272, 4, 21, 'chain', 'relu'),       # N > 128: the general (non-prefetch) sampler at 384 units
+    (16, 400, 1, 30, 'chain', 'relu'),        # no H x H layer: general path
+    (16, 640, 2, 19, 'chain', 'relu'),        # more than 512 units: general path
 ]
 
 
@@ -131,3 +138,24 @@ def test_wide_limits():
   with pytest.raises(NotImplementedError):
     eng.sr_reserve(2)
   eng.close()
+
+
+def test_wide_fast_and_general_path_agree(monkeypatch):
+  """CGS_VMC_WIDE_FAST=0 (general path) and the fused kernels give the same logits, local energies and
+  accumulators for one relu network within the stated fp32 tolerances."""
+  from cgs_vmc_amd import _hip
+  outs = []
+  for fast in (True, False):
+    if fast:
+      monkeypatch.delenv('CGS_VMC_WIDE_FAST', raising=False)
+    else:
+      monkeypatch.setenv('CGS_VMC_WIDE_FAST', '0')
+    eng, theta, cfg, bonds = _make(36, 512, 3, 64, 'torus6x6', 'relu')
+    eng.reset_accumulators()
+    eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+    outs.append((eng.amplitude()[0], eng.local_energy()[0], eng.get_accumulators()))
+    eng.close()
+  (l0, e0, a0), (l1, e1, a1) = outs
+  _close(l0, l1, 2e-5)
+  _close(e0, e1, 2e-4)
+  assert np.abs(a0 - a1).max() < 2e-3 * np.abs(a1).max()
