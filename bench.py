@@ -489,6 +489,8 @@ def main():
       out['local_energy_evals_per_sec'] = world * b / t_eloc_call
       dom = 'sweep' if timings['sweep']['ms_total'] >= timings['tail_eloc']['ms_total'] else 'tail_eloc'
       k_sweep, k_eloc = ('k_conv_sweep', 'k_conv_rows(eloc)') if conv else ('k_sweep16', 'k_tail16(eloc)')
+      if not conv and h > 256:        # 257..512 relu units: the LDS-operand row kernel (tail_co.hip)
+        k_eloc = 'k_tail_lds(eloc)' if h <= 512 else 'wide GEMM rows(eloc)'
       per_kernel = {
           k_sweep: {'ms_avg': ts * 1e3, 'flops_executed': exec_sweep, 'flops_nominal': flops_sweep},
           k_eloc: {'ms_avg': te * 1e3, 'flops_executed': exec_eloc, 'flops_nominal': flops_eloc},

@@ -70,8 +70,9 @@ typedef struct {
   int32_t batch_size;        /* chains owned by THIS ctx         (utils.py:135)      */
   int32_t num_layers;        /* hparams.num_fc_layers (utils.py:104); conv_2d: num_conv_layers
                                 (108); res_net_2d: num_resnet_blocks (114)                     */
-  int32_t layer_size;        /* hparams.fc_layer_size (utils.py:105; fully_connected: up to 4096,
-                                more than 256 units run on the general multi-launch path; rbm:
+  int32_t layer_size;        /* hparams.fc_layer_size (utils.py:105; fully_connected: up to 4096
+                                -- fused kernels up to 256 units and, for relu with num_layers
+                                >= 2, up to 512; the general multi-launch path otherwise; rbm:
                                 up to 256); convolutional ansatz types: num_conv_filters (111),
                                 at most 16                                                      */
   int32_t nonlinearity;      /* VMC_ACT_*: hparams.nonlinearity  (utils.py:128)      */
