@@ -91,6 +91,8 @@ __device__ __forceinline__ float vmc_logcosh(float z) {
 #define VMC_ACT_TANH_ 4
 #define VMC_ACT_SIGMOID_ 5
 #define VMC_ACT_IDENTITY_ 6
+// run-time only: the RBM's last-stage log cosh as an "activation" of the general (wide.hip) path
+#define VMC_ACT_LOGCOSH_ 100
 
 template <int ACT>
 __device__ __forceinline__ float vmc_act(float z) {
@@ -123,6 +125,7 @@ __device__ __forceinline__ float vmc_act_rt(int act, float z) {
     case VMC_ACT_TAN_: return vmc_act<VMC_ACT_TAN_>(z);
     case VMC_ACT_TANH_: return vmc_act<VMC_ACT_TANH_>(z);
     case VMC_ACT_SIGMOID_: return vmc_act<VMC_ACT_SIGMOID_>(z);
+    case VMC_ACT_LOGCOSH_: return vmc_logcosh(z);
     default: return z;
   }
 }
@@ -311,9 +314,16 @@ hipError_t launch_sr_colsum(hipStream_t s, const float* x, long long ldx, const 
 // fully_connected with fc_layer_size > 256: the general path through materialised rows (wide.hip)
 hipError_t launch_wide_rows_act(hipStream_t s, const float* z1, const float* w1p, const int2* rowinfo,
                                 const int2* bonds, long long row0, int n_rows, int Hp, int act, float* out);
+// RBM onsite term of the rows of k_wide_out: x . w_on of the base configuration (`base`, per chain
+// or per external row) plus the exchange update of the row's bond (`bonds`) or of the proposed
+// move (`iup` / `idn`, one row per chain); base == nullptr: fully_connected
+struct WideOnsite {
+  const float* base; const float* won; const int2* bonds; const int* iup; const int* idn;
+};
 hipError_t launch_wide_out(hipStream_t s, const float* a, const float* wout, const float* bout, int n_rows,
                            int H, int Hp, const int2* rowinfo, long long row0, const float* half_jx,
-                           const float* logit_base, int oact, bool ratio, float* out);
+                           const float* logit_base, int oact, bool ratio, float* out,
+                           const WideOnsite& on = WideOnsite{nullptr, nullptr, nullptr, nullptr, nullptr});
 hipError_t launch_wide_propose(hipStream_t s, const float* configs, int B, int N, uint32_t seed_lo,
                                uint32_t seed_hi, int chain_offset, unsigned long long step, const int* inj_up,
                                const int* inj_dn, const float* inj_u, int* iup, int* idn, float* u);
@@ -321,6 +331,7 @@ hipError_t launch_wide_build(hipStream_t s, const float* z1, const float* w1p, c
                              int B, int Hp, int act, float* zc, float* a0);
 hipError_t launch_wide_accept(hipStream_t s, float* configs, float* z1, const float* zc, float* logit,
                               const float* lnew, const int* iup, const int* idn, const float* u, int B, int N,
-                              int Hp, int oact, unsigned long long* accepted, unsigned char* acc_mask);
+                              int Hp, int oact, unsigned long long* accepted, unsigned char* acc_mask,
+                              float* onsite = nullptr, const float* won = nullptr);
 hipError_t launch_wide_delta_last(hipStream_t s, const float* a_last, const float* wout, const float* oscale,
                                   int B, int H, int Hp, int act, float* delta);

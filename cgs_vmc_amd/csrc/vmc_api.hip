@@ -378,12 +378,21 @@ int first_layer(vmc_ctx* c, const ParamSet& p, const float* configs, float* z1, 
   return VMC_OK;
 }
 
+// activation behind linear stage l (0 = the N x H layer) on the general path
+static int wide_stage_act(const vmc_ctx* c, int l) {
+  return (c->rbm && l == c->n_hh) ? VMC_ACT_LOGCOSH_ : c->hact;
+}
+
 // fc_layer_size > 256: rows {chain, bond} of a row list over the cached z1 -> logits / ratios,
 // `wrows` rows at a time: rank-2 first layer written out, H x H layers as GEMMs, output dot
+// RBM (wavefunctions.py:418-437): the last linear stage goes through log cosh instead of the hidden
+// activation, the output "dot" is against ones (+ b_on) and `onsite` holds x . w_on of the base rows
 int wide_forward(vmc_ctx* c, int which, const float* z1, const int2* rowinfo, long long n_rows, bool ratio,
-                 float* out) {
+                 float* out, const float* onsite) {
   ParamSet& p = c->ps[which];
   const int H = c->H, Hp = c->Hp, NH = c->n_hh;
+  const int2* bonds = c->bonds ? c->bonds : c->bond_dummy;
+  const WideOnsite on{c->rbm ? onsite : nullptr, p.won, bonds, nullptr, nullptr};
   if (c->wide_fast) {
     TailArgs a = tail_args(c, which);
     a.z1 = z1; a.logit_base = p.logit; a.rowinfo = rowinfo;
@@ -393,18 +402,18 @@ int wide_forward(vmc_ctx* c, int which, const float* z1, const int2* rowinfo, lo
   }
   for (long long row0 = 0; row0 < n_rows; row0 += c->wrows) {
     const int rows = (int)(n_rows - row0 < c->wrows ? n_rows - row0 : c->wrows);
-    HIPCHK(c, launch_wide_rows_act(c->stream, z1, p.w1p, rowinfo, c->bonds ? c->bonds : c->bond_dummy, row0, rows,
-                                   Hp, c->hact, c->wbuf[0]));
+    HIPCHK(c, launch_wide_rows_act(c->stream, z1, p.w1p, rowinfo, bonds, row0, rows,
+                                   Hp, wide_stage_act(c, 0), c->wbuf[0]));
     for (int l = 1; l <= NH; ++l) {
       GemmArgs g; memset(&g, 0, sizeof(g));
       g.A = c->wbuf[(l - 1) & 1]; g.sam = Hp; g.sak = 1;
       g.B = p.theta + off_w(c, l); g.sbk = H; g.sbn = 1;
       g.M = rows; g.N = H; g.K = H; g.C = c->wbuf[l & 1]; g.ldc = Hp;
-      g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1; g.act = c->hact;
+      g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1; g.act = wide_stage_act(c, l);
       HIPCHK(c, launch_gemm(c->stream, g));
     }
     HIPCHK(c, launch_wide_out(c->stream, c->wbuf[NH & 1], p.woutp, p.bout, rows, H, Hp, rowinfo, row0, c->half_jx,
-                              p.logit, c->oact, ratio, out));
+                              p.logit, c->oact, ratio, out, on));
   }
   return VMC_OK;
 }
@@ -428,7 +437,7 @@ int ensure_cache(vmc_ctx* c, int which) {
   }
   if (c->wide) {
     Timer t(c, "tail_amp");
-    PROPAGATE(wide_forward(c, which, p.z1, c->rowinfo_id, c->B, false, p.logit));
+    PROPAGATE(wide_forward(c, which, p.z1, c->rowinfo_id, c->B, false, p.logit, p.onsite));
   } else {
     Timer t(c, "tail_amp");
     TailArgs a = tail_args(c, which);
@@ -477,7 +486,7 @@ int local_energy_device(vmc_ctx* c, int which) {
     int n_rows = 0;      // the GEMM grids need the row count on the host
     HIPCHK(c, hipMemcpyAsync(&n_rows, c->off + c->B, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    PROPAGATE(wide_forward(c, which, p.z1, c->rowinfo, n_rows, true, c->val));
+    PROPAGATE(wide_forward(c, which, p.z1, c->rowinfo, n_rows, true, c->val, p.onsite));
   } else {
     Timer t(c, "tail_eloc");
     TailArgs a = tail_args(c, which);
@@ -601,8 +610,8 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (rbm && d->output_activation != VMC_ACT_EXP)
     return fail(nullptr, VMC_ERR_INVALID, "the rbm ansatz has no output_activation: it is always exp (wavefunctions.py:419-420)");
   const bool wide = !conv && d->layer_size > 256;
-  if (wide && (rbm || d->nonlinearity == VMC_ACT_COS || d->layer_size > 4096))
-    return fail(nullptr, VMC_ERR_UNSUPPORTED, "fc_layer_size > 256 is supported for fully_connected (any nonlinearity but cos, at most 4096 units)");
+  if (wide && (d->nonlinearity == VMC_ACT_COS || d->layer_size > 4096))
+    return fail(nullptr, VMC_ERR_UNSUPPORTED, "fc_layer_size > 256 is supported for fully_connected and rbm with any nonlinearity but cos, at most 4096 units");
   if (!conv && !wide) {  // the sampler keeps 16 chains' spins, z1 and operands in LDS (160 KiB per CU)
     const int hp = (d->layer_size + 63) / 64 * 64;
     const int n_hh = rbm ? d->num_layers : d->num_layers - 1;
@@ -633,7 +642,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (wide) c->overlap = false;
   c->hact = d->nonlinearity; c->oact = d->output_activation;
   c->lay = make_layout(rbm, c->N, c->H, c->L);
-  if (wide && c->H <= 512 && c->hact == VMC_ACT_RELU_ && c->L >= 2) {
+  if (wide && !rbm && c->H <= 512 && c->hact == VMC_ACT_RELU_ && c->L >= 2) {
     const int hp = (c->H + 127) / 128 * 128;     // 8 waves x whole 16-unit tiles
     const char* e = getenv("CGS_VMC_WIDE_FAST");
     if (!(e && atoi(e) == 0) && tail_lds_supported(hp, (int)c->L - 1) &&
@@ -921,7 +930,8 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
       PROPAGATE(conv_rows(c, which, c->tmp_cfg, c->tmp_rowinfo, (int)n_rows, nullptr, false, c->tmp_out, false));
     } else if (c->wide) {
       PROPAGATE(first_layer(c, p, c->tmp_cfg, c->tmp_z1, (int)n_rows));
-      PROPAGATE(wide_forward(c, which, c->tmp_z1, c->tmp_rowinfo, n_rows, false, c->tmp_out));
+      if (c->rbm) HIPCHK(c, launch_onsite(c->stream, c->tmp_cfg, p.won, (int)n_rows, c->N, c->tmp_on));
+      PROPAGATE(wide_forward(c, which, c->tmp_z1, c->tmp_rowinfo, n_rows, false, c->tmp_out, c->tmp_on));
     } else {
       PROPAGATE(first_layer(c, p, c->tmp_cfg, c->tmp_z1, (int)n_rows));
       if (c->rbm) HIPCHK(c, launch_onsite(c->stream, c->tmp_cfg, p.won, (int)n_rows, c->N, c->tmp_on));
@@ -967,21 +977,22 @@ static int run_sweep_wide(vmc_ctx* c, long long n_steps, bool injected, bool dbg
                                   step0 + (unsigned long long)st, injected ? c->inj_up : nullptr,
                                   injected ? c->inj_dn : nullptr, injected ? c->inj_u : nullptr, c->wide_iup,
                                   c->wide_idn, c->wide_u));
-    HIPCHK(c, launch_wide_build(c->stream, p.z1, p.w1p, c->wide_iup, c->wide_idn, B, Hp, c->hact, c->wide_zc,
-                                c->wbuf[0]));
+    HIPCHK(c, launch_wide_build(c->stream, p.z1, p.w1p, c->wide_iup, c->wide_idn, B, Hp, wide_stage_act(c, 0),
+                                c->wide_zc, c->wbuf[0]));
     for (int l = 1; l <= NH; ++l) {
       GemmArgs g; memset(&g, 0, sizeof(g));
       g.A = c->wbuf[(l - 1) & 1]; g.sam = Hp; g.sak = 1;
       g.B = p.theta + off_w(c, l); g.sbk = H; g.sbn = 1;
       g.M = B; g.N = H; g.K = H; g.C = c->wbuf[l & 1]; g.ldc = Hp;
-      g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1; g.act = c->hact;
+      g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1; g.act = wide_stage_act(c, l);
       HIPCHK(c, launch_gemm(c->stream, g));
     }
+    const WideOnsite on{c->rbm ? p.onsite : nullptr, p.won, nullptr, c->wide_iup, c->wide_idn};
     HIPCHK(c, launch_wide_out(c->stream, c->wbuf[NH & 1], p.woutp, p.bout, B, H, Hp, c->rowinfo_id, 0, c->half_jx,
-                              p.logit, c->oact, false, c->wide_lnew));
+                              p.logit, c->oact, false, c->wide_lnew, on));
     HIPCHK(c, launch_wide_accept(c->stream, c->configs, p.z1, c->wide_zc, p.logit, c->wide_lnew, c->wide_iup,
                                  c->wide_idn, c->wide_u, B, N, Hp, c->oact, c->d_accepted,
-                                 injected ? c->acc_mask : nullptr));
+                                 injected ? c->acc_mask : nullptr, c->rbm ? p.onsite : nullptr, p.won));
   }
   c->acts_valid = false;
   c->acc_since_sweep = false;
@@ -1232,6 +1243,9 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
   // workgroup, transposed weight fragments on 16x16x4 MFMA (k_backprop16)
   if (c->wide) {
     // delta_NH = w_out (.) f'(z_NH); delta_{l-1} = f'(z_{l-1}) (.) (delta_l W_l^T) on the generic GEMM
+    if (c->rbm)   // d sum log cosh(z) / d z = tanh(z), which the forward left in act[NH]
+      HIPCHK(c, hipMemcpyAsync(c->delta[NH], c->act[NH], (size_t)B * Hp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    else
     HIPCHK(c, launch_wide_delta_last(c->stream, c->act[NH], p.woutp, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr,
                                      B, H, Hp, c->hact, c->delta[NH]));
     for (int l = NH; l >= 1; --l) {

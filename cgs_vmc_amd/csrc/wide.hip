@@ -1,4 +1,4 @@
-// fully_connected with fc_layer_size > 256 (utils.py:105 allows any size): the general path.
+// fully_connected / rbm with fc_layer_size > 256 (utils.py:105 allows any size): the general path.
 // The register-resident kernels (k_tail16 / k_sweep16 / k_backprop16) hold all hidden units of a
 // row tile in registers, which ends at 256 units.  Wider layers go through materialised rows and
 // the library's LDS-tiled fp32-MFMA GEMM (grad.hip): the rank-2 first layer of every connected /
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_wide_out(const float* __restrict__ a, c
                                                   const int2* __restrict__ rowinfo, long long row0,
                                                   const float* __restrict__ half_jx,
                                                   const float* __restrict__ logit_base, int oact, int ratio,
-                                                  float* __restrict__ out) {
+                                                  float* __restrict__ out, WideOnsite on) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_rows) return;
@@ -56,7 +56,17 @@ __global__ __launch_bounds__(256) void k_wide_out(const float* __restrict__ a, c
   for (int h = lane; h < H; h += 64) s = fmaf(a[(long long)r * Hp + h], wout[h], s);
   s = wave_sum_w(s);
   if (lane == 0) {
-    const float logit = s + bout[0];
+    float logit = s + bout[0];
+    if (on.base) {   // RestrictedBoltzmannNetwork: + x' . w_on (wavefunctions.py:436), rank-2 in the exchange
+      const int2 ri = rowinfo[row0 + r];
+      float o = on.base[ri.x];
+      if (ri.y != 0) {
+        const int2 ab = on.bonds[(ri.y > 0 ? ri.y : -ri.y) - 1];
+        o = fmaf(ri.y > 0 ? -2.f : 2.f, on.won[ab.x] - on.won[ab.y], o);
+      }
+      if (on.iup) o = fmaf(2.f, on.won[on.idn[r]] - on.won[on.iup[r]], o);
+      logit += o;
+    }
     if (ratio) {
       const int2 ri = rowinfo[row0 + r];
       const int bs = ri.y;
@@ -139,7 +149,8 @@ __global__ __launch_bounds__(256) void k_wide_accept(float* __restrict__ configs
                                                      const int* __restrict__ idn, const float* __restrict__ u,
                                                      int B, int N, int Hp, int oact,
                                                      unsigned long long* __restrict__ accepted,
-                                                     unsigned char* __restrict__ acc_mask) {
+                                                     unsigned char* __restrict__ acc_mask,
+                                                     float* __restrict__ onsite, const float* __restrict__ won) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= B) return;
@@ -151,6 +162,7 @@ __global__ __launch_bounds__(256) void k_wide_accept(float* __restrict__ configs
       configs[(long long)c * N + idn[c]] += 2.f;      // graph_builders.py:67-71
       configs[(long long)c * N + iup[c]] -= 2.f;
       logit[c] = lnew[c];
+      if (onsite) onsite[c] = fmaf(2.f, won[idn[c]] - won[iup[c]], onsite[c]);
       atomicAdd(accepted, 1ull);
     }
   }
@@ -183,10 +195,10 @@ hipError_t launch_wide_rows_act(hipStream_t s, const float* z1, const float* w1p
 
 hipError_t launch_wide_out(hipStream_t s, const float* a, const float* wout, const float* bout, int n_rows,
                            int H, int Hp, const int2* rowinfo, long long row0, const float* half_jx,
-                           const float* logit_base, int oact, bool ratio, float* out) {
+                           const float* logit_base, int oact, bool ratio, float* out, const WideOnsite& on) {
   if (n_rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_wide_out, dim3((n_rows + 3) / 4), dim3(256), 0, s, a, wout, bout, n_rows, H, Hp, rowinfo,
-                     row0, half_jx, logit_base, oact, ratio ? 1 : 0, out);
+                     row0, half_jx, logit_base, oact, ratio ? 1 : 0, out, on);
   return hipGetLastError();
 }
 
@@ -207,9 +219,10 @@ hipError_t launch_wide_build(hipStream_t s, const float* z1, const float* w1p, c
 
 hipError_t launch_wide_accept(hipStream_t s, float* configs, float* z1, const float* zc, float* logit,
                               const float* lnew, const int* iup, const int* idn, const float* u, int B, int N,
-                              int Hp, int oact, unsigned long long* accepted, unsigned char* acc_mask) {
+                              int Hp, int oact, unsigned long long* accepted, unsigned char* acc_mask,
+                              float* onsite, const float* won) {
   hipLaunchKernelGGL(k_wide_accept, dim3((B + 3) / 4), dim3(256), 0, s, configs, z1, zc, logit, lnew, iup, idn,
-                     u, B, N, Hp, oact, accepted, acc_mask);
+                     u, B, N, Hp, oact, accepted, acc_mask, onsite, won);
   return hipGetLastError();
 }
 

@@ -1,6 +1,6 @@
 """GPU parity of the RestrictedBoltzmannNetwork ansatz (wavefunctions.py:391-452; the RBM
-variants of k_tail16 / k_tail0 / k_sweep16 and the generalised gradient chain) against the numpy
-oracle, through the C ABI.  Same tolerances as tests/test_gpu_engine.py:
+variants of k_tail16 / k_tail0 / k_sweep16 and the generalised gradient chain; beyond 256 hidden
+units the general path of csrc/wide.hip) against the numpy oracle, through the C ABI.  Same tolerances as tests/test_gpu_engine.py:
   logits 2e-5 * max(1, |logit|), local energies 2e-4 * max(1, |E|), gradient sums
   2e-3 * ||.||_inf + 1e-4, accept masks bit-exact outside |ratio - sqrt(u)| < 1e-4 ratio.
 """
@@ -20,7 +20,13 @@ RBM_SHAPES = [
     (20, 256, 2, 130, 'chain'),     # 8-wave sampler
     (14, 160, 2, 70, 'chain'),      # H padded to 192: the 12-tile kernel instantiations
     (100, 256, 2, 48, 'torus10x10'),  # config-3 lattice: W1 does not fit LDS next to 2 bias rows
+    # more than 256 hidden units: the general path of csrc/wide.hip (materialised rows + GEMMs)
+    (16, 400, 0, 30, 'chain'),      # classic RBM, alpha = 25
+    (100, 400, 0, 64, 'torus10x10'),  # classic RBM with alpha = 4 on the config-3 lattice
+    (12, 320, 1, 23, 'chain'),      # one relu layer in front of the cosh layer, ragged batch
+    (16, 640, 2, 19, 'chain'),
 ]
+WIDE_FROM = 7
 
 
 def _bonds(kind, n):
@@ -93,7 +99,7 @@ def test_rbm_injected_mc_step_and_cache(n, h, L, b, kind):
   eng.close()
 
 
-@pytest.mark.parametrize('n,h,L,b,kind', RBM_SHAPES[:3])
+@pytest.mark.parametrize('n,h,L,b,kind', RBM_SHAPES[:3] + RBM_SHAPES[WIDE_FROM:WIDE_FROM + 3])
 def test_rbm_sampler_trajectory_follows_oracle(n, h, L, b, kind):
   eng, theta, cfg, bonds = _make(n, h, L, b, kind)
   amp = lambda c: vo.rbm_psi(theta, c, h, L, dtype=np.float64)
@@ -196,3 +202,30 @@ def test_rbm_through_run_training_and_evaluation(tmp_path):
   wavefunctions.reset_name_scope()
   run_energy_evaluation.main(['--checkpoint_dir', d, '--heisenberg_jx', '-1.0',
                               '--hparams', 'num_evaluation_samples=5'])
+
+
+def test_wide_classic_rbm_through_run_training(tmp_path):
+  """A classic RBM (num_fc_layers=0) with 272 hidden units -- beyond the register-resident kernels, on
+  the general path of csrc/wide.hip -- through the run_training counterpart: every epoch energy is
+  finite and variational (>= E0 of the 4x4 torus within noise), the checkpoint holds the Sonnet
+  variable names and shapes.  (With Sonnet's default initialisation 272 cosh units make |psi|^2 so
+  peaked that Adam needs far more than a test's worth of epochs to leave the initial plateau -- the
+  fused path at 200 units behaves the same -- so no convergence claim is made here.)"""
+  import os
+  from cgs_vmc_amd import lattice, run_training, session as session_lib, wavefunctions
+  session_lib.reset_default_graph()
+  wavefunctions.reset_name_scope()
+  os.environ.update(CGS_VMC_SEED='78', CGS_VMC_CONFIG_SEED='6', CGS_VMC_INIT_SEED='32')
+  d = str(tmp_path)
+  lattice.write_bonds(d, lattice.torus_bonds(4, 4))
+  hp = ('batch_size=256,fc_layer_size=272,num_fc_layers=0,num_equilibration_sweeps=5,'
+        'num_batches_per_epoch=5,learning_rates=[0.001,0.0005],learning_rate_stops=[10]')
+  run_training.main(['--checkpoint_dir', d, '--num_sites', '16', '--heisenberg_jx', '-1.0',
+                     '--wavefunction_type', 'rbm', '--optimizer', 'EnergyGradient',
+                     '--num_epochs', '20', '--hparams', hp])
+  energies = np.array([float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()])
+  assert energies.size == 20 and np.isfinite(energies).all()
+  assert (energies > -11.2285 - 0.3).all() and (energies < 0.0).all(), energies
+  ck = np.load(session_lib.latest_checkpoint(d) + '.npz')
+  assert ck['restricted_boltzmann_network/linear/w'].shape == (16, 272)
+  assert ck['restricted_boltzmann_network/linear_1/w'].shape == (16, 1)    # onsite layer (L + 1 = 1)

@@ -131,13 +131,14 @@ def test_wide_energy_gradient_accumulators(n, h, L, b, kind, nonlin):
 def test_wide_limits():
   from cgs_vmc_amd.engine import VmcEngine
   with pytest.raises(NotImplementedError):
-    VmcEngine(16, 8, 2, 320, ansatz='rbm')
-  with pytest.raises(NotImplementedError):
     VmcEngine(16, 8, 2, 320, nonlinearity='cos')
-  eng = VmcEngine(16, 8, 2, 320)
   with pytest.raises(NotImplementedError):
-    eng.sr_reserve(2)
-  eng.close()
+    VmcEngine(16, 8, 2, 4100, ansatz='rbm')
+  for ansatz in ('fully_connected', 'rbm'):
+    eng = VmcEngine(16, 8, 2, 320, ansatz=ansatz)
+    with pytest.raises(NotImplementedError):
+      eng.sr_reserve(2)
+    eng.close()
 
 
 def test_wide_fast_and_general_path_agree(monkeypatch):
