@@ -52,9 +52,13 @@ __global__ __launch_bounds__(256) void k_wide_out(const float* __restrict__ a, c
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_rows) return;
-  float s = 0.f;
-  for (int h = lane; h < H; h += 64) s = fmaf(a[(long long)r * Hp + h], wout[h], s);
-  s = wave_sum_w(s);
+  // the dot runs over up to 4096 terms of one sign (RBM: log cosh values, logit ~ H / 2): summed in
+  // double so that logit' - logit keeps its digits (as k_tail0 does); the products are exact in double
+  double sd = 0.0;
+  for (int h = lane; h < H; h += 64) sd += (double)a[(long long)r * Hp + h] * (double)wout[h];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) sd += __shfl_xor(sd, m);
+  const float s = (float)sd;
   if (lane == 0) {
     float logit = s + bout[0];
     if (on.base) {   // RestrictedBoltzmannNetwork: + x' . w_on (wavefunctions.py:436), rank-2 in the exchange
