@@ -27,6 +27,16 @@
 #ifndef SWEEP_CO_PRIO
 #define SWEEP_CO_PRIO 3
 #endif
+// The two switches below are on for the two-draw variants (UPRE = 2, N <= 128 sites) only: with
+// five draws per lane (UPRE = 4) the second copy of layer 0 costs registers (6 -> 15 spilled);
+// the split is also left out of the variants without W1 in LDS or without resident k-tiles (a few
+// spills each, among them the register-capped k_sweep16_co).
+#ifndef SWEEP_SPLIT
+#define SWEEP_SPLIT(UPRE) ((UPRE) == 2)   // waves 4-7 run layer 0 without the Philox pieces
+#endif
+#ifndef SWEEP_PIN
+#define SWEEP_PIN(UPRE) ((UPRE) == 2)     // keep every Philox round inside layer 0 (see pin_draw)
+#endif
 #ifndef SWEEP_PF
 #define SWEEP_PF 2    // stages of the weight prefetch ring; (16 - SWEEP_RT) % SWEEP_PF == 0
 #endif
@@ -507,10 +517,14 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
     // issued under a runtime condition makes it wait for ALL outstanding loads at the next use.
     int cur = 0;
     // FS = first streamed k-tile of the layer (RT for layer 0, 0 afterwards)
-    auto layer = [&](int l, auto fs_c, auto first_c) {
+    auto layer = [&](int l, auto fs_c, auto first_c, auto draw_c) {
       constexpr int FS = decltype(fs_c)::value;
-      // layer 0 carries the Philox pieces: in its resident k-tiles, or (no resident tile) in all
-      constexpr bool FIRST = decltype(first_c)::value;
+      // layer 0 carries the Philox pieces: in its resident k-tiles, or (no resident tile) in all.
+      // DRAW: this wave owns chains (waves 0-3 of an 8-wave workgroup); with SWEEP_SPLIT the others
+      // run a copy of the layer without the pieces -- their draws would be for chains that do not
+      // exist, and VALU instructions between MFMAs are not free
+      constexpr bool DRAW = decltype(draw_c)::value;
+      constexpr bool FIRST = decltype(first_c)::value && DRAW;
       constexpr int PT = FIRST ? (FS > 0 ? FS : NT) : 0;
       SWEEP_STAMP(FS > 0 ? 7 : 11)
       __syncthreads();
@@ -548,11 +562,20 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
           for (int to = 0; to < TO; ++to)
             acc[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(wres[ti * TO + to][r], inb[ti & 1][r],
                                                            acc[to], 0, 0, 0);
-          if (r == 1) { piece(2 * ti); __builtin_amdgcn_sched_barrier(0); }
-          if (r == 3) { piece(2 * ti + 1); __builtin_amdgcn_sched_barrier(0); }
+          if (DRAW && r == 1) { piece(2 * ti); __builtin_amdgcn_sched_barrier(0); }
+          if (DRAW && r == 3) { piece(2 * ti + 1); __builtin_amdgcn_sched_barrier(0); }
         }
       }
-      if (FS > 0) finish_draw(cs, next_step);
+      // the draws are only read by the NEXT step's proposals: without a use here LLVM sinks half
+      // of the rounds below the layer, into the serial part of the step (one whole draw of the
+      // two at config 3)
+      auto pin_draw = [&]() {
+        if (!SWEEP_PIN(UPRE)) return;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+          asm volatile("" : "+v"(cs[d].x), "+v"(cs[d].y), "+v"(cs[d].z), "+v"(cs[d].w));
+      };
+      if (DRAW && FS > 0) { pin_draw(); finish_draw(cs, next_step); }
       if (FS > 0) { SWEEP_STAMP(9) }
       // streamed k-tiles: weights PF-1 tiles ahead, activations one tile ahead
       if (FS == 0) inb[0] = xin[0];
@@ -575,7 +598,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
           }
         }
       }
-      if (FIRST && FS == 0) finish_draw(cs, next_step);
+      if (FIRST && FS == 0) { pin_draw(); finish_draw(cs, next_step); }
       SWEEP_STAMP(FS > 0 ? 10 : 13)
       float* xout = s_x + (cur ^ 1) * NT * 256;
 #pragma unroll
@@ -587,8 +610,9 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       cur ^= 1;
       SWEEP_STAMP(FS > 0 ? 11 : 14)
     };
-    layer(0, std::integral_constant<int, RT>{}, std::true_type{});
-    for (int l = 1; l < n_hidden; ++l) layer(l, std::integral_constant<int, 0>{}, std::false_type{});
+    if (SWEEP_SPLIT(UPRE) && W1L && RT > 0 && NW > 4 && wave >= 4) layer(0, std::integral_constant<int, RT>{}, std::true_type{}, std::false_type{});
+    else layer(0, std::integral_constant<int, RT>{}, std::true_type{}, std::true_type{});
+    for (int l = 1; l < n_hidden; ++l) layer(l, std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{});
   };
 
   // output dot of the last activations (own) -> per-wave partial logits in s_part
@@ -689,7 +713,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
     const unsigned long long next_step = a.step0 + (unsigned long long)(it + 1);
     const bool pre_here = use_pref && n_hidden > 0;
     if (n_hidden > 0) forward(next_step);
-    if (use_pref && !pre_here) draw_all(next_step);
+    if (use_pref && !pre_here && !(NW > 4 && wave >= 4)) draw_all(next_step);
     SWEEP_STAMP(3)
     output_dot();
     SWEEP_STAMP(4)

@@ -1152,10 +1152,16 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   HIPCHK(c, hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   hipFree(d);
+  // CGS_VMC_PROFILE_WAVES = bit mask of the waves of a workgroup to average over (diagnostic;
+  // default all): waves 0-3 own the chains (proposals, accept, Philox), waves 4-7 do not
+  unsigned wave_mask = ~0u;
+  if (const char* e = getenv("CGS_VMC_PROFILE_WAVES")) wave_mask = (unsigned)strtoul(e, nullptr, 0);
   for (int k = 0; k < 16; ++k) {
     double s = 0.0;
-    for (int i = 0; i < grid * c->sweep_waves; ++i) s += (double)h[(size_t)i * 16 + k];
-    phase_cycles[k] = s / ((double)grid * c->sweep_waves * (double)n_steps);
+    long long cnt = 0;
+    for (int i = 0; i < grid * c->sweep_waves; ++i)
+      if ((wave_mask >> (i % c->sweep_waves)) & 1u) { s += (double)h[(size_t)i * 16 + k]; ++cnt; }
+    phase_cycles[k] = cnt ? s / ((double)cnt * (double)n_steps) : 0.0;
   }
   return VMC_OK;
 }
