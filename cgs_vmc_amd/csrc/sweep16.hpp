@@ -37,6 +37,9 @@
 #ifndef SWEEP_PIN
 #define SWEEP_PIN(UPRE) ((UPRE) == 2)     // keep every Philox round inside layer 0 (see pin_draw)
 #endif
+#ifndef SWEEP_HANDOFF
+#define SWEEP_HANDOFF 1   // waves 4-7 draw the next step's uniforms in the serial phase (see HANDOFF)
+#endif
 #ifndef SWEEP_PF
 #define SWEEP_PF 2    // stages of the weight prefetch ring; (16 - SWEEP_RT) % SWEEP_PF == 0
 #endif
@@ -239,7 +242,9 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   // lattice (N <= 124), so ND = 2; with UPRE = 4 it has a slot of its own (ND = 5).
   constexpr int ND = UPRE == 2 ? 2 : UPRE + 1;
   const bool use_pref = FAST || ((nblk <= 16 * UPRE) && (a.inj_up == nullptr));
-  const int my_c = wave * 4 + g;
+  // chains 4w..4w+3 belong to wave w (< 4); waves 4-7 of an 8-wave workgroup see their SIMD
+  // partner's chains (only the hand-over draws below use that)
+  const int my_c = (NW > 4 ? (wave & 3) : wave) * 4 + g;
   const uint32_t my_gid = (uint32_t)(a.chain_offset + chain0 + my_c);
   float u_pre[4 * UPRE];
   float u_pre_acc = 0.f;
@@ -512,6 +517,15 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
 #pragma unroll
     for (int st = 0; st < PF - 1; ++st) issue(ring_l0, ring_t0 + st, st);
   }
+  // HANDOFF (production variant of H = 256 with W1 in LDS): the NEXT step's uniforms are drawn
+  // by waves 4-7 at the top of the iteration -- while waves 0-3 resolve the previous step and
+  // build the proposals, they have nothing to do until barrier0 -- and handed over through the
+  // part of operand buffer 1 that is dead between the output dot and layer 0's epilogue
+  // (behind s_part when that lives there).  Layer 0 then carries no Philox pieces at all.
+  constexpr bool HANDOFF_T = SWEEP_HANDOFF && FAST && W1L && NW == 8 && UPRE == 2 && RT > 0 && !RBM;
+  const bool handoff = HANDOFF_T && n_hidden > 0;
+  float* s_uh = s_x + NT * 256 + NW * 16;    // [4 waves][3][64 lanes][4]
+  static_assert(!HANDOFF_T || NW * 16 + 4 * 3 * 256 <= NT * 256, "hand-over area must fit operand buffer 1");
   auto forward = [&](unsigned long long next_step) {
     // Every issue below is unconditional so that the compiler can count vmcnt exactly; a load
     // issued under a runtime condition makes it wait for ALL outstanding loads at the next use.
@@ -610,7 +624,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       cur ^= 1;
       SWEEP_STAMP(FS > 0 ? 11 : 14)
     };
-    if (SWEEP_SPLIT(UPRE) && W1L && RT > 0 && NW > 4 && wave >= 4) layer(0, std::integral_constant<int, RT>{}, std::true_type{}, std::false_type{});
+    if ((HANDOFF_T && handoff) || (SWEEP_SPLIT(UPRE) && W1L && RT > 0 && NW > 4 && wave >= 4)) layer(0, std::integral_constant<int, RT>{}, std::true_type{}, std::false_type{});
     else layer(0, std::integral_constant<int, RT>{}, std::true_type{}, std::true_type{});
     for (int l = 1; l < n_hidden; ++l) layer(l, std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{});
   };
@@ -692,6 +706,13 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   }
   for (long long it = it_first; it <= a.n_steps; ++it) {
     const bool is_step = it >= 0 && it < a.n_steps;
+    if (HANDOFF_T && handoff && wave >= 4) {
+      draw_all(a.step0 + (unsigned long long)(it + 1));
+      float* dst = s_uh + ((wave - 4) * 3 * 64 + lane) * 4;
+      *(f32x4*)dst = f32x4{u_pre[0], u_pre[1], u_pre[2], u_pre[3]};
+      *(f32x4*)(dst + 256) = f32x4{u_pre[4], u_pre[5], u_pre[6], u_pre[7]};
+      dst[512] = u_pre_acc;
+    }
     save_acts = (it == a.n_steps) && (a.act_out != nullptr);
     stamp_on = is_step;
     if (STAMP) t0 = vmc_stamp();
@@ -708,6 +729,13 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
     SWEEP_STAMP(0)
     __syncthreads();
     SWEEP_STAMP(1)
+    if (HANDOFF_T && handoff && wave < 4) {   // the reads complete under build (next barrier at the latest)
+      const float* src = s_uh + (wave * 3 * 64 + lane) * 4;
+      const f32x4 ua = *(const f32x4*)src, ub = *(const f32x4*)(src + 256);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { u_pre[e] = ua[e]; u_pre[4 + e] = ub[e]; }
+      u_pre_acc = src[512];
+    }
     build(is_step);
     SWEEP_STAMP(2)
     const unsigned long long next_step = a.step0 + (unsigned long long)(it + 1);
