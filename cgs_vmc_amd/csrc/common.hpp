@@ -203,6 +203,7 @@ struct SweepArgs {
   float* dact_out;          // [L][B][Hp] f'(z) of the final chains (cosine only) or nullptr
   int waves;                // waves per workgroup of the sweep kernel (4 or 8)
   int no_w1l;               // 1: never hold W1 in LDS (the two-workgroups-per-CU variant)
+  int uh_lds;               // set by the launcher: the sampler's dedicated hand-over area is part of its LDS
   int co;                   // 1: the co-resident variant k_sweep16_co (H = 256, relu, N <= 128; ignored otherwise)
   int cache_in_valid;       // z1 / logit already hold the exact cache of `configs`
   float* act_out;           // [L][B][Hp] activations of the final chains (gradient path) or nullptr

@@ -522,10 +522,15 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   // build the proposals, they have nothing to do until barrier0 -- and handed over through the
   // part of operand buffer 1 that is dead between the output dot and layer 0's epilogue
   // (behind s_part when that lives there).  Layer 0 then carries no Philox pieces at all.
-  constexpr bool HANDOFF_T = SWEEP_HANDOFF && FAST && W1L && NW == 8 && UPRE == 2 && RT > 0 && !RBM;
-  const bool handoff = HANDOFF_T && n_hidden > 0;
-  float* s_uh = s_x + NT * 256 + NW * 16;    // [4 waves][3][64 lanes][4]
-  static_assert(!HANDOFF_T || NW * 16 + 4 * 3 * 256 <= NT * 256, "hand-over area must fit operand buffer 1");
+  // The area holds UPRE + 1 float4 slots per lane of waves 0-3; where it does not fit operand
+  // buffer 1 (256 units with 129..256 sites: five slots) it is a region of its own behind the
+  // chain state, which the launcher grants when the lattice leaves room (a.uh_lds; those shapes
+  // do not have W1 in LDS).
+  constexpr int UH_FLOATS = 4 * (UPRE + 1) * 256;
+  constexpr bool UH_IN_X = NW * 16 + UH_FLOATS <= NT * 256;
+  constexpr bool HANDOFF_T = SWEEP_HANDOFF && FAST && NW == 8 && RT > 0 && (UH_IN_X || !W1L);
+  const bool handoff = HANDOFF_T && n_hidden > 0 && (UH_IN_X || a.uh_lds != 0);
+  float* s_uh = UH_IN_X ? s_x + NT * 256 + NW * 16 : s_w1;    // [4 waves][UPRE + 1][64 lanes][4]
   auto forward = [&](unsigned long long next_step) {
     // Every issue below is unconditional so that the compiler can count vmcnt exactly; a load
     // issued under a runtime condition makes it wait for ALL outstanding loads at the next use.
@@ -708,10 +713,11 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
     const bool is_step = it >= 0 && it < a.n_steps;
     if (HANDOFF_T && handoff && wave >= 4) {
       draw_all(a.step0 + (unsigned long long)(it + 1));
-      float* dst = s_uh + ((wave - 4) * 3 * 64 + lane) * 4;
-      *(f32x4*)dst = f32x4{u_pre[0], u_pre[1], u_pre[2], u_pre[3]};
-      *(f32x4*)(dst + 256) = f32x4{u_pre[4], u_pre[5], u_pre[6], u_pre[7]};
-      dst[512] = u_pre_acc;
+      float* dst = s_uh + ((wave - 4) * (UPRE + 1) * 64 + lane) * 4;
+#pragma unroll
+      for (int b = 0; b < UPRE; ++b)
+        *(f32x4*)(dst + 256 * b) = f32x4{u_pre[4 * b], u_pre[4 * b + 1], u_pre[4 * b + 2], u_pre[4 * b + 3]};
+      dst[256 * UPRE] = u_pre_acc;
     }
     save_acts = (it == a.n_steps) && (a.act_out != nullptr);
     stamp_on = is_step;
@@ -730,11 +736,14 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
     __syncthreads();
     SWEEP_STAMP(1)
     if (HANDOFF_T && handoff && wave < 4) {   // the reads complete under build (next barrier at the latest)
-      const float* src = s_uh + (wave * 3 * 64 + lane) * 4;
-      const f32x4 ua = *(const f32x4*)src, ub = *(const f32x4*)(src + 256);
+      const float* src = s_uh + (wave * (UPRE + 1) * 64 + lane) * 4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { u_pre[e] = ua[e]; u_pre[4 + e] = ub[e]; }
-      u_pre_acc = src[512];
+      for (int b = 0; b < UPRE; ++b) {
+        const f32x4 ub = *(const f32x4*)(src + 256 * b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) u_pre[4 * b + e] = ub[e];
+      }
+      u_pre_acc = src[256 * UPRE];
     }
     build(is_step);
     SWEEP_STAMP(2)
@@ -788,24 +797,31 @@ void k_sweep16_co(SweepArgs a) {
   sweep16_body<16, 8, SWEEP_RT_CO, false, false, true, 2, false, ACT>(a);
 }
 
-static inline size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool rbm) {
+static inline size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool rbm, int uh_floats = 0) {
   const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
   return sizeof(float) * (size_t)(16 * Nst + (w1l ? 1 : 2) * 16 * ZS + 2 * NT * 256 + 16 +
                                   16 + 7 * 16 + Hp + n_hidden * Hp + (rbm ? (w1l ? 0 : Nst) + 16 : 0) +
-                                  (w1l ? N * (Hp + 4) : 0));
+                                  (w1l ? N * (Hp + 4) : 0) + uh_floats);
 }
 
 template <int NT, int NW, int RTP, bool RBM, int ACT>
-static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a) {
+static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a_in) {
+  SweepArgs a = a_in;
   const dim3 grid((a.B + 15) / 16), block(NW * 64);
   const size_t lds_full = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, true, RBM);
   // (more than 256 units: W1 alone would need > 160 KiB; those variants are not instantiated)
   const bool w1l = NT <= 16 && lds_full <= 160 * 1024 && !a.no_w1l;
-  const size_t lds = w1l ? lds_full : sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false, RBM);
+  size_t lds = w1l ? lds_full : sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false, RBM);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   const int nblk = (a.N + 3) / 4;
   const bool plain = a.inj_up == nullptr && a.dbg_up == nullptr;
   const bool fast2 = nblk <= 32 && plain, fast4 = nblk <= 64 && plain;
+  // five-slot hand-over area of the UPRE = 4 variant at 256 units (sweep16_body: UH_IN_X is false)
+  a.uh_lds = 0;
+  if (NT == 16 && NW == 8 && !w1l && !fast2 && fast4) {
+    const size_t with_uh = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false, RBM, 4 * 5 * 256);
+    if (with_uh <= 160 * 1024) { lds = with_uh; a.uh_lds = 1; }
+  }
 #define SWEEP_LAUNCH(ST, WL, FA, UP)                                                          \
   do {                                                                                        \
     hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, NW, RTP, ST, WL, FA, UP, RBM, ACT>, \
