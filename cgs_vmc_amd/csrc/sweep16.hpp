@@ -116,9 +116,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   int* s_iup = (int*)(s_u + 16);              // [16]
   int* s_idn = s_iup + 16;                    // [16]
   int* s_sel = s_idn + 16;                    // [16]
-  int* s_pup = s_sel + 16;                    // [16] previous step's proposal / accept flag
-  int* s_pdn = s_pup + 16;                    // [16]
-  int* s_pacc = s_pdn + 16;                   // [16]
+  int* s_pacc = s_sel + 48;                   // [16] previous step's accept flag (after two unused [16] slots)
   float* s_hlu = (float*)(s_pacc + 16);       // [16] 0.5 log(u_accept)
   float* s_wout = s_hlu + 16;                 // [Hp]
   float* s_bias = s_wout + Hp;                // [n_hidden][Hp] biases of the H x H layers
@@ -146,7 +144,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
     if (n < N) v = gc < a.B ? a.configs_in[(long long)gc * N + n] : ((n & 1) ? -1.f : 1.f);
     s_spin[i] = v;
   }
-  if (tid < 16) { s_sel[tid] = 0; s_pacc[tid] = 0; s_pup[tid] = 0; s_pdn[tid] = 0; }
+  if (tid < 16) { s_sel[tid] = 0; s_pacc[tid] = 0; }
   for (int i = tid; i < n_hidden * Hp; i += NTH) s_bias[i] = pp.bh[i];
   for (int i = tid; i < Hp; i += NTH) s_wout[i] = pp.woutp[i];
   if (RBM) {
@@ -424,25 +422,27 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       for (int e = 0; e < 4; ++e) own[to][e] = vmc_logcosh(z[e]);
     }
   };
+  f32x4 dprev[TO];   // W1[i_dn] - W1[i_up] of the previous proposal (W1L build)
+#pragma unroll
+  for (int to = 0; to < TO; ++to) dprev[to] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto build = [&](bool with_delta) {
     if (W1L) {
       // single z1 buffer; the previous step's accepted move is folded in first (each thread
       // owns fixed elements of z1, so no barrier is needed for the read-modify-write).
       // Branch-free and with every LDS read issued before the first use: the phase costs one
       // LDS round trip instead of three per output tile.
+      // The difference of the two W1 rows of the previous proposal (dprev, in registers) is what an
+      // accepted move adds: no second pair of row reads.
       float* zrow = s_z1 + j * ZS;
       const float cp = s_pacc[j] != 0 ? 2.f : 0.f;
       const float cd = with_delta ? 2.f : 0.f;
-      const float* px = s_w1 + s_pdn[j] * W1S;
-      const float* py = s_w1 + s_pup[j] * W1S;
       const float* wa = s_w1 + (with_delta ? s_idn[j] : 0) * W1S;
       const float* wb = s_w1 + (with_delta ? s_iup[j] : 0) * W1S;
-      f32x4 z[TO], x0[TO], y0[TO], x1[TO], y1[TO];
+      f32x4 z[TO], x1[TO], y1[TO];
 #pragma unroll
       for (int to = 0; to < TO; ++to) {
         const int col = 16 * (wave * TO + to) + 4 * g;
         z[to] = *(const f32x4*)(zrow + col);
-        x0[to] = *(const f32x4*)(px + col); y0[to] = *(const f32x4*)(py + col);
         x1[to] = *(const f32x4*)(wa + col); y1[to] = *(const f32x4*)(wb + col);
       }
 #pragma unroll
@@ -451,8 +451,9 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
         f32x4 zc;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          z[to][e] = fmaf(cp, x0[to][e] - y0[to][e], z[to][e]);     // committed z1
-          zc[e] = fmaf(cd, x1[to][e] - y1[to][e], z[to][e]);        // candidate z1'
+          z[to][e] = fmaf(cp, dprev[to][e], z[to][e]);              // committed z1
+          dprev[to][e] = x1[to][e] - y1[to][e];
+          zc[e] = fmaf(cd, dprev[to][e], z[to][e]);                 // candidate z1'
         }
         finish_own(to, zc, n_hidden == 0);
         *(f32x4*)(zrow + col) = z[to];
@@ -686,7 +687,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
           if (!W1L) s_sel[c] ^= 1;
           ++n_acc;
         }
-        if (W1L) { s_pacc[c] = acc ? 1 : 0; s_pup[c] = s_iup[c]; s_pdn[c] = s_idn[c]; }
+        if (W1L) s_pacc[c] = acc ? 1 : 0;
         if (!FAST && a.acc_mask && gc < a.B) a.acc_mask[gc] = acc ? 1 : 0;
       }
     } else if (j == 0) {
