@@ -300,12 +300,41 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       s_hlu[my_c] = 0.5f * __logf(uacc);
     }
   };
+  // HANDOFF (production variant of H = 256 with W1 in LDS): the NEXT step's uniforms are drawn
+  // by waves 4-7 at the top of the iteration -- while waves 0-3 resolve the previous step and
+  // build the proposals, they have nothing to do until barrier0 -- and handed over through the
+  // part of operand buffer 1 that is dead between the output dot and layer 0's epilogue
+  // (behind s_part when that lives there).  Layer 0 then carries no Philox pieces at all.
+  // The area holds UPRE + 1 float4 slots per lane of waves 0-3; where it does not fit operand
+  // buffer 1 (256 units with 129..256 sites: five slots) it is a region of its own behind the
+  // chain state, which the launcher grants when the lattice leaves room (a.uh_lds; those shapes
+  // do not have W1 in LDS).
+  constexpr int UH_FLOATS = 4 * (UPRE + 1) * 256;
+  constexpr bool UH_IN_X = NW * 16 + UH_FLOATS <= NT * 256;
+  constexpr bool HANDOFF_T = SWEEP_HANDOFF && FAST && NW == 8 && RT > 0 && (UH_IN_X || !W1L);
+  const bool handoff = HANDOFF_T && n_hidden > 0 && (UH_IN_X || a.uh_lds != 0);
+  float* s_uh = UH_IN_X ? s_x + NT * 256 + NW * 16 : s_w1;    // [4 waves][UPRE + 1][64 lanes][4]
   // validity of this lane's 4*UPRE prefetched sites (bit k <-> site 4*(j+16*(k/4)) + k%4)
   unsigned pre_valid = 0;
 #pragma unroll
   for (int k = 0; k < 4 * UPRE; ++k)
     if (4 * (j + 16 * (k / 4)) + (k % 4) < N) pre_valid |= 1u << k;
 
+  // Hand-over variants carry each site's uniform as a sortable key: (24-bit draw << 8) | (255 - site),
+  // 0 for a site beyond the lattice.  The larger key is the larger uniform and, among equal
+  // uniforms, the smaller site index -- the first-index tie rule of tf.argmax / tf.argmin
+  // (graph_builders.py:62-65) -- so argmax / argmin of s*u over the up / down spins are two
+  // integer max reductions.  (A draw of exactly 0 at site 255 is indistinguishable from "no site";
+  // it would have to be the largest draw among all up or all down spins to matter.)
+  auto to_keys = [&]() {
+#pragma unroll
+    for (int k = 0; k < 4 * UPRE; ++k) {
+      const int n = 4 * (j + 16 * (k / 4)) + (k % 4);
+      const unsigned kk = (unsigned)(u_pre[k] * 16777216.f);
+      const unsigned key = ((pre_valid >> k) & 1u) ? ((kk << 8) | (unsigned)(255 - n)) : 0u;
+      u_pre[k] = __uint_as_float(key);
+    }
+  };
   // proposals of absolute step `step` into s_iup / s_idn / s_u
   auto proposals = [&](unsigned long long step) {
     if (NW > 4 && wave >= 4) return;   // chains 4w..4w+3 belong to waves 0-3
@@ -317,6 +346,30 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
         s_idn[tid] = ok ? a.inj_dn[gc] : 1;
         s_u[tid] = ok ? a.inj_u[gc] : 2.f;
         s_hlu[tid] = 0.5f * __logf(s_u[tid]);
+      }
+      return;
+    }
+    if (HANDOFF_T && handoff) {   // keys handed over by waves 4-7 (or made from the launch's first draw)
+      unsigned kup = 0u, kdn = 0u;
+#pragma unroll
+      for (int b = 0; b < UPRE; ++b) {
+        const f32x4 sp = *(const f32x4*)(s_spin + my_c * Nst + 4 * (j + 16 * b));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned key = __float_as_uint(u_pre[4 * b + e]);
+          kup = max(kup, sp[e] > 0.f ? key : 0u);
+          kdn = max(kdn, sp[e] < 0.f ? key : 0u);
+        }
+      }
+#define VMC_KEY_STEP(CTRL) \
+      kup = max(kup, (unsigned)dpp_i<CTRL>((int)kup)); kdn = max(kdn, (unsigned)dpp_i<CTRL>((int)kdn));
+      VMC_KEY_STEP(DPP_XOR1) VMC_KEY_STEP(DPP_XOR2) VMC_KEY_STEP(DPP_HALF_MIRROR) VMC_KEY_STEP(DPP_MIRROR)
+#undef VMC_KEY_STEP
+      if (j == 15) {
+        s_iup[my_c] = 255 - (int)(kup & 255u);   // argmax of s*u: the UP spin to lower   (graph_builders.py:64-65)
+        s_idn[my_c] = 255 - (int)(kdn & 255u);   // argmin of s*u: the DOWN spin to raise (graph_builders.py:62-63)
+        s_u[my_c] = u_pre_acc;
+        s_hlu[my_c] = 0.5f * __logf(u_pre_acc);
       }
       return;
     }
@@ -518,20 +571,6 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
 #pragma unroll
     for (int st = 0; st < PF - 1; ++st) issue(ring_l0, ring_t0 + st, st);
   }
-  // HANDOFF (production variant of H = 256 with W1 in LDS): the NEXT step's uniforms are drawn
-  // by waves 4-7 at the top of the iteration -- while waves 0-3 resolve the previous step and
-  // build the proposals, they have nothing to do until barrier0 -- and handed over through the
-  // part of operand buffer 1 that is dead between the output dot and layer 0's epilogue
-  // (behind s_part when that lives there).  Layer 0 then carries no Philox pieces at all.
-  // The area holds UPRE + 1 float4 slots per lane of waves 0-3; where it does not fit operand
-  // buffer 1 (256 units with 129..256 sites: five slots) it is a region of its own behind the
-  // chain state, which the launcher grants when the lattice leaves room (a.uh_lds; those shapes
-  // do not have W1 in LDS).
-  constexpr int UH_FLOATS = 4 * (UPRE + 1) * 256;
-  constexpr bool UH_IN_X = NW * 16 + UH_FLOATS <= NT * 256;
-  constexpr bool HANDOFF_T = SWEEP_HANDOFF && FAST && NW == 8 && RT > 0 && (UH_IN_X || !W1L);
-  const bool handoff = HANDOFF_T && n_hidden > 0 && (UH_IN_X || a.uh_lds != 0);
-  float* s_uh = UH_IN_X ? s_x + NT * 256 + NW * 16 : s_w1;    // [4 waves][UPRE + 1][64 lanes][4]
   auto forward = [&](unsigned long long next_step) {
     // Every issue below is unconditional so that the compiler can count vmcnt exactly; a load
     // issued under a runtime condition makes it wait for ALL outstanding loads at the next use.
@@ -707,6 +746,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
     if (tid < 16) s_logit[tid] = chain0 + tid < a.B ? a.logit_in[chain0 + tid] : 0.f;
     onsite_direct();
     if (use_pref) draw_all(a.step0);
+    if (HANDOFF_T && handoff) to_keys();
     __syncthreads();
     it_first = 0;
   }
@@ -714,6 +754,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
     const bool is_step = it >= 0 && it < a.n_steps;
     if (HANDOFF_T && handoff && wave >= 4) {
       draw_all(a.step0 + (unsigned long long)(it + 1));
+      to_keys();
       float* dst = s_uh + ((wave - 4) * (UPRE + 1) * 64 + lane) * 4;
 #pragma unroll
       for (int b = 0; b < UPRE; ++b)
