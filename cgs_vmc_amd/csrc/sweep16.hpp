@@ -677,14 +677,21 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   // output dot of the last activations (own) -> per-wave partial logits in s_part
   auto output_dot = [&]() {
     float part = 0.f;
+    f32x4 w[TO];
 #pragma unroll
-    for (int to = 0; to < TO; ++to) {
-      const f32x4 w = *(const f32x4*)(s_wout + 16 * (wave * TO + to) + 4 * g);
+    for (int to = 0; to < TO; ++to) w[to] = *(const f32x4*)(s_wout + 16 * (wave * TO + to) + 4 * g);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) part = fmaf(own[to][e], w[e], part);
+    for (int to = 0; to < TO; ++to)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part = fmaf(own[to][e], w[to][e], part);
+    // sum over the four 16-lane rows: lane ^ 16, then lane ^ 32 (gfx950 row / half swaps: pure
+    // VALU, the same two additions per lane as __shfl_xor without its two LDS-crossbar round trips)
+    {
+      const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+      part = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+      const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+      part = __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
     }
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
     if (g == 0) s_part[wave * 16 + j] = part;   // NW partials per chain
     __syncthreads();
   };
