@@ -475,6 +475,8 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       for (int e = 0; e < 4; ++e) own[to][e] = vmc_logcosh(z[e]);
     }
   };
+  f32x4 zreg[TO];    // committed z1 of this thread's columns (W1L build)
+  bool z_valid = false;
   f32x4 dprev[TO];   // W1[i_dn] - W1[i_up] of the previous proposal (W1L build)
 #pragma unroll
   for (int to = 0; to < TO; ++to) dprev[to] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -491,25 +493,29 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       const float cd = with_delta ? 2.f : 0.f;
       const float* wa = s_w1 + (with_delta ? s_idn[j] : 0) * W1S;
       const float* wb = s_w1 + (with_delta ? s_iup[j] : 0) * W1S;
-      f32x4 z[TO], x1[TO], y1[TO];
+      // The committed z1 of this thread's columns lives in registers (zreg) between steps; LDS
+      // holds it only where another phase produces or consumes it: the launch's cache load, the
+      // exact refresh passes (z1_direct) and the final write-back, which follows a refresh.
+      const bool from_lds = !with_delta || !z_valid;
+      f32x4 x1[TO], y1[TO];
 #pragma unroll
       for (int to = 0; to < TO; ++to) {
         const int col = 16 * (wave * TO + to) + 4 * g;
-        z[to] = *(const f32x4*)(zrow + col);
+        if (from_lds) zreg[to] = *(const f32x4*)(zrow + col);
         x1[to] = *(const f32x4*)(wa + col); y1[to] = *(const f32x4*)(wb + col);
       }
+      z_valid = true;
 #pragma unroll
       for (int to = 0; to < TO; ++to) {
-        const int t = wave * TO + to, col = 16 * t + 4 * g;
+        const int t = wave * TO + to;
         f32x4 zc;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          z[to][e] = fmaf(cp, dprev[to][e], z[to][e]);              // committed z1
+          zreg[to][e] = fmaf(cp, dprev[to][e], zreg[to][e]);        // committed z1
           dprev[to][e] = x1[to][e] - y1[to][e];
-          zc[e] = fmaf(cd, dprev[to][e], z[to][e]);                 // candidate z1'
+          zc[e] = fmaf(cd, dprev[to][e], zreg[to][e]);              // candidate z1'
         }
         finish_own(to, zc, n_hidden == 0);
-        *(f32x4*)(zrow + col) = z[to];
         *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
       }
       if (save_acts) save_own(0);
