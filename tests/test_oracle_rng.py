@@ -37,3 +37,21 @@ def test_proposal_picks_one_up_one_down():
   i_up, i_dn = vo.propose_exchange(cfg, u)
   rows = np.arange(50)
   assert (cfg[rows, i_up] == 1).all() and (cfg[rows, i_dn] == -1).all()
+
+
+def test_tie_event_fixture_matches_the_philox_stream():
+  """tests/golden/tie_events.json (gen_tie_events.py): the listed chains really draw their largest
+  site uniform twice at the listed step, and np.argmax / np.argmin break the tie by first index."""
+  import json
+  import os
+  here = os.path.dirname(os.path.abspath(__file__))
+  with open(os.path.join(here, 'golden', 'tie_events.json')) as f:
+    ties = json.load(f)
+  assert len(ties['events']) >= 4
+  for e in ties['events']:
+    u, _ = vo.step_uniforms(ties['seed'], np.array([e['chain']], np.uint32), e['step'], e['n_sites'])
+    top = np.nonzero(u[0] == u[0].max())[0]
+    assert [int(s) for s in top] == e['sites'] and len(top) >= 2
+    up = np.ones((1, e['n_sites']), np.float32)
+    assert vo.propose_exchange(up, u)[0][0] == e['sites'][0]
+    assert vo.propose_exchange(-up, u)[1][0] == e['sites'][0]
