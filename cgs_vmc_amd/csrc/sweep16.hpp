@@ -51,8 +51,12 @@
 //   layers 2..L by 16x16x4 MFMA, wave w owns output units [w*Hp/NW, (w+1)*Hp/NW)
 //   accept = exp(logit' - logit) > sqrt(u)        (graph_builders.py:75-79), evaluated as
 //            logit' - logit > 0.5 log u by the wave that owns the chain
-// Chain state (spins, z1, logit) stays in LDS; z1 and logit are recomputed from the spins
-// at launch start and end so the cache written back never carries incremental drift.
+// Chain state (spins, logit) stays in LDS, the committed z1 of a thread's columns in its registers
+// (W1-in-LDS variants); z1 and logit are recomputed from the spins at launch start and end so the
+// cache written back never carries incremental drift.
+// With 8 waves the chains belong to waves 0-3; waves 4-7 use the time until barrier0 to draw the
+// next step's Philox uniforms and hand them over as sortable keys (HANDOFF below), so that the
+// MFMA phases carry no VALU work.
 //
 // Weight traffic: the A-operand fragments of the first RT (= 14 of 16 at H = 256) k-tiles of
 // the FIRST H x H layer of this wave's output units are loaded once and stay in registers for
@@ -300,7 +304,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       s_hlu[my_c] = 0.5f * __logf(uacc);
     }
   };
-  // HANDOFF (production variant of H = 256 with W1 in LDS): the NEXT step's uniforms are drawn
+  // HANDOFF (every prefetching 8-wave variant with resident k-tiles): the NEXT step's uniforms are drawn
   // by waves 4-7 at the top of the iteration -- while waves 0-3 resolve the previous step and
   // build the proposals, they have nothing to do until barrier0 -- and handed over through the
   // part of operand buffer 1 that is dead between the output dot and layer 0's epilogue
