@@ -96,7 +96,13 @@ __device__ __forceinline__ float vmc_logcosh(float z) {
 
 template <int ACT>
 __device__ __forceinline__ float vmc_act(float z) {
-  if (ACT == VMC_ACT_RELU_) return fmaxf(z, 0.f);
+  if (ACT == VMC_ACT_RELU_) {
+    // one v_max_f32: fmaxf() costs a second one (LLVM quiets a possible signalling NaN first), and
+    // VALU instructions next to MFMAs are paid in matrix time; max(0, NaN) = 0 either way
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(z));
+    return r;
+  }
   if (ACT == VMC_ACT_EXP_) return expf(z);
   if (ACT == VMC_ACT_COS_) return __cosf(z);
   if (ACT == VMC_ACT_TAN_) return __sinf(z) / __cosf(z);
