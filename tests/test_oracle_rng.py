@@ -55,3 +55,22 @@ def test_tie_event_fixture_matches_the_philox_stream():
     up = np.ones((1, e['n_sites']), np.float32)
     assert vo.propose_exchange(up, u)[0][0] == e['sites'][0]
     assert vo.propose_exchange(-up, u)[1][0] == e['sites'][0]
+
+
+def test_sortable_keys_order_like_argmax_with_first_index_ties():
+  """The production sampler reduces keys (24-bit draw << 8) | (255 - site) with integer max
+  (csrc/sweep16.hpp: to_keys / keyed_publish) instead of argmax / argmin of s*u.  Restated in numpy
+  on draws with many forced ties: both give the same (i_up, i_dn) as propose_exchange."""
+  rng = np.random.default_rng(7)
+  for n in (16, 100, 256):
+    draws = rng.integers(0, 1 << 24, size=(2000, n), dtype=np.uint32)
+    draws[:, : n // 2] >>= rng.integers(14, 24, size=(2000, 1)).astype(np.uint32)  # few distinct values: ties
+    rng.permuted(draws, axis=1, out=draws)
+    u = draws.astype(np.float32) * np.float32(1.0 / 16777216.0)
+    spins = np.where(rng.permuted(np.tile(np.arange(n) % 2, (2000, 1)), axis=1) == 0, 1.0, -1.0).astype(np.float32)
+    i_up, i_dn = vo.propose_exchange(spins, u)
+    keys = (draws.astype(np.uint64) << np.uint64(8)) | (np.uint64(255) - np.arange(n, dtype=np.uint64))[None, :]
+    kup = np.where(spins > 0, keys, 0).max(axis=1)
+    kdn = np.where(spins < 0, keys, 0).max(axis=1)
+    np.testing.assert_array_equal(255 - (kup & np.uint64(255)).astype(np.int64), i_up)
+    np.testing.assert_array_equal(255 - (kdn & np.uint64(255)).astype(np.int64), i_dn)
