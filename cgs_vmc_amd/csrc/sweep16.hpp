@@ -723,23 +723,31 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   auto resolve = [&]() {
     if (prev_kind == 0 || (NW > 4 && wave >= 4)) return;
     const int c = my_c, gc = chain0 + c;
+    // every LDS operand of the accept test is requested before the first one is used: one LDS
+    // round trip for the phase instead of four (the asm pins the loads above the branches)
+    float lg = s_logit[c], hl = s_hlu[c];
+    int idn = s_idn[c], iup = s_iup[c];
     float ln = logit_of(c);
+    asm volatile("" : "+v"(lg), "+v"(hl), "+v"(idn), "+v"(iup));
     float on_new = 0.f;
     if (RBM) {   // onsite term of the evaluated configuration: committed value (+ exchange update)
       on_new = s_on[c];
-      if (prev_kind == 2) on_new += 2.f * (won_at(s_idn[c]) - won_at(s_iup[c]));
+      if (prev_kind == 2) on_new += 2.f * (won_at(idn) - won_at(iup));
       ln += on_new;
     }
     if (prev_kind == 2) {
       // Metropolis accept (graph_builders.py:75-88)
       // exp(dlogit) > sqrt(u)  <=>  dlogit > 0.5 log(u)  (monotone; u = 0 always accepts)
-      const bool acc = (gc < a.B) && vmc_out_accept(a.oact, ln, s_logit[c], s_u[c], s_hlu[c]);
+      bool acc;
+      if (a.oact == VMC_ACT_EXP_) acc = (ln - lg) > hl;
+      else acc = vmc_out_accept(a.oact, ln, lg, s_u[c], hl);
+      acc = acc && (gc < a.B);
       if (j == 0) {
         if (acc) {
           s_logit[c] = ln;
           if (RBM) s_on[c] = on_new;
-          s_spin[c * Nst + s_idn[c]] = 1.f;
-          s_spin[c * Nst + s_iup[c]] = -1.f;
+          s_spin[c * Nst + idn] = 1.f;
+          s_spin[c * Nst + iup] = -1.f;
           if (!W1L) s_sel[c] ^= 1;
           ++n_acc;
         }
