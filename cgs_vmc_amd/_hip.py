@@ -46,6 +46,10 @@ class HipLibraryError(RuntimeError):
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
 _ctx = C.c_void_p
+_bp = C.POINTER(C.c_uint8)
+VMC_REDUCE_SUM, VMC_REDUCE_MAX = 0, 1
+# vmc_host_allreduce_fn: int hook(void* user, float* host_buf, int64_t n_floats, int32_t op)
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_int64, C.c_int32)
 
 # name -> (restype, argtypes); every symbol include/cgsvmc.h declares
 SIGNATURES = {
@@ -88,6 +92,20 @@ SIGNATURES = {
     'vmc_epoch_log_overlap': (C.c_int, [_ctx, C.c_float, C.c_int64, C.c_int32, C.c_int64, C.c_float,
                                         C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.POINTER(C.c_double)]),
+    'vmc_set_host_allreduce': (C.c_int, [_ctx, HOST_ALLREDUCE_FN, C.c_void_p]),
+    'vmc_rccl_unique_id': (C.c_int, [_bp]),
+    'vmc_rccl_comm_create': (C.c_int, [_bp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    'vmc_rccl_comm_destroy': (C.c_int, [C.c_void_p]),
+    'vmc_rccl_last_error': (C.c_char_p, []),
+    'vmc_debug_allreduce': (C.c_int, [_ctx, C.c_void_p, C.c_int32, _fp, C.c_int64, C.c_int32]),
+    'vmc_update_norm_dist': (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_float]),
+    'vmc_epoch_energy_gradient_dist': (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,
+                                                 C.c_int64, C.c_float]),
+    'vmc_epoch_log_overlap_dist': (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_float, C.c_int64,
+                                             C.c_int32, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                             C.c_float, C.c_float, C.POINTER(C.c_double)]),
+    'vmc_sr_solve_dist': (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int32,
+                                    C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     'vmc_sr_reserve': (C.c_int, [_ctx, C.c_int32]),
     'vmc_sr_num_stored': (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     'vmc_sr_begin': (C.c_int, [_ctx, C.POINTER(C.c_double)]),
@@ -117,7 +135,7 @@ _STAMP_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libcgsvm
 # the files the library is built from, in the order csrc/Makefile hashes them
 _SOURCES = ('vmc_api.hip', 'mlp.hip', 'eloc.hip', 'grad.hip', 'sr.hip', 'srmm.hip', 'conv.hip', 'wide.hip', 'tail_co.hip', 'act_tail.hip',
             'act_sweep.hip', 'common.hpp', 'tail16.hpp', 'sweep16.hpp', 'conv.hpp',
-            os.path.join('..', '..', 'include', 'cgsvmc.h'))
+            os.path.join('..', '..', 'include', 'cgsvmc.h'), 'Makefile')
 
 
 def library_path() -> str:
@@ -136,10 +154,16 @@ def source_hash() -> str:
 
 
 def stamp_matches() -> bool:
-  """True when libcgsvmc_hip.so was linked from exactly the sources in the tree."""
+  """True when libcgsvmc_hip.so was linked from exactly the sources in the tree, with the
+  product flags (a build with EXTRA=... flags -- diagnostics such as the s_memtime-stamped sampler
+  -- only loads under CGS_VMC_ALLOW_EXTRA_BUILD=1)."""
   try:
     with open(_STAMP_PATH) as f:
-      return f.read().split()[0] == source_hash()
+      fields = f.read().split()
+    if fields[0] != source_hash():
+      return False
+    extra = fields[1] if len(fields) > 1 else '-'
+    return extra == '-' or os.environ.get('CGS_VMC_ALLOW_EXTRA_BUILD', '0') == '1'
   except (OSError, IndexError):
     return False
 

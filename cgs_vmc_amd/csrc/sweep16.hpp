@@ -370,10 +370,17 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       VMC_KEY_STEP(DPP_XOR1) VMC_KEY_STEP(DPP_XOR2) VMC_KEY_STEP(DPP_HALF_MIRROR) VMC_KEY_STEP(DPP_MIRROR)
 #undef VMC_KEY_STEP
       if (j == 15) {
-        s_iup[my_c] = 255 - (int)(kup & 255u);   // argmax of s*u: the UP spin to lower   (graph_builders.py:64-65)
-        s_idn[my_c] = 255 - (int)(kdn & 255u);   // argmin of s*u: the DOWN spin to raise (graph_builders.py:62-63)
-        s_u[my_c] = u_pre_acc;
-        s_hlu[my_c] = 0.5f * __logf(u_pre_acc);
+        // A chain without an up (or without a down) spin has no exchange move: no key survives the
+        // reduction and 255 - (0 & 255) would address site 255 of a smaller lattice (W1 rows, a
+        // neighbouring chain's spins).  Such a chain proposes the null move 0 <-> 0 with a NaN
+        // acceptance uniform, which every accept test rejects (x > NaN is false): it stays frozen.
+        // The reference's scatter arithmetic (graph_builders.py:67-71) would write a spin of +-3.
+        const bool none = (kup == 0u) | (kdn == 0u);
+        const float ua = none ? __uint_as_float(0x7fc00000u) : u_pre_acc;
+        s_iup[my_c] = none ? 0 : 255 - (int)(kup & 255u);   // argmax of s*u: the UP spin to lower   (graph_builders.py:64-65)
+        s_idn[my_c] = none ? 0 : 255 - (int)(kdn & 255u);   // argmin of s*u: the DOWN spin to raise (graph_builders.py:62-63)
+        s_u[my_c] = ua;
+        s_hlu[my_c] = 0.5f * __logf(ua);
       }
       return;
     }

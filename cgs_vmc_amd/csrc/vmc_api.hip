@@ -132,6 +132,12 @@ struct vmc_ctx {
   double *sr_partial = nullptr, *sr_sc = nullptr;
   GemmArgs* sr_batch = nullptr;                                       // [L+1]
   bool sr_begun = false;
+  // collectives over sharded chains: host hook for non-RCCL transports + its staging
+  vmc_host_allreduce_fn host_reduce = nullptr;
+  void* host_reduce_user = nullptr;
+  float* h_stage = nullptr;      // pinned
+  float* d_stage = nullptr;      // vmc_debug_allreduce only
+  long long h_stage_n = 0, d_stage_n = 0;
   // scratch
   unsigned long long* d_accepted = nullptr;
   double* d_sum = nullptr;
@@ -537,6 +543,85 @@ float host_activation(int act, float x) {
   }
 }
 
+// ---------------------------------------------------------------- collectives
+// RCCL is resolved at first use with dlopen -- the copy already loaded into the process (torch's)
+// if there is one -- so the library itself carries no link-time dependency on it.
+struct RcclUniqueId { char internal[128]; };   // ncclUniqueId
+struct Rccl {
+  int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*get_unique_id)(RcclUniqueId*) = nullptr;
+  int (*comm_init_rank)(void**, int, RcclUniqueId, int) = nullptr;
+  int (*comm_destroy)(void*) = nullptr;
+  const char* (*get_error_string)(int) = nullptr;
+};
+std::string g_rccl_error;
+
+const Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false, ok = false;
+  if (!tried) {
+    tried = true;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (h) {
+      r.all_reduce = (decltype(r.all_reduce))dlsym(h, "ncclAllReduce");
+      r.get_unique_id = (decltype(r.get_unique_id))dlsym(h, "ncclGetUniqueId");
+      r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(h, "ncclCommInitRank");
+      r.comm_destroy = (decltype(r.comm_destroy))dlsym(h, "ncclCommDestroy");
+      r.get_error_string = (decltype(r.get_error_string))dlsym(h, "ncclGetErrorString");
+    }
+    ok = r.all_reduce && r.get_unique_id && r.comm_init_rank && r.comm_destroy;
+    if (!ok) g_rccl_error = "librccl.so / its nccl* entry points not found";
+  }
+  return ok ? &r : nullptr;
+}
+
+std::string rccl_error_string(const Rccl* r, int rc) {
+  return (r && r->get_error_string) ? std::string(r->get_error_string(rc)) : "code " + std::to_string(rc);
+}
+
+// In-place all-reduce of n floats at device pointer buf, ordered on the ctx's stream.
+//   comm != NULL                : ncclAllReduce on the stream (no host synchronisation)
+//   comm == NULL, world <= 1    : nothing to do
+//   comm == NULL, world  > 1    : the registered host hook, staged through pinned host memory
+int reduce_buffer(vmc_ctx* c, void* comm, int world, float* buf, long long n, int op) {
+  if (comm) {
+    const Rccl* r = rccl();
+    if (!r) return fail(c, VMC_ERR_UNSUPPORTED, g_rccl_error);
+    const int rc = r->all_reduce(buf, buf, (size_t)n, /*ncclFloat32*/ 7, op == VMC_REDUCE_MAX ? /*ncclMax*/ 2 : /*ncclSum*/ 0,
+                                 comm, c->stream);
+    if (rc != 0) return fail(c, VMC_ERR_HIP, "ncclAllReduce: " + rccl_error_string(r, rc));
+    return VMC_OK;
+  }
+  if (world <= 1) return VMC_OK;
+  if (!c->host_reduce)
+    return fail(c, VMC_ERR_STATE, "world_size > 1 needs an RCCL communicator or vmc_set_host_allreduce");
+  if (n > c->h_stage_n) {
+    if (c->h_stage) hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->h_stage_n = 0;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, (size_t)n * sizeof(float), hipHostMallocDefault));
+    c->h_stage_n = n;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_stage, buf, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int rc = c->host_reduce(c->host_reduce_user, c->h_stage, n, op);
+  if (rc != 0) return fail(c, VMC_ERR_HIP, "host all-reduce hook failed with code " + std::to_string(rc));
+  HIPCHK(c, hipMemcpyAsync(buf, c->h_stage, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  return VMC_OK;
+}
+
+bool sharded(void* comm, int world) { return comm != nullptr || world > 1; }
+
+int reduce_accumulators(vmc_ctx* c, void* comm, int world) {
+  if (!sharded(comm, world)) return VMC_OK;
+  PROPAGATE(reduce_buffer(c, comm, world, c->acc, 2 * c->P + 8, VMC_REDUCE_SUM));
+  HIPCHK(c, launch_scale_one(c->stream, c->acc + 2 * c->P + 4, 1.f / (float)(world > 1 ? world : 1)));
+  return VMC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -808,6 +893,8 @@ void vmc_destroy(vmc_ctx* c) {
   void* sr[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_u, c->sr_x, c->sr_r,
                 c->sr_p, c->sr_q, c->sr_partial, c->sr_sc, c->sr_batch, c->sr_ones};
   for (void* q : sr) if (q) hipFree(q);
+  if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->d_stage) hipFree(c->d_stage);
   delete c;
 }
 
@@ -1357,25 +1444,77 @@ int vmc_accumulators_devptr(vmc_ctx* c, void** dev_ptr, int64_t* n_floats) {
   return VMC_OK;
 }
 
-// In-place SUM all-reduce of the accumulator buffer over an existing RCCL communicator, for hosts
-// without torch.distributed.  librccl is resolved at the first call (dlopen), so the library
-// itself does not depend on it; comm == NULL is the single-rank no-op.  g_count (number of
-// accumulate calls, identical on every rank) is divided back by the world size so that sharded
-// and unsharded gradients agree (see cgs_vmc_amd/parallel.py).
+// In-place SUM all-reduce of the accumulator buffer, stream-ordered on the ctx's stream (transport:
+// see reduce_buffer).  g_count (number of accumulate calls, identical on every rank) is divided
+// back by the world size so that sharded and unsharded gradients agree (cgs_vmc_amd/parallel.py).
 int vmc_allreduce_accumulators(vmc_ctx* c, void* nccl_comm, int32_t world_size) {
   CHECK_CTX(c);
-  if (!nccl_comm || world_size <= 1) return VMC_OK;
-  typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
-  static allreduce_fn fn = nullptr;
-  if (!fn) {
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (h) fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
-    if (!fn) return fail(c, VMC_ERR_UNSUPPORTED, "librccl.so / ncclAllReduce not found");
+  PROPAGATE(reduce_accumulators(c, nccl_comm, world_size));
+  return VMC_OK;
+}
+
+int vmc_set_host_allreduce(vmc_ctx* c, vmc_host_allreduce_fn hook, void* user) {
+  CHECK_CTX(c);
+  c->host_reduce = hook;
+  c->host_reduce_user = user;
+  return VMC_OK;
+}
+
+const char* vmc_rccl_last_error(void) { return g_rccl_error.c_str(); }
+
+int vmc_rccl_unique_id(uint8_t id[128]) {
+  if (!id) { g_rccl_error = "null id"; return VMC_ERR_INVALID; }
+  const Rccl* r = rccl();
+  if (!r) return VMC_ERR_UNSUPPORTED;
+  RcclUniqueId u;
+  const int rc = r->get_unique_id(&u);
+  if (rc != 0) { g_rccl_error = std::string("ncclGetUniqueId: ") + rccl_error_string(r, rc); return VMC_ERR_HIP; }
+  memcpy(id, u.internal, sizeof(u.internal));
+  return VMC_OK;
+}
+
+int vmc_rccl_comm_create(const uint8_t id[128], int32_t world_size, int32_t rank, int32_t device,
+                         void** nccl_comm) {
+  if (!id || !nccl_comm || world_size < 1 || rank < 0 || rank >= world_size) {
+    g_rccl_error = "bad communicator arguments";
+    return VMC_ERR_INVALID;
   }
-  const int rc = fn(c->acc, c->acc, (size_t)(2 * c->P + 8), /*ncclFloat32*/ 7, /*ncclSum*/ 0, nccl_comm, c->stream);
-  if (rc != 0) return fail(c, VMC_ERR_HIP, "ncclAllReduce failed with code " + std::to_string(rc));
-  HIPCHK(c, launch_scale_one(c->stream, c->acc + 2 * c->P + 4, 1.f / (float)world_size));
+  *nccl_comm = nullptr;
+  const Rccl* r = rccl();
+  if (!r) return VMC_ERR_UNSUPPORTED;
+  DeviceGuard guard(device);
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != device) { g_rccl_error = "cannot select the device"; return VMC_ERR_HIP; }
+  RcclUniqueId u;
+  memcpy(u.internal, id, sizeof(u.internal));
+  const int rc = r->comm_init_rank(nccl_comm, world_size, u, rank);
+  if (rc != 0) { g_rccl_error = std::string("ncclCommInitRank: ") + rccl_error_string(r, rc); *nccl_comm = nullptr; return VMC_ERR_HIP; }
+  return VMC_OK;
+}
+
+int vmc_rccl_comm_destroy(void* nccl_comm) {
+  if (!nccl_comm) return VMC_OK;
+  const Rccl* r = rccl();
+  if (!r) return VMC_ERR_UNSUPPORTED;
+  const int rc = r->comm_destroy(nccl_comm);
+  if (rc != 0) { g_rccl_error = std::string("ncclCommDestroy: ") + rccl_error_string(r, rc); return VMC_ERR_HIP; }
+  return VMC_OK;
+}
+
+int vmc_debug_allreduce(vmc_ctx* c, void* nccl_comm, int32_t world_size, float* host, int64_t n, int32_t op) {
+  ENTER(c);
+  if (!host || n < 1 || (op != VMC_REDUCE_SUM && op != VMC_REDUCE_MAX)) return fail(c, VMC_ERR_INVALID, "bad arguments");
+  if (n > c->d_stage_n) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_stage) hipFree(c->d_stage);
+    c->d_stage = nullptr; c->d_stage_n = 0;
+    HIPCHK(c, dalloc(&c->d_stage, n));
+    c->d_stage_n = n;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_stage, host, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  PROPAGATE(reduce_buffer(c, nccl_comm, world_size, c->d_stage, n, op));
+  HIPCHK(c, hipMemcpyAsync(host, c->d_stage, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return VMC_OK;
 }
 
@@ -1449,11 +1588,12 @@ int vmc_set_adam_state(vmc_ctx* c, const float* m, const float* v, int64_t t) {
   return VMC_OK;
 }
 
-int vmc_update_norm(vmc_ctx* c, float max_value) {
-  ENTER(c);
+// Wavefunction.update_norm (wavefunctions.py:261-288); max_b psi over the chains of all ranks
+static int update_norm_impl(vmc_ctx* c, void* comm, int world, float max_value) {
   if (c->oact != VMC_ACT_EXP_) return VMC_OK;   // wavefunctions.py:276-277: no exp_norm_shift, nothing to do
   PROPAGATE(ensure_cache(c, VMC_PSI));
   HIPCHK(c, launch_max(c->stream, c->ps[0].logit, c->B, c->d_max));
+  PROPAGATE(reduce_buffer(c, comm, world, c->d_max, 1, VMC_REDUCE_MAX));
   float mx = 0.f;
   HIPCHK(c, hipMemcpyAsync(&mx, c->d_max, sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1467,18 +1607,66 @@ int vmc_update_norm(vmc_ctx* c, float max_value) {
   return VMC_OK;
 }
 
-int vmc_epoch_energy_gradient(vmc_ctx* c, int64_t n_eq_steps, int32_t n_batches, int64_t n_mc_steps,
-                              float max_value) {
+int vmc_update_norm(vmc_ctx* c, float max_value) {
   ENTER(c);
+  return update_norm_impl(c, nullptr, 1, max_value);
+}
+
+int vmc_update_norm_dist(vmc_ctx* c, void* nccl_comm, int32_t world_size, float max_value) {
+  ENTER(c);
+  return update_norm_impl(c, nccl_comm, world_size, max_value);
+}
+
+static int epoch_energy_gradient_impl(vmc_ctx* c, void* comm, int world, int64_t n_eq_steps, int32_t n_batches,
+                                      int64_t n_mc_steps, float max_value) {
   if (n_eq_steps < 0 || n_batches < 0 || n_mc_steps < 0) return fail(c, VMC_ERR_INVALID, "negative count");
   PROPAGATE(vmc_mc_steps(c, n_eq_steps, nullptr));                       // training.py:608-609
-  if (max_value > 0.f) PROPAGATE(vmc_update_norm(c, max_value));          // training.py:611-612
+  if (max_value > 0.f) {                                                  // training.py:611-612
+    PROPAGATE(join_sweep(c));
+    PROPAGATE(update_norm_impl(c, comm, world, max_value));
+  }
   PROPAGATE(vmc_reset_accumulators(c));                                   // training.py:613
   for (int b = 0; b < n_batches; ++b) {                                   // training.py:614-617
     c->expect_sweep = n_mc_steps > 0;
     PROPAGATE(vmc_accumulate(c, VMC_MODE_ENERGY_GRADIENT, 0.f));
     PROPAGATE(vmc_mc_steps(c, n_mc_steps, nullptr));
   }
+  // sharded chains: the accumulators leave this call summed over ranks (the last sweep, on its own
+  // stream when it overtook the accumulate, keeps running underneath the collective)
+  PROPAGATE(reduce_accumulators(c, comm, world));
+  return VMC_OK;
+}
+
+int vmc_epoch_energy_gradient(vmc_ctx* c, int64_t n_eq_steps, int32_t n_batches, int64_t n_mc_steps,
+                              float max_value) {
+  ENTER(c);
+  return epoch_energy_gradient_impl(c, nullptr, 1, n_eq_steps, n_batches, n_mc_steps, max_value);
+}
+
+int vmc_epoch_energy_gradient_dist(vmc_ctx* c, void* nccl_comm, int32_t world_size, int64_t n_eq_steps,
+                                   int32_t n_batches, int64_t n_mc_steps, float max_value) {
+  ENTER(c);
+  return epoch_energy_gradient_impl(c, nccl_comm, world_size, n_eq_steps, n_batches, n_mc_steps, max_value);
+}
+
+static int epoch_log_overlap_impl(vmc_ctx* c, void* comm, int world, float beta, int64_t n_eq_steps,
+                                  int32_t n_batches, int64_t n_mc_steps, float max_value, float lr,
+                                  float beta1, float beta2, float eps, double* energy) {
+  if (n_eq_steps < 0 || n_batches < 0 || n_mc_steps < 0) return fail(c, VMC_ERR_INVALID, "negative count");
+  PROPAGATE(vmc_mc_steps(c, n_eq_steps, nullptr));                       // training.py:750-751
+  if (max_value > 0.f) {                                                  // training.py:753-754
+    PROPAGATE(join_sweep(c));
+    PROPAGATE(update_norm_impl(c, comm, world, max_value));
+  }
+  PROPAGATE(vmc_transfer_params(c));                                      // training.py:755
+  for (int b = 0; b < n_batches; ++b) {                                   // training.py:756-761
+    PROPAGATE(vmc_mc_steps(c, n_mc_steps, nullptr));
+    PROPAGATE(vmc_reset_accumulators(c));
+    PROPAGATE(vmc_accumulate(c, VMC_MODE_LOG_OVERLAP_ITSWO, beta));
+    PROPAGATE(reduce_accumulators(c, comm, world));   // in stream: Adam sees the sums over all ranks
+    PROPAGATE(vmc_apply_adam(c, VMC_MODE_LOG_OVERLAP_ITSWO, lr, beta1, beta2, eps, nullptr));
+  }
+  if (energy) PROPAGATE(vmc_mean_energy(c, energy));                      // training.py:763
   return VMC_OK;
 }
 
@@ -1486,18 +1674,16 @@ int vmc_epoch_log_overlap(vmc_ctx* c, float beta, int64_t n_eq_steps, int32_t n_
                           int64_t n_mc_steps, float max_value, float lr, float beta1, float beta2,
                           float eps, double* energy) {
   ENTER(c);
-  if (n_eq_steps < 0 || n_batches < 0 || n_mc_steps < 0) return fail(c, VMC_ERR_INVALID, "negative count");
-  PROPAGATE(vmc_mc_steps(c, n_eq_steps, nullptr));                       // training.py:750-751
-  if (max_value > 0.f) PROPAGATE(vmc_update_norm(c, max_value));          // training.py:753-754
-  PROPAGATE(vmc_transfer_params(c));                                      // training.py:755
-  for (int b = 0; b < n_batches; ++b) {                                   // training.py:756-761
-    PROPAGATE(vmc_mc_steps(c, n_mc_steps, nullptr));
-    PROPAGATE(vmc_reset_accumulators(c));
-    PROPAGATE(vmc_accumulate(c, VMC_MODE_LOG_OVERLAP_ITSWO, beta));
-    PROPAGATE(vmc_apply_adam(c, VMC_MODE_LOG_OVERLAP_ITSWO, lr, beta1, beta2, eps, nullptr));
-  }
-  if (energy) PROPAGATE(vmc_mean_energy(c, energy));                      // training.py:763
-  return VMC_OK;
+  return epoch_log_overlap_impl(c, nullptr, 1, beta, n_eq_steps, n_batches, n_mc_steps, max_value, lr, beta1, beta2,
+                                eps, energy);
+}
+
+int vmc_epoch_log_overlap_dist(vmc_ctx* c, void* nccl_comm, int32_t world_size, float beta, int64_t n_eq_steps,
+                               int32_t n_batches, int64_t n_mc_steps, float max_value, float lr, float beta1,
+                               float beta2, float eps, double* energy) {
+  ENTER(c);
+  return epoch_log_overlap_impl(c, nccl_comm, world_size, beta, n_eq_steps, n_batches, n_mc_steps, max_value, lr,
+                                beta1, beta2, eps, energy);
 }
 
 // ------------------------------------------------------------------ stochastic reconfiguration
@@ -1655,8 +1841,8 @@ int vmc_sr_cg_update(vmc_ctx* c, float diag_shift, double* rr) {
   return sr_read_rr(c, cur ^ 1, rr);
 }
 
-int vmc_sr_solve(vmc_ctx* c, float diag_shift, float tol, int32_t max_iter, int32_t* iters, double* rel_residual) {
-  ENTER(c);
+static int sr_solve_impl(vmc_ctx* c, void* comm, int world, float diag_shift, float tol, int32_t max_iter,
+                         int32_t* iters, double* rel_residual) {
   if (max_iter < 0 || tol < 0.f) return fail(c, VMC_ERR_INVALID, "bad CG arguments");
   double rr0 = 0.0, rr = 0.0;
   PROPAGATE(vmc_sr_begin(c, &rr0));
@@ -1664,12 +1850,25 @@ int vmc_sr_solve(vmc_ctx* c, float diag_shift, float tol, int32_t max_iter, int3
   int it = 0;
   while (it < max_iter && rr > (double)tol * (double)tol * rr0 && rr0 > 0.0) {
     PROPAGATE(vmc_sr_matvec_partial(c));
+    // sharded samples: u = sum_b (O_b . p) O_b and sum_b O_b . p over all ranks, in stream
+    if (sharded(comm, world)) PROPAGATE(reduce_buffer(c, comm, world, c->sr_u, c->P + 1, VMC_REDUCE_SUM));
     PROPAGATE(vmc_sr_cg_update(c, diag_shift, &rr));
     ++it;
   }
   if (iters) *iters = it;
   if (rel_residual) *rel_residual = rr0 > 0.0 ? sqrt(rr / rr0) : 0.0;
   return VMC_OK;
+}
+
+int vmc_sr_solve(vmc_ctx* c, float diag_shift, float tol, int32_t max_iter, int32_t* iters, double* rel_residual) {
+  ENTER(c);
+  return sr_solve_impl(c, nullptr, 1, diag_shift, tol, max_iter, iters, rel_residual);
+}
+
+int vmc_sr_solve_dist(vmc_ctx* c, void* nccl_comm, int32_t world_size, float diag_shift, float tol,
+                      int32_t max_iter, int32_t* iters, double* rel_residual) {
+  ENTER(c);
+  return sr_solve_impl(c, nccl_comm, world_size, diag_shift, tol, max_iter, iters, rel_residual);
 }
 
 int vmc_sr_get_solution(vmc_ctx* c, float* x) {

@@ -283,6 +283,60 @@ class VmcEngine:
   def update_norm(self, max_value: float = 1e10):
     self._check(self._lib.vmc_update_norm(self._ctx, float(max_value)))
 
+  # ------------------------------------------------------------------ chains sharded over ranks
+  # `coll` is a parallel.Collective: (RCCL communicator handle or None, world size, host hook).
+  def _bind_collective(self, coll):
+    """Registers coll's host all-reduce hook (non-RCCL transports) and returns (comm, world)."""
+    hook = coll.host_hook()
+    if getattr(self, '_host_hook', None) is not hook:
+      self._check(self._lib.vmc_set_host_allreduce(
+          self._ctx, hook if hook is not None else _hip.HOST_ALLREDUCE_FN(), None))
+      self._host_hook = hook       # keeps the ctypes thunk alive as long as the ctx may call it
+    return C.c_void_p(coll.comm or None), int(coll.world)
+
+  def allreduce_accumulators_dist(self, coll):
+    comm, world = self._bind_collective(coll)
+    self._check(self._lib.vmc_allreduce_accumulators(self._ctx, comm, world))
+
+  def update_norm_dist(self, coll, max_value: float = 1e10):
+    comm, world = self._bind_collective(coll)
+    self._check(self._lib.vmc_update_norm_dist(self._ctx, comm, world, float(max_value)))
+
+  def debug_allreduce(self, coll, values: np.ndarray, op: str = 'sum') -> np.ndarray:
+    comm, world = self._bind_collective(coll)
+    buf = np.ascontiguousarray(values, np.float32).copy()
+    self._check(self._lib.vmc_debug_allreduce(
+        self._ctx, comm, world, _fptr(buf), buf.size,
+        _hip.VMC_REDUCE_MAX if op == 'max' else _hip.VMC_REDUCE_SUM))
+    return buf
+
+  def epoch_energy_gradient_dist(self, coll, n_eq_steps: int, n_batches: int, n_mc_steps: int,
+                                 max_value: float = 1e10):
+    """epoch_energy_gradient over sharded chains; the accumulators come back all-reduced."""
+    comm, world = self._bind_collective(coll)
+    self._check(self._lib.vmc_epoch_energy_gradient_dist(
+        self._ctx, comm, world, int(n_eq_steps), int(n_batches), int(n_mc_steps), float(max_value)))
+
+  def epoch_log_overlap_dist(self, coll, beta: float, n_eq_steps: int, n_batches: int,
+                             n_mc_steps: int, max_value: float, lr: float, beta1: float,
+                             beta2: float, eps: float) -> float:
+    """epoch_log_overlap over sharded chains: one in-stream all-reduce per batch."""
+    comm, world = self._bind_collective(coll)
+    e = C.c_double()
+    self._check(self._lib.vmc_epoch_log_overlap_dist(
+        self._ctx, comm, world, float(beta), int(n_eq_steps), int(n_batches), int(n_mc_steps),
+        float(max_value), lr, beta1, beta2, eps, C.byref(e)))
+    return float(e.value)
+
+  def sr_solve_dist(self, coll, diag_shift: float, tol: float, max_iter: int) -> Tuple[int, float]:
+    """sr_solve with the stored samples sharded over ranks (one in-stream all-reduce per iteration)."""
+    comm, world = self._bind_collective(coll)
+    it = C.c_int32()
+    res = C.c_double()
+    self._check(self._lib.vmc_sr_solve_dist(self._ctx, comm, world, float(diag_shift), float(tol),
+                                            int(max_iter), C.byref(it), C.byref(res)))
+    return int(it.value), float(res.value)
+
   # ------------------------------------------------------------------ stochastic reconfiguration
   # Extension named by the north star, absent from the reference (see include/cgsvmc.h).
   def sr_reserve(self, n_batches: int):

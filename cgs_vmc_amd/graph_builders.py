@@ -79,6 +79,9 @@ class ConfigsVariable:
     self.shape = (batch_size, n_sites)
     self.local_batch, self.chain_offset = parallel.shard(batch_size)
     self._seed = seed
+    # the sampler key is drawn (and shared over ranks: a collective) HERE, where every rank
+    # constructs the variable, not at first engine use, which a rank may reach in another order
+    self._sampler_seed = sampler_seed()
     self._engine = None
     self._engine_spec = None
     self._slots = {}
@@ -102,7 +105,7 @@ class ConfigsVariable:
   def _get_engine(self, wavefunction):
     if self._engine is None:
       from .engine import VmcEngine
-      seed = sampler_seed()
+      seed = self._sampler_seed
       self._engine = VmcEngine(
           n_sites=self.shape[1], batch_size=self.local_batch,
           device=parallel.local_rank(), chain_offset=self.chain_offset, seed=seed,

@@ -162,13 +162,108 @@ def allreduce_sr_buffer(engine):
   _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
 
 
+class Collective:
+  """How the LIBRARY reduces over ranks inside its device-resident epoch / CG entry points
+  (include/cgsvmc.h, `*_dist`): an RCCL communicator the library itself created next to
+  torch.distributed's process group (backend 'nccl': in-stream ncclAllReduce over xGMI, no host
+  synchronisation), or -- any other backend, e.g. the gloo tests -- a host hook that all-reduces
+  a pinned staging buffer through torch.distributed.  `comm` is the ncclComm_t as an integer (0:
+  none), `world` the number of ranks."""
+
+  def __init__(self, comm: int = 0, world: int = 1, use_hook: bool = False):
+    self.comm, self.world = int(comm), int(world)
+    self._hook = None
+    if use_hook:
+      from . import _hip
+      self._hook = _hip.HOST_ALLREDUCE_FN(self._host_allreduce)
+
+  def host_hook(self):
+    return self._hook
+
+  def allreduce_host(self, buf: np.ndarray, op: str = 'sum') -> np.ndarray:
+    """In-place all-reduce of a float32 host array over torch.distributed (what the hook does)."""
+    if self.world > 1:
+      import torch
+      dist = _dist()
+      t = torch.from_numpy(buf)
+      if dist.get_backend() == 'nccl':     # host data on an RCCL group: stage through the device
+        d = t.to(torch.device('cuda', local_rank()))
+        dist.all_reduce(d, op=dist.ReduceOp.MAX if op == 'max' else dist.ReduceOp.SUM)
+        t.copy_(d)
+      else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 'max' else dist.ReduceOp.SUM)
+    return buf
+
+  def _host_allreduce(self, user, ptr, n, op):   # vmc_host_allreduce_fn
+    try:
+      buf = np.ctypeslib.as_array(ptr, shape=(int(n),))
+      self.allreduce_host(buf, 'max' if op == 1 else 'sum')
+      return 0
+    except Exception:  # pylint: disable=broad-except
+      import traceback
+      traceback.print_exc()
+      return 1
+
+  def close(self):
+    if self.comm:
+      from . import _hip
+      _hip.load().vmc_rccl_comm_destroy(self.comm)
+      self.comm = 0
+
+
+_collective = None
+
+
+def collective(device: int = None) -> Collective:
+  """The process-wide Collective for the current torch.distributed group (created on first use;
+  a collective call: every rank must reach it)."""
+  global _collective
+  if _collective is not None and _collective.world == world_size():
+    return _collective
+  if world_size() == 1:
+    _collective = Collective()
+    return _collective
+  dist = _dist()
+  use_rccl = dist.get_backend() == 'nccl' and os.environ.get('CGS_VMC_LIBRARY_RCCL', '1') != '0'
+  if not use_rccl:
+    _collective = Collective(0, world_size(), use_hook=True)
+    return _collective
+  _collective = rccl_collective(local_rank() if device is None else device)
+  return _collective
+
+
+def rccl_collective(device: int, world: int = None, rank_: int = None) -> Collective:
+  """Creates the library's own RCCL communicator: rank 0 draws the ncclUniqueId, it travels over
+  the existing process group (or not at all for world == 1), every rank joins on `device`."""
+  import ctypes as C
+  from . import _hip
+  lib = _hip.load()
+  world = world_size() if world is None else world
+  rank_ = rank() if rank_ is None else rank_
+  uid = (C.c_uint8 * 128)()
+  if rank_ == 0 and lib.vmc_rccl_unique_id(uid) != 0:
+    raise _hip.HipLibraryError('vmc_rccl_unique_id: ' + lib.vmc_rccl_last_error().decode())
+  if world > 1:
+    box = [bytes(uid)]
+    _dist().broadcast_object_list(box, src=0)
+    uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+  comm = C.c_void_p()
+  if lib.vmc_rccl_comm_create(uid, world, rank_, device, C.byref(comm)) != 0:
+    raise _hip.HipLibraryError('vmc_rccl_comm_create: ' + lib.vmc_rccl_last_error().decode())
+  return Collective(comm.value, world)
+
+
 def sr_solve(engine, diag_shift: float, tol: float, max_iter: int):
   """Matrix-free CG for (S + diag_shift I) x = f with the chains (and therefore the stored
   samples) sharded over ranks: one P+1-float SUM all-reduce per iteration; every rank runs the
   identical recurrence on the reduced vectors.  Returns (iterations, |r| / |f|).  The
-  accumulators must already be all-reduced (vmc_sr_begin reads f and <O> from them)."""
+  accumulators must already be all-reduced (vmc_sr_begin reads f and <O> from them).
+  Engines with the device-resident entry (vmc_sr_solve_dist) run the whole loop in one call, the
+  all-reduce in stream; the op-by-op loop below remains for engines without it."""
   if world_size() == 1:
     return engine.sr_solve(diag_shift, tol, max_iter)
+  if hasattr(engine, 'sr_solve_dist') and os.environ.get('CGS_VMC_DIST_FUSED', '1') != '0':
+    return engine.sr_solve_dist(collective(), diag_shift, tol, max_iter)
   rr0 = rr = engine.sr_begin()
   it = 0
   while it < max_iter and rr0 > 0.0 and rr > tol * tol * rr0:

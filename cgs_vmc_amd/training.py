@@ -230,16 +230,16 @@ class EnergyGradientOptimizer(WavefunctionOptimizer):
     if train_ops is getattr(self, '_train_ops', None):
       fused = self._fused
       fused['configs']._ensure_hamiltonian(fused['hamiltonian'])
+      max_value = 1e10 if train_ops.update_wf_norm is not None else 0.0
       if parallel.world_size() == 1:
-        fused['engine'].epoch_energy_gradient(
-            n_eq, hparams.num_batches_per_epoch, n_mc,
-            1e10 if train_ops.update_wf_norm is not None else 0.0)
-      else:   # update_norm needs the max over all ranks: keep it as its own op
-        _run_mc_steps(session, train_ops.mc_step, n_eq)
-        if train_ops.update_wf_norm is not None:
-          session.run(train_ops.update_wf_norm)
-        fused['engine'].epoch_energy_gradient(0, hparams.num_batches_per_epoch, n_mc, 0.0)
-      fused['state'].reduced = False
+        fused['engine'].epoch_energy_gradient(n_eq, hparams.num_batches_per_epoch, n_mc, max_value)
+        fused['state'].reduced = False
+      else:
+        # sharded chains: still ONE call per rank -- update_norm's MAX and the accumulator SUM
+        # all-reduce are issued in stream by the library (vmc_epoch_energy_gradient_dist)
+        fused['engine'].epoch_energy_gradient_dist(
+            parallel.collective(), n_eq, hparams.num_batches_per_epoch, n_mc, max_value)
+        fused['state'].reduced = True
     else:
       _run_mc_steps(session, train_ops.mc_step, n_eq)
       if train_ops.update_wf_norm is not None:
@@ -318,17 +318,23 @@ class LogOverlapImaginaryTimeSWO(WavefunctionOptimizer):
 
   def run_optimization_epoch(self, train_ops, session, hparams, epoch_number: int = 0
                              ) -> np.float32:
-    """training.py:731-778.  Single process + own handles: the whole epoch is one call into
-    the library (vmc_epoch_log_overlap, same op order)."""
-    if train_ops is getattr(self, '_train_ops', None) and parallel.world_size() == 1:
+    """training.py:731-778.  Own handles: the whole epoch is one call into the library
+    (vmc_epoch_log_overlap / vmc_epoch_log_overlap_dist, same op order); foreign handles run op by
+    op."""
+    if train_ops is getattr(self, '_train_ops', None):
       fused = self._fused
       fused['configs']._ensure_hamiltonian(fused['hamiltonian'])
       opt = fused['optimizer']
-      energy = fused['engine'].epoch_log_overlap(
-          fused['beta'], hparams.num_equilibration_sweeps * hparams.num_sites,
-          hparams.num_batches_per_epoch, hparams.num_monte_carlo_sweeps * hparams.num_sites,
-          1e10 if train_ops.update_wf_norm is not None else 0.0,
-          opt.learning_rate(), opt.beta1, opt.beta2, opt.epsilon)
+      args = (fused['beta'], hparams.num_equilibration_sweeps * hparams.num_sites,
+              hparams.num_batches_per_epoch, hparams.num_monte_carlo_sweeps * hparams.num_sites,
+              1e10 if train_ops.update_wf_norm is not None else 0.0,
+              opt.learning_rate(), opt.beta1, opt.beta2, opt.epsilon)
+      if parallel.world_size() == 1:
+        energy = fused['engine'].epoch_log_overlap(*args)
+      else:
+        # sharded chains: per batch one in-stream all-reduce of the 2P+8 accumulators between
+        # accumulate and Adam, no host round trip (vmc_epoch_log_overlap_dist)
+        energy = fused['engine'].epoch_log_overlap_dist(parallel.collective(), *args)
       self._wf_omega._has_values, self._wf_omega._theta = True, None
       fused['state'].reduced = True
       session.run(train_ops.epoch_increment)

@@ -318,8 +318,11 @@ class FullyConnectedNetwork(Wavefunction):
   def _update_norm(self, batch_of_amplitudes, max_value):
     from . import parallel
     if (isinstance(batch_of_amplitudes, AmplitudeTensor) and batch_of_amplitudes.configs is None
-        and batch_of_amplitudes.wavefunction is self and parallel.world_size() == 1):
-      self._engine.update_norm(max_value)        # max-reduce on the GPU
+        and batch_of_amplitudes.wavefunction is self):
+      if parallel.world_size() == 1:
+        self._engine.update_norm(max_value)        # max-reduce on the GPU
+      else:                                        # ... and a one-float MAX all-reduce in stream
+        self._engine.update_norm_dist(parallel.collective(), max_value)
       return
     log_max = self._global_log_max(batch_of_amplitudes)
     max_log = np.log(np.float32(max_value))

@@ -196,6 +196,51 @@ int vmc_epoch_log_overlap(vmc_ctx* ctx, float beta, int64_t n_eq_steps, int32_t 
                           int64_t n_mc_steps, float max_value, float lr, float beta1, float beta2,
                           float eps, double* energy);
 
+/* ---- chains sharded over ranks (the reference is single-process) ----------------
+ * Rank r owns chains [r B/G, (r+1) B/G) (vmc_desc.chain_offset); the only exchanges are a SUM
+ * all-reduce of the accumulator buffer per optimizer step, a MAX all-reduce of one float for
+ * update_norm and a SUM all-reduce of P+1 floats per CG iteration of the SR extension.  The
+ * entries below issue them IN STREAM, between the kernels of the epoch, so that a multi-rank
+ * epoch is one host call per rank exactly like the single-rank one.
+ *
+ * Transport: an RCCL communicator (`nccl_comm` = ncclComm_t; librccl is resolved with dlopen at
+ * first use, the copy torch has already loaded if there is one) or, when nccl_comm == NULL and
+ * world_size > 1, the host hook registered with vmc_set_host_allreduce: the library copies the
+ * buffer to pinned host memory, calls the hook (which must all-reduce host_buf in place over all
+ * ranks: gloo, MPI, ...), and copies it back.  nccl_comm == NULL with world_size <= 1 is the
+ * single-rank no-op; a 1-rank communicator still goes through ncclAllReduce. */
+enum { VMC_REDUCE_SUM = 0, VMC_REDUCE_MAX = 1 };
+typedef int (*vmc_host_allreduce_fn)(void* user, float* host_buf, int64_t n_floats, int32_t op);
+int vmc_set_host_allreduce(vmc_ctx* ctx, vmc_host_allreduce_fn hook, void* user);
+/* Communicator life cycle for hosts whose collective library does not expose its ncclComm_t
+ * (torch.distributed): rank 0 draws the 128-byte ncclUniqueId and shares it by any channel, every
+ * rank then calls vmc_rccl_comm_create (ncclCommInitRank on `device`). */
+int vmc_rccl_unique_id(uint8_t id[128]);
+int vmc_rccl_comm_create(const uint8_t id[128], int32_t world_size, int32_t rank, int32_t device,
+                         void** nccl_comm);
+int vmc_rccl_comm_destroy(void* nccl_comm);
+const char* vmc_rccl_last_error(void);
+/* Test / diagnostic hook: in-place all-reduce of n_floats of host data through the same transport
+ * (staged through the ctx's device scratch for RCCL); op = VMC_REDUCE_*. */
+int vmc_debug_allreduce(vmc_ctx* ctx, void* nccl_comm, int32_t world_size, float* host,
+                        int64_t n_floats, int32_t op);
+/* Wavefunction.update_norm with max_b psi taken over the chains of ALL ranks (logit domain). */
+int vmc_update_norm_dist(vmc_ctx* ctx, void* nccl_comm, int32_t world_size, float max_value);
+/* vmc_epoch_energy_gradient over sharded chains: update_norm sees the global maximum and the
+ * accumulators are all-reduced (g_count corrected) before the call returns, ready for
+ * vmc_apply_adam / vmc_sr_solve_dist on every rank. */
+int vmc_epoch_energy_gradient_dist(vmc_ctx* ctx, void* nccl_comm, int32_t world_size,
+                                   int64_t n_eq_steps, int32_t n_batches, int64_t n_mc_steps,
+                                   float max_value);
+/* vmc_epoch_log_overlap over sharded chains (training.py:750-763): per batch
+ * [n_mc_steps mc_steps, reset, accumulate, all-reduce, Adam] with no host synchronisation;
+ * every rank applies the identical Adam step.  With a 1-rank communicator the result is
+ * bit-identical to vmc_epoch_log_overlap. */
+int vmc_epoch_log_overlap_dist(vmc_ctx* ctx, void* nccl_comm, int32_t world_size, float beta,
+                               int64_t n_eq_steps, int32_t n_batches, int64_t n_mc_steps,
+                               float max_value, float lr, float beta1, float beta2, float eps,
+                               double* energy);
+
 /* Stochastic reconfiguration -- EXTENSION: named by the north star, absent from the reference
  * (training.py has only the plain energy gradient + Adam), so these entries replace no reference
  * interface; they sit where TrainOpsTraditional.apply_gradients (training.py:560-567) sits.
@@ -219,6 +264,11 @@ int vmc_sr_set_buffer(vmc_ctx* ctx, const float* host /*[P+1]*/);
 int vmc_sr_cg_update(vmc_ctx* ctx, float diag_shift, double* rr);
 int vmc_sr_solve(vmc_ctx* ctx, float diag_shift, float tol, int32_t max_iter, int32_t* iters,
                  double* rel_residual);
+/* vmc_sr_solve with the stored samples sharded over ranks: the P+1-float all-reduce of every CG
+ * iteration is issued in stream (transport as above); every rank runs the identical recurrence.
+ * The accumulators must already be all-reduced. */
+int vmc_sr_solve_dist(vmc_ctx* ctx, void* nccl_comm, int32_t world_size, float diag_shift, float tol,
+                      int32_t max_iter, int32_t* iters, double* rel_residual);
 int vmc_sr_get_solution(vmc_ctx* ctx, float* x /*[P]*/);
 int vmc_sr_apply(vmc_ctx* ctx, float lr, double* energy);
 /* test hook: out = (S + diag_shift I) v over the stored samples (single rank) */

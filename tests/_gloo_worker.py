@@ -47,6 +47,101 @@ class _OracleSrEngine:
     return rr_new
 
 
+def _gather_rows(local_rows):
+  """Global batch [B, N] from every rank's [B/2, N] shard."""
+  import torch
+  t = torch.from_numpy(np.ascontiguousarray(local_rows, np.float32))
+  parts = [torch.empty_like(t) for _ in range(2)]
+  dist.all_gather(parts, t)
+  return np.concatenate([p.numpy() for p in parts])
+
+
+def routed_training_epochs(rank):
+  """The PRODUCT routing for sharded chains -- training.run_optimization_epoch ->
+  engine.epoch_*_dist(parallel.collective()) / parallel.sr_solve -> engine.sr_solve_dist, with
+  the gloo host hook as transport -- against the unsharded oracle epoch.  The engine is the
+  oracle-backed double of tests/oracle_engine.py (no GPU here); the same routing runs against
+  libcgsvmc_hip.so in tests/test_gpu_dist.py."""
+  os.environ.update(CGS_VMC_SEED='77', CGS_VMC_CONFIG_SEED='5', CGS_VMC_INIT_SEED='31')
+  import cgs_vmc_amd.engine as engine_mod
+  from cgs_vmc_amd import graph_builders, lattice, operators, session, training, utils, wavefunctions
+  from tests.oracle_engine import OracleEngine
+  engine_mod.VmcEngine = OracleEngine
+  coll = parallel.collective()
+  assert coll.world == 2 and coll.comm == 0 and coll.host_hook() is not None   # gloo: host hook
+  for name in ('LogOverlapITSWO', 'EnergyGradient', 'StochasticReconfiguration'):
+    session.reset_default_graph()
+    wavefunctions.reset_name_scope()
+    hp = utils.create_hparams(wavefunction_type='fully_connected', num_sites=8, num_fc_layers=2,
+                              fc_layer_size=16, batch_size=32, num_equilibration_sweeps=2,
+                              num_monte_carlo_sweeps=1, num_batches_per_epoch=2,
+                              learning_rates=[1e-2, 1e-3], learning_rate_stops=[1])
+    n, h, L = hp.num_sites, hp.fc_layer_size, hp.num_fc_layers
+    wf = wavefunctions.build_wavefunction(hp)
+    ham = operators.HeisenbergHamiltonian(lattice.chain_bonds(n), -1.0, 1.0)
+    opt = training.GROUND_STATE_OPTIMIZERS[name]()
+    shared = {}
+    ops = opt.build_opt_ops(wavefunction=wf, hamiltonian=ham, hparams=hp, shared_resources=shared)
+    sess = session.Session()
+    sess.run([session.global_variables_initializer(), session.local_variables_initializer()])
+    cfg_var = shared[graph_builders.ResourceName.CONFIGS]
+    assert isinstance(cfg_var._engine, OracleEngine) and cfg_var.local_batch == 16
+    # ---- unsharded oracle restatement of the same epochs on the gathered global batch
+    theta = wf._get_theta().copy()
+    cfg = _gather_rows(cfg_var.eval())
+    bonds = ham._bonds_list
+    sweeps = lambda th, c, k, s0: vo.run_sweeps(th, c, k, 77, s0, h, L, dtype=np.float64)[0]
+    adam = vo.AdamState(theta.size)
+    step = 0
+    # entries whose gradient is identically zero up to rounding (b_out, always-active units) get
+    # steps of order lr from Adam in ANY summation order: only well-conditioned ones are compared
+    well = np.ones(theta.size, bool)
+    for epoch in range(2):
+      lr = vo.piecewise_constant(epoch, hp.learning_rate_stops, hp.learning_rates)
+      cfg = sweeps(theta, cfg, hp.num_equilibration_sweeps * n, step); step += hp.num_equilibration_sweeps * n
+      if name == 'LogOverlapITSWO':
+        theta_w = theta.copy()
+        for _ in range(hp.num_batches_per_epoch):
+          cfg = sweeps(theta, cfg, n, step); step += n
+          acc = vo.Accumulators(theta.size, np.float64)
+          vo.log_overlap_accumulate(acc, theta, theta_w, cfg, bonds, -1.0, 1.0, -10.0, -10.0,
+                                    hp.time_evolution_beta, h, L, np.float64)
+          grad = vo.log_overlap_gradient(acc)
+          well &= np.abs(grad) > 1e-3 * np.abs(grad).max()
+          theta = vo.adam_apply(adam, theta, grad, lr, 0.9, hp.beta2, 1e-8)
+      else:
+        acc = vo.Accumulators(theta.size, np.float64)
+        samples = []
+        for _ in range(hp.num_batches_per_epoch):
+          vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, h, L, np.float64)
+          samples.append(cfg.copy())
+          cfg = sweeps(theta, cfg, n, step); step += n
+        if name == 'EnergyGradient':
+          grad = vo.energy_gradient(acc)
+          well &= np.abs(grad) > 1e-3 * np.abs(grad).max()
+          theta = vo.adam_apply(adam, theta, grad, lr, 0.9, hp.beta2, 1e-8)
+        else:
+          rows = np.concatenate(samples)
+          o = vo.per_sample_logit_grads(theta, rows, h, L)
+          amp = lambda c: vo.fc_psi(theta, c, h, L, -10.0, dtype=np.float64)
+          e = vo.local_value(amp, rows, bonds, -1.0, 1.0, dtype=np.float64)
+          theta = (theta - np.float32(lr) * vo.sr_solve(o, e, 0.01)).astype(np.float32)
+      # ---- the routed, sharded epoch
+      energy = opt.run_optimization_epoch(ops, sess, hp, epoch)
+      assert abs(energy - acc.mean_energy()) < 1e-5 * max(1.0, abs(acc.mean_energy())), (name, energy)
+      mine = cfg_var.eval()
+      np.testing.assert_array_equal(mine, cfg[16 * rank:16 * (rank + 1)].astype(np.float32))
+      tol = 2e-4 if name == 'StochasticReconfiguration' else 2e-6    # CG tolerance 1e-3 vs dense solve
+      got = wf._get_theta()
+      err = np.abs(got - theta)[well].max()
+      assert err <= tol * max(1.0, np.abs(theta).max()) and well.sum() > 0.8 * well.size, (name, epoch, err)
+      theta = got.copy()    # keep the two trajectories on the same parameters epoch by epoch
+      adam.m, adam.v = cfg_var._engine.adam.m.copy(), cfg_var._engine.adam.v.copy()
+    # every rank holds the identical parameters
+    both = _gather_rows(wf._get_theta()[None, :])
+    np.testing.assert_array_equal(both[0], both[1])
+
+
 def main():
   parallel.init_from_env('gloo')
   assert parallel.is_distributed() and parallel.world_size() == 2
@@ -104,6 +199,7 @@ def main():
 
   assert parallel.allreduce_max(float(rank) + 0.5) == 1.5
   assert parallel.allreduce_sum(float(rank) + 1.0) == 3.0
+  routed_training_epochs(rank)
   dist.barrier()
   dist.destroy_process_group()
   print('rank {} ok'.format(rank))

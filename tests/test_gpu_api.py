@@ -358,7 +358,11 @@ def test_cabi_allreduce_over_an_rccl_communicator():
     eng.reset_accumulators()
     eng.accumulate(0)
     before = eng.get_accumulators()
-    eng.allreduce_accumulators_rccl(0, 8)                       # NULL communicator: no-op
+    eng.allreduce_accumulators_rccl(0, 1)                       # NULL communicator, one rank: no-op
+    np.testing.assert_array_equal(eng.get_accumulators(), before)
+    from cgs_vmc_amd import _hip
+    with pytest.raises(_hip.HipLibraryError):                   # ranks > 1 without any transport
+      eng.allreduce_accumulators_rccl(0, 8)
     np.testing.assert_array_equal(eng.get_accumulators(), before)
     eng.allreduce_accumulators_rccl(comm.value, 2)             # really calls ncclAllReduce
     after = eng.get_accumulators()

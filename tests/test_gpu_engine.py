@@ -387,3 +387,86 @@ def test_lattice_size_limit_is_checked_at_create_and_large_lattices_run():
   assert 0 <= acc <= 20 * b and (np.abs(got) == 1).all() and (got.sum(1) == cfg.sum(1)).all()
   _close(eng.amplitude()[0], vo.fc_logit(theta, got, h, L, dtype=np.float64), 2e-5)
   eng.close()
+
+
+@pytest.mark.parametrize('n,h,L', [(100, 256, 3), (36, 256, 2), (36, 128, 3), (16, 32, 2), (150, 256, 6)])
+def test_uniform_chain_is_safe_next_to_normal_chains(n, h, L):
+  """vmc_set_configs accepts any +-1 rows, also all-up / all-down ones, for which the
+  exchange move does not exist (graph_builders.py:62-71 would write a spin of +-3).  The
+  sortable-key sampler used to turn `no key` into site 255: W1 rows past the allocation and a
+  neighbouring chain's spins in LDS.  Now such a chain proposes the null move with a NaN
+  acceptance uniform (frozen); the other sampler variants take argmin / argmax over all sites like
+  the reference and stay inside the lattice.  Either way the NEIGHBOURS must walk exactly the
+  chains they walk without the uniform rows (chains are independent)."""
+  from cgs_vmc_amd.engine import VmcEngine
+  b = 48
+  rng = np.random.default_rng(n + h)
+  theta = vo.init_params(n, h, L, rng)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(2))
+  bad = cfg.copy()
+  bad[5] = 1.0; bad[17] = -1.0; bad[31] = 1.0; bad[47] = -1.0
+  normal = np.array([i for i in range(b) if i not in (5, 17, 31, 47)])
+  out = []
+  for start in (cfg, bad):
+    eng = VmcEngine(n, b, L, h, seed=99)
+    eng.set_params(theta); eng.set_configs(start)
+    eng.mc_steps(3 * n)
+    out.append(eng.get_configs())
+    eng.close()
+  np.testing.assert_array_equal(out[1][normal], out[0][normal])
+  assert (np.abs(out[1]) == 1.0).all()
+  if h == 256 and n <= 128:          # the production (key hand-over) sampler: frozen
+    np.testing.assert_array_equal(out[1][[5, 17, 31, 47]], bad[[5, 17, 31, 47]])
+
+
+@pytest.mark.parametrize('n,h,L,b,kind', [(16, 32, 2, 64, 'torus4x4'), (36, 128, 3, 200, 'torus6x6')])
+def test_log_domain_stays_finite_where_linear_psi_overflows(n, h, L, b, kind):
+  """SURVEY B9 / BASELINE.md "overflow semantics".  The reference works with psi itself:
+  psi = exp(logit - shift) (wavefunctions.py:232), ratio = psi'/psi (graph_builders.py:75),
+  E_loc = diag + offdiag / psi (operators.py:259).  With exp_norm_shift = -100 every psi of this
+  network overflows float32: the fp32 twin of the oracle -- the reference's arithmetic -- gets
+  inf/inf = NaN for E_loc and for the acceptance ratio (no move is ever accepted).  The HIP path
+  keeps logits and differences of logits, in which the shift cancels: its local energies, accept
+  masks and gradient sums stay finite and equal the fp64 twin (which does not overflow) within the
+  usual tolerances; vmc_amplitude still REPORTS psi = inf, as the reference's tensor would."""
+  eng, theta, cfg, bonds = _make(n, h, L, b, kind)
+  shift = -100.0
+  eng.set_shift(shift)
+  amp32 = lambda c: vo.fc_psi(theta, c, h, L, shift, dtype=np.float32)
+  amp64 = lambda c: vo.fc_psi(theta, c, h, L, shift, dtype=np.float64)
+  with np.errstate(over='ignore', invalid='ignore'):
+    assert np.isinf(amp32(cfg)).all()
+    e32 = vo.local_value(amp32, cfg, bonds, -1.0, 1.0, dtype=np.float32)
+  assert np.isnan(e32).all()                                    # the reference's fp32 result
+  e64 = vo.local_value(amp64, cfg, bonds, -1.0, 1.0, dtype=np.float64)
+  eloc, mean = eng.local_energy()
+  assert np.isfinite(eloc).all() and np.isfinite(mean)
+  _close(eloc, e64, 2e-4)
+  logit, psi = eng.amplitude()
+  assert np.isfinite(logit).all() and np.isinf(psi).all()
+  # Metropolis accept: NaN > sqrt(u) is False in the fp32 twin, the log-domain test follows fp64
+  u_sites, u_acc = vo.step_uniforms(99, np.arange(b), 0, n)
+  i_up, i_dn = vo.propose_exchange(cfg, u_sites)
+  with np.errstate(over='ignore', invalid='ignore'):
+    _, acc32, _ = vo.mc_step(amp32, cfg, i_up, i_dn, u_acc)
+  _, acc64, ratios = vo.mc_step(amp64, cfg, i_up, i_dn, u_acc)
+  assert not acc32.any() and acc64.any()
+  mask = eng.mc_step_injected(i_up, i_dn, u_acc)
+  band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
+  assert np.array_equal(mask[~band], acc64[~band])
+  # gradient accumulators: finite, equal to the fp64 twin
+  eng.set_configs(cfg)
+  eng.reset_accumulators()
+  eng.accumulate(0)
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, shift, h, L, np.float64)
+  got = eng.get_accumulators()
+  assert np.isfinite(got).all()
+  p = theta.size
+  for lo, ref in ((0, acc.g1_total), (p, acc.g2_total)):
+    assert np.abs(got[lo:lo + p] - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-4
+  # update_norm moves the shift by log(max psi) - log(1e10) taken in the logit domain
+  eng.update_norm(1e10)
+  expect = shift + (float(vo.fc_logit(theta, cfg, h, L, dtype=np.float64).max()) - shift - np.log(1e10))
+  assert abs(eng.get_shift() - expect) < 1e-4 * abs(expect)
+  eng.close()

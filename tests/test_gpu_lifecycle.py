@@ -1,0 +1,38 @@
+"""GPU: engine life cycles leak nothing, and torch can create its HIP context afterwards.
+
+VERDICT r2 item 6: tests/conftest.py used to initialise torch before the first VmcEngine because
+"torch's lazy init after ~140 engine life cycles ... 'No HIP GPUs are available'" had been seen once.
+tools/lifecycle_probe.py (a FRESH process, torch untouched) creates and destroys 500 engines of mixed
+ansatz types -- dense, padded, rbm, conv_2d, the general wide path -- each doing a sweep, an
+accumulate and an external amplitude call, and prints open file descriptors, memory mappings,
+resident memory, threads and the device's free memory (hipMemGetInfo) every 20 cycles; then torch
+initialises its context and runs a kernel.  Measured on MI355X (round 3): every column is flat from
+cycle 20 to cycle 499 and torch starts normally; the whole GPU suite is green without the pre-init,
+which is gone.  The one-off failure could not be reproduced and is not a leak in vmc_create /
+vmc_destroy."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_500_engine_life_cycles_leak_nothing_and_torch_starts_afterwards():
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'lifecycle_probe.py'), '500'],
+                     stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+  out = p.stdout.decode()
+  assert p.returncode == 0 and 'torch after 500 cycles: ok' in out, out[-3000:]
+  rows = [tuple(int(x) for x in line.split()) for line in out.splitlines()
+          if line and line[0].isdigit() and len(line.split()) == 6]
+  assert len(rows) >= 20
+  base = next(r for r in rows if r[0] >= 20)       # after the first cycles (code objects, pools)
+  last = rows[-1]
+  assert last[0] == 499
+  fds, maps, rss, thr, free = (last[i] - base[i] for i in range(1, 6))
+  assert fds <= 0 and thr <= 0, (base, last)
+  assert maps <= 8, (base, last)                    # memory mappings
+  assert rss <= 64, (base, last)                    # MB of host memory
+  assert free >= -64, (base, last)                  # MB of device memory
