@@ -146,7 +146,104 @@ def _cpu_step_seconds(vo, theta, cfg, bonds, jx, jz, h, L, n, mc_steps_timed, an
   return t_acc, t_sweep
 
 
-def cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg, ansatz='fully_connected', k=0, lx=0, ly=0):
+def usable_cpus():
+  """CPUs this process may actually use: the scheduler affinity mask capped by the cgroup CPU
+  quota (a GPU box hands a 1-GPU job a share of the host, not all of os.cpu_count())."""
+  try:
+    n = len(os.sched_getaffinity(0))
+  except AttributeError:
+    n = os.cpu_count() or 1
+  quota = None
+  for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+    try:
+      with open(path) as f:
+        fields = f.read().split()
+      if path.endswith('cpu.max'):
+        if fields[0] != 'max':
+          quota = float(fields[0]) / float(fields[1])
+      else:
+        q = float(fields[0])
+        if q > 0:
+          with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+            quota = q / float(f.read().split()[0])
+      break
+    except (OSError, ValueError, IndexError):
+      continue
+  if quota is not None:
+    n = max(1, min(n, int(quota + 0.5)))
+  return n, quota
+
+
+def cpu_worker_main(argv):
+  """`bench.py --cpu-worker WORKLOAD INDEX P T_GO SECONDS`: one single-threaded process of the
+  all-core CPU baseline.  Takes its own disjoint shard of the chains (64, or 16 for the
+  convolutional types), waits for the common start time, then repeats the reference-structured
+  step -- accumulate_gradients + one sweep (timed on a few of its mc_steps and scaled) -- until
+  SECONDS have passed, and prints its median rate.  No GPU, no torch."""
+  workload, index, nproc, t_go, seconds = argv[0], int(argv[1]), int(argv[2]), float(argv[3]), float(argv[4])
+  from oracle import vmc_oracle as vo
+  lx, ly, nnn, L, h, b = WORKLOADS[workload][:6]
+  ansatz, ksz = (WORKLOADS[workload][6:] + ('fully_connected', 0))[:2]
+  conv = ansatz in ('conv_2d', 'res_net_2d')
+  n = lx * ly
+  bonds = torus_bonds(lx, ly, nnn)
+  jx, jz = couplings(len(bonds), nnn)
+  bs = 16 if conv else 64
+  theta, cfg = make_inputs(n, h, L, bs, index * bs, ansatz, ksz)      # this worker's own chains
+  shape = (h, ksz, ly, lx) if conv else h
+  steps = max(2, min(n, 4 if conv else 10))
+  _cpu_step_seconds(vo, theta, cfg[:8], bonds, jx, jz, shape, L, n, 1, ansatz)   # page in, first touch
+  late = time.time() - t_go
+  while time.time() < t_go:
+    time.sleep(0.005)
+  t_start = time.time()
+  rates = []
+  while True:
+    t_acc, t_sw = _cpu_step_seconds(vo, theta, cfg, bonds, jx, jz, shape, L, n, steps, ansatz)
+    rates.append(bs / (t_acc + t_sw))
+    if time.time() - t_start >= seconds:
+      break
+  rates.sort()
+  print(json.dumps({'index': index, 'chains': bs, 'rate': rates[len(rates) // 2], 'reps': len(rates),
+                    'late_s': max(0.0, late), 'busy_s': time.time() - t_start}))
+
+
+def cpu_all_cores_leg(workload, seconds=6.0):
+  """All-core CPU baseline: chains are independent, so the honest many-core
+  figure is P single-threaded processes on DISJOINT chain shards -- not one threaded BLAS call on a
+  small batch.  P = the CPUs this job may use (usable_cpus; half of them when nothing limits the
+  job, i.e. one per physical core).  Aggregate = sum of the workers' rates while all of them run."""
+  cpus, quota = usable_cpus()
+  limited = quota is not None or cpus < (os.cpu_count() or 1)
+  nproc = max(1, cpus if limited else cpus // 2)
+  env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1',
+             NUMEXPR_NUM_THREADS='1')
+  for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+    env.pop(k, None)
+  t_go = time.time() + 4.0 + 0.02 * nproc           # interpreter + numpy start-up of every worker
+  procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', workload, str(i),
+                             str(nproc), repr(t_go), repr(seconds)], env=env, stdout=subprocess.PIPE,
+                            stderr=subprocess.DEVNULL) for i in range(nproc)]
+  res = []
+  for pr in procs:
+    try:
+      out, _ = pr.communicate(timeout=120 + 4 * seconds)
+      res.append(json.loads(out.decode().strip().splitlines()[-1]))
+    except Exception:  # pylint: disable=broad-except
+      pr.kill()
+  if not res:
+    return {'error': 'no CPU worker finished'}
+  total = sum(r['rate'] for r in res)
+  return {'value': total, 'unit': 'chain-evals/s', 'cores': len(res), 'processes_started': nproc,
+          'per_core': total / len(res), 'usable_cpus': cpus, 'cgroup_cpu_quota': quota,
+          'host_cpu_count': os.cpu_count(), 'late_workers': sum(1 for r in res if r['late_s'] > 0),
+          'sample': '{} single-threaded processes x {} chains each (disjoint shards), every process repeating '
+                    '1 step = accumulate_gradients + sweep (scaled from a few mc_steps) for {:.0f} s from a common '
+                    'start; sum of the per-process median rates; numpy fp32 restatement of the reference '
+                    'algorithm (TensorFlow 1.x unavailable)'.format(len(res), res[0]['chains'], seconds)}
+
+
+def cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg, ansatz='fully_connected', k=0, lx=0, ly=0, workload=None):
   """Times the oracle (numpy fp32 restatement with the reference's call structure: one host
   call per mc_step with two forwards, 1 + n_bonds full-batch forwards per local energy, two
   back-prop passes per accumulate; no rank-2 update, no bond skipping) on a bounded sample of
@@ -199,6 +296,17 @@ def cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg, ansatz='fully_connected', k
     # small batches that stay in one core's cache beat the threaded BLAS on this host: the
     # reported baseline is the faster of the two configurations
     out['value'], out['cores'], out['sample'] = st['value'], 1, st['sample'] + '; numpy fp32 restatement of the reference algorithm (TensorFlow 1.x unavailable)'
+  # every core the job may use, one single-threaded process per core on its own chain shard
+  if workload is not None:
+    try:
+      out['all_cores'] = cpu_all_cores_leg(workload)
+      ac = out['all_cores']
+      if 'value' in ac:
+        ac['gflops'] = flops_per_chain_step * ac['value'] / 1e9
+        if ac['value'] > out['value']:
+          out['value'], out['cores'], out['sample'] = ac['value'], ac['cores'], ac['sample']
+    except Exception as e:  # pylint: disable=broad-except
+      out['all_cores'] = {'error': repr(e)}
   out['gflops'] = flops_per_chain_step * out['value'] / 1e9
   if not conv:
     try:
@@ -313,8 +421,77 @@ def spawn_ranks(n_ranks):
   return 0
 
 
+def device_identity(dev):
+  """(PCI bus id, name, uuid or None) of HIP device `dev` -- what tells two ranks' devices apart."""
+  import ctypes as C
+  import torch
+  bus = None
+  try:
+    hip = C.CDLL('libamdhip64.so')
+    buf = C.create_string_buffer(64)
+    if hip.hipDeviceGetPCIBusId(buf, 64, int(dev)) == 0:
+      bus = buf.value.decode()
+  except OSError:
+    pass
+  props = torch.cuda.get_device_properties(dev)
+  uuid = getattr(props, 'uuid', None)
+  return {'ordinal': int(dev), 'pci_bus_id': bus, 'name': props.name, 'uuid': None if uuid is None else str(uuid)}
+
+
+def prove_collectives(eng, world, rank, dev):
+  """N > 1: evidence in the JSON line that the job really ran on `world` DISTINCT devices and that
+  both collective paths reduce correctly -- (1) the library's own transport (in-stream RCCL
+  communicator, or the host hook under a non-RCCL backend) on a device buffer of the library:
+  sum of rank ids == N(N-1)/2 and sum of ones == N; (2) torch.distributed's process group on the
+  library's accumulator buffer, the exact call the timed step makes: every float == N(N+1)/2 and
+  g_count divided back by N.  Under the `nccl` backend two ranks on one device are refused."""
+  import torch
+  import torch.distributed as dist
+  from cgs_vmc_amd import parallel
+  ident = dict(device_identity(dev), rank=rank, host=socket.gethostname(), pid=os.getpid())
+  idents = [None] * world
+  dist.all_gather_object(idents, ident)
+  backend = dist.get_backend()
+  keys = [(i['host'], i['pci_bus_id'] or i['ordinal']) for i in idents]
+  distinct = len(set(keys)) == world
+  if backend == 'nccl' and not distinct:
+    raise SystemExit('bench.py: {} ranks but only {} distinct devices {}: refusing to report an N-GPU number'
+                     .format(world, len(set(keys)), sorted(set(keys))))
+  # (1) the library's own transport.  The timed step does not depend on it (it uses the process
+  # group, checked below), so a failure to set it up is reported, not fatal.
+  lib = {}
+  try:
+    coll = parallel.collective()
+    got = eng.debug_allreduce(coll, np.array([float(rank), 1.0], np.float32), 'sum')
+    got_max = eng.debug_allreduce(coll, np.array([float(rank)], np.float32), 'max')
+    lib = {'library_transport': 'rccl communicator (in stream)' if coll.comm else 'host hook',
+           'library_sum_of_ranks': float(got[0]), 'library_sum_of_ones': float(got[1]),
+           'library_max_of_ranks': float(got_max[0]),
+           'library_ok': bool(got[0] == world * (world - 1) / 2 and got[1] == world and got_max[0] == world - 1)}
+  except Exception as e:  # pylint: disable=broad-except
+    lib = {'library_transport': 'unavailable', 'library_error': repr(e), 'library_ok': None}
+  nacc = 2 * eng.num_params + 8
+  eng.set_accumulators(np.full(nacc, rank + 1.0, np.float32))
+  parallel.allreduce_accumulators(eng)
+  acc = eng.get_accumulators()
+  tot = world * (world + 1) / 2
+  expect = np.full(nacc, tot, np.float32)
+  expect[nacc - 4] = np.float32(tot) / np.float32(world)
+  pg_ok = bool(np.array_equal(acc, expect))
+  eng.reset_accumulators()
+  if not pg_ok or lib.get('library_ok') is False:
+    raise SystemExit('bench.py: collective check failed on rank {} (process group ok={}, library transport: {})'
+                     .format(rank, pg_ok, lib))
+  return {'backend': backend, 'library_transport': lib['library_transport'], 'devices': idents,
+          'distinct_devices': distinct,
+          'checked_allreduce': dict(lib, expected_sum_of_ranks=world * (world - 1) / 2,
+                                    process_group_on_accumulators=pg_ok, ok=True)}
+
+
 # ----------------------------------------------------------------------------- main
 def main():
+  if len(sys.argv) > 1 and sys.argv[1] == '--cpu-worker':
+    return cpu_worker_main(sys.argv[2:])
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=100)
@@ -323,12 +500,14 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-timing', action='store_true', help='disable per-kernel HIP events')
   ap.add_argument('--reps', type=int, default=REPS, help='repetitions of the timed region (median reported)')
+  ap.add_argument('--spawn', action='store_true', help='start the rank processes from here even for --gpus 1 '
+                  '(checks that the launcher path costs nothing)')
   args = ap.parse_args()
 
   if args.gpus < 1:
     ap.error('--gpus must be >= 1')
   env_world = os.environ.get('WORLD_SIZE')
-  if env_world is None and args.gpus > 1:
+  if env_world is None and (args.gpus > 1 or args.spawn):
     sys.exit(spawn_ranks(args.gpus))          # no GPU call has been made in this process
   world = int(env_world or '1')
   if world != args.gpus:
@@ -363,6 +542,7 @@ def main():
   eng.set_params(theta)
   eng.set_configs(cfg)
   eng.set_bonds(bonds, jx, jz)
+  proof = prove_collectives(eng, world, rank, dev) if world > 1 else None
   for _ in range(10):                              # 10 warm-up sweeps, one launch each
     eng.mc_steps(n, want_accepted=False)           # (every k_sweep16 launch of a run is one sweep, so
                                                    # rocprofv3's per-kernel average is per sweep)
@@ -393,18 +573,26 @@ def main():
   # kernels are timed in a few extra steps after the timed region
   eng.timing_enable(0 if args.no_timing else 2)
   eng.timing_reset()
-  rep_s = []
+  rep_s, rep_local = [], []
   for _ in range(max(1, args.reps)):
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
       step()
+    eng.synchronize()
+    torch.cuda.synchronize()
+    rep_local.append(time.perf_counter() - t0)     # this rank alone: a straggler shows up here
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
       elapsed = parallel.allreduce_max(elapsed)
     rep_s.append(elapsed)
   elapsed = sorted(rep_s)[len(rep_s) // 2]
+  local_ms = 1e3 * sorted(rep_local)[len(rep_local) // 2] / args.steps
+  rank_ms = [local_ms]
+  if world > 1:
+    rank_ms = [None] * world
+    torch.distributed.all_gather_object(rank_ms, local_ms)
   eng.timing_enable(False)
   main_timings = {name: eng.timing_get(name) for name in ('sweep', 'tail_eloc')}
   if not args.no_timing:
@@ -476,8 +664,8 @@ def main():
         'kernels': timings,
     }
     if world > 1:
-      out['rccl'] = {'ranks': world, 'allreduce_floats': 2 * p + 8,
-                     'allreduce_ms_blocking': allreduce_ms}
+      out['rccl'] = dict(proof, ranks=world, allreduce_floats=2 * p + 8, allreduce_ms_blocking=allreduce_ms,
+                         ms_per_step_ranks={'min': min(rank_ms), 'max': max(rank_ms), 'all': rank_ms})
     if 'sweep' in timings and 'tail_eloc' in timings:
       ts = timings['sweep']['ms_avg'] * 1e-3
       te = timings['tail_eloc']['ms_avg'] * 1e-3
@@ -506,17 +694,28 @@ def main():
       # tools/collect_profiles.sh); null when no matching profile is present
       traffic = None
       pmc = None
-      tag = {'heisenberg10x10_fc3x256_b4096': 'r2', 'heisenberg16x16j1j2_fc6x256_b1024': 'r2_config5',
-             'heisenberg10x10_conv5x16k5_b4096': 'r2_conv', 'heisenberg16x16j1j2_conv5x16k5_b1024': 'r2_conv16'}.get(args.workload)
-      tpath = os.path.join(ROOT, 'profiles', '{}_traffic.json'.format(tag))
-      if tag and os.path.exists(tpath):
+      suffix = {'heisenberg10x10_fc3x256_b4096': '', 'heisenberg16x16j1j2_fc6x256_b1024': '_config5',
+                'heisenberg10x10_conv5x16k5_b4096': '_conv', 'heisenberg16x16j1j2_conv5x16k5_b1024': '_conv16',
+                'heisenberg10x10_fc3x512_b4096': '_fc3x512'}.get(args.workload)
+      for rnd in ('r3', 'r2'):                    # the newest committed profile of this workload
+        tag = None if suffix is None else rnd + suffix
+        tpath = os.path.join(ROOT, 'profiles', '{}_traffic.json'.format(tag))
+        if tag and os.path.exists(tpath):
+          break
+        tag = None
+      if tag:
         try:
           prof = json.load(open(tpath))
+          collected_at = prof.pop('_collected_at_source_hash', None)
           for name, rec in prof.items():
             if name.startswith(key.split('(')[0]) and rec.get('hbm_read_bytes') is not None:
               traffic = rec['hbm_read_bytes'] + (rec.get('hbm_write_bytes') or 0)
               pmc = {k: rec[k] for k in ('mfma_util', 'clock_ghz', 'median_us') if k in rec}
               pmc['source'] = 'profiles/{}_traffic.json'.format(tag)
+              # counters are collected in separate rocprofv3 --pmc passes (tools/collect_profiles.sh),
+              # not by this run: say whether the kernels have changed since
+              pmc['collected_at_source_hash'] = collected_at
+              pmc['stale'] = None if collected_at is None else bool(collected_at != _hip.source_hash())
         except Exception:  # pylint: disable=broad-except
           traffic = None
       nominal = per_kernel[key]['algorithmic_tflops']
@@ -537,7 +736,7 @@ def main():
       }
     if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0's host cores)
       try:
-        out['cpu_baseline'] = cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg, ansatz, ksz, lx, ly)
+        out['cpu_baseline'] = cpu_baseline(n, h, L, bonds, jx, jz, theta, cfg, ansatz, ksz, lx, ly, args.workload)
       except Exception as e:  # pylint: disable=broad-except
         out['cpu_baseline'] = {'error': repr(e)}
     print(json.dumps(out))

@@ -250,12 +250,53 @@ def test_two_rank_bench_path_on_one_gpu(tmp_path):
   assert len(lines) == 1                      # rank 0 only
   d = json.loads(lines[0])
   assert d['n_gpus'] == 2 and d['config']['global_chains'] == 2048 and d['value'] > 0
-  assert d['rccl']['ranks'] == 2 and d['rccl']['allreduce_floats'] == 2 * 37889 + 8
+  r = d['rccl']
+  assert r['ranks'] == 2 and r['allreduce_floats'] == 2 * 37889 + 8
+  # the N > 1 line proves what it ran on and that its collectives reduce
+  assert r['backend'] == 'gloo' and r['library_transport'] == 'host hook'
+  assert [i['rank'] for i in r['devices']] == [0, 1]
+  assert all(i['ordinal'] == 0 and i['pci_bus_id'] and i['name'] for i in r['devices'])
+  assert r['distinct_devices'] is False        # two ranks share this GPU: tolerated under gloo only
+  c = r['checked_allreduce']
+  assert c['ok'] and c['library_ok'] and c['process_group_on_accumulators']
+  assert c['library_sum_of_ranks'] == c['expected_sum_of_ranks'] == 1.0
+  assert c['library_sum_of_ones'] == 2.0 and c['library_max_of_ranks'] == 1.0
+  assert r['allreduce_ms_blocking'] > 0
+  m = r['ms_per_step_ranks']
+  assert len(m['all']) == 2 and 0 < m['min'] <= m['max'] <= d['ms_per_step'] * 1.05
   # a rank count that contradicts the environment is refused instead of silently mislabelled
   bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'],
                        env=dict(env, WORLD_SIZE='1', RANK='0'), stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300)
   assert bad.returncode == 2 and b'WORLD_SIZE' in bad.stderr
+
+
+def test_one_rank_through_the_launcher_costs_nothing():
+  """`bench.py --gpus 1 --spawn` (the rank started by bench.py's own launcher, as for N > 1) against
+  the direct N = 1 run: same value within 1 % (medians of 5 repetitions of 50 steps at config 3;
+  one re-measurement allowed, run-to-run spread of a median is ~0.5 %)."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+
+  def run(extra):
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '50', '--warmup', '5',
+                        '--no-cpu-baseline', '--no-timing'] + extra, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    return json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
+
+  rel = None
+  for _ in range(2):
+    direct, spawned = run([]), run(['--gpus', '1', '--spawn'])
+    assert direct['n_gpus'] == spawned['n_gpus'] == 1 and 'rccl' not in spawned
+    rel = abs(spawned['value'] - direct['value']) / direct['value']
+    if rel <= 0.01:
+      break
+  assert rel <= 0.01, (direct['ms_per_step'], spawned['ms_per_step'])
 
 
 @pytest.mark.parametrize('optimizer', ['EnergyGradient', 'LogOverlapITSWO'])

@@ -1,9 +1,10 @@
+#!/bin/bash
 # usage: co_pair_trace.sh tag  -- bench + kernel trace durations of the pair
-set -e
+set -euo pipefail
 tag=$1
 mkdir -p gpurun_out/co_pair_$tag
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:?run through gpurun}"
 CGS_VMC_CO=1 timeout -k 10 300 rocprofv3 --kernel-trace -d gpurun_out/co_pair_$tag/prof -o tr --output-format csv -- python bench.py --no-cpu-baseline --no-timing --steps 10 --warmup 3 --reps 1 > gpurun_out/co_pair_$tag/bench.json 2> gpurun_out/co_pair_$tag/bench.err
 f=$(find gpurun_out/co_pair_$tag/prof -name '*kernel_trace.csv' | head -1)
 test -n "$f"

@@ -3,12 +3,12 @@
 # bench workload.  Usage: tools/collect_profiles.sh <tag> [workload]
 # Output under gpurun_out/<tag>_prof/; summarise with tools/summarise_profiles.py <tag> and the
 # summaries land in profiles/<tag>_*.
-set -u
-TAG=${1:-r2}
+set -euo pipefail
+TAG=${1:-r3}
 WL=${2:-heisenberg10x10_fc3x256_b4096}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/${TAG}_prof
-mkdir -p $OUT
+mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # the program itself follows `--` (no env / bash -c hop under the profiler)
 B="python3 $ROOT/bench.py --workload $WL --steps 10 --warmup 2 --reps 1 --no-cpu-baseline --no-timing"
@@ -20,6 +20,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_C
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1
 python3 $ROOT/bench.py --workload $WL > $OUT/bench.json 2> $OUT/bench.err
-cd $ROOT && python3 tools/summarise_profiles.py $TAG
-# raw counter dumps are large; the summaries under gpurun_out/<tag>_summary are what is kept
-rm -rf $OUT/pmc_sq $OUT/pmc_fetch $OUT/pmc_write $OUT/stats
+cd "$ROOT" && python3 tools/summarise_profiles.py "$TAG"
+# raw counter dumps are large; the summaries under gpurun_out/<tag>_summary are what is kept.
+# Reached only when every pass and the summary succeeded (set -e): a failed run keeps its dumps.
+rm -rf "$OUT/pmc_sq" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/stats"

@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r3'
 SRC = os.path.join(ROOT, 'gpurun_out', TAG + '_prof')
 DST = os.path.join(ROOT, 'gpurun_out', TAG + '_summary') if os.environ.get('GRAFT_REPO_ROOT') else os.path.join(ROOT, 'profiles')
 
@@ -71,6 +71,14 @@ def main():
           'median_us': s['median_ns'] / 1e3, 'clock_ghz': clock, 'mfma_util': util,
       }
   open(os.path.join(DST, TAG + '_pmc_summary.txt'), 'w').write('\n'.join(lines) + '\n')
+  # the kernel sources these counters were collected from: bench.py marks the numbers stale when
+  # the library it runs was built from other sources
+  try:
+    sys.path.insert(0, ROOT)
+    from cgs_vmc_amd import _hip
+    traffic['_collected_at_source_hash'] = _hip.source_hash()
+  except Exception:  # pylint: disable=broad-except
+    pass
   json.dump(traffic, open(os.path.join(DST, TAG + '_traffic.json'), 'w'), indent=1, sort_keys=True)
   if os.path.exists(SRC + '/bench.json'):
     shutil.copy(SRC + '/bench.json', os.path.join(DST, TAG + '_bench.json'))
