@@ -277,12 +277,12 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
 // `count` dual / ones-row GEMMs (device array of GemmArgs, all with the same splitk and their
 // own workspace) in one launch + one reduction launch; max_m counts MFMA rows (M - 1)
 hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
-                               int max_n, int splitk, bool dual = true);
+                               int max_n, int splitk, bool dual = true, bool fresh = false);
 hipError_t launch_act_copy(hipStream_t s, const float* z, float* a, float* dact, long long n, int act);
 hipError_t launch_out_scale(hipStream_t s, const float* x, float* oscale, int B, int oact);
 hipError_t launch_tanh_copy(hipStream_t s, const float* z, float* a, long long n);
 hipError_t launch_scalar_accum(hipStream_t s, const float* eloc, const float* ratio, int B,
-                               float* acc_scalars, int mode);
+                               float* acc_scalars, int mode, bool fresh = false);
 hipError_t launch_itswo_ratio(hipStream_t s, const float* logit_psi, const float* logit_omega,
                               const float* eloc_omega, float log_factor, float beta, int B,
                               float* ratio, int oact);

@@ -252,8 +252,9 @@ __global__ __launch_bounds__(256) void k_gemm_batched(const GemmArgs* __restrict
   gemm_block<DUAL, NS>(g, blockIdx.x, blockIdx.y, blockIdx.z % splitk);
 }
 
+// fresh: the destination holds no sum yet (accumulators after reset_gradients): epilogue 3 stores
 __device__ __forceinline__ void gemm_reduce_body(const GemmArgs& g, long long start,
-                                                 long long stride) {
+                                                 long long stride, bool fresh = false) {
   const long long mn = (long long)g.M * g.N;
   const int nd = g.dual ? 2 : 1;
   for (long long i = start; i < mn * nd; i += stride) {
@@ -261,13 +262,14 @@ __device__ __forceinline__ void gemm_reduce_body(const GemmArgs& g, long long st
     const long long e = i % mn;
     float v = 0.f;
     for (int z = 0; z < g.splitk; ++z) v += g.workspace[((long long)z * nd + d) * mn + e];
-    gemm_epilogue(g, d ? g.C2 : g.C, (int)(e / g.N), (int)(e % g.N), v);
+    if (fresh && g.epilogue == 3) (d ? g.C2 : g.C)[(e / g.N) * g.ldc + (e % g.N)] = v;
+    else gemm_epilogue(g, d ? g.C2 : g.C, (int)(e / g.N), (int)(e % g.N), v);
   }
 }
 
-__global__ __launch_bounds__(256) void k_gemm_reduce_batched(const GemmArgs* __restrict__ batch) {
+__global__ __launch_bounds__(256) void k_gemm_reduce_batched(const GemmArgs* __restrict__ batch, int fresh) {
   const GemmArgs g = batch[blockIdx.y];
-  gemm_reduce_body(g, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+  gemm_reduce_body(g, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, fresh != 0);
 }
 
 __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
@@ -298,14 +300,14 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
 }
 
 hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
-                               int max_n, int splitk, bool dual) {
+                               int max_n, int splitk, bool dual, bool fresh) {
   if (count <= 0) return hipSuccess;
   const dim3 grid((max_n + GT - 1) / GT, (max_m + GT - 1) / GT, count * splitk);
   if (dual) hipLaunchKernelGGL((k_gemm_batched<true>), grid, dim3(256), 0, s, dev_batch, splitk);
   else hipLaunchKernelGGL((k_gemm_batched<false>), grid, dim3(256), 0, s, dev_batch, splitk);
   const long long total = (dual ? 2LL : 1LL) * (max_m + 1) * max_n;
   const int blocks = (int)min((total + 255) / 256, (long long)512);
-  hipLaunchKernelGGL(k_gemm_reduce_batched, dim3(blocks, count), dim3(256), 0, s, dev_batch);
+  hipLaunchKernelGGL(k_gemm_reduce_batched, dim3(blocks, count), dim3(256), 0, s, dev_batch, fresh ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -374,7 +376,7 @@ hipError_t launch_fill(hipStream_t s, float* x, float v, long long n) {
 // scalars = [e_total, e_count, r_total, r_count, g_count]
 __global__ __launch_bounds__(1024) void k_scalar_accum(const float* __restrict__ eloc,
                                                        const float* __restrict__ ratio, int B,
-                                                       float* __restrict__ sc, int mode) {
+                                                       float* __restrict__ sc, int mode, int fresh) {
   __shared__ double se[1024];
   __shared__ double sr[1024];
   double e = 0.0, r = 0.0;
@@ -389,6 +391,10 @@ __global__ __launch_bounds__(1024) void k_scalar_accum(const float* __restrict__
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    if (fresh) {   // first accumulate after reset_gradients: the scalars hold no sum yet
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sc[i] = 0.f;
+    }
     sc[0] += (float)se[0];
     sc[1] += (float)B;
     if (mode == 1) { sc[2] += (float)sr[0]; sc[3] += (float)B; }
@@ -397,9 +403,9 @@ __global__ __launch_bounds__(1024) void k_scalar_accum(const float* __restrict__
 }
 
 hipError_t launch_scalar_accum(hipStream_t s, const float* eloc, const float* ratio, int B,
-                               float* acc_scalars, int mode) {
+                               float* acc_scalars, int mode, bool fresh) {
   hipLaunchKernelGGL(k_scalar_accum, dim3(1), dim3(1024), 0, s, eloc, ratio, B, acc_scalars,
-                     mode);
+                     mode, fresh ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -115,6 +115,10 @@ struct vmc_ctx {
   bool batch_ready[2][2] = {{false, false}, {false, false}};
   float *ratio = nullptr, *ones = nullptr;
   float *acc = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad_tmp = nullptr;
+  // reset_gradients does not zero `acc` at once: the first dense accumulate after it WRITES its sums
+  // (no 1.3 MB memset + read-modify-write per optimizer step); everything else that touches `acc`
+  // materialises the zeros first (acc_zeros)
+  bool acc_fresh = false;
   long long adam_t = 0;
   float* gemm_ws = nullptr;
   int splitk = 16;           // upper bound (workspace size); see pick_splitk
@@ -212,6 +216,16 @@ bool co_active(const vmc_ctx* c) {
 }
 bool can_overlap(const vmc_ctx* c) {
   return c->overlap && (c->overlap_full || co_active(c) || sweep_cus(c) <= (3 * c->num_cus) / 4);
+}
+
+// `acc` is about to be read or partially written: turn a pending reset into real zeros
+int acc_zeros(vmc_ctx* c) {
+  if (c->acc_fresh) {
+    hipError_t e = hipMemsetAsync(c->acc, 0, (2 * c->P + 8) * sizeof(float), c->stream);
+    if (e != hipSuccess) return fail(c, VMC_ERR_HIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    c->acc_fresh = false;
+  }
+  return VMC_OK;
 }
 
 int join_sweep(vmc_ctx* c) {
@@ -617,6 +631,7 @@ bool sharded(void* comm, int world) { return comm != nullptr || world > 1; }
 
 int reduce_accumulators(vmc_ctx* c, void* comm, int world) {
   if (!sharded(comm, world)) return VMC_OK;
+  PROPAGATE(acc_zeros(c));
   PROPAGATE(reduce_buffer(c, comm, world, c->acc, 2 * c->P + 8, VMC_REDUCE_SUM));
   HIPCHK(c, launch_scale_one(c->stream, c->acc + 2 * c->P + 4, 1.f / (float)(world > 1 ? world : 1)));
   return VMC_OK;
@@ -1285,7 +1300,7 @@ int vmc_local_energy_terms(vmc_ctx* c, int which, float* diag, float* offdiag_ov
 int vmc_last_connected_rows(vmc_ctx* c, int64_t* rows) { CHECK_CTX(c); if (!rows) return fail(c, VMC_ERR_INVALID, "null"); *rows = c->last_rows; return VMC_OK; }
 
 // sum_b O_k(b) -> g1, sum_b w_b O_k(b) -> g2 for the psi parameter set
-static int gradient_sums(vmc_ctx* c, const float* w) {
+static int gradient_sums(vmc_ctx* c, const float* w, bool fresh) {
   ParamSet& p = c->ps[0];
   const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, NH = c->n_hh;
   float* g1 = c->acc;
@@ -1378,7 +1393,7 @@ static int gradient_sums(vmc_ctx* c, const float* w) {
     HIPCHK(c, hipMemcpy(c->d_batch[slot][par], tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
     c->batch_ready[slot][par] = true;
   }
-  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot][par], NH + 2, N > H ? N : H, H, pick_splitk(c, B)));
+  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot][par], NH + 2, N > H ? N : H, H, pick_splitk(c, B), true, fresh));
   return VMC_OK;
 }
 
@@ -1409,7 +1424,7 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   // may start as soon as ev_mark has passed (vmc_mc_steps).  If this call has to rebuild the
   // psi cache the sampler reads, the launch must wait for all of it instead.
   const bool cache_was_valid = c->ps[0].cache_valid && c->ps[0].packed_valid;
-  HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));
+  if (can_overlap(c)) HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));
   if (mode == VMC_MODE_ENERGY_GRADIENT) {
     PROPAGATE(local_energy_device(c, VMC_PSI));               // training.py:542-543
     w = e = c->ps[0].eloc;
@@ -1422,8 +1437,13 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
     w = c->ratio; e = c->ps[1].eloc;
   }
   PROPAGATE(ensure_cache(c, VMC_PSI));
-  PROPAGATE(gradient_sums(c, w));
-  HIPCHK(c, launch_scalar_accum(c->stream, e, mode == 1 ? c->ratio : nullptr, c->B, c->acc + 2 * c->P, mode));
+  // the batched weight-gradient GEMMs of the dense ansatz types cover every parameter, so a pending
+  // reset is absorbed: their reduction stores instead of adding (conv: zero first)
+  if (c->conv) PROPAGATE(acc_zeros(c));
+  const bool fresh = c->acc_fresh;
+  PROPAGATE(gradient_sums(c, w, fresh));
+  HIPCHK(c, launch_scalar_accum(c->stream, e, mode == 1 ? c->ratio : nullptr, c->B, c->acc + 2 * c->P, mode, fresh));
+  c->acc_fresh = false;
   if (c->sr_cap > 0 && mode == VMC_MODE_ENERGY_GRADIENT) PROPAGATE(sr_record(c));
   c->acc_since_sweep = true;
   c->token = cache_was_valid;
@@ -1432,13 +1452,14 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
 
 int vmc_reset_accumulators(vmc_ctx* c) {
   CHECK_CTX(c);
-  HIPCHK(c, hipMemsetAsync(c->acc, 0, (2 * c->P + 8) * sizeof(float), c->stream));
+  c->acc_fresh = true;            // zeroed lazily: see vmc_ctx::acc_fresh
   c->sr_n = 0; c->sr_begun = false;
   return VMC_OK;
 }
 
 int vmc_accumulators_devptr(vmc_ctx* c, void** dev_ptr, int64_t* n_floats) {
   CHECK_CTX(c);
+  PROPAGATE(acc_zeros(c));
   if (dev_ptr) *dev_ptr = c->acc;
   if (n_floats) *n_floats = 2 * c->P + 8;
   return VMC_OK;
@@ -1449,6 +1470,7 @@ int vmc_accumulators_devptr(vmc_ctx* c, void** dev_ptr, int64_t* n_floats) {
 // back by the world size so that sharded and unsharded gradients agree (cgs_vmc_amd/parallel.py).
 int vmc_allreduce_accumulators(vmc_ctx* c, void* nccl_comm, int32_t world_size) {
   CHECK_CTX(c);
+  PROPAGATE(acc_zeros(c));
   PROPAGATE(reduce_accumulators(c, nccl_comm, world_size));
   return VMC_OK;
 }
@@ -1520,6 +1542,7 @@ int vmc_debug_allreduce(vmc_ctx* c, void* nccl_comm, int32_t world_size, float* 
 
 int vmc_get_accumulators(vmc_ctx* c, float* host) {
   CHECK_CTX(c);
+  PROPAGATE(acc_zeros(c));
   if (!host) return fail(c, VMC_ERR_INVALID, "null");
   HIPCHK(c, hipMemcpyAsync(host, c->acc, (2 * c->P + 8) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1529,6 +1552,7 @@ int vmc_get_accumulators(vmc_ctx* c, float* host) {
 int vmc_set_accumulators(vmc_ctx* c, const float* host) {
   CHECK_CTX(c);
   if (!host) return fail(c, VMC_ERR_INVALID, "null");
+  c->acc_fresh = false;           // fully overwritten
   HIPCHK(c, hipMemcpyAsync(c->acc, host, (2 * c->P + 8) * sizeof(float), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return VMC_OK;
@@ -1536,6 +1560,7 @@ int vmc_set_accumulators(vmc_ctx* c, const float* host) {
 
 int vmc_mean_energy(vmc_ctx* c, double* energy) {
   CHECK_CTX(c);
+  PROPAGATE(acc_zeros(c));
   if (!energy) return fail(c, VMC_ERR_INVALID, "null");
   float sc[8];
   HIPCHK(c, hipMemcpyAsync(sc, c->acc + 2 * c->P, 8 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -1547,6 +1572,7 @@ int vmc_mean_energy(vmc_ctx* c, double* energy) {
 int vmc_get_gradient(vmc_ctx* c, int mode, float* grad) {
   CHECK_CTX(c);
   if (!grad || (mode != 0 && mode != 1)) return fail(c, VMC_ERR_INVALID, "bad arguments");
+  PROPAGATE(acc_zeros(c));
   HIPCHK(c, launch_adam(c->stream, nullptr, nullptr, nullptr, c->acc, (int)c->P, mode, 0.f, 0.f, 0.f, 0.f, c->grad_tmp));
   HIPCHK(c, hipMemcpyAsync(grad, c->grad_tmp, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1557,6 +1583,7 @@ int vmc_apply_adam(vmc_ctx* c, int mode, float lr, float beta1, float beta2, flo
   ENTER(c);
   if (mode != 0 && mode != 1) return fail(c, VMC_ERR_INVALID, "bad mode");
   if (!c->ps[0].has_params) return fail(c, VMC_ERR_STATE, "parameters not set");
+  PROPAGATE(acc_zeros(c));
   c->adam_t += 1;
   const float t = (float)c->adam_t;
   const float lr_t = lr * sqrtf(1.f - powf(beta2, t)) / (1.f - powf(beta1, t));
@@ -1761,6 +1788,7 @@ int vmc_sr_begin(vmc_ctx* c, double* rr0) {
   ENTER(c);
   if (c->sr_cap <= 0) return fail(c, VMC_ERR_STATE, "vmc_sr_reserve first");
   if (c->sr_n <= 0) return fail(c, VMC_ERR_STATE, "no samples recorded (vmc_accumulate in ENERGY_GRADIENT mode)");
+  PROPAGATE(acc_zeros(c));
   PROPAGATE(sr_build_table(c));
   HIPCHK(c, launch_sr_rhs(c->stream, c->acc, (int)c->P, c->sr_x, c->sr_r, c->sr_p, c->sr_partial, c->sr_sc));
   c->sr_iter = 0; c->sr_begun = true;
