@@ -75,7 +75,7 @@ def mfma_flops_per_amp(n, h, L, ansatz, k):
     # 16-channel tiles (filters zero padded), taps of the first convolution padded to 4
     n_conv = L if ansatz == 'conv_2d' else 1 + 2 * L
     return 2 * n * 16 * (4 * ((k * k + 3) // 4) + (n_conv - 1) * k * k * 16)
-  hp = (h + 63) // 64 * 64
+  hp = (h + 63) // 64 * 64 if h <= 256 else (h + 127) // 128 * 128   # 257..512 units pad to 384 / 512
   return 2 * (L - 1) * hp * hp
 
 

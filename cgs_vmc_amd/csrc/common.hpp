@@ -239,9 +239,10 @@ hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp);
 size_t tail_co_lds_bytes(int n_hidden);
 size_t sweep_co_lds_bytes(int N, int n_hidden);
 hipError_t launch_tail_co(hipStream_t s, const TailArgs& a, size_t lds_bytes);
-// the LDS-operand row kernel for 384 / 512 padded units (tail_co.hip): fully_connected, relu
+// the LDS-operand row kernel for 384 / 512 padded units (tail_lds.hpp; one instantiation per hidden
+// activation in act_tail.hip): fully_connected and rbm with at least one H x H layer
 bool tail_lds_supported(int Hp, int n_hidden);
-hipError_t launch_tail_lds(hipStream_t s, const TailArgs& a, int Hp, bool ratio);
+hipError_t launch_tail_lds(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm);
 size_t sweep_lds_required(int N, int Hp, int n_hidden, bool rbm);
 
 // bond list / local-energy reduction (eloc.hip)

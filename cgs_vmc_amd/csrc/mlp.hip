@@ -113,6 +113,7 @@ hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n) {
 // pick the instantiation (an unknown id is an error, never a silent relu).
 #define VMC_DECL_ACT(N)                                                                          \
   hipError_t launch_tail_inst_##N(hipStream_t, const TailArgs&, int, bool, bool);                \
+  hipError_t launch_tail_lds_inst_##N(hipStream_t, const TailArgs&, int, bool, bool);            \
   hipError_t launch_backprop16_inst_##N(hipStream_t, const float*, float*, const float*,         \
                                         const float*, int, int, int, bool, const float*,         \
                                         const float*);                                           \
@@ -131,6 +132,12 @@ VMC_DECL_ACT(0) VMC_DECL_ACT(1) VMC_DECL_ACT(2) VMC_DECL_ACT(3) VMC_DECL_ACT(4) 
 
 hipError_t launch_tail(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm) {
 #define CALL(N) launch_tail_inst_##N(s, a, Hp, ratio_mode, rbm)
+  VMC_ACT_SWITCH(a.act, CALL)
+#undef CALL
+}
+
+hipError_t launch_tail_lds(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm) {
+#define CALL(N) launch_tail_lds_inst_##N(s, a, Hp, ratio_mode, rbm)
   VMC_ACT_SWITCH(a.act, CALL)
 #undef CALL
 }

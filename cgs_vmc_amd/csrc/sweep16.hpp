@@ -953,12 +953,11 @@ static hipError_t launch_sweep16_r(hipStream_t s, const SweepArgs& a, int Hp) {
 #endif
     case 16: return launch_sweep16_t<16, 8, SWEEP_RT, RBM, ACT>(s, a);
 #ifndef VMC_QUICK
-    // 257 .. 512 units (fully_connected, relu): wave w owns 3 or 4 output tiles, W1 in L2, the
-    // weight stream addressed from a scalar base (SWEEP_SCALAR_NT)
-    case 24: if constexpr (!RBM && ACT == VMC_ACT_RELU_) return launch_sweep16_t<24, 8, SWEEP_RT_WIDE, RBM, ACT>(s, a);
-             return hipErrorInvalidValue;
-    case 32: if constexpr (!RBM && ACT == VMC_ACT_RELU_) return launch_sweep16_t<32, 8, SWEEP_RT_WIDE, RBM, ACT>(s, a);
-             return hipErrorInvalidValue;
+    // 257 .. 512 units (384 / 512 padded): wave w owns 3 or 4 output tiles, W1 in L2, the weight
+    // stream addressed from a scalar base (SWEEP_SCALAR_NT).  relu gets the prefetched-Philox
+    // variants, the other activations the general one (as at <= 256 units); both dense ansatz types.
+    case 24: return launch_sweep16_t<24, 8, SWEEP_RT_WIDE, RBM, ACT>(s, a);
+    case 32: return launch_sweep16_t<32, 8, SWEEP_RT_WIDE, RBM, ACT>(s, a);
 #endif
     default: return hipErrorInvalidValue;
   }

@@ -448,6 +448,9 @@ static hipError_t launch_backprop16_t(hipStream_t s, const float* act_all, float
     case 8: hipLaunchKernelGGL((k_backprop16<8, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale); break;
     case 12: hipLaunchKernelGGL((k_backprop16<12, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale); break;
     case 16: hipLaunchKernelGGL((k_backprop16<16, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale); break;
+    // 257 .. 512 hidden units (384 / 512 padded): wave w owns 3 or 4 output tiles, 48 / 64 KB of operands in LDS
+    case 24: hipLaunchKernelGGL((k_backprop16<24, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale); break;
+    case 32: hipLaunchKernelGGL((k_backprop16<32, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -415,9 +415,10 @@ int wide_forward(vmc_ctx* c, int which, const float* z1, const int2* rowinfo, lo
   const WideOnsite on{c->rbm ? onsite : nullptr, p.won, bonds, nullptr, nullptr};
   if (c->wide_fast) {
     TailArgs a = tail_args(c, which);
-    a.z1 = z1; a.logit_base = p.logit; a.rowinfo = rowinfo;
+    a.z1 = z1; a.logit_base = p.logit; a.rowinfo = rowinfo; a.on_base = onsite;
     a.n_rows = (int)n_rows; a.out = out;
-    HIPCHK(c, launch_tail_lds(c->stream, a, Hp, ratio));
+    if (NH == 0) HIPCHK(c, launch_tail(c->stream, a, Hp, ratio, c->rbm));      // k_tail0 takes any Hp
+    else HIPCHK(c, launch_tail_lds(c->stream, a, Hp, ratio, c->rbm));
     return VMC_OK;
   }
   for (long long row0 = 0; row0 < n_rows; row0 += c->wrows) {
@@ -500,7 +501,8 @@ int local_energy_device(vmc_ctx* c, int which) {
     a.n_rows_dev = c->off + c->B;                 // the row count stays on the device
     a.n_rows = (int)((long long)c->B * c->n_bonds);
     a.out = c->val;
-    HIPCHK(c, launch_tail_lds(c->stream, a, c->Hp, true));
+    if (c->n_hh == 0) HIPCHK(c, launch_tail(c->stream, a, c->Hp, true, c->rbm));
+    else HIPCHK(c, launch_tail_lds(c->stream, a, c->Hp, true, c->rbm));
   } else if (c->wide) {
     Timer t(c, "tail_eloc");
     int n_rows = 0;      // the GEMM grids need the row count on the host
@@ -742,11 +744,15 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (wide) c->overlap = false;
   c->hact = d->nonlinearity; c->oact = d->output_activation;
   c->lay = make_layout(rbm, c->N, c->H, c->L);
-  if (wide && !rbm && c->H <= 512 && c->hact == VMC_ACT_RELU_ && c->L >= 2) {
+  if (wide && c->H <= 512) {
+    // 257 .. 512 units: the fused sampler padded to 384 / 512 units (k_sweep16<24|32>), rows on the
+    // LDS-operand kernel (k_tail_lds; without an H x H layer: k_tail0) and the fused back-propagation
+    // (k_backprop16<24|32>); both dense ansatz types, every hidden activation but cos
     const int hp = (c->H + 127) / 128 * 128;     // 8 waves x whole 16-unit tiles
     const char* e = getenv("CGS_VMC_WIDE_FAST");
-    if (!(e && atoi(e) == 0) && tail_lds_supported(hp, (int)c->L - 1) &&
-        sweep_lds_required(c->N, hp, (int)c->L - 1, false) <= 160 * 1024) {
+    const int n_hh = c->lay.n_hh;
+    if (!(e && atoi(e) == 0) && (n_hh == 0 || tail_lds_supported(hp, n_hh)) &&
+        sweep_lds_required(c->N, hp, n_hh, rbm) <= 160 * 1024) {
       c->wide_fast = true;
       c->Hp = hp;
     }
@@ -1297,6 +1303,13 @@ int vmc_local_energy_terms(vmc_ctx* c, int which, float* diag, float* offdiag_ov
   return VMC_OK;
 }
 
+int vmc_debug_kernel_path(vmc_ctx* c, int32_t* path) {
+  CHECK_CTX(c);
+  if (!path) return fail(c, VMC_ERR_INVALID, "null");
+  *path = c->conv ? 3 : (c->wide ? (c->wide_fast ? 1 : 2) : 0);
+  return VMC_OK;
+}
+
 int vmc_last_connected_rows(vmc_ctx* c, int64_t* rows) { CHECK_CTX(c); if (!rows) return fail(c, VMC_ERR_INVALID, "null"); *rows = c->last_rows; return VMC_OK; }
 
 // sum_b O_k(b) -> g1, sum_b w_b O_k(b) -> g2 for the psi parameter set
@@ -1349,7 +1362,7 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh) {
   // back-propagation of d logit / d z_l: FC delta[NH] = w_out (.) relu'; RBM delta[NH] = tanh(z)
   // (which IS act[NH]); then the W_l^T chain through the relu masks -- one launch, 16 chains per
   // workgroup, transposed weight fragments on 16x16x4 MFMA (k_backprop16)
-  if (c->wide) {
+  if (c->wide && !c->wide_fast) {
     // delta_NH = w_out (.) f'(z_NH); delta_{l-1} = f'(z_{l-1}) (.) (delta_l W_l^T) on the generic GEMM
     if (c->rbm)   // d sum log cosh(z) / d z = tanh(z), which the forward left in act[NH]
       HIPCHK(c, hipMemcpyAsync(c->delta[NH], c->act[NH], (size_t)B * Hp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));

@@ -416,6 +416,12 @@ class VmcEngine:
     self._check(self._lib.vmc_timing_get(self._ctx, name.encode(), C.byref(ms), C.byref(n)))
     return float(ms.value), int(n.value)
 
+  def kernel_path(self) -> int:
+    """0 fused (<= 256 units), 1 fused with LDS operands (257..512), 2 general path, 3 conv."""
+    v = C.c_int32()
+    self._check(self._lib.vmc_debug_kernel_path(self._ctx, C.byref(v)))
+    return int(v.value)
+
   def synchronize(self):
     self._check(self._lib.vmc_synchronize(self._ctx))
 

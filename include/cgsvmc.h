@@ -70,11 +70,12 @@ typedef struct {
   int32_t batch_size;        /* chains owned by THIS ctx         (utils.py:135)      */
   int32_t num_layers;        /* hparams.num_fc_layers (utils.py:104); conv_2d: num_conv_layers
                                 (108); res_net_2d: num_resnet_blocks (114)                     */
-  int32_t layer_size;        /* hparams.fc_layer_size (utils.py:105; fully_connected: up to 4096
-                                -- fused kernels up to 256 units and, for relu with num_layers
-                                >= 2, up to 512; the general multi-launch path otherwise; rbm:
-                                up to 256); convolutional ansatz types: num_conv_filters (111),
-                                at most 16                                                      */
+  int32_t layer_size;        /* hparams.fc_layer_size (utils.py:105): fully_connected and rbm take up
+                                to 4096 units -- the fused kernels up to 512 (any nonlinearity; 257
+                                .. 512 not with cos), beyond that the general multi-launch path
+                                (materialised rows + GEMMs, no cos; two [131072][units] float
+                                buffers per ctx: 4 GiB at 4096 units).  Convolutional ansatz types:
+                                num_conv_filters (111), at most 16                              */
   int32_t nonlinearity;      /* VMC_ACT_*: hparams.nonlinearity  (utils.py:128)      */
   int32_t output_activation; /* VMC_ACT_*: hparams.output_activation (utils.py:129)  */
   int32_t device;            /* HIP device ordinal                                   */
@@ -287,6 +288,10 @@ int vmc_timing_reset(vmc_ctx* ctx);
 int vmc_timing_get(vmc_ctx* ctx, const char* name, double* ms, int64_t* launches);
 /* rows the last local-energy call actually evaluated (antiparallel bonds) */
 int vmc_last_connected_rows(vmc_ctx* ctx, int64_t* rows);
+/* Diagnostic: which kernel family serves this ctx.  0: fused, register-resident rows (<= 256 hidden
+ * units); 1: fused, LDS-operand rows (257 .. 512 units); 2: general multi-launch path (> 512 units,
+ * or CGS_VMC_WIDE_FAST=0); 3: convolutional kernels. */
+int vmc_debug_kernel_path(vmc_ctx* ctx, int32_t* path);
 int vmc_synchronize(vmc_ctx* ctx);
 
 /* Test hook: C[M,N] = op(A) op(B) through the library's fp32 MFMA GEMM

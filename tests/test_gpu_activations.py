@@ -19,6 +19,8 @@ SHAPES = [
     (36, 128, 3, 100, 'torus6x6'),
     (12, 200, 1, 48, 'chain'),      # single layer, H padded to 256: k_tail0
     (20, 256, 3, 40, 'chain'),      # 8-wave sampler
+    (16, 320, 2, 40, 'torus4x4'),   # 257 .. 512 units: k_sweep16<24>, k_tail_lds<24>, k_backprop16<24>
+    (12, 448, 3, 30, 'chain'),      # ... <32>, two H x H layers
 ]
 
 
@@ -29,8 +31,10 @@ def _bonds(kind, n):
   return vo.torus_bonds(lx, n // lx)
 
 
-def _tols(act):
-  loose = act in ('cos', 'tan')
+def _tols(act, h=0):
+  # exp as HIDDEN activation beyond 256 units: three layers of up to 512 positive terms e^z each,
+  # summed in fp32 in an order that differs from the oracle's -- the loose class as well
+  loose = act in ('cos', 'tan') or (act == 'exp' and h > 256)
   return (2e-4 if loose else 2e-5), (2e-3 if loose else 2e-4), (1e-2 if loose else 2e-3)
 
 
@@ -60,9 +64,12 @@ def _make(n, h, L, b, kind, act, oact='exp', seed=0, scale=1.0, b_out=0.0):
 @pytest.mark.parametrize('act', HIDDEN)
 def test_hidden_activation_parity(act, n, h, L, b, kind):
   from cgs_vmc_amd import _hip
-  t_logit, t_e, t_g = _tols(act)
+  t_logit, t_e, t_g = _tols(act, h)
+  if act == 'cos' and h > 256:
+    pytest.skip('cos is offered up to 256 hidden units (include/cgsvmc.h)')
   scale = {'tan': 0.2, 'exp': 0.4}.get(act, 1.0)     # keep tan away from its poles, exp from overflow
   eng, theta, cfg, bonds = _make(n, h, L, b, kind, act, scale=scale)
+  assert eng.kernel_path() == (0 if h <= 256 else 1)
   kw = dict(nonlinearity=act)
   amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64, **kw)
   _close(eng.amplitude()[0], vo.fc_logit(theta, cfg, h, L, dtype=np.float64, **kw), t_logit)

@@ -45,6 +45,8 @@ def _make(n, h, L, b, kind, seed=0):
   bonds = _bonds(kind, n)
   eng = VmcEngine(n, b, L, h, seed=2024, ansatz='rbm')
   assert eng.num_params == theta.size == vo.rbm_num_params(n, h, L)
+  # up to 256 hidden units: register-resident rows; 257 .. 512: the fused LDS-operand kernels; beyond: general path
+  assert eng.kernel_path() == (0 if h <= 256 else (1 if h <= 512 else 2))
   eng.set_params(theta)
   eng.set_configs(cfg)
   eng.set_bonds(bonds, -1.0, 1.0)

@@ -1,8 +1,9 @@
 """GPU parity of fully_connected with fc_layer_size > 256 (utils.py:105 allows any size) against the
-numpy oracle, through the C ABI: relu networks of at most 512 units with an H x H layer run the fused
-sampler / row kernels padded to 384 or 512 units (k_sweep16<24|32>, k_tail_lds), everything else the
-general path of csrc/wide.hip (materialised rows + the library's fp32-MFMA GEMM, a few launches per
-mc_step).  Tolerances as tests/test_gpu_engine.py:
+numpy oracle, through the C ABI: networks of at most 512 units (any hidden activation but cos) run
+the fused kernels padded to 384 or 512 units (k_sweep16<24|32>, k_tail_lds / k_tail0,
+k_backprop16<24|32>; kernel_path() == 1), everything beyond 512 units the general path of
+csrc/wide.hip (materialised rows + the library's fp32-MFMA GEMM, a few launches per mc_step;
+kernel_path() == 2).  Tolerances as tests/test_gpu_engine.py:
 logits 2e-5 * max(1, |logit|), local energies 2e-4 * max(1, |E|), gradient sums
 2e-3 * ||.||_inf + 1e-4, accept masks bit-exact outside |ratio - sqrt(u)| < 1e-4 ratio, proposals
 bit-exact."""
@@ -17,14 +18,21 @@ WIDE_SHAPES = [
     # n_sites, H, num_layers, B, bonds, nonlinearity
     (16, 320, 2, 40, 'torus4x4', 'relu'),
     (36, 512, 3, 64, 'torus6x6', 'relu'),
-    (12, 300, 1, 23, 'chain', 'tanh'),        # no H x H layer, H not a multiple of 64
-    (20, 264, 2, 17, 'chain', 'sigmoid'),
+    (12, 300, 1, 23, 'chain', 'tanh'),        # no H x H layer (k_tail0), H not a multiple of 64
+    (20, 264, 2, 17, 'chain', 'sigmoid'),     # non-relu at 384 padded units: general sampler variant
     (10, 384, 3, 50, 'chain', 'relu'),        # exactly 24 unit tiles, two H x H layers
     (24, 500, 2, 33, 'chain', 'relu'),        # padded to 512, ragged batch
     (150, 272, 4, 21, 'chain', 'relu'),       # N > 128: the general (non-prefetch) sampler at 384 units
-    (16, 400, 1, 30, 'chain', 'relu'),        # no H x H layer: general path
+    (16, 400, 1, 30, 'chain', 'relu'),        # no H x H layer
+    (36, 448, 3, 48, 'torus6x6', 'tanh'),     # non-relu at 512 padded units, two H x H layers
+    (16, 300, 2, 25, 'torus4x4', 'identity'),
+    (12, 512, 2, 31, 'chain', 'sigmoid'),
     (16, 640, 2, 19, 'chain', 'relu'),        # more than 512 units: general path
 ]
+
+
+def _expected_path(h):
+  return 1 if h <= 512 else 2
 
 
 def _bonds(kind, n):
@@ -43,6 +51,7 @@ def _make(n, h, L, b, kind, nonlin, seed=0):
   bonds = _bonds(kind, n)
   eng = VmcEngine(n, b, L, h, nonlinearity=nonlin, seed=2024)
   assert eng.num_params == theta.size
+  assert eng.kernel_path() == _expected_path(h)        # 257..512 units run fused, beyond: general path
   eng.set_params(theta); eng.set_configs(cfg); eng.set_bonds(bonds, -1.0, 1.0)
   return eng, theta, cfg, bonds
 
@@ -151,7 +160,15 @@ def test_wide_fast_and_general_path_agree(monkeypatch):
       monkeypatch.delenv('CGS_VMC_WIDE_FAST', raising=False)
     else:
       monkeypatch.setenv('CGS_VMC_WIDE_FAST', '0')
-    eng, theta, cfg, bonds = _make(36, 512, 3, 64, 'torus6x6', 'relu')
+    from cgs_vmc_amd.engine import VmcEngine
+    rng = np.random.default_rng(0)
+    n, h, L, b = 36, 512, 3, 64
+    theta = vo.init_params(n, h, L, rng)
+    cfg = vo.random_configurations(n, b, np.random.RandomState(1))
+    bonds = vo.torus_bonds(6, 6)
+    eng = VmcEngine(n, b, L, h, seed=2024)
+    assert eng.kernel_path() == (1 if fast else 2)
+    eng.set_params(theta); eng.set_configs(cfg); eng.set_bonds(bonds, -1.0, 1.0)
     eng.reset_accumulators()
     eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
     outs.append((eng.amplitude()[0], eng.local_energy()[0], eng.get_accumulators()))
