@@ -259,12 +259,20 @@ __global__ __launch_bounds__(256) void k_tail16(TailArgs a) {
 // rowinfo of a plain batch of rows: row r = chain r, no exchange update
 
 
-// no H x H layer: logit = relu(z1') . w_out + b_out (FC, L = 1) or sum log cosh(z1') + onsite
-// (RBM, num_layers = 0: the classic restricted Boltzmann machine), one thread per row
+// no H x H layer: logit = f(z1') . w_out + b_out (FC, L = 1) or sum log cosh(z1') + onsite
+// (RBM, num_layers = 0: the classic restricted Boltzmann machine).  One WAVE per row: the lanes read
+// the chain's cached z1 and the two W1 rows of the exchanged sites as consecutive 16-byte vectors
+// (1 KiB per load instruction), every lane sums its Hp / 64 terms and the wave folds the 64 partials
+// in a fixed tree (in double: the RBM logit is a sum of H positive terms of order 1 whose
+// DIFFERENCES between configurations are what the sampler and the local energy use).  L2-bound:
+// 3 Hp floats per row; any Hp that is a multiple of 64.
 template <bool RATIO, bool RBM, int ACT>
 __global__ __launch_bounds__(256) void k_tail0(TailArgs a, int Hp) {
   const int n_rows = a.n_rows_dev ? *a.n_rows_dev : a.n_rows;
-  for (int row = blockIdx.x * 256 + threadIdx.x; row < n_rows; row += gridDim.x * 256) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int n_waves = gridDim.x * 4;
+  for (int row = wave; row < n_rows; row += n_waves) {
     int chain = row, bs = 0;
     if (a.rowinfo) { const int2 ri = a.rowinfo[row]; chain = ri.x; bs = ri.y; }
     const float* zb = a.z1 + (long long)chain * Hp;
@@ -279,21 +287,27 @@ __global__ __launch_bounds__(256) void k_tail0(TailArgs a, int Hp) {
       wa += (long long)ab.x * Hp; wb += (long long)ab.y * Hp;
       if (RBM) on = fmaf(coef, a.pp.won[ab.x] - a.pp.won[ab.y], on);
     }
-    float s = 0.f;
-    if (RBM) {
-      // the logit is a sum of H positive terms (~ H / 2): accumulate in double so that
-      // logit' - logit keeps its digits (this kernel is not hot)
-      double sd = 0.0;
-      for (int i = 0; i < a.n_units; ++i) {
-        sd += (double)vmc_logcosh(fmaf(coef, wa[i] - wb[i], zb[i]));
+    float part = 0.f;
+    for (int i = 4 * lane; i < Hp; i += 256) {
+      const f32x4 z = *(const f32x4*)(zb + i);
+      const f32x4 x = *(const f32x4*)(wa + i);
+      const f32x4 y = *(const f32x4*)(wb + i);
+      f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (!RBM) w = *(const f32x4*)(a.pp.woutp + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = fmaf(coef, x[e] - y[e], z[e]);
+        if (RBM) part += i + e < a.n_units ? vmc_logcosh(v) : 0.f;
+        else part = fmaf(vmc_act<ACT>(v), w[e], part);
       }
-      s = (float)sd;
-    } else {
-      for (int i = 0; i < Hp; ++i)
-        s = fmaf(vmc_act<ACT>(fmaf(coef, wa[i] - wb[i], zb[i])), a.pp.woutp[i], s);
     }
-    const float logit = s + a.pp.bout[0] + on;
-    a.out[row] = RATIO ? a.half_jx[bond] * vmc_out_ratio(a.oact, logit, a.logit_base[chain]) : logit;
+    double s = (double)part;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (lane == 0) {
+      const float logit = (float)s + a.pp.bout[0] + on;
+      a.out[row] = RATIO ? a.half_jx[bond] * vmc_out_ratio(a.oact, logit, a.logit_base[chain]) : logit;
+    }
   }
 }
 
@@ -314,8 +328,8 @@ template <bool RATIO, bool RBM, int ACT>
 static hipError_t launch_tail_t(hipStream_t s, const TailArgs& a, int Hp) {
   if (a.n_rows <= 0) return hipSuccess;
   if (a.n_hidden == 0) {
-    const int blocks = (a.n_rows + 255) / 256;
-    hipLaunchKernelGGL((k_tail0<RATIO, RBM, ACT>), dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, s, a, Hp);
+    const int blocks = (a.n_rows + 3) / 4;      // one wave per row, 8 workgroups per CU's worth of rows in flight
+    hipLaunchKernelGGL((k_tail0<RATIO, RBM, ACT>), dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, s, a, Hp);
     return hipGetLastError();
   }
   switch (Hp / 16) {
