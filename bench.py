@@ -55,6 +55,8 @@ WORKLOADS = {
     'heisenberg10x10_fc3x512_b4096': (10, 10, False, 3, 512, 4096),   # > 256 units: general path (wide.hip)
     'heisenberg10x10_conv5x16k5_b4096': (10, 10, False, 5, 16, 4096, 'conv_2d', 5),
     'heisenberg10x10_resnet2x16k5_b4096': (10, 10, False, 2, 16, 4096, 'res_net_2d', 5),
+    'heisenberg10x10_conv5x32k5_b4096': (10, 10, False, 5, 32, 4096, 'conv_2d', 5),    # two 16-channel blocks
+    'heisenberg10x10_conv3x32k3_b4096': (10, 10, False, 3, 32, 4096, 'conv_2d', 3),
     'heisenberg16x16j1j2_conv5x16k5_b1024': (16, 16, True, 5, 16, 1024, 'conv_2d', 5),
 }
 
@@ -72,9 +74,10 @@ def f_amp(n, h, L, ansatz='fully_connected', k=0):
 def mfma_flops_per_amp(n, h, L, ansatz, k):
   """flops one amplitude ISSUES to the matrix cores."""
   if ansatz in ('conv_2d', 'res_net_2d'):
-    # 16-channel tiles (filters zero padded), taps of the first convolution padded to 4
+    # 16-channel tiles (filters zero padded to ncb blocks), taps of the first convolution padded to 4
     n_conv = L if ansatz == 'conv_2d' else 1 + 2 * L
-    return 2 * n * 16 * (4 * ((k * k + 3) // 4) + (n_conv - 1) * k * k * 16)
+    ncb = (h + 15) // 16
+    return 2 * n * 16 * ncb * (4 * ((k * k + 3) // 4) + (n_conv - 1) * k * k * 16 * ncb)
   hp = (h + 63) // 64 * 64 if h <= 256 else (h + 127) // 128 * 128   # 257..512 units pad to 384 / 512
   return 2 * (L - 1) * hp * hp
 
@@ -696,7 +699,7 @@ def main():
       pmc = None
       suffix = {'heisenberg10x10_fc3x256_b4096': '', 'heisenberg16x16j1j2_fc6x256_b1024': '_config5',
                 'heisenberg10x10_conv5x16k5_b4096': '_conv', 'heisenberg16x16j1j2_conv5x16k5_b1024': '_conv16',
-                'heisenberg10x10_fc3x512_b4096': '_fc3x512'}.get(args.workload)
+                'heisenberg10x10_fc3x512_b4096': '_fc3x512', 'heisenberg10x10_conv5x32k5_b4096': '_conv32'}.get(args.workload)
       for rnd in ('r3', 'r2'):                    # the newest committed profile of this workload
         tag = None if suffix is None else rnd + suffix
         tpath = os.path.join(ROOT, 'profiles', '{}_traffic.json'.format(tag))

@@ -5,12 +5,14 @@
 #include "common.hpp"
 
 #define CONV_MAX_LAYERS 32
-#define CONV_FP 16          // channel tile: num_conv_filters <= 16, zero padded to 16
+#define CONV_FP 16          // channel tile of the MFMA: filters are zero padded to NCB blocks of 16
+#define CONV_MAX_NCB 2      // num_conv_filters <= 32
 
 // Geometry of one network.  A feature map of one sample is stored -- in LDS and in the HBM tapes
-// alike -- channel-group major: [4 groups][GS dwords], element (site, channel c) at
+// alike -- channel-group major: [4 NCB groups][GS dwords], element (site, channel c) at
 // (c / 4) * GS + 4 * site + c % 4, with GS >= 4 N a multiple of 64 dwords so that the 16-lane
-// groups of ds_read_b128 / ds_write_b128 fall on distinct banks.
+// groups of ds_read_b128 / ds_write_b128 fall on distinct banks; NCB = ceil(F / 16) channel blocks
+// of one MFMA tile each, CS = 4 NCB GS dwords per sample.
 struct ConvGeom {
   int K;        // kernel_size
   int D1, D2;   // size_x, size_y: inputs are reshaped to [-1, size_x, size_y, 1] (wavefunctions.py:596)
@@ -24,15 +26,20 @@ struct ConvGeom {
                 // the 1-D modules pad K/2 in front and K-1-K/2 behind (layers.py:66-72)
   int KW;       // taps along axis 2: K (Conv2dPeriodic) or 1 (Conv1dPeriodic on an [N, 1] lattice)
   int lo2, hi2; // the same padding for axis 2 (0 for the 1-D modules)
+  int NCB;      // channel blocks of 16: (F + 15) / 16
+  int CS;       // dwords of one sample's feature map: 4 * NCB * GS
 };
 
-// One packed parameter set (k_conv_pack):
-//   w0   [Q0][64]           first convolution (1 input channel), taps are the k index:
-//                           lane (m, g) of k-step q = W0[tap 4q+g][0][cout m]
-//   wf   [n_conv-1][K*KW][64][4] forward fragments of convolutions 1..: lane (m, g), element e =
-//                           W[tap][cin 4g+e][cout m]        (A operand of v_mfma_f32_16x16x4_f32)
-//   wb   same shape: the transposed convolution, lane (m, g), e = W[K*K-1-tap][cin m][cout 4g+e]
-//   bias [n_conv][16]
+// One packed parameter set (k_conv_pack); co / ci = output / input channel block of 16:
+//   w0   [NCB co][Q0][64]   first convolution (1 input channel), taps are the k index:
+//                           lane (m, g) of k-step q = W0[tap 4q+g][0][cout 16 co + m]
+//   wf   [n_conv-1][NCB co][NCB ci][K*KW][64][4] forward fragments of convolutions 1..: lane (m, g),
+//                           element e = W[tap][cin 16 ci + 4g+e][cout 16 co + m]
+//                           (A operand of v_mfma_f32_16x16x4_f32)
+//   wb   same shape, the transposed convolution: block (co, ci) of the image produces channel block
+//                           co of d/d(input) from block ci of d/d(output): lane (m, g), e =
+//                           W[K*K-1-tap][cin 16 co + m][cout 16 ci + 4g+e]
+//   bias [n_conv][16 NCB]
 struct ConvParams {
   const float* w0;
   const float* wf;
@@ -54,7 +61,8 @@ struct ConvRowsArgs {
   int oact;
   int G;                    // samples per pass (LDS resident)
   float* out;               // [n_rows]
-  float* tape;              // [n_conv-1][n_rows][4 GS] inputs of convolutions 1.. (gradient path) or nullptr
+  float* tape;              // [n_conv-1][n_rows][CS] inputs of convolutions 1.. (gradient path; the cosine
+                            // tapes the PRE-activation, its derivative needs z) or nullptr
   long long tape_stride;    // floats between the tapes of consecutive convolutions
 };
 
@@ -81,10 +89,10 @@ struct ConvSweepArgs {
 struct ConvBackArgs {
   ConvGeom g;
   ConvParams p;
-  const float* tape;        // [n_conv-1][B][4 GS]
+  const float* tape;        // [n_conv-1][B][CS]
   long long tape_stride;
   const float* oscale;      // [B] (1/psi) d psi / d logit (1 for the exp output)
-  float* delta;             // [n_conv][B][4 GS]  d logit / d (output of convolution l)
+  float* delta;             // [n_conv][B][CS]  d logit / d (output of convolution l)
   long long delta_stride;
   int B, G;
 };
@@ -97,7 +105,7 @@ struct ConvDwArgs {
   const float* w;           // [B] weights of the second (scaled) sum
   int B;
   int n_slices;             // sample slices = gridDim.x
-  float* ws;                // [n_slices][n_conv][2][(K*K*16 + 1) * 16] partial sums
+  float* ws;                // [n_slices][n_conv][2][(K*K*16 NCB + 1) * 16 NCB] partial sums
   float* g1; float* g2;     // accumulators (theta layout), += on reduce
 };
 

@@ -686,23 +686,23 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
       return fail(nullptr, VMC_ERR_INVALID, "size_x * size_y must equal num_sites");
     if (d->kernel_size < 1 || d->kernel_size > 6)
       return fail(nullptr, VMC_ERR_UNSUPPORTED, "kernel_size 1..6 supported by the convolution kernels (weights are register resident)");
-    if (d->layer_size > CONV_FP)
-      return fail(nullptr, VMC_ERR_UNSUPPORTED, "num_conv_filters > 16 not supported by the convolution kernels");
+    if (d->layer_size > CONV_FP * CONV_MAX_NCB)
+      return fail(nullptr, VMC_ERR_UNSUPPORTED, "num_conv_filters > 32 not supported by the convolution kernels");
     if (sx < d->kernel_size / 2 || (!one_d && sy < d->kernel_size / 2) || sx > 1023 || sy > 1023)
       return fail(nullptr, VMC_ERR_UNSUPPORTED, "lattice sides must be in [kernel_size / 2, 1023]");
-    if (!resnet && d->nonlinearity == VMC_ACT_COS)
-      return fail(nullptr, VMC_ERR_UNSUPPORTED, "the cos nonlinearity is not offered by the convolution kernels");
     cg.K = d->kernel_size; cg.D1 = sx; cg.D2 = sy; cg.N = d->n_sites; cg.F = d->layer_size;
     cg.n_conv = resnet ? 1 + 2 * d->num_layers : d->num_layers;
     cg.resnet = resnet ? 1 : 0; cg.hact = d->nonlinearity;
     cg.GS = (4 * cg.N + 63) / 64 * 64;
+    cg.NCB = (cg.F + CONV_FP - 1) / CONV_FP;
+    cg.CS = 4 * cg.NCB * cg.GS;
     if (one_d) {   // layers.py:66-72: k/2 in front, k - 1 - k/2 behind (odd k: (k-1)/2 both)
       cg.KW = 1; cg.lo = cg.K / 2; cg.hi = cg.K - 1 - cg.lo; cg.lo2 = cg.hi2 = 0;
     } else {       // layers.py:132-141: (k-1)/2 in front, k/2 behind, both axes
       cg.KW = cg.K; cg.lo = cg.lo2 = (cg.K - 1) / 2; cg.hi = cg.hi2 = cg.K / 2;
     }
     if (cg.n_conv > CONV_MAX_LAYERS) return fail(nullptr, VMC_ERR_UNSUPPORTED, "too many convolutions");
-    if ((long long)d->batch_size * 4 * cg.GS >= (1LL << 31))
+    if ((long long)d->batch_size * cg.CS >= (1LL << 31))
       return fail(nullptr, VMC_ERR_UNSUPPORTED, "batch_size x lattice too large for the 32-bit tape offsets of the convolution kernels");
     if (conv_rows_lds(cg, 1) > 160 * 1024)
       return fail(nullptr, VMC_ERR_UNSUPPORTED, "lattice too large: the feature maps of one sample must fit the 160 KiB of LDS");
@@ -858,8 +858,10 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     const long long KK = (long long)cg.K * cg.KW, nl = cg.n_conv > 1 ? cg.n_conv - 1 : 1;
     for (int w = 0; w < 2; ++w) {
       ParamSet& p = c->ps[w];
-      CA(dalloc(&p.cw0, (KK + 3) / 4 * 64)); CA(dalloc(&p.cwf, nl * KK * 256)); CA(dalloc(&p.cwb, nl * KK * 256));
-      CA(dalloc(&p.cbias, (long long)cg.n_conv * 16));
+      const long long nb = cg.NCB;
+      CA(dalloc(&p.cw0, nb * ((KK + 3) / 4) * 64)); CA(dalloc(&p.cwf, nl * nb * nb * KK * 256));
+      CA(dalloc(&p.cwb, nl * nb * nb * KK * 256));
+      CA(dalloc(&p.cbias, (long long)cg.n_conv * 16 * nb));
     }
     const int nw = conv_waves();
     c->cG = conv_pick_group(cg, nw);
@@ -874,10 +876,10 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; c->cGs = G; }
       }
     }
-    c->ctape_stride = B * 4 * cg.GS; c->cdelta_stride = B * 4 * cg.GS;
+    c->ctape_stride = B * cg.CS; c->cdelta_stride = B * cg.CS;
     CA(dalloc(&c->ctape, nl * c->ctape_stride)); CA(dalloc(&c->cdelta, (long long)cg.n_conv * c->cdelta_stride));
     c->c_slices = B < 64 ? (int)B : 64;
-    CA(dalloc(&c->cws, (long long)c->c_slices * cg.n_conv * 2 * (KK * 16 + 1) * 16));
+    CA(dalloc(&c->cws, (long long)c->c_slices * cg.n_conv * 2 * (KK * 16 * cg.NCB + 1) * 16 * cg.NCB));
   }
   CA(hipStreamSynchronize(c->stream));
 #undef CA

@@ -61,7 +61,7 @@ enum { VMC_ANSATZ_FULLY_CONNECTED = 0, VMC_ANSATZ_RBM = 1, VMC_ANSATZ_CONV_2D = 
        VMC_ANSATZ_RES_NET_2D = 3, VMC_ANSATZ_CONV_1D = 4, VMC_ANSATZ_RES_NET_1D = 5 };
 
 /* layers.NONLINEARITIES ids (layers.py:13-21).  Every id is accepted as hidden and as output
- * activation of the dense ansatz types; the convolutional ones take every hidden id but cos. */
+ * activation of every ansatz type with kernels (dense types beyond 256 hidden units: not cos). */
 enum { VMC_ACT_RELU = 0, VMC_ACT_EXP = 1, VMC_ACT_COS = 2, VMC_ACT_TAN = 3, VMC_ACT_TANH = 4,
        VMC_ACT_SIGMOID = 5, VMC_ACT_IDENTITY = 6 };
 
@@ -75,7 +75,7 @@ typedef struct {
                                 .. 512 not with cos), beyond that the general multi-launch path
                                 (materialised rows + GEMMs, no cos; two [131072][units] float
                                 buffers per ctx: 4 GiB at 4096 units).  Convolutional ansatz types:
-                                num_conv_filters (111), at most 16                              */
+                                num_conv_filters (111), at most 32 (two 16-channel MFMA blocks)  */
   int32_t nonlinearity;      /* VMC_ACT_*: hparams.nonlinearity  (utils.py:128)      */
   int32_t output_activation; /* VMC_ACT_*: hparams.output_activation (utils.py:129)  */
   int32_t device;            /* HIP device ordinal                                   */
