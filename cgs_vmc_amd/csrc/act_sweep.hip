@@ -24,7 +24,4 @@ hipError_t VMC_CAT(launch_sweep16_inst_, VMC_INST_ACT)(hipStream_t s, const Swee
   if (a.rbm) return VMC_CAT(launch_sweep16_rbm_inst_, VMC_INST_ACT)(s, a, Hp);
   return launch_sweep16_r<false, VMC_INST_ACT>(s, a, Hp);
 }
-#if VMC_INST_ACT == 0
-size_t sweep_co_lds_bytes(int N, int n_hidden) { return sweep_lds_bytes(N, 256, n_hidden, false, false); }
-#endif
 #endif

@@ -210,7 +210,6 @@ struct SweepArgs {
   int waves;                // waves per workgroup of the sweep kernel (4 or 8)
   int no_w1l;               // 1: never hold W1 in LDS (the two-workgroups-per-CU variant)
   int uh_lds;               // set by the launcher: the sampler's dedicated hand-over area is part of its LDS
-  int co;                   // 1: the co-resident variant k_sweep16_co (H = 256, relu, N <= 128; ignored otherwise)
   int cache_in_valid;       // z1 / logit already hold the exact cache of `configs`
   float* act_out;           // [L][B][Hp] activations of the final chains (gradient path) or nullptr
   int B, N, n_hidden;
@@ -235,10 +234,6 @@ hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, 
                          float* out);
 hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n);
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp);
-// the CU-sharing pair (tail_co.hip / k_sweep16_co): LDS footprints and the row kernel's launcher
-size_t tail_co_lds_bytes(int n_hidden);
-size_t sweep_co_lds_bytes(int N, int n_hidden);
-hipError_t launch_tail_co(hipStream_t s, const TailArgs& a, size_t lds_bytes);
 // the LDS-operand row kernel for 384 / 512 padded units (tail_lds.hpp; one instantiation per hidden
 // activation in act_tail.hip): fully_connected and rbm with at least one H x H layer
 bool tail_lds_supported(int Hp, int n_hidden);

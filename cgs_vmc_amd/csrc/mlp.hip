@@ -136,6 +136,14 @@ hipError_t launch_tail(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode
 #undef CALL
 }
 
+// 384 or 512 padded units and at least one H x H layer (the sampler's LDS need is checked by vmc_create);
+// LDS of k_tail_lds: two operand buffers [2 halves][NT][64][4], partial dots, row meta, biases, w_out
+bool tail_lds_supported(int Hp, int n_hidden) {
+  const size_t nt = (size_t)Hp / 16;
+  const size_t lds = sizeof(float) * (2 * (2 * nt * 256) + 4 * 32 + 96 + (size_t)n_hidden * nt * 16 + nt * 16);
+  return (Hp == 384 || Hp == 512) && n_hidden >= 1 && lds <= 160 * 1024;
+}
+
 hipError_t launch_tail_lds(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm) {
 #define CALL(N) launch_tail_lds_inst_##N(s, a, Hp, ratio_mode, rbm)
   VMC_ACT_SWITCH(a.act, CALL)

@@ -12,25 +12,16 @@
 #ifndef SWEEP_OCC0
 #define SWEEP_OCC0 4    // waves per SIMD the all-streamed (RTP = 0) H = 256 variant is compiled for
 #endif
-#ifndef SWEEP_RT_CO
-#define SWEEP_RT_CO 0     // resident k-tiles of the co-resident variant k_sweep16_co
-#endif
-#ifndef SWEEP_VGPR_CO
-#define SWEEP_VGPR_CO 100 // its register budget (two waves per SIMD + one wave of k_tail_co <= 512)
-#endif
 #ifndef SWEEP_RT_WIDE
 #define SWEEP_RT_WIDE 2      // resident k-tiles of the 384- and 512-unit variants
 #endif
 #ifndef SWEEP_SCALAR_NT
 #define SWEEP_SCALAR_NT 16   // layers wider than this many tiles keep the weight base address scalar (see issue())
 #endif
-#ifndef SWEEP_CO_PRIO
-#define SWEEP_CO_PRIO 3
-#endif
 // The two switches below are on for the two-draw variants (UPRE = 2, N <= 128 sites) only: with
 // five draws per lane (UPRE = 4) the second copy of layer 0 costs registers (6 -> 15 spilled);
 // the split is also left out of the variants without W1 in LDS or without resident k-tiles (a few
-// spills each, among them the register-capped k_sweep16_co).
+// spills each).
 #ifndef SWEEP_SPLIT
 #define SWEEP_SPLIT(UPRE) ((UPRE) == 2)   // waves 4-7 run layer 0 without the Philox pieces
 #endif
@@ -858,19 +849,6 @@ __global__ __launch_bounds__(NW * 64, NT == 16 ? (RTP == 0 ? SWEEP_OCC0 : 2) : 1
   sweep16_body<NT, NW, RTP, STAMP, W1L, FAST, UPRE, RBM, ACT>(a);
 }
 
-// The co-resident variant (H = 256, production path only): SWEEP_RT_CO resident k-tiles, W1 in
-// L2 and at most SWEEP_VGPR_CO registers, so that its two waves per SIMD leave 512 - 2 x
-// SWEEP_VGPR_CO registers of every SIMD -- and half the LDS -- to one wave of k_tail_co
-// (tail_co.hpp), which evaluates local energies in the matrix-pipe time the sampler's serial
-// phases leave idle.
-template <int ACT>
-__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(SWEEP_VGPR_CO)))
-void k_sweep16_co(SweepArgs a) {
-  // the sampler's mc_step is the critical path of the pair: its waves issue ahead of k_tail_co's
-  __builtin_amdgcn_s_setprio(SWEEP_CO_PRIO);
-  sweep16_body<16, 8, SWEEP_RT_CO, false, false, true, 2, false, ACT>(a);
-}
-
 static inline size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool rbm, int uh_floats = 0) {
   const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
   return sizeof(float) * (size_t)(16 * Nst + (w1l ? 1 : 2) * 16 * ZS + 2 * NT * 256 + 16 +
@@ -905,16 +883,6 @@ static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a_in) {
     return hipGetLastError();                                                                 \
   } while (0)
   constexpr bool TUNED = ACT == VMC_ACT_RELU_;   // other activations only get the general variant
-  if constexpr (TUNED && NT == 16 && NW == 8 && !RBM) {
-    if (a.co && fast2 && !a.dbg_cycles) {   // co-resident variant: W1 in L2, capped registers
-      const size_t lds_co = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false, false);
-      hipError_t e = hipFuncSetAttribute((const void*)k_sweep16_co<ACT>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_co);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL((k_sweep16_co<ACT>), grid, block, lds_co, s, a);
-      return hipGetLastError();
-    }
-  }
   if (a.dbg_cycles) {
     if (!(w1l && fast2) || RBM || NT != 16 || !TUNED) return hipErrorInvalidValue;   // diagnostic build: production variant only
     if constexpr (!RBM && NT == 16 && TUNED) SWEEP_LAUNCH(true, true, true, 2);

@@ -3,7 +3,6 @@
 // 16-row halves that share every weight fragment).  Wave w owns output units 16 TO w .. 16 TO (w+1) - 1
 // of both halves; the B operands of a layer come from LDS, the A fragments stream from L2 through a
 // two-stage register ring behind a scalar base.
-//   NT = 16, relu, fully_connected, register-capped: k_tail_co (tail_co.hip), the CU-sharing experiment
 //   NT = 24 / 32 (384 / 512 padded hidden units): the row kernel of the fused path for
 //        fc_layer_size 257 .. 512, where k_tail16's register-resident activations (2 x NT x 4
 //        registers, twice) no longer fit.  Every hidden activation of layers.NONLINEARITIES (one
@@ -112,7 +111,7 @@ __device__ __forceinline__ void tail_lds_body(const TailArgs& a) {
       const int l_next = l + 1 < n_hidden ? l + 1 : 0;
 #pragma unroll
       for (int ti = 0; ti < NT; ++ti) {
-        // B operands of this k-tile (one LDS round trip, hidden by the co-resident sampler waves),
+        // B operands of this k-tile (one LDS round trip),
         // then the A fragments of the next one
         const f32x4 b0 = xin[ti * 64], b1 = xin[(NT + ti) * 64];
         if (ti + 1 < NT) issue(l, ti + 1, (ti + 1) & 1);

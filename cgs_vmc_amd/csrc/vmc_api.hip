@@ -125,16 +125,12 @@ struct vmc_ctx {
   int num_cus = 256;
   int sweep_waves = 8;       // waves per sweep workgroup at Hp = 256 (CGS_VMC_SWEEP_WAVES=4|8)
   int sweep_no_w1l = 0;      // CGS_VMC_SWEEP_W1L=0: W1 stays in L2 (smaller LDS footprint)
-  int sweep_co = 0;          // CGS_VMC_SWEEP_CO=1: force the co-resident sampler variant (diagnostic)
-  bool co = false;           // sampler and local-energy kernel share every CU (k_sweep16_co + k_tail_co)
-  size_t co_lds = 0;         // padded LDS request of k_tail_co (> half a CU: never two of them per CU)
   // stochastic reconfiguration (extension, sr.hip): sample store + CG vectors
   int sr_cap = 0, sr_n = 0, sr_iter = 0;
   float *sr_cfg = nullptr, *sr_act = nullptr, *sr_delta = nullptr;   // [cap B][N], [L][cap B][Hp] x2
   float *sr_ws = nullptr, *sr_t = nullptr, *sr_ones = nullptr;        // [slices][(max(N,H)+1) H], [cap B] x2
   float *sr_u = nullptr, *sr_x = nullptr, *sr_r = nullptr, *sr_p = nullptr, *sr_q = nullptr;
   double *sr_partial = nullptr, *sr_sc = nullptr;
-  GemmArgs* sr_batch = nullptr;                                       // [L+1]
   bool sr_begun = false;
   // collectives over sharded chains: host hook for non-RCCL transports + its staging
   vmc_host_allreduce_fn host_reduce = nullptr;
@@ -209,13 +205,8 @@ int sweep_cus(const vmc_ctx* c) { return (c->B + 15) / 16; }
 // The sampler may overtake the accumulate enqueued just before it when it leaves the local-energy
 // kernel at least a quarter of the CUs; with one 16-chain tile per CU (config 3) there is nothing
 // to share and the launch stays on `stream`.
-// ... unless the CU-sharing pair applies (c->co): k_sweep16_co and k_tail_co are sized so that one
-// workgroup of each is resident per CU, and the row kernel's MFMAs fill the sampler's serial phases.
-bool co_active(const vmc_ctx* c) {
-  return c->overlap && c->co && sweep_cus(c) > (3 * c->num_cus) / 4;
-}
 bool can_overlap(const vmc_ctx* c) {
-  return c->overlap && (c->overlap_full || co_active(c) || sweep_cus(c) <= (3 * c->num_cus) / 4);
+  return c->overlap && (c->overlap_full || sweep_cus(c) <= (3 * c->num_cus) / 4);
 }
 
 // `acc` is about to be read or partially written: turn a pending reset into real zeros
@@ -520,11 +511,7 @@ int local_energy_device(vmc_ctx* c, int which) {
     // CU each, so the persistent grid leaves them free
     if (c->expect_sweep && can_overlap(c) && c->num_cus - sweep_cus(c) >= c->num_cus / 4)
       a.num_cus = c->num_cus - sweep_cus(c);
-    if (c->expect_sweep && co_active(c) && which == 0) {
-      HIPCHK(c, launch_tail_co(c->stream, a, c->co_lds));   // shares each CU with the overtaking sampler
-    } else {
-      HIPCHK(c, launch_tail(c->stream, a, c->Hp, true, c->rbm));
-    }
+    HIPCHK(c, launch_tail(c->stream, a, c->Hp, true, c->rbm));
   }
   {
     Timer t(c, "eloc_reduce");
@@ -762,25 +749,6 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
               : vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
   c->stream = (hipStream_t)d->stream;
   if (const char* e = getenv("CGS_VMC_SWEEP_W1L")) c->sweep_no_w1l = atoi(e) == 0 ? 1 : 0;
-  if (const char* e = getenv("CGS_VMC_SWEEP_CO")) c->sweep_co = atoi(e) != 0 ? 1 : 0;
-  {
-    // the CU-sharing pair: fully_connected, relu, H = 256, N <= 128 (the prefetched-Philox sampler),
-    // and both LDS footprints (in 1280-byte granules) fit one CU with the row kernel above half of it
-    const bool shape = !conv && !wide && !c->rbm && c->hact == VMC_ACT_RELU_ && c->Hp == 256 &&
-                       c->n_hh >= 1 && c->N <= 128;
-    if (shape) {
-      const size_t gran = 1280, cu = 160 * 1024;
-      const size_t sw = (sweep_co_lds_bytes(c->N, c->n_hh) + gran - 1) / gran * gran;
-      size_t tl = tail_co_lds_bytes(c->n_hh);
-      if (tl < cu / 2 + gran) tl = cu / 2 + gran;
-      tl = (tl + gran - 1) / gran * gran;
-      c->co = sw + tl <= cu;
-      c->co_lds = tl;
-    }
-    // measured slower than the separate kernels at config 3 (2.07 vs 2.04 ms): opt-in only
-    const char* e = getenv("CGS_VMC_CO");
-    c->co = c->co && e && atoi(e) != 0;
-  }
   if (const char* e = getenv("CGS_VMC_OVERLAP")) { c->overlap = !conv && !wide && atoi(e) != 0; c->overlap_full = atoi(e) == 2; }
   {
     hipDeviceProp_t prop;
@@ -914,7 +882,7 @@ void vmc_destroy(vmc_ctx* c) {
                   c->acc_mask};
   for (void* q : ptrs) if (q) hipFree(q);
   void* sr[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_u, c->sr_x, c->sr_r,
-                c->sr_p, c->sr_q, c->sr_partial, c->sr_sc, c->sr_batch, c->sr_ones};
+                c->sr_p, c->sr_q, c->sr_partial, c->sr_sc, c->sr_ones};
   for (void* q : sr) if (q) hipFree(q);
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->d_stage) hipFree(c->d_stage);
@@ -1130,7 +1098,6 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = step0; a.n_steps = n_steps;
   a.waves = c->sweep_waves; a.no_w1l = c->sweep_no_w1l;
-  a.co = (c->sweep_co || (overtake && co_active(c) && c->expect_sweep)) ? 1 : 0;
   a.act = c->hact; a.oact = c->oact;
   // the activations of the final chains are handed to the gradient path only when a gradient
   // accumulate has been seen since the previous launch (equilibration / evaluation sweeps skip
@@ -1751,37 +1718,12 @@ int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   HIPCHK(c, dalloc(&c->sr_t, R)); HIPCHK(c, dalloc(&c->sr_ones, R));
   HIPCHK(c, launch_fill(c->stream, c->sr_ones, 1.f, R));
   if (!c->sr_u) {
-    HIPCHK(c, dalloc(&c->sr_batch, L + 1));
     HIPCHK(c, dalloc(&c->sr_u, P + 1)); HIPCHK(c, dalloc(&c->sr_x, P)); HIPCHK(c, dalloc(&c->sr_r, P));
     HIPCHK(c, dalloc(&c->sr_p, P)); HIPCHK(c, dalloc(&c->sr_q, P));
     HIPCHK(c, dalloc(&c->sr_partial, 256)); HIPCHK(c, dalloc(&c->sr_sc, 4));
     HIPCHK(c, hipMemsetAsync(c->sr_x, 0, P * sizeof(float), c->stream));
   }
   c->sr_cap = n_batches;
-  return VMC_OK;
-}
-
-// weighted-sum GEMM table over the rows recorded so far: u += [a_{l-1} | 1]^T [t (.) delta_l]
-static int sr_build_table(vmc_ctx* c) {
-  const long long B = c->B, N = c->N, H = c->H, Hp = c->Hp, L = c->A;
-  const long long R = (long long)c->sr_cap * B, rows = (long long)c->sr_n * B;
-  std::vector<GemmArgs> tab;
-  const long long ws_stride = (long long)c->splitk * 2 * ((N > H ? N : H) + 1) * H;
-  auto add = [&](const float* a, long long a_ld, int k_in, const float* delta, long long sbk,
-                 long long sbn, int n_out, long long off) {
-    GemmArgs g; memset(&g, 0, sizeof(g));
-    g.A = a; g.sam = 1; g.sak = a_ld; g.M = k_in + 1; g.ones_row = 1;
-    g.B = delta; g.sbk = sbk; g.sbn = sbn; g.kscale = c->sr_t; g.dual = 0;
-    g.N = n_out; g.K = (int)rows; g.C = c->sr_u + off; g.ldc = n_out; g.epilogue = 3;
-    g.splitk = pick_splitk(c, rows); g.workspace = c->gemm_ws + (long long)tab.size() * ws_stride;
-    tab.push_back(g);
-  };
-  // only the N = 1 layer goes through the batched GEMM (u += [a | 1]^T [t]); the H-wide layers
-  // run on the large-tile kernels of srmm.hip
-  if (c->rbm) add(c->sr_cfg, N, (int)N, c->sr_ones, 1, 0, 1, c->lay.off_won);        // onsite layer
-  else add(c->sr_act + (L - 1) * R * Hp, Hp, (int)H, c->sr_ones, 1, 0, 1, off_wout(c));
-  HIPCHK(c, hipMemcpyAsync(c->sr_batch, tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // tab is a stack object
   return VMC_OK;
 }
 
@@ -1804,7 +1746,6 @@ int vmc_sr_begin(vmc_ctx* c, double* rr0) {
   if (c->sr_cap <= 0) return fail(c, VMC_ERR_STATE, "vmc_sr_reserve first");
   if (c->sr_n <= 0) return fail(c, VMC_ERR_STATE, "no samples recorded (vmc_accumulate in ENERGY_GRADIENT mode)");
   PROPAGATE(acc_zeros(c));
-  PROPAGATE(sr_build_table(c));
   HIPCHK(c, launch_sr_rhs(c->stream, c->acc, (int)c->P, c->sr_x, c->sr_r, c->sr_p, c->sr_partial, c->sr_sc));
   c->sr_iter = 0; c->sr_begun = true;
   return sr_read_rr(c, 0, rr0);

@@ -154,47 +154,12 @@ def test_full_size_engine_matches_oracle_on_sampled_chains(name):
   eng.close()
 
 
-def test_cu_sharing_pair_matches_separate_kernels(monkeypatch):
-  """CGS_VMC_CO=1 (k_sweep16_co + k_tail_co resident together) walks the same chains bit
-  for bit and gives the same local energies / accumulators as the default kernels; checked against
-  the oracle on sampled chains as well."""
-  from cgs_vmc_amd import _hip
-  name = 'config3_10x10_h256_b4096'
-
-  def run(co):
-    if co:
-      monkeypatch.setenv('CGS_VMC_CO', '1')
-    else:
-      monkeypatch.delenv('CGS_VMC_CO', raising=False)
-    eng, theta, cfg, bonds, (n, h, L, b) = _setup(name)
-    accs = []
-    for _ in range(3):    # the pair engages from the second (accumulate, sweep) iteration on
-      eng.reset_accumulators()
-      eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
-      eng.mc_steps(n, want_accepted=False)
-      accs.append(eng.get_accumulators().copy())
-    e = eng.local_energy()[0]      # a sweep is expected next: with co this is k_tail_co
-    out = eng.get_configs()
-    eng.close()
-    return accs, e, out, (theta, bonds, h, L)
-
-  accs0, e0, out0, _ = run(False)
-  accs1, e1, out1, (theta, bonds, h, L) = run(True)
-  np.testing.assert_array_equal(out1, out0)
-  for a0, a1 in zip(accs0, accs1):
-    assert np.abs(a1 - a0).max() <= 1e-6 * np.abs(a0).max()
-  assert np.abs(e1 - e0).max() <= 2e-5 * max(1.0, np.abs(e0).max())
-  idx = np.random.default_rng(1).choice(len(out1), 32, replace=False)
-  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
-  e_ref = vo.local_value(amp, out1[idx], bonds, *_couplings(name, bonds), dtype=np.float64)
-  assert np.abs(e1[idx] - e_ref).max() < 2e-4 * max(1.0, np.abs(e_ref).max())
-
-
 # the convolutional bench workloads (bench.py WORKLOADS) at their full sizes
 FULL_CONV = {
     'conv10x10_5x16k5_b4096': ('conv_2d', 10, 10, False, 5, 16, 5, 4096),
     'resnet10x10_2x16k5_b4096': ('res_net_2d', 10, 10, False, 2, 16, 5, 4096),
     'conv16x16j1j2_5x16k5_b1024': ('conv_2d', 16, 16, True, 5, 16, 5, 1024),
+    'conv10x10_3x32k3_b4096': ('conv_2d', 10, 10, False, 3, 32, 3, 4096),      # two channel blocks
 }
 
 
