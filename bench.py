@@ -442,13 +442,10 @@ def device_identity(dev):
 
 
 def prove_collectives(eng, world, rank, dev):
-  """N > 1: evidence in the JSON line that the job really ran on `world` DISTINCT devices and that
-  both collective paths reduce correctly -- (1) the library's own transport (in-stream RCCL
-  communicator, or the host hook under a non-RCCL backend) on a device buffer of the library:
-  sum of rank ids == N(N-1)/2 and sum of ones == N; (2) torch.distributed's process group on the
-  library's accumulator buffer, the exact call the timed step makes: every float == N(N+1)/2 and
-  g_count divided back by N.  Under the `nccl` backend two ranks on one device are refused."""
-  import torch
+  """N > 1, BEFORE the timed region: evidence in the JSON line that the job really ran on `world`
+  DISTINCT devices and that the collective the timed step makes reduces correctly --
+  torch.distributed's process group on the library's accumulator buffer: every float == N(N+1)/2
+  and g_count divided back by N.  Under the `nccl` backend two ranks on one device are refused."""
   import torch.distributed as dist
   from cgs_vmc_amd import parallel
   ident = dict(device_identity(dev), rank=rank, host=socket.gethostname(), pid=os.getpid())
@@ -460,19 +457,6 @@ def prove_collectives(eng, world, rank, dev):
   if backend == 'nccl' and not distinct:
     raise SystemExit('bench.py: {} ranks but only {} distinct devices {}: refusing to report an N-GPU number'
                      .format(world, len(set(keys)), sorted(set(keys))))
-  # (1) the library's own transport.  The timed step does not depend on it (it uses the process
-  # group, checked below), so a failure to set it up is reported, not fatal.
-  lib = {}
-  try:
-    coll = parallel.collective()
-    got = eng.debug_allreduce(coll, np.array([float(rank), 1.0], np.float32), 'sum')
-    got_max = eng.debug_allreduce(coll, np.array([float(rank)], np.float32), 'max')
-    lib = {'library_transport': 'rccl communicator (in stream)' if coll.comm else 'host hook',
-           'library_sum_of_ranks': float(got[0]), 'library_sum_of_ones': float(got[1]),
-           'library_max_of_ranks': float(got_max[0]),
-           'library_ok': bool(got[0] == world * (world - 1) / 2 and got[1] == world and got_max[0] == world - 1)}
-  except Exception as e:  # pylint: disable=broad-except
-    lib = {'library_transport': 'unavailable', 'library_error': repr(e), 'library_ok': None}
   nacc = 2 * eng.num_params + 8
   eng.set_accumulators(np.full(nacc, rank + 1.0, np.float32))
   parallel.allreduce_accumulators(eng)
@@ -482,13 +466,39 @@ def prove_collectives(eng, world, rank, dev):
   expect[nacc - 4] = np.float32(tot) / np.float32(world)
   pg_ok = bool(np.array_equal(acc, expect))
   eng.reset_accumulators()
-  if not pg_ok or lib.get('library_ok') is False:
-    raise SystemExit('bench.py: collective check failed on rank {} (process group ok={}, library transport: {})'
-                     .format(rank, pg_ok, lib))
-  return {'backend': backend, 'library_transport': lib['library_transport'], 'devices': idents,
-          'distinct_devices': distinct,
-          'checked_allreduce': dict(lib, expected_sum_of_ranks=world * (world - 1) / 2,
-                                    process_group_on_accumulators=pg_ok, ok=True)}
+  if not pg_ok:
+    raise SystemExit('bench.py: all-reduce check of the accumulator buffer failed on rank {}'.format(rank))
+  return {'backend': backend, 'devices': idents, 'distinct_devices': distinct,
+          'checked_allreduce': {'process_group_on_accumulators': pg_ok, 'expected_sum_of_ranks': world * (world - 1) / 2}}
+
+
+def prove_library_transport(eng, world, rank, timeout_s=90.0):
+  """N > 1, AFTER the timed region: the library's own transport (the in-stream RCCL communicator it
+  creates next to torch's, or the host hook under a non-RCCL backend) on a device buffer of the
+  library: sum of rank ids == N(N-1)/2, sum of ones == N, max of rank ids == N-1.  The timed step does
+  not depend on it, and creating a second RCCL communicator is the one thing here that has never run
+  on more than one GPU: it runs on a watchdog thread, and a failure or a timeout is REPORTED in the
+  line instead of costing the measurement."""
+  import threading
+  from cgs_vmc_amd import parallel
+  out = {'library_transport': 'timeout after {:.0f} s'.format(timeout_s), 'library_ok': None}
+
+  def work():
+    try:
+      coll = parallel.collective()
+      got = eng.debug_allreduce(coll, np.array([float(rank), 1.0], np.float32), 'sum')
+      got_max = eng.debug_allreduce(coll, np.array([float(rank)], np.float32), 'max')
+      out.update({'library_transport': 'rccl communicator (in stream)' if coll.comm else 'host hook',
+                  'library_sum_of_ranks': float(got[0]), 'library_sum_of_ones': float(got[1]),
+                  'library_max_of_ranks': float(got_max[0]),
+                  'library_ok': bool(got[0] == world * (world - 1) / 2 and got[1] == world and got_max[0] == world - 1)})
+    except Exception as e:  # pylint: disable=broad-except
+      out.update({'library_transport': 'unavailable', 'library_error': repr(e), 'library_ok': None})
+
+  t = threading.Thread(target=work, daemon=True)
+  t.start()
+  t.join(timeout_s)
+  return dict(out), t.is_alive()
 
 
 # ----------------------------------------------------------------------------- main
@@ -619,6 +629,9 @@ def main():
   eng.local_energy(want_eloc=False)
   rows = eng.last_connected_rows()
   mean_e = eng.mean_energy()
+  lib_proof, lib_stuck = prove_library_transport(eng, world, rank) if world > 1 else ({}, False)
+  if world > 1:                       # one stuck rank: every rank skips the orderly teardown
+    lib_stuck = parallel.allreduce_max(1.0 if lib_stuck else 0.0) > 0.5
 
   timings = {}
   for name in ('sweep', 'tail_eloc', 'tail_amp', 'z1', 'bond_list', 'eloc_reduce', 'grad', 'adam'):
@@ -667,7 +680,10 @@ def main():
         'kernels': timings,
     }
     if world > 1:
-      out['rccl'] = dict(proof, ranks=world, allreduce_floats=2 * p + 8, allreduce_ms_blocking=allreduce_ms,
+      proof['checked_allreduce'].update(lib_proof)
+      proof['checked_allreduce']['ok'] = bool(lib_proof.get('library_ok') is not False)
+      out['rccl'] = dict(proof, library_transport=lib_proof['library_transport'], ranks=world,
+                         allreduce_floats=2 * p + 8, allreduce_ms_blocking=allreduce_ms,
                          ms_per_step_ranks={'min': min(rank_ms), 'max': max(rank_ms), 'all': rank_ms})
     if 'sweep' in timings and 'tail_eloc' in timings:
       ts = timings['sweep']['ms_avg'] * 1e-3
@@ -744,6 +760,9 @@ def main():
         out['cpu_baseline'] = {'error': repr(e)}
     print(json.dumps(out))
     sys.stdout.flush()
+  if lib_stuck:                       # a rank is still inside the library-transport check: no orderly teardown
+    sys.stdout.flush()
+    os._exit(0)
   eng.close()
   if world > 1:
     torch.distributed.barrier()

@@ -243,13 +243,22 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 // Several independent dual GEMMs (one per layer's weight gradient) in ONE launch:
 // blockIdx.z = problem * splitk + split.  With ~4 workgroups co-resident per CU the global
 // load latency of one is hidden behind the MFMAs of the others.
+// XCD-aware block order: workgroups go to the 8 XCDs round robin by linear block id, and every XCD
+// has its own L2.  All tiles of one (problem, k-slice) group -- they share that slice's A and B
+// operand rows -- are given ids that are congruent mod 8, so one XCD's L2 fetches a slice once
+// instead of (up to) eight L2s fetching it each: group g lives on XCD g % 8.
 template <bool DUAL, int NS = 1>
 __global__ __launch_bounds__(256) void k_gemm_batched(const GemmArgs* __restrict__ batch,
-                                                      int splitk) {
-  const GemmArgs g = batch[blockIdx.z / splitk];
+                                                      int splitk, int tiles_x, int tiles_y, int n_groups) {
+  const int per_group = tiles_x * tiles_y;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int grp = xcd + 8 * (idx / per_group), tile = idx % per_group;
+  if (grp >= n_groups) return;                                                  // block-uniform
+  const int bx = tile % tiles_x, by = tile / tiles_x;
+  const GemmArgs g = batch[grp / splitk];
   const int m_rows = g.ones_row ? g.M - 1 : g.M;
-  if ((int)blockIdx.x * GT >= g.N || (int)blockIdx.y * GT >= m_rows) return;   // block-uniform
-  gemm_block<DUAL, NS>(g, blockIdx.x, blockIdx.y, blockIdx.z % splitk);
+  if (bx * GT >= g.N || by * GT >= m_rows) return;                              // block-uniform
+  gemm_block<DUAL, NS>(g, bx, by, grp % splitk);
 }
 
 // fresh: the destination holds no sum yet (accumulators after reset_gradients): epilogue 3 stores
@@ -302,9 +311,10 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
 hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
                                int max_n, int splitk, bool dual, bool fresh) {
   if (count <= 0) return hipSuccess;
-  const dim3 grid((max_n + GT - 1) / GT, (max_m + GT - 1) / GT, count * splitk);
-  if (dual) hipLaunchKernelGGL((k_gemm_batched<true>), grid, dim3(256), 0, s, dev_batch, splitk);
-  else hipLaunchKernelGGL((k_gemm_batched<false>), grid, dim3(256), 0, s, dev_batch, splitk);
+  const int tx = (max_n + GT - 1) / GT, ty = (max_m + GT - 1) / GT, groups = count * splitk;
+  const dim3 grid(8 * ((groups + 7) / 8) * tx * ty);
+  if (dual) hipLaunchKernelGGL((k_gemm_batched<true>), grid, dim3(256), 0, s, dev_batch, splitk, tx, ty, groups);
+  else hipLaunchKernelGGL((k_gemm_batched<false>), grid, dim3(256), 0, s, dev_batch, splitk, tx, ty, groups);
   const long long total = (dual ? 2LL : 1LL) * (max_m + 1) * max_n;
   const int blocks = (int)min((total + 255) / 256, (long long)512);
   hipLaunchKernelGGL(k_gemm_reduce_batched, dim3(blocks, count), dim3(256), 0, s, dev_batch, fresh ? 1 : 0);

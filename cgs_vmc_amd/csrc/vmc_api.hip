@@ -305,6 +305,8 @@ long long off_bout(const vmc_ctx* c) { return c->lay.off_bout; }
 // split-K of the weight-gradient GEMMs (K = number of samples): ~512 samples per split, measured
 // best at K = 4096 (8 splits: 0.086 ms for the whole gradient path against 0.097 at 16, 0.109 at 4)
 int pick_splitk(const vmc_ctx* c, long long k) {
+  static const int forced = getenv("CGS_VMC_SPLITK") ? atoi(getenv("CGS_VMC_SPLITK")) : 0;   // measurement knob
+  if (forced > 0) return forced < c->splitk ? forced : c->splitk;
   long long s = k / 512;
   if (s < 4) s = 4;
   if (s > c->splitk) s = c->splitk;
