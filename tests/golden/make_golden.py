@@ -6,7 +6,7 @@ oracle's float64 outputs on fixed seeded inputs.  The oracle itse
 by tests/test_oracle_physics.py (closed forms, exact diagonalisation, autograd, finite
 differences) and tests/test_oracle_rng.py (Random123 known answers).
 
-  python tests/golden/make_golden.py        # rewrites vmc_small.npz
+  python tests/golden/make_golden.py        # rewrites every fixture (--wide-only: the round-3 ones)
 """
 import os
 import sys
@@ -77,10 +77,19 @@ RBM_CASES = {
 }
 
 
-def build_rbm_case(name):
-  """Same quantities as build_case for the rbm ansatz (tests/golden/rbm_small.npz)."""
-  n, h, L, b, bonds = RBM_CASES[name]
-  rng = np.random.default_rng({'rbm_torus4x4': 21, 'rbm_classic_chain12': 22}[name])
+# more than 256 hidden units (round 3: the fused 257..512 path; tests/golden/rbm_wide.npz)
+RBM_WIDE_CASES = {
+    'rbm_classic_chain12_h400': (12, 400, 0, 24, vo.chain_bonds(12)),   # alpha = 33: k_sweep16<32> + k_tail0
+    'rbm_chain10_h260_l1': (10, 260, 1, 20, vo.chain_bonds(10)),        # padded to 384: k_tail_lds<24, RBM>
+}
+_RBM_SEEDS = {'rbm_torus4x4': 21, 'rbm_classic_chain12': 22, 'rbm_classic_chain12_h400': 23,
+              'rbm_chain10_h260_l1': 24}
+
+
+def build_rbm_case(name, cases=None):
+  """Same quantities as build_case for the rbm ansatz (tests/golden/rbm_small.npz, rbm_wide.npz)."""
+  n, h, L, b, bonds = (cases or RBM_CASES)[name]
+  rng = np.random.default_rng(_RBM_SEEDS[name])
   theta = vo.rbm_init_params(n, h, L, rng)
   theta = (theta + 0.05 * rng.standard_normal(theta.size)).astype(np.float32)
   cfg = vo.random_configurations(n, b, np.random.RandomState(7))
@@ -97,7 +106,8 @@ def build_rbm_case(name):
              ratio=ratio)
   acc_eg = vo.Accumulators(theta.size, f64)
   vo.energy_gradient_accumulate(acc_eg, theta, cfg, bonds, JX, JZ, -10.0, h, L, f64, ansatz='rbm')
-  out['eg_g1'], out['eg_g2'] = acc_eg.g1_total, acc_eg.g2_total
+  if cases is None:                    # the wide fixtures keep the gradient only (file size)
+    out['eg_g1'], out['eg_g2'] = acc_eg.g1_total, acc_eg.g2_total
   out['eg_grad'] = vo.energy_gradient(acc_eg)
   return out
 
@@ -112,15 +122,25 @@ CONV_CASES = {
 }
 
 
-def build_conv_case(name):
+# more than 16 filters and the cosine (round 3; tests/golden/conv_wide.npz)
+CONV_WIDE_CASES = {
+    'conv2d_4x4_f32': ('conv_2d', (32, 3, 4, 4), 3, 24, vo.torus_bonds(4, 4), 'relu'),
+    'conv2d_6x4_f24_cos': ('conv_2d', (24, 3, 6, 4), 2, 20, vo.torus_bonds(4, 6), 'cos'),
+    'resnet2d_4x4_f32': ('res_net_2d', (32, 3, 4, 4), 1, 24, vo.torus_bonds(4, 4), 'relu'),
+    'conv1d_12_f20_even': ('conv_1d', (20, 4, 12, 1), 2, 18, vo.chain_bonds(12), 'tanh'),
+}
+
+
+def build_conv_case(name, cases=None, seed0=31):
   """Same quantities as build_rbm_case for the convolutional ansatz types
-  (tests/golden/conv_small.npz); `scale` = sum |last feature map|, the fp32 summation scale the
-  logit tolerance is stated on."""
-  ansatz, geom, L, b, bonds, nonlin = CONV_CASES[name]
+  (tests/golden/conv_small.npz, conv_wide.npz); `scale` = sum |last feature map|, the fp32 summation
+  scale the logit tolerance is stated on."""
+  cases = cases or CONV_CASES
+  ansatz, geom, L, b, bonds, nonlin = cases[name]
   n = geom[2] * geom[3]
-  rng = np.random.default_rng(31 + sorted(CONV_CASES).index(name))
+  rng = np.random.default_rng(seed0 + sorted(cases).index(name))
   theta = vo.conv_init_params(ansatz, geom, L, rng)
-  theta = (theta + 0.03 * rng.standard_normal(theta.size)).astype(np.float32)
+  theta = (theta + (0.03 if geom[0] <= 16 else 0.01) * rng.standard_normal(theta.size)).astype(np.float32)
   cfg = vo.random_configurations(n, b, np.random.RandomState(7))
   f64 = np.float64
   amp = lambda c: vo.ANSATZ[ansatz][0](theta, c, geom, L, nonlinearity=nonlin, dtype=f64)
@@ -141,7 +161,21 @@ def build_conv_case(name):
   return out
 
 
+def _write(fname, cases, builder):
+  data = {}
+  for name in cases:
+    for k, v in builder(name).items():
+      data['{}/{}'.format(name, k)] = v
+  path = os.path.join(HERE, fname)
+  np.savez_compressed(path, **data)
+  print('wrote', path, os.path.getsize(path), 'bytes')
+
+
 def main():
+  _write('conv_wide.npz', CONV_WIDE_CASES, lambda n: build_conv_case(n, CONV_WIDE_CASES, 51))
+  _write('rbm_wide.npz', RBM_WIDE_CASES, lambda n: build_rbm_case(n, RBM_WIDE_CASES))
+  if '--wide-only' in sys.argv:
+    return
   conv = {}
   for name in CONV_CASES:
     for k, v in build_conv_case(name).items():

@@ -93,10 +93,11 @@ def test_gradient_accumulators_and_adam(name):
   eng.close()
 
 
-@pytest.mark.parametrize('name', ['rbm_torus4x4', 'rbm_classic_chain12'])
+@pytest.mark.parametrize('name', ['rbm_torus4x4', 'rbm_classic_chain12', 'rbm_classic_chain12_h400',
+                                  'rbm_chain10_h260_l1'])
 def test_rbm_golden(name):
   from cgs_vmc_amd.engine import VmcEngine
-  gold = np.load(os.path.join(HERE, 'golden', 'rbm_small.npz'))
+  gold = np.load(os.path.join(HERE, 'golden', 'rbm_wide.npz' if '_h' in name else 'rbm_small.npz'))
   g = {k.split('/', 1)[1]: gold[k] for k in gold.files if k.startswith(name + '/')}
   n, h, L, b = [int(x) for x in g['shape']]
   eng = VmcEngine(n, b, L, h, seed=int(g['seed'][0]), ansatz='rbm')
@@ -121,16 +122,21 @@ def test_rbm_golden(name):
   eng.close()
 
 
-@pytest.mark.parametrize('name', ['conv2d_4x4', 'conv2d_6x4_even', 'resnet2d_4x4', 'conv1d_12_even', 'resnet1d_12'])
+_CONV_WIDE = {'conv2d_4x4_f32': 'relu', 'conv2d_6x4_f24_cos': 'cos', 'resnet2d_4x4_f32': 'relu',
+              'conv1d_12_f20_even': 'tanh'}
+
+
+@pytest.mark.parametrize('name', ['conv2d_4x4', 'conv2d_6x4_even', 'resnet2d_4x4', 'conv1d_12_even', 'resnet1d_12']
+                         + sorted(_CONV_WIDE))
 def test_conv_golden(name):
-  """Convolutional ansatz types against tests/golden/conv_small.npz (tolerances of
+  """Convolutional ansatz types against tests/golden/conv_small.npz / conv_wide.npz (tolerances of
   tests/test_gpu_conv.py: logits on the fp32 summation scale)."""
   from cgs_vmc_amd.engine import VmcEngine
-  gold = np.load(os.path.join(HERE, 'golden', 'conv_small.npz'))
+  gold = np.load(os.path.join(HERE, 'golden', 'conv_wide.npz' if name in _CONV_WIDE else 'conv_small.npz'))
   g = {k.split('/', 1)[1]: gold[k] for k in gold.files if k.startswith(name + '/')}
   f, k, sx, sy, L, b = [int(x) for x in g['shape']]
   ansatz = {'conv2d': 'conv_2d', 'resnet2d': 'res_net_2d', 'conv1d': 'conv_1d', 'resnet1d': 'res_net_1d'}[name.split('_')[0]]
-  nonlin = 'tanh' if name == 'conv2d_6x4_even' else 'relu'
+  nonlin = _CONV_WIDE.get(name, 'tanh' if name == 'conv2d_6x4_even' else 'relu')
   eng = VmcEngine(sx * sy, b, L, f, nonlinearity=nonlin, seed=int(g['seed'][0]), ansatz=ansatz, kernel_size=k,
                   size_x=sx, size_y=sy)
   eng.set_params(g['theta']); eng.set_configs(g['configs'])
