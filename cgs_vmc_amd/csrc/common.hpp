@@ -307,8 +307,8 @@ hipError_t launch_sr_rowdot(hipStream_t s, const float* A, long long lda, const 
                             int M, int N, int K, bool first);
 int sr_wsum_slices(int R, int num_cus);
 hipError_t launch_sr_wsum(hipStream_t s, const float* A, long long lda, const float* D,
-                          long long ldd, const float* t, float* ws, float* out, int M, int N, int R,
-                          int slices);
+                          long long ldd, const float* t, float* ws, float* out, long long ldo,
+                          float* bias_out, int M, int N, int R, int slices);
 hipError_t launch_sr_row_linear(hipStream_t s, const float* x, long long ldx, const float* v,
                                 const float* vb, int R, int K, float* t);
 hipError_t launch_sr_colsum(hipStream_t s, const float* x, long long ldx, const float* t, int R,

@@ -37,7 +37,8 @@ struct SrWsumArgs {
   const float* D; long long ldd;      // delta(k, n)
   const float* t;                     // [R] row scale of delta
   float* ws;                          // [slices][(M + 1) * N]
-  float* out;                         // [(M + 1) * N]: W rows then the bias row (theta layout)
+  float* out; long long ldo;          // out(m, n) = out[m * ldo + n]: a block of the W rows (theta layout)
+  float* bias_out;                    // [N] bias row of these columns, or nullptr (row blocks m0 > 0)
   int M, N, R, slices;
 };
 
@@ -321,7 +322,10 @@ __global__ __launch_bounds__(256) void k_sr_wsum_reduce(SrWsumArgs g) {
       for (int e = 0; e < 8; ++e) v[e] += g.ws[(long long)(s + e) * mn + i];
     }
     for (; s < g.slices; ++s) v[0] += g.ws[(long long)s * mn + i];
-    g.out[i] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    const float sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    const long long m = i / g.N, n = i % g.N;
+    if (m < g.M) g.out[m * g.ldo + n] = sum;
+    else if (g.bias_out) g.bias_out[n] = sum;
   }
 }
 
@@ -423,11 +427,12 @@ int sr_wsum_slices(int R, int num_cus) {
   return s < 1 ? 1 : s;
 }
 
+// one (<= 256 x <= 256) block of u_W = A^T (t (.) D); wider layers are tiled by the caller
 hipError_t launch_sr_wsum(hipStream_t s, const float* A, long long lda, const float* D,
-                          long long ldd, const float* t, float* ws, float* out, int M, int N, int R,
-                          int slices) {
+                          long long ldd, const float* t, float* ws, float* out, long long ldo,
+                          float* bias_out, int M, int N, int R, int slices) {
   if (M > WS_T || N > WS_T) return hipErrorInvalidValue;
-  SrWsumArgs g{A, lda, D, ldd, t, ws, out, M, N, R, slices};
+  SrWsumArgs g{A, lda, D, ldd, t, ws, out, ldo, bias_out, M, N, R, slices};
   const bool vec = (lda & 3) == 0 && (ldd & 3) == 0 && (M & 3) == 0 && (N & 3) == 0 && M >= 4 && N >= 4 &&
                    (((size_t)A | (size_t)D) & 15) == 0;
   if (vec) hipLaunchKernelGGL(k_sr_wsum<true>, dim3(slices), dim3(512), 0, s, g);

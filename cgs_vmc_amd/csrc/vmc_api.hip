@@ -1701,8 +1701,8 @@ int vmc_epoch_log_overlap_dist(vmc_ctx* c, void* nccl_comm, int32_t world_size, 
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   ENTER(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
-  if (n_batches > 0 && (c->conv || c->wide))
-    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the fully_connected (<= 256 units) and rbm ansatz types");
+  if (n_batches > 0 && (c->conv || (c->wide && !c->wide_fast)))
+    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the fully_connected and rbm ansatz types up to 512 hidden units");
   if (n_batches > 0 && (c->oact != VMC_ACT_EXP_ || c->hact == VMC_ACT_COS_))
     return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation and every hidden activation except cos");
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1763,24 +1763,35 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
   const float* v = c->sr_p;
   Timer t(c, "sr_matvec");
   HIPCHK(c, hipMemsetAsync(c->sr_u, 0, (c->P + 1) * sizeof(float), c->stream));
-  // t_b = O_b . p = sum_l delta_l[b] . (a_{l-1}[b] V_l + v_l) + (output / onsite layer term)
+  // t_b = O_b . p = sum_l delta_l[b] . (a_{l-1}[b] V_l + v_l) + (output / onsite layer term);
+  // the row-dot kernel takes <= 256 output units at a time (257 .. 512 units: two column blocks)
   for (int l = 0; l < L; ++l) {
     const float* a_in = l == 0 ? c->sr_cfg : c->sr_act + (long long)(l - 1) * R * Hp;
-    HIPCHK(c, launch_sr_rowdot(c->stream, a_in, l == 0 ? N : Hp, v + off_w(c, l), H, v + off_b(c, l),
-                               c->sr_delta + (long long)l * R * Hp, Hp, c->sr_t, rows, H, l == 0 ? N : H,
-                               l == 0));
+    for (int n0 = 0; n0 < H; n0 += 256) {
+      const int nb = H - n0 < 256 ? H - n0 : 256;
+      HIPCHK(c, launch_sr_rowdot(c->stream, a_in, l == 0 ? N : Hp, v + off_w(c, l) + n0, H, v + off_b(c, l) + n0,
+                                 c->sr_delta + (long long)l * R * Hp + n0, Hp, c->sr_t, rows, nb, l == 0 ? N : H,
+                                 l == 0 && n0 == 0));
+    }
   }
   if (c->rbm)
     HIPCHK(c, launch_sr_row_linear(c->stream, c->sr_cfg, N, v + c->lay.off_won, v + off_bout(c), rows, N, c->sr_t));
   else
     HIPCHK(c, launch_sr_row_linear(c->stream, c->sr_act + (long long)(L - 1) * R * Hp, Hp, v + off_wout(c),
                                    v + off_bout(c), rows, H, c->sr_t));
-  // u = sum_b t_b O_b: per layer [a_{l-1} | 1]^T (t (.) delta_l), written in the theta layout
+  // u = sum_b t_b O_b: per layer [a_{l-1} | 1]^T (t (.) delta_l), written in the theta layout, in
+  // (<= 256 input rows) x (<= 256 output units) blocks; the bias row comes with the first row block
   const int slices = sr_wsum_slices(rows, c->num_cus);
   for (int l = 0; l < L; ++l) {
     const float* a_in = l == 0 ? c->sr_cfg : c->sr_act + (long long)(l - 1) * R * Hp;
-    HIPCHK(c, launch_sr_wsum(c->stream, a_in, l == 0 ? N : Hp, c->sr_delta + (long long)l * R * Hp, Hp, c->sr_t,
-                             c->sr_ws, c->sr_u + off_w(c, l), l == 0 ? N : H, H, rows, slices));
+    const int M = l == 0 ? N : H;
+    for (int m0 = 0; m0 < M; m0 += 256)
+      for (int n0 = 0; n0 < H; n0 += 256) {
+        const int mb = M - m0 < 256 ? M - m0 : 256, nb = H - n0 < 256 ? H - n0 : 256;
+        HIPCHK(c, launch_sr_wsum(c->stream, a_in + m0, l == 0 ? N : Hp, c->sr_delta + (long long)l * R * Hp + n0, Hp,
+                                 c->sr_t, c->sr_ws, c->sr_u + off_w(c, l) + (long long)m0 * H + n0, H,
+                                 m0 == 0 ? c->sr_u + off_b(c, l) + n0 : nullptr, mb, nb, rows, slices));
+      }
   }
   // the N = 1 layer (w_out, b_out of fully_connected; w_on, b_on of rbm: weights then bias in
   // theta) and sum_b t_b in one column-sum pass

@@ -214,3 +214,52 @@ def test_sr_rbm_matvec_and_solution(n, h, L, b, kind, n_store):
   x = eng.sr_get_solution()
   assert res <= 1e-4 and np.abs(x - x_ref).max() <= 2e-3 * np.abs(x_ref).max(), (iters, res)
   eng.close()
+
+
+@pytest.mark.parametrize('ansatz,n,h,L,b,n_store', [('fully_connected', 8, 272, 2, 24, 2),    # padded to 384 units
+                                                    ('fully_connected', 10, 500, 3, 20, 2),   # padded to 512, two H x H layers
+                                                    ('rbm', 8, 300, 1, 24, 2)])
+def test_sr_beyond_256_units_matvec_and_solution(ansatz, n, h, L, b, n_store):
+  """SR on the fused 257 .. 512-unit path (round 3): the row-dot / weighted-sum kernels take the layer
+  in <= 256-unit blocks.  P is ~1e5 here, so the reference is the matrix-free fp64 operator
+  S v = O^T (O v) / n - <O> mean(O v) on the explicit per-sample gradients, and the CG solution is
+  checked through its residual (and against the fp64 run of the same recurrence)."""
+  from cgs_vmc_amd.engine import VmcEngine
+  rbm = ansatz == 'rbm'
+  rng = np.random.default_rng(6)
+  theta = (vo.rbm_init_params if rbm else vo.init_params)(n, h, L, rng)
+  theta += (0.03 * rng.standard_normal(theta.size)).astype(np.float32)
+  bonds = vo.chain_bonds(n)
+  eng = VmcEngine(n, b, L, h, seed=2024, ansatz=ansatz)
+  assert eng.kernel_path() == 1
+  eng.set_params(theta)
+  eng.set_bonds(bonds, -1.0, 1.0)
+  eng.sr_reserve(n_store)
+  eng.reset_accumulators()
+  cfgs, elocs = [], []
+  for k in range(n_store):
+    cfg = vo.random_configurations(n, b, np.random.RandomState(40 + k))
+    eng.set_configs(cfg)
+    if k == 1:
+      eng.mc_steps(2)                    # activations handed over by the sampler for this batch
+      cfg = eng.get_configs()
+    eng.accumulate(0)
+    cfgs.append(cfg)
+    elocs.append(eng.local_energy()[0])
+  o = (vo.rbm_per_sample_logit_grads if rbm else vo.per_sample_logit_grads)(theta, np.concatenate(cfgs, 0), h, L)
+  e = np.concatenate(elocs, 0).astype(np.float64)
+  nsmp, o_mean = o.shape[0], o.mean(0)
+  f = o.T @ e / nsmp - e.mean() * o_mean
+  lam = 0.01
+  op = lambda v: o.T @ (o @ v) / nsmp - o_mean * (o_mean @ v) + lam * v
+  v = rng.standard_normal(theta.size).astype(np.float32)
+  ref = op(v.astype(np.float64))
+  got = eng.sr_debug_matvec(v, lam)
+  assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()
+  iters, res = eng.sr_solve(lam, 1e-5, 3000)
+  x = eng.sr_get_solution().astype(np.float64)
+  assert res <= 1e-4, (iters, res)
+  assert np.linalg.norm(op(x) - f) <= 5e-4 * np.linalg.norm(f)
+  x64, it64 = vo.sr_conjugate_gradient(o, e, lam, 1e-5, 3000)
+  assert np.abs(x - x64).max() <= 5e-3 * np.abs(x64).max() and iters <= 2 * it64 + 10
+  eng.close()

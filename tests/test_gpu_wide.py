@@ -144,7 +144,7 @@ def test_wide_limits():
   with pytest.raises(NotImplementedError):
     VmcEngine(16, 8, 2, 4100, ansatz='rbm')
   for ansatz in ('fully_connected', 'rbm'):
-    eng = VmcEngine(16, 8, 2, 320, ansatz=ansatz)
+    eng = VmcEngine(16, 8, 2, 640, ansatz=ansatz)     # beyond 512 units: general path, no SR
     with pytest.raises(NotImplementedError):
       eng.sr_reserve(2)
     eng.close()
