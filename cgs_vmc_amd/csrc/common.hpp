@@ -300,6 +300,7 @@ hipError_t launch_sr_q(hipStream_t s, const float* u, const float* acc, int P, c
                        float lambda, float* q, double* partial, double* sc);
 hipError_t launch_sr_step(hipStream_t s, double* sc, int cur, int P, float* p, const float* q,
                           float* x, float* r, double* partial);
+hipError_t launch_sr_tsum(hipStream_t s, const float* t, int n, float* out);
 hipError_t launch_sr_apply(hipStream_t s, float* theta, const float* x, float lr, int P);
 // large-tile GEMMs of the SR matrix-vector product (srmm.hip)
 hipError_t launch_sr_rowdot(hipStream_t s, const float* A, long long lda, const float* V,

@@ -8,6 +8,7 @@ hipError_t conv_launch_rows_cb2(hipStream_t s, const ConvRowsArgs& a, dim3 grid,
 hipError_t conv_launch_sweep_cb2(hipStream_t s, const ConvSweepArgs& a, dim3 grid, size_t lds);
 hipError_t conv_launch_back_cb2(hipStream_t s, const ConvBackArgs& a, dim3 grid, size_t lds);
 hipError_t conv_launch_dw_cb2(hipStream_t s, const ConvDwArgs& a, dim3 grid, size_t lds);
+hipError_t conv_launch_sr_rowdot_cb2(hipStream_t s, const ConvSrRowdotArgs& a, dim3 grid, size_t lds);
 
 namespace {
 
@@ -154,4 +155,14 @@ hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a) {
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_conv_dw_reduce, dim3(32), dim3(256), 0, s, a, a.g.K * a.g.KW);
   return hipGetLastError();
+}
+
+hipError_t launch_conv_sr_rowdot(hipStream_t s, const ConvSrRowdotArgs& a, int num_cus) {
+  if (a.n_rows <= 0) return hipSuccess;
+  const int groups = (a.n_rows + a.G - 1) / a.G;
+  const size_t lds = conv_rows_lds(a.g, a.G);
+  const int slots = num_cus * (lds <= CONV_LDS_PER_WG ? 2 : 1);
+  const dim3 grid(groups < slots ? groups : slots);
+  if (a.g.NCB == 2) return conv_launch_sr_rowdot_cb2(s, a, grid, lds);
+  return conv_launch_sr_rowdot_t<1>(s, a, grid, lds);
 }

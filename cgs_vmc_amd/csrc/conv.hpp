@@ -109,6 +109,17 @@ struct ConvDwArgs {
   float* g1; float* g2;     // accumulators (theta layout), += on reduce
 };
 
+// stochastic reconfiguration (extension): t[row] = O_row . p over the stored samples
+struct ConvSrRowdotArgs {
+  ConvGeom g;
+  ConvParams p;             // the CG direction p packed like a parameter set (launch_conv_pack)
+  const float* configs;     // [n_rows][N] stored chains
+  const float* tape;  long long tape_stride;     // [n_conv-1][R][CS]
+  const float* delta; long long delta_stride;    // [n_conv][R][CS]
+  float* t;                 // [n_rows]
+  int n_rows, G;
+};
+
 size_t conv_rows_lds(const ConvGeom& g, int G);
 size_t conv_lds_cap(const ConvGeom& g);   // LDS budget of one workgroup (two per CU when a sample fits)
 int conv_waves();                         // waves per workgroup of the conv kernels
@@ -120,3 +131,4 @@ hipError_t launch_conv_rows(hipStream_t s, const ConvRowsArgs& a, int num_cus);
 hipError_t launch_conv_sweep(hipStream_t s, const ConvSweepArgs& a);
 hipError_t launch_conv_back(hipStream_t s, const ConvBackArgs& a, int num_cus);
 hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a);
+hipError_t launch_conv_sr_rowdot(hipStream_t s, const ConvSrRowdotArgs& a, int num_cus);

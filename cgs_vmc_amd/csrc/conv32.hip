@@ -14,3 +14,6 @@ hipError_t conv_launch_back_cb2(hipStream_t s, const ConvBackArgs& a, dim3 grid,
 hipError_t conv_launch_dw_cb2(hipStream_t s, const ConvDwArgs& a, dim3 grid, size_t lds) {
   return conv_launch_dw_t<2>(s, a, grid, lds);
 }
+hipError_t conv_launch_sr_rowdot_cb2(hipStream_t s, const ConvSrRowdotArgs& a, dim3 grid, size_t lds) {
+  return conv_launch_sr_rowdot_t<2>(s, a, grid, lds);
+}

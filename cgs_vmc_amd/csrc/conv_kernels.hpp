@@ -64,7 +64,8 @@ enum { EP_LINEAR = 0,     // out = acc + bias
        EP_RESADD = 3,     // out = out + acc + bias              (ResBlock2d shortcut, layers.py:228)
        EP_BACK_DACT = 4,  // out = acc * f'(tape)                (back-propagation, conv_2d)
        EP_BACK_SELU = 5,  // out = acc * selu'(tape)
-       EP_BACK_ADD = 6 }; // out = out + acc
+       EP_BACK_ADD = 6,   // out = out + acc
+       EP_DOT = 7 };      // out = out + (acc + bias) * delta(tape_in)   (SR: O_b . p, summed per sample later)
 
 // per-position descriptor: sample slot, lattice coordinates (built once per kernel, LDS)
 __device__ __forceinline__ unsigned pack_pos(int s, int a1, int a2) {
@@ -183,9 +184,18 @@ __device__ __forceinline__ void conv_first(const ConvSmem& sm, float* out, const
 #pragma unroll
       for (int qq = 0; qq < Q0; ++qq) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[cb][qq], bx[qq], acc, 0, 0, 0);
       f32x4 taped;
+      float* dst = out + (size_t)s * g.CS + (4 * cb + gl) * g.GS + 4 * site;
+      if (ep == EP_DOT) {      // tape_out is delta_0 here: out += (conv + bias) * delta
+        if (valid) {
+          const f32x4 d = row >= 0 ? *(const f32x4*)(tape_out + ((long long)row * 4 * NCB + 4 * cb + gl) * g.GS + 4 * site)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+          *(f32x4*)dst = *(const f32x4*)dst + acc * d;
+        }
+        continue;
+      }
       conv_act_epilogue(ep, g.hact, acc, taped);
       if (valid) {
-        *(f32x4*)(out + (size_t)s * g.CS + (4 * cb + gl) * g.GS + 4 * site) = acc;
+        *(f32x4*)dst = acc;
         if (tape_out && row >= 0)
           *(f32x4*)(tape_out + ((long long)row * 4 * NCB + 4 * cb + gl) * g.GS + 4 * site) = taped;
       }
@@ -213,6 +223,10 @@ __device__ __forceinline__ void conv_store_tile(const ConvSmem& sm, const ConvGe
     for (int r = 0; r < 4; ++r)
       v[r] *= ep == EP_BACK_SELU ? selu_deriv_from_t(a[r]) : dact_from_tape_rt(g.hact, a[r]);
     taped = v;
+  } else if (ep == EP_DOT) {
+    const f32x4 d = row >= 0 ? *(const f32x4*)(tape_in + trow) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 old = *(const f32x4*)dst;
+    v = old + v * d;
   }
   if (valid) {
     *(f32x4*)dst = v;
@@ -641,6 +655,72 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_back(ConvBackArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------- SR row dot
+// Stochastic reconfiguration (extension): t_b = O_b . p = sum_l <delta_l[b], conv(in_l[b], V_l) + v_l>
+// over the stored samples, with (V_l, v_l) the slice of the CG direction p for convolution l (packed
+// like a parameter set) and in_l / delta_l the taped inputs and back-propagated d logit / d (output)
+// of the gradient path.  Per layer the taped input is staged in LDS, the convolution runs with the
+// EP_DOT epilogue (accumulate (conv + bias) * delta per element) and the per-sample sum is the same
+// fixed-order reduction as the forward's.  Persistent over groups of G stored samples.
+template <int K, int KW, int NCB>
+__global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_sr_rowdot(ConvSrRowdotArgs a) {
+  constexpr size_t WL = (size_t)NCB * NCB * K * KW * 256;
+  constexpr int BL = 16 * NCB;
+  extern __shared__ float s_conv[];
+  const ConvGeom& g = a.g;
+  const int G = a.G;
+  const ConvSmem sm = conv_carve(s_conv, g, G);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xs_stride = conv_xs_stride(g);
+  const bool tape_is_z = !g.resnet && g.hact == VMC_ACT_COS_;
+  conv_build_pinfo(sm, g, G);
+  for (int grp = blockIdx.x; grp * G < a.n_rows; grp += gridDim.x) {
+    for (int s = wave; s < G; s += CONV_WAVES) {
+      const int row = grp * G + s;
+      const bool valid = row < a.n_rows;
+      const float* x = a.configs + (long long)(valid ? row : a.n_rows - 1) * g.N;
+      for (int i = lane; i < g.N; i += 64) sm.xs[s * xs_stride + i] = x[i];
+      if (lane == 0) sm.row_chain[s] = valid ? row : -1;
+    }
+    for (int i = threadIdx.x; i < G * g.CS; i += blockDim.x) sm.buf1[i] = 0.f;     // the accumulation buffer
+    __syncthreads();
+    conv_first<K, KW, NCB>(sm, sm.buf1, g, a.p, G, EP_DOT, wave, lane, const_cast<float*>(a.delta), 0);
+    __syncthreads();
+    for (int l = 1; l < g.n_conv; ++l) {
+      // stage the taped input of convolution l (slot l - 1): [row][CS] -> buf0[s][CS]
+      const float* tp = a.tape + (long long)(l - 1) * a.tape_stride;
+      for (int s = 0; s < G; ++s) {
+        const int row = sm.row_chain[s];
+        const float* src = tp + (long long)(row >= 0 ? row : 0) * g.CS;
+        for (int i = 4 * threadIdx.x; i < g.CS; i += 4 * blockDim.x) {
+          f32x4 v = *(const f32x4*)(src + i);
+          if (tape_is_z) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = vmc_act_rt(VMC_ACT_COS_, v[r]);
+          }
+          *(f32x4*)(sm.buf0 + (size_t)s * g.CS + i) = v;
+        }
+      }
+      __syncthreads();
+      conv_layer<K, KW, NCB>(sm, sm.buf0, sm.buf1, g, a.p.wf + (size_t)(l - 1) * WL, a.p.bias + BL * l, 0, G,
+                             EP_DOT, wave, lane, a.delta + (long long)l * a.delta_stride, nullptr);
+      __syncthreads();
+    }
+    for (int s = wave; s < G; s += CONV_WAVES) {
+      const float* m = sm.buf1 + (size_t)s * g.CS;
+      float part = 0.f;
+      for (int gq = 0; gq < 4 * NCB; ++gq)
+        for (int i = lane; i < 4 * g.N; i += 64) part += m[gq * g.GS + i];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+      const int row = sm.row_chain[s];
+      if (lane == 0 && row >= 0) a.t[row] = part;
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------- weight gradient
 // sum_b (1 | w_b) * d logit_b / d W_l for every convolution: dW[tap][cin][cout] =
 // sum_{b, pos} in_l[b, pos + tap, cin] * delta_l[b, pos, cout]  (and the bias: sum of delta_l).
@@ -841,6 +921,11 @@ hipError_t conv_launch_sweep_t(hipStream_t s, const ConvSweepArgs& a, dim3 grid,
 template <int NCB>
 hipError_t conv_launch_back_t(hipStream_t s, const ConvBackArgs& a, dim3 grid, size_t lds) {
   CONV_DISPATCH_K(a.g, return launch_k(k_conv_back<KK_, KW_, NCB>, grid, lds, s, a));
+  return hipSuccess;
+}
+template <int NCB>
+hipError_t conv_launch_sr_rowdot_t(hipStream_t s, const ConvSrRowdotArgs& a, dim3 grid, size_t lds) {
+  CONV_DISPATCH_K(a.g, return launch_k(k_conv_sr_rowdot<KK_, KW_, NCB>, grid, lds, s, a));
   return hipSuccess;
 }
 template <int NCB>

@@ -208,6 +208,25 @@ hipError_t launch_sr_step(hipStream_t s, double* sc, int cur, int P, float* p, c
   return hipGetLastError();
 }
 
+// out[0] = sum_b t[b] (single block, fixed order, double partials): u[P] of the convolutional matvec
+__global__ __launch_bounds__(1024) void k_sr_tsum(const float* __restrict__ t, int n, float* __restrict__ out) {
+  __shared__ double s[1024];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) a += (double)t[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int d = 512; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)s[0];
+}
+
+hipError_t launch_sr_tsum(hipStream_t s, const float* t, int n, float* out) {
+  hipLaunchKernelGGL(k_sr_tsum, dim3(1), dim3(1024), 0, s, t, n, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_sr_apply(hipStream_t s, float* theta, const float* x, float lr, int P) {
   hipLaunchKernelGGL(k_sr_apply, dim3(SR_GRID(P)), dim3(256), 0, s, theta, x, lr, P);
   return hipGetLastError();

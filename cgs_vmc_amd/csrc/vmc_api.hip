@@ -128,6 +128,11 @@ struct vmc_ctx {
   // stochastic reconfiguration (extension, sr.hip): sample store + CG vectors
   int sr_cap = 0, sr_n = 0, sr_iter = 0;
   float *sr_cfg = nullptr, *sr_act = nullptr, *sr_delta = nullptr;   // [cap B][N], [L][cap B][Hp] x2
+  // convolutional ansatz types: stored tapes / deltas [n_conv-1 | n_conv][cap B][CS], the CG direction
+  // packed like a parameter set, and the slices of the weight-gradient kernel over the stored samples
+  float *sr_ctape = nullptr, *sr_cdelta = nullptr, *sr_cws = nullptr;
+  float *sr_cw0 = nullptr, *sr_cwf = nullptr, *sr_cwb = nullptr, *sr_cbias = nullptr;
+  int sr_cslices = 0;
   float *sr_ws = nullptr, *sr_t = nullptr, *sr_ones = nullptr;        // [slices][(max(N,H)+1) H], [cap B] x2
   float *sr_u = nullptr, *sr_x = nullptr, *sr_r = nullptr, *sr_p = nullptr, *sr_q = nullptr;
   double *sr_partial = nullptr, *sr_sc = nullptr;
@@ -883,6 +888,7 @@ void vmc_destroy(vmc_ctx* c) {
                   c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->tmp_on, c->tmp_rowinfo, c->rowinfo_id, c->bond_dummy, c->inj_up, c->inj_dn, c->inj_u,
                   c->acc_mask};
   for (void* q : ptrs) if (q) hipFree(q);
+  for (float* q : {c->sr_ctape, c->sr_cdelta, c->sr_cws, c->sr_cw0, c->sr_cwf, c->sr_cwb, c->sr_cbias}) if (q) hipFree(q);
   void* sr[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_u, c->sr_x, c->sr_r,
                 c->sr_p, c->sr_q, c->sr_partial, c->sr_sc, c->sr_ones};
   for (void* q : sr) if (q) hipFree(q);
@@ -1388,6 +1394,16 @@ static int sr_record(vmc_ctx* c) {
     return fail(c, VMC_ERR_STATE, "SR sample store full: vmc_sr_reserve fewer batches than accumulate calls");
   const long long B = c->B, N = c->N, Hp = c->Hp, L = c->A, k = c->sr_n, R = (long long)c->sr_cap * B;
   HIPCHK(c, hipMemcpyAsync(c->sr_cfg + k * B * N, c->configs, B * N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  if (c->conv) {   // the taped inputs of every convolution and d logit / d (their outputs) of this batch
+    const long long CS = c->cg.CS, nc = c->cg.n_conv;
+    if (nc > 1)
+      HIPCHK(c, hipMemcpy2DAsync(c->sr_ctape + k * B * CS, R * CS * sizeof(float), c->ctape, c->ctape_stride * sizeof(float),
+                                 B * CS * sizeof(float), nc - 1, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(c->sr_cdelta + k * B * CS, R * CS * sizeof(float), c->cdelta, c->cdelta_stride * sizeof(float),
+                               B * CS * sizeof(float), nc, hipMemcpyDeviceToDevice, c->stream));
+    c->sr_n += 1;
+    return VMC_OK;
+  }
   // layer-major store [L][cap * B][Hp]: every layer's rows of ALL stored batches are contiguous,
   // so the CG matrix-vector product runs each GEMM once over all samples
   HIPCHK(c, hipMemcpy2DAsync(c->sr_act + k * B * Hp, R * Hp * sizeof(float), c->act_all, B * Hp * sizeof(float),
@@ -1701,17 +1717,40 @@ int vmc_epoch_log_overlap_dist(vmc_ctx* c, void* nccl_comm, int32_t world_size, 
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   ENTER(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
-  if (n_batches > 0 && (c->conv || (c->wide && !c->wide_fast)))
-    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the fully_connected and rbm ansatz types up to 512 hidden units");
-  if (n_batches > 0 && (c->oact != VMC_ACT_EXP_ || c->hact == VMC_ACT_COS_))
+  if (n_batches > 0 && c->wide && !c->wide_fast)
+    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the dense ansatz types up to 512 hidden units and the convolutional ones");
+  if (n_batches > 0 && (c->oact != VMC_ACT_EXP_ || (c->hact == VMC_ACT_COS_ && !c->conv)))
     return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation and every hidden activation except cos");
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_ones};
+  void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_ones, c->sr_ctape, c->sr_cdelta, c->sr_cws};
   for (void* q : old) if (q) hipFree(q);
   c->sr_cfg = c->sr_act = c->sr_delta = c->sr_ws = c->sr_t = c->sr_ones = nullptr;
+  c->sr_ctape = c->sr_cdelta = c->sr_cws = nullptr;
   c->sr_cap = 0; c->sr_n = 0; c->sr_begun = false;
   if (n_batches == 0) return VMC_OK;
   const long long B = c->B, N = c->N, Hp = c->Hp, L = c->A, P = c->P, R = (long long)n_batches * B;
+  if (c->conv) {
+    const ConvGeom& cg = c->cg;
+    const long long CS = cg.CS, nc = cg.n_conv, KK = (long long)cg.K * cg.KW, nb = cg.NCB, nl = nc > 1 ? nc - 1 : 1;
+    if (R * CS >= (1LL << 31)) return fail(c, VMC_ERR_UNSUPPORTED, "SR sample store too large (rows * feature-map size >= 2^31)");
+    HIPCHK(c, dalloc(&c->sr_cfg, R * N));
+    HIPCHK(c, dalloc(&c->sr_ctape, nl * R * CS)); HIPCHK(c, dalloc(&c->sr_cdelta, nc * R * CS));
+    HIPCHK(c, dalloc(&c->sr_t, R));
+    c->sr_cslices = R < 256 ? (int)R : 256;
+    HIPCHK(c, dalloc(&c->sr_cws, (long long)c->sr_cslices * nc * 2 * (KK * 16 * nb + 1) * 16 * nb));
+    if (!c->sr_cw0) {
+      HIPCHK(c, dalloc(&c->sr_cw0, nb * ((KK + 3) / 4) * 64)); HIPCHK(c, dalloc(&c->sr_cwf, nl * nb * nb * KK * 256));
+      HIPCHK(c, dalloc(&c->sr_cwb, nl * nb * nb * KK * 256)); HIPCHK(c, dalloc(&c->sr_cbias, nc * 16 * nb));
+    }
+    if (!c->sr_u) {
+      HIPCHK(c, dalloc(&c->sr_u, P + 1)); HIPCHK(c, dalloc(&c->sr_x, P)); HIPCHK(c, dalloc(&c->sr_r, P));
+      HIPCHK(c, dalloc(&c->sr_p, P)); HIPCHK(c, dalloc(&c->sr_q, P));
+      HIPCHK(c, dalloc(&c->sr_partial, 256)); HIPCHK(c, dalloc(&c->sr_sc, 4));
+      HIPCHK(c, hipMemsetAsync(c->sr_x, 0, P * sizeof(float), c->stream));
+    }
+    c->sr_cap = n_batches;
+    return VMC_OK;
+  }
   if (R > 0x7fffffffLL / Hp) return fail(c, VMC_ERR_UNSUPPORTED, "SR sample store too large (rows * Hp >= 2^31)");
   HIPCHK(c, dalloc(&c->sr_cfg, R * N));
   HIPCHK(c, dalloc(&c->sr_act, L * R * Hp));
@@ -1763,6 +1802,27 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
   const float* v = c->sr_p;
   Timer t(c, "sr_matvec");
   HIPCHK(c, hipMemsetAsync(c->sr_u, 0, (c->P + 1) * sizeof(float), c->stream));
+  if (c->conv) {
+    // t_b = O_b . p: the CG direction packed like a parameter set, convolved with the taped inputs and
+    // dotted with the stored deltas (k_conv_sr_rowdot); u = sum_b t_b O_b: the weight-gradient kernel
+    // over the stored samples with per-sample weight t_b (its unweighted sum goes to scratch)
+    const long long Rc = (long long)c->sr_cap * B;
+    HIPCHK(c, launch_conv_pack(c->stream, v, c->cg, c->sr_cw0, c->sr_cwf, c->sr_cwb, c->sr_cbias));
+    ConvSrRowdotArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.g = c->cg; ra.p = ConvParams{c->sr_cw0, c->sr_cwf, c->sr_cwb, c->sr_cbias};
+    ra.configs = c->sr_cfg; ra.tape = c->sr_ctape; ra.tape_stride = Rc * c->cg.CS;
+    ra.delta = c->sr_cdelta; ra.delta_stride = Rc * c->cg.CS; ra.t = c->sr_t; ra.n_rows = rows; ra.G = c->cG;
+    HIPCHK(c, launch_conv_sr_rowdot(c->stream, ra, c->num_cus));
+    ConvDwArgs dw;
+    memset(&dw, 0, sizeof(dw));
+    dw.g = c->cg; dw.configs = c->sr_cfg; dw.tape = c->sr_ctape; dw.tape_stride = Rc * c->cg.CS;
+    dw.delta = c->sr_cdelta; dw.delta_stride = Rc * c->cg.CS; dw.w = c->sr_t; dw.B = rows;
+    dw.n_slices = c->sr_cslices < rows ? c->sr_cslices : rows; dw.ws = c->sr_cws; dw.g1 = c->sr_q; dw.g2 = c->sr_u;
+    HIPCHK(c, launch_conv_dw(c->stream, dw));
+    HIPCHK(c, launch_sr_tsum(c->stream, c->sr_t, rows, c->sr_u + c->P));
+    return VMC_OK;
+  }
   // t_b = O_b . p = sum_l delta_l[b] . (a_{l-1}[b] V_l + v_l) + (output / onsite layer term);
   // the row-dot kernel takes <= 256 output units at a time (257 .. 512 units: two column blocks)
   for (int l = 0; l < L; ++l) {

@@ -272,9 +272,9 @@ def test_conv_error_behaviour():
     VmcEngine(16, 8, 2, 33, **kw)                         # more than 32 filters
   with pytest.raises(NotImplementedError):
     VmcEngine(16, 8, 2, 8, ansatz='conv_2d', kernel_size=7, size_x=4, size_y=4)
-  eng = VmcEngine(16, 8, 2, 8, **kw)
+  eng = VmcEngine(16, 8, 2, 8, output_activation='tanh', **kw)
   with pytest.raises(NotImplementedError):
-    eng.sr_reserve(2)
+    eng.sr_reserve(2)                                     # SR (an extension) needs the exp output
   eng.close()
 
 
@@ -397,7 +397,8 @@ def test_conv_random_shapes(ansatz, sx, sy, L, f, k, b, nonlin):
 def test_conv_log_overlap_itswo_training_entry(tmp_path, wf_type, e0):
   """--optimizer=LogOverlapITSWO with a convolutional ansatz (vmc_epoch_log_overlap on the conv
   kernels): 40 epochs approach the exact ground-state energy of the 4x4 torus / the 16-site ring
-  from above; stochastic reconfiguration (an extension for the dense types) says so."""
+  from above; --optimizer=StochasticReconfiguration (an extension; round 3: also over the
+  convolutional kernels) then lowers the energy further from the same checkpoint directory's start."""
   import os
   from cgs_vmc_amd import lattice, run_training, session as session_lib, wavefunctions
   session_lib.reset_default_graph()
@@ -416,5 +417,11 @@ def test_conv_log_overlap_itswo_training_entry(tmp_path, wf_type, e0):
   assert e0 - 0.05 < tail < 0.95 * e0, (wf_type, tail, energies[::8])
   session_lib.reset_default_graph()
   wavefunctions.reset_name_scope()
-  with pytest.raises(NotImplementedError):
-    run_training.main(args + ['--optimizer', 'StochasticReconfiguration'])
+  d2 = os.path.join(d, 'sr')
+  os.makedirs(d2)
+  lattice.write_bonds(d2, lattice.chain_bonds(16) if wf_type.endswith('1d') else lattice.torus_bonds(4, 4))
+  hp_sr = hp.replace('learning_rates=[0.003,0.001]', 'learning_rates=[0.02,0.01]')
+  run_training.main(['--checkpoint_dir', d2, '--num_sites', '16', '--heisenberg_jx', '-1.0', '--wavefunction_type',
+                     wf_type, '--num_epochs', '30', '--hparams', hp_sr, '--optimizer', 'StochasticReconfiguration'])
+  e_sr = [float(x) for x in open(os.path.join(d2, 'metrics.txt')).read().split()]
+  assert np.isfinite(e_sr).all() and np.mean(e_sr[-5:]) < e_sr[0] - 0.5 and np.mean(e_sr[-5:]) > e0 - 0.05, e_sr[::5]

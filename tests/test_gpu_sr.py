@@ -263,3 +263,73 @@ def test_sr_beyond_256_units_matvec_and_solution(ansatz, n, h, L, b, n_store):
   x64, it64 = vo.sr_conjugate_gradient(o, e, lam, 1e-5, 3000)
   assert np.abs(x - x64).max() <= 5e-3 * np.abs(x64).max() and iters <= 2 * it64 + 10
   eng.close()
+
+
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin,n_store', [
+    ('conv_2d', 4, 4, 3, 8, 3, 20, 'relu', 2),
+    ('conv_2d', 6, 4, 2, 16, 4, 13, 'tanh', 2),       # even kernel, non-square
+    ('conv_2d', 4, 4, 2, 24, 3, 12, 'cos', 2),        # two channel blocks, pre-activation tape
+    ('res_net_2d', 4, 4, 2, 8, 3, 16, 'relu', 2),
+    ('conv_1d', 12, 1, 3, 12, 5, 14, 'sigmoid', 3),
+])
+def test_sr_convolutional_matvec_and_solution(ansatz, sx, sy, L, f, k, b, nonlin, n_store):
+  """SR over the convolutional ansatz types (round 3): t_b = O_b . p by k_conv_sr_rowdot on the stored
+  tapes and deltas, u = sum_b t_b O_b by the weight-gradient kernel with per-sample weight t_b.
+  Reference: explicit per-sample gradients from the oracle's back-propagation (one-hot weights)."""
+  from cgs_vmc_amd.engine import VmcEngine
+  n = sx * sy
+  geom = (f, k, sx, sy)
+  rng = np.random.default_rng(8)
+  theta = vo.conv_init_params(ansatz, geom, L, rng)
+  theta += ((0.03 if f <= 16 else 0.01) * rng.standard_normal(theta.size)).astype(np.float32)
+  bonds = vo.chain_bonds(n) if ansatz in vo.CONV_1D else vo.torus_bonds(sy, sx)
+  eng = VmcEngine(n, b, L, f, nonlinearity=nonlin, seed=2024, ansatz=ansatz, kernel_size=k, size_x=sx, size_y=sy)
+  eng.set_params(theta)
+  eng.set_bonds(bonds, -1.0, 1.0)
+  eng.sr_reserve(n_store)
+  eng.reset_accumulators()
+  cfgs, elocs = [], []
+  for j in range(n_store):
+    cfg = vo.random_configurations(n, b, np.random.RandomState(50 + j))
+    eng.set_configs(cfg)
+    if j == 1:
+      eng.mc_steps(2)
+      cfg = eng.get_configs()
+    eng.accumulate(0)
+    cfgs.append(cfg)
+    elocs.append(eng.local_energy()[0])
+  assert eng.sr_num_stored() == n_store
+  cfg_all = np.concatenate(cfgs, 0)
+  e = np.concatenate(elocs, 0).astype(np.float64)
+  o = vo.ANSATZ[ansatz][2](theta, cfg_all, np.eye(cfg_all.shape[0]), geom, L, nonlinearity=nonlin, dtype=np.float64)
+  assert o.shape == (cfg_all.shape[0], theta.size)
+  s_mat, f_vec = vo.sr_system(o, e)
+  v = rng.standard_normal(theta.size).astype(np.float32)
+  # S v = <O (O.v)> - <O><O.v> is a difference of two fp32 averages of size <|O|><|O.v|>: where the
+  # samples' gradients hardly vary (cos networks, the last convolution's biases: O = N for every
+  # sample) the difference is at the rounding level of that size, which the bound has to carry
+  cancel = np.abs(o).mean(0).max() * np.abs(o @ v.astype(np.float64)).mean()
+  for lam in (0.0, 0.01):
+    ref = s_mat @ v.astype(np.float64) + lam * v
+    got = eng.sr_debug_matvec(v, lam)
+    assert np.abs(got - ref).max() <= 5e-4 * np.abs(ref).max() + 4e-6 * cancel, \
+        (lam, np.abs(got - ref).max(), np.abs(ref).max(), cancel)
+  lam = 1e-2
+  x_ref = vo.sr_solve(o, e, lam)
+  iters, res = eng.sr_solve(lam, 1e-6, 3000)
+  x = eng.sr_get_solution()
+  assert res <= 1e-4, (iters, res)
+  # null directions of S (parameters whose O is the same for every sample) carry x = f / lambda with
+  # f at fp32 rounding level: the solution is checked through its residual in the fp64 operator, and
+  # entry by entry where the samples' gradients actually vary
+  resid = (s_mat + lam * np.eye(theta.size)) @ x.astype(np.float64) - f_vec
+  f_round = 4e-6 * np.abs(o).mean(0).max() * np.abs(e).mean() * np.sqrt(theta.size)   # fp32 rounding of f itself
+  assert np.linalg.norm(resid) <= 2e-3 * np.linalg.norm(f_vec) + f_round, (np.linalg.norm(resid), np.linalg.norm(f_vec), f_round)
+  # ... and through what the step does to the samples: with far fewer samples than parameters S has a
+  # large null space, in which x is that noise / lambda; O_c x (the change of every sample's centred
+  # logit per unit step) does not see it
+  oc = o - o.mean(0)
+  assert np.abs(oc @ (x - x_ref)).max() <= 1e-2 * np.abs(oc @ x_ref).max(), (iters, res)
+  eng.sr_apply(0.05)
+  np.testing.assert_allclose(eng.get_params(), theta - np.float32(0.05) * x, rtol=0, atol=1e-6)
+  eng.close()
