@@ -248,7 +248,9 @@ int vmc_epoch_log_overlap_dist(vmc_ctx* ctx, void* nccl_comm, int32_t world_size
  *   S = <O O^T> - <O><O>^T, f = <E O> - <E><O>, (S + diag_shift I) x = f, theta -= lr x
  * over every sample of the vmc_accumulate(ENERGY_GRADIENT) calls since the last reset.
  * vmc_sr_reserve(n) allocates the sample store for n accumulate calls (chains, activations,
- * back-propagated deltas: 2 L B Hp + B N floats each) and switches recording on; 0 frees it.
+ * back-propagated deltas: 2 L B Hp + B N floats each; convolutional types: the taped inputs and
+ * deltas of every convolution, (2 n_conv - 1) B CS floats) and switches recording on; 0 frees it.
+ * Covered: fully_connected and rbm up to 512 hidden units, the convolutional types; exp output.
  * Matrix-free conjugate gradients: vmc_sr_begin (x = 0, r = p = f from the accumulators, which
  * must already be all-reduced), then per iteration vmc_sr_matvec_partial (this rank's
  * sum_b (O_b . p) O_b into the P+1-float buffer of vmc_sr_buffer_devptr, last float =
