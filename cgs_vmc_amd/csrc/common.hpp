@@ -273,7 +273,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
 // `count` dual / ones-row GEMMs (device array of GemmArgs, all with the same splitk and their
 // own workspace) in one launch + one reduction launch; max_m counts MFMA rows (M - 1)
 hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
-                               int max_n, int splitk, bool dual = true, bool fresh = false);
+                               int max_n, int splitk, bool dual = true, bool fresh = false,
+                               const float* sc_eloc = nullptr, const float* sc_ratio = nullptr,
+                               float* sc_out = nullptr, int sc_B = 0, int sc_mode = 0);
 hipError_t launch_act_copy(hipStream_t s, const float* z, float* a, float* dact, long long n, int act);
 hipError_t launch_out_scale(hipStream_t s, const float* x, float* oscale, int B, int oact);
 hipError_t launch_tanh_copy(hipStream_t s, const float* z, float* a, long long n);

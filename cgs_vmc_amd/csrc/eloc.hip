@@ -3,7 +3,7 @@
 //
 // The reference evaluates psi(swap_ij R) for EVERY bond and multiplies by the mask
 // [s_i s_j < 0] afterwards (operators.py:166-168).  Here the masked-out rows are never
-// generated: k_bond_count / k_scan / k_bond_fill build a compact, chain-ordered list of the
+// generated: k_bond_count / k_bond_fill build a compact, chain-ordered list of the
 // antiparallel bonds, k_tail16 (mlp.hip) evaluates exactly those rows, and k_eloc_reduce sums
 // each chain's segment in a fixed order (deterministic, no float atomics).
 #include "common.hpp"
@@ -42,43 +42,40 @@ __global__ __launch_bounds__(256) void k_bond_count(const float* __restrict__ co
   if (lane == 0) { cnt[c] = n; diag[c] = d; }
 }
 
-// single block: off[c] = sum_{c' < c} cnt[c'], off[B] = total.  Thread t owns the contiguous
-// slice [t*per, (t+1)*per): serial sum, wave-level inclusive scan of the 64 slice totals by
-// shuffles, the 16 wave totals through LDS, then the slice is written out (two barriers in all).
-__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ cnt, int B,
-                                               int* __restrict__ off) {
+// 16 chains per workgroup (one wave each): the workgroup first derives the exclusive prefix of the
+// per-chain counts up to its own chains itself -- at most B integers from L2, summed by its 1024
+// threads in a fixed order -- instead of waiting for a separate single-block scan launch; it writes
+// off[c] for its chains (k_eloc_reduce and the row kernels read them; the last workgroup also
+// off[B] = total), then rowinfo[off[c] + p] = {c, +-(bond+1)}, sign = sign of s_i, bonds in
+// ascending order.
+__global__ __launch_bounds__(1024) void k_bond_fill(const float* __restrict__ configs,
+                                                    const int2* __restrict__ bonds, int B, int N,
+                                                    int n_bonds, const int* __restrict__ cnt,
+                                                    int* __restrict__ off,
+                                                    int2* __restrict__ rowinfo) {
   __shared__ int s_wave[16];
+  __shared__ int s_cnt[16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int per = (B + 1023) / 1024;
-  const int beg = min(t * per, B), end = min(beg + per, B);
-  int total = 0;
-  for (int i = beg; i < end; ++i) total += cnt[i];
-  int incl = total;
+  const int c0 = blockIdx.x * 16;
+  // sum of cnt[0 .. c0): thread t takes the elements t, t + 1024, ...
+  int part = 0;
+  for (int i = t; i < c0; i += 1024) part += cnt[i];
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(incl, d);
-    if (lane >= d) incl += o;
-  }
-  if (lane == 63) s_wave[wave] = incl;
+  for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+  if (lane == 0) s_wave[wave] = part;
+  if (t < 16) s_cnt[t] = c0 + t < B ? cnt[c0 + t] : 0;
   __syncthreads();
   int base = 0;
-  for (int w = 0; w < wave; ++w) base += s_wave[w];
-  int run = base + incl - total;          // exclusive prefix of this thread's slice
-  for (int i = beg; i < end; ++i) { off[i] = run; run += cnt[i]; }
-  if (t == 1023) off[B] = base + incl;
-}
-
-// one wave per chain: rowinfo[off[c] + p] = {c, +-(bond+1)}, sign = sign of s_i, bonds in
-// ascending order
-__global__ __launch_bounds__(256) void k_bond_fill(const float* __restrict__ configs,
-                                                   const int2* __restrict__ bonds, int B, int N,
-                                                   int n_bonds, const int* __restrict__ off,
-                                                   int2* __restrict__ rowinfo) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+#pragma unroll
+  for (int w = 0; w < 16; ++w) base += s_wave[w];
+  for (int w = 0; w < wave; ++w) base += s_cnt[w];      // exclusive prefix inside the workgroup
+  const int c = c0 + wave;
   if (c >= B) return;
+  if (lane == 0) {
+    off[c] = base;
+    if (c == B - 1) off[B] = base + s_cnt[wave];
+  }
   const float* x = configs + (long long)c * N;
-  int base = off[c];
   for (int k0 = 0; k0 < n_bonds; k0 += 64) {
     const int k = k0 + lane;
     bool anti = false;
@@ -100,11 +97,10 @@ __global__ __launch_bounds__(256) void k_bond_fill(const float* __restrict__ con
 hipError_t launch_bond_list(hipStream_t s, const float* configs, const int2* bonds,
                             const float* quarter_jz, int B, int N, int n_bonds, int* cnt,
                             int* off, float* diag, int2* rowinfo) {
-  const dim3 grid((B + 3) / 4), block(256);
-  hipLaunchKernelGGL(k_bond_count, grid, block, 0, s, configs, bonds, quarter_jz, B, N, n_bonds,
+  hipLaunchKernelGGL(k_bond_count, dim3((B + 3) / 4), dim3(256), 0, s, configs, bonds, quarter_jz, B, N, n_bonds,
                      cnt, diag);
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, cnt, B, off);
-  hipLaunchKernelGGL(k_bond_fill, grid, block, 0, s, configs, bonds, B, N, n_bonds, off, rowinfo);
+  hipLaunchKernelGGL(k_bond_fill, dim3((B + 15) / 16), dim3(1024), 0, s, configs, bonds, B, N, n_bonds, cnt, off,
+                     rowinfo);
   return hipGetLastError();
 }
 

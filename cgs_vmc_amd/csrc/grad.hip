@@ -276,7 +276,45 @@ __device__ __forceinline__ void gemm_reduce_body(const GemmArgs& g, long long st
   }
 }
 
-__global__ __launch_bounds__(256) void k_gemm_reduce_batched(const GemmArgs* __restrict__ batch, int fresh) {
+// tf.metrics.mean updates (training.py:555, 689-690) + mean_tensor count (550-553):
+// scalars = [e_total, e_count, r_total, r_count, g_count]; one workgroup, fixed order
+struct ScalarJob { const float* eloc; const float* ratio; float* sc; int B, mode; };
+
+__device__ __forceinline__ void scalar_accum_body(const ScalarJob& j, bool fresh) {
+  __shared__ double se[256];
+  __shared__ double sr[256];
+  double e = 0.0, r = 0.0;
+  for (int i = threadIdx.x; i < j.B; i += 256) {
+    e += (double)j.eloc[i];
+    if (j.ratio) r += (double)j.ratio[i];
+  }
+  se[threadIdx.x] = e; sr[threadIdx.x] = r;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) { se[threadIdx.x] += se[threadIdx.x + d]; sr[threadIdx.x] += sr[threadIdx.x + d]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float* sc = j.sc;
+    if (fresh) {   // first accumulate after reset_gradients: the scalars hold no sum yet
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sc[i] = 0.f;
+    }
+    sc[0] += (float)se[0];
+    sc[1] += (float)j.B;
+    if (j.mode == 1) { sc[2] += (float)sr[0]; sc[3] += (float)j.B; }
+    sc[4] += 1.f;
+  }
+}
+
+// grid (blocks, count + 1): rows 0 .. count-1 fold the split-K partials of one problem each; block 0 of
+// the extra row does the scalar accumulators of the same accumulate call (no launch of its own)
+__global__ __launch_bounds__(256) void k_gemm_reduce_batched(const GemmArgs* __restrict__ batch, int count, int fresh,
+                                                             ScalarJob job) {
+  if ((int)blockIdx.y == count) {
+    if (blockIdx.x == 0 && job.sc) scalar_accum_body(job, fresh != 0);
+    return;
+  }
   const GemmArgs g = batch[blockIdx.y];
   gemm_reduce_body(g, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, fresh != 0);
 }
@@ -309,7 +347,8 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
 }
 
 hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
-                               int max_n, int splitk, bool dual, bool fresh) {
+                               int max_n, int splitk, bool dual, bool fresh, const float* sc_eloc,
+                               const float* sc_ratio, float* sc_out, int sc_B, int sc_mode) {
   if (count <= 0) return hipSuccess;
   const int tx = (max_n + GT - 1) / GT, ty = (max_m + GT - 1) / GT, groups = count * splitk;
   const dim3 grid(8 * ((groups + 7) / 8) * tx * ty);
@@ -317,7 +356,9 @@ hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int cou
   else hipLaunchKernelGGL((k_gemm_batched<false>), grid, dim3(256), 0, s, dev_batch, splitk, tx, ty, groups);
   const long long total = (dual ? 2LL : 1LL) * (max_m + 1) * max_n;
   const int blocks = (int)min((total + 255) / 256, (long long)512);
-  hipLaunchKernelGGL(k_gemm_reduce_batched, dim3(blocks, count), dim3(256), 0, s, dev_batch, fresh ? 1 : 0);
+  const ScalarJob job{sc_eloc, sc_ratio, sc_out, sc_B, sc_mode};
+  hipLaunchKernelGGL(k_gemm_reduce_batched, dim3(blocks, count + (sc_out ? 1 : 0)), dim3(256), 0, s, dev_batch, count,
+                     fresh ? 1 : 0, job);
   return hipGetLastError();
 }
 

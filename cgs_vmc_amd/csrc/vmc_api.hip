@@ -1290,7 +1290,10 @@ int vmc_debug_kernel_path(vmc_ctx* c, int32_t* path) {
 int vmc_last_connected_rows(vmc_ctx* c, int64_t* rows) { CHECK_CTX(c); if (!rows) return fail(c, VMC_ERR_INVALID, "null"); *rows = c->last_rows; return VMC_OK; }
 
 // sum_b O_k(b) -> g1, sum_b w_b O_k(b) -> g2 for the psi parameter set
-static int gradient_sums(vmc_ctx* c, const float* w, bool fresh) {
+// `e` / `mode`: the scalar accumulators (sum E, counts, sum ratio) ride in the reduction launch of the
+// dense weight-gradient GEMMs; *scalars_done tells the caller whether they did
+static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e, int mode, bool* scalars_done) {
+  *scalars_done = false;
   ParamSet& p = c->ps[0];
   const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, NH = c->n_hh;
   float* g1 = c->acc;
@@ -1383,7 +1386,9 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh) {
     HIPCHK(c, hipMemcpy(c->d_batch[slot][par], tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
     c->batch_ready[slot][par] = true;
   }
-  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot][par], NH + 2, N > H ? N : H, H, pick_splitk(c, B), true, fresh));
+  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot][par], NH + 2, N > H ? N : H, H, pick_splitk(c, B), true, fresh,
+                                e, mode == 1 ? c->ratio : nullptr, c->acc + 2 * c->P, B, mode));
+  *scalars_done = true;
   return VMC_OK;
 }
 
@@ -1441,8 +1446,10 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   // reset is absorbed: their reduction stores instead of adding (conv: zero first)
   if (c->conv) PROPAGATE(acc_zeros(c));
   const bool fresh = c->acc_fresh;
-  PROPAGATE(gradient_sums(c, w, fresh));
-  HIPCHK(c, launch_scalar_accum(c->stream, e, mode == 1 ? c->ratio : nullptr, c->B, c->acc + 2 * c->P, mode, fresh));
+  bool scalars_done = false;
+  PROPAGATE(gradient_sums(c, w, fresh, e, mode, &scalars_done));
+  if (!scalars_done)
+    HIPCHK(c, launch_scalar_accum(c->stream, e, mode == 1 ? c->ratio : nullptr, c->B, c->acc + 2 * c->P, mode, fresh));
   c->acc_fresh = false;
   if (c->sr_cap > 0 && mode == VMC_MODE_ENERGY_GRADIENT) PROPAGATE(sr_record(c));
   c->acc_since_sweep = true;
