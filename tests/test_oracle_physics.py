@@ -416,3 +416,26 @@ def test_exact_fc_eigenstate_has_constant_local_energy_and_zero_gradient(n, h, L
   g = vo.energy_gradient(acc)
   scale = np.abs(acc.g2_total / acc.g_count).max()
   assert np.abs(g).max() < 1e-4 * scale
+
+
+def test_tf1_adam_is_torch_adam_with_a_rescaled_epsilon():
+  """An independent implementation of the optimizer the oracle restates (training.py:76-91,
+  tf.train.AdamOptimizer): TF1 applies  theta -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps),
+  torch.optim.Adam  theta -= lr / (1 - b1^t) * m / (sqrt(v / (1 - b2^t)) + eps').  They are the same
+  update when eps' = eps / sqrt(1 - b2^t); with that epsilon set per step torch's optimizer must
+  reproduce vo.adam_apply over several steps of changing gradients."""
+  import torch
+  rng = np.random.default_rng(3)
+  theta0 = rng.standard_normal(50).astype(np.float32)
+  lr, b1, b2, eps = 1e-3, 0.9, 0.99, 1e-8
+  p = torch.nn.Parameter(torch.tensor(theta0.astype(np.float64)))
+  opt = torch.optim.Adam([p], lr=lr, betas=(b1, b2), eps=eps)
+  st = vo.AdamState(theta0.size)
+  theta = theta0.copy()
+  for t in range(1, 8):
+    g = (rng.standard_normal(50) * (10.0 ** rng.integers(-3, 2))).astype(np.float32)
+    theta = vo.adam_apply(st, theta, g, lr, b1, b2, eps)
+    opt.param_groups[0]['eps'] = eps / np.sqrt(1.0 - b2 ** t)
+    p.grad = torch.tensor(g.astype(np.float64))
+    opt.step()
+    np.testing.assert_allclose(theta, p.detach().numpy(), rtol=0, atol=2e-6)
