@@ -87,9 +87,10 @@ __global__ void k_conv_pack(const float* __restrict__ theta, ConvGeom g, float* 
 size_t conv_lds_cap(const ConvGeom& g) {
   static const int one_per_cu = getenv("CGS_VMC_CONV_WG_PER_CU") ? atoi(getenv("CGS_VMC_CONV_WG_PER_CU")) == 1 : 0;
   if (one_per_cu) return (size_t)160 * 1024;      // experiment: one workgroup with twice the samples
+  if (g.NCB > 1) return (size_t)160 * 1024;      // one 8-wave workgroup per CU (conv32.hip)
   return conv_rows_lds(g, 1) <= CONV_LDS_PER_WG ? (size_t)CONV_LDS_PER_WG : (size_t)160 * 1024;
 }
-int conv_waves() { return CONV_WAVES; }
+int conv_waves(const ConvGeom& g) { return g.NCB > 1 ? 8 : CONV_WAVES; }
 
 size_t conv_rows_lds(const ConvGeom& g, int G) {
   const size_t xs = (size_t)((g.N + 3) & ~3);
@@ -126,7 +127,7 @@ hipError_t launch_conv_rows(hipStream_t s, const ConvRowsArgs& a, int num_cus) {
   if (a.n_rows <= 0) return hipSuccess;
   const int groups = (a.n_rows + a.G - 1) / a.G;
   const size_t lds = conv_rows_lds(a.g, a.G);
-  const int slots = num_cus * (lds <= CONV_LDS_PER_WG ? 2 : 1);      // co-resident workgroups
+  const int slots = num_cus * ((a.g.NCB == 1 && lds <= CONV_LDS_PER_WG) ? 2 : 1);      // co-resident workgroups
   const dim3 grid(groups < slots ? groups : slots);
   if (a.g.NCB == 2) return conv_launch_rows_cb2(s, a, grid, lds);
   return conv_launch_rows_t<1>(s, a, grid, lds);
@@ -142,7 +143,7 @@ hipError_t launch_conv_sweep(hipStream_t s, const ConvSweepArgs& a) {
 hipError_t launch_conv_back(hipStream_t s, const ConvBackArgs& a, int num_cus) {
   const int groups = (a.B + a.G - 1) / a.G;
   const size_t lds = conv_rows_lds(a.g, a.G);
-  const int slots = num_cus * (lds <= CONV_LDS_PER_WG ? 2 : 1);
+  const int slots = num_cus * ((a.g.NCB == 1 && lds <= CONV_LDS_PER_WG) ? 2 : 1);
   const dim3 grid(groups < slots ? groups : slots);
   if (a.g.NCB == 2) return conv_launch_back_cb2(s, a, grid, lds);
   return conv_launch_back_t<1>(s, a, grid, lds);
@@ -161,7 +162,7 @@ hipError_t launch_conv_sr_rowdot(hipStream_t s, const ConvSrRowdotArgs& a, int n
   if (a.n_rows <= 0) return hipSuccess;
   const int groups = (a.n_rows + a.G - 1) / a.G;
   const size_t lds = conv_rows_lds(a.g, a.G);
-  const int slots = num_cus * (lds <= CONV_LDS_PER_WG ? 2 : 1);
+  const int slots = num_cus * ((a.g.NCB == 1 && lds <= CONV_LDS_PER_WG) ? 2 : 1);
   const dim3 grid(groups < slots ? groups : slots);
   if (a.g.NCB == 2) return conv_launch_sr_rowdot_cb2(s, a, grid, lds);
   return conv_launch_sr_rowdot_t<1>(s, a, grid, lds);

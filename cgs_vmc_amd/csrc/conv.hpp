@@ -122,7 +122,7 @@ struct ConvSrRowdotArgs {
 
 size_t conv_rows_lds(const ConvGeom& g, int G);
 size_t conv_lds_cap(const ConvGeom& g);   // LDS budget of one workgroup (two per CU when a sample fits)
-int conv_waves();                         // waves per workgroup of the conv kernels
+int conv_waves(const ConvGeom& g);        // waves per workgroup of the conv kernels (4; two channel blocks: 8)
 int conv_pick_group(const ConvGeom& g, int waves);
 long long conv_num_params(int n_conv, int F, int taps);
 hipError_t launch_conv_pack(hipStream_t s, const float* theta, const ConvGeom& g, float* w0,

@@ -1,5 +1,6 @@
 // Convolutional ansatz kernels for 17 .. 32 filters: the templates of conv_kernels.hpp with NCB = 2
 // channel blocks (layers.py:89-160 takes any num_conv_filters, utils.py:111).
+#define CONV_WAVES 8     // one 8-wave workgroup per CU (see conv_kernels.hpp)
 #include "conv_kernels.hpp"
 
 hipError_t conv_launch_rows_cb2(hipStream_t s, const ConvRowsArgs& a, dim3 grid, size_t lds) {

@@ -23,11 +23,18 @@
 #include <cstdlib>
 #include <type_traits>
 
-// 4 waves per workgroup (one per SIMD) and two workgroups per CU: the two co-resident workgroups are
-// never in step, so the serial phases of one (row staging behind dependent global loads, the
-// per-layer weight-fragment reload, barriers, the final reduction) run under the MFMAs of the
-// other (one 4-wave workgroup per CU: 0.58 of the fp32-MFMA peak against 0.72 for two).
+// NCB = 1 (conv.hip): 4 waves per workgroup (one per SIMD) and two workgroups per CU: the two
+// co-resident workgroups are never in step, so the serial phases of one (row staging behind dependent
+// global loads, the per-layer weight-fragment reload, barriers, the final reduction) run under the
+// MFMAs of the other (one 4-wave workgroup per CU: 0.58 of the fp32-MFMA peak against 0.72 for two).
+// NCB = 2 (conv32.hip defines CONV_WAVES 8): a sample's feature maps are twice as large, only two
+// samples fit half a CU's LDS and their 13 position tiles divide badly over 4 waves; one 8-wave
+// workgroup per CU with the whole 160 KiB (five samples on a 10 x 10 lattice: 16 tile pairs, two per
+// wave) keeps two waves per SIMD and every wave busy.
+#ifndef CONV_WAVES
 #define CONV_WAVES 4
+#endif
+#define CONV_WG_PER_CU (CONV_WAVES == 4 ? 2 : 1)
 #define CONV_THREADS (CONV_WAVES * 64)
 #define CONV_LDS_PER_WG (80 * 1024)   // two workgroups share the 160 KiB of a CU
 #define SELU_SCALE_F 1.0507009873554805f
@@ -402,7 +409,7 @@ __device__ __forceinline__ void conv_forward(const ConvSmem& sm, const ConvGeom&
     }
     last = sm.buf0;
   }
-  // fixed-order reduction: wave w sums samples w, w + 4, ...; padded channels hold exact zeros
+  // fixed-order reduction: wave w sums samples w, w + CONV_WAVES, ...; padded channels hold exact zeros
   for (int s = wave; s < G; s += CONV_WAVES) {
     const float* m = last + (size_t)s * g.CS;
     float part = 0.f;
@@ -420,7 +427,7 @@ __device__ __forceinline__ void conv_forward(const ConvSmem& sm, const ConvGeom&
 // sites exchanged (operators.py:162-163), or the chain itself (bond 0).  Persistent: workgroup b
 // takes the row groups b, b + gridDim.x, ... of G rows each.
 template <int K, int KW, int NCB>
-__global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_rows(ConvRowsArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, CONV_WG_PER_CU) void k_conv_rows(ConvRowsArgs a) {
   extern __shared__ float s_conv[];
   const ConvGeom& g = a.g;
   const int G = a.G;
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_rows(ConvRowsArgs a) {
 // forward of the proposed configuration (a K x K receptive field grows past the lattice after a few
 // layers, so there is no incremental shortcut).
 template <int K, int KW, int NCB>
-__global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_sweep(ConvSweepArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, CONV_WG_PER_CU) void k_conv_sweep(ConvSweepArgs a) {
   extern __shared__ float s_conv[];
   const ConvGeom& g = a.g;
   const int G = a.G;
@@ -595,7 +602,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_sweep(ConvSweepArgs a)
 // D += convT_{2k+1}(delta_{2k+1}); delta_0 = D.  convT is the same tile loop with the flipped,
 // transposed fragment image and the padding roles exchanged.
 template <int K, int KW, int NCB>
-__global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_back(ConvBackArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, CONV_WG_PER_CU) void k_conv_back(ConvBackArgs a) {
   constexpr size_t WL = (size_t)NCB * NCB * K * KW * 256;
   extern __shared__ float s_conv[];
   const ConvGeom& g = a.g;
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_back(ConvBackArgs a) {
 // EP_DOT epilogue (accumulate (conv + bias) * delta per element) and the per-sample sum is the same
 // fixed-order reduction as the forward's.  Persistent over groups of G stored samples.
 template <int K, int KW, int NCB>
-__global__ __launch_bounds__(CONV_THREADS, 2) void k_conv_sr_rowdot(ConvSrRowdotArgs a) {
+__global__ __launch_bounds__(CONV_THREADS, CONV_WG_PER_CU) void k_conv_sr_rowdot(ConvSrRowdotArgs a) {
   constexpr size_t WL = (size_t)NCB * NCB * K * KW * 256;
   constexpr int BL = 16 * NCB;
   extern __shared__ float s_conv[];

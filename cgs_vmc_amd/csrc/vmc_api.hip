@@ -838,18 +838,31 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
       CA(dalloc(&p.cwb, nl * nb * nb * KK * 256));
       CA(dalloc(&p.cbias, (long long)cg.n_conv * 16 * nb));
     }
-    const int nw = conv_waves();
+    const int nw = conv_waves(cg);
     c->cG = conv_pick_group(cg, nw);
     if (c->cG > B) c->cG = (int)B;
     {  // sampler: chains per workgroup that minimise (workgroups per CU) x (tile rounds of one
-       // forward pass) -- the MFMA time of the busiest CU per mc_step
+       // forward pass) -- the MFMA time of the busiest CU per mc_step.  The two-channel-block kernels
+       // walk their tiles in pairs.  Ties go to the group size that fills the last round of workgroups
+       // best (4096 chains, 32 filters on 10 x 10: G = 4 -> 1024 workgroups = 4 per CU measured 84.9 ms
+       // per sweep, G = 5 -> 820 workgroups 87.8 ms), then to the larger group.
       long long best_cost = -1;
+      double best_fill = 0.0;
       for (int G = 1; G <= 64 && conv_rows_lds(cg, G) <= conv_lds_cap(cg) && G <= B; ++G) {
         const long long wgs = (B + G - 1) / G, per_cu = (wgs + c->num_cus - 1) / c->num_cus;
-        const long long tiles = ((long long)G * cg.N + 15) / 16, tile_rounds = (tiles + nw - 1) / nw;
+        long long tiles = ((long long)G * cg.N + 15) / 16;
+        if (cg.NCB > 1) tiles = (tiles + 1) / 2;          // tile pairs
+        const long long tile_rounds = (tiles + nw - 1) / nw;
         const long long cost = per_cu * tile_rounds;
-        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; c->cGs = G; }
+        const double fill = (double)wgs / (double)(per_cu * c->num_cus);
+        if (best_cost < 0 || cost < best_cost || (cost == best_cost && fill >= best_fill - 1e-9)) {
+          best_cost = cost; best_fill = fill; c->cGs = G;
+        }
       }
+    }
+    if (const char* e = getenv("CGS_VMC_CONV_SWEEP_G")) {     // measurement knob: chains per sampler workgroup
+      const int G = atoi(e);
+      if (G >= 1 && G <= 64 && conv_rows_lds(cg, G) <= conv_lds_cap(cg)) c->cGs = G < B ? G : (int)B;
     }
     c->ctape_stride = B * cg.CS; c->cdelta_stride = B * cg.CS;
     CA(dalloc(&c->ctape, nl * c->ctape_stride)); CA(dalloc(&c->cdelta, (long long)cg.n_conv * c->cdelta_stride));
