@@ -13,35 +13,43 @@ hipError_t conv_launch_sr_rowdot_cb2(hipStream_t s, const ConvSrRowdotArgs& a, d
 namespace {
 
 // g1 / g2 += sum over slices (fixed order) of the partial sums, scattered to the theta layout:
-// convolution l: w [K][K][cin][F] then b [F]   (snt.Conv2D variable order)
-__global__ void k_conv_dw_reduce(ConvDwArgs a, int KK) {
+// convolution l: w [K][K][cin][F] then b [F]   (snt.Conv2D variable order).  Grid (64 parameters,
+// layer); the four waves of a workgroup take the slices s, s + 4, ... and their four partial sums are
+// added as (0 + 1) + (2 + 3).  g1 == nullptr: the weighted sum only (the other half of ws is unwritten)
+__global__ __launch_bounds__(256) void k_conv_dw_reduce(ConvDwArgs a, int KK) {
+  __shared__ float p1[4][64], p2[4][64];
   const ConvGeom& g = a.g;
   const int CW = 16 * g.NCB;
   const size_t rows = (size_t)KK * CW + 1;
-  long long off = 0;
-  for (int l = 0; l < g.n_conv; ++l) {
-    const int cin = l == 0 ? 1 : g.F;
-    const long long nw = (long long)KK * cin * g.F, np = nw + g.F;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (long long)gridDim.x * blockDim.x) {
-      size_t src;
-      if (i < nw) {
-        const int co = (int)(i % g.F);
-        const int ci = (int)((i / g.F) % cin);
-        const int tap = (int)(i / ((long long)g.F * cin));
-        src = ((size_t)tap * CW + ci) * CW + co;
-      } else {
-        src = (size_t)KK * CW * CW + (size_t)(i - nw);
-      }
-      float s1 = 0.f, s2 = 0.f;
-      for (int sl = 0; sl < a.n_slices; ++sl) {
-        const float* w1 = a.ws + (((size_t)sl * g.n_conv + l) * 2) * rows * CW;
-        s1 += w1[src];
-        s2 += w1[rows * CW + src];
-      }
-      a.g1[off + i] += s1;
-      a.g2[off + i] += s2;
+  const int l = blockIdx.y;
+  const long long p0 = (long long)KK * g.F + g.F, pl = (long long)KK * g.F * g.F + g.F;
+  const long long off = l == 0 ? 0 : p0 + (long long)(l - 1) * pl;
+  const int cin = l == 0 ? 1 : g.F;
+  const long long nw = (long long)KK * cin * g.F, np = nw + g.F;
+  const int il = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + il;
+  float s1 = 0.f, s2 = 0.f;
+  if (i < np) {
+    size_t src;
+    if (i < nw) {
+      const int co = (int)(i % g.F);
+      const int ci = (int)((i / g.F) % cin);
+      const int tap = (int)(i / ((long long)g.F * cin));
+      src = ((size_t)tap * CW + ci) * CW + co;
+    } else {
+      src = (size_t)KK * CW * CW + (size_t)(i - nw);
     }
-    off += np;
+    for (int sl = sg; sl < a.n_slices; sl += 4) {
+      const float* w1 = a.ws + (((size_t)sl * g.n_conv + l) * 2) * rows * CW;
+      if (a.g1) s1 += w1[src];
+      s2 += w1[rows * CW + src];
+    }
+  }
+  p1[sg][il] = s1; p2[sg][il] = s2;
+  __syncthreads();
+  if (sg == 0 && i < np) {
+    if (a.g1) a.g1[off + i] += (p1[0][il] + p1[1][il]) + (p1[2][il] + p1[3][il]);
+    a.g2[off + i] += (p2[0][il] + p2[1][il]) + (p2[2][il] + p2[3][il]);
   }
 }
 
@@ -151,10 +159,14 @@ hipError_t launch_conv_back(hipStream_t s, const ConvBackArgs& a, int num_cus) {
 
 hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a) {
   const dim3 grid(a.n_slices, a.g.n_conv);
-  const size_t lds = (size_t)((a.g.N + 3) & ~3) * 32 * a.g.NCB * sizeof(float);
+  const size_t npad = (size_t)(a.g.D1 + a.g.K - 1) * (a.g.D2 + a.g.KW - 1);      // input with its halo
+  const size_t lds = ((size_t)((a.g.N + 3) & ~3) * 16 * a.g.NCB + npad * 16 * a.g.NCB + npad + 16 * a.g.NCB) * sizeof(float);
+  if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
   hipError_t e = a.g.NCB == 2 ? conv_launch_dw_cb2(s, a, grid, lds) : conv_launch_dw_t<1>(s, a, grid, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_conv_dw_reduce, dim3(32), dim3(256), 0, s, a, a.g.K * a.g.KW);
+  const long long np_max = (long long)a.g.K * a.g.KW * a.g.F * a.g.F + a.g.F;
+  hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)((np_max + 63) / 64), a.g.n_conv), dim3(256), 0, s, a,
+                     a.g.K * a.g.KW);
   return hipGetLastError();
 }
 

@@ -106,7 +106,7 @@ struct ConvDwArgs {
   int B;
   int n_slices;             // sample slices = gridDim.x
   float* ws;                // [n_slices][n_conv][2][(K*K*16 NCB + 1) * 16 NCB] partial sums
-  float* g1; float* g2;     // accumulators (theta layout), += on reduce
+  float* g1; float* g2;     // accumulators (theta layout), += on reduce; g1 == nullptr: weighted sum only
 };
 
 // stochastic reconfiguration (extension): t[row] = O_row . p over the stored samples

@@ -731,124 +731,239 @@ __global__ __launch_bounds__(CONV_THREADS, CONV_WG_PER_CU) void k_conv_sr_rowdot
 // ---------------------------------------------------------------------------------- weight gradient
 // sum_b (1 | w_b) * d logit_b / d W_l for every convolution: dW[tap][cin][cout] =
 // sum_{b, pos} in_l[b, pos + tap, cin] * delta_l[b, pos, cout]  (and the bias: sum of delta_l).
-// Grid (slice, layer): a workgroup walks the samples of its slice, each staged in LDS as
-// [site][16 NCB channels]; wave w owns the taps w, w + 8, ...; the reduction over positions is the k
+// Grid (slice, layer): a workgroup walks the samples slice, slice + n_slices, ... (so that at any
+// moment the workgroups read neighbouring samples), each staged in LDS as [site][16 NCB channels]
+// -- the convolution's input with its periodic halo, so that a tap is an address offset; wave w
+// owns the items w, w + 8, ... (the taps, then the bias); the reduction over positions is the k
 // index of the MFMA (4 positions per instruction): A = input at the tap-shifted position (lane =
-// cin), B = delta (lane = cout), and a second accumulator takes w_b * delta; NCB x NCB channel-block
-// products per tap.  Partial sums go to ws[slice][layer]; k_conv_dw_reduce adds the slices in a fixed
-// order into the accumulators.  (cos: the tape holds z, the convolution's input is cos z.)
-#define DW_WAVES 8   // the weight-gradient kernel splits the taps over 8 waves (1 workgroup per CU)
-template <int K, int KW, int NCB>
-__global__ __launch_bounds__(DW_WAVES * 64) void k_conv_dw(ConvDwArgs a) {
+// cin; the bias item: ones), B = delta (lane = cout), and a second accumulator takes w_b * delta;
+// NCB x NCB channel-block products per tap.  Partial sums go to ws[slice][layer];
+// k_conv_dw_reduce adds the slices in a fixed order into the accumulators.  (cos: the tape holds z,
+// the convolution's input is cos z.)
+// What bounds it is latency, not the MFMA count, so: (1) the next sample is fetched into registers
+// while the current one is multiplied, with no branch around a load (the compiler drains the
+// queue at every join); (2) the LDS operands of position quad c + 4 are read before the products of
+// quad c are issued; (3) BOTH (both sums, or the weighted one only: the SR matvec) and FIRST (the
+// one-channel first layer, whose taps are the MFMA's m index) are compile-time, so that no variant
+// pays for another's registers.
+#define DW_WAVES 8   // the weight-gradient kernel splits the items over 8 waves
+template <int K, int KW, int NCB, bool BOTH, bool FIRST>
+__device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
   constexpr int KK = K * KW;
-  constexpr int TPW = (KK + DW_WAVES - 1) / DW_WAVES;        // taps per wave
+  constexpr int NI = KK + 1;                                     // items of a layer > 0: the taps, then the bias
+  constexpr int TPW = FIRST ? 1 : (NI + DW_WAVES - 1) / DW_WAVES;  // items per wave
   constexpr int T0 = (KK + 15) / 16;                             // tap tiles of the first layer
   constexpr int CW = 16 * NCB;                                   // staged channels per site
-  constexpr int NA = TPW * NCB * NCB > T0 * NCB ? TPW * NCB * NCB : T0 * NCB;
-  extern __shared__ float s_dw[];
+  constexpr int NA = FIRST ? ((T0 + DW_WAVES - 1) / DW_WAVES) * NCB : TPW * NCB * NCB;
+  constexpr int GQ = 4 * NCB;                                    // f32x4 channel groups per site
+  constexpr int U = NCB == 1 ? 4 : 5;                            // prefetched vectors per thread
+  constexpr int WGT = DW_WAVES * 64;
   const ConvGeom& g = a.g;
   const int l = blockIdx.y;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ml = lane & 15, gl = lane >> 4;
   const int Np = (g.N + 3) & ~3;
-  float* s_in = s_dw;                       // [Np][CW] (layer 0: [Np] spins)
-  float* s_dl = s_dw + (size_t)Np * CW;     // [Np][CW]
-  const int per = (a.B + a.n_slices - 1) / a.n_slices;
-  const int b0 = blockIdx.x * per, b1 = min(b0 + per, a.B);
+  // LDS: delta [Np][CW]; the input with its halo [D1 + K - 1][D2 + KW - 1][CW] (first layer: spins,
+  // one float per site); the halo map (source site of every padded site); a row of ones
+  const int D2p = g.D2 + KW - 1, NPAD = (g.D1 + K - 1) * D2p;
+  float* s_dl = s_dw;
+  float* s_in = s_dw + (size_t)Np * CW;
+  int* s_map = (int*)(s_in + (size_t)NPAD * CW);
+  float* s_one = (float*)(s_map + NPAD);           // [CW]: 1 for channel block 0 (the bias item's A operand)
+  const int b0 = blockIdx.x, b1 = a.B, bstep = a.n_slices;
   const bool tape_is_z = !g.resnet && g.hact == VMC_ACT_COS_;
-  f32x4 acc1[NA], acc2[NA];
+  f32x4 acc1[BOTH ? NA : 1], acc2[NA];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) { acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i] = acc1[i]; }
-  f32x4 bacc1[NCB], bacc2[NCB];   // bias: A = ones (wave DW_WAVES-1)
+  for (int i = 0; i < NA; ++i) { acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; if (BOTH) acc1[i] = acc2[i]; }
+  f32x4 bacc1[NCB], bacc2[NCB];                    // first layer's bias: A = ones (wave DW_WAVES - 1)
 #pragma unroll
   for (int i = 0; i < NCB; ++i) { bacc1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; bacc2[i] = bacc1[i]; }
-  for (int i = threadIdx.x; i < (Np - g.N) * CW; i += blockDim.x) {   // zero the padded positions once
-    s_dl[g.N * CW + i] = 0.f;
-    if (l > 0) s_in[g.N * CW + i] = 0.f;
+  for (int i = threadIdx.x; i < (Np - g.N) * CW; i += WGT) s_dl[g.N * CW + i] = 0.f;   // padded positions, once
+  if (threadIdx.x < CW) s_one[threadIdx.x] = threadIdx.x < 16 ? 1.f : 0.f;
+  for (int i = threadIdx.x; i < NPAD; i += WGT) {
+    const int p1 = i / D2p, p2 = i - p1 * D2p;
+    s_map[i] = wrap(p1 - g.lo, g.D1) * g.D2 + wrap(p2 - g.lo2, g.D2);
   }
-  for (int b = b0; b < b1; ++b) {
-    __syncthreads();
+  // one flattened item list per sample: delta, then (layers > 0) the input with its halo
+  const int in_off = Np * CW;                      // s_in relative to s_dw, in floats
+  const int nd = GQ * g.N, ntot = nd + (FIRST ? 0 : GQ * NPAD);
+  auto item = [&](int i, int& soff, int& dst) {
+    const bool isd = i < nd;
+    const int k = isd ? i : i - nd;
+    const int gq = k & (GQ - 1), ps = k / GQ;
+    const int site = isd ? ps : s_map[ps];
+    soff = gq * g.GS + 4 * site;
+    dst = (isd ? 0 : in_off) + ps * CW + 4 * gq;
+  };
+  auto put = [&](int dst, f32x4 v) {
+    if (tape_is_z && dst >= in_off) {
+      const int gq = (dst >> 2) & (GQ - 1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (4 * gq + r) < g.F ? vmc_act_rt(VMC_ACT_COS_, v[r]) : 0.f;
+    }
+    *(f32x4*)(s_dw + dst) = v;
+  };
+  // the first U x 512 items of the next sample travel while the current one is multiplied (a 10 x 10
+  // lattice with k = 5 has 1184 items at 16 filters, 2368 at 32); larger lattices stage the rest late
+  f32x4 pre[U];
+  float wb_next = 0.f, spin_next = 0.f;
+  auto prefetch = [&](int b) {
     const float* dsrc = a.delta + (long long)l * a.delta_stride + (long long)b * g.CS;
-    for (int i = threadIdx.x; i < 4 * NCB * g.N; i += blockDim.x) {       // i = (group, site)
-      const int gq = i / g.N, site = i - gq * g.N;
-      *(f32x4*)(s_dl + site * CW + 4 * gq) = *(const f32x4*)(dsrc + gq * g.GS + 4 * site);
-    }
-    if (l == 0) {
-      for (int i = threadIdx.x; i < g.N; i += blockDim.x) s_in[i] = a.configs[(long long)b * g.N + i];
-    } else {
-      const float* isrc = a.tape + (long long)(l - 1) * a.tape_stride + (long long)b * g.CS;
-      for (int i = threadIdx.x; i < 4 * NCB * g.N; i += blockDim.x) {
-        const int gq = i / g.N, site = i - gq * g.N;
-        f32x4 v = *(const f32x4*)(isrc + gq * g.GS + 4 * site);
-        if (tape_is_z) {
+    const float* isrc = a.tape + (long long)(FIRST ? 0 : l - 1) * a.tape_stride + (long long)b * g.CS;
+    wb_next = a.w[b];
+    if (FIRST) spin_next = a.configs[(long long)b * g.N + s_map[min((int)threadIdx.x, NPAD - 1)]];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (4 * gq + r) < g.F ? vmc_act_rt(VMC_ACT_COS_, v[r]) : 0.f;
-        }
-        *(f32x4*)(s_in + site * CW + 4 * gq) = v;
-      }
+    for (int j = 0; j < U; ++j) {
+      // items past the end repeat the last one and are never stored
+      const int i = min((int)threadIdx.x + j * WGT, ntot - 1);
+      int soff, dst;
+      item(i, soff, dst);
+      pre[j] = *(const f32x4*)((dst < in_off ? dsrc : isrc) + soff);
     }
+  };
+  // position c + gl in the padded layout, advanced by 4 positions per iteration
+  const int a1_0 = gl / g.D2, a2_0 = gl - a1_0 * g.D2;
+  int tapoff0[FIRST ? T0 : 1];                     // first layer: lane m = tap 16 tt + m
+  if (FIRST) {
+#pragma unroll
+    for (int tt = 0; tt < T0; ++tt) {
+      int tap = 16 * tt + ml;
+      tap = tap < KK ? tap : 0;
+      tapoff0[tt] = (tap / KW) * D2p + tap % KW;
+    }
+  }
+  // layers > 0, per item: operand pointer less the position term.  Every read is unconditional (a
+  // select on a wave-uniform condition would become a branch around the read): the bias item reads
+  // the ones row, an empty slot tap 0
+  const float* srcb[TPW];
+  bool isb[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int it = wave + i * DW_WAVES;            // wave-uniform
+    const int tp = it < KK ? it : 0;
+    isb[i] = it == KK;
+    srcb[i] = isb[i] ? s_one + ml : s_in + ml + ((tp / KW) * D2p + tp % KW) * CW;
+  }
+  auto read_quad = [&](int c, int a1, int a2, float (&dv)[NCB], float (&av)[TPW][NCB]) {
+    const int pos = min(c + gl, Np - 1);           // (the quad past the end is read and dropped)
+    const bool pv = c + gl < g.N;
+#pragma unroll
+    for (int co = 0; co < NCB; ++co) dv[co] = s_dl[pos * CW + 16 * co + ml];   // padded positions hold zeros
+    const int boff = pv ? (a1 * D2p + a2) * CW : 0;   // padded layout: (a1 + t1, a2 + t2), no wrap
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int ci = 0; ci < NCB; ++ci) {
+        const float x = srcb[i][(isb[i] ? 0 : boff) + 16 * ci];
+        av[i][ci] = pv ? x : 0.f;                  // padded positions: delta is zero as well
+      }
+  };
+  __syncthreads();                                 // s_map
+  if (b0 < b1) prefetch(b0);
+  for (int b = b0; b < b1; b += bstep) {
     __syncthreads();
-    const float wb = a.w[b];
-    for (int c = 0; c < Np; c += 4) {
-      const int pos = c + gl;
-      const bool pv = pos < g.N;
-      float dv[NCB], dv2[NCB];
 #pragma unroll
-      for (int co = 0; co < NCB; ++co) {
-        dv[co] = s_dl[pos * CW + 16 * co + ml];       // padded positions hold zeros
-        dv2[co] = dv[co] * wb;
+    for (int j = 0; j < U; ++j) {
+      const int i = threadIdx.x + j * WGT;
+      if (i < ntot) {
+        int soff, dst;
+        item(i, soff, dst);
+        put(dst, pre[j]);
       }
-      const int a1 = pos / g.D2, a2 = pos - a1 * g.D2;
-      if (l == 0) {
-        // A = spin at the tap-shifted position, lane m = tap 16 tt + m: tap tiles over waves
+    }
+    if (ntot > U * WGT) {                          // larger lattices: the remainder, not prefetched
+      const float* dsrc = a.delta + (long long)l * a.delta_stride + (long long)b * g.CS;
+      const float* isrc = a.tape + (long long)(FIRST ? 0 : l - 1) * a.tape_stride + (long long)b * g.CS;
+      for (int i = threadIdx.x + U * WGT; i < ntot; i += WGT) {
+        int soff, dst;
+        item(i, soff, dst);
+        put(dst, *(const f32x4*)((dst < in_off ? dsrc : isrc) + soff));
+      }
+    }
+    if (FIRST) {
+      if ((int)threadIdx.x < NPAD) s_in[threadIdx.x] = spin_next;
+      for (int i = threadIdx.x + WGT; i < NPAD; i += WGT) s_in[i] = a.configs[(long long)b * g.N + s_map[i]];
+    }
+    const float wb = wb_next;
+    __syncthreads();
+    if (b + bstep < b1) prefetch(b + bstep);
+    int a1 = a1_0, a2 = a2_0;
+    if (FIRST) {
+      // A = spin at the tap-shifted position, lane m = tap 16 tt + m (tap tiles over waves); the
+      // bias (A = ones) on the last wave
+      for (int c = 0; c < Np; c += 4) {
+        const int pos = c + gl;
+        const bool pv = pos < g.N;
+        float dv[NCB], dv2[NCB];
+#pragma unroll
+        for (int co = 0; co < NCB; ++co) {
+          dv[co] = s_dl[pos * CW + 16 * co + ml];
+          dv2[co] = dv[co] * wb;
+        }
+        const int base = pv ? a1 * D2p + a2 : 0;
+        a2 += 4;
+        if (a2 >= g.D2) { a2 -= g.D2; ++a1; }
+        if (a2 >= g.D2) { a2 -= g.D2; ++a1; }
 #pragma unroll
         for (int tt = 0; tt < T0; ++tt) {
           if ((tt % DW_WAVES) == wave) {
-            int tap = 16 * tt + ml;
-            tap = tap < KK ? tap : 0;
-            const int n1 = wrap(a1 + tap / KW - g.lo, g.D1), n2 = wrap(a2 + tap % KW - g.lo2, g.D2);
-            const float av = pv ? s_in[n1 * g.D2 + n2] : 0.f;
+            const float av = pv ? s_in[base + tapoff0[tt]] : 0.f;
 #pragma unroll
             for (int co = 0; co < NCB; ++co) {
-              acc1[(tt / DW_WAVES) * NCB + co] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv[co], acc1[(tt / DW_WAVES) * NCB + co], 0, 0, 0);
-              acc2[(tt / DW_WAVES) * NCB + co] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv2[co], acc2[(tt / DW_WAVES) * NCB + co], 0, 0, 0);
+              const int ai = (tt / DW_WAVES) * NCB + co;
+              if (BOTH) acc1[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv[co], acc1[ai], 0, 0, 0);
+              acc2[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv2[co], acc2[ai], 0, 0, 0);
             }
           }
         }
-      } else {
+        if (wave == DW_WAVES - 1) {
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-          const int tap = wave + i * DW_WAVES;       // wave-uniform
-          if (tap < KK) {
-            const int n1 = wrap(a1 + tap / KW - g.lo, g.D1), n2 = wrap(a2 + tap % KW - g.lo2, g.D2);
-#pragma unroll
-            for (int ci = 0; ci < NCB; ++ci) {
-              const float av = pv ? s_in[(n1 * g.D2 + n2) * CW + 16 * ci + ml] : 0.f;
-#pragma unroll
-              for (int co = 0; co < NCB; ++co) {
-                const int ai = (i * NCB + ci) * NCB + co;
-                acc1[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv[co], acc1[ai], 0, 0, 0);
-                acc2[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv2[co], acc2[ai], 0, 0, 0);
-              }
-            }
+          for (int co = 0; co < NCB; ++co) {
+            if (BOTH) bacc1[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv[co], bacc1[co], 0, 0, 0);
+            bacc2[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv2[co], bacc2[co], 0, 0, 0);
           }
         }
       }
-      if (wave == DW_WAVES - 1) {
+    } else {
+      float dv[NCB], av[TPW][NCB], dvn[NCB], avn[TPW][NCB];
+      read_quad(0, a1, a2, dv, av);
+      for (int c = 0; c < Np; c += 4) {
+        a2 += 4;
+        if (a2 >= g.D2) { a2 -= g.D2; ++a1; }
+        if (a2 >= g.D2) { a2 -= g.D2; ++a1; }
+        read_quad(c + 4, a1, a2, dvn, avn);
+        float dv2[NCB];
 #pragma unroll
-        for (int co = 0; co < NCB; ++co) {
-          bacc1[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv[co], bacc1[co], 0, 0, 0);
-          bacc2[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv2[co], bacc2[co], 0, 0, 0);
+        for (int co = 0; co < NCB; ++co) dv2[co] = dv[co] * wb;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          if (i * DW_WAVES + DW_WAVES - 1 < NI || wave + i * DW_WAVES < NI) {   // last slot: partly filled
+#pragma unroll
+            for (int ci = 0; ci < NCB; ++ci)
+#pragma unroll
+              for (int co = 0; co < NCB; ++co) {
+                const int ai = (i * NCB + ci) * NCB + co;
+                if (BOTH) acc1[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][ci], dv[co], acc1[ai], 0, 0, 0);
+                acc2[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][ci], dv2[co], acc2[ai], 0, 0, 0);
+              }
+          }
         }
+#pragma unroll
+        for (int co = 0; co < NCB; ++co) dv[co] = dvn[co];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+#pragma unroll
+          for (int ci = 0; ci < NCB; ++ci) av[i][ci] = avn[i][ci];
       }
     }
   }
   // partial sums: ws[slice][layer][2][(KK*CW + 1) * CW]: row (tap * CW + cin) or KK*CW = bias, col cout
+  // (the weighted-only variant leaves the first half untouched: the reduce skips it as well)
   const size_t rows = (size_t)KK * CW + 1;
   float* w1 = a.ws + (((size_t)blockIdx.x * g.n_conv + l) * 2) * rows * CW;
   float* w2 = w1 + rows * CW;
-  if (l == 0) {
+  if (FIRST) {
 #pragma unroll
     for (int tt = 0; tt < T0; ++tt)
       if ((tt % DW_WAVES) == wave)
@@ -858,16 +973,23 @@ __global__ __launch_bounds__(DW_WAVES * 64) void k_conv_dw(ConvDwArgs a) {
           if (tap < KK) {
 #pragma unroll
             for (int co = 0; co < NCB; ++co) {
-              w1[(size_t)tap * CW * CW + 16 * co + ml] = acc1[(tt / DW_WAVES) * NCB + co][r];   // cin 0
+              if (BOTH) w1[(size_t)tap * CW * CW + 16 * co + ml] = acc1[(tt / DW_WAVES) * NCB + co][r];   // cin 0
               w2[(size_t)tap * CW * CW + 16 * co + ml] = acc2[(tt / DW_WAVES) * NCB + co][r];
             }
           }
         }
+    if (wave == DW_WAVES - 1 && gl == 0) {
+#pragma unroll
+      for (int co = 0; co < NCB; ++co) {
+        if (BOTH) w1[(size_t)KK * CW * CW + 16 * co + ml] = bacc1[co][0];
+        w2[(size_t)KK * CW * CW + 16 * co + ml] = bacc2[co][0];
+      }
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-      const int tap = wave + i * DW_WAVES;
-      if (tap < KK)
+      const int it = wave + i * DW_WAVES;
+      if (it < KK) {
 #pragma unroll
         for (int ci = 0; ci < NCB; ++ci)
 #pragma unroll
@@ -875,18 +997,26 @@ __global__ __launch_bounds__(DW_WAVES * 64) void k_conv_dw(ConvDwArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int ai = (i * NCB + ci) * NCB + co;
-              w1[((size_t)tap * CW + 16 * ci + 4 * gl + r) * CW + 16 * co + ml] = acc1[ai][r];    // row cin = 16 ci + 4g + r
-              w2[((size_t)tap * CW + 16 * ci + 4 * gl + r) * CW + 16 * co + ml] = acc2[ai][r];
+              const size_t o = ((size_t)it * CW + 16 * ci + 4 * gl + r) * CW + 16 * co + ml;   // row cin = 16 ci + 4g + r
+              if (BOTH) w1[o] = acc1[ai][r];
+              w2[o] = acc2[ai][r];
             }
-    }
-  }
-  if (wave == DW_WAVES - 1 && gl == 0) {
+      } else if (it == KK && gl == 0) {                // bias: every row of the ones product is the sum
 #pragma unroll
-    for (int co = 0; co < NCB; ++co) {
-      w1[(size_t)KK * CW * CW + 16 * co + ml] = bacc1[co][0];
-      w2[(size_t)KK * CW * CW + 16 * co + ml] = bacc2[co][0];
+        for (int co = 0; co < NCB; ++co) {
+          if (BOTH) w1[(size_t)KK * CW * CW + 16 * co + ml] = acc1[(i * NCB) * NCB + co][0];
+          w2[(size_t)KK * CW * CW + 16 * co + ml] = acc2[(i * NCB) * NCB + co][0];
+        }
+      }
     }
   }
+}
+
+template <int K, int KW, int NCB, bool BOTH>
+__global__ __launch_bounds__(DW_WAVES * 64, NCB == 1 ? 4 : 2) void k_conv_dw(ConvDwArgs a) {   // 16 filters: two workgroups per CU
+  extern __shared__ float s_dw[];
+  if (blockIdx.y == 0) conv_dw_body<K, KW, NCB, BOTH, true>(a, s_dw);
+  else conv_dw_body<K, KW, NCB, BOTH, false>(a, s_dw);
 }
 
 template <typename Kern, typename Args>
@@ -937,7 +1067,8 @@ hipError_t conv_launch_sr_rowdot_t(hipStream_t s, const ConvSrRowdotArgs& a, dim
 }
 template <int NCB>
 hipError_t conv_launch_dw_t(hipStream_t s, const ConvDwArgs& a, dim3 grid, size_t lds) {
-  CONV_DISPATCH_K(a.g, return launch_k(k_conv_dw<KK_, KW_, NCB>, grid, lds, s, a, DW_WAVES * 64));
+  if (a.g1) { CONV_DISPATCH_K(a.g, return launch_k(k_conv_dw<KK_, KW_, NCB, true>, grid, lds, s, a, DW_WAVES * 64)); }
+  else { CONV_DISPATCH_K(a.g, return launch_k(k_conv_dw<KK_, KW_, NCB, false>, grid, lds, s, a, DW_WAVES * 64)); }
   return hipSuccess;
 }
 

@@ -1825,7 +1825,7 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
   if (c->conv) {
     // t_b = O_b . p: the CG direction packed like a parameter set, convolved with the taped inputs and
     // dotted with the stored deltas (k_conv_sr_rowdot); u = sum_b t_b O_b: the weight-gradient kernel
-    // over the stored samples with per-sample weight t_b (its unweighted sum goes to scratch)
+    // over the stored samples with per-sample weight t_b (the unweighted sum is skipped)
     const long long Rc = (long long)c->sr_cap * B;
     HIPCHK(c, launch_conv_pack(c->stream, v, c->cg, c->sr_cw0, c->sr_cwf, c->sr_cwb, c->sr_cbias));
     ConvSrRowdotArgs ra;
@@ -1838,7 +1838,7 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
     memset(&dw, 0, sizeof(dw));
     dw.g = c->cg; dw.configs = c->sr_cfg; dw.tape = c->sr_ctape; dw.tape_stride = Rc * c->cg.CS;
     dw.delta = c->sr_cdelta; dw.delta_stride = Rc * c->cg.CS; dw.w = c->sr_t; dw.B = rows;
-    dw.n_slices = c->sr_cslices < rows ? c->sr_cslices : rows; dw.ws = c->sr_cws; dw.g1 = c->sr_q; dw.g2 = c->sr_u;
+    dw.n_slices = c->sr_cslices < rows ? c->sr_cslices : rows; dw.ws = c->sr_cws; dw.g1 = nullptr; dw.g2 = c->sr_u;
     HIPCHK(c, launch_conv_dw(c->stream, dw));
     HIPCHK(c, launch_sr_tsum(c->stream, c->sr_t, rows, c->sr_u + c->P));
     return VMC_OK;

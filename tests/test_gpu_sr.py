@@ -318,7 +318,9 @@ def test_sr_convolutional_matvec_and_solution(ansatz, sx, sy, L, f, k, b, nonlin
   x_ref = vo.sr_solve(o, e, lam)
   iters, res = eng.sr_solve(lam, 1e-6, 3000)
   x = eng.sr_get_solution()
-  assert res <= 1e-4, (iters, res)
+  # (cos: S v is cancellation-dominated, see above; CG stalls at that rounding level, a few 1e-4 of |f|,
+  # which of the orders of summation is in use decides where exactly.  The fp64 checks below decide.)
+  assert res <= (5e-4 if nonlin == 'cos' else 1e-4), (iters, res)
   # null directions of S (parameters whose O is the same for every sample) carry x = f / lambda with
   # f at fp32 rounding level: the solution is checked through its residual in the fp64 operator, and
   # entry by entry where the samples' gradients actually vary
