@@ -159,8 +159,12 @@ hipError_t launch_conv_back(hipStream_t s, const ConvBackArgs& a, int num_cus) {
 
 hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a) {
   const dim3 grid(a.n_slices, a.g.n_conv);
-  const size_t npad = (size_t)(a.g.D1 + a.g.K - 1) * (a.g.D2 + a.g.KW - 1);      // input with its halo
-  const size_t lds = ((size_t)((a.g.N + 3) & ~3) * 16 * a.g.NCB + npad * 16 * a.g.NCB + npad + 16 * a.g.NCB) * sizeof(float);
+  // delta [NQ][CW] + input [NIN][CW] in one padded site numbering, the halo and position maps, ones
+  const size_t d2p = (size_t)a.g.D2 + a.g.KW - 1, npad = (size_t)(a.g.D1 + a.g.K - 1) * d2p;
+  const size_t nq = ((size_t)a.g.D1 * d2p + 3) & ~(size_t)3, nin = nq + (size_t)(a.g.K - 1) * d2p + a.g.KW;
+  const size_t cw = 16 * (size_t)a.g.NCB;
+  // (+ 8 sites: the operands of the quad past the end are read, and dropped)
+  const size_t lds = (nq * cw + nin * cw + npad + a.g.N + cw + 8 * cw) * sizeof(float);
   if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
   hipError_t e = a.g.NCB == 2 ? conv_launch_dw_cb2(s, a, grid, lds) : conv_launch_dw_t<1>(s, a, grid, lds);
   if (e != hipSuccess) return e;

@@ -732,29 +732,32 @@ __global__ __launch_bounds__(CONV_THREADS, CONV_WG_PER_CU) void k_conv_sr_rowdot
 // sum_b (1 | w_b) * d logit_b / d W_l for every convolution: dW[tap][cin][cout] =
 // sum_{b, pos} in_l[b, pos + tap, cin] * delta_l[b, pos, cout]  (and the bias: sum of delta_l).
 // Grid (slice, layer): a workgroup walks the samples slice, slice + n_slices, ... (so that at any
-// moment the workgroups read neighbouring samples), each staged in LDS as [site][16 NCB channels]
-// -- the convolution's input with its periodic halo, so that a tap is an address offset; wave w
-// owns the items w, w + 8, ... (the taps, then the bias); the reduction over positions is the k
-// index of the MFMA (4 positions per instruction): A = input at the tap-shifted position (lane =
-// cin; the bias item: ones), B = delta (lane = cout), and a second accumulator takes w_b * delta;
-// NCB x NCB channel-block products per tap.  Partial sums go to ws[slice][layer];
-// k_conv_dw_reduce adds the slices in a fixed order into the accumulators.  (cos: the tape holds z,
-// the convolution's input is cos z.)
-// What bounds it is latency, not the MFMA count, so: (1) the next sample is fetched into registers
-// while the current one is multiplied, with no branch around a load (the compiler drains the
-// queue at every join); (2) the LDS operands of position quad c + 4 are read before the products of
-// quad c are issued; (3) BOTH (both sums, or the weighted one only: the SR matvec) and FIRST (the
-// one-channel first layer, whose taps are the MFMA's m index) are compile-time, so that no variant
-// pays for another's registers.
+// moment the workgroups read neighbouring samples).  A sample is staged in LDS in ONE padded site
+// numbering q = a1 (D2 + KW - 1) + a2: the convolution's input with its periodic halo,
+// [D1 + K - 1][D2 + KW - 1][16 NCB channels], and delta [D1][D2 + KW - 1][16 NCB] with zeros in the
+// halo columns -- so position q under tap (t1, t2) reads input site q + t1 (D2 + KW - 1) + t2: the
+// walk over positions is a pointer increment, a tap a constant offset, and the halo positions add
+// zeros (1.4 x the products at 10 x 10, k = 5, in exchange for no address arithmetic: the loop was
+// VALU-issue bound).  Wave w owns the items w, w + 8, ... (the taps, then the bias); the reduction
+// over positions is the k index of the MFMA (4 positions per instruction): A = input (lane = cin;
+// the bias item: ones), B = delta (lane = cout), and a second accumulator takes w_b * delta; NCB x NCB
+// channel-block products per tap.  Partial sums go to ws[slice][layer]; k_conv_dw_reduce adds the
+// slices in a fixed order into the accumulators.  (cos: the tape holds z, the input is cos z.)
+// Latency rules: (1) the next sample is fetched into registers while the current one is multiplied,
+// with no branch around a load (the compiler drains the queue at every join); (2) the LDS operands
+// of position quad q + 4 are read before the products of quad q are issued; (3) BOTH (both sums, or
+// the weighted one only: the SR matvec) and FIRST (the one-channel first layer, whose taps are the
+// MFMA's m index) are compile-time, so that no variant pays for another's registers.
 #define DW_WAVES 8   // the weight-gradient kernel splits the items over 8 waves
 template <int K, int KW, int NCB, bool BOTH, bool FIRST>
 __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
   constexpr int KK = K * KW;
   constexpr int NI = KK + 1;                                     // items of a layer > 0: the taps, then the bias
-  constexpr int TPW = FIRST ? 1 : (NI + DW_WAVES - 1) / DW_WAVES;  // items per wave
   constexpr int T0 = (KK + 15) / 16;                             // tap tiles of the first layer
+  constexpr int TPW = FIRST ? (T0 + DW_WAVES - 1) / DW_WAVES : (NI + DW_WAVES - 1) / DW_WAVES;   // items per wave
   constexpr int CW = 16 * NCB;                                   // staged channels per site
-  constexpr int NA = FIRST ? ((T0 + DW_WAVES - 1) / DW_WAVES) * NCB : TPW * NCB * NCB;
+  constexpr int CI = FIRST ? 1 : NCB;                            // input channel blocks
+  constexpr int NA = TPW * CI * NCB;
   constexpr int GQ = 4 * NCB;                                    // f32x4 channel groups per site
   constexpr int U = NCB == 1 ? 4 : 5;                            // prefetched vectors per thread
   constexpr int WGT = DW_WAVES * 64;
@@ -763,14 +766,16 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ml = lane & 15, gl = lane >> 4;
-  const int Np = (g.N + 3) & ~3;
-  // LDS: delta [Np][CW]; the input with its halo [D1 + K - 1][D2 + KW - 1][CW] (first layer: spins,
-  // one float per site); the halo map (source site of every padded site); a row of ones
   const int D2p = g.D2 + KW - 1, NPAD = (g.D1 + K - 1) * D2p;
+  const int NQ = (g.D1 * D2p + 3) & ~3;            // positions walked (padded numbering), whole quads
+  const int NIN = NQ + (K - 1) * D2p + KW;         // input sites a product can touch
+  // LDS: delta [NQ][CW]; input [NIN][CW] (first layer: spins, one float per site); the halo map
+  // (source site of every padded input site), the position map (padded number of every site), ones
   float* s_dl = s_dw;
-  float* s_in = s_dw + (size_t)Np * CW;
-  int* s_map = (int*)(s_in + (size_t)NPAD * CW);
-  float* s_one = (float*)(s_map + NPAD);           // [CW]: 1 for channel block 0 (the bias item's A operand)
+  float* s_in = s_dw + (size_t)NQ * CW;
+  int* s_map = (int*)(s_in + (size_t)NIN * (FIRST ? 1 : CW));
+  int* s_pos = s_map + NPAD;
+  float* s_one = (float*)(s_pos + g.N);            // [CW]: 1 for channel block 0 (the bias item's A operand)
   const int b0 = blockIdx.x, b1 = a.B, bstep = a.n_slices;
   const bool tape_is_z = !g.resnet && g.hact == VMC_ACT_COS_;
   f32x4 acc1[BOTH ? NA : 1], acc2[NA];
@@ -779,22 +784,29 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
   f32x4 bacc1[NCB], bacc2[NCB];                    // first layer's bias: A = ones (wave DW_WAVES - 1)
 #pragma unroll
   for (int i = 0; i < NCB; ++i) { bacc1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; bacc2[i] = bacc1[i]; }
-  for (int i = threadIdx.x; i < (Np - g.N) * CW; i += WGT) s_dl[g.N * CW + i] = 0.f;   // padded positions, once
+  // once: zeros (delta's halo columns and tail, the input's tail stay zero for every sample), maps
+  for (int i = threadIdx.x; i < NQ * CW + NIN * (FIRST ? 1 : CW); i += WGT) s_dw[i] = 0.f;
   if (threadIdx.x < CW) s_one[threadIdx.x] = threadIdx.x < 16 ? 1.f : 0.f;
   for (int i = threadIdx.x; i < NPAD; i += WGT) {
     const int p1 = i / D2p, p2 = i - p1 * D2p;
     s_map[i] = wrap(p1 - g.lo, g.D1) * g.D2 + wrap(p2 - g.lo2, g.D2);
   }
+  for (int i = threadIdx.x; i < g.N; i += WGT) {
+    const int a1 = i / g.D2;
+    s_pos[i] = a1 * D2p + (i - a1 * g.D2);
+  }
+  __syncthreads();
   // one flattened item list per sample: delta, then (layers > 0) the input with its halo
-  const int in_off = Np * CW;                      // s_in relative to s_dw, in floats
+  const int in_off = NQ * CW;                      // s_in relative to s_dw, in floats
   const int nd = GQ * g.N, ntot = nd + (FIRST ? 0 : GQ * NPAD);
   auto item = [&](int i, int& soff, int& dst) {
     const bool isd = i < nd;
     const int k = isd ? i : i - nd;
     const int gq = k & (GQ - 1), ps = k / GQ;
     const int site = isd ? ps : s_map[ps];
+    const int q = isd ? s_pos[ps] : ps;
     soff = gq * g.GS + 4 * site;
-    dst = (isd ? 0 : in_off) + ps * CW + 4 * gq;
+    dst = (isd ? 0 : in_off) + q * CW + 4 * gq;
   };
   auto put = [&](int dst, f32x4 v) {
     if (tape_is_z && dst >= in_off) {
@@ -822,44 +834,25 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
       pre[j] = *(const f32x4*)((dst < in_off ? dsrc : isrc) + soff);
     }
   };
-  // position c + gl in the padded layout, advanced by 4 positions per iteration
-  const int a1_0 = gl / g.D2, a2_0 = gl - a1_0 * g.D2;
-  int tapoff0[FIRST ? T0 : 1];                     // first layer: lane m = tap 16 tt + m
-  if (FIRST) {
-#pragma unroll
-    for (int tt = 0; tt < T0; ++tt) {
-      int tap = 16 * tt + ml;
-      tap = tap < KK ? tap : 0;
-      tapoff0[tt] = (tap / KW) * D2p + tap % KW;
-    }
-  }
-  // layers > 0, per item: operand pointer less the position term.  Every read is unconditional (a
-  // select on a wave-uniform condition would become a branch around the read): the bias item reads
-  // the ones row, an empty slot tap 0
-  const float* srcb[TPW];
-  bool isb[TPW];
+  // per item: A operand pointer of this lane at position quad 0, and its advance per quad.  Layers
+  // > 0: lane (ml, gl) = (cin, position), item = tap or bias (the ones row, which does not advance);
+  // an empty slot reads tap 0 and is not multiplied.  First layer: lane ml = tap 16 tt + ml
+  int ap0[TPW], astep[TPW];                        // offsets into s_dw, in floats (LDS address space kept)
+  const int one_off = (int)(s_one - s_dw), sin_off = (int)(s_in - s_dw);
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    const int it = wave + i * DW_WAVES;            // wave-uniform
-    const int tp = it < KK ? it : 0;
-    isb[i] = it == KK;
-    srcb[i] = isb[i] ? s_one + ml : s_in + ml + ((tp / KW) * D2p + tp % KW) * CW;
+    if (FIRST) {
+      int tap = 16 * (wave + i * DW_WAVES) + ml;
+      tap = tap < KK ? tap : 0;
+      ap0[i] = sin_off + gl + (tap / KW) * D2p + tap % KW;
+      astep[i] = 4;
+    } else {
+      const int it = wave + i * DW_WAVES;          // wave-uniform
+      const int tp = it < KK ? it : 0;
+      ap0[i] = it == KK ? one_off + ml : sin_off + ml + (gl + (tp / KW) * D2p + tp % KW) * CW;
+      astep[i] = it == KK ? 0 : 4 * CW;
+    }
   }
-  auto read_quad = [&](int c, int a1, int a2, float (&dv)[NCB], float (&av)[TPW][NCB]) {
-    const int pos = min(c + gl, Np - 1);           // (the quad past the end is read and dropped)
-    const bool pv = c + gl < g.N;
-#pragma unroll
-    for (int co = 0; co < NCB; ++co) dv[co] = s_dl[pos * CW + 16 * co + ml];   // padded positions hold zeros
-    const int boff = pv ? (a1 * D2p + a2) * CW : 0;   // padded layout: (a1 + t1, a2 + t2), no wrap
-#pragma unroll
-    for (int i = 0; i < TPW; ++i)
-#pragma unroll
-      for (int ci = 0; ci < NCB; ++ci) {
-        const float x = srcb[i][(isb[i] ? 0 : boff) + 16 * ci];
-        av[i][ci] = pv ? x : 0.f;                  // padded positions: delta is zero as well
-      }
-  };
-  __syncthreads();                                 // s_map
   if (b0 < b1) prefetch(b0);
   for (int b = b0; b < b1; b += bstep) {
     __syncthreads();
@@ -888,74 +881,58 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
     const float wb = wb_next;
     __syncthreads();
     if (b + bstep < b1) prefetch(b + bstep);
-    int a1 = a1_0, a2 = a2_0;
-    if (FIRST) {
-      // A = spin at the tap-shifted position, lane m = tap 16 tt + m (tap tiles over waves); the
-      // bias (A = ones) on the last wave
-      for (int c = 0; c < Np; c += 4) {
-        const int pos = c + gl;
-        const bool pv = pos < g.N;
-        float dv[NCB], dv2[NCB];
+    // the walk over position quads, operands read one quad ahead
+    int dp = gl * CW + ml;
+    int ap[TPW];
 #pragma unroll
-        for (int co = 0; co < NCB; ++co) {
-          dv[co] = s_dl[pos * CW + 16 * co + ml];
-          dv2[co] = dv[co] * wb;
-        }
-        const int base = pv ? a1 * D2p + a2 : 0;
-        a2 += 4;
-        if (a2 >= g.D2) { a2 -= g.D2; ++a1; }
-        if (a2 >= g.D2) { a2 -= g.D2; ++a1; }
+    for (int i = 0; i < TPW; ++i) ap[i] = ap0[i];
+    float dv[NCB], av[TPW][CI], dvn[NCB], avn[TPW][CI];
 #pragma unroll
-        for (int tt = 0; tt < T0; ++tt) {
-          if ((tt % DW_WAVES) == wave) {
-            const float av = pv ? s_in[base + tapoff0[tt]] : 0.f;
+    for (int co = 0; co < NCB; ++co) dv[co] = s_dw[dp + 16 * co];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int ci = 0; ci < CI; ++ci) av[i][ci] = s_dw[ap[i] + 16 * ci];
+    for (int q = 0; q < NQ; q += 4) {
+      dp += 4 * CW;                                // (the quad past the end reads the input region: dropped)
+#pragma unroll
+      for (int co = 0; co < NCB; ++co) dvn[co] = s_dw[dp + 16 * co];
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        ap[i] += astep[i];
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) avn[i][ci] = s_dw[ap[i] + 16 * ci];
+      }
+      float dv2[NCB];
+#pragma unroll
+      for (int co = 0; co < NCB; ++co) dv2[co] = dv[co] * wb;
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const bool full = FIRST ? (i * DW_WAVES + DW_WAVES - 1 < T0) : (i * DW_WAVES + DW_WAVES - 1 < NI);
+        if (full || wave + i * DW_WAVES < (FIRST ? T0 : NI)) {   // last slot: partly filled (wave-uniform)
+#pragma unroll
+          for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
             for (int co = 0; co < NCB; ++co) {
-              const int ai = (tt / DW_WAVES) * NCB + co;
-              if (BOTH) acc1[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv[co], acc1[ai], 0, 0, 0);
-              acc2[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dv2[co], acc2[ai], 0, 0, 0);
+              const int ai = (i * CI + ci) * NCB + co;
+              if (BOTH) acc1[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][ci], dv[co], acc1[ai], 0, 0, 0);
+              acc2[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][ci], dv2[co], acc2[ai], 0, 0, 0);
             }
-          }
-        }
-        if (wave == DW_WAVES - 1) {
-#pragma unroll
-          for (int co = 0; co < NCB; ++co) {
-            if (BOTH) bacc1[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv[co], bacc1[co], 0, 0, 0);
-            bacc2[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv2[co], bacc2[co], 0, 0, 0);
-          }
         }
       }
-    } else {
-      float dv[NCB], av[TPW][NCB], dvn[NCB], avn[TPW][NCB];
-      read_quad(0, a1, a2, dv, av);
-      for (int c = 0; c < Np; c += 4) {
-        a2 += 4;
-        if (a2 >= g.D2) { a2 -= g.D2; ++a1; }
-        if (a2 >= g.D2) { a2 -= g.D2; ++a1; }
-        read_quad(c + 4, a1, a2, dvn, avn);
-        float dv2[NCB];
+      if (FIRST && wave == DW_WAVES - 1) {
 #pragma unroll
-        for (int co = 0; co < NCB; ++co) dv2[co] = dv[co] * wb;
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-          if (i * DW_WAVES + DW_WAVES - 1 < NI || wave + i * DW_WAVES < NI) {   // last slot: partly filled
-#pragma unroll
-            for (int ci = 0; ci < NCB; ++ci)
-#pragma unroll
-              for (int co = 0; co < NCB; ++co) {
-                const int ai = (i * NCB + ci) * NCB + co;
-                if (BOTH) acc1[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][ci], dv[co], acc1[ai], 0, 0, 0);
-                acc2[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][ci], dv2[co], acc2[ai], 0, 0, 0);
-              }
-          }
+        for (int co = 0; co < NCB; ++co) {
+          if (BOTH) bacc1[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv[co], bacc1[co], 0, 0, 0);
+          bacc2[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv2[co], bacc2[co], 0, 0, 0);
         }
-#pragma unroll
-        for (int co = 0; co < NCB; ++co) dv[co] = dvn[co];
-#pragma unroll
-        for (int i = 0; i < TPW; ++i)
-#pragma unroll
-          for (int ci = 0; ci < NCB; ++ci) av[i][ci] = avn[i][ci];
       }
+#pragma unroll
+      for (int co = 0; co < NCB; ++co) dv[co] = dvn[co];
+#pragma unroll
+      for (int i = 0; i < TPW; ++i)
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) av[i][ci] = avn[i][ci];
     }
   }
   // partial sums: ws[slice][layer][2][(KK*CW + 1) * CW]: row (tap * CW + cin) or KK*CW = bias, col cout
@@ -965,19 +942,20 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
   float* w2 = w1 + rows * CW;
   if (FIRST) {
 #pragma unroll
-    for (int tt = 0; tt < T0; ++tt)
-      if ((tt % DW_WAVES) == wave)
+    for (int i = 0; i < TPW; ++i) {
+      const int tt = wave + i * DW_WAVES;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int tap = 16 * tt + 4 * gl + r;        // accumulator row = tap
-          if (tap < KK) {
+      for (int r = 0; r < 4; ++r) {
+        const int tap = 16 * tt + 4 * gl + r;          // accumulator row = tap
+        if (tt < T0 && tap < KK) {
 #pragma unroll
-            for (int co = 0; co < NCB; ++co) {
-              if (BOTH) w1[(size_t)tap * CW * CW + 16 * co + ml] = acc1[(tt / DW_WAVES) * NCB + co][r];   // cin 0
-              w2[(size_t)tap * CW * CW + 16 * co + ml] = acc2[(tt / DW_WAVES) * NCB + co][r];
-            }
+          for (int co = 0; co < NCB; ++co) {
+            if (BOTH) w1[(size_t)tap * CW * CW + 16 * co + ml] = acc1[i * NCB + co][r];   // cin 0
+            w2[(size_t)tap * CW * CW + 16 * co + ml] = acc2[i * NCB + co][r];
           }
         }
+      }
+    }
     if (wave == DW_WAVES - 1 && gl == 0) {
 #pragma unroll
       for (int co = 0; co < NCB; ++co) {

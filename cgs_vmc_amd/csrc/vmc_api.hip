@@ -866,7 +866,13 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     }
     c->ctape_stride = B * cg.CS; c->cdelta_stride = B * cg.CS;
     CA(dalloc(&c->ctape, nl * c->ctape_stride)); CA(dalloc(&c->cdelta, (long long)cg.n_conv * c->cdelta_stride));
-    c->c_slices = B < 64 ? (int)B : 64;
+    {
+      // two resident workgroups per CU (NCB = 1) over the layers > 0, whose workgroups carry the work
+      const int per_cu = cg.NCB == 1 ? 2 : 1, heavy = cg.n_conv > 1 ? cg.n_conv - 1 : 1;
+      int sl = (per_cu * c->num_cus + heavy - 1) / heavy;
+      sl = sl < 64 ? 64 : (sl > 256 ? 256 : sl);
+      c->c_slices = B < sl ? (int)B : sl;
+    }
     CA(dalloc(&c->cws, (long long)c->c_slices * cg.n_conv * 2 * (KK * 16 * cg.NCB + 1) * 16 * cg.NCB));
   }
   CA(hipStreamSynchronize(c->stream));
