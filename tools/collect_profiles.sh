@@ -19,8 +19,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BS > $OUT
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $B > $OUT/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1
-python3 $ROOT/bench.py --workload $WL > $OUT/bench.json 2> $OUT/bench.err
+# summarise first and put the fresh traffic file where bench.py looks for it, so that the bench line
+# kept with the profile carries these counters (roofline.pmc.stale = false), then add the line
 cd "$ROOT" && python3 tools/summarise_profiles.py "$TAG"
+cp "$ROOT/gpurun_out/${TAG}_summary/${TAG}_traffic.json" "$ROOT/profiles/"
+python3 $ROOT/bench.py --workload $WL > $OUT/bench.json 2> $OUT/bench.err
+python3 tools/summarise_profiles.py "$TAG"
 # raw counter dumps are large; the summaries under gpurun_out/<tag>_summary are what is kept.
 # Reached only when every pass and the summary succeeded (set -e): a failed run keeps its dumps.
 rm -rf "$OUT/pmc_sq" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/stats"
