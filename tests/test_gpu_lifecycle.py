@@ -6,10 +6,14 @@ tools/lifecycle_probe.py (a FRESH process, torch untouched) creates and destroys
 ansatz types -- dense, padded, rbm, conv_2d, the general wide path -- each doing a sweep, an
 accumulate and an external amplitude call, and prints open file descriptors, memory mappings,
 resident memory, threads and the device's free memory (hipMemGetInfo) every 20 cycles; then torch
-initialises its context and runs a kernel.  Measured on MI355X (round 3): every column is flat from
-cycle 20 to cycle 499 and torch starts normally; the whole GPU suite is green without the pre-init,
-which is gone.  The one-off failure could not be reproduced and is not a leak in vmc_create /
-vmc_destroy."""
+initialises its context and runs a kernel.  Measured on MI355X (round 3): descriptors, threads and
+device memory are flat from cycle 20 on and torch starts normally; the whole GPU suite is green without
+the pre-init, which is gone.  Resident memory is flat too, except for up to three one-off steps of
+173 MB at no fixed cycle: the probe prints the new mappings at such a step -- one anonymous 173.4 MB
+arena plus a 1 MB shared ring and a /dev/dri doorbell page, i.e. the HIP runtime bringing up another
+of its (at most four) hardware queues for a newly created stream; 1000 cycles show no fourth step.  A
+leak would show in every 20-cycle interval instead.  The one-off failure could not be reproduced and
+is not a leak in vmc_create / vmc_destroy."""
 import os
 import subprocess
 import sys
@@ -33,6 +37,12 @@ def test_500_engine_life_cycles_leak_nothing_and_torch_starts_afterwards():
   assert last[0] == 499
   fds, maps, rss, thr, free = (last[i] - base[i] for i in range(1, 6))
   assert fds <= 0 and thr <= 0, (base, last)
-  assert maps <= 8, (base, last)                    # memory mappings
-  assert rss <= 64, (base, last)                    # MB of host memory
   assert free >= -64, (base, last)                  # MB of device memory
+  # host memory: flat in (almost) every 20-cycle interval; the runtime's further hardware queues (at
+  # most three more, 173 MB and 6 mappings each) are the only steps allowed
+  tail = [r for r in rows if r[0] >= 20]
+  steps = [b[3] - a[3] for a, b in zip(tail, tail[1:])]
+  grew = [d for d in steps if d > 2]
+  assert len(grew) <= 3 and all(d <= 200 for d in grew), steps
+  assert rss <= 64 + 200 * len(grew), (base, last)
+  assert maps <= 8 + 8 * len(grew), (base, last)    # memory mappings

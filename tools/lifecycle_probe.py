@@ -58,6 +58,7 @@ def main():
            dict(n_sites=16, batch_size=64, num_layers=2, layer_size=300)]
   bonds = [(i, (i + 1) % 16) for i in range(16)]
   print('cycle fds maps rss_MB threads dev_free_MB')
+  seen_maps, last_rss = None, 0
   for k in range(cycles):
     spec = specs[k % len(specs)]
     eng = VmcEngine(seed=k, **spec)
@@ -72,7 +73,15 @@ def main():
     eng.amplitude(cfg[:7])
     eng.close()
     if k % 20 == 0 or k == cycles - 1:
-      print(k, *proc_stats(), dev_free(), flush=True)
+      st = proc_stats()
+      print(k, *st, dev_free(), flush=True)
+      with open('/proc/self/maps') as f:
+        now = set(line.strip() for line in f)
+      if seen_maps is not None and st[2] - last_rss > 50:      # a step in resident memory: which mappings are new
+        for line in sorted(now - seen_maps):
+          lo, hi = (int(x, 16) for x in line.split()[0].split('-'))
+          print('  new mapping {:8.1f} MB  {}'.format((hi - lo) / 2**20, ' '.join(line.split()[1:])), flush=True)
+      seen_maps, last_rss = now, st[2]
   print('fd kinds:', fd_kinds())
   import torch
   try:
