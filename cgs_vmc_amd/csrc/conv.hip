@@ -157,15 +157,28 @@ hipError_t launch_conv_back(hipStream_t s, const ConvBackArgs& a, int num_cus) {
   return conv_launch_back_t<1>(s, a, grid, lds);
 }
 
-hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a) {
+// LDS of the weight-gradient kernel for bands of `rows` lattice rows: delta [NQ][CW] + input
+// [NIN][CW] in one padded site numbering, the halo and position maps, ones (+ 8 sites: the operands
+// of the quad past the end are read, and dropped)
+static size_t conv_dw_lds(const ConvGeom& g, int rows) {
+  const size_t d2p = (size_t)g.D2 + g.KW - 1, npad = (size_t)(g.D1 + g.K - 1) * d2p;
+  const size_t nq = ((size_t)rows * d2p + 3) & ~(size_t)3, nin = nq + (size_t)(g.K - 1) * d2p + g.KW;
+  const size_t cw = 16 * (size_t)g.NCB;
+  return (nq * cw + nin * cw + npad + g.N + cw + 8 * cw) * sizeof(float);
+}
+
+hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a_in) {
+  ConvDwArgs a = a_in;
   const dim3 grid(a.n_slices, a.g.n_conv);
-  // delta [NQ][CW] + input [NIN][CW] in one padded site numbering, the halo and position maps, ones
-  const size_t d2p = (size_t)a.g.D2 + a.g.KW - 1, npad = (size_t)(a.g.D1 + a.g.K - 1) * d2p;
-  const size_t nq = ((size_t)a.g.D1 * d2p + 3) & ~(size_t)3, nin = nq + (size_t)(a.g.K - 1) * d2p + a.g.KW;
-  const size_t cw = 16 * (size_t)a.g.NCB;
-  // (+ 8 sites: the operands of the quad past the end are read, and dropped)
-  const size_t lds = (nq * cw + nin * cw + npad + a.g.N + cw + 8 * cw) * sizeof(float);
-  if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;
+  // the whole sample at once when it fits (two workgroups per CU at 16 filters when THAT fits), else
+  // the largest band of rows that does
+  const size_t cap = (size_t)160 * 1024;
+  a.band_rows = a.g.D1;
+  if (const char* e = getenv("CGS_VMC_CONV_DW_BAND"))      // test knob: force bands of this many rows
+    if (atoi(e) >= 1 && atoi(e) < a.band_rows) a.band_rows = atoi(e);
+  while (a.band_rows > 1 && conv_dw_lds(a.g, a.band_rows) > cap) --a.band_rows;
+  const size_t lds = conv_dw_lds(a.g, a.band_rows);
+  if (lds > cap) return hipErrorInvalidValue;
   hipError_t e = a.g.NCB == 2 ? conv_launch_dw_cb2(s, a, grid, lds) : conv_launch_dw_t<1>(s, a, grid, lds);
   if (e != hipSuccess) return e;
   const long long np_max = (long long)a.g.K * a.g.KW * a.g.F * a.g.F + a.g.F;

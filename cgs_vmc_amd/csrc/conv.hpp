@@ -107,6 +107,7 @@ struct ConvDwArgs {
   int n_slices;             // sample slices = gridDim.x
   float* ws;                // [n_slices][n_conv][2][(K*K*16 NCB + 1) * 16 NCB] partial sums
   float* g1; float* g2;     // accumulators (theta layout), += on reduce; g1 == nullptr: weighted sum only
+  int band_rows;            // lattice rows staged at a time (set by launch_conv_dw: all of them when LDS allows)
 };
 
 // stochastic reconfiguration (extension): t[row] = O_row . p over the stored samples

@@ -767,7 +767,9 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ml = lane & 15, gl = lane >> 4;
   const int D2p = g.D2 + KW - 1, NPAD = (g.D1 + K - 1) * D2p;
-  const int NQ = (g.D1 * D2p + 3) & ~3;            // positions walked (padded numbering), whole quads
+  // a sample is taken in bands of RB lattice rows (all of them when that fits LDS: a.band_rows)
+  const int RB = a.band_rows, nbands = (g.D1 + RB - 1) / RB;
+  const int NQ = (RB * D2p + 3) & ~3;              // positions walked per band (padded numbering), whole quads
   const int NIN = NQ + (K - 1) * D2p + KW;         // input sites a product can touch
   // LDS: delta [NQ][CW]; input [NIN][CW] (first layer: spins, one float per site); the halo map
   // (source site of every padded input site), the position map (padded number of every site), ones
@@ -796,15 +798,18 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
     s_pos[i] = a1 * D2p + (i - a1 * g.D2);
   }
   __syncthreads();
-  // one flattened item list per sample: delta, then (layers > 0) the input with its halo
+  // one flattened item list per (sample, band): delta rows [r0, r0 + rows), then (layers > 0) the
+  // input's padded rows [r0, r0 + rows + K - 1)
   const int in_off = NQ * CW;                      // s_in relative to s_dw, in floats
-  const int nd = GQ * g.N, ntot = nd + (FIRST ? 0 : GQ * NPAD);
-  auto item = [&](int i, int& soff, int& dst) {
+  auto band_rows_of = [&](int r0) { return min(RB, g.D1 - r0); };
+  auto band_nd = [&](int rows) { return GQ * rows * g.D2; };
+  auto band_ntot = [&](int rows) { return GQ * rows * g.D2 + (FIRST ? 0 : GQ * (rows + K - 1) * D2p); };
+  auto item = [&](int i, int r0, int nd, int& soff, int& dst) {
     const bool isd = i < nd;
     const int k = isd ? i : i - nd;
-    const int gq = k & (GQ - 1), ps = k / GQ;
-    const int site = isd ? ps : s_map[ps];
-    const int q = isd ? s_pos[ps] : ps;
+    const int gq = k & (GQ - 1), ps = k / GQ;      // ps: site within the band / padded site within the band
+    const int site = isd ? r0 * g.D2 + ps : s_map[r0 * D2p + ps];
+    const int q = isd ? s_pos[site] - r0 * D2p : ps;
     soff = gq * g.GS + 4 * site;
     dst = (isd ? 0 : in_off) + q * CW + 4 * gq;
   };
@@ -820,17 +825,19 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
   // lattice with k = 5 has 1184 items at 16 filters, 2368 at 32); larger lattices stage the rest late
   f32x4 pre[U];
   float wb_next = 0.f, spin_next = 0.f;
-  auto prefetch = [&](int b) {
+  auto prefetch = [&](int b, int r0) {
     const float* dsrc = a.delta + (long long)l * a.delta_stride + (long long)b * g.CS;
     const float* isrc = a.tape + (long long)(FIRST ? 0 : l - 1) * a.tape_stride + (long long)b * g.CS;
+    const int rows = band_rows_of(r0), nd = band_nd(rows), ntot = band_ntot(rows);
     wb_next = a.w[b];
-    if (FIRST) spin_next = a.configs[(long long)b * g.N + s_map[min((int)threadIdx.x, NPAD - 1)]];
+    if (FIRST)
+      spin_next = a.configs[(long long)b * g.N + s_map[r0 * D2p + min((int)threadIdx.x, (rows + K - 1) * D2p - 1)]];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       // items past the end repeat the last one and are never stored
       const int i = min((int)threadIdx.x + j * WGT, ntot - 1);
       int soff, dst;
-      item(i, soff, dst);
+      item(i, r0, nd, soff, dst);
       pre[j] = *(const f32x4*)((dst < in_off ? dsrc : isrc) + soff);
     }
   };
@@ -853,15 +860,18 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
       astep[i] = it == KK ? 0 : 4 * CW;
     }
   }
-  if (b0 < b1) prefetch(b0);
-  for (int b = b0; b < b1; b += bstep) {
+  if (b0 < b1) prefetch(b0, 0);
+  for (int b = b0; b < b1; b += bstep)
+  for (int r0 = 0; r0 < g.D1; r0 += RB) {
+    const int rows = band_rows_of(r0), nd = band_nd(rows), ntot = band_ntot(rows);
+    const int nq = (rows * D2p + 3) & ~3;          // positions walked in this band
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       const int i = threadIdx.x + j * WGT;
       if (i < ntot) {
         int soff, dst;
-        item(i, soff, dst);
+        item(i, r0, nd, soff, dst);
         put(dst, pre[j]);
       }
     }
@@ -870,17 +880,24 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
       const float* isrc = a.tape + (long long)(FIRST ? 0 : l - 1) * a.tape_stride + (long long)b * g.CS;
       for (int i = threadIdx.x + U * WGT; i < ntot; i += WGT) {
         int soff, dst;
-        item(i, soff, dst);
+        item(i, r0, nd, soff, dst);
         put(dst, *(const f32x4*)((dst < in_off ? dsrc : isrc) + soff));
       }
     }
     if (FIRST) {
-      if ((int)threadIdx.x < NPAD) s_in[threadIdx.x] = spin_next;
-      for (int i = threadIdx.x + WGT; i < NPAD; i += WGT) s_in[i] = a.configs[(long long)b * g.N + s_map[i]];
+      const int nsp = (rows + K - 1) * D2p;
+      if ((int)threadIdx.x < nsp) s_in[threadIdx.x] = spin_next;
+      for (int i = threadIdx.x + WGT; i < nsp; i += WGT) s_in[i] = a.configs[(long long)b * g.N + s_map[r0 * D2p + i]];
     }
+    // a short last band: the walk's last quad may reach into rows an earlier band wrote
+    if (rows < RB && (int)threadIdx.x < (nq - rows * D2p) * CW) s_dl[rows * D2p * CW + threadIdx.x] = 0.f;
     const float wb = wb_next;
     __syncthreads();
-    if (b + bstep < b1) prefetch(b + bstep);
+    {
+      const bool more_bands = r0 + RB < g.D1;
+      const int nb = more_bands ? b : b + bstep, nr0 = more_bands ? r0 + RB : 0;
+      if (nb < b1) prefetch(nb, nr0);
+    }
     // the walk over position quads, operands read one quad ahead
     int dp = gl * CW + ml;
     int ap[TPW];
@@ -893,7 +910,7 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
     for (int i = 0; i < TPW; ++i)
 #pragma unroll
       for (int ci = 0; ci < CI; ++ci) av[i][ci] = s_dw[ap[i] + 16 * ci];
-    for (int q = 0; q < NQ; q += 4) {
+    for (int q = 0; q < nq; q += 4) {
       dp += 4 * CW;                                // (the quad past the end reads the input region: dropped)
 #pragma unroll
       for (int co = 0; co < NCB; ++co) dvn[co] = s_dw[dp + 16 * co];

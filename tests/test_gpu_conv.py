@@ -196,6 +196,66 @@ def test_conv_energy_gradient_accumulators(ansatz, sx, sy, L, f, k, b, nonlin):
   eng.close()
 
 
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', [
+    ('conv_2d', 6, 5, 3, 16, 3, 37, 'relu'),
+    ('conv_2d', 5, 6, 2, 24, 4, 21, 'cos'),           # two channel blocks, even kernel, pre-activation tape
+    ('res_net_2d', 4, 6, 2, 8, 5, 19, 'relu'),
+    ('conv_1d', 13, 1, 3, 12, 5, 14, 'tanh'),
+])
+def test_conv_weight_gradient_in_row_bands(ansatz, sx, sy, L, f, k, b, nonlin, monkeypatch):
+  """Lattices whose padded sample does not fit the LDS of the weight-gradient kernel are staged in
+  bands of rows (conv.hip: launch_conv_dw).  CGS_VMC_CONV_DW_BAND forces bands on small lattices: bands
+  of 1, 2 and 4 rows (a short last band included) give the sums of the unbanded run up to the order of
+  summation, and both match the oracle."""
+  from cgs_vmc_amd import _hip
+  outs = []
+  for band in (None, 1, 2, 4):
+    if band is None:
+      monkeypatch.delenv('CGS_VMC_CONV_DW_BAND', raising=False)
+    else:
+      monkeypatch.setenv('CGS_VMC_CONV_DW_BAND', str(band))
+    eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+    eng.reset_accumulators()
+    eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+    outs.append(eng.get_accumulators())
+    eng.close()
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, geom, L, np.float64,
+                                ansatz=ansatz, nonlinearity=nonlin)
+  p = theta.size
+  for got in outs:
+    for name, g, r in (('g1', got[:p], acc.g1_total), ('g2', got[p:2 * p], acc.g2_total)):
+      tol = 2e-3 * np.abs(r).max() + 1e-4
+      assert np.abs(g - r).max() < tol, (name, np.abs(g - r).max(), tol)
+  for got in outs[1:]:
+    assert np.abs(got[:2 * p] - outs[0][:2 * p]).max() <= 2e-5 * np.abs(outs[0][:2 * p]).max()
+
+
+@pytest.mark.parametrize('sx,sy,f,k', [(32, 32, 16, 5), (24, 24, 32, 5), (30, 36, 16, 3)])
+def test_conv_weight_gradient_on_the_largest_lattices(sx, sy, f, k):
+  """The largest lattices the forward kernels take (one sample's feature maps in LDS): their padded
+  samples exceed the weight-gradient kernel's LDS, which then walks them in bands of rows on its own.
+  A handful of bonds keeps the oracle's local energies cheap; the sums are over every site."""
+  from cgs_vmc_amd import _hip
+  L, b, ansatz, nonlin = 2, 5, 'conv_2d', 'relu'
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin, noise=0.01)
+  bonds = [bonds[i] for i in range(0, len(bonds), max(1, len(bonds) // 12))][:12]
+  eng.set_bonds(bonds, -1.0, 1.0)
+  theta = (0.5 * theta).astype(np.float32)            # keeps exp(logit) of ~1000 sites inside fp64 for the oracle
+  eng.set_params(theta)
+  acc = vo.Accumulators(theta.size, np.float64)
+  eng.reset_accumulators()
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, geom, L, np.float64,
+                                ansatz=ansatz, nonlinearity=nonlin)
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  got = eng.get_accumulators()
+  p = theta.size
+  for name, g, r in (('g1', got[:p], acc.g1_total), ('g2', got[p:2 * p], acc.g2_total)):
+    tol = 2e-3 * np.abs(r).max() + 1e-4
+    assert np.abs(g - r).max() < tol, (name, np.abs(g - r).max(), tol)
+  eng.close()
+
+
 @pytest.mark.parametrize('ansatz', ['conv_2d', 'res_net_2d'])
 def test_conv_log_overlap_itswo_accumulators(ansatz):
   from cgs_vmc_amd import _hip
