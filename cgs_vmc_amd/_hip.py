@@ -97,6 +97,7 @@ SIGNATURES = {
     'vmc_rccl_comm_create': (C.c_int, [_bp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     'vmc_rccl_comm_destroy': (C.c_int, [C.c_void_p]),
     'vmc_rccl_last_error': (C.c_char_p, []),
+    'vmc_rccl_library_path': (C.c_char_p, []),
     'vmc_debug_allreduce': (C.c_int, [_ctx, C.c_void_p, C.c_int32, _fp, C.c_int64, C.c_int32]),
     'vmc_update_norm_dist': (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_float]),
     'vmc_epoch_energy_gradient_dist': (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,
@@ -182,6 +183,15 @@ def load():
     raise HipLibraryError(
         '{} was not built from the sources in {} (stamp mismatch): rebuild it with '
         '__graft_entry__.build() or `make -C cgs_vmc_amd/csrc`.'.format(_LIB_PATH, _CSRC))
+  # ONE HIP runtime per process.  torch bundles its own libamdhip64 (same soname as ROCm's): whichever is
+  # loaded first serves this library, and torch always loads its own -- so with this library first the
+  # process ends up with two runtimes (engines on one, torch on the other: "No HIP GPUs are available"
+  # from torch's late initialisation and aborts at exit have both been seen that way).  Loading torch
+  # first, where it is installed, makes every import order end in torch's single runtime.
+  try:
+    import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
+  except ImportError:
+    pass
   try:
     lib = C.CDLL(_LIB_PATH)
   except OSError as e:

@@ -312,8 +312,21 @@ int sr_wsum_slices(int R, int num_cus);
 hipError_t launch_sr_wsum(hipStream_t s, const float* A, long long lda, const float* D,
                           long long ldd, const float* t, float* ws, float* out, long long ldo,
                           float* bias_out, int M, int N, int R, int slices);
+// one row-dot problem: t(m) (= | +=) sum_n (A(m, :) V(:, n) + vb(n)) D(m, n)
+struct SrRowdotArgs {
+  const float* A; long long lda;      // A(m, k) = A[m * lda + k]: stored activations / chains
+  const float* V; long long ldv;      // V(k, n) = V[k * ldv + n]: weight slice of the CG direction
+  const float* vb;                    // [N] bias slice
+  const float* D; long long ldd;      // delta(m, n)
+  float* t;                           // [M]
+  int M, N, K;
+  int first;                          // 1: t = ..., 0: t += ...
+};
+hipError_t launch_sr_rowdot_batch(hipStream_t s, const SrRowdotArgs* probs, int count);
+// t = ((parts_0 + parts_1) + ...) + (x . v + vb)   (nparts == 0: t += x . v + vb)
 hipError_t launch_sr_row_linear(hipStream_t s, const float* x, long long ldx, const float* v,
-                                const float* vb, int R, int K, float* t);
+                                const float* vb, int R, int K, float* t, const float* parts, int nparts,
+                                long long pstride);
 hipError_t launch_sr_colsum(hipStream_t s, const float* x, long long ldx, const float* t, int R,
                             int K, float* ws, int slices, float* u, float* tsum);
 

@@ -20,16 +20,18 @@
 //                reduction runs over a slice of the samples (steps of 8); partial products go to a
 //                workspace that k_sr_wsum_reduce folds in slice order.
 #include "common.hpp"
+#include <cstring>
 #include <cstdlib>
 
-struct SrRowdotArgs {
-  const float* A; long long lda;      // A(m, k) = A[m * lda + k]: stored activations / chains
-  const float* V; long long ldv;      // V(k, n) = V[k * ldv + n]: weight slice of the CG direction
-  const float* vb;                    // [N] bias slice
-  const float* D; long long ldd;      // delta(m, n)
-  float* t;                           // [M]
-  int M, N, K;
-  int first;                          // 1: t = ..., 0: t += ...
+// several independent row-dot problems (the layers / column blocks of one matvec, each writing its
+// own t) in ONE launch: a single 204,800-sample problem is 1600 tiles = 6.25 rounds of 256 CUs, i.e.
+// a seventh round with a quarter of the chip; three of them back to back are 18.75 rounds.
+// Workgroup id -> (problem, tile) through first_tile (dispatch order: largest K first).
+#define RD_MAXB 16
+struct SrRowdotBatch {
+  SrRowdotArgs g[RD_MAXB];
+  int first_tile[RD_MAXB + 1];
+  int count;
 };
 
 struct SrWsumArgs {
@@ -57,13 +59,16 @@ namespace {
 // under a run-time branch makes every later use wait for ALL outstanding loads).  !VEC is the
 // general element-wise path.
 template <bool VEC>
-__global__ __launch_bounds__(512, 2) void k_sr_rowdot(SrRowdotArgs g) {
+__global__ __launch_bounds__(512, 2) void k_sr_rowdot(SrRowdotBatch bt) {
   __shared__ __attribute__((aligned(16))) float As[2][RD_K][RD_LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][RD_K][RD_LDB];
   __shared__ float s_part[2][RD_TM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * RD_TM;
+  int slot = 0;
+  while (slot + 1 < bt.count && (int)blockIdx.x >= bt.first_tile[slot + 1]) ++slot;   // block-uniform
+  const SrRowdotArgs g = bt.g[slot];
+  const int m0 = ((int)blockIdx.x - bt.first_tile[slot]) * RD_TM;
   const int T = (g.K + RD_K - 1) / RD_K;
 
   f32x16 acc[4];
@@ -330,49 +335,112 @@ __global__ __launch_bounds__(256) void k_sr_wsum_reduce(SrWsumArgs g) {
 }
 
 // t_b += a_L[b] . v_out + v_bout (fully_connected output layer) or x_b . v_on + v_bon (rbm onsite
-// layer): one wave per sample
+// layer): one wave per sample, four samples (16 loads) in flight per wave, grid-stride.  Per sample
+// the arithmetic is fixed: lane l sums k = l, l + 64, ... in order, then the xor tree.
 __global__ __launch_bounds__(256) void k_sr_row_linear(const float* __restrict__ x, long long ldx,
                                                        const float* __restrict__ v,
                                                        const float* __restrict__ vb, int R, int K,
-                                                       float* __restrict__ t) {
+                                                       float* __restrict__ t,
+                                                       const float* __restrict__ parts, int nparts,
+                                                       long long pstride) {
   const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= R) return;
-  float s = 0.f;
-  for (int k = lane; k < K; k += 64) s = fmaf(x[(long long)b * ldx + k], v[k], s);
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  const float bias = vb[0];
+  for (int b0 = 4 * wave; b0 < R; b0 += 4 * nwaves) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < K; k += 64) {
+      const float vk = v[k];
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-  if (lane == 0) t[b] += s + vb[0];
+      for (int j = 0; j < 4; ++j) {
+        const int b = min(b0 + j, R - 1);              // rows past the end repeat the last one (not stored)
+        s[j] = fmaf(x[(long long)b * ldx + k], vk, s[j]);
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += __shfl_xor(s[j], d);
+    }
+    if (lane < 4 && b0 + lane < R) {
+      // nparts > 0: t = ((part_0 + part_1) + ...) + this term -- the order in which the row-dot
+      // launches used to add into t one after the other
+      const int b = b0 + lane;
+      float acc = nparts > 0 ? parts[b] : t[b];
+      for (int j = 1; j < nparts; ++j) acc += parts[(long long)j * pstride + b];
+      t[b] = acc + ((lane == 0 ? s[0] : lane == 1 ? s[1] : lane == 2 ? s[2] : s[3]) + bias);
+    }
+  }
 }
 
 // u[0..K) = sum_b t_b x[b][0..K), u[K] = sum_b t_b (the N = 1 layer: [x | 1]^T t), and
-// tsum = sum_b t_b.  Two stages, fixed order: slices of the samples, then the slices.
+// tsum = sum_b t_b.  Two stages, fixed order: slices of the samples, then the slices.  A lane
+// carries four neighbouring columns (one 16-byte load per row: a wave reads a whole 256-column row
+// at once, K <= 256 here); wave w takes the samples b0 + w, b0 + w + 4, ..., four rows in flight,
+// each with its own accumulator -- the per-column order of additions is what it always was.
 #define CS_THREADS 256
+template <bool VEC>
 __global__ __launch_bounds__(CS_THREADS) void k_sr_colsum(const float* __restrict__ x, long long ldx,
                                                           const float* __restrict__ t, int R, int K,
                                                           float* __restrict__ ws /*[slices][K + 1]*/) {
-  __shared__ float s_acc[4][64];
+  __shared__ f32x4 s_acc[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int per = (R + gridDim.x - 1) / gridDim.x;
   const int b0 = blockIdx.x * per, b1 = min(R, b0 + per);
   float* out = ws + (long long)blockIdx.x * (K + 1);
-  // 64 columns at a time; wave w takes the samples b0 + w, b0 + w + 4, ..., four loads in flight
-  for (int k0 = 0; k0 < K; k0 += 64) {
-    const int k = min(k0 + lane, K - 1);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int b = b0 + wave;
-    for (; b + 12 < b1; b += 16) {
-      const float x0 = x[(long long)b * ldx + k], x1 = x[(long long)(b + 4) * ldx + k];
-      const float x2 = x[(long long)(b + 8) * ldx + k], x3 = x[(long long)(b + 12) * ldx + k];
-      a0 = fmaf(t[b], x0, a0); a1 = fmaf(t[b + 4], x1, a1);
-      a2 = fmaf(t[b + 8], x2, a2); a3 = fmaf(t[b + 12], x3, a3);
+  if (VEC) {
+    // (row stride a multiple of 4 floats, base 16-byte aligned: a vector that starts inside a row
+    // stays inside it; lanes past the row repeat its last vector and store nothing)
+    for (int k0 = 0; k0 < K; k0 += 256) {
+      const int kc = min(k0 + 4 * lane, (int)ldx - 4);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      f32x4 a0 = z, a1 = z, a2 = z, a3 = z;
+      int b = b0 + wave;
+      for (; b + 12 < b1; b += 16) {
+        const f32x4 x0 = *(const f32x4*)(x + (long long)b * ldx + kc), x1 = *(const f32x4*)(x + (long long)(b + 4) * ldx + kc);
+        const f32x4 x2 = *(const f32x4*)(x + (long long)(b + 8) * ldx + kc), x3 = *(const f32x4*)(x + (long long)(b + 12) * ldx + kc);
+        const float t0 = t[b], t1 = t[b + 4], t2 = t[b + 8], t3 = t[b + 12];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a0[e] = fmaf(t0, x0[e], a0[e]); a1[e] = fmaf(t1, x1[e], a1[e]);
+          a2[e] = fmaf(t2, x2[e], a2[e]); a3[e] = fmaf(t3, x3[e], a3[e]);
+        }
+      }
+      for (; b < b1; b += 4) {
+        const f32x4 x0 = *(const f32x4*)(x + (long long)b * ldx + kc);
+        const float t0 = t[b];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a0[e] = fmaf(t0, x0[e], a0[e]);
+      }
+      s_acc[wave][lane] = (a0 + a1) + (a2 + a3);
+      __syncthreads();
+      if (wave == 0 && k0 + 4 * lane == kc) {
+        const f32x4 r = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kc + e < K) out[kc + e] = r[e];
+      }
+      __syncthreads();
     }
-    for (; b < b1; b += 4) a0 = fmaf(t[b], x[(long long)b * ldx + k], a0);
-    s_acc[wave][lane] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (wave == 0 && k0 + lane < K)
-      out[k0 + lane] = (s_acc[0][lane] + s_acc[1][lane]) + (s_acc[2][lane] + s_acc[3][lane]);
-    __syncthreads();
+  } else {
+    // any row stride: 64 columns at a time, one float per lane
+    float* s_a = (float*)s_acc;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int k = min(k0 + lane, K - 1);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      int b = b0 + wave;
+      for (; b + 12 < b1; b += 16) {
+        const float x0 = x[(long long)b * ldx + k], x1 = x[(long long)(b + 4) * ldx + k];
+        const float x2 = x[(long long)(b + 8) * ldx + k], x3 = x[(long long)(b + 12) * ldx + k];
+        a0 = fmaf(t[b], x0, a0); a1 = fmaf(t[b + 4], x1, a1);
+        a2 = fmaf(t[b + 8], x2, a2); a3 = fmaf(t[b + 12], x3, a3);
+      }
+      for (; b < b1; b += 4) a0 = fmaf(t[b], x[(long long)b * ldx + k], a0);
+      s_a[wave * 64 + lane] = (a0 + a1) + (a2 + a3);
+      __syncthreads();
+      if (wave == 0 && k0 + lane < K)
+        out[k0 + lane] = (s_a[lane] + s_a[64 + lane]) + (s_a[128 + lane] + s_a[192 + lane]);
+      __syncthreads();
+    }
   }
   __shared__ float s_t[CS_THREADS];
   float a = 0.f;
@@ -403,22 +471,60 @@ __global__ __launch_bounds__(256) void k_sr_colsum_reduce(const float* __restric
 
 hipError_t launch_sr_colsum(hipStream_t s, const float* x, long long ldx, const float* t, int R,
                             int K, float* ws, int slices, float* u, float* tsum) {
-  hipLaunchKernelGGL(k_sr_colsum, dim3(slices), dim3(CS_THREADS), 0, s, x, ldx, t, R, K, ws);
+  if (ldx % 4 == 0 && ldx >= 4 && ((size_t)x & 15) == 0)
+    hipLaunchKernelGGL(k_sr_colsum<true>, dim3(slices), dim3(CS_THREADS), 0, s, x, ldx, t, R, K, ws);
+  else
+    hipLaunchKernelGGL(k_sr_colsum<false>, dim3(slices), dim3(CS_THREADS), 0, s, x, ldx, t, R, K, ws);
   hipLaunchKernelGGL(k_sr_colsum_reduce, dim3((K + 4) / 4), dim3(256), 0, s, ws, slices, K, u, tsum);
+  return hipGetLastError();
+}
+
+static bool rowdot_vec(const SrRowdotArgs& g) {
+  return (g.lda & 3) == 0 && (g.ldv & 3) == 0 && (g.K & 3) == 0 && (g.N & 3) == 0 && g.K >= 4 && g.N >= 4 &&
+         (((size_t)g.A | (size_t)g.V) & 15) == 0;
+}
+
+// count problems in as few launches as possible: one when they agree on the vector path and count
+// <= RD_MAXB (the usual case), else one per run of compatible problems
+hipError_t launch_sr_rowdot_batch(hipStream_t s, const SrRowdotArgs* probs, int count) {
+  int i = 0;
+  while (i < count) {
+    const bool vec = rowdot_vec(probs[i]);
+    int n = 1;
+    while (i + n < count && n < RD_MAXB && rowdot_vec(probs[i + n]) == vec) ++n;
+    // dispatch order: largest K first (list scheduling: the light tiles fill the end)
+    int order[RD_MAXB];
+    for (int j = 0; j < n; ++j) order[j] = i + j;
+    for (int a = 1; a < n; ++a)
+      for (int b2 = a; b2 > 0 && probs[order[b2]].K > probs[order[b2 - 1]].K; --b2) {
+        const int tmp = order[b2]; order[b2] = order[b2 - 1]; order[b2 - 1] = tmp;
+      }
+    SrRowdotBatch bt;
+    memset((void*)&bt, 0, sizeof(bt));
+    bt.count = n;
+    int tiles = 0;
+    for (int j = 0; j < n; ++j) {
+      const SrRowdotArgs& g = probs[order[j]];
+      if (g.N > RD_TN) return hipErrorInvalidValue;
+      bt.g[j] = g;
+      bt.first_tile[j] = tiles;
+      tiles += (g.M + RD_TM - 1) / RD_TM;
+    }
+    bt.first_tile[n] = tiles;
+    if (tiles > 0) {
+      if (vec) hipLaunchKernelGGL(k_sr_rowdot<true>, dim3(tiles), dim3(512), 0, s, bt);
+      else hipLaunchKernelGGL(k_sr_rowdot<false>, dim3(tiles), dim3(512), 0, s, bt);
+    }
+    i += n;
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_sr_rowdot(hipStream_t s, const float* A, long long lda, const float* V,
                             long long ldv, const float* vb, const float* D, long long ldd, float* t,
                             int M, int N, int K, bool first) {
-  if (N > RD_TN) return hipErrorInvalidValue;
   SrRowdotArgs g{A, lda, V, ldv, vb, D, ldd, t, M, N, K, first ? 1 : 0};
-  const bool vec = (lda & 3) == 0 && (ldv & 3) == 0 && (K & 3) == 0 && (N & 3) == 0 && K >= 4 && N >= 4 &&
-                   (((size_t)A | (size_t)V) & 15) == 0;
-  const dim3 grid((M + RD_TM - 1) / RD_TM);
-  if (vec) hipLaunchKernelGGL(k_sr_rowdot<true>, grid, dim3(512), 0, s, g);
-  else hipLaunchKernelGGL(k_sr_rowdot<false>, grid, dim3(512), 0, s, g);
-  return hipGetLastError();
+  return launch_sr_rowdot_batch(s, &g, 1);
 }
 
 int sr_wsum_slices(int R, int num_cus) {
@@ -444,7 +550,9 @@ hipError_t launch_sr_wsum(hipStream_t s, const float* A, long long lda, const fl
 }
 
 hipError_t launch_sr_row_linear(hipStream_t s, const float* x, long long ldx, const float* v,
-                                const float* vb, int R, int K, float* t) {
-  hipLaunchKernelGGL(k_sr_row_linear, dim3((R + 3) / 4), dim3(256), 0, s, x, ldx, v, vb, R, K, t);
+                                const float* vb, int R, int K, float* t, const float* parts, int nparts,
+                                long long pstride) {
+  const int blocks = (R + 15) / 16 < 2048 ? (R + 15) / 16 : 2048;      // 4 waves x 4 samples per pass
+  hipLaunchKernelGGL(k_sr_row_linear, dim3(blocks), dim3(256), 0, s, x, ldx, v, vb, R, K, t, parts, nparts, pstride);
   return hipGetLastError();
 }

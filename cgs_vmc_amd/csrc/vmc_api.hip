@@ -134,6 +134,7 @@ struct vmc_ctx {
   float *sr_cw0 = nullptr, *sr_cwf = nullptr, *sr_cwb = nullptr, *sr_cbias = nullptr;
   int sr_cslices = 0;
   float *sr_ws = nullptr, *sr_t = nullptr, *sr_ones = nullptr;        // [slices][(max(N,H)+1) H], [cap B] x2
+  float* sr_tpart = nullptr;                                          // [layers x column blocks][cap B] partial t
   float *sr_u = nullptr, *sr_x = nullptr, *sr_r = nullptr, *sr_p = nullptr, *sr_q = nullptr;
   double *sr_partial = nullptr, *sr_sc = nullptr;
   bool sr_begun = false;
@@ -571,11 +572,26 @@ const Rccl* rccl() {
   static bool tried = false, ok = false;
   if (!tried) {
     tried = true;
+    // The librccl that belongs to the HIP runtime THIS library is bound to: a process may hold two ROCm
+    // stacks (torch bundles libamdhip64 / librccl next to the system's, same sonames), and a
+    // communicator of the other stack's librccl would launch through the other runtime on this one's
+    // streams and buffers.  So: the directory of the libamdhip64 behind our hip* symbols first.
     void* h = nullptr;
-    for (const char* name : {"librccl.so.1", "librccl.so"})
-      if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-    for (const char* name : {"librccl.so.1", "librccl.so"})
-      if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+      std::string dir(info.dli_fname);
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) {
+        dir.resize(slash);
+        names.push_back(dir + "/librccl.so.1");
+        names.push_back(dir + "/librccl.so");
+      }
+    }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    for (const std::string& name : names)
+      if (!h) h = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (h) {
       r.all_reduce = (decltype(r.all_reduce))dlsym(h, "ncclAllReduce");
       r.get_unique_id = (decltype(r.get_unique_id))dlsym(h, "ncclGetUniqueId");
@@ -909,7 +925,7 @@ void vmc_destroy(vmc_ctx* c) {
   for (void* q : ptrs) if (q) hipFree(q);
   for (float* q : {c->sr_ctape, c->sr_cdelta, c->sr_cws, c->sr_cw0, c->sr_cwf, c->sr_cwb, c->sr_cbias}) if (q) hipFree(q);
   void* sr[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_u, c->sr_x, c->sr_r,
-                c->sr_p, c->sr_q, c->sr_partial, c->sr_sc, c->sr_ones};
+                c->sr_p, c->sr_q, c->sr_partial, c->sr_sc, c->sr_ones, c->sr_tpart};
   for (void* q : sr) if (q) hipFree(q);
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->d_stage) hipFree(c->d_stage);
@@ -1510,6 +1526,14 @@ int vmc_set_host_allreduce(vmc_ctx* c, vmc_host_allreduce_fn hook, void* user) {
 
 const char* vmc_rccl_last_error(void) { return g_rccl_error.c_str(); }
 
+const char* vmc_rccl_library_path(void) {
+  static std::string path;
+  const Rccl* r = rccl();
+  Dl_info info;
+  if (r && dladdr((void*)r->all_reduce, &info) && info.dli_fname) path = info.dli_fname;
+  return path.c_str();
+}
+
 int vmc_rccl_unique_id(uint8_t id[128]) {
   if (!id) { g_rccl_error = "null id"; return VMC_ERR_INVALID; }
   const Rccl* r = rccl();
@@ -1748,9 +1772,9 @@ int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   if (n_batches > 0 && (c->oact != VMC_ACT_EXP_ || (c->hact == VMC_ACT_COS_ && !c->conv)))
     return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation and every hidden activation except cos");
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_ones, c->sr_ctape, c->sr_cdelta, c->sr_cws};
+  void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_ones, c->sr_ctape, c->sr_cdelta, c->sr_cws, c->sr_tpart};
   for (void* q : old) if (q) hipFree(q);
-  c->sr_cfg = c->sr_act = c->sr_delta = c->sr_ws = c->sr_t = c->sr_ones = nullptr;
+  c->sr_cfg = c->sr_act = c->sr_delta = c->sr_ws = c->sr_t = c->sr_ones = c->sr_tpart = nullptr;
   c->sr_ctape = c->sr_cdelta = c->sr_cws = nullptr;
   c->sr_cap = 0; c->sr_n = 0; c->sr_begun = false;
   if (n_batches == 0) return VMC_OK;
@@ -1783,6 +1807,7 @@ int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   HIPCHK(c, dalloc(&c->sr_delta, L * R * Hp));
   HIPCHK(c, dalloc(&c->sr_ws, (long long)sr_wsum_slices((int)R, c->num_cus) * ((N > c->H ? N : c->H) + 1) * c->H));
   HIPCHK(c, dalloc(&c->sr_t, R)); HIPCHK(c, dalloc(&c->sr_ones, R));
+  HIPCHK(c, dalloc(&c->sr_tpart, L * ((c->H + 255) / 256) * R));
   HIPCHK(c, launch_fill(c->stream, c->sr_ones, 1.f, R));
   if (!c->sr_u) {
     HIPCHK(c, dalloc(&c->sr_u, P + 1)); HIPCHK(c, dalloc(&c->sr_x, P)); HIPCHK(c, dalloc(&c->sr_r, P));
@@ -1851,20 +1876,30 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
   }
   // t_b = O_b . p = sum_l delta_l[b] . (a_{l-1}[b] V_l + v_l) + (output / onsite layer term);
   // the row-dot kernel takes <= 256 output units at a time (257 .. 512 units: two column blocks)
-  for (int l = 0; l < L; ++l) {
-    const float* a_in = l == 0 ? c->sr_cfg : c->sr_act + (long long)(l - 1) * R * Hp;
-    for (int n0 = 0; n0 < H; n0 += 256) {
-      const int nb = H - n0 < 256 ? H - n0 : 256;
-      HIPCHK(c, launch_sr_rowdot(c->stream, a_in, l == 0 ? N : Hp, v + off_w(c, l) + n0, H, v + off_b(c, l) + n0,
-                                 c->sr_delta + (long long)l * R * Hp + n0, Hp, c->sr_t, rows, nb, l == 0 ? N : H,
-                                 l == 0 && n0 == 0));
+  // every (layer, column block) writes its own partial t: ONE launch for all of them (no round of
+  // the chip left a quarter full per layer); the output / onsite term folds the partials in the order
+  // in which they used to be added into t
+  {
+    std::vector<SrRowdotArgs> probs;
+    for (int l = 0; l < L; ++l) {
+      const float* a_in = l == 0 ? c->sr_cfg : c->sr_act + (long long)(l - 1) * R * Hp;
+      for (int n0 = 0; n0 < H; n0 += 256) {
+        const int nb = H - n0 < 256 ? H - n0 : 256;
+        SrRowdotArgs g{a_in, l == 0 ? N : Hp, v + off_w(c, l) + n0, H, v + off_b(c, l) + n0,
+                       c->sr_delta + (long long)l * R * Hp + n0, Hp, c->sr_tpart + (long long)probs.size() * R,
+                       rows, nb, (int)(l == 0 ? N : H), 1};
+        probs.push_back(g);
+      }
     }
+    HIPCHK(c, launch_sr_rowdot_batch(c->stream, probs.data(), (int)probs.size()));
+    const int np = (int)probs.size();
+    if (c->rbm)
+      HIPCHK(c, launch_sr_row_linear(c->stream, c->sr_cfg, N, v + c->lay.off_won, v + off_bout(c), rows, N, c->sr_t,
+                                     c->sr_tpart, np, R));
+    else
+      HIPCHK(c, launch_sr_row_linear(c->stream, c->sr_act + (long long)(L - 1) * R * Hp, Hp, v + off_wout(c),
+                                     v + off_bout(c), rows, H, c->sr_t, c->sr_tpart, np, R));
   }
-  if (c->rbm)
-    HIPCHK(c, launch_sr_row_linear(c->stream, c->sr_cfg, N, v + c->lay.off_won, v + off_bout(c), rows, N, c->sr_t));
-  else
-    HIPCHK(c, launch_sr_row_linear(c->stream, c->sr_act + (long long)(L - 1) * R * Hp, Hp, v + off_wout(c),
-                                   v + off_bout(c), rows, H, c->sr_t));
   // u = sum_b t_b O_b: per layer [a_{l-1} | 1]^T (t (.) delta_l), written in the theta layout, in
   // (<= 256 input rows) x (<= 256 output units) blocks; the bias row comes with the first row block
   const int slices = sr_wsum_slices(rows, c->num_cus);

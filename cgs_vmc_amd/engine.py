@@ -5,7 +5,10 @@ graph_builders / training / evaluation dispatch their op handles to it.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import sys
+import weakref
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -23,6 +26,20 @@ def _fptr(a: Optional[np.ndarray]):
 def _iptr(a: np.ndarray):
   assert a.dtype == np.int32 and a.flags['C_CONTIGUOUS']
   return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+_LIVE_ENGINES = weakref.WeakSet()
+
+
+def _close_live_engines():
+  for eng in list(_LIVE_ENGINES):
+    try:
+      eng.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+
+atexit.register(_close_live_engines)
 
 
 class VmcEngine:
@@ -52,6 +69,7 @@ class VmcEngine:
       msg = self._lib.vmc_last_error(None).decode()
       self._ctx = C.c_void_p()
       self._raise(rc, msg)
+    _LIVE_ENGINES.add(self)
     self.n_sites, self.batch_size = n_sites, batch_size
     self.num_layers, self.layer_size = num_layers, layer_size
     self.chain_offset, self.seed, self.device = chain_offset, seed, device
@@ -84,6 +102,11 @@ class VmcEngine:
       self._ctx = C.c_void_p()
 
   def __del__(self):
+    # engines still alive when the interpreter shuts down are closed by _close_live_engines (atexit,
+    # i.e. while the HIP runtime and librccl are certainly still up); a finalizer that runs later
+    # than that must not call into them any more
+    if sys.is_finalizing():
+      return
     try:
       self.close()
     except Exception:  # pylint: disable=broad-except

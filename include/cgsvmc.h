@@ -221,6 +221,12 @@ int vmc_rccl_comm_create(const uint8_t id[128], int32_t world_size, int32_t rank
                          void** nccl_comm);
 int vmc_rccl_comm_destroy(void* nccl_comm);
 const char* vmc_rccl_last_error(void);
+/* File the library's nccl* entry points were resolved from: the librccl next to the libamdhip64 this
+ * library is bound to (a process can hold two ROCm stacks -- torch bundles its own -- and streams,
+ * buffers and communicators of one must not be handed to the other), else the first librccl.so.1 on
+ * the loader path; "" when none was found.  A caller's ncclComm_t must come from THIS instance: a
+ * communicator of another librccl in the process is rejected by ncclAllReduce as corrupted. */
+const char* vmc_rccl_library_path(void);
 /* Test / diagnostic hook: in-place all-reduce of n_floats of host data through the same transport
  * (staged through the ctx's device scratch for RCCL); op = VMC_REDUCE_*. */
 int vmc_debug_allreduce(vmc_ctx* ctx, void* nccl_comm, int32_t world_size, float* host,

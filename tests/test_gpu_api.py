@@ -379,7 +379,12 @@ def test_cabi_allreduce_over_an_rccl_communicator():
   divided by the world size the caller states."""
   import ctypes as C
   from cgs_vmc_amd.engine import VmcEngine
-  rccl = C.CDLL('librccl.so')
+  # the communicator has to come from the librccl instance the library calls into (with torch in the
+  # process that is torch's bundled copy, not necessarily the first librccl.so on the loader path)
+  from cgs_vmc_amd import _hip as hip_binding
+  path = hip_binding.load().vmc_rccl_library_path().decode()
+  assert path and os.path.exists(path), path
+  rccl = C.CDLL(path)
 
   class UniqueId(C.Structure):
     _fields_ = [('internal', C.c_char * 128)]

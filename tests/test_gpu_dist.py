@@ -52,7 +52,8 @@ def rccl1():
   coll = parallel.rccl_collective(device=0, world=1, rank_=0)
   assert coll.comm != 0 and coll.world == 1
   yield coll
-  coll.close()
+  if not os.environ.get('CGS_TEST_KEEP_COMM'):
+    coll.close()
 
 
 def test_library_rccl_allreduce_one_rank(rccl1):

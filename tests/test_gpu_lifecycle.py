@@ -12,8 +12,9 @@ the pre-init, which is gone.  Resident memory is flat too, except for up to thre
 173 MB at no fixed cycle: the probe prints the new mappings at such a step -- one anonymous 173.4 MB
 arena plus a 1 MB shared ring and a /dev/dri doorbell page, i.e. the HIP runtime bringing up another
 of its (at most four) hardware queues for a newly created stream; 1000 cycles show no fourth step.  A
-leak would show in every 20-cycle interval instead.  The one-off failure could not be reproduced and
-is not a leak in vmc_create / vmc_destroy."""
+leak would show in every 20-cycle interval instead.  The one-off failure is not a leak in vmc_create /
+vmc_destroy; its likely cause -- a second HIP runtime in the process when this library was loaded before
+torch, which bundles its own libamdhip64 -- is removed in _hip.load() ("Engine life cycles")."""
 import os
 import subprocess
 import sys
