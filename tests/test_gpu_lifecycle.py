@@ -47,3 +47,34 @@ def test_500_engine_life_cycles_leak_nothing_and_torch_starts_afterwards():
   assert len(grew) <= 3 and all(d <= 200 for d in grew), steps
   assert rss <= 64 + 200 * len(grew), (base, last)
   assert maps <= 8 + 8 * len(grew), (base, last)    # memory mappings
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+  """torch bundles its own libamdhip64 / librccl (same sonames as the system ROCm's).  In a fresh
+  process that touches this package BEFORE torch, the engine, torch and the library's RCCL binding must
+  still end up on ONE copy of each (cgs_vmc_amd/_hip.py loads torch first; vmc_api.hip takes librccl
+  from next to the runtime it is bound to)."""
+  code = r'''
+import os, sys
+sys.path.insert(0, %r)
+from cgs_vmc_amd.engine import VmcEngine           # before any "import torch" of the caller
+from cgs_vmc_amd import _hip
+eng = VmcEngine(16, 64, 2, 32, seed=1)
+path = _hip.load().vmc_rccl_library_path().decode()
+import torch
+x = torch.ones(8, device='cuda'); assert float(x.sum()) == 8.0
+eng.close()
+libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l or 'librccl' in l})
+print('LIBS', *libs)
+print('RCCL', path)
+''' % ROOT
+  p = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+  out = p.stdout.decode()
+  assert p.returncode == 0, out[-2000:]
+  libs = next(line for line in out.splitlines() if line.startswith('LIBS')).split()[1:]
+  rccl = next(line for line in out.splitlines() if line.startswith('RCCL')).split()[1]
+  hips = [l for l in libs if 'libamdhip64' in l]
+  rccls = [l for l in libs if 'librccl' in l]
+  assert len(hips) == 1, libs
+  assert len(rccls) == 1 and os.path.realpath(rccls[0]) == os.path.realpath(rccl), (libs, rccl)
+  assert os.path.dirname(os.path.realpath(hips[0])) == os.path.dirname(os.path.realpath(rccl)), (libs, rccl)
