@@ -1031,11 +1031,13 @@ hipError_t launch_k(Kern kern, dim3 grid, size_t lds, hipStream_t s, const Args&
     case 4: { constexpr int KK_ = 4, KW_ = 4; CALL; } break;                            \
     case 5: { constexpr int KK_ = 5, KW_ = 5; CALL; } break;                            \
     case 6: { constexpr int KK_ = 6, KW_ = 6; CALL; } break;                            \
+    case 7: { constexpr int KK_ = 7, KW_ = 7; CALL; } break;                            \
     case -2: { constexpr int KK_ = 2, KW_ = 1; CALL; } break;                           \
     case -3: { constexpr int KK_ = 3, KW_ = 1; CALL; } break;                           \
     case -4: { constexpr int KK_ = 4, KW_ = 1; CALL; } break;                           \
     case -5: { constexpr int KK_ = 5, KW_ = 1; CALL; } break;                           \
     case -6: { constexpr int KK_ = 6, KW_ = 1; CALL; } break;                           \
+    case -7: { constexpr int KK_ = 7, KW_ = 1; CALL; } break;                           \
     default: return hipErrorInvalidValue;                                               \
   }
 

@@ -694,8 +694,8 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     const int sx = one_d ? d->n_sites : d->size_x, sy = one_d ? 1 : d->size_y;
     if (sx < 1 || sy < 1 || (long long)sx * sy != d->n_sites)
       return fail(nullptr, VMC_ERR_INVALID, "size_x * size_y must equal num_sites");
-    if (d->kernel_size < 1 || d->kernel_size > 6)
-      return fail(nullptr, VMC_ERR_UNSUPPORTED, "kernel_size 1..6 supported by the convolution kernels (weights are register resident)");
+    if (d->kernel_size < 1 || d->kernel_size > 7)
+      return fail(nullptr, VMC_ERR_UNSUPPORTED, "kernel_size 1..7 supported by the convolution kernels (weights are register resident)");
     if (d->layer_size > CONV_FP * CONV_MAX_NCB)
       return fail(nullptr, VMC_ERR_UNSUPPORTED, "num_conv_filters > 32 not supported by the convolution kernels");
     if (sx < d->kernel_size / 2 || (!one_d && sy < d->kernel_size / 2) || sx > 1023 || sy > 1023)

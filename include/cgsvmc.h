@@ -85,7 +85,7 @@ typedef struct {
   uint64_t seed;             /* Philox key                                           */
   void* stream;              /* hipStream_t to launch on, or NULL for the null stream*/
   /* convolutional ansatz types only (ignored otherwise) */
-  int32_t kernel_size;       /* hparams.kernel_size (utils.py:110), 1..6             */
+  int32_t kernel_size;       /* hparams.kernel_size (utils.py:110), 1..7             */
   int32_t size_x, size_y;    /* hparams.size_x, size_y (utils.py:99-100); n_sites = size_x*size_y
                                 (ignored by the 1-D types: the chain has n_sites sites)          */
   int32_t reserved2;         /* 0                                                    */

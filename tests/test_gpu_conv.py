@@ -25,6 +25,7 @@ CONV_SHAPES = [
     ('conv_2d', 10, 10, 5, 16, 5, 40, 'relu'),      # hparams defaults (utils.py:108-111) on 10 x 10
     ('conv_2d', 4, 4, 3, 16, 1, 16, 'tan'),         # 1 x 1 kernels
     ('conv_2d', 6, 6, 2, 12, 6, 10, 'identity'),    # k = 6 = lattice side
+    ('conv_2d', 8, 7, 3, 16, 7, 14, 'relu'),        # k = 7 (49 taps: the largest register-resident kernel)
     ('res_net_2d', 4, 4, 2, 8, 3, 20, 'relu'),
     ('res_net_2d', 6, 6, 2, 16, 5, 40, 'relu'),
     ('res_net_2d', 5, 4, 1, 16, 4, 12, 'relu'),
@@ -36,6 +37,8 @@ CONV_SHAPES = [
     ('conv_2d', 10, 10, 4, 24, 5, 26, 'relu'),      # 24 filters padded to 32, 10 x 10
     ('conv_2d', 5, 4, 2, 17, 4, 9, 'sigmoid'),      # 17 filters, even kernel
     ('conv_2d', 6, 6, 2, 20, 6, 7, 'identity'),     # k = 6 with two channel blocks
+    ('conv_2d', 7, 8, 2, 24, 7, 9, 'tanh'),         # k = 7 with two channel blocks
+    ('res_net_2d', 7, 7, 1, 16, 7, 11, 'relu'),
     ('res_net_2d', 6, 6, 2, 32, 3, 18, 'relu'),
     ('res_net_2d', 4, 6, 1, 28, 5, 13, 'relu'),
     # the cosine (layers.py:15): its derivative needs the pre-activation, which the tape then holds
@@ -331,7 +334,7 @@ def test_conv_error_behaviour():
   with pytest.raises(NotImplementedError):
     VmcEngine(16, 8, 2, 33, **kw)                         # more than 32 filters
   with pytest.raises(NotImplementedError):
-    VmcEngine(16, 8, 2, 8, ansatz='conv_2d', kernel_size=7, size_x=4, size_y=4)
+    VmcEngine(16, 8, 2, 8, ansatz='conv_2d', kernel_size=8, size_x=4, size_y=4)
   eng = VmcEngine(16, 8, 2, 8, output_activation='tanh', **kw)
   with pytest.raises(NotImplementedError):
     eng.sr_reserve(2)                                     # SR (an extension) needs the exp output

@@ -271,6 +271,7 @@ def test_sr_beyond_256_units_matvec_and_solution(ansatz, n, h, L, b, n_store):
     ('conv_2d', 4, 4, 2, 24, 3, 12, 'cos', 2),        # two channel blocks, pre-activation tape
     ('res_net_2d', 4, 4, 2, 8, 3, 16, 'relu', 2),
     ('conv_1d', 12, 1, 3, 12, 5, 14, 'sigmoid', 3),
+    ('conv_2d', 7, 7, 2, 8, 7, 10, 'relu', 2),        # 7 x 7 kernel
 ])
 def test_sr_convolutional_matvec_and_solution(ansatz, sx, sy, L, f, k, b, nonlin, n_store):
   """SR over the convolutional ansatz types (round 3): t_b = O_b . p by k_conv_sr_rowdot on the stored
