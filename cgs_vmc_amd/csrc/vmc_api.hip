@@ -722,8 +722,21 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (rbm && d->output_activation != VMC_ACT_EXP)
     return fail(nullptr, VMC_ERR_INVALID, "the rbm ansatz has no output_activation: it is always exp (wavefunctions.py:419-420)");
   const bool wide = !conv && d->layer_size > 256;
-  if (wide && (d->nonlinearity == VMC_ACT_COS || d->layer_size > 4096))
-    return fail(nullptr, VMC_ERR_UNSUPPORTED, "fc_layer_size > 256 is supported for fully_connected and rbm with any nonlinearity but cos, at most 4096 units");
+  // 257 .. 512 units run the fused kernels (every activation); beyond that -- or with the fused path
+  // switched off or out of LDS -- the general path, whose back-propagation reads f' off the
+  // activation and therefore has no cos
+  bool wide_fast_ok = false;
+  if (wide && d->layer_size <= 512) {
+    const int hp = (d->layer_size + 127) / 128 * 128;     // 8 waves x whole 16-unit tiles
+    const int n_hh = rbm ? d->num_layers : d->num_layers - 1;
+    const char* e = getenv("CGS_VMC_WIDE_FAST");
+    wide_fast_ok = !(e && atoi(e) == 0) && (n_hh == 0 || tail_lds_supported(hp, n_hh)) &&
+                   sweep_lds_required(d->n_sites, hp, n_hh, rbm) <= 160 * 1024;
+  }
+  if (wide && d->layer_size > 4096)
+    return fail(nullptr, VMC_ERR_UNSUPPORTED, "fc_layer_size > 4096 is not supported");
+  if (wide && !wide_fast_ok && d->nonlinearity == VMC_ACT_COS)
+    return fail(nullptr, VMC_ERR_UNSUPPORTED, "nonlinearity cos is supported up to 512 units (the fused kernels); the general path beyond has every other activation");
   if (!conv && !wide) {  // the sampler keeps 16 chains' spins, z1 and operands in LDS (160 KiB per CU)
     const int hp = (d->layer_size + 63) / 64 * 64;
     const int n_hh = rbm ? d->num_layers : d->num_layers - 1;
@@ -754,18 +767,12 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (wide) c->overlap = false;
   c->hact = d->nonlinearity; c->oact = d->output_activation;
   c->lay = make_layout(rbm, c->N, c->H, c->L);
-  if (wide && c->H <= 512) {
+  if (wide_fast_ok) {
     // 257 .. 512 units: the fused sampler padded to 384 / 512 units (k_sweep16<24|32>), rows on the
     // LDS-operand kernel (k_tail_lds; without an H x H layer: k_tail0) and the fused back-propagation
-    // (k_backprop16<24|32>); both dense ansatz types, every hidden activation but cos
-    const int hp = (c->H + 127) / 128 * 128;     // 8 waves x whole 16-unit tiles
-    const char* e = getenv("CGS_VMC_WIDE_FAST");
-    const int n_hh = c->lay.n_hh;
-    if (!(e && atoi(e) == 0) && (n_hh == 0 || tail_lds_supported(hp, n_hh)) &&
-        sweep_lds_required(c->N, hp, n_hh, rbm) <= 160 * 1024) {
-      c->wide_fast = true;
-      c->Hp = hp;
-    }
+    // (k_backprop16<24|32>); both dense ansatz types, every hidden activation
+    c->wide_fast = true;
+    c->Hp = (c->H + 127) / 128 * 128;
   }
   c->n_hh = c->lay.n_hh; c->A = c->n_hh + 1;
   c->P = conv ? vmc_num_params_conv(d->ansatz, d->num_layers, d->layer_size, d->kernel_size)
@@ -1769,8 +1776,8 @@ int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
   if (n_batches > 0 && c->wide && !c->wide_fast)
     return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the dense ansatz types up to 512 hidden units and the convolutional ones");
-  if (n_batches > 0 && (c->oact != VMC_ACT_EXP_ || (c->hact == VMC_ACT_COS_ && !c->conv)))
-    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation and every hidden activation except cos");
+  if (n_batches > 0 && c->oact != VMC_ACT_EXP_)
+    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation (every hidden activation)");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   void* old[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_ones, c->sr_ctape, c->sr_cdelta, c->sr_cws, c->sr_tpart};
   for (void* q : old) if (q) hipFree(q);

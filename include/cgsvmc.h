@@ -61,7 +61,7 @@ enum { VMC_ANSATZ_FULLY_CONNECTED = 0, VMC_ANSATZ_RBM = 1, VMC_ANSATZ_CONV_2D = 
        VMC_ANSATZ_RES_NET_2D = 3, VMC_ANSATZ_CONV_1D = 4, VMC_ANSATZ_RES_NET_1D = 5 };
 
 /* layers.NONLINEARITIES ids (layers.py:13-21).  Every id is accepted as hidden and as output
- * activation of every ansatz type with kernels (dense types beyond 256 hidden units: not cos). */
+ * activation of every ansatz type with kernels (dense types beyond 512 hidden units: not cos). */
 enum { VMC_ACT_RELU = 0, VMC_ACT_EXP = 1, VMC_ACT_COS = 2, VMC_ACT_TAN = 3, VMC_ACT_TANH = 4,
        VMC_ACT_SIGMOID = 5, VMC_ACT_IDENTITY = 6 };
 
@@ -71,8 +71,8 @@ typedef struct {
   int32_t num_layers;        /* hparams.num_fc_layers (utils.py:104); conv_2d: num_conv_layers
                                 (108); res_net_2d: num_resnet_blocks (114)                     */
   int32_t layer_size;        /* hparams.fc_layer_size (utils.py:105): fully_connected and rbm take up
-                                to 4096 units -- the fused kernels up to 512 (any nonlinearity; 257
-                                .. 512 not with cos), beyond that the general multi-launch path
+                                to 4096 units -- the fused kernels up to 512 (any nonlinearity),
+                                beyond that the general multi-launch path
                                 (materialised rows + GEMMs, no cos; two [131072][units] float
                                 buffers per ctx: 4 GiB at 4096 units).  Convolutional ansatz types:
                                 num_conv_filters (111), at most 32 (two 16-channel MFMA blocks)  */

@@ -179,7 +179,7 @@ def test_activation_error_behaviour():
     VmcEngine(16, 8, 2, 32, nonlinearity='gelu')
   with pytest.raises(ValueError):
     VmcEngine(16, 8, 2, 32, output_activation='tanh', ansatz='rbm')
-  eng = VmcEngine(16, 8, 2, 32, nonlinearity='cos')
+  eng = VmcEngine(16, 8, 2, 32, output_activation='tanh')
   with pytest.raises(NotImplementedError):
-    eng.sr_reserve(2)                       # SR (an extension) does not cover the cosine
+    eng.sr_reserve(2)                       # SR (an extension) needs the exp output
   eng.close()

@@ -29,13 +29,13 @@ def _bonds(kind, n):
   return vo.torus_bonds(lx, n // lx)
 
 
-def _setup(n, h, L, b, kind, n_store, seed=0):
+def _setup(n, h, L, b, kind, n_store, seed=0, nonlin='relu'):
   from cgs_vmc_amd.engine import VmcEngine
   rng = np.random.default_rng(seed)
   theta = vo.init_params(n, h, L, rng)
   theta += (0.05 * rng.standard_normal(theta.size)).astype(np.float32)
   bonds = _bonds(kind, n)
-  eng = VmcEngine(n, b, L, h, seed=2024)
+  eng = VmcEngine(n, b, L, h, seed=2024, nonlinearity=nonlin)
   eng.set_params(theta)
   eng.set_bonds(bonds, -1.0, 1.0)
   eng.sr_reserve(n_store)
@@ -50,7 +50,7 @@ def _setup(n, h, L, b, kind, n_store, seed=0):
   assert eng.sr_num_stored() == n_store
   cfg_all = np.concatenate(cfgs, 0)
   e_all = np.concatenate(elocs, 0).astype(np.float64)
-  o = vo.per_sample_logit_grads(theta, cfg_all, h, L)
+  o = vo.per_sample_logit_grads(theta, cfg_all, h, L, nonlinearity=nonlin)
   return eng, theta, o, e_all
 
 
@@ -64,6 +64,29 @@ def test_sr_matvec_matches_explicit_s(n, h, L, b, kind, n_store):
     ref = s @ v.astype(np.float64) + lam * v
     got = eng.sr_debug_matvec(v, lam)
     assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()
+  eng.close()
+
+
+@pytest.mark.parametrize('nonlin', ['tanh', 'cos', 'sigmoid', 'identity'])
+def test_sr_other_hidden_activations(nonlin):
+  """The reverse-mode matvec needs no activation derivative of its own (delta carries it), so every
+  hidden activation is covered -- cos included, whose derivative the gradient path takes from the
+  f'(z) arrays next to the activations."""
+  n, h, L, b, n_store = 16, 48, 2, 72, 2
+  eng, theta, o, e = _setup(n, h, L, b, 'torus4x4', n_store, seed=3, nonlin=nonlin)
+  s_mat, f_vec = vo.sr_system(o, e)
+  v = np.random.default_rng(9).standard_normal(theta.size).astype(np.float32)
+  cancel = np.abs(o).mean(0).max() * np.abs(o @ v.astype(np.float64)).mean()
+  for lam in (0.0, 0.01):
+    ref = s_mat @ v.astype(np.float64) + lam * v
+    got = eng.sr_debug_matvec(v, lam)
+    assert np.abs(got - ref).max() <= 5e-4 * np.abs(ref).max() + 4e-6 * cancel, (nonlin, lam)
+  lam = 1e-2
+  iters, res = eng.sr_solve(lam, 1e-6, 3000)
+  x = eng.sr_get_solution().astype(np.float64)
+  resid = (s_mat + lam * np.eye(theta.size)) @ x - f_vec
+  f_round = 4e-6 * np.abs(o).mean(0).max() * np.abs(e).mean() * np.sqrt(theta.size)
+  assert np.linalg.norm(resid) <= 2e-3 * np.linalg.norm(f_vec) + f_round, (nonlin, iters, res)
   eng.close()
 
 

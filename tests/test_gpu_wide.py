@@ -1,5 +1,5 @@
 """GPU parity of fully_connected with fc_layer_size > 256 (utils.py:105 allows any size) against the
-numpy oracle, through the C ABI: networks of at most 512 units (any hidden activation but cos) run
+numpy oracle, through the C ABI: networks of at most 512 units (any hidden activation) run
 the fused kernels padded to 384 or 512 units (k_sweep16<24|32>, k_tail_lds / k_tail0,
 k_backprop16<24|32>; kernel_path() == 1), everything beyond 512 units the general path of
 csrc/wide.hip (materialised rows + the library's fp32-MFMA GEMM, a few launches per mc_step;
@@ -27,6 +27,8 @@ WIDE_SHAPES = [
     (36, 448, 3, 48, 'torus6x6', 'tanh'),     # non-relu at 512 padded units, two H x H layers
     (16, 300, 2, 25, 'torus4x4', 'identity'),
     (12, 512, 2, 31, 'chain', 'sigmoid'),
+    (16, 320, 2, 27, 'torus4x4', 'cos'),       # cos: f'(z) arrays next to the activations, 384 padded units
+    (20, 512, 3, 22, 'chain', 'cos'),
     (16, 640, 2, 19, 'chain', 'relu'),        # more than 512 units: general path
 ]
 
@@ -140,7 +142,7 @@ def test_wide_energy_gradient_accumulators(n, h, L, b, kind, nonlin):
 def test_wide_limits():
   from cgs_vmc_amd.engine import VmcEngine
   with pytest.raises(NotImplementedError):
-    VmcEngine(16, 8, 2, 320, nonlinearity='cos')
+    VmcEngine(16, 8, 2, 640, nonlinearity='cos')        # the general path has no cos
   with pytest.raises(NotImplementedError):
     VmcEngine(16, 8, 2, 4100, ansatz='rbm')
   for ansatz in ('fully_connected', 'rbm'):
