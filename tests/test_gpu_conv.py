@@ -56,6 +56,9 @@ ONE_D = [
     ('res_net_1d', 40, 1, 2, 16, 3, 16, 'relu'),
     ('conv_1d', 16, 1, 3, 32, 5, 14, 'relu'),
     ('res_net_1d', 12, 1, 1, 24, 3, 10, 'relu'),
+    ('conv_1d', 16, 1, 3, 12, 7, 15, 'relu'),       # 7 taps on the chain
+    ('res_net_1d', 14, 1, 1, 20, 7, 9, 'relu'),     # ... with two channel blocks
+    ('conv_1d', 11, 1, 2, 18, 2, 8, 'tanh'),        # 2 taps, two channel blocks (the variant with the most spills)
 ]
 CONV_SHAPES = CONV_SHAPES + ONE_D
 BIG = [
