@@ -152,3 +152,60 @@ def test_random_shape_itswo_and_sr(seed):
   got = eng.sr_debug_matvec(v, 0.01)
   assert np.abs(got - ref).max() <= 3e-4 * np.abs(ref).max(), tag
   eng.close()
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_shape_with_a_random_hidden_activation(seed):
+  """fully_connected over the hidden activations of layers.NONLINEARITIES that keep a random network
+  inside fp32 (relu, tanh, sigmoid, cos, identity) at widths on both sides of the 256-unit border of the
+  register-resident kernels (cos beyond it since round 3): logits, local energies, gradient sums, one
+  injected step."""
+  from cgs_vmc_amd import _hip
+  from cgs_vmc_amd.engine import VmcEngine
+  rng = np.random.default_rng(9000 + seed)
+  nonlin = ['relu', 'tanh', 'sigmoid', 'cos', 'identity'][seed % 5]
+  n = int(rng.integers(6, 41))
+  h = int(rng.choice([24, 100, 256, 272, 384, 448, 512]))
+  L = int(rng.integers(1, 4))
+  b = int(rng.integers(2, 61))
+  n_b = int(rng.integers(2, 2 * n))
+  bonds = []
+  while len(bonds) < n_b:
+    i, j = (int(x) for x in rng.integers(0, n, 2))
+    if i != j:
+      bonds.append((i, j))
+  jx = rng.uniform(-1.5, 1.5, n_b).astype(np.float32)
+  jz = rng.uniform(-1.0, 1.5, n_b).astype(np.float32)
+  theta = vo.init_params(n, h, L, rng)
+  theta = ((0.3 if h > 256 else 1.0) * theta + 0.02 * rng.standard_normal(theta.size)).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(seed))
+  eng = VmcEngine(n, b, L, h, seed=11, nonlinearity=nonlin)
+  assert eng.kernel_path() == (1 if h > 256 else 0)
+  eng.set_params(theta); eng.set_configs(cfg); eng.set_bonds(bonds, jx, jz)
+  tag = (nonlin, n, h, L, b, n_b)
+  kw = dict(nonlinearity=nonlin, dtype=np.float64)
+
+  def close(a, ref, rel):
+    a = np.asarray(a, np.float64); ref = np.asarray(ref, np.float64)
+    err = np.abs(a - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() <= rel, (tag, float(err.max()))
+
+  close(eng.amplitude()[0], vo.fc_logit(theta, cfg, h, L, **kw), 2e-5)
+  amp = lambda c: vo.fc_psi(theta, c, h, L, **kw)
+  close(eng.local_energy()[0], vo.local_value(amp, cfg, bonds, jx, jz, dtype=np.float64), 3e-4)
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, jx, jz, -10.0, h, L, np.float64, nonlinearity=nonlin)
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  got = eng.get_accumulators()
+  p = theta.size
+  for g, r in ((got[:p], acc.g1_total), (got[p:2 * p], acc.g2_total)):
+    assert np.abs(g - r).max() < 2e-3 * np.abs(r).max() + 2e-4, tag
+  u_sites, u_acc = vo.step_uniforms(5, np.arange(b), seed, n)
+  i_up, i_dn = vo.propose_exchange(cfg, u_sites)
+  _, acc_ref, ratios = vo.mc_step(amp, cfg, i_up, i_dn, u_acc)
+  mask = eng.mc_step_injected(i_up, i_dn, u_acc)
+  band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
+  assert np.array_equal(mask[~band], acc_ref[~band]), tag
+  close(eng.amplitude()[0], vo.fc_logit(theta, eng.get_configs(), h, L, **kw), 2e-5)
+  eng.close()
