@@ -396,17 +396,17 @@ def test_conv_1d_through_run_training(tmp_path):
   assert 'conv_1d_network/conv_1d_periodic_2/conv_1d/w' in set(np.load(ck + '.npz').files)
 
 
-def _random_conv_shapes(count, seed=2025):
-  """Seeded random geometries inside the limits vmc_create states (kernel 1..6, <= 32 filters,
+def _random_conv_shapes(count, seed=2025, kmax=6, with_cos=False):
+  """Seeded random geometries inside the limits vmc_create states (kernel 1..7, <= 32 filters,
   lattice sides >= kernel // 2): every padding parity, ragged batches, k larger than a side."""
   rng = np.random.default_rng(seed)
   # (tan and exp hidden units are covered by CONV_SHAPES at controlled magnitudes: near a pole of
   # tan the fp32 error of the pre-activation is amplified without bound)
-  acts = ['relu', 'tanh', 'sigmoid', 'identity']
+  acts = ['relu', 'tanh', 'sigmoid', 'identity'] + (['cos'] if with_cos else [])
   shapes = []
   while len(shapes) < count:
     ansatz = ['conv_2d', 'res_net_2d', 'conv_1d', 'res_net_1d'][int(rng.integers(4))]
-    k = int(rng.integers(1, 7))
+    k = int(rng.integers(1, kmax + 1))
     if ansatz in vo.CONV_1D:
       sx, sy = int(rng.integers(max(2, k // 2), 33)), 1
     else:
@@ -422,7 +422,8 @@ def _random_conv_shapes(count, seed=2025):
   return shapes
 
 
-RANDOM_SHAPES = _random_conv_shapes(36)
+# the round-2 / early round-3 set (kernel <= 6), then one with 7 x 7 kernels and cos
+RANDOM_SHAPES = _random_conv_shapes(36) + _random_conv_shapes(18, seed=3031, kmax=7, with_cos=True)
 
 
 @pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', RANDOM_SHAPES,
