@@ -50,9 +50,12 @@ WORKLOADS = {
     # convolutional ansatz types: L = num_conv_layers / num_resnet_blocks,
     # H = num_conv_filters, hparams defaults of utils.py:108-114
     'heisenberg10x10_fc3x256_b4096': (10, 10, False, 3, 256, 4096),
+    # the WHOLE batch of config 4 on one GPU (its 8-GPU shard is the line above): 8 rounds of the sampler's
+    # one-tile-per-CU grid; not a driver line, a sizing check (32768 chains are 3 % of the HBM)
+    'heisenberg10x10_fc3x256_b32768': (10, 10, False, 3, 256, 32768),
     'heisenberg6x6_fc3x128_b1024': (6, 6, False, 3, 128, 1024),
     'heisenberg16x16j1j2_fc6x256_b1024': (16, 16, True, 6, 256, 1024),
-    'heisenberg10x10_fc3x512_b4096': (10, 10, False, 3, 512, 4096),   # > 256 units: general path (wide.hip)
+    'heisenberg10x10_fc3x512_b4096': (10, 10, False, 3, 512, 4096),   # 257 .. 512 units: the fused kernels padded to 512
     'heisenberg10x10_conv5x16k5_b4096': (10, 10, False, 5, 16, 4096, 'conv_2d', 5),
     'heisenberg10x10_resnet2x16k5_b4096': (10, 10, False, 2, 16, 4096, 'res_net_2d', 5),
     'heisenberg10x10_conv5x32k5_b4096': (10, 10, False, 5, 32, 4096, 'conv_2d', 5),    # two 16-channel blocks
