@@ -47,9 +47,11 @@ _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
 _ctx = C.c_void_p
 _bp = C.POINTER(C.c_uint8)
-VMC_REDUCE_SUM, VMC_REDUCE_MAX = 0, 1
-# vmc_host_allreduce_fn: int hook(void* user, float* host_buf, int64_t n_floats, int32_t op)
+VMC_REDUCE_SUM, VMC_REDUCE_MAX, VMC_REDUCE_SUM_F64 = 0, 1, 2
+# vmc_host_allreduce_fn: int hook(void* user, float* host_buf, int64_t n_elements, int32_t op)
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_int64, C.c_int32)
+# vmc_device_allreduce_fn: int hook(void* user, void* dev_buf, int64_t n_elements, int32_t op, void* stream)
+DEVICE_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
 
 # name -> (restype, argtypes); every symbol include/cgsvmc.h declares
 SIGNATURES = {
@@ -93,6 +95,9 @@ SIGNATURES = {
                                         C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.POINTER(C.c_double)]),
     'vmc_set_host_allreduce': (C.c_int, [_ctx, HOST_ALLREDUCE_FN, C.c_void_p]),
+    'vmc_set_device_allreduce': (C.c_int, [_ctx, DEVICE_ALLREDUCE_FN, C.c_void_p]),
+    'vmc_evaluate': (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64,
+                               C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'vmc_rccl_unique_id': (C.c_int, [_bp]),
     'vmc_rccl_comm_create': (C.c_int, [_bp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     'vmc_rccl_comm_destroy': (C.c_int, [C.c_void_p]),
@@ -188,10 +193,18 @@ def load():
   # process ends up with two runtimes (engines on one, torch on the other: "No HIP GPUs are available"
   # from torch's late initialisation and aborts at exit have both been seen that way).  Loading torch
   # first, where it is installed, makes every import order end in torch's single runtime.
-  try:
-    import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
-  except ImportError:
-    pass
+  # CGS_VMC_NO_TORCH_PRELOAD=1 skips it (torch-free hosts that want the seconds of start-up back).
+  if os.environ.get('CGS_VMC_NO_TORCH_PRELOAD', '0') != '1':
+    try:
+      import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
+    except ImportError:
+      pass
+    except Exception as e:  # pylint: disable=broad-except
+      # a broken torch install (OSError / RuntimeError from its own shared objects) must not make
+      # the library unloadable for torch-free use
+      import warnings
+      warnings.warn('cgs_vmc_amd: importing torch before libcgsvmc_hip.so failed ({!r}); loading the '
+                    'library on the system HIP runtime'.format(e))
   try:
     lib = C.CDLL(_LIB_PATH)
   except OSError as e:

@@ -249,6 +249,7 @@ hipError_t launch_eloc_reduce(hipStream_t s, const int* off, const float* diag, 
 hipError_t launch_check_pm1(hipStream_t s, const float* x, long long n, int* flag);
 hipError_t launch_sum(hipStream_t s, const float* x, int n, double* out_sum);
 hipError_t launch_max(hipStream_t s, const float* x, int n, float* out_max);
+hipError_t launch_div_f64(hipStream_t s, double* x, int n, double d);
 
 // gradient path (grad.hip)
 struct GemmArgs {

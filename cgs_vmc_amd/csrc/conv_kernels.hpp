@@ -768,7 +768,7 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
   const int ml = lane & 15, gl = lane >> 4;
   const int D2p = g.D2 + KW - 1, NPAD = (g.D1 + K - 1) * D2p;
   // a sample is taken in bands of RB lattice rows (all of them when that fits LDS: a.band_rows)
-  const int RB = a.band_rows, nbands = (g.D1 + RB - 1) / RB;
+  const int RB = a.band_rows;
   const int NQ = (RB * D2p + 3) & ~3;              // positions walked per band (padded numbering), whole quads
   const int NIN = NQ + (K - 1) * D2p + KW;         // input sites a product can touch
   // LDS: delta [NQ][CW]; input [NIN][CW] (first layer: spins, one float per site); the halo map

@@ -165,6 +165,17 @@ hipError_t launch_sum(hipStream_t s, const float* x, int n, double* out_sum) {
   return hipGetLastError();
 }
 
+__global__ void k_div_f64(double* __restrict__ x, int n, double d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = x[i] / d;       // IEEE division: the same bits as the host's sum / B
+}
+
+hipError_t launch_div_f64(hipStream_t s, double* x, int n, double d) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_div_f64, dim3((n + 255) / 256), dim3(256), 0, s, x, n, d);
+  return hipGetLastError();
+}
+
 hipError_t launch_max(hipStream_t s, const float* x, int n, float* out_max) {
   hipLaunchKernelGGL(k_max, dim3(1), dim3(1024), 0, s, x, n, out_max);
   return hipGetLastError();

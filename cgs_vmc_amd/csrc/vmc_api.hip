@@ -141,6 +141,10 @@ struct vmc_ctx {
   // collectives over sharded chains: host hook for non-RCCL transports + its staging
   vmc_host_allreduce_fn host_reduce = nullptr;
   void* host_reduce_user = nullptr;
+  vmc_device_allreduce_fn dev_reduce = nullptr;   // in-stream transport of the host's own collective library
+  void* dev_reduce_user = nullptr;
+  double* d_eval = nullptr;      // vmc_evaluate: batch sums / means of the samples
+  int d_eval_n = 0;
   float* h_stage = nullptr;      // pinned
   float* d_stage = nullptr;      // vmc_debug_allreduce only
   long long h_stage_n = 0, d_stage_n = 0;
@@ -312,7 +316,9 @@ long long off_bout(const vmc_ctx* c) { return c->lay.off_bout; }
 // best at K = 4096 (8 splits: 0.086 ms for the whole gradient path against 0.097 at 16, 0.109 at 4)
 int pick_splitk(const vmc_ctx* c, long long k) {
   static const int forced = getenv("CGS_VMC_SPLITK") ? atoi(getenv("CGS_VMC_SPLITK")) : 0;   // measurement knob
-  if (forced > 0) return forced < c->splitk ? forced : c->splitk;
+  // never 1: a single slice accumulates straight into C and the fixed-order reduction that follows
+  // would fold a workspace nobody wrote
+  if (forced > 0) return forced < 2 ? 2 : (forced < c->splitk ? forced : c->splitk);
   long long s = k / 512;
   if (s < 4) s = 4;
   if (s > c->splitk) s = c->splitk;
@@ -613,29 +619,39 @@ std::string rccl_error_string(const Rccl* r, int rc) {
 //   comm != NULL                : ncclAllReduce on the stream (no host synchronisation)
 //   comm == NULL, world <= 1    : nothing to do
 //   comm == NULL, world  > 1    : the registered host hook, staged through pinned host memory
-int reduce_buffer(vmc_ctx* c, void* comm, int world, float* buf, long long n, int op) {
+//   comm == NULL, world  > 1    : the device hook (the host's collective library reduces the device
+//                                 buffer in stream order), else the host hook through pinned memory
+// op == VMC_REDUCE_SUM_F64: buf holds n doubles.
+int reduce_buffer(vmc_ctx* c, void* comm, int world, void* buf, long long n, int op) {
+  const bool f64 = op == VMC_REDUCE_SUM_F64;
   if (comm) {
     const Rccl* r = rccl();
     if (!r) return fail(c, VMC_ERR_UNSUPPORTED, g_rccl_error);
-    const int rc = r->all_reduce(buf, buf, (size_t)n, /*ncclFloat32*/ 7, op == VMC_REDUCE_MAX ? /*ncclMax*/ 2 : /*ncclSum*/ 0,
-                                 comm, c->stream);
+    const int rc = r->all_reduce(buf, buf, (size_t)n, f64 ? /*ncclFloat64*/ 8 : /*ncclFloat32*/ 7,
+                                 op == VMC_REDUCE_MAX ? /*ncclMax*/ 2 : /*ncclSum*/ 0, comm, c->stream);
     if (rc != 0) return fail(c, VMC_ERR_HIP, "ncclAllReduce: " + rccl_error_string(r, rc));
     return VMC_OK;
   }
   if (world <= 1) return VMC_OK;
+  if (c->dev_reduce) {
+    const int rc = c->dev_reduce(c->dev_reduce_user, buf, n, op, (void*)c->stream);
+    if (rc != 0) return fail(c, VMC_ERR_HIP, "device all-reduce hook failed with code " + std::to_string(rc));
+    return VMC_OK;
+  }
   if (!c->host_reduce)
-    return fail(c, VMC_ERR_STATE, "world_size > 1 needs an RCCL communicator or vmc_set_host_allreduce");
-  if (n > c->h_stage_n) {
+    return fail(c, VMC_ERR_STATE, "world_size > 1 needs an RCCL communicator, vmc_set_device_allreduce or vmc_set_host_allreduce");
+  const long long nf = f64 ? 2 * n : n;          // staging size in floats
+  if (nf > c->h_stage_n) {
     if (c->h_stage) hipHostFree(c->h_stage);
     c->h_stage = nullptr; c->h_stage_n = 0;
-    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, (size_t)n * sizeof(float), hipHostMallocDefault));
-    c->h_stage_n = n;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, (size_t)nf * sizeof(float), hipHostMallocDefault));
+    c->h_stage_n = nf;
   }
-  HIPCHK(c, hipMemcpyAsync(c->h_stage, buf, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->h_stage, buf, nf * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const int rc = c->host_reduce(c->host_reduce_user, c->h_stage, n, op);
   if (rc != 0) return fail(c, VMC_ERR_HIP, "host all-reduce hook failed with code " + std::to_string(rc));
-  HIPCHK(c, hipMemcpyAsync(buf, c->h_stage, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(buf, c->h_stage, nf * sizeof(float), hipMemcpyHostToDevice, c->stream));
   return VMC_OK;
 }
 
@@ -936,6 +952,7 @@ void vmc_destroy(vmc_ctx* c) {
   for (void* q : sr) if (q) hipFree(q);
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->d_stage) hipFree(c->d_stage);
+  if (c->d_eval) hipFree(c->d_eval);
   delete c;
 }
 
@@ -1531,6 +1548,13 @@ int vmc_set_host_allreduce(vmc_ctx* c, vmc_host_allreduce_fn hook, void* user) {
   return VMC_OK;
 }
 
+int vmc_set_device_allreduce(vmc_ctx* c, vmc_device_allreduce_fn hook, void* user) {
+  CHECK_CTX(c);
+  c->dev_reduce = hook;
+  c->dev_reduce_user = user;
+  return VMC_OK;
+}
+
 const char* vmc_rccl_last_error(void) { return g_rccl_error.c_str(); }
 
 const char* vmc_rccl_library_path(void) {
@@ -1768,6 +1792,51 @@ int vmc_epoch_log_overlap_dist(vmc_ctx* c, void* nccl_comm, int32_t world_size, 
   ENTER(c);
   return epoch_log_overlap_impl(c, nccl_comm, world_size, beta, n_eq_steps, n_batches, n_mc_steps, max_value, lr,
                                 beta1, beta2, eps, energy);
+}
+
+// MonteCarloOperatorEvaluator.run_evaluation (evaluation.py:138-145) without a host round trip per
+// sample: the batch sums go to d_eval[s]; one float64 all-reduce of the per-rank means at the end.
+int vmc_evaluate(vmc_ctx* c, void* nccl_comm, int32_t world_size, int64_t n_eq_steps, int32_t n_samples,
+                 int64_t n_mc_steps, double* means, int64_t* accepted) {
+  ENTER(c);
+  if (n_eq_steps < 0 || n_samples < 0 || n_mc_steps < 0) return fail(c, VMC_ERR_INVALID, "negative count");
+  if (n_samples > 0 && !means) return fail(c, VMC_ERR_INVALID, "null means");
+  if (c->n_bonds <= 0) return fail(c, VMC_ERR_STATE, "bonds not set (vmc_set_bonds)");
+  if (n_samples > c->d_eval_n) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_eval) hipFree(c->d_eval);
+    c->d_eval = nullptr; c->d_eval_n = 0;
+    HIPCHK(c, dalloc(&c->d_eval, n_samples));
+    c->d_eval_n = n_samples;
+  }
+  PROPAGATE(vmc_mc_steps(c, n_eq_steps, nullptr));                        // evaluation.py:135-136
+  PROPAGATE(join_sweep(c));
+  // the samplers add their acceptances to the device counter; it is read once, at the end
+  HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), c->stream));
+  for (int s = 0; s < n_samples; ++s) {                                   // evaluation.py:138-145
+    PROPAGATE(join_sweep(c));
+    PROPAGATE(local_energy_device(c, VMC_PSI));
+    HIPCHK(c, launch_sum(c->stream, c->ps[0].eloc, c->B, c->d_eval + s));
+    PROPAGATE(vmc_mc_steps(c, n_mc_steps, nullptr));
+  }
+  PROPAGATE(join_sweep(c));
+  const int world = world_size > 1 ? world_size : 1;
+  if (n_samples > 0) {
+    HIPCHK(c, launch_div_f64(c->stream, c->d_eval, n_samples, (double)c->B));   // this rank's batch means
+    if (sharded(nccl_comm, world_size))
+      PROPAGATE(reduce_buffer(c, nccl_comm, world_size, c->d_eval, n_samples, VMC_REDUCE_SUM_F64));
+    HIPCHK(c, hipMemcpyAsync(means, c->d_eval, n_samples * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  }
+  unsigned long long h_acc = 0;
+  int cnt_total = 0;
+  HIPCHK(c, hipMemcpyAsync(&h_acc, c->d_accepted, sizeof(h_acc), hipMemcpyDeviceToHost, c->stream));
+  if (n_samples > 0) HIPCHK(c, hipMemcpyAsync(&cnt_total, c->off + c->B, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (n_samples > 0) c->last_rows = cnt_total;
+  if (world > 1)
+    for (int s = 0; s < n_samples; ++s) means[s] /= (double)world;       // mean over ALL ranks' chains
+  if (accepted) *accepted = (int64_t)h_acc;
+  return VMC_OK;
 }
 
 // ------------------------------------------------------------------ stochastic reconfiguration

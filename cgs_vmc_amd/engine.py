@@ -32,6 +32,9 @@ _LIVE_ENGINES = weakref.WeakSet()
 
 
 def _close_live_engines():
+  par = sys.modules.get(__package__ + '.parallel')
+  if par is not None:                # the library's RCCL communicator goes first (ncclCommDestroy)
+    par.close_collective()
   for eng in list(_LIVE_ENGINES):
     try:
       eng.close()
@@ -73,6 +76,7 @@ class VmcEngine:
     self.n_sites, self.batch_size = n_sites, batch_size
     self.num_layers, self.layer_size = num_layers, layer_size
     self.chain_offset, self.seed, self.device = chain_offset, seed, device
+    self.stream = int(stream or 0)     # hipStream_t the ctx launches on (0: the null stream)
     self.ansatz = ansatz
     self.kernel_size, self.size_x, self.size_y = kernel_size, size_x, size_y
     if ansatz in _hip.CONV_ANSATZ:
@@ -309,13 +313,31 @@ class VmcEngine:
   # ------------------------------------------------------------------ chains sharded over ranks
   # `coll` is a parallel.Collective: (RCCL communicator handle or None, world size, host hook).
   def _bind_collective(self, coll):
-    """Registers coll's host all-reduce hook (non-RCCL transports) and returns (comm, world)."""
+    """Registers coll's device / host all-reduce hooks (the transports without a communicator of
+    the library's own) and returns (comm, world)."""
     hook = coll.host_hook()
     if getattr(self, '_host_hook', None) is not hook:
       self._check(self._lib.vmc_set_host_allreduce(
           self._ctx, hook if hook is not None else _hip.HOST_ALLREDUCE_FN(), None))
       self._host_hook = hook       # keeps the ctypes thunk alive as long as the ctx may call it
+    dhook = coll.device_hook()
+    if getattr(self, '_device_hook', None) is not dhook:
+      self._check(self._lib.vmc_set_device_allreduce(
+          self._ctx, dhook if dhook is not None else _hip.DEVICE_ALLREDUCE_FN(), None))
+      self._device_hook = dhook
     return C.c_void_p(coll.comm or None), int(coll.world)
+
+  def evaluate(self, coll, n_eq_steps: int, n_samples: int, n_mc_steps: int):
+    """evaluation.py:113-152 in one host call -> (batch means over ALL ranks' chains [n_samples]
+    float64, acceptance count of this rank's chains over the measurement steps).  `coll` is a
+    parallel.Collective or None (single rank)."""
+    comm, world = self._bind_collective(coll) if coll is not None else (C.c_void_p(None), 1)
+    means = np.empty(max(int(n_samples), 1), np.float64)
+    acc = C.c_int64(0)
+    self._check(self._lib.vmc_evaluate(self._ctx, comm, world, int(n_eq_steps), int(n_samples),
+                                       int(n_mc_steps), means.ctypes.data_as(C.POINTER(C.c_double)),
+                                       C.byref(acc)))
+    return means[:int(n_samples)], int(acc.value)
 
   def allreduce_accumulators_dist(self, coll):
     comm, world = self._bind_collective(coll)

@@ -2,10 +2,14 @@
 MonteCarloOperatorEvaluator)."""
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, List, NamedTuple
+
+import numpy as np
 
 from . import graph_builders
 from . import operators
+from . import parallel
 from . import session as session_lib
 from .training import _run_mc_steps
 
@@ -29,6 +33,24 @@ class WavefunctionEvaluator():
 
   def run_evaluation(self, eval_ops, session, hparams, epoch_num: int) -> Any:
     raise NotImplementedError
+
+
+def _fused_evaluation(eval_ops):
+  """(engine, ensure_hamiltonian) when `eval_ops` are the handles build_eval_ops made -- the batch
+  mean of a Hamiltonian's local value under the wavefunction that also drives mc_step on the same
+  CONFIGS variable -- else None (the op-by-op loop serves anything else).  CGS_VMC_EVAL_FUSED=0
+  forces the op-by-op loop."""
+  if os.environ.get('CGS_VMC_EVAL_FUSED', '1') == '0':
+    return None
+  lv = getattr(eval_ops.value, 'local_value_tensor', None)
+  mc = eval_ops.mc_step
+  if not isinstance(lv, operators.LocalValueTensor) or not hasattr(mc, 'run_many'):
+    return None
+  if lv.configs is not getattr(mc, 'configs', None) or lv.wavefunction is not getattr(mc, 'wavefunction', None):
+    return None
+  if lv.wavefunction._which != 0 or not hasattr(lv.engine, 'evaluate'):
+    return None
+  return lv.engine, lambda: lv.configs._ensure_hamiltonian(lv.operator)
 
 
 class MonteCarloOperatorEvaluator(WavefunctionEvaluator):
@@ -64,6 +86,18 @@ class MonteCarloOperatorEvaluator(WavefunctionEvaluator):
     steps_per_sweep = hparams.num_sites
     decorrelation = hparams.num_monte_carlo_sweeps * steps_per_sweep
     self.acceptance_count = 0
+    fused = _fused_evaluation(eval_ops)
+    if fused is not None:
+      # the whole loop in ONE host call (vmc_evaluate): batch sums stay on the device, sharded
+      # chains are reduced in one float64 all-reduce at the end -- the same list of float32 means
+      engine, ensure = fused
+      ensure()
+      coll = parallel.collective() if parallel.world_size() > 1 else None
+      means, accepted = engine.evaluate(coll, hparams.num_equilibration_sweeps * steps_per_sweep,
+                                        hparams.num_evaluation_samples, decorrelation)
+      self.acceptance_count = accepted
+      eval_ops.mc_step.last_accepted = accepted
+      return [np.float32(m) for m in means]
 
     def measurements():
       _run_mc_steps(session, eval_ops.mc_step, hparams.num_equilibration_sweeps * steps_per_sweep)

@@ -125,5 +125,7 @@ class LocalValueTensor(session_lib.Tensor):
 def reduce_mean(tensor) -> session_lib.Tensor:
   """tf.reduce_mean for the tensors of this module."""
   if isinstance(tensor, LocalValueTensor):
-    return session_lib.Tensor(lambda: np.float32(tensor.mean()), 'mean')
+    out = session_lib.Tensor(lambda: np.float32(tensor.mean()), 'mean')
+    out.local_value_tensor = tensor       # evaluation.run_evaluation fuses the loop over it
+    return out
   return session_lib.Tensor(lambda: np.float32(np.mean(tensor._run())), 'mean')

@@ -74,9 +74,19 @@ def shard(batch_size: int):
 class _DevArray:
   """__cuda_array_interface__ view of library-owned device memory (zero copy)."""
 
-  def __init__(self, ptr: int, n: int):
+  def __init__(self, ptr: int, n: int, typestr: str = '<f4'):
     self.__cuda_array_interface__ = {
-        'shape': (n,), 'typestr': '<f4', 'data': (ptr, False), 'version': 2, 'strides': None}
+        'shape': (n,), 'typestr': typestr, 'data': (ptr, False), 'version': 2, 'strides': None}
+
+
+def _torch_stream(device: int, stream: int):
+  """torch's handle of the hipStream_t a ctx launches on (vmc_desc.stream; 0 = the null stream, which
+  is torch's default stream).  Collectives issued under `with torch.cuda.stream(...)` of it are
+  ordered against the library's kernels without a host synchronisation."""
+  import torch
+  if stream:
+    return torch.cuda.ExternalStream(int(stream), device=torch.device('cuda', device))
+  return torch.cuda.default_stream(torch.device('cuda', device))
 
 
 _acc_views = {}
@@ -103,34 +113,39 @@ def allreduce_accumulators(engine):
     # gloo (tests, CPU rendezvous): stage through the host
     engine.set_accumulators(reduce_accumulators_host(engine.get_accumulators()))
     return
-  # Stream ordering, no host sync: the library launches on the legacy null stream, which is
-  # torch's current (default) stream; the RCCL collective waits for that stream before it
-  # starts and makes it wait for the result (torch.distributed semantics for async_op=False).
+  # Stream ordering, no host sync: the collective is issued with the ctx's own stream
+  # (vmc_desc.stream; the null stream = torch's default stream unless the caller chose one) as
+  # torch's current stream: RCCL waits for that stream before it starts and makes it wait for
+  # the result (torch.distributed semantics for async_op=False).
   # CGS_VMC_SAFE_SYNC=1 adds explicit host synchronisation on both sides.
+  import torch
   safe = os.environ.get('CGS_VMC_SAFE_SYNC', '0') == '1'
   if safe:
     engine.synchronize()
   t = accumulator_tensor(engine)
-  _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
-  # mean_tensor's count is the number of accumulate CALLS (training.py:550-553), which every
-  # rank made in lock-step: undo the sum so that sharded == unsharded gradients
-  t[t.numel() - 4] /= world_size()
+  st = _torch_stream(engine.device, getattr(engine, 'stream', 0))
+  with torch.cuda.stream(st):
+    _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
+    # mean_tensor's count is the number of accumulate CALLS (training.py:550-553), which every
+    # rank made in lock-step: undo the sum so that sharded == unsharded gradients
+    t[t.numel() - 4] /= world_size()
   if safe:
-    import torch
-    torch.cuda.current_stream(t.device).synchronize()
+    st.synchronize()
 
 
 class _PendingReduce:
   """Handle of an in-flight accumulator all-reduce (see allreduce_accumulators_begin)."""
 
-  def __init__(self, work, tensor):
-    self.work, self.tensor = work, tensor
+  def __init__(self, work, tensor, stream=None):
+    self.work, self.tensor, self.stream = work, tensor, stream
 
   def wait(self):
-    """Orders the current stream after the collective (no host sync) and restores g_count."""
+    """Orders the ctx's stream after the collective (no host sync) and restores g_count."""
     if self.work is not None:
-      self.work.wait()
-      self.tensor[self.tensor.numel() - 4] /= world_size()
+      import torch
+      with torch.cuda.stream(self.stream):
+        self.work.wait()
+        self.tensor[self.tensor.numel() - 4] /= world_size()
       self.work = None
 
 
@@ -143,8 +158,12 @@ def allreduce_accumulators_begin(engine) -> _PendingReduce:
   if _dist().get_backend() != 'nccl':
     allreduce_accumulators(engine)
     return _PendingReduce(None, None)
+  import torch
   t = accumulator_tensor(engine)
-  return _PendingReduce(_dist().all_reduce(t, op=_dist().ReduceOp.SUM, async_op=True), t)
+  st = _torch_stream(engine.device, getattr(engine, 'stream', 0))
+  with torch.cuda.stream(st):
+    work = _dist().all_reduce(t, op=_dist().ReduceOp.SUM, async_op=True)
+  return _PendingReduce(work, t, st)
 
 
 def allreduce_sr_buffer(engine):
@@ -159,29 +178,55 @@ def allreduce_sr_buffer(engine):
     return
   ptr, n = engine.sr_buffer_devptr()
   t = torch.as_tensor(_DevArray(ptr, n), device=torch.device('cuda', engine.device))
-  _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
+  with torch.cuda.stream(_torch_stream(engine.device, getattr(engine, 'stream', 0))):
+    _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
 
 
 class Collective:
-  """How the LIBRARY reduces over ranks inside its device-resident epoch / CG entry points
-  (include/cgsvmc.h, `*_dist`): an RCCL communicator the library itself created next to
-  torch.distributed's process group (backend 'nccl': in-stream ncclAllReduce over xGMI, no host
-  synchronisation), or -- any other backend, e.g. the gloo tests -- a host hook that all-reduces
-  a pinned staging buffer through torch.distributed.  `comm` is the ncclComm_t as an integer (0:
-  none), `world` the number of ranks."""
+  """How the LIBRARY reduces over ranks inside its device-resident epoch / CG / evaluation entry
+  points (include/cgsvmc.h, `*_dist`, vmc_evaluate).  Three transports:
 
-  def __init__(self, comm: int = 0, world: int = 1, use_hook: bool = False):
-    self.comm, self.world = int(comm), int(world)
+  * 'torch' (default under backend 'nccl'): a DEVICE hook -- the library calls back at the point of
+    the epoch where the all-reduce belongs and the hook issues torch.distributed.all_reduce (RCCL
+    over xGMI, torch's own communicator) on a zero-copy view of the device buffer with the ctx's
+    stream as torch's current stream: in stream, no staging, no host synchronisation;
+  * 'rccl' (CGS_VMC_TRANSPORT=rccl): an RCCL communicator the library itself created next to
+    torch's (in-stream ncclAllReduce, no Python in the loop).  Opt-in: it has run on one rank only
+    (tests/test_gpu_dist.py) -- no multi-GPU box has been available to this repository;
+  * 'host' (any other backend, e.g. the gloo tests; CGS_VMC_TRANSPORT=host): a host hook that
+    all-reduces a pinned staging buffer through torch.distributed.
+
+  `comm` is the ncclComm_t as an integer (0: none), `world` the number of ranks."""
+
+  def __init__(self, comm: int = 0, world: int = 1, use_hook: bool = False,
+               use_device_hook: bool = False, device: int = 0):
+    self.comm, self.world, self.device = int(comm), int(world), int(device)
     self._hook = None
+    self._dhook = None
+    self._views = {}
+    from . import _hip
     if use_hook:
-      from . import _hip
       self._hook = _hip.HOST_ALLREDUCE_FN(self._host_allreduce)
+    if use_device_hook:
+      self._dhook = _hip.DEVICE_ALLREDUCE_FN(self._device_allreduce)
+
+  @property
+  def transport(self) -> str:
+    if self.comm:
+      return 'rccl'
+    if self.world <= 1:
+      return 'none'
+    return 'torch' if self._dhook is not None else 'host'
 
   def host_hook(self):
     return self._hook
 
+  def device_hook(self):
+    return self._dhook
+
   def allreduce_host(self, buf: np.ndarray, op: str = 'sum') -> np.ndarray:
-    """In-place all-reduce of a float32 host array over torch.distributed (what the hook does)."""
+    """In-place all-reduce of a float32 / float64 host array over torch.distributed (what the
+    host hook does)."""
     if self.world > 1:
       import torch
       dist = _dist()
@@ -196,7 +241,11 @@ class Collective:
 
   def _host_allreduce(self, user, ptr, n, op):   # vmc_host_allreduce_fn
     try:
-      buf = np.ctypeslib.as_array(ptr, shape=(int(n),))
+      if op == 2:                                # VMC_REDUCE_SUM_F64: n doubles in the float staging buffer
+        import ctypes as C
+        buf = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(int(n),))
+      else:
+        buf = np.ctypeslib.as_array(ptr, shape=(int(n),))
       self.allreduce_host(buf, 'max' if op == 1 else 'sum')
       return 0
     except Exception:  # pylint: disable=broad-except
@@ -204,7 +253,28 @@ class Collective:
       traceback.print_exc()
       return 1
 
+  def _device_allreduce(self, user, ptr, n, op, stream):   # vmc_device_allreduce_fn
+    try:
+      import torch
+      dist = _dist()
+      key = (int(ptr), int(n), int(op))
+      t = self._views.get(key)
+      if t is None:
+        if len(self._views) > 16:
+          self._views.clear()
+        t = torch.as_tensor(_DevArray(int(ptr), int(n), '<f8' if op == 2 else '<f4'),
+                            device=torch.device('cuda', self.device))
+        self._views[key] = t
+      with torch.cuda.stream(_torch_stream(self.device, stream or 0)):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+      return 0
+    except Exception:  # pylint: disable=broad-except
+      import traceback
+      traceback.print_exc()
+      return 1
+
   def close(self):
+    self._views.clear()
     if self.comm:
       from . import _hip
       _hip.load().vmc_rccl_comm_destroy(self.comm)
@@ -214,43 +284,89 @@ class Collective:
 _collective = None
 
 
+def transport_choice() -> str:
+  """'torch' | 'rccl' | 'host' for the current process group (see Collective)."""
+  nccl = _dist().get_backend() == 'nccl'
+  choice = os.environ.get('CGS_VMC_TRANSPORT')
+  if choice is None:
+    if not nccl:
+      return 'host'
+    choice = 'rccl' if os.environ.get('CGS_VMC_LIBRARY_RCCL', '0') == '1' else 'torch'
+  if choice not in ('torch', 'rccl', 'host'):
+    raise ValueError("CGS_VMC_TRANSPORT must be 'torch', 'rccl' or 'host', not {!r}".format(choice))
+  if choice == 'rccl' and not nccl:
+    raise ValueError("CGS_VMC_TRANSPORT=rccl needs the 'nccl' backend (one device per rank)")
+  return choice       # 'torch' under gloo: gloo reduces device tensors too (the single-GPU tests)
+
+
 def collective(device: int = None) -> Collective:
   """The process-wide Collective for the current torch.distributed group (created on first use;
   a collective call: every rank must reach it)."""
   global _collective
   if _collective is not None and _collective.world == world_size():
     return _collective
+  if _collective is not None:
+    _collective.close()
   if world_size() == 1:
     _collective = Collective()
     return _collective
-  dist = _dist()
-  use_rccl = dist.get_backend() == 'nccl' and os.environ.get('CGS_VMC_LIBRARY_RCCL', '1') != '0'
-  if not use_rccl:
-    _collective = Collective(0, world_size(), use_hook=True)
-    return _collective
-  _collective = rccl_collective(local_rank() if device is None else device)
+  dev = local_rank() if device is None else device
+  choice = transport_choice()
+  if choice == 'host':
+    _collective = Collective(0, world_size(), use_hook=True, device=dev)
+  elif choice == 'torch':
+    _collective = Collective(0, world_size(), use_device_hook=True, device=dev)
+  else:
+    _collective = rccl_collective(dev)
   return _collective
+
+
+def close_collective():
+  """Destroys the process-wide Collective (ncclCommDestroy for the 'rccl' transport).  Runs at
+  interpreter exit BEFORE the engines are closed (engine._close_live_engines)."""
+  global _collective
+  if _collective is not None:
+    try:
+      _collective.close()
+    except Exception:  # pylint: disable=broad-except
+      pass
+    _collective = None
 
 
 def rccl_collective(device: int, world: int = None, rank_: int = None) -> Collective:
   """Creates the library's own RCCL communicator: rank 0 draws the ncclUniqueId, it travels over
-  the existing process group (or not at all for world == 1), every rank joins on `device`."""
+  the existing process group (or not at all for world == 1), every rank joins on `device`.  A
+  failure on ANY rank (the id on rank 0, ncclCommInitRank anywhere) is raised on EVERY rank: the
+  id travels together with rank 0's status, and a success flag is all-reduced after the join."""
   import ctypes as C
   from . import _hip
   lib = _hip.load()
   world = world_size() if world is None else world
   rank_ = rank() if rank_ is None else rank_
   uid = (C.c_uint8 * 128)()
+  status = ''
   if rank_ == 0 and lib.vmc_rccl_unique_id(uid) != 0:
-    raise _hip.HipLibraryError('vmc_rccl_unique_id: ' + lib.vmc_rccl_last_error().decode())
+    status = 'vmc_rccl_unique_id: ' + lib.vmc_rccl_last_error().decode()
   if world > 1:
-    box = [bytes(uid)]
+    box = [(status, bytes(uid))]
     _dist().broadcast_object_list(box, src=0)
-    uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+    status, raw = box[0]
+    uid = (C.c_uint8 * 128).from_buffer_copy(raw)
+  if status:
+    raise _hip.HipLibraryError(status)       # every rank raises together, nobody is left waiting
   comm = C.c_void_p()
+  err = ''
   if lib.vmc_rccl_comm_create(uid, world, rank_, device, C.byref(comm)) != 0:
-    raise _hip.HipLibraryError('vmc_rccl_comm_create: ' + lib.vmc_rccl_last_error().decode())
-  return Collective(comm.value, world)
+    err = 'vmc_rccl_comm_create: ' + lib.vmc_rccl_last_error().decode()
+  if world > 1:
+    failed = allreduce_sum(1.0 if err else 0.0)
+    if failed > 0.0:
+      if comm.value:
+        lib.vmc_rccl_comm_destroy(comm)
+      raise _hip.HipLibraryError(err or 'vmc_rccl_comm_create failed on {:.0f} other rank(s)'.format(failed))
+  elif err:
+    raise _hip.HipLibraryError(err)
+  return Collective(comm.value, world, device=device)
 
 
 def sr_solve(engine, diag_shift: float, tol: float, max_iter: int):

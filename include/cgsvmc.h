@@ -206,13 +206,25 @@ int vmc_epoch_log_overlap(vmc_ctx* ctx, float beta, int64_t n_eq_steps, int32_t 
  *
  * Transport: an RCCL communicator (`nccl_comm` = ncclComm_t; librccl is resolved with dlopen at
  * first use, the copy torch has already loaded if there is one) or, when nccl_comm == NULL and
- * world_size > 1, the host hook registered with vmc_set_host_allreduce: the library copies the
- * buffer to pinned host memory, calls the hook (which must all-reduce host_buf in place over all
- * ranks: gloo, MPI, ...), and copies it back.  nccl_comm == NULL with world_size <= 1 is the
+ * world_size > 1, the device hook of vmc_set_device_allreduce (below) or the host hook registered
+ * with vmc_set_host_allreduce: the library copies the buffer to pinned host memory, calls the hook
+ * (which must all-reduce host_buf in place over all ranks: gloo, MPI, ...), and copies it back.  nccl_comm == NULL with world_size <= 1 is the
  * single-rank no-op; a 1-rank communicator still goes through ncclAllReduce. */
-enum { VMC_REDUCE_SUM = 0, VMC_REDUCE_MAX = 1 };
-typedef int (*vmc_host_allreduce_fn)(void* user, float* host_buf, int64_t n_floats, int32_t op);
+enum { VMC_REDUCE_SUM = 0, VMC_REDUCE_MAX = 1,
+       VMC_REDUCE_SUM_F64 = 2 /* the buffer holds n DOUBLES (vmc_evaluate's batch means) */ };
+typedef int (*vmc_host_allreduce_fn)(void* user, float* host_buf, int64_t n_elements, int32_t op);
 int vmc_set_host_allreduce(vmc_ctx* ctx, vmc_host_allreduce_fn hook, void* user);
+/* Third transport, for hosts whose collective library keeps its communicator to itself but reduces
+ * device memory in stream order (torch.distributed's ProcessGroupNCCL = RCCL on ROCm): with
+ * nccl_comm == NULL and world_size > 1 the library calls this hook -- when one is registered it wins
+ * over the host hook -- at the point of the epoch where the all-reduce belongs.  The hook must ENQUEUE
+ * an in-place all-reduce of n_elements (float32; float64 for VMC_REDUCE_SUM_F64) at dev_buf that is
+ * ordered after the work already on `stream` (the ctx's hipStream_t, NULL = the null stream) and
+ * before whatever is enqueued on it afterwards; it need not wait for completion.  No staging copy,
+ * no host synchronisation. */
+typedef int (*vmc_device_allreduce_fn)(void* user, void* dev_buf, int64_t n_elements, int32_t op,
+                                       void* stream);
+int vmc_set_device_allreduce(vmc_ctx* ctx, vmc_device_allreduce_fn hook, void* user);
 /* Communicator life cycle for hosts whose collective library does not expose its ncclComm_t
  * (torch.distributed): rank 0 draws the 128-byte ncclUniqueId and shares it by any channel, every
  * rank then calls vmc_rccl_comm_create (ncclCommInitRank on `device`). */
@@ -247,6 +259,17 @@ int vmc_epoch_log_overlap_dist(vmc_ctx* ctx, void* nccl_comm, int32_t world_size
                                int64_t n_eq_steps, int32_t n_batches, int64_t n_mc_steps,
                                float max_value, float lr, float beta1, float beta2, float eps,
                                double* energy);
+
+/* MonteCarloOperatorEvaluator.run_evaluation (evaluation.py:113-152) in ONE host call: n_eq_steps
+ * mc_steps, then n_samples x [batch mean of the Hamiltonian's local value (evaluation.py:102),
+ * n_mc_steps mc_steps].  The batch sums stay on the device; with sharded chains (transport as
+ * above) the n_samples per-rank means are SUM-all-reduced in float64 in one collective at the end
+ * and divided by world_size, exactly what the op-by-op loop does per sample.  means[n_samples]
+ * receives the list run_evaluation returns (as doubles; the Python side rounds to float32 like
+ * tf.reduce_mean); *accepted (may be NULL) the acceptance count of THIS rank's chains over the
+ * n_samples x n_mc_steps measurement steps (the count the reference computes and drops). */
+int vmc_evaluate(vmc_ctx* ctx, void* nccl_comm, int32_t world_size, int64_t n_eq_steps,
+                 int32_t n_samples, int64_t n_mc_steps, double* means, int64_t* accepted);
 
 /* Stochastic reconfiguration -- EXTENSION: named by the north star, absent from the reference
  * (training.py has only the plain energy gradient + Adam), so these entries replace no reference

@@ -1,7 +1,10 @@
-"""Worker of tests/test_gpu_dist.py: two gloo ranks sharing ONE GPU drive the product routing for
-sharded chains (training.run_optimization_epoch -> vmc_epoch_*_dist, parallel.sr_solve ->
-vmc_sr_solve_dist; transport = the host all-reduce hook, because RCCL refuses two ranks on one
-device) and compare every epoch with an UNSHARDED engine stepping the same global batch op by op."""
+"""Worker of tests/test_gpu_dist.py: WORLD_SIZE (2 or 4) gloo ranks sharing ONE GPU drive the product
+routing for sharded chains (training.run_optimization_epoch -> vmc_epoch_*_dist, parallel.sr_solve ->
+vmc_sr_solve_dist, evaluation.run_evaluation -> vmc_evaluate) and compare every epoch with an
+UNSHARDED engine stepping the same global batch op by op.  Transport (CGS_VMC_TRANSPORT): 'host' =
+the host all-reduce hook, or 'torch' = the device hook, i.e. torch.distributed.all_reduce on the
+library's device buffer in stream order -- the default transport of a real multi-GPU job (backend
+'nccl'), here over gloo, which reduces device tensors too (RCCL refuses two ranks on one device)."""
 import os
 import sys
 
@@ -27,10 +30,14 @@ def _gather_rows(local_rows):
 def main():
   os.environ.update(CGS_VMC_SEED='77', CGS_VMC_CONFIG_SEED='5', CGS_VMC_INIT_SEED='31')
   parallel.init_from_env('gloo')
-  assert parallel.world_size() == 2
+  world = int(os.environ['WORLD_SIZE'])
+  assert parallel.world_size() == world
   rank = parallel.rank()
   coll = parallel.collective()
-  assert coll.comm == 0 and coll.host_hook() is not None
+  want = os.environ.get('CGS_VMC_TRANSPORT', 'host')
+  assert coll.comm == 0 and coll.transport == want
+  assert (coll.device_hook() is not None) == (want == 'torch') and (coll.host_hook() is not None) == (want == 'host')
+  lb = 64 // world
   for name in ('LogOverlapITSWO', 'EnergyGradient', 'StochasticReconfiguration'):
     session.reset_default_graph()
     wavefunctions.reset_name_scope()
@@ -47,7 +54,7 @@ def main():
     sess = session.Session()
     sess.run([session.global_variables_initializer(), session.local_variables_initializer()])
     cfg_var = shared[graph_builders.ResourceName.CONFIGS]
-    assert cfg_var.local_batch == 32 and cfg_var.chain_offset == 32 * rank
+    assert cfg_var.local_batch == lb and cfg_var.chain_offset == lb * rank
     # the unsharded twin: the gathered global batch on one engine, stepped op by op
     ref = VmcEngine(n, 64, L, h, seed=77)
     ref.set_params(wf._get_theta())
@@ -86,7 +93,7 @@ def main():
         ref.reset_accumulators()
       energy = opt.run_optimization_epoch(ops, sess, hp, epoch)
       assert abs(energy - e_ref) < 2e-5 * max(1.0, abs(e_ref)), (name, epoch, energy, e_ref)
-      np.testing.assert_array_equal(cfg_var.eval(), ref.get_configs()[32 * rank:32 * (rank + 1)])
+      np.testing.assert_array_equal(cfg_var.eval(), ref.get_configs()[lb * rank:lb * (rank + 1)])
       got, want = wf._get_theta(), ref.get_params()
       if name == 'StochasticReconfiguration':
         assert opt.last_cg[0] == it_ref and abs(opt.last_cg[1] - res_ref) < 1e-3, (opt.last_cg, it_ref, res_ref)
@@ -99,8 +106,30 @@ def main():
       ref.set_params(got)
       m, v, t = cfg_var._engine.get_adam_state()
       ref.set_adam_state(m, v, t)
-    both = _gather_rows(wf._get_theta()[None, :])
-    np.testing.assert_array_equal(both[0], both[1])       # identical step on every rank
+    every = _gather_rows(wf._get_theta()[None, :])
+    for r in range(1, world):
+      np.testing.assert_array_equal(every[0], every[r])   # identical step on every rank
+    if name == 'EnergyGradient':
+      # evaluation.run_evaluation on the sharded chains: the fused entry (vmc_evaluate, one float64
+      # all-reduce) against the op-by-op loop (one all-reduce per sample) and the unsharded engine
+      from cgs_vmc_amd import evaluation
+      hp.set_hparam('num_evaluation_samples', 5)
+      ev = evaluation.MonteCarloOperatorEvaluator()
+      eops = ev.build_eval_ops(wavefunction=wf, operator=ham, hparams=hp, shared_resources=shared)
+      eng = cfg_var._engine
+      start, step0 = cfg_var.eval().copy(), eng.step_counter
+      fused = ev.run_evaluation(eops, sess, hp, 0)
+      acc_fused = ev.acceptance_count
+      cfg_var.load(start); eng.step_counter = step0
+      os.environ['CGS_VMC_EVAL_FUSED'] = '0'
+      loop = ev.run_evaluation(eops, sess, hp, 0)
+      del os.environ['CGS_VMC_EVAL_FUSED']
+      assert len(fused) == 5 and fused == loop and acc_fused == ev.acceptance_count, (fused, loop)
+      ref.set_params(wf._get_theta())
+      ref.set_shift(wf._get_shift())
+      ref.set_configs(_gather_rows(start)); ref.step_counter = step0
+      m_ref, _ = ref.evaluate(None, 2 * n, 5, n)
+      assert np.allclose(fused, m_ref, rtol=1e-6, atol=1e-6), (fused, m_ref)
     ref.close()
   dist.barrier()
   dist.destroy_process_group()

@@ -1,5 +1,6 @@
-"""Worker of tests/test_parallel_gloo.py: world_size-2 check of the sharding + reduction
-logic of cgs_vmc_amd.parallel with the oracle standing in for the GPU kernels."""
+"""Worker of tests/test_parallel_gloo.py: world_size 2 and 8 (BASELINE configs 4 / 5 are 8-rank jobs)
+check of the sharding + reduction logic of cgs_vmc_amd.parallel with the oracle standing in for the
+GPU kernels."""
 import os
 import sys
 
@@ -48,10 +49,10 @@ class _OracleSrEngine:
 
 
 def _gather_rows(local_rows):
-  """Global batch [B, N] from every rank's [B/2, N] shard."""
+  """Global batch [B, N] from every rank's [B/W, N] shard."""
   import torch
   t = torch.from_numpy(np.ascontiguousarray(local_rows, np.float32))
-  parts = [torch.empty_like(t) for _ in range(2)]
+  parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
   dist.all_gather(parts, t)
   return np.concatenate([p.numpy() for p in parts])
 
@@ -68,7 +69,10 @@ def routed_training_epochs(rank):
   from tests.oracle_engine import OracleEngine
   engine_mod.VmcEngine = OracleEngine
   coll = parallel.collective()
-  assert coll.world == 2 and coll.comm == 0 and coll.host_hook() is not None   # gloo: host hook
+  world = parallel.world_size()
+  assert coll.world == world and coll.comm == 0 and coll.host_hook() is not None   # gloo: host hook
+  assert coll.transport == 'host' and coll.device_hook() is None
+  lb = 32 // world
   for name in ('LogOverlapITSWO', 'EnergyGradient', 'StochasticReconfiguration'):
     session.reset_default_graph()
     wavefunctions.reset_name_scope()
@@ -85,7 +89,8 @@ def routed_training_epochs(rank):
     sess = session.Session()
     sess.run([session.global_variables_initializer(), session.local_variables_initializer()])
     cfg_var = shared[graph_builders.ResourceName.CONFIGS]
-    assert isinstance(cfg_var._engine, OracleEngine) and cfg_var.local_batch == 16
+    assert isinstance(cfg_var._engine, OracleEngine) and cfg_var.local_batch == lb
+    assert cfg_var.chain_offset == lb * rank
     # ---- unsharded oracle restatement of the same epochs on the gathered global batch
     theta = wf._get_theta().copy()
     cfg = _gather_rows(cfg_var.eval())
@@ -130,21 +135,25 @@ def routed_training_epochs(rank):
       energy = opt.run_optimization_epoch(ops, sess, hp, epoch)
       assert abs(energy - acc.mean_energy()) < 1e-5 * max(1.0, abs(acc.mean_energy())), (name, energy)
       mine = cfg_var.eval()
-      np.testing.assert_array_equal(mine, cfg[16 * rank:16 * (rank + 1)].astype(np.float32))
-      tol = 2e-4 if name == 'StochasticReconfiguration' else 2e-6    # CG tolerance 1e-3 vs dense solve
+      np.testing.assert_array_equal(mine, cfg[lb * rank:lb * (rank + 1)].astype(np.float32))
+      # CG tolerance 1e-3 vs dense solve; Adam: fp32 accumulators summed over `world` shards (the 8-way
+      # split re-associates more than the 2-way one: 2.1e-6 seen)
+      tol = 2e-4 if name == 'StochasticReconfiguration' else (2e-6 if world <= 2 else 6e-6)
       got = wf._get_theta()
       err = np.abs(got - theta)[well].max()
       assert err <= tol * max(1.0, np.abs(theta).max()) and well.sum() > 0.8 * well.size, (name, epoch, err)
       theta = got.copy()    # keep the two trajectories on the same parameters epoch by epoch
       adam.m, adam.v = cfg_var._engine.adam.m.copy(), cfg_var._engine.adam.v.copy()
     # every rank holds the identical parameters
-    both = _gather_rows(wf._get_theta()[None, :])
-    np.testing.assert_array_equal(both[0], both[1])
+    every = _gather_rows(wf._get_theta()[None, :])
+    for r in range(1, world):
+      np.testing.assert_array_equal(every[0], every[r])
 
 
 def main():
   parallel.init_from_env('gloo')
-  assert parallel.is_distributed() and parallel.world_size() == 2
+  world = int(os.environ['WORLD_SIZE'])
+  assert parallel.is_distributed() and parallel.world_size() == world
   rank = parallel.rank()
   n, h, L, b = 8, 16, 2, 32
   rng = np.random.default_rng(0)
@@ -153,7 +162,7 @@ def main():
   bonds = vo.chain_bonds(n)
 
   local, offset = parallel.shard(b)
-  assert (local, offset) == (16, 16 * rank)
+  assert (local, offset) == (b // world, (b // world) * rank)
   try:
     parallel.shard(33)
     raise AssertionError('expected ValueError')
@@ -197,8 +206,8 @@ def main():
   assert res <= 1e-5 and 0 < iters < 500, (iters, res)
   assert np.abs(fake.x - x_ref).max() <= 1e-3 * np.abs(x_ref).max(), np.abs(fake.x - x_ref).max()
 
-  assert parallel.allreduce_max(float(rank) + 0.5) == 1.5
-  assert parallel.allreduce_sum(float(rank) + 1.0) == 3.0
+  assert parallel.allreduce_max(float(rank) + 0.5) == world - 0.5
+  assert parallel.allreduce_sum(float(rank) + 1.0) == world * (world + 1) / 2
   routed_training_epochs(rank)
   dist.barrier()
   dist.destroy_process_group()

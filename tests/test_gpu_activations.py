@@ -65,8 +65,6 @@ def _make(n, h, L, b, kind, act, oact='exp', seed=0, scale=1.0, b_out=0.0):
 def test_hidden_activation_parity(act, n, h, L, b, kind):
   from cgs_vmc_amd import _hip
   t_logit, t_e, t_g = _tols(act, h)
-  if act == 'cos' and h > 256:
-    pytest.skip('cos is offered up to 256 hidden units (include/cgsvmc.h)')
   scale = {'tan': 0.2, 'exp': 0.4}.get(act, 1.0)     # keep tan away from its poles, exp from overflow
   eng, theta, cfg, bonds = _make(n, h, L, b, kind, act, scale=scale)
   assert eng.kernel_path() == (0 if h <= 256 else 1)

@@ -3,10 +3,12 @@
 (a) with a 1-rank RCCL communicator created by the library itself (vmc_rccl_comm_create) every
     `_dist` entry is BIT-IDENTICAL to its single-rank twin -- the in-stream ncclAllReduce over one
     rank is the identity and `g_count / 1` is exact;
-(b) two ranks sharing this GPU over gloo (the host-hook transport; RCCL refuses two ranks on one
-    device) run the product routing -- training.run_optimization_epoch / parallel.sr_solve -- and
-    match the same epochs of an unsharded engine: chains bit-identical (Philox keyed by global
-    chain id), parameters within the fp32 reduction-order tolerance (tests/_dist_gpu_worker.py).
+(b) two / four ranks sharing this GPU over gloo (the host-hook and the device-hook transport; RCCL
+    refuses two ranks on one device) run the product routing -- training.run_optimization_epoch /
+    parallel.sr_solve / evaluation.run_evaluation -- and match the same epochs of an unsharded
+    engine: chains bit-identical (Philox keyed by global chain id), parameters within the fp32
+    reduction-order tolerance (tests/_dist_gpu_worker.py);
+(c) vmc_evaluate (the evaluation loop in one host call) against the op-by-op loop.
 """
 import os
 import socket
@@ -118,6 +120,7 @@ def test_sharded_world_without_transport_is_refused():
   eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
   with pytest.raises(_hip.HipLibraryError, match='vmc_set_host_allreduce'):
     eng.allreduce_accumulators_dist(parallel.Collective(0, 2))
+  assert parallel.Collective(0, 2).transport == 'host' and parallel.Collective().transport == 'none'
   eng.close()
 
 
@@ -147,17 +150,118 @@ def test_host_hook_transport_doubles_like_two_identical_ranks():
   eng.close()
 
 
+def test_device_hook_transport_doubles_like_two_identical_ranks():
+  """The device-hook path (the default transport of an `nccl` job: torch.distributed reduces the
+  library's device buffer in stream order) end to end in one process: a hook that behaves like a second
+  rank holding the same data, written with torch ops on the zero-copy view and the ctx's stream."""
+  import torch
+  from cgs_vmc_amd import _hip, parallel
+
+  seen = []
+
+  class Twin(parallel.Collective):
+    def _device_allreduce(self, user, ptr, n, op, stream):
+      seen.append((int(n), int(op), int(stream or 0)))
+      t = torch.as_tensor(parallel._DevArray(int(ptr), int(n), '<f8' if op == 2 else '<f4'),
+                          device=torch.device('cuda', 0))
+      with torch.cuda.stream(parallel._torch_stream(0, stream or 0)):
+        if op != 1:
+          t *= 2
+      return 0
+
+  coll = Twin(0, 2, use_device_hook=True)
+  assert coll.transport == 'torch' and coll.host_hook() is None
+  eng = _engine()
+  x = np.arange(1, 300, dtype=np.float32)
+  np.testing.assert_array_equal(eng.debug_allreduce(coll, x, 'sum'), 2 * x)
+  np.testing.assert_array_equal(eng.debug_allreduce(coll, x, 'max'), x)
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  before = eng.get_accumulators()
+  eng.allreduce_accumulators_dist(coll)
+  expect = 2 * before
+  expect[-4] = before[-4]                  # g_count: calls, not calls x ranks
+  np.testing.assert_array_equal(eng.get_accumulators(), expect)
+  # whole epochs with the hook in the loop.  EnergyGradient: the same chains and shift, twice the sums
+  a = _engine()
+  a.epoch_energy_gradient(32, 3, 16, 1e10)
+  eng.epoch_energy_gradient_dist(coll, 32, 3, 16, 1e10)
+  acc_a, acc_b = a.get_accumulators(), eng.get_accumulators()
+  expect = 2 * acc_a
+  expect[-4] = acc_a[-4]
+  np.testing.assert_array_equal(acc_b, expect)
+  np.testing.assert_array_equal(a.get_configs(), eng.get_configs())
+  assert a.get_shift() == eng.get_shift()
+  # LogOverlapITSWO (Adam inside the epoch, fed by the hook's sums every batch): the batch-SUM gradient
+  # of twice the samples is twice the gradient, which Adam's normalisation takes out again up to epsilon
+  args = (0.12, 32, 3, 16, 1e10, 1e-2, 0.9, 0.99, 1e-8)
+  e_a = a.epoch_log_overlap(*args)
+  e_b = eng.epoch_log_overlap_dist(coll, *args)
+  assert abs(e_a - e_b) < 1e-4 * max(1.0, abs(e_a))
+  d = np.abs(a.get_params() - eng.get_params())
+  assert np.median(d) < 1e-6 and (d < 1e-4).mean() > 0.9
+  # evaluation: the float64 means of two identical ranks are the single-rank means
+  m_a, acc_a = a.evaluate(None, 16, 4, 16)
+  m_b, acc_b = eng.evaluate(coll, 16, 4, 16)
+  np.testing.assert_array_equal(m_a, m_b)
+  assert acc_a == acc_b and (4, 2, 0) in seen
+  a.close(); eng.close()
+
+
+def test_evaluate_is_bit_identical_to_the_op_by_op_loop(rccl1):
+  """vmc_evaluate = evaluation.py:135-145 in one host call: same means, same chains, same acceptance
+  count as n_samples x [vmc_local_energy, vmc_mc_steps]; a 1-rank RCCL communicator is the identity."""
+  n = 16
+  a, b, c = _engine(), _engine(), _engine()
+  a.mc_steps(3 * n)
+  means, accepted = [], 0
+  for _ in range(6):
+    means.append(a.local_energy(want_eloc=False)[1])
+    accepted += a.mc_steps(2 * n)
+  m_b, acc_b = b.evaluate(None, 3 * n, 6, 2 * n)
+  m_c, acc_c = c.evaluate(rccl1, 3 * n, 6, 2 * n)
+  np.testing.assert_array_equal(np.asarray(means), m_b)
+  np.testing.assert_array_equal(m_b, m_c)
+  assert accepted == acc_b == acc_c > 0
+  np.testing.assert_array_equal(a.get_configs(), b.get_configs())
+  np.testing.assert_array_equal(a.get_configs(), c.get_configs())
+  assert a.step_counter == b.step_counter == c.step_counter == 15 * n
+  # no samples: only the equilibration runs; negative counts are refused
+  m0, acc0 = b.evaluate(None, n, 0, n)
+  assert m0.size == 0 and acc0 == 0 and b.step_counter == 16 * n
+  with pytest.raises(ValueError):
+    b.evaluate(None, -1, 1, 1)
+  for x in (a, b, c):
+    x.close()
+
+
+def test_evaluate_needs_bonds():
+  from cgs_vmc_amd import _hip
+  from cgs_vmc_amd.engine import VmcEngine
+  eng = VmcEngine(16, 32, 2, 32)
+  eng.set_params(vo.init_params(16, 32, 2, np.random.default_rng(0)))
+  eng.set_configs(vo.random_configurations(16, 32, np.random.RandomState(1)))
+  with pytest.raises(_hip.HipLibraryError, match='bonds'):
+    eng.evaluate(None, 4, 2, 4)
+  eng.close()
+
+
 def _free_port():
   s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
   return p
 
 
-def test_two_gloo_ranks_route_training_epochs_through_the_dist_entries():
+# (ranks, transport).  The pool's process guard allows 6 processes on the GPU and this pytest process
+# holds one: 4 ranks is the widest multi-PROCESS job a box can run; 8 ranks run as threads
+# (tests/test_gpu_eightway.py) and as CPU processes (tests/test_parallel_gloo.py).
+@pytest.mark.parametrize('world,transport', [(2, 'host'), (4, 'torch')])
+def test_gloo_ranks_route_training_epochs_through_the_dist_entries(world, transport):
   port = _free_port()
   procs = []
-  for rank in range(2):
-    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
-               MASTER_PORT=str(port), CGS_VMC_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  for rank in range(world):
+    env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(port), CGS_VMC_DIST_BACKEND='gloo', CGS_VMC_TRANSPORT=transport,
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
     procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_dist_gpu_worker.py')],
                                   env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
   outs = []
