@@ -404,9 +404,10 @@ def _free_port():
   return port
 
 
-def spawn_ranks(n_ranks):
-  """Starts `n_ranks` copies of this script (one per GPU) and relays rank 0's output.  Runs
-  before this process has made any GPU / HIP call: the children are fresh processes."""
+def spawn_ranks(n_ranks, script=None):
+  """Starts `n_ranks` copies of this script (or `script`: tools/itswo_bench.py, tools/sr_bench.py), one
+  per GPU, and relays rank 0's output.  Runs before this process has made any GPU / HIP call: the
+  children are fresh processes."""
   port = os.environ.get('MASTER_PORT') or str(_free_port())
   procs = []
   for r in range(n_ranks):
@@ -414,7 +415,7 @@ def spawn_ranks(n_ranks):
     env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(n_ranks),
                 'LOCAL_WORLD_SIZE': str(n_ranks), 'MASTER_ADDR': '127.0.0.1',
                 'MASTER_PORT': port, 'HSA_ENABLE_IPC_MODE_LEGACY': os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')})
-    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + sys.argv[1:],
                                   env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
   out0, _ = procs[0].communicate()
   codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
@@ -475,13 +476,18 @@ def prove_collectives(eng, world, rank, dev):
           'checked_allreduce': {'process_group_on_accumulators': pg_ok, 'expected_sum_of_ranks': world * (world - 1) / 2}}
 
 
+TRANSPORT_NAMES = {'torch': 'device hook: torch.distributed all-reduce on the library buffer, in stream',
+                   'rccl': "the library's own RCCL communicator (in stream)", 'host': 'host hook (pinned staging)'}
+
+
 def prove_library_transport(eng, world, rank, timeout_s=90.0):
-  """N > 1, AFTER the timed region: the library's own transport (the in-stream RCCL communicator it
-  creates next to torch's, or the host hook under a non-RCCL backend) on a device buffer of the
-  library: sum of rank ids == N(N-1)/2, sum of ones == N, max of rank ids == N-1.  The timed step does
-  not depend on it, and creating a second RCCL communicator is the one thing here that has never run
-  on more than one GPU: it runs on a watchdog thread, and a failure or a timeout is REPORTED in the
-  line instead of costing the measurement."""
+  """N > 1, BEFORE the timed region: the transport of the library's multi-rank entry points
+  (cgs_vmc_amd/parallel.py Collective: the device hook over torch's process group by default, the
+  library's own RCCL communicator under CGS_VMC_TRANSPORT=rccl, the host hook under a non-RCCL
+  backend) on a device buffer of the library: sum of rank ids == N(N-1)/2, sum of ones == N, max of
+  rank ids == N-1, and the same sums in float64 (the evaluation means).  It runs on a watchdog thread:
+  creating a second RCCL communicator has never run on more than one GPU, and a failure or a timeout
+  is REPORTED (and the timed step falls back to torch's process group) instead of costing the run."""
   import threading
   from cgs_vmc_amd import parallel
   out = {'library_transport': 'timeout after {:.0f} s'.format(timeout_s), 'library_ok': None}
@@ -491,12 +497,12 @@ def prove_library_transport(eng, world, rank, timeout_s=90.0):
       coll = parallel.collective()
       got = eng.debug_allreduce(coll, np.array([float(rank), 1.0], np.float32), 'sum')
       got_max = eng.debug_allreduce(coll, np.array([float(rank)], np.float32), 'max')
-      out.update({'library_transport': 'rccl communicator (in stream)' if coll.comm else 'host hook',
+      out.update({'library_transport': TRANSPORT_NAMES.get(coll.transport, coll.transport),
                   'library_sum_of_ranks': float(got[0]), 'library_sum_of_ones': float(got[1]),
                   'library_max_of_ranks': float(got_max[0]),
                   'library_ok': bool(got[0] == world * (world - 1) / 2 and got[1] == world and got_max[0] == world - 1)})
     except Exception as e:  # pylint: disable=broad-except
-      out.update({'library_transport': 'unavailable', 'library_error': repr(e), 'library_ok': None})
+      out.update({'library_transport': 'unavailable', 'library_error': repr(e), 'library_ok': False})
 
   t = threading.Thread(target=work, daemon=True)
   t.start()
@@ -516,6 +522,11 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-timing', action='store_true', help='disable per-kernel HIP events')
   ap.add_argument('--reps', type=int, default=REPS, help='repetitions of the timed region (median reported)')
+  ap.add_argument('--collective', choices=['library', 'torch'], default=None,
+                  help="N > 1: 'library' (default) = the step is ONE call of vmc_epoch_energy_gradient_dist, the "
+                       "entry training.run_optimization_epoch uses, all-reduce issued in stream by the library "
+                       "(transport: CGS_VMC_TRANSPORT); 'torch' = op by op with torch.distributed's async "
+                       "all-reduce overlapped with the sweep")
   ap.add_argument('--spawn', action='store_true', help='start the rank processes from here even for --gpus 1 '
                   '(checks that the launcher path costs nothing)')
   args = ap.parse_args()
@@ -559,11 +570,35 @@ def main():
   eng.set_configs(cfg)
   eng.set_bonds(bonds, jx, jz)
   proof = prove_collectives(eng, world, rank, dev) if world > 1 else None
+  lib_proof, lib_stuck = prove_library_transport(eng, world, rank) if world > 1 else ({}, False)
+  if world > 1 and lib_stuck:
+    # a rank is stuck inside the transport check (communicator creation): no further collective can be
+    # trusted to line up -- say so and stop
+    if rank == 0:
+      print(json.dumps({'metric': 'mc_sweep+local_energy_evals_per_sec', 'value': None, 'n_gpus': world,
+                        'error': 'library transport check timed out', 'rccl': dict(proof, **lib_proof)}))
+      sys.stdout.flush()
+    os._exit(3)
+  collective = args.collective or 'library'
+  collective_fallback = None
+  if world > 1:
+    # every rank must take the same path: fall back together when ANY rank's check failed
+    bad = parallel.allreduce_max(0.0 if lib_proof.get('library_ok') is True else 1.0) > 0.5
+    if bad and collective == 'library':
+      collective, collective_fallback = 'torch', 'library transport check failed: {}'.format(
+          lib_proof.get('library_error', lib_proof.get('library_transport')))
+  coll = parallel.collective() if (world > 1 and collective == 'library') else None
   for _ in range(10):                              # 10 warm-up sweeps, one launch each
     eng.mc_steps(n, want_accepted=False)           # (every k_sweep16 launch of a run is one sweep, so
                                                    # rocprofv3's per-kernel average is per sweep)
 
-  def step():
+  def step_library():
+    # the same slice as ONE host call of the entry training.run_optimization_epoch uses for sharded
+    # chains (vmc_epoch_energy_gradient_dist: reset, [accumulate, sweep] x 1, accumulator all-reduce
+    # issued in stream by the library; no equilibration, no update_norm)
+    eng.epoch_energy_gradient_dist(coll, 0, 1, n, 0.0)
+
+  def step_torch():
     # one optimizer-step slice: fresh accumulators (training.py:613 / 758), gradient accumulate,
     # accumulator all-reduce (multi-GPU), one MC sweep
     eng.reset_accumulators()
@@ -572,6 +607,8 @@ def main():
     pending = parallel.allreduce_accumulators_begin(eng)
     eng.mc_steps(n, want_accepted=False)
     pending.wait()
+
+  step = step_library if coll is not None else step_torch
 
   def barrier():
     eng.synchronize()
@@ -629,12 +666,28 @@ def main():
     barrier()
     allreduce_ms = parallel.allreduce_max(1e3 * (time.perf_counter() - t0) / 10)
 
+  # N > 1: the two ways of taking the step -- op by op with torch.distributed's all-reduce, and the
+  # library's one-call entry with the all-reduce issued in stream -- from the same chains and step counter
+  paths_agree = None
+  if world > 1:
+    start_cfg, start_step = eng.get_configs(), eng.step_counter
+    eng.set_configs(start_cfg)          # both start from chains just loaded (no sampler hand-over of activations)
+    step_torch(); acc_t = eng.get_accumulators()
+    eng.set_configs(start_cfg); eng.step_counter = start_step
+    try:
+      lib_coll = parallel.collective()
+      eng.epoch_energy_gradient_dist(lib_coll, 0, 1, n, 0.0)
+      acc_l = eng.get_accumulators()
+      scale = float(np.abs(acc_t).max())
+      paths_agree = {'bitwise': bool(np.array_equal(acc_t, acc_l)),
+                     'max_abs_diff_over_max_abs': float(np.abs(acc_t - acc_l).max() / scale) if scale > 0 else 0.0,
+                     'g_count': [float(acc_t[-4]), float(acc_l[-4])], 'e_count': [float(acc_t[-7]), float(acc_l[-7])]}
+    except Exception as e:  # pylint: disable=broad-except
+      paths_agree = {'error': repr(e)}
+
   eng.local_energy(want_eloc=False)
   rows = eng.last_connected_rows()
   mean_e = eng.mean_energy()
-  lib_proof, lib_stuck = prove_library_transport(eng, world, rank) if world > 1 else ({}, False)
-  if world > 1:                       # one stuck rank: every rank skips the orderly teardown
-    lib_stuck = parallel.allreduce_max(1.0 if lib_stuck else 0.0) > 0.5
 
   timings = {}
   for name in ('sweep', 'tail_eloc', 'tail_amp', 'z1', 'bond_list', 'eloc_reduce', 'grad', 'adam'):
@@ -673,8 +726,10 @@ def main():
                               else 'fully_connected {}x{} relu/exp'.format(L, h)),
                    'chains_per_gpu': b, 'global_chains': world * b,
                    'step': 'reset + accumulate_gradients (E_loc + grad sums) + 1 MC sweep'
-                           + (' + RCCL accumulator all-reduce (overlapped with the sweep)'
-                              if world > 1 else ''),
+                           + ('' if world == 1 else
+                              ' + accumulator all-reduce in stream (one vmc_epoch_energy_gradient_dist call)'
+                              if coll is not None else
+                              ' + RCCL accumulator all-reduce (torch.distributed, overlapped with the sweep)'),
                    'parallelism': 'chains sharded x{}'.format(world)},
         'repetitions': len(rep_s), 'statistic': 'median',
         'repetitions_ms_per_step': [1e3 * t / args.steps for t in rep_s],
@@ -684,8 +739,12 @@ def main():
     }
     if world > 1:
       proof['checked_allreduce'].update(lib_proof)
-      proof['checked_allreduce']['ok'] = bool(lib_proof.get('library_ok') is not False)
+      proof['checked_allreduce']['ok'] = bool(lib_proof.get('library_ok') is True)
       out['rccl'] = dict(proof, library_transport=lib_proof['library_transport'], ranks=world,
+                         timed_collective=('library entry (vmc_epoch_energy_gradient_dist), transport: '
+                                           + lib_proof['library_transport']) if coll is not None
+                         else 'torch.distributed async all-reduce on the accumulator buffer',
+                         collective_fallback=collective_fallback, paths_agree=paths_agree,
                          allreduce_floats=2 * p + 8, allreduce_ms_blocking=allreduce_ms,
                          ms_per_step_ranks={'min': min(rank_ms), 'max': max(rank_ms), 'all': rank_ms})
     if 'sweep' in timings and 'tail_eloc' in timings:
@@ -763,9 +822,6 @@ def main():
         out['cpu_baseline'] = {'error': repr(e)}
     print(json.dumps(out))
     sys.stdout.flush()
-  if lib_stuck:                       # a rank is still inside the library-transport check: no orderly teardown
-    sys.stdout.flush()
-    os._exit(0)
   eng.close()
   if world > 1:
     torch.distributed.barrier()

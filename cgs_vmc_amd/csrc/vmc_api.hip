@@ -1208,6 +1208,10 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
 int vmc_mc_steps(vmc_ctx* c, int64_t n_steps, int64_t* accepted) {
   CHECK_CTX(c);
   if (n_steps < 0) return fail(c, VMC_ERR_INVALID, "n_steps < 0");
+  if (n_steps == 0) {               // `for _ in range(0)`: nothing runs, nothing is launched
+    if (accepted) *accepted = 0;
+    return VMC_OK;
+  }
   // training.py:614-617: accumulate_gradients and the following mc_steps only share the chains
   // R_t, which the sampler reads and never writes in place, so the launch need not wait for the
   // accumulate that was enqueued just before it: it waits for the event recorded when that

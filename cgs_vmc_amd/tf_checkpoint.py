@@ -5,7 +5,10 @@ trained here can be loaded by the reference -- without TensorFlow.
 
 Format (TensorFlow `tensor_bundle` over the LevelDB table format; restated from the published
 format descriptions, NOT validated against TensorFlow in this container -- no TF is installed;
-`tests/test_host_logic.py` round-trips writer -> reader and checks the framing invariants):
+`tests/test_host_logic.py` round-trips writer -> reader and checks the framing invariants;
+`tests/test_tf_bundle_independent.py` decodes the writer's bytes with google.protobuf messages
+declared from TensorFlow's .proto files and an independent table reader, and feeds the reader a
+bundle serialised by google.protobuf and framed by an independent writer):
 
   <prefix>.index   LevelDB table ("sstable"), uncompressed blocks
       block    = entries, restart offsets (uint32 LE each), number of restarts (uint32 LE),
@@ -227,7 +230,8 @@ def write_bundle(prefix: str, tensors: Dict[str, np.ndarray]) -> None:
   """Writes {variable name: array} as a single-shard V2 bundle (`tf.train.Saver` layout)."""
   names = sorted(tensors, key=lambda s: s.encode())
   entries: List[Tuple[bytes, bytes]] = []
-  header = (_field(1, 0, _put_varint(1)) + _field(2, 0, _put_varint(0)) +
+  # proto3 serialisers (TensorFlow's) omit zero-valued scalars: endianness LITTLE = 0 is not written
+  header = (_field(1, 0, _put_varint(1)) +
             _field(3, 2, _put_varint(2) + _field(1, 0, _put_varint(1))))
   entries.append((b'', header))
   offset = 0

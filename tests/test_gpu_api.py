@@ -229,8 +229,12 @@ def test_accumulator_device_view_for_rccl():
   eng.close()
 
 
-def test_two_rank_bench_path_on_one_gpu(tmp_path):
-  """`python bench.py --gpus 2` with NO rank environment: bench.py starts the two ranks itself
+# (ranks, --collective, CGS_VMC_TRANSPORT).  4 ranks is the widest multi-process job a box of this pool
+# can hold (at most 6 processes on the GPU, pytest itself is one); the default N > 1 step is the
+# library's one-call entry, its default transport under gloo the host hook, under nccl the device hook.
+@pytest.mark.parametrize('gpus,collective,transport', [(2, None, None), (4, 'library', 'torch'), (2, 'torch', None)])
+def test_multi_rank_bench_path_on_one_gpu(tmp_path, gpus, collective, transport):
+  """`python bench.py --gpus N` with NO rank environment: bench.py starts the N ranks itself
   (sharded chains, accumulator all-reduce, max-over-ranks timing); they share this GPU over gloo.
   RCCL itself needs >= 2 GPUs and is exercised by the driver's scaling runs; everything around
   the collective is covered here."""
@@ -239,31 +243,44 @@ def test_two_rank_bench_path_on_one_gpu(tmp_path):
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   env = {k: v for k, v in os.environ.items()
-         if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+         if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'CGS_VMC_TRANSPORT')}
   env['CGS_VMC_DIST_BACKEND'] = 'gloo'
+  if transport:
+    env['CGS_VMC_TRANSPORT'] = transport
   p = subprocess.run(
-      [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup',
-       '1', '--reps', '2', '--no-cpu-baseline', '--workload', 'heisenberg6x6_fc3x128_b1024'],
+      [sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(gpus), '--steps', '2', '--warmup',
+       '1', '--reps', '2', '--no-cpu-baseline', '--workload', 'heisenberg6x6_fc3x128_b1024']
+      + (['--collective', collective] if collective else []),
       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
   assert p.returncode == 0, p.stderr.decode()[-2000:]
   lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
   assert len(lines) == 1                      # rank 0 only
   d = json.loads(lines[0])
-  assert d['n_gpus'] == 2 and d['config']['global_chains'] == 2048 and d['value'] > 0
+  assert d['n_gpus'] == gpus and d['config']['global_chains'] == gpus * 1024 and d['value'] > 0
   r = d['rccl']
-  assert r['ranks'] == 2 and r['allreduce_floats'] == 2 * 37889 + 8
+  assert r['ranks'] == gpus and r['allreduce_floats'] == 2 * 37889 + 8
   # the N > 1 line proves what it ran on and that its collectives reduce
-  assert r['backend'] == 'gloo' and r['library_transport'] == 'host hook'
-  assert [i['rank'] for i in r['devices']] == [0, 1]
+  assert r['backend'] == 'gloo'
+  assert r['library_transport'].startswith('device hook' if transport == 'torch' else 'host hook')
+  assert [i['rank'] for i in r['devices']] == list(range(gpus))
   assert all(i['ordinal'] == 0 and i['pci_bus_id'] and i['name'] for i in r['devices'])
-  assert r['distinct_devices'] is False        # two ranks share this GPU: tolerated under gloo only
+  assert r['distinct_devices'] is False        # the ranks share this GPU: tolerated under gloo only
   c = r['checked_allreduce']
-  assert c['ok'] and c['library_ok'] and c['process_group_on_accumulators']
-  assert c['library_sum_of_ranks'] == c['expected_sum_of_ranks'] == 1.0
-  assert c['library_sum_of_ones'] == 2.0 and c['library_max_of_ranks'] == 1.0
-  assert r['allreduce_ms_blocking'] > 0
+  assert c['ok'] is True and c['library_ok'] is True and c['process_group_on_accumulators']
+  assert c['library_sum_of_ranks'] == c['expected_sum_of_ranks'] == gpus * (gpus - 1) / 2
+  assert c['library_sum_of_ones'] == gpus and c['library_max_of_ranks'] == gpus - 1
+  assert r['allreduce_ms_blocking'] > 0 and r['collective_fallback'] is None
+  # the timed step goes through the library's own entry by default, and both ways
+  # of taking the step leave the same accumulators
+  assert r['timed_collective'].startswith('torch.distributed' if collective == 'torch' else 'library entry')
+  assert ('in stream' in d['config']['step']) == (collective != 'torch')
+  pa = r['paths_agree']
+  assert pa['g_count'] == [1.0, 1.0] and pa['e_count'] == [gpus * 1024.0] * 2
+  assert pa['bitwise'] if gpus == 2 else pa['max_abs_diff_over_max_abs'] < 1e-6
   m = r['ms_per_step_ranks']
-  assert len(m['all']) == 2 and 0 < m['min'] <= m['max'] <= d['ms_per_step'] * 1.05
+  assert len(m['all']) == gpus and 0 < m['min'] <= m['max'] <= d['ms_per_step'] * 1.05
+  if gpus != 2 or collective:
+    return
   # a rank count that contradicts the environment is refused instead of silently mislabelled
   bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'],
                        env=dict(env, WORLD_SIZE='1', RANK='0'), stdout=subprocess.PIPE,

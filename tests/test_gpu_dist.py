@@ -184,7 +184,8 @@ def test_device_hook_transport_doubles_like_two_identical_ranks():
   np.testing.assert_array_equal(eng.get_accumulators(), expect)
   # whole epochs with the hook in the loop.  EnergyGradient: the same chains and shift, twice the sums
   a = _engine()
-  a.epoch_energy_gradient(32, 3, 16, 1e10)
+  a.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)    # the same history as `eng` (an accumulate before the first
+  a.epoch_energy_gradient(32, 3, 16, 1e10)       # sweep makes the sampler hand its activations over)
   eng.epoch_energy_gradient_dist(coll, 32, 3, 16, 1e10)
   acc_a, acc_b = a.get_accumulators(), eng.get_accumulators()
   expect = 2 * acc_a
@@ -192,6 +193,11 @@ def test_device_hook_transport_doubles_like_two_identical_ranks():
   np.testing.assert_array_equal(acc_b, expect)
   np.testing.assert_array_equal(a.get_configs(), eng.get_configs())
   assert a.get_shift() == eng.get_shift()
+  # evaluation: the float64 means of two identical ranks are the single-rank means
+  m_a, acc_a = a.evaluate(None, 16, 4, 16)
+  m_b, acc_b = eng.evaluate(coll, 16, 4, 16)
+  np.testing.assert_array_equal(m_a, m_b)
+  assert acc_a == acc_b and (4, 2, 0) in seen
   # LogOverlapITSWO (Adam inside the epoch, fed by the hook's sums every batch): the batch-SUM gradient
   # of twice the samples is twice the gradient, which Adam's normalisation takes out again up to epsilon
   args = (0.12, 32, 3, 16, 1e10, 1e-2, 0.9, 0.99, 1e-8)
@@ -200,11 +206,6 @@ def test_device_hook_transport_doubles_like_two_identical_ranks():
   assert abs(e_a - e_b) < 1e-4 * max(1.0, abs(e_a))
   d = np.abs(a.get_params() - eng.get_params())
   assert np.median(d) < 1e-6 and (d < 1e-4).mean() > 0.9
-  # evaluation: the float64 means of two identical ranks are the single-rank means
-  m_a, acc_a = a.evaluate(None, 16, 4, 16)
-  m_b, acc_b = eng.evaluate(coll, 16, 4, 16)
-  np.testing.assert_array_equal(m_a, m_b)
-  assert acc_a == acc_b and (4, 2, 0) in seen
   a.close(); eng.close()
 
 
