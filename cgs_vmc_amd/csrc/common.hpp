@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "plan.hpp"   // every pure-host decision (layouts, LDS budgets, grids); no HIP in it
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -59,14 +61,7 @@ struct PackedParams {
   const float* won;   // [N] onsite weights (RBM) or nullptr
 };
 
-// offsets of the pieces of the flat parameter vector (both ansatz types), see vmc_api.hip
-struct ParamLayout {
-  long long off_w1, off_b1;   // first layer [N,H], [H]
-  long long off_h0;           // first H x H layer; layer l at off_h0 + l (H*H + H): w then b
-  long long off_wout, off_bout;  // FC: w_out [H], b_out;  RBM: off_wout = -1, off_bout = b_on
-  long long off_won;          // RBM: onsite weights [N]; FC: -1
-  int n_hh;                   // number of H x H layers (FC: L-1, RBM: L)
-};
+// (ParamLayout, the offsets of the pieces of the flat parameter vector: plan.hpp)
 
 // log cosh(z) = |z| + log(1 + exp(-2|z|)) - log 2 (finite for every z, unlike log(cosh(z)))
 __device__ __forceinline__ float vmc_logcosh(float z) {

@@ -91,39 +91,19 @@ __global__ void k_conv_pack(const float* __restrict__ theta, ConvGeom g, float* 
 
 }  // namespace
 
-// LDS budget of one workgroup: half a CU when a sample's feature maps allow two workgroups per CU
-size_t conv_lds_cap(const ConvGeom& g) {
-  static const int one_per_cu = getenv("CGS_VMC_CONV_WG_PER_CU") ? atoi(getenv("CGS_VMC_CONV_WG_PER_CU")) == 1 : 0;
-  if (one_per_cu) return (size_t)160 * 1024;      // experiment: one workgroup with twice the samples
-  if (g.NCB > 1) return (size_t)160 * 1024;      // one 8-wave workgroup per CU (conv32.hip)
-  return conv_rows_lds(g, 1) <= CONV_LDS_PER_WG ? (size_t)CONV_LDS_PER_WG : (size_t)160 * 1024;
+// the planners live in plan.hpp; these are the names the rest of the library calls
+static bool conv_one_wg_per_cu() {     // experiment knob: one workgroup per CU with twice the samples
+  static const int v = getenv("CGS_VMC_CONV_WG_PER_CU") ? atoi(getenv("CGS_VMC_CONV_WG_PER_CU")) == 1 : 0;
+  return v != 0;
 }
-int conv_waves(const ConvGeom& g) { return g.NCB > 1 ? 8 : CONV_WAVES; }
-
-size_t conv_rows_lds(const ConvGeom& g, int G) {
-  const size_t xs = (size_t)((g.N + 3) & ~3);
-  // buf0, buf1, xs, pinfo, row_chain, red + the sampler's cur_logit, prop, prop_u
-  return ((size_t)G * 2 * g.CS + (size_t)G * xs + (size_t)G * g.N + (size_t)G * 7 + 16 * (size_t)(g.D1 + g.D2) + 16) * sizeof(float);
+size_t conv_lds_cap(const ConvGeom& g) { return plan_conv_lds_cap(g, conv_one_wg_per_cu()); }
+int conv_waves(const ConvGeom& g) { return plan_conv_waves(g); }
+size_t conv_rows_lds(const ConvGeom& g, int G) { return plan_conv_rows_lds(g, G); }
+int conv_pick_group(const ConvGeom& g, int waves) { return plan_conv_pick_group(g, waves, conv_one_wg_per_cu()); }
+int conv_pick_sweep_group(const ConvGeom& g, long long B, int num_cus, int waves) {
+  return plan_conv_pick_sweep_group(g, B, num_cus, waves, conv_one_wg_per_cu());
 }
-
-// samples per pass: the group size (<= 64, LDS <= 160 KiB) whose position tiles divide most evenly
-// over the waves; ties go to the larger group
-int conv_pick_group(const ConvGeom& g, int waves) {
-  int best = 1; double best_eff = -1.0;
-  for (int G = 1; G <= 64; ++G) {
-    if (conv_rows_lds(g, G) > conv_lds_cap(g)) break;
-    const int tiles = (G * g.N + 15) / 16;
-    const int rounds = (tiles + waves - 1) / waves;
-    const double eff = (double)G * g.N / 16.0 / ((double)rounds * waves);
-    if (eff >= best_eff - 1e-9) { best = G; best_eff = eff; }
-  }
-  return best;
-}
-
-long long conv_num_params(int n_conv, int F, int taps) {
-  const long long KK = taps;
-  return KK * F + F + (long long)(n_conv - 1) * (KK * F * F + F);
-}
+long long conv_num_params(int n_conv, int F, int taps) { return plan_num_params_conv(n_conv, F, taps); }
 
 hipError_t launch_conv_pack(hipStream_t s, const float* theta, const ConvGeom& g, float* w0,
                             float* wf, float* wb, float* bias) {
@@ -133,10 +113,8 @@ hipError_t launch_conv_pack(hipStream_t s, const float* theta, const ConvGeom& g
 
 hipError_t launch_conv_rows(hipStream_t s, const ConvRowsArgs& a, int num_cus) {
   if (a.n_rows <= 0) return hipSuccess;
-  const int groups = (a.n_rows + a.G - 1) / a.G;
   const size_t lds = conv_rows_lds(a.g, a.G);
-  const int slots = num_cus * ((a.g.NCB == 1 && lds <= CONV_LDS_PER_WG) ? 2 : 1);      // co-resident workgroups
-  const dim3 grid(groups < slots ? groups : slots);
+  const dim3 grid(plan_conv_grid(a.g, a.n_rows, a.G, num_cus));      // one workgroup per co-resident slot
   if (a.g.NCB == 2) return conv_launch_rows_cb2(s, a, grid, lds);
   return conv_launch_rows_t<1>(s, a, grid, lds);
 }
@@ -149,22 +127,10 @@ hipError_t launch_conv_sweep(hipStream_t s, const ConvSweepArgs& a) {
 }
 
 hipError_t launch_conv_back(hipStream_t s, const ConvBackArgs& a, int num_cus) {
-  const int groups = (a.B + a.G - 1) / a.G;
   const size_t lds = conv_rows_lds(a.g, a.G);
-  const int slots = num_cus * ((a.g.NCB == 1 && lds <= CONV_LDS_PER_WG) ? 2 : 1);
-  const dim3 grid(groups < slots ? groups : slots);
+  const dim3 grid(plan_conv_grid(a.g, a.B, a.G, num_cus));
   if (a.g.NCB == 2) return conv_launch_back_cb2(s, a, grid, lds);
   return conv_launch_back_t<1>(s, a, grid, lds);
-}
-
-// LDS of the weight-gradient kernel for bands of `rows` lattice rows: delta [NQ][CW] + input
-// [NIN][CW] in one padded site numbering, the halo and position maps, ones (+ 8 sites: the operands
-// of the quad past the end are read, and dropped)
-static size_t conv_dw_lds(const ConvGeom& g, int rows) {
-  const size_t d2p = (size_t)g.D2 + g.KW - 1, npad = (size_t)(g.D1 + g.K - 1) * d2p;
-  const size_t nq = ((size_t)rows * d2p + 3) & ~(size_t)3, nin = nq + (size_t)(g.K - 1) * d2p + g.KW;
-  const size_t cw = 16 * (size_t)g.NCB;
-  return (nq * cw + nin * cw + npad + g.N + cw + 8 * cw) * sizeof(float);
 }
 
 hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a_in) {
@@ -172,13 +138,10 @@ hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a_in) {
   const dim3 grid(a.n_slices, a.g.n_conv);
   // the whole sample at once when it fits (two workgroups per CU at 16 filters when THAT fits), else
   // the largest band of rows that does
-  const size_t cap = (size_t)160 * 1024;
-  a.band_rows = a.g.D1;
-  if (const char* e = getenv("CGS_VMC_CONV_DW_BAND"))      // test knob: force bands of this many rows
-    if (atoi(e) >= 1 && atoi(e) < a.band_rows) a.band_rows = atoi(e);
-  while (a.band_rows > 1 && conv_dw_lds(a.g, a.band_rows) > cap) --a.band_rows;
-  const size_t lds = conv_dw_lds(a.g, a.band_rows);
-  if (lds > cap) return hipErrorInvalidValue;
+  const char* e_band = getenv("CGS_VMC_CONV_DW_BAND");      // test knob: force bands of this many rows
+  a.band_rows = plan_conv_dw_band(a.g, e_band ? atoi(e_band) : 0);
+  if (a.band_rows < 1) return hipErrorInvalidValue;
+  const size_t lds = plan_conv_dw_lds(a.g, a.band_rows);
   hipError_t e = a.g.NCB == 2 ? conv_launch_dw_cb2(s, a, grid, lds) : conv_launch_dw_t<1>(s, a, grid, lds);
   if (e != hipSuccess) return e;
   const long long np_max = (long long)a.g.K * a.g.KW * a.g.F * a.g.F + a.g.F;
@@ -189,10 +152,8 @@ hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a_in) {
 
 hipError_t launch_conv_sr_rowdot(hipStream_t s, const ConvSrRowdotArgs& a, int num_cus) {
   if (a.n_rows <= 0) return hipSuccess;
-  const int groups = (a.n_rows + a.G - 1) / a.G;
   const size_t lds = conv_rows_lds(a.g, a.G);
-  const int slots = num_cus * ((a.g.NCB == 1 && lds <= CONV_LDS_PER_WG) ? 2 : 1);
-  const dim3 grid(groups < slots ? groups : slots);
+  const dim3 grid(plan_conv_grid(a.g, a.n_rows, a.G, num_cus));
   if (a.g.NCB == 2) return conv_launch_sr_rowdot_cb2(s, a, grid, lds);
   return conv_launch_sr_rowdot_t<1>(s, a, grid, lds);
 }

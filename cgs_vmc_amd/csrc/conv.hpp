@@ -4,31 +4,7 @@
 #pragma once
 #include "common.hpp"
 
-#define CONV_MAX_LAYERS 32
-#define CONV_FP 16          // channel tile of the MFMA: filters are zero padded to NCB blocks of 16
-#define CONV_MAX_NCB 2      // num_conv_filters <= 32
-
-// Geometry of one network.  A feature map of one sample is stored -- in LDS and in the HBM tapes
-// alike -- channel-group major: [4 NCB groups][GS dwords], element (site, channel c) at
-// (c / 4) * GS + 4 * site + c % 4, with GS >= 4 N a multiple of 64 dwords so that the 16-lane
-// groups of ds_read_b128 / ds_write_b128 fall on distinct banks; NCB = ceil(F / 16) channel blocks
-// of one MFMA tile each, CS = 4 NCB GS dwords per sample.
-struct ConvGeom {
-  int K;        // kernel_size
-  int D1, D2;   // size_x, size_y: inputs are reshaped to [-1, size_x, size_y, 1] (wavefunctions.py:596)
-  int N;        // D1 * D2
-  int F;        // num_conv_filters
-  int n_conv;   // number of Conv2dPeriodic modules: num_conv_layers, or 1 + 2 num_resnet_blocks
-  int resnet;   // 0: Conv2DNetwork, 1: ResNet2D
-  int hact;     // hidden activation id of Conv2DNetwork (ResNet2D: selu, layers.py:226)
-  int GS;       // dwords per channel group of a feature map (see above)
-  int lo, hi;   // periodic padding in front / behind along axis 1: (K-1)/2 and K/2 (layers.py:132-141);
-                // the 1-D modules pad K/2 in front and K-1-K/2 behind (layers.py:66-72)
-  int KW;       // taps along axis 2: K (Conv2dPeriodic) or 1 (Conv1dPeriodic on an [N, 1] lattice)
-  int lo2, hi2; // the same padding for axis 2 (0 for the 1-D modules)
-  int NCB;      // channel blocks of 16: (F + 15) / 16
-  int CS;       // dwords of one sample's feature map: 4 * NCB * GS
-};
+// (ConvGeom, CONV_FP / CONV_MAX_NCB / CONV_MAX_LAYERS and every LDS / grid formula: plan.hpp)
 
 // One packed parameter set (k_conv_pack); co / ci = output / input channel block of 16:
 //   w0   [NCB co][Q0][64]   first convolution (1 input channel), taps are the k index:
@@ -125,6 +101,7 @@ size_t conv_rows_lds(const ConvGeom& g, int G);
 size_t conv_lds_cap(const ConvGeom& g);   // LDS budget of one workgroup (two per CU when a sample fits)
 int conv_waves(const ConvGeom& g);        // waves per workgroup of the conv kernels (4; two channel blocks: 8)
 int conv_pick_group(const ConvGeom& g, int waves);
+int conv_pick_sweep_group(const ConvGeom& g, long long B, int num_cus, int waves);   // chains per sampler workgroup
 long long conv_num_params(int n_conv, int F, int taps);
 hipError_t launch_conv_pack(hipStream_t s, const float* theta, const ConvGeom& g, float* w0,
                             float* wf, float* wb, float* bias);

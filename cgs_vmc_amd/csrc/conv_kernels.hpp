@@ -36,7 +36,7 @@
 #endif
 #define CONV_WG_PER_CU (CONV_WAVES == 4 ? 2 : 1)
 #define CONV_THREADS (CONV_WAVES * 64)
-#define CONV_LDS_PER_WG (80 * 1024)   // two workgroups share the 160 KiB of a CU
+// (CONV_LDS_PER_WG, the 80 KiB a workgroup gets when two share a CU: plan.hpp)
 #define SELU_SCALE_F 1.0507009873554805f
 #define SELU_ALPHA_F 1.6732632423543772f
 

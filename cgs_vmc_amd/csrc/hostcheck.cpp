@@ -1,0 +1,398 @@
+// hostcheck.cpp -- the host-side planners of libcgsvmc_hip.so (plan.hpp: parameter layouts, vmc_create's
+// shape / LDS validation, convolution group / band / slice pickers, the sampler's LDS plan, split-K and
+// XCD block-order maps, SR tile schedules, buffer sizes) driven over a grid of shapes on the CPU under
+// AddressSanitizer + UndefinedBehaviourSanitizer (GPU sanitizers are not available on this pool):
+//     make -C cgs_vmc_amd/csrc hostcheck        (g++ -fsanitize=address,undefined; tests/test_hostcheck.py)
+// Every index a kernel derives from these plans is re-derived here into REAL arrays of the planned
+// size, so that an offset one past a buffer is an ASan report and an overflowing product a UBSan one.
+// The grid contains all five BASELINE configurations and the limits of include/cgsvmc.h (512 / 4096
+// units, 32 filters, kernel 7, 32 x 32 lattices, 1023-site chains).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "plan.hpp"
+
+static long long g_checks = 0, g_shapes = 0, g_rejected = 0;
+#define CHECK(cond)                                                                      \
+  do {                                                                                   \
+    ++g_checks;                                                                          \
+    if (!(cond)) { fprintf(stderr, "hostcheck FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); abort(); } \
+  } while (0)
+
+static const int kCus[] = {256, 304, 64, 1};
+
+static vmc_desc dense_desc(int ansatz, int n, int b, int L, int h, int act, int oact) {
+  vmc_desc d;
+  memset(&d, 0, sizeof(d));
+  d.n_sites = n; d.batch_size = b; d.num_layers = L; d.layer_size = h;
+  d.nonlinearity = act; d.output_activation = oact; d.ansatz = ansatz;
+  return d;
+}
+
+// every piece of the parameter vector lands in [0, P), the pieces are disjoint and cover it
+static void check_layout(const DescPlan& p, long long N, long long H) {
+  const ParamLayout& lay = p.lay;
+  const long long P = p.P;
+  CHECK(P > 0);
+  if (P > 6000000) {       // too large to mark: the pieces are consecutive, so the ends tell everything
+    const long long last = p.rbm ? plan_off_b(lay, H, lay.n_hh) + H : lay.off_bout + 1;
+    CHECK(last == P);
+    CHECK(lay.off_w1 >= 0 && lay.off_b1 == lay.off_w1 + N * H && lay.off_h0 == lay.off_b1 + H);
+    return;
+  }
+  std::vector<unsigned char> mark((size_t)P, 0);
+  auto piece = [&](long long off, long long n) {
+    CHECK(off >= 0 && off + n <= P);
+    for (long long i = 0; i < n; ++i) { CHECK(mark[(size_t)(off + i)] == 0); mark[(size_t)(off + i)] = 1; }
+  };
+  piece(lay.off_w1, N * H); piece(lay.off_b1, H);
+  for (int l = 1; l <= lay.n_hh; ++l) { piece(plan_off_w(lay, H, l), H * H); piece(plan_off_b(lay, H, l), H); }
+  if (p.rbm) { CHECK(lay.off_wout == -1); piece(lay.off_won, N); piece(lay.off_bout, 1); }
+  else { CHECK(lay.off_won == -1); piece(lay.off_wout, H); piece(lay.off_bout, 1); }
+  for (long long i = 0; i < P; ++i) CHECK(mark[(size_t)i] == 1);
+}
+
+// split-K of the general GEMM and its workspace: the slices cover [0, K) once, every partial a
+// workgroup stores lies inside the workspace of its problem
+static void check_gemm(long long N, long long H, int n_problems, long long K) {
+  const int cap = 16;
+  for (int forced : {0, 1, 2, 5, 16, 40}) {
+    const int s = plan_splitk(K, cap, forced);
+    CHECK(s >= 2 && s <= cap);
+    int kc = (int)((K + s - 1) / s);
+    kc = (kc + 31) / 32 * 32;
+    long long covered = 0;
+    for (int z = 0; z < s; ++z) {
+      const long long kbeg = (long long)z * kc, kend = std::min<long long>(K, kbeg + kc);
+      if (kbeg < kend) { CHECK(kbeg == covered); covered = kend; }
+    }
+    CHECK(covered == K);
+    const long long ws = plan_gemm_ws_floats(n_problems, cap, N, H), stride = ws / n_problems;
+    CHECK(stride * n_problems == ws);
+    // problems of the gradient batch: (M = k_in + 1 rows incl. the ones row) x n_out, dual
+    const long long shapes[3][2] = {{H + 1, 1}, {H + 1, H}, {N + 1, H}};
+    for (auto& mn : shapes) {
+      const long long last = ((long long)(s - 1) * 2 + 1) * mn[0] * mn[1] + (mn[0] - 1) * mn[1] + (mn[1] - 1);
+      CHECK(last < stride);
+    }
+  }
+}
+
+// XCD-aware block orders: a bijection onto (group / slice, tile), all tiles of one group on one XCD
+static void check_block_maps() {
+  for (int per_group : {1, 4, 8, 16, 20, 33})
+    for (int groups : {1, 7, 8, 9, 32, 48, 100}) {
+      const int grid = 8 * ((groups + 7) / 8) * per_group;
+      std::vector<int> hit((size_t)groups * per_group, 0);
+      for (int b = 0; b < grid; ++b) {
+        const WgradBlock m = plan_gemm_batched_block(b, per_group, groups);
+        if (m.slice < 0) continue;
+        CHECK(m.slice < groups && m.tile >= 0 && m.tile < per_group);
+        CHECK((b & 7) == (m.slice & 7));                 // group g lives on XCD g % 8
+        hit[(size_t)m.slice * per_group + m.tile] += 1;
+      }
+      for (int v : hit) CHECK(v == 1);
+      CHECK(plan_wgrad_grid(per_group, groups) == grid);
+      std::vector<int> hit2((size_t)groups * per_group, 0);
+      for (int b = 0; b < grid; ++b) {
+        const WgradBlock m = plan_wgrad_block(b, per_group, groups);
+        if (m.slice < 0) continue;
+        CHECK(m.slice < groups && m.tile < per_group && (b & 7) == (m.slice & 7));
+        hit2[(size_t)m.slice * per_group + m.tile] += 1;
+      }
+      for (int v : hit2) CHECK(v == 1);
+    }
+}
+
+// the batched weight-gradient kernel: tiles, K slices and their chunks
+static void check_wgrad(long long N, long long H, int n_hh, long long B) {
+  long long tiles = plan_wgrad_tiles((int)N, (int)H) + (long long)n_hh * plan_wgrad_tiles((int)H, (int)H);
+  CHECK(plan_wgrad_tiles((int)H, 1) == 0);
+  for (int cus : kCus) {
+    const int s = plan_wgrad_slices(tiles, B, cus);
+    CHECK(s >= 1 && s <= WG_MAX_SPLIT);
+    CHECK(s == 1 || tiles * s <= cus);
+    CHECK(s == 1 || (long long)(s - 1) * 64 < B + 64);
+    const int kc = plan_wgrad_kchunk((int)B, s);
+    CHECK(kc % WG_TK == 0 && (long long)kc * s >= B);
+    CHECK((long long)kc * (s - 1) < B);                 // no slice is empty
+  }
+}
+
+static void check_sweep(const vmc_desc& d, const DescPlan& p) {
+  if (p.conv || (p.wide && !p.wide_fast)) return;
+  const int NT = p.Hp / 16;
+  CHECK(NT == 4 || NT == 8 || NT == 12 || NT == 16 || NT == 24 || NT == 32);   // the instantiated tile counts
+  const int NW = (NT == 16 || NT >= 24) ? 8 : 4;
+  const size_t need = plan_sweep_lds_required(d.n_sites, p.Hp, p.n_hh, p.rbm != 0);
+  CHECK(need <= PLAN_LDS_PER_CU);
+  for (int no_w1l = 0; no_w1l < 2; ++no_w1l)
+    for (int plain = 0; plain < 2; ++plain)
+      for (int tuned = 0; tuned < 2; ++tuned) {
+        const SweepPlan sp = plan_sweep(d.n_sites, NT, NW, p.n_hh, p.rbm != 0, no_w1l != 0, plain != 0, tuned != 0);
+        CHECK(sp.ok == 1);
+        CHECK(sp.lds <= PLAN_LDS_PER_CU && sp.lds >= (sp.w1l ? (size_t)0 : need));
+        CHECK(sp.fast == 0 || sp.fast == 2 || sp.fast == 4);
+        CHECK(!(sp.w1l && (NT > 16 || no_w1l)));
+        CHECK(!(sp.fast && (!plain || !tuned)));
+        if (sp.fast == 2) CHECK((d.n_sites + 3) / 4 <= 32);      // two Philox draws cover 256 sites
+        if (sp.fast == 4) CHECK((d.n_sites + 3) / 4 <= 64);
+        if (sp.w1l) CHECK(sp.lds == plan_sweep_lds_bytes(d.n_sites, p.Hp, p.n_hh, true, p.rbm != 0));
+      }
+  if (p.wide_fast && p.n_hh >= 1) {
+    CHECK(plan_tail_lds_supported(p.Hp, p.n_hh));
+    CHECK(plan_tail_lds_bytes(p.Hp, p.n_hh) <= PLAN_LDS_PER_CU);
+  }
+}
+
+static void dense_grid() {
+  const int sites[] = {2, 4, 10, 16, 36, 100, 144, 256, 400, 1024};
+  const int units[] = {1, 7, 32, 64, 80, 128, 200, 256, 257, 300, 384, 400, 512, 513, 1024, 4096, 4097};
+  const int layers[] = {0, 1, 2, 3, 6};
+  const long long batches[] = {1, 64, 1000, 4096, 32768};
+  char msg[256];
+  for (int ansatz : {VMC_ANSATZ_FULLY_CONNECTED, VMC_ANSATZ_RBM})
+    for (int n : sites)
+      for (int h : units)
+        for (int L : layers)
+          for (int act : {VMC_ACT_RELU, VMC_ACT_COS, VMC_ACT_TANH}) {
+            const vmc_desc d = dense_desc(ansatz, n, 4096, L, h, act, VMC_ACT_EXP);
+            DescPlan p;
+            for (int wf = 0; wf < 2; ++wf) {
+              const int rc = plan_desc(&d, wf != 0, &p, msg, sizeof(msg));
+              ++g_shapes;
+              if (rc != VMC_OK) {
+                ++g_rejected;
+                CHECK(msg[0] != 0 && (rc == VMC_ERR_INVALID || rc == VMC_ERR_UNSUPPORTED));
+                if (ansatz == VMC_ANSATZ_FULLY_CONNECTED && L == 0) CHECK(rc == VMC_ERR_INVALID);
+                continue;
+              }
+              CHECK(h <= 4096 && !(L == 0 && ansatz == VMC_ANSATZ_FULLY_CONNECTED));
+              CHECK(p.Hp >= h && p.Hp % 64 == 0 && p.Hp - h < 128);
+              CHECK(p.wide == (h > 256));
+              CHECK(!p.wide_fast || (wf && h > 256 && h <= 512 && (p.Hp == 384 || p.Hp == 512)));
+              CHECK(!(p.wide && !p.wide_fast && act == VMC_ACT_COS));
+              CHECK(p.n_hh == (ansatz == VMC_ANSATZ_RBM ? L : L - 1) && p.lay.n_hh == p.n_hh);
+              CHECK(p.P == plan_num_params_dense(ansatz, n, h, L));
+              check_layout(p, n, h);
+              check_sweep(d, p);
+              for (long long b : batches) {
+                check_gemm(n, h, p.n_hh + 2, b);
+                check_wgrad(n, h, p.n_hh, b);
+              }
+            }
+          }
+  // the limits of include/cgsvmc.h, and what lies one step beyond them
+  DescPlan p;
+  vmc_desc d = dense_desc(VMC_ANSATZ_FULLY_CONNECTED, 100, 4096, 3, 4097, VMC_ACT_RELU, VMC_ACT_EXP);
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_UNSUPPORTED);
+  d = dense_desc(VMC_ANSATZ_FULLY_CONNECTED, 100, 4096, 3, 513, VMC_ACT_COS, VMC_ACT_EXP);
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_UNSUPPORTED);
+  d = dense_desc(VMC_ANSATZ_FULLY_CONNECTED, 100, 4096, 3, 512, VMC_ACT_COS, VMC_ACT_EXP);
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_OK && p.wide_fast && p.Hp == 512);
+  CHECK(plan_desc(&d, false, &p, msg, sizeof(msg)) == VMC_ERR_UNSUPPORTED);
+  d = dense_desc(VMC_ANSATZ_RBM, 100, 4096, 2, 256, VMC_ACT_RELU, VMC_ACT_TANH);
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_INVALID);
+  d = dense_desc(VMC_ANSATZ_FULLY_CONNECTED, 100, 4096, 3, 256, 7, VMC_ACT_EXP);
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_INVALID);
+  d = dense_desc(7, 100, 4096, 3, 256, 0, VMC_ACT_EXP);
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_UNSUPPORTED);
+  // BASELINE configs 1 - 5 (config 4 = config 3 per rank)
+  const int cfg[4][4] = {{16, 64, 2, 32}, {36, 1024, 3, 128}, {100, 4096, 3, 256}, {256, 1024, 6, 256}};
+  for (auto& c : cfg) {
+    d = dense_desc(VMC_ANSATZ_FULLY_CONNECTED, c[0], c[1], c[2], c[3], VMC_ACT_RELU, VMC_ACT_EXP);
+    CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_OK && !p.wide);
+  }
+  d = dense_desc(VMC_ANSATZ_FULLY_CONNECTED, 100, 4096, 3, 256, VMC_ACT_RELU, VMC_ACT_EXP);
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_OK && p.P == 157697);
+  const SweepPlan sp = plan_sweep(100, 16, 8, 2, false, false, true, true);
+  CHECK(sp.ok && sp.w1l && sp.fast == 2);                     // config 3: W1 in LDS, two Philox draws per lane
+}
+
+// index of (site, channel) in a feature map; wrap of a periodic coordinate
+static long long fmap_index(const ConvGeom& g, int site, int c) { return (long long)(c / 4) * g.GS + 4 * site + c % 4; }
+static int wrap(int v, int n) { v %= n; return v < 0 ? v + n : v; }
+
+static void check_conv(const vmc_desc& d, const DescPlan& p) {
+  const ConvGeom& g = p.cg;
+  const long long B = d.batch_size;
+  const int KK = g.K * g.KW, CW = 16 * g.NCB;
+  CHECK(g.N == g.D1 * g.D2 && g.GS >= 4 * g.N && g.GS % 64 == 0 && g.CS == 4 * g.NCB * g.GS);
+  CHECK(g.NCB >= 1 && g.NCB <= CONV_MAX_NCB && g.F <= CW && g.n_conv >= 1 && g.n_conv <= CONV_MAX_LAYERS);
+  CHECK(g.lo + g.hi == g.K - 1 && g.lo2 + g.hi2 == g.KW - 1);
+  CHECK(B * g.CS < (1LL << 31));
+  {  // the feature-map layout is injective into [0, CS)
+    std::vector<unsigned char> mark((size_t)g.CS, 0);
+    for (int s = 0; s < g.N; ++s)
+      for (int c = 0; c < CW; ++c) {
+        const long long i = fmap_index(g, s, c);
+        CHECK(i >= 0 && i < g.CS && mark[(size_t)i] == 0);
+        mark[(size_t)i] = 1;
+      }
+  }
+  CHECK(p.P == plan_num_params_conv(g.n_conv, g.F, KK));
+  {  // k_conv_pack: every theta element it reads is inside the parameter vector, every image element
+     // it writes inside the planned image
+    const long long p0 = (long long)KK * g.F + g.F, pl = (long long)KK * g.F * g.F + g.F, Q0 = (KK + 3) / 4;
+    CHECK(plan_conv_w0_floats(g) == (long long)g.NCB * Q0 * 64);
+    long long max_theta = -1;
+    for (long long i = 0; i < (long long)g.NCB * Q0 * 64; ++i) {
+      const int cb = (int)(i / (Q0 * 64)), q = (int)((i / 64) % Q0), lane = (int)(i % 64), m = lane & 15, gq = lane >> 4;
+      const int tap = 4 * q + gq, co = 16 * cb + m;
+      if (tap < KK && co < g.F) max_theta = std::max(max_theta, (long long)tap * g.F + co);
+    }
+    CHECK(max_theta < p0);
+    for (int l = 0; l < g.n_conv; ++l) {
+      const long long base = l == 0 ? (long long)KK * g.F : p0 + (long long)(l - 1) * pl + (long long)KK * g.F * g.F;
+      CHECK(base + g.F <= p.P);
+    }
+    CHECK(plan_conv_bias_floats(g) == (long long)g.n_conv * 16 * g.NCB);
+    const long long per_layer = (long long)KK * 256 * g.NCB * g.NCB;
+    CHECK((long long)(g.n_conv - 1) * per_layer <= plan_conv_wf_floats(g));
+    if (g.n_conv > 1) {
+      const long long wlast = p0 + (long long)(g.n_conv - 2) * pl;     // [tap][cin][cout] of the last convolution
+      CHECK(wlast + ((long long)(KK - 1) * g.F + (g.F - 1)) * g.F + (g.F - 1) < p.P);
+    }
+  }
+  const int nw = plan_conv_waves(g);
+  CHECK(nw == 4 || nw == 8);
+  for (int one = 0; one < 2; ++one) {
+    const size_t cap = plan_conv_lds_cap(g, one != 0);
+    CHECK(cap == CONV_LDS_PER_WG || cap == PLAN_LDS_PER_CU);
+    const int G = plan_conv_pick_group(g, nw, one != 0);
+    CHECK(G >= 1 && G <= 64 && plan_conv_rows_lds(g, G) <= cap);
+    for (int cus : kCus) {
+      const int Gs = plan_conv_pick_sweep_group(g, B, cus, nw, one != 0);
+      CHECK(Gs >= 1 && Gs <= 64 && Gs <= B && plan_conv_rows_lds(g, Gs) <= cap);
+      const int grid = plan_conv_grid(g, B * 7, G, cus);
+      CHECK(grid >= 1 && grid <= 2 * cus && (long long)grid * G <= B * 7 + G);
+      const int sl = plan_conv_dw_slices(g, B, cus);
+      CHECK(sl >= 1 && sl <= 256 && sl <= B);
+      // weight-gradient workspace: the last element slice sl-1 / layer n_conv-1 / second sum writes
+      const long long rows = (long long)KK * CW + 1, ws = plan_conv_dw_ws_floats(g, sl);
+      const long long last = ((((long long)(sl - 1) * g.n_conv + (g.n_conv - 1)) * 2) + 1) * rows * CW + (rows * CW - 1);
+      CHECK(last == ws - 1);
+      // k_conv_dw_reduce's source index of the last weight and the last bias
+      CHECK(((long long)(KK - 1) * CW + (g.F - 1)) * CW + (g.F - 1) < rows * CW);
+      CHECK((long long)KK * CW * CW + (g.F - 1) < rows * CW);
+    }
+  }
+  // weight-gradient bands: a band always exists, fits, and its padded numbering stays inside its maps
+  for (int forced : {0, 1, 3}) {
+    const int rb = plan_conv_dw_band(g, forced);
+    CHECK(rb >= 1 && rb <= g.D1 && plan_conv_dw_lds(g, rb) <= PLAN_LDS_PER_CU);
+    if (forced >= 1 && forced < g.D1) CHECK(rb <= forced);
+    const int D2p = g.D2 + g.KW - 1, NPAD = (g.D1 + g.K - 1) * D2p;
+    const int NQ = (rb * D2p + 3) & ~3, NIN = NQ + (g.K - 1) * D2p + g.KW;
+    std::vector<int> s_map((size_t)NPAD), s_pos((size_t)g.N);
+    for (int i = 0; i < NPAD; ++i) {
+      const int p1 = i / D2p, p2 = i - p1 * D2p;
+      s_map[(size_t)i] = wrap(p1 - g.lo, g.D1) * g.D2 + wrap(p2 - g.lo2, g.D2);
+      CHECK(s_map[(size_t)i] >= 0 && s_map[(size_t)i] < g.N);
+    }
+    for (int i = 0; i < g.N; ++i) {
+      const int a1 = i / g.D2;
+      s_pos[(size_t)i] = a1 * D2p + (i - a1 * g.D2);
+      CHECK(s_pos[(size_t)i] < NPAD);
+    }
+    // a band of rb rows starting at row r0: position q of the band + tap offset < NIN
+    const int q_last = (rb - 1) * D2p + (g.D2 - 1);
+    CHECK(q_last < NQ && q_last + (g.K - 1) * D2p + (g.KW - 1) < NIN);
+    const size_t floats = ((size_t)NQ * CW + (size_t)NIN * CW + NPAD + g.N + CW + 8 * CW);
+    CHECK(floats * sizeof(float) == plan_conv_dw_lds(g, rb));
+  }
+}
+
+static void conv_grid() {
+  struct Lat { int x, y; };
+  const Lat lats[] = {{4, 4}, {3, 5}, {6, 6}, {10, 10}, {16, 16}, {24, 24}, {30, 30}, {32, 32}, {33, 33}, {2, 50}};
+  const int chains[] = {8, 40, 100, 1000, 1023, 1024};
+  const int filters[] = {1, 4, 8, 16, 17, 24, 32, 33};
+  const long long batches[] = {1, 7, 1024, 4096, 100000};
+  char msg[256];
+  for (int ansatz : {VMC_ANSATZ_CONV_2D, VMC_ANSATZ_RES_NET_2D, VMC_ANSATZ_CONV_1D, VMC_ANSATZ_RES_NET_1D}) {
+    const bool one_d = ansatz == VMC_ANSATZ_CONV_1D || ansatz == VMC_ANSATZ_RES_NET_1D;
+    const bool resnet = ansatz == VMC_ANSATZ_RES_NET_2D || ansatz == VMC_ANSATZ_RES_NET_1D;
+    const int n_lat = one_d ? (int)(sizeof(chains) / sizeof(chains[0])) : (int)(sizeof(lats) / sizeof(lats[0]));
+    for (int li = 0; li < n_lat; ++li)
+      for (int F : filters)
+        for (int K = 1; K <= 8; ++K)
+          for (int L : {0, 1, 2, 5, 16})
+            for (long long B : batches) {
+              vmc_desc d;
+              memset(&d, 0, sizeof(d));
+              d.ansatz = ansatz; d.batch_size = (int)B; d.num_layers = L; d.layer_size = F; d.kernel_size = K;
+              d.nonlinearity = VMC_ACT_RELU; d.output_activation = VMC_ACT_EXP;
+              if (one_d) { d.n_sites = chains[li]; }
+              else { d.size_x = lats[li].x; d.size_y = lats[li].y; d.n_sites = d.size_x * d.size_y; }
+              DescPlan p;
+              const int rc = plan_desc(&d, true, &p, msg, sizeof(msg));
+              ++g_shapes;
+              if (rc != VMC_OK) {
+                ++g_rejected;
+                CHECK(msg[0] != 0);
+                continue;
+              }
+              CHECK(F <= 32 && K <= 7 && (resnet || L >= 1) && p.conv);
+              CHECK(plan_conv_rows_lds(p.cg, 1) <= PLAN_LDS_PER_CU);
+              check_conv(d, p);
+            }
+  }
+  // named limits: 32 filters and kernel 7 are in, 33 and 8 are out; the bench workloads are in
+  vmc_desc d;
+  DescPlan p;
+  memset(&d, 0, sizeof(d));
+  d.ansatz = VMC_ANSATZ_CONV_2D; d.batch_size = 4096; d.num_layers = 5; d.layer_size = 32; d.kernel_size = 7;
+  d.size_x = d.size_y = 10; d.n_sites = 100; d.output_activation = VMC_ACT_EXP;
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_OK && p.cg.NCB == 2);
+  d.layer_size = 33;
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_UNSUPPORTED);
+  d.layer_size = 16; d.kernel_size = 8;
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_UNSUPPORTED);
+  d.kernel_size = 5; d.size_x = 9;
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_INVALID);        // size_x * size_y != num_sites
+  d.size_x = 10;
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_OK && p.P == plan_num_params_conv(5, 16, 25));
+  CHECK(plan_conv_pick_group(p.cg, 4) == 5);                                 // G = 5 on the 10 x 10 lattice
+}
+
+static void sr_schedules() {
+  unsigned state = 12345u;
+  auto rnd = [&](int lo, int hi) { state = state * 1664525u + 1013904223u; return lo + (int)((state >> 8) % (unsigned)(hi - lo + 1)); };
+  for (int trial = 0; trial < 2000; ++trial) {
+    const int n = rnd(1, RD_MAXB);
+    int K[RD_MAXB], M[RD_MAXB], order[RD_MAXB], first[RD_MAXB + 1];
+    for (int j = 0; j < n; ++j) { K[j] = rnd(1, 512); M[j] = rnd(1, 300000); }
+    const int tiles = plan_rowdot_schedule(K, M, n, order, first);
+    std::vector<int> seen((size_t)n, 0);
+    long long sum = 0;
+    for (int j = 0; j < n; ++j) {
+      CHECK(order[j] >= 0 && order[j] < n);
+      seen[(size_t)order[j]] += 1;
+      if (j > 0) {
+        CHECK(K[order[j]] <= K[order[j - 1]]);
+        if (K[order[j]] == K[order[j - 1]]) CHECK(order[j] > order[j - 1]);   // stable
+      }
+      CHECK(first[j] == sum);
+      sum += (M[order[j]] + RD_TM - 1) / RD_TM;
+    }
+    for (int v : seen) CHECK(v == 1);
+    CHECK(first[n] == sum && tiles == sum);
+  }
+  for (int R : {1, 63, 64, 65, 4096, 204800})
+    for (int cus : kCus) {
+      const int s = plan_sr_wsum_slices(R, cus);
+      CHECK(s >= 1 && s <= cus && (s == 1 || (long long)(s - 1) * 64 < R));
+    }
+}
+
+int main() {
+  check_block_maps();
+  dense_grid();
+  conv_grid();
+  sr_schedules();
+  printf("hostcheck ok: %lld shapes (%lld rejected by plan_desc), %lld assertions\n", g_shapes, g_rejected, g_checks);
+  return 0;
+}

@@ -138,11 +138,7 @@ hipError_t launch_tail(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode
 
 // 384 or 512 padded units and at least one H x H layer (the sampler's LDS need is checked by vmc_create);
 // LDS of k_tail_lds: two operand buffers [2 halves][NT][64][4], partial dots, row meta, biases, w_out
-bool tail_lds_supported(int Hp, int n_hidden) {
-  const size_t nt = (size_t)Hp / 16;
-  const size_t lds = sizeof(float) * (2 * (2 * nt * 256) + 4 * 32 + 96 + (size_t)n_hidden * nt * 16 + nt * 16);
-  return (Hp == 384 || Hp == 512) && n_hidden >= 1 && lds <= 160 * 1024;
-}
+bool tail_lds_supported(int Hp, int n_hidden) { return plan_tail_lds_supported(Hp, n_hidden); }
 
 hipError_t launch_tail_lds(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm) {
 #define CALL(N) launch_tail_lds_inst_##N(s, a, Hp, ratio_mode, rbm)
@@ -166,8 +162,4 @@ hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp) {
 }
 
 // LDS the sampler needs at least (W1 streamed from L2); vmc_create rejects shapes beyond 160 KiB
-size_t sweep_lds_required(int N, int Hp, int n_hidden, bool rbm) {
-  const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
-  return sizeof(float) * (size_t)(16 * Nst + 2 * 16 * ZS + 2 * NT * 256 + 16 + 16 + 7 * 16 + Hp +
-                                  n_hidden * Hp + (rbm ? Nst + 16 : 0));
-}
+size_t sweep_lds_required(int N, int Hp, int n_hidden, bool rbm) { return plan_sweep_lds_required(N, Hp, n_hidden, rbm); }

@@ -3,7 +3,7 @@
 // sampler's LDS plan and kernel-variant choice, split-K and the XCD-aware block order of the
 // weight-gradient GEMM, the stochastic-reconfiguration tile schedules, and the sizes of the buffers
 // they index.  The .hip files call these functions (there is no second copy of any formula); the same
-// header is compiled by g++ -fsanitize=address,undefined into tests/hostcheck.cpp, which walks a grid of
+// header is compiled by g++ -fsanitize=address,undefined into hostcheck.cpp, which walks a grid of
 // shapes on the CPU and asserts that every offset, grid and LDS figure is in range
 // (`make -C cgs_vmc_amd/csrc hostcheck`, tests/test_hostcheck.py; SURVEY.md 5 "sanitizers").
 #pragma once
@@ -381,6 +381,11 @@ inline int plan_wgrad_slices(long long total_tiles, long long K, int num_cus) {
   const long long by_k = (K + 63) / 64;
   if (s > by_k) s = by_k;
   if (s > WG_MAX_SPLIT) s = WG_MAX_SPLIT;
+  if (s < 1) s = 1;
+  // whole k-steps per slice; then no more slices than have samples (no slice is ever empty)
+  long long kc = (K + s - 1) / s;
+  kc = (kc + WG_TK - 1) / WG_TK * WG_TK;
+  s = (K + kc - 1) / kc;
   return s < 1 ? 1 : (int)s;
 }
 

@@ -27,7 +27,7 @@
 // own t) in ONE launch: a single 204,800-sample problem is 1600 tiles = 6.25 rounds of 256 CUs, i.e.
 // a seventh round with a quarter of the chip; three of them back to back are 18.75 rounds.
 // Workgroup id -> (problem, tile) through first_tile (dispatch order: largest K first).
-#define RD_MAXB 16
+// (RD_MAXB, problems per launch: plan.hpp)
 struct SrRowdotBatch {
   SrRowdotArgs g[RD_MAXB];
   int first_tile[RD_MAXB + 1];
@@ -46,7 +46,7 @@ struct SrWsumArgs {
 
 namespace {
 
-#define RD_TM 128
+// (RD_TM = 128 samples per tile: plan.hpp)
 #define RD_TN 256
 #define RD_K 16
 #define RD_LDA (RD_TM + 4)
@@ -492,25 +492,18 @@ hipError_t launch_sr_rowdot_batch(hipStream_t s, const SrRowdotArgs* probs, int 
     const bool vec = rowdot_vec(probs[i]);
     int n = 1;
     while (i + n < count && n < RD_MAXB && rowdot_vec(probs[i + n]) == vec) ++n;
-    // dispatch order: largest K first (list scheduling: the light tiles fill the end)
-    int order[RD_MAXB];
-    for (int j = 0; j < n; ++j) order[j] = i + j;
-    for (int a = 1; a < n; ++a)
-      for (int b2 = a; b2 > 0 && probs[order[b2]].K > probs[order[b2 - 1]].K; --b2) {
-        const int tmp = order[b2]; order[b2] = order[b2 - 1]; order[b2 - 1] = tmp;
-      }
+    // dispatch order: largest K first (list scheduling: the light tiles fill the end) -- plan.hpp
+    int order[RD_MAXB], ks[RD_MAXB], ms[RD_MAXB];
+    for (int j = 0; j < n; ++j) { ks[j] = probs[i + j].K; ms[j] = probs[i + j].M; }
     SrRowdotBatch bt;
     memset((void*)&bt, 0, sizeof(bt));
     bt.count = n;
-    int tiles = 0;
+    const int tiles = plan_rowdot_schedule(ks, ms, n, order, bt.first_tile);
     for (int j = 0; j < n; ++j) {
-      const SrRowdotArgs& g = probs[order[j]];
+      const SrRowdotArgs& g = probs[i + order[j]];
       if (g.N > RD_TN) return hipErrorInvalidValue;
       bt.g[j] = g;
-      bt.first_tile[j] = tiles;
-      tiles += (g.M + RD_TM - 1) / RD_TM;
     }
-    bt.first_tile[n] = tiles;
     if (tiles > 0) {
       if (vec) hipLaunchKernelGGL(k_sr_rowdot<true>, dim3(tiles), dim3(512), 0, s, bt);
       else hipLaunchKernelGGL(k_sr_rowdot<false>, dim3(tiles), dim3(512), 0, s, bt);
@@ -527,11 +520,7 @@ hipError_t launch_sr_rowdot(hipStream_t s, const float* A, long long lda, const 
   return launch_sr_rowdot_batch(s, &g, 1);
 }
 
-int sr_wsum_slices(int R, int num_cus) {
-  int s = (R + 63) / 64;              // at least 64 samples per slice
-  if (s > num_cus) s = num_cus;
-  return s < 1 ? 1 : s;
-}
+int sr_wsum_slices(int R, int num_cus) { return plan_sr_wsum_slices(R, num_cus); }
 
 // one (<= 256 x <= 256) block of u_W = A^T (t (.) D); wider layers are tiled by the caller
 hipError_t launch_sr_wsum(hipStream_t s, const float* A, long long lda, const float* D,

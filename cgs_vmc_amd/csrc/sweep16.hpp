@@ -849,31 +849,18 @@ __global__ __launch_bounds__(NW * 64, NT == 16 ? (RTP == 0 ? SWEEP_OCC0 : 2) : 1
   sweep16_body<NT, NW, RTP, STAMP, W1L, FAST, UPRE, RBM, ACT>(a);
 }
 
-static inline size_t sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool rbm, int uh_floats = 0) {
-  const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
-  return sizeof(float) * (size_t)(16 * Nst + (w1l ? 1 : 2) * 16 * ZS + 2 * NT * 256 + 16 +
-                                  16 + 7 * 16 + Hp + n_hidden * Hp + (rbm ? (w1l ? 0 : Nst) + 16 : 0) +
-                                  (w1l ? N * (Hp + 4) : 0) + uh_floats);
-}
-
+// (LDS bytes and the choice of variant: plan_sweep_lds_bytes / plan_sweep, plan.hpp)
 template <int NT, int NW, int RTP, bool RBM, int ACT>
 static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a_in) {
   SweepArgs a = a_in;
   const dim3 grid((a.B + 15) / 16), block(NW * 64);
-  const size_t lds_full = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, true, RBM);
-  // (more than 256 units: W1 alone would need > 160 KiB; those variants are not instantiated)
-  const bool w1l = NT <= 16 && lds_full <= 160 * 1024 && !a.no_w1l;
-  size_t lds = w1l ? lds_full : sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false, RBM);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  const int nblk = (a.N + 3) / 4;
+  constexpr bool TUNED = ACT == VMC_ACT_RELU_;   // other activations only get the general variant
   const bool plain = a.inj_up == nullptr && a.dbg_up == nullptr;
-  const bool fast2 = nblk <= 32 && plain, fast4 = nblk <= 64 && plain;
-  // five-slot hand-over area of the UPRE = 4 variant at 256 units (sweep16_body: UH_IN_X is false)
-  a.uh_lds = 0;
-  if (NT == 16 && NW == 8 && !w1l && !fast2 && fast4) {
-    const size_t with_uh = sweep_lds_bytes(a.N, NT * 16, a.n_hidden, false, RBM, 4 * 5 * 256);
-    if (with_uh <= 160 * 1024) { lds = with_uh; a.uh_lds = 1; }
-  }
+  const SweepPlan sp = plan_sweep(a.N, NT, NW, a.n_hidden, RBM, a.no_w1l != 0, plain, TUNED);
+  if (!sp.ok) return hipErrorInvalidValue;
+  const bool w1l = sp.w1l != 0, fast2 = sp.fast == 2, fast4 = sp.fast == 2 || sp.fast == 4;
+  const size_t lds = sp.lds;
+  a.uh_lds = sp.uh_lds;
 #define SWEEP_LAUNCH(ST, WL, FA, UP)                                                          \
   do {                                                                                        \
     hipError_t e = hipFuncSetAttribute((const void*)k_sweep16<NT, NW, RTP, ST, WL, FA, UP, RBM, ACT>, \
@@ -882,7 +869,6 @@ static hipError_t launch_sweep16_t(hipStream_t s, const SweepArgs& a_in) {
     hipLaunchKernelGGL((k_sweep16<NT, NW, RTP, ST, WL, FA, UP, RBM, ACT>), grid, block, lds, s, a); \
     return hipGetLastError();                                                                 \
   } while (0)
-  constexpr bool TUNED = ACT == VMC_ACT_RELU_;   // other activations only get the general variant
   if (a.dbg_cycles) {
     if (!(w1l && fast2) || RBM || NT != 16 || !TUNED) return hipErrorInvalidValue;   // diagnostic build: production variant only
     if constexpr (!RBM && NT == 16 && TUNED) SWEEP_LAUNCH(true, true, true, 2);

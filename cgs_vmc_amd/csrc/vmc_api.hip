@@ -302,42 +302,15 @@ void drain_timings(vmc_ctx* c) {
   c->pending.clear();
 }
 
-long long off_w(const vmc_ctx* c, int l) {  // weight matrix of layer l (0 = first)
-  if (l == 0) return c->lay.off_w1;
-  return c->lay.off_h0 + (long long)(l - 1) * ((long long)c->H * c->H + c->H);
-}
-long long off_b(const vmc_ctx* c, int l) {  // biases sit right behind their weights
-  return l == 0 ? c->lay.off_b1 : off_w(c, l) + (long long)c->H * c->H;
-}
+long long off_w(const vmc_ctx* c, int l) { return plan_off_w(c->lay, c->H, l); }   // weight matrix of layer l (0 = first)
+long long off_b(const vmc_ctx* c, int l) { return plan_off_b(c->lay, c->H, l); }   // biases sit right behind their weights
 long long off_wout(const vmc_ctx* c) { return c->lay.off_wout; }
 long long off_bout(const vmc_ctx* c) { return c->lay.off_bout; }
 
-// split-K of the weight-gradient GEMMs (K = number of samples): ~512 samples per split, measured
-// best at K = 4096 (8 splits: 0.086 ms for the whole gradient path against 0.097 at 16, 0.109 at 4)
+// split-K of the general GEMMs (K = number of samples): plan_splitk; CGS_VMC_SPLITK is a measurement knob
 int pick_splitk(const vmc_ctx* c, long long k) {
-  static const int forced = getenv("CGS_VMC_SPLITK") ? atoi(getenv("CGS_VMC_SPLITK")) : 0;   // measurement knob
-  // never 1: a single slice accumulates straight into C and the fixed-order reduction that follows
-  // would fold a workspace nobody wrote
-  if (forced > 0) return forced < 2 ? 2 : (forced < c->splitk ? forced : c->splitk);
-  long long s = k / 512;
-  if (s < 4) s = 4;
-  if (s > c->splitk) s = c->splitk;
-  return (int)s;
-}
-
-ParamLayout make_layout(bool rbm, long long N, long long H, long long L) {
-  ParamLayout lay;
-  if (rbm) {   // w_on[N] b_on | w_1 b_1 | (w b) x L        (see include/cgsvmc.h)
-    lay.off_won = 0; lay.off_bout = N; lay.off_wout = -1;
-    lay.off_w1 = N + 1; lay.off_b1 = lay.off_w1 + N * H; lay.off_h0 = lay.off_b1 + H;
-    lay.n_hh = (int)L;
-  } else {     // w_1 b_1 | (w b) x (L-1) | w_out b_out
-    lay.off_w1 = 0; lay.off_b1 = N * H; lay.off_h0 = lay.off_b1 + H;
-    lay.n_hh = (int)L - 1;
-    lay.off_wout = lay.off_h0 + (L - 1) * (H * H + H); lay.off_bout = lay.off_wout + H;
-    lay.off_won = -1;
-  }
-  return lay;
+  static const int forced = getenv("CGS_VMC_SPLITK") ? atoi(getenv("CGS_VMC_SPLITK")) : 0;
+  return plan_splitk(k, c->splitk, forced);
 }
 
 int ensure_packed(vmc_ctx* c, int which) {
@@ -670,14 +643,11 @@ int reduce_accumulators(vmc_ctx* c, void* comm, int world) {
 extern "C" {
 
 int64_t vmc_num_params(int32_t n_sites, int32_t layer_size, int32_t num_layers) {
-  const int64_t N = n_sites, H = layer_size, L = num_layers;
-  return N * H + H + (L - 1) * (H * H + H) + H + 1;
+  return plan_num_params_dense(VMC_ANSATZ_FULLY_CONNECTED, n_sites, layer_size, num_layers);
 }
 
 int64_t vmc_num_params_ansatz(int32_t ansatz, int32_t n_sites, int32_t layer_size, int32_t num_layers) {
-  const int64_t N = n_sites, H = layer_size, L = num_layers;
-  if (ansatz == VMC_ANSATZ_RBM) return N + 1 + N * H + H + L * (H * H + H);
-  return vmc_num_params(n_sites, layer_size, num_layers);
+  return plan_num_params_dense(ansatz, n_sites, layer_size, num_layers);
 }
 
 int64_t vmc_num_params_conv(int32_t ansatz, int32_t num_layers, int32_t num_filters, int32_t kernel_size) {
@@ -694,76 +664,16 @@ const char* vmc_last_error(const vmc_ctx* ctx) {
 int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (!d || !out) return fail(nullptr, VMC_ERR_INVALID, "null argument");
   *out = nullptr;
-  if (d->ansatz < VMC_ANSATZ_FULLY_CONNECTED || d->ansatz > VMC_ANSATZ_RES_NET_1D)
-    return fail(nullptr, VMC_ERR_UNSUPPORTED, "only the fully_connected, rbm, conv_1d/2d and res_net_1d/2d ansatz types have HIP kernels");
-  const bool rbm = d->ansatz == VMC_ANSATZ_RBM;
-  const bool conv = d->ansatz >= VMC_ANSATZ_CONV_2D;
-  const bool resnet = d->ansatz == VMC_ANSATZ_RES_NET_2D || d->ansatz == VMC_ANSATZ_RES_NET_1D;
-  const bool one_d = d->ansatz == VMC_ANSATZ_CONV_1D || d->ansatz == VMC_ANSATZ_RES_NET_1D;
-  if (d->n_sites < 2 || d->batch_size < 1 || d->num_layers < ((rbm || resnet) ? 0 : 1) || d->layer_size < 1)
-    return fail(nullptr, VMC_ERR_INVALID, "n_sites >= 2, batch_size, layer_size >= 1, num_layers >= 1 (rbm, res_net_2d: >= 0) required");
-  ConvGeom cg;
-  memset(&cg, 0, sizeof(cg));
-  if (conv) {
-    // Conv2DNetwork reshapes its input to [-1, size_x, size_y, 1] (wavefunctions.py:596-597);
-    // Conv1DNetwork expands [B, N] to [B, N, 1] (wavefunctions.py:511): an N x 1 lattice here
-    const int sx = one_d ? d->n_sites : d->size_x, sy = one_d ? 1 : d->size_y;
-    if (sx < 1 || sy < 1 || (long long)sx * sy != d->n_sites)
-      return fail(nullptr, VMC_ERR_INVALID, "size_x * size_y must equal num_sites");
-    if (d->kernel_size < 1 || d->kernel_size > 7)
-      return fail(nullptr, VMC_ERR_UNSUPPORTED, "kernel_size 1..7 supported by the convolution kernels (weights are register resident)");
-    if (d->layer_size > CONV_FP * CONV_MAX_NCB)
-      return fail(nullptr, VMC_ERR_UNSUPPORTED, "num_conv_filters > 32 not supported by the convolution kernels");
-    if (sx < d->kernel_size / 2 || (!one_d && sy < d->kernel_size / 2) || sx > 1023 || sy > 1023)
-      return fail(nullptr, VMC_ERR_UNSUPPORTED, "lattice sides must be in [kernel_size / 2, 1023]");
-    cg.K = d->kernel_size; cg.D1 = sx; cg.D2 = sy; cg.N = d->n_sites; cg.F = d->layer_size;
-    cg.n_conv = resnet ? 1 + 2 * d->num_layers : d->num_layers;
-    cg.resnet = resnet ? 1 : 0; cg.hact = d->nonlinearity;
-    cg.GS = (4 * cg.N + 63) / 64 * 64;
-    cg.NCB = (cg.F + CONV_FP - 1) / CONV_FP;
-    cg.CS = 4 * cg.NCB * cg.GS;
-    if (one_d) {   // layers.py:66-72: k/2 in front, k - 1 - k/2 behind (odd k: (k-1)/2 both)
-      cg.KW = 1; cg.lo = cg.K / 2; cg.hi = cg.K - 1 - cg.lo; cg.lo2 = cg.hi2 = 0;
-    } else {       // layers.py:132-141: (k-1)/2 in front, k/2 behind, both axes
-      cg.KW = cg.K; cg.lo = cg.lo2 = (cg.K - 1) / 2; cg.hi = cg.hi2 = cg.K / 2;
-    }
-    if (cg.n_conv > CONV_MAX_LAYERS) return fail(nullptr, VMC_ERR_UNSUPPORTED, "too many convolutions");
-    if ((long long)d->batch_size * cg.CS >= (1LL << 31))
-      return fail(nullptr, VMC_ERR_UNSUPPORTED, "batch_size x lattice too large for the 32-bit tape offsets of the convolution kernels");
-    if (conv_rows_lds(cg, 1) > 160 * 1024)
-      return fail(nullptr, VMC_ERR_UNSUPPORTED, "lattice too large: the feature maps of one sample must fit the 160 KiB of LDS");
+  // every shape decision (ansatz, limits, LDS budgets, padded sizes, parameter layout): plan_desc, plan.hpp
+  DescPlan dp;
+  {
+    char msg[256];
+    const char* wf = getenv("CGS_VMC_WIDE_FAST");
+    const int rc = plan_desc(d, !(wf && atoi(wf) == 0), &dp, msg, sizeof(msg));
+    if (rc != VMC_OK) return fail(nullptr, rc, msg);
   }
-  if (d->nonlinearity < 0 || d->nonlinearity > 6 || d->output_activation < 0 || d->output_activation > 6)
-    return fail(nullptr, VMC_ERR_INVALID, "unknown activation id (layers.NONLINEARITIES has 7 entries)");
-  if (rbm && d->output_activation != VMC_ACT_EXP)
-    return fail(nullptr, VMC_ERR_INVALID, "the rbm ansatz has no output_activation: it is always exp (wavefunctions.py:419-420)");
-  const bool wide = !conv && d->layer_size > 256;
-  // 257 .. 512 units run the fused kernels (every activation); beyond that -- or with the fused path
-  // switched off or out of LDS -- the general path, whose back-propagation reads f' off the
-  // activation and therefore has no cos
-  bool wide_fast_ok = false;
-  if (wide && d->layer_size <= 512) {
-    const int hp = (d->layer_size + 127) / 128 * 128;     // 8 waves x whole 16-unit tiles
-    const int n_hh = rbm ? d->num_layers : d->num_layers - 1;
-    const char* e = getenv("CGS_VMC_WIDE_FAST");
-    wide_fast_ok = !(e && atoi(e) == 0) && (n_hh == 0 || tail_lds_supported(hp, n_hh)) &&
-                   sweep_lds_required(d->n_sites, hp, n_hh, rbm) <= 160 * 1024;
-  }
-  if (wide && d->layer_size > 4096)
-    return fail(nullptr, VMC_ERR_UNSUPPORTED, "fc_layer_size > 4096 is not supported");
-  if (wide && !wide_fast_ok && d->nonlinearity == VMC_ACT_COS)
-    return fail(nullptr, VMC_ERR_UNSUPPORTED, "nonlinearity cos is supported up to 512 units (the fused kernels); the general path beyond has every other activation");
-  if (!conv && !wide) {  // the sampler keeps 16 chains' spins, z1 and operands in LDS (160 KiB per CU)
-    const int hp = (d->layer_size + 63) / 64 * 64;
-    const int n_hh = rbm ? d->num_layers : d->num_layers - 1;
-    const size_t need = sweep_lds_required(d->n_sites, hp, n_hh, rbm);
-    if (need > 160 * 1024) {
-      char msg[200];
-      snprintf(msg, sizeof(msg), "num_sites = %d with %d hidden units needs %zu bytes of LDS for the sampler's "
-               "chain state (limit 163840)", d->n_sites, d->layer_size, need);
-      return fail(nullptr, VMC_ERR_UNSUPPORTED, msg);
-    }
-  }
+  const bool rbm = dp.rbm != 0, conv = dp.conv != 0, wide = dp.wide != 0, wide_fast_ok = dp.wide_fast != 0;
+  const ConvGeom cg = dp.cg;
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0)
@@ -775,24 +685,20 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   vmc_ctx* c = new vmc_ctx();
   c->d = *d;
   c->N = d->n_sites; c->B = d->batch_size; c->L = d->num_layers; c->H = d->layer_size;
-  c->Hp = (c->H + 63) / 64 * 64;
   c->rbm = rbm;
   c->conv = conv; c->cg = cg;
-  if (conv) { c->L = 1; c->Hp = 64; c->overlap = false; }   // minimal dense-side shapes (unused)
+  if (conv) { c->L = 1; c->overlap = false; }   // minimal dense-side shapes (unused)
   c->wide = wide;
   if (wide) c->overlap = false;
   c->hact = d->nonlinearity; c->oact = d->output_activation;
-  c->lay = make_layout(rbm, c->N, c->H, c->L);
-  if (wide_fast_ok) {
-    // 257 .. 512 units: the fused sampler padded to 384 / 512 units (k_sweep16<24|32>), rows on the
-    // LDS-operand kernel (k_tail_lds; without an H x H layer: k_tail0) and the fused back-propagation
-    // (k_backprop16<24|32>); both dense ansatz types, every hidden activation
-    c->wide_fast = true;
-    c->Hp = (c->H + 127) / 128 * 128;
-  }
+  c->lay = dp.lay;
+  // 257 .. 512 units (wide_fast): the fused sampler padded to 384 / 512 units (k_sweep16<24|32>), rows on
+  // the LDS-operand kernel (k_tail_lds; without an H x H layer: k_tail0) and the fused back-propagation
+  // (k_backprop16<24|32>); both dense ansatz types, every hidden activation
+  c->wide_fast = wide_fast_ok;
+  c->Hp = dp.Hp;
   c->n_hh = c->lay.n_hh; c->A = c->n_hh + 1;
-  c->P = conv ? vmc_num_params_conv(d->ansatz, d->num_layers, d->layer_size, d->kernel_size)
-              : vmc_num_params_ansatz(d->ansatz, c->N, c->H, c->L);
+  c->P = dp.P;
   c->stream = (hipStream_t)d->stream;
   if (const char* e = getenv("CGS_VMC_SWEEP_W1L")) c->sweep_no_w1l = atoi(e) == 0 ? 1 : 0;
   if (const char* e = getenv("CGS_VMC_OVERLAP")) { c->overlap = !conv && !wide && atoi(e) != 0; c->overlap_full = atoi(e) == 2; }
@@ -852,8 +758,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(hipMemsetAsync(c->acc, 0, (2 * P + 8) * sizeof(float), c->stream));
   CA(hipMemsetAsync(c->adam_m, 0, P * sizeof(float), c->stream));
   CA(hipMemsetAsync(c->adam_v, 0, P * sizeof(float), c->stream));
-  const long long mmax = N > c->H ? N : c->H;
-  CA(dalloc(&c->gemm_ws, (long long)(L + 1) * c->splitk * 2 * (mmax + 1) * c->H));
+  CA(dalloc(&c->gemm_ws, plan_gemm_ws_floats(L + 1, c->splitk, N, c->H)));
   CA(dalloc(&c->d_accepted, 1)); CA(dalloc(&c->d_sum, 1)); CA(dalloc(&c->d_max, 1));
   CA(dalloc(&c->inj_up, B)); CA(dalloc(&c->inj_dn, B)); CA(dalloc(&c->inj_u, B));
   CA(dalloc(&c->acc_mask, B));
@@ -869,50 +774,25 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     CA(hipMemsetAsync(c->wide_zero, 0, Hp * sizeof(float), c->stream));
   }
   if (conv) {
-    const long long KK = (long long)cg.K * cg.KW, nl = cg.n_conv > 1 ? cg.n_conv - 1 : 1;
+    const long long nl = cg.n_conv > 1 ? cg.n_conv - 1 : 1;
     for (int w = 0; w < 2; ++w) {
       ParamSet& p = c->ps[w];
-      const long long nb = cg.NCB;
-      CA(dalloc(&p.cw0, nb * ((KK + 3) / 4) * 64)); CA(dalloc(&p.cwf, nl * nb * nb * KK * 256));
-      CA(dalloc(&p.cwb, nl * nb * nb * KK * 256));
-      CA(dalloc(&p.cbias, (long long)cg.n_conv * 16 * nb));
+      CA(dalloc(&p.cw0, plan_conv_w0_floats(cg))); CA(dalloc(&p.cwf, plan_conv_wf_floats(cg)));
+      CA(dalloc(&p.cwb, plan_conv_wf_floats(cg)));
+      CA(dalloc(&p.cbias, plan_conv_bias_floats(cg)));
     }
     const int nw = conv_waves(cg);
     c->cG = conv_pick_group(cg, nw);
     if (c->cG > B) c->cG = (int)B;
-    {  // sampler: chains per workgroup that minimise (workgroups per CU) x (tile rounds of one
-       // forward pass) -- the MFMA time of the busiest CU per mc_step.  The two-channel-block kernels
-       // walk their tiles in pairs.  Ties go to the group size that fills the last round of workgroups
-       // best (4096 chains, 32 filters on 10 x 10: G = 4 -> 1024 workgroups = 4 per CU measured 84.9 ms
-       // per sweep, G = 5 -> 820 workgroups 87.8 ms), then to the larger group.
-      long long best_cost = -1;
-      double best_fill = 0.0;
-      for (int G = 1; G <= 64 && conv_rows_lds(cg, G) <= conv_lds_cap(cg) && G <= B; ++G) {
-        const long long wgs = (B + G - 1) / G, per_cu = (wgs + c->num_cus - 1) / c->num_cus;
-        long long tiles = ((long long)G * cg.N + 15) / 16;
-        if (cg.NCB > 1) tiles = (tiles + 1) / 2;          // tile pairs
-        const long long tile_rounds = (tiles + nw - 1) / nw;
-        const long long cost = per_cu * tile_rounds;
-        const double fill = (double)wgs / (double)(per_cu * c->num_cus);
-        if (best_cost < 0 || cost < best_cost || (cost == best_cost && fill >= best_fill - 1e-9)) {
-          best_cost = cost; best_fill = fill; c->cGs = G;
-        }
-      }
-    }
+    c->cGs = conv_pick_sweep_group(cg, B, c->num_cus, nw);     // chains per sampler workgroup (plan.hpp)
     if (const char* e = getenv("CGS_VMC_CONV_SWEEP_G")) {     // measurement knob: chains per sampler workgroup
       const int G = atoi(e);
       if (G >= 1 && G <= 64 && conv_rows_lds(cg, G) <= conv_lds_cap(cg)) c->cGs = G < B ? G : (int)B;
     }
     c->ctape_stride = B * cg.CS; c->cdelta_stride = B * cg.CS;
     CA(dalloc(&c->ctape, nl * c->ctape_stride)); CA(dalloc(&c->cdelta, (long long)cg.n_conv * c->cdelta_stride));
-    {
-      // two resident workgroups per CU (NCB = 1) over the layers > 0, whose workgroups carry the work
-      const int per_cu = cg.NCB == 1 ? 2 : 1, heavy = cg.n_conv > 1 ? cg.n_conv - 1 : 1;
-      int sl = (per_cu * c->num_cus + heavy - 1) / heavy;
-      sl = sl < 64 ? 64 : (sl > 256 ? 256 : sl);
-      c->c_slices = B < sl ? (int)B : sl;
-    }
-    CA(dalloc(&c->cws, (long long)c->c_slices * cg.n_conv * 2 * (KK * 16 * cg.NCB + 1) * 16 * cg.NCB));
+    c->c_slices = plan_conv_dw_slices(cg, B, c->num_cus);
+    CA(dalloc(&c->cws, plan_conv_dw_ws_floats(cg, c->c_slices)));
   }
   CA(hipStreamSynchronize(c->stream));
 #undef CA
@@ -1861,16 +1741,16 @@ int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   const long long B = c->B, N = c->N, Hp = c->Hp, L = c->A, P = c->P, R = (long long)n_batches * B;
   if (c->conv) {
     const ConvGeom& cg = c->cg;
-    const long long CS = cg.CS, nc = cg.n_conv, KK = (long long)cg.K * cg.KW, nb = cg.NCB, nl = nc > 1 ? nc - 1 : 1;
+    const long long CS = cg.CS, nc = cg.n_conv, nl = nc > 1 ? nc - 1 : 1;
     if (R * CS >= (1LL << 31)) return fail(c, VMC_ERR_UNSUPPORTED, "SR sample store too large (rows * feature-map size >= 2^31)");
     HIPCHK(c, dalloc(&c->sr_cfg, R * N));
     HIPCHK(c, dalloc(&c->sr_ctape, nl * R * CS)); HIPCHK(c, dalloc(&c->sr_cdelta, nc * R * CS));
     HIPCHK(c, dalloc(&c->sr_t, R));
     c->sr_cslices = R < 256 ? (int)R : 256;
-    HIPCHK(c, dalloc(&c->sr_cws, (long long)c->sr_cslices * nc * 2 * (KK * 16 * nb + 1) * 16 * nb));
+    HIPCHK(c, dalloc(&c->sr_cws, plan_conv_dw_ws_floats(c->cg, c->sr_cslices)));
     if (!c->sr_cw0) {
-      HIPCHK(c, dalloc(&c->sr_cw0, nb * ((KK + 3) / 4) * 64)); HIPCHK(c, dalloc(&c->sr_cwf, nl * nb * nb * KK * 256));
-      HIPCHK(c, dalloc(&c->sr_cwb, nl * nb * nb * KK * 256)); HIPCHK(c, dalloc(&c->sr_cbias, nc * 16 * nb));
+      HIPCHK(c, dalloc(&c->sr_cw0, plan_conv_w0_floats(cg))); HIPCHK(c, dalloc(&c->sr_cwf, plan_conv_wf_floats(cg)));
+      HIPCHK(c, dalloc(&c->sr_cwb, plan_conv_wf_floats(cg))); HIPCHK(c, dalloc(&c->sr_cbias, plan_conv_bias_floats(cg)));
     }
     if (!c->sr_u) {
       HIPCHK(c, dalloc(&c->sr_u, P + 1)); HIPCHK(c, dalloc(&c->sr_x, P)); HIPCHK(c, dalloc(&c->sr_r, P));
