@@ -266,12 +266,24 @@ struct GemmArgs {
   float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
 };
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
-// `count` dual / ones-row GEMMs (device array of GemmArgs, all with the same splitk and their
-// own workspace) in one launch + one reduction launch; max_m counts MFMA rows (M - 1)
-hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
-                               int max_n, int splitk, bool dual = true, bool fresh = false,
-                               const float* sc_eloc = nullptr, const float* sc_ratio = nullptr,
-                               float* sc_out = nullptr, int sc_B = 0, int sc_mode = 0);
+// All weight gradients of one accumulate call -- [a_{l-1} | 1]^T [delta_l | w (.) delta_l] of every
+// layer, the N = 1 column sums and the scalar accumulators -- in ONE launch (k_wgrad, grad.hip; tiles,
+// slices and block order: plan.hpp).  The problem table lives in device memory and is built once per
+// weight vector with wgrad_fill_problem into a host buffer of n x wgrad_problem_bytes().
+struct WgradLaunch {
+  const void* dev_problems; int n_prob;
+  int tiles, slices, col_blocks;       // plan_wgrad_tiles summed, plan_wgrad_slices, 64-column blocks of the N = 1 problems
+  int K;                               // samples
+  const float* w;                      // [K] weights of the second sum
+  float* g1; float* g2;                // accumulators (theta layout)
+  float* ws; int* tickets;             // plan_wgrad_ws_floats(tiles, slices) floats, `tiles` zeroed ints
+  bool fresh;                          // the accumulators hold no sum yet: store
+  const float* sc_eloc; const float* sc_ratio; float* sc_out; int sc_B, sc_mode;   // scalar accumulators (sc_out may be null)
+};
+size_t wgrad_problem_bytes();
+void wgrad_fill_problem(void* dst, int index, const float* A, long long lda, const float* D, long long ldd,
+                        long long c_off, int k_in, int n_out, int tile0, int col0);
+hipError_t launch_wgrad(hipStream_t s, const WgradLaunch& L);
 hipError_t launch_act_copy(hipStream_t s, const float* z, float* a, float* dact, long long n, int act);
 hipError_t launch_out_scale(hipStream_t s, const float* x, float* oscale, int B, int oact);
 hipError_t launch_tanh_copy(hipStream_t s, const float* z, float* a, long long n);

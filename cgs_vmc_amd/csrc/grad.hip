@@ -240,49 +240,11 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
   gemm_block<DUAL, NS>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// Several independent dual GEMMs (one per layer's weight gradient) in ONE launch:
-// blockIdx.z = problem * splitk + split.  With ~4 workgroups co-resident per CU the global
-// load latency of one is hidden behind the MFMAs of the others.
-// XCD-aware block order: workgroups go to the 8 XCDs round robin by linear block id, and every XCD
-// has its own L2.  All tiles of one (problem, k-slice) group -- they share that slice's A and B
-// operand rows -- are given ids that are congruent mod 8, so one XCD's L2 fetches a slice once
-// instead of (up to) eight L2s fetching it each: group g lives on XCD g % 8.
-template <bool DUAL, int NS = 1>
-__global__ __launch_bounds__(256) void k_gemm_batched(const GemmArgs* __restrict__ batch,
-                                                      int splitk, int tiles_x, int tiles_y, int n_groups) {
-  const int per_group = tiles_x * tiles_y;
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int grp = xcd + 8 * (idx / per_group), tile = idx % per_group;
-  if (grp >= n_groups) return;                                                  // block-uniform
-  const int bx = tile % tiles_x, by = tile / tiles_x;
-  const GemmArgs g = batch[grp / splitk];
-  const int m_rows = g.ones_row ? g.M - 1 : g.M;
-  if (bx * GT >= g.N || by * GT >= m_rows) return;                              // block-uniform
-  gemm_block<DUAL, NS>(g, bx, by, grp % splitk);
-}
-
-// fresh: the destination holds no sum yet (accumulators after reset_gradients): epilogue 3 stores
-__device__ __forceinline__ void gemm_reduce_body(const GemmArgs& g, long long start,
-                                                 long long stride, bool fresh = false) {
-  const long long mn = (long long)g.M * g.N;
-  const int nd = g.dual ? 2 : 1;
-  for (long long i = start; i < mn * nd; i += stride) {
-    const int d = (int)(i / mn);
-    const long long e = i % mn;
-    float v = 0.f;
-    for (int z = 0; z < g.splitk; ++z) v += g.workspace[((long long)z * nd + d) * mn + e];
-    if (fresh && g.epilogue == 3) (d ? g.C2 : g.C)[(e / g.N) * g.ldc + (e % g.N)] = v;
-    else gemm_epilogue(g, d ? g.C2 : g.C, (int)(e / g.N), (int)(e % g.N), v);
-  }
-}
-
 // tf.metrics.mean updates (training.py:555, 689-690) + mean_tensor count (550-553):
 // scalars = [e_total, e_count, r_total, r_count, g_count]; one workgroup, fixed order
 struct ScalarJob { const float* eloc; const float* ratio; float* sc; int B, mode; };
 
-__device__ __forceinline__ void scalar_accum_body(const ScalarJob& j, bool fresh) {
-  __shared__ double se[256];
-  __shared__ double sr[256];
+__device__ __forceinline__ void scalar_accum_body(const ScalarJob& j, bool fresh, double* se, double* sr) {
   double e = 0.0, r = 0.0;
   for (int i = threadIdx.x; i < j.B; i += 256) {
     e += (double)j.eloc[i];
@@ -307,16 +269,320 @@ __device__ __forceinline__ void scalar_accum_body(const ScalarJob& j, bool fresh
   }
 }
 
-// grid (blocks, count + 1): rows 0 .. count-1 fold the split-K partials of one problem each; block 0 of
-// the extra row does the scalar accumulators of the same accumulate call (no launch of its own)
-__global__ __launch_bounds__(256) void k_gemm_reduce_batched(const GemmArgs* __restrict__ batch, int count, int fresh,
-                                                             ScalarJob job) {
-  if ((int)blockIdx.y == count) {
-    if (blockIdx.x == 0 && job.sc) scalar_accum_body(job, fresh != 0);
+// ----------------------------------------------------------------- batched weight-gradient kernel
+// Every weight gradient of the dense ansatz types is [a_{l-1} | 1]^T [delta_l | w (.) delta_l] over the
+// B samples of the batch (training.py:545-547): rows 0 .. k_in-1 give dW, the implicit ones row gives
+// db (b_l sits right behind w_l in theta); the unscaled product goes to g1, the w-scaled one to g2.
+// ALL layers run as ONE launch of three kinds of workgroup (block-uniform dispatch on the block id):
+//  * MFMA tiles: a 128 x 64 output tile of one layer over one K slice of the samples.  4 waves as 2 x 2,
+//    each 64 x 32 = two 32x32x2 accumulators per product (four MFMAs per four LDS operand reads); the
+//    operands of k-tile t+1 travel global -> registers while tile t is multiplied from LDS and go to the
+//    OTHER LDS buffer afterwards: one barrier per 32 samples.  Slices are sized so that tiles x slices
+//    fills the CUs once (plan_wgrad_slices); slice s lives on XCD s % 8, whose L2 then fetches that
+//    slice's operand rows once (plan_wgrad_block).  The partial tile goes to the workspace in
+//    accumulator order (coalesced), the workgroup takes a ticket, and the LAST one to arrive folds the
+//    slices 0 .. S-1 of its tile in that fixed order into the accumulators -- no reduction launch, no
+//    float atomics, the same bits whoever arrives last.
+//  * column sums: the N = 1 problems (output layer: d logit / d w_out = a_L; RBM onsite layer) are
+//    [a | 1]^T s with a per-sample scalar s -- VALU work, 64 columns per workgroup over all samples.
+//  * one workgroup for the scalar accumulators (sum E, counts) of the same accumulate call.
+struct WgradProblem {
+  const float* A; long long lda;      // A(b, m) = A[b * lda + m], m < k_in (m == k_in: the ones row)
+  const float* D; long long ldd;      // delta(b, n) = D[b * ldd + n], n < n_out
+  long long c_off;                    // offset of C[(k_in + 1)][n_out] in g1 / g2 (theta layout: w then b)
+  int k_in, n_out;
+  int tile0, tiles_n;                 // first MFMA tile of this problem, tiles along n (n_out > 1)
+  int col0;                           // first column-sum block of this problem (n_out == 1)
+};
+
+struct WgradArgs {
+  const WgradProblem* prob;           // device table
+  int n_prob;
+  int tiles, slices, kchunk;          // MFMA tiles over all problems, K slices, samples per slice
+  int mfma_blocks, col_blocks;        // block id ranges: [0, mfma_blocks) tiles, then column sums, then the scalars
+  int K;                              // samples
+  const float* w;                     // [K] per-sample weight of the second sum
+  float* g1; float* g2;
+  float* ws;                          // [tiles][slices][2][WG_TM * WG_TN + WG_TN] partial tiles + ones rows
+  int* tickets;                       // [tiles], zero between launches
+  int fresh;                          // 1: the accumulators hold no sum yet (store instead of add)
+  ScalarJob job;
+};
+
+#define WG_LDA (WG_TM + 4)
+#define WG_LDB (WG_TN + 4)
+#define WG_STAGE (WG_TK * WG_LDA + 2 * WG_TK * WG_LDB)      // floats of one LDS stage: A, B, w (.) B
+#define WG_PART (WG_TM * WG_TN + WG_TN)                      // floats of one partial (tile + ones row)
+
+struct WgradRegs { f32x4 a[4]; f32x4 b[2]; float w[2]; };
+
+// operands of the k-tile starting at sample k0 (all loads unconditional and clamped: an out-of-range
+// row or column is read somewhere valid and zeroed, so that vmcnt is counted exactly)
+__device__ __forceinline__ void wgrad_load(const WgradProblem& P, const float* __restrict__ w, int m0, int n0,
+                                           int k0, int kend, int tid, bool vec_a, bool vec_d, WgradRegs& r) {
+  const int am = m0 + 4 * (tid & 31);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + (tid >> 5) + 8 * i;
+    const int kc = k < kend ? k : kend - 1;
+    const float* p = P.A + (long long)kc * P.lda;
+    f32x4 v;
+    if (vec_a && am + 3 < P.k_in) {
+      v = *(const f32x4*)(p + am);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = am + j < P.k_in ? p[am + j] : 0.f;
+    }
+    r.a[i] = k < kend ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int bn = n0 + 4 * (tid & 15);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = k0 + (tid >> 4) + 16 * i;
+    const int kc = k < kend ? k : kend - 1;
+    const float* p = P.D + (long long)kc * P.ldd;
+    f32x4 v;
+    if (vec_d && bn + 3 < P.n_out) {
+      v = *(const f32x4*)(p + bn);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = bn + j < P.n_out ? p[bn + j] : 0.f;
+    }
+    r.b[i] = k < kend ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    r.w[i] = w[kc];
+  }
+}
+
+__device__ __forceinline__ void wgrad_stage(float* st, int tid, const WgradRegs& r) {
+  float* As = st;
+  float* Bs = st + WG_TK * WG_LDA;
+  float* Bs2 = Bs + WG_TK * WG_LDB;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *(f32x4*)(As + ((tid >> 5) + 8 * i) * WG_LDA + 4 * (tid & 31)) = r.a[i];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int o = ((tid >> 4) + 16 * i) * WG_LDB + 4 * (tid & 15);
+    *(f32x4*)(Bs + o) = r.b[i];
+    *(f32x4*)(Bs2 + o) = r.b[i] * r.w[i];
+  }
+}
+
+// element i (0 .. 31) of a thread's accumulators: i = 16 blk + r -> (m, n) inside the tile
+__device__ __forceinline__ void wgrad_mn(int tid, int i, int& m, int& n) {
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int blk = i >> 4, r = i & 15;
+  m = wm * 64 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  n = wn * 32 + (lane & 31);
+}
+
+__device__ __forceinline__ void wgrad_tile(const WgradArgs& a, int slice, int tile, float* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  // tile -> problem (block-uniform; a handful of problems)
+  int pi = 0;
+  for (int i = 0; i < a.n_prob; ++i)
+    if (a.prob[i].n_out > 1 && tile >= a.prob[i].tile0) pi = i;      // tile0 ascends with the problem index
+  const WgradProblem P = a.prob[pi];
+  const int lt = tile - P.tile0, tm = lt / P.tiles_n, tn = lt % P.tiles_n;
+  const int m0 = tm * WG_TM, n0 = tn * WG_TN;
+  const int kbeg = slice * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+  const int T = (kend - kbeg + WG_TK - 1) / WG_TK;             // >= 1: no slice is empty (plan_wgrad_slices)
+  const bool vec_a = (P.lda & 3) == 0 && (((size_t)P.A) & 15) == 0;
+  const bool vec_d = (P.ldd & 3) == 0 && (((size_t)P.D) & 15) == 0;
+  const bool ones = tm == 0;                                   // the m-tile-0 workgroups also sum the columns of B
+
+  f32x16 acc[2], acc2[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc2[0][r] = 0.f; acc2[1][r] = 0.f; }
+  float cs = 0.f, cs2 = 0.f;
+
+  WgradRegs regs;
+  wgrad_load(P, a.w, m0, n0, kbeg, kend, tid, vec_a, vec_d, regs);
+  wgrad_stage(smem, tid, regs);
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const float* st = smem + (t & 1) * WG_STAGE;
+    const float* As = st;
+    const float* Bs = st + WG_TK * WG_LDA;
+    const float* Bs2 = Bs + WG_TK * WG_LDB;
+    // tile t + 1 travels to registers under the MFMAs of tile t (clamped: the last iteration re-reads its own)
+    wgrad_load(P, a.w, m0, n0, kbeg + min(t + 1, T - 1) * WG_TK, kend, tid, vec_a, vec_d, regs);
+    if (ones) {       // wave w adds the k rows 8w .. 8w+7 of the columns it sees: 16 LDS reads per k-tile
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        cs += Bs[(8 * wave + kk) * WG_LDB + lane];
+        cs2 += Bs2[(8 * wave + kk) * WG_LDB + lane];
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < WG_TK; kk += 2) {
+      const int kr = kk + (lane >> 5);
+      const float a0 = As[kr * WG_LDA + wm * 64 + (lane & 31)];
+      const float a1 = As[kr * WG_LDA + wm * 64 + 32 + (lane & 31)];
+      const float b = Bs[kr * WG_LDB + wn * 32 + (lane & 31)];
+      const float b2 = Bs2[kr * WG_LDB + wn * 32 + (lane & 31)];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
+      acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc2[0], 0, 0, 0);
+      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc2[1], 0, 0, 0);
+    }
+    if (t + 1 < T) wgrad_stage(smem + ((t + 1) & 1) * WG_STAGE, tid, regs);
+    __syncthreads();
+  }
+  // column sums of the four waves, fixed order
+  float* s_cs = smem + 2 * WG_STAGE;          // [2][4][64]
+  if (ones) {
+    s_cs[wave * 64 + lane] = cs;
+    s_cs[256 + wave * 64 + lane] = cs2;
+  }
+  __syncthreads();
+  if (ones && tid < 128) {
+    const float* q = s_cs + (tid >> 6) * 256 + (tid & 63);
+    cs = (q[0] + q[64]) + (q[128] + q[192]);    // tid < 64: column sums of B; 64 .. 127: of w (.) B
+  }
+
+  const long long ldc = P.n_out;
+  float* c1 = a.g1 + P.c_off;
+  float* c2 = a.g2 + P.c_off;
+  if (a.slices == 1) {                          // one slice: straight into the accumulators
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      int m, n;
+      wgrad_mn(tid, i, m, n);
+      m += m0; n += n0;
+      if (m < P.k_in && n < P.n_out) {
+        const float v1 = acc[i >> 4][i & 15], v2 = acc2[i >> 4][i & 15];
+        float* q1 = c1 + (long long)m * ldc + n;
+        float* q2 = c2 + (long long)m * ldc + n;
+        if (a.fresh) { *q1 = v1; *q2 = v2; } else { *q1 += v1; *q2 += v2; }
+      }
+    }
+    if (ones && tid < 128 && n0 + (tid & 63) < P.n_out) {
+      float* q = (tid < 64 ? c1 : c2) + (long long)P.k_in * ldc + n0 + (tid & 63);
+      if (a.fresh) *q = cs; else *q += cs;
+    }
     return;
   }
-  const GemmArgs g = batch[blockIdx.y];
-  gemm_reduce_body(g, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, fresh != 0);
+  // partial tile -> workspace, in accumulator order
+  float* part = a.ws + ((long long)tile * a.slices + slice) * 2 * WG_PART;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    part[i * 256 + tid] = acc[i >> 4][i & 15];
+    part[WG_PART + i * 256 + tid] = acc2[i >> 4][i & 15];
+  }
+  if (ones && tid < 128) part[(tid >> 6) * WG_PART + WG_TM * WG_TN + (tid & 63)] = cs;
+  // ticket: the partial is released device-wide before the counter moves; whoever draws the last ticket
+  // acquires everybody's
+  __threadfence();
+  __syncthreads();
+  int* s_ticket = (int*)(s_cs + 512);
+  if (tid == 0) *s_ticket = __hip_atomic_fetch_add(a.tickets + tile, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*s_ticket != a.slices - 1) return;        // block-uniform
+  __threadfence();
+  const float* base = a.ws + (long long)tile * a.slices * 2 * WG_PART;
+#pragma unroll 4
+  for (int i = 0; i < 32; ++i) {
+    int m, n;
+    wgrad_mn(tid, i, m, n);
+    m += m0; n += n0;
+    float v1 = 0.f, v2 = 0.f;
+    for (int z = 0; z < a.slices; ++z) {        // fixed order, whoever folds
+      const float* q = base + (long long)z * 2 * WG_PART + i * 256 + tid;
+      v1 += __builtin_nontemporal_load(q);
+      v2 += __builtin_nontemporal_load(q + WG_PART);
+    }
+    if (m < P.k_in && n < P.n_out) {
+      float* q1 = c1 + (long long)m * ldc + n;
+      float* q2 = c2 + (long long)m * ldc + n;
+      if (a.fresh) { *q1 = v1; *q2 = v2; } else { *q1 += v1; *q2 += v2; }
+    }
+  }
+  if (ones && tid < 128) {
+    float v = 0.f;
+    for (int z = 0; z < a.slices; ++z)
+      v += __builtin_nontemporal_load(base + ((long long)z * 2 + (tid >> 6)) * WG_PART + WG_TM * WG_TN + (tid & 63));
+    if (n0 + (tid & 63) < P.n_out) {
+      float* q = (tid < 64 ? c1 : c2) + (long long)P.k_in * ldc + n0 + (tid & 63);
+      if (a.fresh) *q = v; else *q += v;
+    }
+  }
+  if (tid == 0) a.tickets[tile] = 0;            // for the next launch (stream-ordered after this one)
+}
+
+// N = 1 problems: C[m] = sum_b A(b, m) s_b and sum_b A(b, m) w_b s_b for 64 columns m (m == k_in: the ones
+// row), s_b = D[b * ldd]; 4 row groups x 64 columns, rows b = rg, rg + 4, ...; groups added as (0+1)+(2+3)
+__device__ __forceinline__ void wgrad_colsum(const WgradArgs& a, int cblock, float* smem) {
+  const int tid = threadIdx.x, col = tid & 63, rg = tid >> 6;
+  int pi = 0;
+  for (int i = 0; i < a.n_prob; ++i)
+    if (a.prob[i].n_out <= 1 && cblock >= a.prob[i].col0) pi = i;      // block-uniform
+  const WgradProblem P = a.prob[pi];
+  const int m = (cblock - P.col0) * 64 + col;
+  const bool real = m < P.k_in, one = m == P.k_in;
+  const float* ap = P.A + (real ? m : 0);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+  for (int b = rg; b < a.K; b += 4) {
+    const float av = real ? ap[(long long)b * P.lda] : (one ? 1.f : 0.f);
+    const float sv = P.D[(long long)b * P.ldd];
+    s1 += av * sv;
+    s2 += av * (a.w[b] * sv);
+  }
+  smem[rg * 64 + col] = s1;
+  smem[256 + rg * 64 + col] = s2;
+  __syncthreads();
+  if (tid < 128 && (real || one)) {
+    const float* q = smem + (tid >> 6) * 256 + col;
+    const float v = (q[0] + q[64]) + (q[128] + q[192]);
+    float* dst = (tid < 64 ? a.g1 : a.g2) + P.c_off + m;
+    if (a.fresh) *dst = v; else *dst += v;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float wg_smem[];
+  const int b = blockIdx.x;
+  if (b < a.mfma_blocks) {
+    const WgradBlock m = plan_wgrad_block(b, a.tiles, a.slices);
+    if (m.slice < 0) return;
+    wgrad_tile(a, m.slice, m.tile, wg_smem);
+  } else if (b < a.mfma_blocks + a.col_blocks) {
+    wgrad_colsum(a, b - a.mfma_blocks, wg_smem);
+  } else if (a.job.sc) {
+    scalar_accum_body(a.job, a.fresh != 0, (double*)wg_smem, (double*)wg_smem + 256);
+  }
+}
+
+size_t wgrad_lds_bytes() { return sizeof(float) * (2 * WG_STAGE + 512 + 4); }
+
+hipError_t launch_wgrad(hipStream_t s, const WgradLaunch& L) {
+  WgradArgs a;
+  memset((void*)&a, 0, sizeof(a));
+  a.prob = (const WgradProblem*)L.dev_problems; a.n_prob = L.n_prob;
+  a.tiles = L.tiles; a.slices = L.slices; a.kchunk = plan_wgrad_kchunk(L.K, L.slices);
+  a.mfma_blocks = plan_wgrad_grid(L.tiles, L.slices); a.col_blocks = L.col_blocks;
+  a.K = L.K; a.w = L.w; a.g1 = L.g1; a.g2 = L.g2; a.ws = L.ws; a.tickets = L.tickets; a.fresh = L.fresh ? 1 : 0;
+  a.job = ScalarJob{L.sc_eloc, L.sc_ratio, L.sc_out, L.sc_B, L.sc_mode};
+  const int grid = a.mfma_blocks + a.col_blocks + (L.sc_out ? 1 : 0);
+  if (grid <= 0 || L.K <= 0) return hipSuccess;
+  static bool attr_set = false;
+  const size_t lds = wgrad_lds_bytes();
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+size_t wgrad_problem_bytes() { return sizeof(WgradProblem); }
+
+void wgrad_fill_problem(void* dst, int index, const float* A, long long lda, const float* D, long long ldd,
+                        long long c_off, int k_in, int n_out, int tile0, int col0) {
+  WgradProblem& p = ((WgradProblem*)dst)[index];
+  p.A = A; p.lda = lda; p.D = D; p.ldd = ldd; p.c_off = c_off; p.k_in = k_in; p.n_out = n_out;
+  p.tile0 = tile0; p.tiles_n = (n_out + WG_TN - 1) / WG_TN; p.col0 = col0;
 }
 
 __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
@@ -343,22 +609,6 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
     const int blocks = (int)min((total + 255) / 256, (long long)2048);
     hipLaunchKernelGGL(k_gemm_reduce, dim3(blocks), dim3(256), 0, s, g);
   }
-  return hipGetLastError();
-}
-
-hipError_t launch_gemm_batched(hipStream_t s, const GemmArgs* dev_batch, int count, int max_m,
-                               int max_n, int splitk, bool dual, bool fresh, const float* sc_eloc,
-                               const float* sc_ratio, float* sc_out, int sc_B, int sc_mode) {
-  if (count <= 0) return hipSuccess;
-  const int tx = (max_n + GT - 1) / GT, ty = (max_m + GT - 1) / GT, groups = count * splitk;
-  const dim3 grid(8 * ((groups + 7) / 8) * tx * ty);
-  if (dual) hipLaunchKernelGGL((k_gemm_batched<true>), grid, dim3(256), 0, s, dev_batch, splitk, tx, ty, groups);
-  else hipLaunchKernelGGL((k_gemm_batched<false>), grid, dim3(256), 0, s, dev_batch, splitk, tx, ty, groups);
-  const long long total = (dual ? 2LL : 1LL) * (max_m + 1) * max_n;
-  const int blocks = (int)min((total + 255) / 256, (long long)512);
-  const ScalarJob job{sc_eloc, sc_ratio, sc_out, sc_B, sc_mode};
-  hipLaunchKernelGGL(k_gemm_reduce_batched, dim3(blocks, count + (sc_out ? 1 : 0)), dim3(256), 0, s, dev_batch, count,
-                     fresh ? 1 : 0, job);
   return hipGetLastError();
 }
 

@@ -54,46 +54,11 @@ static void check_layout(const DescPlan& p, long long N, long long H) {
   for (long long i = 0; i < P; ++i) CHECK(mark[(size_t)i] == 1);
 }
 
-// split-K of the general GEMM and its workspace: the slices cover [0, K) once, every partial a
-// workgroup stores lies inside the workspace of its problem
-static void check_gemm(long long N, long long H, int n_problems, long long K) {
-  const int cap = 16;
-  for (int forced : {0, 1, 2, 5, 16, 40}) {
-    const int s = plan_splitk(K, cap, forced);
-    CHECK(s >= 2 && s <= cap);
-    int kc = (int)((K + s - 1) / s);
-    kc = (kc + 31) / 32 * 32;
-    long long covered = 0;
-    for (int z = 0; z < s; ++z) {
-      const long long kbeg = (long long)z * kc, kend = std::min<long long>(K, kbeg + kc);
-      if (kbeg < kend) { CHECK(kbeg == covered); covered = kend; }
-    }
-    CHECK(covered == K);
-    const long long ws = plan_gemm_ws_floats(n_problems, cap, N, H), stride = ws / n_problems;
-    CHECK(stride * n_problems == ws);
-    // problems of the gradient batch: (M = k_in + 1 rows incl. the ones row) x n_out, dual
-    const long long shapes[3][2] = {{H + 1, 1}, {H + 1, H}, {N + 1, H}};
-    for (auto& mn : shapes) {
-      const long long last = ((long long)(s - 1) * 2 + 1) * mn[0] * mn[1] + (mn[0] - 1) * mn[1] + (mn[1] - 1);
-      CHECK(last < stride);
-    }
-  }
-}
-
 // XCD-aware block orders: a bijection onto (group / slice, tile), all tiles of one group on one XCD
 static void check_block_maps() {
   for (int per_group : {1, 4, 8, 16, 20, 33})
     for (int groups : {1, 7, 8, 9, 32, 48, 100}) {
       const int grid = 8 * ((groups + 7) / 8) * per_group;
-      std::vector<int> hit((size_t)groups * per_group, 0);
-      for (int b = 0; b < grid; ++b) {
-        const WgradBlock m = plan_gemm_batched_block(b, per_group, groups);
-        if (m.slice < 0) continue;
-        CHECK(m.slice < groups && m.tile >= 0 && m.tile < per_group);
-        CHECK((b & 7) == (m.slice & 7));                 // group g lives on XCD g % 8
-        hit[(size_t)m.slice * per_group + m.tile] += 1;
-      }
-      for (int v : hit) CHECK(v == 1);
       CHECK(plan_wgrad_grid(per_group, groups) == grid);
       std::vector<int> hit2((size_t)groups * per_group, 0);
       for (int b = 0; b < grid; ++b) {
@@ -106,19 +71,48 @@ static void check_block_maps() {
     }
 }
 
-// the batched weight-gradient kernel: tiles, K slices and their chunks
-static void check_wgrad(long long N, long long H, int n_hh, long long B) {
-  long long tiles = plan_wgrad_tiles((int)N, (int)H) + (long long)n_hh * plan_wgrad_tiles((int)H, (int)H);
+// the batched weight-gradient kernel: tiles, K slices and their chunks, the partial-tile workspace and
+// the (tile -> problem, m-tile, n-tile) walk of k_wgrad
+static void check_wgrad(long long N, long long H, int n_hh, bool rbm, long long B) {
+  struct Prob { int k_in, n_out, tile0; };
+  std::vector<Prob> probs;
+  int tile0 = 0;
+  auto add = [&](int k_in, int n_out) { probs.push_back({k_in, n_out, tile0}); tile0 += plan_wgrad_tiles(k_in, n_out); };
+  add(rbm ? (int)N : (int)H, 1);
+  for (int l = 0; l < n_hh; ++l) add((int)H, (int)H);
+  add((int)N, (int)H);
+  const long long tiles = tile0;
+  CHECK(tiles == plan_wgrad_tiles((int)N, (int)H) + (long long)n_hh * plan_wgrad_tiles((int)H, (int)H));
   CHECK(plan_wgrad_tiles((int)H, 1) == 0);
-  for (int cus : kCus) {
-    const int s = plan_wgrad_slices(tiles, B, cus);
-    CHECK(s >= 1 && s <= WG_MAX_SPLIT);
-    CHECK(s == 1 || tiles * s <= cus);
-    CHECK(s == 1 || (long long)(s - 1) * 64 < B + 64);
-    const int kc = plan_wgrad_kchunk((int)B, s);
-    CHECK(kc % WG_TK == 0 && (long long)kc * s >= B);
-    CHECK((long long)kc * (s - 1) < B);                 // no slice is empty
+  const int cols = plan_wgrad_col_blocks(rbm ? (int)N : (int)H);
+  CHECK((long long)cols * 64 >= (rbm ? N : H) + 1 && (long long)(cols - 1) * 64 < (rbm ? N : H) + 1);
+  // every tile belongs to exactly one problem and lies inside its output; together they cover it
+  for (const Prob& p : probs) {
+    if (p.n_out <= 1) continue;
+    const int tn = (p.n_out + WG_TN - 1) / WG_TN, nt = plan_wgrad_tiles(p.k_in, p.n_out);
+    for (int t = p.tile0; t < p.tile0 + nt; ++t) {
+      int pi = 0;
+      for (size_t i = 0; i < probs.size(); ++i)
+        if (probs[i].n_out > 1 && t >= probs[i].tile0) pi = (int)i;
+      CHECK(&probs[(size_t)pi] == &p);
+      const int lt = t - p.tile0, tm = lt / tn, tnn = lt % tn;
+      CHECK(tm * WG_TM < p.k_in && tnn * WG_TN < p.n_out);
+    }
+    CHECK((long long)((p.k_in + WG_TM - 1) / WG_TM) * tn == nt);
   }
+  for (int cus : kCus)
+    for (int forced : {0, 1, 3, 12, 100}) {
+      const int s = plan_wgrad_slices(tiles, B, cus, cols + 1, forced);
+      CHECK(s >= 1 && s <= WG_MAX_SPLIT);
+      if (!forced) CHECK(s == 1 || tiles * s + cols + 1 <= cus);
+      const int kc = plan_wgrad_kchunk((int)B, s);
+      CHECK(kc % WG_TK == 0 && (long long)kc * s >= B);
+      CHECK((long long)kc * (s - 1) < B);                 // no slice is empty
+      // the last float the last slice of the last tile writes (second product's ones row)
+      const long long part = (long long)WG_TM * WG_TN + WG_TN;
+      const long long last = (((tiles - 1) * s + (s - 1)) * 2 + 1) * part + (part - 1);
+      CHECK(tiles == 0 || last < plan_wgrad_ws_floats(tiles, WG_MAX_SPLIT));
+    }
 }
 
 static void check_sweep(const vmc_desc& d, const DescPlan& p) {
@@ -178,10 +172,7 @@ static void dense_grid() {
               CHECK(p.P == plan_num_params_dense(ansatz, n, h, L));
               check_layout(p, n, h);
               check_sweep(d, p);
-              for (long long b : batches) {
-                check_gemm(n, h, p.n_hh + 2, b);
-                check_wgrad(n, h, p.n_hh, b);
-              }
+              for (long long b : batches) check_wgrad(n, h, p.n_hh, p.rbm != 0, b);
             }
           }
   // the limits of include/cgsvmc.h, and what lies one step beyond them

@@ -352,18 +352,7 @@ inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, c
 #define WG_TM 128          // output tile of the batched weight-gradient kernel (k_wgrad, grad.hip)
 #define WG_TN 64
 #define WG_TK 32
-#define WG_MAX_SPLIT 16    // workspace bound
-
-// split-K of the general GEMM (K = number of samples): ~512 samples per split, measured best at
-// K = 4096 (8 splits).  forced > 0: the measurement knob CGS_VMC_SPLITK -- never 1: a single slice would
-// accumulate straight into C and the fixed-order reduction that follows would fold a workspace nobody wrote
-inline int plan_splitk(long long k, int cap, int forced = 0) {
-  if (forced > 0) return forced < 2 ? 2 : (forced < cap ? forced : cap);
-  long long s = k / 512;
-  if (s < 4) s = 4;
-  if (s > cap) s = cap;
-  return (int)s;
-}
+#define WG_MAX_SPLIT 32    // workspace bound
 
 // One problem of the batched weight-gradient launch: C[m_rows (+ ones row)][n_cols] over K samples
 struct WgradShape { int m_rows, n_cols; };
@@ -373,11 +362,13 @@ PLAN_HD inline int plan_wgrad_tiles(int m_rows, int n_cols) {
   return n_cols <= 1 ? 0 : ((m_rows + WG_TM - 1) / WG_TM) * ((n_cols + WG_TN - 1) / WG_TN);
 }
 
-// K slices: as many as fill the CUs once (tiles x slices <= num_cus), each a whole number of WG_TK steps,
-// at least 64 samples per slice
-inline int plan_wgrad_slices(long long total_tiles, long long K, int num_cus) {
+// K slices: as many as fill the CUs once (tiles x slices + the column-sum blocks <= num_cus), each a
+// whole number of WG_TK steps, at least 64 samples per slice.  forced > 0: the measurement knob
+// CGS_VMC_WGRAD_SLICES
+inline int plan_wgrad_slices(long long total_tiles, long long K, int num_cus, int other_blocks = 0, int forced = 0) {
   if (total_tiles <= 0) return 1;
-  long long s = num_cus / total_tiles;
+  long long s = (num_cus - other_blocks) / total_tiles;
+  if (forced > 0) s = forced;
   const long long by_k = (K + 63) / 64;
   if (s > by_k) s = by_k;
   if (s > WG_MAX_SPLIT) s = WG_MAX_SPLIT;
@@ -409,20 +400,12 @@ PLAN_HD inline WgradBlock plan_wgrad_block(int block, int tiles, int slices) {
 }
 inline int plan_wgrad_grid(int tiles, int slices) { return tiles <= 0 ? 0 : 8 * ((slices + 7) / 8) * tiles; }
 
-// the general batched GEMM (64 x 64 tiles; wide path and tests): group g = problem * splitk + split
-PLAN_HD inline WgradBlock plan_gemm_batched_block(int block, int per_group, int n_groups) {
-  WgradBlock b;
-  const int xcd = block & 7, idx = block >> 3;
-  b.slice = xcd + 8 * (idx / per_group);      // the group
-  b.tile = idx % per_group;
-  if (b.slice >= n_groups) b.slice = -1;
-  return b;
-}
+// 64-column blocks of an N = 1 problem (k_in columns + the ones row)
+inline int plan_wgrad_col_blocks(int k_in) { return (k_in + 1 + 63) / 64; }
 
-// floats of the split-K workspace of the dense gradient path: per problem [split][2][(max(N,H)+1) H]
-inline long long plan_gemm_ws_floats(long long n_problems, int split_cap, long long N, long long H) {
-  const long long mmax = N > H ? N : H;
-  return n_problems * split_cap * 2 * (mmax + 1) * H;
+// floats of the partial-tile workspace: [tiles][slices][2][WG_TM * WG_TN + WG_TN]
+inline long long plan_wgrad_ws_floats(long long tiles, int slices) {
+  return tiles * slices * 2 * ((long long)WG_TM * WG_TN + WG_TN);
 }
 
 // ------------------------------------------------------------------------------- stochastic reconfiguration

@@ -111,8 +111,10 @@ struct vmc_ctx {
   bool acts_valid = false;   // act[] hold the activations of psi on the current chains
   std::vector<float*> delta;   // L views [B][Hp] into delta_all: d logit / d z_l
   float* delta_all = nullptr;
-  GemmArgs* d_batch[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // weight-gradient GEMM tables [w = eloc / ratio][parity]
+  void* d_batch[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // weight-gradient problem tables [w = eloc / ratio][parity]
   bool batch_ready[2][2] = {{false, false}, {false, false}};
+  int wg_tiles = 0, wg_cols = 0;   // MFMA tiles / column-sum blocks of the weight-gradient launch (plan.hpp)
+  int* wg_tickets = nullptr;       // [wg_tiles] arrival tickets of the split-K fold, zero between launches
   float *ratio = nullptr, *ones = nullptr;
   float *acc = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad_tmp = nullptr;
   // reset_gradients does not zero `acc` at once: the first dense accumulate after it WRITES its sums
@@ -120,8 +122,7 @@ struct vmc_ctx {
   // materialises the zeros first (acc_zeros)
   bool acc_fresh = false;
   long long adam_t = 0;
-  float* gemm_ws = nullptr;
-  int splitk = 16;           // upper bound (workspace size); see pick_splitk
+  float* gemm_ws = nullptr;  // partial tiles of the weight-gradient launch: plan_wgrad_ws_floats(wg_tiles, WG_MAX_SPLIT)
   int num_cus = 256;
   int sweep_waves = 8;       // waves per sweep workgroup at Hp = 256 (CGS_VMC_SWEEP_WAVES=4|8)
   int sweep_no_w1l = 0;      // CGS_VMC_SWEEP_W1L=0: W1 stays in L2 (smaller LDS footprint)
@@ -306,12 +307,6 @@ long long off_w(const vmc_ctx* c, int l) { return plan_off_w(c->lay, c->H, l); }
 long long off_b(const vmc_ctx* c, int l) { return plan_off_b(c->lay, c->H, l); }   // biases sit right behind their weights
 long long off_wout(const vmc_ctx* c) { return c->lay.off_wout; }
 long long off_bout(const vmc_ctx* c) { return c->lay.off_bout; }
-
-// split-K of the general GEMMs (K = number of samples): plan_splitk; CGS_VMC_SPLITK is a measurement knob
-int pick_splitk(const vmc_ctx* c, long long k) {
-  static const int forced = getenv("CGS_VMC_SPLITK") ? atoi(getenv("CGS_VMC_SPLITK")) : 0;
-  return plan_splitk(k, c->splitk, forced);
-}
 
 int ensure_packed(vmc_ctx* c, int which) {
   ParamSet& p = c->ps[which];
@@ -744,7 +739,13 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(dalloc(&c->delta_all, L * B * Hp));
   CA(hipMemsetAsync(c->delta_all, 0, L * B * Hp * sizeof(float), c->stream));
   for (int l = 0; l < L; ++l) c->delta[l] = c->delta_all + l * B * Hp;
-  for (int i = 0; i < 4; ++i) CA(dalloc(&c->d_batch[i / 2][i % 2], L + 1));
+  for (int i = 0; i < 4; ++i) CA(hipMalloc(&c->d_batch[i / 2][i % 2], (size_t)(L + 1) * wgrad_problem_bytes()));
+  {  // weight-gradient launch: tiles of the layers with a matrix output, 64-column blocks of the N = 1 layer
+    c->wg_tiles = plan_wgrad_tiles((int)N, c->H) + (int)NH * plan_wgrad_tiles(c->H, c->H);
+    c->wg_cols = plan_wgrad_col_blocks(rbm ? (int)N : c->H);
+    CA(dalloc(&c->wg_tickets, c->wg_tiles > 0 ? c->wg_tiles : 1));
+    CA(hipMemsetAsync(c->wg_tickets, 0, (size_t)(c->wg_tiles > 0 ? c->wg_tiles : 1) * sizeof(int), c->stream));
+  }
   CA(dalloc(&c->ratio, B)); CA(dalloc(&c->ones, B)); CA(dalloc(&c->oscale, B));
   CA(launch_fill(c->stream, c->ones, 1.f, B));
   CA(launch_fill(c->stream, c->oscale, 1.f, B));
@@ -758,7 +759,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(hipMemsetAsync(c->acc, 0, (2 * P + 8) * sizeof(float), c->stream));
   CA(hipMemsetAsync(c->adam_m, 0, P * sizeof(float), c->stream));
   CA(hipMemsetAsync(c->adam_v, 0, P * sizeof(float), c->stream));
-  CA(dalloc(&c->gemm_ws, plan_gemm_ws_floats(L + 1, c->splitk, N, c->H)));
+  CA(dalloc(&c->gemm_ws, plan_wgrad_ws_floats(c->wg_tiles, WG_MAX_SPLIT)));
   CA(dalloc(&c->d_accepted, 1)); CA(dalloc(&c->d_sum, 1)); CA(dalloc(&c->d_max, 1));
   CA(dalloc(&c->inj_up, B)); CA(dalloc(&c->inj_dn, B)); CA(dalloc(&c->inj_u, B));
   CA(dalloc(&c->acc_mask, B));
@@ -822,7 +823,7 @@ void vmc_destroy(vmc_ctx* c) {
   for (int* q : {c->wide_iup, c->wide_idn}) if (q) hipFree(q);
   void* ptrs[] = {c->configs, c->configs_alt, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
-                  c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->d_accepted, c->d_sum,
+                  c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->wg_tickets, c->d_accepted, c->d_sum,
                   c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->tmp_on, c->tmp_rowinfo, c->rowinfo_id, c->bond_dummy, c->inj_up, c->inj_dn, c->inj_u,
                   c->acc_mask};
   for (void* q : ptrs) if (q) hipFree(q);
@@ -1303,34 +1304,39 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e,
   } else
   HIPCHK(c, launch_backprop16(c->stream, c->act_all, c->delta_all, p.p16t, p.woutp, B, Hp, NH, c->rbm, c->hact,
                               c->dact_all, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr));
-  // Every weight-gradient GEMM is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows 0..K_in-1
-  // give dW, the implicit ones row gives db (b_l sits right behind w_l in theta), the unscaled
-  // product goes to g1 and the w-scaled one to g2.  All NH+2 of them run as ONE batched launch
-  // (+ one reduction launch); the argument table is built once per weight vector `w`.
+  // Every weight gradient is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows 0..K_in-1 give dW, the
+  // implicit ones row gives db (b_l sits right behind w_l in theta), the unscaled product goes to g1 and
+  // the w-scaled one to g2.  All NH+2 of them, the N = 1 column sums and the scalar accumulators run as
+  // ONE launch (k_wgrad); the problem table is built once per weight vector `w`.
   const int slot = (w == c->ratio) ? 1 : 0, par = c->parity;
   if (!c->batch_ready[slot][par]) {
-    std::vector<GemmArgs> tab;
-    const long long ws_stride = (long long)c->splitk * 2 * ((N > H ? N : H) + 1) * H;
-    auto add = [&](const float* a, long long a_ld, int k_in, const float* delta, long long sbk,
-                   long long sbn, int n_out, long long off) {
-      GemmArgs g; memset(&g, 0, sizeof(g));
-      g.A = a; g.sam = 1; g.sak = a_ld; g.M = k_in + 1; g.ones_row = 1;
-      g.B = delta; g.sbk = sbk; g.sbn = sbn; g.kscale = w; g.dual = 1;
-      g.N = n_out; g.K = B; g.C = g1 + off; g.C2 = g2 + off; g.ldc = n_out; g.epilogue = 3;
-      g.splitk = pick_splitk(c, B); g.workspace = c->gemm_ws + (long long)tab.size() * ws_stride;
-      tab.push_back(g);
+    std::vector<unsigned char> tab((size_t)(NH + 2) * wgrad_problem_bytes());
+    int n = 0, tile0 = 0;
+    auto add = [&](const float* a, long long a_ld, int k_in, const float* delta, long long ldd, int n_out, long long off) {
+      wgrad_fill_problem(tab.data(), n++, a, a_ld, delta, ldd, off, k_in, n_out, tile0, 0);
+      tile0 += plan_wgrad_tiles(k_in, n_out);
     };
     if (c->rbm)   // onsite layer: d logit / d w_on = x, d logit / d b_on = 1
-      add(c->configs, N, N, c->ones, 1, 0, 1, c->lay.off_won);
+      add(c->configs, N, N, c->ones, 1, 1, c->lay.off_won);
     else          // output layer: d logit / d w_out = a_L, d logit / d b_out = 1
-      add(c->act[NH], Hp, H, c->oscale, 1, 0, 1, off_wout(c));   // oscale == 1 for the exp output
-    for (int l = NH; l > 0; --l) add(c->act[l - 1], Hp, H, c->delta[l], Hp, 1, H, off_w(c, l));
-    add(c->configs, N, N, c->delta[0], Hp, 1, H, off_w(c, 0));
-    HIPCHK(c, hipMemcpy(c->d_batch[slot][par], tab.data(), tab.size() * sizeof(GemmArgs), hipMemcpyHostToDevice));
+      add(c->act[NH], Hp, H, c->oscale, 1, 1, off_wout(c));   // oscale == 1 for the exp output
+    for (int l = NH; l > 0; --l) add(c->act[l - 1], Hp, H, c->delta[l], Hp, H, off_w(c, l));
+    add(c->configs, N, N, c->delta[0], Hp, H, off_w(c, 0));
+    if (tile0 != c->wg_tiles) return fail(c, VMC_ERR_STATE, "weight-gradient tile count does not match the plan");
+    HIPCHK(c, hipMemcpy(c->d_batch[slot][par], tab.data(), tab.size(), hipMemcpyHostToDevice));
     c->batch_ready[slot][par] = true;
   }
-  HIPCHK(c, launch_gemm_batched(c->stream, c->d_batch[slot][par], NH + 2, N > H ? N : H, H, pick_splitk(c, B), true, fresh,
-                                e, mode == 1 ? c->ratio : nullptr, c->acc + 2 * c->P, B, mode));
+  {
+    static const int forced = getenv("CGS_VMC_WGRAD_SLICES") ? atoi(getenv("CGS_VMC_WGRAD_SLICES")) : 0;   // measurement knob
+    WgradLaunch L;
+    memset((void*)&L, 0, sizeof(L));
+    L.dev_problems = c->d_batch[slot][par]; L.n_prob = NH + 2;
+    L.tiles = c->wg_tiles; L.col_blocks = c->wg_cols;
+    L.slices = plan_wgrad_slices(c->wg_tiles, B, c->num_cus, c->wg_cols + 1, forced);
+    L.K = B; L.w = w; L.g1 = g1; L.g2 = g2; L.ws = c->gemm_ws; L.tickets = c->wg_tickets; L.fresh = fresh;
+    L.sc_eloc = e; L.sc_ratio = mode == 1 ? c->ratio : nullptr; L.sc_out = c->acc + 2 * c->P; L.sc_B = B; L.sc_mode = mode;
+    HIPCHK(c, launch_wgrad(c->stream, L));
+  }
   *scalars_done = true;
   return VMC_OK;
 }
