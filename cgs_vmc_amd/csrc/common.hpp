@@ -267,12 +267,12 @@ struct GemmArgs {
 };
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
 // All weight gradients of one accumulate call -- [a_{l-1} | 1]^T [delta_l | w (.) delta_l] of every
-// layer, the N = 1 column sums and the scalar accumulators -- in ONE launch (k_wgrad, grad.hip; tiles,
+// layer and the scalar accumulators -- in ONE launch (k_wgrad, grad.hip; tiles,
 // slices and block order: plan.hpp).  The problem table lives in device memory and is built once per
 // weight vector with wgrad_fill_problem into a host buffer of n x wgrad_problem_bytes().
 struct WgradLaunch {
   const void* dev_problems; int n_prob;
-  int tiles, slices, col_blocks;       // plan_wgrad_tiles summed, plan_wgrad_slices, 64-column blocks of the N = 1 problems
+  int tiles, slices;                   // plan_wgrad_total_tiles, plan_wgrad_slices
   int K;                               // samples
   const float* w;                      // [K] weights of the second sum
   float* g1; float* g2;                // accumulators (theta layout)
@@ -282,7 +282,7 @@ struct WgradLaunch {
 };
 size_t wgrad_problem_bytes();
 void wgrad_fill_problem(void* dst, int index, const float* A, long long lda, const float* D, long long ldd,
-                        long long c_off, int k_in, int n_out, int tile0, int col0);
+                        long long c_off, int k_in, int n_out, int tile0);
 hipError_t launch_wgrad(hipStream_t s, const WgradLaunch& L);
 hipError_t launch_act_copy(hipStream_t s, const float* z, float* a, float* dact, long long n, int act);
 hipError_t launch_out_scale(hipStream_t s, const float* x, float* oscale, int B, int oact);

@@ -3,6 +3,11 @@
 // forward / back-prop (k_backprop16, mlp.hip) / weight-gradient GEMM chain on fp32 MFMA, plus the accumulator,
 // ratio and Adam element-wise kernels.  All reductions are fixed-order (no float atomics).
 #include "common.hpp"
+#ifdef VMC_WGRAD_STAMPS
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+#endif
 
 // ----------------------------------------------------------------------------------- GEMM
 // C[M,N] = A[M,K] B[K,N] with arbitrary element strides on fp32 MFMA.
@@ -273,297 +278,475 @@ __device__ __forceinline__ void scalar_accum_body(const ScalarJob& j, bool fresh
 // Every weight gradient of the dense ansatz types is [a_{l-1} | 1]^T [delta_l | w (.) delta_l] over the
 // B samples of the batch (training.py:545-547): rows 0 .. k_in-1 give dW, the implicit ones row gives
 // db (b_l sits right behind w_l in theta); the unscaled product goes to g1, the w-scaled one to g2.
-// ALL layers run as ONE launch of three kinds of workgroup (block-uniform dispatch on the block id):
-//  * MFMA tiles: a 128 x 64 output tile of one layer over one K slice of the samples.  4 waves as 2 x 2,
-//    each 64 x 32 = two 32x32x2 accumulators per product (four MFMAs per four LDS operand reads); the
-//    operands of k-tile t+1 travel global -> registers while tile t is multiplied from LDS and go to the
-//    OTHER LDS buffer afterwards: one barrier per 32 samples.  Slices are sized so that tiles x slices
+// ALL layers run as ONE launch of two kinds of workgroup (block-uniform dispatch on the block id):
+//  * MFMA tiles: a 64 x 64 output tile of one layer over one K slice of the samples.  4 waves as 2 x 2,
+//    each one 32x32x2 accumulator per product; the operands of k-tile t+1 travel global -> registers
+//    while tile t is multiplied from LDS and go to the OTHER LDS buffer afterwards: one barrier per 32
+//    samples.  (128 x 64 tiles halve the operand traffic per flop but double the partial a last arriver
+//    has to read from other XCDs -- 62-70 GB/s per workgroup, MI355X_MICROARCH.md -- which is the
+//    critical path of the tail: 64 x 64 with half as many slices.)  Slices are sized so that tiles x slices
 //    fills the CUs once (plan_wgrad_slices); slice s lives on XCD s % 8, whose L2 then fetches that
 //    slice's operand rows once (plan_wgrad_block).  The partial tile goes to the workspace in
 //    accumulator order (coalesced), the workgroup takes a ticket, and the LAST one to arrive folds the
 //    slices 0 .. S-1 of its tile in that fixed order into the accumulators -- no reduction launch, no
 //    float atomics, the same bits whoever arrives last.
-//  * column sums: the N = 1 problems (output layer: d logit / d w_out = a_L; RBM onsite layer) are
-//    [a | 1]^T s with a per-sample scalar s -- VALU work, 64 columns per workgroup over all samples.
+//    The N = 1 problems (output layer: d logit / d w_out = a_L; RBM onsite layer) are one-column tiles.
 //  * one workgroup for the scalar accumulators (sum E, counts) of the same accumulate call.
 struct WgradProblem {
   const float* A; long long lda;      // A(b, m) = A[b * lda + m], m < k_in (m == k_in: the ones row)
   const float* D; long long ldd;      // delta(b, n) = D[b * ldd + n], n < n_out
   long long c_off;                    // offset of C[(k_in + 1)][n_out] in g1 / g2 (theta layout: w then b)
   int k_in, n_out;
-  int tile0, tiles_n;                 // first MFMA tile of this problem, tiles along n (n_out > 1)
-  int col0;                           // first column-sum block of this problem (n_out == 1)
+  int tile0, tiles_n;                 // first MFMA tile of this problem, tiles along n
 };
 
 struct WgradArgs {
   const WgradProblem* prob;           // device table
   int n_prob;
   int tiles, slices, kchunk;          // MFMA tiles over all problems, K slices, samples per slice
-  int mfma_blocks, col_blocks;        // block id ranges: [0, mfma_blocks) tiles, then column sums, then the scalars
+  int mfma_blocks;                    // block ids [0, mfma_blocks): tiles; the next one: the scalars
   int K;                              // samples
   const float* w;                     // [K] per-sample weight of the second sum
   float* g1; float* g2;
-  float* ws;                          // [tiles][slices][2][WG_TM * WG_TN + WG_TN] partial tiles + ones rows
+  float* ws;                          // [tiles][slices][2 x WG_TM x WG_TN + 2 x WG_TN] partial tiles + ones rows
   int* tickets;                       // [tiles], zero between launches
   int fresh;                          // 1: the accumulators hold no sum yet (store instead of add)
+  unsigned long long* stamps;         // diagnostic build (-DVMC_WGRAD_STAMPS): [blocks][8] wall-clock stamps (100 MHz)
   ScalarJob job;
 };
 
-#define WG_LDA (WG_TM + 4)
-#define WG_LDB (WG_TN + 4)
-#define WG_STAGE (WG_TK * WG_LDA + 2 * WG_TK * WG_LDB)      // floats of one LDS stage: A, B, w (.) B
-#define WG_PART (WG_TM * WG_TN + WG_TN)                      // floats of one partial (tile + ones row)
+// LDS image of one k-tile: A and delta TRANSPOSED, [m or n][position of k], row stride WG_LDT floats; the
+// 32 samples of a tile sit at position p(k) = 16 (k & 1) + (k >> 1), so that the 16 operands an MFMA lane
+// needs over the tile (32x32x2: lane (row, half h) takes k = 2 q + h) are 16 CONSECUTIVE floats = four
+// ds_read_b128 instead of sixteen ds_read_b32 (a single wave per SIMD gets a fifth of the ds_read_b32
+// rate: MI355X_MICROARCH.md, LDS).  WG_LDT = 36: rows stay 16-byte aligned and the 16 lanes of a
+// ds_read_b128 group start on 16 distinct bank quads (36 / 4 = 9 is odd).
+#define WG_LDT 36
+#define WG_STAGE ((WG_TM + WG_TN) * WG_LDT + WG_TK)          // floats of one LDS stage: A^T, delta^T, w
+#define WG_QUADS 8                                           // accumulator quads per thread (2 products x 16 / 4)
+#define WG_PART (WG_TM * WG_TN * 2 + 2 * WG_TN)              // floats of one partial: both products' tiles + ones rows
 
-struct WgradRegs { f32x4 a[4]; f32x4 b[2]; float w[2]; };
-
-// operands of the k-tile starting at sample k0 (all loads unconditional and clamped: an out-of-range
-// row or column is read somewhere valid and zeroed, so that vmcnt is counted exactly)
-__device__ __forceinline__ void wgrad_load(const WgradProblem& P, const float* __restrict__ w, int m0, int n0,
-                                           int k0, int kend, int tid, bool vec_a, bool vec_d, WgradRegs& r) {
-  const int am = m0 + 4 * (tid & 31);
+// Hand-over of the partial tiles between workgroups (other CUs, other XCDs: their L2s are not coherent).
+// MI355X_MICROARCH.md "inter-workgroup visibility", the measured row "ONE lane of each storing workgroup
+// adds to ONE counter; the workgroup whose add came last loads": EVERY store of the handed-over bytes is a
+// 16-byte sc1 (write-through) store, every storing wave drains them (s_waitcnt vmcnt(0)) before the
+// workgroup barrier behind which lane 0 takes the ticket with an agent-scope atomic add; the last arriver
+// loads EVERY byte with 16-byte sc1 loads behind a barrier its ticket-taking wave has joined.  One
+// workgroup per CU (the launch asks for more than half a CU's LDS).  A release fence instead
+// (buffer_wbl2) costs microseconds per wave: the first version of this kernel took 250 us that way.
+typedef __attribute__((address_space(1))) f32x4* wg_gf4_p;
+__device__ __forceinline__ void wg_store_sc1(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"((wg_gf4_p)p), "v"(v) : "memory");
+}
+// quads of up to 8 slices z0 .. z0 + 7 (clamped to the last slice: unconditional loads), all in flight at once
+__device__ __forceinline__ void wg_load8_sc1(const float* p0, long long stride, int z0, int S, f32x4 (&v)[8]) {
+  wg_gf4_p q[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = k0 + (tid >> 5) + 8 * i;
-    const int kc = k < kend ? k : kend - 1;
-    const float* p = P.A + (long long)kc * P.lda;
-    f32x4 v;
-    if (vec_a && am + 3 < P.k_in) {
-      v = *(const f32x4*)(p + am);
-    } else {
+  for (int j = 0; j < 8; ++j) q[j] = (wg_gf4_p)(p0 + (long long)min(z0 + j, S - 1) * stride);
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\t"
+      "global_load_dwordx4 %1, %9, off sc1\n\t"
+      "global_load_dwordx4 %2, %10, off sc1\n\t"
+      "global_load_dwordx4 %3, %11, off sc1\n\t"
+      "global_load_dwordx4 %4, %12, off sc1\n\t"
+      "global_load_dwordx4 %5, %13, off sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc1\n\t"
+      "global_load_dwordx4 %7, %15, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7])
+      : "memory");
+}
+// sum over the slices 0 .. S-1, in that order, of one quad
+__device__ __forceinline__ f32x4 wg_fold_quad(const float* p0, long long stride, int S) {
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  for (int z0 = 0; z0 < S; z0 += 8) {
+    f32x4 v[8];
+    wg_load8_sc1(p0, stride, z0, S, v);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = am + j < P.k_in ? p[am + j] : 0.f;
-    }
-    r.a[i] = k < kend ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 8; ++j)
+      if (z0 + j < S) sum += v[j];
   }
-  const int bn = n0 + 4 * (tid & 15);
+  return sum;
+}
+
+// the same for two quads at once: sixteen loads in flight
+__device__ __forceinline__ void wg_fold_quads2(const float* pa, const float* pb, long long stride, int S, f32x4& sa, f32x4& sb) {
+  sa = f32x4{0.f, 0.f, 0.f, 0.f};
+  sb = sa;
+  for (int z0 = 0; z0 < S; z0 += 8) {
+    wg_gf4_p qa[8], qb[8];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int k = k0 + (tid >> 4) + 16 * i;
-    const int kc = k < kend ? k : kend - 1;
-    const float* p = P.D + (long long)kc * P.ldd;
-    f32x4 v;
-    if (vec_d && bn + 3 < P.n_out) {
-      v = *(const f32x4*)(p + bn);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = bn + j < P.n_out ? p[bn + j] : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      const long long o = (long long)min(z0 + j, S - 1) * stride;
+      qa[j] = (wg_gf4_p)(pa + o);
+      qb[j] = (wg_gf4_p)(pb + o);
     }
-    r.b[i] = k < kend ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-    r.w[i] = w[kc];
+    f32x4 va[8], vb[8];
+    asm volatile(
+        "global_load_dwordx4 %0, %16, off sc1\n\t"
+        "global_load_dwordx4 %1, %17, off sc1\n\t"
+        "global_load_dwordx4 %2, %18, off sc1\n\t"
+        "global_load_dwordx4 %3, %19, off sc1\n\t"
+        "global_load_dwordx4 %4, %20, off sc1\n\t"
+        "global_load_dwordx4 %5, %21, off sc1\n\t"
+        "global_load_dwordx4 %6, %22, off sc1\n\t"
+        "global_load_dwordx4 %7, %23, off sc1\n\t"
+        "global_load_dwordx4 %8, %24, off sc1\n\t"
+        "global_load_dwordx4 %9, %25, off sc1\n\t"
+        "global_load_dwordx4 %10, %26, off sc1\n\t"
+        "global_load_dwordx4 %11, %27, off sc1\n\t"
+        "global_load_dwordx4 %12, %28, off sc1\n\t"
+        "global_load_dwordx4 %13, %29, off sc1\n\t"
+        "global_load_dwordx4 %14, %30, off sc1\n\t"
+        "global_load_dwordx4 %15, %31, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(va[0]), "=&v"(va[1]), "=&v"(va[2]), "=&v"(va[3]), "=&v"(va[4]), "=&v"(va[5]), "=&v"(va[6]), "=&v"(va[7]),
+          "=&v"(vb[0]), "=&v"(vb[1]), "=&v"(vb[2]), "=&v"(vb[3]), "=&v"(vb[4]), "=&v"(vb[5]), "=&v"(vb[6]), "=&v"(vb[7])
+        : "v"(qa[0]), "v"(qa[1]), "v"(qa[2]), "v"(qa[3]), "v"(qa[4]), "v"(qa[5]), "v"(qa[6]), "v"(qa[7]),
+          "v"(qb[0]), "v"(qb[1]), "v"(qb[2]), "v"(qb[3]), "v"(qb[4]), "v"(qb[5]), "v"(qb[6]), "v"(qb[7])
+        : "memory");
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (z0 + j < S) { sa += va[j]; sb += vb[j]; }
   }
 }
 
-__device__ __forceinline__ void wgrad_stage(float* st, int tid, const WgradRegs& r) {
-  float* As = st;
-  float* Bs = st + WG_TK * WG_LDA;
-  float* Bs2 = Bs + WG_TK * WG_LDB;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) *(f32x4*)(As + ((tid >> 5) + 8 * i) * WG_LDA + 4 * (tid & 31)) = r.a[i];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int o = ((tid >> 4) + 16 * i) * WG_LDB + 4 * (tid & 15);
-    *(f32x4*)(Bs + o) = r.b[i];
-    *(f32x4*)(Bs2 + o) = r.b[i] * r.w[i];
-  }
-}
+struct WgradRegs { float a[8]; float b[8]; float w; };
 
-// element i (0 .. 31) of a thread's accumulators: i = 16 blk + r -> (m, n) inside the tile
-__device__ __forceinline__ void wgrad_mn(int tid, int i, int& m, int& n) {
+typedef const __attribute__((address_space(1))) float* wg_gfc_p;
+
+// Loading the operands of a k-tile (the lambdas of wgrad_tile) is BRANCH-FREE and in the global address
+// space: a load under a run-time branch makes the compiler drain the whole memory queue at the join (the
+// first version -- `if (aligned) vector load else scalar loads` on flat pointers -- serialised five round
+// trips per k-tile behind `s_waitcnt vmcnt(0)`: 137 us per launch).  Out-of-range samples, rows and
+// columns are read from a clamped, valid address and zeroed by a select WHEN THEY GO TO LDS: a select at
+// load time lets the compiler wait for every load of the ring at once.  Lane l of wave w takes row m0 + l
+// of A (column n0 + l of delta) at the samples 4 c + e of the k-quads c = w, w + 4: 64 consecutive floats
+// per load instruction, any stride, any alignment.
+// accumulator register r (0 .. 15) of a thread -> (m, n) inside the 64 x 64 tile (32x32x2 MFMA layout)
+__device__ __forceinline__ void wgrad_mn(int tid, int r, int& m, int& n) {
   const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int blk = i >> 4, r = i & 15;
-  m = wm * 64 + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
   n = wn * 32 + (lane & 31);
 }
 
-__device__ __forceinline__ void wgrad_tile(const WgradArgs& a, int slice, int tile, float* smem) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  // tile -> problem (block-uniform; a handful of problems)
-  int pi = 0;
-  for (int i = 0; i < a.n_prob; ++i)
-    if (a.prob[i].n_out > 1 && tile >= a.prob[i].tile0) pi = i;      // tile0 ascends with the problem index
-  const WgradProblem P = a.prob[pi];
+#ifdef VMC_WGRAD_STAMPS
+#define WG_STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[(long long)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define WG_STAMP(i) do { } while (0)
+#endif
+
+// FAST: every k-tile of the slice is full (the slice holds a whole number of 32-sample tiles; all slices
+// but possibly the last do): no per-element clamping, ONE scalar base per matrix and tile.
+template <bool FAST>
+__device__ __forceinline__ void wgrad_tile(const WgradArgs& a, const WgradProblem& P, int slice, int tile, float* smem) {
+  // Two GROUPS of four waves share the tile: group g takes the first / second half of the slice's k-tiles
+  // with its own LDS stages and accumulators, group 1's sums are added to group 0's at the end (always in
+  // that order).  Two waves per SIMD with the same instruction stream fill each other's gaps -- LDS read
+  // latency after every barrier, the VALU / LDS / VMEM pieces between the MFMAs: with one wave per SIMD a
+  // k-tile took 3,076 cycles for 2,048 cycles of MFMAs (s_memtime stamps, tools/wgrad_stamps.sh).
+  const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  smem += grp * 3 * WG_STAGE;
+  WG_STAMP(0);
   const int lt = tile - P.tile0, tm = lt / P.tiles_n, tn = lt % P.tiles_n;
   const int m0 = tm * WG_TM, n0 = tn * WG_TN;
-  const int kbeg = slice * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
-  const int T = (kend - kbeg + WG_TK - 1) / WG_TK;             // >= 1: no slice is empty (plan_wgrad_slices)
-  const bool vec_a = (P.lda & 3) == 0 && (((size_t)P.A) & 15) == 0;
-  const bool vec_d = (P.ldd & 3) == 0 && (((size_t)P.D) & 15) == 0;
-  const bool ones = tm == 0;                                   // the m-tile-0 workgroups also sum the columns of B
+  const int s_kbeg = slice * a.kchunk, s_kend = min(a.K, s_kbeg + a.kchunk);
+  const int s_T = (s_kend - s_kbeg + WG_TK - 1) / WG_TK;       // >= 1: no slice is empty (plan_wgrad_slices)
+  const int T0 = (s_T + 1) / 2;                                // k-tiles of group 0; group 1: the rest (maybe none)
+  const bool idle = grp == 1 && s_T - T0 == 0;                 // nothing to do: reads the slice's first tile, stages zeros
+  const int kbeg = (grp == 0 || idle) ? s_kbeg : s_kbeg + T0 * WG_TK;
+  const int kend = grp == 0 ? min(s_kend, s_kbeg + T0 * WG_TK) : s_kend;
+  const int T = (kend - kbeg + WG_TK - 1) / WG_TK;             // >= 1
+  const int T_loop = T0;                                       // both groups make the same number of barriers
+  const bool ones = tm == 0;                                   // the m-tile-0 workgroups own the ones row (column sums of delta)
+  const bool sums = ones && __builtin_amdgcn_readfirstlane(wm) == 0;   // ... and their waves 0, 1 hold every column of delta once
 
-  f32x16 acc[2], acc2[2];
+  f32x16 acc, acc2;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; acc2[0][r] = 0.f; acc2[1][r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
   float cs = 0.f, cs2 = 0.f;
 
-  WgradRegs regs;
-  wgrad_load(P, a.w, m0, n0, kbeg, kend, tid, vec_a, vec_d, regs);
-  wgrad_stage(smem, tid, regs);
-  __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    const float* st = smem + (t & 1) * WG_STAGE;
-    const float* As = st;
-    const float* Bs = st + WG_TK * WG_LDA;
-    const float* Bs2 = Bs + WG_TK * WG_LDB;
-    // tile t + 1 travels to registers under the MFMAs of tile t (clamped: the last iteration re-reads its own)
-    wgrad_load(P, a.w, m0, n0, kbeg + min(t + 1, T - 1) * WG_TK, kend, tid, vec_a, vec_d, regs);
-    if (ones) {       // wave w adds the k rows 8w .. 8w+7 of the columns it sees: 16 LDS reads per k-tile
+  // Three k-tiles of operands are in flight global -> registers (a ring of three register sets) while the
+  // tile before them sits in LDS and the one before that is multiplied: with ONE workgroup per CU (one
+  // wave per SIMD) nothing else hides the 1 - 2 us a load takes under load; one tile of look-ahead
+  // (0.85 us of MFMAs) left every iteration waiting for memory (56 us per launch against 22 of MFMAs).
+  // The loop is unrolled three times so that ring slot and LDS stage are compile-time: straight-line
+  // code, every load unconditional (tiles past the end of the slice are clamped reads that stage
+  // zeros), so vmcnt is counted exactly and nothing drains the queue.
+  const int h16 = (lane >> 5) * 16;
+  WgradRegs R0, R1, R2;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const bool m_in = m0 + lane < P.k_in, n_in = n0 + lane < P.n_out;
+  // Addresses: a SCALAR row base (the sample index of a load is wave-uniform: SALU multiplies) plus a
+  // 32-bit lane offset that never changes -- `global_load_dword v, v_off, s[base]`.  Per-lane 64-bit
+  // products (two quarter-rate v_mul_lo_u32 + v_mad_u64_u32 per load, seventeen loads per k-tile) cost
+  // 1,600 VALU cycles per 2,048-cycle tile, all of them paid in matrix time.
+  const int swave = __builtin_amdgcn_readfirstlane(wave);
+  const int a_off = m_in ? m0 + lane : 0, d_off = n_in ? n0 + lane : 0;
+  wg_gfc_p pw = (wg_gfc_p)a.w;
+  typedef const __attribute__((address_space(1))) char* wg_gcc_p;
+  // FAST: byte offsets of the eight elements of a register set from the tile's scalar base -- loop
+  // invariant, 32 bits: one `global_load_dword v, v_off, s[base:base+1]` per element and nothing else.
+  // (The general form below computes a clamped row per element: 14 SALU instructions per load, 240 per
+  // k-tile; with one wave per SIMD the kernel was bound by instruction ISSUE -- ~430 instructions per
+  // 2,048-cycle tile at 8 cycles each -- not by the matrix pipe: 3,430 cycles per tile measured.)
+  unsigned avo[8], dvo[8];
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        cs += Bs[(8 * wave + kk) * WG_LDB + lane];
-        cs2 += Bs2[(8 * wave + kk) * WG_LDB + lane];
+  for (int j = 0; j < 8; ++j) {
+    const int row = 16 * (j >> 2) + (j & 3);
+    avo[j] = 4u * (unsigned)(a_off + row * (int)P.lda);
+    dvo[j] = 4u * (unsigned)(d_off + row * (int)P.ldd);
+  }
+  const unsigned wvo = 4u * (unsigned)(tid & 31);
+  // scalar bases of tile tt (FAST): tiles past the end re-read the last one (their values are zeroed)
+  wg_gcc_p sA = nullptr, sD = nullptr, sW = nullptr;
+  auto bases = [&](int tt) {
+    const int tc = min(tt, T - 1);
+    const long long k0 = kbeg + tc * WG_TK;
+    sA = (wg_gcc_p)P.A + 4 * (k0 + 4 * swave) * P.lda;
+    sD = (wg_gcc_p)P.D + 4 * (k0 + 4 * swave) * P.ldd;
+    sW = (wg_gcc_p)a.w + 4 * k0;
+  };
+  // element j (0 .. 7) of a register set: sample 4 (wave + 4 (j >> 2)) + (j & 3) of its tile
+  auto load1 = [&](WgradRegs& r, int tt, int j) {
+    if (FAST) {
+      r.a[j] = *(wg_gfc_p)(sA + avo[j]);
+      r.b[j] = *(wg_gfc_p)(sD + dvo[j]);
+      return;
+    }
+    const int k = kbeg + tt * WG_TK + 4 * (swave + 4 * (j >> 2)) + (j & 3);
+    const int kc = k < kend ? k : kend - 1;
+    wg_gfc_p ra = (wg_gfc_p)P.A + (long long)kc * P.lda;
+    wg_gfc_p rd = (wg_gfc_p)P.D + (long long)kc * P.ldd;
+    r.a[j] = ra[a_off];
+    r.b[j] = rd[d_off];
+  };
+  auto loadw = [&](WgradRegs& r, int tt) {
+    if (FAST) { r.w = *(wg_gfc_p)(sW + wvo); return; }
+    const int k0 = kbeg + tt * WG_TK;                       // scalar; at least one sample of the slice lies at or before it
+    const int kk = min(tid & 31, kend - 1 - min(k0, kend - 1));
+    r.w = (pw + min(k0, kend - 1))[kk];
+  };
+  // store j (0 .. 7) of a register set: matrix (j >> 2), k-quad wave + 4 ((j >> 1) & 1), parity (j & 1):
+  // samples 4c + parity and 4c + parity + 2 go to positions 16 parity + 2c, + 1
+  auto store1 = [&](float* st, const WgradRegs& r, int tt, int j) {
+    const int x = j >> 2, i = (j >> 1) & 1, par = j & 1, c = swave + 4 * i;
+    const int k = kbeg + tt * WG_TK + 4 * c + par;
+    const bool in = x ? n_in : m_in;
+    const float* v = x ? r.b : r.a;
+    const bool l0 = !idle && (FAST ? tt < T : k < kend), l1 = !idle && (FAST ? tt < T : k + 2 < kend);
+    const float v0 = (l0 && in) ? v[4 * i + par] : 0.f;
+    const float v1 = (l1 && in) ? v[4 * i + par + 2] : 0.f;
+    *(f32x2*)(st + x * WG_TM * WG_LDT + lane * WG_LDT + 16 * par + 2 * c) = f32x2{v0, v1};
+  };
+  // every thread writes w (eight of them the same value to each of the 32 positions): under `if (tid < 32)`
+  // the compiler sinks the load of w into the branch and drains the whole memory queue behind it
+  auto storew = [&](float* st, const WgradRegs& r, int tt) {
+    const bool live = !idle && (FAST ? tt < T : kbeg + tt * WG_TK + (tid & 31) < kend);
+    st[(WG_TM + WG_TN) * WG_LDT + 16 * (tid & 1) + ((tid & 31) >> 1)] = live ? r.w : 0.f;
+  };
+  // One k-tile: 32 MFMAs from stage `cur`; BETWEEN them, one piece per MFMA pair, the register set `r`
+  // (tile tt + 1) goes to stage `nxt` (pieces 0 .. 8) and is then refilled with tile tt + 4 (pieces
+  // 8 .. 15).  With one wave per SIMD an instruction only overlaps an MFMA if it is issued right behind
+  // it: compute, THEN stage, THEN load cost 13.7 + 7 + 26 us per launch, each in full
+  // (CGS_VMC_WGRAD_DBG experiments).  sched_barrier pins the interleaving.
+  auto step = [&](const float* cur, float* nxt, WgradRegs& r, int tt) {
+    const f32x4* At = (const f32x4*)(cur + (wm * 32 + (lane & 31)) * WG_LDT + h16);
+    const f32x4* Dt = (const f32x4*)(cur + WG_TM * WG_LDT + (wn * 32 + (lane & 31)) * WG_LDT + h16);
+    const f32x4* Wt = (const f32x4*)(cur + (WG_TM + WG_TN) * WG_LDT + h16);
+    f32x4 av[4], bv[4], wv[4], b2v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { av[q] = At[q]; bv[q] = Dt[q]; wv[q] = Wt[q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b2v[q] = bv[q] * wv[q];
+    if (FAST) bases(tt + 4);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], bv[q >> 2][q & 3], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], b2v[q >> 2][q & 3], acc2, 0, 0, 0);
+      if (q < 8) store1(nxt, r, tt + 1, q);
+      if (q == 8) storew(nxt, r, tt + 1);
+      if (q >= 8) load1(r, tt + 4, q - 8);
+      if (q == 15) loadw(r, tt + 4);
+      if (sums) {     // block- and wave-uniform; fixed order; one plain v_add each (left to itself the compiler
+                      // SLP-packs them behind v_mov pairs: three VALU instructions per add, beside MFMAs)
+        asm volatile("v_add_f32 %0, %1, %0" : "+v"(cs) : "v"(bv[q >> 2][q & 3]));
+        asm volatile("v_add_f32 %0, %1, %0" : "+v"(cs2) : "v"(b2v[q >> 2][q & 3]));
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+  };
+  // Three k-tiles of operands are in flight global -> registers (a ring of three register sets) while the
+  // tile before them sits in LDS and the one before that is multiplied.  The loop is unrolled three times
+  // so that ring slot and LDS stage are compile-time: straight-line code, every load unconditional (tiles
+  // past the end of the slice are clamped reads that stage zeros), so vmcnt is counted exactly.
+  float* L0 = smem;
+  float* L1 = smem + WG_STAGE;
+  float* L2 = smem + 2 * WG_STAGE;
+  auto load_all = [&](WgradRegs& r, int tt) {
+    if (FAST) bases(tt);
 #pragma unroll
-    for (int kk = 0; kk < WG_TK; kk += 2) {
-      const int kr = kk + (lane >> 5);
-      const float a0 = As[kr * WG_LDA + wm * 64 + (lane & 31)];
-      const float a1 = As[kr * WG_LDA + wm * 64 + 32 + (lane & 31)];
-      const float b = Bs[kr * WG_LDB + wn * 32 + (lane & 31)];
-      const float b2 = Bs2[kr * WG_LDB + wn * 32 + (lane & 31)];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1], 0, 0, 0);
-      acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b2, acc2[0], 0, 0, 0);
-      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b2, acc2[1], 0, 0, 0);
-    }
-    if (t + 1 < T) wgrad_stage(smem + ((t + 1) & 1) * WG_STAGE, tid, regs);
-    __syncthreads();
+    for (int j = 0; j < 8; ++j) load1(r, tt, j);
+    loadw(r, tt);
+  };
+  load_all(R0, 0); load_all(R1, 1); load_all(R2, 2);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) store1(L0, R0, 0, j);
+  storew(L0, R0, 0);
+  load_all(R0, 3);
+  __syncthreads();
+  WG_STAMP(1);
+#ifdef VMC_WGRAD_STAMPS
+  if (a.stamps && threadIdx.x == 0) a.stamps[(long long)blockIdx.x * 8 + 6] = clock64();
+#endif
+  for (int t = 0; t < T_loop; t += 3) {     // tiles t, t + 1, t + 2 (those >= T are zeros)
+    step(L0, L1, R1, t); __syncthreads();
+    step(L1, L2, R2, t + 1); __syncthreads();
+    step(L2, L0, R0, t + 2); __syncthreads();
   }
-  // column sums of the four waves, fixed order
-  float* s_cs = smem + 2 * WG_STAGE;          // [2][4][64]
-  if (ones) {
-    s_cs[wave * 64 + lane] = cs;
-    s_cs[256 + wave * 64 + lane] = cs2;
+  WG_STAMP(2);
+#ifdef VMC_WGRAD_STAMPS
+  if (a.stamps && threadIdx.x == 0) a.stamps[(long long)blockIdx.x * 8 + 7] = clock64();
+#endif
+  // group 1 hands its sums to group 0 through its own (now idle) LDS stages
+  {
+    float* g1s = grp ? smem : smem + 3 * WG_STAGE;     // group 1's stages (smem already points there for group 1)
+    if (grp) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { g1s[r * 256 + tid] = acc[r]; g1s[(16 + r) * 256 + tid] = acc2[r]; }
+      g1s[32 * 256 + tid] = cs;
+      g1s[33 * 256 + tid] = cs2;
+    }
+    __syncthreads();
+    if (!grp) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[r] += g1s[r * 256 + tid]; acc2[r] += g1s[(16 + r) * 256 + tid]; }
+      cs += g1s[32 * 256 + tid];
+      cs2 += g1s[33 * 256 + tid];
+    }
+  }
+  // column sums: lane (n, h) of waves 0, 1 holds the sum over its half of the samples; s_ones[0..63] of
+  // delta, [64..127] of w (.) delta
+  float* s_cs = smem - grp * 3 * WG_STAGE + 6 * WG_STAGE;     // [2 products][2 halves][64] (behind both groups' stages)
+  float* s_ones = s_cs + 512;                 // [128]
+  int* s_ticket = (int*)(s_ones + 128);
+  if (sums && !grp) {
+    s_cs[(lane >> 5) * 64 + wn * 32 + (lane & 31)] = cs;
+    s_cs[128 + (lane >> 5) * 64 + wn * 32 + (lane & 31)] = cs2;
   }
   __syncthreads();
-  if (ones && tid < 128) {
-    const float* q = s_cs + (tid >> 6) * 256 + (tid & 63);
-    cs = (q[0] + q[64]) + (q[128] + q[192]);    // tid < 64: column sums of B; 64 .. 127: of w (.) B
+  if (ones && !grp && tid < 128) {
+    const float* q = s_cs + (tid >> 6) * 128 + (tid & 63);
+    s_ones[tid] = q[0] + q[64];
   }
-
+  __syncthreads();
   const long long ldc = P.n_out;
   float* c1 = a.g1 + P.c_off;
   float* c2 = a.g2 + P.c_off;
+  auto put = [&](float* dst, float v) { if (a.fresh) *dst = v; else *dst += v; };
   if (a.slices == 1) {                          // one slice: straight into the accumulators
+    if (grp) return;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
+    for (int r = 0; r < 16; ++r) {
       int m, n;
-      wgrad_mn(tid, i, m, n);
+      wgrad_mn(tid, r, m, n);
       m += m0; n += n0;
       if (m < P.k_in && n < P.n_out) {
-        const float v1 = acc[i >> 4][i & 15], v2 = acc2[i >> 4][i & 15];
-        float* q1 = c1 + (long long)m * ldc + n;
-        float* q2 = c2 + (long long)m * ldc + n;
-        if (a.fresh) { *q1 = v1; *q2 = v2; } else { *q1 += v1; *q2 += v2; }
+        put(c1 + (long long)m * ldc + n, acc[r]);
+        put(c2 + (long long)m * ldc + n, acc2[r]);
       }
     }
-    if (ones && tid < 128 && n0 + (tid & 63) < P.n_out) {
-      float* q = (tid < 64 ? c1 : c2) + (long long)P.k_in * ldc + n0 + (tid & 63);
-      if (a.fresh) *q = cs; else *q += cs;
-    }
+    if (ones && tid < 128 && n0 + (tid & 63) < P.n_out)
+      put((tid < 64 ? c1 : c2) + (long long)P.k_in * ldc + n0 + (tid & 63), s_ones[tid]);
     return;
   }
-  // partial tile -> workspace, in accumulator order
-  float* part = a.ws + ((long long)tile * a.slices + slice) * 2 * WG_PART;
+  // partial -> workspace: quad q of thread t at [q][t][4] (q < 4: first product, 4 .. 7: second, q = 8:
+  // the ones rows); group 0 holds the sums
+  float* part = a.ws + ((long long)tile * a.slices + slice) * WG_PART;
+  if (!grp) {
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    part[i * 256 + tid] = acc[i >> 4][i & 15];
-    part[WG_PART + i * 256 + tid] = acc2[i >> 4][i & 15];
+    for (int q = 0; q < 4; ++q) {
+      wg_store_sc1(part + (q * 256 + tid) * 4, f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
+      wg_store_sc1(part + ((q + 4) * 256 + tid) * 4, f32x4{acc2[4 * q], acc2[4 * q + 1], acc2[4 * q + 2], acc2[4 * q + 3]});
+    }
+    if (ones && tid < 32) wg_store_sc1(part + (WG_QUADS * 256 + tid) * 4, *(const f32x4*)(s_ones + 4 * tid));
   }
-  if (ones && tid < 128) part[(tid >> 6) * WG_PART + WG_TM * WG_TN + (tid & 63)] = cs;
-  // ticket: the partial is released device-wide before the counter moves; whoever draws the last ticket
-  // acquires everybody's
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its write-through stores
   __syncthreads();
-  int* s_ticket = (int*)(s_cs + 512);
-  if (tid == 0) *s_ticket = __hip_atomic_fetch_add(a.tickets + tile, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  WG_STAMP(3);
+  if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(a.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (*s_ticket != a.slices - 1) return;        // block-uniform
-  __threadfence();
-  const float* base = a.ws + (long long)tile * a.slices * 2 * WG_PART;
-#pragma unroll 4
-  for (int i = 0; i < 32; ++i) {
-    int m, n;
-    wgrad_mn(tid, i, m, n);
-    m += m0; n += n0;
-    float v1 = 0.f, v2 = 0.f;
-    for (int z = 0; z < a.slices; ++z) {        // fixed order, whoever folds
-      const float* q = base + (long long)z * 2 * WG_PART + i * 256 + tid;
-      v1 += __builtin_nontemporal_load(q);
-      v2 += __builtin_nontemporal_load(q + WG_PART);
-    }
-    if (m < P.k_in && n < P.n_out) {
-      float* q1 = c1 + (long long)m * ldc + n;
-      float* q2 = c2 + (long long)m * ldc + n;
-      if (a.fresh) { *q1 = v1; *q2 = v2; } else { *q1 += v1; *q2 += v2; }
-    }
-  }
-  if (ones && tid < 128) {
-    float v = 0.f;
-    for (int z = 0; z < a.slices; ++z)
-      v += __builtin_nontemporal_load(base + ((long long)z * 2 + (tid >> 6)) * WG_PART + WG_TM * WG_TN + (tid & 63));
-    if (n0 + (tid & 63) < P.n_out) {
-      float* q = (tid < 64 ? c1 : c2) + (long long)P.k_in * ldc + n0 + (tid & 63);
-      if (a.fresh) *q = v; else *q += v;
+  WG_STAMP(4);
+  if (*s_ticket != a.slices - 1) return;        // block-uniform: only the last arriver folds
+  // Fold by all eight waves: group g takes product g + 1 (quads 4 g .. 4 g + 3), two quads = up to sixteen
+  // 16-byte loads in flight per lane and round trip (the slices one at a time, quad after quad, were nine
+  // dependent round trips: 7.5 us for 165 KB)
+  const float* base = a.ws + (long long)tile * a.slices * WG_PART;
+  float* cg = grp ? c2 : c1;
+#pragma unroll
+  for (int hq = 0; hq < 2; ++hq) {
+    const int q0 = 2 * hq, q1 = q0 + 1;                       // quads of this group's product
+    f32x4 v0, v1;
+    wg_fold_quads2(base + ((4 * grp + q0) * 256 + tid) * 4, base + ((4 * grp + q1) * 256 + tid) * 4, WG_PART, a.slices, v0, v1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      int m, n;
+      wgrad_mn(tid, 4 * (e < 4 ? q0 : q1) + (e & 3), m, n);
+      m += m0; n += n0;
+      if (m < P.k_in && n < P.n_out) put(cg + (long long)m * ldc + n, e < 4 ? v0[e] : v1[e & 3]);
     }
   }
-  if (tid == 0) a.tickets[tile] = 0;            // for the next launch (stream-ordered after this one)
+  if (ones && !grp && tid < 32) {
+    const f32x4 v = wg_fold_quad(base + (WG_QUADS * 256 + tid) * 4, WG_PART, a.slices);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = 4 * tid + e, n = n0 + (j & 63);
+      if (n < P.n_out) put((j < 64 ? c1 : c2) + (long long)P.k_in * ldc + n, v[e]);
+    }
+  }
+  if (threadIdx.x == 0) a.tickets[tile] = 0;    // for the next launch (stream-ordered after this one)
+  WG_STAMP(5);
 }
 
-// N = 1 problems: C[m] = sum_b A(b, m) s_b and sum_b A(b, m) w_b s_b for 64 columns m (m == k_in: the ones
-// row), s_b = D[b * ldd]; 4 row groups x 64 columns, rows b = rg, rg + 4, ...; groups added as (0+1)+(2+3)
-__device__ __forceinline__ void wgrad_colsum(const WgradArgs& a, int cblock, float* smem) {
-  const int tid = threadIdx.x, col = tid & 63, rg = tid >> 6;
-  int pi = 0;
-  for (int i = 0; i < a.n_prob; ++i)
-    if (a.prob[i].n_out <= 1 && cblock >= a.prob[i].col0) pi = i;      // block-uniform
-  const WgradProblem P = a.prob[pi];
-  const int m = (cblock - P.col0) * 64 + col;
-  const bool real = m < P.k_in, one = m == P.k_in;
-  const float* ap = P.A + (real ? m : 0);
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
-  for (int b = rg; b < a.K; b += 4) {
-    const float av = real ? ap[(long long)b * P.lda] : (one ? 1.f : 0.f);
-    const float sv = P.D[(long long)b * P.ldd];
-    s1 += av * sv;
-    s2 += av * (a.w[b] * sv);
-  }
-  smem[rg * 64 + col] = s1;
-  smem[256 + rg * 64 + col] = s2;
-  __syncthreads();
-  if (tid < 128 && (real || one)) {
-    const float* q = smem + (tid >> 6) * 256 + col;
-    const float v = (q[0] + q[64]) + (q[128] + q[192]);
-    float* dst = (tid < 64 ? a.g1 : a.g2) + P.c_off + m;
-    if (a.fresh) *dst = v; else *dst += v;
-  }
-}
-
-__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+__global__ __launch_bounds__(512) void k_wgrad(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wg_smem[];
   const int b = blockIdx.x;
   if (b < a.mfma_blocks) {
     const WgradBlock m = plan_wgrad_block(b, a.tiles, a.slices);
     if (m.slice < 0) return;
-    wgrad_tile(a, m.slice, m.tile, wg_smem);
-  } else if (b < a.mfma_blocks + a.col_blocks) {
-    wgrad_colsum(a, b - a.mfma_blocks, wg_smem);
-  } else if (a.job.sc) {
+    int pi = 0;                                   // tile -> problem (block-uniform; a handful of problems)
+    for (int i = 0; i < a.n_prob; ++i)
+      if (m.tile >= a.prob[i].tile0) pi = i;      // tile0 ascends with the problem index
+    const WgradProblem P = a.prob[pi];
+    const int kbeg = m.slice * a.kchunk, klen = min(a.K, kbeg + a.kchunk) - kbeg;
+    if ((klen & (WG_TK - 1)) == 0 && (long long)P.lda * 80 < (1LL << 31) && (long long)P.ldd * 80 < (1LL << 31))
+      wgrad_tile<true>(a, P, m.slice, m.tile, wg_smem);
+    else
+      wgrad_tile<false>(a, P, m.slice, m.tile, wg_smem);
+  } else if (a.job.sc && threadIdx.x < 256) {     // (waves 4 .. 7 retire: 256 threads do the scalars)
     scalar_accum_body(a.job, a.fresh != 0, (double*)wg_smem, (double*)wg_smem + 256);
   }
 }
 
-size_t wgrad_lds_bytes() { return sizeof(float) * (2 * WG_STAGE + 512 + 4); }
+// more than half a CU's LDS: one workgroup per CU (a condition of the hand-over protocol above)
+size_t wgrad_lds_bytes() {
+  const size_t need = sizeof(float) * (6 * WG_STAGE + 512 + 128 + 4), one_per_cu = 81 * 1024;   // need: 114 KB
+  return need > one_per_cu ? need : one_per_cu;
+}
 
 hipError_t launch_wgrad(hipStream_t s, const WgradLaunch& L) {
   WgradArgs a;
   memset((void*)&a, 0, sizeof(a));
   a.prob = (const WgradProblem*)L.dev_problems; a.n_prob = L.n_prob;
   a.tiles = L.tiles; a.slices = L.slices; a.kchunk = plan_wgrad_kchunk(L.K, L.slices);
-  a.mfma_blocks = plan_wgrad_grid(L.tiles, L.slices); a.col_blocks = L.col_blocks;
+  a.mfma_blocks = plan_wgrad_grid(L.tiles, L.slices);
   a.K = L.K; a.w = L.w; a.g1 = L.g1; a.g2 = L.g2; a.ws = L.ws; a.tickets = L.tickets; a.fresh = L.fresh ? 1 : 0;
   a.job = ScalarJob{L.sc_eloc, L.sc_ratio, L.sc_out, L.sc_B, L.sc_mode};
-  const int grid = a.mfma_blocks + a.col_blocks + (L.sc_out ? 1 : 0);
+
+  const int grid = a.mfma_blocks + (L.sc_out ? 1 : 0);
   if (grid <= 0 || L.K <= 0) return hipSuccess;
   static bool attr_set = false;
   const size_t lds = wgrad_lds_bytes();
@@ -572,17 +755,53 @@ hipError_t launch_wgrad(hipStream_t s, const WgradLaunch& L) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(256), lds, s, a);
+#ifdef VMC_WGRAD_STAMPS
+  // diagnostic build: every 20th launch is stamped, read back synchronously and summarised on stderr
+  static unsigned long long* d_st = nullptr;
+  static int n_launch = 0;
+  if (!d_st) hipMalloc((void**)&d_st, 4096 * 8 * sizeof(unsigned long long));
+  const bool probe = (++n_launch % 20) == 0 && grid <= 4096;
+  if (probe) { hipMemsetAsync(d_st, 0, (size_t)grid * 64, s); a.stamps = d_st; }
+
+#endif
+  hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(512), lds, s, a);
+#ifdef VMC_WGRAD_STAMPS
+  if (probe) {
+    std::vector<unsigned long long> h((size_t)grid * 8);
+    hipStreamSynchronize(s);
+    hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t_end = 0;
+    for (int b = 0; b < a.mfma_blocks; ++b) if (h[(size_t)b * 8]) t0 = std::min(t0, h[(size_t)b * 8]);
+    double sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0};
+    int n = 0, nf = 0;
+    double cyc = 0.0, wall = 0.0;
+    for (int b = 0; b < a.mfma_blocks; ++b) {
+      const unsigned long long* q = &h[(size_t)b * 8];
+      if (!q[0]) continue;
+      ++n;
+      for (int i = 0; i < 5; ++i) { const double v = (double)(q[i] - t0) * 0.01; sum[i] += v; mx[i] = std::max(mx[i], v); }
+      if (q[5]) { ++nf; const double v = (double)(q[5] - t0) * 0.01; sum[5] += v; mx[5] = std::max(mx[5], v); }
+      for (int i = 0; i < 6; ++i) t_end = std::max(t_end, q[i]);
+      cyc += (double)(q[7] - q[6]); wall += (double)(q[2] - q[1]) * 0.01;
+    }
+    fprintf(stderr, "[wgrad stamps] loop: %.0f shader cycles (s_memtime) in %.2f us per workgroup = %.3f GHz; %.0f cycles per k-tile\n",
+            cyc / n, wall / n, cyc / wall * 1e-3, cyc / n / (3.0 * ((a.kchunk / WG_TK + 2) / 3)));
+    fprintf(stderr, "[wgrad stamps] blocks %d (folding %d) slices %d tiles %d | us since the first block started, mean / max: "
+            "start %.2f/%.2f  loop %.2f/%.2f  loop end %.2f/%.2f  stores drained %.2f/%.2f  ticket %.2f/%.2f  fold end %.2f/%.2f | last stamp %.2f\n",
+            n, nf, a.slices, a.tiles, sum[0] / n, mx[0], sum[1] / n, mx[1], sum[2] / n, mx[2], sum[3] / n, mx[3], sum[4] / n, mx[4],
+            nf ? sum[5] / nf : 0.0, mx[5], (double)(t_end - t0) * 0.01);
+  }
+#endif
   return hipGetLastError();
 }
 
 size_t wgrad_problem_bytes() { return sizeof(WgradProblem); }
 
 void wgrad_fill_problem(void* dst, int index, const float* A, long long lda, const float* D, long long ldd,
-                        long long c_off, int k_in, int n_out, int tile0, int col0) {
+                        long long c_off, int k_in, int n_out, int tile0) {
   WgradProblem& p = ((WgradProblem*)dst)[index];
   p.A = A; p.lda = lda; p.D = D; p.ldd = ldd; p.c_off = c_off; p.k_in = k_in; p.n_out = n_out;
-  p.tile0 = tile0; p.tiles_n = (n_out + WG_TN - 1) / WG_TN; p.col0 = col0;
+  p.tile0 = tile0; p.tiles_n = (n_out + WG_TN - 1) / WG_TN;
 }
 
 __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {

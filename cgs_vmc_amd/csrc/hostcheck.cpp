@@ -54,20 +54,27 @@ static void check_layout(const DescPlan& p, long long N, long long H) {
   for (long long i = 0; i < P; ++i) CHECK(mark[(size_t)i] == 1);
 }
 
-// XCD-aware block orders: a bijection onto (group / slice, tile), all tiles of one group on one XCD
+// XCD-aware block order: a bijection onto (slice, tile); every XCD gets the same number of work items
+// (+- 1 range), contiguous in slice-major order
 static void check_block_maps() {
-  for (int per_group : {1, 4, 8, 16, 20, 33})
-    for (int groups : {1, 7, 8, 9, 32, 48, 100}) {
-      const int grid = 8 * ((groups + 7) / 8) * per_group;
-      CHECK(plan_wgrad_grid(per_group, groups) == grid);
-      std::vector<int> hit2((size_t)groups * per_group, 0);
+  for (int tiles : {1, 4, 8, 16, 20, 33, 44})
+    for (int slices : {1, 5, 7, 8, 9, 12, 32}) {
+      const int grid = plan_wgrad_grid(tiles, slices), W = tiles * slices;
+      CHECK(grid % 8 == 0 && grid >= W && grid < W + 8 * 8);
+      std::vector<int> hit((size_t)W, 0), per_xcd(8, 0), last(8, -1);
       for (int b = 0; b < grid; ++b) {
-        const WgradBlock m = plan_wgrad_block(b, per_group, groups);
+        const WgradBlock m = plan_wgrad_block(b, tiles, slices);
         if (m.slice < 0) continue;
-        CHECK(m.slice < groups && m.tile < per_group && (b & 7) == (m.slice & 7));
-        hit2[(size_t)m.slice * per_group + m.tile] += 1;
+        CHECK(m.slice < slices && m.tile >= 0 && m.tile < tiles);
+        const int w = m.slice * tiles + m.tile;
+        hit[(size_t)w] += 1;
+        per_xcd[(size_t)(b & 7)] += 1;
+        CHECK(w > last[(size_t)(b & 7)]);               // one XCD walks a contiguous, ascending range
+        last[(size_t)(b & 7)] = w;
       }
-      for (int v : hit2) CHECK(v == 1);
+      for (int v : hit) CHECK(v == 1);
+      const int G = (W + 7) / 8;
+      for (int x = 0; x < 8; ++x) CHECK(per_xcd[(size_t)x] <= G && (per_xcd[(size_t)x] == G || (x + 1) * G > W));
     }
 }
 
@@ -82,18 +89,14 @@ static void check_wgrad(long long N, long long H, int n_hh, bool rbm, long long 
   for (int l = 0; l < n_hh; ++l) add((int)H, (int)H);
   add((int)N, (int)H);
   const long long tiles = tile0;
-  CHECK(tiles == plan_wgrad_tiles((int)N, (int)H) + (long long)n_hh * plan_wgrad_tiles((int)H, (int)H));
-  CHECK(plan_wgrad_tiles((int)H, 1) == 0);
-  const int cols = plan_wgrad_col_blocks(rbm ? (int)N : (int)H);
-  CHECK((long long)cols * 64 >= (rbm ? N : H) + 1 && (long long)(cols - 1) * 64 < (rbm ? N : H) + 1);
+  CHECK(tiles == plan_wgrad_total_tiles((int)N, (int)H, n_hh, rbm) && tiles >= 2);
   // every tile belongs to exactly one problem and lies inside its output; together they cover it
   for (const Prob& p : probs) {
-    if (p.n_out <= 1) continue;
     const int tn = (p.n_out + WG_TN - 1) / WG_TN, nt = plan_wgrad_tiles(p.k_in, p.n_out);
     for (int t = p.tile0; t < p.tile0 + nt; ++t) {
       int pi = 0;
       for (size_t i = 0; i < probs.size(); ++i)
-        if (probs[i].n_out > 1 && t >= probs[i].tile0) pi = (int)i;
+        if (t >= probs[i].tile0) pi = (int)i;
       CHECK(&probs[(size_t)pi] == &p);
       const int lt = t - p.tile0, tm = lt / tn, tnn = lt % tn;
       CHECK(tm * WG_TM < p.k_in && tnn * WG_TN < p.n_out);
@@ -102,15 +105,15 @@ static void check_wgrad(long long N, long long H, int n_hh, bool rbm, long long 
   }
   for (int cus : kCus)
     for (int forced : {0, 1, 3, 12, 100}) {
-      const int s = plan_wgrad_slices(tiles, B, cus, cols + 1, forced);
+      const int s = plan_wgrad_slices(tiles, B, cus, 1, forced);
       CHECK(s >= 1 && s <= WG_MAX_SPLIT);
-      if (!forced) CHECK(s == 1 || tiles * s + cols + 1 <= cus);
+      if (!forced) CHECK(s == 1 || tiles * s + 1 <= cus);
       const int kc = plan_wgrad_kchunk((int)B, s);
       CHECK(kc % WG_TK == 0 && (long long)kc * s >= B);
       CHECK((long long)kc * (s - 1) < B);                 // no slice is empty
       // the last float the last slice of the last tile writes (second product's ones row)
-      const long long part = (long long)WG_TM * WG_TN + WG_TN;
-      const long long last = (((tiles - 1) * s + (s - 1)) * 2 + 1) * part + (part - 1);
+      const long long part = 2 * ((long long)WG_TM * WG_TN + WG_TN);      // WG_PART of grad.hip
+      const long long last = ((tiles - 1) * s + (s - 1)) * part + (part - 1);
       CHECK(tiles == 0 || last < plan_wgrad_ws_floats(tiles, WG_MAX_SPLIT));
     }
 }

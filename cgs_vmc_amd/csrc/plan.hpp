@@ -349,7 +349,7 @@ inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, c
 }
 
 // ------------------------------------------------------------------------------- weight-gradient GEMM
-#define WG_TM 128          // output tile of the batched weight-gradient kernel (k_wgrad, grad.hip)
+#define WG_TM 64           // output tile of the batched weight-gradient kernel (k_wgrad, grad.hip)
 #define WG_TN 64
 #define WG_TK 32
 #define WG_MAX_SPLIT 32    // workspace bound
@@ -357,12 +357,14 @@ inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, c
 // One problem of the batched weight-gradient launch: C[m_rows (+ ones row)][n_cols] over K samples
 struct WgradShape { int m_rows, n_cols; };
 
-// tiles of one problem (the N = 1 output-layer problem takes no MFMA tile: it is a column sum)
+// tiles of one problem (the N = 1 output / onsite problem is a one-column tile row like any other: its
+// MFMAs multiply mostly zeros, but it needs no code of its own -- a VALU column sum over all samples in a
+// workgroup of its own was latency bound at 190 us)
 PLAN_HD inline int plan_wgrad_tiles(int m_rows, int n_cols) {
-  return n_cols <= 1 ? 0 : ((m_rows + WG_TM - 1) / WG_TM) * ((n_cols + WG_TN - 1) / WG_TN);
+  return ((m_rows + WG_TM - 1) / WG_TM) * ((n_cols + WG_TN - 1) / WG_TN);
 }
 
-// K slices: as many as fill the CUs once (tiles x slices + the column-sum blocks <= num_cus), each a
+// K slices: as many as fill the CUs once (tiles x slices + the other blocks of the launch <= num_cus), each a
 // whole number of WG_TK steps, at least 64 samples per slice.  forced > 0: the measurement knob
 // CGS_VMC_WGRAD_SLICES
 inline int plan_wgrad_slices(long long total_tiles, long long K, int num_cus, int other_blocks = 0, int forced = 0) {
@@ -387,23 +389,29 @@ PLAN_HD inline int plan_wgrad_kchunk(int K, int slices) {
 }
 
 // XCD-aware block order: workgroups go to the 8 XCDs round robin by linear block id and every XCD has
-// its own L2.  All tiles of one k-slice share that slice's operand rows, so slice s lives on XCD s % 8:
-// block id -> (slice, tile).  n_blocks = 8 * ceil(slices / 8) * tiles; ids whose slice is out of range exit.
+// its own L2.  The W = tiles x slices work items, slice-major (all tiles of a k-slice share that slice's
+// operand rows), are cut into 8 contiguous ranges of G = ceil(W / 8), one per XCD: every XCD gets the
+// same number of workgroups (slices per XCD would leave XCDs idle whenever slices % 8 != 0: 5 slices
+// ran on 5 of 8 XCDs) and mostly one slice's rows in its L2.  Block b -> item (b % 8) G + b / 8.
 struct WgradBlock { int slice, tile; };
 PLAN_HD inline WgradBlock plan_wgrad_block(int block, int tiles, int slices) {
   WgradBlock b;
-  const int xcd = block & 7, idx = block >> 3;
-  b.slice = xcd + 8 * (idx / tiles);
-  b.tile = idx % tiles;
-  if (b.slice >= slices) b.slice = -1;
+  const int W = tiles * slices, G = (W + 7) / 8;
+  const int j = block >> 3, w = (block & 7) * G + j;
+  if (j >= G || w >= W) { b.slice = -1; b.tile = 0; return b; }
+  b.slice = w / tiles;
+  b.tile = w % tiles;
   return b;
 }
-inline int plan_wgrad_grid(int tiles, int slices) { return tiles <= 0 ? 0 : 8 * ((slices + 7) / 8) * tiles; }
+inline int plan_wgrad_grid(int tiles, int slices) { return tiles <= 0 ? 0 : 8 * ((tiles * slices + 7) / 8); }
 
-// 64-column blocks of an N = 1 problem (k_in columns + the ones row)
-inline int plan_wgrad_col_blocks(int k_in) { return (k_in + 1 + 63) / 64; }
+// MFMA tiles of the whole dense gradient launch: the output (FC) / onsite (RBM) problem
+// [k_in = H or N][1], n_hh hidden problems [H][H], the first layer [N][H]
+inline int plan_wgrad_total_tiles(int N, int H, int n_hh, bool rbm) {
+  return plan_wgrad_tiles(rbm ? N : H, 1) + n_hh * plan_wgrad_tiles(H, H) + plan_wgrad_tiles(N, H);
+}
 
-// floats of the partial-tile workspace: [tiles][slices][2][WG_TM * WG_TN + WG_TN]
+// floats of the partial-tile workspace: [tiles][slices][2 x WG_TM x WG_TN + 2 x WG_TN]
 inline long long plan_wgrad_ws_floats(long long tiles, int slices) {
   return tiles * slices * 2 * ((long long)WG_TM * WG_TN + WG_TN);
 }

@@ -113,7 +113,7 @@ struct vmc_ctx {
   float* delta_all = nullptr;
   void* d_batch[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // weight-gradient problem tables [w = eloc / ratio][parity]
   bool batch_ready[2][2] = {{false, false}, {false, false}};
-  int wg_tiles = 0, wg_cols = 0;   // MFMA tiles / column-sum blocks of the weight-gradient launch (plan.hpp)
+  int wg_tiles = 0;                // MFMA tiles of the weight-gradient launch (plan.hpp)
   int* wg_tickets = nullptr;       // [wg_tiles] arrival tickets of the split-K fold, zero between launches
   float *ratio = nullptr, *ones = nullptr;
   float *acc = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad_tmp = nullptr;
@@ -740,9 +740,8 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(hipMemsetAsync(c->delta_all, 0, L * B * Hp * sizeof(float), c->stream));
   for (int l = 0; l < L; ++l) c->delta[l] = c->delta_all + l * B * Hp;
   for (int i = 0; i < 4; ++i) CA(hipMalloc(&c->d_batch[i / 2][i % 2], (size_t)(L + 1) * wgrad_problem_bytes()));
-  {  // weight-gradient launch: tiles of the layers with a matrix output, 64-column blocks of the N = 1 layer
-    c->wg_tiles = plan_wgrad_tiles((int)N, c->H) + (int)NH * plan_wgrad_tiles(c->H, c->H);
-    c->wg_cols = plan_wgrad_col_blocks(rbm ? (int)N : c->H);
+  {  // weight-gradient launch: the tiles of all layers
+    c->wg_tiles = plan_wgrad_total_tiles((int)N, c->H, (int)NH, rbm);
     CA(dalloc(&c->wg_tickets, c->wg_tiles > 0 ? c->wg_tiles : 1));
     CA(hipMemsetAsync(c->wg_tickets, 0, (size_t)(c->wg_tiles > 0 ? c->wg_tiles : 1) * sizeof(int), c->stream));
   }
@@ -1306,14 +1305,14 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e,
                               c->dact_all, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr));
   // Every weight gradient is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows 0..K_in-1 give dW, the
   // implicit ones row gives db (b_l sits right behind w_l in theta), the unscaled product goes to g1 and
-  // the w-scaled one to g2.  All NH+2 of them, the N = 1 column sums and the scalar accumulators run as
+  // the w-scaled one to g2.  All NH+2 of them and the scalar accumulators run as
   // ONE launch (k_wgrad); the problem table is built once per weight vector `w`.
   const int slot = (w == c->ratio) ? 1 : 0, par = c->parity;
   if (!c->batch_ready[slot][par]) {
     std::vector<unsigned char> tab((size_t)(NH + 2) * wgrad_problem_bytes());
     int n = 0, tile0 = 0;
     auto add = [&](const float* a, long long a_ld, int k_in, const float* delta, long long ldd, int n_out, long long off) {
-      wgrad_fill_problem(tab.data(), n++, a, a_ld, delta, ldd, off, k_in, n_out, tile0, 0);
+      wgrad_fill_problem(tab.data(), n++, a, a_ld, delta, ldd, off, k_in, n_out, tile0);
       tile0 += plan_wgrad_tiles(k_in, n_out);
     };
     if (c->rbm)   // onsite layer: d logit / d w_on = x, d logit / d b_on = 1
@@ -1331,8 +1330,8 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e,
     WgradLaunch L;
     memset((void*)&L, 0, sizeof(L));
     L.dev_problems = c->d_batch[slot][par]; L.n_prob = NH + 2;
-    L.tiles = c->wg_tiles; L.col_blocks = c->wg_cols;
-    L.slices = plan_wgrad_slices(c->wg_tiles, B, c->num_cus, c->wg_cols + 1, forced);
+    L.tiles = c->wg_tiles;
+    L.slices = plan_wgrad_slices(c->wg_tiles, B, c->num_cus, 1, forced);
     L.K = B; L.w = w; L.g1 = g1; L.g2 = g2; L.ws = c->gemm_ws; L.tickets = c->wg_tickets; L.fresh = fresh;
     L.sc_eloc = e; L.sc_ratio = mode == 1 ? c->ratio : nullptr; L.sc_out = c->acc + 2 * c->P; L.sc_B = B; L.sc_mode = mode;
     HIPCHK(c, launch_wgrad(c->stream, L));
