@@ -42,6 +42,7 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense f32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 matrix peak = 16 x the f32 rate (same guide)
 HBM_PEAK_GBS = 8000.0
 REPS = 5                        # repetitions of the timed region; the median is reported
 
@@ -53,6 +54,10 @@ WORKLOADS = {
     # the WHOLE batch of config 4 on one GPU (its 8-GPU shard is the line above): 8 rounds of the sampler's
     # one-tile-per-CU grid; not a driver line, a sizing check (32768 chains are 3 % of the HBM)
     'heisenberg10x10_fc3x256_b32768': (10, 10, False, 3, 256, 32768),
+    # EXPERIMENT, never the headline line: config 3 with the local-energy row kernel on the
+    # BF16 matrix cores -- fp32 operands as three bf16 terms, six products, fp32 accumulate
+    # (CGS_VMC_SPLIT_BF16=1, cgs_vmc_amd/csrc/tail_split.hip); sampler and gradient path native fp32
+    'heisenberg10x10_fc3x256_b4096_split3xbf16': (10, 10, False, 3, 256, 4096),
     'heisenberg6x6_fc3x128_b1024': (6, 6, False, 3, 128, 1024),
     'heisenberg16x16j1j2_fc6x256_b1024': (16, 16, True, 6, 256, 1024),
     'heisenberg10x10_fc3x512_b4096': (10, 10, False, 3, 512, 4096),   # 257 .. 512 units: the fused kernels padded to 512
@@ -552,6 +557,9 @@ def main():
   dev = parallel.local_rank()
   torch.cuda.set_device(dev)
 
+  split = args.workload.endswith('_split3xbf16')
+  if split:
+    os.environ['CGS_VMC_SPLIT_BF16'] = '1'
   lx, ly, nnn, L, h, b = WORKLOADS[args.workload][:6]
   ansatz, ksz = (WORKLOADS[args.workload][6:] + ('fully_connected', 0))[:2]
   conv = ansatz in ('conv_2d', 'res_net_2d')
@@ -569,6 +577,8 @@ def main():
   eng.set_params(theta)
   eng.set_configs(cfg)
   eng.set_bonds(bonds, jx, jz)
+  if split and eng.kernel_path() != 4:
+    raise SystemExit('bench.py: the split workload did not get the split kernel')
   proof = prove_collectives(eng, world, rank, dev) if world > 1 else None
   lib_proof, lib_stuck = prove_library_transport(eng, world, rank) if world > 1 else ({}, False)
   if world > 1 and lib_stuck:
@@ -720,7 +730,8 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': 'f32 via 3xbf16 split, fp32 accumulate (E_loc row kernel only; sampler and gradients native f32)' if split else 'f32',
+        'data': 'synthetic',
         'config': {'workload': args.workload, 'lattice': '{}x{} torus'.format(lx, ly),
                    'n_sites': n, 'n_bonds': nb, 'ansatz': ('{} {} x {} filters, kernel {}, relu/exp'.format(ansatz, L, h, ksz) if conv
                               else 'fully_connected {}x{} relu/exp'.format(L, h)),
@@ -764,10 +775,18 @@ def main():
           k_sweep: {'ms_avg': ts * 1e3, 'flops_executed': exec_sweep, 'flops_nominal': flops_sweep},
           k_eloc: {'ms_avg': te * 1e3, 'flops_executed': exec_eloc, 'flops_nominal': flops_eloc},
       }
+      if split:       # six bf16 products per fp32 product, priced against the BF16 peak
+        per_kernel[k_eloc]['kernel'] = 'k_tail16s (3 x bf16 split)'
+        per_kernel[k_eloc]['flops_executed_bf16'] = 6 * exec_eloc
+        per_kernel[k_eloc]['f32_equivalent_tflops'] = exec_eloc / te / 1e12
       for v in per_kernel.values():
         t = v['ms_avg'] * 1e-3
         v['achieved'] = v['flops_executed'] / t / 1e12         # TFLOP/s issued to the matrix cores
         v['frac'] = v['achieved'] / FP32_MFMA_PEAK_TFLOPS
+        if 'flops_executed_bf16' in v:
+          v['achieved'] = v['flops_executed_bf16'] / t / 1e12
+          v['peak'] = BF16_MFMA_PEAK_TFLOPS
+          v['frac'] = v['achieved'] / BF16_MFMA_PEAK_TFLOPS
         v['algorithmic_tflops'] = v['flops_nominal'] / t / 1e12   # SURVEY 8d count / time; not a roofline fraction
       key = k_sweep if dom == 'sweep' else k_eloc
       # HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command
@@ -802,7 +821,7 @@ def main():
       nominal = per_kernel[key]['algorithmic_tflops']
       out['roofline'] = {
           'kernel': key, 'bound': 'mfma', 'achieved': per_kernel[key]['achieved'],
-          'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': per_kernel[key]['frac'],
+          'peak': per_kernel[key].get('peak', FP32_MFMA_PEAK_TFLOPS), 'unit': 'TFLOP/s', 'frac': per_kernel[key]['frac'],
           'traffic': traffic,
           'nominal_achieved': nominal, 'nominal_frac': nominal / FP32_MFMA_PEAK_TFLOPS,
           'step_frac': (exec_sweep + exec_eloc + exec_grad) / (ms_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,

@@ -234,6 +234,10 @@ hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp);
 bool tail_lds_supported(int Hp, int n_hidden);
 hipError_t launch_tail_lds(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm);
 size_t sweep_lds_required(int N, int Hp, int n_hidden, bool rbm);
+// the 3 x bf16 split experiment of the row kernel (tail_split.hip; CGS_VMC_SPLIT_BF16=1)
+hipError_t launch_pack_split(hipStream_t s, const float* theta, int H, const ParamLayout& lay, unsigned* out);
+long long pack_split_dwords(int n_hh);
+hipError_t launch_tail16_split(hipStream_t s, const TailArgs& a, const unsigned* p16s, bool ratio_mode);
 
 // bond list / local-energy reduction (eloc.hip)
 hipError_t launch_bond_list(hipStream_t s, const float* configs, const int2* bonds,

@@ -30,6 +30,7 @@ struct ParamSet {
   float* eloc = nullptr;   // [B]
   // convolutional ansatz types: fragment images of conv.hpp ConvParams
   float *cw0 = nullptr, *cwf = nullptr, *cwb = nullptr, *cbias = nullptr;
+  unsigned* p16s = nullptr;   // CGS_VMC_SPLIT_BF16=1: the H x H layers as three bf16 terms (tail_split.hip)
   bool packed_valid = false, cache_valid = false, has_params = false;
   float shift = -10.f;     // wavefunctions.py:209
   PackedParams packed() const { return PackedParams{w1p, b1p, bh, p16, woutp, bout, won}; }
@@ -61,6 +62,9 @@ struct vmc_ctx {
   // are instantiations of the fused kernels (k_sweep16<24|32>, k_tail_lds); only the gradient path
   // stays on the general GEMMs.  CGS_VMC_WIDE_FAST=0 forces the general path.
   bool wide_fast = false;
+  // EXPERIMENT (CGS_VMC_SPLIT_BF16=1; fully_connected, relu, 193 .. 256 units, >= 1 H x H layer): the row
+  // kernel computes its fp32 results on the bf16 matrix cores from three-term splits (tail_split.hip)
+  bool split = false;
   long long wrows = 0;     // rows of the two activation row buffers
   float *wbuf[2] = {nullptr, nullptr}, *wide_zc = nullptr, *wide_lnew = nullptr, *wide_u = nullptr, *wide_zero = nullptr;
   int *wide_iup = nullptr, *wide_idn = nullptr;
@@ -319,8 +323,15 @@ int ensure_packed(vmc_ctx* c, int which) {
   }
   HIPCHK(c, launch_pack(c->stream, p.theta, c->N, c->H, c->Hp, c->lay, p.w1p, p.b1p, p.bh, p.p16,
                         p.p16t, p.woutp, p.bout, p.won));
+  if (c->split) HIPCHK(c, launch_pack_split(c->stream, p.theta, c->H, c->lay, p.p16s));
   p.packed_valid = true;
   return VMC_OK;
+}
+
+// rows through the fused row kernel of this ctx (the 3 x bf16 split experiment when it is switched on)
+hipError_t launch_rows(vmc_ctx* c, int which, const TailArgs& a, bool ratio) {
+  if (c->split) return launch_tail16_split(c->stream, a, c->ps[which].p16s, ratio);
+  return launch_tail(c->stream, a, c->Hp, ratio, c->rbm);
 }
 
 TailArgs tail_args(vmc_ctx* c, int which) {
@@ -436,7 +447,7 @@ int ensure_cache(vmc_ctx* c, int which) {
     Timer t(c, "tail_amp");
     TailArgs a = tail_args(c, which);
     a.z1 = p.z1; a.n_rows = c->B; a.out = p.logit; a.rowinfo = c->rowinfo_id;
-    HIPCHK(c, launch_tail(c->stream, a, c->Hp, false, c->rbm));
+    HIPCHK(c, launch_rows(c, which, a, false));
   }
   p.cache_valid = true;
   return VMC_OK;
@@ -493,7 +504,7 @@ int local_energy_device(vmc_ctx* c, int which) {
     // CU each, so the persistent grid leaves them free
     if (c->expect_sweep && can_overlap(c) && c->num_cus - sweep_cus(c) >= c->num_cus / 4)
       a.num_cus = c->num_cus - sweep_cus(c);
-    HIPCHK(c, launch_tail(c->stream, a, c->Hp, true, c->rbm));
+    HIPCHK(c, launch_rows(c, which, a, true));
   }
   {
     Timer t(c, "eloc_reduce");
@@ -696,6 +707,8 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   c->P = dp.P;
   c->stream = (hipStream_t)d->stream;
   if (const char* e = getenv("CGS_VMC_SWEEP_W1L")) c->sweep_no_w1l = atoi(e) == 0 ? 1 : 0;
+  if (const char* e = getenv("CGS_VMC_SPLIT_BF16"))
+    c->split = atoi(e) == 1 && !conv && !wide && !rbm && c->Hp == 256 && c->n_hh >= 1 && c->hact == VMC_ACT_RELU_;
   if (const char* e = getenv("CGS_VMC_OVERLAP")) { c->overlap = !conv && !wide && atoi(e) != 0; c->overlap_full = atoi(e) == 2; }
   {
     hipDeviceProp_t prop;
@@ -717,6 +730,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     CA(hipMemsetAsync(p.won, 0, N * sizeof(float), c->stream));
     CA(hipMemsetAsync(p.onsite, 0, B * sizeof(float), c->stream));
     CA(dalloc(&p.woutp, Hp)); CA(dalloc(&p.bout, 1));
+    if (c->split) CA(dalloc(&p.p16s, pack_split_dwords((int)NH)));
     CA(dalloc(&p.z1, B * Hp)); CA(dalloc(&p.logit, B)); CA(dalloc(&p.eloc, B));
     if (w == 0) {
       CA(dalloc(&p.z1_alt, B * Hp)); CA(dalloc(&p.logit_alt, B)); CA(dalloc(&p.onsite_alt, B));
@@ -814,6 +828,7 @@ void vmc_destroy(vmc_ctx* c) {
     float* ptrs[] = {p.theta, p.w1p, p.b1p, p.bh, p.p16, p.p16t, p.woutp, p.bout, p.z1, p.logit, p.eloc, p.won, p.onsite,
                      p.z1_alt, p.logit_alt, p.onsite_alt, p.cw0, p.cwf, p.cwb, p.cbias};
     for (float* q : ptrs) if (q) hipFree(q);
+    if (p.p16s) hipFree(p.p16s);
   }
   if (c->act_all) hipFree(c->act_all);
   if (c->act_alt) hipFree(c->act_alt);
@@ -962,7 +977,7 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
       if (c->rbm) HIPCHK(c, launch_onsite(c->stream, c->tmp_cfg, p.won, (int)n_rows, c->N, c->tmp_on));
       TailArgs a = tail_args(c, which);
       a.z1 = c->tmp_z1; a.on_base = c->tmp_on; a.n_rows = (int)n_rows; a.out = c->tmp_out; a.rowinfo = c->tmp_rowinfo;
-      HIPCHK(c, launch_tail(c->stream, a, c->Hp, false, c->rbm));
+      HIPCHK(c, launch_rows(c, which, a, false));
     }
     HIPCHK(c, hipMemcpyAsync(host.data(), c->tmp_out, n_rows * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   }
@@ -1226,7 +1241,7 @@ int vmc_local_energy_terms(vmc_ctx* c, int which, float* diag, float* offdiag_ov
 int vmc_debug_kernel_path(vmc_ctx* c, int32_t* path) {
   CHECK_CTX(c);
   if (!path) return fail(c, VMC_ERR_INVALID, "null");
-  *path = c->conv ? 3 : (c->wide ? (c->wide_fast ? 1 : 2) : 0);
+  *path = c->conv ? 3 : (c->wide ? (c->wide_fast ? 1 : 2) : (c->split ? 4 : 0));
   return VMC_OK;
 }
 

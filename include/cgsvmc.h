@@ -321,7 +321,9 @@ int vmc_timing_get(vmc_ctx* ctx, const char* name, double* ms, int64_t* launches
 int vmc_last_connected_rows(vmc_ctx* ctx, int64_t* rows);
 /* Diagnostic: which kernel family serves this ctx.  0: fused, register-resident rows (<= 256 hidden
  * units); 1: fused, LDS-operand rows (257 .. 512 units); 2: general multi-launch path (> 512 units,
- * or CGS_VMC_WIDE_FAST=0); 3: convolutional kernels. */
+ * or CGS_VMC_WIDE_FAST=0); 3: convolutional kernels; 4: the 3 x bf16 split experiment of the row kernel
+ * (CGS_VMC_SPLIT_BF16=1: fully_connected, relu, 193 .. 256 units; fp32 results from the bf16 matrix cores,
+ * cgs_vmc_amd/csrc/tail_split.hip -- never the headline configuration). */
 int vmc_debug_kernel_path(vmc_ctx* ctx, int32_t* path);
 int vmc_synchronize(vmc_ctx* ctx);
 

@@ -1,0 +1,111 @@
+"""GPU: the 3 x bf16 split experiment of the row kernel (CGS_VMC_SPLIT_BF16=1, cgs_vmc_amd/csrc/tail_split.hip:
+fp32 results from the bf16 matrix cores -- every f32 operand as three bf16 terms, six products accumulated
+in fp32) at the SAME tolerances as the native fp32 kernel's logit and local-energy cases
+(tests/test_gpu_engine.py, tests/test_gpu_fullsize.py), with its maximum error against the fp64 oracle
+reported next to the native kernel's on the same inputs."""
+import numpy as np
+import pytest
+
+from oracle import vmc_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+# (n, h, L, b, lattice): padded to 256 units in every case (the experiment covers 193 .. 256 units)
+SHAPES = [(16, 256, 2, 96, 'torus4x4'), (36, 200, 3, 70, 'torus6x6'), (100, 256, 3, 160, 'torus10x10'),
+          (40, 256, 4, 33, 'chain')]
+
+
+def _bonds(kind, n):
+  if kind == 'chain':
+    return vo.chain_bonds(n)
+  side = int(kind[5:].split('x')[0])
+  return vo.torus_bonds(side, n // side)
+
+
+def _engine(monkeypatch, split, n, h, L, b, kind, seed=0):
+  from cgs_vmc_amd.engine import VmcEngine
+  if split:
+    monkeypatch.setenv('CGS_VMC_SPLIT_BF16', '1')
+  else:
+    monkeypatch.delenv('CGS_VMC_SPLIT_BF16', raising=False)
+  rng = np.random.default_rng(seed)
+  theta = vo.init_params(n, h, L, rng) + (0.03 * rng.standard_normal(vo.num_params(n, h, L))).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(seed + 1))
+  bonds = _bonds(kind, n)
+  eng = VmcEngine(n, b, L, h, seed=2024)
+  eng.set_params(theta); eng.set_configs(cfg); eng.set_bonds(bonds, -1.0, 1.0)
+  assert eng.kernel_path() == (4 if split else 0)
+  return eng, theta, cfg, bonds
+
+
+@pytest.mark.parametrize('n,h,L,b,kind', SHAPES)
+def test_split_rows_meet_the_native_tolerances(monkeypatch, n, h, L, b, kind):
+  ref_logit = ref_eloc = None
+  errs = {}
+  for split in (False, True):
+    eng, theta, cfg, bonds = _engine(monkeypatch, split, n, h, L, b, kind)
+    if ref_logit is None:
+      amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+      ref_logit = vo.fc_logit(theta, cfg, h, L, dtype=np.float64)
+      ref_eloc = vo.local_value(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64)
+    logit = eng.amplitude()[0].astype(np.float64)
+    ext = eng.amplitude(cfg[:9])[0].astype(np.float64)          # rows supplied by the caller
+    eloc = eng.local_energy()[0].astype(np.float64)
+    e_logit = np.abs(logit - ref_logit).max() / max(1.0, np.abs(ref_logit).max())
+    e_eloc = np.abs(eloc - ref_eloc).max() / max(1.0, np.abs(ref_eloc).max())
+    errs[split] = (e_logit, e_eloc)
+    assert e_logit <= 2e-5 and e_eloc <= 2e-4, (split, errs)                       # tests/test_gpu_engine.py's bars
+    assert np.abs(ext - ref_logit[:9]).max() <= 2e-5 * max(1.0, np.abs(ref_logit).max())
+    eng.close()
+  print('\nmax error / scale vs the fp64 oracle  logit: native {:.2e} split {:.2e}   E_loc: native {:.2e} split {:.2e}'
+        .format(errs[False][0], errs[True][0], errs[False][1], errs[True][1]))
+  # the split is an fp32-grade computation, not a bf16-grade one
+  assert errs[True][0] <= 4 * errs[False][0] + 2e-6 and errs[True][1] <= 4 * errs[False][1] + 2e-5
+
+
+def test_split_rows_at_config3_full_size(monkeypatch):
+  """BASELINE config 3 (10x10, FC 3x256, 4096 chains) on the split kernel: logits and local energies of
+  every 64th chain against the fp64 oracle before and after a sweep (tests/test_gpu_fullsize.py's bars);
+  the sampler is the native fp32 kernel either way, so the chains are the native ones."""
+  import bench
+  from cgs_vmc_amd.engine import VmcEngine
+  n, h, L, b = 100, 256, 3, 4096
+  theta, cfg = bench.make_inputs(n, h, L, b, 0)
+  bonds = vo.torus_bonds(10, 10, False)
+  outs = {}
+  for split in (False, True):
+    if split:
+      monkeypatch.setenv('CGS_VMC_SPLIT_BF16', '1')
+    else:
+      monkeypatch.delenv('CGS_VMC_SPLIT_BF16', raising=False)
+    eng = VmcEngine(n, b, L, h, seed=2024)
+    eng.set_params(theta); eng.set_configs(cfg); eng.set_bonds(bonds, -1.0, 1.0)
+    assert eng.kernel_path() == (4 if split else 0)
+    e0 = eng.local_energy()[0]
+    eng.mc_steps(n)
+    outs[split] = (e0, eng.get_configs(), eng.amplitude()[0], eng.local_energy()[0])
+    eng.close()
+  np.testing.assert_array_equal(outs[False][1], outs[True][1])            # same sampler, same chains
+  pick = np.arange(0, b, 64)
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+  moved = outs[True][1]
+  ref_logit = vo.fc_logit(theta, moved[pick], h, L, dtype=np.float64)
+  ref_e0 = vo.local_value(amp, cfg[pick], bonds, -1.0, 1.0, dtype=np.float64)
+  ref_e1 = vo.local_value(amp, moved[pick], bonds, -1.0, 1.0, dtype=np.float64)
+  for split in (False, True):
+    e0, _, logit, e1 = outs[split]
+    assert np.abs(e0[pick] - ref_e0).max() <= 2e-4 * max(1.0, np.abs(ref_e0).max()), split
+    assert np.abs(e1[pick] - ref_e1).max() <= 2e-4 * max(1.0, np.abs(ref_e1).max()), split
+  # (the cached logits after a sweep come from the sampler, not from the row kernel)
+  assert np.abs(outs[True][2][pick] - ref_logit).max() <= 2e-5 * max(1.0, np.abs(ref_logit).max())
+  assert np.abs(outs[True][3] - outs[False][3]).max() <= 2e-4 * max(1.0, np.abs(outs[False][3]).max())
+
+
+def test_split_is_refused_silently_where_it_does_not_apply(monkeypatch):
+  """The switch only acts on shapes the experiment covers; everything else keeps its native kernels."""
+  from cgs_vmc_amd.engine import VmcEngine
+  monkeypatch.setenv('CGS_VMC_SPLIT_BF16', '1')
+  for kw in (dict(layer_size=128), dict(layer_size=256, nonlinearity='tanh'), dict(layer_size=256, ansatz='rbm')):
+    eng = VmcEngine(16, 32, 2, kw.pop('layer_size'), **kw)
+    assert eng.kernel_path() == 0
+    eng.close()
