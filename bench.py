@@ -794,10 +794,11 @@ def main():
       # tools/collect_profiles.sh); null when no matching profile is present
       traffic = None
       pmc = None
-      suffix = {'heisenberg10x10_fc3x256_b4096': '', 'heisenberg16x16j1j2_fc6x256_b1024': '_config5',
+      suffix = {'heisenberg10x10_fc3x256_b4096': '', 'heisenberg10x10_fc3x256_b4096_split3xbf16': '_split',
+                'heisenberg16x16j1j2_fc6x256_b1024': '_config5',
                 'heisenberg10x10_conv5x16k5_b4096': '_conv', 'heisenberg16x16j1j2_conv5x16k5_b1024': '_conv16',
                 'heisenberg10x10_fc3x512_b4096': '_fc3x512', 'heisenberg10x10_conv5x32k5_b4096': '_conv32'}.get(args.workload)
-      for rnd in ('r3', 'r2'):                    # the newest committed profile of this workload
+      for rnd in ('r4', 'r3', 'r2'):              # the newest committed profile of this workload
         tag = None if suffix is None else rnd + suffix
         tpath = os.path.join(ROOT, 'profiles', '{}_traffic.json'.format(tag))
         if tag and os.path.exists(tpath):
@@ -808,7 +809,7 @@ def main():
           prof = json.load(open(tpath))
           collected_at = prof.pop('_collected_at_source_hash', None)
           for name, rec in prof.items():
-            if name.startswith(key.split('(')[0]) and rec.get('hbm_read_bytes') is not None:
+            if name.startswith('k_tail16s' if (split and key == k_eloc) else key.split('(')[0]) and rec.get('hbm_read_bytes') is not None:
               traffic = rec['hbm_read_bytes'] + (rec.get('hbm_write_bytes') or 0)
               pmc = {k: rec[k] for k in ('mfma_util', 'clock_ghz', 'median_us') if k in rec}
               pmc['source'] = 'profiles/{}_traffic.json'.format(tag)

@@ -221,9 +221,14 @@ hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp,
 // d logit / d z_l of every layer: act_all / delta_all are [n_hidden + 1][B][Hp]
 // act: hidden activation id; dact_all: f'(z) arrays (cosine only) or nullptr; oscale: [B]
 // (1/psi) d psi / d x of a non-exp output activation or nullptr
+// eloc: the local-energy reduction of the same accumulate call rides in this launch (k_eloc_reduce's job,
+// chain by chain with its summation order: the workgroup that owns 16 chains also folds their rows of
+// `val`), one dependent launch (6 us at config 3) less per step; off == nullptr: nothing to fold
+struct ElocFold { const int* off; const float* diag; const float* val; float* offdiag; float* eloc; };
 hipError_t launch_backprop16(hipStream_t s, const float* act_all, float* delta_all,
                              const float* p16t, const float* woutp, int B, int Hp, int n_hidden,
-                             bool rbm, int act, const float* dact_all, const float* oscale);
+                             bool rbm, int act, const float* dact_all, const float* oscale,
+                             const ElocFold& eloc = ElocFold{nullptr, nullptr, nullptr, nullptr, nullptr});
 hipError_t launch_tail(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm);
 hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, int rows, int N,
                          float* out);

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
                                                         const float* __restrict__ woutp, int B,
                                                         int n_hidden, int rbm,
                                                         const float* __restrict__ dact_all,
-                                                        const float* __restrict__ oscale) {
+                                                        const float* __restrict__ oscale, ElocFold ef) {
   constexpr int Hp = NT * 16, TO = NT / NW, PF = 4;
   static_assert(NT % NW == 0 && NT % PF == 0, "tiles divide over waves and the prefetch ring");
   __shared__ __attribute__((aligned(16))) float s_x[2 * NT * 256];   // [2][NT][64 lanes][4]
@@ -381,6 +381,25 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
     return d;
   };
   const float osc = (oscale && ok) ? oscale[chain] : 1.f;
+  // local energies of this workgroup's 16 chains (k_eloc_reduce's job and order: lane-strided partial
+  // sums, xor tree): wave w takes chains 16 / NW at a time.  Nothing below reads them.
+  if (ef.off) {
+#pragma unroll
+    for (int q = 0; q < 16 / NW; ++q) {
+      const int c = blockIdx.x * 16 + wave * (16 / NW) + q;
+      if (c < B) {
+        const int r0 = ef.off[c], r1 = ef.off[c + 1];
+        float sum = 0.f;
+        for (int r = r0 + lane; r < r1; r += 64) sum += ef.val[r];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+        if (lane == 0) {
+          if (ef.offdiag) ef.offdiag[c] = sum;
+          ef.eloc[c] = ef.diag[c] + sum;
+        }
+      }
+    }
+  }
 
   // last layer's delta for this wave's own unit tiles
   {
@@ -453,18 +472,18 @@ template <int ACT>
 static hipError_t launch_backprop16_t(hipStream_t s, const float* act_all, float* delta_all,
                                       const float* p16t, const float* woutp, int B, int Hp,
                                       int n_hidden, bool rbm, const float* dact_all,
-                                      const float* oscale) {
+                                      const float* oscale, const ElocFold& ef) {
   if (B <= 0) return hipSuccess;
   const dim3 grid((B + 15) / 16);
   const int r = rbm ? 1 : 0;
   switch (Hp / 16) {
-    case 4: hipLaunchKernelGGL((k_backprop16<4, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale); break;
-    case 8: hipLaunchKernelGGL((k_backprop16<8, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale); break;
-    case 12: hipLaunchKernelGGL((k_backprop16<12, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale); break;
-    case 16: hipLaunchKernelGGL((k_backprop16<16, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale); break;
+    case 4: hipLaunchKernelGGL((k_backprop16<4, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
+    case 8: hipLaunchKernelGGL((k_backprop16<8, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
+    case 12: hipLaunchKernelGGL((k_backprop16<12, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
+    case 16: hipLaunchKernelGGL((k_backprop16<16, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
     // 257 .. 512 hidden units (384 / 512 padded): wave w owns 3 or 4 output tiles, 48 / 64 KB of operands in LDS
-    case 24: hipLaunchKernelGGL((k_backprop16<24, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale); break;
-    case 32: hipLaunchKernelGGL((k_backprop16<32, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale); break;
+    case 24: hipLaunchKernelGGL((k_backprop16<24, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
+    case 32: hipLaunchKernelGGL((k_backprop16<32, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

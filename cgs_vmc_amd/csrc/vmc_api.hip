@@ -470,7 +470,10 @@ int ensure_list(vmc_ctx* c) {
 }
 
 // eloc[which] on device
-int local_energy_device(vmc_ctx* c, int which) {
+// defer_reduce: the caller folds the rows into eloc itself (vmc_accumulate lets k_backprop16 do it: one
+// dependent launch less per step); *deferred tells whether that is still owed
+int local_energy_device(vmc_ctx* c, int which, bool defer_reduce = false, bool* deferred = nullptr) {
+  if (deferred) *deferred = false;
   PROPAGATE(ensure_cache(c, which));
   PROPAGATE(ensure_list(c));
   ParamSet& p = c->ps[which];
@@ -505,6 +508,10 @@ int local_energy_device(vmc_ctx* c, int which) {
     if (c->expect_sweep && can_overlap(c) && c->num_cus - sweep_cus(c) >= c->num_cus / 4)
       a.num_cus = c->num_cus - sweep_cus(c);
     HIPCHK(c, launch_rows(c, which, a, true));
+  }
+  if (defer_reduce && deferred && !c->conv && !(c->wide && !c->wide_fast)) {
+    *deferred = true;              // the fused back-propagation launch folds val into eloc
+    return VMC_OK;
   }
   {
     Timer t(c, "eloc_reduce");
@@ -1250,7 +1257,8 @@ int vmc_last_connected_rows(vmc_ctx* c, int64_t* rows) { CHECK_CTX(c); if (!rows
 // sum_b O_k(b) -> g1, sum_b w_b O_k(b) -> g2 for the psi parameter set
 // `e` / `mode`: the scalar accumulators (sum E, counts, sum ratio) ride in the reduction launch of the
 // dense weight-gradient GEMMs; *scalars_done tells the caller whether they did
-static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e, int mode, bool* scalars_done) {
+static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e, int mode, bool* scalars_done,
+                         bool fold_eloc = false) {
   *scalars_done = false;
   ParamSet& p = c->ps[0];
   const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, NH = c->n_hh;
@@ -1317,7 +1325,9 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e,
     }
   } else
   HIPCHK(c, launch_backprop16(c->stream, c->act_all, c->delta_all, p.p16t, p.woutp, B, Hp, NH, c->rbm, c->hact,
-                              c->dact_all, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr));
+                              c->dact_all, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr,
+                              fold_eloc ? ElocFold{c->off, c->diag, c->val, c->offdiag, c->ps[0].eloc}
+                                        : ElocFold{nullptr, nullptr, nullptr, nullptr, nullptr}));
   // Every weight gradient is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows 0..K_in-1 give dW, the
   // implicit ones row gives db (b_l sits right behind w_l in theta), the unscaled product goes to g1 and
   // the w-scaled one to g2.  All NH+2 of them and the scalar accumulators run as
@@ -1393,8 +1403,9 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   // psi cache the sampler reads, the launch must wait for all of it instead.
   const bool cache_was_valid = c->ps[0].cache_valid && c->ps[0].packed_valid;
   if (can_overlap(c)) HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));
+  bool fold_eloc = false;
   if (mode == VMC_MODE_ENERGY_GRADIENT) {
-    PROPAGATE(local_energy_device(c, VMC_PSI));               // training.py:542-543
+    PROPAGATE(local_energy_device(c, VMC_PSI, true, &fold_eloc));   // training.py:542-543
     w = e = c->ps[0].eloc;
   } else {
     if (!c->ps[1].has_params) return fail(c, VMC_ERR_STATE, "supervisor parameters not set (vmc_transfer_params)");
@@ -1410,7 +1421,7 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   if (c->conv) PROPAGATE(acc_zeros(c));
   const bool fresh = c->acc_fresh;
   bool scalars_done = false;
-  PROPAGATE(gradient_sums(c, w, fresh, e, mode, &scalars_done));
+  PROPAGATE(gradient_sums(c, w, fresh, e, mode, &scalars_done, fold_eloc));
   if (!scalars_done)
     HIPCHK(c, launch_scalar_accum(c->stream, e, mode == 1 ? c->ratio : nullptr, c->B, c->acc + 2 * c->P, mode, fresh));
   c->acc_fresh = false;

@@ -4,7 +4,7 @@
 # Output under gpurun_out/<tag>_prof/; summarise with tools/summarise_profiles.py <tag> and the
 # summaries land in profiles/<tag>_*.
 set -euo pipefail
-TAG=${1:-r3}
+TAG=${1:-r4}
 WL=${2:-heisenberg10x10_fc3x256_b4096}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/${TAG}_prof
@@ -17,7 +17,7 @@ B="python3 $ROOT/bench.py --workload $WL --steps 10 --warmup 2 --reps 1 --no-cpu
 BS="python3 $ROOT/bench.py --workload $WL --steps 100 --warmup 10 --reps 1 --no-cpu-baseline --no-timing"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BS > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $B > $OUT/pmc_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1
 # summarise first and put the fresh traffic file where bench.py looks for it, so that the bench line
 # kept with the profile carries these counters (roofline.pmc.stale = false), then add the line

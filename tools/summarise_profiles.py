@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else 'r3'
+TAG = sys.argv[1] if len(sys.argv) > 1 else 'r4'
 SRC = os.path.join(ROOT, 'gpurun_out', TAG + '_prof')
 DST = os.path.join(ROOT, 'gpurun_out', TAG + '_summary') if os.environ.get('GRAFT_REPO_ROOT') else os.path.join(ROOT, 'profiles')
 
@@ -52,6 +52,8 @@ def main():
     for c in sorted(s):
       if c not in ('n', 'median_ns'):
         lines.append('    {:32s} {:16.0f}'.format(c, s[c]))
+    if fe.get(k, {}).get('SQ_INSTS_VALU_MFMA_MOPS_BF16'):
+      lines.append('    {:32s} {:16.0f}  (collected in the FETCH_SIZE pass)'.format('SQ_INSTS_VALU_MFMA_MOPS_BF16', fe[k]['SQ_INSTS_VALU_MFMA_MOPS_BF16']))
     f_kb = fe.get(k, {}).get('FETCH_SIZE')
     w_kb = wr.get(k, {}).get('WRITE_SIZE')
     if f_kb is not None:
