@@ -12,15 +12,27 @@ from tests.exact_states import exact_fc_eigenstate
 pytestmark = pytest.mark.gpu
 
 
-# (8 sites, 2 x 128): one H x H layer on the 4-wave kernels; (10 sites, 3 x 256): the config-3 kernels
-@pytest.mark.parametrize('n,h,L', [(8, 128, 2), (10, 256, 3)])
-def test_exact_eigenstate_on_the_hip_path(n, h, L):
+# (8 sites, 2 x 128): one H x H layer on the 4-wave kernels; (10 sites, 3 x 256): the config-3 kernels;
+# round 4: the 4 x 2 torus (a 2-D bond list with doubled bonds across the short direction), the fused
+# 384- and 512-unit kernels (k_sweep16<24|32>, k_tail_lds, k_backprop16<24|32>), and the config-3 shape with
+# the local-energy rows on the 3 x bf16 split kernel (CGS_VMC_SPLIT_BF16=1)
+CASES = [(8, 128, 2, 'chain', False), (10, 256, 3, 'chain', False), (8, 128, 2, 'torus4x2', False),
+         (10, 384, 2, 'chain', False), (10, 512, 3, 'chain', False), (10, 256, 3, 'chain', True)]
+
+
+@pytest.mark.parametrize('n,h,L,kind,split', CASES)
+def test_exact_eigenstate_on_the_hip_path(monkeypatch, n, h, L, kind, split):
   from cgs_vmc_amd import _hip
   from cgs_vmc_amd.engine import VmcEngine
-  bonds = vo.chain_bonds(n)
+  if split:
+    monkeypatch.setenv('CGS_VMC_SPLIT_BF16', '1')
+  else:
+    monkeypatch.delenv('CGS_VMC_SPLIT_BF16', raising=False)
+  bonds = vo.chain_bonds(n) if kind == 'chain' else vo.torus_bonds(4, 2)
   theta, e0, cfgs, vec = exact_fc_eigenstate(n, bonds, h, L)
   b = len(cfgs)                                   # 70 / 252: every configuration of the sector once
   eng = VmcEngine(n, b, L, h, seed=5)
+  assert eng.kernel_path() == (4 if split else (1 if h > 256 else 0))
   eng.set_params(theta)
   eng.set_shift(0.0)
   eng.set_configs(cfgs)
