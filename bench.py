@@ -66,6 +66,11 @@ WORKLOADS = {
     'heisenberg10x10_conv5x32k5_b4096': (10, 10, False, 5, 32, 4096, 'conv_2d', 5),    # two 16-channel blocks
     'heisenberg10x10_conv3x32k3_b4096': (10, 10, False, 3, 32, 4096, 'conv_2d', 3),
     'heisenberg16x16j1j2_conv5x16k5_b1024': (16, 16, True, 5, 16, 1024, 'conv_2d', 5),
+    # round 4: four channel blocks (conv64.hip), kernels beyond 7 x 7 (fragments in chunks of <= 25 taps)
+    'heisenberg10x10_conv5x64k5_b1024': (10, 10, False, 5, 64, 1024, 'conv_2d', 5),
+    'heisenberg10x10_conv3x48k3_b4096': (10, 10, False, 3, 48, 4096, 'conv_2d', 3),
+    'heisenberg10x10_conv3x16k9_b4096': (10, 10, False, 3, 16, 4096, 'conv_2d', 9),
+    'heisenberg10x10_conv3x32k7_b4096': (10, 10, False, 3, 32, 4096, 'conv_2d', 7),
 }
 
 

@@ -1,14 +1,28 @@
 // Convolutional ansatz types on gfx950: host side (launchers, LDS budgets, parameter packing, the
 // weight-gradient reduction) and the kernels for up to 16 filters (NCB = 1).  The kernels are the
-// templates of conv_kernels.hpp; conv32.hip instantiates them for 17 .. 32 filters (NCB = 2).
+// templates of conv_kernels.hpp; conv32 / conv48 / conv64.hip instantiate them for 17 .. 64 filters (NCB = 2, 3, 4).
 #include "conv_kernels.hpp"
 
-// NCB = 2 launchers (conv32.hip)
-hipError_t conv_launch_rows_cb2(hipStream_t s, const ConvRowsArgs& a, dim3 grid, size_t lds);
-hipError_t conv_launch_sweep_cb2(hipStream_t s, const ConvSweepArgs& a, dim3 grid, size_t lds);
-hipError_t conv_launch_back_cb2(hipStream_t s, const ConvBackArgs& a, dim3 grid, size_t lds);
-hipError_t conv_launch_dw_cb2(hipStream_t s, const ConvDwArgs& a, dim3 grid, size_t lds);
-hipError_t conv_launch_sr_rowdot_cb2(hipStream_t s, const ConvSrRowdotArgs& a, dim3 grid, size_t lds);
+// NCB = 2, 3, 4 launchers (conv32.hip, conv48.hip, conv64.hip through conv_wide.hpp)
+#define CONV_DECLARE_CB(N)                                                                              \
+  hipError_t conv_launch_rows_cb##N(hipStream_t s, const ConvRowsArgs& a, dim3 grid, size_t lds);       \
+  hipError_t conv_launch_sweep_cb##N(hipStream_t s, const ConvSweepArgs& a, dim3 grid, size_t lds);     \
+  hipError_t conv_launch_back_cb##N(hipStream_t s, const ConvBackArgs& a, dim3 grid, size_t lds);       \
+  hipError_t conv_launch_dw_cb##N(hipStream_t s, const ConvDwArgs& a, dim3 grid, size_t lds);           \
+  hipError_t conv_launch_sr_rowdot_cb##N(hipStream_t s, const ConvSrRowdotArgs& a, dim3 grid, size_t lds);
+CONV_DECLARE_CB(2)
+CONV_DECLARE_CB(3)
+CONV_DECLARE_CB(4)
+// the instantiation for a.g.NCB channel blocks (vmc_create admits 1 .. CONV_MAX_NCB)
+#define CONV_BY_NCB(NAME, ...)                                         \
+  switch (a.g.NCB) {                                                   \
+    case 1: return conv_launch_##NAME##_t<1>(__VA_ARGS__);             \
+    case 2: return conv_launch_##NAME##_cb2(__VA_ARGS__);              \
+    case 3: return conv_launch_##NAME##_cb3(__VA_ARGS__);              \
+    case 4: return conv_launch_##NAME##_cb4(__VA_ARGS__);              \
+    default: return hipErrorInvalidValue;                              \
+  }
+static_assert(CONV_MAX_NCB == 4, "one launcher set per channel-block count");
 
 namespace {
 
@@ -115,34 +129,31 @@ hipError_t launch_conv_rows(hipStream_t s, const ConvRowsArgs& a, int num_cus) {
   if (a.n_rows <= 0) return hipSuccess;
   const size_t lds = conv_rows_lds(a.g, a.G);
   const dim3 grid(plan_conv_grid(a.g, a.n_rows, a.G, num_cus));      // one workgroup per co-resident slot
-  if (a.g.NCB == 2) return conv_launch_rows_cb2(s, a, grid, lds);
-  return conv_launch_rows_t<1>(s, a, grid, lds);
+  CONV_BY_NCB(rows, s, a, grid, lds);
 }
 
 hipError_t launch_conv_sweep(hipStream_t s, const ConvSweepArgs& a) {
   const dim3 grid((a.B + a.G - 1) / a.G);
   const size_t lds = conv_rows_lds(a.g, a.G);
-  if (a.g.NCB == 2) return conv_launch_sweep_cb2(s, a, grid, lds);
-  return conv_launch_sweep_t<1>(s, a, grid, lds);
+  CONV_BY_NCB(sweep, s, a, grid, lds);
 }
 
 hipError_t launch_conv_back(hipStream_t s, const ConvBackArgs& a, int num_cus) {
   const size_t lds = conv_rows_lds(a.g, a.G);
   const dim3 grid(plan_conv_grid(a.g, a.B, a.G, num_cus));
-  if (a.g.NCB == 2) return conv_launch_back_cb2(s, a, grid, lds);
-  return conv_launch_back_t<1>(s, a, grid, lds);
+  CONV_BY_NCB(back, s, a, grid, lds);
 }
 
 hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a_in) {
   ConvDwArgs a = a_in;
-  const dim3 grid(a.n_slices, a.g.n_conv);
+  const dim3 grid(a.n_slices, a.g.n_conv, plan_conv_dw_grid_z(a.g));
   // the whole sample at once when it fits (two workgroups per CU at 16 filters when THAT fits), else
   // the largest band of rows that does
   const char* e_band = getenv("CGS_VMC_CONV_DW_BAND");      // test knob: force bands of this many rows
   a.band_rows = plan_conv_dw_band(a.g, e_band ? atoi(e_band) : 0);
   if (a.band_rows < 1) return hipErrorInvalidValue;
   const size_t lds = plan_conv_dw_lds(a.g, a.band_rows);
-  hipError_t e = a.g.NCB == 2 ? conv_launch_dw_cb2(s, a, grid, lds) : conv_launch_dw_t<1>(s, a, grid, lds);
+  hipError_t e = [&]() -> hipError_t { CONV_BY_NCB(dw, s, a, grid, lds); }();
   if (e != hipSuccess) return e;
   const long long np_max = (long long)a.g.K * a.g.KW * a.g.F * a.g.F + a.g.F;
   hipLaunchKernelGGL(k_conv_dw_reduce, dim3((unsigned)((np_max + 63) / 64), a.g.n_conv), dim3(256), 0, s, a,
@@ -154,6 +165,5 @@ hipError_t launch_conv_sr_rowdot(hipStream_t s, const ConvSrRowdotArgs& a, int n
   if (a.n_rows <= 0) return hipSuccess;
   const size_t lds = conv_rows_lds(a.g, a.G);
   const dim3 grid(plan_conv_grid(a.g, a.n_rows, a.G, num_cus));
-  if (a.g.NCB == 2) return conv_launch_sr_rowdot_cb2(s, a, grid, lds);
-  return conv_launch_sr_rowdot_t<1>(s, a, grid, lds);
+  CONV_BY_NCB(sr_rowdot, s, a, grid, lds);
 }

@@ -89,10 +89,20 @@ struct ConvSmem {
   // periodic neighbour tables, built once per kernel (the wrap arithmetic costs ~15 VALU
   // instructions per tap column / row and tile otherwise): rtab[dir][a1][d] = 16 D2 ((a1 + d - lo)
   // mod D1), ctab[dir][a2][d] = 16 ((a2 + d - lo) mod D2) in bytes (one v_add3 per tap and tile), lo = g.lo (dir 0: forward) or
-  // g.hi (dir 1: transposed convolution); rows of 8 ints
-  int* rtab;        // [2][D1][8]
-  int* ctab;        // [2][D2][8]
+  // g.hi (dir 1: transposed convolution); rows of plan_conv_tab(g) ints (8; 16 beyond 8 taps per axis)
+  int* rtab;        // [2][D1][tab]
+  int* ctab;        // [2][D2][tab]
 };
+
+// f(integral_constant<int, 0>), ..., f(integral_constant<int, N - 1>)
+template <typename F, int... I>
+__device__ __forceinline__ void conv_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void conv_static_for(F&& f) {
+  conv_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 __device__ __forceinline__ int conv_xs_stride(const ConvGeom& g) { return (g.N + 3) & ~3; }
 
@@ -105,7 +115,7 @@ __device__ __forceinline__ ConvSmem conv_carve(float* base, const ConvGeom& g, i
   s.row_chain = (int*)(s.pinfo + (size_t)G * g.N);
   s.red = (float*)(s.row_chain + G);
   s.rtab = (int*)(s.red + 6 * G);       // red, cur_logit, prop[2], prop_u of the sampler + spare
-  s.ctab = s.rtab + 2 * g.D1 * 8;
+  s.ctab = s.rtab + 2 * g.D1 * plan_conv_tab(g);
   return s;
 }
 
@@ -121,10 +131,11 @@ __device__ __forceinline__ void conv_build_pinfo(const ConvSmem& sm, const ConvG
     const int a1 = site / g.D2, a2 = site - a1 * g.D2;
     sm.pinfo[q] = pack_pos(s, a1, a2);
   }
-  for (int i = threadIdx.x; i < 2 * (g.D1 + g.D2) * 8; i += blockDim.x) {
-    const bool is_r = i < 2 * g.D1 * 8;
-    const int j = is_r ? i : i - 2 * g.D1 * 8, D = is_r ? g.D1 : g.D2;
-    const int dir = j / (D * 8), a = (j / 8) % D, d = j & 7;
+  const int tab = plan_conv_tab(g);
+  for (int i = threadIdx.x; i < 2 * (g.D1 + g.D2) * tab; i += blockDim.x) {
+    const bool is_r = i < 2 * g.D1 * tab;
+    const int j = is_r ? i : i - 2 * g.D1 * tab, D = is_r ? g.D1 : g.D2;
+    const int dir = j / (D * tab), a = (j / tab) % D, d = j & (tab - 1);
     const int lo = is_r ? (dir ? g.hi : g.lo) : (dir ? g.hi2 : g.lo2);
     const int w = ((a + min(d, (is_r ? g.K : g.KW) - 1) - lo) % D + D) % D;
     (is_r ? sm.rtab : sm.ctab)[j] = is_r ? 16 * g.D2 * w : 16 * w;     // byte offsets
@@ -155,6 +166,7 @@ __device__ __forceinline__ void conv_first(const ConvSmem& sm, float* out, const
                                            const ConvParams& p, int G, int ep, int wave, int lane,
                                            float* tape_out, long long tape_rows) {
   constexpr int Q0 = (K * KW + 3) / 4;
+  constexpr int CONV_TAB = K <= 8 ? 8 : 16;       // plan_conv_tab(g)
   const int pl = lane & 15, gl = lane >> 4;
   float w0[NCB][Q0];
   f32x4 bias[NCB];
@@ -182,7 +194,7 @@ __device__ __forceinline__ void conv_first(const ConvSmem& sm, float* out, const
     const float* xs = sm.xs + s * xs_stride;
     float bx[Q0];
 #pragma unroll
-    for (int qq = 0; qq < Q0; ++qq) bx[qq] = xs[(sm.rtab[a1 * 8 + d1[qq]] + sm.ctab[a2 * 8 + d2[qq]]) >> 4];
+    for (int qq = 0; qq < Q0; ++qq) bx[qq] = xs[(sm.rtab[a1 * CONV_TAB + d1[qq]] + sm.ctab[a2 * CONV_TAB + d2[qq]]) >> 4];
     const int site = a1 * g.D2 + a2;
     const int row = sm.row_chain[s];
 #pragma unroll
@@ -249,6 +261,7 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
                                            int dir, int G, int ep, int wave, int lane,
                                            const float* tape_in, float* tape_out) {
   constexpr int KK = K * KW;
+  constexpr int CONV_TAB = K <= 8 ? 8 : 16;       // plan_conv_tab(g)
   const int pl = lane & 15, gl = lane >> 4;
   const int n_pos = G * g.N, n_tiles = (n_pos + 15) >> 4;
   // position descriptors + the tap loop of NTL adjacent tiles for one (co, ci) block pair:
@@ -256,8 +269,10 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
   // the MFMAs that consume them (3-stage register ring per tile; the sched_barrier keeps the
   // compiler from sinking the reads back next to their use, which would expose one LDS round trip
   // per tap)
-  auto taps = [&](int t0, auto nt_c, int ci, const f32x4 (&w)[KK], f32x4* acc) {
+  // `tb_c`, `tn_c`: the taps [TB, TB + TN) of the kernel, whose fragments are w[0 .. TN)
+  auto taps = [&](int t0, auto nt_c, auto tb_c, auto tn_c, int ci, const f32x4* w, f32x4* acc) {
     constexpr int NTL = decltype(nt_c)::value;
+    constexpr int TB = decltype(tb_c)::value, TN = decltype(tn_c)::value;
     const char* base[NTL];
     int roff[NTL][K], coff[NTL][KW];
 #pragma unroll
@@ -266,8 +281,8 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
       const unsigned info = sm.pinfo[q < n_pos ? q : n_pos - 1];
       const int a2 = info & 1023, a1 = (info >> 10) & 1023, sl = info >> 20;
       base[h] = (const char*)(in + (size_t)sl * g.CS + (4 * ci + gl) * g.GS);
-      const int* rt = sm.rtab + (dir * g.D1 + a1) * 8;
-      const int* ct = sm.ctab + (dir * g.D2 + a2) * 8;
+      const int* rt = sm.rtab + (dir * g.D1 + a1) * CONV_TAB;
+      const int* ct = sm.ctab + (dir * g.D2 + a2) * CONV_TAB;
 #pragma unroll
       for (int d = 0; d < K; ++d) roff[h][d] = rt[d];
 #pragma unroll
@@ -276,22 +291,22 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
     f32x4 bq[NTL][3];
 #pragma unroll
     for (int h = 0; h < NTL; ++h) {
-      bq[h][0] = *(const f32x4*)(base[h] + roff[h][0] + coff[h][0]);
-      if (KK > 1) bq[h][1] = *(const f32x4*)(base[h] + roff[h][KK > 1 ? 1 / KW : 0] + coff[h][KK > 1 ? 1 % KW : 0]);
+      bq[h][0] = *(const f32x4*)(base[h] + roff[h][TB / KW] + coff[h][TB % KW]);
+      if (TN > 1) bq[h][1] = *(const f32x4*)(base[h] + roff[h][TN > 1 ? (TB + 1) / KW : 0] + coff[h][TN > 1 ? (TB + 1) % KW : 0]);
     }
 #pragma unroll
-    for (int tap = 0; tap < KK; ++tap) {
-      if (tap + 2 < KK) {
+    for (int tp = 0; tp < TN; ++tp) {
+      if (tp + 2 < TN) {
 #pragma unroll
         for (int h = 0; h < NTL; ++h)
-          bq[h][(tap + 2) % 3] = *(const f32x4*)(base[h] + roff[h][(tap + 2) / KW] + coff[h][(tap + 2) % KW]);
+          bq[h][(tp + 2) % 3] = *(const f32x4*)(base[h] + roff[h][(TB + tp + 2) / KW] + coff[h][(TB + tp + 2) % KW]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int h = 0; h < NTL; ++h)
-          acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][e], bq[h][tap % 3][e], acc[h], 0, 0, 0);
+          acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tp][e], bq[h][tp % 3][e], acc[h], 0, 0, 0);
     }
   };
   auto store = [&](int t, int co, const f32x4& v) {
@@ -301,12 +316,16 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
     const int a2 = info & 1023, a1 = (info >> 10) & 1023, sl = info >> 20;
     conv_store_tile(sm, g, out, ep, NCB, co, gl, valid, sl, a1 * g.D2 + a2, v, tape_in, tape_out);
   };
+  constexpr std::integral_constant<int, 0> c0{};
+  constexpr std::integral_constant<int, 1> c1{};
+  constexpr std::integral_constant<int, 2> c2{};
 
-  if constexpr (NCB == 1) {
+  if constexpr (NCB == 1 && KK <= 49) {
     // every fragment of the layer stays in registers; a wave's tiles in pairs (2w, 2w+1),
     // (2w + 2 NW, ...); an odd last tile runs alone.  With more than 25 taps (6 x 6: 144 weight
     // registers) the pair's second accumulator set would spill, so those kernels take the two tiles
     // one after the other.
+    constexpr std::integral_constant<int, KK> ckk{};
     f32x4 w[KK];
 #pragma unroll
     for (int t = 0; t < KK; ++t) w[t] = *(const f32x4*)(wfrag + ((size_t)t * 64 + lane) * 4);
@@ -316,15 +335,15 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
     for (int t0 = 2 * wave; t0 < n_tiles; t0 += 2 * CONV_WAVES) {
       if (PAIR && t0 + 1 < n_tiles) {
         f32x4 acc[2] = {bias, bias};
-        taps(t0, std::integral_constant<int, 2>{}, 0, w, acc);
+        taps(t0, c2, c0, ckk, 0, w, acc);
         store(t0, 0, acc[0]); store(t0 + 1, 0, acc[1]);
       } else {
         f32x4 acc[1] = {bias};
-        taps(t0, std::integral_constant<int, 1>{}, 0, w, acc);
+        taps(t0, c1, c0, ckk, 0, w, acc);
         store(t0, 0, acc[0]);
         if (!PAIR && t0 + 1 < n_tiles) {
           f32x4 acc1[1] = {bias};
-          taps(t0 + 1, std::integral_constant<int, 1>{}, 0, w, acc1);
+          taps(t0 + 1, c1, c0, ckk, 0, w, acc1);
           store(t0 + 1, 0, acc1[0]);
         }
       }
@@ -332,8 +351,12 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
   } else {
     // NCB x NCB block products.  The wave's tile pairs are taken TC at a time; for one output block
     // their accumulators live in registers while the fragments of (co, ci = 0), (co, 1), ... are
-    // loaded in turn and swept over all of them.
-    constexpr int TC = KK <= 25 ? 4 : 2;
+    // loaded in turn and swept over all of them -- in NCH chunks of at most 25 taps (100 registers),
+    // so that the accumulators of four tile pairs and a chunk fit the 256 registers of a wave at any
+    // kernel size (6 x 6: 2 x 18 taps, 7 x 7: 25 + 24, 8 x 8: 3 x 22, 9 x 9: 4 x 21).  Also the
+    // single-block kernels beyond 7 x 7, whose fragments no longer fit the registers at once.
+    constexpr int NCH = (KK + 24) / 25, CH = (KK + NCH - 1) / NCH;
+    constexpr int TC = 4;
     const int n_pairs = (n_tiles + 1) >> 1;
     for (int k0 = 0; wave + CONV_WAVES * k0 < n_pairs; k0 += TC) {
 #pragma unroll 1
@@ -345,15 +368,22 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
         for (int c = 0; c < TC; ++c) { acc[c][0] = bias; acc[c][1] = bias; }
 #pragma unroll 1
         for (int ci = 0; ci < NCB; ++ci) {
-          f32x4 w[KK];
           const float* wp = wfrag + (size_t)(co * NCB + ci) * KK * 256;
+          // (one channel block: the fragments do not depend on the tile loop, and hoisting all of them out
+          // of it is what no longer fits the registers -- keep the loads of a chunk next to its use)
+          if (NCB == 1) asm volatile("" : "+v"(wp));
+          conv_static_for<NCH>([&](auto ch_c) {
+            constexpr int TB = decltype(ch_c)::value * CH, TN = TB + CH <= KK ? CH : KK - TB;
+            f32x4 w[TN];
 #pragma unroll
-          for (int t = 0; t < KK; ++t) w[t] = *(const f32x4*)(wp + ((size_t)t * 64 + lane) * 4);
+            for (int t = 0; t < TN; ++t) w[t] = *(const f32x4*)(wp + ((size_t)(TB + t) * 64 + lane) * 4);
 #pragma unroll
-          for (int c = 0; c < TC; ++c) {
-            const int pi = wave + CONV_WAVES * (k0 + c);
-            if (pi < n_pairs) taps(2 * pi, std::integral_constant<int, 2>{}, ci, w, acc[c]);   // wave-uniform
-          }
+            for (int c = 0; c < TC; ++c) {
+              const int pi = wave + CONV_WAVES * (k0 + c);
+              if (pi < n_pairs)    // wave-uniform
+                taps(2 * pi, c2, std::integral_constant<int, TB>{}, std::integral_constant<int, TN>{}, ci, w, acc[c]);
+            }
+          });
         }
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
@@ -751,18 +781,26 @@ __global__ __launch_bounds__(CONV_THREADS, CONV_WG_PER_CU) void k_conv_sr_rowdot
 #define DW_WAVES 8   // the weight-gradient kernel splits the items over 8 waves
 template <int K, int KW, int NCB, bool BOTH, bool FIRST>
 __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
+  constexpr int NCO = plan_conv_dw_nco(K, KW, NCB);              // output channel blocks of this workgroup
+  constexpr int NTP = plan_conv_dw_parts(K, KW, NCB);            // parts the items of a layer > 0 are cut into (grid z)
   constexpr int KK = K * KW;
   constexpr int NI = KK + 1;                                     // items of a layer > 0: the taps, then the bias
   constexpr int T0 = (KK + 15) / 16;                             // tap tiles of the first layer
-  constexpr int TPW = FIRST ? (T0 + DW_WAVES - 1) / DW_WAVES : (NI + DW_WAVES - 1) / DW_WAVES;   // items per wave
-  constexpr int CW = 16 * NCB;                                   // staged channels per site
+  constexpr int TPW = FIRST ? (T0 + DW_WAVES - 1) / DW_WAVES : (NI + DW_WAVES * NTP - 1) / (DW_WAVES * NTP);   // items per wave
+  static_assert(DW_WAVES == PLAN_DW_WAVES, "plan.hpp sizes the item parts for this many waves");
+  constexpr int CW = 16 * NCB;                                   // staged input channels per site
+  constexpr int CWD = 16 * NCO;                                  // staged delta channels per site (this workgroup's output blocks)
   constexpr int CI = FIRST ? 1 : NCB;                            // input channel blocks
-  constexpr int NA = TPW * CI * NCB;
-  constexpr int GQ = 4 * NCB;                                    // f32x4 channel groups per site
-  constexpr int U = NCB == 1 ? 4 : 5;                            // prefetched vectors per thread
+  constexpr int NA = TPW * CI * NCO;
+  constexpr int GQ = 4 * NCB, GQD = 4 * NCO;                     // f32x4 channel groups per site: input, delta
+  constexpr int U = NCB == 1 ? 4 : (NCB == 2 ? 5 : 7);           // prefetched vectors per thread
   constexpr int WGT = DW_WAVES * 64;
   const ConvGeom& g = a.g;
   const int l = blockIdx.y;
+  const int co0 = (blockIdx.z % (NCB / NCO)) * NCO;   // first output channel block of this workgroup
+  const int part = blockIdx.z / (NCB / NCO);       // its part of the items (uniform)
+  if (FIRST && part > 0) return;                   // the first layer's tap tiles fit one part
+  const int i0 = part * TPW;                       // first item slot of this part
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ml = lane & 15, gl = lane >> 4;
@@ -771,10 +809,10 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
   const int RB = a.band_rows;
   const int NQ = (RB * D2p + 3) & ~3;              // positions walked per band (padded numbering), whole quads
   const int NIN = NQ + (K - 1) * D2p + KW;         // input sites a product can touch
-  // LDS: delta [NQ][CW]; input [NIN][CW] (first layer: spins, one float per site); the halo map
+  // LDS: delta [NQ][CWD]; input [NIN][CW] (first layer: spins, one float per site); the halo map
   // (source site of every padded input site), the position map (padded number of every site), ones
   float* s_dl = s_dw;
-  float* s_in = s_dw + (size_t)NQ * CW;
+  float* s_in = s_dw + (size_t)NQ * CWD;
   int* s_map = (int*)(s_in + (size_t)NIN * (FIRST ? 1 : CW));
   int* s_pos = s_map + NPAD;
   float* s_one = (float*)(s_pos + g.N);            // [CW]: 1 for channel block 0 (the bias item's A operand)
@@ -783,11 +821,11 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
   f32x4 acc1[BOTH ? NA : 1], acc2[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) { acc2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; if (BOTH) acc1[i] = acc2[i]; }
-  f32x4 bacc1[NCB], bacc2[NCB];                    // first layer's bias: A = ones (wave DW_WAVES - 1)
+  f32x4 bacc1[NCO], bacc2[NCO];                    // first layer's bias: A = ones (wave DW_WAVES - 1)
 #pragma unroll
-  for (int i = 0; i < NCB; ++i) { bacc1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; bacc2[i] = bacc1[i]; }
+  for (int i = 0; i < NCO; ++i) { bacc1[i] = f32x4{0.f, 0.f, 0.f, 0.f}; bacc2[i] = bacc1[i]; }
   // once: zeros (delta's halo columns and tail, the input's tail stay zero for every sample), maps
-  for (int i = threadIdx.x; i < NQ * CW + NIN * (FIRST ? 1 : CW); i += WGT) s_dw[i] = 0.f;
+  for (int i = threadIdx.x; i < NQ * CWD + NIN * (FIRST ? 1 : CW); i += WGT) s_dw[i] = 0.f;
   if (threadIdx.x < CW) s_one[threadIdx.x] = threadIdx.x < 16 ? 1.f : 0.f;
   for (int i = threadIdx.x; i < NPAD; i += WGT) {
     const int p1 = i / D2p, p2 = i - p1 * D2p;
@@ -800,22 +838,23 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
   __syncthreads();
   // one flattened item list per (sample, band): delta rows [r0, r0 + rows), then (layers > 0) the
   // input's padded rows [r0, r0 + rows + K - 1)
-  const int in_off = NQ * CW;                      // s_in relative to s_dw, in floats
+  const int in_off = NQ * CWD;                     // s_in relative to s_dw, in floats
   auto band_rows_of = [&](int r0) { return min(RB, g.D1 - r0); };
-  auto band_nd = [&](int rows) { return GQ * rows * g.D2; };
-  auto band_ntot = [&](int rows) { return GQ * rows * g.D2 + (FIRST ? 0 : GQ * (rows + K - 1) * D2p); };
+  auto band_nd = [&](int rows) { return GQD * rows * g.D2; };
+  auto band_ntot = [&](int rows) { return GQD * rows * g.D2 + (FIRST ? 0 : GQ * (rows + K - 1) * D2p); };
   auto item = [&](int i, int r0, int nd, int& soff, int& dst) {
     const bool isd = i < nd;
     const int k = isd ? i : i - nd;
-    const int gq = k & (GQ - 1), ps = k / GQ;      // ps: site within the band / padded site within the band
+    // ps: site within the band / padded site within the band; gq: channel group (constant divisors)
+    const int ps = isd ? k / GQD : k / GQ, gq = isd ? k - ps * GQD : k - ps * GQ;
     const int site = isd ? r0 * g.D2 + ps : s_map[r0 * D2p + ps];
     const int q = isd ? s_pos[site] - r0 * D2p : ps;
-    soff = gq * g.GS + 4 * site;
-    dst = (isd ? 0 : in_off) + q * CW + 4 * gq;
+    soff = ((isd ? 4 * co0 : 0) + gq) * g.GS + 4 * site;
+    dst = isd ? q * CWD + 4 * gq : in_off + q * CW + 4 * gq;
   };
   auto put = [&](int dst, f32x4 v) {
     if (tape_is_z && dst >= in_off) {
-      const int gq = (dst >> 2) & (GQ - 1);
+      const int gq = ((dst - in_off) >> 2) % GQ;
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (4 * gq + r) < g.F ? vmc_act_rt(VMC_ACT_COS_, v[r]) : 0.f;
     }
@@ -854,7 +893,7 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
       ap0[i] = sin_off + gl + (tap / KW) * D2p + tap % KW;
       astep[i] = 4;
     } else {
-      const int it = wave + i * DW_WAVES;          // wave-uniform
+      const int it = wave + (i0 + i) * DW_WAVES;   // wave-uniform
       const int tp = it < KK ? it : 0;
       ap0[i] = it == KK ? one_off + ml : sin_off + ml + (gl + (tp / KW) * D2p + tp % KW) * CW;
       astep[i] = it == KK ? 0 : 4 * CW;
@@ -890,7 +929,7 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
       for (int i = threadIdx.x + WGT; i < nsp; i += WGT) s_in[i] = a.configs[(long long)b * g.N + s_map[r0 * D2p + i]];
     }
     // a short last band: the walk's last quad may reach into rows an earlier band wrote
-    if (rows < RB && (int)threadIdx.x < (nq - rows * D2p) * CW) s_dl[rows * D2p * CW + threadIdx.x] = 0.f;
+    if (rows < RB && (int)threadIdx.x < (nq - rows * D2p) * CWD) s_dl[rows * D2p * CWD + threadIdx.x] = 0.f;
     const float wb = wb_next;
     __syncthreads();
     {
@@ -899,39 +938,39 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
       if (nb < b1) prefetch(nb, nr0);
     }
     // the walk over position quads, operands read one quad ahead
-    int dp = gl * CW + ml;
+    int dp = gl * CWD + ml;
     int ap[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) ap[i] = ap0[i];
-    float dv[NCB], av[TPW][CI], dvn[NCB], avn[TPW][CI];
+    float dv[NCO], av[TPW][CI], dvn[NCO], avn[TPW][CI];
 #pragma unroll
-    for (int co = 0; co < NCB; ++co) dv[co] = s_dw[dp + 16 * co];
+    for (int co = 0; co < NCO; ++co) dv[co] = s_dw[dp + 16 * co];
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
 #pragma unroll
       for (int ci = 0; ci < CI; ++ci) av[i][ci] = s_dw[ap[i] + 16 * ci];
     for (int q = 0; q < nq; q += 4) {
-      dp += 4 * CW;                                // (the quad past the end reads the input region: dropped)
+      dp += 4 * CWD;                               // (the quad past the end reads the input region: dropped)
 #pragma unroll
-      for (int co = 0; co < NCB; ++co) dvn[co] = s_dw[dp + 16 * co];
+      for (int co = 0; co < NCO; ++co) dvn[co] = s_dw[dp + 16 * co];
 #pragma unroll
       for (int i = 0; i < TPW; ++i) {
         ap[i] += astep[i];
 #pragma unroll
         for (int ci = 0; ci < CI; ++ci) avn[i][ci] = s_dw[ap[i] + 16 * ci];
       }
-      float dv2[NCB];
+      float dv2[NCO];
 #pragma unroll
-      for (int co = 0; co < NCB; ++co) dv2[co] = dv[co] * wb;
+      for (int co = 0; co < NCO; ++co) dv2[co] = dv[co] * wb;
 #pragma unroll
       for (int i = 0; i < TPW; ++i) {
-        const bool full = FIRST ? (i * DW_WAVES + DW_WAVES - 1 < T0) : (i * DW_WAVES + DW_WAVES - 1 < NI);
-        if (full || wave + i * DW_WAVES < (FIRST ? T0 : NI)) {   // last slot: partly filled (wave-uniform)
+        const bool full = FIRST ? (i * DW_WAVES + DW_WAVES - 1 < T0) : (NTP == 1 && i * DW_WAVES + DW_WAVES - 1 < NI);
+        if (full || wave + (i0 + i) * DW_WAVES < (FIRST ? T0 : NI)) {   // last slot: partly filled (wave-uniform)
 #pragma unroll
           for (int ci = 0; ci < CI; ++ci)
 #pragma unroll
-            for (int co = 0; co < NCB; ++co) {
-              const int ai = (i * CI + ci) * NCB + co;
+            for (int co = 0; co < NCO; ++co) {
+              const int ai = (i * CI + ci) * NCO + co;
               if (BOTH) acc1[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][ci], dv[co], acc1[ai], 0, 0, 0);
               acc2[ai] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][ci], dv2[co], acc2[ai], 0, 0, 0);
             }
@@ -939,13 +978,13 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
       }
       if (FIRST && wave == DW_WAVES - 1) {
 #pragma unroll
-        for (int co = 0; co < NCB; ++co) {
+        for (int co = 0; co < NCO; ++co) {
           if (BOTH) bacc1[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv[co], bacc1[co], 0, 0, 0);
           bacc2[co] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dv2[co], bacc2[co], 0, 0, 0);
         }
       }
 #pragma unroll
-      for (int co = 0; co < NCB; ++co) dv[co] = dvn[co];
+      for (int co = 0; co < NCO; ++co) dv[co] = dvn[co];
 #pragma unroll
       for (int i = 0; i < TPW; ++i)
 #pragma unroll
@@ -966,49 +1005,53 @@ __device__ __forceinline__ void conv_dw_body(const ConvDwArgs& a, float* s_dw) {
         const int tap = 16 * tt + 4 * gl + r;          // accumulator row = tap
         if (tt < T0 && tap < KK) {
 #pragma unroll
-          for (int co = 0; co < NCB; ++co) {
-            if (BOTH) w1[(size_t)tap * CW * CW + 16 * co + ml] = acc1[i * NCB + co][r];   // cin 0
-            w2[(size_t)tap * CW * CW + 16 * co + ml] = acc2[i * NCB + co][r];
+          for (int co = 0; co < NCO; ++co) {
+            if (BOTH) w1[(size_t)tap * CW * CW + 16 * (co0 + co) + ml] = acc1[i * NCO + co][r];   // cin 0
+            w2[(size_t)tap * CW * CW + 16 * (co0 + co) + ml] = acc2[i * NCO + co][r];
           }
         }
       }
     }
     if (wave == DW_WAVES - 1 && gl == 0) {
 #pragma unroll
-      for (int co = 0; co < NCB; ++co) {
-        if (BOTH) w1[(size_t)KK * CW * CW + 16 * co + ml] = bacc1[co][0];
-        w2[(size_t)KK * CW * CW + 16 * co + ml] = bacc2[co][0];
+      for (int co = 0; co < NCO; ++co) {
+        if (BOTH) w1[(size_t)KK * CW * CW + 16 * (co0 + co) + ml] = bacc1[co][0];
+        w2[(size_t)KK * CW * CW + 16 * (co0 + co) + ml] = bacc2[co][0];
       }
     }
   } else {
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-      const int it = wave + i * DW_WAVES;
+      const int it = wave + (i0 + i) * DW_WAVES;
       if (it < KK) {
 #pragma unroll
         for (int ci = 0; ci < NCB; ++ci)
 #pragma unroll
-          for (int co = 0; co < NCB; ++co)
+          for (int co = 0; co < NCO; ++co)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int ai = (i * NCB + ci) * NCB + co;
-              const size_t o = ((size_t)it * CW + 16 * ci + 4 * gl + r) * CW + 16 * co + ml;   // row cin = 16 ci + 4g + r
+              const int ai = (i * NCB + ci) * NCO + co;
+              const size_t o = ((size_t)it * CW + 16 * ci + 4 * gl + r) * CW + 16 * (co0 + co) + ml;   // row cin = 16 ci + 4g + r
               if (BOTH) w1[o] = acc1[ai][r];
               w2[o] = acc2[ai][r];
             }
       } else if (it == KK && gl == 0) {                // bias: every row of the ones product is the sum
 #pragma unroll
-        for (int co = 0; co < NCB; ++co) {
-          if (BOTH) w1[(size_t)KK * CW * CW + 16 * co + ml] = acc1[(i * NCB) * NCB + co][0];
-          w2[(size_t)KK * CW * CW + 16 * co + ml] = acc2[(i * NCB) * NCB + co][0];
+        for (int co = 0; co < NCO; ++co) {
+          if (BOTH) w1[(size_t)KK * CW * CW + 16 * (co0 + co) + ml] = acc1[(i * NCB) * NCO + co][0];
+          w2[(size_t)KK * CW * CW + 16 * (co0 + co) + ml] = acc2[(i * NCB) * NCO + co][0];
         }
       }
     }
   }
 }
 
+// Grid (slice, layer, z): z = (output channel block group, item part).  Up to two channel blocks and
+// 7 x 7 taps a workgroup takes every output block and every tap of its layer; beyond, the NCB x NCB
+// accumulator pairs per tap would not fit the register file, so a workgroup stages the whole input
+// but only NCO blocks of delta, and takes one of NTP parts of the taps (plan_conv_dw_nco / _parts)
 template <int K, int KW, int NCB, bool BOTH>
-__global__ __launch_bounds__(DW_WAVES * 64, NCB == 1 ? 4 : 2) void k_conv_dw(ConvDwArgs a) {   // 16 filters: two workgroups per CU
+__global__ __launch_bounds__(DW_WAVES * 64, (NCB == 1 && K * KW <= 49) ? 4 : 2) void k_conv_dw(ConvDwArgs a) {   // 16 filters: two workgroups per CU
   extern __shared__ float s_dw[];
   if (blockIdx.y == 0) conv_dw_body<K, KW, NCB, BOTH, true>(a, s_dw);
   else conv_dw_body<K, KW, NCB, BOTH, false>(a, s_dw);
@@ -1032,12 +1075,16 @@ hipError_t launch_k(Kern kern, dim3 grid, size_t lds, hipStream_t s, const Args&
     case 5: { constexpr int KK_ = 5, KW_ = 5; CALL; } break;                            \
     case 6: { constexpr int KK_ = 6, KW_ = 6; CALL; } break;                            \
     case 7: { constexpr int KK_ = 7, KW_ = 7; CALL; } break;                            \
+    case 8: { constexpr int KK_ = 8, KW_ = 8; CALL; } break;                            \
+    case 9: { constexpr int KK_ = 9, KW_ = 9; CALL; } break;                            \
     case -2: { constexpr int KK_ = 2, KW_ = 1; CALL; } break;                           \
     case -3: { constexpr int KK_ = 3, KW_ = 1; CALL; } break;                           \
     case -4: { constexpr int KK_ = 4, KW_ = 1; CALL; } break;                           \
     case -5: { constexpr int KK_ = 5, KW_ = 1; CALL; } break;                           \
     case -6: { constexpr int KK_ = 6, KW_ = 1; CALL; } break;                           \
     case -7: { constexpr int KK_ = 7, KW_ = 1; CALL; } break;                           \
+    case -8: { constexpr int KK_ = 8, KW_ = 1; CALL; } break;                           \
+    case -9: { constexpr int KK_ = 9, KW_ = 1; CALL; } break;                           \
     default: return hipErrorInvalidValue;                                               \
   }
 

@@ -6,7 +6,7 @@
 // Every index a kernel derives from these plans is re-derived here into REAL arrays of the planned
 // size, so that an offset one past a buffer is an ASan report and an overflowing product a UBSan one.
 // The grid contains all five BASELINE configurations and the limits of include/cgsvmc.h (512 / 4096
-// units, 32 filters, kernel 7, 32 x 32 lattices, 1023-site chains).
+// units, 64 filters, kernel 9, 32 x 32 lattices, 1023-site chains).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -264,6 +264,22 @@ static void check_conv(const vmc_desc& d, const DescPlan& p) {
       CHECK(grid >= 1 && grid <= 2 * cus && (long long)grid * G <= B * 7 + G);
       const int sl = plan_conv_dw_slices(g, B, cus);
       CHECK(sl >= 1 && sl <= 256 && sl <= B);
+      {  // grid z of k_conv_dw: the output block groups x item parts cover every block and every item
+         // once, with at most PLAN_DW_MAX_ACC accumulator pairs per wave
+        const int nco = plan_conv_dw_nco(g), parts = plan_conv_dw_parts(g.K, g.KW, g.NCB);
+        CHECK(nco >= 1 && g.NCB % nco == 0 && parts >= 1 && plan_conv_dw_grid_z(g) == (g.NCB / nco) * parts);
+        const int ni = KK + 1, tpw = (ni + PLAN_DW_WAVES * parts - 1) / (PLAN_DW_WAVES * parts);
+        CHECK(tpw * g.NCB * nco <= PLAN_DW_MAX_ACC);
+        std::vector<int> seen((size_t)ni, 0);
+        for (int part = 0; part < parts; ++part)
+          for (int i = 0; i < tpw; ++i)
+            for (int w = 0; w < PLAN_DW_WAVES; ++w) {
+              const int it = w + (part * tpw + i) * PLAN_DW_WAVES;
+              if (it < ni) ++seen[(size_t)it];
+            }
+        for (int it = 0; it < ni; ++it) CHECK(seen[(size_t)it] == 1);
+        CHECK((KK + 15) / 16 <= PLAN_DW_WAVES);       // the first layer's tap tiles: one per wave, one part
+      }
       // weight-gradient workspace: the last element slice sl-1 / layer n_conv-1 / second sum writes
       const long long rows = (long long)KK * CW + 1, ws = plan_conv_dw_ws_floats(g, sl);
       const long long last = ((((long long)(sl - 1) * g.n_conv + (g.n_conv - 1)) * 2) + 1) * rows * CW + (rows * CW - 1);
@@ -294,7 +310,10 @@ static void check_conv(const vmc_desc& d, const DescPlan& p) {
     // a band of rb rows starting at row r0: position q of the band + tap offset < NIN
     const int q_last = (rb - 1) * D2p + (g.D2 - 1);
     CHECK(q_last < NQ && q_last + (g.K - 1) * D2p + (g.KW - 1) < NIN);
-    const size_t floats = ((size_t)NQ * CW + (size_t)NIN * CW + NPAD + g.N + CW + 8 * CW);
+    const int CWD = 16 * plan_conv_dw_nco(g);
+    const size_t floats = ((size_t)NQ * CWD + (size_t)NIN * CW + NPAD + g.N + CW + 8 * CW);
+    // the walk reads delta one quad past the end (dropped): NQ + 4 positions of CWD floats stay inside the LDS
+    CHECK(((size_t)NQ + 4) * CWD <= floats);
     CHECK(floats * sizeof(float) == plan_conv_dw_lds(g, rb));
   }
 }
@@ -303,7 +322,7 @@ static void conv_grid() {
   struct Lat { int x, y; };
   const Lat lats[] = {{4, 4}, {3, 5}, {6, 6}, {10, 10}, {16, 16}, {24, 24}, {30, 30}, {32, 32}, {33, 33}, {2, 50}};
   const int chains[] = {8, 40, 100, 1000, 1023, 1024};
-  const int filters[] = {1, 4, 8, 16, 17, 24, 32, 33};
+  const int filters[] = {1, 4, 8, 16, 17, 32, 33, 48, 49, 64, 65};
   const long long batches[] = {1, 7, 1024, 4096, 100000};
   char msg[256];
   for (int ansatz : {VMC_ANSATZ_CONV_2D, VMC_ANSATZ_RES_NET_2D, VMC_ANSATZ_CONV_1D, VMC_ANSATZ_RES_NET_1D}) {
@@ -312,7 +331,7 @@ static void conv_grid() {
     const int n_lat = one_d ? (int)(sizeof(chains) / sizeof(chains[0])) : (int)(sizeof(lats) / sizeof(lats[0]));
     for (int li = 0; li < n_lat; ++li)
       for (int F : filters)
-        for (int K = 1; K <= 8; ++K)
+        for (int K = 1; K <= 10; ++K)
           for (int L : {0, 1, 2, 5, 16})
             for (long long B : batches) {
               vmc_desc d;
@@ -329,21 +348,26 @@ static void conv_grid() {
                 CHECK(msg[0] != 0);
                 continue;
               }
-              CHECK(F <= 32 && K <= 7 && (resnet || L >= 1) && p.conv);
+              CHECK(F <= 64 && K <= 9 && (resnet || L >= 1) && p.conv);
               CHECK(plan_conv_rows_lds(p.cg, 1) <= PLAN_LDS_PER_CU);
               check_conv(d, p);
             }
   }
-  // named limits: 32 filters and kernel 7 are in, 33 and 8 are out; the bench workloads are in
+  // named limits: 64 filters and kernel 9 are in, 65 and 10 are out; the bench workloads are in
   vmc_desc d;
   DescPlan p;
   memset(&d, 0, sizeof(d));
   d.ansatz = VMC_ANSATZ_CONV_2D; d.batch_size = 4096; d.num_layers = 5; d.layer_size = 32; d.kernel_size = 7;
   d.size_x = d.size_y = 10; d.n_sites = 100; d.output_activation = VMC_ACT_EXP;
   CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_OK && p.cg.NCB == 2);
-  d.layer_size = 33;
+  d.layer_size = 64; d.kernel_size = 9;
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_OK && p.cg.NCB == 4 && plan_conv_tab(p.cg) == 16);
+  CHECK(plan_conv_dw_nco(p.cg) == 1 && plan_conv_dw_parts(9, 9, 4) == 2 && plan_conv_dw_grid_z(p.cg) == 8);
+  CHECK(plan_conv_dw_nco(5, 5, 2) == 2 && plan_conv_dw_parts(5, 5, 2) == 1);      // the measured 32-filter kernels are unchanged
+  CHECK(plan_conv_dw_nco(5, 5, 1) == 1 && plan_conv_dw_parts(5, 5, 1) == 1 && plan_conv_dw_parts(9, 9, 1) == 1);
+  d.layer_size = 65;
   CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_UNSUPPORTED);
-  d.layer_size = 16; d.kernel_size = 8;
+  d.layer_size = 16; d.kernel_size = 10;
   CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_UNSUPPORTED);
   d.kernel_size = 5; d.size_x = 9;
   CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_INVALID);        // size_x * size_y != num_sites

@@ -67,8 +67,8 @@ inline long long plan_num_params_conv(int n_conv, long long F, long long taps) {
 // ------------------------------------------------------------------------------- convolutional geometry
 #define CONV_MAX_LAYERS 32
 #define CONV_FP 16          // channel tile of the MFMA: filters are zero padded to NCB blocks of 16
-#define CONV_MAX_NCB 2      // num_conv_filters <= 32
-#define CONV_MAX_K 7        // kernel_size (weights of a block pair are register resident)
+#define CONV_MAX_NCB 4      // num_conv_filters <= 64
+#define CONV_MAX_K 9        // kernel_size (one instantiation per size; weights of a block pair in register-resident chunks of <= 25 taps)
 #define CONV_LDS_PER_WG ((size_t)80 * 1024)   // two 4-wave workgroups share the 160 KiB of a CU
 
 // Geometry of one network.  A feature map of one sample is stored -- in LDS and in the HBM tapes
@@ -95,9 +95,11 @@ struct ConvGeom {
 
 // LDS of a row / sampler / backward workgroup holding G samples: buf0, buf1, xs, pinfo, row_chain,
 // red + the sampler's cur_logit, prop, prop_u + the two wrap tables
+// ints per row of the periodic neighbour tables (one entry per tap along an axis)
+PLAN_HD inline int plan_conv_tab(const ConvGeom& g) { return g.K <= 8 ? 8 : 16; }
 inline size_t plan_conv_rows_lds(const ConvGeom& g, int G) {
   const size_t xs = (size_t)((g.N + 3) & ~3);
-  return ((size_t)G * 2 * g.CS + (size_t)G * xs + (size_t)G * g.N + (size_t)G * 7 + 16 * (size_t)(g.D1 + g.D2) + 16) * sizeof(float);
+  return ((size_t)G * 2 * g.CS + (size_t)G * xs + (size_t)G * g.N + (size_t)G * 7 + 2 * (size_t)plan_conv_tab(g) * (size_t)(g.D1 + g.D2) + 16) * sizeof(float);
 }
 
 // LDS budget of one workgroup: half a CU when a sample's feature maps allow two workgroups per CU
@@ -156,11 +158,30 @@ inline int plan_conv_grid(const ConvGeom& g, long long n_rows, int G, int num_cu
 // LDS of the weight-gradient kernel for bands of `rows` lattice rows: delta [NQ][CW] + input
 // [NIN][CW] in one padded site numbering, the halo and position maps, ones (+ 8 sites: the operands
 // of the quad past the end are read, and dropped)
+// k_conv_dw keeps (items per wave) x (input blocks) x (output blocks) accumulator pairs in registers
+// (items of a layer: the taps and the bias, over PLAN_DW_WAVES waves): at most PLAN_DW_MAX_ACC of them.
+// A workgroup therefore takes NCO of the NCB output channel blocks (all of them when that fits with at most
+// two blocks, else one) and one of NTP parts of the items; grid z = (NCB / NCO) * NTP.
+#define PLAN_DW_WAVES 8
+#define PLAN_DW_MAX_ACC 24
+PLAN_HD constexpr int plan_conv_dw_nco(int K, int KW, int NCB) {
+  return (NCB <= 2 && ((K * KW + 1 + PLAN_DW_WAVES - 1) / PLAN_DW_WAVES) * NCB * NCB <= PLAN_DW_MAX_ACC) ? NCB : 1;
+}
+PLAN_HD constexpr int plan_conv_dw_parts(int K, int KW, int NCB) {
+  const int nco = plan_conv_dw_nco(K, KW, NCB), ni = K * KW + 1;
+  int p = 1;
+  while (((ni + PLAN_DW_WAVES * p - 1) / (PLAN_DW_WAVES * p)) * NCB * nco > PLAN_DW_MAX_ACC) ++p;
+  return p;
+}
+inline int plan_conv_dw_nco(const ConvGeom& g) { return plan_conv_dw_nco(g.K, g.KW, g.NCB); }
+inline int plan_conv_dw_grid_z(const ConvGeom& g) {
+  return (g.NCB / plan_conv_dw_nco(g)) * plan_conv_dw_parts(g.K, g.KW, g.NCB);
+}
 inline size_t plan_conv_dw_lds(const ConvGeom& g, int rows) {
   const size_t d2p = (size_t)g.D2 + g.KW - 1, npad = (size_t)(g.D1 + g.K - 1) * d2p;
   const size_t nq = ((size_t)rows * d2p + 3) & ~(size_t)3, nin = nq + (size_t)(g.K - 1) * d2p + g.KW;
-  const size_t cw = 16 * (size_t)g.NCB;
-  return (nq * cw + nin * cw + npad + g.N + cw + 8 * cw) * sizeof(float);
+  const size_t cw = 16 * (size_t)g.NCB, cwd = 16 * (size_t)plan_conv_dw_nco(g);
+  return (nq * cwd + nin * cw + npad + g.N + cw + 8 * cw) * sizeof(float);
 }
 
 // rows per band: the whole sample when it fits the CU's LDS, else the largest band that does
@@ -175,7 +196,8 @@ inline int plan_conv_dw_band(const ConvGeom& g, int forced = 0) {
 // sample slices of the weight-gradient kernel: two resident workgroups per CU (NCB = 1) over the
 // layers > 0, whose workgroups carry the work
 inline int plan_conv_dw_slices(const ConvGeom& g, long long B, int num_cus) {
-  const int per_cu = g.NCB == 1 ? 2 : 1, heavy = g.n_conv > 1 ? g.n_conv - 1 : 1;
+  const int per_cu = g.NCB == 1 ? 2 : 1;
+  const int heavy = (g.n_conv > 1 ? g.n_conv - 1 : 1) * plan_conv_dw_grid_z(g);
   int sl = (per_cu * num_cus + heavy - 1) / heavy;
   sl = sl < 64 ? 64 : (sl > 256 ? 256 : sl);
   return B < sl ? (int)B : sl;
@@ -282,9 +304,9 @@ inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, c
     if (sx < 1 || sy < 1 || (long long)sx * sy != d->n_sites)
       PLAN_FAIL(VMC_ERR_INVALID, "size_x * size_y must equal num_sites");
     if (d->kernel_size < 1 || d->kernel_size > CONV_MAX_K)
-      PLAN_FAIL(VMC_ERR_UNSUPPORTED, "kernel_size 1..7 supported by the convolution kernels (weights are register resident)");
+      PLAN_FAIL(VMC_ERR_UNSUPPORTED, "kernel_size 1..9 supported by the convolution kernels (one instantiation per size)");
     if (d->layer_size > CONV_FP * CONV_MAX_NCB)
-      PLAN_FAIL(VMC_ERR_UNSUPPORTED, "num_conv_filters > 32 not supported by the convolution kernels");
+      PLAN_FAIL(VMC_ERR_UNSUPPORTED, "num_conv_filters > 64 not supported by the convolution kernels (four channel blocks of 16)");
     if (sx < d->kernel_size / 2 || (!one_d && sy < d->kernel_size / 2) || sx > 1023 || sy > 1023)
       PLAN_FAIL(VMC_ERR_UNSUPPORTED, "lattice sides must be in [kernel_size / 2, 1023]");
     if ((long long)d->num_layers > CONV_MAX_LAYERS)

@@ -44,6 +44,27 @@ CONV_SHAPES = [
     # the cosine (layers.py:15): its derivative needs the pre-activation, which the tape then holds
     ('conv_2d', 4, 4, 3, 8, 3, 20, 'cos'),
     ('conv_2d', 6, 4, 2, 32, 3, 11, 'cos'),
+    # round 4: 33 .. 64 filters (three / four channel blocks: conv48.hip, conv64.hip; the weight gradient
+    # takes one output block per workgroup) ...
+    ('conv_2d', 4, 4, 3, 48, 3, 20, 'relu'),
+    ('conv_2d', 6, 6, 3, 64, 5, 13, 'tanh'),
+    ('conv_2d', 10, 10, 3, 40, 5, 9, 'relu'),       # 40 filters padded to 48, 10 x 10
+    ('conv_2d', 5, 4, 2, 33, 4, 9, 'sigmoid'),      # 33 filters, even kernel
+    ('conv_2d', 6, 6, 2, 50, 6, 7, 'identity'),     # 2 x 18 taps per block pair
+    ('conv_2d', 7, 8, 2, 64, 7, 6, 'tanh'),         # 25 + 24 taps, the weight gradient in two tap parts
+    ('conv_2d', 6, 4, 2, 64, 3, 11, 'cos'),
+    ('res_net_2d', 6, 6, 2, 64, 3, 12, 'relu'),
+    ('res_net_2d', 4, 6, 1, 44, 5, 10, 'relu'),
+    # ... and kernels of 8 and 9 taps per axis (fragments in chunks of <= 25 taps; 16-entry wrap tables at 9)
+    ('conv_2d', 8, 8, 2, 8, 8, 11, 'relu'),
+    ('conv_2d', 9, 10, 3, 16, 9, 7, 'tanh'),
+    ('conv_2d', 6, 4, 2, 12, 9, 9, 'sigmoid'),      # k = 9 on a 6 x 4 lattice: every tap wraps
+    ('conv_2d', 8, 8, 2, 24, 8, 6, 'relu'),
+    ('conv_2d', 10, 9, 2, 32, 9, 5, 'relu'),
+    ('conv_2d', 8, 8, 2, 40, 8, 5, 'tanh'),
+    ('conv_2d', 10, 10, 2, 64, 9, 4, 'relu'),       # the largest instantiation
+    ('res_net_2d', 8, 8, 1, 16, 9, 8, 'relu'),
+    ('res_net_2d', 8, 6, 1, 36, 8, 6, 'relu'),
 ]
 ONE_D = [
     # Conv1DNetwork / ResNet1D (wavefunctions.py:455-527, 618-707): N x 1 lattice, k x 1 taps
@@ -59,6 +80,9 @@ ONE_D = [
     ('conv_1d', 16, 1, 3, 12, 7, 15, 'relu'),       # 7 taps on the chain
     ('res_net_1d', 14, 1, 1, 20, 7, 9, 'relu'),     # ... with two channel blocks
     ('conv_1d', 11, 1, 2, 18, 2, 8, 'tanh'),        # 2 taps, two channel blocks (the variant with the most spills)
+    ('conv_1d', 16, 1, 3, 64, 5, 12, 'relu'),
+    ('conv_1d', 20, 1, 2, 12, 9, 10, 'relu'),       # 9 taps on the chain
+    ('res_net_1d', 18, 1, 1, 48, 8, 7, 'relu'),
 ]
 CONV_SHAPES = CONV_SHAPES + ONE_D
 BIG = [
@@ -74,6 +98,10 @@ def _make(ansatz, sx, sy, L, f, k, b, nonlin, seed=0, output_activation='exp', n
   geom = (f, k, sx, sy)
   rng = np.random.default_rng(seed)
   theta = vo.conv_init_params(ansatz, geom, L, rng)
+  if f > 32 or k > 7:
+    # the round-4 shapes: up to 81 x 64 inputs per output -- the per-weight noise is scaled to the
+    # fan-in so that the logits stay at the magnitudes of the smaller shapes
+    noise = min(noise, 0.03 * np.sqrt(400.0 / (f * k * (1 if ansatz in vo.CONV_1D else k))))
   theta += (noise * rng.standard_normal(theta.size)).astype(np.float32)   # non-zero biases
   cfg = vo.random_configurations(n, b, np.random.RandomState(seed + 1))
   # site = a2 + size_y * a1 (row-major reshape); the 1-D types live on the periodic chain
@@ -335,9 +363,9 @@ def test_conv_error_behaviour():
   with pytest.raises(ValueError):
     VmcEngine(15, 8, 2, 8, **kw)                          # size_x * size_y != num_sites
   with pytest.raises(NotImplementedError):
-    VmcEngine(16, 8, 2, 33, **kw)                         # more than 32 filters
+    VmcEngine(16, 8, 2, 65, **kw)                         # more than 64 filters
   with pytest.raises(NotImplementedError):
-    VmcEngine(16, 8, 2, 8, ansatz='conv_2d', kernel_size=8, size_x=4, size_y=4)
+    VmcEngine(16, 8, 2, 8, ansatz='conv_2d', kernel_size=10, size_x=4, size_y=4)
   eng = VmcEngine(16, 8, 2, 8, output_activation='tanh', **kw)
   with pytest.raises(NotImplementedError):
     eng.sr_reserve(2)                                     # SR (an extension) needs the exp output
@@ -396,8 +424,8 @@ def test_conv_1d_through_run_training(tmp_path):
   assert 'conv_1d_network/conv_1d_periodic_2/conv_1d/w' in set(np.load(ck + '.npz').files)
 
 
-def _random_conv_shapes(count, seed=2025, kmax=6, with_cos=False):
-  """Seeded random geometries inside the limits vmc_create states (kernel 1..7, <= 32 filters,
+def _random_conv_shapes(count, seed=2025, kmax=6, with_cos=False, fmax=32):
+  """Seeded random geometries inside the limits vmc_create states (kernel 1..9, <= 64 filters,
   lattice sides >= kernel // 2): every padding parity, ragged batches, k larger than a side."""
   rng = np.random.default_rng(seed)
   # (tan and exp hidden units are covered by CONV_SHAPES at controlled magnitudes: near a pole of
@@ -415,15 +443,17 @@ def _random_conv_shapes(count, seed=2025, kmax=6, with_cos=False):
       continue
     resnet = ansatz.startswith('res_net')
     L = int(rng.integers(0, 3)) if resnet else int(rng.integers(1, 5))
-    f = int(rng.integers(1, 17)) if len(shapes) % 3 else int(rng.integers(17, 33))
+    f = int(rng.integers(1, 17)) if len(shapes) % 3 else int(rng.integers(17, fmax + 1))
     b = int(rng.integers(1, 41))
     nonlin = 'relu' if resnet else acts[int(rng.integers(len(acts)))]
     shapes.append((ansatz, sx, sy, L, f, k, b, nonlin))
   return shapes
 
 
-# the round-2 / early round-3 set (kernel <= 6), then one with 7 x 7 kernels and cos
-RANDOM_SHAPES = _random_conv_shapes(36) + _random_conv_shapes(18, seed=3031, kmax=7, with_cos=True)
+# the round-2 / early round-3 set (kernel <= 6), then one with 7 x 7 kernels and cos, then (round 4) one up to
+# 9 x 9 kernels and 64 filters
+RANDOM_SHAPES = (_random_conv_shapes(36) + _random_conv_shapes(18, seed=3031, kmax=7, with_cos=True) +
+                 _random_conv_shapes(24, seed=4044, kmax=9, with_cos=True, fmax=64))
 
 
 @pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', RANDOM_SHAPES,
@@ -434,13 +464,16 @@ def test_conv_random_shapes(ansatz, sx, sy, L, f, k, b, nonlin):
   # the parameter noise is per weight: with up to 36 x 32 inputs per output it is scaled down so that
   # the residual stacks stay at logits of order 10, not 10^27
   eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin, seed=b + 7 * k,
-                                       noise=0.03 if f <= 16 else 0.01)
+                                       noise=0.03 if f <= 16 else (0.01 if f <= 32 else 0.005))
   n = sx * sy
   psi_fn = vo.ANSATZ[ansatz][0]
   amp = lambda c: psi_fn(theta, c, geom, L, nonlinearity=nonlin, dtype=np.float64)
   _logits_close(eng.amplitude()[0], theta, cfg, ansatz, geom, L, nonlin)
   e_ref = vo.local_value(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64)
-  _close(eng.local_energy()[0], e_ref, 2e-4)
+  # an amplitude ratio carries the fp32 rounding of two logits, each ~ 1e-6 of the sum of the magnitudes of
+  # its terms (what _logits_close allows): with 64 filters that sum reaches several thousand
+  _, scale = vo.conv_forward(theta, cfg, ansatz, geom, L, nonlin, np.float64, return_tape='scale')
+  _close(eng.local_energy()[0], e_ref, max(2e-4, 4e-6 * float(np.max(scale))))
   acc = vo.Accumulators(theta.size, np.float64)
   vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, geom, L, np.float64,
                                 ansatz=ansatz, nonlinearity=nonlin)

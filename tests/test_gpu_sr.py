@@ -295,6 +295,13 @@ def test_sr_beyond_256_units_matvec_and_solution(ansatz, n, h, L, b, n_store):
     ('res_net_2d', 4, 4, 2, 8, 3, 16, 'relu', 2),
     ('conv_1d', 12, 1, 3, 12, 5, 14, 'sigmoid', 3),
     ('conv_2d', 7, 7, 2, 8, 7, 10, 'relu', 2),        # 7 x 7 kernel
+    # round 4: three / four channel blocks, 8 / 9 taps per axis (the reference is an explicit P x P matrix:
+    # shapes with at most ~ 8000 parameters)
+    ('conv_2d', 6, 4, 2, 33, 2, 11, 'relu', 2),
+    ('conv_1d', 12, 1, 2, 50, 3, 9, 'tanh', 2),
+    ('conv_2d', 4, 4, 2, 49, 2, 10, 'relu', 2),
+    ('conv_2d', 8, 8, 2, 4, 9, 8, 'tanh', 2),
+    ('res_net_1d', 16, 1, 1, 17, 8, 6, 'relu', 2),
 ])
 def test_sr_convolutional_matvec_and_solution(ansatz, sx, sy, L, f, k, b, nonlin, n_store):
   """SR over the convolutional ansatz types (round 3): t_b = O_b . p by k_conv_sr_rowdot on the stored
@@ -305,7 +312,10 @@ def test_sr_convolutional_matvec_and_solution(ansatz, sx, sy, L, f, k, b, nonlin
   geom = (f, k, sx, sy)
   rng = np.random.default_rng(8)
   theta = vo.conv_init_params(ansatz, geom, L, rng)
-  theta += ((0.03 if f <= 16 else 0.01) * rng.standard_normal(theta.size)).astype(np.float32)
+  noise = 0.03 if f <= 16 else 0.01
+  if f > 32 or k > 7:      # the round-4 shapes: per-weight noise scaled to the fan-in (tests/test_gpu_conv.py:_make)
+    noise = min(noise, 0.03 * np.sqrt(400.0 / (f * k * (1 if ansatz in vo.CONV_1D else k))))
+  theta += (noise * rng.standard_normal(theta.size)).astype(np.float32)
   bonds = vo.chain_bonds(n) if ansatz in vo.CONV_1D else vo.torus_bonds(sy, sx)
   eng = VmcEngine(n, b, L, f, nonlinearity=nonlin, seed=2024, ansatz=ansatz, kernel_size=k, size_x=sx, size_y=sy)
   eng.set_params(theta)
@@ -357,5 +367,6 @@ def test_sr_convolutional_matvec_and_solution(ansatz, sx, sy, L, f, k, b, nonlin
   oc = o - o.mean(0)
   assert np.abs(oc @ (x - x_ref)).max() <= 1e-2 * np.abs(oc @ x_ref).max(), (iters, res)
   eng.sr_apply(0.05)
-  np.testing.assert_allclose(eng.get_params(), theta - np.float32(0.05) * x, rtol=0, atol=1e-6)
+  # (one ulp of the result where the null-space noise / lambda makes x large: fused or separate multiply-subtract)
+  np.testing.assert_allclose(eng.get_params(), theta - np.float32(0.05) * x, rtol=2.5e-7, atol=1e-6)
   eng.close()
