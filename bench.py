@@ -61,6 +61,7 @@ WORKLOADS = {
     'heisenberg6x6_fc3x128_b1024': (6, 6, False, 3, 128, 1024),
     'heisenberg16x16j1j2_fc6x256_b1024': (16, 16, True, 6, 256, 1024),
     'heisenberg10x10_fc3x512_b4096': (10, 10, False, 3, 512, 4096),   # 257 .. 512 units: the fused kernels padded to 512
+    'heisenberg10x10_fc3x1024_b4096': (10, 10, False, 3, 1024, 4096),  # beyond 512 units: the general path (wide.hip)
     'heisenberg10x10_conv5x16k5_b4096': (10, 10, False, 5, 16, 4096, 'conv_2d', 5),
     'heisenberg10x10_resnet2x16k5_b4096': (10, 10, False, 2, 16, 4096, 'res_net_2d', 5),
     'heisenberg10x10_conv5x32k5_b4096': (10, 10, False, 5, 32, 4096, 'conv_2d', 5),    # two 16-channel blocks
