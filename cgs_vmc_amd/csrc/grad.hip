@@ -3,6 +3,7 @@
 // forward / back-prop (k_backprop16, mlp.hip) / weight-gradient GEMM chain on fp32 MFMA, plus the accumulator,
 // ratio and Adam element-wise kernels.  All reductions are fixed-order (no float atomics).
 #include "common.hpp"
+#include <cstdlib>
 #ifdef VMC_WGRAD_STAMPS
 #include <algorithm>
 #include <cstdio>
@@ -804,6 +805,127 @@ void wgrad_fill_problem(void* dst, int index, const float* A, long long lda, con
   p.tile0 = tile0; p.tiles_n = (n_out + WG_TN - 1) / WG_TN;
 }
 
+// ------------------------------------------------------------------- GEMM, large forward shape
+// C[M,N] = epilogue(A[M,K] B[K,N]) for the shape the general path of wide.hip spends its time in: A = a
+// block of materialised activation rows (k contiguous), B = a weight matrix [K][N] (n contiguous), M in
+// the hundreds of thousands, K, N = the layer width.  128 x 128 x 16 tiles, 4 waves in a 2 x 2 grid, each
+// 64 x 64 of the tile as 2 x 2 v_mfma_f32_32x32x2_f32 accumulators: one LDS operand read per MFMA (k_gemm:
+// two), half the global bytes per flop of the 64 x 64 tile.  Two LDS stages: tile t + 1 travels into
+// registers while tile t is multiplied and goes to the other stage behind it -- one barrier per tile.
+// Out-of-range rows read a clamped row and are not stored; out-of-range k / n quads are zeroed when they
+// are staged (not at the load: a select there makes the compiler wait for the load at once).
+// Requirements (launch_gemm checks them, else k_gemm): sak == 1, sbn == 1, K % 4 == N % 4 == 0, rows of
+// A and B 16-byte aligned, no split-K / dual / ones row.
+// Block order: the N / 128 column tiles of one row tile run back to back on ONE XCD (block b -> XCD
+// b % 8), so that a row block of A is fetched into one L2 once instead of into all eight.
+#define G2_TM 128
+#define G2_TN 128
+#define G2_TK 16
+#define G2_LD 132
+__global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int tiles_n) {
+  __shared__ __attribute__((aligned(16))) float As[2][G2_TK][G2_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][G2_TK][G2_LD];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: XCD x takes the row tiles x, x + 8, ..., each with all of its column tiles
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int tm = (j / tiles_n) * 8 + xcd, tn = j % tiles_n;
+  if (tm >= tiles_m) return;                        // (whole workgroup; before any barrier)
+  const int m0 = tm * G2_TM, n0 = tn * G2_TN;
+  const int T = (g.K + G2_TK - 1) / G2_TK;
+  // this thread's two quads of the A tile (row am + 64 i, k quad ak) and of the B tile (k row bk + 8 i, n quad bn)
+  const int am = tid >> 2, ak = 4 * (tid & 3);
+  const int bk = tid >> 5, bn = 4 * (tid & 31);
+  const float* ap[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) ap[i] = g.A + (long long)min(m0 + am + 64 * i, g.M - 1) * g.sam;
+  const bool b_in = n0 + bn < g.N;                  // N % 4 == 0: a quad is inside or outside as a whole
+  const float* bp = g.B + (b_in ? n0 + bn : 0);
+  f32x4 ra[2], rb[2];
+  const int sbk = (int)g.sbk;                       // K * sbk < 2^31 (gemm128_applies)
+  auto request = [&](int t) {
+    const int k0 = min(t, T - 1) * G2_TK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = *(const f32x4*)(ap[i] + min(k0 + ak, g.K - 4));
+      rb[i] = *(const f32x4*)(bp + min(k0 + bk + 8 * i, g.K - 1) * sbk);
+    }
+    // (the loads stay HERE, a whole tile of MFMAs ahead of their use: without the barrier the compiler
+    // sinks them behind the products, next to the stage that consumes them)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto stage = [&](int t) {
+    const int k0 = t * G2_TK, st = t & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool a_ok = k0 + ak < g.K;              // K % 4 == 0
+#pragma unroll
+      for (int e = 0; e < 4; ++e) As[st][ak + e][am + 64 * i] = a_ok ? ra[i][e] : 0.f;
+      const bool b_ok = b_in && k0 + bk + 8 * i < g.K;
+      *(f32x4*)&Bs[st][bk + 8 * i][bn] = b_ok ? rb[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+  request(0);
+  stage(0);
+  __syncthreads();
+  const int l31 = lane & 31, hi = lane >> 5;
+  for (int t = 0; t < T; ++t) {
+    request(t + 1);                                 // (clamped: the last one re-reads tile T - 1, unused)
+    const int st = t & 1;
+    // operands of k-step s + 1 are read before the products of step s issue (one LDS round trip ahead)
+    float av[2][2], bv[2][2];
+    auto operands = [&](int kk, float (&a2)[2], float (&b2)[2]) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a2[i] = As[st][kk + hi][wm * 64 + 32 * i + l31];
+        b2[i] = Bs[st][kk + hi][wn * 64 + 32 * i + l31];
+      }
+    };
+    operands(0, av[0], bv[0]);
+#pragma unroll
+    for (int ks = 0; ks < G2_TK / 2; ++ks) {
+      if (ks + 1 < G2_TK / 2) operands(2 * (ks + 1), av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][i], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
+    }
+    if (t + 1 < T) stage(t + 1);                    // uniform
+    __syncthreads();
+  }
+  auto finish = [&](const f32x16& v, int i, int jj) {
+    const int n = n0 + wn * 64 + 32 * jj + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      if (m < g.M && n < g.N) gemm_epilogue(g, g.C, m, n, v[r]);
+    }
+  };
+  finish(acc[0][0], 0, 0); finish(acc[0][1], 0, 1); finish(acc[1][0], 1, 0); finish(acc[1][1], 1, 1);
+}
+
+// CGS_VMC_GEMM128=0: the 64 x 64 kernel for every shape (A/B measurements)
+static bool gemm128_enabled() {
+  static const int v = getenv("CGS_VMC_GEMM128") ? atoi(getenv("CGS_VMC_GEMM128")) : 1;
+  return v != 0;
+}
+static bool gemm128_applies(const GemmArgs& g) {
+  return gemm128_enabled() && g.sak == 1 && g.sbn == 1 && g.splitk <= 1 && !g.dual && !g.ones_row && !g.kscale &&
+         g.M >= 4 * G2_TM && g.N >= G2_TN && g.K >= 4 * G2_TK && g.K % 4 == 0 && g.N % 4 == 0 &&
+         g.sam % 4 == 0 && g.sbk % 4 == 0 && ((size_t)g.A & 15) == 0 && ((size_t)g.B & 15) == 0 &&
+         (long long)g.K * g.sbk < (1LL << 31);
+}
+
 __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
   const long long mn = (long long)g.M * g.N;
   const int nd = g.dual ? 2 : 1;
@@ -819,6 +941,12 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
+  if (gemm128_applies(g)) {
+    const int tiles_m = (g.M + G2_TM - 1) / G2_TM, tiles_n = (g.N + G2_TN - 1) / G2_TN;
+    const int blocks = ((tiles_m + 7) / 8) * 8 * tiles_n;      // whole rounds of the eight XCDs
+    hipLaunchKernelGGL(k_gemm128, dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);
+    return hipGetLastError();
+  }
   const int m_rows = g.ones_row ? g.M - 1 : g.M;
   const dim3 grid((g.N + GT - 1) / GT, (m_rows + GT - 1) / GT, g.splitk);
   if (g.dual) hipLaunchKernelGGL((k_gemm<true>), grid, dim3(256), 0, s, g);
