@@ -914,14 +914,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int
   finish(acc[0][0], 0, 0); finish(acc[0][1], 0, 1); finish(acc[1][0], 1, 0); finish(acc[1][1], 1, 1);
 }
 
-// CGS_VMC_GEMM128=0: the 64 x 64 kernel for every shape (A/B measurements)
-static bool gemm128_enabled() {
-  static const int v = getenv("CGS_VMC_GEMM128") ? atoi(getenv("CGS_VMC_GEMM128")) : 1;
-  return v != 0;
-}
+// CGS_VMC_GEMM128=0: the 64 x 64 kernel for every shape (A/B measurements); =2: the 128 x 128 kernel
+// wherever its operand layout allows, whatever the grid size (tests: small shapes with ragged edges).
+// Read at every launch so that a test can compare the two in one process.
+static int gemm128_mode() { const char* e = getenv("CGS_VMC_GEMM128"); return e ? atoi(e) : 1; }
 static bool gemm128_applies(const GemmArgs& g) {
-  return gemm128_enabled() && g.sak == 1 && g.sbn == 1 && g.splitk <= 1 && !g.dual && !g.ones_row && !g.kscale &&
-         g.M >= 4 * G2_TM && g.N >= G2_TN && g.K >= 4 * G2_TK && g.K % 4 == 0 && g.N % 4 == 0 &&
+  const int mode = gemm128_mode();
+  return mode != 0 && g.sak == 1 && g.sbn == 1 && g.splitk <= 1 && !g.dual && !g.ones_row && !g.kscale &&
+         g.N >= G2_TN && g.K >= 4 * G2_TK && g.K % 4 == 0 && g.N % 4 == 0 &&
+         // at least four 4-wave workgroups per CU (256 CUs): with fewer the 64 x 64 tiles' larger grid hides
+         // latency better (4096 x 1024 x 1024, the sampler's shape: 86 us against 111 us with 256 large tiles)
+         (mode == 2 || (long long)((g.M + G2_TM - 1) / G2_TM) * ((g.N + G2_TN - 1) / G2_TN) >= 1024) &&
          g.sam % 4 == 0 && g.sbk % 4 == 0 && ((size_t)g.A & 15) == 0 && ((size_t)g.B & 15) == 0 &&
          (long long)g.K * g.sbk < (1LL << 31);
 }

@@ -179,3 +179,33 @@ def test_wide_fast_and_general_path_agree(monkeypatch):
   _close(l0, l1, 2e-5)
   _close(e0, e1, 2e-4)
   assert np.abs(a0 - a1).max() < 2e-3 * np.abs(a1).max()
+
+
+@pytest.mark.parametrize('n,h,L,b,kind', [(16, 1000, 3, 40, 'chain'), (36, 644, 4, 33, 'torus6x6'), (10, 1024, 2, 64, 'chain')])
+def test_general_path_gemm_tilings_agree(monkeypatch, n, h, L, b, kind):
+  """The general path's H x H layers on the 128 x 128-tile kernel (k_gemm128, forced with CGS_VMC_GEMM128=2:
+  by itself it only takes grids of >= 1024 tiles) against the oracle and against the 64 x 64-tile kernel
+  (CGS_VMC_GEMM128=0): ragged row counts, widths that are no multiple of the tile (1000, 644), K tails."""
+  from cgs_vmc_amd.engine import VmcEngine
+  rng = np.random.default_rng(3)
+  theta = vo.init_params(n, h, L, rng)
+  theta += (0.02 * rng.standard_normal(theta.size)).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(4))
+  bonds = _bonds(kind, n)
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+  e_ref = vo.local_value(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64)
+  outs = []
+  for mode in ('2', '0'):
+    monkeypatch.setenv('CGS_VMC_GEMM128', mode)
+    eng = VmcEngine(n, b, L, h, seed=2024)
+    assert eng.kernel_path() == 2
+    eng.set_params(theta); eng.set_configs(cfg); eng.set_bonds(bonds, -1.0, 1.0)
+    logit = eng.amplitude()[0]
+    e = eng.local_energy()[0]
+    _close(logit, vo.fc_logit(theta, cfg, h, L, dtype=np.float64), 2e-5)
+    _close(e, e_ref, 2e-4)
+    eng.mc_steps(n)
+    outs.append((logit, e, eng.get_configs()))
+    eng.close()
+  _close(outs[0][0], outs[1][0], 2e-5)
+  _close(outs[0][1], outs[1][1], 2e-4)
