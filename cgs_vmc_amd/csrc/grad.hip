@@ -822,9 +822,14 @@ void wgrad_fill_problem(void* dst, int index, const float* A, long long lda, con
 #define G2_TN 128
 #define G2_TK 16
 #define G2_LD 132
+// TN = 128.  (TN = 64 -- 128 x 64 tiles for grids the square tile does not fill the chip with -- was measured
+// on the sampler's 4096 x 1024 x 1024 products: 2 % over k_gemm's 64 x 64 tiles, not kept as a launch path.)
+template <int TN>
 __global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int tiles_n) {
+  constexpr int NJ = TN / 64;                        // 32-column accumulators per wave
+  constexpr int BQ = TN / 4, BR = 256 / BQ, BP = G2_TK / BR;   // B tile: quads per k row, k rows per pass, passes
   __shared__ __attribute__((aligned(16))) float As[2][G2_TK][G2_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][G2_TK][G2_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][G2_TK][TN + 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -832,25 +837,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int tm = (j / tiles_n) * 8 + xcd, tn = j % tiles_n;
   if (tm >= tiles_m) return;                        // (whole workgroup; before any barrier)
-  const int m0 = tm * G2_TM, n0 = tn * G2_TN;
+  const int m0 = tm * G2_TM, n0 = tn * TN;
   const int T = (g.K + G2_TK - 1) / G2_TK;
   // this thread's two quads of the A tile (row am + 64 i, k quad ak) and of the B tile (k row bk + 8 i, n quad bn)
   const int am = tid >> 2, ak = 4 * (tid & 3);
-  const int bk = tid >> 5, bn = 4 * (tid & 31);
+  const int bk = tid / BQ, bn = 4 * (tid % BQ);
   const float* ap[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) ap[i] = g.A + (long long)min(m0 + am + 64 * i, g.M - 1) * g.sam;
   const bool b_in = n0 + bn < g.N;                  // N % 4 == 0: a quad is inside or outside as a whole
   const float* bp = g.B + (b_in ? n0 + bn : 0);
-  f32x4 ra[2], rb[2];
+  f32x4 ra[2], rb[BP];
   const int sbk = (int)g.sbk;                       // K * sbk < 2^31 (gemm128_applies)
   auto request = [&](int t) {
     const int k0 = min(t, T - 1) * G2_TK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      ra[i] = *(const f32x4*)(ap[i] + min(k0 + ak, g.K - 4));
-      rb[i] = *(const f32x4*)(bp + min(k0 + bk + 8 * i, g.K - 1) * sbk);
-    }
+    for (int i = 0; i < 2; ++i) ra[i] = *(const f32x4*)(ap[i] + min(k0 + ak, g.K - 4));
+#pragma unroll
+    for (int i = 0; i < BP; ++i) rb[i] = *(const f32x4*)(bp + min(k0 + bk + BR * i, g.K - 1) * sbk);
     // (the loads stay HERE, a whole tile of MFMAs ahead of their use: without the barrier the compiler
     // sinks them behind the products, next to the stage that consumes them)
     __builtin_amdgcn_sched_barrier(0);
@@ -862,15 +866,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int
       const bool a_ok = k0 + ak < g.K;              // K % 4 == 0
 #pragma unroll
       for (int e = 0; e < 4; ++e) As[st][ak + e][am + 64 * i] = a_ok ? ra[i][e] : 0.f;
-      const bool b_ok = b_in && k0 + bk + 8 * i < g.K;
-      *(f32x4*)&Bs[st][bk + 8 * i][bn] = b_ok ? rb[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const bool b_ok = b_in && k0 + bk + BR * i < g.K;
+      *(f32x4*)&Bs[st][bk + BR * i][bn] = b_ok ? rb[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
+    for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
   request(0);
@@ -881,13 +888,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int
     request(t + 1);                                 // (clamped: the last one re-reads tile T - 1, unused)
     const int st = t & 1;
     // operands of k-step s + 1 are read before the products of step s issue (one LDS round trip ahead)
-    float av[2][2], bv[2][2];
-    auto operands = [&](int kk, float (&a2)[2], float (&b2)[2]) {
+    float av[2][2], bv[2][NJ];
+    auto operands = [&](int kk, float (&a2)[2], float (&b2)[NJ]) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a2[i] = As[st][kk + hi][wm * 64 + 32 * i + l31];
-        b2[i] = Bs[st][kk + hi][wn * 64 + 32 * i + l31];
-      }
+      for (int i = 0; i < 2; ++i) a2[i] = As[st][kk + hi][wm * 64 + 32 * i + l31];
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) b2[jj] = Bs[st][kk + hi][wn * (TN / 2) + 32 * jj + l31];
     };
     operands(0, av[0], bv[0]);
 #pragma unroll
@@ -897,36 +903,40 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < NJ; ++jj)
           acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks & 1][i], bv[ks & 1][jj], acc[i][jj], 0, 0, 0);
     }
     if (t + 1 < T) stage(t + 1);                    // uniform
     __syncthreads();
   }
   auto finish = [&](const f32x16& v, int i, int jj) {
-    const int n = n0 + wn * 64 + 32 * jj + l31;
+    const int n = n0 + wn * (TN / 2) + 32 * jj + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
       if (m < g.M && n < g.N) gemm_epilogue(g, g.C, m, n, v[r]);
     }
   };
-  finish(acc[0][0], 0, 0); finish(acc[0][1], 0, 1); finish(acc[1][0], 1, 0); finish(acc[1][1], 1, 1);
+  finish(acc[0][0], 0, 0); finish(acc[1][0], 1, 0);
+  if constexpr (NJ == 2) { finish(acc[0][1], 0, 1); finish(acc[1][1], 1, 1); }
 }
 
 // CGS_VMC_GEMM128=0: the 64 x 64 kernel for every shape (A/B measurements); =2: the 128 x 128 kernel
 // wherever its operand layout allows, whatever the grid size (tests: small shapes with ragged edges).
 // Read at every launch so that a test can compare the two in one process.
 static int gemm128_mode() { const char* e = getenv("CGS_VMC_GEMM128"); return e ? atoi(e) : 1; }
-static bool gemm128_applies(const GemmArgs& g) {
-  const int mode = gemm128_mode();
-  return mode != 0 && g.sak == 1 && g.sbn == 1 && g.splitk <= 1 && !g.dual && !g.ones_row && !g.kscale &&
-         g.N >= G2_TN && g.K >= 4 * G2_TK && g.K % 4 == 0 && g.N % 4 == 0 &&
-         // at least four 4-wave workgroups per CU (256 CUs): with fewer the 64 x 64 tiles' larger grid hides
-         // latency better (4096 x 1024 x 1024, the sampler's shape: 86 us against 111 us with 256 large tiles)
-         (mode == 2 || (long long)((g.M + G2_TM - 1) / G2_TM) * ((g.N + G2_TN - 1) / G2_TN) >= 1024) &&
+static bool gemm128_layout_ok(const GemmArgs& g) {
+  return g.sak == 1 && g.sbn == 1 && g.splitk <= 1 && !g.dual && !g.ones_row && !g.kscale &&
+         g.N >= 64 && g.K >= 4 * G2_TK && g.K % 4 == 0 && g.N % 4 == 0 &&
          g.sam % 4 == 0 && g.sbk % 4 == 0 && ((size_t)g.A & 15) == 0 && ((size_t)g.B & 15) == 0 &&
          (long long)g.K * g.sbk < (1LL << 31);
+}
+static bool gemm128_applies(const GemmArgs& g) {
+  const int mode = gemm128_mode();
+  // at least four 4-wave workgroups per CU (256 CUs): with fewer the 64 x 64 tiles' larger grid hides
+  // latency better (4096 x 1024 x 1024, the sampler's shape: 86 us against 111 us with 256 large tiles)
+  return mode != 0 && gemm128_layout_ok(g) && g.N >= G2_TN &&
+         (mode == 2 || (long long)((g.M + G2_TM - 1) / G2_TM) * ((g.N + G2_TN - 1) / G2_TN) >= 1024);
 }
 
 __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
@@ -947,7 +957,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
   if (gemm128_applies(g)) {
     const int tiles_m = (g.M + G2_TM - 1) / G2_TM, tiles_n = (g.N + G2_TN - 1) / G2_TN;
     const int blocks = ((tiles_m + 7) / 8) * 8 * tiles_n;      // whole rounds of the eight XCDs
-    hipLaunchKernelGGL(k_gemm128, dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);
+    hipLaunchKernelGGL(k_gemm128<G2_TN>, dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);
     return hipGetLastError();
   }
   const int m_rows = g.ones_row ? g.M - 1 : g.M;

@@ -146,7 +146,11 @@ __global__ void k_wide_build(const float* __restrict__ z1, const float* __restri
   }
 }
 
-// Metropolis test and commit (graph_builders.py:75-88): one wave per chain
+// Metropolis test and commit (graph_builders.py:75-88).  A workgroup takes 16 chains: 16 threads decide and
+// commit the scalars, one atomic per workgroup carries the accept count (one per accepted chain serialised
+// ~2000 atomics on one address: 54 us per step at 4096 chains), then all threads copy the accepted chains'
+// candidate first layer in 16-byte pieces.
+#define WIDE_ACC_CHAINS 16
 __global__ __launch_bounds__(256) void k_wide_accept(float* __restrict__ configs, float* __restrict__ z1,
                                                      const float* __restrict__ zc, float* __restrict__ logit,
                                                      const float* __restrict__ lnew, const int* __restrict__ iup,
@@ -155,22 +159,39 @@ __global__ __launch_bounds__(256) void k_wide_accept(float* __restrict__ configs
                                                      unsigned long long* __restrict__ accepted,
                                                      unsigned char* __restrict__ acc_mask,
                                                      float* __restrict__ onsite, const float* __restrict__ won) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= B) return;
-  const float uu = u[c];
-  const bool acc = vmc_out_accept(oact, lnew[c], logit[c], uu, 0.5f * __logf(uu));
-  if (acc) {
-    for (int h = lane; h < Hp; h += 64) z1[(long long)c * Hp + h] = zc[(long long)c * Hp + h];
-    if (lane == 0) {
-      configs[(long long)c * N + idn[c]] += 2.f;      // graph_builders.py:67-71
-      configs[(long long)c * N + iup[c]] -= 2.f;
-      logit[c] = lnew[c];
-      if (onsite) onsite[c] = fmaf(2.f, won[idn[c]] - won[iup[c]], onsite[c]);
-      atomicAdd(accepted, 1ull);
+  __shared__ int s_acc[WIDE_ACC_CHAINS];
+  const int c0 = blockIdx.x * WIDE_ACC_CHAINS;
+  if (threadIdx.x < WIDE_ACC_CHAINS) {
+    const int c = c0 + threadIdx.x;
+    bool acc = false;
+    if (c < B) {
+      const float uu = u[c];
+      acc = vmc_out_accept(oact, lnew[c], logit[c], uu, 0.5f * __logf(uu));
+      if (acc) {
+        configs[(long long)c * N + idn[c]] += 2.f;      // graph_builders.py:67-71
+        configs[(long long)c * N + iup[c]] -= 2.f;
+        logit[c] = lnew[c];
+        if (onsite) onsite[c] = fmaf(2.f, won[idn[c]] - won[iup[c]], onsite[c]);
+      }
+      if (acc_mask) acc_mask[c] = acc ? 1 : 0;
+    }
+    s_acc[threadIdx.x] = acc ? 1 : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < WIDE_ACC_CHAINS; ++i) n += s_acc[i];
+    if (n) atomicAdd(accepted, (unsigned long long)n);
+  }
+  const int q = Hp >> 2;
+  for (int i = threadIdx.x; i < WIDE_ACC_CHAINS * q; i += 256) {
+    const int s = i / q, c4 = (i - s * q) * 4;
+    if (s_acc[s]) {
+      const long long o = (long long)(c0 + s) * Hp + c4;
+      *(f32x4*)(z1 + o) = *(const f32x4*)(zc + o);
     }
   }
-  if (lane == 0 && acc_mask) acc_mask[c] = acc ? 1 : 0;
 }
 
 // delta of the last hidden layer: d logit / d z_L = w_out (.) f'(z_L) (x the output-activation factor)
@@ -225,7 +246,7 @@ hipError_t launch_wide_accept(hipStream_t s, float* configs, float* z1, const fl
                               const float* lnew, const int* iup, const int* idn, const float* u, int B, int N,
                               int Hp, int oact, unsigned long long* accepted, unsigned char* acc_mask,
                               float* onsite, const float* won) {
-  hipLaunchKernelGGL(k_wide_accept, dim3((B + 3) / 4), dim3(256), 0, s, configs, z1, zc, logit, lnew, iup, idn,
+  hipLaunchKernelGGL(k_wide_accept, dim3((B + WIDE_ACC_CHAINS - 1) / WIDE_ACC_CHAINS), dim3(256), 0, s, configs, z1, zc, logit, lnew, iup, idn,
                      u, B, N, Hp, oact, accepted, acc_mask, onsite, won);
   return hipGetLastError();
 }
