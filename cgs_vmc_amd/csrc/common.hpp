@@ -270,7 +270,8 @@ struct GemmArgs {
   int act;                              // hidden activation id of epilogues 1 / 5 / 6
   float* dact_out;                      // epilogue 1: also store f'(z) (layout of C) or nullptr
   int epilogue;                         // 0 none, 1 f(v + bias), 3 accumulate (C += ), 4 bias,
-                                        // 5 f' (.) (v + bias), 6 f' (.) (C + v + bias), 7 tanh(v + bias), 8 C + v + bias
+                                        // 5 f' (.) (v + bias), 6 f' (.) (C + v + bias), 7 tanh(v + bias), 8 C + v + bias,
+                                        // 9 mask (.) (v + bias) with mask = a stored f'(z)
   int splitk;                           // >= 1
   float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
 };
@@ -370,4 +371,4 @@ hipError_t launch_wide_accept(hipStream_t s, float* configs, float* z1, const fl
                               int Hp, int oact, unsigned long long* accepted, unsigned char* acc_mask,
                               float* onsite = nullptr, const float* won = nullptr);
 hipError_t launch_wide_delta_last(hipStream_t s, const float* a_last, const float* wout, const float* oscale,
-                                  int B, int H, int Hp, int act, float* delta);
+                                  int B, int H, int Hp, int act, float* delta, const float* dact = nullptr);

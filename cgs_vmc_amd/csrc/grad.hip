@@ -41,6 +41,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, int m
     // tangent pass: f'(z) (.) (...), f' read off the stored activation a = f(z)
     case 5: *c = vmc_dact_rt(g.act, g.mask[(long long)m * g.ldmask + n], g.mask[(long long)m * g.ldmask + n]) * (v + g.bias[n]); break;
     case 7: *c = tanhf(v + g.bias[n]); break;
+    case 9: *c = g.mask[(long long)m * g.ldmask + n] * (v + g.bias[n]); break;   // mask IS f'(z) (cosine: stored by epilogue 1)
     case 8: *c = *c + v + g.bias[n]; break;
     case 6: *c = vmc_dact_rt(g.act, g.mask[(long long)m * g.ldmask + n], g.mask[(long long)m * g.ldmask + n]) * (*c + v + g.bias[n]); break;
     default: *c = v; break;

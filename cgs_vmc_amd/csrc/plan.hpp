@@ -335,8 +335,8 @@ inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, c
   const bool wide = !conv && d->layer_size > 256;
   const int n_hh = conv ? 0 : (rbm ? d->num_layers : d->num_layers - 1);
   // 257 .. 512 units run the fused kernels (every activation); beyond that -- or with the fused path
-  // switched off or out of LDS -- the general path, whose back-propagation reads f' off the
-  // activation and therefore has no cos
+  // switched off or out of LDS -- the general path (every activation: its back-propagation reads f' off
+  // the activation, or off the stored f'(z) for the cosine)
   bool wide_fast = false;
   if (wide && d->layer_size <= 512) {
     const int hp = (d->layer_size + 127) / 128 * 128;     // 8 waves x whole 16-unit tiles
@@ -344,8 +344,6 @@ inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, c
                 plan_sweep_lds_required(d->n_sites, hp, n_hh, rbm) <= PLAN_LDS_PER_CU;
   }
   if (wide && d->layer_size > 4096) PLAN_FAIL(VMC_ERR_UNSUPPORTED, "fc_layer_size > 4096 is not supported");
-  if (wide && !wide_fast && d->nonlinearity == VMC_ACT_COS)
-    PLAN_FAIL(VMC_ERR_UNSUPPORTED, "nonlinearity cos is supported up to 512 units (the fused kernels); the general path beyond has every other activation");
   if (!conv && !wide) {  // the sampler keeps 16 chains' spins, z1 and operands in LDS (160 KiB per CU)
     const int hp = (d->layer_size + 63) / 64 * 64;
     const size_t need = plan_sweep_lds_required(d->n_sites, hp, n_hh, rbm);

@@ -1314,13 +1314,15 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e,
       HIPCHK(c, hipMemcpyAsync(c->delta[NH], c->act[NH], (size_t)B * Hp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     else
     HIPCHK(c, launch_wide_delta_last(c->stream, c->act[NH], p.woutp, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr,
-                                     B, H, Hp, c->hact, c->delta[NH]));
+                                     B, H, Hp, c->hact, c->delta[NH],
+                                     c->dact_all ? c->dact_all + (long long)NH * B * Hp : nullptr));
     for (int l = NH; l >= 1; --l) {
       GemmArgs g; memset(&g, 0, sizeof(g));
       g.A = c->delta[l]; g.sam = Hp; g.sak = 1;
       g.B = p.theta + off_w(c, l); g.sbk = 1; g.sbn = H;          // B(k = out, n = in) = W_l[in][out]
       g.M = B; g.N = H; g.K = H; g.C = c->delta[l - 1]; g.ldc = Hp;
       g.bias = c->wide_zero; g.mask = c->act[l - 1]; g.ldmask = Hp; g.epilogue = 5; g.splitk = 1; g.act = c->hact;
+      if (c->dact_all) { g.mask = c->dact_all + (long long)(l - 1) * B * Hp; g.epilogue = 9; }   // cosine: the stored f'(z)
       HIPCHK(c, launch_gemm(c->stream, g));
     }
   } else
@@ -1758,8 +1760,6 @@ int vmc_evaluate(vmc_ctx* c, void* nccl_comm, int32_t world_size, int64_t n_eq_s
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   ENTER(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
-  if (n_batches > 0 && c->wide && !c->wide_fast)
-    return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the dense ansatz types up to 512 hidden units and the convolutional ones");
   if (n_batches > 0 && c->oact != VMC_ACT_EXP_)
     return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation (every hidden activation)");
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -195,14 +195,16 @@ __global__ __launch_bounds__(256) void k_wide_accept(float* __restrict__ configs
 }
 
 // delta of the last hidden layer: d logit / d z_L = w_out (.) f'(z_L) (x the output-activation factor)
+// (`dact` != nullptr: the stored f'(z) of the layer -- the cosine, whose derivative is no function of a)
 __global__ void k_wide_delta_last(const float* __restrict__ a_last, const float* __restrict__ wout,
                                   const float* __restrict__ oscale, int B, int H, int Hp, int act,
-                                  float* __restrict__ delta) {
+                                  float* __restrict__ delta, const float* __restrict__ dact) {
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)B * Hp;
        idx += (long long)gridDim.x * blockDim.x) {
     const int b = (int)(idx / Hp), h = (int)(idx % Hp);
     const float a = a_last[idx];
-    delta[idx] = h < H ? wout[h] * vmc_dact_rt(act, a, a) * (oscale ? oscale[b] : 1.f) : 0.f;
+    const float d = dact ? dact[idx] : vmc_dact_rt(act, a, a);
+    delta[idx] = h < H ? wout[h] * d * (oscale ? oscale[b] : 1.f) : 0.f;
   }
 }
 
@@ -252,8 +254,8 @@ hipError_t launch_wide_accept(hipStream_t s, float* configs, float* z1, const fl
 }
 
 hipError_t launch_wide_delta_last(hipStream_t s, const float* a_last, const float* wout, const float* oscale,
-                                  int B, int H, int Hp, int act, float* delta) {
+                                  int B, int H, int Hp, int act, float* delta, const float* dact) {
   hipLaunchKernelGGL(k_wide_delta_last, dim3(blocks_for((long long)B * Hp)), dim3(256), 0, s, a_last, wout,
-                     oscale, B, H, Hp, act, delta);
+                     oscale, B, H, Hp, act, delta, dact);
   return hipGetLastError();
 }

@@ -61,7 +61,7 @@ enum { VMC_ANSATZ_FULLY_CONNECTED = 0, VMC_ANSATZ_RBM = 1, VMC_ANSATZ_CONV_2D = 
        VMC_ANSATZ_RES_NET_2D = 3, VMC_ANSATZ_CONV_1D = 4, VMC_ANSATZ_RES_NET_1D = 5 };
 
 /* layers.NONLINEARITIES ids (layers.py:13-21).  Every id is accepted as hidden and as output
- * activation of every ansatz type with kernels (dense types beyond 512 hidden units: not cos). */
+ * activation of every ansatz type with kernels. */
 enum { VMC_ACT_RELU = 0, VMC_ACT_EXP = 1, VMC_ACT_COS = 2, VMC_ACT_TAN = 3, VMC_ACT_TANH = 4,
        VMC_ACT_SIGMOID = 5, VMC_ACT_IDENTITY = 6 };
 
@@ -73,7 +73,7 @@ typedef struct {
   int32_t layer_size;        /* hparams.fc_layer_size (utils.py:105): fully_connected and rbm take up
                                 to 4096 units -- the fused kernels up to 512 (any nonlinearity),
                                 beyond that the general multi-launch path
-                                (materialised rows + GEMMs, no cos; two [131072][units] float
+                                (materialised rows + GEMMs; two [131072][units] float
                                 buffers per ctx: 4 GiB at 4096 units).  Convolutional ansatz types:
                                 num_conv_filters (111), at most 64 (four 16-channel MFMA blocks) */
   int32_t nonlinearity;      /* VMC_ACT_*: hparams.nonlinearity  (utils.py:128)      */
@@ -279,7 +279,7 @@ int vmc_evaluate(vmc_ctx* ctx, void* nccl_comm, int32_t world_size, int64_t n_eq
  * vmc_sr_reserve(n) allocates the sample store for n accumulate calls (chains, activations,
  * back-propagated deltas: 2 L B Hp + B N floats each; convolutional types: the taped inputs and
  * deltas of every convolution, (2 n_conv - 1) B CS floats) and switches recording on; 0 frees it.
- * Covered: fully_connected and rbm up to 512 hidden units, the convolutional types; exp output.
+ * Covered: fully_connected and rbm (every width the library takes), the convolutional types; exp output.
  * Matrix-free conjugate gradients: vmc_sr_begin (x = 0, r = p = f from the accumulators, which
  * must already be all-reduced), then per iteration vmc_sr_matvec_partial (this rank's
  * sum_b (O_b . p) O_b into the P+1-float buffer of vmc_sr_buffer_devptr, last float =

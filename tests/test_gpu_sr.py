@@ -241,10 +241,15 @@ def test_sr_rbm_matvec_and_solution(n, h, L, b, kind, n_store):
 
 @pytest.mark.parametrize('ansatz,n,h,L,b,n_store', [('fully_connected', 8, 272, 2, 24, 2),    # padded to 384 units
                                                     ('fully_connected', 10, 500, 3, 20, 2),   # padded to 512, two H x H layers
-                                                    ('rbm', 8, 300, 1, 24, 2)])
+                                                    ('rbm', 8, 300, 1, 24, 2),
+                                                    # round 4: the general path beyond 512 units (same sample store)
+                                                    ('fully_connected', 8, 640, 2, 20, 2),
+                                                    ('fully_connected', 10, 1000, 3, 12, 2),
+                                                    ('rbm', 8, 600, 1, 16, 2)])
 def test_sr_beyond_256_units_matvec_and_solution(ansatz, n, h, L, b, n_store):
-  """SR on the fused 257 .. 512-unit path (round 3): the row-dot / weighted-sum kernels take the layer
-  in <= 256-unit blocks.  P is ~1e5 here, so the reference is the matrix-free fp64 operator
+  """SR on the fused 257 .. 512-unit path (round 3) and on the general path beyond (round 4): the
+  row-dot / weighted-sum kernels take the layer
+  in <= 256-unit blocks.  P is ~1e5 .. 2e6 here, so the reference is the matrix-free fp64 operator
   S v = O^T (O v) / n - <O> mean(O v) on the explicit per-sample gradients, and the CG solution is
   checked through its residual (and against the fp64 run of the same recurrence)."""
   from cgs_vmc_amd.engine import VmcEngine
@@ -254,7 +259,7 @@ def test_sr_beyond_256_units_matvec_and_solution(ansatz, n, h, L, b, n_store):
   theta += (0.03 * rng.standard_normal(theta.size)).astype(np.float32)
   bonds = vo.chain_bonds(n)
   eng = VmcEngine(n, b, L, h, seed=2024, ansatz=ansatz)
-  assert eng.kernel_path() == 1
+  assert eng.kernel_path() == (1 if h <= 512 else 2)
   eng.set_params(theta)
   eng.set_bonds(bonds, -1.0, 1.0)
   eng.sr_reserve(n_store)

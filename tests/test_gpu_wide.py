@@ -30,6 +30,8 @@ WIDE_SHAPES = [
     (16, 320, 2, 27, 'torus4x4', 'cos'),       # cos: f'(z) arrays next to the activations, 384 padded units
     (20, 512, 3, 22, 'chain', 'cos'),
     (16, 640, 2, 19, 'chain', 'relu'),        # more than 512 units: general path
+    (16, 640, 3, 21, 'torus4x4', 'cos'),      # ... with the cosine (round 4): back-propagation through the stored f'(z)
+    (12, 1000, 2, 14, 'chain', 'tanh'),
 ]
 
 
@@ -142,13 +144,12 @@ def test_wide_energy_gradient_accumulators(n, h, L, b, kind, nonlin):
 def test_wide_limits():
   from cgs_vmc_amd.engine import VmcEngine
   with pytest.raises(NotImplementedError):
-    VmcEngine(16, 8, 2, 640, nonlinearity='cos')        # the general path has no cos
-  with pytest.raises(NotImplementedError):
     VmcEngine(16, 8, 2, 4100, ansatz='rbm')
   for ansatz in ('fully_connected', 'rbm'):
-    eng = VmcEngine(16, 8, 2, 640, ansatz=ansatz)     # beyond 512 units: general path, no SR
-    with pytest.raises(NotImplementedError):
-      eng.sr_reserve(2)
+    eng = VmcEngine(16, 8, 2, 640, ansatz=ansatz)     # beyond 512 units: general path (SR: tests/test_gpu_sr.py)
+    assert eng.kernel_path() == 2
+    eng.sr_reserve(2)
+    eng.sr_reserve(0)
     eng.close()
 
 
