@@ -19,9 +19,10 @@ hipError_t VMC_CAT(launch_backprop16_inst_, VMC_INST_ACT)(hipStream_t s, const f
                                                           const float* woutp, int B, int Hp,
                                                           int n_hidden, bool rbm,
                                                           const float* dact_all,
-                                                          const float* oscale, const ElocFold& ef) {
+                                                          const float* oscale, const ElocFold& ef,
+                                                          const OutLayerSums& out) {
   return launch_backprop16_t<VMC_INST_ACT>(s, act_all, delta_all, p16t, woutp, B, Hp, n_hidden, rbm,
-                                           dact_all, oscale, ef);
+                                           dact_all, oscale, ef, out);
 }
 
 // 257 .. 512 hidden units (384 / 512 padded): the LDS-operand row kernel of tail_lds.hpp

@@ -225,10 +225,16 @@ hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp,
 // chain by chain with its summation order: the workgroup that owns 16 chains also folds their rows of
 // `val`), one dependent launch (6 us at config 3) less per step; off == nullptr: nothing to fold
 struct ElocFold { const int* off; const float* diag; const float* val; float* offdiag; float* eloc; };
+// out: the output layer's weight gradient (fully_connected: sum_b (1 | w_b) s_b [a_L(b) | 1], s = oscale or 1)
+// as per-workgroup partial sums over the 16 chains a workgroup owns anyway, part[workgroup][2][Hp + 4]
+// (slot Hp: the bias); k_wgrad folds them (its N = 1 tiles -- one column of 64 used -- leave the MFMA grid,
+// which frees a k-slice).  w == ElocFold::eloc: the weights are the local energies this launch folds.
+struct OutLayerSums { float* part; const float* w; };
 hipError_t launch_backprop16(hipStream_t s, const float* act_all, float* delta_all,
                              const float* p16t, const float* woutp, int B, int Hp, int n_hidden,
                              bool rbm, int act, const float* dact_all, const float* oscale,
-                             const ElocFold& eloc = ElocFold{nullptr, nullptr, nullptr, nullptr, nullptr});
+                             const ElocFold& eloc = ElocFold{nullptr, nullptr, nullptr, nullptr, nullptr},
+                             const OutLayerSums& out = OutLayerSums{nullptr, nullptr});
 hipError_t launch_tail(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm);
 hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, int rows, int N,
                          float* out);
@@ -289,6 +295,8 @@ struct WgradLaunch {
   float* ws; int* tickets;             // plan_wgrad_ws_floats(tiles, slices) floats, `tiles` zeroed ints
   bool fresh;                          // the accumulators hold no sum yet: store
   const float* sc_eloc; const float* sc_ratio; float* sc_out; int sc_B, sc_mode;   // scalar accumulators (sc_out may be null)
+  // output layer from k_backprop16's partials (OutLayerSums) or nullptr: [out_nwg][2][out_ld] -> g1 / g2 + out_off
+  const float* out_part; int out_nwg, out_H, out_ld; long long out_off;
 };
 size_t wgrad_problem_bytes();
 void wgrad_fill_problem(void* dst, int index, const float* A, long long lda, const float* D, long long ldd,

@@ -315,6 +315,7 @@ struct WgradArgs {
   int fresh;                          // 1: the accumulators hold no sum yet (store instead of add)
   unsigned long long* stamps;         // diagnostic build (-DVMC_WGRAD_STAMPS): [blocks][8] wall-clock stamps (100 MHz)
   ScalarJob job;
+  const float* out_part; int out_nwg, out_H, out_ld; long long out_off;   // WgradLaunch: the output layer's partials
 };
 
 // LDS image of one k-tile: A and delta TRANSPOSED, [m or n][position of k], row stride WG_LDT floats; the
@@ -713,6 +714,36 @@ __device__ __forceinline__ void wgrad_tile(const WgradArgs& a, const WgradProble
   WG_STAMP(5);
 }
 
+// The output layer's two sums (and its bias) from the per-workgroup partials of k_backprop16: output
+// idx = s (H + 1) + k of fold block fb is taken by the four threads (idx, row group 0..3); a thread adds its
+// quarter of the partial rows in ascending order, sixteen loads in flight, the four quarters are added as
+// (0 + 1) + (2 + 3) -- a fixed order for a given batch size.
+__device__ __forceinline__ void wgrad_fold_out(const WgradArgs& a, int fb, float* smem) {
+  const int tid = threadIdx.x, o = tid & (WG_FOLD_OUT - 1), gq = tid >> 7;
+  const int idx = fb * WG_FOLD_OUT + o, n_out = 2 * (a.out_H + 1);
+  const bool live = idx < n_out;
+  const int sidx = live ? idx / (a.out_H + 1) : 0, k = live ? idx - sidx * (a.out_H + 1) : 0;
+  const int col = k < a.out_H ? k : a.out_ld - 4;                          // the bias slot: Hp
+  const int per = (a.out_nwg + 3) >> 2, i0 = gq * per, i1 = min(a.out_nwg, i0 + per);
+  const float* src = a.out_part + (long long)sidx * a.out_ld + col;
+  const long long stride = 2LL * a.out_ld;
+  float acc = 0.f;
+  for (int i = i0; i < i1; i += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = src[(long long)min(i + u, i1 - 1) * stride];     // clamped: unconditional
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += i + u < i1 ? v[u] : 0.f;
+  }
+  smem[gq * WG_FOLD_OUT + o] = acc;
+  __syncthreads();
+  if (gq == 0 && live) {
+    const float v = (smem[o] + smem[WG_FOLD_OUT + o]) + (smem[2 * WG_FOLD_OUT + o] + smem[3 * WG_FOLD_OUT + o]);
+    float* dst = (sidx ? a.g2 : a.g1) + a.out_off + k;
+    if (a.fresh) *dst = v; else *dst += v;
+  }
+}
+
 __global__ __launch_bounds__(512) void k_wgrad(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wg_smem[];
   const int b = blockIdx.x;
@@ -728,8 +759,11 @@ __global__ __launch_bounds__(512) void k_wgrad(WgradArgs a) {
       wgrad_tile<true>(a, P, m.slice, m.tile, wg_smem);
     else
       wgrad_tile<false>(a, P, m.slice, m.tile, wg_smem);
-  } else if (a.job.sc && threadIdx.x < 256) {     // (waves 4 .. 7 retire: 256 threads do the scalars)
-    scalar_accum_body(a.job, a.fresh != 0, (double*)wg_smem, (double*)wg_smem + 256);
+  } else if (b == a.mfma_blocks) {                // the scalar accumulators' block (always present in the grid)
+    if (a.job.sc && threadIdx.x < 256)            // (waves 4 .. 7 retire: 256 threads do the scalars)
+      scalar_accum_body(a.job, a.fresh != 0, (double*)wg_smem, (double*)wg_smem + 256);
+  } else if (a.out_part) {
+    wgrad_fold_out(a, b - a.mfma_blocks - 1, wg_smem);
   }
 }
 
@@ -748,7 +782,9 @@ hipError_t launch_wgrad(hipStream_t s, const WgradLaunch& L) {
   a.K = L.K; a.w = L.w; a.g1 = L.g1; a.g2 = L.g2; a.ws = L.ws; a.tickets = L.tickets; a.fresh = L.fresh ? 1 : 0;
   a.job = ScalarJob{L.sc_eloc, L.sc_ratio, L.sc_out, L.sc_B, L.sc_mode};
 
-  const int grid = a.mfma_blocks + (L.sc_out ? 1 : 0);
+  a.out_part = L.out_part; a.out_nwg = L.out_nwg; a.out_H = L.out_H; a.out_ld = L.out_ld; a.out_off = L.out_off;
+  const int n_fold = L.out_part ? plan_wgrad_fold_blocks(L.out_H) : 0;
+  const int grid = a.mfma_blocks + ((L.sc_out || n_fold) ? 1 : 0) + n_fold;
   if (grid <= 0 || L.K <= 0) return hipSuccess;
   static bool attr_set = false;
   const size_t lds = wgrad_lds_bytes();

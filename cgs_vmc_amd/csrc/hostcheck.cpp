@@ -80,16 +80,27 @@ static void check_block_maps() {
 
 // the batched weight-gradient kernel: tiles, K slices and their chunks, the partial-tile workspace and
 // the (tile -> problem, m-tile, n-tile) walk of k_wgrad
-static void check_wgrad(long long N, long long H, int n_hh, bool rbm, long long B) {
+// (out_in_tiles = false: the output layer's sums come from the back-propagation kernel's partials and are
+// folded by extra workgroups of the launch -- fully_connected on the fused kernels)
+static void check_wgrad(long long N, long long H, int n_hh, bool rbm, long long B, bool out_in_tiles = true) {
   struct Prob { int k_in, n_out, tile0; };
   std::vector<Prob> probs;
   int tile0 = 0;
   auto add = [&](int k_in, int n_out) { probs.push_back({k_in, n_out, tile0}); tile0 += plan_wgrad_tiles(k_in, n_out); };
-  add(rbm ? (int)N : (int)H, 1);
+  if (out_in_tiles) add(rbm ? (int)N : (int)H, 1);
   for (int l = 0; l < n_hh; ++l) add((int)H, (int)H);
   add((int)N, (int)H);
   const long long tiles = tile0;
-  CHECK(tiles == plan_wgrad_total_tiles((int)N, (int)H, n_hh, rbm) && tiles >= 2);
+  CHECK(tiles == plan_wgrad_total_tiles((int)N, (int)H, n_hh, rbm, out_in_tiles) && tiles >= 1);
+  const int other = 1 + (out_in_tiles ? 0 : plan_wgrad_fold_blocks((int)H));
+  if (!out_in_tiles) {   // wgrad_fold_out: every output (two sums x (H weights + bias)) in exactly one (block, lane)
+    const int nb = plan_wgrad_fold_blocks((int)H), n_out = 2 * ((int)H + 1);
+    CHECK(nb >= 1 && nb * WG_FOLD_OUT >= n_out && (nb - 1) * WG_FOLD_OUT < n_out && 4 * WG_FOLD_OUT == 512);
+    const int n_wg = (int)((B + 15) / 16), per = (n_wg + 3) >> 2;
+    int covered = 0;
+    for (int gq = 0; gq < 4; ++gq) { const int i0 = gq * per, i1 = std::min(n_wg, i0 + per); covered += i1 > i0 ? i1 - i0 : 0; }
+    CHECK(covered == n_wg);
+  }
   // every tile belongs to exactly one problem and lies inside its output; together they cover it
   for (const Prob& p : probs) {
     const int tn = (p.n_out + WG_TN - 1) / WG_TN, nt = plan_wgrad_tiles(p.k_in, p.n_out);
@@ -105,9 +116,9 @@ static void check_wgrad(long long N, long long H, int n_hh, bool rbm, long long 
   }
   for (int cus : kCus)
     for (int forced : {0, 1, 3, 12, 100}) {
-      const int s = plan_wgrad_slices(tiles, B, cus, 1, forced);
+      const int s = plan_wgrad_slices(tiles, B, cus, other, forced);
       CHECK(s >= 1 && s <= WG_MAX_SPLIT);
-      if (!forced) CHECK(s == 1 || tiles * s + 1 <= cus);
+      if (!forced) CHECK(s == 1 || tiles * s + other <= cus);
       const int kc = plan_wgrad_kchunk((int)B, s);
       CHECK(kc % WG_TK == 0 && (long long)kc * s >= B);
       CHECK((long long)kc * (s - 1) < B);                 // no slice is empty
@@ -174,7 +185,10 @@ static void dense_grid() {
               CHECK(p.P == plan_num_params_dense(ansatz, n, h, L));
               check_layout(p, n, h);
               check_sweep(d, p);
-              for (long long b : batches) check_wgrad(n, h, p.n_hh, p.rbm != 0, b);
+              for (long long b : batches) {
+                check_wgrad(n, h, p.n_hh, p.rbm != 0, b);
+                if (!p.rbm && !(p.wide && !p.wide_fast)) check_wgrad(n, h, p.n_hh, false, b, false);
+              }
             }
           }
   // the limits of include/cgsvmc.h, and what lies one step beyond them

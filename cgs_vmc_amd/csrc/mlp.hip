@@ -116,7 +116,7 @@ hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n) {
   hipError_t launch_tail_lds_inst_##N(hipStream_t, const TailArgs&, int, bool, bool);            \
   hipError_t launch_backprop16_inst_##N(hipStream_t, const float*, float*, const float*,         \
                                         const float*, int, int, int, bool, const float*,         \
-                                        const float*, const ElocFold&);                          \
+                                        const float*, const ElocFold&, const OutLayerSums&);     \
   hipError_t launch_sweep16_inst_##N(hipStream_t, const SweepArgs&, int);
 VMC_DECL_ACT(0) VMC_DECL_ACT(1) VMC_DECL_ACT(2) VMC_DECL_ACT(3) VMC_DECL_ACT(4) VMC_DECL_ACT(5) VMC_DECL_ACT(6)
 #undef VMC_DECL_ACT
@@ -149,8 +149,8 @@ hipError_t launch_tail_lds(hipStream_t s, const TailArgs& a, int Hp, bool ratio_
 hipError_t launch_backprop16(hipStream_t s, const float* act_all, float* delta_all,
                              const float* p16t, const float* woutp, int B, int Hp, int n_hidden,
                              bool rbm, int act, const float* dact_all, const float* oscale,
-                             const ElocFold& eloc) {
-#define CALL(N) launch_backprop16_inst_##N(s, act_all, delta_all, p16t, woutp, B, Hp, n_hidden, rbm, dact_all, oscale, eloc)
+                             const ElocFold& eloc, const OutLayerSums& out) {
+#define CALL(N) launch_backprop16_inst_##N(s, act_all, delta_all, p16t, woutp, B, Hp, n_hidden, rbm, dact_all, oscale, eloc, out)
   VMC_ACT_SWITCH(act, CALL)
 #undef CALL
 }

@@ -427,9 +427,14 @@ inline int plan_wgrad_grid(int tiles, int slices) { return tiles <= 0 ? 0 : 8 * 
 
 // MFMA tiles of the whole dense gradient launch: the output (FC) / onsite (RBM) problem
 // [k_in = H or N][1], n_hh hidden problems [H][H], the first layer [N][H]
-inline int plan_wgrad_total_tiles(int N, int H, int n_hh, bool rbm) {
-  return plan_wgrad_tiles(rbm ? N : H, 1) + n_hh * plan_wgrad_tiles(H, H) + plan_wgrad_tiles(N, H);
+// out_in_tiles: the N = 1 layer (w_out, b_out / w_on, b_on) is one of the tile problems; false: its sums come
+// from the back-propagation kernel's per-workgroup partials and are folded by plan_wgrad_fold_blocks(H)
+// workgroups of the same launch (fully_connected on the fused kernels)
+inline int plan_wgrad_total_tiles(int N, int H, int n_hh, bool rbm, bool out_in_tiles = true) {
+  return (out_in_tiles ? plan_wgrad_tiles(rbm ? N : H, 1) : 0) + n_hh * plan_wgrad_tiles(H, H) + plan_wgrad_tiles(N, H);
 }
+#define WG_FOLD_OUT 128    // outputs (two sums x (H weights + bias)) per fold workgroup, four row groups each
+inline int plan_wgrad_fold_blocks(int H) { return (2 * (H + 1) + WG_FOLD_OUT - 1) / WG_FOLD_OUT; }
 
 // floats of the partial-tile workspace: [tiles][slices][2 x WG_TM x WG_TN + 2 x WG_TN]
 inline long long plan_wgrad_ws_floats(long long tiles, int slices) {

@@ -359,10 +359,12 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
                                                         const float* __restrict__ woutp, int B,
                                                         int n_hidden, int rbm,
                                                         const float* __restrict__ dact_all,
-                                                        const float* __restrict__ oscale, ElocFold ef) {
+                                                        const float* __restrict__ oscale, ElocFold ef,
+                                                        OutLayerSums op) {
   constexpr int Hp = NT * 16, TO = NT / NW, PF = 4;
   static_assert(NT % NW == 0 && NT % PF == 0, "tiles divide over waves and the prefetch ring");
   __shared__ __attribute__((aligned(16))) float s_x[2 * NT * 256];   // [2][NT][64 lanes][4]
+  __shared__ float s_wj[16];                                         // per-chain weight of the second sum (op.part)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, j = lane & 15;
@@ -395,10 +397,38 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
         for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
         if (lane == 0) {
           if (ef.offdiag) ef.offdiag[c] = sum;
-          ef.eloc[c] = ef.diag[c] + sum;
+          const float e = ef.diag[c] + sum;
+          ef.eloc[c] = e;
+          if (op.part && op.w == ef.eloc) s_wj[wave * (16 / NW) + q] = e;
         }
       }
     }
+  }
+  // output layer's weight gradient over this workgroup's chains (OutLayerSums, common.hpp): the weight of
+  // the second sum is the local energy folded above (through LDS) or a vector of an earlier launch
+  float wj = 0.f;
+  if (op.part) {                                   // block-uniform
+    if (ef.off && op.w == ef.eloc) {
+      __syncthreads();
+      wj = ok ? s_wj[j] : 0.f;
+    } else {
+      wj = ok ? op.w[chain] : 0.f;
+    }
+  }
+  // sum over the 16 lanes of a DPP row (the 16 chains): xor 1, xor 2, half mirror, mirror -- every lane
+  // ends with the same value
+  auto row16_sum = [](float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+    return v;
+  };
+  constexpr int LDP = Hp + 4;
+  float* part = op.part ? op.part + (long long)blockIdx.x * 2 * LDP : nullptr;
+  if (part && wave == 0) {                         // the bias: sum_b s_b and sum_b w_b s_b
+    const float s1 = row16_sum(ok ? osc : 0.f), s2 = row16_sum(ok ? osc * wj : 0.f);
+    if (lane == 0) { part[Hp] = s1; part[LDP + Hp] = s2; }
   }
 
   // last layer's delta for this wave's own unit tiles
@@ -409,6 +439,15 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
     for (int to = 0; to < TO; ++to) {
       const int t = wave * TO + to, col = 16 * t + 4 * g;
       const f32x4 a = *(const f32x4*)(a_last + col);
+      if (part) {
+        f32x4 s1, s2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = ok ? osc * a[e] : 0.f;
+          s1[e] = row16_sum(v); s2[e] = row16_sum(v * wj);
+        }
+        if (j == 0) { *(f32x4*)(part + col) = s1; *(f32x4*)(part + LDP + col) = s2; }
+      }
       f32x4 d;
       if (rbm) d = a;
       else {
@@ -472,18 +511,18 @@ template <int ACT>
 static hipError_t launch_backprop16_t(hipStream_t s, const float* act_all, float* delta_all,
                                       const float* p16t, const float* woutp, int B, int Hp,
                                       int n_hidden, bool rbm, const float* dact_all,
-                                      const float* oscale, const ElocFold& ef) {
+                                      const float* oscale, const ElocFold& ef, const OutLayerSums& op) {
   if (B <= 0) return hipSuccess;
   const dim3 grid((B + 15) / 16);
   const int r = rbm ? 1 : 0;
   switch (Hp / 16) {
-    case 4: hipLaunchKernelGGL((k_backprop16<4, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
-    case 8: hipLaunchKernelGGL((k_backprop16<8, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
-    case 12: hipLaunchKernelGGL((k_backprop16<12, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
-    case 16: hipLaunchKernelGGL((k_backprop16<16, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
+    case 4: hipLaunchKernelGGL((k_backprop16<4, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef, op); break;
+    case 8: hipLaunchKernelGGL((k_backprop16<8, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef, op); break;
+    case 12: hipLaunchKernelGGL((k_backprop16<12, 4, ACT>), grid, dim3(256), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef, op); break;
+    case 16: hipLaunchKernelGGL((k_backprop16<16, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef, op); break;
     // 257 .. 512 hidden units (384 / 512 padded): wave w owns 3 or 4 output tiles, 48 / 64 KB of operands in LDS
-    case 24: hipLaunchKernelGGL((k_backprop16<24, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
-    case 32: hipLaunchKernelGGL((k_backprop16<32, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef); break;
+    case 24: hipLaunchKernelGGL((k_backprop16<24, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef, op); break;
+    case 32: hipLaunchKernelGGL((k_backprop16<32, 8, ACT>), grid, dim3(512), 0, s, act_all, delta_all, p16t, woutp, B, n_hidden, r, dact_all, oscale, ef, op); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -118,6 +118,8 @@ struct vmc_ctx {
   void* d_batch[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // weight-gradient problem tables [w = eloc / ratio][parity]
   bool batch_ready[2][2] = {{false, false}, {false, false}};
   int wg_tiles = 0;                // MFMA tiles of the weight-gradient launch (plan.hpp)
+  bool wg_out_partials = false;    // the output layer's sums come from k_backprop16's partials (OutLayerSums)
+  float* wg_outpart = nullptr;     // [ceil(B / 16)][2][Hp + 4]
   int* wg_tickets = nullptr;       // [wg_tiles] arrival tickets of the split-K fold, zero between launches
   float *ratio = nullptr, *ones = nullptr;
   float *acc = nullptr, *adam_m = nullptr, *adam_v = nullptr, *grad_tmp = nullptr;
@@ -762,7 +764,12 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   for (int l = 0; l < L; ++l) c->delta[l] = c->delta_all + l * B * Hp;
   for (int i = 0; i < 4; ++i) CA(hipMalloc(&c->d_batch[i / 2][i % 2], (size_t)(L + 1) * wgrad_problem_bytes()));
   {  // weight-gradient launch: the tiles of all layers
-    c->wg_tiles = plan_wgrad_total_tiles((int)N, c->H, (int)NH, rbm);
+    // fully_connected on the kernels that run k_backprop16: the N = 1 output layer leaves the MFMA tile grid
+    // (CGS_VMC_WGRAD_OUT_TILES=1 keeps it there: A/B measurements)
+    const char* e_out = getenv("CGS_VMC_WGRAD_OUT_TILES");
+    c->wg_out_partials = !rbm && !conv && !(wide && !c->wide_fast) && !(e_out && atoi(e_out) == 1);
+    c->wg_tiles = plan_wgrad_total_tiles((int)N, c->H, (int)NH, rbm, !c->wg_out_partials);
+    if (c->wg_out_partials) CA(dalloc(&c->wg_outpart, ((B + 15) / 16) * 2 * (Hp + 4)));
     CA(dalloc(&c->wg_tickets, c->wg_tiles > 0 ? c->wg_tiles : 1));
     CA(hipMemsetAsync(c->wg_tickets, 0, (size_t)(c->wg_tiles > 0 ? c->wg_tiles : 1) * sizeof(int), c->stream));
   }
@@ -846,7 +853,7 @@ void vmc_destroy(vmc_ctx* c) {
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->wg_tickets, c->d_accepted, c->d_sum,
                   c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->tmp_on, c->tmp_rowinfo, c->rowinfo_id, c->bond_dummy, c->inj_up, c->inj_dn, c->inj_u,
-                  c->acc_mask};
+                  c->acc_mask, c->wg_outpart};
   for (void* q : ptrs) if (q) hipFree(q);
   for (float* q : {c->sr_ctape, c->sr_cdelta, c->sr_cws, c->sr_cw0, c->sr_cwf, c->sr_cwb, c->sr_cbias}) if (q) hipFree(q);
   void* sr[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_u, c->sr_x, c->sr_r,
@@ -1329,14 +1336,15 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e,
   HIPCHK(c, launch_backprop16(c->stream, c->act_all, c->delta_all, p.p16t, p.woutp, B, Hp, NH, c->rbm, c->hact,
                               c->dact_all, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr,
                               fold_eloc ? ElocFold{c->off, c->diag, c->val, c->offdiag, c->ps[0].eloc}
-                                        : ElocFold{nullptr, nullptr, nullptr, nullptr, nullptr}));
+                                        : ElocFold{nullptr, nullptr, nullptr, nullptr, nullptr},
+                              OutLayerSums{c->wg_out_partials ? c->wg_outpart : nullptr, w}));
   // Every weight gradient is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows 0..K_in-1 give dW, the
   // implicit ones row gives db (b_l sits right behind w_l in theta), the unscaled product goes to g1 and
   // the w-scaled one to g2.  All NH+2 of them and the scalar accumulators run as
   // ONE launch (k_wgrad); the problem table is built once per weight vector `w`.
   const int slot = (w == c->ratio) ? 1 : 0, par = c->parity;
   if (!c->batch_ready[slot][par]) {
-    std::vector<unsigned char> tab((size_t)(NH + 2) * wgrad_problem_bytes());
+    std::vector<unsigned char> tab((size_t)(NH + 2) * wgrad_problem_bytes(), 0);
     int n = 0, tile0 = 0;
     auto add = [&](const float* a, long long a_ld, int k_in, const float* delta, long long ldd, int n_out, long long off) {
       wgrad_fill_problem(tab.data(), n++, a, a_ld, delta, ldd, off, k_in, n_out, tile0);
@@ -1344,7 +1352,7 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e,
     };
     if (c->rbm)   // onsite layer: d logit / d w_on = x, d logit / d b_on = 1
       add(c->configs, N, N, c->ones, 1, 1, c->lay.off_won);
-    else          // output layer: d logit / d w_out = a_L, d logit / d b_out = 1
+    else if (!c->wg_out_partials)   // output layer: d logit / d w_out = a_L, d logit / d b_out = 1
       add(c->act[NH], Hp, H, c->oscale, 1, 1, off_wout(c));   // oscale == 1 for the exp output
     for (int l = NH; l > 0; --l) add(c->act[l - 1], Hp, H, c->delta[l], Hp, H, off_w(c, l));
     add(c->configs, N, N, c->delta[0], Hp, H, off_w(c, 0));
@@ -1356,9 +1364,12 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e,
     static const int forced = getenv("CGS_VMC_WGRAD_SLICES") ? atoi(getenv("CGS_VMC_WGRAD_SLICES")) : 0;   // measurement knob
     WgradLaunch L;
     memset((void*)&L, 0, sizeof(L));
-    L.dev_problems = c->d_batch[slot][par]; L.n_prob = NH + 2;
+    L.dev_problems = c->d_batch[slot][par]; L.n_prob = NH + (c->wg_out_partials ? 1 : 2);
+    if (c->wg_out_partials) {
+      L.out_part = c->wg_outpart; L.out_nwg = (B + 15) / 16; L.out_H = H; L.out_ld = Hp + 4; L.out_off = off_wout(c);
+    }
     L.tiles = c->wg_tiles;
-    L.slices = plan_wgrad_slices(c->wg_tiles, B, c->num_cus, 1, forced);
+    L.slices = plan_wgrad_slices(c->wg_tiles, B, c->num_cus, 1 + (c->wg_out_partials ? plan_wgrad_fold_blocks(H) : 0), forced);
     L.K = B; L.w = w; L.g1 = g1; L.g2 = g2; L.ws = c->gemm_ws; L.tickets = c->wg_tickets; L.fresh = fresh;
     L.sc_eloc = e; L.sc_ratio = mode == 1 ? c->ratio : nullptr; L.sc_out = c->acc + 2 * c->P; L.sc_B = B; L.sc_mode = mode;
     HIPCHK(c, launch_wgrad(c->stream, L));
