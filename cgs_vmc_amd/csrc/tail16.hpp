@@ -361,7 +361,10 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
                                                         const float* __restrict__ dact_all,
                                                         const float* __restrict__ oscale, ElocFold ef,
                                                         OutLayerSums op) {
-  constexpr int Hp = NT * 16, TO = NT / NW, PF = 4;
+#ifndef VMC_BACKPROP_PF
+#define VMC_BACKPROP_PF 8
+#endif
+  constexpr int Hp = NT * 16, TO = NT / NW, PF = (NT % VMC_BACKPROP_PF == 0) ? VMC_BACKPROP_PF : 4;   // weight-ring depth
   static_assert(NT % NW == 0 && NT % PF == 0, "tiles divide over waves and the prefetch ring");
   __shared__ __attribute__((aligned(16))) float s_x[2 * NT * 256];   // [2][NT][64 lanes][4]
   __shared__ float s_wj[16];                                         // per-chain weight of the second sum (op.part)
@@ -483,6 +486,9 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
 #pragma unroll
       for (int to = 0; to < TO; ++to) wb[(ti + PF - 1) % PF][to] = wp[((wave * TO + to) * NT + tn) * 64];
       const f32x4 b = xin[ti * 64];
+      // (the loads stay PF - 1 tiles ahead of their use: unpinned, the compiler sinks each next to its MFMAs and
+      // every k-tile waits an L2 round trip -- the kernel ran at 0.25 MFMA busy, half its wave cycles waiting)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
