@@ -27,16 +27,25 @@ __global__ __launch_bounds__(256) void k_bond_count(const float* __restrict__ co
   const float* x = configs + (long long)c * N;
   float d = 0.f;
   int n = 0;
-  for (int k0 = 0; k0 < n_bonds; k0 += 64) {
-    const int k = k0 + lane;
-    bool anti = false;
-    if (k < n_bonds) {
-      const int2 ab = bonds[k];
-      const float sz = x[ab.x] * x[ab.y];
-      d = fmaf(quarter_jz[k], sz, d);
-      anti = sz < 0.f;
+  // four 64-bond groups per pass, their loads issued together (bonds, then spins): two dependent round
+  // trips per 256 bonds instead of eight (the loop was the kernel's whole time); same per-lane order of the
+  // fused multiply-adds as one group per pass
+  for (int k0 = 0; k0 < n_bonds; k0 += 256) {
+    int2 ab[4]; float q[4], xi[4], xj[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 64 * u + lane, kk = k < n_bonds ? k : 0;
+      ab[u] = bonds[kk]; q[u] = quarter_jz[kk];
     }
-    n += __popcll(__ballot(anti));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { xi[u] = x[ab[u].x]; xj[u] = x[ab[u].y]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool in = k0 + 64 * u + lane < n_bonds;
+      const float sz = xi[u] * xj[u];
+      if (in) d = fmaf(q[u], sz, d);
+      n += __popcll(__ballot(in && sz < 0.f));
+    }
   }
   d = wave_sum(d);
   if (lane == 0) { cnt[c] = n; diag[c] = d; }
@@ -57,6 +66,14 @@ __global__ __launch_bounds__(1024) void k_bond_fill(const float* __restrict__ co
   __shared__ int s_cnt[16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int c0 = blockIdx.x * 16;
+  // the first 256 bonds of this wave's chain travel while the prefix is summed (they do not depend on it)
+  const int cw = c0 + wave < B ? c0 + wave : B - 1;
+  const float* x = configs + (long long)cw * N;
+  int2 ab0[4]; float xi0[4], xj0[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { const int k = 64 * u + lane; ab0[u] = bonds[k < n_bonds ? k : 0]; }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { xi0[u] = x[ab0[u].x]; xj0[u] = x[ab0[u].y]; }
   // sum of cnt[0 .. c0): thread t takes the elements t, t + 1024, ...
   int part = 0;
   for (int i = t; i < c0; i += 1024) part += cnt[i];
@@ -75,12 +92,16 @@ __global__ __launch_bounds__(1024) void k_bond_fill(const float* __restrict__ co
     off[c] = base;
     if (c == B - 1) off[B] = base + s_cnt[wave];
   }
-  const float* x = configs + (long long)c * N;
   for (int k0 = 0; k0 < n_bonds; k0 += 64) {
     const int k = k0 + lane;
     bool anti = false;
     float si = 0.f;
-    if (k < n_bonds) {
+    if (k0 < 256) {                               // (uniform) the prefetched groups
+      const int u = k0 >> 6;
+      si = u == 0 ? xi0[0] : (u == 1 ? xi0[1] : (u == 2 ? xi0[2] : xi0[3]));
+      const float sj = u == 0 ? xj0[0] : (u == 1 ? xj0[1] : (u == 2 ? xj0[2] : xj0[3]));
+      anti = k < n_bonds && si * sj < 0.f;
+    } else if (k < n_bonds) {
       const int2 ab = bonds[k];
       si = x[ab.x];
       anti = si * x[ab.y] < 0.f;
