@@ -90,6 +90,8 @@ struct vmc_ctx {
   hipStream_t sweep_stream = nullptr;   // private non-blocking stream of the sampler
   bool overlap = true;            // CGS_VMC_OVERLAP=0: everything on `stream`
   bool overlap_full = false;      // CGS_VMC_OVERLAP=2: overtake even when the sampler fills every CU
+  bool side_sweep_once = false;   // the next vmc_mc_steps goes to sweep_stream BEHIND everything enqueued so far, so that
+                                  // what follows on `stream` (the accumulator all-reduce of a sharded epoch) runs beside it
   hipEvent_t ev_mark = nullptr;   // recorded on `stream` at the start of the latest accumulate
   hipEvent_t ev_now = nullptr;    // scratch: "everything enqueued on `stream` so far"
   hipEvent_t ev_sweep_done = nullptr;
@@ -1128,15 +1130,20 @@ int vmc_mc_steps(vmc_ctx* c, int64_t n_steps, int64_t* accepted) {
   // for everything enqueued so far.
   const bool after_acc = c->token && c->ps[0].packed_valid;
   c->token = false;
-  const bool overtake = can_overlap(c);
+  // side: a sampler that fills the chip (config 3) cannot overtake its accumulate, but it can leave `stream`
+  // free for the collective that follows it (epoch_energy_gradient_impl): same launch, other stream, behind
+  // an event recorded after everything enqueued so far
+  const bool side = c->side_sweep_once && c->overlap && !can_overlap(c);
+  c->side_sweep_once = false;
+  const bool overtake = can_overlap(c) || side;
   hipEvent_t dep = c->ev_mark;
-  if (overtake && !after_acc) {
+  if (overtake && (!after_acc || side)) {
     PROPAGATE(ensure_packed(c, 0));
     HIPCHK(c, hipEventRecord(c->ev_now, c->stream));
     dep = c->ev_now;
   }
   if (!overtake) PROPAGATE(join_sweep(c));
-  c->expect_sweep = overtake && after_acc;
+  c->expect_sweep = overtake && after_acc && !side;
   PROPAGATE(run_sweep(c, n_steps, false, false, nullptr, nullptr, nullptr, c->step, accepted != nullptr,
                       overtake, dep));
   c->step += (unsigned long long)n_steps;
@@ -1653,6 +1660,8 @@ int vmc_update_norm_dist(vmc_ctx* c, void* nccl_comm, int32_t world_size, float 
   return update_norm_impl(c, nccl_comm, world_size, max_value);
 }
 
+static bool side_sweep_enabled() { const char* e = getenv("CGS_VMC_SIDE_SWEEP"); return !(e && atoi(e) == 0); }
+
 static int epoch_energy_gradient_impl(vmc_ctx* c, void* comm, int world, int64_t n_eq_steps, int32_t n_batches,
                                       int64_t n_mc_steps, float max_value) {
   if (n_eq_steps < 0 || n_batches < 0 || n_mc_steps < 0) return fail(c, VMC_ERR_INVALID, "negative count");
@@ -1665,10 +1674,13 @@ static int epoch_energy_gradient_impl(vmc_ctx* c, void* comm, int world, int64_t
   for (int b = 0; b < n_batches; ++b) {                                   // training.py:614-617
     c->expect_sweep = n_mc_steps > 0;
     PROPAGATE(vmc_accumulate(c, VMC_MODE_ENERGY_GRADIENT, 0.f));
+    // sharded chains: the last sweep does not touch the accumulators -- on its own stream it runs beside the
+    // all-reduce instead of in front of it (CGS_VMC_SIDE_SWEEP=0: in stream order, for A/B)
+    if (b == n_batches - 1 && world > 1 && side_sweep_enabled()) c->side_sweep_once = true;
     PROPAGATE(vmc_mc_steps(c, n_mc_steps, nullptr));
   }
   // sharded chains: the accumulators leave this call summed over ranks (the last sweep, on its own
-  // stream when it overtook the accumulate, keeps running underneath the collective)
+  // stream, keeps running underneath the collective)
   PROPAGATE(reduce_accumulators(c, comm, world));
   return VMC_OK;
 }
