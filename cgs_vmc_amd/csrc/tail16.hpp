@@ -388,52 +388,46 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
   const float osc = (oscale && ok) ? oscale[chain] : 1.f;
   // local energies of this workgroup's 16 chains (k_eloc_reduce's job and order: lane-strided partial
   // sums, xor tree): wave w takes chains 16 / NW at a time.  Nothing below reads them.
+  // The wave's chains are taken TOGETHER and without a branch around a load: both segment bounds first,
+  // then the first 128 rows of every chain (clamped addresses, masked values), so that the 16 / NW chains
+  // cost two dependent round trips, not two each; a chain's rows beyond 128 follow in the general loop.
   if (ef.off) {
+    constexpr int Q = 16 / NW;
+    int cq[Q], r0[Q], r1[Q];
 #pragma unroll
-    for (int q = 0; q < 16 / NW; ++q) {
-      const int c = blockIdx.x * 16 + wave * (16 / NW) + q;
-      if (c < B) {
-        const int r0 = ef.off[c], r1 = ef.off[c + 1];
-        float sum = 0.f;
-        for (int r = r0 + lane; r < r1; r += 64) sum += ef.val[r];
+    for (int q = 0; q < Q; ++q) {
+      const int c = blockIdx.x * 16 + wave * Q + q;
+      cq[q] = c < B ? c : B - 1;
+      r0[q] = ef.off[cq[q]];
+      r1[q] = ef.off[cq[q] + 1];
+    }
+    float v0[Q], v1[Q], dg[Q];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
-        if (lane == 0) {
-          if (ef.offdiag) ef.offdiag[c] = sum;
-          const float e = ef.diag[c] + sum;
-          ef.eloc[c] = e;
-          if (op.part && op.w == ef.eloc) s_wj[wave * (16 / NW) + q] = e;
-        }
+    for (int q = 0; q < Q; ++q) {
+      const int last = r1[q] > r0[q] ? r1[q] - 1 : r0[q];       // (an empty segment reads one row of its neighbour: masked)
+      const int ra = r0[q] + lane, rb = ra + 64;
+      v0[q] = ef.val[ra < last ? ra : last];
+      v1[q] = ef.val[rb < last ? rb : last];
+      dg[q] = ef.diag[cq[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int c = blockIdx.x * 16 + wave * Q + q;
+      const int ra = r0[q] + lane, rb = ra + 64;
+      float sum = 0.f;
+      if (ra < r1[q]) sum += v0[q];
+      if (rb < r1[q]) sum += v1[q];
+      for (int r = rb + 64; r < r1[q]; r += 64) sum += ef.val[r];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+      if (lane == 0 && c < B) {
+        if (ef.offdiag) ef.offdiag[c] = sum;
+        const float e = dg[q] + sum;
+        ef.eloc[c] = e;
+        if (op.part && op.w == ef.eloc) s_wj[wave * Q + q] = e;
       }
     }
   }
-  // output layer's weight gradient over this workgroup's chains (OutLayerSums, common.hpp): the weight of
-  // the second sum is the local energy folded above (through LDS) or a vector of an earlier launch
-  float wj = 0.f;
-  if (op.part) {                                   // block-uniform
-    if (ef.off && op.w == ef.eloc) {
-      __syncthreads();
-      wj = ok ? s_wj[j] : 0.f;
-    } else {
-      wj = ok ? op.w[chain] : 0.f;
-    }
-  }
-  // sum over the 16 lanes of a DPP row (the 16 chains): xor 1, xor 2, half mirror, mirror -- every lane
-  // ends with the same value
-  auto row16_sum = [](float v) {
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
-    return v;
-  };
-  constexpr int LDP = Hp + 4;
-  float* part = op.part ? op.part + (long long)blockIdx.x * 2 * LDP : nullptr;
-  if (part && wave == 0) {                         // the bias: sum_b s_b and sum_b w_b s_b
-    const float s1 = row16_sum(ok ? osc : 0.f), s2 = row16_sum(ok ? osc * wj : 0.f);
-    if (lane == 0) { part[Hp] = s1; part[LDP + Hp] = s2; }
-  }
-
   // last layer's delta for this wave's own unit tiles
   {
     const float* a_last = act_all + n_hidden * layer_stride + row;
@@ -442,15 +436,6 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
     for (int to = 0; to < TO; ++to) {
       const int t = wave * TO + to, col = 16 * t + 4 * g;
       const f32x4 a = *(const f32x4*)(a_last + col);
-      if (part) {
-        f32x4 s1, s2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = ok ? osc * a[e] : 0.f;
-          s1[e] = row16_sum(v); s2[e] = row16_sum(v * wj);
-        }
-        if (j == 0) { *(f32x4*)(part + col) = s1; *(f32x4*)(part + LDP + col) = s2; }
-      }
       f32x4 d;
       if (rbm) d = a;
       else {
@@ -508,6 +493,47 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
       *(f32x4*)(xout + (t * 64 + lane) * 4) = d;
     }
     cur ^= 1;
+  }
+  // Output layer's weight gradient over this workgroup's chains (OutLayerSums, common.hpp), LAST: the weight
+  // of the second sum is the local energy folded at the top (through LDS -- the layer loop's barriers, or the
+  // one below, lie in between, so nothing waits for the fold's round trips) or a vector of an earlier launch;
+  // the last activations are read again (L2).
+  if (op.part) {                                   // block-uniform
+    float wj;
+    if (ef.off && op.w == ef.eloc) {
+      if (n_hidden == 0) __syncthreads();
+      wj = ok ? s_wj[j] : 0.f;
+    } else {
+      wj = ok ? op.w[chain] : 0.f;
+    }
+    // sum over the 16 lanes of a DPP row (the 16 chains): xor 1, xor 2, half mirror, mirror -- every lane
+    // ends with the same value
+    auto row16_sum = [](float v) {
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+      v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+      return v;
+    };
+    constexpr int LDP = Hp + 4;
+    float* part = op.part + (long long)blockIdx.x * 2 * LDP;
+    if (wave == 0) {                               // the bias: sum_b s_b and sum_b w_b s_b
+      const float s1 = row16_sum(ok ? osc : 0.f), s2 = row16_sum(ok ? osc * wj : 0.f);
+      if (lane == 0) { part[Hp] = s1; part[LDP + Hp] = s2; }
+    }
+    const float* a_last = act_all + n_hidden * layer_stride + row;
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+      const int col = 16 * (wave * TO + to) + 4 * g;
+      const f32x4 a = *(const f32x4*)(a_last + col);
+      f32x4 s1, s2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = ok ? osc * a[e] : 0.f;
+        s1[e] = row16_sum(v); s2[e] = row16_sum(v * wj);
+      }
+      if (j == 0) { *(f32x4*)(part + col) = s1; *(f32x4*)(part + LDP + col) = s2; }
+    }
   }
 }
 
