@@ -212,6 +212,10 @@ struct SweepArgs {
   uint32_t seed_lo, seed_hi;
   unsigned long long step0;
   long long n_steps;
+  // bond census of the final chains (k_bond_count's job and arithmetic, eloc.hip) or cnt_out == nullptr:
+  // the sampler has the chains in LDS when it ends, the launch that would count them costs 5 us
+  const int2* bonds; const float* quarter_jz; int n_bonds;
+  int* cnt_out; float* diag_out;
 };
 
 // launchers (one per TU)
@@ -253,7 +257,7 @@ hipError_t launch_tail16_split(hipStream_t s, const TailArgs& a, const unsigned*
 // bond list / local-energy reduction (eloc.hip)
 hipError_t launch_bond_list(hipStream_t s, const float* configs, const int2* bonds,
                             const float* quarter_jz, int B, int N, int n_bonds, int* cnt,
-                            int* off, float* diag, int2* rowinfo);
+                            int* off, float* diag, int2* rowinfo, bool counted = false);   // counted: cnt / diag are up to date
 hipError_t launch_eloc_reduce(hipStream_t s, const int* off, const float* diag, const float* val,
                               int B, float* offdiag, float* eloc);
 hipError_t launch_check_pm1(hipStream_t s, const float* x, long long n, int* flag);

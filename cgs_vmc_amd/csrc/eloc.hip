@@ -117,9 +117,10 @@ __global__ __launch_bounds__(1024) void k_bond_fill(const float* __restrict__ co
 
 hipError_t launch_bond_list(hipStream_t s, const float* configs, const int2* bonds,
                             const float* quarter_jz, int B, int N, int n_bonds, int* cnt,
-                            int* off, float* diag, int2* rowinfo) {
-  hipLaunchKernelGGL(k_bond_count, dim3((B + 3) / 4), dim3(256), 0, s, configs, bonds, quarter_jz, B, N, n_bonds,
-                     cnt, diag);
+                            int* off, float* diag, int2* rowinfo, bool counted) {
+  if (!counted)      // (the sampler's last launch has left the census of these chains: sweep16.hpp)
+    hipLaunchKernelGGL(k_bond_count, dim3((B + 3) / 4), dim3(256), 0, s, configs, bonds, quarter_jz, B, N, n_bonds,
+                       cnt, diag);
   hipLaunchKernelGGL(k_bond_fill, dim3((B + 15) / 16), dim3(1024), 0, s, configs, bonds, B, N, n_bonds, cnt, off,
                      rowinfo);
   return hipGetLastError();

@@ -842,6 +842,35 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
     if (gc < a.B) *(f32x4*)(a.z1 + (long long)gc * Hp + 4 * c4) = *(const f32x4*)(s_z1 + c * ZS + 4 * c4);
   }
   if (j == 0 && n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);   // waves 0-3 only
+  // Bond census of the chains this workgroup leaves behind (k_bond_count, eloc.hip: antiparallel bonds and
+  // diag = sum 0.25 jz s_i s_j per chain, the same per-lane order of fused multiply-adds and the same xor
+  // tree, so the local energies do not depend on who counted): the spins are still in LDS.  A wave takes
+  // its chains one after the other, four 64-bond groups per pass with their bond loads issued together.
+  if (a.cnt_out) {
+    for (int c = wave; c < 16 && chain0 + c < a.B; c += NW) {
+      const float* x = s_spin + c * Nst;
+      float d = 0.f;
+      int n = 0;
+      for (int k0 = 0; k0 < a.n_bonds; k0 += 256) {
+        int2 ab[4]; float q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + 64 * u + lane, kk = k < a.n_bonds ? k : 0;
+          ab[u] = a.bonds[kk]; q[u] = a.quarter_jz[kk];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool in = k0 + 64 * u + lane < a.n_bonds;
+          const float sz = x[ab[u].x] * x[ab[u].y];
+          if (in) d = fmaf(q[u], sz, d);
+          n += __popcll(__ballot(in && sz < 0.f));
+        }
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) d += __shfl_xor(d, m);
+      if (lane == 0) { a.cnt_out[chain0 + c] = n; a.diag_out[chain0 + c] = d; }
+    }
+  }
 }
 
 template <int NT, int NW, int RTP, bool STAMP, bool W1L, bool FAST, int UPRE, bool RBM, int ACT>

@@ -110,6 +110,8 @@ struct vmc_ctx {
   int2* rowinfo_id = nullptr;   // identity list {r, 0} for plain rows (cache refresh)
   int2* tmp_rowinfo = nullptr;
   bool list_valid = false;
+  bool cnt_valid = false;          // cnt / diag hold the census of `configs` (left by the sampler's last launch)
+  int* cnt_alt = nullptr; float* diag_alt = nullptr;   // the census the NEXT sampler launch writes (swapped with the chains)
   long long last_rows = 0;
   // gradient path
   std::vector<float*> act;   // L views [B][Hp] into act_all
@@ -253,6 +255,7 @@ void swap_chain_buffers(vmc_ctx* c) {
   std::swap(p.z1, p.z1_alt); std::swap(p.logit, p.logit_alt); std::swap(p.onsite, p.onsite_alt);
   std::swap(c->act_all, c->act_alt);
   std::swap(c->dact_all, c->dact_alt);
+  std::swap(c->cnt, c->cnt_alt); std::swap(c->diag, c->diag_alt);
   for (size_t l = 0; l < c->act.size(); ++l) c->act[l] = c->act_all + (long long)l * c->B * c->Hp;
   c->parity ^= 1;
 }
@@ -461,6 +464,7 @@ void invalidate_configs(vmc_ctx* c) {
   c->acts_valid = false;
   c->ps[0].cache_valid = c->ps[1].cache_valid = false;
   c->list_valid = false;
+  c->cnt_valid = false;
 }
 
 int ensure_list(vmc_ctx* c) {
@@ -468,7 +472,7 @@ int ensure_list(vmc_ctx* c) {
   if (c->list_valid) return VMC_OK;
   Timer t(c, "bond_list");
   HIPCHK(c, launch_bond_list(c->stream, c->configs, c->bonds, c->quarter_jz, c->B, c->N,
-                             c->n_bonds, c->cnt, c->off, c->diag, c->rowinfo));
+                             c->n_bonds, c->cnt, c->off, c->diag, c->rowinfo, c->cnt_valid));
   c->list_valid = true;
   return VMC_OK;
 }
@@ -793,6 +797,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(dalloc(&c->inj_up, B)); CA(dalloc(&c->inj_dn, B)); CA(dalloc(&c->inj_u, B));
   CA(dalloc(&c->acc_mask, B));
   CA(dalloc(&c->cnt, B)); CA(dalloc(&c->off, B + 1)); CA(dalloc(&c->diag, B));
+  CA(dalloc(&c->cnt_alt, B)); CA(dalloc(&c->diag_alt, B));
   CA(dalloc(&c->rowinfo_id, B)); CA(launch_iota_rows(c->stream, c->rowinfo_id, (int)B));
   CA(dalloc(&c->bond_dummy, 1)); CA(hipMemsetAsync(c->bond_dummy, 0, sizeof(int2), c->stream));
   CA(dalloc(&c->offdiag, B));
@@ -855,7 +860,7 @@ void vmc_destroy(vmc_ctx* c) {
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->wg_tickets, c->d_accepted, c->d_sum,
                   c->d_max, c->tmp_cfg, c->tmp_z1, c->tmp_out, c->tmp_on, c->tmp_rowinfo, c->rowinfo_id, c->bond_dummy, c->inj_up, c->inj_dn, c->inj_u,
-                  c->acc_mask, c->wg_outpart};
+                  c->acc_mask, c->wg_outpart, c->cnt_alt, c->diag_alt};
   for (void* q : ptrs) if (q) hipFree(q);
   for (float* q : {c->sr_ctape, c->sr_cdelta, c->sr_cws, c->sr_cw0, c->sr_cwf, c->sr_cwb, c->sr_cbias}) if (q) hipFree(q);
   void* sr[] = {c->sr_cfg, c->sr_act, c->sr_delta, c->sr_ws, c->sr_t, c->sr_u, c->sr_x, c->sr_r,
@@ -896,6 +901,7 @@ int vmc_set_bonds(vmc_ctx* c, int32_t n_bonds, const int32_t* ij, const float* j
   HIPCHK(c, hipMemcpy(c->half_jx, hx.data(), n_bonds * sizeof(float), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->quarter_jz, qz.data(), n_bonds * sizeof(float), hipMemcpyHostToDevice));
   c->list_valid = false;
+  c->cnt_valid = false;
   return VMC_OK;
 }
 
@@ -1059,6 +1065,7 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
                      float* dbg_u, unsigned long long step0, bool count_accepted = false,
                      bool overtake = false, hipEvent_t dep = nullptr) {
   PROPAGATE(ensure_packed(c, 0));
+  if (!dbg) c->cnt_valid = false;   // the chains change (set again below when this launch leaves their census)
   if (c->wide && !c->wide_fast)
     return run_sweep_wide(c, n_steps, injected, dbg, dbg_up, dbg_dn, dbg_u, step0, count_accepted);
   ParamSet& p = c->ps[0];
@@ -1084,6 +1091,13 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   a.act_out = hand_over ? c->act_alt : nullptr;
   a.dact_out = hand_over ? c->dact_alt : nullptr;
   a.cache_in_valid = (!dbg && !injected && p.cache_valid) ? 1 : 0;
+  // the census of the chains this launch leaves behind (k_bond_count's job; CGS_VMC_SWEEP_CENSUS=0: a launch of its own)
+  static const bool census_on = !(getenv("CGS_VMC_SWEEP_CENSUS") && atoi(getenv("CGS_VMC_SWEEP_CENSUS")) == 0);
+  const bool census = census_on && !c->conv && !dbg && !injected && c->n_bonds > 0 && c->bonds && c->cnt_alt;
+  if (census) {
+    a.bonds = c->bonds; a.quarter_jz = c->quarter_jz; a.n_bonds = c->n_bonds;
+    a.cnt_out = c->cnt_alt; a.diag_out = c->diag_alt;
+  }
   hipStream_t st = overtake ? c->sweep_stream : c->stream;
   if (overtake) HIPCHK(c, hipStreamWaitEvent(st, dep, 0));
   // the device counter is only zeroed when the caller will read it back
@@ -1107,6 +1121,7 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   }
   if (dbg) return VMC_OK;               // the proposal dump writes nothing back
   swap_chain_buffers(c);
+  c->cnt_valid = census;
   c->acts_valid = hand_over;
   c->acc_since_sweep = false;
   if (overtake) {
@@ -1172,6 +1187,7 @@ int vmc_mc_step_injected(vmc_ctx* c, const int32_t* i_up, const int32_t* i_dn, c
   HIPCHK(c, hipMemcpyAsync(c->inj_u, u, c->B * sizeof(float), hipMemcpyHostToDevice, c->stream));
   PROPAGATE(run_sweep(c, 1, true, false, nullptr, nullptr, nullptr, c->step));
   c->ps[0].cache_valid = !c->wide || c->wide_fast; c->ps[1].cache_valid = false; c->list_valid = false;
+  c->cnt_valid = false;
   if (accept_mask)
     HIPCHK(c, hipMemcpyAsync(accept_mask, c->acc_mask, c->B, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1212,6 +1228,7 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   c->acts_valid = false;
   c->step += (unsigned long long)n_steps;
   c->ps[0].cache_valid = true; c->ps[1].cache_valid = false; c->list_valid = false;
+  c->cnt_valid = false;
   std::vector<unsigned long long> h((size_t)grid * 128);
   HIPCHK(c, hipMemcpyAsync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
