@@ -1,7 +1,8 @@
 // Convolutional ansatz kernels (Conv2DNetwork / ResNet2D, wavefunctions.py:531-615, 710-809, and
 // their 1-D siblings Conv1DNetwork / ResNet1D, 455-527, 618-707, as k x 1 taps on an N x 1 lattice)
 // for gfx950, templated on (kernel size K, taps along axis 2 KW, channel blocks NCB).  Included by
-// conv.hip (NCB = 1: up to 16 filters) and conv32.hip (NCB = 2: 17 .. 32 filters).
+// conv.hip (NCB = 1: up to 16 filters) and, through conv_wide.hpp, conv32 / conv48 / conv64.hip (NCB = 2, 3, 4:
+// 17 .. 64 filters).
 // See DESIGN.md 4 "Convolutional ansatz types".
 //
 // A periodic convolution with <= 16 channels is an implicit GEMM whose output tile is exactly one
@@ -13,11 +14,11 @@
 // register r, which is the layout the next layer reads, so the epilogue is one ds_write_b128.
 // Feature maps of the G samples a workgroup has in flight never leave LDS between layers.
 //
-// More than 16 filters (NCB = 2 channel blocks of 16): a convolution is NCB x NCB such block
-// products.  The K*K fragments of ONE (output block, input block) pair are held in registers
-// (as above) while the wave sweeps all of its position tiles, whose accumulators stay in
-// registers across the input blocks: the weights are re-read from L2 once per block pair and
-// layer -- the same bytes per MFMA as the single-block kernel.
+// More than 16 filters (NCB = 2 .. 4 channel blocks of 16): a convolution is NCB x NCB such block
+// products.  The fragments of ONE (output block, input block) pair are held in registers -- in
+// chunks of at most 25 taps -- while the wave sweeps its position tiles, whose accumulators stay in
+// registers across the chunks and the input blocks: the weights are re-read from L2 once per block
+// pair and layer -- the same bytes per MFMA as the single-block kernel.
 #pragma once
 #include "conv.hpp"
 #include <cstdlib>
@@ -27,7 +28,7 @@
 // co-resident workgroups are never in step, so the serial phases of one (row staging behind dependent
 // global loads, the per-layer weight-fragment reload, barriers, the final reduction) run under the
 // MFMAs of the other (one 4-wave workgroup per CU: 0.58 of the fp32-MFMA peak against 0.72 for two).
-// NCB = 2 (conv32.hip defines CONV_WAVES 8): a sample's feature maps are twice as large, only two
+// NCB >= 2 (conv_wide.hpp defines CONV_WAVES 8): a sample's feature maps are at least twice as large, only two
 // samples fit half a CU's LDS and their 13 position tiles divide badly over 4 waves; one 8-wave
 // workgroup per CU with the whole 160 KiB (five samples on a 10 x 10 lattice: 16 tile pairs, two per
 // wave) keeps two waves per SIMD and every wave busy.
@@ -1088,7 +1089,7 @@ hipError_t launch_k(Kern kern, dim3 grid, size_t lds, hipStream_t s, const Args&
     default: return hipErrorInvalidValue;                                               \
   }
 
-// the four launchers for one NCB (conv.hip: 1, conv32.hip: 2)
+// the five launchers for one NCB (conv.hip: 1; conv_wide.hpp: 2, 3, 4)
 template <int NCB>
 hipError_t conv_launch_rows_t(hipStream_t s, const ConvRowsArgs& a, dim3 grid, size_t lds) {
   CONV_DISPATCH_K(a.g, return launch_k(k_conv_rows<KK_, KW_, NCB>, grid, lds, s, a));

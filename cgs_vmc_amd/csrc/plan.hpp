@@ -104,7 +104,7 @@ inline size_t plan_conv_rows_lds(const ConvGeom& g, int G) {
 
 // LDS budget of one workgroup: half a CU when a sample's feature maps allow two workgroups per CU
 inline size_t plan_conv_lds_cap(const ConvGeom& g, bool one_wg_per_cu = false) {
-  if (one_wg_per_cu || g.NCB > 1) return PLAN_LDS_PER_CU;      // one 8-wave workgroup per CU (conv32.hip)
+  if (one_wg_per_cu || g.NCB > 1) return PLAN_LDS_PER_CU;      // one 8-wave workgroup per CU (conv_wide.hpp)
   return plan_conv_rows_lds(g, 1) <= CONV_LDS_PER_WG ? CONV_LDS_PER_WG : PLAN_LDS_PER_CU;
 }
 
