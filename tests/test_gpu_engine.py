@@ -470,3 +470,44 @@ def test_log_domain_stays_finite_where_linear_psi_overflows(n, h, L, b, kind):
   expect = shift + (float(vo.fc_logit(theta, cfg, h, L, dtype=np.float64).max()) - shift - np.log(1e10))
   assert abs(eng.get_shift() - expect) < 1e-4 * abs(expect)
   eng.close()
+
+
+@pytest.mark.parametrize('ansatz,h', [('fully_connected', 64), ('rbm', 48), ('fully_connected', 320)])
+def test_bond_census_follows_every_writer_of_the_chains(ansatz, h):
+  """The dense sampler leaves the bond census (antiparallel counts, diagonal terms) of its final chains
+  (sweep16.hpp epilogue); every other writer of the chains or the bonds must invalidate it.  After each kind
+  of change the local energies are those of the oracle on the chains the engine reports, and the row count is
+  the number of antiparallel bonds."""
+  from cgs_vmc_amd.engine import VmcEngine
+  n, L, b = 16, 2, 37
+  rbm = ansatz == 'rbm'
+  rng = np.random.default_rng(5)
+  theta = (vo.rbm_init_params if rbm else vo.init_params)(n, h, L, rng)
+  psi = (lambda c: vo.rbm_psi(theta, c, h, L, dtype=np.float64)) if rbm else \
+        (lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64))
+  eng = VmcEngine(n, b, L, h, seed=9, ansatz=ansatz)
+  eng.set_params(theta)
+  chain, torus = vo.chain_bonds(n), vo.torus_bonds(4, 4)
+  state = {'bonds': chain}
+
+  def check():
+    c = eng.get_configs()
+    e = eng.local_energy()[0]
+    ref = vo.local_value(psi, c, state['bonds'], -1.0, 1.0, dtype=np.float64)
+    assert np.abs(e - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    assert eng.last_connected_rows() == sum(int((c[:, i] * c[:, j] < 0).sum()) for (i, j) in state['bonds'])
+
+  eng.set_bonds(chain, -1.0, 1.0)
+  eng.set_configs(vo.random_configurations(n, b, np.random.RandomState(1)))
+  check()                                   # census by its own launch
+  eng.mc_steps(7); check()                  # census left by the sampler
+  eng.mc_steps(3); eng.mc_steps(2); check() # two launches in a row
+  u_sites, u_acc = vo.step_uniforms(3, np.arange(b), 0, n)
+  i_up, i_dn = vo.propose_exchange(eng.get_configs(), u_sites)
+  eng.mc_step_injected(i_up, i_dn, u_acc); check()          # injected step: no census
+  eng.mc_steps(5)
+  eng.set_bonds(torus, -1.0, 1.0); state['bonds'] = torus; check()   # new bonds after a sampler launch
+  eng.mc_steps(4)
+  eng.set_configs(vo.random_configurations(n, b, np.random.RandomState(2))); check()   # new chains after one
+  eng.reset_accumulators(); eng.accumulate(0); eng.mc_steps(n); eng.accumulate(0); check()   # the training order
+  eng.close()
