@@ -67,3 +67,46 @@ def exact_fc_eigenstate(n, bonds, layer_size, num_layers, seed=7, jx=-1.0, jz=1.
   theta[p - 1 - layer_size:p - 1] = w_out
   theta[p - 1] = b_out
   return theta.astype(np.float32), float(e0), cfgs.astype(np.float32), vec
+
+
+def exact_conv_eigenstate(ansatz, geom, num_layers, bonds, nonlinearity='relu', seed=11, jx=-1.0, jz=1.0):
+  """Conv2DNetwork / Conv1DNetwork parameters (wavefunctions.py:531-615 / 455-527) whose psi = exp(logit) is
+  the exact Heisenberg ground state on the whole Sz = 0 sector of a small periodic lattice.
+
+  The last convolution has no activation behind it and the logit is the sum of its output over sites and
+  channels; on a torus every tap visits every site once, so
+    logit(R) = sum_ci (sum_{tap, co} W_last[tap, ci, co]) S_ci(R) + N sum_co b_last[co],
+    S_ci(R) = sum over sites of channel ci of the last convolution's INPUT.
+  The earlier convolutions keep their random weights; W_last[tap, ci, 0] = w_ci / taps (other output channels
+  zero) and b_last[0] = b / N with (w, b) the least-squares solution of sum_ci w_ci S_ci + b = log psi_ED.
+  The features are translation invariant, like the ground state, so the system is consistent as soon as the
+  filters outnumber the translation orbits of the sector (10 necklaces for 8 sites); the residual is asserted.
+  Returns (theta, E0, configs[dim, n], psi_ED)."""
+  f, k, sx, sy = geom
+  n = sx * sy
+  assert ansatz in vo.CONV_PLAIN and num_layers >= 2
+  e0, vec, cfgs, _ = ed_ground_state(n, bonds, jx, jz)
+  vec = vec * np.sign(vec[np.argmax(np.abs(vec))])
+  assert (vec > 0).all(), 'ground state is not sign-free: use jx < 0 on a bipartite lattice'
+  theta = vo.conv_init_params(ansatz, geom, num_layers, np.random.default_rng(seed)).astype(np.float64)
+  theta += 0.05 * np.random.default_rng(seed + 1).standard_normal(theta.size)      # non-zero biases
+  _, tape, layers_ = vo.conv_forward(theta, cfgs, ansatz, geom, num_layers, nonlinearity, np.float64, return_tape=True)
+  a_in = tape[-1][0]                                   # input of the last convolution: [dim, sx, sy, F]
+  s_feat = a_in.reshape(a_in.shape[0], -1, a_in.shape[-1]).sum(1)                  # [dim, F]
+  target = np.log(vec)
+  design = np.concatenate([s_feat, np.ones((len(vec), 1))], 1)
+  sol, _, _, _ = np.linalg.lstsq(design, target, rcond=None)
+  assert np.abs(design @ sol - target).max() < 1e-8, 'too few filters for the translation orbits of this sector'
+  w_ci, b = sol[:-1], sol[-1]
+  shapes = vo.conv_param_shapes(ansatz, geom, num_layers)
+  w_shape, b_shape = shapes[-2], shapes[-1]
+  taps = w_shape[0] * w_shape[1]
+  w_last = np.zeros(w_shape)
+  w_last[:, :, :, 0] = (w_ci / taps)[None, None, :]
+  b_last = np.zeros(b_shape)
+  b_last[0] = b / n
+  n_last = int(np.prod(w_shape)) + int(np.prod(b_shape))
+  theta[theta.size - n_last:] = np.concatenate([w_last.ravel(), b_last.ravel()])
+  check = vo.conv_forward(theta, cfgs, ansatz, geom, num_layers, nonlinearity, np.float64)
+  assert np.abs(check - target).max() < 1e-8
+  return theta.astype(np.float32), float(e0), cfgs.astype(np.float32), vec

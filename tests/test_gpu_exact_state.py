@@ -84,3 +84,47 @@ def test_exact_eigenstate_on_the_hip_path(monkeypatch, n, h, L, kind, split):
   out = eng.get_configs()
   assert (out.sum(1) == 0).all()
   eng.close()
+
+
+# the convolutional path against the same kind of known answer (round 4): parameters solved so that the
+# network IS the ground state (tests/exact_states.py:exact_conv_eigenstate -- the last convolution is linear in
+# its weights and the logit only sees the site sums of its input); one to four channel blocks, 3 .. 9 taps
+CONV_CASES = [('conv_2d', (16, 3, 4, 2), 3, 'torus'), ('conv_1d', (48, 5, 8, 1), 3, 'chain'),
+              ('conv_2d', (64, 3, 4, 2), 3, 'torus'), ('conv_1d', (24, 9, 8, 1), 3, 'chain')]
+
+
+@pytest.mark.parametrize('ansatz,geom,L,kind', CONV_CASES)
+def test_exact_eigenstate_on_the_convolutional_path(ansatz, geom, L, kind):
+  from cgs_vmc_amd import _hip
+  from cgs_vmc_amd.engine import VmcEngine
+  from tests.exact_states import exact_conv_eigenstate
+  f, k, sx, sy = geom
+  n = sx * sy
+  bonds = vo.chain_bonds(n) if kind == 'chain' else vo.torus_bonds(sy, sx)
+  theta, e0, cfgs, vec = exact_conv_eigenstate(ansatz, geom, L, bonds)
+  b = len(cfgs)
+  eng = VmcEngine(n, b, L, f, seed=5, ansatz=ansatz, kernel_size=k, size_x=sx, size_y=sy)
+  eng.set_params(theta)
+  eng.set_shift(0.0)
+  eng.set_configs(cfgs)
+  eng.set_bonds(bonds, -1.0, 1.0)
+  # (measured on MI355X: logits within 3e-6 of log psi_ED, local energies within 3e-5 of E0, the gradient
+  # within 1e-5 of the size of its two terms -- fp32 evaluation of an fp64-exact eigenstate)
+  assert np.abs(eng.amplitude()[0] - np.log(vec)).max() < 2e-5
+  e = eng.local_energy()[0]
+  assert np.abs(e - e0).max() < 2e-4
+  # zero-variance principle (training.py:560-564): <E O> - <E><O> = 0 when E_loc is constant
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  g = eng.get_gradient(_hip.VMC_MODE_ENERGY_GRADIENT)
+  acc = eng.get_accumulators()
+  p = theta.size
+  size = np.abs(acc[p:2 * p]).max() / b               # |mean of E_loc O_k|, the size of either term
+  assert np.abs(g).max() < 1e-4 * size
+  assert abs(eng.mean_energy() - e0) < 2e-4
+  # sampling keeps E_loc = E0 on every chain and the chains inside the sector
+  eng.mc_steps(10 * n)
+  e = eng.local_energy()[0]
+  assert np.abs(e - e0).max() < 2e-4
+  assert (eng.get_configs().sum(1) == 0).all()
+  eng.close()
