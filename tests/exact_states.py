@@ -70,7 +70,8 @@ def exact_fc_eigenstate(n, bonds, layer_size, num_layers, seed=7, jx=-1.0, jz=1.
 
 
 def exact_conv_eigenstate(ansatz, geom, num_layers, bonds, nonlinearity='relu', seed=11, jx=-1.0, jz=1.0):
-  """Conv2DNetwork / Conv1DNetwork parameters (wavefunctions.py:531-615 / 455-527) whose psi = exp(logit) is
+  """Conv2DNetwork / Conv1DNetwork (and ResNet2D / ResNet1D: num_layers = blocks) parameters
+  (wavefunctions.py:531-615 / 455-527 / 710-809) whose psi = exp(logit) is
   the exact Heisenberg ground state on the whole Sz = 0 sector of a small periodic lattice.
 
   The last convolution has no activation behind it and the logit is the sum of its output over sites and
@@ -84,7 +85,8 @@ def exact_conv_eigenstate(ansatz, geom, num_layers, bonds, nonlinearity='relu', 
   Returns (theta, E0, configs[dim, n], psi_ED)."""
   f, k, sx, sy = geom
   n = sx * sy
-  assert ansatz in vo.CONV_PLAIN and num_layers >= 2
+  resnet = ansatz not in vo.CONV_PLAIN
+  assert num_layers >= (1 if resnet else 2)
   e0, vec, cfgs, _ = ed_ground_state(n, bonds, jx, jz)
   vec = vec * np.sign(vec[np.argmax(np.abs(vec))])
   assert (vec > 0).all(), 'ground state is not sign-free: use jx < 0 on a bipartite lattice'
@@ -94,6 +96,10 @@ def exact_conv_eigenstate(ansatz, geom, num_layers, bonds, nonlinearity='relu', 
   a_in = tape[-1][0]                                   # input of the last convolution: [dim, sx, sy, F]
   s_feat = a_in.reshape(a_in.shape[0], -1, a_in.shape[-1]).sum(1)                  # [dim, F]
   target = np.log(vec)
+  if resnet:   # ResNet2D (wavefunctions.py:766-773): logit = sum(h + conv2(selu(conv1 h))); the shortcut's share
+               # sum(h) is translation invariant as well and moves to the right-hand side
+    h_prev = tape[-2][0]
+    target = target - h_prev.reshape(h_prev.shape[0], -1).sum(1)
   design = np.concatenate([s_feat, np.ones((len(vec), 1))], 1)
   sol, _, _, _ = np.linalg.lstsq(design, target, rcond=None)
   assert np.abs(design @ sol - target).max() < 1e-8, 'too few filters for the translation orbits of this sector'
@@ -108,5 +114,5 @@ def exact_conv_eigenstate(ansatz, geom, num_layers, bonds, nonlinearity='relu', 
   n_last = int(np.prod(w_shape)) + int(np.prod(b_shape))
   theta[theta.size - n_last:] = np.concatenate([w_last.ravel(), b_last.ravel()])
   check = vo.conv_forward(theta, cfgs, ansatz, geom, num_layers, nonlinearity, np.float64)
-  assert np.abs(check - target).max() < 1e-8
+  assert np.abs(check - np.log(vec)).max() < 1e-8
   return theta.astype(np.float32), float(e0), cfgs.astype(np.float32), vec

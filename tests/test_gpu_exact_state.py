@@ -90,7 +90,9 @@ def test_exact_eigenstate_on_the_hip_path(monkeypatch, n, h, L, kind, split):
 # network IS the ground state (tests/exact_states.py:exact_conv_eigenstate -- the last convolution is linear in
 # its weights and the logit only sees the site sums of its input); one to four channel blocks, 3 .. 9 taps
 CONV_CASES = [('conv_2d', (16, 3, 4, 2), 3, 'torus'), ('conv_1d', (48, 5, 8, 1), 3, 'chain'),
-              ('conv_2d', (64, 3, 4, 2), 3, 'torus'), ('conv_1d', (24, 9, 8, 1), 3, 'chain')]
+              ('conv_2d', (64, 3, 4, 2), 3, 'torus'), ('conv_1d', (24, 9, 8, 1), 3, 'chain'),
+              # ResNet2D / ResNet1D (one and two blocks): the shortcut's site sum moves to the right-hand side
+              ('res_net_2d', (16, 3, 4, 2), 1, 'torus'), ('res_net_1d', (32, 5, 8, 1), 2, 'chain')]
 
 
 @pytest.mark.parametrize('ansatz,geom,L,kind', CONV_CASES)
