@@ -797,17 +797,17 @@ hipError_t launch_wgrad(hipStream_t s, const WgradLaunch& L) {
   // diagnostic build: every 20th launch is stamped, read back synchronously and summarised on stderr
   static unsigned long long* d_st = nullptr;
   static int n_launch = 0;
-  if (!d_st) hipMalloc((void**)&d_st, 4096 * 8 * sizeof(unsigned long long));
+  if (!d_st && hipMalloc((void**)&d_st, 4096 * 8 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
   const bool probe = (++n_launch % 20) == 0 && grid <= 4096;
-  if (probe) { hipMemsetAsync(d_st, 0, (size_t)grid * 64, s); a.stamps = d_st; }
+  if (probe) { if (hipMemsetAsync(d_st, 0, (size_t)grid * 64, s) != hipSuccess) return hipGetLastError(); a.stamps = d_st; }
 
 #endif
   hipLaunchKernelGGL(k_wgrad, dim3(grid), dim3(512), lds, s, a);
 #ifdef VMC_WGRAD_STAMPS
   if (probe) {
     std::vector<unsigned long long> h((size_t)grid * 8);
-    hipStreamSynchronize(s);
-    hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+    if (hipStreamSynchronize(s) != hipSuccess ||
+        hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return hipGetLastError();
     unsigned long long t0 = ~0ull, t_end = 0;
     for (int b = 0; b < a.mfma_blocks; ++b) if (h[(size_t)b * 8]) t0 = std::min(t0, h[(size_t)b * 8]);
     double sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0};
