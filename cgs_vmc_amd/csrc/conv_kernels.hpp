@@ -271,36 +271,37 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
   // compiler from sinking the reads back next to their use, which would expose one LDS round trip
   // per tap)
   // `tb_c`, `tn_c`: the taps [TB, TB + TN) of the kernel, whose fragments are w[0 .. TN)
-  auto taps = [&](int t0, auto nt_c, auto tb_c, auto tn_c, int ci, const f32x4* w, f32x4* acc) {
+  // position descriptor of one tile for this lane: LDS byte address of its sample's channel group gl of
+  // block 0, and the byte offsets of the K row / KW column neighbours of its position
+  struct TileDesc { const char* base; int roff[K]; int coff[KW]; };
+  auto describe = [&](int t, TileDesc& d) {
+    const int q = t * 16 + pl;
+    const unsigned info = sm.pinfo[q < n_pos ? q : n_pos - 1];
+    const int a2 = info & 1023, a1 = (info >> 10) & 1023, sl = info >> 20;
+    d.base = (const char*)(in + (size_t)sl * g.CS + gl * g.GS);
+    const int* rt = sm.rtab + (dir * g.D1 + a1) * CONV_TAB;
+    const int* ct = sm.ctab + (dir * g.D2 + a2) * CONV_TAB;
+#pragma unroll
+    for (int dd = 0; dd < K; ++dd) d.roff[dd] = rt[dd];
+#pragma unroll
+    for (int dd = 0; dd < KW; ++dd) d.coff[dd] = ct[dd];
+  };
+  // the taps [TB, TB + TN) of NTL described tiles against input channel block ci (cib = its byte offset)
+  auto multiply = [&](auto nt_c, auto tb_c, auto tn_c, const TileDesc* d, int cib, const f32x4* w, f32x4* acc) {
     constexpr int NTL = decltype(nt_c)::value;
     constexpr int TB = decltype(tb_c)::value, TN = decltype(tn_c)::value;
-    const char* base[NTL];
-    int roff[NTL][K], coff[NTL][KW];
-#pragma unroll
-    for (int h = 0; h < NTL; ++h) {
-      const int q = (t0 + h) * 16 + pl;
-      const unsigned info = sm.pinfo[q < n_pos ? q : n_pos - 1];
-      const int a2 = info & 1023, a1 = (info >> 10) & 1023, sl = info >> 20;
-      base[h] = (const char*)(in + (size_t)sl * g.CS + (4 * ci + gl) * g.GS);
-      const int* rt = sm.rtab + (dir * g.D1 + a1) * CONV_TAB;
-      const int* ct = sm.ctab + (dir * g.D2 + a2) * CONV_TAB;
-#pragma unroll
-      for (int d = 0; d < K; ++d) roff[h][d] = rt[d];
-#pragma unroll
-      for (int d = 0; d < KW; ++d) coff[h][d] = ct[d];
-    }
     f32x4 bq[NTL][3];
 #pragma unroll
     for (int h = 0; h < NTL; ++h) {
-      bq[h][0] = *(const f32x4*)(base[h] + roff[h][TB / KW] + coff[h][TB % KW]);
-      if (TN > 1) bq[h][1] = *(const f32x4*)(base[h] + roff[h][TN > 1 ? (TB + 1) / KW : 0] + coff[h][TN > 1 ? (TB + 1) % KW : 0]);
+      bq[h][0] = *(const f32x4*)(d[h].base + cib + d[h].roff[TB / KW] + d[h].coff[TB % KW]);
+      if (TN > 1) bq[h][1] = *(const f32x4*)(d[h].base + cib + d[h].roff[TN > 1 ? (TB + 1) / KW : 0] + d[h].coff[TN > 1 ? (TB + 1) % KW : 0]);
     }
 #pragma unroll
     for (int tp = 0; tp < TN; ++tp) {
       if (tp + 2 < TN) {
 #pragma unroll
         for (int h = 0; h < NTL; ++h)
-          bq[h][(tp + 2) % 3] = *(const f32x4*)(base[h] + roff[h][(TB + tp + 2) / KW] + coff[h][(TB + tp + 2) % KW]);
+          bq[h][(tp + 2) % 3] = *(const f32x4*)(d[h].base + cib + d[h].roff[(TB + tp + 2) / KW] + d[h].coff[(TB + tp + 2) % KW]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -309,6 +310,14 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
         for (int h = 0; h < NTL; ++h)
           acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tp][e], bq[h][tp % 3][e], acc[h], 0, 0, 0);
     }
+  };
+  // `tb_c`, `tn_c`: the taps [TB, TB + TN) of the kernel, whose fragments are w[0 .. TN)
+  auto taps = [&](int t0, auto nt_c, auto tb_c, auto tn_c, int ci, const f32x4* w, f32x4* acc) {
+    constexpr int NTL = decltype(nt_c)::value;
+    TileDesc d[NTL];
+#pragma unroll
+    for (int h = 0; h < NTL; ++h) describe(t0 + h, d[h]);
+    multiply(nt_c, tb_c, tn_c, d, ci * 4 * g.GS * (int)sizeof(float), w, acc);
   };
   auto store = [&](int t, int co, const f32x4& v) {
     const int q = t * 16 + pl;
@@ -359,7 +368,21 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
     constexpr int NCH = (KK + 24) / 25, CH = (KK + NCH - 1) / NCH;
     constexpr int TC = 4;
     const int n_pairs = (n_tiles + 1) >> 1;
+    // Small kernels with several channel blocks (K + KW <= 6: 3 x 3, 2 x 2, 1 x 1, the chains up to 5 taps):
+    // a block pair's products are few (72 MFMAs per tile pair at 3 x 3), and the position descriptors -- a
+    // chain of dependent LDS reads: descriptor, wrap tables, then the first operand -- were rebuilt for every
+    // one of the NCB x NCB pairs.  They depend on the tile alone: built once per tile group (<= 56 registers)
+    // and reused by every pair.
+    constexpr bool HOIST = NCB > 1 && K + KW <= 6;
     for (int k0 = 0; wave + CONV_WAVES * k0 < n_pairs; k0 += TC) {
+      TileDesc dsc[HOIST ? TC : 1][2];
+      if constexpr (HOIST) {
+#pragma unroll
+        for (int c = 0; c < TC; ++c) {
+          const int pi = wave + CONV_WAVES * (k0 + c);
+          if (pi < n_pairs) { describe(2 * pi, dsc[c][0]); describe(2 * pi + 1, dsc[c][1]); }   // wave-uniform
+        }
+      }
 #pragma unroll 1
       for (int co = 0; co < NCB; ++co) {
         f32x4 bias = {0.f, 0.f, 0.f, 0.f};
@@ -381,8 +404,13 @@ __device__ __forceinline__ void conv_layer(const ConvSmem& sm, const float* in, 
 #pragma unroll
             for (int c = 0; c < TC; ++c) {
               const int pi = wave + CONV_WAVES * (k0 + c);
-              if (pi < n_pairs)    // wave-uniform
-                taps(2 * pi, c2, std::integral_constant<int, TB>{}, std::integral_constant<int, TN>{}, ci, w, acc[c]);
+              if (pi < n_pairs) {  // wave-uniform
+                if constexpr (HOIST)
+                  multiply(c2, std::integral_constant<int, TB>{}, std::integral_constant<int, TN>{}, dsc[c],
+                           ci * 4 * g.GS * (int)sizeof(float), w, acc[c]);
+                else
+                  taps(2 * pi, c2, std::integral_constant<int, TB>{}, std::integral_constant<int, TN>{}, ci, w, acc[c]);
+              }
             }
           });
         }
