@@ -124,6 +124,15 @@ def test_exact_eigenstate_on_the_convolutional_path(ansatz, geom, L, kind):
   size = np.abs(acc[p:2 * p]).max() / b               # |mean of E_loc O_k|, the size of either term
   assert np.abs(g).max() < 1e-4 * size
   assert abs(eng.mean_energy() - e0) < 2e-4
+  # imaginary-time target of an eigenstate is the eigenstate (training.py:652-729): with omega = psi the ratio
+  # (1 - beta H) omega / psi is constant and the log-overlap gradient vanishes for any set of samples
+  eng.transfer_params()
+  eng.set_shift(0.0, _hip.VMC_OMEGA)
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_LOG_OVERLAP_ITSWO, 0.12)
+  g = eng.get_gradient(_hip.VMC_MODE_LOG_OVERLAP_ITSWO)
+  acc = eng.get_accumulators()
+  assert np.abs(g).max() < 1e-4 * (np.abs(acc[:p]).max() / b)
   # sampling keeps E_loc = E0 on every chain and the chains inside the sector
   eng.mc_steps(10 * n)
   e = eng.local_energy()[0]
