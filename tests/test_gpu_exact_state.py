@@ -133,8 +133,18 @@ def test_exact_eigenstate_on_the_convolutional_path(ansatz, geom, L, kind):
   g = eng.get_gradient(_hip.VMC_MODE_LOG_OVERLAP_ITSWO)
   acc = eng.get_accumulators()
   assert np.abs(g).max() < 1e-4 * (np.abs(acc[:p]).max() / b)
-  # sampling keeps E_loc = E0 on every chain and the chains inside the sector
-  eng.mc_steps(10 * n)
+  # sampling keeps E_loc = E0 on every chain and the chains inside the sector, and the chains sample |psi|^2:
+  # the exact nearest-neighbour correlation sum_R psi(R)^2 s_i s_j, averaged over the bonds
+  exact = float(np.mean([(vec ** 2 * cfgs[:, i] * cfgs[:, j]).sum() for (i, j) in bonds]))
+  eng.mc_steps(20 * n)
+  snaps, corr = 150, 0.0
+  for _ in range(snaps):
+    eng.mc_steps(n)
+    c = eng.get_configs()
+    corr += np.mean([np.mean(c[:, i] * c[:, j]) for (i, j) in bonds])
+  corr /= snaps
+  sigma = 1.0 / np.sqrt(b * snaps)        # strongly correlated within a configuration: ~ b * snaps independent samples
+  assert abs(corr - exact) < 5 * sigma, (corr, exact)
   e = eng.local_energy()[0]
   assert np.abs(e - e0).max() < 2e-4
   assert (eng.get_configs().sum(1) == 0).all()
