@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 # 384- and 512-unit kernels (k_sweep16<24|32>, k_tail_lds, k_backprop16<24|32>), and the config-3 shape with
 # the local-energy rows on the 3 x bf16 split kernel (CGS_VMC_SPLIT_BF16=1)
 CASES = [(8, 128, 2, 'chain', False), (10, 256, 3, 'chain', False), (8, 128, 2, 'torus4x2', False),
-         (10, 384, 2, 'chain', False), (10, 512, 3, 'chain', False), (10, 256, 3, 'chain', True)]
+         (10, 384, 2, 'chain', False), (10, 512, 3, 'chain', False), (10, 256, 3, 'chain', True),
+         (10, 640, 2, 'chain', False)]       # beyond 512 units: the general path (128 x 128-tile GEMM, k_wide_accept)
 
 
 @pytest.mark.parametrize('n,h,L,kind,split', CASES)
@@ -32,7 +33,7 @@ def test_exact_eigenstate_on_the_hip_path(monkeypatch, n, h, L, kind, split):
   theta, e0, cfgs, vec = exact_fc_eigenstate(n, bonds, h, L)
   b = len(cfgs)                                   # 70 / 252: every configuration of the sector once
   eng = VmcEngine(n, b, L, h, seed=5)
-  assert eng.kernel_path() == (4 if split else (1 if h > 256 else 0))
+  assert eng.kernel_path() == (4 if split else (2 if h > 512 else (1 if h > 256 else 0)))
   eng.set_params(theta)
   eng.set_shift(0.0)
   eng.set_configs(cfgs)
