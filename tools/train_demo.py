@@ -18,28 +18,36 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 CASES = [
-    # name, lx, ly, layers, units, chains, epochs, exact energy per site
-    ('4x4', 4, 4, 2, 64, 512, 200, -11.228483 / 16),
-    ('6x6', 6, 6, 3, 128, 1024, 300, -0.678872),
-    ('10x10', 10, 10, 3, 256, 4096, 250, -0.671549),
+    # name, lx, ly, wavefunction_type, optimizer, ansatz hparams, chains, epochs, learning rates, exact energy per site
+    ('4x4', 4, 4, 'fully_connected', 'EnergyGradient', 'fc_layer_size=64,num_fc_layers=2', 512, 200,
+     (0.001, 0.0003, 0.0001), -11.228483 / 16),
+    ('4x4', 4, 4, 'fully_connected', 'StochasticReconfiguration',
+     'fc_layer_size=64,num_fc_layers=2,sr_diag_shift=0.01,sr_cg_tolerance=0.001,sr_cg_max_iterations=200', 512, 100,
+     (0.05, 0.02, 0.01), -11.228483 / 16),
+    ('6x6', 6, 6, 'fully_connected', 'EnergyGradient', 'fc_layer_size=128,num_fc_layers=3', 1024, 300,
+     (0.001, 0.0003, 0.0001), -0.678872),
+    ('6x6', 6, 6, 'conv_2d', 'EnergyGradient', 'size_x=6,size_y=6,num_conv_layers=4,num_conv_filters=16,kernel_size=3',
+     1024, 300, (0.001, 0.0003, 0.0001), -0.678872),
+    ('10x10', 10, 10, 'fully_connected', 'EnergyGradient', 'fc_layer_size=256,num_fc_layers=3', 4096, 250,
+     (0.001, 0.0003, 0.0001), -0.671549),
 ]
 
 
 def main():
   from cgs_vmc_amd import lattice, run_energy_evaluation, run_training, session, wavefunctions
-  cases = CASES[:2] if len(sys.argv) > 1 and sys.argv[1] == 'small' else CASES
-  for name, lx, ly, L, h, b, epochs, exact in cases:
+  cases = CASES[:4] if len(sys.argv) > 1 and sys.argv[1] == 'small' else CASES
+  for name, lx, ly, wf_type, optimizer, ansatz_hp, b, epochs, lrs, exact in cases:
     n = lx * ly
     d = tempfile.mkdtemp(prefix='cgsvmc_demo_')
     try:
       lattice.write_bonds(d, lattice.torus_bonds(lx, ly))
       session.reset_default_graph(); wavefunctions.reset_name_scope()
-      hp = ('batch_size={},fc_layer_size={},num_fc_layers={},num_equilibration_sweeps=20,'
-            'num_batches_per_epoch=50,learning_rates=[0.001,0.0003,0.0001],learning_rate_stops=[{},{}],'
-            'num_evaluation_samples=50').format(b, h, L, epochs // 2, (3 * epochs) // 4)
+      hp = ('batch_size={},{},num_equilibration_sweeps=20,num_batches_per_epoch=50,'
+            'learning_rates=[{},{},{}],learning_rate_stops=[{},{}],num_evaluation_samples=50').format(
+                b, ansatz_hp, lrs[0], lrs[1], lrs[2], epochs // 2, (3 * epochs) // 4)
       t0 = time.time()
       run_training.main(['--checkpoint_dir', d, '--num_sites', str(n), '--heisenberg_jx', '-1.0',
-                         '--wavefunction_type', 'fully_connected', '--optimizer', 'EnergyGradient',
+                         '--wavefunction_type', wf_type, '--optimizer', optimizer,
                          '--num_epochs', str(epochs), '--hparams', hp])
       t_train = time.time() - t0
       metrics = [float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()]
@@ -47,8 +55,8 @@ def main():
       mean, unc = run_energy_evaluation.main(['--checkpoint_dir', d, '--heisenberg_jx', '-1.0'])
       tail = metrics[-10:]
       out = {
-          'lattice': name + ' torus', 'ansatz': 'fully_connected {}x{}'.format(L, h), 'chains': b, 'epochs': epochs,
-          'batches_per_epoch': 50, 'train_seconds': round(t_train, 1),
+          'lattice': name + ' torus', 'wavefunction_type': wf_type, 'optimizer': optimizer, 'hparams': ansatz_hp,
+          'chains': b, 'epochs': epochs, 'batches_per_epoch': 50, 'train_seconds': round(t_train, 1),
           'energy_per_site_first_epoch': metrics[0] / n,
           'energy_per_site_last_10_epochs_mean': sum(tail) / len(tail) / n,
           'energy_per_site_min_epoch': min(metrics) / n,
