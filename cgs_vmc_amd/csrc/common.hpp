@@ -228,7 +228,13 @@ hipError_t launch_pack(hipStream_t s, const float* theta, int N, int H, int Hp,
 // eloc: the local-energy reduction of the same accumulate call rides in this launch (k_eloc_reduce's job,
 // chain by chain with its summation order: the workgroup that owns 16 chains also folds their rows of
 // `val`), one dependent launch (6 us at config 3) less per step; off == nullptr: nothing to fold
-struct ElocFold { const int* off; const float* diag; const float* val; float* offdiag; float* eloc; };
+// ratio != nullptr (LogOverlapITSWO, training.py:665-672): eloc is the SUPERVISOR's local energy and the launch
+// also leaves ratio_b = psi_w / psi (1 - beta E_loc^w) -- k_itswo_ratio's job and expression (grad.hip) -- from
+// the two cached logits; that ratio is then the weight of the second sum (OutLayerSums::w == ratio)
+struct ElocFold {
+  const int* off; const float* diag; const float* val; float* offdiag; float* eloc;
+  float* ratio; const float* logit_psi; const float* logit_omega; float log_factor, beta; int oact;
+};
 // out: the output layer's weight gradient (fully_connected: sum_b (1 | w_b) s_b [a_L(b) | 1], s = oscale or 1)
 // as per-workgroup partial sums over the 16 chains a workgroup owns anyway, part[workgroup][2][Hp + 4]
 // (slot Hp: the bias); k_wgrad folds them (its N = 1 tiles -- one column of 64 used -- leave the MFMA grid,
@@ -237,7 +243,7 @@ struct OutLayerSums { float* part; const float* w; };
 hipError_t launch_backprop16(hipStream_t s, const float* act_all, float* delta_all,
                              const float* p16t, const float* woutp, int B, int Hp, int n_hidden,
                              bool rbm, int act, const float* dact_all, const float* oscale,
-                             const ElocFold& eloc = ElocFold{nullptr, nullptr, nullptr, nullptr, nullptr},
+                             const ElocFold& eloc = ElocFold{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0},
                              const OutLayerSums& out = OutLayerSums{nullptr, nullptr});
 hipError_t launch_tail(hipStream_t s, const TailArgs& a, int Hp, bool ratio_mode, bool rbm);
 hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, int rows, int N,

@@ -424,7 +424,15 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
         if (ef.offdiag) ef.offdiag[c] = sum;
         const float e = dg[q] + sum;
         ef.eloc[c] = e;
-        if (op.part && op.w == ef.eloc) s_wj[wave * Q + q] = e;
+        float wgt = e;
+        if (ef.ratio) {     // LogOverlapITSWO: the supervisor's local energy -> the ratio (k_itswo_ratio's expression)
+          const float lw = ef.logit_omega[c], lp = ef.logit_psi[c];
+          const float amp = ef.oact == VMC_ACT_EXP_ ? expf(lw - lp + ef.log_factor)
+                                                    : vmc_act_rt(ef.oact, lw) / vmc_act_rt(ef.oact, lp);
+          wgt = amp * (1.f - ef.beta * e);
+          ef.ratio[c] = wgt;
+        }
+        if (op.part && op.w == (ef.ratio ? ef.ratio : ef.eloc)) s_wj[wave * Q + q] = wgt;
       }
     }
   }
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(NW * 64) void k_backprop16(const float* __restrict_
   // the last activations are read again (L2).
   if (op.part) {                                   // block-uniform
     float wj;
-    if (ef.off && op.w == ef.eloc) {
+    if (ef.off && op.w == (ef.ratio ? ef.ratio : ef.eloc)) {
       if (n_hidden == 0) __syncthreads();
       wj = ok ? s_wj[j] : 0.f;
     } else {

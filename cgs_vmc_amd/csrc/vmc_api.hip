@@ -1289,7 +1289,7 @@ int vmc_last_connected_rows(vmc_ctx* c, int64_t* rows) { CHECK_CTX(c); if (!rows
 // `e` / `mode`: the scalar accumulators (sum E, counts, sum ratio) ride in the reduction launch of the
 // dense weight-gradient GEMMs; *scalars_done tells the caller whether they did
 static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e, int mode, bool* scalars_done,
-                         bool fold_eloc = false) {
+                         bool fold_eloc = false, float beta = 0.f) {
   *scalars_done = false;
   ParamSet& p = c->ps[0];
   const int B = c->B, N = c->N, H = c->H, Hp = c->Hp, NH = c->n_hh;
@@ -1359,8 +1359,13 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e,
   } else
   HIPCHK(c, launch_backprop16(c->stream, c->act_all, c->delta_all, p.p16t, p.woutp, B, Hp, NH, c->rbm, c->hact,
                               c->dact_all, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr,
-                              fold_eloc ? ElocFold{c->off, c->diag, c->val, c->offdiag, c->ps[0].eloc}
-                                        : ElocFold{nullptr, nullptr, nullptr, nullptr, nullptr},
+                              // the fold of the local energies (EnergyGradient: psi's; LogOverlapITSWO: the
+                              // supervisor's, and the ratio behind them) rides in this launch
+                              !fold_eloc ? ElocFold{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0}
+                              : mode == VMC_MODE_ENERGY_GRADIENT
+                                  ? ElocFold{c->off, c->diag, c->val, c->offdiag, c->ps[0].eloc, nullptr, nullptr, nullptr, 0.f, 0.f, 0}
+                                  : ElocFold{c->off, c->diag, c->val, c->offdiag, c->ps[1].eloc, c->ratio, c->ps[0].logit,
+                                             c->ps[1].logit, c->ps[0].shift - c->ps[1].shift, beta, c->oact},
                               OutLayerSums{c->wg_out_partials ? c->wg_outpart : nullptr, w}));
   // Every weight gradient is [a_{l-1} | 1]^T [delta_l | w (.) delta_l]: rows 0..K_in-1 give dW, the
   // implicit ones row gives db (b_l sits right behind w_l in theta), the unscaled product goes to g1 and
@@ -1446,10 +1451,11 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
     w = e = c->ps[0].eloc;
   } else {
     if (!c->ps[1].has_params) return fail(c, VMC_ERR_STATE, "supervisor parameters not set (vmc_transfer_params)");
-    PROPAGATE(local_energy_device(c, VMC_OMEGA));             // training.py:664, 667
+    PROPAGATE(local_energy_device(c, VMC_OMEGA, true, &fold_eloc));   // training.py:664, 667
     PROPAGATE(ensure_cache(c, VMC_PSI));
-    HIPCHK(c, launch_itswo_ratio(c->stream, c->ps[0].logit, c->ps[1].logit, c->ps[1].eloc,
-                                 c->ps[0].shift - c->ps[1].shift, beta, c->B, c->ratio, c->oact));
+    if (!fold_eloc)   // (otherwise the back-propagation launch folds E_loc^w and forms the ratio: two launches less)
+      HIPCHK(c, launch_itswo_ratio(c->stream, c->ps[0].logit, c->ps[1].logit, c->ps[1].eloc,
+                                   c->ps[0].shift - c->ps[1].shift, beta, c->B, c->ratio, c->oact));
     w = c->ratio; e = c->ps[1].eloc;
   }
   PROPAGATE(ensure_cache(c, VMC_PSI));
@@ -1458,7 +1464,7 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   if (c->conv) PROPAGATE(acc_zeros(c));
   const bool fresh = c->acc_fresh;
   bool scalars_done = false;
-  PROPAGATE(gradient_sums(c, w, fresh, e, mode, &scalars_done, fold_eloc));
+  PROPAGATE(gradient_sums(c, w, fresh, e, mode, &scalars_done, fold_eloc, beta));
   if (!scalars_done)
     HIPCHK(c, launch_scalar_accum(c->stream, e, mode == 1 ? c->ratio : nullptr, c->B, c->acc + 2 * c->P, mode, fresh));
   c->acc_fresh = false;
