@@ -757,6 +757,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
     }
   };
   long long it_first = -1;
+  if (a.n_steps == 0) it_first = 0;   // a pure cache refresh (refresh_cache_by_sampler, vmc_api.hip): one pass, the final one
   if (a.cache_in_valid && a.n_steps > 0) {
     // the previous launch left an exact z1 / logit cache for these very chains: load it
     // instead of recomputing it (saves one of the two refresh passes per launch)

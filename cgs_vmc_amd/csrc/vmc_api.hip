@@ -1061,6 +1061,38 @@ static int run_sweep_wide(vmc_ctx* c, long long n_steps, bool injected, bool dbg
   return VMC_OK;
 }
 
+// z1 / logit (/ onsite) cache of parameter set `which` for the current chains by ONE refresh pass of the sampler
+// kernel (n_steps = 0: z1 from the spins, the layers, the output): the 4096 chains of config 3 as 256
+// sixteen-chain tiles in one forward (~20 us) where first-layer GEMM + row kernel over 128 units of 32 rows
+// take 92 (LogOverlapITSWO's supervisor amplitudes).  The chains are not touched (the kernel's copy of them
+// goes to the buffer the next sampler launch overwrites anyway); nothing is swapped.
+static bool sampler_refresh_ok(const vmc_ctx* c) {
+  static const bool on = !(getenv("CGS_VMC_SAMPLER_REFRESH") && atoi(getenv("CGS_VMC_SAMPLER_REFRESH")) == 0);
+  return on && !c->conv && !(c->wide && !c->wide_fast);
+}
+static int refresh_cache_by_sampler(vmc_ctx* c, int which) {
+  PROPAGATE(ensure_packed(c, which));
+  ParamSet& p = c->ps[which];
+  SweepArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pp = p.packed();
+  a.configs_in = c->configs; a.z1_in = p.z1; a.logit_in = p.logit;
+  a.configs = c->configs_alt; a.z1 = p.z1; a.logit = p.logit;
+  a.onsite = p.onsite; a.rbm = c->rbm ? 1 : 0;
+  a.accepted = c->d_accepted;
+  a.B = c->B; a.N = c->N; a.n_hidden = c->n_hh;
+  a.chain_offset = c->d.chain_offset;
+  a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
+  a.step0 = c->step; a.n_steps = 0;
+  a.waves = c->sweep_waves; a.no_w1l = c->sweep_no_w1l;
+  a.act = c->hact; a.oact = c->oact;
+  a.cache_in_valid = 0;
+  Timer t(c, "refresh");
+  HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
+  p.cache_valid = true;
+  return VMC_OK;
+}
+
 static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int* dbg_up, int* dbg_dn,
                      float* dbg_u, unsigned long long step0, bool count_accepted = false,
                      bool overtake = false, hipEvent_t dep = nullptr) {
@@ -1451,6 +1483,7 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
     w = e = c->ps[0].eloc;
   } else {
     if (!c->ps[1].has_params) return fail(c, VMC_ERR_STATE, "supervisor parameters not set (vmc_transfer_params)");
+    if (!c->ps[1].cache_valid && sampler_refresh_ok(c)) PROPAGATE(refresh_cache_by_sampler(c, VMC_OMEGA));
     PROPAGATE(local_energy_device(c, VMC_OMEGA, true, &fold_eloc));   // training.py:664, 667
     PROPAGATE(ensure_cache(c, VMC_PSI));
     if (!fold_eloc)   // (otherwise the back-propagation launch folds E_loc^w and forms the ratio: two launches less)
