@@ -45,7 +45,11 @@ def test_500_engine_life_cycles_leak_nothing_and_torch_starts_afterwards():
   steps = [b[3] - a[3] for a, b in zip(tail, tail[1:])]
   grew = [d for d in steps if d > 2]
   assert len(grew) <= 3 and all(d <= 200 for d in grew), steps
-  assert rss <= 64 + 200 * len(grew), (base, last)
+  # ... and outside those steps the resident memory does not grow at all (a slow leak of 2 MB per
+  # interval would have passed the bound above): the other intervals together stay within 8 MB over 480 cycles
+  flat = [d for d in steps if d <= 2]
+  assert sum(flat) <= 8, steps
+  assert rss <= 8 + 200 * len(grew), (base, last)
   assert maps <= 8 + 8 * len(grew), (base, last)    # memory mappings
 
 
