@@ -1167,6 +1167,7 @@ int vmc_mc_steps(vmc_ctx* c, int64_t n_steps, int64_t* accepted) {
   CHECK_CTX(c);
   if (n_steps < 0) return fail(c, VMC_ERR_INVALID, "n_steps < 0");
   if (n_steps == 0) {               // `for _ in range(0)`: nothing runs, nothing is launched
+    c->side_sweep_once = false;     // (a request for the side stream does not outlive the call it was made for)
     if (accepted) *accepted = 0;
     return VMC_OK;
   }
@@ -1732,7 +1733,7 @@ static int epoch_energy_gradient_impl(vmc_ctx* c, void* comm, int world, int64_t
     PROPAGATE(vmc_accumulate(c, VMC_MODE_ENERGY_GRADIENT, 0.f));
     // sharded chains: the last sweep does not touch the accumulators -- on its own stream it runs beside the
     // all-reduce instead of in front of it (CGS_VMC_SIDE_SWEEP=0: in stream order, for A/B)
-    if (b == n_batches - 1 && world > 1 && side_sweep_enabled()) c->side_sweep_once = true;
+    if (b == n_batches - 1 && world > 1 && n_mc_steps > 0 && side_sweep_enabled()) c->side_sweep_once = true;
     PROPAGATE(vmc_mc_steps(c, n_mc_steps, nullptr));
   }
   // sharded chains: the accumulators leave this call summed over ranks (the last sweep, on its own
