@@ -48,6 +48,7 @@ _ip = C.POINTER(C.c_int32)
 _ctx = C.c_void_p
 _bp = C.POINTER(C.c_uint8)
 VMC_REDUCE_SUM, VMC_REDUCE_MAX, VMC_REDUCE_SUM_F64 = 0, 1, 2
+VMC_HOST_REDUCE_CAP_F64 = 1
 # vmc_host_allreduce_fn: int hook(void* user, float* host_buf, int64_t n_elements, int32_t op)
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_int64, C.c_int32)
 # vmc_device_allreduce_fn: int hook(void* user, void* dev_buf, int64_t n_elements, int32_t op, void* stream)
@@ -95,6 +96,7 @@ SIGNATURES = {
                                         C.c_float, C.c_float, C.c_float, C.c_float,
                                         C.POINTER(C.c_double)]),
     'vmc_set_host_allreduce': (C.c_int, [_ctx, HOST_ALLREDUCE_FN, C.c_void_p]),
+    'vmc_set_host_allreduce_caps': (C.c_int, [_ctx, C.c_int32]),
     'vmc_set_device_allreduce': (C.c_int, [_ctx, DEVICE_ALLREDUCE_FN, C.c_void_p]),
     'vmc_evaluate': (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int64,
                                C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -103,6 +105,8 @@ SIGNATURES = {
     'vmc_rccl_comm_destroy': (C.c_int, [C.c_void_p]),
     'vmc_rccl_last_error': (C.c_char_p, []),
     'vmc_rccl_library_path': (C.c_char_p, []),
+    'vmc_device_pci_bus_id': (C.c_int, [C.c_int32, C.c_char_p, C.c_int32]),
+    'vmc_hip_runtime_path': (C.c_char_p, []),
     'vmc_debug_allreduce': (C.c_int, [_ctx, C.c_void_p, C.c_int32, _fp, C.c_int64, C.c_int32]),
     'vmc_update_norm_dist': (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_float]),
     'vmc_epoch_energy_gradient_dist': (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,
@@ -181,6 +185,16 @@ def load():
   global _lib
   if _lib is not None:
     return _lib
+  # Diagnostic builds (in-kernel stamps, ...) live under a path of their own and are selected explicitly:
+  # CGS_VMC_DIAGNOSTIC_LIBRARY=/path/lib.so together with CGS_VMC_ALLOW_EXTRA_BUILD=1.  They never replace
+  # the product library in the tree (tools/wgrad_stamps.sh).
+  diag = os.environ.get('CGS_VMC_DIAGNOSTIC_LIBRARY')
+  if diag:
+    if os.environ.get('CGS_VMC_ALLOW_EXTRA_BUILD', '0') != '1':
+      raise HipLibraryError('CGS_VMC_DIAGNOSTIC_LIBRARY is set without CGS_VMC_ALLOW_EXTRA_BUILD=1')
+    import sys
+    sys.stderr.write('cgs_vmc_amd: loading the DIAGNOSTIC library {} (never quote its run times)\n'.format(diag))
+    return _bind(diag, preload_torch=True)
   if not os.path.exists(_LIB_PATH):
     raise HipLibraryError(
         '{} not found: build it with __graft_entry__.build() (hipcc --offload-arch=gfx950). '
@@ -189,13 +203,18 @@ def load():
     raise HipLibraryError(
         '{} was not built from the sources in {} (stamp mismatch): rebuild it with '
         '__graft_entry__.build() or `make -C cgs_vmc_amd/csrc`.'.format(_LIB_PATH, _CSRC))
+  return _bind(_LIB_PATH, preload_torch=True)
+
+
+def _bind(path, preload_torch):
+  global _lib
   # ONE HIP runtime per process.  torch bundles its own libamdhip64 (same soname as ROCm's): whichever is
   # loaded first serves this library, and torch always loads its own -- so with this library first the
   # process ends up with two runtimes (engines on one, torch on the other: "No HIP GPUs are available"
   # from torch's late initialisation and aborts at exit have both been seen that way).  Loading torch
   # first, where it is installed, makes every import order end in torch's single runtime.
   # CGS_VMC_NO_TORCH_PRELOAD=1 skips it (torch-free hosts that want the seconds of start-up back).
-  if os.environ.get('CGS_VMC_NO_TORCH_PRELOAD', '0') != '1':
+  if preload_torch and os.environ.get('CGS_VMC_NO_TORCH_PRELOAD', '0') != '1':
     try:
       import torch  # noqa: F401  pylint: disable=unused-import,import-outside-toplevel
     except ImportError:
@@ -207,14 +226,14 @@ def load():
       warnings.warn('cgs_vmc_amd: importing torch before libcgsvmc_hip.so failed ({!r}); loading the '
                     'library on the system HIP runtime'.format(e))
   try:
-    lib = C.CDLL(_LIB_PATH)
+    lib = C.CDLL(path)
   except OSError as e:
-    raise HipLibraryError('cannot load {}: {}'.format(_LIB_PATH, e)) from e
+    raise HipLibraryError('cannot load {}: {}'.format(path, e)) from e
   for name, (res, args) in SIGNATURES.items():
     try:
       fn = getattr(lib, name)
     except AttributeError as e:
-      raise HipLibraryError('{} does not export {}'.format(_LIB_PATH, name)) from e
+      raise HipLibraryError('{} does not export {}'.format(path, name)) from e
     fn.restype = res
     fn.argtypes = args
   _lib = lib

@@ -2,6 +2,13 @@
 // (sum_b O_k(b) and sum_b w_b O_k(b), O_k = d logit / d theta_k) as an explicit
 // forward / back-prop (k_backprop16, mlp.hip) / weight-gradient GEMM chain on fp32 MFMA, plus the accumulator,
 // ratio and Adam element-wise kernels.  All reductions are fixed-order (no float atomics).
+// ---- arch guard: k_wgrad's split-K hand-over (sc1 write-through stores drained by every storing wave, a
+// relaxed agent-scope ticket, sc1 loads by the last arriver) relies on the scope-bit behaviour measured on
+// gfx950 (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads in place of the acquire"); it is not a
+// C++-memory-model release/acquire pair.  Refuse to compile device code for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "grad.hip: k_wgrad's sc1 hand-over protocol is validated on gfx950 only"
+#endif
 #include "common.hpp"
 #include <cstdlib>
 #ifdef VMC_WGRAD_STAMPS
@@ -786,12 +793,12 @@ hipError_t launch_wgrad(hipStream_t s, const WgradLaunch& L) {
   const int n_fold = L.out_part ? plan_wgrad_fold_blocks(L.out_H) : 0;
   const int grid = a.mfma_blocks + ((L.sc_out || n_fold) ? 1 : 0) + n_fold;
   if (grid <= 0 || L.K <= 0) return hipSuccess;
-  static bool attr_set = false;
+  // The opt-in is per DEVICE and the library serves several devices per process (DeviceGuard): set it on
+  // every launch like the other launchers (tail16.hpp, sweep16.hpp, conv_kernels.hpp), never cached.
   const size_t lds = wgrad_lds_bytes();
-  if (!attr_set) {
+  {
     hipError_t e = hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
 #ifdef VMC_WGRAD_STAMPS
   // diagnostic build: every 20th launch is stamped, read back synchronously and summarised on stderr

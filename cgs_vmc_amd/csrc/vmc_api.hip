@@ -152,6 +152,7 @@ struct vmc_ctx {
   // collectives over sharded chains: host hook for non-RCCL transports + its staging
   vmc_host_allreduce_fn host_reduce = nullptr;
   void* host_reduce_user = nullptr;
+  int host_reduce_caps = 0;                       // VMC_HOST_REDUCE_CAP_*: what the registered host hook has declared
   vmc_device_allreduce_fn dev_reduce = nullptr;   // in-stream transport of the host's own collective library
   void* dev_reduce_user = nullptr;
   double* d_eval = nullptr;      // vmc_evaluate: batch sums / means of the samples
@@ -634,6 +635,9 @@ int reduce_buffer(vmc_ctx* c, void* comm, int world, void* buf, long long n, int
   }
   if (!c->host_reduce)
     return fail(c, VMC_ERR_STATE, "world_size > 1 needs an RCCL communicator, vmc_set_device_allreduce or vmc_set_host_allreduce");
+  if (f64 && !(c->host_reduce_caps & VMC_HOST_REDUCE_CAP_F64))
+    return fail(c, VMC_ERR_UNSUPPORTED, "the registered host all-reduce hook has not declared float64 support "
+                "(vmc_set_host_allreduce_caps(ctx, VMC_HOST_REDUCE_CAP_F64)): it would be handed doubles");
   const long long nf = f64 ? 2 * n : n;          // staging size in floats
   if (nf > c->h_stage_n) {
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -1423,7 +1427,8 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e,
     c->batch_ready[slot][par] = true;
   }
   {
-    static const int forced = getenv("CGS_VMC_WGRAD_SLICES") ? atoi(getenv("CGS_VMC_WGRAD_SLICES")) : 0;   // measurement knob
+    const char* fe = getenv("CGS_VMC_WGRAD_SLICES");        // measurement / test knob, read per launch
+    const int forced = fe ? atoi(fe) : 0;
     WgradLaunch L;
     memset((void*)&L, 0, sizeof(L));
     L.dev_problems = c->d_batch[slot][par]; L.n_prob = NH + (c->wg_out_partials ? 1 : 2);
@@ -1478,13 +1483,19 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   // psi cache the sampler reads, the launch must wait for all of it instead.
   const bool cache_was_valid = c->ps[0].cache_valid && c->ps[0].packed_valid;
   if (can_overlap(c)) HIPCHK(c, hipEventRecord(c->ev_mark, c->stream));
-  bool fold_eloc = false;
+  bool fold_eloc = false, refresh_ran = false;
   if (mode == VMC_MODE_ENERGY_GRADIENT) {
     PROPAGATE(local_energy_device(c, VMC_PSI, true, &fold_eloc));   // training.py:542-543
     w = e = c->ps[0].eloc;
   } else {
     if (!c->ps[1].has_params) return fail(c, VMC_ERR_STATE, "supervisor parameters not set (vmc_transfer_params)");
-    if (!c->ps[1].cache_valid && sampler_refresh_ok(c)) PROPAGATE(refresh_cache_by_sampler(c, VMC_OMEGA));
+    if (!c->ps[1].cache_valid && sampler_refresh_ok(c)) {
+      // the refresh pass is a sampler launch: it writes its chain copy to configs_alt, the buffer a directly
+      // following vmc_mc_steps writes too.  Behind ev_mark alone that launch could overtake it and have its
+      // new chains overwritten by the refresh's old ones: no token, the sampler waits for all of this.
+      PROPAGATE(refresh_cache_by_sampler(c, VMC_OMEGA));
+      refresh_ran = true;
+    }
     PROPAGATE(local_energy_device(c, VMC_OMEGA, true, &fold_eloc));   // training.py:664, 667
     PROPAGATE(ensure_cache(c, VMC_PSI));
     if (!fold_eloc)   // (otherwise the back-propagation launch folds E_loc^w and forms the ratio: two launches less)
@@ -1504,7 +1515,7 @@ int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   c->acc_fresh = false;
   if (c->sr_cap > 0 && mode == VMC_MODE_ENERGY_GRADIENT) PROPAGATE(sr_record(c));
   c->acc_since_sweep = true;
-  c->token = cache_was_valid;
+  c->token = cache_was_valid && !refresh_ran;
   return VMC_OK;
 }
 
@@ -1537,6 +1548,14 @@ int vmc_set_host_allreduce(vmc_ctx* c, vmc_host_allreduce_fn hook, void* user) {
   CHECK_CTX(c);
   c->host_reduce = hook;
   c->host_reduce_user = user;
+  c->host_reduce_caps = 0;          // a new hook has declared nothing yet
+  return VMC_OK;
+}
+
+int vmc_set_host_allreduce_caps(vmc_ctx* c, int32_t caps) {
+  CHECK_CTX(c);
+  if (caps & ~VMC_HOST_REDUCE_CAP_F64) return fail(c, VMC_ERR_INVALID, "unknown capability bits");
+  c->host_reduce_caps = caps;
   return VMC_OK;
 }
 
@@ -1554,6 +1573,22 @@ const char* vmc_rccl_library_path(void) {
   const Rccl* r = rccl();
   Dl_info info;
   if (r && dladdr((void*)r->all_reduce, &info) && info.dli_fname) path = info.dli_fname;
+  return path.c_str();
+}
+
+int vmc_device_pci_bus_id(int32_t device, char* buf, int32_t len) {
+  if (!buf || len < 16) return VMC_ERR_INVALID;
+  buf[0] = 0;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return VMC_ERR_HIP;
+  if (device < 0 || device >= n) return VMC_ERR_INVALID;
+  return hipDeviceGetPCIBusId(buf, len, device) == hipSuccess ? VMC_OK : VMC_ERR_HIP;
+}
+
+const char* vmc_hip_runtime_path(void) {
+  static std::string path;
+  Dl_info info;
+  if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) path = info.dli_fname;
   return path.c_str();
 }
 

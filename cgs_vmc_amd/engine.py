@@ -102,6 +102,10 @@ class VmcEngine:
 
   def close(self):
     if getattr(self, '_ctx', None) is not None and self._ctx.value:
+      coll = getattr(self, '_coll', None)
+      if coll is not None:           # zero-copy views of this ctx's device buffers die with it
+        coll.drop_views()
+        self._coll = None
       self._lib.vmc_destroy(self._ctx)
       self._ctx = C.c_void_p()
 
@@ -315,10 +319,16 @@ class VmcEngine:
   def _bind_collective(self, coll):
     """Registers coll's device / host all-reduce hooks (the transports without a communicator of
     the library's own) and returns (comm, world)."""
+    coll.raise_if_broken()
+    self._coll = coll
     hook = coll.host_hook()
     if getattr(self, '_host_hook', None) is not hook:
       self._check(self._lib.vmc_set_host_allreduce(
           self._ctx, hook if hook is not None else _hip.HOST_ALLREDUCE_FN(), None))
+      # this binding's host hook reduces float64 buffers too (op VMC_REDUCE_SUM_F64: vmc_evaluate's means);
+      # a hook that has not said so gets VMC_ERR_UNSUPPORTED instead of doubles it would read as floats
+      self._check(self._lib.vmc_set_host_allreduce_caps(
+          self._ctx, _hip.VMC_HOST_REDUCE_CAP_F64 if hook is not None else 0))
       self._host_hook = hook       # keeps the ctypes thunk alive as long as the ctx may call it
     dhook = coll.device_hook()
     if getattr(self, '_device_hook', None) is not dhook:

@@ -11,6 +11,7 @@ is used by the CPU tests.  Every rank then applies the identical Adam step.
 from __future__ import annotations
 
 import os
+import sys
 
 import numpy as np
 
@@ -204,6 +205,7 @@ class Collective:
     self._hook = None
     self._dhook = None
     self._views = {}
+    self._broken = None          # the first exception raised inside a hook (the C call only sees a code)
     from . import _hip
     if use_hook:
       self._hook = _hip.HOST_ALLREDUCE_FN(self._host_allreduce)
@@ -248,10 +250,8 @@ class Collective:
         buf = np.ctypeslib.as_array(ptr, shape=(int(n),))
       self.allreduce_host(buf, 'max' if op == 1 else 'sum')
       return 0
-    except Exception:  # pylint: disable=broad-except
-      import traceback
-      traceback.print_exc()
-      return 1
+    except Exception as e:  # pylint: disable=broad-except
+      return self._hook_failed(e)
 
   def _device_allreduce(self, user, ptr, n, op, stream):   # vmc_device_allreduce_fn
     try:
@@ -268,10 +268,36 @@ class Collective:
       with torch.cuda.stream(_torch_stream(self.device, stream or 0)):
         dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
       return 0
-    except Exception:  # pylint: disable=broad-except
-      import traceback
-      traceback.print_exc()
-      return 1
+    except Exception as e:  # pylint: disable=broad-except
+      return self._hook_failed(e)
+
+  def _hook_failed(self, exc) -> int:
+    """A hook runs inside a C call: the exception cannot cross it, the call returns VMC_ERR_HIP and the
+    engine raises HipLibraryError on THIS rank while the others may already sit in the collective.  The
+    cause is kept (raise_if_broken re-raises it on the next use of this Collective, which is then
+    refused for good), and with CGS_VMC_HOOK_FAILURE=abort the rank leaves at once with exit code 70, so
+    that a launcher (torch.distributed.run) tears the job down instead of leaving the peers blocked
+    until the backend's own timeout."""
+    import traceback
+    traceback.print_exc()
+    if self._broken is None:
+      self._broken = exc
+    if self.world > 1 and os.environ.get('CGS_VMC_HOOK_FAILURE', 'raise') == 'abort':
+      sys.stderr.write('cgs_vmc_amd.parallel: all-reduce hook failed on rank {}; aborting the rank '
+                       '(CGS_VMC_HOOK_FAILURE=abort)\n'.format(rank()))
+      sys.stderr.flush()
+      os._exit(70)
+    return 1
+
+  def raise_if_broken(self):
+    if self._broken is not None:
+      raise RuntimeError('this Collective failed inside an all-reduce hook and the ranks may be out of step; '
+                         'restart the job') from self._broken
+
+  def drop_views(self):
+    """Forgets the zero-copy torch views of engine buffers (an engine that closes calls this: its
+    device pointers may be handed out again to another allocation of the same size)."""
+    self._views.clear()
 
   def close(self):
     self._views.clear()

@@ -131,8 +131,11 @@ def _proto_scalar(typ, v):
 
 
 def _float_text(v: float) -> str:
-  # protobuf text_format prints float fields with the shortest float32 round-trip repr
-  return str(np.float32(v))
+  # protobuf's text_format prints a float field as str() of the Python float with the shortest float32
+  # round-trip digits (type_checkers.ToShortestFloat): '0.0001', '1e-05', '0.99' -- numpy's own str()
+  # switches to the exponent form one decade earlier ('1e-04'), found by the google.protobuf cross-check
+  # (tests/test_hparams_independent.py)
+  return repr(float(str(np.float32(v))))
 
 
 class HParamDefText:

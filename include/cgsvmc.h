@@ -214,6 +214,14 @@ enum { VMC_REDUCE_SUM = 0, VMC_REDUCE_MAX = 1,
        VMC_REDUCE_SUM_F64 = 2 /* the buffer holds n DOUBLES (vmc_evaluate's batch means) */ };
 typedef int (*vmc_host_allreduce_fn)(void* user, float* host_buf, int64_t n_elements, int32_t op);
 int vmc_set_host_allreduce(vmc_ctx* ctx, vmc_host_allreduce_fn hook, void* user);
+/* CONTRACT CHANGE (round 4 -> 5): op VMC_REDUCE_SUM_F64 hands the hook n_elements DOUBLES in host_buf
+ * (cast the pointer).  A hook written for ops 0 / 1 would silently reduce half of them as floats, so the
+ * library only passes op 2 to a host hook that has declared it: vmc_set_host_allreduce_caps(ctx,
+ * VMC_HOST_REDUCE_CAP_F64) after registering it (registering a hook clears the caps).  Without the
+ * declaration the entries that need it (vmc_evaluate with world_size > 1 on the host hook) return
+ * VMC_ERR_UNSUPPORTED.  The device hook always receives op 2 (its contract has had it from the start). */
+enum { VMC_HOST_REDUCE_CAP_F64 = 1 };
+int vmc_set_host_allreduce_caps(vmc_ctx* ctx, int32_t caps);
 /* Third transport, for hosts whose collective library keeps its communicator to itself but reduces
  * device memory in stream order (torch.distributed's ProcessGroupNCCL = RCCL on ROCm): with
  * nccl_comm == NULL and world_size > 1 the library calls this hook -- when one is registered it wins
@@ -239,6 +247,12 @@ const char* vmc_rccl_last_error(void);
  * the loader path; "" when none was found.  A caller's ncclComm_t must come from THIS instance: a
  * communicator of another librccl in the process is rejected by ncclAllReduce as corrupted. */
 const char* vmc_rccl_library_path(void);
+/* PCI bus id ("0000:75:00.0") of HIP device `device`, and the file of the libamdhip64 behind this
+ * library's hip* symbols -- both answered by THE runtime the library is bound to, so a caller that
+ * wants to tell two ranks' devices apart never has to open a HIP runtime of its own by soname (a
+ * second runtime in the process: see vmc_rccl_library_path).  Needs no ctx; `len` >= 16. */
+int vmc_device_pci_bus_id(int32_t device, char* buf, int32_t len);
+const char* vmc_hip_runtime_path(void);
 /* Test / diagnostic hook: in-place all-reduce of n_floats of host data through the same transport
  * (staged through the ctx's device scratch for RCCL); op = VMC_REDUCE_*. */
 int vmc_debug_allreduce(vmc_ctx* ctx, void* nccl_comm, int32_t world_size, float* host,

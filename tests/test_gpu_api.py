@@ -265,6 +265,11 @@ def test_multi_rank_bench_path_on_one_gpu(tmp_path, gpus, collective, transport)
   assert [i['rank'] for i in r['devices']] == list(range(gpus))
   assert all(i['ordinal'] == 0 and i['pci_bus_id'] and i['name'] for i in r['devices'])
   assert r['distinct_devices'] is False        # the ranks share this GPU: tolerated under gloo only
+  # the device identity comes from the runtime the process already has -- every rank
+  # maps exactly ONE libamdhip64, and it is the one behind the library's hip* symbols
+  for i in r['devices']:
+    assert len(i['hip_runtimes_mapped']) == 1, i['hip_runtimes_mapped']
+    assert os.path.realpath(i['hip_runtime']) == i['hip_runtimes_mapped'][0]
   c = r['checked_allreduce']
   assert c['ok'] is True and c['library_ok'] is True and c['process_group_on_accumulators']
   assert c['library_sum_of_ranks'] == c['expected_sum_of_ranks'] == gpus * (gpus - 1) / 2
@@ -301,7 +306,7 @@ def test_one_rank_through_the_launcher_costs_nothing():
 
   def run(extra):
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '50', '--warmup', '5',
-                        '--no-cpu-baseline', '--no-timing'] + extra, env=env, stdout=subprocess.PIPE,
+                        '--no-cpu-baseline', '--no-timing', '--no-extra'] + extra, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     return json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])

@@ -150,6 +150,31 @@ def test_host_hook_transport_doubles_like_two_identical_ranks():
   eng.close()
 
 
+def test_host_hook_gets_float64_buffers_only_after_declaring_them():
+  """VMC_REDUCE_SUM_F64 hands a host hook DOUBLES in its float staging buffer.  A hook only
+  receives that op once vmc_set_host_allreduce_caps(VMC_HOST_REDUCE_CAP_F64) has declared it (the Python
+  binding does on registration); without the declaration vmc_evaluate is refused instead of returning
+  means reduced as floats."""
+  from cgs_vmc_amd import parallel
+
+  class Twin(parallel.Collective):
+    def allreduce_host(self, buf, op='sum'):
+      if op == 'sum':
+        buf *= 2.0
+      return buf
+
+  coll = Twin(0, 2, use_hook=True)
+  eng = _engine()
+  means, _ = eng.evaluate(coll, 8, 3, 8)
+  assert means.shape == (3,) and np.all(np.isfinite(means))
+  eng._check(eng._lib.vmc_set_host_allreduce_caps(eng._ctx, 0))      # a hook of the old contract
+  with pytest.raises(NotImplementedError, match='float64'):
+    eng.evaluate(coll, 8, 3, 8)
+  with pytest.raises(ValueError):
+    eng._check(eng._lib.vmc_set_host_allreduce_caps(eng._ctx, 6))
+  eng.close()
+
+
 def test_device_hook_transport_doubles_like_two_identical_ranks():
   """The device-hook path (the default transport of an `nccl` job: torch.distributed reduces the
   library's device buffer in stream order) end to end in one process: a hook that behaves like a second

@@ -11,10 +11,10 @@ OUT=$ROOT/gpurun_out/${TAG}_prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # the program itself follows `--` (no env / bash -c hop under the profiler)
-B="python3 $ROOT/bench.py --workload $WL --steps 10 --warmup 2 --reps 1 --no-cpu-baseline --no-timing"
+B="python3 $ROOT/bench.py --workload $WL --steps 10 --warmup 2 --reps 1 --no-cpu-baseline --no-extra --no-timing"
 # the stats pass runs the bench's own step count, so that its per-kernel average is the steady
 # state the bench line reports (the first launches of a process run ~10 % slower: clocks, caches)
-BS="python3 $ROOT/bench.py --workload $WL --steps 100 --warmup 10 --reps 1 --no-cpu-baseline --no-timing"
+BS="python3 $ROOT/bench.py --workload $WL --steps 100 --warmup 10 --reps 1 --no-cpu-baseline --no-extra --no-timing"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BS > $OUT/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $B > $OUT/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1

@@ -17,6 +17,6 @@ print(d["ms_per_step"], d["repetitions_ms_per_step"])
 print({k: round(v["ms_avg"] * 1e3, 1) for k, v in d["kernels"].items()})
 PY
 ROOT=$(pwd)
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o p -- python3 $ROOT/bench.py --steps 20 --warmup 5 --reps 2 --no-cpu-baseline --no-timing > /dev/null 2>&1)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o p -- python3 $ROOT/bench.py --steps 20 --warmup 5 --reps 2 --no-cpu-baseline --no-extra --no-timing > /dev/null 2>&1)
 F=$(find $OUT/prof -name '*kernel_stats.csv' | head -1)
 [ -n "$F" ] && cut -d, -f1-4 "$F" | sed 's/(.*)//' | cut -c1-110 | head -14

@@ -4,9 +4,15 @@ energy of the periodic spin-1/2 Heisenberg antiferromagnet -- an answer no part 
   4 x 4 torus:   E0 = -11.228483 (exact diagonalisation, also tests/exact_states.py)
   6 x 6 torus:   E0 / N = -0.678872 (exact diagonalisation, Schulz, Ziman, Poilblanc 1996)
   10 x 10 torus: E0 / N = -0.671549(4) (quantum Monte Carlo, Sandvik 1997)
-The variational principle bounds every epoch energy from below by E0 (up to the Monte Carlo error); a wrong
-sampler distribution, local energy, gradient estimator or optimizer shows up as an energy that falls through the
-bound or does not approach it.  Prints one JSON line per lattice.  usage: python tools/train_demo.py [small]"""
+The variational principle bounds the energy of chains that sample |psi_theta|^2 from below by E0 (up to the Monte
+Carlo error): the final evaluation and the late epochs must respect it; a wrong sampler distribution, local
+energy, gradient estimator or optimizer shows up as an energy that falls through the bound or does not approach
+it.  EARLY epochs may read below E0: an epoch's chains get 20 equilibration sweeps after each Adam step, and while
+the parameters still move fast they partly carry the previous distribution (a non-equilibrated transient, not a
+variational estimate).  The record therefore counts the epochs below `exact - 5 sigma_epoch` and names the last
+one; tests/test_gpu_train_demo.py asserts the late-epoch bound on the 4 x 4 case.  Error bars: the conventional
+standard error std/sqrt(n) of the evaluation's batch means (the reference's printed `sqrt(std)/n`, defect B6, is
+recorded next to it but never used for a test).  Prints one JSON line per lattice.  usage: python tools/train_demo.py [small]"""
 import json
 import os
 import shutil
@@ -33,41 +39,74 @@ CASES = [
 ]
 
 
-def main():
-  from cgs_vmc_amd import lattice, run_energy_evaluation, run_training, session, wavefunctions
-  cases = CASES[:4] if len(sys.argv) > 1 and sys.argv[1] == 'small' else CASES
-  for name, lx, ly, wf_type, optimizer, ansatz_hp, b, epochs, lrs, exact in cases:
-    n = lx * ly
-    d = tempfile.mkdtemp(prefix='cgsvmc_demo_')
-    try:
-      lattice.write_bonds(d, lattice.torus_bonds(lx, ly))
-      session.reset_default_graph(); wavefunctions.reset_name_scope()
-      hp = ('batch_size={},{},num_equilibration_sweeps=20,num_batches_per_epoch=50,'
-            'learning_rates=[{},{},{}],learning_rate_stops=[{},{}],num_evaluation_samples=50').format(
-                b, ansatz_hp, lrs[0], lrs[1], lrs[2], epochs // 2, (3 * epochs) // 4)
-      t0 = time.time()
+def run_case(case, epochs=None, quiet=False):
+  """Trains one case through run_training.main, evaluates it through run_energy_evaluation, returns the record."""
+  import contextlib
+  import io
+  import numpy as np
+  from cgs_vmc_amd import cli_common, lattice, run_energy_evaluation, run_training, session, wavefunctions
+  name, lx, ly, wf_type, optimizer, ansatz_hp, b, epochs_default, lrs, exact = case
+  epochs = epochs or epochs_default
+  n = lx * ly
+  n_batches = 50
+  d = tempfile.mkdtemp(prefix='cgsvmc_demo_')
+  sink = io.StringIO() if quiet else None
+  try:
+    lattice.write_bonds(d, lattice.torus_bonds(lx, ly))
+    session.reset_default_graph(); wavefunctions.reset_name_scope()
+    hp = ('batch_size={},{},num_equilibration_sweeps=20,num_batches_per_epoch={},'
+          'learning_rates=[{},{},{}],learning_rate_stops=[{},{}],num_evaluation_samples=50').format(
+              b, ansatz_hp, n_batches, lrs[0], lrs[1], lrs[2], epochs // 2, (3 * epochs) // 4)
+    t0 = time.time()
+    with contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext():
       run_training.main(['--checkpoint_dir', d, '--num_sites', str(n), '--heisenberg_jx', '-1.0',
                          '--wavefunction_type', wf_type, '--optimizer', optimizer,
                          '--num_epochs', str(epochs), '--hparams', hp])
-      t_train = time.time() - t0
-      metrics = [float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()]
-      session.reset_default_graph(); wavefunctions.reset_name_scope()
-      mean, unc = run_energy_evaluation.main(['--checkpoint_dir', d, '--heisenberg_jx', '-1.0'])
-      tail = metrics[-10:]
-      out = {
-          'lattice': name + ' torus', 'wavefunction_type': wf_type, 'optimizer': optimizer, 'hparams': ansatz_hp,
-          'chains': b, 'epochs': epochs, 'batches_per_epoch': 50, 'train_seconds': round(t_train, 1),
-          'energy_per_site_first_epoch': metrics[0] / n,
-          'energy_per_site_last_10_epochs_mean': sum(tail) / len(tail) / n,
-          'energy_per_site_min_epoch': min(metrics) / n,
-          'evaluation_energy_per_site': mean / n, 'evaluation_uncertainty_per_site': unc / n,
-          'exact_energy_per_site': exact,
-          'relative_error_of_evaluation': (mean / n - exact) / abs(exact),
-          'below_exact_by_more_than_5_sigma': bool(mean / n < exact - 5 * unc / n),
-      }
-      print(json.dumps(out), flush=True)
-    finally:
-      shutil.rmtree(d, ignore_errors=True)
+    t_train = time.time() - t0
+    metrics = np.array([float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()])
+    session.reset_default_graph(); wavefunctions.reset_name_scope()
+    flags = cli_common.parser_from_table('', run_energy_evaluation.FLAG_TABLE).parse_args(
+        ['--checkpoint_dir', d, '--heisenberg_jx', '-1.0'])
+    samples = run_energy_evaluation.evaluate(flags)       # batch means, one sweep apart (evaluation.py:138-145)
+    mean = float(samples.mean())
+    # run_energy_evaluation.py:47 prints sqrt(std) / n -- dimensionally not an error bar (SURVEY defect B6, kept
+    # there so the printed line is comparable); the standard error of the mean of n batch means is std / sqrt(n)
+    unc_b6 = float(np.sqrt(samples.std()) / samples.size)
+    stderr = float(samples.std(ddof=1) / np.sqrt(samples.size))
+    # an epoch energy is the mean over n_batches batches of the same spacing: its statistical error at the
+    # FINAL parameters (early epochs scatter more: the variance of E_loc falls as psi approaches an eigenstate)
+    sigma_epoch = float(samples.std(ddof=1) / np.sqrt(n_batches))
+    e_site = metrics / n
+    below = np.nonzero(e_site < exact - 5 * sigma_epoch / n)[0]
+    tail = metrics[-10:]
+    return {
+        'lattice': name + ' torus', 'wavefunction_type': wf_type, 'optimizer': optimizer, 'hparams': ansatz_hp,
+        'chains': b, 'epochs': epochs, 'batches_per_epoch': n_batches, 'train_seconds': round(t_train, 1),
+        'energy_per_site_first_epoch': float(e_site[0]),
+        'energy_per_site_last_10_epochs_mean': float(tail.mean() / n),
+        'energy_per_site_min_epoch': float(e_site.min()), 'min_epoch_index': int(e_site.argmin()),
+        'evaluation_energy_per_site': mean / n,
+        'evaluation_standard_error_per_site': stderr / n,
+        'evaluation_uncertainty_per_site_reference_b6_expression': unc_b6 / n,
+        'sigma_epoch_per_site_at_final_parameters': sigma_epoch / n,
+        'exact_energy_per_site': exact,
+        'relative_error_of_evaluation': (mean / n - exact) / abs(exact),
+        'evaluation_below_exact_by_more_than_5_standard_errors': bool(mean / n < exact - 5 * stderr / n),
+        # the variational bound holds for a chain population that samples |psi_theta|^2 of the CURRENT theta;
+        # an epoch whose chains still carry the previous parameters' distribution can read anything
+        'epochs_below_exact_minus_5_sigma_epoch': int(below.size),
+        'epochs_below_exact_at_all': int((e_site < exact).sum()),
+        'last_epoch_below_exact_minus_5_sigma_epoch': int(below[-1]) if below.size else None,
+        'first_10_epoch_energies_per_site': [round(float(x), 5) for x in e_site[:10]],
+    }
+  finally:
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def main():
+  cases = CASES[:4] if len(sys.argv) > 1 and sys.argv[1] == 'small' else CASES
+  for case in cases:
+    print(json.dumps(run_case(case)), flush=True)
 
 
 if __name__ == '__main__':
