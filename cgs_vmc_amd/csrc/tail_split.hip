@@ -290,11 +290,22 @@ __global__ __launch_bounds__(256) void k_tail16s(TailArgs a, const unsigned* __r
                  "s_mov_b32 m0, %0"                                                                              \
                  : "=&s"(sv_) : "s"(LDS), "v"(VOFF), "s"(STAGE), "n"(OFF) : "memory");                           \
   } while (0)
-// three 16-byte loads of one row half at byte offset OFF (z1 of the chain, the two W1 rows of the bond)
-#define GATHER3(Z, X, Y, PZ, PX, PY, OFF)                                                                       \
-  asm volatile("global_load_dwordx4 %0, %3, off offset:%6\n\tglobal_load_dwordx4 %1, %4, off offset:%6\n\t"     \
-               "global_load_dwordx4 %2, %5, off offset:%6"                                                       \
-               : "=&v"(Z), "=&v"(X), "=&v"(Y) : "v"(PZ), "v"(PX), "v"(PY), "n"(OFF) : "memory")
+// the three 1 KiB pieces of one row half of the NEXT row tile (z1 of the chain, the two W1 rows of the bond), by
+// LDS-DMA with per-lane addresses into this wave's staging area: lane L fetches 16 bytes at its pointer + OFF and
+// they land at LDS [base + k KiB + 16 L].  The instruction offset moves BOTH addresses, so M0 is set OFF lower.
+// (No register ever receives data behind the compiler's back here: an asynchronous load into registers that the
+// compiler believes already valid -- the first form of this gather -- is at the mercy of its live-range splitting:
+// it copied the "value" elsewhere before it had landed, the landing then overwrote whatever had moved in: a
+// pointer, a memory fault.)
+#define GATHER_DMA3(PZ, PX, PY, LDS, OFF)                                                                          \
+  do {                                                                                                             \
+    unsigned sv_;                                                                                                  \
+    asm volatile("s_mov_b32 %0, m0\n\ts_sub_u32 m0, %1, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off offset:%5\n\t" \
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off offset:%5\n\t"              \
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off offset:%5\n\t"              \
+                 "s_mov_b32 m0, %0"                                                                                \
+                 : "=&s"(sv_) : "s"(LDS), "v"(PZ), "v"(PX), "v"(PY), "n"(OFF) : "memory", "scc");                  \
+  } while (0)
 
 // A-operand fragments from the ring, as inline asm (the compiler must not see an LDS access next to the DMA, and
 // its scheduler, short of registers, sinks ordinary LDS loads next to their use).  ONE statement per item: wait
@@ -319,9 +330,9 @@ template <bool B> struct bool_c { static constexpr bool value = B; };
 // the LDS reads 0.022 ms.  Hence:
 //   * one DMA piece per item (items 0 .. 5), so each is issued into an idle address unit under MFMAs;
 //   * the gather only in the last layer, in LOAD layout -- lane L takes row L >> 2, 16-byte piece L & 3: a quad reads
-//     64 contiguous bytes, 16 look-ups per load -- one row half at a time (items 0 and 3), the first-layer arithmetic
-//     in that layout (coefficient and pointers of row L >> 2), then ONE lane transpose of the result
-//     (ds_bpermute, source lane 4 j + g) into the MFMA operand layout;
+//     64 contiguous bytes, 16 look-ups per load -- one row half at a time (items 0 and 3), by LDS-DMA into a 6 KiB
+//     staging area of the wave; lane (j, g) reads piece 4 j + g back (the transpose is the read address) and does
+//     the first-layer arithmetic in the MFMA operand layout;
 //   * the epilogue of output tile `to` (relu / output dot) written into stage to + 1 behind its second item, where
 //     it fills MFMA shadows instead of standing between two stages;
 //   * the layer loop body twice, with `last` a compile-time constant: no branch inside a layer's sixteen stages.
@@ -365,10 +376,9 @@ __global__ __launch_bounds__(256) void k_tail16r(TailArgs a, const unsigned* __r
   float* s_bias = (float*)(s_ring + R * SPLIT_STAGE_BYTES);
   for (int l = 0; l < n_hidden; ++l) s_bias[l * Hp + threadIdx.x] = a.pp.bh[l * Hp + threadIdx.x];
   s_bias[n_hidden * Hp + threadIdx.x] = a.pp.woutp[threadIdx.x];
-  const unsigned bias0 = (unsigned)(size_t)s_bias + 16 * g;      // + 1024 l + 64 to: units 16 to + 4 g .. + 3
 
   // rows in the MFMA operand layout (lane (j, g): row j of a half): the output side
-  struct Desc { float lbase, hjx; int row, valid; };
+  struct Desc { float lbase, hjx, coef; int row, valid; };
   auto describe = [&](int tile, int half) {
     Desc d;
     d.row = tile * 128 + wave * 32 + 16 * half + j;
@@ -376,53 +386,56 @@ __global__ __launch_bounds__(256) void k_tail16r(TailArgs a, const unsigned* __r
     const int2 ri = a.rowinfo[d.valid ? d.row : n_rows - 1];   // {chain, +-(bond+1) or 0}
     const int bs = ri.y;
     const int bond = (bs > 0 ? bs : -bs) - (bs != 0 ? 1 : 0);
+    d.coef = bs > 0 ? -2.f : (bs < 0 ? 2.f : 0.f);
     d.lbase = RATIO ? a.logit_base[ri.x] : 0.f;
     d.hjx = RATIO ? a.half_jx[bond] : 0.f;
     return d;
   };
   // rows in the LOAD layout (lane L: row L >> 2 of a half, 16-byte piece L & 3 of a unit tile): the gather side
-  struct Src { const float* zb; const float* wa; const float* wb; float coef; };
+  struct Src { const float* zb; const float* wa; const float* wb; };
   auto source = [&](int tile, int half) {
     Src d;
     const int row = tile * 128 + wave * 32 + 16 * half + (lane >> 2);
     const int2 ri = a.rowinfo[row < n_rows ? row : n_rows - 1];
     const int bs = ri.y;
     const int bond = (bs > 0 ? bs : -bs) - (bs != 0 ? 1 : 0);
-    d.coef = bs > 0 ? -2.f : (bs < 0 ? 2.f : 0.f);
     const int2 ab = a.bonds[bond];
     d.wa = a.pp.w1p + (long long)ab.x * Hp + 4 * (lane & 3);
     d.wb = a.pp.w1p + (long long)ab.y * Hp + 4 * (lane & 3);
     d.zb = a.z1 + (long long)ri.x * Hp + 4 * (lane & 3);
     return d;
   };
-  const int tsrc = 4 * (4 * j + g);            // ds_bpermute byte index: lane (j, g) takes the value of lane 4 j + g
-  auto transpose = [&](const f32x4& v) {
-    f32x4 r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(tsrc, __float_as_int(v[e])));
-    return r;
-  };
-  auto first_layer = [&](const Src& d, const f32x4& z, const f32x4& x, const f32x4& y) {
+  // this wave's gather staging: [2 halves][z, x, y][1 KiB], behind the bias image; lane (j, g) reads piece 4 j + g
+  char* s_stage = s_ring + R * SPLIT_STAGE_BYTES + (n_hidden + 1) * 1024 + wave * 6144;
+  const unsigned stage_lds = (unsigned)(size_t)s_stage;
+  const f32x4* s_mine = (const f32x4*)s_stage + (4 * j + g);
+  auto first_layer = [&](float coef, const f32x4& z, const f32x4& x, const f32x4& y) {
     f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = vmc_act<VMC_ACT_RELU_>(fmaf(d.coef, x[e] - y[e], z[e]));
+    for (int e = 0; e < 4; ++e) v[e] = vmc_act<VMC_ACT_RELU_>(fmaf(coef, x[e] - y[e], z[e]));
     return v;
   };
-
   Desc cur[2];
   Src nsrc[2];
+  float ncoef[2];
   u32x4 Xh[2][KT], Xm[2][KT], Xl[2][KT];         // B operands of the current layer: [half][k-step] x (hi, mid, lo)
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
     cur[hf] = describe(tile, hf);
-    const Src s0 = source(tile, hf);
+    // (the first row tile of a workgroup: ordinary loads in the operand layout, once)
+    const int2 ri = a.rowinfo[cur[hf].valid ? cur[hf].row : n_rows - 1];
+    const int bs = ri.y;
+    const int2 ab = a.bonds[(bs > 0 ? bs : -bs) - (bs != 0 ? 1 : 0)];
+    const float* zb = a.z1 + (long long)ri.x * Hp + 4 * g;
+    const float* wa = a.pp.w1p + (long long)ab.x * Hp + 4 * g;
+    const float* wb = a.pp.w1p + (long long)ab.y * Hp + 4 * g;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       f32x4 v[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int off = 16 * (2 * kt + u);
-        v[u] = transpose(first_layer(s0, *(const f32x4*)(s0.zb + off), *(const f32x4*)(s0.wa + off), *(const f32x4*)(s0.wb + off)));
+        v[u] = first_layer(cur[hf].coef, *(const f32x4*)(zb + off), *(const f32x4*)(wa + off), *(const f32x4*)(wb + off));
       }
       split8(v[0], v[1], Xh[hf][kt], Xm[hf][kt], Xl[hf][kt]);
     }
@@ -434,20 +447,22 @@ __global__ __launch_bounds__(256) void k_tail16r(TailArgs a, const unsigned* __r
   // certifies st+1
   asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   u32x4 wh[2], wm[2], wl[2];                     // fragments of the item being multiplied / the one behind it
   wh[1] = wm[1] = wl[1] = u32x4{0, 0, 0, 0};
   asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048"
                : "=&v"(wh[0]), "=&v"(wm[0]), "=&v"(wl[0]) : "v"(ring0));
   bool first_stage = true;
-  f32x4 bias;                                    // of the stage about to be multiplied (layer 0, output tile 0)
-  asm volatile("ds_read_b128 %[b], %[a]\n\ts_waitcnt lgkmcnt(0)" : [b] "=&v"(bias), "+v"(wh[0]), "+v"(wm[0]), "+v"(wl[0]) : [a] "v"(bias0));
+  f32x4 bias = ((const f32x4*)s_bias)[g];       // of the stage about to be multiplied (layer 0, output tile 0)
 
   float part[2];
   f32x4 out[2][NT];
   // the sixteen stages of one layer; `last` is a compile-time constant (bool_c)
   auto layer = [&](auto last_c, const int l) __attribute__((always_inline)) {
     constexpr bool last = decltype(last_c)::value;
-    const unsigned wo_base = bias0 + n_hidden * 1024, bias_l = bias0 + l * 1024, bias_nl = last ? bias0 : bias_l + 1024;
+    const f32x4* s_wo = (const f32x4*)(s_bias + n_hidden * Hp) + g;        // + 4 to: units 16 to + 4 g .. + 3
+    const f32x4* s_bl = (const f32x4*)(s_bias + l * Hp) + g;
+    const f32x4* s_bnl = (const f32x4*)(s_bias + (last ? 0 : l + 1) * Hp) + g;
     f32x4 pacc0, pacc1, pwo;                     // accumulators and w_out of the previous output tile (deferred epilogue)
     f32x4 gv[2];                                 // first-layer activations of unit tile `to` of the next row tile
     auto epilogue = [&](int t, const f32x4& acc0, const f32x4& acc1, const f32x4& wo) {
@@ -472,37 +487,33 @@ __global__ __launch_bounds__(256) void k_tail16r(TailArgs a, const unsigned* __r
       first_stage = false;
       // w_out of this tile (epilogue) and the bias of the NEXT stage (its top), from LDS; the lgkmcnt(0) of the
       // next LDS_STEP covers them, the empty asm behind it carries the values past it
-      // (one base register each and immediate offsets: as computed addresses the compiler kept all thirty-two of them
-      // live through the layer and spilled them -- a scratch load with a vmcnt(0) at the top of every stage)
-      f32x4 wo, bias_next;
-      if (to + 1 < NT)
-        asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4+64"
-                     : "=&v"(wo), "=&v"(bias_next) : "v"(wo_base), "v"(bias_l), "n"(64 * to));
-      else
-        asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3"
-                     : "=&v"(wo), "=&v"(bias_next) : "v"(wo_base), "v"(bias_nl), "n"(64 * to));
+      // w_out of this tile (epilogue) and the bias of the NEXT stage (its top): ordinary loads of the LDS image that
+      // was written once before the first barrier (nothing to order them against; the compiler counts their waits)
+      const f32x4 wo = s_wo[4 * to];
+      const f32x4 bias_next = to + 1 < NT ? s_bl[4 * (to + 1)] : s_bnl[0];
       const unsigned sbase = ring0 + slot * SPLIT_STAGE_BYTES;
       const int nslot = slot + 1 == R ? 0 : slot + 1;
       const unsigned nbase = ring0 + nslot * SPLIT_STAGE_BYTES;
       f32x4 acc0 = bias, acc1 = bias;
-      f32x4 gz, gx, gy;
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         if (VMC_SPLIT_ABLATE & 32) asm volatile("" : "+v"(wh[0]), "+v"(wm[0]), "+v"(wl[0]), "+v"(wh[1]), "+v"(wm[1]), "+v"(wl[1]));
         else if (kt + 1 < KT) LDS_STEP(kt & 1, (kt + 1) & 1, sbase, (kt + 1) * 3072);
         else LDS_STEP(kt & 1, (kt + 1) & 1, nbase, 0);
-        if (kt == 0) asm volatile("" : "+v"(wo), "+v"(bias_next));
         // vector-memory operations of this item, in this order: the gather of one row half (last layer: half 0 in item
         // 0, consumed in item 3; half 1 in item 3 into the same registers, consumed in item 6), then one DMA piece of
         // stage st+3 (items 0 .. 5)
         if (last && (kt == 3 || kt == 6) && !(VMC_SPLIT_ABLATE & 2)) {
-          // behind the three loads of a row half this wave issued three DMA pieces: those may stay in flight
-          asm volatile("s_waitcnt vmcnt(3)" : "+v"(gz), "+v"(gx), "+v"(gy));
-          gv[kt == 3 ? 0 : 1] = transpose(first_layer(nsrc[kt == 3 ? 0 : 1], gz, gx, gy));
+          // behind the three pieces of a row half this wave issued three ring pieces: those may stay in flight.
+          // The staging area is this wave's own: no barrier, its vmcnt is the whole hand-over.
+          const int hf = kt == 3 ? 0 : 1;
+          asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+          gv[hf] = first_layer(ncoef[hf], s_mine[hf * 192], s_mine[hf * 192 + 64], s_mine[hf * 192 + 128]);
+          asm volatile("" ::: "memory");           // (the reads stay in front of the next DMA into this area)
         }
         if (last && (kt == 0 || kt == 3) && !(VMC_SPLIT_ABLATE & 2)) {
           const int hf = kt == 0 ? 0 : 1;
-          GATHER3(gz, gx, gy, nsrc[hf].zb, nsrc[hf].wa, nsrc[hf].wb, 64 * to);
+          GATHER_DMA3(nsrc[hf].zb, nsrc[hf].wa, nsrc[hf].wb, stage_lds + hf * 3072, 64 * to);
         }
         if (kt < 6 && !(VMC_SPLIT_ABLATE & 4)) DMA_PIECE(kt);
         const u32x4 h = wh[kt & 1], m = wm[kt & 1], lo = wl[kt & 1];
@@ -534,7 +545,7 @@ __global__ __launch_bounds__(256) void k_tail16r(TailArgs a, const unsigned* __r
     const int nt_safe = has_next ? next_tile : tile;
     Desc nxt[2];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) { nxt[hf] = describe(nt_safe, hf); nsrc[hf] = source(nt_safe, hf); }
+    for (int hf = 0; hf < 2; ++hf) { nxt[hf] = describe(nt_safe, hf); nsrc[hf] = source(nt_safe, hf); ncoef[hf] = nxt[hf].coef; }
     part[0] = part[1] = 0.f;
     for (int l = 0; l + 1 < n_hidden; ++l) {
       layer(bool_c<false>(), l);
@@ -584,7 +595,7 @@ hipError_t launch_tail16_split(hipStream_t s, const TailArgs& a, const unsigned*
   const dim3 grid(tiles < persistent ? tiles : persistent), block(256);
   hipError_t e;
   if (split_ring_on() && a.n_hidden > 0) {       // round 5: the weight stream through a per-CU LDS ring (k_tail16r)
-    const size_t rlds = (size_t)SPLIT_RING * SPLIT_STAGE_BYTES + (size_t)(a.n_hidden + 1) * 1024;   // ring + bias / w_out image
+    const size_t rlds = (size_t)SPLIT_RING * SPLIT_STAGE_BYTES + (size_t)(a.n_hidden + 1) * 1024 + 4 * 6144;   // ring + bias / w_out image + gather staging
     if (ratio_mode) {
       e = hipFuncSetAttribute((const void*)k_tail16r<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
       if (e != hipSuccess) return e;
