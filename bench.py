@@ -58,6 +58,9 @@ WORKLOADS = {
     # BF16 matrix cores -- fp32 operands as three bf16 terms, six products, fp32 accumulate
     # (CGS_VMC_SPLIT_BF16=1, cgs_vmc_amd/csrc/tail_split.hip); sampler and gradient path native fp32
     'heisenberg10x10_fc3x256_b4096_split3xbf16': (10, 10, False, 3, 256, 4096),
+    # EXPERIMENT, round 5: the same with the SAMPLER's two H x H layers on the BF16 matrix cores too
+    # (CGS_VMC_SPLIT_BF16=2, k_sweep16s in cgs_vmc_amd/csrc/sweep16.hpp / sweep_split.hip); gradient path native fp32
+    'heisenberg10x10_fc3x256_b4096_split3xbf16_sampler': (10, 10, False, 3, 256, 4096),
     'heisenberg6x6_fc3x128_b1024': (6, 6, False, 3, 128, 1024),
     'heisenberg16x16j1j2_fc6x256_b1024': (16, 16, True, 6, 256, 1024),
     'heisenberg10x10_fc3x512_b4096': (10, 10, False, 3, 512, 4096),   # 257 .. 512 units: the fused kernels padded to 512
@@ -666,9 +669,10 @@ def main():
   dev = parallel.local_rank()
   torch.cuda.set_device(dev)
 
-  split = args.workload.endswith('_split3xbf16')
+  split_sweep = args.workload.endswith('_split3xbf16_sampler')
+  split = args.workload.endswith('_split3xbf16') or split_sweep
   if split:
-    os.environ['CGS_VMC_SPLIT_BF16'] = '1'
+    os.environ['CGS_VMC_SPLIT_BF16'] = '2' if split_sweep else '1'
   lx, ly, nnn, L, h, b = WORKLOADS[args.workload][:6]
   ansatz, ksz = (WORKLOADS[args.workload][6:] + ('fully_connected', 0))[:2]
   conv = ansatz in ('conv_2d', 'res_net_2d')
@@ -686,8 +690,8 @@ def main():
   eng.set_params(theta)
   eng.set_configs(cfg)
   eng.set_bonds(bonds, jx, jz)
-  if split and eng.kernel_path() != 4:
-    raise SystemExit('bench.py: the split workload did not get the split kernel')
+  if split and eng.kernel_path() != (5 if split_sweep else 4):
+    raise SystemExit('bench.py: the split workload did not get the split kernels')
   proof = prove_collectives(eng, world, rank, dev) if world > 1 else None
   lib_proof, lib_stuck = prove_library_transport(eng, world, rank) if world > 1 else ({}, False)
   if world > 1 and lib_stuck:
@@ -848,7 +852,8 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 via 3xbf16 split, fp32 accumulate (E_loc row kernel only; sampler and gradients native f32)' if split else 'f32',
+        'dtype': ('f32 via 3xbf16 split, fp32 accumulate (E_loc row kernel and sampler; gradients native f32)' if split_sweep else
+                  'f32 via 3xbf16 split, fp32 accumulate (E_loc row kernel only; sampler and gradients native f32)' if split else 'f32'),
         'data': 'synthetic',
         'config': {'workload': args.workload, 'lattice': '{}x{} torus'.format(lx, ly),
                    'n_sites': n, 'n_bonds': nb, 'ansatz': ('{} {} x {} filters, kernel {}, relu/exp'.format(ansatz, L, h, ksz) if conv
@@ -893,8 +898,12 @@ def main():
           k_sweep: {'ms_avg': ts * 1e3, 'flops_executed': exec_sweep, 'flops_nominal': flops_sweep},
           k_eloc: {'ms_avg': te * 1e3, 'flops_executed': exec_eloc, 'flops_nominal': flops_eloc},
       }
+      if split_sweep:
+        per_kernel[k_sweep]['kernel'] = 'k_sweep16s (3 x bf16 split)'
+        per_kernel[k_sweep]['flops_executed_bf16'] = 6 * exec_sweep
+        per_kernel[k_sweep]['f32_equivalent_tflops'] = exec_sweep / ts / 1e12
       if split:       # six bf16 products per fp32 product, priced against the BF16 peak
-        per_kernel[k_eloc]['kernel'] = 'k_tail16s (3 x bf16 split)'
+        per_kernel[k_eloc]['kernel'] = 'k_tail16r (3 x bf16 split, weights through an LDS-DMA ring)'
         per_kernel[k_eloc]['flops_executed_bf16'] = 6 * exec_eloc
         per_kernel[k_eloc]['f32_equivalent_tflops'] = exec_eloc / te / 1e12
       for v in per_kernel.values():
@@ -912,11 +921,11 @@ def main():
       # tools/collect_profiles.sh); null when no matching profile is present
       traffic = None
       pmc = None
-      suffix = {'heisenberg10x10_fc3x256_b4096': '', 'heisenberg10x10_fc3x256_b4096_split3xbf16': '_split',
+      suffix = {'heisenberg10x10_fc3x256_b4096': '', 'heisenberg10x10_fc3x256_b4096_split3xbf16': '_split', 'heisenberg10x10_fc3x256_b4096_split3xbf16_sampler': '_splits',
                 'heisenberg16x16j1j2_fc6x256_b1024': '_config5',
                 'heisenberg10x10_conv5x16k5_b4096': '_conv', 'heisenberg16x16j1j2_conv5x16k5_b1024': '_conv16',
                 'heisenberg10x10_fc3x512_b4096': '_fc3x512', 'heisenberg10x10_conv5x32k5_b4096': '_conv32'}.get(args.workload)
-      for rnd in ('r4', 'r3', 'r2'):              # the newest committed profile of this workload
+      for rnd in ('r5', 'r4', 'r3', 'r2'):        # the newest committed profile of this workload
         tag = None if suffix is None else rnd + suffix
         tpath = os.path.join(ROOT, 'profiles', '{}_traffic.json'.format(tag))
         if tag and os.path.exists(tpath):
@@ -927,7 +936,7 @@ def main():
           prof = json.load(open(tpath))
           collected_at = prof.pop('_collected_at_source_hash', None)
           for name, rec in prof.items():
-            if name.startswith('k_tail16s' if (split and key == k_eloc) else key.split('(')[0]) and rec.get('hbm_read_bytes') is not None:
+            if name.startswith(('k_tail16r', 'k_tail16s') if (split and key == k_eloc) else (('k_sweep16s',) if (split_sweep and key == k_sweep) else (key.split('(')[0],))) and rec.get('hbm_read_bytes') is not None:
               traffic = rec['hbm_read_bytes'] + (rec.get('hbm_write_bytes') or 0)
               pmc = {k: rec[k] for k in ('mfma_util', 'clock_ghz', 'median_us') if k in rec}
               pmc['source'] = 'profiles/{}_traffic.json'.format(tag)

@@ -89,6 +89,17 @@ __device__ __forceinline__ float vmc_logcosh(float z) {
 // run-time only: the RBM's last-stage log cosh as an "activation" of the general (wide.hip) path
 #define VMC_ACT_LOGCOSH_ 100
 
+// The relu below is an inline-asm v_max_f32, and the compiler's hazard recogniser does not look inside an asm
+// statement: where it reads an MFMA result directly -- no compiler-visible instruction (a copy out of an AGPR, an
+// add) in between -- no wait states are inserted and it sees the accumulator before the last MFMAs have written it
+// (round 5: the split sampler lost the last k-step of a layer in 4 .. 8 of 16 output rows that way; the fp32 kernels
+// happen to have such an instruction in between).  vmc_mfma_settle stands between the last MFMA of a chain and
+// such a reader: the accumulators pass through it (so it follows the MFMAs and precedes the readers) and it holds
+// the 16 wait states itself -- issued while the last MFMA still occupies the matrix pipe.
+__device__ __forceinline__ void vmc_mfma_settle(f32x4& a, f32x4& b) {
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b));
+}
+
 template <int ACT>
 __device__ __forceinline__ float vmc_act(float z) {
   if (ACT == VMC_ACT_RELU_) {
@@ -216,6 +227,7 @@ struct SweepArgs {
   // the sampler has the chains in LDS when it ends, the launch that would count them costs 5 us
   const int2* bonds; const float* quarter_jz; int n_bonds;
   int* cnt_out; float* diag_out;
+  const unsigned* p16s;     // split sampler only (CGS_VMC_SPLIT_BF16=2): the three-term weight image of tail_split.hip
 };
 
 // launchers (one per TU)
@@ -250,6 +262,9 @@ hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, 
                          float* out);
 hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n);
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp);
+// EXPERIMENT: the sampler with its H x H layers as 3 x bf16 split products (sweep_split.hip); false: shape not covered
+bool sweep16_split_supported(int N, int Hp, int n_hidden);
+hipError_t launch_sweep16_split(hipStream_t s, const SweepArgs& a);
 // the LDS-operand row kernel for 384 / 512 padded units (tail_lds.hpp; one instantiation per hidden
 // activation in act_tail.hip): fully_connected and rbm with at least one H x H layer
 bool tail_lds_supported(int Hp, int n_hidden);

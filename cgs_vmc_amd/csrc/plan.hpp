@@ -220,9 +220,11 @@ inline long long plan_conv_bias_floats(const ConvGeom& g) { return (long long)g.
 // ------------------------------------------------------------------------------- fused dense kernels
 // LDS of the sampler k_sweep16 (16 chains per workgroup): spins, one or two z1 images, two operand
 // buffers, chain scalars, biases, [W1 itself when w1l], [the Philox hand-over area]
-inline size_t plan_sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool rbm, int uh_floats = 0) {
+// split_operands: the 3 x bf16 split sampler's operand buffers ([8 k-steps][3 terms][64][4] dwords each)
+inline size_t plan_sweep_lds_bytes(int N, int Hp, int n_hidden, bool w1l, bool rbm, int uh_floats = 0, bool split_operands = false) {
   const int Nst = (N + 3) & ~3, NT = Hp / 16, ZS = Hp + 4;
-  return sizeof(float) * ((size_t)16 * Nst + (size_t)(w1l ? 1 : 2) * 16 * ZS + (size_t)2 * NT * 256 + 16 +
+  const size_t xb = split_operands ? (size_t)8 * 3 * 256 : (size_t)NT * 256;
+  return sizeof(float) * ((size_t)16 * Nst + (size_t)(w1l ? 1 : 2) * 16 * ZS + (size_t)2 * xb + 16 +
                           16 + 7 * 16 + Hp + (size_t)n_hidden * Hp + (rbm ? (w1l ? 0 : Nst) + 16 : 0) +
                           (w1l ? (size_t)N * (Hp + 4) : 0) + uh_floats);
 }

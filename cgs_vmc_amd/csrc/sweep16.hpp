@@ -1,6 +1,6 @@
 // Persistent Metropolis exchange sampler k_sweep16 (graph_builders.py:38-89) and its launcher
-// template.  Included by sweep_fc.hip and sweep_rbm.hip, which instantiate the fully-connected
-// and the RBM epilogue separately (the instantiations dominate the build time).
+// template.  Included by act_sweep.hip (one object per hidden activation and output epilogue: the
+// instantiations dominate the build time) and by sweep_split.hip (the 3 x bf16 split experiment).
 #pragma once
 #include "common.hpp"
 #include <cstdlib>
@@ -33,6 +33,41 @@
 #endif
 #ifndef SWEEP_PF
 #define SWEEP_PF 2    // stages of the weight prefetch ring; (16 - SWEEP_RT) % SWEEP_PF == 0
+#endif
+
+
+// ---- 3 x bf16 split pieces shared with tail_split.hip (EXPERIMENT, CGS_VMC_SPLIT_BF16): see there for the scheme
+#ifndef VMC_SPLIT_HELPERS
+#define VMC_SPLIT_HELPERS
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 sw_bf16x8;
+typedef unsigned sw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned sw_cvt_pk_bf16(float a, float b) {   // lo 16 bits = bf16(a), hi = bf16(b); round to nearest even
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ void sw_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = sw_cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = sw_cvt_pk_bf16(r0, r1);
+  const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+  l = sw_cvt_pk_bf16(s0, s1);
+}
+// the eight k slots of a lane for a 32-deep k-step: its registers of unit tiles 2 kt and 2 kt + 1
+__device__ __forceinline__ void sw_split8(const f32x4& a, const f32x4& b, sw_u32x4& H, sw_u32x4& M, sw_u32x4& L) {
+  unsigned h[4], m[4], l[4];
+  sw_split2(a[0], a[1], h[0], m[0], l[0]);
+  sw_split2(a[2], a[3], h[1], m[1], l[1]);
+  sw_split2(b[0], b[1], h[2], m[2], l[2]);
+  sw_split2(b[2], b[3], h[3], m[3], l[3]);
+  H = sw_u32x4{h[0], h[1], h[2], h[3]};
+  M = sw_u32x4{m[0], m[1], m[2], m[3]};
+  L = sw_u32x4{l[0], l[1], l[2], l[3]};
+}
+__device__ __forceinline__ f32x4 sw_mfma(const sw_u32x4& a, const sw_u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sw_bf16x8, a), __builtin_bit_cast(sw_bf16x8, b), c, 0, 0, 0);
+}
+struct SwFrag { sw_u32x4 h, m, l; };
 #endif
 
 // --------------------------------------------------------------------------------- sweep16
@@ -94,11 +129,20 @@ __device__ __forceinline__ unsigned long long vmc_stamp() {
 // registers, i.e. two workgroups per CU).
 // UPRE: Philox site blocks per lane drawn one step ahead (2: N <= 128 sites, 4: N <= 256).
 // ACT: hidden activation (layers.NONLINEARITIES id); relu is the tuned path.
-template <int NT, int NW, int RTP, bool STAMP, bool W1L, bool FAST, int UPRE, bool RBM, int ACT>
+// SW (EXPERIMENT, round 5, CGS_VMC_SPLIT_BF16=2): the H x H layers on the BF16 matrix cores with every f32 operand
+// as three bf16 terms and six products accumulated in fp32 (tail_split.hip has the scheme and the slot order of the
+// weight image p16s).  256 units, 8 waves, fully_connected, relu, W1 in L2 only.  Wave w owns unit tiles 2 w and
+// 2 w + 1 -- exactly the two tiles of the 32-deep k-step w of the NEXT layer -- so it splits its own activations
+// once in its epilogue and leaves them in LDS as that k-step's B operand (hi, mid, lo); the operand buffers are
+// [8 k-steps][3 terms][64 lanes][16 bytes] = 24 KiB each.  RTP / 2 k-steps of layer 0 stay in registers, the rest
+// streams L2 -> registers through a two-item ring (an item = the six 1 KiB fragments of one k-step and both tiles).
+template <int NT, int NW, int RTP, bool STAMP, bool W1L, bool FAST, int UPRE, bool RBM, int ACT, bool SW = false>
 __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   static_assert(NT % NW == 0, "output tiles must divide over the waves");
+  static_assert(!SW || (NT == 16 && NW == 8 && !RBM && !W1L && ACT == VMC_ACT_RELU_ && !STAMP), "split sampler: 256 relu units, 8 waves, W1 in L2");
   constexpr int NTH = NW * 64;
   constexpr int Hp = NT * 16, TO = NT / NW, ZS = Hp + 4, W1S = Hp + 4, PF = SWEEP_PF;
+  constexpr int XB = SW ? 8 * 3 * 256 : NT * 256;   // floats per operand buffer
   constexpr int RT = NT < RTP ? NT : RTP;   // k-tiles of the first H x H layer kept in registers
   static_assert((NT - RT) % PF == 0, "the streamed k-tiles of layer 0 must fill whole ring turns");
   extern __shared__ float smem[];
@@ -106,7 +150,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   float* s_spin = smem;                       // [16][Nst]
   float* s_z1 = s_spin + 16 * Nst;            // [W1L ? 1 : 2][16][ZS]
   float* s_x = s_z1 + (W1L ? 1 : 2) * 16 * ZS;  // [2][NT][64][4]
-  float* s_logit = s_x + 2 * NT * 256;        // [16]
+  float* s_logit = s_x + 2 * XB;              // [16]
   float* s_u = s_logit + 16;                  // [16]
   int* s_iup = (int*)(s_u + 16);              // [16]
   int* s_idn = s_iup + 16;                    // [16]
@@ -131,7 +175,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   // [4 waves][16 chains] partials of the output dot live in the operand buffer the LAST layer does
   // not read (free from the barrier at that layer's top until the next step's build, which
   // comes after every reader of s_part has passed barrier0)
-  float* s_part = s_x + (n_hidden == 0 ? 1 : (n_hidden & 1)) * NT * 256;
+  float* s_part = s_x + (n_hidden == 0 ? 1 : (n_hidden & 1)) * XB;
 
   for (int i = tid; i < 16 * Nst; i += NTH) {
     const int c = i / Nst, n = i % Nst, gc = chain0 + c;
@@ -166,7 +210,25 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
 
   // register-resident fragments of the first H x H layer
   f32x4 wres[RT * TO > 0 ? RT * TO : 1];
-  if (n_hidden > 0) {
+  constexpr int RES = SW ? RT / 2 : 0;           // resident 32-deep k-steps of layer 0 (split sampler)
+  SwFrag wres_s[RES > 0 ? RES : 1][TO];
+  typedef const __attribute__((address_space(1))) sw_u32x4* sw_gp;
+  // (the image base is re-made opaque once per layer pass: with a visible base the compiler hoists a 64-bit scalar
+  // address per (layer, k-step, tile) out of the step loop and spills them)
+  const unsigned* sw_base = a.p16s + (long long)wave * TO * 8 * 3 * 256;
+  auto sw_frag = [&](int l, int kt, int to) {    // p16s: [layer][unit tile 16][k-step 8][term 3][64 lanes][4 dwords]
+    sw_gp q = (sw_gp)(sw_base + (((long long)l * NT + to) * 8 + kt) * 3 * 256) + lane;
+    SwFrag f;
+    f.h = q[0]; f.m = q[64]; f.l = q[128];
+    return f;
+  };
+  if (SW && n_hidden > 0) {
+#pragma unroll
+    for (int kt = 0; kt < RES; ++kt)
+#pragma unroll
+      for (int to = 0; to < TO; ++to) wres_s[kt][to] = sw_frag(0, kt, to);
+  }
+  if (!SW && n_hidden > 0) {
     const f32x4* __restrict__ wp0 = (const f32x4*)pp.p16 + wave * TO * NT * 64;
 #pragma unroll
     for (int ti = 0; ti < RT; ++ti)
@@ -305,10 +367,10 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   // chain state, which the launcher grants when the lattice leaves room (a.uh_lds; those shapes
   // do not have W1 in LDS).
   constexpr int UH_FLOATS = 4 * (UPRE + 1) * 256;
-  constexpr bool UH_IN_X = NW * 16 + UH_FLOATS <= NT * 256;
+  constexpr bool UH_IN_X = NW * 16 + UH_FLOATS <= XB;
   constexpr bool HANDOFF_T = SWEEP_HANDOFF && FAST && NW == 8 && RT > 0 && (UH_IN_X || !W1L);
   const bool handoff = HANDOFF_T && n_hidden > 0 && (UH_IN_X || a.uh_lds != 0);
-  float* s_uh = UH_IN_X ? s_x + NT * 256 + NW * 16 : s_w1;    // [4 waves][UPRE + 1][64 lanes][4]
+  float* s_uh = UH_IN_X ? s_x + XB + NW * 16 : s_w1;    // [4 waves][UPRE + 1][64 lanes][4]
   // validity of this lane's 4*UPRE prefetched sites (bit k <-> site 4*(j+16*(k/4)) + k%4)
   unsigned pre_valid = 0;
 #pragma unroll
@@ -477,6 +539,15 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       for (int e = 0; e < 4; ++e) own[to][e] = vmc_logcosh(z[e]);
     }
   };
+  // split sampler: this wave's two unit tiles = k-step `wave` of the next layer's B operand, as three bf16 terms
+  auto sw_publish = [&](float* buf) {
+    if constexpr (SW) {
+      sw_u32x4 H, M, L;
+      sw_split8(own[0], own[TO - 1], H, M, L);
+      sw_u32x4* dst = (sw_u32x4*)buf + (wave * 3) * 64 + lane;
+      dst[0] = H; dst[64] = M; dst[128] = L;
+    }
+  };
   f32x4 zreg[TO];    // committed z1 of this thread's columns (W1L build)
   bool z_valid = false;
   f32x4 dprev[TO];   // W1[i_dn] - W1[i_up] of the previous proposal (W1L build)
@@ -544,8 +615,9 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
         *(f32x4*)(zn + col) = z;
       }
       finish_own(to, z, n_hidden == 0);
-      *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
+      if (!SW) *(f32x4*)(s_x + (t * 64 + lane) * 4) = own[to];
     }
+    if constexpr (SW) sw_publish(s_x);
     if (save_acts) save_own(0);
   };
 
@@ -575,10 +647,20 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
   // layer 1's first k-tile
   const int ring_l0 = RT < NT ? 0 : min(1, l_last);
   constexpr int ring_t0 = RT < NT ? RT : 0;
-  if (n_hidden > 0) {
+  if (!SW && n_hidden > 0) {
 #pragma unroll
     for (int st = 0; st < PF - 1; ++st) issue(ring_l0, ring_t0 + st, st);
   }
+  // split sampler: two-item ring; an item = (layer, k-step) x both tiles x three terms.  Stream order per step:
+  // layer 0 k-steps RES .. 7, then every k-step of the later layers; the last item of a step fetches the first of
+  // the next (the weights do not change during a launch).  Both counts are even, so an item's slot is kt & 1.
+  static_assert(!SW || ((8 - RES) % 2 == 0 && RES < 8), "ring slots continue across layers only for an even item count");
+  SwFrag ring_s[2][TO];
+  auto sw_issue = [&](int l, int kt, int slot) {
+#pragma unroll
+    for (int to = 0; to < TO; ++to) ring_s[slot][to] = sw_frag(l, kt, to);
+  };
+  if (SW && n_hidden > 0) sw_issue(0, RES, RES & 1);
   auto forward = [&](unsigned long long next_step) {
     // Every issue below is unconditional so that the compiler can count vmcnt exactly; a load
     // issued under a runtime condition makes it wait for ALL outstanding loads at the next use.
@@ -677,6 +759,52 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       cur ^= 1;
       SWEEP_STAMP(FS > 0 ? 11 : 14)
     };
+    // split sampler: one layer = eight 32-deep k-steps; B operands (hi, mid, lo) from LDS one k-step ahead
+    auto layer_s = [&](int l, auto first_c) {
+      constexpr bool FIRSTL = decltype(first_c)::value;
+      asm volatile("" : "+s"(sw_base));
+      __syncthreads();
+      const sw_u32x4* xin = (const sw_u32x4*)(s_x + cur * XB) + lane;       // [k-step][term][64 lanes]
+      f32x4 acc[TO];
+#pragma unroll
+      for (int to = 0; to < TO; ++to)
+        acc[to] = *(const f32x4*)(s_bias + l * Hp + 16 * (wave * TO + to) + 4 * g);
+      sw_u32x4 xb[2][3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) xb[0][t] = xin[t * 64];
+#pragma unroll
+      for (int kt = 0; kt < 8; ++kt) {
+        const bool resident = FIRSTL && kt < RES;
+        if (!resident) {          // fetch the item behind this one (all issues unconditional: exact vmcnt)
+          if (kt + 1 < 8) sw_issue(l, kt + 1, (kt + 1) & 1);
+          else if (l < l_last) sw_issue(l + 1, 0, 0);
+          else sw_issue(0, RES, RES & 1);
+        }
+        if (kt + 1 < 8) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t) xb[(kt + 1) & 1][t] = xin[((kt + 1) * 3 + t) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetches ahead of this k-step's MFMAs
+        const sw_u32x4 &xh = xb[kt & 1][0], &xm = xb[kt & 1][1], &xl = xb[kt & 1][2];
+        // smallest terms first (the order of k_tail16s / k_tail16r)
+#define SW_PRODUCT(WT, XT)                                                                                   \
+        _Pragma("unroll") for (int to = 0; to < TO; ++to)                                                     \
+          acc[to] = sw_mfma(resident ? wres_s[kt < RES ? kt : 0][to].WT : ring_s[kt & 1][to].WT, XT, acc[to]);
+        SW_PRODUCT(l, xh) SW_PRODUCT(h, xl) SW_PRODUCT(m, xm) SW_PRODUCT(m, xh) SW_PRODUCT(h, xm) SW_PRODUCT(h, xh)
+#undef SW_PRODUCT
+      }
+      vmc_mfma_settle(acc[0], acc[TO - 1]);      // the relu reads the accumulators through inline asm (common.hpp)
+#pragma unroll
+      for (int to = 0; to < TO; ++to) finish_own(to, acc[to], l + 1 == n_hidden);
+      if (l + 1 < n_hidden) sw_publish(s_x + (cur ^ 1) * XB);
+      if (save_acts) save_own(l + 1);
+      cur ^= 1;
+    };
+    if constexpr (SW) {
+      layer_s(0, std::true_type{});
+      for (int l = 1; l < n_hidden; ++l) layer_s(l, std::false_type{});
+      return;
+    }
     if ((HANDOFF_T && handoff) || (SWEEP_SPLIT(UPRE) && W1L && RT > 0 && NW > 4 && wave >= 4)) layer(0, std::integral_constant<int, RT>{}, std::true_type{}, std::false_type{});
     else layer(0, std::integral_constant<int, RT>{}, std::true_type{}, std::true_type{});
     for (int l = 1; l < n_hidden; ++l) layer(l, std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{});
@@ -814,7 +942,8 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
     build(is_step);
     SWEEP_STAMP(2)
     const unsigned long long next_step = a.step0 + (unsigned long long)(it + 1);
-    const bool pre_here = use_pref && n_hidden > 0;
+    // (the split layers carry no Philox pieces: without the hand-over the draws follow the layers un-overlapped)
+    const bool pre_here = use_pref && n_hidden > 0 && !(SW && !(HANDOFF_T && handoff));
     if (n_hidden > 0) forward(next_step);
     if (use_pref && !pre_here && !(NW > 4 && wave >= 4)) draw_all(next_step);
     SWEEP_STAMP(3)
@@ -877,6 +1006,11 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
 template <int NT, int NW, int RTP, bool STAMP, bool W1L, bool FAST, int UPRE, bool RBM, int ACT>
 __global__ __launch_bounds__(NW * 64, NT == 16 ? (RTP == 0 ? SWEEP_OCC0 : 2) : 1) void k_sweep16(SweepArgs a) {
   sweep16_body<NT, NW, RTP, STAMP, W1L, FAST, UPRE, RBM, ACT>(a);
+}
+// the 3 x bf16 split sampler (instantiated by sweep_split.hip only)
+template <int RTP, bool FAST>
+__global__ __launch_bounds__(512, 2) void k_sweep16s(SweepArgs a) {
+  sweep16_body<16, 8, RTP, false, false, FAST, 2, false, VMC_ACT_RELU_, true>(a);
 }
 
 // (LDS bytes and the choice of variant: plan_sweep_lds_bytes / plan_sweep, plan.hpp)

@@ -535,7 +535,12 @@ __global__ __launch_bounds__(256) void k_tail16r(TailArgs a, const unsigned* __r
       if (last && !(VMC_SPLIT_ABLATE & 2)) { out[0][to] = gv[0]; out[1][to] = gv[1]; }
       else if (last) { out[0][to] = acc0; out[1][to] = acc1; }
       if (to + 1 < NT) { pacc0 = acc0; pacc1 = acc1; pwo = wo; }
-      else epilogue(to, acc0, acc1, wo);
+      else {
+#ifndef VMC_TAIL_NO_SETTLE
+        vmc_mfma_settle(acc0, acc1);             // (read right behind the last MFMA, through inline asm: common.hpp)
+#endif
+        epilogue(to, acc0, acc1, wo);
+      }
     }
   };
 

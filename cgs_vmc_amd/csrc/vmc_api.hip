@@ -64,7 +64,8 @@ struct vmc_ctx {
   bool wide_fast = false;
   // EXPERIMENT (CGS_VMC_SPLIT_BF16=1; fully_connected, relu, 193 .. 256 units, >= 1 H x H layer): the row
   // kernel computes its fp32 results on the bf16 matrix cores from three-term splits (tail_split.hip)
-  bool split = false;
+  bool split = false;             // CGS_VMC_SPLIT_BF16 >= 1: the row kernel on the BF16 matrix cores (3 x bf16 split, EXPERIMENT)
+  bool split_sweep = false;       // CGS_VMC_SPLIT_BF16 == 2: the sampler's H x H layers too (k_sweep16s)
   long long wrows = 0;     // rows of the two activation row buffers
   float *wbuf[2] = {nullptr, nullptr}, *wide_zc = nullptr, *wide_lnew = nullptr, *wide_u = nullptr, *wide_zero = nullptr;
   int *wide_iup = nullptr, *wide_idn = nullptr;
@@ -726,8 +727,10 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   c->P = dp.P;
   c->stream = (hipStream_t)d->stream;
   if (const char* e = getenv("CGS_VMC_SWEEP_W1L")) c->sweep_no_w1l = atoi(e) == 0 ? 1 : 0;
-  if (const char* e = getenv("CGS_VMC_SPLIT_BF16"))
-    c->split = atoi(e) == 1 && !conv && !wide && !rbm && c->Hp == 256 && c->n_hh >= 1 && c->hact == VMC_ACT_RELU_;
+  if (const char* e = getenv("CGS_VMC_SPLIT_BF16")) {
+    c->split = (atoi(e) == 1 || atoi(e) == 2) && !conv && !wide && !rbm && c->Hp == 256 && c->n_hh >= 1 && c->hact == VMC_ACT_RELU_;
+    c->split_sweep = c->split && atoi(e) == 2 && sweep16_split_supported(c->N, c->Hp, c->n_hh);
+  }
   if (const char* e = getenv("CGS_VMC_OVERLAP")) { c->overlap = !conv && !wide && atoi(e) != 0; c->overlap_full = atoi(e) == 2; }
   {
     hipDeviceProp_t prop;
@@ -1021,6 +1024,12 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
 //   overtake: the launch goes to sweep_stream and only waits for `dep` (an event on `stream`)
 // fc_layer_size > 256: one mc_step = proposals, candidate first layer, H x H GEMMs, output dot,
 // accept -- a handful of launches per step, chain state updated in place
+// the sampler launch of this ctx (the 3 x bf16 split sampler when it is switched on)
+static hipError_t launch_sampler(vmc_ctx* c, hipStream_t st, SweepArgs& a, int which) {
+  if (c->split_sweep) { a.p16s = c->ps[which].p16s; return launch_sweep16_split(st, a); }
+  return launch_sweep16(st, a, c->Hp);
+}
+
 static int run_sweep_wide(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int* dbg_up, int* dbg_dn,
                           float* dbg_u, unsigned long long step0, bool count_accepted) {
   ParamSet& p = c->ps[0];
@@ -1092,7 +1101,7 @@ static int refresh_cache_by_sampler(vmc_ctx* c, int which) {
   a.act = c->hact; a.oact = c->oact;
   a.cache_in_valid = 0;
   Timer t(c, "refresh");
-  HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
+  HIPCHK(c, launch_sampler(c, c->stream, a, which));
   p.cache_valid = true;
   return VMC_OK;
 }
@@ -1153,7 +1162,7 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
     HIPCHK(c, launch_conv_sweep(st, s));
   } else {
     Timer t(c, "sweep", st, true);
-    HIPCHK(c, launch_sweep16(st, a, c->Hp));
+    HIPCHK(c, launch_sampler(c, st, a, 0));
   }
   if (dbg) return VMC_OK;               // the proposal dump writes nothing back
   swap_chain_buffers(c);
@@ -1316,7 +1325,7 @@ int vmc_local_energy_terms(vmc_ctx* c, int which, float* diag, float* offdiag_ov
 int vmc_debug_kernel_path(vmc_ctx* c, int32_t* path) {
   CHECK_CTX(c);
   if (!path) return fail(c, VMC_ERR_INVALID, "null");
-  *path = c->conv ? 3 : (c->wide ? (c->wide_fast ? 1 : 2) : (c->split ? 4 : 0));
+  *path = c->conv ? 3 : (c->wide ? (c->wide_fast ? 1 : 2) : (c->split ? (c->split_sweep ? 5 : 4) : 0));
   return VMC_OK;
 }
 

@@ -25,7 +25,7 @@ def _bonds(kind, n):
 def _engine(monkeypatch, split, n, h, L, b, kind, seed=0):
   from cgs_vmc_amd.engine import VmcEngine
   if split:
-    monkeypatch.setenv('CGS_VMC_SPLIT_BF16', '1')
+    monkeypatch.setenv('CGS_VMC_SPLIT_BF16', str(int(split)))       # True / 1: row kernel; 2: row kernel + sampler
   else:
     monkeypatch.delenv('CGS_VMC_SPLIT_BF16', raising=False)
   rng = np.random.default_rng(seed)
@@ -34,7 +34,7 @@ def _engine(monkeypatch, split, n, h, L, b, kind, seed=0):
   bonds = _bonds(kind, n)
   eng = VmcEngine(n, b, L, h, seed=2024)
   eng.set_params(theta); eng.set_configs(cfg); eng.set_bonds(bonds, -1.0, 1.0)
-  assert eng.kernel_path() == (4 if split else 0)
+  assert eng.kernel_path() == ({1: 4, 2: 5}[int(split)] if split else 0)
   return eng, theta, cfg, bonds
 
 
@@ -157,3 +157,109 @@ def test_split_is_refused_silently_where_it_does_not_apply(monkeypatch):
     eng = VmcEngine(16, 32, 2, kw.pop('layer_size'), **kw)
     assert eng.kernel_path() == 0
     eng.close()
+
+
+# --------------------------------------------------------------------------------------------- the split SAMPLER
+# k_sweep16s (CGS_VMC_SPLIT_BF16=2): tests/test_gpu_engine.py's sampler cases at their tolerances, on 256-unit shapes
+SAMPLER_SHAPES = [(16, 256, 2, 64, 'torus4x4'), (36, 200, 3, 70, 'torus6x6'), (100, 256, 3, 96, 'torus10x10'),
+                  (40, 256, 4, 33, 'chain')]
+
+
+@pytest.mark.parametrize('n,h,L,b,kind', SAMPLER_SHAPES)
+def test_split_sampler_injected_step_matches_oracle(monkeypatch, n, h, L, b, kind):
+  """test_gpu_engine.py::test_injected_mc_step_matches_oracle on the split sampler: accept masks bit-exact outside
+  BASELINE.md's band, the chains exactly the accepted exchanges, the written-back cache = the new chains' logits."""
+  eng, theta, cfg, _ = _engine(monkeypatch, 2, n, h, L, b, kind)
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+  cur = cfg
+  for step in range(6):
+    u_sites, u_acc = vo.step_uniforms(99, np.arange(b), step, n)
+    i_up, i_dn = vo.propose_exchange(cur, u_sites)
+    new_ref, acc_ref, ratios = vo.mc_step(amp, cur, i_up, i_dn, u_acc)
+    mask = eng.mc_step_injected(i_up, i_dn, u_acc)
+    band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
+    assert np.array_equal(mask[~band], acc_ref[~band])
+    got = eng.get_configs()
+    expect = cur.copy()
+    rows = np.arange(b)[mask]
+    expect[rows, i_dn[mask]] = 1.0
+    expect[rows, i_up[mask]] = -1.0
+    np.testing.assert_array_equal(got, expect)
+    cur = got
+    ref = vo.fc_logit(theta, cur, h, L, dtype=np.float64)
+    assert np.abs(eng.amplitude()[0] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+  eng.close()
+
+
+@pytest.mark.parametrize('n,h,L,b,kind', SAMPLER_SHAPES)
+def test_split_sampler_trajectory_follows_oracle(monkeypatch, n, h, L, b, kind):
+  """vmc_mc_steps on the split sampler reproduces the oracle's chains step by step (chains whose accept test falls
+  in the band are excluded from then on); one launch of 12 steps == 12 launches of one; two engines agree bit for
+  bit (run-to-run identity inside the mode); a shard walks the rows of the whole batch (shard invariance)."""
+  from cgs_vmc_amd.engine import VmcEngine
+  eng, theta, cfg, bonds = _engine(monkeypatch, 2, n, h, L, b, kind)
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+  cur = cfg.copy()
+  ok = np.ones(b, bool)
+  for step in range(12):
+    u_sites, u_acc = vo.step_uniforms(2024, np.arange(b), step, n)
+    i_up, i_dn = vo.propose_exchange(cur, u_sites)
+    cur, acc, ratios = vo.mc_step(amp, cur, i_up, i_dn, u_acc)
+    ok &= ~(np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30))
+    eng.mc_steps(1)
+    np.testing.assert_array_equal(eng.get_configs()[ok], cur[ok])
+  assert ok.sum() > b // 2
+  eng2, _, _, _ = _engine(monkeypatch, 2, n, h, L, b, kind)
+  eng2.mc_steps(12)
+  np.testing.assert_array_equal(eng2.get_configs(), eng.get_configs())
+  np.testing.assert_array_equal(eng2.amplitude()[0], eng.amplitude()[0])
+  half = VmcEngine(n, b - b // 2, L, h, seed=2024, chain_offset=b // 2)
+  half.set_params(theta); half.set_configs(cfg[b // 2:]); half.set_bonds(bonds, -1.0, 1.0)
+  assert half.kernel_path() == 5
+  half.mc_steps(12)
+  np.testing.assert_array_equal(half.get_configs(), eng2.get_configs()[b // 2:])
+  # the exact cache the sampler leaves and the local energies of its chains, against the fp64 oracle
+  got = eng2.get_configs()
+  ref = vo.fc_logit(theta, got, h, L, dtype=np.float64)
+  assert np.abs(eng2.amplitude()[0] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+  ref_e = vo.local_value(amp, got, bonds, -1.0, 1.0, dtype=np.float64)
+  assert np.abs(eng2.local_energy()[0] - ref_e).max() <= 2e-4 * max(1.0, np.abs(ref_e).max())
+  eng.close(); eng2.close(); half.close()
+
+
+def test_split_sampler_at_config3_full_size(monkeypatch):
+  """BASELINE config 3 on both split kernels: after a sweep the chains are the native sampler's except where an
+  accept test fell into the band (a handful of 409,600 decisions), logits and local energies of every 64th chain
+  within the native bars of the fp64 oracle, gradient accumulators within theirs of the native engine's."""
+  import bench
+  from cgs_vmc_amd import _hip
+  from cgs_vmc_amd.engine import VmcEngine
+  n, h, L, b = 100, 256, 3, 4096
+  theta, cfg = bench.make_inputs(n, h, L, b, 0)
+  bonds = vo.torus_bonds(10, 10, False)
+  outs = {}
+  for mode in (None, '2'):
+    if mode:
+      monkeypatch.setenv('CGS_VMC_SPLIT_BF16', mode)
+    else:
+      monkeypatch.delenv('CGS_VMC_SPLIT_BF16', raising=False)
+    eng = VmcEngine(n, b, L, h, seed=2024)
+    eng.set_params(theta); eng.set_configs(cfg); eng.set_bonds(bonds, -1.0, 1.0)
+    assert eng.kernel_path() == (5 if mode else 0)
+    eng.mc_steps(n)
+    got = eng.get_configs()
+    eng.reset_accumulators(); eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+    outs[mode] = (got, eng.amplitude()[0], eng.local_energy()[0], eng.get_accumulators())
+    eng.close()
+  same = (outs[None][0] == outs['2'][0]).all(1)
+  assert same.mean() > 0.995, same.mean()          # band events only
+  pick = np.arange(0, b, 64)
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+  got = outs['2'][0]
+  ref = vo.fc_logit(theta, got[pick], h, L, dtype=np.float64)
+  assert np.abs(outs['2'][1][pick] - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+  ref_e = vo.local_value(amp, got[pick], bonds, -1.0, 1.0, dtype=np.float64)
+  assert np.abs(outs['2'][2][pick] - ref_e).max() <= 2e-4 * max(1.0, np.abs(ref_e).max())
+  if same.all():
+    a0, a1 = outs[None][3], outs['2'][3]
+    assert np.abs(a0 - a1).max() <= 2e-3 * np.abs(a0).max() + 1e-4
