@@ -362,10 +362,19 @@ __global__ __launch_bounds__(256) void k_tail16r(TailArgs a, const unsigned* __r
     istage = p16s + (long long)(il * NT + ito) * (KT * 3 * 256);
     ilds = lds0 + islot * SPLIT_STAGE_BYTES + wave * 6144;
   };
+  // (the scalar operands pass through readfirstlane: short of SGPRs the compiler keeps uniform values in VGPRs and
+  // hands such a register to an "s" operand as it stands -- `s_mov_b32 m0, v1` does not assemble)
+  auto sgpr_ptr = [](const unsigned* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const unsigned*)(((unsigned long long)hi << 32) | lo);
+  };
 #define DMA_PIECE(P)                                                                   \
   do {                                                                                 \
-    if ((P) < 4) DMA1(istage, voff0, ilds, (P) * 1024);                                \
-    else DMA1(istage, voff1, ilds + 4096, ((P) - 4) * 1024);                           \
+    const unsigned* st_ = sgpr_ptr(istage);                                            \
+    const unsigned ld_ = __builtin_amdgcn_readfirstlane(ilds);                         \
+    if ((P) < 4) DMA1(st_, voff0, ld_, (P) * 1024);                                    \
+    else DMA1(st_, voff1, ld_ + 4096, ((P) - 4) * 1024);                               \
   } while (0)
 #pragma unroll
   for (int i = 0; i < R - 1; ++i) {
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(256) void k_tail16r(TailArgs a, const unsigned* __r
         }
         if (last && (kt == 0 || kt == 3) && !(VMC_SPLIT_ABLATE & 2)) {
           const int hf = kt == 0 ? 0 : 1;
-          GATHER_DMA3(nsrc[hf].zb, nsrc[hf].wa, nsrc[hf].wb, stage_lds + hf * 3072, 64 * to);
+          GATHER_DMA3(nsrc[hf].zb, nsrc[hf].wa, nsrc[hf].wb, __builtin_amdgcn_readfirstlane(stage_lds + hf * 3072), 64 * to);
         }
         if (kt < 6 && !(VMC_SPLIT_ABLATE & 4)) DMA_PIECE(kt);
         const u32x4 h = wh[kt & 1], m = wm[kt & 1], lo = wl[kt & 1];
@@ -527,6 +536,14 @@ __global__ __launch_bounds__(256) void k_tail16r(TailArgs a, const unsigned* __r
         acc0 = mfma_bf16(h, Xh[0][kt], acc0); acc1 = mfma_bf16(h, Xh[1][kt], acc1);
         } else { acc0[0] += __uint_as_float(h[0] ^ Xh[0][kt][0]); acc1[0] += __uint_as_float(m[0] ^ lo[0] ^ Xm[1][kt][1] ^ Xl[0][kt][2]); }
         if (kt == 1 && to > 0) epilogue(to - 1, pacc0, pacc1, pwo);      // of the previous output tile, under these MFMAs
+        // the operand split for the NEXT layer (or row tile), k-step by k-step inside the LAST stage of this layer:
+        // item kt was the last reader of X[.][kt], and unit tiles 2 kt, 2 kt + 1 <= 13 of `out` are final (the
+        // deferred epilogue of tile 14 runs above, tile 15 is this stage) -- 88 VALU instructions per item into the
+        // MFMA shadows instead of a 704-instruction burst between two layers; k-step 7 follows behind the stage
+        if (to == NT - 1 && kt < KT - 1 && !(VMC_SPLIT_ABLATE & 1)) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) split8(out[hf][2 * kt], out[hf][2 * kt + 1], Xh[hf][kt], Xm[hf][kt], Xl[hf][kt]);
+        }
         if (kt == 1 || kt == 5) __builtin_amdgcn_sched_barrier(0);       // (keeps those two pieces of filler where they are)
       }
       if (!(VMC_SPLIT_ABLATE & 4)) advance();
@@ -555,12 +572,11 @@ __global__ __launch_bounds__(256) void k_tail16r(TailArgs a, const unsigned* __r
     for (int l = 0; l + 1 < n_hidden; ++l) {
       layer(bool_c<false>(), l);
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-          if (!(VMC_SPLIT_ABLATE & 1)) split8(out[hf][2 * kt], out[hf][2 * kt + 1], Xh[hf][kt], Xm[hf][kt], Xl[hf][kt]);
-          else Xh[hf][kt][0] ^= __float_as_uint(out[hf][2 * kt][0] + out[hf][2 * kt + 1][3]);
-        }
+      for (int hf = 0; hf < 2; ++hf) {
+        constexpr int kt = KT - 1;               // (k-steps 0 .. 6 were split inside the layer's last stage)
+        if (!(VMC_SPLIT_ABLATE & 1)) split8(out[hf][2 * kt], out[hf][2 * kt + 1], Xh[hf][kt], Xm[hf][kt], Xl[hf][kt]);
+        else Xh[hf][kt][0] ^= __float_as_uint(out[hf][2 * kt][0] + out[hf][2 * kt + 1][3]);
+      }
     }
     layer(bool_c<true>(), n_hidden - 1);      // out[] now holds the first-layer activations of the next row tile
 #pragma unroll
@@ -579,12 +595,11 @@ __global__ __launch_bounds__(256) void k_tail16r(TailArgs a, const unsigned* __r
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) cur[hf] = nxt[hf];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        if (!(VMC_SPLIT_ABLATE & 1)) split8(out[hf][2 * kt], out[hf][2 * kt + 1], Xh[hf][kt], Xm[hf][kt], Xl[hf][kt]);
-        else Xh[hf][kt][0] ^= __float_as_uint(out[hf][2 * kt][0] + out[hf][2 * kt + 1][3]);
-      }
+    for (int hf = 0; hf < 2; ++hf) {
+      constexpr int kt = KT - 1;
+      if (!(VMC_SPLIT_ABLATE & 1)) split8(out[hf][2 * kt], out[hf][2 * kt + 1], Xh[hf][kt], Xm[hf][kt], Xl[hf][kt]);
+      else Xh[hf][kt][0] ^= __float_as_uint(out[hf][2 * kt][0] + out[hf][2 * kt + 1][3]);
+    }
   }
   // the prefetched fragments of the stage that is never multiplied, and my DMA still in flight
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(wh[0]), "+v"(wm[0]), "+v"(wl[0]) :: "memory");
