@@ -61,6 +61,8 @@ WORKLOADS = {
     # EXPERIMENT, round 5: the same with the SAMPLER's two H x H layers on the BF16 matrix cores too
     # (CGS_VMC_SPLIT_BF16=2, k_sweep16s in cgs_vmc_amd/csrc/sweep16.hpp / sweep_split.hip); gradient path native fp32
     'heisenberg10x10_fc3x256_b4096_split3xbf16_sampler': (10, 10, False, 3, 256, 4096),
+    # config 5's shard with both split kernels (129 .. 256 sites: the split sampler's four-block Philox variant)
+    'heisenberg16x16j1j2_fc6x256_b1024_split3xbf16_sampler': (16, 16, True, 6, 256, 1024),
     'heisenberg6x6_fc3x128_b1024': (6, 6, False, 3, 128, 1024),
     'heisenberg16x16j1j2_fc6x256_b1024': (16, 16, True, 6, 256, 1024),
     'heisenberg10x10_fc3x512_b4096': (10, 10, False, 3, 512, 4096),   # 257 .. 512 units: the fused kernels padded to 512

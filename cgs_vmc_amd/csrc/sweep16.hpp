@@ -1008,9 +1008,9 @@ __global__ __launch_bounds__(NW * 64, NT == 16 ? (RTP == 0 ? SWEEP_OCC0 : 2) : 1
   sweep16_body<NT, NW, RTP, STAMP, W1L, FAST, UPRE, RBM, ACT>(a);
 }
 // the 3 x bf16 split sampler (instantiated by sweep_split.hip only)
-template <int RTP, bool FAST>
+template <int RTP, bool FAST, int UPRE = 2>
 __global__ __launch_bounds__(512, 2) void k_sweep16s(SweepArgs a) {
-  sweep16_body<16, 8, RTP, false, false, FAST, 2, false, VMC_ACT_RELU_, true>(a);
+  sweep16_body<16, 8, RTP, false, false, FAST, UPRE, false, VMC_ACT_RELU_, true>(a);
 }
 
 // (LDS bytes and the choice of variant: plan_sweep_lds_bytes / plan_sweep, plan.hpp)

@@ -162,7 +162,8 @@ def test_split_is_refused_silently_where_it_does_not_apply(monkeypatch):
 # --------------------------------------------------------------------------------------------- the split SAMPLER
 # k_sweep16s (CGS_VMC_SPLIT_BF16=2): tests/test_gpu_engine.py's sampler cases at their tolerances, on 256-unit shapes
 SAMPLER_SHAPES = [(16, 256, 2, 64, 'torus4x4'), (36, 200, 3, 70, 'torus6x6'), (100, 256, 3, 96, 'torus10x10'),
-                  (40, 256, 4, 33, 'chain')]
+                  (40, 256, 4, 33, 'chain'),
+                  (144, 256, 3, 40, 'torus12x12'), (256, 256, 6, 24, 'torus16x16')]   # 129 .. 256 sites: four Philox blocks per lane
 
 
 @pytest.mark.parametrize('n,h,L,b,kind', SAMPLER_SHAPES)
