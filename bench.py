@@ -201,6 +201,48 @@ def extra_legs(eng, step, n, b, L, h, soak_seconds):
   extra['sr_matvec_frac_of_fp32_mfma_peak'] = (fa_exec * n_store * b / (extra['sr_cg_ms_per_iteration'] * 1e-3)
                                                / 1e12 / FP32_MFMA_PEAK_TFLOPS)
   eng.sr_reserve(0)
+  # --- EXPERIMENT (never the headline; its own workload tags carry the full lines): the same step with fp32 results
+  # from the BF16 matrix cores -- CGS_VMC_SPLIT_BF16=1: the local-energy row kernel (k_tail16r), =2: the sampler too
+  # (k_sweep16s) -- on fresh engines with the headline's inputs, so that the driver's own run carries the numbers
+  if h == 256:
+    bonds = torus_bonds(int(round(n ** 0.5)), int(round(n ** 0.5)), False)
+    theta, cfg = make_inputs(n, h, L, b, 0)
+    prev = os.environ.get('CGS_VMC_SPLIT_BF16')
+    try:
+      for mode, key in (('1', 'split3xbf16_rows'), ('2', 'split3xbf16_rows_and_sampler')):
+        os.environ['CGS_VMC_SPLIT_BF16'] = mode
+        e2 = VmcEngine(n, b, L, h, device=eng.device, seed=2024)
+        e2.set_params(theta); e2.set_configs(cfg); e2.set_bonds(bonds, -1.0, 1.0)
+        if e2.kernel_path() != (4 if mode == '1' else 5):
+          e2.close()
+          continue
+        for _ in range(10):
+          e2.mc_steps(n, want_accepted=False)
+
+        def step2():
+          e2.reset_accumulators(); e2.accumulate(0); e2.mc_steps(n, want_accepted=False)
+        for _ in range(5):
+          step2()
+        e2.synchronize()
+        e2.timing_enable(2); e2.timing_reset()
+        t0 = time.perf_counter()
+        for _ in range(40):
+          step2()
+        e2.synchronize()
+        extra[key + '_ms_per_step'] = 1e3 * (time.perf_counter() - t0) / 40
+        e2.timing_enable(False)
+        for name, k2 in (('sweep', '_sampler_kernel_ms'), ('tail_eloc', '_row_kernel_ms')):
+          ms, cnt = e2.timing_get(name)
+          if cnt:
+            extra[key + k2] = ms / cnt
+        e2.local_energy(want_eloc=False)
+        extra[key + '_energy_per_site'] = e2.mean_energy() / n
+        e2.close()
+    finally:
+      if prev is None:
+        os.environ.pop('CGS_VMC_SPLIT_BF16', None)
+      else:
+        os.environ['CGS_VMC_SPLIT_BF16'] = prev
   # --- one epoch at the reference's default hparams (a second, small engine)
   dn, dh, dL, db, dnb = 40, 80, 3, 200, 50
   theta, cfg = make_inputs(dn, dh, dL, db, 0)
@@ -821,9 +863,9 @@ def main():
       timings[name] = {'ms_total': ms, 'launches': cnt, 'ms_avg': ms / cnt}
 
   # the legs BASELINE config 3's wording asks for beside the EnergyGradient slice (N = 1, the dense
-  # fully-connected headline shape; they change theta, so they come after every headline reading)
+  # headline workload only; they change theta, so they come after every headline reading)
   extra = None
-  if world == 1 and not args.no_extra and not conv and ansatz == 'fully_connected' and h <= 256:
+  if world == 1 and not args.no_extra and args.workload == 'heisenberg10x10_fc3x256_b4096':
     try:
       extra = extra_legs(eng, step, n, b, L, h, args.soak_seconds)
     except Exception as e:  # pylint: disable=broad-except

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 # the local-energy rows on the 3 x bf16 split kernel (CGS_VMC_SPLIT_BF16=1)
 CASES = [(8, 128, 2, 'chain', False), (10, 256, 3, 'chain', False), (8, 128, 2, 'torus4x2', False),
          (10, 384, 2, 'chain', False), (10, 512, 3, 'chain', False), (10, 256, 3, 'chain', True),
+         (10, 256, 3, 'chain', 2),           # round 5: row kernel AND sampler on the split (k_tail16r + k_sweep16s)
          (10, 640, 2, 'chain', False)]       # beyond 512 units: the general path (128 x 128-tile GEMM, k_wide_accept)
 
 
@@ -26,14 +27,14 @@ def test_exact_eigenstate_on_the_hip_path(monkeypatch, n, h, L, kind, split):
   from cgs_vmc_amd import _hip
   from cgs_vmc_amd.engine import VmcEngine
   if split:
-    monkeypatch.setenv('CGS_VMC_SPLIT_BF16', '1')
+    monkeypatch.setenv('CGS_VMC_SPLIT_BF16', str(int(split)))
   else:
     monkeypatch.delenv('CGS_VMC_SPLIT_BF16', raising=False)
   bonds = vo.chain_bonds(n) if kind == 'chain' else vo.torus_bonds(4, 2)
   theta, e0, cfgs, vec = exact_fc_eigenstate(n, bonds, h, L)
   b = len(cfgs)                                   # 70 / 252: every configuration of the sector once
   eng = VmcEngine(n, b, L, h, seed=5)
-  assert eng.kernel_path() == (4 if split else (2 if h > 512 else (1 if h > 256 else 0)))
+  assert eng.kernel_path() == ({1: 4, 2: 5}[int(split)] if split else (2 if h > 512 else (1 if h > 256 else 0)))
   eng.set_params(theta)
   eng.set_shift(0.0)
   eng.set_configs(cfgs)
