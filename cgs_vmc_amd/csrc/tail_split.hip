@@ -614,8 +614,10 @@ hipError_t launch_tail16_split(hipStream_t s, const TailArgs& a, const unsigned*
   const int persistent = a.num_cus > 0 ? a.num_cus : 256;
   const dim3 grid(tiles < persistent ? tiles : persistent), block(256);
   hipError_t e;
-  if (split_ring_on() && a.n_hidden > 0) {       // round 5: the weight stream through a per-CU LDS ring (k_tail16r)
-    const size_t rlds = (size_t)SPLIT_RING * SPLIT_STAGE_BYTES + (size_t)(a.n_hidden + 1) * 1024 + 4 * 6144;   // ring + bias / w_out image + gather staging
+  // round 5: the weight stream through a per-CU LDS ring (k_tail16r); ring + bias / w_out image + gather staging
+  // (networks whose bias image does not fit next to the ring -- more than 38 H x H layers -- keep k_tail16s)
+  const size_t rlds = (size_t)SPLIT_RING * SPLIT_STAGE_BYTES + (size_t)(a.n_hidden + 1) * 1024 + 4 * 6144;
+  if (split_ring_on() && a.n_hidden > 0 && rlds <= 160 * 1024) {
     if (ratio_mode) {
       e = hipFuncSetAttribute((const void*)k_tail16r<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
       if (e != hipSuccess) return e;
