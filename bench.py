@@ -966,7 +966,7 @@ def main():
       traffic = None
       pmc = None
       suffix = {'heisenberg10x10_fc3x256_b4096': '', 'heisenberg10x10_fc3x256_b4096_split3xbf16': '_split', 'heisenberg10x10_fc3x256_b4096_split3xbf16_sampler': '_splits',
-                'heisenberg16x16j1j2_fc6x256_b1024': '_config5',
+                'heisenberg16x16j1j2_fc6x256_b1024': '_config5', 'heisenberg16x16j1j2_fc6x256_b1024_split3xbf16_sampler': '_config5_splits',
                 'heisenberg10x10_conv5x16k5_b4096': '_conv', 'heisenberg16x16j1j2_conv5x16k5_b1024': '_conv16',
                 'heisenberg10x10_fc3x512_b4096': '_fc3x512', 'heisenberg10x10_conv5x32k5_b4096': '_conv32'}.get(args.workload)
       for rnd in ('r5', 'r4', 'r3', 'r2'):        # the newest committed profile of this workload
