@@ -397,11 +397,20 @@ hipError_t launch_wide_out(hipStream_t s, const float* a, const float* wout, con
 hipError_t launch_wide_propose(hipStream_t s, const float* configs, int B, int N, uint32_t seed_lo,
                                uint32_t seed_hi, int chain_offset, unsigned long long step, const int* inj_up,
                                const int* inj_dn, const float* inj_u, int* iup, int* idn, float* u);
-hipError_t launch_wide_build(hipStream_t s, const float* z1, const float* w1p, const int* iup, const int* idn,
-                             int B, int Hp, int act, float* zc, float* a0);
-hipError_t launch_wide_accept(hipStream_t s, float* configs, float* z1, const float* zc, float* logit,
-                              const float* lnew, const int* iup, const int* idn, const float* u, int B, int N,
-                              int Hp, int oact, unsigned long long* accepted, unsigned char* acc_mask,
-                              float* onsite = nullptr, const float* won = nullptr);
+// one mc_step of the general sampler in one launch (k_wide_step): accept the previous step's proposal from the
+// last layer's activations `a_last`, propose this step's move, update z1, write the candidate's a0
+struct WideStepArgs {
+  float* configs; float* z1; const float* w1p;
+  const float* a_last; float* a0;                 // may alias (see k_wide_step)
+  const float* wout; const float* bout; float* logit;
+  int* iup; int* idn; float* u;                   // the proposal in flight: read by (1), rewritten by (2)
+  const int* inj_up; const int* inj_dn; const float* inj_u;   // injected proposal (tests) or nullptr
+  unsigned long long* accepted; unsigned char* acc_mask;
+  float* onsite; const float* won;                // RestrictedBoltzmannNetwork or nullptr
+  int B, N, H, Hp, act, oact;
+  int do_accept, do_propose;
+  uint32_t seed_lo, seed_hi; int chain_offset; unsigned long long step;
+};
+hipError_t launch_wide_step(hipStream_t s, const WideStepArgs& a);
 hipError_t launch_wide_delta_last(hipStream_t s, const float* a_last, const float* wout, const float* oscale,
                                   int B, int H, int Hp, int act, float* delta, const float* dact = nullptr);

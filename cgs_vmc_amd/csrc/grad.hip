@@ -866,37 +866,46 @@ void wgrad_fill_problem(void* dst, int index, const float* A, long long lda, con
 #define G2_TN 128
 #define G2_TK 16
 #define G2_LD 132
+#define GEMM128_MIN8 160
 // TN = 128.  (TN = 64 -- 128 x 64 tiles for grids the square tile does not fill the chip with -- was measured
 // on the sampler's 4096 x 1024 x 1024 products: 2 % over k_gemm's 64 x 64 tiles, not kept as a launch path.)
-template <int TN>
-__global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int tiles_n) {
-  constexpr int NJ = TN / 64;                        // 32-column accumulators per wave
-  constexpr int BQ = TN / 4, BR = 256 / BQ, BP = G2_TK / BR;   // B tile: quads per k row, k rows per pass, passes
+// WAVES = 4: 2 x 2 waves of 64 x TN / 2 (two workgroups per CU; grids of >= 1024 tiles: the local-energy rows).
+// WAVES = 8: 2 x 4 waves of 64 x TN / 4 (round 5): the sampler's 4096-row products are 256 tiles, one per CU --
+// with four waves that is ONE wave per SIMD and nothing hides an LDS round trip or a barrier (111 us at
+// 4096 x 1024 x 1024 against 86 for 1024 small tiles); eight waves put two on every SIMD at 1.5 LDS operand
+// reads per MFMA (k_gemm: 2, the 4-wave form: 1).
+template <int TN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_gemm128(GemmArgs g, int tiles_m, int tiles_n) {
+  constexpr int NT = 64 * WAVES;                     // threads
+  constexpr int WN = WAVES / 2;                      // waves along n (two along m)
+  constexpr int NJ = TN / WN / 32;                   // 32-column accumulators per wave
+  constexpr int AP = 512 / NT;                       // A tile (128 x 16): quads per thread
+  constexpr int BQ = TN / 4, BR = NT / BQ, BP = G2_TK / BR;   // B tile: quads per k row, k rows per pass, passes
   __shared__ __attribute__((aligned(16))) float As[2][G2_TK][G2_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][G2_TK][TN + 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   // XCD-aware tile order: XCD x takes the row tiles x, x + 8, ..., each with all of its column tiles
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int tm = (j / tiles_n) * 8 + xcd, tn = j % tiles_n;
   if (tm >= tiles_m) return;                        // (whole workgroup; before any barrier)
   const int m0 = tm * G2_TM, n0 = tn * TN;
   const int T = (g.K + G2_TK - 1) / G2_TK;
-  // this thread's two quads of the A tile (row am + 64 i, k quad ak) and of the B tile (k row bk + 8 i, n quad bn)
+  // this thread's quads of the A tile (row am + NT / 4 i, k quad ak) and of the B tile (k row bk + BR i, n quad bn)
   const int am = tid >> 2, ak = 4 * (tid & 3);
   const int bk = tid / BQ, bn = 4 * (tid % BQ);
-  const float* ap[2];
+  const float* ap[AP];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) ap[i] = g.A + (long long)min(m0 + am + 64 * i, g.M - 1) * g.sam;
+  for (int i = 0; i < AP; ++i) ap[i] = g.A + (long long)min(m0 + am + (NT / 4) * i, g.M - 1) * g.sam;
   const bool b_in = n0 + bn < g.N;                  // N % 4 == 0: a quad is inside or outside as a whole
   const float* bp = g.B + (b_in ? n0 + bn : 0);
-  f32x4 ra[2], rb[BP];
+  f32x4 ra[AP], rb[BP];
   const int sbk = (int)g.sbk;                       // K * sbk < 2^31 (gemm128_applies)
   auto request = [&](int t) {
     const int k0 = min(t, T - 1) * G2_TK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ra[i] = *(const f32x4*)(ap[i] + min(k0 + ak, g.K - 4));
+    for (int i = 0; i < AP; ++i) ra[i] = *(const f32x4*)(ap[i] + min(k0 + ak, g.K - 4));
 #pragma unroll
     for (int i = 0; i < BP; ++i) rb[i] = *(const f32x4*)(bp + min(k0 + bk + BR * i, g.K - 1) * sbk);
     // (the loads stay HERE, a whole tile of MFMAs ahead of their use: without the barrier the compiler
@@ -906,10 +915,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int
   auto stage = [&](int t) {
     const int k0 = t * G2_TK, st = t & 1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AP; ++i) {
       const bool a_ok = k0 + ak < g.K;              // K % 4 == 0
 #pragma unroll
-      for (int e = 0; e < 4; ++e) As[st][ak + e][am + 64 * i] = a_ok ? ra[i][e] : 0.f;
+      for (int e = 0; e < 4; ++e) As[st][ak + e][am + (NT / 4) * i] = a_ok ? ra[i][e] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
@@ -937,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int
 #pragma unroll
       for (int i = 0; i < 2; ++i) a2[i] = As[st][kk + hi][wm * 64 + 32 * i + l31];
 #pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) b2[jj] = Bs[st][kk + hi][wn * (TN / 2) + 32 * jj + l31];
+      for (int jj = 0; jj < NJ; ++jj) b2[jj] = Bs[st][kk + hi][wn * (TN / WN) + 32 * jj + l31];
     };
     operands(0, av[0], bv[0]);
 #pragma unroll
@@ -954,7 +963,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int
     __syncthreads();
   }
   auto finish = [&](const f32x16& v, int i, int jj) {
-    const int n = n0 + wn * (TN / 2) + 32 * jj + l31;
+    const int n = n0 + wn * (TN / WN) + 32 * jj + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -965,9 +974,245 @@ __global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int
   if constexpr (NJ == 2) { finish(acc[0][1], 0, 1); finish(acc[1][1], 1, 1); }
 }
 
+// ------------------------------------------------------------------- GEMM, one tile per CU (round 5)
+// The general sampler's products (4096 chains x H x H, one per hidden layer and mc_step) are 256 tiles of
+// 128 x 128: ONE round of the 256 CUs.  A kernel that stages through registers has one k-tile of look-ahead
+// (k_gemm128: 16 k = 0.85 us of MFMAs at two waves per SIMD) -- less than a first touch of the activation
+// rows takes -- and with one workgroup per CU nothing else runs while it waits: 111 us (4 waves) / 95 us
+// (8 waves) against 86 for k_gemm's 1024 small tiles, whose four workgroups per CU cover for each other.
+// k_gemm_ring keeps the large tile and fetches BOTH operands by LDS-DMA (global_load_lds_dwordx4: no VGPR
+// round trip, nothing for a wave to wait on) into a ring of GR_RING stages of 32 k, three stages = 5 us ahead:
+//   stage    A tile 128 rows x 32 k (16 KiB) + B tile 32 k x 128 n (16 KiB); eight waves fetch four 1 KiB
+//            pieces each, one per item, under the MFMAs.
+//   A image  a DMA instruction writes lane L's 16 bytes at [M0 + 16 L]; lane L fetches row 8 i + (L >> 3),
+//            k quad (L & 7) ^ ((row >> 1) & 7): eight lanes cover one 128-byte line of a row, and the XOR puts the
+//            quads an MFMA-layout read wants (sixteen consecutive rows, one k quad) on sixteen distinct bank
+//            quads.  One ds_read_b128 = this lane's A operands of FOUR k-steps.
+//   B image  [k][n] as in memory (a piece = two k rows); operands by ds_read2st64_b32 (two k rows per read).
+//   k order  lane half h of an MFMA takes k = 4 (2 p + h) + e in item p, step e -- a permutation of the
+//            stage's 32 k (the sum's order differs from k_gemm's: equal within rounding, not bit for bit).
+//   waves    2 (m) x 4 (n), each 64 x 32 of the tile as two 32x32x2 accumulators sharing the B operand:
+//            4 LDS instructions per 8 MFMAs.
+//   protocol (every wave runs the same sequence; ONE s_barrier per stage = 2,048 matrix cycles per wave)
+//     every item: issue one piece; wait for this item's operands, read the operands of the NEXT item (item 3:
+//                 of stage s + 1, item 0); eight MFMAs.
+//     item 3 of stage s, between that wait and those reads:  s_waitcnt vmcnt(8) -- my pieces of stage s + 1
+//                 have landed, two stages' worth may be in flight -- and s_barrier: all of s + 1 has landed
+//                 (it is about to be read), and every wave holds its last operands of stage s in registers,
+//                 so the slot of s is free: the pieces of stage s + 4 go there, from this item on (item 3
+//                 of s, items 0 .. 2 of s + 1).  A piece has 2.25 .. 3 stages (4 .. 7 us) to land.  (With
+//                 the barrier at the stage boundary and the pieces of s + 3 issued in items 0 .. 3 of s the
+//                 last piece had ONE stage, less than a miss to HBM takes under load: MFMA busy 0.61.)
+//   The stages behind the last are re-fetches of the last (in bounds, never read): the counts stay uniform.
+//   Every wave drains its DMA before it exits.  Rows beyond M / columns beyond N fetch a clamped row / quad
+//   and are not stored.
+// Requirements (gemm_ring_ok): the k_gemm128 layout, K % 128 == 0 (whole turns of the ring).
+#define GR_TK 32
+#define GR_RING 4
+#define GR_ABYTES (G2_TM * GR_TK * 4)
+#define GR_BBYTES (GR_TK * G2_TN * 4)
+#define GR_LDS (GR_RING * (GR_ABYTES + GR_BBYTES))
+#define GR_LDC (G2_TN + 4)                 // row stride of the output tile's LDS image (floats): 16-byte rows, banks spread
+// DIAGNOSTIC builds only (-DVMC_GR_ABLATE=mask, tools/gemm_ring_ablate.sh; results are garbage, only the time is read):
+// 1 no DMA in the stage loop, 2 no barrier, 4 no operand reads, 8 no MFMAs
+#ifndef VMC_GR_ABLATE
+#define VMC_GR_ABLATE 0
+#endif
+typedef float f32x2_gr __attribute__((ext_vector_type(2)));
+
+// ONE 1 KiB piece: lane L's 16 bytes from [base + voff] to LDS [lds + 16 L].  M0 is saved and restored.
+#define GR_DMA(BASE, VOFF, LDS)                                                                             \
+  do {                                                                                                      \
+    unsigned sv_;                                                                                           \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"     \
+                 "s_mov_b32 m0, %0"                                                                         \
+                 : "=&s"(sv_) : "s"(LDS), "v"(VOFF), "s"(BASE) : "memory");                                 \
+  } while (0)
+// ONE statement per item: wait for the operands of the item about to be multiplied (set S, issued by the
+// previous statement), then issue the reads of the item behind it (ring slot SLOT, item P) into the other
+// set T.  Both sets are in/out operands: the MFMAs of this item follow the statement (they read its
+// outputs), the next statement follows them (it redefines set S) -- tail_split.hip, LDS_STEP.  The
+// accumulators are in/out operands too (the statement does not touch them): without that tie the compiler
+// renames set S with register copies and sinks the MFMAs of an item behind the NEXT statement's wait.
+#if VMC_GR_ABLATE & 4
+#define GR_READS(T, SLOT, P) "; %[ta0] %[pa0] %[oa] %[ta1] %[pa1] %[tb0] %[pb] %[ob] %[tb1]"
+#else
+#define GR_READS(T, SLOT, P)                                                                                \
+  "ds_read_b128 %[ta0], %[pa0] offset:%[oa]\n\tds_read_b128 %[ta1], %[pa1] offset:%[oa]\n\t"               \
+  "ds_read2st64_b32 %[tb0], %[pb] offset0:%[ob] offset1:%[ob]+2\n\t"                                        \
+  "ds_read2st64_b32 %[tb1], %[pb] offset0:%[ob]+4 offset1:%[ob]+6"
+#endif
+#if VMC_GR_ABLATE & 2
+#define GR_BARRIER "s_nop 0"
+#else
+#define GR_BARRIER "s_barrier"
+#endif
+#define GR_STEP_(WAIT, S, T, SLOT, P)                                                                       \
+  asm volatile(WAIT "\n\t" GR_READS(T, SLOT, P)                                                              \
+               : [sa0] "+v"(a0[S]), [sa1] "+v"(a1[S]), [sb0] "+v"(b01[S]), [sb1] "+v"(b23[S]),               \
+                 [ta0] "+v"(a0[T]), [ta1] "+v"(a1[T]), [tb0] "+v"(b01[T]), [tb1] "+v"(b23[T]),               \
+                 "+v"(acc0), "+v"(acc1)                                                                     \
+               : [pa0] "v"(adA[0][P]), [pa1] "v"(adA[1][P]), [pb] "v"(adB),                                 \
+                 [oa] "n"((SLOT) * GR_ABYTES), [ob] "n"((SLOT) * (GR_BBYTES / 256) + (P) * 16)              \
+               : "memory")
+#define GR_STEP(S, T, SLOT, P) GR_STEP_("s_waitcnt lgkmcnt(0)", S, T, SLOT, P)
+// item 3: the stage hand-over (see the protocol above) sits between the wait and the reads
+#define GR_STEP_NEXT(S, T, SLOT) GR_STEP_("s_waitcnt vmcnt(8) lgkmcnt(0)\n\t" GR_BARRIER, S, T, SLOT, 0)
+
+__global__ __launch_bounds__(512) void k_gemm_ring(GemmArgs g, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char gr_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  // XCD-aware tile order (k_gemm128): XCD x takes the row tiles x, x + 8, ..., each with all of its column tiles
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int tm = (jb / tiles_n) * 8 + xcd, tn = jb % tiles_n;
+  if (tm >= tiles_m) return;                        // (whole workgroup; before any barrier or DMA)
+  const int m0 = tm * G2_TM, n0 = tn * G2_TN;
+  const int T = g.K / GR_TK;
+  const int sam = (int)g.sam, sbk = (int)g.sbk;     // 128 sam, 4 sbk + N < 2^29 (gemm_ring_ok)
+  const unsigned lds0 = (unsigned)(size_t)gr_lds;
+
+  // ---- this wave's four pieces of a stage: A pieces 2 wave, 2 wave + 1 (eight rows each), B pieces likewise (two k rows each)
+  unsigned voffA[2], voffB[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = 8 * (2 * wave + u) + (lane >> 3);
+    const int rc = min(m0 + r, g.M - 1) - m0;
+    const int q = (lane & 7) ^ ((r >> 1) & 7);
+    voffA[u] = (unsigned)(rc * sam + 4 * q) * 4u;
+    const int nq = min(n0 + 4 * (lane & 31), g.N - 4);
+    voffB[u] = (unsigned)((2 * u + (lane >> 5)) * sbk + nq) * 4u;
+  }
+  const float* const abase = g.A + (long long)m0 * g.sam;
+  const float* const bbase = g.B + (long long)(4 * wave) * g.sbk;
+  const unsigned ldsA = lds0 + (2 * wave) * 1024, ldsB = lds0 + GR_RING * GR_ABYTES + (2 * wave) * 1024;
+  auto sgpr_ptr = [](const float* p) {              // (tail_split.hip: an "s" operand must really be in SGPRs)
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float*)(((unsigned long long)hi32 << 32) | lo);
+  };
+  // piece p (0, 1: A; 2, 3: B) of stage s into ring slot `slot`
+  auto piece = [&](int p, int s, int slot) {
+    if ((VMC_GR_ABLATE & 1) && s >= GR_RING) return;
+    const int k0 = min(s, T - 1) * GR_TK;
+    if (p < 2) {
+      const float* b_ = sgpr_ptr(abase + k0);
+      const unsigned l_ = __builtin_amdgcn_readfirstlane(ldsA + slot * GR_ABYTES + p * 1024);
+      GR_DMA(b_, voffA[p], l_);
+    } else {
+      const float* b_ = sgpr_ptr(bbase + (long long)k0 * sbk);
+      const unsigned l_ = __builtin_amdgcn_readfirstlane(ldsB + slot * GR_BBYTES + (p - 2) * 1024);
+      GR_DMA(b_, voffB[p - 2], l_);
+    }
+  };
+
+  // ---- operand addresses: A row m = 64 wm + 32 i + l31, k quad 2 p + hi (swizzled as it was fetched); B row hi, column n
+  unsigned adA[2][4], adB;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = wm * 64 + 32 * i + l31;
+      adA[i][p] = lds0 + (unsigned)(m * 8 + ((2 * p + hi) ^ ((m >> 1) & 7))) * 16u;
+    }
+  adB = lds0 + GR_RING * GR_ABYTES + (unsigned)(hi * 4 * G2_TN + wn * 32 + l31) * 4u;
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  f32x4 a0[2], a1[2];
+  f32x2_gr b01[2], b23[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { a0[i] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[i] = a0[i]; b01[i] = f32x2_gr{0.f, 0.f}; b23[i] = b01[i]; }
+
+#pragma unroll
+  for (int s = 0; s < GR_RING - 1; ++s) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) piece(p, s, s);
+  }
+  asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier\n\t" GR_READS(0, 0, 0)     // stage 0 has landed: mine, everybody's
+               : [ta0] "+v"(a0[0]), [ta1] "+v"(a1[0]), [tb0] "+v"(b01[0]), [tb1] "+v"(b23[0])
+               : [pa0] "v"(adA[0][0]), [pa1] "v"(adA[1][0]), [pb] "v"(adB), [oa] "n"(0), [ob] "n"(0) : "memory");
+  piece(0, GR_RING - 1, GR_RING - 1);
+
+#define GR_MFMA8(S)                                                                          \
+  do {                                                                                       \
+    if (VMC_GR_ABLATE & 8) break;                                                            \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S][0], b01[S][0], acc0, 0, 0, 0);         \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[S][0], b01[S][0], acc1, 0, 0, 0);         \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S][1], b01[S][1], acc0, 0, 0, 0);         \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[S][1], b01[S][1], acc1, 0, 0, 0);         \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S][2], b23[S][0], acc0, 0, 0, 0);         \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[S][2], b23[S][0], acc1, 0, 0, 0);         \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S][3], b23[S][1], acc0, 0, 0, 0);         \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[S][3], b23[S][1], acc1, 0, 0, 0);         \
+  } while (0)
+  // one stage in ring slot SLOT (a compile-time constant: the LDS offsets are instruction immediates)
+#define GR_STAGE(SLOT)                                                                       \
+  do {                                                                                       \
+    const int s_ = st + (SLOT);                                                              \
+    piece(1, s_ + 3, ((SLOT) + 3) & 3); GR_STEP(0, 1, SLOT, 1); GR_MFMA8(0);                 \
+    piece(2, s_ + 3, ((SLOT) + 3) & 3); GR_STEP(1, 0, SLOT, 2); GR_MFMA8(1);                 \
+    piece(3, s_ + 3, ((SLOT) + 3) & 3); GR_STEP(0, 1, SLOT, 3); GR_MFMA8(0);                 \
+    GR_STEP_NEXT(1, 0, ((SLOT) + 1) & 3); piece(0, s_ + 4, SLOT); GR_MFMA8(1);               \
+  } while (0)
+  for (int st = 0; st < T; st += GR_RING) {         // (T % GR_RING == 0: gemm_ring_ok)
+    GR_STAGE(0); GR_STAGE(1); GR_STAGE(2); GR_STAGE(3);
+  }
+  // the read issued by the last item (a stage never multiplied) and this wave's re-fetches land before it leaves
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+               : "+v"(a0[0]), "+v"(a1[0]), "+v"(b01[0]), "+v"(b23[0]) :: "memory");
+#undef GR_STAGE
+#undef GR_MFMA8
+
+  // Epilogue through LDS (the ring is drained: every wave waited for its DMA and holds no operand in flight): the
+  // tile goes to LDS in accumulator order and comes back as 16-byte row pieces in a ROLLED loop -- the
+  // element epilogue (a switch over epilogue kinds and activations) exists four times in the code instead of 32
+  // times per accumulator as in k_gemm128, whose unrolled form is ~100 KB of instructions that every wave walks
+  // through once, one instruction-cache miss after the other (mask 15 of tools/gemm_ring_ablate.sh: 22 us of an
+  // 83 us launch were outside the stage loop).
+  __syncthreads();
+  float* const ct = (float*)gr_lds;                 // [128][GR_LDC]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f32x16& v = i ? acc1 : acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      ct[(wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi) * GR_LDC + wn * 32 + l31] = v[r];
+  }
+  __syncthreads();
+  const int cq = 4 * (tid & 31), n = n0 + cq;       // this thread's column quad (N % 4 == 0: inside or outside as a whole)
+  if (n < g.N) {
+#pragma unroll 1
+    for (int row = tid >> 5; row < G2_TM; row += 16) {
+      const int m = m0 + row;
+      if (m >= g.M) break;
+      const f32x4 v = *(const f32x4*)(ct + row * GR_LDC + cq);
+      if (g.epilogue == 1 && g.act == VMC_ACT_RELU_ && !g.dact_out) {          // the sampler's case: relu(v + bias), one 16-byte store
+        const f32x4 b = *(const f32x4*)(g.bias + n);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = vmc_act<VMC_ACT_RELU_>(v[e] + b[e]);
+        *(f32x4*)(g.C + (long long)m * g.ldc + n) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gemm_epilogue(g, g.C, m, n + e, v[e]);
+      }
+    }
+  }
+}
+
+static bool gemm128_layout_ok(const GemmArgs& g);
+static bool gemm_ring_ok(const GemmArgs& g) {
+  return gemm128_layout_ok(g) && g.N >= G2_TN && g.K % (GR_RING * GR_TK) == 0 &&
+         g.sam * 128 < (1LL << 29) && g.sbk * 4 + g.N < (1LL << 29);
+}
+
 // CGS_VMC_GEMM128=0: the 64 x 64 kernel for every shape (A/B measurements); =2: the 128 x 128 kernel
-// wherever its operand layout allows, whatever the grid size (tests: small shapes with ragged edges).
-// Read at every launch so that a test can compare the two in one process.
+// wherever its operand layout allows, whatever the grid size (tests: small shapes with ragged edges); =3: the
+// same with eight waves; =4: the round-4 rule (eight-wave form never taken).
+// Read at every launch so that a test can compare the tilings in one process.
 static int gemm128_mode() { const char* e = getenv("CGS_VMC_GEMM128"); return e ? atoi(e) : 1; }
 static bool gemm128_layout_ok(const GemmArgs& g) {
   return g.sak == 1 && g.sbn == 1 && g.splitk <= 1 && !g.dual && !g.ones_row && !g.kscale &&
@@ -975,12 +1220,19 @@ static bool gemm128_layout_ok(const GemmArgs& g) {
          g.sam % 4 == 0 && g.sbk % 4 == 0 && ((size_t)g.A & 15) == 0 && ((size_t)g.B & 15) == 0 &&
          (long long)g.K * g.sbk < (1LL << 31);
 }
-static bool gemm128_applies(const GemmArgs& g) {
+// 0: k_gemm; 4 / 8: k_gemm128 with that many waves; 16: k_gemm_ring
+static int gemm128_waves(const GemmArgs& g) {
   const int mode = gemm128_mode();
-  // at least four 4-wave workgroups per CU (256 CUs): with fewer the 64 x 64 tiles' larger grid hides
-  // latency better (4096 x 1024 x 1024, the sampler's shape: 86 us against 111 us with 256 large tiles)
-  return mode != 0 && gemm128_layout_ok(g) && g.N >= G2_TN &&
-         (mode == 2 || (long long)((g.M + G2_TM - 1) / G2_TM) * ((g.N + G2_TN - 1) / G2_TN) >= 1024);
+  if (mode == 0 || !gemm128_layout_ok(g) || g.N < G2_TN) return 0;
+  if (mode == 2) return 4;
+  if (mode == 3) return 8;
+  if (mode == 5) return gemm_ring_ok(g) ? 16 : 0;
+  const long long tiles = (long long)((g.M + G2_TM - 1) / G2_TM) * ((g.N + G2_TN - 1) / G2_TN);
+  // at least four 4-wave workgroups per CU (256 CUs) for the 4-wave form; one workgroup per CU from
+  // GEMM128_MIN8 tiles on (below that the 64 x 64 tiles' larger grid fills more CUs)
+  if (tiles >= 1024) return 4;
+  if (mode == 4 || tiles < GEMM128_MIN8 || tiles > 512) return 0;
+  return mode == 6 ? 8 : (gemm_ring_ok(g) ? 16 : 0);
 }
 
 __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
@@ -998,10 +1250,16 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
-  if (gemm128_applies(g)) {
+  if (const int waves = gemm128_waves(g)) {
     const int tiles_m = (g.M + G2_TM - 1) / G2_TM, tiles_n = (g.N + G2_TN - 1) / G2_TN;
     const int blocks = ((tiles_m + 7) / 8) * 8 * tiles_n;      // whole rounds of the eight XCDs
-    hipLaunchKernelGGL(k_gemm128<G2_TN>, dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);
+    if (waves == 16) {
+      // (the opt-in is per device: set on every launch, grad.hip launch_wgrad)
+      hipError_t e = hipFuncSetAttribute((const void*)k_gemm_ring, hipFuncAttributeMaxDynamicSharedMemorySize, GR_LDS);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k_gemm_ring, dim3(blocks), dim3(512), GR_LDS, s, g, tiles_m, tiles_n);
+    } else if (waves == 8) hipLaunchKernelGGL((k_gemm128<G2_TN, 8>), dim3(blocks), dim3(512), 0, s, g, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((k_gemm128<G2_TN, 4>), dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);
     return hipGetLastError();
   }
   const int m_rows = g.ones_row ? g.M - 1 : g.M;

@@ -67,7 +67,7 @@ struct vmc_ctx {
   bool split = false;             // CGS_VMC_SPLIT_BF16 >= 1: the row kernel on the BF16 matrix cores (3 x bf16 split, EXPERIMENT)
   bool split_sweep = false;       // CGS_VMC_SPLIT_BF16 == 2: the sampler's H x H layers too (k_sweep16s)
   long long wrows = 0;     // rows of the two activation row buffers
-  float *wbuf[2] = {nullptr, nullptr}, *wide_zc = nullptr, *wide_lnew = nullptr, *wide_u = nullptr, *wide_zero = nullptr;
+  float *wbuf[2] = {nullptr, nullptr}, *wide_u = nullptr, *wide_zero = nullptr;
   int *wide_iup = nullptr, *wide_idn = nullptr;
   int hact = VMC_ACT_RELU_;  // hidden activation (layers.NONLINEARITIES id)
   int oact = VMC_ACT_EXP_;   // output activation; exp: psi = exp(x - shift), else psi = g(x), no shift
@@ -811,7 +811,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (wide) {
     c->wrows = B > 131072 ? B : 131072;
     CA(dalloc(&c->wbuf[0], c->wrows * Hp)); CA(dalloc(&c->wbuf[1], c->wrows * Hp));
-    CA(dalloc(&c->wide_zc, B * Hp)); CA(dalloc(&c->wide_lnew, B)); CA(dalloc(&c->wide_u, B));
+    CA(dalloc(&c->wide_u, B));
     CA(dalloc(&c->wide_iup, B)); CA(dalloc(&c->wide_idn, B)); CA(dalloc(&c->wide_zero, Hp));
     CA(hipMemsetAsync(c->wide_zero, 0, Hp * sizeof(float), c->stream));
   }
@@ -861,7 +861,7 @@ void vmc_destroy(vmc_ctx* c) {
   if (c->act_all) hipFree(c->act_all);
   if (c->act_alt) hipFree(c->act_alt);
   for (float* q : {c->oscale, c->dact_all, c->dact_alt, c->ctape, c->cdelta, c->cws, c->wbuf[0], c->wbuf[1],
-                   c->wide_zc, c->wide_lnew, c->wide_u, c->wide_zero}) if (q) hipFree(q);
+                   c->wide_u, c->wide_zero}) if (q) hipFree(q);
   for (int* q : {c->wide_iup, c->wide_idn}) if (q) hipFree(q);
   void* ptrs[] = {c->configs, c->configs_alt, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
@@ -1043,17 +1043,28 @@ static int run_sweep_wide(vmc_ctx* c, long long n_steps, bool injected, bool dbg
   PROPAGATE(ensure_cache(c, VMC_PSI));
   if (count_accepted) HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), c->stream));
   Timer t(c, "sweep");
+  // Per step ONE k_wide_step launch (accept the move in flight, propose the next, candidate activations) and
+  // the H x H layers as GEMMs; a segment of steps ends with an accept-only launch.
+  WideStepArgs w; memset((void*)&w, 0, sizeof(w));
+  w.configs = c->configs; w.z1 = p.z1; w.w1p = p.w1p; w.a_last = c->wbuf[NH & 1]; w.a0 = c->wbuf[0];
+  w.wout = p.woutp; w.bout = p.bout; w.logit = p.logit;
+  w.iup = c->wide_iup; w.idn = c->wide_idn; w.u = c->wide_u;
+  if (injected) { w.inj_up = c->inj_up; w.inj_dn = c->inj_dn; w.inj_u = c->inj_u; w.acc_mask = c->acc_mask; }
+  w.accepted = c->d_accepted;
+  if (c->rbm) { w.onsite = p.onsite; w.won = p.won; }
+  w.B = B; w.N = N; w.H = H; w.Hp = Hp; w.act = wide_stage_act(c, 0); w.oact = c->oact;
+  w.seed_lo = seed_lo; w.seed_hi = seed_hi; w.chain_offset = c->d.chain_offset;
+  bool in_flight = false;                          // a proposal whose last-layer activations are in a_last
   for (long long st = 0; st < n_steps; ++st) {
     if (st > 0 && st % 128 == 0) {   // z1 is updated incrementally: re-derive it from the spins now and then
+      w.do_accept = 1; w.do_propose = 0;
+      HIPCHK(c, launch_wide_step(c->stream, w));
+      in_flight = false;
       p.cache_valid = false;
       PROPAGATE(ensure_cache(c, VMC_PSI));
     }
-    HIPCHK(c, launch_wide_propose(c->stream, c->configs, B, N, seed_lo, seed_hi, c->d.chain_offset,
-                                  step0 + (unsigned long long)st, injected ? c->inj_up : nullptr,
-                                  injected ? c->inj_dn : nullptr, injected ? c->inj_u : nullptr, c->wide_iup,
-                                  c->wide_idn, c->wide_u));
-    HIPCHK(c, launch_wide_build(c->stream, p.z1, p.w1p, c->wide_iup, c->wide_idn, B, Hp, wide_stage_act(c, 0),
-                                c->wide_zc, c->wbuf[0]));
+    w.do_accept = in_flight ? 1 : 0; w.do_propose = 1; w.step = step0 + (unsigned long long)st;
+    HIPCHK(c, launch_wide_step(c->stream, w));
     for (int l = 1; l <= NH; ++l) {
       GemmArgs g; memset(&g, 0, sizeof(g));
       g.A = c->wbuf[(l - 1) & 1]; g.sam = Hp; g.sak = 1;
@@ -1062,12 +1073,11 @@ static int run_sweep_wide(vmc_ctx* c, long long n_steps, bool injected, bool dbg
       g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1; g.act = wide_stage_act(c, l);
       HIPCHK(c, launch_gemm(c->stream, g));
     }
-    const WideOnsite on{c->rbm ? p.onsite : nullptr, p.won, nullptr, c->wide_iup, c->wide_idn};
-    HIPCHK(c, launch_wide_out(c->stream, c->wbuf[NH & 1], p.woutp, p.bout, B, H, Hp, c->rowinfo_id, 0, c->half_jx,
-                              p.logit, c->oact, false, c->wide_lnew, on));
-    HIPCHK(c, launch_wide_accept(c->stream, c->configs, p.z1, c->wide_zc, p.logit, c->wide_lnew, c->wide_iup,
-                                 c->wide_idn, c->wide_u, B, N, Hp, c->oact, c->d_accepted,
-                                 injected ? c->acc_mask : nullptr, c->rbm ? p.onsite : nullptr, p.won));
+    in_flight = true;
+  }
+  if (in_flight) {
+    w.do_accept = 1; w.do_propose = 0;
+    HIPCHK(c, launch_wide_step(c->stream, w));
   }
   c->acts_valid = false;
   c->acc_since_sweep = false;

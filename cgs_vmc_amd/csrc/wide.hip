@@ -127,70 +127,150 @@ __global__ __launch_bounds__(256) void k_wide_propose(const float* __restrict__ 
   }
 }
 
-// candidate first layer of every chain: zc = z1 + 2 (W1[i_dn] - W1[i_up]), a0 = f(zc)
-__global__ void k_wide_build(const float* __restrict__ z1, const float* __restrict__ w1p,
-                             const int* __restrict__ iup, const int* __restrict__ idn, int B, int Hp, int act,
-                             float* __restrict__ zc, float* __restrict__ a0) {
-  const int q = Hp >> 2;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long long)B * q;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(idx / q), c4 = (int)(idx % q) * 4;
-    f32x4 z = *(const f32x4*)(z1 + (long long)c * Hp + c4);
-    const f32x4 x = *(const f32x4*)(w1p + (long long)idn[c] * Hp + c4);
-    const f32x4 y = *(const f32x4*)(w1p + (long long)iup[c] * Hp + c4);
-    f32x4 a;
+// One launch per mc_step of the general sampler (graph_builders.py:38-89), one wave per chain, sixteen chains
+// per workgroup.  In program order:
+//  (1) Metropolis test of the PREVIOUS step's proposal (`do_accept`): logit' = a_last[chain] . w_out + b_out
+//      (+ the RBM on-site term) in the arithmetic of k_wide_out -- double accumulation, lane h % 64 -- and the
+//      accept rule of graph_builders.py:75-88;
+//  (2) this step's proposal (`do_propose`, graph_builders.py:59-65) from the chain as it stands AFTER (1): the
+//      flipped spins are patched into the loaded values, the stores to `configs` are issued behind the loads;
+//  (3) one pass over the chain's first-layer row: z1 += 2 (W1[i_dn] - W1[i_up]) of the accepted move (the
+//      same fmaf the candidate was built with: no second copy of the candidate rows is kept), then the new
+//      candidate's activations a0 = f(z1 + 2 (W1[i_dn'] - W1[i_up'])) for the GEMMs that follow.
+// `a_last` and `a0` may be the same buffer (an even number of H x H layers): a wave reads its row of a_last
+// in (1), whose result (3) depends on, and writes the same row.  One atomic per workgroup carries the accept
+// count (one per accepted chain serialised ~2000 atomics on one address: 54 us per step at 4096 chains).
+// Round 5: was four launches (propose, build, out, accept: 33 us + four launch gaps per step at 4096 x 1024).
+#define WIDE_STEP_CHAINS 16
+__global__ __launch_bounds__(64 * WIDE_STEP_CHAINS) void k_wide_step(WideStepArgs s) {
+  __shared__ int s_acc[WIDE_STEP_CHAINS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * WIDE_STEP_CHAINS + w;
+  const bool live = c < s.B;
+  bool acc = false;
+  int pu = 0, pd = 0;
+  float lnew = 0.f, onew = 0.f;
+  if (live && s.do_accept) {
+    const float* a = s.a_last + (long long)c * s.Hp;
+    pu = s.iup[c]; pd = s.idn[c];
+    double sd = 0.0;
+    for (int h0 = lane; h0 < s.H; h0 += 512) {        // the order of k_wide_out (h = lane, lane + 64, ...), eight loads in flight
+      float av[8], wv[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { z[e] = fmaf(2.f, x[e] - y[e], z[e]); a[e] = vmc_act_rt(act, z[e]); }
-    *(f32x4*)(zc + (long long)c * Hp + c4) = z;
-    *(f32x4*)(a0 + (long long)c * Hp + c4) = a;
-  }
-}
-
-// Metropolis test and commit (graph_builders.py:75-88).  A workgroup takes 16 chains: 16 threads decide and
-// commit the scalars, one atomic per workgroup carries the accept count (one per accepted chain serialised
-// ~2000 atomics on one address: 54 us per step at 4096 chains), then all threads copy the accepted chains'
-// candidate first layer in 16-byte pieces.
-#define WIDE_ACC_CHAINS 16
-__global__ __launch_bounds__(256) void k_wide_accept(float* __restrict__ configs, float* __restrict__ z1,
-                                                     const float* __restrict__ zc, float* __restrict__ logit,
-                                                     const float* __restrict__ lnew, const int* __restrict__ iup,
-                                                     const int* __restrict__ idn, const float* __restrict__ u,
-                                                     int B, int N, int Hp, int oact,
-                                                     unsigned long long* __restrict__ accepted,
-                                                     unsigned char* __restrict__ acc_mask,
-                                                     float* __restrict__ onsite, const float* __restrict__ won) {
-  __shared__ int s_acc[WIDE_ACC_CHAINS];
-  const int c0 = blockIdx.x * WIDE_ACC_CHAINS;
-  if (threadIdx.x < WIDE_ACC_CHAINS) {
-    const int c = c0 + threadIdx.x;
-    bool acc = false;
-    if (c < B) {
-      const float uu = u[c];
-      acc = vmc_out_accept(oact, lnew[c], logit[c], uu, 0.5f * __logf(uu));
-      if (acc) {
-        configs[(long long)c * N + idn[c]] += 2.f;      // graph_builders.py:67-71
-        configs[(long long)c * N + iup[c]] -= 2.f;
-        logit[c] = lnew[c];
-        if (onsite) onsite[c] = fmaf(2.f, won[idn[c]] - won[iup[c]], onsite[c]);
-      }
-      if (acc_mask) acc_mask[c] = acc ? 1 : 0;
+      for (int i = 0; i < 8; ++i) { const int h = min(h0 + 64 * i, s.H - 1); av[i] = a[h]; wv[i] = s.wout[h]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (h0 + 64 * i < s.H) sd += (double)av[i] * (double)wv[i];
     }
-    s_acc[threadIdx.x] = acc ? 1 : 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sd += __shfl_xor(sd, m);
+    lnew = (float)sd + s.bout[0];
+    if (s.onsite) {   // RestrictedBoltzmannNetwork: + x' . w_on (wavefunctions.py:436), rank-2 in the exchange
+      onew = fmaf(2.f, s.won[pd] - s.won[pu], s.onsite[c]);
+      lnew += onew;
+    }
+    const float uu = s.u[c];
+    acc = vmc_out_accept(s.oact, lnew, s.logit[c], uu, 0.5f * __logf(uu));
+  }
+  acc = __builtin_amdgcn_readfirstlane(acc ? 1 : 0) != 0;
+  int nu = 0, nd = 0;
+  float nuu = 0.f;
+  if (live && s.do_propose) {
+    if (s.inj_up) {
+      nu = s.inj_up[c]; nd = s.inj_dn[c]; nuu = s.inj_u[c];
+    } else {
+      const float* x = s.configs + (long long)c * s.N;
+      const uint2 key = make_uint2(s.seed_lo, s.seed_hi);
+      const uint32_t gid = (uint32_t)(s.chain_offset + c);
+      float best_hi = -INFINITY, best_lo = INFINITY;
+      int idx_hi = 0x7fffffff, idx_lo = 0x7fffffff;
+      const int nblk = (s.N + 3) >> 2;
+      for (int b = lane; b < nblk; b += 64) {
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)b, gid, (uint32_t)s.step, (uint32_t)(s.step >> 32)), key);
+        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * b + e;
+          if (i < s.N) {
+            float xv = x[i];
+            if (acc) xv += i == pd ? 2.f : (i == pu ? -2.f : 0.f);   // graph_builders.py:67-71, not stored yet
+            const float v = xv * u32_to_uniform(rr[e]);
+            if (v > best_hi) { best_hi = v; idx_hi = i; }
+            if (v < best_lo) { best_lo = v; idx_lo = i; }
+          }
+        }
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const float oh = __shfl_xor(best_hi, d); const int ih = __shfl_xor(idx_hi, d);
+        if (oh > best_hi || (oh == best_hi && ih < idx_hi)) { best_hi = oh; idx_hi = ih; }
+        const float ol = __shfl_xor(best_lo, d); const int il = __shfl_xor(idx_lo, d);
+        if (ol < best_lo || (ol == best_lo && il < idx_lo)) { best_lo = ol; idx_lo = il; }
+      }
+      const uint4 ra = philox4x32_10(make_uint4(VMC_ACCEPT_BLOCK, gid, (uint32_t)s.step, (uint32_t)(s.step >> 32)), key);
+      nu = idx_hi; nd = idx_lo; nuu = u32_to_uniform(ra.x);
+    }
+    nu = __builtin_amdgcn_readfirstlane(nu); nd = __builtin_amdgcn_readfirstlane(nd);
+  }
+  if (live && lane == 0) {          // (behind every load of this chain's spins and of its previous proposal)
+    if (acc) {
+      s.configs[(long long)c * s.N + pd] += 2.f;
+      s.configs[(long long)c * s.N + pu] -= 2.f;
+      s.logit[c] = lnew;
+      if (s.onsite) s.onsite[c] = onew;
+    }
+    if (s.do_accept && s.acc_mask) s.acc_mask[c] = acc ? 1 : 0;
+    if (s.do_propose) { s.iup[c] = nu; s.idn[c] = nd; s.u[c] = nuu; }
+  }
+  if (lane == 0) s_acc[w] = acc ? 1 : 0;
+  if (live && (acc || s.do_propose)) {
+    float* z1 = s.z1 + (long long)c * s.Hp;
+    float* a0 = s.a0 + (long long)c * s.Hp;
+    const float* xo = s.w1p + (long long)pd * s.Hp; const float* yo = s.w1p + (long long)pu * s.Hp;
+    const float* xn = s.w1p + (long long)nd * s.Hp; const float* yn = s.w1p + (long long)nu * s.Hp;
+    // 1024 units at a time: every load of a block is issued before its first store (the stores may alias the
+    // loads as far as the compiler knows: it would serialise a load -- store -- load chain per 16 bytes)
+    for (int base = 4 * lane; base < s.Hp; base += 1024) {
+      f32x4 z[4], x[4], y[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c4 = min(base + 256 * i, s.Hp - 4);               // (clamped: unconditional loads)
+        z[i] = *(const f32x4*)(z1 + c4);
+        if (acc) { x[i] = *(const f32x4*)(xo + c4); y[i] = *(const f32x4*)(yo + c4); }
+      }
+      if (acc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[i][e] = fmaf(2.f, x[i][e] - y[i][e], z[i][e]);
+      }
+      f32x4 a[4];
+      if (s.do_propose) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c4 = min(base + 256 * i, s.Hp - 4);
+          x[i] = *(const f32x4*)(xn + c4); y[i] = *(const f32x4*)(yn + c4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[i][e] = vmc_act_rt(s.act, fmaf(2.f, x[i][e] - y[i][e], z[i][e]));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c4 = base + 256 * i;
+        if (c4 < s.Hp) {
+          if (acc) *(f32x4*)(z1 + c4) = z[i];
+          if (s.do_propose) *(f32x4*)(a0 + c4) = a[i];
+        }
+      }
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && s.do_accept) {
     int n = 0;
 #pragma unroll
-    for (int i = 0; i < WIDE_ACC_CHAINS; ++i) n += s_acc[i];
-    if (n) atomicAdd(accepted, (unsigned long long)n);
-  }
-  const int q = Hp >> 2;
-  for (int i = threadIdx.x; i < WIDE_ACC_CHAINS * q; i += 256) {
-    const int s = i / q, c4 = (i - s * q) * 4;
-    if (s_acc[s]) {
-      const long long o = (long long)(c0 + s) * Hp + c4;
-      *(f32x4*)(z1 + o) = *(const f32x4*)(zc + o);
-    }
+    for (int i = 0; i < WIDE_STEP_CHAINS; ++i) n += s_acc[i];
+    if (n) atomicAdd(s.accepted, (unsigned long long)n);
   }
 }
 
@@ -237,19 +317,9 @@ hipError_t launch_wide_propose(hipStream_t s, const float* configs, int B, int N
   return hipGetLastError();
 }
 
-hipError_t launch_wide_build(hipStream_t s, const float* z1, const float* w1p, const int* iup, const int* idn,
-                             int B, int Hp, int act, float* zc, float* a0) {
-  hipLaunchKernelGGL(k_wide_build, dim3(blocks_for((long long)B * (Hp / 4))), dim3(256), 0, s, z1, w1p, iup, idn,
-                     B, Hp, act, zc, a0);
-  return hipGetLastError();
-}
-
-hipError_t launch_wide_accept(hipStream_t s, float* configs, float* z1, const float* zc, float* logit,
-                              const float* lnew, const int* iup, const int* idn, const float* u, int B, int N,
-                              int Hp, int oact, unsigned long long* accepted, unsigned char* acc_mask,
-                              float* onsite, const float* won) {
-  hipLaunchKernelGGL(k_wide_accept, dim3((B + WIDE_ACC_CHAINS - 1) / WIDE_ACC_CHAINS), dim3(256), 0, s, configs, z1, zc, logit, lnew, iup, idn,
-                     u, B, N, Hp, oact, accepted, acc_mask, onsite, won);
+hipError_t launch_wide_step(hipStream_t st, const WideStepArgs& s) {
+  if (s.B <= 0 || (!s.do_accept && !s.do_propose)) return hipSuccess;
+  hipLaunchKernelGGL(k_wide_step, dim3((s.B + WIDE_STEP_CHAINS - 1) / WIDE_STEP_CHAINS), dim3(64 * WIDE_STEP_CHAINS), 0, st, s);
   return hipGetLastError();
 }
 

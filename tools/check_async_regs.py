@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Static check of k_tail16r's one asynchronous register hand-over (cgs_vmc_amd/csrc/tail_split.hip, LDS_STEP).
+"""Static check of the asynchronous register hand-overs of k_tail16r (cgs_vmc_amd/csrc/tail_split.hip, LDS_STEP)
+and k_gemm_ring (cgs_vmc_amd/csrc/grad.hip, GR_STEP: two ds_read_b128 + two ds_read2st64_b32 per statement).
 
 An LDS_STEP statement issues three ds_read_b128 into the register set of the NEXT item and only the following
 LDS_STEP waits for them (s_waitcnt lgkmcnt(0) at its head).  The compiler believes the destination registers valid
@@ -17,7 +18,10 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, 'cgs_vmc_amd', 'csrc', 'tail_split.hip')
+CSRC = os.path.join(ROOT, 'cgs_vmc_amd', 'csrc')
+# source, kernel-name fragment of the mangled symbol, instantiations expected, in-flight windows expected per instantiation
+TARGETS = [('tail_split.hip', 'k_tail16r', 2, 2 * 128), ('grad.hip', 'k_gemm_ring', 1, 17)]
+READS = ('ds_read_b128', 'ds_read2st64_b32')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
 REG_RANGE = re.compile(r'\b([va])\[(\d+):(\d+)\]')
@@ -34,18 +38,19 @@ def regs_of(text):
   return out
 
 
-def assembly():
+def assembly(src):
   with tempfile.TemporaryDirectory() as d:
-    out = os.path.join(d, 'tail_split.s')
-    cmd = [HIPCC, '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '--cuda-device-only', '-S', SRC, '-o', out]
-    subprocess.run(cmd, check=True, cwd=os.path.dirname(SRC))
+    out = os.path.join(d, 'out.s')
+    cmd = [HIPCC, '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '--cuda-device-only', '-S',
+           os.path.join(CSRC, src), '-o', out]
+    subprocess.run(cmd, check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
     return open(out).read()
 
 
-def kernels(text):
+def kernels(text, fragment):
   cur, name = [], None
   for line in text.splitlines():
-    m = re.match(r'^(_Z\w*k_tail16r\w*):', line)
+    m = re.match(r'^(_Z\w*' + fragment + r'\w*):', line)
     if m:
       name, cur = m.group(1), []
       continue
@@ -70,7 +75,7 @@ def check(name, lines):
       while j < n and not lines[j].strip().startswith(';;#ASMEND'):
         block.append(lines[j].strip())
         j += 1
-      reads = [b for b in block if b.startswith('ds_read_b128')]
+      reads = [b for b in block if b.startswith(READS)]
       waits = any(b.startswith('s_waitcnt') and 'lgkmcnt(0)' in b for b in block)
       if waits and inflight is not None:
         inflight = None                                  # the window closes at this block's wait
@@ -82,7 +87,7 @@ def check(name, lines):
           dst |= regs_of(b.split(',')[0])
         wait_after = False
         for b in block:
-          if b.startswith('ds_read_b128'):
+          if b.startswith(READS):
             wait_after = False
           elif b.startswith('s_waitcnt') and 'lgkmcnt(0)' in b:
             wait_after = True
@@ -102,19 +107,23 @@ def check(name, lines):
 
 def main():
   keep = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == '--keep' else None
-  text = assembly()
-  if keep:
-    open(keep, 'w').write(text)
   total, bad, seen = 0, [], 0
-  for name, lines in kernels(text):
-    seen += 1
-    w, b = check(name, lines)
-    total += w
-    bad += b
-  if seen != 2 or total < 2 * 2 * 128:
-    print('check_async_regs: expected both k_tail16r instantiations with >= 256 windows each, saw {} kernels, {} windows'
-          .format(seen, total))
-    return 2
+  for src, fragment, n_inst, n_windows in TARGETS:
+    text = assembly(src)
+    if keep:
+      open(keep + '.' + src + '.s', 'w').write(text)
+    here, windows = 0, 0
+    for name, lines in kernels(text, fragment):
+      here += 1
+      w, b = check(name, lines)
+      windows += w
+      bad += b
+    if here != n_inst or windows < n_inst * n_windows:
+      print('check_async_regs: {}: expected {} instantiation(s) of {} with >= {} windows each, saw {} kernels, {} windows'
+            .format(src, n_inst, fragment, n_windows, here, windows))
+      return 2
+    seen += here
+    total += windows
   for name, line, issued, code, regs in bad[:20]:
     print('{}: line {} touches {} in flight since the asm block at line {}: {}'.format(name, line, regs, issued, code))
   print('check_async_regs: {} kernels, {} in-flight windows, {} violations'.format(seen, total, len(bad)))
