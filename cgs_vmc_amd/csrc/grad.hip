@@ -849,6 +849,31 @@ void wgrad_fill_problem(void* dst, int index, const float* A, long long lda, con
   p.tile0 = tile0; p.tiles_n = (n_out + WG_TN - 1) / WG_TN;
 }
 
+// The output tile of k_gemm128 / k_gemm_ring from its LDS image ct[128][ldt] (rows m0 .., columns n0 ..): thread
+// tid of NT takes one column quad (N % 4 == 0: inside or outside as a whole) of every (NT / 32)-th row, in a
+// ROLLED loop, so that the element epilogue exists four times in the code.
+template <int NT>
+__device__ __forceinline__ void gemm_tile_epilogue(const GemmArgs& g, const float* ct, int ldt, int m0, int n0, int tid) {
+  const int cq = 4 * (tid & 31), n = n0 + cq;
+  if (n >= g.N) return;
+#pragma unroll 1
+  for (int row = tid >> 5; row < 128; row += NT / 32) {
+    const int m = m0 + row;
+    if (m >= g.M) break;
+    const f32x4 v = *(const f32x4*)(ct + row * ldt + cq);
+    if (g.epilogue == 1 && g.act == VMC_ACT_RELU_ && !g.dact_out) {   // the common case: relu(v + bias), one 16-byte store
+      const f32x4 b = *(const f32x4*)(g.bias + n);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = vmc_act<VMC_ACT_RELU_>(v[e] + b[e]);
+      *(f32x4*)(g.C + (long long)m * g.ldc + n) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gemm_epilogue(g, g.C, m, n + e, v[e]);
+    }
+  }
+}
+
 // ------------------------------------------------------------------- GEMM, large forward shape
 // C[M,N] = epilogue(A[M,K] B[K,N]) for the shape the general path of wide.hip spends its time in: A = a
 // block of materialised activation rows (k contiguous), B = a weight matrix [K][N] (n contiguous), M in
@@ -866,46 +891,46 @@ void wgrad_fill_problem(void* dst, int index, const float* A, long long lda, con
 #define G2_TN 128
 #define G2_TK 16
 #define G2_LD 132
-#define GEMM128_MIN8 160
+#define GEMM_RING_MIN 160
 // TN = 128.  (TN = 64 -- 128 x 64 tiles for grids the square tile does not fill the chip with -- was measured
 // on the sampler's 4096 x 1024 x 1024 products: 2 % over k_gemm's 64 x 64 tiles, not kept as a launch path.)
-// WAVES = 4: 2 x 2 waves of 64 x TN / 2 (two workgroups per CU; grids of >= 1024 tiles: the local-energy rows).
-// WAVES = 8: 2 x 4 waves of 64 x TN / 4 (round 5): the sampler's 4096-row products are 256 tiles, one per CU --
-// with four waves that is ONE wave per SIMD and nothing hides an LDS round trip or a barrier (111 us at
-// 4096 x 1024 x 1024 against 86 for 1024 small tiles); eight waves put two on every SIMD at 1.5 LDS operand
-// reads per MFMA (k_gemm: 2, the 4-wave form: 1).
-template <int TN, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_gemm128(GemmArgs g, int tiles_m, int tiles_n) {
-  constexpr int NT = 64 * WAVES;                     // threads
-  constexpr int WN = WAVES / 2;                      // waves along n (two along m)
-  constexpr int NJ = TN / WN / 32;                   // 32-column accumulators per wave
-  constexpr int AP = 512 / NT;                       // A tile (128 x 16): quads per thread
-  constexpr int BQ = TN / 4, BR = NT / BQ, BP = G2_TK / BR;   // B tile: quads per k row, k rows per pass, passes
-  __shared__ __attribute__((aligned(16))) float As[2][G2_TK][G2_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][G2_TK][TN + 4];
+// Epilogue (round 5): the tile goes to LDS in accumulator order and comes back as 16-byte row pieces in a ROLLED
+// loop.  The unrolled form -- the element epilogue, a switch over epilogue kinds and activations, 64 times per
+// thread -- was ~100 KB of instructions that every wave walked through once per tile (see k_gemm_ring).
+// (An eight-wave form of this kernel, 2 x 4 waves of 64 x 32, for the sampler's one-tile-per-CU grids was measured
+// in round 5: 95 us at 4096 x 1024 x 1024 against 111 with four waves and 86 for k_gemm; k_gemm_ring serves there.)
+template <int TN>
+__global__ __launch_bounds__(256, 2) void k_gemm128(GemmArgs g, int tiles_m, int tiles_n) {
+  static_assert(TN == 128, "the LDS image of the output tile is [128][128]");
+  constexpr int NJ = TN / 64;                        // 32-column accumulators per wave
+  constexpr int BQ = TN / 4, BR = 256 / BQ, BP = G2_TK / BR;   // B tile: quads per k row, k rows per pass, passes
+  // 64 KB: the two stages of both operands during the loop (33 KB), the output tile behind it
+  __shared__ __attribute__((aligned(16))) float g2_lds[G2_TM * TN];
+  float (*const As)[G2_TK][G2_LD] = (float (*)[G2_TK][G2_LD])g2_lds;
+  float (*const Bs)[G2_TK][TN + 4] = (float (*)[G2_TK][TN + 4])(g2_lds + 2 * G2_TK * G2_LD);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order: XCD x takes the row tiles x, x + 8, ..., each with all of its column tiles
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int tm = (j / tiles_n) * 8 + xcd, tn = j % tiles_n;
   if (tm >= tiles_m) return;                        // (whole workgroup; before any barrier)
   const int m0 = tm * G2_TM, n0 = tn * TN;
   const int T = (g.K + G2_TK - 1) / G2_TK;
-  // this thread's quads of the A tile (row am + NT / 4 i, k quad ak) and of the B tile (k row bk + BR i, n quad bn)
+  // this thread's two quads of the A tile (row am + 64 i, k quad ak) and of the B tile (k row bk + 8 i, n quad bn)
   const int am = tid >> 2, ak = 4 * (tid & 3);
   const int bk = tid / BQ, bn = 4 * (tid % BQ);
-  const float* ap[AP];
+  const float* ap[2];
 #pragma unroll
-  for (int i = 0; i < AP; ++i) ap[i] = g.A + (long long)min(m0 + am + (NT / 4) * i, g.M - 1) * g.sam;
+  for (int i = 0; i < 2; ++i) ap[i] = g.A + (long long)min(m0 + am + 64 * i, g.M - 1) * g.sam;
   const bool b_in = n0 + bn < g.N;                  // N % 4 == 0: a quad is inside or outside as a whole
   const float* bp = g.B + (b_in ? n0 + bn : 0);
-  f32x4 ra[AP], rb[BP];
-  const int sbk = (int)g.sbk;                       // K * sbk < 2^31 (gemm128_applies)
+  f32x4 ra[2], rb[BP];
+  const int sbk = (int)g.sbk;                       // K * sbk < 2^31 (gemm128_layout_ok)
   auto request = [&](int t) {
     const int k0 = min(t, T - 1) * G2_TK;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) ra[i] = *(const f32x4*)(ap[i] + min(k0 + ak, g.K - 4));
+    for (int i = 0; i < 2; ++i) ra[i] = *(const f32x4*)(ap[i] + min(k0 + ak, g.K - 4));
 #pragma unroll
     for (int i = 0; i < BP; ++i) rb[i] = *(const f32x4*)(bp + min(k0 + bk + BR * i, g.K - 1) * sbk);
     // (the loads stay HERE, a whole tile of MFMAs ahead of their use: without the barrier the compiler
@@ -915,10 +940,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_gemm128(Gemm
   auto stage = [&](int t) {
     const int k0 = t * G2_TK, st = t & 1;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
+    for (int i = 0; i < 2; ++i) {
       const bool a_ok = k0 + ak < g.K;              // K % 4 == 0
 #pragma unroll
-      for (int e = 0; e < 4; ++e) As[st][ak + e][am + (NT / 4) * i] = a_ok ? ra[i][e] : 0.f;
+      for (int e = 0; e < 4; ++e) As[st][ak + e][am + 64 * i] = a_ok ? ra[i][e] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
@@ -946,7 +971,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_gemm128(Gemm
 #pragma unroll
       for (int i = 0; i < 2; ++i) a2[i] = As[st][kk + hi][wm * 64 + 32 * i + l31];
 #pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) b2[jj] = Bs[st][kk + hi][wn * (TN / WN) + 32 * jj + l31];
+      for (int jj = 0; jj < NJ; ++jj) b2[jj] = Bs[st][kk + hi][wn * (TN / 2) + 32 * jj + l31];
     };
     operands(0, av[0], bv[0]);
 #pragma unroll
@@ -962,16 +987,16 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_gemm128(Gemm
     if (t + 1 < T) stage(t + 1);                    // uniform
     __syncthreads();
   }
-  auto finish = [&](const f32x16& v, int i, int jj) {
-    const int n = n0 + wn * (TN / WN) + 32 * jj + l31;
+  // (the barrier that ended the loop: every wave has read its last operands; the stages may be overwritten)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      if (m < g.M && n < g.N) gemm_epilogue(g, g.C, m, n, v[r]);
-    }
-  };
-  finish(acc[0][0], 0, 0); finish(acc[1][0], 1, 0);
-  if constexpr (NJ == 2) { finish(acc[0][1], 0, 1); finish(acc[1][1], 1, 1); }
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        g2_lds[(wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi) * TN + wn * (TN / 2) + 32 * jj + l31] = acc[i][jj][r];
+  __syncthreads();
+  gemm_tile_epilogue<256>(g, g2_lds, TN, m0, n0, tid);
 }
 
 // ------------------------------------------------------------------- GEMM, one tile per CU (round 5)
@@ -1006,7 +1031,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void k_gemm128(Gemm
 //   The stages behind the last are re-fetches of the last (in bounds, never read): the counts stay uniform.
 //   Every wave drains its DMA before it exits.  Rows beyond M / columns beyond N fetch a clamped row / quad
 //   and are not stored.
-// Requirements (gemm_ring_ok): the k_gemm128 layout, K % 128 == 0 (whole turns of the ring).
+// Requirements (gemm_ring_ok): the k_gemm128 layout, K % 32 == 0 (whole stages).
 #define GR_TK 32
 #define GR_RING 4
 #define GR_ABYTES (G2_TM * GR_TK * 4)
@@ -1059,6 +1084,8 @@ typedef float f32x2_gr __attribute__((ext_vector_type(2)));
 // item 3: the stage hand-over (see the protocol above) sits between the wait and the reads
 #define GR_STEP_NEXT(S, T, SLOT) GR_STEP_("s_waitcnt vmcnt(8) lgkmcnt(0)\n\t" GR_BARRIER, S, T, SLOT, 0)
 
+// WHOLE: K is a multiple of 128 -- whole turns of the ring, no stage is skipped (no branch around the MFMAs)
+template <bool WHOLE>
 __global__ __launch_bounds__(512) void k_gemm_ring(GemmArgs g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char gr_lds[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -1138,7 +1165,7 @@ __global__ __launch_bounds__(512) void k_gemm_ring(GemmArgs g, int tiles_m, int 
 
 #define GR_MFMA8(S)                                                                          \
   do {                                                                                       \
-    if (VMC_GR_ABLATE & 8) break;                                                            \
+    if ((VMC_GR_ABLATE & 8) || (!WHOLE && s_ >= T)) break;   /* (a stage behind the last: the turn is completed, nothing is added) */ \
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S][0], b01[S][0], acc0, 0, 0, 0);         \
     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[S][0], b01[S][0], acc1, 0, 0, 0);         \
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[S][1], b01[S][1], acc0, 0, 0, 0);         \
@@ -1157,7 +1184,7 @@ __global__ __launch_bounds__(512) void k_gemm_ring(GemmArgs g, int tiles_m, int 
     piece(3, s_ + 3, ((SLOT) + 3) & 3); GR_STEP(0, 1, SLOT, 3); GR_MFMA8(0);                 \
     GR_STEP_NEXT(1, 0, ((SLOT) + 1) & 3); piece(0, s_ + 4, SLOT); GR_MFMA8(1);               \
   } while (0)
-  for (int st = 0; st < T; st += GR_RING) {         // (T % GR_RING == 0: gemm_ring_ok)
+  for (int st = 0; st < T; st += GR_RING) {         // whole turns of the ring (the slot is an instruction immediate)
     GR_STAGE(0); GR_STAGE(1); GR_STAGE(2); GR_STAGE(3);
   }
   // the read issued by the last item (a stage never multiplied) and this wave's re-fetches land before it leaves
@@ -1167,11 +1194,11 @@ __global__ __launch_bounds__(512) void k_gemm_ring(GemmArgs g, int tiles_m, int 
 #undef GR_MFMA8
 
   // Epilogue through LDS (the ring is drained: every wave waited for its DMA and holds no operand in flight): the
-  // tile goes to LDS in accumulator order and comes back as 16-byte row pieces in a ROLLED loop -- the
-  // element epilogue (a switch over epilogue kinds and activations) exists four times in the code instead of 32
-  // times per accumulator as in k_gemm128, whose unrolled form is ~100 KB of instructions that every wave walks
-  // through once, one instruction-cache miss after the other (mask 15 of tools/gemm_ring_ablate.sh: 22 us of an
-  // 83 us launch were outside the stage loop).
+  // tile goes to LDS in accumulator order and comes back as 16-byte row pieces in a ROLLED loop
+  // (gemm_tile_epilogue) -- the element epilogue, a switch over epilogue kinds and activations, exists four
+  // times in the code.  Unrolled, 32 times per thread, it was ~100 KB of instructions that every wave walked
+  // through once, one instruction-cache miss after the other: 22 us of an 83 us launch were outside the stage
+  // loop (mask 15 of tools/gemm_ring_ablate.sh), 9 us with this form.
   __syncthreads();
   float* const ct = (float*)gr_lds;                 // [128][GR_LDC]
 #pragma unroll
@@ -1182,36 +1209,18 @@ __global__ __launch_bounds__(512) void k_gemm_ring(GemmArgs g, int tiles_m, int 
       ct[(wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi) * GR_LDC + wn * 32 + l31] = v[r];
   }
   __syncthreads();
-  const int cq = 4 * (tid & 31), n = n0 + cq;       // this thread's column quad (N % 4 == 0: inside or outside as a whole)
-  if (n < g.N) {
-#pragma unroll 1
-    for (int row = tid >> 5; row < G2_TM; row += 16) {
-      const int m = m0 + row;
-      if (m >= g.M) break;
-      const f32x4 v = *(const f32x4*)(ct + row * GR_LDC + cq);
-      if (g.epilogue == 1 && g.act == VMC_ACT_RELU_ && !g.dact_out) {          // the sampler's case: relu(v + bias), one 16-byte store
-        const f32x4 b = *(const f32x4*)(g.bias + n);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = vmc_act<VMC_ACT_RELU_>(v[e] + b[e]);
-        *(f32x4*)(g.C + (long long)m * g.ldc + n) = o;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) gemm_epilogue(g, g.C, m, n + e, v[e]);
-      }
-    }
-  }
+  gemm_tile_epilogue<512>(g, ct, GR_LDC, m0, n0, tid);
 }
 
 static bool gemm128_layout_ok(const GemmArgs& g);
 static bool gemm_ring_ok(const GemmArgs& g) {
-  return gemm128_layout_ok(g) && g.N >= G2_TN && g.K % (GR_RING * GR_TK) == 0 &&
+  return gemm128_layout_ok(g) && g.N >= G2_TN && g.K % GR_TK == 0 && g.K >= 4 * GR_TK &&
          g.sam * 128 < (1LL << 29) && g.sbk * 4 + g.N < (1LL << 29);
 }
 
-// CGS_VMC_GEMM128=0: the 64 x 64 kernel for every shape (A/B measurements); =2: the 128 x 128 kernel
-// wherever its operand layout allows, whatever the grid size (tests: small shapes with ragged edges); =3: the
-// same with eight waves; =4: the round-4 rule (eight-wave form never taken).
+// CGS_VMC_GEMM128=0: the 64 x 64 kernel for every shape (A/B measurements); =2: k_gemm128 wherever its operand
+// layout allows, whatever the grid size (tests: small shapes with ragged edges); =5: k_gemm_ring wherever it
+// applies; =4: the round-4 rule (k_gemm_ring never taken).
 // Read at every launch so that a test can compare the tilings in one process.
 static int gemm128_mode() { const char* e = getenv("CGS_VMC_GEMM128"); return e ? atoi(e) : 1; }
 static bool gemm128_layout_ok(const GemmArgs& g) {
@@ -1220,19 +1229,17 @@ static bool gemm128_layout_ok(const GemmArgs& g) {
          g.sam % 4 == 0 && g.sbk % 4 == 0 && ((size_t)g.A & 15) == 0 && ((size_t)g.B & 15) == 0 &&
          (long long)g.K * g.sbk < (1LL << 31);
 }
-// 0: k_gemm; 4 / 8: k_gemm128 with that many waves; 16: k_gemm_ring
-static int gemm128_waves(const GemmArgs& g) {
+// 0: k_gemm; 1: k_gemm128; 2: k_gemm_ring
+static int gemm_tiling(const GemmArgs& g) {
   const int mode = gemm128_mode();
   if (mode == 0 || !gemm128_layout_ok(g) || g.N < G2_TN) return 0;
-  if (mode == 2) return 4;
-  if (mode == 3) return 8;
-  if (mode == 5) return gemm_ring_ok(g) ? 16 : 0;
+  if (mode == 2) return 1;
+  if (mode == 5) return gemm_ring_ok(g) ? 2 : 0;
   const long long tiles = (long long)((g.M + G2_TM - 1) / G2_TM) * ((g.N + G2_TN - 1) / G2_TN);
-  // at least four 4-wave workgroups per CU (256 CUs) for the 4-wave form; one workgroup per CU from
-  // GEMM128_MIN8 tiles on (below that the 64 x 64 tiles' larger grid fills more CUs)
-  if (tiles >= 1024) return 4;
-  if (mode == 4 || tiles < GEMM128_MIN8 || tiles > 512) return 0;
-  return mode == 6 ? 8 : (gemm_ring_ok(g) ? 16 : 0);
+  // k_gemm_ring (one workgroup per CU) from GEMM_RING_MIN tiles on -- below that the 64 x 64 tiles' larger grid
+  // fills more CUs; k_gemm128 where the ring does not apply (K % 32 != 0), from four workgroups per CU on
+  if (mode != 4 && tiles >= GEMM_RING_MIN && gemm_ring_ok(g)) return 2;
+  return tiles >= 1024 ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
@@ -1250,16 +1257,20 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
-  if (const int waves = gemm128_waves(g)) {
+  if (const int tiling = gemm_tiling(g)) {
     const int tiles_m = (g.M + G2_TM - 1) / G2_TM, tiles_n = (g.N + G2_TN - 1) / G2_TN;
     const int blocks = ((tiles_m + 7) / 8) * 8 * tiles_n;      // whole rounds of the eight XCDs
-    if (waves == 16) {
-      // (the opt-in is per device: set on every launch, grad.hip launch_wgrad)
-      hipError_t e = hipFuncSetAttribute((const void*)k_gemm_ring, hipFuncAttributeMaxDynamicSharedMemorySize, GR_LDS);
+    if (tiling == 2) {
+      // (the opt-in is per device: set on every launch, as launch_wgrad does)
+      const bool whole = g.K % (GR_RING * GR_TK) == 0;
+      const void* f = whole ? (const void*)k_gemm_ring<true> : (const void*)k_gemm_ring<false>;
+      hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GR_LDS);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(k_gemm_ring, dim3(blocks), dim3(512), GR_LDS, s, g, tiles_m, tiles_n);
-    } else if (waves == 8) hipLaunchKernelGGL((k_gemm128<G2_TN, 8>), dim3(blocks), dim3(512), 0, s, g, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((k_gemm128<G2_TN, 4>), dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);
+      if (whole) hipLaunchKernelGGL(k_gemm_ring<true>, dim3(blocks), dim3(512), GR_LDS, s, g, tiles_m, tiles_n);
+      else hipLaunchKernelGGL(k_gemm_ring<false>, dim3(blocks), dim3(512), GR_LDS, s, g, tiles_m, tiles_n);
+    } else {
+      hipLaunchKernelGGL(k_gemm128<G2_TN>, dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);
+    }
     return hipGetLastError();
   }
   const int m_rows = g.ones_row ? g.M - 1 : g.M;

@@ -183,14 +183,14 @@ def test_wide_fast_and_general_path_agree(monkeypatch):
 
 
 @pytest.mark.parametrize('n,h,L,b,kind', [(16, 1000, 3, 40, 'chain'), (36, 644, 4, 33, 'torus6x6'), (10, 1024, 2, 64, 'chain'),
-                                          (16, 640, 3, 200, 'chain')])
+                                          (16, 640, 3, 200, 'chain'), (16, 800, 2, 130, 'chain')])
 def test_general_path_gemm_tilings_agree(monkeypatch, n, h, L, b, kind):
-  """The general path's H x H layers on the 128 x 128-tile kernel (k_gemm128, forced with CGS_VMC_GEMM128=2 in
-  its four-wave form -- by itself only taken for grids of >= 1024 tiles -- and with =3 in its eight-wave form
-  -- never taken by itself) and on the LDS-DMA ring kernel (k_gemm_ring, =5: wherever K is a multiple of 128,
-  i.e. the 1024- and 640-unit cases here, with row counts below and off the tile; by itself taken for 160 .. 512
-  tiles) against the oracle and against the 64 x 64-tile kernel (CGS_VMC_GEMM128=0): ragged row counts, widths
-  that are no multiple of the tile (1000, 644), K tails."""
+  """The general path's H x H layers on the 128 x 128-tile kernel (k_gemm128, forced with CGS_VMC_GEMM128=2 -- by
+  itself only taken for grids of >= 1024 tiles where the ring does not apply) and on the LDS-DMA ring kernel
+  (k_gemm_ring, =5: wherever K is a multiple of 32, i.e. the 1024-, 640- and 800-unit cases here -- 32, 20 and 25
+  stages: whole and broken turns of the four-slot ring -- with row counts below and off the tile; by itself taken
+  from 160 tiles on) against the oracle and against the 64 x 64-tile kernel (CGS_VMC_GEMM128=0): ragged
+  row counts, widths that are no multiple of the tile (1000, 644), K tails."""
   from cgs_vmc_amd.engine import VmcEngine
   rng = np.random.default_rng(3)
   theta = vo.init_params(n, h, L, rng)
@@ -200,7 +200,7 @@ def test_general_path_gemm_tilings_agree(monkeypatch, n, h, L, b, kind):
   amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
   e_ref = vo.local_value(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64)
   outs = []
-  for mode in ('2', '3', '5', '0'):
+  for mode in ('2', '5', '0'):
     monkeypatch.setenv('CGS_VMC_GEMM128', mode)
     eng = VmcEngine(n, b, L, h, seed=2024)
     assert eng.kernel_path() == 2
@@ -212,10 +212,6 @@ def test_general_path_gemm_tilings_agree(monkeypatch, n, h, L, b, kind):
     eng.mc_steps(n)
     outs.append((logit, e, eng.get_configs()))
     eng.close()
-  for o in outs[:3]:
-    _close(o[0], outs[3][0], 2e-5)
-    _close(o[1], outs[3][1], 2e-4)
-  # the two forms of k_gemm128 add the same products in the same order
-  np.testing.assert_array_equal(outs[0][0], outs[1][0])
-  np.testing.assert_array_equal(outs[0][1], outs[1][1])
-  np.testing.assert_array_equal(outs[0][2], outs[1][2])
+  for o in outs[:2]:
+    _close(o[0], outs[2][0], 2e-5)
+    _close(o[1], outs[2][1], 2e-4)
