@@ -302,11 +302,19 @@ struct GemmArgs {
   float* dact_out;                      // epilogue 1: also store f'(z) (layout of C) or nullptr
   int epilogue;                         // 0 none, 1 f(v + bias), 3 accumulate (C += ), 4 bias,
                                         // 5 f' (.) (v + bias), 6 f' (.) (C + v + bias), 7 tanh(v + bias), 8 C + v + bias,
-                                        // 9 mask (.) (v + bias) with mask = a stored f'(z)
+                                        // 9 mask (.) (v + bias) with mask = a stored f'(z),
+                                        // 10 row dot: nothing is stored to C; dot_out[tn * M + m] = the sum over the 128
+                                        //    columns of column tile tn of f(v + bias) * dot_w[n], in double (the output
+                                        //    layer's dot product folded into the last H x H layer; only the 128 x 128-tile
+                                        //    kernels have it: ask gemm_rowdot_ok)
+  const float* dot_w; double* dot_out;  // epilogue 10
   int splitk;                           // >= 1
   float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
 };
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
+// whether launch_gemm takes this product (epilogue 10 set) with a kernel that has the row-dot epilogue
+bool gemm_rowdot_ok(const GemmArgs& g);
+inline int gemm_rowdot_tiles(int N) { return (N + 127) / 128; }
 // All weight gradients of one accumulate call -- [a_{l-1} | 1]^T [delta_l | w (.) delta_l] of every
 // layer and the scalar accumulators -- in ONE launch (k_wgrad, grad.hip; tiles,
 // slices and block order: plan.hpp).  The problem table lives in device memory and is built once per
@@ -394,6 +402,10 @@ hipError_t launch_wide_out(hipStream_t s, const float* a, const float* wout, con
                            int H, int Hp, const int2* rowinfo, long long row0, const float* half_jx,
                            const float* logit_base, int oact, bool ratio, float* out,
                            const WideOnsite& on = WideOnsite{nullptr, nullptr, nullptr, nullptr, nullptr});
+// the same from the row-dot partials of the last H x H layer (GemmArgs epilogue 10): part[t * n_rows + r], t < n_part
+hipError_t launch_wide_out_part(hipStream_t s, const double* part, int n_part, const float* bout, int n_rows,
+                                const int2* rowinfo, long long row0, const float* half_jx, const float* logit_base,
+                                int oact, bool ratio, float* out, const WideOnsite& on);
 hipError_t launch_wide_propose(hipStream_t s, const float* configs, int B, int N, uint32_t seed_lo,
                                uint32_t seed_hi, int chain_offset, unsigned long long step, const int* inj_up,
                                const int* inj_dn, const float* inj_u, int* iup, int* idn, float* u);
@@ -402,6 +414,7 @@ hipError_t launch_wide_propose(hipStream_t s, const float* configs, int B, int N
 struct WideStepArgs {
   float* configs; float* z1; const float* w1p;
   const float* a_last; float* a0;                 // may alias (see k_wide_step)
+  const double* dot_part; int n_part;             // or the row-dot partials of the last layer [n_part][B] (a_last unused)
   const float* wout; const float* bout; float* logit;
   int* iup; int* idn; float* u;                   // the proposal in flight: read by (1), rewritten by (2)
   const int* inj_up; const int* inj_dn; const float* inj_u;   // injected proposal (tests) or nullptr

@@ -855,7 +855,35 @@ void wgrad_fill_problem(void* dst, int index, const float* A, long long lda, con
 template <int NT>
 __device__ __forceinline__ void gemm_tile_epilogue(const GemmArgs& g, const float* ct, int ldt, int m0, int n0, int tid) {
   const int cq = 4 * (tid & 31), n = n0 + cq;
-  if (n >= g.N) return;
+  const bool in = n < g.N;
+  if (g.epilogue == 10) {
+    // row dot (the output layer folded into the last H x H layer): the 32 lanes of a row add their quads'
+    // products in double -- e = 0 .. 3, then the butterfly 16, 8, 4, 2, 1: a fixed order -- and lane 0 stores the
+    // tile's partial; nothing goes to C.  (A lane outside N adds zeros: every lane of a row stays in the shuffles.)
+    f32x4 b = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+    if (in) { b = *(const f32x4*)(g.bias + n); w = *(const f32x4*)(g.dot_w + n); }
+    double* const dst = g.dot_out + (long long)(n0 / 128) * g.M;
+#pragma unroll 1
+    for (int row = tid >> 5; row < 128; row += NT / 32) {
+      const int m = m0 + row;
+      if (m >= g.M) break;                        // (uniform over the 32 lanes of the row)
+      const f32x4 v = *(const f32x4*)(ct + row * ldt + cq);
+      double p = 0.0;
+      if (g.act == VMC_ACT_RELU_) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p += (double)vmc_act<VMC_ACT_RELU_>(v[e] + b[e]) * (double)w[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p += (double)vmc_act_rt(g.act, v[e] + b[e]) * (double)w[e];
+      }
+      if (!in) p = 0.0;                           // (an activation of the padding need not be finite)
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) p += __shfl_xor(p, d);
+      if ((tid & 31) == 0) dst[m] = p;
+    }
+    return;
+  }
+  if (!in) return;
 #pragma unroll 1
   for (int row = tid >> 5; row < 128; row += NT / 32) {
     const int m = m0 + row;
@@ -1255,6 +1283,8 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
   }
 }
 
+bool gemm_rowdot_ok(const GemmArgs& g) { return g.M > 0 && g.N > 0 && gemm_tiling(g) != 0; }
+
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
   if (g.M <= 0 || g.N <= 0) return hipSuccess;
   if (const int tiling = gemm_tiling(g)) {
@@ -1273,6 +1303,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
     }
     return hipGetLastError();
   }
+  if (g.epilogue == 10) return hipErrorInvalidValue;           // only the tile kernels above (gemm_rowdot_ok)
   const int m_rows = g.ones_row ? g.M - 1 : g.M;
   const dim3 grid((g.N + GT - 1) / GT, (m_rows + GT - 1) / GT, g.splitk);
   if (g.dual) hipLaunchKernelGGL((k_gemm<true>), grid, dim3(256), 0, s, g);

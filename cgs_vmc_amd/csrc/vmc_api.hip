@@ -68,6 +68,7 @@ struct vmc_ctx {
   bool split_sweep = false;       // CGS_VMC_SPLIT_BF16 == 2: the sampler's H x H layers too (k_sweep16s)
   long long wrows = 0;     // rows of the two activation row buffers
   float *wbuf[2] = {nullptr, nullptr}, *wide_u = nullptr, *wide_zero = nullptr;
+  double* wide_dot = nullptr;          // [ceil(H / 128)][wrows] row-dot partials of the last H x H layer (GemmArgs epilogue 10)
   int *wide_iup = nullptr, *wide_idn = nullptr;
   int hact = VMC_ACT_RELU_;  // hidden activation (layers.NONLINEARITIES id)
   int oact = VMC_ACT_EXP_;   // output activation; exp: psi = exp(x - shift), else psi = g(x), no shift
@@ -396,6 +397,19 @@ static int wide_stage_act(const vmc_ctx* c, int l) {
   return (c->rbm && l == c->n_hh) ? VMC_ACT_LOGCOSH_ : c->hact;
 }
 
+// The last H x H layer of a forward whose activations nobody reads: turn its GEMM into the row-dot form (the output
+// layer's dot product as column-tile partials in c->wide_dot, nothing stored to C) where a tile kernel takes the
+// shape.  CGS_VMC_ROWDOT=0: never (A/B measurements, tests).  Returns whether `g` was changed.
+static bool wide_rowdot(vmc_ctx* c, const ParamSet& p, GemmArgs& g) {
+  const char* e = getenv("CGS_VMC_ROWDOT");
+  if (e && atoi(e) == 0) return false;
+  GemmArgs t = g;
+  t.epilogue = 10; t.dot_w = p.woutp; t.dot_out = c->wide_dot; t.C = nullptr;
+  if (!gemm_rowdot_ok(t)) return false;
+  g = t;
+  return true;
+}
+
 // fc_layer_size > 256: rows {chain, bond} of a row list over the cached z1 -> logits / ratios,
 // `wrows` rows at a time: rank-2 first layer written out, H x H layers as GEMMs, output dot
 // RBM (wavefunctions.py:418-437): the last linear stage goes through log cosh instead of the hidden
@@ -418,14 +432,20 @@ int wide_forward(vmc_ctx* c, int which, const float* z1, const int2* rowinfo, lo
     const int rows = (int)(n_rows - row0 < c->wrows ? n_rows - row0 : c->wrows);
     HIPCHK(c, launch_wide_rows_act(c->stream, z1, p.w1p, rowinfo, bonds, row0, rows,
                                    Hp, wide_stage_act(c, 0), c->wbuf[0]));
+    bool dot_fused = false;          // the output dot rode in the last layer's GEMM (row-dot epilogue)
     for (int l = 1; l <= NH; ++l) {
       GemmArgs g; memset(&g, 0, sizeof(g));
       g.A = c->wbuf[(l - 1) & 1]; g.sam = Hp; g.sak = 1;
       g.B = p.theta + off_w(c, l); g.sbk = H; g.sbn = 1;
       g.M = rows; g.N = H; g.K = H; g.C = c->wbuf[l & 1]; g.ldc = Hp;
       g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1; g.act = wide_stage_act(c, l);
+      if (l == NH) dot_fused = wide_rowdot(c, p, g);
       HIPCHK(c, launch_gemm(c->stream, g));
     }
+    if (dot_fused)
+      HIPCHK(c, launch_wide_out_part(c->stream, c->wide_dot, gemm_rowdot_tiles(H), p.bout, rows, rowinfo, row0,
+                                     c->half_jx, p.logit, c->oact, ratio, out, on));
+    else
     HIPCHK(c, launch_wide_out(c->stream, c->wbuf[NH & 1], p.woutp, p.bout, rows, H, Hp, rowinfo, row0, c->half_jx,
                               p.logit, c->oact, ratio, out, on));
   }
@@ -812,6 +832,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     c->wrows = B > 131072 ? B : 131072;
     CA(dalloc(&c->wbuf[0], c->wrows * Hp)); CA(dalloc(&c->wbuf[1], c->wrows * Hp));
     CA(dalloc(&c->wide_u, B));
+    CA(dalloc(&c->wide_dot, (long long)gemm_rowdot_tiles(c->H) * c->wrows));
     CA(dalloc(&c->wide_iup, B)); CA(dalloc(&c->wide_idn, B)); CA(dalloc(&c->wide_zero, Hp));
     CA(hipMemsetAsync(c->wide_zero, 0, Hp * sizeof(float), c->stream));
   }
@@ -863,6 +884,7 @@ void vmc_destroy(vmc_ctx* c) {
   for (float* q : {c->oscale, c->dact_all, c->dact_alt, c->ctape, c->cdelta, c->cws, c->wbuf[0], c->wbuf[1],
                    c->wide_u, c->wide_zero}) if (q) hipFree(q);
   for (int* q : {c->wide_iup, c->wide_idn}) if (q) hipFree(q);
+  if (c->wide_dot) hipFree(c->wide_dot);
   void* ptrs[] = {c->configs, c->configs_alt, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->wg_tickets, c->d_accepted, c->d_sum,
@@ -1071,6 +1093,7 @@ static int run_sweep_wide(vmc_ctx* c, long long n_steps, bool injected, bool dbg
       g.B = p.theta + off_w(c, l); g.sbk = H; g.sbn = 1;
       g.M = B; g.N = H; g.K = H; g.C = c->wbuf[l & 1]; g.ldc = Hp;
       g.bias = p.theta + off_b(c, l); g.epilogue = 1; g.splitk = 1; g.act = wide_stage_act(c, l);
+      if (l == NH && wide_rowdot(c, p, g)) { w.dot_part = c->wide_dot; w.n_part = gemm_rowdot_tiles(H); }
       HIPCHK(c, launch_gemm(c->stream, g));
     }
     in_flight = true;

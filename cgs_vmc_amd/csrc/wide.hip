@@ -42,6 +42,32 @@ __global__ void k_wide_rows_act(const float* __restrict__ z1, const float* __res
   }
 }
 
+// row r's logit from its output dot `sd` (+ b_out, + the RBM on-site term), stored as the logit or as the ratio term
+__device__ __forceinline__ void wide_out_finish(double sd, int r, const float* __restrict__ bout,
+                                                const int2* __restrict__ rowinfo, long long row0,
+                                                const float* __restrict__ half_jx,
+                                                const float* __restrict__ logit_base, int oact, int ratio,
+                                                float* __restrict__ out, const WideOnsite& on) {
+  float logit = (float)sd + bout[0];
+  if (on.base) {   // RestrictedBoltzmannNetwork: + x' . w_on (wavefunctions.py:436), rank-2 in the exchange
+    const int2 ri = rowinfo[row0 + r];
+    float o = on.base[ri.x];
+    if (ri.y != 0) {
+      const int2 ab = on.bonds[(ri.y > 0 ? ri.y : -ri.y) - 1];
+      o = fmaf(ri.y > 0 ? -2.f : 2.f, on.won[ab.x] - on.won[ab.y], o);
+    }
+    if (on.iup) o = fmaf(2.f, on.won[on.idn[r]] - on.won[on.iup[r]], o);
+    logit += o;
+  }
+  if (ratio) {
+    const int2 ri = rowinfo[row0 + r];
+    const int bs = ri.y;
+    out[row0 + r] = half_jx[(bs > 0 ? bs : -bs) - 1] * vmc_out_ratio(oact, logit, logit_base[ri.x]);
+  } else {
+    out[row0 + r] = logit;
+  }
+}
+
 // logit[r] = a[r] . w_out + b_out (one wave per row); ratio: out = 0.5 jx[bond] psi'/psi
 __global__ __launch_bounds__(256) void k_wide_out(const float* __restrict__ a, const float* __restrict__ wout,
                                                   const float* __restrict__ bout, int n_rows, int H, int Hp,
@@ -58,27 +84,22 @@ __global__ __launch_bounds__(256) void k_wide_out(const float* __restrict__ a, c
   for (int h = lane; h < H; h += 64) sd += (double)a[(long long)r * Hp + h] * (double)wout[h];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) sd += __shfl_xor(sd, m);
-  const float s = (float)sd;
-  if (lane == 0) {
-    float logit = s + bout[0];
-    if (on.base) {   // RestrictedBoltzmannNetwork: + x' . w_on (wavefunctions.py:436), rank-2 in the exchange
-      const int2 ri = rowinfo[row0 + r];
-      float o = on.base[ri.x];
-      if (ri.y != 0) {
-        const int2 ab = on.bonds[(ri.y > 0 ? ri.y : -ri.y) - 1];
-        o = fmaf(ri.y > 0 ? -2.f : 2.f, on.won[ab.x] - on.won[ab.y], o);
-      }
-      if (on.iup) o = fmaf(2.f, on.won[on.idn[r]] - on.won[on.iup[r]], o);
-      logit += o;
-    }
-    if (ratio) {
-      const int2 ri = rowinfo[row0 + r];
-      const int bs = ri.y;
-      out[row0 + r] = half_jx[(bs > 0 ? bs : -bs) - 1] * vmc_out_ratio(oact, logit, logit_base[ri.x]);
-    } else {
-      out[row0 + r] = logit;
-    }
-  }
+  if (lane == 0) wide_out_finish(sd, r, bout, rowinfo, row0, half_jx, logit_base, oact, ratio, out, on);
+}
+
+// the same from the row-dot partials of the last H x H layer (GemmArgs epilogue 10, grad.hip): one thread per row
+// adds the column tiles' partials in ascending order
+__global__ __launch_bounds__(256) void k_wide_out_part(const double* __restrict__ part, int n_part,
+                                                       const float* __restrict__ bout, int n_rows,
+                                                       const int2* __restrict__ rowinfo, long long row0,
+                                                       const float* __restrict__ half_jx,
+                                                       const float* __restrict__ logit_base, int oact, int ratio,
+                                                       float* __restrict__ out, WideOnsite on) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  double sd = 0.0;
+  for (int t = 0; t < n_part; ++t) sd += part[(long long)t * n_rows + r];
+  wide_out_finish(sd, r, bout, rowinfo, row0, half_jx, logit_base, oact, ratio, out, on);
 }
 
 // proposals of one mc_step (graph_builders.py:59-65): one wave per chain
@@ -151,18 +172,22 @@ __global__ __launch_bounds__(64 * WIDE_STEP_CHAINS) void k_wide_step(WideStepArg
   int pu = 0, pd = 0;
   float lnew = 0.f, onew = 0.f;
   if (live && s.do_accept) {
-    const float* a = s.a_last + (long long)c * s.Hp;
     pu = s.iup[c]; pd = s.idn[c];
     double sd = 0.0;
-    for (int h0 = lane; h0 < s.H; h0 += 512) {        // the order of k_wide_out (h = lane, lane + 64, ...), eight loads in flight
-      float av[8], wv[8];
+    if (s.dot_part) {                                 // the last layer's GEMM left the dot as column-tile partials
+      for (int t = 0; t < s.n_part; ++t) sd += s.dot_part[(long long)t * s.B + c];
+    } else {
+      const float* a = s.a_last + (long long)c * s.Hp;
+      for (int h0 = lane; h0 < s.H; h0 += 512) {      // the order of k_wide_out (h = lane, lane + 64, ...), eight loads in flight
+        float av[8], wv[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int h = min(h0 + 64 * i, s.H - 1); av[i] = a[h]; wv[i] = s.wout[h]; }
+        for (int i = 0; i < 8; ++i) { const int h = min(h0 + 64 * i, s.H - 1); av[i] = a[h]; wv[i] = s.wout[h]; }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) if (h0 + 64 * i < s.H) sd += (double)av[i] * (double)wv[i];
+        for (int i = 0; i < 8; ++i) if (h0 + 64 * i < s.H) sd += (double)av[i] * (double)wv[i];
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) sd += __shfl_xor(sd, m);
     }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) sd += __shfl_xor(sd, m);
     lnew = (float)sd + s.bout[0];
     if (s.onsite) {   // RestrictedBoltzmannNetwork: + x' . w_on (wavefunctions.py:436), rank-2 in the exchange
       onew = fmaf(2.f, s.won[pd] - s.won[pu], s.onsite[c]);
@@ -305,6 +330,15 @@ hipError_t launch_wide_out(hipStream_t s, const float* a, const float* wout, con
                            const float* logit_base, int oact, bool ratio, float* out, const WideOnsite& on) {
   if (n_rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_wide_out, dim3((n_rows + 3) / 4), dim3(256), 0, s, a, wout, bout, n_rows, H, Hp, rowinfo,
+                     row0, half_jx, logit_base, oact, ratio ? 1 : 0, out, on);
+  return hipGetLastError();
+}
+
+hipError_t launch_wide_out_part(hipStream_t s, const double* part, int n_part, const float* bout, int n_rows,
+                                const int2* rowinfo, long long row0, const float* half_jx, const float* logit_base,
+                                int oact, bool ratio, float* out, const WideOnsite& on) {
+  if (n_rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wide_out_part, dim3((n_rows + 255) / 256), dim3(256), 0, s, part, n_part, bout, n_rows, rowinfo,
                      row0, half_jx, logit_base, oact, ratio ? 1 : 0, out, on);
   return hipGetLastError();
 }
