@@ -1,6 +1,6 @@
-"""CPU: static check of the generated code of k_tail16r (tools/check_async_regs.py): between the asm statement that
-issues the LDS reads of the next item's weight fragments and the statement that waits for them, no instruction
-may name one of the twelve destination registers (the compiler believes them valid from the issue on).  hipcc
+"""CPU: static check of the generated code of k_tail16r and k_gemm_ring (tools/check_async_regs.py): between the asm
+statement that issues the LDS reads of the next item's operands and the statement that waits for them, no
+instruction may name one of the destination registers (the compiler believes them valid from the issue on).  hipcc
 cross-compiles gfx950 here; no GPU."""
 import os
 import subprocess
