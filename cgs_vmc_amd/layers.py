@@ -4,9 +4,11 @@ In the reference the values are TensorFlow functions; here they are named tokens
 the engine maps to kernel epilogues (cgsvmc.h VMC_ACT_*): all seven are available as the hidden
 nonlinearity (template parameter of the fused row / sampler kernels; relu is the tuned path) and
 as the output activation (exp works in the log domain with exp_norm_shift, any other g gives
-psi = g(x) and linear-domain ratios).  The periodic-conv / residual /
-MPS / graph-conv building blocks of layers.py serve only ansaetze outside the hot path
- and are not provided.
+psi = g(x) and linear-domain ratios).  The periodic convolutions and residual blocks of layers.py
+(Conv1dPeriodic / Conv2dPeriodic / ResBlock1d / ResBlock2d, layers.py:24-229) have no Python class here: they
+exist as kernels (csrc/conv_kernels.hpp) behind wavefunctions.Conv1DNetwork / Conv2DNetwork / ResNet1D / ResNet2D.
+The MPS and graph-convolution building blocks serve ansaetze outside the hot path and are
+not provided.
 """
 import numpy as np
 
