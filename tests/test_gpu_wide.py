@@ -215,3 +215,60 @@ def test_general_path_gemm_tilings_agree(monkeypatch, n, h, L, b, kind):
   for o in outs[:2]:
     _close(o[0], outs[2][0], 2e-5)
     _close(o[1], outs[2][1], 2e-4)
+
+
+def test_general_path_full_size_default_dispatch(monkeypatch):
+  """bench.py's general-path workload at its full size (10 x 10 torus, 3 x 1024 units, 4096 chains) on the DEFAULT
+  dispatch: 4096 rows x 8 column tiles = 256 tiles take k_gemm_ring by themselves (the small shapes above only reach it
+  through CGS_VMC_GEMM128=5), the sampler's and the local energies' last layers run the row-dot epilogue, the
+  local-energy rows go through 131,072-row blocks.  Logits of every chain and two injected steps against the fp64
+  oracle, local energies of sampled chains, then a 100-step sweep twice from the same state and seed: the same
+  chains, the same accept count (no float atomics, a fixed order of additions everywhere) -- and the same run with
+  the row-dot epilogue and the ring switched off within the logit tolerance."""
+  from cgs_vmc_amd.engine import VmcEngine
+  n, h, L, b = 100, 1024, 3, 4096
+  rng = np.random.default_rng(11)
+  theta = vo.init_params(n, h, L, rng)
+  theta += (0.01 * rng.standard_normal(theta.size)).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(12))
+  bonds = vo.torus_bonds(10, 10)
+  logit_ref = lambda c: vo.fc_logit(theta, c, h, L, dtype=np.float64)
+  amp = lambda c: vo.fc_psi(theta, c, h, L, dtype=np.float64)
+
+  def engine():
+    e = VmcEngine(n, b, L, h, seed=77)
+    assert e.kernel_path() == 2
+    e.set_params(theta); e.set_configs(cfg); e.set_bonds(bonds, -1.0, 1.0)
+    return e
+  eng = engine()
+  logit = eng.amplitude()[0]
+  _close(logit, logit_ref(cfg), 2e-5)
+  e_loc = eng.local_energy()[0]
+  idx = np.random.RandomState(5).choice(b, 16, replace=False)
+  _close(e_loc[idx], vo.local_value(amp, cfg[idx], bonds, -1.0, 1.0, dtype=np.float64), 2e-4)
+  cur = cfg
+  for step in range(2):
+    u_sites, u_acc = vo.step_uniforms(99, np.arange(b), step, n)
+    i_up, i_dn = vo.propose_exchange(cur, u_sites)
+    _, acc_ref, ratios = vo.mc_step(amp, cur, i_up, i_dn, u_acc)
+    mask = eng.mc_step_injected(i_up, i_dn, u_acc)
+    band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
+    assert band.sum() < b // 100 and np.array_equal(mask[~band], acc_ref[~band])
+    cur = eng.get_configs()
+  _close(eng.amplitude()[0], logit_ref(cur), 2e-5)
+  eng.set_configs(cfg); eng.step_counter = 0
+  acc1 = eng.mc_steps(n)
+  got1, e1 = eng.get_configs(), eng.local_energy()[0]
+  eng.set_configs(cfg); eng.step_counter = 0
+  acc2 = eng.mc_steps(n)
+  np.testing.assert_array_equal(eng.get_configs(), got1)
+  np.testing.assert_array_equal(eng.local_energy()[0], e1)
+  assert acc1 == acc2 and 0.05 * n * b < acc1 < 0.95 * n * b
+  assert (got1.sum(axis=1) == 0).all() and (np.abs(got1) == 1).all()
+  _close(e1[idx], vo.local_value(amp, got1[idx], bonds, -1.0, 1.0, dtype=np.float64), 2e-4)
+  eng.close()
+  monkeypatch.setenv('CGS_VMC_ROWDOT', '0'); monkeypatch.setenv('CGS_VMC_GEMM128', '0')
+  eng = engine()
+  _close(eng.amplitude()[0], logit, 2e-5)
+  _close(eng.local_energy()[0], e_loc, 2e-4)
+  eng.close()
