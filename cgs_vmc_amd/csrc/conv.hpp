@@ -110,3 +110,33 @@ hipError_t launch_conv_sweep(hipStream_t s, const ConvSweepArgs& a);
 hipError_t launch_conv_back(hipStream_t s, const ConvBackArgs& a, int num_cus);
 hipError_t launch_conv_dw(hipStream_t s, const ConvDwArgs& a);
 hipError_t launch_conv_sr_rowdot(hipStream_t s, const ConvSrRowdotArgs& a, int num_cus);
+
+// ---- general path (conv_general.hip): feature maps in HBM [row][site][Fp], a convolution = im2col + one GEMM
+#define CGEN_PRE_SELU 7                                            // pre_act ids: -1 none, 0 .. 6 = VMC_ACT_*, 7 selu
+inline int cgen_fp(const ConvGeom& g) { return (g.F + 3) & ~3; }
+inline int cgen_kdim(const ConvGeom& g, int l) { return g.K * g.KW * (l == 0 ? 1 : g.F); }
+inline long long cgen_off_w(const ConvGeom& g, int l) {            // theta: w[k][kw][Cin][F] then b[F], creation order
+  long long o = 0;
+  for (int i = 0; i < l; ++i) o += (long long)cgen_kdim(g, i) * g.F + g.F;
+  return o;
+}
+inline long long cgen_off_b(const ConvGeom& g, int l) { return cgen_off_w(g, l) + (long long)cgen_kdim(g, l) * g.F; }
+struct CgenIm2colArgs {
+  ConvGeom g;
+  int layer;                 // 0: gather from the spins (with the exchanged pair negated); > 0: from a feature map
+  const float* src;          // layer 0: configs [n_base][N]; else the input map [rows][N][Fp]
+  int Fp;
+  int pre_act;               // applied to the gathered values (layer > 0)
+  const int2* rowinfo;       // layer 0: [..] {chain, +-(bond+1) or 0}, or nullptr: row r is chain row0 + r
+  long long row0;            // first row of this block in rowinfo / iup / idn
+  const int2* bonds;
+  const int* iup; const int* idn;   // layer 0: the proposed exchange of row r (or nullptr)
+  int rows;                  // rows of this block
+  int lda;                   // floats per row of A
+  float* A;                  // [rows * N][lda]
+};
+hipError_t launch_cgen_im2col(hipStream_t s, const CgenIm2colArgs& a);
+hipError_t launch_cgen_rowsum(hipStream_t s, const float* fm, int rows, int N, int F, int Fp, double* out);
+hipError_t launch_cgen_accept(hipStream_t s, float* configs, float* logit, const float* lnew, const int* iup,
+                              const int* idn, const float* u, int B, int N, int oact, unsigned long long* accepted,
+                              unsigned char* acc_mask);

@@ -1,0 +1,154 @@
+// Convolutional ansatz types beyond the limits of the fused kernels (conv_kernels.hpp keeps a sample's feature maps
+// in LDS: kernel_size <= 9, num_conv_filters <= 64, two maps within 160 KiB): the general path.  The reference takes
+// any value (wavefunctions.py:534-579, utils.py:107-111).  Feature maps live in HBM, channel-last
+// [row][site][Fp] (Fp = filters padded to 4); one Conv2dPeriodic / Conv1dPeriodic (layers.py:24-160) is
+//   * an im2col gather  A[(row, site)][(tap, c)] = f(in[row][(site + tap - lo) mod lattice][c])  -- the periodic
+//     padding of layers.py:118-148 / 51-74 is the index arithmetic, the hidden activation (selu in the residual
+//     blocks, layers.py:226) is applied as the operand is gathered, so every stored map is a PRE-activation --
+//   * ONE product with the parameter slice as it lies in theta: snt.Conv2D's w[k, k, Cin, F] IS the row-major
+//     [k k Cin][F] B matrix (launch_gemm: k_gemm_ring / k_gemm128 / k_gemm by shape), bias in the epilogue, the
+//     residual add of ResBlock2d (layers.py:227) as the accumulate-into-C epilogue.
+// The first convolution gathers from the spins themselves, with the exchanged pair of a connected configuration
+// (operators.py:162-163) or of a proposed move (graph_builders.py:67-71) negated on the fly.  The logit is the sum of
+// the last map (wavefunctions.py:569, 577; 760, 773) in double, one wave per row.
+// Same arithmetic as the fused kernels up to the order of additions; same Philox streams, same accept rule.
+#include "conv.hpp"
+
+namespace {
+
+__device__ __forceinline__ float cg_selu(float x) {   // layers.py:226 tf.nn.selu; constants as the fused kernels / the oracle
+  const float scale = 1.0507009873554805f, alpha = 1.6732632423543772f;
+  return scale * (x > 0.f ? x : alpha * (expf(x) - 1.f));
+}
+__device__ __forceinline__ float cg_pre(int pre, float x) {
+  return pre < 0 ? x : (pre == CGEN_PRE_SELU ? cg_selu(x) : vmc_act_rt(pre, x));
+}
+
+// site index of tap t at position n: ((a1 + d1 - lo) mod D1, (a2 + d2 - lo2) mod D2), layers.py:132-141 / 66-72
+__device__ __forceinline__ int cg_site(const ConvGeom& g, int n, int t) {
+  const int a1 = n / g.D2, a2 = n - a1 * g.D2;
+  const int d1 = t / g.KW, d2 = t - d1 * g.KW;
+  int s1 = (a1 + d1 - g.lo) % g.D1; if (s1 < 0) s1 += g.D1;
+  int s2 = (a2 + d2 - g.lo2) % g.D2; if (s2 < 0) s2 += g.D2;
+  return s1 * g.D2 + s2;
+}
+
+// convolutions 1 ..: A[m][t F + c] = f(in[row][site(n, t)][c]); VEC = 4: F % 4 == 0 (16-byte pieces), else scalar
+template <int VEC>
+__global__ __launch_bounds__(256) void k_cgen_im2col(CgenIm2colArgs a) {
+  const ConvGeom g = a.g;
+  const int T = g.K * g.KW, C = g.F / VEC;
+  const long long total = (long long)a.rows * g.N * T * C;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cq = (int)(idx % C);
+    const long long mt = idx / C;
+    const int t = (int)(mt % T);
+    const long long m = mt / T;
+    const int r = (int)(m / g.N), n = (int)(m - (long long)r * g.N);
+    const float* src = a.src + ((long long)r * g.N + cg_site(g, n, t)) * a.Fp + VEC * cq;
+    float* dst = a.A + m * a.lda + (long long)t * g.F + VEC * cq;
+    if (VEC == 4) {
+      f32x4 v = *(const f32x4*)src;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = cg_pre(a.pre_act, v[e]);
+      *(f32x4*)dst = v;
+    } else {
+      *dst = cg_pre(a.pre_act, *src);
+    }
+  }
+}
+
+// first convolution: A[m][t] = s'(site(n, t)) with s' = the row's spins, the exchanged pair negated
+__global__ __launch_bounds__(256) void k_cgen_im2col0(CgenIm2colArgs a) {
+  const ConvGeom g = a.g;
+  const int T = g.K * g.KW;
+  const long long total = (long long)a.rows * g.N * T;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int t = (int)(idx % T);
+    const long long m = idx / T;
+    const int r = (int)(m / g.N), n = (int)(m - (long long)r * g.N);
+    int chain = (int)a.row0 + r, fa = -1, fb = -1;
+    if (a.rowinfo) {
+      const int2 ri = a.rowinfo[a.row0 + r];
+      chain = ri.x;
+      if (ri.y != 0) { const int2 ab = a.bonds[(ri.y > 0 ? ri.y : -ri.y) - 1]; fa = ab.x; fb = ab.y; }
+    }
+    if (a.iup) { fa = a.iup[a.row0 + r]; fb = a.idn[a.row0 + r]; }
+    const int s = cg_site(g, n, t);
+    const float x = a.src[(long long)chain * g.N + s];
+    a.A[m * a.lda + t] = (s == fa || s == fb) ? -x : x;
+  }
+}
+
+// sum of a row's last feature map over sites and channels (wavefunctions.py:569 reduce_sum), in double: one wave per row
+__global__ __launch_bounds__(256) void k_cgen_rowsum(const float* __restrict__ fm, int rows, int N, int F, int Fp,
+                                                     double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* p = fm + (long long)r * N * Fp;
+  double s = 0.0;
+  for (int i = lane; i < N * Fp; i += 64) s += (i % Fp) < F ? (double)p[i] : 0.0;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) out[r] = s;
+}
+
+// Metropolis test and commit of one mc_step (graph_builders.py:75-88): one thread per chain, one atomic per workgroup
+__global__ __launch_bounds__(256) void k_cgen_accept(float* __restrict__ configs, float* __restrict__ logit,
+                                                     const float* __restrict__ lnew, const int* __restrict__ iup,
+                                                     const int* __restrict__ idn, const float* __restrict__ u, int B,
+                                                     int N, int oact, unsigned long long* __restrict__ accepted,
+                                                     unsigned char* __restrict__ acc_mask) {
+  __shared__ int s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  bool acc = false;
+  if (c < B) {
+    const float uu = u[c];
+    acc = vmc_out_accept(oact, lnew[c], logit[c], uu, 0.5f * __logf(uu));
+    if (acc) {
+      configs[(long long)c * N + idn[c]] += 2.f;      // graph_builders.py:67-71
+      configs[(long long)c * N + iup[c]] -= 2.f;
+      logit[c] = lnew[c];
+    }
+    if (acc_mask) acc_mask[c] = acc ? 1 : 0;
+  }
+  const unsigned long long b = __ballot(acc);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&s_n, __popcll(b));
+  __syncthreads();
+  if (threadIdx.x == 0 && s_n) atomicAdd(accepted, (unsigned long long)s_n);
+}
+
+int cg_blocks(long long n) { const long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b < 16384 ? b : 16384)); }
+
+}  // namespace
+
+hipError_t launch_cgen_im2col(hipStream_t s, const CgenIm2colArgs& a) {
+  if (a.rows <= 0) return hipSuccess;
+  const ConvGeom& g = a.g;
+  const long long T = (long long)g.K * g.KW;
+  if (a.layer == 0) {
+    hipLaunchKernelGGL(k_cgen_im2col0, dim3(cg_blocks((long long)a.rows * g.N * T)), dim3(256), 0, s, a);
+  } else if (g.F % 4 == 0) {
+    hipLaunchKernelGGL(k_cgen_im2col<4>, dim3(cg_blocks((long long)a.rows * g.N * T * (g.F / 4))), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(k_cgen_im2col<1>, dim3(cg_blocks((long long)a.rows * g.N * T * g.F)), dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_rowsum(hipStream_t s, const float* fm, int rows, int N, int F, int Fp, double* out) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cgen_rowsum, dim3((rows + 3) / 4), dim3(256), 0, s, fm, rows, N, F, Fp, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_accept(hipStream_t s, float* configs, float* logit, const float* lnew, const int* iup,
+                              const int* idn, const float* u, int B, int N, int oact, unsigned long long* accepted,
+                              unsigned char* acc_mask) {
+  hipLaunchKernelGGL(k_cgen_accept, dim3((B + 255) / 256), dim3(256), 0, s, configs, logit, lnew, iup, idn, u, B, N,
+                     oact, accepted, acc_mask);
+  return hipGetLastError();
+}

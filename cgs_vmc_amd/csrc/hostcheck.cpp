@@ -14,7 +14,7 @@
 
 #include "plan.hpp"
 
-static long long g_checks = 0, g_shapes = 0, g_rejected = 0;
+static long long g_checks = 0, g_shapes = 0, g_rejected = 0, g_general = 0;
 #define CHECK(cond)                                                                      \
   do {                                                                                   \
     ++g_checks;                                                                          \
@@ -361,7 +361,14 @@ static void conv_grid() {
                 CHECK(msg[0] != 0);
                 continue;
               }
-              CHECK(F <= 64 && K <= 9 && (resnet || L >= 1) && p.conv);
+              CHECK((resnet || L >= 1) && p.conv);
+              if (p.conv_general) {       // beyond the fused kernels: for exactly one of their four reasons
+                CHECK(F > 64 || K > 9 || plan_conv_rows_lds(p.cg, 1) > PLAN_LDS_PER_CU || B * p.cg.CS >= (1LL << 31));
+                CHECK((long long)p.cg.N * plan_cgen_lda(p.cg) < (1LL << 28));
+                ++g_general;
+                continue;
+              }
+              CHECK(F <= 64 && K <= 9);
               CHECK(plan_conv_rows_lds(p.cg, 1) <= PLAN_LDS_PER_CU);
               check_conv(d, p);
             }
@@ -378,10 +385,18 @@ static void conv_grid() {
   CHECK(plan_conv_dw_nco(p.cg) == 1 && plan_conv_dw_parts(9, 9, 4) == 2 && plan_conv_dw_grid_z(p.cg) == 8);
   CHECK(plan_conv_dw_nco(5, 5, 2) == 2 && plan_conv_dw_parts(5, 5, 2) == 1);      // the measured 32-filter kernels are unchanged
   CHECK(plan_conv_dw_nco(5, 5, 1) == 1 && plan_conv_dw_parts(5, 5, 1) == 1 && plan_conv_dw_parts(9, 9, 1) == 1);
-  d.layer_size = 65;
+  CHECK(!p.conv_general);
+  d.layer_size = 65;                                                           // beyond: the general path (conv_general.hip)
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_OK && p.conv_general);
+  d.layer_size = 1025;
   CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_UNSUPPORTED);
   d.layer_size = 16; d.kernel_size = 10;
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_OK && p.conv_general && p.P == plan_num_params_conv(5, 16, 100));
+  d.kernel_size = 32;
   CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_UNSUPPORTED);
+  d.kernel_size = 5;
+  CHECK(plan_desc(&d, true, &p, msg, sizeof(msg), true) == VMC_OK && p.conv_general);      // forced (CGS_VMC_CONV_GENERAL=1)
+  d.kernel_size = 10;
   d.kernel_size = 5; d.size_x = 9;
   CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_INVALID);        // size_x * size_y != num_sites
   d.size_x = 10;
@@ -424,6 +439,6 @@ int main() {
   dense_grid();
   conv_grid();
   sr_schedules();
-  printf("hostcheck ok: %lld shapes (%lld rejected by plan_desc), %lld assertions\n", g_shapes, g_rejected, g_checks);
+  printf("hostcheck ok: %lld shapes (%lld rejected by plan_desc, %lld convolutional ones on the general path), %lld assertions\n", g_shapes, g_rejected, g_general, g_checks);
   return 0;
 }

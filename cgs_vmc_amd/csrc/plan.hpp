@@ -68,6 +68,8 @@ inline long long plan_num_params_conv(int n_conv, long long F, long long taps) {
 #define CONV_MAX_LAYERS 32
 #define CONV_FP 16          // channel tile of the MFMA: filters are zero padded to NCB blocks of 16
 #define CONV_MAX_NCB 4      // num_conv_filters <= 64
+#define CONV_GENERAL_MAX_K 31   // general path (conv_general.hip): any kernel size the periodic padding allows, bounded for the index arithmetic
+#define CONV_GENERAL_MAX_F 1024
 #define CONV_MAX_K 9        // kernel_size (one instantiation per size; weights of a block pair in register-resident chunks of <= 25 taps)
 #define CONV_LDS_PER_WG ((size_t)80 * 1024)   // two 4-wave workgroups share the 160 KiB of a CU
 
@@ -96,6 +98,8 @@ struct ConvGeom {
 // LDS of a row / sampler / backward workgroup holding G samples: buf0, buf1, xs, pinfo, row_chain,
 // red + the sampler's cur_logit, prop, prop_u + the two wrap tables
 // ints per row of the periodic neighbour tables (one entry per tap along an axis)
+// general path: row stride (floats) of the im2col matrix = taps x input channels of the widest convolution, 16-byte rows
+PLAN_HD inline int plan_cgen_lda(const ConvGeom& g) { return (g.K * g.KW * (g.n_conv > 1 ? g.F : 1) + 3) & ~3; }
 PLAN_HD inline int plan_conv_tab(const ConvGeom& g) { return g.K <= 8 ? 8 : 16; }
 inline size_t plan_conv_rows_lds(const ConvGeom& g, int G) {
   const size_t xs = (size_t)((g.N + 3) & ~3);
@@ -276,6 +280,7 @@ inline bool plan_tail_lds_supported(int Hp, int n_hidden) {
 // ------------------------------------------------------------------------------- vmc_create
 struct DescPlan {
   int rbm, conv, resnet, one_d;
+  int conv_general;          // conv beyond the fused kernels' limits (or forced): conv_general.hip
   int wide, wide_fast;       // > 256 units; of those, the fused 384 / 512-unit kernels
   int Hp;                    // padded units of the dense kernels (conv: 64, unused)
   int n_hh;                  // H x H layers
@@ -286,7 +291,8 @@ struct DescPlan {
 
 // Everything vmc_create decides before it touches the device.  Returns a vmc_status; `msg` receives the
 // reason.  wide_fast_allowed = false is CGS_VMC_WIDE_FAST=0.
-inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, char* msg, size_t msg_len) {
+inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, char* msg, size_t msg_len,
+                     bool force_conv_general = false) {
   memset(out, 0, sizeof(*out));
 #define PLAN_FAIL(code, text) do { snprintf(msg, msg_len, "%s", text); return code; } while (0)
   if (d->ansatz < VMC_ANSATZ_FULLY_CONNECTED || d->ansatz > VMC_ANSATZ_RES_NET_1D)
@@ -305,10 +311,16 @@ inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, c
     const int sx = one_d ? d->n_sites : d->size_x, sy = one_d ? 1 : d->size_y;
     if (sx < 1 || sy < 1 || (long long)sx * sy != d->n_sites)
       PLAN_FAIL(VMC_ERR_INVALID, "size_x * size_y must equal num_sites");
-    if (d->kernel_size < 1 || d->kernel_size > CONV_MAX_K)
-      PLAN_FAIL(VMC_ERR_UNSUPPORTED, "kernel_size 1..9 supported by the convolution kernels (one instantiation per size)");
-    if (d->layer_size > CONV_FP * CONV_MAX_NCB)
-      PLAN_FAIL(VMC_ERR_UNSUPPORTED, "num_conv_filters > 64 not supported by the convolution kernels (four channel blocks of 16)");
+    // Beyond the limits of the fused kernels (feature maps in LDS: kernel_size <= 9 -- one instantiation per size --,
+    // num_conv_filters <= 64 -- four channel blocks of 16 --, a sample's two maps within 160 KiB) the general path
+    // of conv_general.hip serves: feature maps in HBM, a convolution = im2col + one GEMM (round 5; forward, local
+    // energies and sampler -- the gradient and SR entries refuse such a ctx)
+    bool general = force_conv_general;
+    if (d->kernel_size < 1 || d->kernel_size > CONV_GENERAL_MAX_K)
+      PLAN_FAIL(VMC_ERR_UNSUPPORTED, "kernel_size 1..31 supported by the convolution kernels");
+    if (d->layer_size > CONV_GENERAL_MAX_F)
+      PLAN_FAIL(VMC_ERR_UNSUPPORTED, "num_conv_filters > 1024 not supported by the convolution kernels");
+    if (d->kernel_size > CONV_MAX_K || d->layer_size > CONV_FP * CONV_MAX_NCB) general = true;
     if (sx < d->kernel_size / 2 || (!one_d && sy < d->kernel_size / 2) || sx > 1023 || sy > 1023)
       PLAN_FAIL(VMC_ERR_UNSUPPORTED, "lattice sides must be in [kernel_size / 2, 1023]");
     if ((long long)d->num_layers > CONV_MAX_LAYERS)
@@ -325,10 +337,11 @@ inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, c
       cg.KW = cg.K; cg.lo = cg.lo2 = (cg.K - 1) / 2; cg.hi = cg.hi2 = cg.K / 2;
     }
     if (cg.n_conv > CONV_MAX_LAYERS) PLAN_FAIL(VMC_ERR_UNSUPPORTED, "too many convolutions");
-    if ((long long)d->batch_size * cg.CS >= (1LL << 31))
-      PLAN_FAIL(VMC_ERR_UNSUPPORTED, "batch_size x lattice too large for the 32-bit tape offsets of the convolution kernels");
-    if (plan_conv_rows_lds(cg, 1) > PLAN_LDS_PER_CU)
-      PLAN_FAIL(VMC_ERR_UNSUPPORTED, "lattice too large: the feature maps of one sample must fit the 160 KiB of LDS");
+    if ((long long)d->batch_size * cg.CS >= (1LL << 31)) general = true;   // 32-bit tape offsets of the fused kernels
+    if (plan_conv_rows_lds(cg, 1) > PLAN_LDS_PER_CU) general = true;       // a sample's maps beyond 160 KiB of LDS
+    if (general && (long long)cg.N * plan_cgen_lda(cg) >= (1LL << 28))
+      PLAN_FAIL(VMC_ERR_UNSUPPORTED, "lattice x kernel x filters too large for the general convolution path (one sample's im2col rows beyond 1 GiB)");
+    out->conv_general = general ? 1 : 0;
   }
   if (d->nonlinearity < 0 || d->nonlinearity > 6 || d->output_activation < 0 || d->output_activation > 6)
     PLAN_FAIL(VMC_ERR_INVALID, "unknown activation id (layers.NONLINEARITIES has 7 entries)");

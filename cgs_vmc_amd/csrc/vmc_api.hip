@@ -69,6 +69,14 @@ struct vmc_ctx {
   long long wrows = 0;     // rows of the two activation row buffers
   float *wbuf[2] = {nullptr, nullptr}, *wide_u = nullptr, *wide_zero = nullptr;
   double* wide_dot = nullptr;          // [ceil(H / 128)][wrows] row-dot partials of the last H x H layer (GemmArgs epilogue 10)
+  // general convolution path (conv_general.hip; plan.hpp: conv beyond the fused kernels' limits): block buffers
+  bool conv_general = false;
+  long long cg_rows = 0;                   // row configurations per block
+  float* cg_A = nullptr;                   // im2col rows [cg_rows * N][plan_cgen_lda]
+  float* cg_fm[2] = {nullptr, nullptr};    // feature maps [cg_rows][N][Fp] (pre-activations)
+  double* cg_sum = nullptr;                // [cg_rows] sums of the last map
+  float* cg_zero = nullptr;                // one 0.f (the "b_out" of wide_out_finish)
+  float* cg_lnew = nullptr;                // [B] candidate logits of the sampler
   int *wide_iup = nullptr, *wide_idn = nullptr;
   int hact = VMC_ACT_RELU_;  // hidden activation (layers.NONLINEARITIES id)
   int oact = VMC_ACT_EXP_;   // output activation; exp: psi = exp(x - shift), else psi = g(x), no shift
@@ -327,7 +335,8 @@ int ensure_packed(vmc_ctx* c, int which) {
   if (!p.has_params) return fail(c, VMC_ERR_STATE, "parameters not set (vmc_set_params)");
   if (p.packed_valid) return VMC_OK;
   if (c->conv) {
-    HIPCHK(c, launch_conv_pack(c->stream, p.theta, c->cg, p.cw0, p.cwf, p.cwb, p.cbias));
+    // (general path: the parameter slices are the B matrices of its GEMMs as they lie in theta)
+    if (!c->conv_general) HIPCHK(c, launch_conv_pack(c->stream, p.theta, c->cg, p.cw0, p.cwf, p.cwb, p.cbias));
     p.packed_valid = true;
     return VMC_OK;
   }
@@ -364,8 +373,68 @@ ConvParams conv_params(const ParamSet& p) { return ConvParams{p.cw0, p.cwf, p.cw
 // Conv2DNetwork / ResNet2D forward (wavefunctions.py:596-598, 790-792) of parameter set `which` on
 // the rows of a row list over `configs`: logits (ratio == false) or 0.5 jx psi'/psi of the
 // bond-exchanged configurations.  with_tape: the inputs of every convolution go to c->ctape.
+// The same on the general path (conv_general.hip): blocks of cg_rows row configurations; per convolution an im2col
+// gather (the hidden activation applied as the operand is gathered: every stored map is a pre-activation) and one
+// GEMM against the parameter slice in theta; ResBlock2d's `v + h` (layers.py:227) is the accumulate epilogue.
+// iup / idn != nullptr: row r is chain r with that pair exchanged (the sampler's candidates).
+static int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2* rowinfo, long long n_rows,
+                        const int* iup, const int* idn, bool ratio, float* out) {
+  const ConvGeom& g = c->cg;
+  const ParamSet& p = c->ps[which];
+  const int Fp = cgen_fp(g), lda = plan_cgen_lda(g);
+  auto conv = [&](int l, int rows, const float* in, int pre, float* dst, bool residual, long long row0) -> int {
+    CgenIm2colArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = g; a.layer = l; a.Fp = Fp; a.pre_act = pre; a.rows = rows; a.lda = lda; a.A = c->cg_A;
+    if (l == 0) {
+      a.src = configs; a.rowinfo = rowinfo; a.row0 = row0; a.bonds = c->bonds ? c->bonds : c->bond_dummy;
+      a.iup = iup; a.idn = idn;
+    } else {
+      a.src = in;
+    }
+    HIPCHK(c, launch_cgen_im2col(c->stream, a));
+    GemmArgs m; memset(&m, 0, sizeof(m));
+    m.A = c->cg_A; m.sam = lda; m.sak = 1;
+    m.B = p.theta + cgen_off_w(g, l); m.sbk = g.F; m.sbn = 1;
+    m.M = rows * g.N; m.N = g.F; m.K = cgen_kdim(g, l); m.C = dst; m.ldc = Fp;
+    m.bias = p.theta + cgen_off_b(g, l); m.epilogue = residual ? 8 : 4; m.splitk = 1;
+    HIPCHK(c, launch_gemm(c->stream, m));
+    return VMC_OK;
+  };
+  for (long long row0 = 0; row0 < n_rows; row0 += c->cg_rows) {
+    const int rows = (int)(n_rows - row0 < c->cg_rows ? n_rows - row0 : c->cg_rows);
+    const float* last;
+    PROPAGATE(conv(0, rows, nullptr, -1, c->cg_fm[0], false, row0));
+    if (!g.resnet) {           // Conv2DNetwork (wavefunctions.py:572-575): act between the convolutions, none behind the last
+      for (int l = 1; l < g.n_conv; ++l)
+        PROPAGATE(conv(l, rows, c->cg_fm[(l - 1) & 1], g.hact, c->cg_fm[l & 1], false, row0));
+      last = c->cg_fm[(g.n_conv - 1) & 1];
+    } else {                   // ResNet2D (wavefunctions.py:766-772; layers.py:226-228): h += second(selu(first(h)))
+      for (int l = 1; l + 1 < g.n_conv; l += 2) {
+        PROPAGATE(conv(l, rows, c->cg_fm[0], -1, c->cg_fm[1], false, row0));
+        PROPAGATE(conv(l + 1, rows, c->cg_fm[1], CGEN_PRE_SELU, c->cg_fm[0], true, row0));
+      }
+      last = c->cg_fm[0];
+    }
+    HIPCHK(c, launch_cgen_rowsum(c->stream, last, rows, g.N, g.F, Fp, c->cg_sum));
+    const WideOnsite on{nullptr, nullptr, nullptr, nullptr, nullptr};
+    HIPCHK(c, launch_wide_out_part(c->stream, c->cg_sum, 1, c->cg_zero, rows, rowinfo ? rowinfo : c->rowinfo_id, row0,
+                                   c->half_jx, p.logit, c->oact, ratio, out, on));
+  }
+  return VMC_OK;
+}
+
 int conv_rows(vmc_ctx* c, int which, const float* configs, const int2* rowinfo, int rows,
               const int* rows_dev, bool ratio, float* out, bool with_tape) {
+  if (c->conv_general) {
+    if (with_tape) return fail(c, VMC_ERR_UNSUPPORTED, "the general convolution path has no gradient tape");
+    int n_rows = rows;
+    if (rows_dev) {            // the blocks need the row count on the host
+      HIPCHK(c, hipMemcpyAsync(&n_rows, rows_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return cgen_forward(c, which, configs, rowinfo, n_rows, nullptr, nullptr, ratio, out);
+  }
   ConvRowsArgs a;
   memset(&a, 0, sizeof(a));
   a.g = c->cg; a.p = conv_params(c->ps[which]);
@@ -459,8 +528,9 @@ int ensure_cache(vmc_ctx* c, int which) {
   if (p.cache_valid) return VMC_OK;
   if (c->conv) {
     Timer t(c, "tail_amp");
-    PROPAGATE(conv_rows(c, which, c->configs, c->rowinfo_id, c->B, nullptr, false, p.logit, which == VMC_PSI));
-    if (which == VMC_PSI) c->acts_valid = true;
+    const bool tape = which == VMC_PSI && !c->conv_general;       // (the general path keeps no gradient tape)
+    PROPAGATE(conv_rows(c, which, c->configs, c->rowinfo_id, c->B, nullptr, false, p.logit, tape));
+    if (tape) c->acts_valid = true;
     p.cache_valid = true;
     return VMC_OK;
   }
@@ -715,7 +785,8 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   {
     char msg[256];
     const char* wf = getenv("CGS_VMC_WIDE_FAST");
-    const int rc = plan_desc(d, !(wf && atoi(wf) == 0), &dp, msg, sizeof(msg));
+    const char* fg = getenv("CGS_VMC_CONV_GENERAL");      // =1: the general convolution path for every shape (tests, A/B runs)
+    const int rc = plan_desc(d, !(wf && atoi(wf) == 0), &dp, msg, sizeof(msg), fg && atoi(fg) != 0);
     if (rc != VMC_OK) return fail(nullptr, rc, msg);
   }
   const bool rbm = dp.rbm != 0, conv = dp.conv != 0, wide = dp.wide != 0, wide_fast_ok = dp.wide_fast != 0;
@@ -732,7 +803,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   c->d = *d;
   c->N = d->n_sites; c->B = d->batch_size; c->L = d->num_layers; c->H = d->layer_size;
   c->rbm = rbm;
-  c->conv = conv; c->cg = cg;
+  c->conv = conv; c->cg = cg; c->conv_general = conv && dp.conv_general != 0;
   if (conv) { c->L = 1; c->overlap = false; }   // minimal dense-side shapes (unused)
   c->wide = wide;
   if (wide) c->overlap = false;
@@ -836,7 +907,19 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     CA(dalloc(&c->wide_iup, B)); CA(dalloc(&c->wide_idn, B)); CA(dalloc(&c->wide_zero, Hp));
     CA(hipMemsetAsync(c->wide_zero, 0, Hp * sizeof(float), c->stream));
   }
-  if (conv) {
+  if (conv && c->conv_general) {
+    // blocks of at most ~768 MB of im2col rows (one row configuration at least), at least B rows when that fits
+    const long long per_row = (long long)cg.N * plan_cgen_lda(cg) * (long long)sizeof(float);
+    long long rows = (768LL << 20) / per_row;
+    if (rows < 1) rows = 1;
+    if (rows > (1LL << 30) / cg.N) rows = (1LL << 30) / cg.N;          // rows * N: the M of a GEMM (int)
+    c->cg_rows = rows;
+    CA(dalloc(&c->cg_A, rows * cg.N * plan_cgen_lda(cg)));
+    for (int i = 0; i < 2; ++i) CA(dalloc(&c->cg_fm[i], rows * cg.N * cgen_fp(cg)));
+    CA(dalloc(&c->cg_sum, rows)); CA(dalloc(&c->cg_zero, 1)); CA(dalloc(&c->cg_lnew, B));
+    CA(hipMemsetAsync(c->cg_zero, 0, sizeof(float), c->stream));
+    CA(dalloc(&c->wide_u, B)); CA(dalloc(&c->wide_iup, B)); CA(dalloc(&c->wide_idn, B));
+  } else if (conv) {
     const long long nl = cg.n_conv > 1 ? cg.n_conv - 1 : 1;
     for (int w = 0; w < 2; ++w) {
       ParamSet& p = c->ps[w];
@@ -885,6 +968,8 @@ void vmc_destroy(vmc_ctx* c) {
                    c->wide_u, c->wide_zero}) if (q) hipFree(q);
   for (int* q : {c->wide_iup, c->wide_idn}) if (q) hipFree(q);
   if (c->wide_dot) hipFree(c->wide_dot);
+  for (float* q : {c->cg_A, c->cg_fm[0], c->cg_fm[1], c->cg_zero, c->cg_lnew}) if (q) hipFree(q);
+  if (c->cg_sum) hipFree(c->cg_sum);
   void* ptrs[] = {c->configs, c->configs_alt, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->wg_tickets, c->d_accepted, c->d_sum,
@@ -1139,6 +1224,36 @@ static int refresh_cache_by_sampler(vmc_ctx* c, int which) {
   return VMC_OK;
 }
 
+// The sampler of the general convolution path: per mc_step the proposals (k_wide_propose: the Philox streams and the
+// arg-max / arg-min rule of every sampler here), a full forward of the B candidates (the exchanged pair negated as the
+// first convolution gathers its operand), the Metropolis test and commit.  In place on configs / logit.
+static int run_sweep_cgen(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int* dbg_up, int* dbg_dn,
+                          float* dbg_u, unsigned long long step0, bool count_accepted) {
+  ParamSet& p = c->ps[0];
+  const int B = c->B, N = c->N;
+  const uint32_t seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull), seed_hi = (uint32_t)(c->d.seed >> 32);
+  if (dbg) {
+    HIPCHK(c, launch_wide_propose(c->stream, c->configs, B, N, seed_lo, seed_hi, c->d.chain_offset, step0, nullptr,
+                                  nullptr, nullptr, dbg_up, dbg_dn, dbg_u));
+    return VMC_OK;
+  }
+  PROPAGATE(ensure_cache(c, VMC_PSI));
+  if (count_accepted) HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), c->stream));
+  Timer t(c, "sweep");
+  for (long long st = 0; st < n_steps; ++st) {
+    HIPCHK(c, launch_wide_propose(c->stream, c->configs, B, N, seed_lo, seed_hi, c->d.chain_offset,
+                                  step0 + (unsigned long long)st, injected ? c->inj_up : nullptr,
+                                  injected ? c->inj_dn : nullptr, injected ? c->inj_u : nullptr, c->wide_iup,
+                                  c->wide_idn, c->wide_u));
+    PROPAGATE(cgen_forward(c, VMC_PSI, c->configs, nullptr, B, c->wide_iup, c->wide_idn, false, c->cg_lnew));
+    HIPCHK(c, launch_cgen_accept(c->stream, c->configs, p.logit, c->cg_lnew, c->wide_iup, c->wide_idn, c->wide_u, B, N,
+                                 c->oact, c->d_accepted, injected ? c->acc_mask : nullptr));
+  }
+  c->acts_valid = false;
+  c->acc_since_sweep = false;
+  return VMC_OK;
+}
+
 static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int* dbg_up, int* dbg_dn,
                      float* dbg_u, unsigned long long step0, bool count_accepted = false,
                      bool overtake = false, hipEvent_t dep = nullptr) {
@@ -1146,6 +1261,8 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
   if (!dbg) c->cnt_valid = false;   // the chains change (set again below when this launch leaves their census)
   if (c->wide && !c->wide_fast)
     return run_sweep_wide(c, n_steps, injected, dbg, dbg_up, dbg_dn, dbg_u, step0, count_accepted);
+  if (c->conv_general)
+    return run_sweep_cgen(c, n_steps, injected, dbg, dbg_up, dbg_dn, dbg_u, step0, count_accepted);
   ParamSet& p = c->ps[0];
   SweepArgs a;
   memset(&a, 0, sizeof(a));
@@ -1358,7 +1475,7 @@ int vmc_local_energy_terms(vmc_ctx* c, int which, float* diag, float* offdiag_ov
 int vmc_debug_kernel_path(vmc_ctx* c, int32_t* path) {
   CHECK_CTX(c);
   if (!path) return fail(c, VMC_ERR_INVALID, "null");
-  *path = c->conv ? 3 : (c->wide ? (c->wide_fast ? 1 : 2) : (c->split ? (c->split_sweep ? 5 : 4) : 0));
+  *path = c->conv ? (c->conv_general ? 6 : 3) : (c->wide ? (c->wide_fast ? 1 : 2) : (c->split ? (c->split_sweep ? 5 : 4) : 0));
   return VMC_OK;
 }
 
@@ -1514,10 +1631,15 @@ static int sr_record(vmc_ctx* c) {
   return VMC_OK;
 }
 
+// (the gradient accumulators and SR of a convolutional ctx beyond the fused kernels' limits: not built yet)
+#define CGEN_NO_GRADIENTS(c) \
+  do { if ((c)->conv_general) return fail(c, VMC_ERR_UNSUPPORTED, "the general convolution path (kernel_size > 9, num_conv_filters > 64 or feature maps beyond 160 KiB of LDS) evaluates amplitudes, local energies and Monte-Carlo steps; its gradient accumulators are not available"); } while (0)
+
 int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   ENTER(c);
   if (mode != VMC_MODE_ENERGY_GRADIENT && mode != VMC_MODE_LOG_OVERLAP_ITSWO)
     return fail(c, VMC_ERR_INVALID, "bad mode");
+  CGEN_NO_GRADIENTS(c);
   const float* w = nullptr;
   const float* e = nullptr;
   // everything this call enqueues comes after ev_mark; a sampler launch that follows directly
@@ -1917,6 +2039,7 @@ int vmc_evaluate(vmc_ctx* c, void* nccl_comm, int32_t world_size, int64_t n_eq_s
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   ENTER(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
+  if (n_batches > 0) CGEN_NO_GRADIENTS(c);
   if (n_batches > 0 && c->oact != VMC_ACT_EXP_)
     return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation (every hidden activation)");
   HIPCHK(c, hipStreamSynchronize(c->stream));

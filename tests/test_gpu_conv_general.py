@@ -1,0 +1,133 @@
+"""GPU parity of the GENERAL convolution path (csrc/conv_general.hip, kernel_path() == 6) against the numpy oracle,
+through the C ABI: Conv2DNetwork / ResNet2D / Conv1DNetwork / ResNet1D (wavefunctions.py:455-809 on
+layers.Conv*Periodic / ResBlock*, layers.py:24-293) at shapes the fused kernels refuse -- num_conv_filters > 64,
+kernel_size > 9, feature maps beyond 160 KiB of LDS; the reference takes any value (utils.py:107-111) -- and, forced
+with CGS_VMC_CONV_GENERAL=1, at shapes both paths take, where the two must agree.  Amplitudes, local energies,
+proposals, injected steps and trajectories; the gradient accumulators of this path are not built and must refuse.
+Tolerances as tests/test_gpu_conv.py."""
+import numpy as np
+import pytest
+
+from oracle import vmc_oracle as vo
+from tests.test_gpu_conv import _close, _logits_close, _make
+
+pytestmark = pytest.mark.gpu
+
+GENERAL_SHAPES = [
+    # ansatz, size_x, size_y, num_layers / num_blocks, filters, kernel, B, nonlinearity
+    ('conv_2d', 4, 4, 2, 80, 3, 12, 'relu'),        # more than 64 filters
+    ('conv_2d', 6, 6, 3, 72, 3, 9, 'tanh'),
+    ('conv_2d', 4, 4, 2, 130, 3, 6, 'relu'),        # filters no multiple of 4: the scalar gather, the strided GEMM
+    ('conv_2d', 6, 6, 2, 128, 3, 600, 'relu'),      # 21,600 x 1152 x 128: the second convolution runs on k_gemm_ring
+    ('conv_2d', 10, 10, 2, 8, 11, 7, 'relu'),       # kernel_size > 9
+    ('conv_2d', 12, 12, 2, 6, 10, 5, 'sigmoid'),    # ... even: k/2 - 1 in front, k/2 behind
+    ('conv_2d', 20, 20, 2, 64, 3, 4, 'relu'),       # two maps of 102 KB: beyond the LDS of the fused kernels
+    ('conv_2d', 40, 40, 3, 16, 5, 3, 'cos'),       # 1,600 sites at 16 filters: two maps of 102 KB
+    ('res_net_2d', 4, 4, 2, 96, 3, 8, 'relu'),
+    ('res_net_2d', 8, 8, 1, 12, 10, 6, 'relu'),
+    ('res_net_2d', 4, 6, 0, 70, 3, 5, 'relu'),      # no block: the initial convolution alone
+    ('conv_1d', 30, 1, 3, 100, 5, 9, 'relu'),
+    ('conv_1d', 26, 1, 2, 10, 12, 8, 'tanh'),       # even 1-D kernel: k/2 in front, k/2 - 1 behind
+    ('res_net_1d', 24, 1, 2, 70, 3, 7, 'relu'),
+]
+IDS = ['{}-{}x{}-L{}-F{}-K{}-B{}-{}'.format(*s) for s in GENERAL_SHAPES]
+# shapes both paths take (a subset of tests/test_gpu_conv.py's)
+BOTH = [
+    ('conv_2d', 6, 4, 3, 16, 5, 33, 'tanh'),
+    ('conv_2d', 4, 6, 3, 8, 4, 24, 'sigmoid'),
+    ('conv_2d', 5, 5, 2, 5, 2, 17, 'relu'),
+    ('conv_2d', 3, 4, 1, 16, 3, 9, 'relu'),
+    ('conv_2d', 10, 10, 5, 16, 5, 40, 'relu'),
+    ('conv_2d', 6, 6, 3, 64, 5, 13, 'tanh'),
+    ('conv_2d', 6, 4, 2, 12, 9, 9, 'sigmoid'),
+    ('res_net_2d', 6, 6, 2, 16, 5, 40, 'relu'),
+    ('res_net_2d', 5, 4, 1, 16, 4, 12, 'relu'),
+    ('conv_1d', 10, 1, 2, 8, 4, 17, 'tanh'),
+    ('res_net_1d', 24, 1, 1, 12, 6, 13, 'relu'),
+]
+
+
+def _check_forward_and_sampler(eng, theta, cfg, bonds, geom, ansatz, L, nonlin, b, steps=6):
+  sx, sy = geom[2], geom[3]
+  n = sx * sy
+  psi_fn = vo.ANSATZ[ansatz][0]
+  logit, psi = eng.amplitude(cfg)
+  _logits_close(logit, theta, cfg, ansatz, geom, L, nonlin)
+  _logits_close(eng.amplitude()[0], theta, cfg, ansatz, geom, L, nonlin)             # cached path
+  with np.errstate(over='ignore'):
+    np.testing.assert_allclose(psi, np.exp(logit.astype(np.float32) + np.float32(10.0)), rtol=1e-6)
+  c2 = vo.random_configurations(n, 21, np.random.RandomState(9))
+  _logits_close(eng.amplitude(c2)[0], theta, c2, ansatz, geom, L, nonlin)
+  amp = lambda c: psi_fn(theta, c, geom, L, nonlinearity=nonlin, dtype=np.float64)
+  for jx in (-1.0, 1.0):
+    eng.set_bonds(bonds, jx, 1.0)
+    _close(eng.local_energy()[0], vo.local_value(amp, cfg, bonds, jx, 1.0, dtype=np.float64), 2e-4)
+  u_sites, u_acc = vo.step_uniforms(2024, np.arange(b), 7, n)
+  i_up, i_dn = vo.propose_exchange(cfg, u_sites)
+  g_up, g_dn, g_u = eng.debug_proposals(7)
+  np.testing.assert_array_equal(g_up, i_up); np.testing.assert_array_equal(g_dn, i_dn)
+  np.testing.assert_array_equal(g_u, u_acc)
+  cur = cfg
+  for step in range(2):
+    u_sites, u_acc = vo.step_uniforms(99, np.arange(b), step, n)
+    i_up, i_dn = vo.propose_exchange(cur, u_sites)
+    _, acc_ref, ratios = vo.mc_step(amp, cur, i_up, i_dn, u_acc)
+    mask = eng.mc_step_injected(i_up, i_dn, u_acc)
+    band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
+    assert np.array_equal(mask[~band], acc_ref[~band])
+    expect = cur.copy()
+    rows = np.arange(b)[mask]
+    expect[rows, i_dn[mask]] = 1.0
+    expect[rows, i_up[mask]] = -1.0
+    got = eng.get_configs()
+    np.testing.assert_array_equal(got, expect)
+    cur = got
+    _logits_close(eng.amplitude()[0], theta, cur, ansatz, geom, L, nonlin)
+  eng.step_counter = 0
+  start = cur.copy()
+  ok = np.ones(b, bool)
+  for step in range(steps):
+    u_sites, u_acc = vo.step_uniforms(2024, np.arange(b), step, n)
+    i_up, i_dn = vo.propose_exchange(cur, u_sites)
+    cur, acc, ratios = vo.mc_step(amp, cur, i_up, i_dn, u_acc)
+    ok &= ~(np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30))
+  accepted = eng.mc_steps(steps)
+  got = eng.get_configs()
+  np.testing.assert_array_equal(got[ok], cur[ok])
+  assert ok.sum() > b // 2 and (got.sum(1) == start.sum(1)).all() and 0 <= accepted <= steps * b
+  _close(eng.local_energy()[0], vo.local_value(amp, got, bonds, 1.0, 1.0, dtype=np.float64), 2e-4)
+
+
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', GENERAL_SHAPES, ids=IDS)
+def test_general_convolution_beyond_the_fused_limits(ansatz, sx, sy, L, f, k, b, nonlin):
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6
+  _check_forward_and_sampler(eng, theta, cfg, bonds, geom, ansatz, L, nonlin, b, steps=4 if b > 100 else 6)
+  eng.close()
+
+
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', BOTH)
+def test_general_and_fused_convolution_paths_agree(monkeypatch, ansatz, sx, sy, L, f, k, b, nonlin):
+  monkeypatch.delenv('CGS_VMC_CONV_GENERAL', raising=False)
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 3
+  fused = (eng.amplitude()[0], eng.local_energy()[0])
+  eng.close()
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6
+  _, scale = vo.conv_forward(theta, cfg, ansatz, geom, L, nonlin, np.float64, return_tape='scale')
+  assert (np.abs(eng.amplitude()[0].astype(np.float64) - fused[0]) <= 2e-6 * scale + 4e-5).all()
+  _close(eng.local_energy()[0], fused[1], 4e-4)
+  _check_forward_and_sampler(eng, theta, cfg, bonds, geom, ansatz, L, nonlin, b)
+  eng.close()
+
+
+def test_general_convolution_path_refuses_the_gradient_entries():
+  from cgs_vmc_amd import _hip
+  eng, theta, cfg, bonds, geom = _make('conv_2d', 4, 4, 2, 80, 3, 12, 'relu')
+  eng.reset_accumulators()
+  with pytest.raises(Exception) as e:
+    eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  assert 'general convolution path' in str(e.value)
+  eng.close()
