@@ -23,7 +23,8 @@ def test_host_planners_under_asan_and_ubsan():
   assert p.returncode == 0, out[-4000:]
   assert '-fsanitize=address,undefined' in out
   assert 'ERROR: AddressSanitizer' not in out and 'runtime error' not in out
-  m = re.search(r'hostcheck ok: (\d+) shapes \((\d+) rejected by plan_desc\), (\d+) assertions', out)
+  m = re.search(r'hostcheck ok: (\d+) shapes \((\d+) rejected by plan_desc, (\d+) convolutional ones on the general path\), '
+                r'(\d+) assertions', out)
   assert m, out[-2000:]
-  shapes, rejected, checks = map(int, m.groups())
-  assert shapes > 50000 and 0 < rejected < shapes and checks > 10 ** 8
+  shapes, rejected, general, checks = map(int, m.groups())
+  assert shapes > 50000 and 0 < rejected < shapes and 0 < general < shapes and checks > 10 ** 8
