@@ -127,6 +127,7 @@ struct CgenIm2colArgs {
   const float* src;          // layer 0: configs [n_base][N]; else the input map [rows][N][Fp]
   int Fp;
   int pre_act;               // applied to the gathered values (layer > 0)
+  int inverse;               // layer > 0: gather of the TRANSPOSED convolution (the position whose tap t reads the site)
   const int2* rowinfo;       // layer 0: [..] {chain, +-(bond+1) or 0}, or nullptr: row r is chain row0 + r
   long long row0;            // first row of this block in rowinfo / iup / idn
   const int2* bonds;
@@ -140,3 +141,9 @@ hipError_t launch_cgen_rowsum(hipStream_t s, const float* fm, int rows, int N, i
 hipError_t launch_cgen_accept(hipStream_t s, float* configs, float* logit, const float* lnew, const int* iup,
                               const int* idn, const float* u, int B, int N, int oact, unsigned long long* accepted,
                               unsigned char* acc_mask);
+// gradient path: d logit / d (last map), d (.) f'(z), per-position weights, transposed weight image [T F][F] of a layer >= 1
+hipError_t launch_cgen_fill(hipStream_t s, float* gm, const float* oscale, long long row0, int rows, int N, int F, int Fp);
+hipError_t launch_cgen_dact(hipStream_t s, const float* d, const float* z, int pre, long long n, int F, int Fp, float* out);
+hipError_t launch_cgen_wpos(hipStream_t s, const float* w, long long row0, int rows, int N, float* wpos);
+hipError_t launch_cgen_pack_t(hipStream_t s, const float* w, int T, int F, float* wt);
+inline long long cgen_off_wt(const ConvGeom& g, int l) { return (long long)(l - 1) * g.K * g.KW * g.F * g.F; }   // l >= 1

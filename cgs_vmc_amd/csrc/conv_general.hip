@@ -25,11 +25,13 @@ __device__ __forceinline__ float cg_pre(int pre, float x) {
 }
 
 // site index of tap t at position n: ((a1 + d1 - lo) mod D1, (a2 + d2 - lo2) mod D2), layers.py:132-141 / 66-72
-__device__ __forceinline__ int cg_site(const ConvGeom& g, int n, int t) {
+// inverse: the position whose tap t reads site n, ((a1 - d1 + lo) mod D1, (a2 - d2 + lo2) mod D2) -- the gather of
+// the transposed convolution (d / d input from d / d output)
+__device__ __forceinline__ int cg_site(const ConvGeom& g, int n, int t, bool inverse = false) {
   const int a1 = n / g.D2, a2 = n - a1 * g.D2;
   const int d1 = t / g.KW, d2 = t - d1 * g.KW;
-  int s1 = (a1 + d1 - g.lo) % g.D1; if (s1 < 0) s1 += g.D1;
-  int s2 = (a2 + d2 - g.lo2) % g.D2; if (s2 < 0) s2 += g.D2;
+  int s1 = (inverse ? a1 - d1 + g.lo : a1 + d1 - g.lo) % g.D1; if (s1 < 0) s1 += g.D1;
+  int s2 = (inverse ? a2 - d2 + g.lo2 : a2 + d2 - g.lo2) % g.D2; if (s2 < 0) s2 += g.D2;
   return s1 * g.D2 + s2;
 }
 
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void k_cgen_im2col(CgenIm2colArgs a) {
     const int t = (int)(mt % T);
     const long long m = mt / T;
     const int r = (int)(m / g.N), n = (int)(m - (long long)r * g.N);
-    const float* src = a.src + ((long long)r * g.N + cg_site(g, n, t)) * a.Fp + VEC * cq;
+    const float* src = a.src + ((long long)r * g.N + cg_site(g, n, t, a.inverse != 0)) * a.Fp + VEC * cq;
     float* dst = a.A + m * a.lda + (long long)t * g.F + VEC * cq;
     if (VEC == 4) {
       f32x4 v = *(const f32x4*)src;
@@ -121,6 +123,51 @@ __global__ __launch_bounds__(256) void k_cgen_accept(float* __restrict__ configs
   if (threadIdx.x == 0 && s_n) atomicAdd(accepted, (unsigned long long)s_n);
 }
 
+// ---- gradient path
+__device__ __forceinline__ float cg_dpre(int pre, float z) {    // f'(z) of the gather's activation
+  if (pre < 0) return 1.f;
+  if (pre == CGEN_PRE_SELU) {
+    const float scale = 1.0507009873554805f, alpha = 1.6732632423543772f;
+    return z > 0.f ? scale : scale * alpha * expf(z);
+  }
+  return vmc_dact_rt(pre, z, vmc_act_rt(pre, z));
+}
+
+// d logit / d (last map) = the per-sample output factor (1 for the exp output); padding channels 0
+__global__ void k_cgen_fill(float* __restrict__ gm, const float* __restrict__ oscale, long long row0, int rows, int N,
+                            int F, int Fp) {
+  const long long total = (long long)rows * N * Fp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ((long long)N * Fp));
+    gm[i] = (int)(i % Fp) < F ? (oscale ? oscale[row0 + r] : 1.f) : 0.f;
+  }
+}
+
+// out = d (.) f'(z)  (d / d pre-activation from d / d activation); padding channels 0
+__global__ void k_cgen_dact(const float* __restrict__ d, const float* __restrict__ z, int pre, long long n, int F,
+                            int Fp, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = (int)(i % Fp) < F ? d[i] * cg_dpre(pre, z[i]) : 0.f;
+}
+
+// per-position copy of the per-sample weights: the k-scale of the weight-gradient products
+__global__ void k_cgen_wpos(const float* __restrict__ w, long long row0, int rows, int N, float* __restrict__ wpos) {
+  const long long total = (long long)rows * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    wpos[i] = w[row0 + i / N];
+}
+
+// transposed weight image of convolution l >= 1: wt[(t F + o) F + c] = w[(t F + c) F + o]
+__global__ void k_cgen_pack_t(const float* __restrict__ w, int T, int F, float* __restrict__ wt) {
+  const long long total = (long long)T * F * F;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % F);
+    const long long to = i / F;
+    const int o = (int)(to % F), t = (int)(to / F);
+    wt[i] = w[((long long)t * F + c) * F + o];
+  }
+}
+
 int cg_blocks(long long n) { const long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b < 16384 ? b : 16384)); }
 
 }  // namespace
@@ -150,5 +197,28 @@ hipError_t launch_cgen_accept(hipStream_t s, float* configs, float* logit, const
                               unsigned char* acc_mask) {
   hipLaunchKernelGGL(k_cgen_accept, dim3((B + 255) / 256), dim3(256), 0, s, configs, logit, lnew, iup, idn, u, B, N,
                      oact, accepted, acc_mask);
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_fill(hipStream_t s, float* gm, const float* oscale, long long row0, int rows, int N, int F, int Fp) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cgen_fill, dim3(cg_blocks((long long)rows * N * Fp)), dim3(256), 0, s, gm, oscale, row0, rows, N, F, Fp);
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_dact(hipStream_t s, const float* d, const float* z, int pre, long long n, int F, int Fp, float* out) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cgen_dact, dim3(cg_blocks(n)), dim3(256), 0, s, d, z, pre, n, F, Fp, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_wpos(hipStream_t s, const float* w, long long row0, int rows, int N, float* wpos) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cgen_wpos, dim3(cg_blocks((long long)rows * N)), dim3(256), 0, s, w, row0, rows, N, wpos);
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_pack_t(hipStream_t s, const float* w, int T, int F, float* wt) {
+  hipLaunchKernelGGL(k_cgen_pack_t, dim3(cg_blocks((long long)T * F * F)), dim3(256), 0, s, w, T, F, wt);
   return hipGetLastError();
 }

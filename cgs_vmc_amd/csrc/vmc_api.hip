@@ -77,6 +77,10 @@ struct vmc_ctx {
   double* cg_sum = nullptr;                // [cg_rows] sums of the last map
   float* cg_zero = nullptr;                // one 0.f (the "b_out" of wide_out_finish)
   float* cg_lnew = nullptr;                // [B] candidate logits of the sampler
+  // ... its gradient path (allocated by the first gradient call): the pre-activation of every convolution, two
+  // d logit / d map buffers, per-position weights, the transposed weight images, the split-K workspace
+  float* cg_tape = nullptr; float* cg_g[2] = {nullptr, nullptr}; float* cg_wpos = nullptr; float* cg_wt = nullptr;
+  float* cg_ws = nullptr; long long cg_ws_floats = 0;
   int *wide_iup = nullptr, *wide_idn = nullptr;
   int hact = VMC_ACT_RELU_;  // hidden activation (layers.NONLINEARITIES id)
   int oact = VMC_ACT_EXP_;   // output activation; exp: psi = exp(x - shift), else psi = g(x), no shift
@@ -377,12 +381,15 @@ ConvParams conv_params(const ParamSet& p) { return ConvParams{p.cw0, p.cwf, p.cw
 // gather (the hidden activation applied as the operand is gathered: every stored map is a pre-activation) and one
 // GEMM against the parameter slice in theta; ResBlock2d's `v + h` (layers.py:227) is the accumulate epilogue.
 // iup / idn != nullptr: row r is chain r with that pair exchanged (the sampler's candidates).
-static int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2* rowinfo, long long n_rows,
-                        const int* iup, const int* idn, bool ratio, float* out) {
+int ensure_cache(vmc_ctx* c, int which);
+
+// One convolution of the general path over `rows` row configurations: im2col gather of its input into cg_A, then the
+// product with the parameter slice; residual: dst += (ResBlock2d's `v + h`).
+static int cgen_conv(vmc_ctx* c, const ParamSet& p, const float* configs, const int2* rowinfo, const int* iup,
+                     const int* idn, int l, int rows, const float* in, int pre, float* dst, bool residual, long long row0) {
   const ConvGeom& g = c->cg;
-  const ParamSet& p = c->ps[which];
   const int Fp = cgen_fp(g), lda = plan_cgen_lda(g);
-  auto conv = [&](int l, int rows, const float* in, int pre, float* dst, bool residual, long long row0) -> int {
+  {
     CgenIm2colArgs a;
     memset(&a, 0, sizeof(a));
     a.g = g; a.layer = l; a.Fp = Fp; a.pre_act = pre; a.rows = rows; a.lda = lda; a.A = c->cg_A;
@@ -399,27 +406,150 @@ static int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2*
     m.M = rows * g.N; m.N = g.F; m.K = cgen_kdim(g, l); m.C = dst; m.ldc = Fp;
     m.bias = p.theta + cgen_off_b(g, l); m.epilogue = residual ? 8 : 4; m.splitk = 1;
     HIPCHK(c, launch_gemm(c->stream, m));
-    return VMC_OK;
+  }
+  return VMC_OK;
+}
+
+// tape != nullptr (gradient path, n_rows <= cg_rows): the map of convolution l is kept at tape + l * tape_stride --
+// its pre-activation; for the second convolution of a residual block the block's output h + v
+static int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2* rowinfo, long long n_rows,
+                        const int* iup, const int* idn, bool ratio, float* out, float* tape = nullptr,
+                        long long tape_stride = 0, long long first_row = 0) {
+  const ConvGeom& g = c->cg;
+  const ParamSet& p = c->ps[which];
+  const int Fp = cgen_fp(g);
+  auto conv = [&](int l, int rows, const float* in, int pre, float* dst, bool residual, long long row0) -> int {
+    return cgen_conv(c, p, configs, rowinfo, iup, idn, l, rows, in, pre, dst, residual, row0);
   };
-  for (long long row0 = 0; row0 < n_rows; row0 += c->cg_rows) {
-    const int rows = (int)(n_rows - row0 < c->cg_rows ? n_rows - row0 : c->cg_rows);
+  auto map = [&](int l) { return tape ? tape + (long long)l * tape_stride : c->cg_fm[g.resnet ? (l & 1 ? 1 : 0) : (l & 1)]; };
+  if (tape && n_rows > c->cg_rows) return fail(c, VMC_ERR_STATE, "taped forward beyond one block");
+  for (long long blk0 = 0; blk0 < n_rows; blk0 += c->cg_rows) {
+    const long long row0 = first_row + blk0;
+    const int rows = (int)(n_rows - blk0 < c->cg_rows ? n_rows - blk0 : c->cg_rows);
     const float* last;
-    PROPAGATE(conv(0, rows, nullptr, -1, c->cg_fm[0], false, row0));
+    PROPAGATE(conv(0, rows, nullptr, -1, map(0), false, row0));
     if (!g.resnet) {           // Conv2DNetwork (wavefunctions.py:572-575): act between the convolutions, none behind the last
       for (int l = 1; l < g.n_conv; ++l)
-        PROPAGATE(conv(l, rows, c->cg_fm[(l - 1) & 1], g.hact, c->cg_fm[l & 1], false, row0));
-      last = c->cg_fm[(g.n_conv - 1) & 1];
+        PROPAGATE(conv(l, rows, map(l - 1), g.hact, map(l), false, row0));
+      last = map(g.n_conv - 1);
     } else {                   // ResNet2D (wavefunctions.py:766-772; layers.py:226-228): h += second(selu(first(h)))
       for (int l = 1; l + 1 < g.n_conv; l += 2) {
-        PROPAGATE(conv(l, rows, c->cg_fm[0], -1, c->cg_fm[1], false, row0));
-        PROPAGATE(conv(l + 1, rows, c->cg_fm[1], CGEN_PRE_SELU, c->cg_fm[0], true, row0));
+        const float* h = tape ? map(l - 1) : c->cg_fm[0];
+        float* u = tape ? map(l) : c->cg_fm[1];
+        float* hn = tape ? map(l + 1) : c->cg_fm[0];
+        PROPAGATE(conv(l, rows, h, -1, u, false, row0));
+        if (tape) HIPCHK(c, hipMemcpyAsync(hn, h, (size_t)rows * g.N * Fp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        PROPAGATE(conv(l + 1, rows, u, CGEN_PRE_SELU, hn, true, row0));
       }
-      last = c->cg_fm[0];
+      last = tape ? map(g.n_conv - 1) : c->cg_fm[0];
     }
     HIPCHK(c, launch_cgen_rowsum(c->stream, last, rows, g.N, g.F, Fp, c->cg_sum));
     const WideOnsite on{nullptr, nullptr, nullptr, nullptr, nullptr};
     HIPCHK(c, launch_wide_out_part(c->stream, c->cg_sum, 1, c->cg_zero, rows, rowinfo ? rowinfo : c->rowinfo_id, row0,
                                    c->half_jx, p.logit, c->oact, ratio, out, on));
+  }
+  return VMC_OK;
+}
+
+// Gradient sums of the general path: g1 += sum_b O_b, g2 += sum_b w_b O_b (training.py:545-547), a block of chains at a
+// time.  Taped forward (the pre-activation of every convolution), then from the last convolution down:
+//   d / d W_l = im2col(x_l)^T G_l with the bias as an implicit row of ones -- ONE product per convolution for both sums
+//               (k_gemm: dual product with the per-position weights as the k-scale, split-K) -- G_l = d logit / d z_l;
+//   d / d x_l = the transposed convolution = im2col_inverse(G_l) against the transposed weight image;
+//   G_{l-1}   = d / d x_l (.) f'(z_{l-1}); residual blocks: d / d h accumulates both branches.
+static int cgen_gradient_sums(vmc_ctx* c, const float* w) {
+  const ConvGeom& g = c->cg;
+  ParamSet& p = c->ps[0];
+  const int Fp = cgen_fp(g), lda = plan_cgen_lda(g), T = g.K * g.KW, n_conv = g.n_conv;
+  const long long rows_max = c->cg_rows < c->B ? c->cg_rows : c->B;
+  const long long map_floats = rows_max * g.N * Fp;
+  float* g1 = c->acc;
+  float* g2 = c->acc + c->P;
+  const int kmax = T * (n_conv > 1 ? g.F : 1) + 1;                      // rows of the largest weight-gradient product
+  const int splitk = 32;
+  if (!c->cg_tape) {
+    HIPCHK(c, dalloc(&c->cg_tape, (long long)n_conv * map_floats));
+    for (int i = 0; i < 2; ++i) HIPCHK(c, dalloc(&c->cg_g[i], map_floats));
+    HIPCHK(c, dalloc(&c->cg_wpos, rows_max * g.N));
+    if (n_conv > 1) HIPCHK(c, dalloc(&c->cg_wt, cgen_off_wt(g, n_conv)));
+    c->cg_ws_floats = (long long)splitk * 2 * kmax * g.F;
+    HIPCHK(c, dalloc(&c->cg_ws, c->cg_ws_floats));
+  }
+  for (int l = 1; l < n_conv; ++l)
+    HIPCHK(c, launch_cgen_pack_t(c->stream, p.theta + cgen_off_w(g, l), T, g.F, c->cg_wt + cgen_off_wt(g, l)));
+  if (c->oact != VMC_ACT_EXP_) {
+    PROPAGATE(ensure_cache(c, VMC_PSI));
+    HIPCHK(c, launch_out_scale(c->stream, p.logit, c->oscale, c->B, c->oact));
+  }
+  auto tape = [&](int l) { return c->cg_tape + (long long)l * map_floats; };
+  for (long long row0 = 0; row0 < c->B; row0 += rows_max) {
+    const int rows = (int)(c->B - row0 < rows_max ? c->B - row0 : rows_max);
+    const long long M = (long long)rows * g.N;
+    PROPAGATE(cgen_forward(c, VMC_PSI, c->configs, nullptr, rows, nullptr, nullptr, false, c->cg_lnew, c->cg_tape,
+                           map_floats, row0));     // (its logits land in cg_lnew[row0 ..]: unused)
+    HIPCHK(c, launch_cgen_wpos(c->stream, w, row0, rows, g.N, c->cg_wpos));
+    // gather the input of convolution l into cg_A (as its forward did)
+    auto gather_input = [&](int l) -> int {
+      CgenIm2colArgs a;
+      memset(&a, 0, sizeof(a));
+      a.g = g; a.layer = l; a.Fp = Fp; a.rows = rows; a.lda = lda; a.A = c->cg_A; a.pre_act = -1;
+      if (l == 0) { a.src = c->configs; a.row0 = row0; a.bonds = c->bonds ? c->bonds : c->bond_dummy; }
+      else if (!g.resnet) { a.src = tape(l - 1); a.pre_act = g.hact; }
+      else if (l & 1) { a.src = tape(l - 1); }                              // first convolution of a block: h
+      else { a.src = tape(l - 1); a.pre_act = CGEN_PRE_SELU; }              // second: selu(u)
+      HIPCHK(c, launch_cgen_im2col(c->stream, a));
+      return VMC_OK;
+    };
+    // [w_l ; b_l] += [im2col(x_l) | 1]^T [G | w (.) G]
+    auto weight_sums = [&](int l, const float* G) -> int {
+      PROPAGATE(gather_input(l));
+      const int kd = cgen_kdim(g, l);
+      GemmArgs m; memset(&m, 0, sizeof(m));
+      m.A = c->cg_A; m.sam = 1; m.sak = lda;                                // A(i, k = position) = im2col[k][i]
+      m.B = G; m.sbk = Fp; m.sbn = 1;
+      m.kscale = c->cg_wpos; m.dual = 1; m.ones_row = 1;
+      m.M = kd + 1; m.N = g.F; m.K = (int)M;
+      m.C = g1 + cgen_off_w(g, l); m.C2 = g2 + cgen_off_w(g, l); m.ldc = g.F;
+      m.epilogue = 3; m.splitk = M >= 4096 ? splitk : 1; m.workspace = c->cg_ws;
+      HIPCHK(c, launch_gemm(c->stream, m));
+      return VMC_OK;
+    };
+    // dst (+)= the transposed convolution l of G
+    auto input_grad = [&](int l, const float* G, float* dst, bool accumulate) -> int {
+      CgenIm2colArgs a;
+      memset(&a, 0, sizeof(a));
+      a.g = g; a.layer = l; a.Fp = Fp; a.rows = rows; a.lda = lda; a.A = c->cg_A; a.pre_act = -1; a.inverse = 1;
+      a.src = G;
+      HIPCHK(c, launch_cgen_im2col(c->stream, a));
+      GemmArgs m; memset(&m, 0, sizeof(m));
+      m.A = c->cg_A; m.sam = lda; m.sak = 1;
+      m.B = c->cg_wt + cgen_off_wt(g, l); m.sbk = g.F; m.sbn = 1;
+      m.M = (int)M; m.N = g.F; m.K = T * g.F; m.C = dst; m.ldc = Fp;
+      m.epilogue = accumulate ? 3 : 0; m.splitk = 1;
+      HIPCHK(c, launch_gemm(c->stream, m));
+      return VMC_OK;
+    };
+    float* G = c->cg_g[0];
+    float* D = c->cg_g[1];
+    HIPCHK(c, launch_cgen_fill(c->stream, G, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr, row0, rows, g.N, g.F, Fp));
+    if (!g.resnet) {
+      for (int l = n_conv - 1; l >= 0; --l) {
+        PROPAGATE(weight_sums(l, G));
+        if (l == 0) break;
+        PROPAGATE(input_grad(l, G, D, false));
+        HIPCHK(c, launch_cgen_dact(c->stream, D, tape(l - 1), g.hact, M * Fp, g.F, Fp, G));
+      }
+    } else {                   // G = d / d h
+      for (int l2 = n_conv - 1; l2 >= 2; l2 -= 2) {
+        const int l1 = l2 - 1;
+        PROPAGATE(weight_sums(l2, G));
+        PROPAGATE(input_grad(l2, G, D, false));                                          // d / d selu(u)
+        HIPCHK(c, launch_cgen_dact(c->stream, D, tape(l1), CGEN_PRE_SELU, M * Fp, g.F, Fp, D));   // d / d u
+        PROPAGATE(weight_sums(l1, D));
+        PROPAGATE(input_grad(l1, D, G, true));                                           // d / d h += through the block
+      }
+      PROPAGATE(weight_sums(0, G));
+    }
   }
   return VMC_OK;
 }
@@ -968,7 +1098,8 @@ void vmc_destroy(vmc_ctx* c) {
                    c->wide_u, c->wide_zero}) if (q) hipFree(q);
   for (int* q : {c->wide_iup, c->wide_idn}) if (q) hipFree(q);
   if (c->wide_dot) hipFree(c->wide_dot);
-  for (float* q : {c->cg_A, c->cg_fm[0], c->cg_fm[1], c->cg_zero, c->cg_lnew}) if (q) hipFree(q);
+  for (float* q : {c->cg_A, c->cg_fm[0], c->cg_fm[1], c->cg_zero, c->cg_lnew, c->cg_tape, c->cg_g[0], c->cg_g[1], c->cg_wpos,
+                   c->cg_wt, c->cg_ws}) if (q) hipFree(q);
   if (c->cg_sum) hipFree(c->cg_sum);
   void* ptrs[] = {c->configs, c->configs_alt, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
@@ -1492,6 +1623,7 @@ static int gradient_sums(vmc_ctx* c, const float* w, bool fresh, const float* e,
   float* g1 = c->acc;
   float* g2 = c->acc + c->P;
   Timer t(c, "grad");
+  if (c->conv_general) return cgen_gradient_sums(c, w);
   if (c->conv) {
     // forward tapes (the inputs of every convolution), d logit / d (output of every convolution)
     // back through the transposed convolutions, then the weight-gradient correlations
@@ -1631,15 +1763,14 @@ static int sr_record(vmc_ctx* c) {
   return VMC_OK;
 }
 
-// (the gradient accumulators and SR of a convolutional ctx beyond the fused kernels' limits: not built yet)
-#define CGEN_NO_GRADIENTS(c) \
-  do { if ((c)->conv_general) return fail(c, VMC_ERR_UNSUPPORTED, "the general convolution path (kernel_size > 9, num_conv_filters > 64 or feature maps beyond 160 KiB of LDS) evaluates amplitudes, local energies and Monte-Carlo steps; its gradient accumulators are not available"); } while (0)
+// (stochastic reconfiguration -- an extension -- of a convolutional ctx beyond the fused kernels' limits: not built)
+#define CGEN_NO_SR(c) \
+  do { if ((c)->conv_general) return fail(c, VMC_ERR_UNSUPPORTED, "the general convolution path (kernel_size > 9, num_conv_filters > 64 or feature maps beyond 160 KiB of LDS) has amplitudes, local energies, Monte-Carlo steps and the gradient accumulators; stochastic reconfiguration is not available on it"); } while (0)
 
 int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   ENTER(c);
   if (mode != VMC_MODE_ENERGY_GRADIENT && mode != VMC_MODE_LOG_OVERLAP_ITSWO)
     return fail(c, VMC_ERR_INVALID, "bad mode");
-  CGEN_NO_GRADIENTS(c);
   const float* w = nullptr;
   const float* e = nullptr;
   // everything this call enqueues comes after ev_mark; a sampler launch that follows directly
@@ -2039,7 +2170,7 @@ int vmc_evaluate(vmc_ctx* c, void* nccl_comm, int32_t world_size, int64_t n_eq_s
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   ENTER(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
-  if (n_batches > 0) CGEN_NO_GRADIENTS(c);
+  if (n_batches > 0) CGEN_NO_SR(c);
   if (n_batches > 0 && c->oact != VMC_ACT_EXP_)
     return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation (every hidden activation)");
   HIPCHK(c, hipStreamSynchronize(c->stream));

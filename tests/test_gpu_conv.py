@@ -363,10 +363,17 @@ def test_conv_error_behaviour():
   kw = dict(ansatz='conv_2d', kernel_size=3, size_x=4, size_y=4)
   with pytest.raises(ValueError):
     VmcEngine(15, 8, 2, 8, **kw)                          # size_x * size_y != num_sites
+  eng = VmcEngine(16, 8, 2, 65, **kw)                     # more than 64 filters: the general path (conv_general.hip)
+  assert eng.kernel_path() == 6
   with pytest.raises(NotImplementedError):
-    VmcEngine(16, 8, 2, 65, **kw)                         # more than 64 filters
+    eng.sr_reserve(2)                                     # ... which has no stochastic reconfiguration
+  eng.close()
   with pytest.raises(NotImplementedError):
-    VmcEngine(16, 8, 2, 8, ansatz='conv_2d', kernel_size=10, size_x=4, size_y=4)
+    VmcEngine(16, 8, 2, 1025, **kw)
+  with pytest.raises(NotImplementedError):
+    VmcEngine(16, 8, 2, 8, ansatz='conv_2d', kernel_size=10, size_x=4, size_y=4)    # lattice side < kernel_size / 2
+  with pytest.raises(NotImplementedError):
+    VmcEngine(16 * 16, 8, 2, 8, ansatz='conv_2d', kernel_size=32, size_x=16, size_y=16)
   eng = VmcEngine(16, 8, 2, 8, output_activation='tanh', **kw)
   with pytest.raises(NotImplementedError):
     eng.sr_reserve(2)                                     # SR (an extension) needs the exp output

@@ -3,7 +3,8 @@ through the C ABI: Conv2DNetwork / ResNet2D / Conv1DNetwork / ResNet1D (wavefunc
 layers.Conv*Periodic / ResBlock*, layers.py:24-293) at shapes the fused kernels refuse -- num_conv_filters > 64,
 kernel_size > 9, feature maps beyond 160 KiB of LDS; the reference takes any value (utils.py:107-111) -- and, forced
 with CGS_VMC_CONV_GENERAL=1, at shapes both paths take, where the two must agree.  Amplitudes, local energies,
-proposals, injected steps and trajectories; the gradient accumulators of this path are not built and must refuse.
+proposals, injected steps, trajectories and the gradient accumulators; stochastic reconfiguration (an extension)
+is not built on this path and must refuse.
 Tolerances as tests/test_gpu_conv.py."""
 import numpy as np
 import pytest
@@ -123,11 +124,62 @@ def test_general_and_fused_convolution_paths_agree(monkeypatch, ansatz, sx, sy, 
   eng.close()
 
 
-def test_general_convolution_path_refuses_the_gradient_entries():
+def _check_gradients(eng, theta, cfg, bonds, geom, ansatz, L, nonlin, b):
+  """Two accumulate calls (the second on moved chains) against the oracle's manual back-propagation, the gradient
+  formula, one Adam step: tests/test_gpu_conv.py::test_conv_energy_gradient_accumulators on this path."""
   from cgs_vmc_amd import _hip
-  eng, theta, cfg, bonds, geom = _make('conv_2d', 4, 4, 2, 80, 3, 12, 'relu')
+  acc = vo.Accumulators(theta.size, np.float64)
+  eng.set_bonds(bonds, -1.0, 1.0)
   eng.reset_accumulators()
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, geom, L, np.float64,
+                                ansatz=ansatz, nonlinearity=nonlin)
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  eng.mc_steps(3)
+  cur = eng.get_configs()
+  vo.energy_gradient_accumulate(acc, theta, cur, bonds, -1.0, 1.0, -10.0, geom, L, np.float64,
+                                ansatz=ansatz, nonlinearity=nonlin)
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  got = eng.get_accumulators()
+  p = theta.size
+  for name, g, r in (('g1', got[:p], acc.g1_total), ('g2', got[p:2 * p], acc.g2_total)):
+    tol = 2e-3 * np.abs(r).max() + 1e-4
+    assert np.abs(g - r).max() < tol, (name, np.abs(g - r).max(), tol, int(np.argmax(np.abs(g - r))))
+  sc = got[2 * p:]
+  assert abs(sc[0] - acc.e_total) < 2e-4 * max(1, abs(acc.e_total)) and sc[1] == 2 * b and sc[4] == 2
+  grad_ref = vo.energy_gradient(acc)
+  grad = eng.get_gradient(_hip.VMC_MODE_ENERGY_GRADIENT)
+  cancel = 4e-6 * max(np.abs(acc.g2_total).max(), abs(acc.mean_energy()) * np.abs(acc.g1_total).max()) / 2
+  assert np.abs(grad - grad_ref).max() < 2e-3 * np.abs(grad_ref).max() + 2e-4 + cancel
+  st = vo.AdamState(p)
+  th_ref = vo.adam_apply(st, theta, grad, 1e-3, 0.9, 0.99, 1e-8)
+  eng.apply_adam(_hip.VMC_MODE_ENERGY_GRADIENT, 1e-3, 0.9, 0.99, 1e-8)
+  np.testing.assert_allclose(eng.get_params(), th_ref, rtol=0, atol=2e-6)
+  _logits_close(eng.amplitude()[0], eng.get_params(), cur, ansatz, geom, L, nonlin)
+
+
+GRAD_SHAPES = [s_ for s_ in GENERAL_SHAPES if s_[6] <= 100]      # (the 600-chain case: forward only; its oracle gradient is slow)
+
+
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', GRAD_SHAPES, ids=['{}-{}x{}-L{}-F{}-K{}-B{}-{}'.format(*s_) for s_ in GRAD_SHAPES])
+def test_general_convolution_gradient_accumulators(ansatz, sx, sy, L, f, k, b, nonlin):
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6
+  _check_gradients(eng, theta, cfg, bonds, geom, ansatz, L, nonlin, b)
+  eng.close()
+
+
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', BOTH)
+def test_general_convolution_gradient_accumulators_at_fused_shapes(monkeypatch, ansatz, sx, sy, L, f, k, b, nonlin):
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6
+  _check_gradients(eng, theta, cfg, bonds, geom, ansatz, L, nonlin, b)
+  eng.close()
+
+
+def test_general_convolution_path_refuses_stochastic_reconfiguration():
+  eng, theta, cfg, bonds, geom = _make('conv_2d', 4, 4, 2, 80, 3, 12, 'relu')
   with pytest.raises(Exception) as e:
-    eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+    eng.sr_reserve(2)
   assert 'general convolution path' in str(e.value)
   eng.close()
