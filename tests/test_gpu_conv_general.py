@@ -183,3 +183,30 @@ def test_general_convolution_path_refuses_stochastic_reconfiguration():
     eng.sr_reserve(2)
   assert 'general convolution path' in str(e.value)
   eng.close()
+
+
+def test_general_convolution_through_run_training_and_evaluation(tmp_path):
+  """--wavefunction_type=conv_1d with kernel_size=11 (beyond the fused kernels: the general path) through the
+  run_training / run_energy_evaluation counterparts on the reference's default lattice, the periodic chain
+  (run_training.py:103-109), 16 sites: the variational energy approaches E0 = -7.1423 (exact diagonalisation) from
+  above.  (A test of this kind with MORE THAN 64 FILTERS does not exist for a reason that is the ansatz's, not the
+  path's: the logit is the plain sum of N x filters outputs -- wavefunctions.py:569 -- whose spread at the Sonnet
+  initialisation grows with the filter count, ~ +-25 at 72 filters on 16 sites, so psi'/psi = exp(+-25) and the first
+  Adam steps diverge at any learning rate the reference's schedule offers.)"""
+  import os
+  from cgs_vmc_amd import run_energy_evaluation, run_training, session as session_lib, wavefunctions
+  session_lib.reset_default_graph()
+  wavefunctions.reset_name_scope()
+  os.environ.update(CGS_VMC_SEED='77', CGS_VMC_CONFIG_SEED='5', CGS_VMC_INIT_SEED='31')
+  d = str(tmp_path)
+  hp = ('batch_size=256,num_conv_layers=2,num_conv_filters=8,kernel_size=11,num_equilibration_sweeps=10,'
+        'num_batches_per_epoch=8,learning_rates=[0.003,0.001],learning_rate_stops=[200]')
+  run_training.main(['--checkpoint_dir', d, '--num_sites', '16', '--heisenberg_jx', '-1.0',
+                     '--wavefunction_type', 'conv_1d', '--optimizer', 'EnergyGradient',
+                     '--num_epochs', '250', '--hparams', hp])
+  energies = [float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()]
+  tail = np.mean(energies[-10:])
+  assert -7.1423 - 0.05 < tail < -6.0, (tail, energies[::25])
+  session_lib.reset_default_graph()
+  wavefunctions.reset_name_scope()
+  run_energy_evaluation.main(['--checkpoint_dir', d, '--heisenberg_jx', '-1.0', '--hparams', 'num_evaluation_samples=5'])
