@@ -210,3 +210,81 @@ def test_general_convolution_through_run_training_and_evaluation(tmp_path):
   session_lib.reset_default_graph()
   wavefunctions.reset_name_scope()
   run_energy_evaluation.main(['--checkpoint_dir', d, '--heisenberg_jx', '-1.0', '--hparams', 'num_evaluation_samples=5'])
+
+
+@pytest.mark.parametrize('ansatz,f,k', [('conv_2d', 8, 3), ('res_net_2d', 8, 3), ('conv_2d', 80, 3), ('conv_1d', 6, 11)])
+def test_general_convolution_log_overlap_itswo_accumulators(monkeypatch, ansatz, f, k):
+  """training.py:655-705 on the general path (forced where the fused kernels would take the shape): the supervisor's
+  amplitudes (parameter set 1), the overlap ratio and the weighted gradient sums against the oracle."""
+  from cgs_vmc_amd import _hip
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')
+  sx, sy, L, b = (16, 1, 2, 48) if ansatz == 'conv_1d' else (4, 4, 2, 48)
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, 'relu')
+  assert eng.kernel_path() == 6
+  eng.transfer_params()
+  rng = np.random.default_rng(8)
+  theta2 = theta + (0.02 / np.sqrt(max(1.0, f / 8.0)) * rng.standard_normal(theta.size)).astype(np.float32)
+  eng.set_params(theta2)
+  eng.set_shift(-9.0)
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.log_overlap_accumulate(acc, theta2, theta, cfg, bonds, -1.0, 1.0, -9.0, -10.0, 0.12, geom, L,
+                            np.float64, ansatz=ansatz)
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_LOG_OVERLAP_ITSWO, 0.12)
+  grad_ref = vo.log_overlap_gradient(acc)
+  grad = eng.get_gradient(_hip.VMC_MODE_LOG_OVERLAP_ITSWO)
+  assert np.abs(grad - grad_ref).max() < 2e-3 * np.abs(grad_ref).max() + 2e-4
+  eng.close()
+
+
+@pytest.mark.parametrize('oact', ['tanh', 'identity', 'sigmoid'])
+def test_general_convolution_non_exp_output_activation(monkeypatch, oact):
+  """wavefunctions.py:576-579 on the general path: psi = g(sum), linear-domain ratios, O_k with g'(x) / g(x)."""
+  from cgs_vmc_amd import _hip
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')
+  ansatz, sx, sy, L, f, k, b = 'conv_2d', 4, 4, 2, 8, 3, 32
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, 'tanh', output_activation=oact, noise=0.01)
+  assert eng.kernel_path() == 6
+  amp = lambda c: vo.ANSATZ[ansatz][0](theta, c, geom, L, nonlinearity='tanh', output_activation=oact, dtype=np.float64)
+  logit, psi = eng.amplitude(cfg)
+  _logits_close(logit, theta, cfg, ansatz, geom, L, 'tanh')
+  np.testing.assert_allclose(psi, vo.NONLINEARITIES[oact](logit.astype(np.float64)), rtol=1e-5, atol=1e-6)
+  _close(eng.local_energy()[0], vo.local_value(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64), 5e-4)
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, geom, L, np.float64,
+                                ansatz=ansatz, nonlinearity='tanh', output_activation=oact)
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  grad_ref = vo.energy_gradient(acc)
+  grad = eng.get_gradient(_hip.VMC_MODE_ENERGY_GRADIENT)
+  assert np.abs(grad - grad_ref).max() < 3e-3 * np.abs(grad_ref).max() + 2e-4
+  eng.close()
+
+
+def test_general_convolution_shard_invariance_and_reproducibility():
+  """Chains [16, 48) of a 64-chain run walk the same trajectory as a 32-chain shard with chain_offset 16 (Philox keyed
+  by the global chain id; no float atomics, a fixed order of additions: the energies are the same bits too), two
+  identical runs agree bit for bit -- and so do the gradient sums of two identical accumulate calls (split-K partials
+  folded in slice order)."""
+  from cgs_vmc_amd import _hip
+  from cgs_vmc_amd.engine import VmcEngine
+  ansatz, sx, sy, L, f, k = 'conv_2d', 6, 6, 2, 72, 3
+  n, geom = sx * sy, (f, k, sx, sy)
+  rng = np.random.default_rng(3)
+  theta = (0.5 * vo.conv_init_params(ansatz, geom, L, rng)).astype(np.float32)
+  cfg = vo.random_configurations(n, 64, np.random.RandomState(4))
+  outs = []
+  for (b, off, rows) in ((64, 0, slice(0, 64)), (64, 0, slice(0, 64)), (32, 16, slice(16, 48))):
+    eng = VmcEngine(n, b, L, f, seed=11, ansatz=ansatz, kernel_size=k, size_x=sx, size_y=sy, chain_offset=off)
+    assert eng.kernel_path() == 6
+    eng.set_params(theta); eng.set_configs(cfg[rows]); eng.set_bonds(vo.torus_bonds(6, 6), -1.0, 1.0)
+    eng.mc_steps(n)
+    eng.reset_accumulators()
+    eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+    outs.append((eng.get_configs(), eng.local_energy()[0], eng.get_accumulators()))
+    eng.close()
+  np.testing.assert_array_equal(outs[0][0], outs[1][0])
+  np.testing.assert_array_equal(outs[0][1], outs[1][1])
+  np.testing.assert_array_equal(outs[0][2], outs[1][2])
+  np.testing.assert_array_equal(outs[0][0][16:48], outs[2][0])
+  np.testing.assert_array_equal(outs[0][1][16:48], outs[2][1])
