@@ -35,27 +35,31 @@ __device__ __forceinline__ int cg_site(const ConvGeom& g, int n, int t, bool inv
   return s1 * g.D2 + s2;
 }
 
-// convolutions 1 ..: A[m][t F + c] = f(in[row][site(n, t)][c]); VEC = 4: F % 4 == 0 (16-byte pieces), else scalar
+// convolutions 1 ..: A[m][t F + c] = f(in[row][site(n, t)][c]); VEC = 4: F % 4 == 0 (16-byte pieces), else scalar.
+// A workgroup takes `ppb` consecutive positions (>= 512 items of VEC floats); every index is 32-bit arithmetic (a
+// 64-bit division per item made the first form of this kernel VALU-bound: 3.2 TB/s of 165 us per layer).
 template <int VEC>
-__global__ __launch_bounds__(256) void k_cgen_im2col(CgenIm2colArgs a) {
+__global__ __launch_bounds__(256) void k_cgen_im2col(CgenIm2colArgs a, int ppb) {
   const ConvGeom g = a.g;
-  const int T = g.K * g.KW, C = g.F / VEC;
-  const long long total = (long long)a.rows * g.N * T * C;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int cq = (int)(idx % C);
-    const long long mt = idx / C;
-    const int t = (int)(mt % T);
-    const long long m = mt / T;
-    const int r = (int)(m / g.N), n = (int)(m - (long long)r * g.N);
-    const float* src = a.src + ((long long)r * g.N + cg_site(g, n, t, a.inverse != 0)) * a.Fp + VEC * cq;
-    float* dst = a.A + m * a.lda + (long long)t * g.F + VEC * cq;
-    if (VEC == 4) {
-      f32x4 v = *(const f32x4*)src;
+  const int T = g.K * g.KW, C = g.F / VEC, items = T * C;
+  const int M = a.rows * g.N;                                   // (rows * N < 2^31: the M of the GEMM that follows)
+  for (int m0 = blockIdx.x * ppb; m0 < M; m0 += gridDim.x * ppb) {
+    const int np = min(ppb, M - m0);
+    for (int w = threadIdx.x; w < np * items; w += 256) {
+      const int pl = w / items, it = w - pl * items;
+      const int t = it / C, cq = it - t * C;
+      const int m = m0 + pl;
+      const int r = m / g.N, n = m - r * g.N;
+      const float* src = a.src + ((long long)r * g.N + cg_site(g, n, t, a.inverse != 0)) * a.Fp + VEC * cq;
+      float* dst = a.A + (long long)m * a.lda + t * g.F + VEC * cq;
+      if (VEC == 4) {
+        f32x4 v = *(const f32x4*)src;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = cg_pre(a.pre_act, v[e]);
-      *(f32x4*)dst = v;
-    } else {
-      *dst = cg_pre(a.pre_act, *src);
+        for (int e = 0; e < 4; ++e) v[e] = cg_pre(a.pre_act, v[e]);
+        *(f32x4*)dst = v;
+      } else {
+        *dst = cg_pre(a.pre_act, *src);
+      }
     }
   }
 }
@@ -64,11 +68,13 @@ __global__ __launch_bounds__(256) void k_cgen_im2col(CgenIm2colArgs a) {
 __global__ __launch_bounds__(256) void k_cgen_im2col0(CgenIm2colArgs a) {
   const ConvGeom g = a.g;
   const int T = g.K * g.KW;
-  const long long total = (long long)a.rows * g.N * T;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int t = (int)(idx % T);
-    const long long m = idx / T;
-    const int r = (int)(m / g.N), n = (int)(m - (long long)r * g.N);
+  const int M = a.rows * g.N;
+  const long long total = (long long)M * T;
+  for (long long base = (long long)blockIdx.x * 256; base < total; base += (long long)gridDim.x * 256) {
+    const long long idx = base + threadIdx.x;
+    if (idx >= total) break;
+    const int m = (int)(idx / T), t = (int)(idx - (long long)m * T);
+    const int r = m / g.N, n = m - r * g.N;
     int chain = (int)a.row0 + r, fa = -1, fb = -1;
     if (a.rowinfo) {
       const int2 ri = a.rowinfo[a.row0 + r];
@@ -78,22 +84,30 @@ __global__ __launch_bounds__(256) void k_cgen_im2col0(CgenIm2colArgs a) {
     if (a.iup) { fa = a.iup[a.row0 + r]; fb = a.idn[a.row0 + r]; }
     const int s = cg_site(g, n, t);
     const float x = a.src[(long long)chain * g.N + s];
-    a.A[m * a.lda + t] = (s == fa || s == fb) ? -x : x;
+    a.A[(long long)m * a.lda + t] = (s == fa || s == fb) ? -x : x;
   }
 }
 
-// sum of a row's last feature map over sites and channels (wavefunctions.py:569 reduce_sum), in double: one wave per row
+// sum of a row's last feature map over sites and channels (wavefunctions.py:569 reduce_sum), in double: one workgroup
+// per row, 16-byte loads, a fixed order (thread-strided partial sums, xor tree per wave, the four waves in order)
 __global__ __launch_bounds__(256) void k_cgen_rowsum(const float* __restrict__ fm, int rows, int N, int F, int Fp,
                                                      double* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
+  __shared__ double s_w[4];
+  const int r = blockIdx.x;
   const float* p = fm + (long long)r * N * Fp;
+  const int q = N * Fp / 4, fq = Fp / 4;
   double s = 0.0;
-  for (int i = lane; i < N * Fp; i += 64) s += (i % Fp) < F ? (double)p[i] : 0.0;
+  for (int i = threadIdx.x; i < q; i += 256) {
+    const f32x4 v = *(const f32x4*)(p + 4 * i);
+    const int c0 = 4 * (i % fq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += c0 + e < F ? (double)v[e] : 0.0;
+  }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-  if (lane == 0) out[r] = s;
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[r] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
 // Metropolis test and commit of one mc_step (graph_builders.py:75-88): one thread per chain, one atomic per workgroup
@@ -178,17 +192,21 @@ hipError_t launch_cgen_im2col(hipStream_t s, const CgenIm2colArgs& a) {
   const long long T = (long long)g.K * g.KW;
   if (a.layer == 0) {
     hipLaunchKernelGGL(k_cgen_im2col0, dim3(cg_blocks((long long)a.rows * g.N * T)), dim3(256), 0, s, a);
-  } else if (g.F % 4 == 0) {
-    hipLaunchKernelGGL(k_cgen_im2col<4>, dim3(cg_blocks((long long)a.rows * g.N * T * (g.F / 4))), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL(k_cgen_im2col<1>, dim3(cg_blocks((long long)a.rows * g.N * T * g.F)), dim3(256), 0, s, a);
+    const int vec = g.F % 4 == 0 ? 4 : 1;
+    const long long items = T * (g.F / vec), M = (long long)a.rows * g.N;
+    const int ppb = (int)(items >= 512 ? 1 : (512 + items - 1) / items);
+    const long long blocks = (M + ppb - 1) / ppb;
+    const dim3 grid((unsigned)(blocks < 65536 ? blocks : 65536));
+    if (vec == 4) hipLaunchKernelGGL(k_cgen_im2col<4>, grid, dim3(256), 0, s, a, ppb);
+    else hipLaunchKernelGGL(k_cgen_im2col<1>, grid, dim3(256), 0, s, a, ppb);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_cgen_rowsum(hipStream_t s, const float* fm, int rows, int N, int F, int Fp, double* out) {
   if (rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_cgen_rowsum, dim3((rows + 3) / 4), dim3(256), 0, s, fm, rows, N, F, Fp, out);
+  hipLaunchKernelGGL(k_cgen_rowsum, dim3(rows), dim3(256), 0, s, fm, rows, N, F, Fp, out);
   return hipGetLastError();
 }
 

@@ -1040,7 +1040,9 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   if (conv && c->conv_general) {
     // blocks of at most ~768 MB of im2col rows (one row configuration at least), at least B rows when that fits
     const long long per_row = (long long)cg.N * plan_cgen_lda(cg) * (long long)sizeof(float);
-    long long rows = (768LL << 20) / per_row;
+    long long block_mb = 768;
+    if (const char* e = getenv("CGS_VMC_CONV_GENERAL_BLOCK_MB")) { block_mb = atoll(e); if (block_mb < 1) block_mb = 1; if (block_mb > 16384) block_mb = 16384; }
+    long long rows = (block_mb << 20) / per_row;
     if (rows < 1) rows = 1;
     if (rows > (1LL << 30) / cg.N) rows = (1LL << 30) / cg.N;          // rows * N: the M of a GEMM (int)
     c->cg_rows = rows;
