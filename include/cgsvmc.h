@@ -75,7 +75,8 @@ typedef struct {
                                 beyond that the general multi-launch path
                                 (materialised rows + GEMMs; two [131072][units] float
                                 buffers per ctx: 4 GiB at 4096 units).  Convolutional ansatz types:
-                                num_conv_filters (111), at most 64 (four 16-channel MFMA blocks) */
+                                num_conv_filters (111): the fused kernels up to 64 (four 16-channel MFMA
+                                blocks), the general path (feature maps in HBM, im2col + GEMM; no SR) to 1024 */
   int32_t nonlinearity;      /* VMC_ACT_*: hparams.nonlinearity  (utils.py:128)      */
   int32_t output_activation; /* VMC_ACT_*: hparams.output_activation (utils.py:129)  */
   int32_t device;            /* HIP device ordinal                                   */
@@ -85,7 +86,7 @@ typedef struct {
   uint64_t seed;             /* Philox key                                           */
   void* stream;              /* hipStream_t to launch on, or NULL for the null stream*/
   /* convolutional ansatz types only (ignored otherwise) */
-  int32_t kernel_size;       /* hparams.kernel_size (utils.py:110), 1..9             */
+  int32_t kernel_size;       /* hparams.kernel_size (utils.py:110): fused kernels 1..9, general path to 31 */
   int32_t size_x, size_y;    /* hparams.size_x, size_y (utils.py:99-100); n_sites = size_x*size_y
                                 (ignored by the 1-D types: the chain has n_sites sites)          */
   int32_t reserved2;         /* 0                                                    */
