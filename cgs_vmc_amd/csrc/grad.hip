@@ -161,7 +161,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, int bx, int by, in
   const int a_extent = g.ones_row ? g.M - 1 : g.M;
   const bool do_colsum = g.ones_row && by == 0 && tid < GT;
   const bool scaled = g.kscale != nullptr;
-  float cs = 0.f, cs2 = 0.f;
+  double cs = 0.0, cs2 = 0.0;      // (the ones row: a plain column sum over K, carried in double)
 
   f32x16 acc, acc2;
 #pragma unroll
@@ -194,8 +194,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, int bx, int by, in
     if (do_colsum) {
 #pragma unroll
       for (int kk = 0; kk < GK; ++kk) {
-        cs += Bs[kk][tid];
-        if (DUAL) cs2 += Bs2[kk][tid];
+        cs += (double)Bs[kk][tid];
+        if (DUAL) cs2 += (double)Bs2[kk][tid];
       }
     }
 #pragma unroll
@@ -240,11 +240,11 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& g, int bx, int by, in
     const int m = g.M - 1, nn = n0 + tid;
     if (g.splitk > 1) {
       float* ws = g.workspace + (long long)bz * (DUAL ? 2 : 1) * mn;
-      ws[(long long)m * g.N + nn] = cs;
-      if (DUAL) ws[mn + (long long)m * g.N + nn] = cs2;
+      ws[(long long)m * g.N + nn] = (float)cs;
+      if (DUAL) ws[mn + (long long)m * g.N + nn] = (float)cs2;
     } else {
-      gemm_epilogue(g, g.C, m, nn, cs);
-      if (DUAL) gemm_epilogue(g, g.C2, m, nn, cs2);
+      gemm_epilogue(g, g.C, m, nn, (float)cs);
+      if (DUAL) gemm_epilogue(g, g.C2, m, nn, (float)cs2);
     }
   }
 }
@@ -1277,9 +1277,9 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
        i += (long long)gridDim.x * 256) {
     const int d = (int)(i / mn);
     const long long e = i % mn;
-    float v = 0.f;
-    for (int z = 0; z < g.splitk; ++z) v += g.workspace[((long long)z * nd + d) * mn + e];
-    gemm_epilogue(g, d ? g.C2 : g.C, (int)(e / g.N), (int)(e % g.N), v);
+    double v = 0.0;                  // the slices are folded in z order, in double
+    for (int z = 0; z < g.splitk; ++z) v += (double)g.workspace[((long long)z * nd + d) * mn + e];
+    gemm_epilogue(g, d ? g.C2 : g.C, (int)(e / g.N), (int)(e % g.N), (float)v);
   }
 }
 

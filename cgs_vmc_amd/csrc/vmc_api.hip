@@ -79,7 +79,7 @@ struct vmc_ctx {
   float* cg_lnew = nullptr;                // [B] candidate logits of the sampler
   // ... its gradient path (allocated by the first gradient call): the pre-activation of every convolution, two
   // d logit / d map buffers, per-position weights, the transposed weight images, the split-K workspace
-  float* cg_tape = nullptr; float* cg_g[2] = {nullptr, nullptr}; float* cg_wpos = nullptr; float* cg_wt = nullptr;
+  float* cg_tape = nullptr; float* cg_gl = nullptr; float* cg_g[2] = {nullptr, nullptr}; float* cg_wpos = nullptr; float* cg_wt = nullptr;
   float* cg_ws = nullptr; long long cg_ws_floats = 0;
   int *wide_iup = nullptr, *wide_idn = nullptr;
   int hact = VMC_ACT_RELU_;  // hidden activation (layers.NONLINEARITIES id)
@@ -382,6 +382,7 @@ ConvParams conv_params(const ParamSet& p) { return ConvParams{p.cw0, p.cwf, p.cw
 // GEMM against the parameter slice in theta; ResBlock2d's `v + h` (layers.py:227) is the accumulate epilogue.
 // iup / idn != nullptr: row r is chain r with that pair exchanged (the sampler's candidates).
 int ensure_cache(vmc_ctx* c, int which);
+#define CGEN_SPLITK 32     // K slices of the weight-gradient products of the general convolution path
 
 // One convolution of the general path over `rows` row configurations: im2col gather of its input into cg_A, then the
 // product with the parameter slice; residual: dst += (ResBlock2d's `v + h`).
@@ -451,105 +452,123 @@ static int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2*
   return VMC_OK;
 }
 
+// ---- gradient machinery of the general path, one block of `rows` chains (first chain `row0` of `configs`) at a time
+// buffers of the first gradient call
+static int cgen_grad_buffers(vmc_ctx* c) {
+  const ConvGeom& g = c->cg;
+  if (c->cg_tape) return VMC_OK;
+  const int T = g.K * g.KW, n_conv = g.n_conv;
+  const long long map_floats = c->cg_rows * g.N * cgen_fp(g);
+  const int kmax = T * (n_conv > 1 ? g.F : 1) + 1;                      // rows of the largest weight-gradient product
+  HIPCHK(c, dalloc(&c->cg_tape, (long long)n_conv * map_floats));
+  HIPCHK(c, dalloc(&c->cg_gl, (long long)n_conv * map_floats));
+  HIPCHK(c, dalloc(&c->cg_g[0], map_floats));
+  HIPCHK(c, dalloc(&c->cg_wpos, c->cg_rows * g.N));
+  if (n_conv > 1) HIPCHK(c, dalloc(&c->cg_wt, cgen_off_wt(g, n_conv)));
+  c->cg_ws_floats = (long long)CGEN_SPLITK * 2 * kmax * g.F;
+  HIPCHK(c, dalloc(&c->cg_ws, c->cg_ws_floats));
+  return VMC_OK;
+}
+static float* cgen_tape(vmc_ctx* c, int l) { return c->cg_tape + (long long)l * c->cg_rows * c->cg.N * cgen_fp(c->cg); }
+static float* cgen_gl(vmc_ctx* c, int l) { return c->cg_gl + (long long)l * c->cg_rows * c->cg.N * cgen_fp(c->cg); }
+
+// the input of convolution l gathered into cg_A, as its forward did (from the tape of this block)
+static int cgen_gather_input(vmc_ctx* c, int l, int rows, long long row0, const float* configs) {
+  const ConvGeom& g = c->cg;
+  CgenIm2colArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.layer = l; a.Fp = cgen_fp(g); a.rows = rows; a.lda = plan_cgen_lda(g); a.A = c->cg_A; a.pre_act = -1;
+  if (l == 0) { a.src = configs; a.row0 = row0; a.bonds = c->bonds ? c->bonds : c->bond_dummy; }
+  else if (!g.resnet) { a.src = cgen_tape(c, l - 1); a.pre_act = g.hact; }
+  else if (l & 1) { a.src = cgen_tape(c, l - 1); }                              // first convolution of a block: h
+  else { a.src = cgen_tape(c, l - 1); a.pre_act = CGEN_PRE_SELU; }              // second: selu(u)
+  HIPCHK(c, launch_cgen_im2col(c->stream, a));
+  return VMC_OK;
+}
+
+// dst (+)= the transposed convolution l (>= 1) of G: the inverse gather against the transposed weight image
+static int cgen_input_grad(vmc_ctx* c, int l, int rows, const float* G, float* dst, bool accumulate) {
+  const ConvGeom& g = c->cg;
+  CgenIm2colArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.layer = l; a.Fp = cgen_fp(g); a.rows = rows; a.lda = plan_cgen_lda(g); a.A = c->cg_A; a.pre_act = -1;
+  a.inverse = 1; a.src = G;
+  HIPCHK(c, launch_cgen_im2col(c->stream, a));
+  GemmArgs m; memset(&m, 0, sizeof(m));
+  m.A = c->cg_A; m.sam = a.lda; m.sak = 1;
+  m.B = c->cg_wt + cgen_off_wt(g, l); m.sbk = g.F; m.sbn = 1;
+  m.M = rows * g.N; m.N = g.F; m.K = g.K * g.KW * g.F; m.C = dst; m.ldc = a.Fp;
+  m.epilogue = accumulate ? 3 : 0; m.splitk = 1;
+  HIPCHK(c, launch_gemm(c->stream, m));
+  return VMC_OK;
+}
+
+// cg_gl[l] = d logit / d z_l for every convolution of the block (the tape of the block in cg_tape):
+//   G_{l-1} = (transposed convolution l of G_l) (.) f'(z_{l-1}); residual blocks accumulate both branches into d / d h
+static int cgen_backward(vmc_ctx* c, int rows, long long row0, const float* oscale) {
+  const ConvGeom& g = c->cg;
+  const int Fp = cgen_fp(g), n_conv = g.n_conv;
+  const long long M = (long long)rows * g.N;
+  float* D = c->cg_g[0];
+  HIPCHK(c, launch_cgen_fill(c->stream, cgen_gl(c, n_conv - 1), oscale, row0, rows, g.N, g.F, Fp));
+  if (!g.resnet) {
+    for (int l = n_conv - 1; l >= 1; --l) {
+      PROPAGATE(cgen_input_grad(c, l, rows, cgen_gl(c, l), D, false));
+      HIPCHK(c, launch_cgen_dact(c->stream, D, cgen_tape(c, l - 1), g.hact, M * Fp, g.F, Fp, cgen_gl(c, l - 1)));
+    }
+  } else {                     // gl[even l] = d / d h behind block (l / 2): the gradient of the block's second convolution
+    for (int l2 = n_conv - 1; l2 >= 2; l2 -= 2) {
+      const int l1 = l2 - 1;
+      PROPAGATE(cgen_input_grad(c, l2, rows, cgen_gl(c, l2), D, false));                                   // d / d selu(u)
+      HIPCHK(c, launch_cgen_dact(c->stream, D, cgen_tape(c, l1), CGEN_PRE_SELU, M * Fp, g.F, Fp, cgen_gl(c, l1)));   // d / d u
+      HIPCHK(c, hipMemcpyAsync(cgen_gl(c, l2 - 2), cgen_gl(c, l2), (size_t)M * Fp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+      PROPAGATE(cgen_input_grad(c, l1, rows, cgen_gl(c, l1), cgen_gl(c, l2 - 2), true));                   // d / d h += through the block
+    }
+  }
+  return VMC_OK;
+}
+
+// [w_l ; b_l] sums of convolution l: C1 += [im2col(x_l) | 1]^T G (C1 != nullptr), C2 += [im2col(x_l) | 1]^T (kscale (.) G);
+// kscale = per-position weights (cg_wpos).  ONE product (k_gemm: dual, implicit ones row, split-K over the positions)
+static int cgen_weight_sums(vmc_ctx* c, int l, int rows, long long row0, const float* configs, const float* G,
+                            float* C1, float* C2) {
+  const ConvGeom& g = c->cg;
+  PROPAGATE(cgen_gather_input(c, l, rows, row0, configs));
+  const long long M = (long long)rows * g.N;
+  GemmArgs m; memset(&m, 0, sizeof(m));
+  m.A = c->cg_A; m.sam = 1; m.sak = plan_cgen_lda(g);                       // A(i, k = position) = im2col[k][i]
+  m.B = G; m.sbk = cgen_fp(g); m.sbn = 1;
+  m.kscale = c->cg_wpos; m.ones_row = 1;
+  m.M = cgen_kdim(g, l) + 1; m.N = g.F; m.K = (int)M; m.ldc = g.F;
+  if (C1) { m.dual = 1; m.C = C1 + cgen_off_w(g, l); m.C2 = C2 + cgen_off_w(g, l); }
+  else { m.dual = 0; m.C = C2 + cgen_off_w(g, l); }                         // the scaled product alone
+  m.epilogue = 3; m.splitk = M >= 4096 ? CGEN_SPLITK : 1; m.workspace = c->cg_ws;
+  HIPCHK(c, launch_gemm(c->stream, m));
+  return VMC_OK;
+}
+
 // Gradient sums of the general path: g1 += sum_b O_b, g2 += sum_b w_b O_b (training.py:545-547), a block of chains at a
-// time.  Taped forward (the pre-activation of every convolution), then from the last convolution down:
-//   d / d W_l = im2col(x_l)^T G_l with the bias as an implicit row of ones -- ONE product per convolution for both sums
-//               (k_gemm: dual product with the per-position weights as the k-scale, split-K) -- G_l = d logit / d z_l;
-//   d / d x_l = the transposed convolution = im2col_inverse(G_l) against the transposed weight image;
-//   G_{l-1}   = d / d x_l (.) f'(z_{l-1}); residual blocks: d / d h accumulates both branches.
+// time: taped forward (the pre-activation of every convolution), d logit / d z_l of every convolution, then
+// d / d W_l = im2col(x_l)^T G_l with the bias as an implicit row of ones, one product per convolution for both sums.
 static int cgen_gradient_sums(vmc_ctx* c, const float* w) {
   const ConvGeom& g = c->cg;
   ParamSet& p = c->ps[0];
-  const int Fp = cgen_fp(g), lda = plan_cgen_lda(g), T = g.K * g.KW, n_conv = g.n_conv;
-  const long long rows_max = c->cg_rows < c->B ? c->cg_rows : c->B;
-  const long long map_floats = rows_max * g.N * Fp;
-  float* g1 = c->acc;
-  float* g2 = c->acc + c->P;
-  const int kmax = T * (n_conv > 1 ? g.F : 1) + 1;                      // rows of the largest weight-gradient product
-  const int splitk = 32;
-  if (!c->cg_tape) {
-    HIPCHK(c, dalloc(&c->cg_tape, (long long)n_conv * map_floats));
-    for (int i = 0; i < 2; ++i) HIPCHK(c, dalloc(&c->cg_g[i], map_floats));
-    HIPCHK(c, dalloc(&c->cg_wpos, rows_max * g.N));
-    if (n_conv > 1) HIPCHK(c, dalloc(&c->cg_wt, cgen_off_wt(g, n_conv)));
-    c->cg_ws_floats = (long long)splitk * 2 * kmax * g.F;
-    HIPCHK(c, dalloc(&c->cg_ws, c->cg_ws_floats));
-  }
-  for (int l = 1; l < n_conv; ++l)
-    HIPCHK(c, launch_cgen_pack_t(c->stream, p.theta + cgen_off_w(g, l), T, g.F, c->cg_wt + cgen_off_wt(g, l)));
+  PROPAGATE(cgen_grad_buffers(c));
+  const long long map_floats = c->cg_rows * g.N * cgen_fp(g);
+  for (int l = 1; l < g.n_conv; ++l)
+    HIPCHK(c, launch_cgen_pack_t(c->stream, p.theta + cgen_off_w(g, l), g.K * g.KW, g.F, c->cg_wt + cgen_off_wt(g, l)));
   if (c->oact != VMC_ACT_EXP_) {
     PROPAGATE(ensure_cache(c, VMC_PSI));
     HIPCHK(c, launch_out_scale(c->stream, p.logit, c->oscale, c->B, c->oact));
   }
-  auto tape = [&](int l) { return c->cg_tape + (long long)l * map_floats; };
-  for (long long row0 = 0; row0 < c->B; row0 += rows_max) {
-    const int rows = (int)(c->B - row0 < rows_max ? c->B - row0 : rows_max);
-    const long long M = (long long)rows * g.N;
+  for (long long row0 = 0; row0 < c->B; row0 += c->cg_rows) {
+    const int rows = (int)(c->B - row0 < c->cg_rows ? c->B - row0 : c->cg_rows);
     PROPAGATE(cgen_forward(c, VMC_PSI, c->configs, nullptr, rows, nullptr, nullptr, false, c->cg_lnew, c->cg_tape,
                            map_floats, row0));     // (its logits land in cg_lnew[row0 ..]: unused)
     HIPCHK(c, launch_cgen_wpos(c->stream, w, row0, rows, g.N, c->cg_wpos));
-    // gather the input of convolution l into cg_A (as its forward did)
-    auto gather_input = [&](int l) -> int {
-      CgenIm2colArgs a;
-      memset(&a, 0, sizeof(a));
-      a.g = g; a.layer = l; a.Fp = Fp; a.rows = rows; a.lda = lda; a.A = c->cg_A; a.pre_act = -1;
-      if (l == 0) { a.src = c->configs; a.row0 = row0; a.bonds = c->bonds ? c->bonds : c->bond_dummy; }
-      else if (!g.resnet) { a.src = tape(l - 1); a.pre_act = g.hact; }
-      else if (l & 1) { a.src = tape(l - 1); }                              // first convolution of a block: h
-      else { a.src = tape(l - 1); a.pre_act = CGEN_PRE_SELU; }              // second: selu(u)
-      HIPCHK(c, launch_cgen_im2col(c->stream, a));
-      return VMC_OK;
-    };
-    // [w_l ; b_l] += [im2col(x_l) | 1]^T [G | w (.) G]
-    auto weight_sums = [&](int l, const float* G) -> int {
-      PROPAGATE(gather_input(l));
-      const int kd = cgen_kdim(g, l);
-      GemmArgs m; memset(&m, 0, sizeof(m));
-      m.A = c->cg_A; m.sam = 1; m.sak = lda;                                // A(i, k = position) = im2col[k][i]
-      m.B = G; m.sbk = Fp; m.sbn = 1;
-      m.kscale = c->cg_wpos; m.dual = 1; m.ones_row = 1;
-      m.M = kd + 1; m.N = g.F; m.K = (int)M;
-      m.C = g1 + cgen_off_w(g, l); m.C2 = g2 + cgen_off_w(g, l); m.ldc = g.F;
-      m.epilogue = 3; m.splitk = M >= 4096 ? splitk : 1; m.workspace = c->cg_ws;
-      HIPCHK(c, launch_gemm(c->stream, m));
-      return VMC_OK;
-    };
-    // dst (+)= the transposed convolution l of G
-    auto input_grad = [&](int l, const float* G, float* dst, bool accumulate) -> int {
-      CgenIm2colArgs a;
-      memset(&a, 0, sizeof(a));
-      a.g = g; a.layer = l; a.Fp = Fp; a.rows = rows; a.lda = lda; a.A = c->cg_A; a.pre_act = -1; a.inverse = 1;
-      a.src = G;
-      HIPCHK(c, launch_cgen_im2col(c->stream, a));
-      GemmArgs m; memset(&m, 0, sizeof(m));
-      m.A = c->cg_A; m.sam = lda; m.sak = 1;
-      m.B = c->cg_wt + cgen_off_wt(g, l); m.sbk = g.F; m.sbn = 1;
-      m.M = (int)M; m.N = g.F; m.K = T * g.F; m.C = dst; m.ldc = Fp;
-      m.epilogue = accumulate ? 3 : 0; m.splitk = 1;
-      HIPCHK(c, launch_gemm(c->stream, m));
-      return VMC_OK;
-    };
-    float* G = c->cg_g[0];
-    float* D = c->cg_g[1];
-    HIPCHK(c, launch_cgen_fill(c->stream, G, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr, row0, rows, g.N, g.F, Fp));
-    if (!g.resnet) {
-      for (int l = n_conv - 1; l >= 0; --l) {
-        PROPAGATE(weight_sums(l, G));
-        if (l == 0) break;
-        PROPAGATE(input_grad(l, G, D, false));
-        HIPCHK(c, launch_cgen_dact(c->stream, D, tape(l - 1), g.hact, M * Fp, g.F, Fp, G));
-      }
-    } else {                   // G = d / d h
-      for (int l2 = n_conv - 1; l2 >= 2; l2 -= 2) {
-        const int l1 = l2 - 1;
-        PROPAGATE(weight_sums(l2, G));
-        PROPAGATE(input_grad(l2, G, D, false));                                          // d / d selu(u)
-        HIPCHK(c, launch_cgen_dact(c->stream, D, tape(l1), CGEN_PRE_SELU, M * Fp, g.F, Fp, D));   // d / d u
-        PROPAGATE(weight_sums(l1, D));
-        PROPAGATE(input_grad(l1, D, G, true));                                           // d / d h += through the block
-      }
-      PROPAGATE(weight_sums(0, G));
-    }
+    PROPAGATE(cgen_backward(c, rows, row0, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr));
+    for (int l = g.n_conv - 1; l >= 0; --l)
+      PROPAGATE(cgen_weight_sums(c, l, rows, row0, c->configs, cgen_gl(c, l), c->acc, c->acc + c->P));
   }
   return VMC_OK;
 }
@@ -1045,6 +1064,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     long long rows = (block_mb << 20) / per_row;
     if (rows < 1) rows = 1;
     if (rows > (1LL << 30) / cg.N) rows = (1LL << 30) / cg.N;          // rows * N: the M of a GEMM (int)
+    if (rows > (B > 65536 ? B : 65536)) rows = B > 65536 ? B : 65536;  // (small shapes: no point in hundreds of MB of maps)
     c->cg_rows = rows;
     CA(dalloc(&c->cg_A, rows * cg.N * plan_cgen_lda(cg)));
     for (int i = 0; i < 2; ++i) CA(dalloc(&c->cg_fm[i], rows * cg.N * cgen_fp(cg)));
@@ -1100,7 +1120,7 @@ void vmc_destroy(vmc_ctx* c) {
                    c->wide_u, c->wide_zero}) if (q) hipFree(q);
   for (int* q : {c->wide_iup, c->wide_idn}) if (q) hipFree(q);
   if (c->wide_dot) hipFree(c->wide_dot);
-  for (float* q : {c->cg_A, c->cg_fm[0], c->cg_fm[1], c->cg_zero, c->cg_lnew, c->cg_tape, c->cg_g[0], c->cg_g[1], c->cg_wpos,
+  for (float* q : {c->cg_A, c->cg_fm[0], c->cg_fm[1], c->cg_zero, c->cg_lnew, c->cg_tape, c->cg_gl, c->cg_g[0], c->cg_g[1], c->cg_wpos,
                    c->cg_wt, c->cg_ws}) if (q) hipFree(q);
   if (c->cg_sum) hipFree(c->cg_sum);
   void* ptrs[] = {c->configs, c->configs_alt, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
@@ -1765,10 +1785,6 @@ static int sr_record(vmc_ctx* c) {
   return VMC_OK;
 }
 
-// (stochastic reconfiguration -- an extension -- of a convolutional ctx beyond the fused kernels' limits: not built)
-#define CGEN_NO_SR(c) \
-  do { if ((c)->conv_general) return fail(c, VMC_ERR_UNSUPPORTED, "the general convolution path (kernel_size > 9, num_conv_filters > 64 or feature maps beyond 160 KiB of LDS) has amplitudes, local energies, Monte-Carlo steps and the gradient accumulators; stochastic reconfiguration is not available on it"); } while (0)
-
 int vmc_accumulate(vmc_ctx* c, int mode, float beta) {
   ENTER(c);
   if (mode != VMC_MODE_ENERGY_GRADIENT && mode != VMC_MODE_LOG_OVERLAP_ITSWO)
@@ -2172,7 +2188,6 @@ int vmc_evaluate(vmc_ctx* c, void* nccl_comm, int32_t world_size, int64_t n_eq_s
 int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   ENTER(c);
   if (n_batches < 0) return fail(c, VMC_ERR_INVALID, "n_batches < 0");
-  if (n_batches > 0) CGEN_NO_SR(c);
   if (n_batches > 0 && c->oact != VMC_ACT_EXP_)
     return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration (an extension) covers the exp output activation (every hidden activation)");
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2183,6 +2198,11 @@ int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   c->sr_cap = 0; c->sr_n = 0; c->sr_begun = false;
   if (n_batches == 0) return VMC_OK;
   const long long B = c->B, N = c->N, Hp = c->Hp, L = c->A, P = c->P, R = (long long)n_batches * B;
+  if (c->conv_general)
+    // (built and measured in round 5 -- only the chains stored, every CG iteration re-running the taped forward and the
+    // backward -- and withdrawn: its matvec met the 5e-4 bound of tests/test_gpu_sr.py but the solutions missed the 1 %
+    // bound on O_c x in the ill-conditioned cases; S v = <O (O.v)> - <O><O.v> wants sums that cancel as the fused kernels' do)
+    return fail(c, VMC_ERR_UNSUPPORTED, "the general convolution path (kernel_size > 9, num_conv_filters > 64 or feature maps beyond 160 KiB of LDS) has amplitudes, local energies, Monte-Carlo steps and the gradient accumulators; stochastic reconfiguration is not available on it");
   if (c->conv) {
     const ConvGeom& cg = c->cg;
     const long long CS = cg.CS, nc = cg.n_conv, nl = nc > 1 ? nc - 1 : 1;

@@ -4,7 +4,7 @@ layers.Conv*Periodic / ResBlock*, layers.py:24-293) at shapes the fused kernels 
 kernel_size > 9, feature maps beyond 160 KiB of LDS; the reference takes any value (utils.py:107-111) -- and, forced
 with CGS_VMC_CONV_GENERAL=1, at shapes both paths take, where the two must agree.  Amplitudes, local energies,
 proposals, injected steps, trajectories and the gradient accumulators; stochastic reconfiguration (an extension)
-is not built on this path and must refuse.
+is refused on this path.
 Tolerances as tests/test_gpu_conv.py."""
 import numpy as np
 import pytest
@@ -178,8 +178,10 @@ def test_general_convolution_gradient_accumulators_at_fused_shapes(monkeypatch, 
 
 
 def test_general_convolution_path_refuses_stochastic_reconfiguration():
+  """SR is an extension the reference does not have; on this path it was built, measured and withdrawn (vmc_sr_reserve
+  says why): the ctx must refuse it instead of returning steps that miss the parity bar."""
   eng, theta, cfg, bonds, geom = _make('conv_2d', 4, 4, 2, 80, 3, 12, 'relu')
-  with pytest.raises(Exception) as e:
+  with pytest.raises(NotImplementedError) as e:
     eng.sr_reserve(2)
   assert 'general convolution path' in str(e.value)
   eng.close()
