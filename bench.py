@@ -940,6 +940,8 @@ def main():
       k_sweep, k_eloc = ('k_conv_sweep', 'k_conv_rows(eloc)') if conv else ('k_sweep16', 'k_tail16(eloc)')
       if not conv and h > 256:        # 257..512 relu units: the LDS-operand row kernel (tail_co.hip)
         k_eloc = 'k_tail_lds(eloc)' if h <= 512 else 'wide GEMM rows(eloc)'
+      if conv and eng.kernel_path() == 6:     # the general convolution path (conv_general.hip)
+        k_sweep, k_eloc = 'k_cgen_im2col + GEMM(sampler)', 'k_cgen_im2col + GEMM(eloc)'
       if not conv and h > 512:        # the general path: per mc_step one k_wide_step launch + the H x H layers as GEMMs
         k_sweep = 'k_wide_step + k_gemm_ring(sampler)'
       per_kernel = {
