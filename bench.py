@@ -79,6 +79,7 @@ WORKLOADS = {
     'heisenberg10x10_conv3x32k7_b4096': (10, 10, False, 3, 32, 4096, 'conv_2d', 7),
     # round 5: beyond the fused kernels (more than 64 filters): the general convolution path (conv_general.hip)
     'heisenberg10x10_conv3x128k3_b1024': (10, 10, False, 3, 128, 1024, 'conv_2d', 3),
+    'heisenberg10x10_conv3x96k3_b1024': (10, 10, False, 3, 96, 1024, 'conv_2d', 3),     # one column tile, a quarter of it padding
 }
 
 

@@ -1242,7 +1242,7 @@ __global__ __launch_bounds__(512) void k_gemm_ring(GemmArgs g, int tiles_m, int 
 
 static bool gemm128_layout_ok(const GemmArgs& g);
 static bool gemm_ring_ok(const GemmArgs& g) {
-  return gemm128_layout_ok(g) && g.N >= G2_TN && g.K % GR_TK == 0 && g.K >= 4 * GR_TK &&
+  return gemm128_layout_ok(g) && g.N >= 64 && g.K % GR_TK == 0 && g.K >= 4 * GR_TK &&
          g.sam * 128 < (1LL << 29) && g.sbk * 4 + g.N < (1LL << 29);
 }
 
@@ -1260,7 +1260,10 @@ static bool gemm128_layout_ok(const GemmArgs& g) {
 // 0: k_gemm; 1: k_gemm128; 2: k_gemm_ring
 static int gemm_tiling(const GemmArgs& g) {
   const int mode = gemm128_mode();
-  if (mode == 0 || !gemm128_layout_ok(g) || g.N < G2_TN) return 0;
+  // (64 <= N < 128: ONE column tile with its upper columns clamped and masked -- the general convolution path's 65 .. 127
+  // filters; the 64 x 64 kernel would read the im2col rows twice.  CGS_VMC_GEMM_NARROW=0: as before round 5's last change)
+  static const bool narrow = !(getenv("CGS_VMC_GEMM_NARROW") && atoi(getenv("CGS_VMC_GEMM_NARROW")) == 0);
+  if (mode == 0 || !gemm128_layout_ok(g) || g.N < (narrow ? 64 : G2_TN)) return 0;
   if (mode == 2) return 1;
   if (mode == 5) return gemm_ring_ok(g) ? 2 : 0;
   const long long tiles = (long long)((g.M + G2_TM - 1) / G2_TM) * ((g.N + G2_TN - 1) / G2_TN);

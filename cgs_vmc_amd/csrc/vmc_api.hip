@@ -1065,6 +1065,12 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     if (rows < 1) rows = 1;
     if (rows > (1LL << 30) / cg.N) rows = (1LL << 30) / cg.N;          // rows * N: the M of a GEMM (int)
     if (rows > (B > 65536 ? B : 65536)) rows = B > 65536 ? B : 65536;  // (small shapes: no point in hundreds of MB of maps)
+    // whole rounds of the chip for the 128-row tiles of a block's products (the local energies run many full blocks:
+    // 5.09 rounds of 256 CUs are paid as 6)
+    if (rows * cg.N / 128 >= 2LL * c->num_cus) {
+      const long long rounds = rows * cg.N / (128LL * c->num_cus);
+      rows = rounds * 128LL * c->num_cus / cg.N;
+    }
     c->cg_rows = rows;
     CA(dalloc(&c->cg_A, rows * cg.N * plan_cgen_lda(cg)));
     for (int i = 0; i < 2; ++i) CA(dalloc(&c->cg_fm[i], rows * cg.N * cgen_fp(cg)));
