@@ -302,18 +302,24 @@ struct GemmArgs {
   float* dact_out;                      // epilogue 1: also store f'(z) (layout of C) or nullptr
   int epilogue;                         // 0 none, 1 f(v + bias), 3 accumulate (C += ), 4 bias,
                                         // 5 f' (.) (v + bias), 6 f' (.) (C + v + bias), 7 tanh(v + bias), 8 C + v + bias,
-                                        // 9 mask (.) (v + bias) with mask = a stored f'(z),
+                                        // 9 mask (.) (v + bias) with mask = a stored f'(z), 11 selu(v + bias),
                                         // 10 row dot: nothing is stored to C; dot_out[tn * M + m] = the sum over the 128
                                         //    columns of column tile tn of f(v + bias) * dot_w[n], in double (the output
                                         //    layer's dot product folded into the last H x H layer; only the 128 x 128-tile
                                         //    kernels have it: ask gemm_rowdot_ok)
   const float* dot_w; double* dot_out;  // epilogue 10
+  // conv_a != 0 (k_gemm_ring only; gemm_conv_a_ok): A is NOT a matrix but a channel-last feature map [row][site][ca_Fp] of a
+  // periodic convolution -- A(m = (row, site), k = (tap, c)) = map[row][(site + tap - lo) mod lattice][c]: the im2col
+  // gather happens in the address of the kernel's A pieces (conv_general.hip).  K = taps x ca_F, ca_F % 32 == 0.
+  int conv_a, ca_N, ca_D1, ca_D2, ca_KW, ca_lo, ca_lo2, ca_F, ca_Fp;
   int splitk;                           // >= 1
   float* workspace;                     // [splitk][dual ? 2 : 1][M][N] when splitk > 1
 };
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g);
 // whether launch_gemm takes this product (epilogue 10 set) with a kernel that has the row-dot epilogue
 bool gemm_rowdot_ok(const GemmArgs& g);
+// whether launch_gemm takes this product with conv_a set (the implicit-gather form of k_gemm_ring)
+bool gemm_conv_a_ok(const GemmArgs& g);
 inline int gemm_rowdot_tiles(int N) { return (N + 127) / 128; }
 // All weight gradients of one accumulate call -- [a_{l-1} | 1]^T [delta_l | w (.) delta_l] of every
 // layer and the scalar accumulators -- in ONE launch (k_wgrad, grad.hip; tiles,

@@ -143,7 +143,8 @@ hipError_t launch_cgen_accept(hipStream_t s, float* configs, float* logit, const
                               unsigned char* acc_mask);
 // gradient path: d logit / d (last map), d (.) f'(z), per-position weights, transposed weight image [T F][F] of a layer >= 1
 hipError_t launch_cgen_fill(hipStream_t s, float* gm, const float* oscale, long long row0, int rows, int N, int F, int Fp);
-hipError_t launch_cgen_dact(hipStream_t s, const float* d, const float* z, int pre, long long n, int F, int Fp, float* out);
+hipError_t launch_cgen_dact(hipStream_t s, const float* d, const float* z, int pre, bool from_act, long long n, int F, int Fp,
+                            float* out);
 hipError_t launch_cgen_wpos(hipStream_t s, const float* w, long long row0, int rows, int N, float* wpos);
 hipError_t launch_cgen_pack_t(hipStream_t s, const float* w, int T, int F, float* wt);
 inline long long cgen_off_wt(const ConvGeom& g, int l) { return (long long)(l - 1) * g.K * g.KW * g.F * g.F; }   // l >= 1

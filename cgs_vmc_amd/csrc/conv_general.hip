@@ -158,10 +158,16 @@ __global__ void k_cgen_fill(float* __restrict__ gm, const float* __restrict__ os
 }
 
 // out = d (.) f'(z)  (d / d pre-activation from d / d activation); padding channels 0
-__global__ void k_cgen_dact(const float* __restrict__ d, const float* __restrict__ z, int pre, long long n, int F,
-                            int Fp, float* __restrict__ out) {
+// from_act: the map holds a = f(z) (cgen_post): f' read off the activation (selu: off t = selu(u))
+__device__ __forceinline__ float cg_dpre_from_act(int pre, float a) {
+  if (pre < 0) return 1.f;
+  if (pre == CGEN_PRE_SELU) return a > 0.f ? 1.0507009873554805f : a + 1.0507009873554805f * 1.6732632423543772f;
+  return vmc_dact_rt(pre, a, a);                    // (relu: a > 0 <=> z > 0; the cosine never comes here)
+}
+__global__ void k_cgen_dact(const float* __restrict__ d, const float* __restrict__ z, int pre, int from_act, long long n,
+                            int F, int Fp, float* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    out[i] = (int)(i % Fp) < F ? d[i] * cg_dpre(pre, z[i]) : 0.f;
+    out[i] = (int)(i % Fp) < F ? d[i] * (from_act ? cg_dpre_from_act(pre, z[i]) : cg_dpre(pre, z[i])) : 0.f;
 }
 
 // per-position copy of the per-sample weights: the k-scale of the weight-gradient products
@@ -224,9 +230,10 @@ hipError_t launch_cgen_fill(hipStream_t s, float* gm, const float* oscale, long 
   return hipGetLastError();
 }
 
-hipError_t launch_cgen_dact(hipStream_t s, const float* d, const float* z, int pre, long long n, int F, int Fp, float* out) {
+hipError_t launch_cgen_dact(hipStream_t s, const float* d, const float* z, int pre, bool from_act, long long n, int F, int Fp,
+                            float* out) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_cgen_dact, dim3(cg_blocks(n)), dim3(256), 0, s, d, z, pre, n, F, Fp, out);
+  hipLaunchKernelGGL(k_cgen_dact, dim3(cg_blocks(n)), dim3(256), 0, s, d, z, pre, from_act ? 1 : 0, n, F, Fp, out);
   return hipGetLastError();
 }
 

@@ -50,6 +50,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, float* C, int m
     case 7: *c = tanhf(v + g.bias[n]); break;
     case 9: *c = g.mask[(long long)m * g.ldmask + n] * (v + g.bias[n]); break;   // mask IS f'(z) (cosine: stored by epilogue 1)
     case 8: *c = *c + v + g.bias[n]; break;
+    case 11: {  // ResBlock2d's selu (layers.py:226) -- the general convolution path stores selu(first_conv(h))
+      const float z = v + g.bias[n];
+      *c = 1.0507009873554805f * (z > 0.f ? z : 1.6732632423543772f * (expf(z) - 1.f));
+      break;
+    }
     case 6: *c = vmc_dact_rt(g.act, g.mask[(long long)m * g.ldmask + n], g.mask[(long long)m * g.ldmask + n]) * (*c + v + g.bias[n]); break;
     default: *c = v; break;
   }
@@ -1113,7 +1118,10 @@ typedef float f32x2_gr __attribute__((ext_vector_type(2)));
 #define GR_STEP_NEXT(S, T, SLOT) GR_STEP_("s_waitcnt vmcnt(8) lgkmcnt(0)\n\t" GR_BARRIER, S, T, SLOT, 0)
 
 // WHOLE: K is a multiple of 128 -- whole turns of the ring, no stage is skipped (no branch around the MFMAs)
-template <bool WHOLE>
+// CONVA: the A pieces gather a periodic convolution's input on the fly (GemmArgs.conv_a): lane L of a piece still takes row
+// 8 i + (L >> 3), k quad (L & 7) ^ ((row >> 1) & 7) of the stage -- a stage is 32 channels of ONE tap (ca_F % 32 == 0) -- but
+// the row is a lattice position and the address that of the tap's periodic neighbour: no im2col matrix is written or read.
+template <bool WHOLE, bool CONVA = false>
 __global__ __launch_bounds__(512) void k_gemm_ring(GemmArgs g, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char gr_lds[];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -1130,11 +1138,17 @@ __global__ __launch_bounds__(512) void k_gemm_ring(GemmArgs g, int tiles_m, int 
 
   // ---- this wave's four pieces of a stage: A pieces 2 wave, 2 wave + 1 (eight rows each), B pieces likewise (two k rows each)
   unsigned voffA[2], voffB[2];
+  int ca1[2] = {0, 0}, ca2[2] = {0, 0};             // CONVA: lattice coordinates of this lane's two rows
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int r = 8 * (2 * wave + u) + (lane >> 3);
     const int rc = min(m0 + r, g.M - 1) - m0;
     const int q = (lane & 7) ^ ((r >> 1) & 7);
+    if (CONVA) {                                    // voffA: byte offset of (its row configuration, site 0, quad q)
+      const int m = m0 + rc, rr = m / g.ca_N, n = m - rr * g.ca_N;
+      ca1[u] = n / g.ca_D2; ca2[u] = n - ca1[u] * g.ca_D2;
+      voffA[u] = (unsigned)(rr * g.ca_N * g.ca_Fp + 4 * q) * 4u;
+    } else
     voffA[u] = (unsigned)(rc * sam + 4 * q) * 4u;
     const int nq = min(n0 + 4 * (lane & 31), g.N - 4);
     voffB[u] = (unsigned)((2 * u + (lane >> 5)) * sbk + nq) * 4u;
@@ -1151,7 +1165,17 @@ __global__ __launch_bounds__(512) void k_gemm_ring(GemmArgs g, int tiles_m, int 
   auto piece = [&](int p, int s, int slot) {
     if ((VMC_GR_ABLATE & 1) && s >= GR_RING) return;
     const int k0 = min(s, T - 1) * GR_TK;
-    if (p < 2) {
+    if (p < 2 && CONVA) {
+      // the stage's tap (uniform) and, per lane, the periodic neighbour of its row's site under that tap
+      const int t = k0 / g.ca_F, c0 = k0 - t * g.ca_F, d1 = t / g.ca_KW, d2 = t - d1 * g.ca_KW;
+      int s1 = ca1[p] + d1 - g.ca_lo, s2 = ca2[p] + d2 - g.ca_lo2;
+      s1 += s1 < 0 ? g.ca_D1 : 0; s1 -= s1 >= g.ca_D1 ? g.ca_D1 : 0;
+      s2 += s2 < 0 ? g.ca_D2 : 0; s2 -= s2 >= g.ca_D2 ? g.ca_D2 : 0;
+      const unsigned vo = voffA[p] + (unsigned)((s1 * g.ca_D2 + s2) * g.ca_Fp + c0) * 4u;
+      const float* b_ = sgpr_ptr(g.A);
+      const unsigned l_ = __builtin_amdgcn_readfirstlane(ldsA + slot * GR_ABYTES + p * 1024);
+      GR_DMA(b_, vo, l_);
+    } else if (p < 2) {
       const float* b_ = sgpr_ptr(abase + k0);
       const unsigned l_ = __builtin_amdgcn_readfirstlane(ldsA + slot * GR_ABYTES + p * 1024);
       GR_DMA(b_, voffA[p], l_);
@@ -1287,19 +1311,36 @@ __global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g) {
 }
 
 bool gemm_rowdot_ok(const GemmArgs& g) { return g.M > 0 && g.N > 0 && gemm_tiling(g) != 0; }
+// the implicit-gather A operand: the ring kernel only; whole stages inside one tap; 32-bit byte offsets into the map
+bool gemm_conv_a_ok(const GemmArgs& g) {
+  if (!g.conv_a || g.M <= 0 || g.ca_F % GR_TK != 0 || g.ca_F <= 0 || g.K % g.ca_F != 0 || ((size_t)g.A & 15) || g.ca_Fp % 4 != 0) return false;
+  if ((long long)g.M * g.ca_Fp * 4 >= (1LL << 32)) return false;
+  GemmArgs t = g;
+  t.sam = g.K; t.sak = 1;                            // (the layout checks of the plain form, with a matrix-like stride)
+  return gemm_tiling(t) == 2;
+}
 
-hipError_t launch_gemm(hipStream_t s, const GemmArgs& g) {
-  if (g.M <= 0 || g.N <= 0) return hipSuccess;
+hipError_t launch_gemm(hipStream_t s, const GemmArgs& g_in) {
+  if (g_in.M <= 0 || g_in.N <= 0) return hipSuccess;
+  GemmArgs g = g_in;
+  if (g.conv_a) {
+    if (!gemm_conv_a_ok(g)) return hipErrorInvalidValue;
+    g.sam = g.K; g.sak = 1;                          // (what the layout checks of gemm_tiling read; the kernel does not)
+  }
   if (const int tiling = gemm_tiling(g)) {
     const int tiles_m = (g.M + G2_TM - 1) / G2_TM, tiles_n = (g.N + G2_TN - 1) / G2_TN;
     const int blocks = ((tiles_m + 7) / 8) * 8 * tiles_n;      // whole rounds of the eight XCDs
     if (tiling == 2) {
       // (the opt-in is per device: set on every launch, as launch_wgrad does)
       const bool whole = g.K % (GR_RING * GR_TK) == 0;
-      const void* f = whole ? (const void*)k_gemm_ring<true> : (const void*)k_gemm_ring<false>;
+      const void* f = g.conv_a ? (whole ? (const void*)k_gemm_ring<true, true> : (const void*)k_gemm_ring<false, true>)
+                               : (whole ? (const void*)k_gemm_ring<true> : (const void*)k_gemm_ring<false>);
       hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GR_LDS);
       if (e != hipSuccess) return e;
-      if (whole) hipLaunchKernelGGL(k_gemm_ring<true>, dim3(blocks), dim3(512), GR_LDS, s, g, tiles_m, tiles_n);
+      if (g.conv_a) {
+        if (whole) hipLaunchKernelGGL((k_gemm_ring<true, true>), dim3(blocks), dim3(512), GR_LDS, s, g, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((k_gemm_ring<false, true>), dim3(blocks), dim3(512), GR_LDS, s, g, tiles_m, tiles_n);
+      } else if (whole) hipLaunchKernelGGL(k_gemm_ring<true>, dim3(blocks), dim3(512), GR_LDS, s, g, tiles_m, tiles_n);
       else hipLaunchKernelGGL(k_gemm_ring<false>, dim3(blocks), dim3(512), GR_LDS, s, g, tiles_m, tiles_n);
     } else {
       hipLaunchKernelGGL(k_gemm128<G2_TN>, dim3(blocks), dim3(256), 0, s, g, tiles_m, tiles_n);

@@ -386,41 +386,63 @@ int ensure_cache(vmc_ctx* c, int which);
 
 // One convolution of the general path over `rows` row configurations: im2col gather of its input into cg_A, then the
 // product with the parameter slice; residual: dst += (ResBlock2d's `v + h`).
+// What a stored map of the general path holds: the ACTIVATION of a convolution's output (conv_plain: f(z_l) behind every
+// convolution but the last; residual blocks: selu(u) behind a block's first convolution, the linear h elsewhere) -- so
+// that the next convolution can gather it as it stands -- unless the hidden activation is the cosine, whose derivative
+// needs the pre-activation: then the map holds z_l and f is applied on the gather (as in the first form of this path).
+static bool cgen_post(const vmc_ctx* c) { return c->cg.resnet || c->cg.hact != VMC_ACT_COS_; }
+static int cgen_in_pre(const vmc_ctx* c, int l) {       // activation applied while convolution l's input is gathered
+  if (l == 0 || c->cg.resnet || cgen_post(c)) return -1;
+  return c->cg.hact;
+}
+static bool cgen_implicit_on() {
+  static const bool on = !(getenv("CGS_VMC_CONV_GENERAL_IMPLICIT") && atoi(getenv("CGS_VMC_CONV_GENERAL_IMPLICIT")) == 0);
+  return on;
+}
+
 static int cgen_conv(vmc_ctx* c, const ParamSet& p, const float* configs, const int2* rowinfo, const int* iup,
-                     const int* idn, int l, int rows, const float* in, int pre, float* dst, bool residual, long long row0) {
+                     const int* idn, int l, int rows, const float* in, float* dst, long long row0) {
   const ConvGeom& g = c->cg;
   const int Fp = cgen_fp(g), lda = plan_cgen_lda(g);
-  {
-    CgenIm2colArgs a;
-    memset(&a, 0, sizeof(a));
-    a.g = g; a.layer = l; a.Fp = Fp; a.pre_act = pre; a.rows = rows; a.lda = lda; a.A = c->cg_A;
-    if (l == 0) {
-      a.src = configs; a.rowinfo = rowinfo; a.row0 = row0; a.bonds = c->bonds ? c->bonds : c->bond_dummy;
-      a.iup = iup; a.idn = idn;
-    } else {
-      a.src = in;
-    }
-    HIPCHK(c, launch_cgen_im2col(c->stream, a));
-    GemmArgs m; memset(&m, 0, sizeof(m));
-    m.A = c->cg_A; m.sam = lda; m.sak = 1;
-    m.B = p.theta + cgen_off_w(g, l); m.sbk = g.F; m.sbn = 1;
-    m.M = rows * g.N; m.N = g.F; m.K = cgen_kdim(g, l); m.C = dst; m.ldc = Fp;
-    m.bias = p.theta + cgen_off_b(g, l); m.epilogue = residual ? 8 : 4; m.splitk = 1;
-    HIPCHK(c, launch_gemm(c->stream, m));
+  GemmArgs m; memset(&m, 0, sizeof(m));
+  m.B = p.theta + cgen_off_w(g, l); m.sbk = g.F; m.sbn = 1;
+  m.M = rows * g.N; m.N = g.F; m.K = cgen_kdim(g, l); m.C = dst; m.ldc = Fp;
+  m.bias = p.theta + cgen_off_b(g, l); m.splitk = 1;
+  if (!g.resnet) { m.epilogue = (l + 1 < g.n_conv && cgen_post(c)) ? 1 : 4; m.act = g.hact; }
+  else m.epilogue = l == 0 ? 4 : ((l & 1) ? 11 : 8);       // initial convolution; selu(first_conv(h)); h + second_conv(.)
+  const int pre = cgen_in_pre(c, l);
+  // the gather inside the product's A operand (k_gemm_ring<., true>): no im2col matrix for this convolution
+  if (l > 0 && pre < 0 && cgen_implicit_on()) {
+    m.A = in; m.conv_a = 1; m.ca_N = g.N; m.ca_D1 = g.D1; m.ca_D2 = g.D2; m.ca_KW = g.KW; m.ca_lo = g.lo; m.ca_lo2 = g.lo2;
+    m.ca_F = g.F; m.ca_Fp = Fp;
+    if (gemm_conv_a_ok(m)) { HIPCHK(c, launch_gemm(c->stream, m)); return VMC_OK; }
+    m.conv_a = 0;
   }
+  CgenIm2colArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g = g; a.layer = l; a.Fp = Fp; a.pre_act = pre; a.rows = rows; a.lda = lda; a.A = c->cg_A;
+  if (l == 0) {
+    a.src = configs; a.rowinfo = rowinfo; a.row0 = row0; a.bonds = c->bonds ? c->bonds : c->bond_dummy;
+    a.iup = iup; a.idn = idn;
+  } else {
+    a.src = in;
+  }
+  HIPCHK(c, launch_cgen_im2col(c->stream, a));
+  m.A = c->cg_A; m.sam = lda; m.sak = 1;
+  HIPCHK(c, launch_gemm(c->stream, m));
   return VMC_OK;
 }
 
-// tape != nullptr (gradient path, n_rows <= cg_rows): the map of convolution l is kept at tape + l * tape_stride --
-// its pre-activation; for the second convolution of a residual block the block's output h + v
+// tape != nullptr (gradient path, n_rows <= cg_rows): the map of convolution l is kept at tape + l * tape_stride
+// (cgen_post says what it holds; for the second convolution of a residual block the block's output h + v)
 static int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2* rowinfo, long long n_rows,
                         const int* iup, const int* idn, bool ratio, float* out, float* tape = nullptr,
                         long long tape_stride = 0, long long first_row = 0) {
   const ConvGeom& g = c->cg;
   const ParamSet& p = c->ps[which];
   const int Fp = cgen_fp(g);
-  auto conv = [&](int l, int rows, const float* in, int pre, float* dst, bool residual, long long row0) -> int {
-    return cgen_conv(c, p, configs, rowinfo, iup, idn, l, rows, in, pre, dst, residual, row0);
+  auto conv = [&](int l, int rows, const float* in, float* dst, long long row0) -> int {
+    return cgen_conv(c, p, configs, rowinfo, iup, idn, l, rows, in, dst, row0);
   };
   auto map = [&](int l) { return tape ? tape + (long long)l * tape_stride : c->cg_fm[g.resnet ? (l & 1 ? 1 : 0) : (l & 1)]; };
   if (tape && n_rows > c->cg_rows) return fail(c, VMC_ERR_STATE, "taped forward beyond one block");
@@ -428,19 +450,19 @@ static int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2*
     const long long row0 = first_row + blk0;
     const int rows = (int)(n_rows - blk0 < c->cg_rows ? n_rows - blk0 : c->cg_rows);
     const float* last;
-    PROPAGATE(conv(0, rows, nullptr, -1, map(0), false, row0));
+    PROPAGATE(conv(0, rows, nullptr, map(0), row0));
     if (!g.resnet) {           // Conv2DNetwork (wavefunctions.py:572-575): act between the convolutions, none behind the last
       for (int l = 1; l < g.n_conv; ++l)
-        PROPAGATE(conv(l, rows, map(l - 1), g.hact, map(l), false, row0));
+        PROPAGATE(conv(l, rows, map(l - 1), map(l), row0));
       last = map(g.n_conv - 1);
     } else {                   // ResNet2D (wavefunctions.py:766-772; layers.py:226-228): h += second(selu(first(h)))
       for (int l = 1; l + 1 < g.n_conv; l += 2) {
         const float* h = tape ? map(l - 1) : c->cg_fm[0];
         float* u = tape ? map(l) : c->cg_fm[1];
         float* hn = tape ? map(l + 1) : c->cg_fm[0];
-        PROPAGATE(conv(l, rows, h, -1, u, false, row0));
+        PROPAGATE(conv(l, rows, h, u, row0));
         if (tape) HIPCHK(c, hipMemcpyAsync(hn, h, (size_t)rows * g.N * Fp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-        PROPAGATE(conv(l + 1, rows, u, CGEN_PRE_SELU, hn, true, row0));
+        PROPAGATE(conv(l + 1, rows, u, hn, row0));
       }
       last = tape ? map(g.n_conv - 1) : c->cg_fm[0];
     }
@@ -479,9 +501,7 @@ static int cgen_gather_input(vmc_ctx* c, int l, int rows, long long row0, const 
   memset(&a, 0, sizeof(a));
   a.g = g; a.layer = l; a.Fp = cgen_fp(g); a.rows = rows; a.lda = plan_cgen_lda(g); a.A = c->cg_A; a.pre_act = -1;
   if (l == 0) { a.src = configs; a.row0 = row0; a.bonds = c->bonds ? c->bonds : c->bond_dummy; }
-  else if (!g.resnet) { a.src = cgen_tape(c, l - 1); a.pre_act = g.hact; }
-  else if (l & 1) { a.src = cgen_tape(c, l - 1); }                              // first convolution of a block: h
-  else { a.src = cgen_tape(c, l - 1); a.pre_act = CGEN_PRE_SELU; }              // second: selu(u)
+  else { a.src = cgen_tape(c, l - 1); a.pre_act = cgen_in_pre(c, l); }          // (residual blocks: h / the stored selu(u))
   HIPCHK(c, launch_cgen_im2col(c->stream, a));
   return VMC_OK;
 }
@@ -514,13 +534,13 @@ static int cgen_backward(vmc_ctx* c, int rows, long long row0, const float* osca
   if (!g.resnet) {
     for (int l = n_conv - 1; l >= 1; --l) {
       PROPAGATE(cgen_input_grad(c, l, rows, cgen_gl(c, l), D, false));
-      HIPCHK(c, launch_cgen_dact(c->stream, D, cgen_tape(c, l - 1), g.hact, M * Fp, g.F, Fp, cgen_gl(c, l - 1)));
+      HIPCHK(c, launch_cgen_dact(c->stream, D, cgen_tape(c, l - 1), g.hact, cgen_post(c), M * Fp, g.F, Fp, cgen_gl(c, l - 1)));
     }
   } else {                     // gl[even l] = d / d h behind block (l / 2): the gradient of the block's second convolution
     for (int l2 = n_conv - 1; l2 >= 2; l2 -= 2) {
       const int l1 = l2 - 1;
       PROPAGATE(cgen_input_grad(c, l2, rows, cgen_gl(c, l2), D, false));                                   // d / d selu(u)
-      HIPCHK(c, launch_cgen_dact(c->stream, D, cgen_tape(c, l1), CGEN_PRE_SELU, M * Fp, g.F, Fp, cgen_gl(c, l1)));   // d / d u
+      HIPCHK(c, launch_cgen_dact(c->stream, D, cgen_tape(c, l1), CGEN_PRE_SELU, true, M * Fp, g.F, Fp, cgen_gl(c, l1)));   // d / d u (from the stored selu(u))
       HIPCHK(c, hipMemcpyAsync(cgen_gl(c, l2 - 2), cgen_gl(c, l2), (size_t)M * Fp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
       PROPAGATE(cgen_input_grad(c, l1, rows, cgen_gl(c, l1), cgen_gl(c, l2 - 2), true));                   // d / d h += through the block
     }

@@ -20,7 +20,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'cgs_vmc_amd', 'csrc')
 # source, kernel-name fragment of the mangled symbol, instantiations expected, in-flight windows expected per instantiation
-TARGETS = [('tail_split.hip', 'k_tail16r', 2, 2 * 128), ('grad.hip', 'k_gemm_ring', 2, 17)]
+TARGETS = [('tail_split.hip', 'k_tail16r', 2, 2 * 128), ('grad.hip', 'k_gemm_ring', 4, 17)]
 READS = ('ds_read_b128', 'ds_read2st64_b32')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
