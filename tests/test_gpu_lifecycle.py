@@ -3,7 +3,7 @@
 VERDICT r2 item 6: tests/conftest.py used to initialise torch before the first VmcEngine because
 "torch's lazy init after ~140 engine life cycles ... 'No HIP GPUs are available'" had been seen once.
 tools/lifecycle_probe.py (a FRESH process, torch untouched) creates and destroys 500 engines of mixed
-ansatz types -- dense, padded, rbm, conv_2d, the general wide path -- each doing a sweep, an
+ansatz types -- dense, padded, rbm, conv_2d, the general wide path, the general convolution path -- each doing a sweep, an
 accumulate and an external amplitude call, and prints open file descriptors, memory mappings,
 resident memory, threads and the device's free memory (hipMemGetInfo) every 20 cycles; then torch
 initialises its context and runs a kernel.  Measured on MI355X (round 3): descriptors, threads and

@@ -55,7 +55,9 @@ def main():
            dict(n_sites=36, batch_size=128, num_layers=3, layer_size=128),
            dict(n_sites=16, batch_size=64, num_layers=1, layer_size=32, ansatz='rbm'),
            dict(n_sites=16, batch_size=64, num_layers=2, layer_size=8, ansatz='conv_2d', kernel_size=3, size_x=4, size_y=4),
-           dict(n_sites=16, batch_size=64, num_layers=2, layer_size=300)]
+           dict(n_sites=16, batch_size=64, num_layers=2, layer_size=300),
+           # (round 5) beyond the fused convolution kernels: the general path of conv_general.hip, ~1 GB of block buffers per ctx
+           dict(n_sites=16, batch_size=64, num_layers=2, layer_size=72, ansatz='conv_2d', kernel_size=3, size_x=4, size_y=4)]
   bonds = [(i, (i + 1) % 16) for i in range(16)]
   print('cycle fds maps rss_MB threads dev_free_MB')
   seen_maps, last_rss = None, 0
