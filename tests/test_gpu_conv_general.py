@@ -290,3 +290,65 @@ def test_general_convolution_shard_invariance_and_reproducibility():
   np.testing.assert_array_equal(outs[0][2], outs[1][2])
   np.testing.assert_array_equal(outs[0][0][16:48], outs[2][0])
   np.testing.assert_array_equal(outs[0][1][16:48], outs[2][1])
+
+
+def _random_general_shapes(count, seed=5055):
+  """Seeded random geometries BEYOND the fused limits: 65 .. 160 filters (every residue mod 4 and mod 32) or a
+  10 .. 13-tap kernel; every padding parity, ragged batches, kernels longer than a lattice side."""
+  rng = np.random.default_rng(seed)
+  acts = ['relu', 'tanh', 'sigmoid', 'identity', 'cos']
+  shapes = []
+  while len(shapes) < count:
+    ansatz = ['conv_2d', 'res_net_2d', 'conv_1d', 'res_net_1d'][int(rng.integers(4))]
+    wide = len(shapes) % 2 == 0
+    k = int(rng.integers(1, 6)) if wide else int(rng.integers(10, 14))
+    f = int(rng.integers(65, 161)) if wide else int(rng.integers(1, 13))
+    if ansatz in vo.CONV_1D:
+      sx, sy = int(rng.integers(max(2, (k + 1) // 2), 29)), 1
+    else:
+      sx, sy = int(rng.integers(max(2, (k + 1) // 2), 9)), int(rng.integers(max(2, (k + 1) // 2), 9))
+    if (sx * sy) % 2 or sx * sy < 4:
+      continue
+    resnet = ansatz.startswith('res_net')
+    L = int(rng.integers(0, 3)) if resnet else int(rng.integers(1, 4))
+    b = int(rng.integers(1, 25))
+    nonlin = 'relu' if resnet else acts[int(rng.integers(len(acts)))]
+    shapes.append((ansatz, sx, sy, L, f, k, b, nonlin))
+  return shapes
+
+
+RANDOM_GENERAL = _random_general_shapes(20)
+
+
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', RANDOM_GENERAL,
+                         ids=['{}-{}x{}-L{}-F{}-K{}-B{}-{}'.format(*s_) for s_ in RANDOM_GENERAL])
+def test_general_convolution_random_shapes(ansatz, sx, sy, L, f, k, b, nonlin):
+  """tests/test_gpu_conv.py::test_conv_random_shapes beyond the fused limits: amplitudes, local energies, the gradient
+  sums and one injected mc_step on random geometries."""
+  from cgs_vmc_amd import _hip
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin, seed=b + 7 * k)
+  assert eng.kernel_path() == 6
+  n = sx * sy
+  psi_fn = vo.ANSATZ[ansatz][0]
+  amp = lambda c: psi_fn(theta, c, geom, L, nonlinearity=nonlin, dtype=np.float64)
+  _logits_close(eng.amplitude()[0], theta, cfg, ansatz, geom, L, nonlin)
+  e_ref = vo.local_value(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64)
+  _, scale = vo.conv_forward(theta, cfg, ansatz, geom, L, nonlin, np.float64, return_tape='scale')
+  _close(eng.local_energy()[0], e_ref, max(2e-4, 4e-6 * float(np.max(scale))))
+  acc = vo.Accumulators(theta.size, np.float64)
+  vo.energy_gradient_accumulate(acc, theta, cfg, bonds, -1.0, 1.0, -10.0, geom, L, np.float64,
+                                ansatz=ansatz, nonlinearity=nonlin)
+  eng.reset_accumulators()
+  eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+  got = eng.get_accumulators()
+  p = theta.size
+  for name, g, r in (('g1', got[:p], acc.g1_total), ('g2', got[p:2 * p], acc.g2_total)):
+    tol = 2e-3 * np.abs(r).max() + 1e-4
+    assert np.abs(g - r).max() < tol, (name, np.abs(g - r).max(), tol, int(np.argmax(np.abs(g - r))))
+  u_sites, u_acc = vo.step_uniforms(5, np.arange(b), 0, n)
+  i_up, i_dn = vo.propose_exchange(cfg, u_sites)
+  _, acc_ref, ratios = vo.mc_step(amp, cfg, i_up, i_dn, u_acc)
+  mask = eng.mc_step_injected(i_up, i_dn, u_acc)
+  band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
+  assert np.array_equal(mask[~band], acc_ref[~band])
+  eng.close()
