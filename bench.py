@@ -80,6 +80,8 @@ WORKLOADS = {
     # round 5: beyond the fused kernels (more than 64 filters): the general convolution path (conv_general.hip)
     'heisenberg10x10_conv3x128k3_b1024': (10, 10, False, 3, 128, 1024, 'conv_2d', 3),
     'heisenberg10x10_conv3x96k3_b1024': (10, 10, False, 3, 96, 1024, 'conv_2d', 3),     # one column tile, a quarter of it padding
+    # a lattice whose feature maps exceed the LDS at the DEFAULT filter count: the general path's weak spot (16 output columns)
+    'heisenberg36x36_conv3x16k5_b32': (36, 36, False, 3, 16, 32, 'conv_2d', 5),
 }
 
 
