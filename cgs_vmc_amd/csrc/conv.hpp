@@ -147,4 +147,9 @@ hipError_t launch_cgen_dact(hipStream_t s, const float* d, const float* z, int p
                             float* out);
 hipError_t launch_cgen_wpos(hipStream_t s, const float* w, long long row0, int rows, int N, float* wpos);
 hipError_t launch_cgen_pack_t(hipStream_t s, const float* w, int T, int F, float* wt);
+// SR (single rank): t[r] (+)= < y[r] , g[r] > in double; t = (float) td; the mean of t and sum (t - mean); weights t - mean
+hipError_t launch_cgen_pairdot(hipStream_t s, const float* y, const float* gm, int rows, int N, int F, int Fp, double* t, bool first);
+hipError_t launch_cgen_tstore(hipStream_t s, const double* td, int rows, float* t);
+hipError_t launch_cgen_tmean(hipStream_t s, const float* t, int n, float* centre, float* usum);
+hipError_t launch_cgen_wpos_centred(hipStream_t s, const float* t, const float* centre, long long row0, int rows, int N, float* wpos);
 inline long long cgen_off_wt(const ConvGeom& g, int l) { return (long long)(l - 1) * g.K * g.KW * g.F * g.F; }   // l >= 1

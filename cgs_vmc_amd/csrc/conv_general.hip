@@ -188,6 +188,63 @@ __global__ void k_cgen_pack_t(const float* __restrict__ w, int T, int F, float* 
   }
 }
 
+// ---- stochastic reconfiguration (single rank): t[r] (+)= < y[r] , g[r] > over sites and channels, in double
+__global__ __launch_bounds__(256) void k_cgen_pairdot(const float* __restrict__ y, const float* __restrict__ gm, int N,
+                                                      int F, int Fp, double* __restrict__ t, int first) {
+  __shared__ double s_w[4];
+  const int r = blockIdx.x;
+  const long long base = (long long)r * N * Fp;
+  const int q = N * Fp / 4, fq = Fp / 4;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < q; i += 256) {
+    const f32x4 a = *(const f32x4*)(y + base + 4 * i), b = *(const f32x4*)(gm + base + 4 * i);
+    const int c0 = 4 * (i % fq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += c0 + e < F ? (double)a[e] * (double)b[e] : 0.0;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double v = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    t[r] = first ? v : t[r] + v;
+  }
+}
+
+__global__ void k_cgen_tstore(const double* __restrict__ td, int rows, float* __restrict__ t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < rows) t[i] = (float)td[i];
+}
+
+// centre[0] = c = mean of t (double sum, fixed order, one workgroup); usum[0] = sum_b (t_b - c): what k_sr_q reads as u[P]
+__global__ __launch_bounds__(1024) void k_cgen_tmean(const float* __restrict__ t, int n, float* __restrict__ centre,
+                                                     float* __restrict__ usum) {
+  __shared__ double s[1024];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) a += (double)t[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int d = 512; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float c = (float)(s[0] / (double)n);
+    centre[0] = c;
+    usum[0] = (float)(s[0] - (double)n * (double)c);
+  }
+}
+
+// per-position weights t_b - c
+__global__ void k_cgen_wpos_centred(const float* __restrict__ t, const float* __restrict__ centre, long long row0, int rows,
+                                    int N, float* __restrict__ wpos) {
+  const float c = centre[0];
+  const long long total = (long long)rows * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+    wpos[i] = t[row0 + i / N] - c;
+}
+
 int cg_blocks(long long n) { const long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b < 16384 ? b : 16384)); }
 
 }  // namespace
@@ -245,5 +302,30 @@ hipError_t launch_cgen_wpos(hipStream_t s, const float* w, long long row0, int r
 
 hipError_t launch_cgen_pack_t(hipStream_t s, const float* w, int T, int F, float* wt) {
   hipLaunchKernelGGL(k_cgen_pack_t, dim3(cg_blocks((long long)T * F * F)), dim3(256), 0, s, w, T, F, wt);
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_pairdot(hipStream_t s, const float* y, const float* gm, int rows, int N, int F, int Fp, double* t,
+                               bool first) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cgen_pairdot, dim3(rows), dim3(256), 0, s, y, gm, N, F, Fp, t, first ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_tstore(hipStream_t s, const double* td, int rows, float* t) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cgen_tstore, dim3((rows + 255) / 256), dim3(256), 0, s, td, rows, t);
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_tmean(hipStream_t s, const float* t, int n, float* centre, float* usum) {
+  hipLaunchKernelGGL(k_cgen_tmean, dim3(1), dim3(1024), 0, s, t, n, centre, usum);
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_wpos_centred(hipStream_t s, const float* t, const float* centre, long long row0, int rows, int N,
+                                    float* wpos) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cgen_wpos_centred, dim3(cg_blocks((long long)rows * N)), dim3(256), 0, s, t, centre, row0, rows, N, wpos);
   return hipGetLastError();
 }

@@ -81,6 +81,9 @@ struct vmc_ctx {
   // d logit / d map buffers, per-position weights, the transposed weight images, the split-K workspace
   float* cg_tape = nullptr; float* cg_gl = nullptr; float* cg_g[2] = {nullptr, nullptr}; float* cg_wpos = nullptr; float* cg_wt = nullptr;
   float* cg_ws = nullptr; long long cg_ws_floats = 0;
+  double* cg_td = nullptr;                 // [cg_rows] O_b . v of a block (SR)
+  float* cg_centre = nullptr;              // [1] mean of O_b . v over the stored samples (SR)
+  bool sr_centre = false;                  // the SR matvec may centre its weights: a single-rank solve is running
   int *wide_iup = nullptr, *wide_idn = nullptr;
   int hact = VMC_ACT_RELU_;  // hidden activation (layers.NONLINEARITIES id)
   int oact = VMC_ACT_EXP_;   // output activation; exp: psi = exp(x - shift), else psi = g(x), no shift
@@ -466,6 +469,7 @@ static int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2*
       }
       last = tape ? map(g.n_conv - 1) : c->cg_fm[0];
     }
+    if (!out) continue;        // (taped forward of the SR matvec: the maps are all that is wanted)
     HIPCHK(c, launch_cgen_rowsum(c->stream, last, rows, g.N, g.F, Fp, c->cg_sum));
     const WideOnsite on{nullptr, nullptr, nullptr, nullptr, nullptr};
     HIPCHK(c, launch_wide_out_part(c->stream, c->cg_sum, 1, c->cg_zero, rows, rowinfo ? rowinfo : c->rowinfo_id, row0,
@@ -589,6 +593,54 @@ static int cgen_gradient_sums(vmc_ctx* c, const float* w) {
     PROPAGATE(cgen_backward(c, rows, row0, c->oact != VMC_ACT_EXP_ ? c->oscale : nullptr));
     for (int l = g.n_conv - 1; l >= 0; --l)
       PROPAGATE(cgen_weight_sums(c, l, rows, row0, c->configs, cgen_gl(c, l), c->acc, c->acc + c->P));
+  }
+  return VMC_OK;
+}
+
+// SR matvec of the general path over the `n_rows` stored chains (sr_cfg), SINGLE RANK: u = sum_b (t_b - tbar) O_b with
+// t_b = O_b . v, u[P] = sum_b (t_b - tbar) (~ 0).  k_sr_q forms q = u / n - <O> u[P] / n + lambda p, which is S v + lambda v
+// for ANY constant subtracted from every t_b -- and with the mean subtracted the cancellation of <O (O.v)> - <O><O.v> happens
+// per sample, before the fp32 sums (the uncentred form of this matvec met the 5e-4 bound on S v but its solutions missed
+// the 1 % bound on O_c x; the constant would have to be the same on every rank: hence one rank).  Only the chains are
+// stored: every CG iteration re-runs the taped forward and the backward of a block, t_b = sum_l < G_l , im2col(x_l) V_l
+// + v_l > is one more product per convolution against the slice of v, then the weight sums with t_b - tbar as the k-scale
+// (several blocks: a second forward / backward pass, the mean needs every t first).
+static int cgen_sr_matvec(vmc_ctx* c, const float* v, int n_rows) {
+  const ConvGeom& g = c->cg;
+  ParamSet& p = c->ps[0];
+  PROPAGATE(cgen_grad_buffers(c));
+  if (!c->cg_td) { HIPCHK(c, dalloc(&c->cg_td, c->cg_rows)); HIPCHK(c, dalloc(&c->cg_centre, 1)); }
+  const int Fp = cgen_fp(g), lda = plan_cgen_lda(g);
+  const long long map_floats = c->cg_rows * g.N * Fp;
+  for (int l = 1; l < g.n_conv; ++l)
+    HIPCHK(c, launch_cgen_pack_t(c->stream, p.theta + cgen_off_w(g, l), g.K * g.KW, g.F, c->cg_wt + cgen_off_wt(g, l)));
+  auto fwd_bwd = [&](long long row0, int rows) -> int {
+    PROPAGATE(cgen_forward(c, VMC_PSI, c->sr_cfg, nullptr, rows, nullptr, nullptr, false, nullptr, c->cg_tape, map_floats, row0));
+    return cgen_backward(c, rows, row0, nullptr);
+  };
+  const bool one_block = n_rows <= c->cg_rows;
+  for (long long row0 = 0; row0 < n_rows; row0 += c->cg_rows) {
+    const int rows = (int)(n_rows - row0 < c->cg_rows ? n_rows - row0 : c->cg_rows);
+    PROPAGATE(fwd_bwd(row0, rows));
+    for (int l = 0; l < g.n_conv; ++l) {
+      PROPAGATE(cgen_gather_input(c, l, rows, row0, c->sr_cfg));
+      GemmArgs m; memset(&m, 0, sizeof(m));
+      m.A = c->cg_A; m.sam = lda; m.sak = 1;
+      m.B = v + cgen_off_w(g, l); m.sbk = g.F; m.sbn = 1;
+      m.M = rows * g.N; m.N = g.F; m.K = cgen_kdim(g, l); m.C = c->cg_g[0]; m.ldc = Fp;
+      m.bias = v + cgen_off_b(g, l); m.epilogue = 4; m.splitk = 1;
+      HIPCHK(c, launch_gemm(c->stream, m));
+      HIPCHK(c, launch_cgen_pairdot(c->stream, c->cg_g[0], cgen_gl(c, l), rows, g.N, g.F, Fp, c->cg_td, l == 0));
+    }
+    HIPCHK(c, launch_cgen_tstore(c->stream, c->cg_td, rows, c->sr_t + row0));
+  }
+  HIPCHK(c, launch_cgen_tmean(c->stream, c->sr_t, n_rows, c->cg_centre, c->sr_u + c->P));
+  for (long long row0 = 0; row0 < n_rows; row0 += c->cg_rows) {
+    const int rows = (int)(n_rows - row0 < c->cg_rows ? n_rows - row0 : c->cg_rows);
+    if (!one_block) PROPAGATE(fwd_bwd(row0, rows));
+    HIPCHK(c, launch_cgen_wpos_centred(c->stream, c->sr_t, c->cg_centre, row0, rows, g.N, c->cg_wpos));
+    for (int l = g.n_conv - 1; l >= 0; --l)
+      PROPAGATE(cgen_weight_sums(c, l, rows, row0, c->sr_cfg, cgen_gl(c, l), nullptr, c->sr_u));
   }
   return VMC_OK;
 }
@@ -1091,6 +1143,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
       const long long rounds = rows * cg.N / (128LL * c->num_cus);
       rows = rounds * 128LL * c->num_cus / cg.N;
     }
+    if (const char* e = getenv("CGS_VMC_CONV_GENERAL_BLOCK_ROWS")) { const long long r = atoll(e); if (r >= 1 && r < rows) rows = r; }   // tests: several blocks at small shapes
     c->cg_rows = rows;
     CA(dalloc(&c->cg_A, rows * cg.N * plan_cgen_lda(cg)));
     for (int i = 0; i < 2; ++i) CA(dalloc(&c->cg_fm[i], rows * cg.N * cgen_fp(cg)));
@@ -1149,6 +1202,8 @@ void vmc_destroy(vmc_ctx* c) {
   for (float* q : {c->cg_A, c->cg_fm[0], c->cg_fm[1], c->cg_zero, c->cg_lnew, c->cg_tape, c->cg_gl, c->cg_g[0], c->cg_g[1], c->cg_wpos,
                    c->cg_wt, c->cg_ws}) if (q) hipFree(q);
   if (c->cg_sum) hipFree(c->cg_sum);
+  if (c->cg_td) hipFree(c->cg_td);
+  if (c->cg_centre) hipFree(c->cg_centre);
   void* ptrs[] = {c->configs, c->configs_alt, c->bonds, c->half_jx, c->quarter_jz, c->cnt, c->off, c->diag, c->val,
                   c->offdiag, c->rowinfo, c->delta_all, c->d_batch[0][0], c->d_batch[0][1], c->d_batch[1][0], c->d_batch[1][1], c->ratio, c->ones, c->acc,
                   c->adam_m, c->adam_v, c->grad_tmp, c->gemm_ws, c->wg_tickets, c->d_accepted, c->d_sum,
@@ -1791,6 +1846,7 @@ static int sr_record(vmc_ctx* c) {
     return fail(c, VMC_ERR_STATE, "SR sample store full: vmc_sr_reserve fewer batches than accumulate calls");
   const long long B = c->B, N = c->N, Hp = c->Hp, L = c->A, k = c->sr_n, R = (long long)c->sr_cap * B;
   HIPCHK(c, hipMemcpyAsync(c->sr_cfg + k * B * N, c->configs, B * N * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  if (c->conv_general) { c->sr_n += 1; return VMC_OK; }     // (its matvec re-derives everything from the chains)
   if (c->conv) {   // the taped inputs of every convolution and d logit / d (their outputs) of this batch
     const long long CS = c->cg.CS, nc = c->cg.n_conv;
     if (nc > 1)
@@ -2224,11 +2280,19 @@ int vmc_sr_reserve(vmc_ctx* c, int32_t n_batches) {
   c->sr_cap = 0; c->sr_n = 0; c->sr_begun = false;
   if (n_batches == 0) return VMC_OK;
   const long long B = c->B, N = c->N, Hp = c->Hp, L = c->A, P = c->P, R = (long long)n_batches * B;
-  if (c->conv_general)
-    // (built and measured in round 5 -- only the chains stored, every CG iteration re-running the taped forward and the
-    // backward -- and withdrawn: its matvec met the 5e-4 bound of tests/test_gpu_sr.py but the solutions missed the 1 %
-    // bound on O_c x in the ill-conditioned cases; S v = <O (O.v)> - <O><O.v> wants sums that cancel as the fused kernels' do)
-    return fail(c, VMC_ERR_UNSUPPORTED, "the general convolution path (kernel_size > 9, num_conv_filters > 64 or feature maps beyond 160 KiB of LDS) has amplitudes, local energies, Monte-Carlo steps and the gradient accumulators; stochastic reconfiguration is not available on it");
+  if (c->conv_general) {       // the chains are all that is stored (cgen_sr_matvec; single-rank solves only)
+    if (R * N >= (1LL << 31)) return fail(c, VMC_ERR_UNSUPPORTED, "SR sample store too large (rows * sites >= 2^31)");
+    HIPCHK(c, dalloc(&c->sr_cfg, R * N));
+    HIPCHK(c, dalloc(&c->sr_t, R));
+    if (!c->sr_u) {
+      HIPCHK(c, dalloc(&c->sr_u, P + 1)); HIPCHK(c, dalloc(&c->sr_x, P)); HIPCHK(c, dalloc(&c->sr_r, P));
+      HIPCHK(c, dalloc(&c->sr_p, P)); HIPCHK(c, dalloc(&c->sr_q, P));
+      HIPCHK(c, dalloc(&c->sr_partial, 256)); HIPCHK(c, dalloc(&c->sr_sc, 4));
+      HIPCHK(c, hipMemsetAsync(c->sr_x, 0, P * sizeof(float), c->stream));
+    }
+    c->sr_cap = n_batches;
+    return VMC_OK;
+  }
   if (c->conv) {
     const ConvGeom& cg = c->cg;
     const long long CS = cg.CS, nc = cg.n_conv, nl = nc > 1 ? nc - 1 : 1;
@@ -2303,6 +2367,12 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
   const float* v = c->sr_p;
   Timer t(c, "sr_matvec");
   HIPCHK(c, hipMemsetAsync(c->sr_u, 0, (c->P + 1) * sizeof(float), c->stream));
+  if (c->conv_general) {
+    if (!c->sr_centre)
+      return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration on the general convolution path runs as a single-rank solve "
+                                          "(vmc_sr_solve): its matvec centres the per-sample weights, which sharded samples cannot do without a further all-reduce");
+    return cgen_sr_matvec(c, v, rows);
+  }
   if (c->conv) {
     // t_b = O_b . p: the CG direction packed like a parameter set, convolved with the taped inputs and
     // dotted with the stored deltas (k_conv_sr_rowdot); u = sum_b t_b O_b: the weight-gradient kernel
@@ -2416,6 +2486,7 @@ static int sr_solve_impl(vmc_ctx* c, void* comm, int world, float diag_shift, fl
   PROPAGATE(vmc_sr_begin(c, &rr0));
   rr = rr0;
   int it = 0;
+  c->sr_centre = !sharded(comm, world);          // (general convolution path: see cgen_sr_matvec)
   while (it < max_iter && rr > (double)tol * (double)tol * rr0 && rr0 > 0.0) {
     PROPAGATE(vmc_sr_matvec_partial(c));
     // sharded samples: u = sum_b (O_b . p) O_b and sum_b O_b . p over all ranks, in stream
@@ -2423,6 +2494,7 @@ static int sr_solve_impl(vmc_ctx* c, void* comm, int world, float diag_shift, fl
     PROPAGATE(vmc_sr_cg_update(c, diag_shift, &rr));
     ++it;
   }
+  c->sr_centre = false;
   if (iters) *iters = it;
   if (rel_residual) *rel_residual = rr0 > 0.0 ? sqrt(rr / rr0) : 0.0;
   return VMC_OK;
@@ -2463,7 +2535,9 @@ int vmc_sr_debug_matvec(vmc_ctx* c, const float* v, float diag_shift, float* out
   if (!v || !out) return fail(c, VMC_ERR_INVALID, "null");
   PROPAGATE(vmc_sr_begin(c, nullptr));
   HIPCHK(c, hipMemcpyAsync(c->sr_p, v, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  c->sr_centre = true;
   PROPAGATE(vmc_sr_matvec_partial(c));
+  c->sr_centre = false;
   HIPCHK(c, launch_sr_q(c->stream, c->sr_u, c->acc, (int)c->P, c->sr_p, diag_shift, c->sr_q, c->sr_partial, c->sr_sc));
   HIPCHK(c, hipMemcpyAsync(out, c->sr_q, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -365,8 +365,6 @@ def test_conv_error_behaviour():
     VmcEngine(15, 8, 2, 8, **kw)                          # size_x * size_y != num_sites
   eng = VmcEngine(16, 8, 2, 65, **kw)                     # more than 64 filters: the general path (conv_general.hip)
   assert eng.kernel_path() == 6
-  with pytest.raises(NotImplementedError):
-    eng.sr_reserve(2)                                     # ... which has no stochastic reconfiguration
   eng.close()
   with pytest.raises(NotImplementedError):
     VmcEngine(16, 8, 2, 1025, **kw)

@@ -3,8 +3,7 @@ through the C ABI: Conv2DNetwork / ResNet2D / Conv1DNetwork / ResNet1D (wavefunc
 layers.Conv*Periodic / ResBlock*, layers.py:24-293) at shapes the fused kernels refuse -- num_conv_filters > 64,
 kernel_size > 9, feature maps beyond 160 KiB of LDS; the reference takes any value (utils.py:107-111) -- and, forced
 with CGS_VMC_CONV_GENERAL=1, at shapes both paths take, where the two must agree.  Amplitudes, local energies,
-proposals, injected steps, trajectories and the gradient accumulators; stochastic reconfiguration (an extension)
-is refused on this path.
+proposals, injected steps, trajectories, the gradient accumulators and (single-rank) stochastic reconfiguration.
 Tolerances as tests/test_gpu_conv.py."""
 import numpy as np
 import pytest
@@ -177,14 +176,29 @@ def test_general_convolution_gradient_accumulators_at_fused_shapes(monkeypatch, 
   eng.close()
 
 
-def test_general_convolution_path_refuses_stochastic_reconfiguration():
-  """SR is an extension the reference does not have; on this path it was built, measured and withdrawn (vmc_sr_reserve
-  says why): the ctx must refuse it instead of returning steps that miss the parity bar."""
-  eng, theta, cfg, bonds, geom = _make('conv_2d', 4, 4, 2, 80, 3, 12, 'relu')
-  with pytest.raises(NotImplementedError) as e:
-    eng.sr_reserve(2)
-  assert 'general convolution path' in str(e.value)
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin,n_store,forced', [
+    ('conv_2d', 4, 4, 2, 8, 3, 16, 'relu', 2, True),          # shapes of tests/test_gpu_sr.py, forced onto this path
+    ('conv_2d', 4, 4, 2, 24, 3, 12, 'cos', 2, True),
+    ('res_net_2d', 4, 4, 2, 8, 3, 16, 'relu', 2, True),
+    ('conv_1d', 12, 1, 3, 12, 5, 14, 'sigmoid', 3, True),
+    ('conv_2d', 7, 7, 2, 8, 7, 10, 'relu', 2, True),
+    ('conv_2d', 4, 4, 2, 66, 1, 10, 'relu', 2, False),        # beyond the fused limits: 66 filters (1 x 1 taps: 4,554 parameters)
+    ('conv_1d', 12, 1, 2, 4, 11, 9, 'tanh', 2, False),        # ... an 11-tap kernel
+    ('res_net_1d', 14, 1, 1, 6, 10, 8, 'relu', 2, False),
+])
+def test_general_convolution_stochastic_reconfiguration(monkeypatch, ansatz, sx, sy, L, f, k, b, nonlin, n_store, forced):
+  """SR (an extension) on the general path, single-rank solves: only the chains are stored, every CG iteration re-runs
+  the taped forward and the backward of the stored chains, the per-sample weights are centred.  The checks are
+  tests/test_gpu_sr.py's, at its bounds (explicit S from the oracle's per-sample gradients, matvec, solution through its
+  fp64 residual and through O_c x)."""
+  from tests.test_gpu_sr import test_sr_convolutional_matvec_and_solution as check
+  if forced:
+    monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')
+  from cgs_vmc_amd.engine import VmcEngine
+  eng = VmcEngine(sx * sy, b, L, f, nonlinearity=nonlin, ansatz=ansatz, kernel_size=k, size_x=sx, size_y=sy)
+  assert eng.kernel_path() == 6
   eng.close()
+  check(ansatz, sx, sy, L, f, k, b, nonlin, n_store)
 
 
 def test_general_convolution_through_run_training_and_evaluation(tmp_path):
@@ -352,3 +366,21 @@ def test_general_convolution_random_shapes(ansatz, sx, sy, L, f, k, b, nonlin):
   band = np.abs(ratios - np.sqrt(u_acc.astype(np.float64))) < 1e-4 * np.maximum(ratios, 1e-30)
   assert np.array_equal(mask[~band], acc_ref[~band])
   eng.close()
+
+
+@pytest.mark.parametrize('block_rows', [5, 16])
+def test_general_convolution_in_several_blocks(monkeypatch, block_rows):
+  """The block loops of the path -- row configurations are processed cg_rows at a time (sized for 768 MB of im2col rows:
+  never more than one block at test sizes) -- forced to 5 / 16 rows per block: local energies over ragged last blocks, the
+  gradient sums block by block, the two-pass SR matvec (the mean of O_b . v needs every block's t first)."""
+  from tests.test_gpu_sr import test_sr_convolutional_matvec_and_solution as check_sr
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL_BLOCK_ROWS', str(block_rows))
+  for shape in (('conv_2d', 4, 4, 2, 80, 3, 12, 'relu'), ('res_net_2d', 4, 6, 1, 72, 3, 9, 'relu'), ('conv_1d', 26, 1, 2, 10, 12, 8, 'tanh')):
+    eng, theta, cfg, bonds, geom = _make(*shape)
+    assert eng.kernel_path() == 6
+    _check_forward_and_sampler(eng, theta, cfg, bonds, geom, shape[0], shape[3], shape[7], shape[6], steps=3)
+    eng.set_configs(cfg)
+    _check_gradients(eng, theta, cfg, bonds, geom, shape[0], shape[3], shape[7], shape[6])
+    eng.close()
+  check_sr('conv_2d', 4, 4, 2, 66, 1, 10, 'relu', 2)
+  check_sr('conv_1d', 12, 1, 2, 4, 11, 9, 'tanh', 2)
