@@ -384,3 +384,23 @@ def test_general_convolution_in_several_blocks(monkeypatch, block_rows):
     eng.close()
   check_sr('conv_2d', 4, 4, 2, 66, 1, 10, 'relu', 2)
   check_sr('conv_1d', 12, 1, 2, 4, 11, 9, 'tanh', 2)
+
+
+def test_general_convolution_stochastic_reconfiguration_through_run_training(tmp_path):
+  """--optimizer StochasticReconfiguration (the extension's CLI name) with an 11-tap conv_1d network, i.e. on the general
+  path, one rank: 16-site chain, E0 = -7.1423; SR descends much faster per epoch than Adam on the plain gradient."""
+  import os
+  from cgs_vmc_amd import run_training, session as session_lib, wavefunctions
+  session_lib.reset_default_graph()
+  wavefunctions.reset_name_scope()
+  os.environ.update(CGS_VMC_SEED='77', CGS_VMC_CONFIG_SEED='5', CGS_VMC_INIT_SEED='31')
+  d = str(tmp_path)
+  hp = ('batch_size=256,num_conv_layers=2,num_conv_filters=8,kernel_size=11,num_equilibration_sweeps=10,'
+        'num_batches_per_epoch=8,learning_rates=[0.05,0.02],learning_rate_stops=[30],'
+        'sr_diag_shift=0.01,sr_cg_tolerance=0.001,sr_cg_max_iterations=200')
+  run_training.main(['--checkpoint_dir', d, '--num_sites', '16', '--heisenberg_jx', '-1.0',
+                     '--wavefunction_type', 'conv_1d', '--optimizer', 'StochasticReconfiguration',
+                     '--num_epochs', '40', '--hparams', hp])
+  energies = [float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()]
+  tail = np.mean(energies[-5:])
+  assert -7.1423 - 0.05 < tail < -6.5, (tail, energies[::5])
