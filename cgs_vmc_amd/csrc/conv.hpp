@@ -151,5 +151,6 @@ hipError_t launch_cgen_pack_t(hipStream_t s, const float* w, int T, int F, float
 hipError_t launch_cgen_pairdot(hipStream_t s, const float* y, const float* gm, int rows, int N, int F, int Fp, double* t, bool first);
 hipError_t launch_cgen_tstore(hipStream_t s, const double* td, int rows, float* t);
 hipError_t launch_cgen_tmean(hipStream_t s, const float* t, int n, float* centre, float* usum);
+hipError_t launch_cgen_tcentre_global(hipStream_t s, const float* t, int n, const float* count, float* centre, float* usum);
 hipError_t launch_cgen_wpos_centred(hipStream_t s, const float* t, const float* centre, long long row0, int rows, int N, float* wpos);
 inline long long cgen_off_wt(const ConvGeom& g, int l) { return (long long)(l - 1) * g.K * g.KW * g.F * g.F; }   // l >= 1

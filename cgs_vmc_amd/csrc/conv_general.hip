@@ -236,6 +236,22 @@ __global__ __launch_bounds__(1024) void k_cgen_tmean(const float* __restrict__ t
   }
 }
 
+// sharded solve: centre[0] = (sum of t over ALL ranks) / (samples of all ranks); usum[0] <- this rank's sum_b (t_b - c)
+__global__ __launch_bounds__(1024) void k_cgen_tcentre_global(const float* __restrict__ t, int n, const float* __restrict__ count,
+                                                              float* __restrict__ centre, float* __restrict__ usum) {
+  __shared__ double s[1024];
+  const float c = usum[0] / count[0];               // usum holds the all-reduced sum of t on entry
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) a += (double)t[i] - (double)c;
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int d = 512; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { centre[0] = c; usum[0] = (float)s[0]; }
+}
+
 // per-position weights t_b - c
 __global__ void k_cgen_wpos_centred(const float* __restrict__ t, const float* __restrict__ centre, long long row0, int rows,
                                     int N, float* __restrict__ wpos) {
@@ -327,5 +343,10 @@ hipError_t launch_cgen_wpos_centred(hipStream_t s, const float* t, const float* 
                                     float* wpos) {
   if (rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_cgen_wpos_centred, dim3(cg_blocks((long long)rows * N)), dim3(256), 0, s, t, centre, row0, rows, N, wpos);
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_tcentre_global(hipStream_t s, const float* t, int n, const float* count, float* centre, float* usum) {
+  hipLaunchKernelGGL(k_cgen_tcentre_global, dim3(1), dim3(1024), 0, s, t, n, count, centre, usum);
   return hipGetLastError();
 }

@@ -597,31 +597,31 @@ static int cgen_gradient_sums(vmc_ctx* c, const float* w) {
   return VMC_OK;
 }
 
-// SR matvec of the general path over the `n_rows` stored chains (sr_cfg), SINGLE RANK: u = sum_b (t_b - tbar) O_b with
-// t_b = O_b . v, u[P] = sum_b (t_b - tbar) (~ 0).  k_sr_q forms q = u / n - <O> u[P] / n + lambda p, which is S v + lambda v
-// for ANY constant subtracted from every t_b -- and with the mean subtracted the cancellation of <O (O.v)> - <O><O.v> happens
-// per sample, before the fp32 sums (the uncentred form of this matvec met the 5e-4 bound on S v but its solutions missed
-// the 1 % bound on O_c x; the constant would have to be the same on every rank: hence one rank).  Only the chains are
-// stored: every CG iteration re-runs the taped forward and the backward of a block, t_b = sum_l < G_l , im2col(x_l) V_l
-// + v_l > is one more product per convolution against the slice of v, then the weight sums with t_b - tbar as the k-scale
-// (several blocks: a second forward / backward pass, the mean needs every t first).
-static int cgen_sr_matvec(vmc_ctx* c, const float* v, int n_rows) {
+// SR matvec of the general path over the `n_rows` stored chains (sr_cfg): u = sum_b (t_b - c) O_b with t_b = O_b . v,
+// u[P] = sum_b (t_b - c).  k_sr_q forms q = u / n - <O> u[P] / n + lambda p, which is S v + lambda v for ANY constant c
+// subtracted from every t_b -- and with c = the mean of t the cancellation of <O (O.v)> - <O><O.v> happens per sample,
+// before the fp32 sums (the uncentred form of this matvec met the 5e-4 bound on S v but its solutions missed the 1 %
+// bound on O_c x).  The constant must be the same on every rank: a sharded solve all-reduces sum_b t_b between the two
+// phases (sr_solve_impl), a single rank takes its own mean.  Only the chains are stored: every CG iteration re-runs the
+// taped forward and the backward of a block; t_b = sum_l < G_l , im2col(x_l) V_l + v_l > is one more product per
+// convolution against the slice of v (phase 1), then the weight sums with t_b - c as the k-scale (phase 2; several
+// blocks: a second forward / backward pass, the mean needs every t first).
+static int cgen_sr_fwd_bwd(vmc_ctx* c, long long row0, int rows) {
+  const long long map_floats = c->cg_rows * c->cg.N * cgen_fp(c->cg);
+  PROPAGATE(cgen_forward(c, VMC_PSI, c->sr_cfg, nullptr, rows, nullptr, nullptr, false, nullptr, c->cg_tape, map_floats, row0));
+  return cgen_backward(c, rows, row0, nullptr);
+}
+static int cgen_sr_phase1(vmc_ctx* c, const float* v, int n_rows) {        // sr_t[b] = O_b . v
   const ConvGeom& g = c->cg;
   ParamSet& p = c->ps[0];
   PROPAGATE(cgen_grad_buffers(c));
   if (!c->cg_td) { HIPCHK(c, dalloc(&c->cg_td, c->cg_rows)); HIPCHK(c, dalloc(&c->cg_centre, 1)); }
   const int Fp = cgen_fp(g), lda = plan_cgen_lda(g);
-  const long long map_floats = c->cg_rows * g.N * Fp;
   for (int l = 1; l < g.n_conv; ++l)
     HIPCHK(c, launch_cgen_pack_t(c->stream, p.theta + cgen_off_w(g, l), g.K * g.KW, g.F, c->cg_wt + cgen_off_wt(g, l)));
-  auto fwd_bwd = [&](long long row0, int rows) -> int {
-    PROPAGATE(cgen_forward(c, VMC_PSI, c->sr_cfg, nullptr, rows, nullptr, nullptr, false, nullptr, c->cg_tape, map_floats, row0));
-    return cgen_backward(c, rows, row0, nullptr);
-  };
-  const bool one_block = n_rows <= c->cg_rows;
   for (long long row0 = 0; row0 < n_rows; row0 += c->cg_rows) {
     const int rows = (int)(n_rows - row0 < c->cg_rows ? n_rows - row0 : c->cg_rows);
-    PROPAGATE(fwd_bwd(row0, rows));
+    PROPAGATE(cgen_sr_fwd_bwd(c, row0, rows));
     for (int l = 0; l < g.n_conv; ++l) {
       PROPAGATE(cgen_gather_input(c, l, rows, row0, c->sr_cfg));
       GemmArgs m; memset(&m, 0, sizeof(m));
@@ -634,15 +634,25 @@ static int cgen_sr_matvec(vmc_ctx* c, const float* v, int n_rows) {
     }
     HIPCHK(c, launch_cgen_tstore(c->stream, c->cg_td, rows, c->sr_t + row0));
   }
-  HIPCHK(c, launch_cgen_tmean(c->stream, c->sr_t, n_rows, c->cg_centre, c->sr_u + c->P));
+  return VMC_OK;
+}
+static int cgen_sr_phase2(vmc_ctx* c, int n_rows) {                         // sr_u[0 .. P) += sum_b (t_b - *cg_centre) O_b
+  const ConvGeom& g = c->cg;
+  const bool one_block = n_rows <= c->cg_rows;       // (then the tapes and G_l of phase 1 are still in place)
   for (long long row0 = 0; row0 < n_rows; row0 += c->cg_rows) {
     const int rows = (int)(n_rows - row0 < c->cg_rows ? n_rows - row0 : c->cg_rows);
-    if (!one_block) PROPAGATE(fwd_bwd(row0, rows));
+    if (!one_block) PROPAGATE(cgen_sr_fwd_bwd(c, row0, rows));
     HIPCHK(c, launch_cgen_wpos_centred(c->stream, c->sr_t, c->cg_centre, row0, rows, g.N, c->cg_wpos));
     for (int l = g.n_conv - 1; l >= 0; --l)
       PROPAGATE(cgen_weight_sums(c, l, rows, row0, c->sr_cfg, cgen_gl(c, l), nullptr, c->sr_u));
   }
   return VMC_OK;
+}
+// one rank
+static int cgen_sr_matvec(vmc_ctx* c, const float* v, int n_rows) {
+  PROPAGATE(cgen_sr_phase1(c, v, n_rows));
+  HIPCHK(c, launch_cgen_tmean(c->stream, c->sr_t, n_rows, c->cg_centre, c->sr_u + c->P));
+  return cgen_sr_phase2(c, n_rows);
 }
 
 int conv_rows(vmc_ctx* c, int which, const float* configs, const int2* rowinfo, int rows,
@@ -2369,8 +2379,9 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
   HIPCHK(c, hipMemsetAsync(c->sr_u, 0, (c->P + 1) * sizeof(float), c->stream));
   if (c->conv_general) {
     if (!c->sr_centre)
-      return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration on the general convolution path runs as a single-rank solve "
-                                          "(vmc_sr_solve): its matvec centres the per-sample weights, which sharded samples cannot do without a further all-reduce");
+      return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration on the general convolution path runs through vmc_sr_solve / "
+                                          "vmc_sr_solve_dist: its matvec centres the per-sample weights on the mean over all ranks, which the op-by-op "
+                                          "vmc_sr_matvec_partial cannot know");
     return cgen_sr_matvec(c, v, rows);
   }
   if (c->conv) {
@@ -2488,6 +2499,17 @@ static int sr_solve_impl(vmc_ctx* c, void* comm, int world, float diag_shift, fl
   int it = 0;
   c->sr_centre = !sharded(comm, world);          // (general convolution path: see cgen_sr_matvec)
   while (it < max_iter && rr > (double)tol * (double)tol * rr0 && rr0 > 0.0) {
+    if (c->conv_general && sharded(comm, world)) {
+      // the general convolution path centres its weights on the mean of O_b . p over ALL ranks (cgen_sr_matvec): one more
+      // all-reduce, of sum_b O_b . p alone, between its two phases
+      const int rows = c->sr_n * c->B;
+      HIPCHK(c, hipMemsetAsync(c->sr_u, 0, (c->P + 1) * sizeof(float), c->stream));
+      PROPAGATE(cgen_sr_phase1(c, c->sr_p, rows));
+      HIPCHK(c, launch_sr_tsum(c->stream, c->sr_t, rows, c->sr_u + c->P));
+      PROPAGATE(reduce_buffer(c, comm, world, c->sr_u + c->P, 1, VMC_REDUCE_SUM));
+      HIPCHK(c, launch_cgen_tcentre_global(c->stream, c->sr_t, rows, c->acc + 2 * c->P + 1, c->cg_centre, c->sr_u + c->P));
+      PROPAGATE(cgen_sr_phase2(c, rows));
+    } else
     PROPAGATE(vmc_sr_matvec_partial(c));
     // sharded samples: u = sum_b (O_b . p) O_b and sum_b O_b . p over all ranks, in stream
     if (sharded(comm, world)) PROPAGATE(reduce_buffer(c, comm, world, c->sr_u, c->P + 1, VMC_REDUCE_SUM));

@@ -76,7 +76,7 @@ typedef struct {
                                 (materialised rows + GEMMs; two [131072][units] float
                                 buffers per ctx: 4 GiB at 4096 units).  Convolutional ansatz types:
                                 num_conv_filters (111): the fused kernels up to 64 (four 16-channel MFMA
-                                blocks), the general path (feature maps in HBM, a GEMM per convolution; SR on one rank only) to 1024 */
+                                blocks), the general path (feature maps in HBM, a GEMM per convolution) to 1024 */
   int32_t nonlinearity;      /* VMC_ACT_*: hparams.nonlinearity  (utils.py:128)      */
   int32_t output_activation; /* VMC_ACT_*: hparams.output_activation (utils.py:129)  */
   int32_t device;            /* HIP device ordinal                                   */

@@ -154,9 +154,11 @@ def test_sr_training_lowers_energy():
   eng.close()
 
 
-def test_sharded_sr_two_ranks_one_gpu():
+@pytest.mark.parametrize('case', ['dense', 'conv_general'])
+def test_sharded_sr_two_ranks_one_gpu(case):
   """parallel.sr_solve with the chains split over two ranks (gloo, both on this GPU): the
-  all-reduced matrix-free CG reaches the dense fp64 solution over all samples."""
+  all-reduced matrix-free CG reaches the dense fp64 solution over all samples.  conv_general: an 11-tap conv_1d
+  network on the general convolution path, whose matvec all-reduces sum_b O_b . p between its two phases."""
   import os
   import socket
   import subprocess
@@ -166,7 +168,7 @@ def test_sharded_sr_two_ranks_one_gpu():
   procs = []
   for rank in range(2):
     env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2',
-               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CGS_VMC_DIST_BACKEND='gloo')
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CGS_VMC_DIST_BACKEND='gloo', CGS_SR_WORKER_CASE=case)
     procs.append(subprocess.Popen([sys.executable, os.path.join(root, 'tests', '_sr_gpu_worker.py')],
                                   env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
   outs = [p.communicate(timeout=600)[0].decode() for p in procs]
