@@ -2,15 +2,18 @@
 // in LDS: kernel_size <= 9, num_conv_filters <= 64, two maps within 160 KiB): the general path.  The reference takes
 // any value (wavefunctions.py:534-579, utils.py:107-111).  Feature maps live in HBM, channel-last
 // [row][site][Fp] (Fp = filters padded to 4); one Conv2dPeriodic / Conv1dPeriodic (layers.py:24-160) is
-//   * an im2col gather  A[(row, site)][(tap, c)] = f(in[row][(site + tap - lo) mod lattice][c])  -- the periodic
-//     padding of layers.py:118-148 / 51-74 is the index arithmetic, the hidden activation (selu in the residual
-//     blocks, layers.py:226) is applied as the operand is gathered, so every stored map is a PRE-activation --
+//   * a gather  A[(row, site)][(tap, c)] = in[row][(site + tap - lo) mod lattice][c]  -- the periodic padding of
+//     layers.py:118-148 / 51-74 is the index arithmetic -- either written out as an im2col matrix (k_cgen_im2col) or, for
+//     64 .. filters in multiples of 32, performed by the ring GEMM's A-operand DMA itself (GemmArgs.conv_a, grad.hip);
+//     the stored maps hold ACTIVATIONS (f(z_l) behind a convolution, selu(u) inside a residual block, layers.py:226), so
+//     that nothing has to be applied on the way; only the cosine, whose derivative needs z, keeps pre-activations and
+//     has f applied as k_cgen_im2col gathers --
 //   * ONE product with the parameter slice as it lies in theta: snt.Conv2D's w[k, k, Cin, F] IS the row-major
-//     [k k Cin][F] B matrix (launch_gemm: k_gemm_ring / k_gemm128 / k_gemm by shape), bias in the epilogue, the
-//     residual add of ResBlock2d (layers.py:227) as the accumulate-into-C epilogue.
+//     [k k Cin][F] B matrix (launch_gemm: k_gemm_ring / k_gemm128 / k_gemm by shape), bias and activation in the
+//     epilogue, the residual add of ResBlock2d (layers.py:227) as the accumulate-into-C epilogue.
 // The first convolution gathers from the spins themselves, with the exchanged pair of a connected configuration
 // (operators.py:162-163) or of a proposed move (graph_builders.py:67-71) negated on the fly.  The logit is the sum of
-// the last map (wavefunctions.py:569, 577; 760, 773) in double, one wave per row.
+// the last map (wavefunctions.py:569, 577; 760, 773) in double, one workgroup per row.
 // Same arithmetic as the fused kernels up to the order of additions; same Philox streams, same accept rule.
 #include "conv.hpp"
 
@@ -157,7 +160,7 @@ __global__ void k_cgen_fill(float* __restrict__ gm, const float* __restrict__ os
   }
 }
 
-// out = d (.) f'(z)  (d / d pre-activation from d / d activation); padding channels 0
+// out = d (.) f'  (d / d pre-activation from d / d activation; f' off the stored z or off the stored activation); padding channels 0
 // from_act: the map holds a = f(z) (cgen_post): f' read off the activation (selu: off t = selu(u))
 __device__ __forceinline__ float cg_dpre_from_act(int pre, float a) {
   if (pre < 0) return 1.f;

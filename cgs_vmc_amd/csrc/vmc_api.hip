@@ -73,11 +73,11 @@ struct vmc_ctx {
   bool conv_general = false;
   long long cg_rows = 0;                   // row configurations per block
   float* cg_A = nullptr;                   // im2col rows [cg_rows * N][plan_cgen_lda]
-  float* cg_fm[2] = {nullptr, nullptr};    // feature maps [cg_rows][N][Fp] (pre-activations)
+  float* cg_fm[2] = {nullptr, nullptr};    // feature maps [cg_rows][N][Fp] (cgen_post: activations; the cosine: pre-activations)
   double* cg_sum = nullptr;                // [cg_rows] sums of the last map
   float* cg_zero = nullptr;                // one 0.f (the "b_out" of wide_out_finish)
   float* cg_lnew = nullptr;                // [B] candidate logits of the sampler
-  // ... its gradient path (allocated by the first gradient call): the pre-activation of every convolution, two
+  // ... its gradient path (allocated by the first gradient call): the map of every convolution (the tape), two
   // d logit / d map buffers, per-position weights, the transposed weight images, the split-K workspace
   float* cg_tape = nullptr; float* cg_gl = nullptr; float* cg_g[2] = {nullptr, nullptr}; float* cg_wpos = nullptr; float* cg_wt = nullptr;
   float* cg_ws = nullptr; long long cg_ws_floats = 0;
@@ -381,7 +381,7 @@ ConvParams conv_params(const ParamSet& p) { return ConvParams{p.cw0, p.cwf, p.cw
 // the rows of a row list over `configs`: logits (ratio == false) or 0.5 jx psi'/psi of the
 // bond-exchanged configurations.  with_tape: the inputs of every convolution go to c->ctape.
 // The same on the general path (conv_general.hip): blocks of cg_rows row configurations; per convolution an im2col
-// gather (the hidden activation applied as the operand is gathered: every stored map is a pre-activation) and one
+// gather (explicit, or inside the product's A operand; what the maps hold: cgen_post below) and one
 // GEMM against the parameter slice in theta; ResBlock2d's `v + h` (layers.py:227) is the accumulate epilogue.
 // iup / idn != nullptr: row r is chain r with that pair exchanged (the sampler's candidates).
 int ensure_cache(vmc_ctx* c, int which);
@@ -572,7 +572,7 @@ static int cgen_weight_sums(vmc_ctx* c, int l, int rows, long long row0, const f
 }
 
 // Gradient sums of the general path: g1 += sum_b O_b, g2 += sum_b w_b O_b (training.py:545-547), a block of chains at a
-// time: taped forward (the pre-activation of every convolution), d logit / d z_l of every convolution, then
+// time: taped forward (the map of every convolution), d logit / d z_l of every convolution, then
 // d / d W_l = im2col(x_l)^T G_l with the bias as an implicit row of ones, one product per convolution for both sums.
 static int cgen_gradient_sums(vmc_ctx* c, const float* w) {
   const ConvGeom& g = c->cg;
