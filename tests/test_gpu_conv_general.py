@@ -22,7 +22,7 @@ GENERAL_SHAPES = [
     ('conv_2d', 10, 10, 2, 8, 11, 7, 'relu'),       # kernel_size > 9
     ('conv_2d', 12, 12, 2, 6, 10, 5, 'sigmoid'),    # ... even: k/2 - 1 in front, k/2 behind
     ('conv_2d', 20, 20, 2, 64, 3, 4, 'relu'),       # two maps of 102 KB: beyond the LDS of the fused kernels
-    ('conv_2d', 40, 40, 3, 16, 5, 3, 'cos'),       # 1,600 sites at 16 filters: two maps of 102 KB
+    ('conv_2d', 36, 36, 3, 16, 5, 2, 'cos'),       # 1,296 sites at 16 filters: two maps of 83 KB (beyond the 160 KiB with the rest)
     ('res_net_2d', 4, 4, 2, 96, 3, 8, 'relu'),
     ('res_net_2d', 8, 8, 1, 12, 10, 6, 'relu'),
     ('res_net_2d', 4, 6, 0, 70, 3, 5, 'relu'),      # no block: the initial convolution alone
