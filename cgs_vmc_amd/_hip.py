@@ -135,6 +135,7 @@ SIGNATURES = {
     'vmc_timing_get': (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'vmc_last_connected_rows': (C.c_int, [_ctx, C.POINTER(C.c_int64)]),
     'vmc_debug_kernel_path': (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
+    'vmc_debug_sweep_tile': (C.c_int, [_ctx, C.c_int32, C.POINTER(C.c_int32)]),
     'vmc_synchronize': (C.c_int, [_ctx]),
     'vmc_debug_gemm': (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int64, C.c_int64,
                                  C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp]),
@@ -144,7 +145,7 @@ _lib = None
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 _STAMP_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libcgsvmc_hip.stamp')
 # the files the library is built from, in the order csrc/Makefile hashes them
-_SOURCES = ('vmc_api.hip', 'mlp.hip', 'eloc.hip', 'grad.hip', 'sr.hip', 'srmm.hip', 'conv.hip', 'conv32.hip', 'conv48.hip', 'conv64.hip', 'conv_general.hip', 'wide.hip', 'tail_split.hip', 'sweep_split.hip', 'act_tail.hip',
+_SOURCES = ('vmc_api.hip', 'mlp.hip', 'eloc.hip', 'grad.hip', 'sr.hip', 'srmm.hip', 'conv.hip', 'conv32.hip', 'conv48.hip', 'conv64.hip', 'conv_general.hip', 'wide.hip', 'tail_split.hip', 'sweep_split.hip', 'sweep8.hip', 'act_tail.hip',
             'act_sweep.hip', 'plan.hpp', 'common.hpp', 'tail16.hpp', 'tail_lds.hpp', 'sweep16.hpp', 'conv.hpp', 'conv_kernels.hpp',
             'conv_wide.hpp',
             os.path.join('..', '..', 'include', 'cgsvmc.h'), 'Makefile')

@@ -91,13 +91,26 @@ __device__ __forceinline__ float vmc_logcosh(float z) {
 
 // The relu below is an inline-asm v_max_f32, and the compiler's hazard recogniser does not look inside an asm
 // statement: where it reads an MFMA result directly -- no compiler-visible instruction (a copy out of an AGPR, an
-// add) in between -- no wait states are inserted and it sees the accumulator before the last MFMAs have written it
-// (round 5: the split sampler lost the last k-step of a layer in 4 .. 8 of 16 output rows that way; the fp32 kernels
-// happen to have such an instruction in between).  vmc_mfma_settle stands between the last MFMA of a chain and
-// such a reader: the accumulators pass through it (so it follows the MFMAs and precedes the readers) and it holds
-// the 16 wait states itself -- issued while the last MFMA still occupies the matrix pipe.
+// add) in between -- no wait states are inserted and it may see the accumulator before the last MFMAs have written
+// it (round 5: the split sampler lost the last k-step of a layer in 4 .. 8 of 16 output rows that way).  The fp32
+// samplers had the same shape of code behind v_mfma_f32_16x16x4_f32 chains (tools/check_mfma_read_hazard.py: 200
+// sites, up to all 10 wait states of LLVM's table missing) and passed every parity test, i.e. rested on an
+// interlock nothing documents; since round 6 they settle too and the checker is strict for every MFMA form.
+// vmc_mfma_settle* stand between the last MFMA of a chain and such a reader: EVERY accumulator the reader touches
+// passes through the statement (so it follows the MFMAs and precedes the readers; an accumulator left out could
+// have its last MFMAs scheduled behind the wait) and it holds the wait states itself -- issued while the last MFMA
+// still occupies the matrix pipe.  16 wait states cover every form used here (LLVM's table: 10 for the f32
+// 16x16x4 form, 7 for bf16 16x16x32, 4 for f32 4x4x1).
 __device__ __forceinline__ void vmc_mfma_settle(f32x4& a, f32x4& b) {
   asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b));
+}
+template <int N>
+__device__ __forceinline__ void vmc_mfma_settle_all(f32x4 (&acc)[N]) {
+  static_assert(N >= 1 && N <= 4, "one asm operand per accumulator");
+  if constexpr (N == 1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]));
+  if constexpr (N == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+  if constexpr (N == 3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]));
+  if constexpr (N == 4) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 }
 
 template <int ACT>
@@ -262,6 +275,9 @@ hipError_t launch_onsite(hipStream_t s, const float* configs, const float* won, 
                          float* out);
 hipError_t launch_iota_rows(hipStream_t s, int2* dst, int n);
 hipError_t launch_sweep16(hipStream_t s, const SweepArgs& a, int Hp);
+// eight chains per workgroup (sweep8.hip): fully_connected + relu, plain launches, the shapes of plan_sweep8; the
+// same chains as launch_sweep16, bit for bit
+hipError_t launch_sweep8(hipStream_t s, const SweepArgs& a, int Hp);
 // EXPERIMENT: the sampler with its H x H layers as 3 x bf16 split products (sweep_split.hip); false: shape not covered
 bool sweep16_split_supported(int N, int Hp, int n_hidden);
 hipError_t launch_sweep16_split(hipStream_t s, const SweepArgs& a);

@@ -267,6 +267,40 @@ inline SweepPlan plan_sweep(int N, int NT, int NW, int n_hidden, bool rbm, bool 
   return p;
 }
 
+// k_sweep8 (sweep8.hip): eight chains per workgroup on the 4x4x1 MFMA shape, bit-identical chains to k_sweep16.
+// fully_connected + relu, 128 or 256 padded units (one wave per 32 units), at least one H x H layer, one Philox site
+// block per lane of a chain's group (8 * Hp / 32 lanes): n_sites <= Hp.  LDS: spins [8][Nst], two operand buffers
+// [8][Hp + 16], three [8] int arrays, w_out, the biases of the H x H layers, [W1 when it fits].
+struct Sweep8Plan {
+  int ok;
+  int w1l;
+  size_t lds;
+};
+inline size_t plan_sweep8_lds_bytes(int N, int Hp, int n_hidden, bool w1l) {
+  const size_t Nst = (size_t)((N + 3) & ~3);
+  return sizeof(float) * (8 * Nst + 2 * 8 * ((size_t)Hp + 16) + 24 + (size_t)Hp + (size_t)n_hidden * Hp +
+                          (w1l ? (size_t)N * ((size_t)Hp + 4) : 0));
+}
+inline Sweep8Plan plan_sweep8(int N, int Hp, int n_hidden, bool no_w1l) {
+  Sweep8Plan p;
+  memset(&p, 0, sizeof(p));
+  if ((Hp != 128 && Hp != 256) || n_hidden < 1 || N < 2 || N > Hp || N > 256) return p;
+  const size_t full = plan_sweep8_lds_bytes(N, Hp, n_hidden, true);
+  const bool w1l = !no_w1l && full <= PLAN_LDS_PER_CU;
+  const size_t lds = w1l ? full : plan_sweep8_lds_bytes(N, Hp, n_hidden, false);
+  if (lds > PLAN_LDS_PER_CU) return p;
+  p.ok = 1; p.w1l = w1l ? 1 : 0; p.lds = lds;
+  return p;
+}
+// Chains per sampler workgroup: 8 when the shape has a k_sweep8 and sixteen-chain tiles would leave at least half of
+// the CUs without one (graph_builders.py:57-88: the batch is the only parallel axis); forced: CGS_VMC_SWEEP_TILE
+// (0 = this rule, 8, 16; 8 is honoured where a k_sweep8 exists).
+inline int plan_sweep_tile(long long B, int num_cus, bool sweep8_ok, int forced) {
+  if (!sweep8_ok || forced == 16) return 16;
+  if (forced == 8) return 8;
+  return (B + 15) / 16 <= num_cus / 2 ? 8 : 16;
+}
+
 // 384 or 512 padded units and at least one H x H layer; LDS of k_tail_lds: two operand buffers
 // [2 halves][NT][64][4], partial dots, row meta, biases, w_out
 inline size_t plan_tail_lds_bytes(int Hp, int n_hidden) {

@@ -749,6 +749,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
       }
       if (FIRST && FS == 0) { pin_draw(); finish_draw(cs, next_step); }
       SWEEP_STAMP(FS > 0 ? 10 : 13)
+      if (ACT == VMC_ACT_RELU_) vmc_mfma_settle_all(acc);   // the asm relu reads the accumulators (common.hpp)
       float* xout = s_x + (cur ^ 1) * NT * 256;
 #pragma unroll
       for (int to = 0; to < TO; ++to) {
@@ -793,7 +794,7 @@ __device__ __forceinline__ void sweep16_body(const SweepArgs& a) {
         SW_PRODUCT(l, xh) SW_PRODUCT(h, xl) SW_PRODUCT(m, xm) SW_PRODUCT(m, xh) SW_PRODUCT(h, xm) SW_PRODUCT(h, xh)
 #undef SW_PRODUCT
       }
-      vmc_mfma_settle(acc[0], acc[TO - 1]);      // the relu reads the accumulators through inline asm (common.hpp)
+      vmc_mfma_settle_all(acc);                  // the relu reads the accumulators through inline asm (common.hpp)
 #pragma unroll
       for (int to = 0; to < TO; ++to) finish_own(to, acc[to], l + 1 == n_hidden);
       if (l + 1 < n_hidden) sw_publish(s_x + (cur ^ 1) * XB);

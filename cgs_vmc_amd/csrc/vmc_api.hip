@@ -153,6 +153,8 @@ struct vmc_ctx {
   int num_cus = 256;
   int sweep_waves = 8;       // waves per sweep workgroup at Hp = 256 (CGS_VMC_SWEEP_WAVES=4|8)
   int sweep_no_w1l = 0;      // CGS_VMC_SWEEP_W1L=0: W1 stays in L2 (smaller LDS footprint)
+  int sweep_tile = 16;       // chains per sampler workgroup: 16 (k_sweep16) or 8 (k_sweep8; plan_sweep_tile)
+  bool sweep8_ok = false;    // the shape has a k_sweep8
   // stochastic reconfiguration (extension, sr.hip): sample store + CG vectors
   int sr_cap = 0, sr_n = 0, sr_iter = 0;
   float *sr_cfg = nullptr, *sr_act = nullptr, *sr_delta = nullptr;   // [cap B][N], [L][cap B][Hp] x2
@@ -239,7 +241,7 @@ struct DeviceGuard {
   do { int rc_ = (expr); if (rc_ != VMC_OK) return rc_; } while (0)
 
 // CUs a sampler launch occupies (8 waves at 255 registers, or LDS, fill a CU per workgroup)
-int sweep_cus(const vmc_ctx* c) { return (c->B + 15) / 16; }
+int sweep_cus(const vmc_ctx* c) { return c->sweep_tile == 8 ? (c->B + 7) / 8 : (c->B + 15) / 16; }
 
 // The sampler may overtake the accumulate enqueued just before it when it leaves the local-energy
 // kernel at least a quarter of the CUs; with one 16-chain tile per CU (config 3) there is nothing
@@ -1059,6 +1061,14 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0)
       c->num_cus = prop.multiProcessorCount;
   }
+  // eight-chain sampler tiles where sixteen-chain tiles would leave half of the chip idle (sweep8.hip)
+  c->sweep8_ok = !conv && !wide && !rbm && c->hact == VMC_ACT_RELU_ && !c->split_sweep &&
+                 plan_sweep8(c->N, c->Hp, c->n_hh, c->sweep_no_w1l != 0).ok;
+  {
+    int forced = 0;
+    if (const char* e = getenv("CGS_VMC_SWEEP_TILE")) forced = atoi(e);
+    c->sweep_tile = plan_sweep_tile(c->B, c->num_cus, c->sweep8_ok, forced);
+  }
   const long long B = c->B, N = c->N, Hp = c->Hp, P = c->P, L = c->A, NH = c->n_hh;   // L: activation buffers
 #define CA(expr) do { hipError_t e2 = (expr); if (e2 != hipSuccess) { \
     g_create_error = std::string(#expr) + ": " + hipGetErrorString(e2); vmc_destroy(c); return VMC_ERR_HIP; } } while (0)
@@ -1378,6 +1388,8 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
 // the sampler launch of this ctx (the 3 x bf16 split sampler when it is switched on)
 static hipError_t launch_sampler(vmc_ctx* c, hipStream_t st, SweepArgs& a, int which) {
   if (c->split_sweep) { a.p16s = c->ps[which].p16s; return launch_sweep16_split(st, a); }
+  // (injected proposals, the proposal dump and the diagnostic stamps stay on k_sweep16: the same chains, bit for bit)
+  if (c->sweep_tile == 8 && !a.inj_up && !a.dbg_up && !a.dbg_cycles && !a.acc_mask) return launch_sweep8(st, a, c->Hp);
   return launch_sweep16(st, a, c->Hp);
 }
 
@@ -1720,6 +1732,15 @@ int vmc_debug_kernel_path(vmc_ctx* c, int32_t* path) {
   CHECK_CTX(c);
   if (!path) return fail(c, VMC_ERR_INVALID, "null");
   *path = c->conv ? (c->conv_general ? 6 : 3) : (c->wide ? (c->wide_fast ? 1 : 2) : (c->split ? (c->split_sweep ? 5 : 4) : 0));
+  return VMC_OK;
+}
+
+int vmc_debug_sweep_tile(vmc_ctx* c, int32_t set, int32_t* chains) {
+  ENTER(c);
+  if (set != 0 && set != 8 && set != 16) return fail(c, VMC_ERR_INVALID, "sweep tile: 0 (query), 8 or 16");
+  if (set == 8 && !c->sweep8_ok) return fail(c, VMC_ERR_UNSUPPORTED, "no eight-chain sampler for this shape (fully_connected + relu, 128 or 256 padded units, n_sites <= units)");
+  if (set) { PROPAGATE(join_sweep(c)); c->sweep_tile = set; }
+  if (chains) *chains = c->sweep_tile;
   return VMC_OK;
 }
 

@@ -477,6 +477,12 @@ class VmcEngine:
     self._check(self._lib.vmc_debug_kernel_path(self._ctx, C.byref(v)))
     return int(v.value)
 
+  def sweep_tile(self, set_to: int = 0) -> int:
+    """Chains per sampler workgroup (16: k_sweep16, 8: k_sweep8); set_to = 8 / 16 switches (test hook)."""
+    v = C.c_int32()
+    self._check(self._lib.vmc_debug_sweep_tile(self._ctx, int(set_to), C.byref(v)))
+    return int(v.value)
+
   def synchronize(self):
     self._check(self._lib.vmc_synchronize(self._ctx))
 

@@ -340,6 +340,11 @@ int vmc_last_connected_rows(vmc_ctx* ctx, int64_t* rows);
  * (CGS_VMC_SPLIT_BF16=1: fully_connected, relu, 193 .. 256 units; fp32 results from the bf16 matrix cores,
  * cgs_vmc_amd/csrc/tail_split.hip -- never the headline configuration). */
 int vmc_debug_kernel_path(vmc_ctx* ctx, int32_t* path);
+/* Chains per workgroup of the fused dense sampler: 16 (k_sweep16, sweep16.hpp) or 8 (k_sweep8, sweep8.hip: chosen by
+ * vmc_create when sixteen-chain tiles would occupy at most half of the CUs -- BASELINE configs 2 and 5 -- or by
+ * CGS_VMC_SWEEP_TILE=8|16).  Both kernels implement graph_builders.py:38-89 and produce the same chains bit for bit.
+ * set = 0 queries, 8 / 16 switches (test hook; 8 is refused where no k_sweep8 exists for the shape). */
+int vmc_debug_sweep_tile(vmc_ctx* ctx, int32_t set, int32_t* chains);
 int vmc_synchronize(vmc_ctx* ctx);
 
 /* Test hook: C[M,N] = op(A) op(B) through the library's fp32 MFMA GEMM
