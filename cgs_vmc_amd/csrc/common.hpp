@@ -30,6 +30,21 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
   return c;
 }
 
+// The same ten rounds with each 32 x 32 -> 64 bit product as ONE v_mad_u64_u32 (the form above compiles to
+// v_mul_hi_u32 + v_mul_lo_u32, both quarter rate): 272 against 356 clocks per un-overlapped call
+// (tools/ubench/philox_rate.hip).  For callers that draw OUTSIDE an MFMA phase (k_sweep8); k_sweep16's Philox pieces
+// between MFMA groups were tuned around the form above and ran ~1 % slower with this one.
+__device__ __forceinline__ uint4 philox4x32_10_wide(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x, p1 = (unsigned long long)0xCD9E8D57u * c.z;
+    c = make_uint4((uint32_t)(p1 >> 32) ^ c.y ^ k.x, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k.y, (uint32_t)p0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+
 __device__ __forceinline__ float u32_to_uniform(uint32_t x) {
   return (float)(x >> 8) * (1.0f / 16777216.0f);
 }

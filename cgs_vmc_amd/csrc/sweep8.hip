@@ -34,7 +34,7 @@
 #include <type_traits>
 
 #ifndef SWEEP8_PF
-#define SWEEP8_PF 8     // ring slots (fragments of 16 bytes per lane); even
+#define SWEEP8_PF 4     // ring slots (fragments of 16 bytes per lane); even
 #endif
 
 namespace {
@@ -57,7 +57,20 @@ __device__ __forceinline__ void settle1(f32x4& a) { asm volatile("s_nop 7\n\ts_n
 // position of unit u in the order the MFMAs consume k: within a 16-unit tile register r outer, slot g inner
 __device__ __forceinline__ int m_of(int u) { return (u & ~15) | ((u & 3) << 2) | ((u >> 2) & 3); }
 
-template <int NW, int R0, int R1, bool W1L>
+// s_memtime stamp for the diagnostic instantiation (STAMP = true) only
+__device__ __forceinline__ unsigned long long stamp8() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+// STAMP (vmc_debug_sweep_profile): s_memtime ticks per mc_step and wave of the phases
+//   0 resolve (output dot + accept)   1 proposals   2 barrier A   3 build (+ Philox draw)   4 layer 0: barrier
+//   5 layer 0: MFMAs   6 layer 0: epilogue   7 later layers: barriers   8 later layers: MFMAs   9 later layers: epilogues
+//   10 end barrier
+template <int NW, int R0, int R1, bool W1L, bool STAMP>
 __global__ __launch_bounds__(NW * 64) void k_sweep8(SweepArgs a) {
   constexpr int NTH = NW * 64, Hp = 32 * NW, NT = Hp / 16, NI = 2 * NT;   // NI fragments per layer and wave
   constexpr int S = Hp + 16, W1S = Hp + 4, LPC = 8 * NW, PF = SWEEP8_PF;
@@ -155,16 +168,24 @@ __global__ __launch_bounds__(NW * 64) void k_sweep8(SweepArgs a) {
   }
   __syncthreads();
 
+  unsigned long long cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0;
+  bool stamp_on = false;
+#define SW8_STAMP(k) \
+  if (STAMP) { const unsigned long long t1_ = stamp8(); if (stamp_on) cyc[k] += t1_ - t0; t0 = t1_; }
+
   // ---- owner helpers
   unsigned ukey[4] = {0u, 0u, 0u, 0u};   // sortable keys of the NEXT proposal: (24-bit draw << 8) | (255 - site); 0 beyond the lattice
   float uacc_next = 0.f;
   // The uniforms of `step`: site block blk -> four keys; the acceptance uniform from block VMC_ACCEPT_BLOCK, word 0
   // (graph_builders.py:59, 76-77).  When the lattice leaves the group's last lane without a site block it draws the
   // acceptance block instead; otherwise every lane makes a second call.
+  // (The draw runs in build(), behind the issue of the W1 row reads: at 256 sites those come from L2 and the ~350
+  // clocks of a Philox call vanish in their latency.  Riding the rounds between layer 0's MFMA rows was measured and
+  // dropped: both waves of a SIMD reach them together, layer 0 grew by more than build() shrank.)
+  const bool spare = nblk < LPC;
   auto draw = [&](unsigned long long step) {
-    const bool spare = nblk < LPC;
     const uint32_t b0 = (spare && blk == LPC - 1) ? VMC_ACCEPT_BLOCK : (uint32_t)blk;
-    const uint4 r = philox4x32_10(make_uint4(b0, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
+    const uint4 r = philox4x32_10_wide(make_uint4(b0, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
     const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -174,7 +195,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep8(SweepArgs a) {
     if (spare) {
       uacc_next = __shfl(u32_to_uniform(r.x), lane | (LPC - 1));
     } else {
-      const uint4 q = philox4x32_10(make_uint4(VMC_ACCEPT_BLOCK, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
+      const uint4 q = philox4x32_10_wide(make_uint4(VMC_ACCEPT_BLOCK, my_gid, (uint32_t)step, (uint32_t)(step >> 32)), key);
       uacc_next = u32_to_uniform(q.x);
     }
   };
@@ -289,21 +310,16 @@ __global__ __launch_bounds__(NW * 64) void k_sweep8(SweepArgs a) {
   };
 
   // ---- H x H layers
-  auto mfma8 = [&](const f32x4& xa, const f32x4& w0, const f32x4& w1, f32x4 acc, auto jb_c) {
-    constexpr int JB = decltype(jb_c)::value;    // ABID base of this tile: 4 (ti & 1)
-#define SW8_MFMA(R, XE, W, BL) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(xa[XE], W[R], acc, 3, JB + R, BL);
-#define SW8_ROW(R) SW8_MFMA(R, 0, w0, 1) SW8_MFMA(R, 1, w0, 2) SW8_MFMA(R, 2, w1, 1) SW8_MFMA(R, 3, w1, 2)
-    SW8_ROW(0) SW8_ROW(1) SW8_ROW(2) SW8_ROW(3)
-#undef SW8_ROW
-#undef SW8_MFMA
-    return acc;
-  };
+  // the four MFMAs of register r of a tile pair (slots g = 0..3 ascending: k_sweep16's order); JB = 4 (ti & 1)
+#define SW8_MFMA(R, JB, XE, W, BL) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(xa_[XE], W[R], acc, 3, JB + R, BL);
+#define SW8_ROW(R, JB) SW8_MFMA(R, JB, 0, w0, 1) SW8_MFMA(R, JB, 1, w0, 2) SW8_MFMA(R, JB, 2, w1, 1) SW8_MFMA(R, JB, 3, w1, 2)
   const int l_last = n_hidden - 1;
   // FL: 0 = layer 0 (all fragments resident), 1 = layer 1 (R1 resident, the rest streamed), 2 = streamed
   auto layer = [&](int l, auto fl_c) {
     constexpr int FL = decltype(fl_c)::value;
     constexpr int FS = FL == 0 ? NI : (FL == 1 ? R1 : 0);    // first streamed fragment
     __syncthreads();
+    SW8_STAMP(FL == 0 ? 4 : 7)
     const float* xrow = s_x + (l & 1) * 8 * S + (4 * hh + (lane & 3)) * S + 4 * ((lane >> 2) & 7);
     f32x4 acc;
     {
@@ -341,16 +357,19 @@ __global__ __launch_bounds__(NW * 64) void k_sweep8(SweepArgs a) {
         w0 = ring[(2 * ti - FS) % PF];
         w1 = ring[(2 * ti + 1 - FS) % PF];
       }
-      if (ti & 1) acc = mfma8(xa[(ti >> 1) & 1], w0, w1, acc, std::integral_constant<int, 4>{});
-      else acc = mfma8(xa[(ti >> 1) & 1], w0, w1, acc, std::integral_constant<int, 0>{});
+      const f32x4& xa_ = xa[(ti >> 1) & 1];
+      if (ti & 1) { SW8_ROW(0, 4) SW8_ROW(1, 4) SW8_ROW(2, 4) SW8_ROW(3, 4) }
+      else { SW8_ROW(0, 0) SW8_ROW(1, 0) SW8_ROW(2, 0) SW8_ROW(3, 0) }
     }
     settle1(acc);
+    SW8_STAMP(FL == 0 ? 5 : 8)
 #pragma unroll
     for (int v = 0; v < 4; ++v) own[v] = vmc_act<VMC_ACT_RELU_>(acc[v]);
     float* dst = s_x + ((l + 1) & 1) * 8 * S + (4 * hh) * S + (l + 1 < n_hidden ? mu : u);
 #pragma unroll
     for (int v = 0; v < 4; ++v) dst[v * S] = own[v];
     if (save_acts) save_own(l + 1);
+    SW8_STAMP(FL == 0 ? 6 : 9)
   };
 
   // ---- the step loop.  it = -1: exact cache of the initial spins; 0 .. n_steps - 1: mc_steps; n_steps: exact cache
@@ -375,6 +394,8 @@ __global__ __launch_bounds__(NW * 64) void k_sweep8(SweepArgs a) {
   for (long long it = it_first; it <= a.n_steps; ++it) {
     const bool is_step = it >= 0 && it < a.n_steps;
     save_acts = (it == a.n_steps) && (a.act_out != nullptr);
+    stamp_on = is_step;
+    if (STAMP) t0 = stamp8();
     // resolve the previous iteration (the owner group of the chain; every lane of the group holds the same values)
     if (prev_kind != 0) {
       const float ln = chain_logit();
@@ -398,6 +419,7 @@ __global__ __launch_bounds__(NW * 64) void k_sweep8(SweepArgs a) {
         logit_c = ln;
       }
     }
+    SW8_STAMP(0)
     if (is_step) {
       // proposals (graph_builders.py:59-65): argmax / argmin of s * u with the first-index tie rule = two integer
       // max reductions over the sortable keys of the up / down spins (k_sweep16's hand-over variants)
@@ -420,21 +442,31 @@ __global__ __launch_bounds__(NW * 64) void k_sweep8(SweepArgs a) {
       spins_to_lds();
       if (blk == 0) s_pacc[oc] = 0;
     }
+    SW8_STAMP(1)
     __syncthreads();
+    SW8_STAMP(2)
     if (!is_step) { z1_direct(); dprev = f32x4{0.f, 0.f, 0.f, 0.f}; }
     build(is_step, a.step0 + (unsigned long long)(it + 1), it + 1 < a.n_steps);
-    if (n_hidden > 0) {
-      layer(0, std::integral_constant<int, 0>{});
+    SW8_STAMP(3)
+    {
+      typedef std::integral_constant<int, 0> c0; typedef std::integral_constant<int, 1> c1; typedef std::integral_constant<int, 2> c2;
+      layer(0, c0{});
       if (n_hidden > 1) {
-        if (R1 > 0) layer(1, std::integral_constant<int, 1>{});
-        else layer(1, std::integral_constant<int, 2>{});
+        if (R1 > 0) layer(1, c1{});
+        else layer(1, c2{});
       }
-      for (int l = 2; l < n_hidden; ++l) layer(l, std::integral_constant<int, 2>{});
+      for (int l = 2; l < n_hidden; ++l) layer(l, c2{});
     }
     __syncthreads();
+    SW8_STAMP(10)
     prev_kind = is_step ? 2 : 1;
   }
+#undef SW8_STAMP
   logit_c = chain_logit();    // logit of the final refresh
+  if (STAMP && a.dbg_cycles && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a.dbg_cycles[((long long)blockIdx.x * NW + wave) * 16 + k] = cyc[k];
+  }
 
   // ---- write back chains and the exact cache
   if (blk == 0 && own_ok) a.logit[gc_own] = logit_c;
@@ -483,16 +515,20 @@ __global__ __launch_bounds__(NW * 64) void k_sweep8(SweepArgs a) {
 template <int NW, int R0, int R1>
 hipError_t launch_t(hipStream_t s, const SweepArgs& a, const Sweep8Plan& sp) {
   const dim3 grid((a.B + 7) / 8), block(NW * 64);
-#define SW8_LAUNCH(WL)                                                                                     \
+#define SW8_LAUNCH(WL, ST)                                                                                 \
   do {                                                                                                     \
-    hipError_t e = hipFuncSetAttribute((const void*)k_sweep8<NW, R0, R1, WL>,                              \
+    hipError_t e = hipFuncSetAttribute((const void*)k_sweep8<NW, R0, R1, WL, ST>,                          \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sp.lds);          \
     if (e != hipSuccess) return e;                                                                         \
-    hipLaunchKernelGGL((k_sweep8<NW, R0, R1, WL>), grid, block, sp.lds, s, a);                             \
+    hipLaunchKernelGGL((k_sweep8<NW, R0, R1, WL, ST>), grid, block, sp.lds, s, a);                         \
     return hipGetLastError();                                                                              \
   } while (0)
-  if (sp.w1l) SW8_LAUNCH(true);
-  SW8_LAUNCH(false);
+  if (a.dbg_cycles) {
+    if (sp.w1l) SW8_LAUNCH(true, true);
+    SW8_LAUNCH(false, true);
+  }
+  if (sp.w1l) SW8_LAUNCH(true, false);
+  SW8_LAUNCH(false, false);
 #undef SW8_LAUNCH
 }
 
@@ -505,7 +541,7 @@ hipError_t launch_t(hipStream_t s, const SweepArgs& a, const Sweep8Plan& sp) {
 // the shapes k_sweep8 takes: plan_sweep8 (plan.hpp); the caller has checked it
 hipError_t launch_sweep8(hipStream_t s, const SweepArgs& a, int Hp) {
   if (a.B <= 0) return hipSuccess;
-  if (a.rbm || a.act != VMC_ACT_RELU_ || a.inj_up || a.dbg_up || a.dbg_cycles || a.acc_mask) return hipErrorInvalidValue;
+  if (a.rbm || a.act != VMC_ACT_RELU_ || a.inj_up || a.dbg_up || a.acc_mask) return hipErrorInvalidValue;
   const Sweep8Plan sp = plan_sweep8(a.N, Hp, a.n_hidden, a.no_w1l != 0);
   if (!sp.ok) return hipErrorInvalidValue;
   if (Hp == 256) return launch_t<8, 32, SWEEP8_R1_256>(s, a, sp);

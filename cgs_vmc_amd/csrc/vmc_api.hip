@@ -838,8 +838,23 @@ int local_energy_device(vmc_ctx* c, int which, bool defer_reduce = false, bool* 
     a.out = c->val;
     // a sampler launch is expected to overtake this accumulate: its workgroups need a whole
     // CU each, so the persistent grid leaves them free
-    if (c->expect_sweep && can_overlap(c) && c->num_cus - sweep_cus(c) >= c->num_cus / 4)
+    if (c->expect_sweep && can_overlap(c) && c->num_cus - sweep_cus(c) >= c->num_cus / 4) {
       a.num_cus = c->num_cus - sweep_cus(c);
+      // Long row lists (config 5: 4,100 tiles of ~170 us) as SHORT-LIVED workgroups instead: a grid of
+      // tiles / K workgroups of K tiles each (about CGS_VMC_TAIL_CHUNK_US of work), which the dispatcher hands to
+      // whichever CU is free -- the CUs of the sampler too once it has finished (its launch, on the high-priority
+      // sweep_stream, takes the CUs the first workgroups free).  A persistent grid on the CUs the sampler leaves
+      // cannot grow when the sampler ends before it (eight-chain tiles: 3.6 ms against 5.1 ms on 128 CUs).
+      static const int chunk_us = getenv("CGS_VMC_TAIL_CHUNK_US") ? atoi(getenv("CGS_VMC_TAIL_CHUNK_US")) : 150;
+      if (chunk_us > 0 && !c->split && c->n_hh > 0) {
+        const long long tiles = ((long long)a.n_rows + 127) / 128;
+        const double tile_us = 128.0 * c->n_hh * 2.0 * c->Hp * c->Hp / 491520.0;   // 0.8 of a CU's 256 flops per clock at 2.4 GHz
+        long long k = (long long)(chunk_us / tile_us);
+        if (k < 1) k = 1;
+        const long long wgs = (tiles + k - 1) / k;
+        if (wgs >= 4LL * c->num_cus) a.num_cus = (int)wgs;
+      }
+    }
     HIPCHK(c, launch_rows(c, which, a, true));
   }
   if (defer_reduce && deferred && !c->conv && !(c->wide && !c->wide_fast)) {
@@ -1098,7 +1113,11 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   CA(dalloc(&c->act_all, L * B * Hp)); CA(dalloc(&c->act_alt, L * B * Hp));
   CA(hipMemsetAsync(c->act_all, 0, L * B * Hp * sizeof(float), c->stream));
   CA(hipMemsetAsync(c->act_alt, 0, L * B * Hp * sizeof(float), c->stream));
-  CA(hipStreamCreateWithFlags(&c->sweep_stream, hipStreamNonBlocking));
+  {  // the sampler's stream outranks `stream`: where both have workgroups waiting for a CU, the sampler's go first
+    int least = 0, greatest = 0;
+    CA(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    CA(hipStreamCreateWithPriority(&c->sweep_stream, hipStreamNonBlocking, greatest));
+  }
   CA(hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming));
   CA(hipEventCreateWithFlags(&c->ev_now, hipEventDisableTiming));
   CA(hipEventCreateWithFlags(&c->ev_sweep_done, hipEventDisableTiming));
@@ -1389,7 +1408,7 @@ int vmc_amplitude(vmc_ctx* c, int which, const float* configs, int64_t n_rows, f
 static hipError_t launch_sampler(vmc_ctx* c, hipStream_t st, SweepArgs& a, int which) {
   if (c->split_sweep) { a.p16s = c->ps[which].p16s; return launch_sweep16_split(st, a); }
   // (injected proposals, the proposal dump and the diagnostic stamps stay on k_sweep16: the same chains, bit for bit)
-  if (c->sweep_tile == 8 && !a.inj_up && !a.dbg_up && !a.dbg_cycles && !a.acc_mask) return launch_sweep8(st, a, c->Hp);
+  if (c->sweep_tile == 8 && !a.inj_up && !a.dbg_up && !a.acc_mask) return launch_sweep8(st, a, c->Hp);
   return launch_sweep16(st, a, c->Hp);
 }
 
@@ -1662,7 +1681,9 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   if (n_steps < 1 || !phase_cycles) return fail(c, VMC_ERR_INVALID, "bad arguments");
   if (c->rbm || c->conv || c->wide) return fail(c, VMC_ERR_UNSUPPORTED, "the diagnostic sweep build exists for fully_connected (<= 256 units) only");
   PROPAGATE(ensure_packed(c, 0));
-  const int grid = (c->B + 15) / 16;
+  const bool tile8 = c->sweep_tile == 8;      // k_sweep8's stamped instantiation (phases: sweep8.hip)
+  const int wpg = tile8 ? c->Hp / 32 : c->sweep_waves;
+  const int grid = tile8 ? (c->B + 7) / 8 : (c->B + 15) / 16;
   unsigned long long* d = nullptr;
   HIPCHK(c, dalloc(&d, (long long)grid * 128));
   HIPCHK(c, hipMemsetAsync(d, 0, (size_t)grid * 128 * sizeof(unsigned long long), c->stream));
@@ -1675,7 +1696,8 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   a.B = c->B; a.N = c->N; a.n_hidden = c->n_hh; a.chain_offset = c->d.chain_offset;
   a.seed_lo = (uint32_t)(c->d.seed & 0xFFFFFFFFull); a.seed_hi = (uint32_t)(c->d.seed >> 32);
   a.step0 = c->step; a.n_steps = n_steps;
-  HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
+  if (tile8) HIPCHK(c, launch_sweep8(c->stream, a, c->Hp));
+  else HIPCHK(c, launch_sweep16(c->stream, a, c->Hp));
   swap_chain_buffers(c);
   c->acts_valid = false;
   c->step += (unsigned long long)n_steps;
@@ -1692,8 +1714,8 @@ int vmc_debug_sweep_profile(vmc_ctx* c, int64_t n_steps, double* phase_cycles) {
   for (int k = 0; k < 16; ++k) {
     double s = 0.0;
     long long cnt = 0;
-    for (int i = 0; i < grid * c->sweep_waves; ++i)
-      if ((wave_mask >> (i % c->sweep_waves)) & 1u) { s += (double)h[(size_t)i * 16 + k]; ++cnt; }
+    for (int i = 0; i < grid * wpg; ++i)
+      if ((wave_mask >> (i % wpg)) & 1u) { s += (double)h[(size_t)i * 16 + k]; ++cnt; }
     phase_cycles[k] = cnt ? s / ((double)cnt * (double)n_steps) : 0.0;
   }
   return VMC_OK;

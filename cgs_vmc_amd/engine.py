@@ -210,6 +210,9 @@ class VmcEngine:
     names = ('proposals', 'barrier0', 'build_z1', 'hidden_tail', 'output_dot', 'accept',
              'barrier1', 'l0_ring_prologue', 'l0_barrier', 'l0_resident_mfma',
              'l0_streamed_mfma', 'l0_epilogue', 'l1_barrier', 'l1_mfma', 'l1_epilogue', 'unused')
+    if self.sweep_tile() == 8:      # k_sweep8's phases (csrc/sweep8.hip)
+      names = ('resolve', 'proposals', 'barrier_a', 'build_draw', 'l0_barrier', 'l0_mfma', 'l0_epilogue',
+               'lx_barrier', 'lx_mfma', 'lx_epilogue', 'end_barrier', 'u11', 'u12', 'u13', 'u14', 'u15')
     return dict(zip(names, [float(x) for x in out]))
 
   @property
