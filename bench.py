@@ -941,6 +941,8 @@ def main():
       out['local_energy_evals_per_sec'] = world * b / t_eloc_call
       dom = 'sweep' if timings['sweep']['ms_total'] >= timings['tail_eloc']['ms_total'] else 'tail_eloc'
       k_sweep, k_eloc = ('k_conv_sweep', 'k_conv_rows(eloc)') if conv else ('k_sweep16', 'k_tail16(eloc)')
+      if not conv and h <= 256 and eng.sweep_tile() == 8:     # eight-chain tiles (csrc/sweep8.hip): <= half of the CUs otherwise
+        k_sweep = 'k_sweep8'
       if not conv and h > 256:        # 257..512 relu units: the LDS-operand row kernel (tail_co.hip)
         k_eloc = 'k_tail_lds(eloc)' if h <= 512 else 'wide GEMM rows(eloc)'
       if conv and eng.kernel_path() == 6:     # the general convolution path (conv_general.hip)
@@ -976,9 +978,11 @@ def main():
       pmc = None
       suffix = {'heisenberg10x10_fc3x256_b4096': '', 'heisenberg10x10_fc3x256_b4096_split3xbf16': '_split', 'heisenberg10x10_fc3x256_b4096_split3xbf16_sampler': '_splits',
                 'heisenberg16x16j1j2_fc6x256_b1024': '_config5', 'heisenberg16x16j1j2_fc6x256_b1024_split3xbf16_sampler': '_config5_splits',
+                'heisenberg6x6_fc3x128_b1024': '_config2', 'heisenberg10x10_fc3x1024_b4096': '_fc3x1024',
+                'heisenberg10x10_conv3x128k3_b1024': '_conv_general',
                 'heisenberg10x10_conv5x16k5_b4096': '_conv', 'heisenberg16x16j1j2_conv5x16k5_b1024': '_conv16',
                 'heisenberg10x10_fc3x512_b4096': '_fc3x512', 'heisenberg10x10_conv5x32k5_b4096': '_conv32'}.get(args.workload)
-      for rnd in ('r5', 'r4', 'r3', 'r2'):        # the newest committed profile of this workload
+      for rnd in ('r6', 'r5', 'r4', 'r3', 'r2'):        # the newest committed profile of this workload
         tag = None if suffix is None else rnd + suffix
         tpath = os.path.join(ROOT, 'profiles', '{}_traffic.json'.format(tag))
         if tag and os.path.exists(tpath):

@@ -280,7 +280,9 @@ def _free_port():
 # (ranks, transport).  The pool's process guard allows 6 processes on the GPU and this pytest process
 # holds one: 4 ranks is the widest multi-PROCESS job a box can run; 8 ranks run as threads
 # (tests/test_gpu_eightway.py) and as CPU processes (tests/test_parallel_gloo.py).
-@pytest.mark.parametrize('world,transport', [(2, 'host'), (4, 'torch')])
+# (4 ranks with the 'torch' transport -- gloo reducing DEVICE tensors, one staging copy per all-reduce and rank --
+# took 105 s of the suite in round 6; the device hook is covered at 2 ranks, 4 ranks by the host hook)
+@pytest.mark.parametrize('world,transport', [(2, 'torch'), (4, 'host')])
 def test_gloo_ranks_route_training_epochs_through_the_dist_entries(world, transport):
   port = _free_port()
   procs = []
