@@ -681,6 +681,8 @@ def main():
   ap.add_argument('--steps', type=int, default=100)
   ap.add_argument('--warmup', type=int, default=10)
   ap.add_argument('--workload', default='heisenberg10x10_fc3x256_b4096', choices=sorted(WORKLOADS))
+  ap.add_argument('--warm-sweeps', type=int, default=10, help='equilibration sweeps before the warm-up steps (BASELINE.md: 10; '
+                  'fewer only for rocprofv3 --pmc passes of the general paths, whose sweeps are hundreds of launches)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-timing', action='store_true', help='disable per-kernel HIP events')
   ap.add_argument('--no-extra', action='store_true',
@@ -760,7 +762,7 @@ def main():
       collective, collective_fallback = 'torch', 'library transport check failed: {}'.format(
           lib_proof.get('library_error', lib_proof.get('library_transport')))
   coll = parallel.collective() if (world > 1 and collective == 'library') else None
-  for _ in range(10):                              # 10 warm-up sweeps, one launch each
+  for _ in range(args.warm_sweeps):                # 10 warm-up sweeps, one launch each
     eng.mc_steps(n, want_accepted=False)           # (every k_sweep16 launch of a run is one sweep, so
                                                    # rocprofv3's per-kernel average is per sweep)
 
@@ -1001,6 +1003,33 @@ def main():
               # not by this run: say whether the kernels have changed since
               pmc['collected_at_source_hash'] = collected_at
               pmc['stale'] = None if collected_at is None else bool(collected_at != _hip.source_hash())
+          # The general paths (more than 512 units; convolutions beyond the fused kernels) keep their activations /
+          # feature maps in HBM and run the products on k_gemm_ring with one launch shape per role: the counters of the
+          # dominant role's shape (tools/summarise_profiles.py: "k_gemm_ring<...> @ grid <threads>"), per launch,
+          # next to the bytes that product has to move: A rows x K in (a convolution's implicit gather reads the map,
+          # rows x F, once), the weights, rows x columns out.
+          general = (not conv and h > 512) or (conv and eng.kernel_path() == 6)
+          if general and traffic is None:
+            shapes = {k2: v2 for k2, v2 in prof.items() if k2.startswith('k_gemm_ring') and ' @ grid ' in k2
+                      and v2.get('hbm_read_bytes') is not None}
+            if shapes:
+              if dom == 'sweep':       # the sampler's shape is the one launched most often
+                k2, rec = max(shapes.items(), key=lambda kv: kv[1].get('launches', 0))
+              else:                    # the local energies' row blocks: the largest grid
+                k2, rec = max(shapes.items(), key=lambda kv: int(kv[0].rsplit(' ', 1)[1]))
+              cols = h if not conv else ((h + 127) // 128) * 128
+              col_tiles = (cols + 127) // 128
+              rows = int(k2.rsplit(' ', 1)[1]) // 512 // col_tiles * 128
+              kdim = h if not conv else h * ksz * (ksz if ly > 1 else 1)
+              a_bytes = rows * (h if conv else kdim) * 4           # the map / activation rows the product reads once
+              algorithmic = a_bytes + kdim * h * 4 + rows * h * 4
+              traffic = rec['hbm_read_bytes'] + (rec.get('hbm_write_bytes') or 0)
+              pmc = {k3: rec[k3] for k3 in ('mfma_util', 'clock_ghz', 'median_us', 'launches') if k3 in rec}
+              pmc.update(source='profiles/{}_traffic.json'.format(tag), launch_shape=k2, rows_per_launch=rows,
+                         hbm_read_bytes=rec['hbm_read_bytes'], hbm_write_bytes=rec.get('hbm_write_bytes'),
+                         algorithmic_bytes=algorithmic, traffic_over_algorithmic=traffic / algorithmic,
+                         collected_at_source_hash=collected_at,
+                         stale=None if collected_at is None else bool(collected_at != _hip.source_hash()))
         except Exception:  # pylint: disable=broad-except
           traffic = None
       nominal = per_kernel[key]['algorithmic_tflops']

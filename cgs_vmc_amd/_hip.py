@@ -120,6 +120,8 @@ SIGNATURES = {
     'vmc_sr_num_stored': (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     'vmc_sr_begin': (C.c_int, [_ctx, C.POINTER(C.c_double)]),
     'vmc_sr_matvec_partial': (C.c_int, [_ctx]),
+    'vmc_sr_matvec_phase1': (C.c_int, [_ctx]),
+    'vmc_sr_matvec_phase2': (C.c_int, [_ctx]),
     'vmc_sr_buffer_devptr': (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     'vmc_sr_get_buffer': (C.c_int, [_ctx, _fp]),
     'vmc_sr_set_buffer': (C.c_int, [_ctx, _fp]),
@@ -145,7 +147,7 @@ _lib = None
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 _STAMP_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libcgsvmc_hip.stamp')
 # the files the library is built from, in the order csrc/Makefile hashes them
-_SOURCES = ('vmc_api.hip', 'mlp.hip', 'eloc.hip', 'grad.hip', 'sr.hip', 'srmm.hip', 'conv.hip', 'conv32.hip', 'conv48.hip', 'conv64.hip', 'conv_general.hip', 'wide.hip', 'tail_split.hip', 'sweep_split.hip', 'sweep8.hip', 'act_tail.hip',
+_SOURCES = ('vmc_api.hip', 'mlp.hip', 'eloc.hip', 'grad.hip', 'sr.hip', 'srmm.hip', 'conv.hip', 'conv32.hip', 'conv48.hip', 'conv64.hip', 'conv_general.hip', 'conv_band.hip', 'wide.hip', 'tail_split.hip', 'sweep_split.hip', 'sweep8.hip', 'act_tail.hip',
             'act_sweep.hip', 'plan.hpp', 'common.hpp', 'tail16.hpp', 'tail_lds.hpp', 'sweep16.hpp', 'conv.hpp', 'conv_kernels.hpp',
             'conv_wide.hpp',
             os.path.join('..', '..', 'include', 'cgsvmc.h'), 'Makefile')

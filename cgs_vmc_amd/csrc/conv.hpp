@@ -137,6 +137,26 @@ struct CgenIm2colArgs {
   float* A;                  // [rows * N][lda]
 };
 hipError_t launch_cgen_im2col(hipStream_t s, const CgenIm2colArgs& a);
+// One convolution of the general path at <= 16 filters WITHOUT an im2col matrix (conv_band.hip): bands of lattice rows
+// staged through LDS with their periodic halo, 16 output channels x 16 positions per MFMA tile, weights in registers.
+#define CGEN_BAND_LDS (40 * 1024)      // bytes of one staged band (several workgroups per CU)
+struct CgenBandArgs {
+  ConvGeom g;
+  int layer;                 // 0: the spins (exchanged pair negated); > 0: a feature map
+  int Fp;
+  const float* w;            // the convolution's weights as they lie in theta: [K][KW][Cin][F]
+  const float* bias;         // [F]
+  const float* in;           // layer > 0: [rows][N][Fp]
+  float* out;                // [rows][N][Fp]
+  int rows;
+  int pre_act;               // applied to the staged input (layer > 0; -1: none)
+  int epilogue, act;         // GemmArgs' ids: 1 f(v + bias), 4 v + bias, 8 C + v + bias, 11 selu(v + bias)
+  const float* configs; const int2* rowinfo; long long row0; const int2* bonds; const int* iup; const int* idn;   // layer 0 (as CgenIm2colArgs)
+  int band_rows;             // set by the launcher
+};
+bool cgen_band_ok(const ConvGeom& g);
+int cgen_band_rows(const ConvGeom& g);
+hipError_t launch_cgen_band(hipStream_t s, const CgenBandArgs& a, int num_cus);
 hipError_t launch_cgen_rowsum(hipStream_t s, const float* fm, int rows, int N, int F, int Fp, double* out);
 hipError_t launch_cgen_accept(hipStream_t s, float* configs, float* logit, const float* lnew, const int* iup,
                               const int* idn, const float* u, int B, int N, int oact, unsigned long long* accepted,

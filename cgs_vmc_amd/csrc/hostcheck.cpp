@@ -153,6 +153,29 @@ static void check_sweep(const vmc_desc& d, const DescPlan& p) {
     CHECK(plan_tail_lds_supported(p.Hp, p.n_hh));
     CHECK(plan_tail_lds_bytes(p.Hp, p.n_hh) <= PLAN_LDS_PER_CU);
   }
+  // the eight-chain sampler (sweep8.hip): its shapes, its LDS, and the tile rule
+  for (int no_w1l = 0; no_w1l < 2; ++no_w1l) {
+    const Sweep8Plan s8 = plan_sweep8(d.n_sites, p.Hp, p.n_hh, no_w1l != 0);
+    if (s8.ok) {
+      CHECK(p.Hp == 128 || p.Hp == 256);
+      CHECK(p.n_hh >= 1 && d.n_sites <= p.Hp && d.n_sites <= 256);        // one Philox site block per lane of a chain's group
+      CHECK(s8.lds <= PLAN_LDS_PER_CU && s8.lds == plan_sweep8_lds_bytes(d.n_sites, p.Hp, p.n_hh, s8.w1l != 0));
+      CHECK(!(s8.w1l && no_w1l));
+      // every array of the kernel's LDS carve-up starts on a 16-byte boundary
+      const size_t nst = (size_t)((d.n_sites + 3) & ~3);
+      CHECK((8 * nst) % 4 == 0 && (2 * 8 * ((size_t)p.Hp + 16)) % 4 == 0 && ((size_t)p.Hp + 16) % 4 == 0 && ((size_t)p.Hp + 4) % 4 == 0);
+    } else {
+      CHECK(s8.lds == 0 && s8.w1l == 0);
+    }
+    for (int forced : {0, 8, 16}) {
+      const int tile = plan_sweep_tile(d.batch_size, 256, s8.ok != 0, forced);
+      CHECK(tile == 8 || tile == 16);
+      if (!s8.ok || forced == 16) CHECK(tile == 16);
+      if (s8.ok && forced == 8) CHECK(tile == 8);
+      if (s8.ok && forced == 0) CHECK((tile == 8) == ((d.batch_size + 15) / 16 <= 128));
+      if (tile == 8 && forced == 0) CHECK((d.batch_size + 7) / 8 <= 256);   // never more eight-chain tiles than CUs by the rule itself
+    }
+  }
 }
 
 static void dense_grid() {
@@ -216,6 +239,11 @@ static void dense_grid() {
   CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_OK && p.P == 157697);
   const SweepPlan sp = plan_sweep(100, 16, 8, 2, false, false, true, true);
   CHECK(sp.ok && sp.w1l && sp.fast == 2);                     // config 3: W1 in LDS, two Philox draws per lane
+  // BASELINE configs 2 and 5 (1,024 chains per GPU) take eight-chain tiles, config 3 (4,096) sixteen-chain tiles
+  const Sweep8Plan c2 = plan_sweep8(36, 128, 2, false), c5 = plan_sweep8(256, 256, 5, false);
+  CHECK(c2.ok && c2.w1l && c5.ok && !c5.w1l);                 // 16 x 16 sites: W1 (266 KB) stays in L2
+  CHECK(plan_sweep_tile(1024, 256, true, 0) == 8 && plan_sweep_tile(4096, 256, true, 0) == 16 && plan_sweep_tile(2048, 256, true, 0) == 8);
+  CHECK(!plan_sweep8(300, 256, 2, false).ok && !plan_sweep8(100, 256, 0, false).ok && !plan_sweep8(100, 192, 2, false).ok);
 }
 
 // index of (site, channel) in a feature map; wrap of a periodic coordinate

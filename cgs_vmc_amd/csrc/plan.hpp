@@ -347,8 +347,9 @@ inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, c
       PLAN_FAIL(VMC_ERR_INVALID, "size_x * size_y must equal num_sites");
     // Beyond the limits of the fused kernels (feature maps in LDS: kernel_size <= 9 -- one instantiation per size --,
     // num_conv_filters <= 64 -- four channel blocks of 16 --, a sample's two maps within 160 KiB) the general path
-    // of conv_general.hip serves: feature maps in HBM, a convolution = im2col + one GEMM (round 5; forward, local
-    // energies and sampler -- the gradient and SR entries refuse such a ctx)
+    // of conv_general.hip serves: feature maps in HBM, a convolution = im2col (explicit, or in the A operand's address)
+    // + one GEMM (round 5: forward, local energies, sampler, the gradient accumulators of both optimizers and
+    // stochastic reconfiguration through the one-call solves)
     bool general = force_conv_general;
     if (d->kernel_size < 1 || d->kernel_size > CONV_GENERAL_MAX_K)
       PLAN_FAIL(VMC_ERR_UNSUPPORTED, "kernel_size 1..31 supported by the convolution kernels");

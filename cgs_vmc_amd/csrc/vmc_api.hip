@@ -84,6 +84,7 @@ struct vmc_ctx {
   double* cg_td = nullptr;                 // [cg_rows] O_b . v of a block (SR)
   float* cg_centre = nullptr;              // [1] mean of O_b . v over the stored samples (SR)
   bool sr_centre = false;                  // the SR matvec may centre its weights: a single-rank solve is running
+  bool sr_phase1_done = false;             // vmc_sr_matvec_phase1 has run for the current CG direction (general convolution path)
   int *wide_iup = nullptr, *wide_idn = nullptr;
   int hact = VMC_ACT_RELU_;  // hidden activation (layers.NONLINEARITIES id)
   int oact = VMC_ACT_EXP_;   // output activation; exp: psi = exp(x - shift), else psi = g(x), no shift
@@ -405,6 +406,9 @@ static bool cgen_implicit_on() {
   return on;
 }
 
+// CGS_VMC_CONV_BAND=0: the im2col + GEMM form for every filter count (read per call: A/B tests in one process)
+static bool cgen_band_on() { const char* e = getenv("CGS_VMC_CONV_BAND"); return !(e && atoi(e) == 0); }
+
 static int cgen_conv(vmc_ctx* c, const ParamSet& p, const float* configs, const int2* rowinfo, const int* iup,
                      const int* idn, int l, int rows, const float* in, float* dst, long long row0) {
   const ConvGeom& g = c->cg;
@@ -416,6 +420,18 @@ static int cgen_conv(vmc_ctx* c, const ParamSet& p, const float* configs, const 
   if (!g.resnet) { m.epilogue = (l + 1 < g.n_conv && cgen_post(c)) ? 1 : 4; m.act = g.hact; }
   else m.epilogue = l == 0 ? 4 : ((l & 1) ? 11 : 8);       // initial convolution; selu(first_conv(h)); h + second_conv(.)
   const int pre = cgen_in_pre(c, l);
+  // up to 16 filters: the band kernel (conv_band.hip) -- no im2col matrix, no 64-column tile for 16 columns
+  if (cgen_band_on() && cgen_band_ok(g)) {
+    CgenBandArgs b; memset(&b, 0, sizeof(b));
+    b.g = g; b.layer = l; b.Fp = Fp; b.w = m.B; b.bias = m.bias; b.in = in; b.out = dst; b.rows = rows;
+    b.pre_act = pre; b.epilogue = m.epilogue; b.act = m.act;
+    if (l == 0) {
+      b.configs = configs; b.rowinfo = rowinfo; b.row0 = row0; b.bonds = c->bonds ? c->bonds : c->bond_dummy;
+      b.iup = iup; b.idn = idn;
+    }
+    HIPCHK(c, launch_cgen_band(c->stream, b, c->num_cus));
+    return VMC_OK;
+  }
   // the gather inside the product's A operand (k_gemm_ring<., true>): no im2col matrix for this convolution
   if (l > 0 && pre < 0 && cgen_implicit_on()) {
     m.A = in; m.conv_a = 1; m.ca_N = g.N; m.ca_D1 = g.D1; m.ca_D2 = g.D2; m.ca_KW = g.KW; m.ca_lo = g.lo; m.ca_lo2 = g.lo2;
@@ -660,7 +676,8 @@ static int cgen_sr_matvec(vmc_ctx* c, const float* v, int n_rows) {
 int conv_rows(vmc_ctx* c, int which, const float* configs, const int2* rowinfo, int rows,
               const int* rows_dev, bool ratio, float* out, bool with_tape) {
   if (c->conv_general) {
-    if (with_tape) return fail(c, VMC_ERR_UNSUPPORTED, "the general convolution path has no gradient tape");
+    // (the gradient path of the general convolution re-runs its own taped forward, cgen_gradient: the row entry keeps none)
+    if (with_tape) return fail(c, VMC_ERR_UNSUPPORTED, "conv_rows keeps no tape on the general convolution path (its gradient entries run their own taped forward)");
     int n_rows = rows;
     if (rows_dev) {            // the blocks need the row count on the host
       HIPCHK(c, hipMemcpyAsync(&n_rows, rows_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -2422,9 +2439,9 @@ int vmc_sr_matvec_partial(vmc_ctx* c) {
   HIPCHK(c, hipMemsetAsync(c->sr_u, 0, (c->P + 1) * sizeof(float), c->stream));
   if (c->conv_general) {
     if (!c->sr_centre)
-      return fail(c, VMC_ERR_UNSUPPORTED, "stochastic reconfiguration on the general convolution path runs through vmc_sr_solve / "
-                                          "vmc_sr_solve_dist: its matvec centres the per-sample weights on the mean over all ranks, which the op-by-op "
-                                          "vmc_sr_matvec_partial cannot know");
+      return fail(c, VMC_ERR_UNSUPPORTED, "on the general convolution path the op-by-op matvec is vmc_sr_matvec_phase1 -> all-reduce of the buffer's "
+                                          "last float -> vmc_sr_matvec_phase2 (its per-sample weights are centred on the mean over ALL ranks, which "
+                                          "vmc_sr_matvec_partial cannot know); or vmc_sr_solve / vmc_sr_solve_dist");
     return cgen_sr_matvec(c, v, rows);
   }
   if (c->conv) {
@@ -2533,6 +2550,51 @@ int vmc_sr_cg_update(vmc_ctx* c, float diag_shift, double* rr) {
   return sr_read_rr(c, cur ^ 1, rr);
 }
 
+// sr_centre for the extent of a solve / debug matvec, whatever way the function leaves (an error return inside the CG
+// loop used to leave it set: a later op-by-op vmc_sr_matvec_partial of a sharded caller would then have run the
+// single-rank centred matvec instead of being refused)
+struct SrCentreScope {
+  vmc_ctx* c;
+  SrCentreScope(vmc_ctx* ctx, bool on) : c(ctx) { c->sr_centre = on; }
+  ~SrCentreScope() { c->sr_centre = false; }
+  SrCentreScope(const SrCentreScope&) = delete;
+  SrCentreScope& operator=(const SrCentreScope&) = delete;
+};
+
+// The op-by-op matvec in two phases (every path; only the general convolution path needs the pair):
+//   phase 1  general convolutions: t_b = O_b . p of this rank's stored samples, buffer[P] = sum_b t_b, buffer[0 .. P) = 0;
+//            elsewhere nothing
+//   -- the caller all-reduces buffer[P] (one float) when the samples are sharded --
+//   phase 2  general convolutions: the weights t_b centred on buffer[P] / (samples over all ranks), buffer[0 .. P) =
+//            sum_b (t_b - mean) O_b; elsewhere vmc_sr_matvec_partial
+// followed, as after vmc_sr_matvec_partial, by the all-reduce of the whole buffer and vmc_sr_cg_update.
+int vmc_sr_matvec_phase1(vmc_ctx* c) {
+  ENTER(c);
+  if (!c->sr_begun) return fail(c, VMC_ERR_STATE, "vmc_sr_begin first");
+  if (!c->conv_general) return VMC_OK;
+  const int rows = c->sr_n * c->B;
+  Timer t(c, "sr_matvec");
+  HIPCHK(c, hipMemsetAsync(c->sr_u, 0, (c->P + 1) * sizeof(float), c->stream));
+  PROPAGATE(cgen_sr_phase1(c, c->sr_p, rows));
+  HIPCHK(c, launch_sr_tsum(c->stream, c->sr_t, rows, c->sr_u + c->P));
+  c->sr_phase1_done = true;
+  return VMC_OK;
+}
+
+int vmc_sr_matvec_phase2(vmc_ctx* c) {
+  ENTER(c);
+  if (!c->sr_begun) return fail(c, VMC_ERR_STATE, "vmc_sr_begin first");
+  if (!c->conv_general) return vmc_sr_matvec_partial(c);
+  if (!c->sr_phase1_done) return fail(c, VMC_ERR_STATE, "vmc_sr_matvec_phase1 first");
+  c->sr_phase1_done = false;
+  const int rows = c->sr_n * c->B;
+  Timer t(c, "sr_matvec");
+  // (acc[2 P + 1]: the number of samples behind the accumulators -- over all ranks once they are all-reduced, which
+  // vmc_sr_begin requires)
+  HIPCHK(c, launch_cgen_tcentre_global(c->stream, c->sr_t, rows, c->acc + 2 * c->P + 1, c->cg_centre, c->sr_u + c->P));
+  return cgen_sr_phase2(c, rows);
+}
+
 static int sr_solve_impl(vmc_ctx* c, void* comm, int world, float diag_shift, float tol, int32_t max_iter,
                          int32_t* iters, double* rel_residual) {
   if (max_iter < 0 || tol < 0.f) return fail(c, VMC_ERR_INVALID, "bad CG arguments");
@@ -2540,7 +2602,7 @@ static int sr_solve_impl(vmc_ctx* c, void* comm, int world, float diag_shift, fl
   PROPAGATE(vmc_sr_begin(c, &rr0));
   rr = rr0;
   int it = 0;
-  c->sr_centre = !sharded(comm, world);          // (general convolution path: see cgen_sr_matvec)
+  SrCentreScope centre(c, !sharded(comm, world));   // (general convolution path: see cgen_sr_matvec)
   while (it < max_iter && rr > (double)tol * (double)tol * rr0 && rr0 > 0.0) {
     if (c->conv_general && sharded(comm, world)) {
       // the general convolution path centres its weights on the mean of O_b . p over ALL ranks (cgen_sr_matvec): one more
@@ -2559,7 +2621,6 @@ static int sr_solve_impl(vmc_ctx* c, void* comm, int world, float diag_shift, fl
     PROPAGATE(vmc_sr_cg_update(c, diag_shift, &rr));
     ++it;
   }
-  c->sr_centre = false;
   if (iters) *iters = it;
   if (rel_residual) *rel_residual = rr0 > 0.0 ? sqrt(rr / rr0) : 0.0;
   return VMC_OK;
@@ -2600,9 +2661,10 @@ int vmc_sr_debug_matvec(vmc_ctx* c, const float* v, float diag_shift, float* out
   if (!v || !out) return fail(c, VMC_ERR_INVALID, "null");
   PROPAGATE(vmc_sr_begin(c, nullptr));
   HIPCHK(c, hipMemcpyAsync(c->sr_p, v, c->P * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  c->sr_centre = true;
-  PROPAGATE(vmc_sr_matvec_partial(c));
-  c->sr_centre = false;
+  {
+    SrCentreScope centre(c, true);
+    PROPAGATE(vmc_sr_matvec_partial(c));
+  }
   HIPCHK(c, launch_sr_q(c->stream, c->sr_u, c->acc, (int)c->P, c->sr_p, diag_shift, c->sr_q, c->sr_partial, c->sr_sc));
   HIPCHK(c, hipMemcpyAsync(out, c->sr_q, c->P * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

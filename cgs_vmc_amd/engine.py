@@ -414,6 +414,14 @@ class VmcEngine:
   def sr_matvec_partial(self):
     self._check(self._lib.vmc_sr_matvec_partial(self._ctx))
 
+  def sr_matvec_phase1(self):
+    """General convolution path: O_b . p of this rank's samples, their sum in the buffer's last float (all-reduce it)."""
+    self._check(self._lib.vmc_sr_matvec_phase1(self._ctx))
+
+  def sr_matvec_phase2(self):
+    """The matvec proper (weights centred on the all-reduced mean on the general convolution path)."""
+    self._check(self._lib.vmc_sr_matvec_phase2(self._ctx))
+
   def sr_buffer_devptr(self) -> Tuple[int, int]:
     p = C.c_void_p()
     n = C.c_int64()

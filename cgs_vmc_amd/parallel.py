@@ -408,8 +408,14 @@ def sr_solve(engine, diag_shift: float, tol: float, max_iter: int):
     return engine.sr_solve_dist(collective(), diag_shift, tol, max_iter)
   rr0 = rr = engine.sr_begin()
   it = 0
+  two_phase = hasattr(engine, 'sr_matvec_phase1') and engine.kernel_path() == 6
   while it < max_iter and rr0 > 0.0 and rr > tol * tol * rr0:
-    engine.sr_matvec_partial()
+    if two_phase:      # general convolutions: the weights O_b . p are centred on their mean over ALL ranks
+      engine.sr_matvec_phase1()
+      allreduce_sr_buffer(engine)     # (zeros but for the last float, sum_b O_b . p)
+      engine.sr_matvec_phase2()
+    else:
+      engine.sr_matvec_partial()
     allreduce_sr_buffer(engine)
     rr = engine.sr_cg_update(diag_shift)
     it += 1

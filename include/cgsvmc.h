@@ -305,6 +305,13 @@ int vmc_sr_reserve(vmc_ctx* ctx, int32_t n_batches);
 int vmc_sr_num_stored(vmc_ctx* ctx, int32_t* n);
 int vmc_sr_begin(vmc_ctx* ctx, double* rr0);
 int vmc_sr_matvec_partial(vmc_ctx* ctx);
+/* The same matvec in two phases, for every path (required on the general convolution path, kernel path 6, whose
+ * per-sample weights O_b . p are centred on their mean over ALL ranks; elsewhere phase 1 does nothing and phase 2 is
+ * vmc_sr_matvec_partial): phase 1 leaves sum_b O_b . p of this rank's samples in the buffer's last float (the rest
+ * zero); SUM all-reduce that float across ranks; phase 2 fills the buffer as vmc_sr_matvec_partial does.  Then the
+ * all-reduce of the whole buffer and vmc_sr_cg_update as above.  (An extension like all of SR: no reference line.) */
+int vmc_sr_matvec_phase1(vmc_ctx* ctx);
+int vmc_sr_matvec_phase2(vmc_ctx* ctx);
 int vmc_sr_buffer_devptr(vmc_ctx* ctx, void** dev_ptr, int64_t* n_floats);
 int vmc_sr_get_buffer(vmc_ctx* ctx, float* host /*[P+1]*/);   /* host staging (non-RCCL backends) */
 int vmc_sr_set_buffer(vmc_ctx* ctx, const float* host /*[P+1]*/);

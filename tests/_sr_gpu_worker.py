@@ -54,6 +54,12 @@ def main_conv_general():
   oc = o - o.mean(0)
   err = np.abs(oc @ (x - ref)).max() / np.abs(oc @ ref).max()
   assert res <= 1e-4 and err <= 1e-2, (iters, res, err)
+  # the op-by-op loop of parallel.sr_solve (two-phase matvec, round 6) arrives at the same solution
+  os.environ['CGS_VMC_DIST_FUSED'] = '0'
+  it2, res2 = parallel.sr_solve(eng, 0.01, 1e-6, 2000)
+  os.environ.pop('CGS_VMC_DIST_FUSED')
+  x2 = eng.sr_get_solution()
+  assert abs(it2 - iters) <= 2 and np.abs(x2 - x).max() <= 1e-4 * np.abs(x).max(), (it2, iters, np.abs(x2 - x).max())
   eng.close()
   dist.barrier()
   dist.destroy_process_group()

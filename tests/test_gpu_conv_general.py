@@ -201,6 +201,47 @@ def test_general_convolution_stochastic_reconfiguration(monkeypatch, ansatz, sx,
   check(ansatz, sx, sy, L, f, k, b, nonlin, n_store)
 
 
+def test_general_convolution_sr_op_by_op_two_phase_matvec():
+  """The op-by-op CG loop on the general path (round 6): vmc_sr_matvec_phase1 -> [all-reduce of the buffer's last float]
+  -> vmc_sr_matvec_phase2 -> [all-reduce of the buffer] -> vmc_sr_cg_update arrives where the one-call vmc_sr_solve
+  does; vmc_sr_matvec_partial still refuses (it cannot know the mean over all ranks) and says what to call."""
+  from cgs_vmc_amd.engine import VmcEngine
+  ansatz, n, L, f, k, b, n_store = 'conv_1d', 12, 2, 4, 11, 18, 2
+  geom = (f, k, n, 1)
+  rng = np.random.default_rng(0)
+  theta = vo.conv_init_params(ansatz, geom, L, rng)
+  theta += (0.03 * rng.standard_normal(theta.size)).astype(np.float32)
+  eng = VmcEngine(n, b, L, f, nonlinearity='tanh', seed=2024, ansatz=ansatz, kernel_size=k, size_x=n, size_y=1)
+  assert eng.kernel_path() == 6
+  eng.set_params(theta)
+  eng.set_bonds(vo.chain_bonds(n), -1.0, 1.0)
+  eng.sr_reserve(n_store)
+  eng.reset_accumulators()
+  for j in range(n_store):
+    eng.set_configs(vo.random_configurations(n, b, np.random.RandomState(20 + j)))
+    eng.accumulate(0)
+  lam, tol = 0.01, 1e-6
+  it_ref, res_ref = eng.sr_solve(lam, tol, 500)
+  x_ref = eng.sr_get_solution()
+  rr0 = rr = eng.sr_begin()
+  with pytest.raises(Exception, match='vmc_sr_matvec_phase1'):
+    eng.sr_matvec_partial()
+  with pytest.raises(Exception, match='phase1 first'):
+    eng.sr_matvec_phase2()
+  it = 0
+  while it < 500 and rr > tol * tol * rr0:
+    eng.sr_matvec_phase1()
+    buf = eng.sr_get_buffer()
+    assert not buf[:-1].any()                  # only the last float (sum_b O_b . p) travels between the phases
+    eng.sr_matvec_phase2()
+    rr = eng.sr_cg_update(lam)
+    it += 1
+  x = eng.sr_get_solution()
+  assert abs(it - it_ref) <= 2, (it, it_ref)
+  assert np.abs(x - x_ref).max() <= 1e-4 * np.abs(x_ref).max(), (it, it_ref)
+  eng.close()
+
+
 def test_general_convolution_through_run_training_and_evaluation(tmp_path):
   """--wavefunction_type=conv_1d with kernel_size=11 (beyond the fused kernels: the general path) through the
   run_training / run_energy_evaluation counterparts on the reference's default lattice, the periodic chain

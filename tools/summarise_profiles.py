@@ -27,6 +27,15 @@ def medians(path):
       k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
       per[k][r['Counter_Name']].append(float(r['Counter_Value']))
       dur[k][r['Dispatch_Id']] = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+      # the GEMM kernels of the general paths run with several launch shapes in one step (the sampler's B candidates,
+      # the local energies' row blocks): also one record per grid, "name @ grid <threads>" (round 6)
+      if k.startswith('k_gemm') and r.get('Grid_Size'):
+        kg = '{} @ grid {}'.format(k, r['Grid_Size'])
+        per[kg][r['Counter_Name']].append(float(r['Counter_Value']))
+        dur[kg][r['Dispatch_Id']] = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+  for kg in [k for k in per if ' @ grid ' in k]:      # keep the shapes with at least three launches
+    if len(dur[kg]) < 3:
+      del per[kg]; del dur[kg]
   out = {}
   for k in per:
     ds = sorted(dur[k].values())
@@ -70,7 +79,7 @@ def main():
       traffic[k] = {
           'hbm_read_bytes': None if f_kb is None else 2 * 1024 * f_kb,
           'hbm_write_bytes': None if w_kb is None else 1024 * w_kb,
-          'median_us': s['median_ns'] / 1e3, 'clock_ghz': clock, 'mfma_util': util,
+          'median_us': s['median_ns'] / 1e3, 'clock_ghz': clock, 'mfma_util': util, 'launches': s['n'],
       }
   open(os.path.join(DST, TAG + '_pmc_summary.txt'), 'w').write('\n'.join(lines) + '\n')
   # the kernel sources these counters were collected from: bench.py marks the numbers stale when
