@@ -139,7 +139,6 @@ struct CgenIm2colArgs {
 hipError_t launch_cgen_im2col(hipStream_t s, const CgenIm2colArgs& a);
 // One convolution of the general path at <= 16 filters WITHOUT an im2col matrix (conv_band.hip): bands of lattice rows
 // staged through LDS with their periodic halo, 16 output channels x 16 positions per MFMA tile, weights in registers.
-#define CGEN_BAND_LDS (40 * 1024)      // bytes of one staged band (several workgroups per CU)
 struct CgenBandArgs {
   ConvGeom g;
   int layer;                 // 0: the spins (exchanged pair negated); > 0: a feature map

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256, (K * KW <= 9 ? 4 : (K * KW <= 25 ? 2 : 1))) vo
   extern __shared__ float s_band[];                     // [SR][SC][FIRST ? 1 : 16]
   const ConvGeom g = a.g;
   const int D1 = g.D1, D2 = g.D2, N = g.N, F = g.F, Fp = a.Fp;
-  const int BH = a.band_rows, SR = BH + K - 1, SC = D2 + KW - 1, NB = (D1 + BH - 1) / BH;
+  const int BH = a.band_rows, SC = D2 + KW - 1, NB = (D1 + BH - 1) / BH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, gq = lane >> 4;
 
@@ -156,8 +156,7 @@ __global__ __launch_bounds__(256, (K * KW <= 9 ? 4 : (K * KW <= 25 ? 2 : 1))) vo
 
 template <int K, int KW>
 hipError_t launch_k(hipStream_t s, const CgenBandArgs& a, int num_cus) {
-  const int SR = a.band_rows + K - 1, SC = a.g.D2 + KW - 1;
-  const size_t lds = (size_t)SR * SC * (a.layer == 0 ? 1 : 16) * sizeof(float);
+  const size_t lds = plan_cgen_band_lds_bytes(a.g, a.layer == 0);
   const int NB = (a.g.D1 + a.band_rows - 1) / a.band_rows;
   const long long items = (long long)a.rows * NB;
   // workgroups per CU: what the registers (K KW 4 fragments + ~48) and the LDS allow, at most 4
@@ -183,20 +182,9 @@ hipError_t launch_k(hipStream_t s, const CgenBandArgs& a, int num_cus) {
 
 }  // namespace
 
-// lattice rows per band: as many as keep a band with its halo within CGEN_BAND_LDS bytes (several workgroups per CU)
-int cgen_band_rows(const ConvGeom& g) {
-  const long long per_row = (long long)(g.D2 + g.KW - 1) * 16 * sizeof(float);
-  long long bh = CGEN_BAND_LDS / per_row - (g.K - 1);
-  if (bh > g.D1) bh = g.D1;
-  return (int)bh;      // < 1: the lattice is too wide for a band (cgen_band_ok says no)
-}
-
-// the shapes k_cgen_band takes: up to 16 filters, 2 .. 7 taps per axis (2-D: K x K; 1-D: K x 1)
-bool cgen_band_ok(const ConvGeom& g) {
-  if (g.F < 1 || g.F > 16 || g.K < 2 || g.K > 7) return false;
-  if (!(g.KW == g.K || g.KW == 1)) return false;
-  return cgen_band_rows(g) >= 1;
-}
+// (rows per band and the shapes taken: plan_cgen_band_rows / plan_cgen_band_ok, plan.hpp -- pure host, under ASan in hostcheck)
+int cgen_band_rows(const ConvGeom& g) { return plan_cgen_band_rows(g); }
+bool cgen_band_ok(const ConvGeom& g) { return plan_cgen_band_ok(g); }
 
 hipError_t launch_cgen_band(hipStream_t s, const CgenBandArgs& a_in, int num_cus) {
   if (a_in.rows <= 0) return hipSuccess;

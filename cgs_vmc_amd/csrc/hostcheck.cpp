@@ -393,6 +393,19 @@ static void conv_grid() {
               if (p.conv_general) {       // beyond the fused kernels: for exactly one of their four reasons
                 CHECK(F > 64 || K > 9 || plan_conv_rows_lds(p.cg, 1) > PLAN_LDS_PER_CU || B * p.cg.CS >= (1LL << 31));
                 CHECK((long long)p.cg.N * plan_cgen_lda(p.cg) < (1LL << 28));
+                // the band kernel of the general path (<= 16 filters, 2 .. 7 taps): a band with its halo fits its LDS
+                // budget, the bands cover the lattice, the staged index stays in 32 bits
+                if (plan_cgen_band_ok(p.cg)) {
+                  const int bh = plan_cgen_band_rows(p.cg);
+                  CHECK(F <= 16 && K >= 2 && K <= 7 && bh >= 1 && bh <= p.cg.D1);
+                  CHECK(plan_cgen_band_lds_bytes(p.cg, false) <= (size_t)PLAN_CGEN_BAND_LDS + 0 &&
+                        plan_cgen_band_lds_bytes(p.cg, true) <= plan_cgen_band_lds_bytes(p.cg, false));
+                  const int nb = (p.cg.D1 + bh - 1) / bh;
+                  CHECK((long long)nb * bh >= p.cg.D1 && (long long)(nb - 1) * bh < p.cg.D1);
+                  CHECK((long long)(bh + p.cg.K - 1) * (p.cg.D2 + p.cg.KW - 1) * 16 < (1LL << 24));
+                } else {
+                  CHECK(F > 16 || K > 7 || K < 2 || plan_cgen_band_rows(p.cg) < 1);
+                }
                 ++g_general;
                 continue;
               }
@@ -424,6 +437,13 @@ static void conv_grid() {
   CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_UNSUPPORTED);
   d.kernel_size = 5;
   CHECK(plan_desc(&d, true, &p, msg, sizeof(msg), true) == VMC_OK && p.conv_general);      // forced (CGS_VMC_CONV_GENERAL=1)
+  CHECK(plan_cgen_band_ok(p.cg) && plan_cgen_band_rows(p.cg) == 10);           // 16 filters 5 x 5 on 10 x 10: the band kernel, one band
+  {  // 36 x 36 x 16 filters, 5 x 5 (bench workload heisenberg36x36_conv3x16k5_b32): three bands of 12 lattice rows
+    vmc_desc b = d; DescPlan q;
+    b.layer_size = 16; b.num_layers = 3; b.size_x = b.size_y = 36; b.n_sites = 1296; b.batch_size = 32;
+    CHECK(plan_desc(&b, true, &q, msg, sizeof(msg)) == VMC_OK && q.conv_general && plan_cgen_band_ok(q.cg));
+    CHECK(plan_cgen_band_rows(q.cg) == 12 && plan_cgen_band_lds_bytes(q.cg, false) == 16u * 40u * 64u);
+  }
   d.kernel_size = 10;
   d.kernel_size = 5; d.size_x = 9;
   CHECK(plan_desc(&d, true, &p, msg, sizeof(msg)) == VMC_ERR_INVALID);        // size_x * size_y != num_sites

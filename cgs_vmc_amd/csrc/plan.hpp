@@ -101,6 +101,25 @@ struct ConvGeom {
 // general path: row stride (floats) of the im2col matrix = taps x input channels of the widest convolution, 16-byte rows
 PLAN_HD inline int plan_cgen_lda(const ConvGeom& g) { return (g.K * g.KW * (g.n_conv > 1 ? g.F : 1) + 3) & ~3; }
 PLAN_HD inline int plan_conv_tab(const ConvGeom& g) { return g.K <= 8 ? 8 : 16; }
+// general path at <= 16 filters: k_cgen_band (conv_band.hip) stages bands of lattice rows with their periodic halo,
+// (rows + K - 1) x (D2 + KW - 1) sites x 16 channels, in LDS; rows per band = as many as keep a band within
+// PLAN_CGEN_BAND_LDS bytes (several workgroups per CU); < 1: the lattice is too wide for a band
+#define PLAN_CGEN_BAND_LDS (40 * 1024)
+inline int plan_cgen_band_rows(const ConvGeom& g) {
+  const long long per_row = (long long)(g.D2 + g.KW - 1) * 16 * (long long)sizeof(float);
+  long long bh = PLAN_CGEN_BAND_LDS / per_row - (g.K - 1);
+  if (bh > g.D1) bh = g.D1;
+  return (int)bh;
+}
+// the shapes k_cgen_band takes: up to 16 filters, 2 .. 7 taps per axis (2-D: K x K; 1-D: K x 1)
+inline bool plan_cgen_band_ok(const ConvGeom& g) {
+  if (g.F < 1 || g.F > 16 || g.K < 2 || g.K > 7) return false;
+  if (!(g.KW == g.K || g.KW == 1)) return false;
+  return plan_cgen_band_rows(g) >= 1;
+}
+inline size_t plan_cgen_band_lds_bytes(const ConvGeom& g, bool first) {
+  return (size_t)(plan_cgen_band_rows(g) + g.K - 1) * (size_t)(g.D2 + g.KW - 1) * (first ? 1 : 16) * sizeof(float);
+}
 inline size_t plan_conv_rows_lds(const ConvGeom& g, int G) {
   const size_t xs = (size_t)((g.N + 3) & ~3);
   return ((size_t)G * 2 * g.CS + (size_t)G * xs + (size_t)G * g.N + (size_t)G * 7 + 2 * (size_t)plan_conv_tab(g) * (size_t)(g.D1 + g.D2) + 16) * sizeof(float);

@@ -201,6 +201,54 @@ def test_general_convolution_stochastic_reconfiguration(monkeypatch, ansatz, sx,
   check(ansatz, sx, sy, L, f, k, b, nonlin, n_store)
 
 
+BAND_SHAPES = [
+    # ansatz, size_x, size_y, layers / blocks, filters, kernel, B, nonlinearity: <= 16 filters, 2 .. 7 taps per axis
+    ('conv_2d', 36, 36, 3, 16, 5, 3, 'relu'),       # maps beyond the LDS of the fused kernels: three bands of 12 lattice rows
+    ('conv_2d', 20, 12, 2, 5, 4, 7, 'tanh'),        # 5 filters (Fp = 8), even kernel, ragged last tile
+    ('conv_2d', 3, 4, 2, 16, 7, 9, 'relu'),         # lattice smaller than the kernel: the wrap runs around more than once
+    ('conv_2d', 40, 9, 2, 12, 3, 5, 'cos'),         # pre-activation maps (the cosine is applied while the band is staged)
+    ('res_net_2d', 24, 24, 2, 16, 5, 4, 'relu'),    # selu / residual-add epilogues
+    ('conv_1d', 300, 1, 3, 16, 7, 6, 'sigmoid'),    # 1-D: K x 1 taps
+    ('res_net_1d', 64, 1, 1, 9, 2, 8, 'relu'),
+]
+
+
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', BAND_SHAPES,
+                         ids=['{}-{}x{}-L{}-F{}-K{}-B{}-{}'.format(*s) for s in BAND_SHAPES])
+def test_band_kernel_agrees_with_im2col_gemm_and_the_oracle(monkeypatch, ansatz, sx, sy, L, f, k, b, nonlin):
+  """Round 6: at <= 16 filters the general path's convolutions run on k_cgen_band (conv_band.hip: bands of lattice rows
+  staged through LDS, no im2col matrix).  Same engine, CGS_VMC_CONV_BAND=0 / 1 (read per call): logits, local energies,
+  a sampler trajectory and the gradient sums (whose taped forward takes the band kernel too) agree to fp32 summation-order
+  differences, and the band results meet tests/test_gpu_conv.py's bars against the fp64 oracle."""
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')
+  from cgs_vmc_amd import _hip
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6
+  out = {}
+  for band in ('0', '1'):
+    monkeypatch.setenv('CGS_VMC_CONV_BAND', band)
+    eng.set_configs(cfg)
+    eng.step_counter = 0
+    logit = eng.amplitude(cfg)[0]
+    eloc = eng.local_energy()[0]
+    eng.reset_accumulators()
+    eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+    acc = eng.get_accumulators()
+    eng.mc_steps(5)
+    out[band] = (logit, eloc, acc, eng.get_configs(), eng.amplitude()[0])
+  _, scale = vo.conv_forward(theta, cfg, ansatz, geom, L, nonlin, np.float64, return_tape='scale')
+  tol = 1e-6 * scale + 2e-5                            # tests/test_gpu_conv.py::_logits_close's bound against the oracle
+  _logits_close(out['1'][0], theta, cfg, ansatz, geom, L, nonlin)
+  _logits_close(out['0'][0], theta, cfg, ansatz, geom, L, nonlin)
+  assert (np.abs(out['1'][0].astype(np.float64) - out['0'][0]) <= 2 * tol).all()
+  assert np.abs(out['1'][1] - out['0'][1]).max() <= 4e-4 * max(1.0, np.abs(out['0'][1]).max())
+  assert np.abs(out['1'][2] - out['0'][2]).max() <= 4e-3 * np.abs(out['0'][2]).max() + 2e-4
+  same = (out['1'][3] == out['0'][3]).all(1)          # chains whose five accept tests fell the same way
+  assert same.mean() >= 0.8
+  _logits_close(out['1'][4][same], theta, out['1'][3][same], ansatz, geom, L, nonlin)
+  eng.close()
+
+
 def test_general_convolution_sr_op_by_op_two_phase_matvec():
   """The op-by-op CG loop on the general path (round 6): vmc_sr_matvec_phase1 -> [all-reduce of the buffer's last float]
   -> vmc_sr_matvec_phase2 -> [all-reduce of the buffer] -> vmc_sr_cg_update arrives where the one-call vmc_sr_solve
