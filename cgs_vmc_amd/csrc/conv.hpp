@@ -156,6 +156,9 @@ struct CgenBandArgs {
 bool cgen_band_ok(const ConvGeom& g);
 int cgen_band_rows(const ConvGeom& g);
 hipError_t launch_cgen_band(hipStream_t s, const CgenBandArgs& a, int num_cus);
+// the FIRST convolution (one input channel) of any filter count without an im2col matrix (k_cgen_first_direct)
+bool cgen_first_direct_ok(const ConvGeom& g, int epilogue);
+hipError_t launch_cgen_first_direct(hipStream_t s, const CgenBandArgs& a, int num_cus);
 hipError_t launch_cgen_rowsum(hipStream_t s, const float* fm, int rows, int N, int F, int Fp, double* out);
 hipError_t launch_cgen_accept(hipStream_t s, float* configs, float* logit, const float* lnew, const int* iup,
                               const int* idn, const float* u, int B, int N, int oact, unsigned long long* accepted,

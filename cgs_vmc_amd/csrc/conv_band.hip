@@ -154,16 +154,74 @@ __global__ __launch_bounds__(256, (K * KW <= 9 ? 4 : (K * KW <= 25 ? 2 : 1))) vo
   }
 }
 
+// First convolution (one input channel) at MORE than 16 filters, directly: out[row][n][f] = epilogue(b[f] + sum_t w[t][f] s'(site(n, t)))
+// with s' = the row's spins, the exchanged pair negated -- instead of an im2col matrix [rows N][taps] and a K = taps GEMM
+// (48 + 15 us per mc_step of 0.7 ms at 3 x 128 filters on 10 x 10).  One workgroup per row at a time; the spins, the
+// weights and the neighbour table live in LDS; a thread makes four channels of a site (taps x 4 fused multiply-adds) and
+// stores 16 bytes: the launch is bounded by the write of the map.  Taps ascending, as the im2col + GEMM form's k index.
+__global__ __launch_bounds__(256) void k_cgen_first_direct(CgenBandArgs a) {
+  extern __shared__ float s_first[];
+  const ConvGeom g = a.g;
+  const int N = g.N, T = g.K * g.KW, F = g.F, Fp = a.Fp, FQ = Fp / 4;
+  float* s_spin = s_first;                 // [N]
+  float* s_w = s_spin + ((N + 3) & ~3);    // [T][Fp]
+  float* s_b = s_w + T * Fp;               // [Fp]
+  int* s_nb = (int*)(s_b + Fp);            // [N][T]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < T * Fp; i += 256) { const int t = i / Fp, f = i - t * Fp; s_w[i] = f < F ? a.w[(long long)t * F + f] : 0.f; }
+  for (int i = tid; i < Fp; i += 256) s_b[i] = i < F ? a.bias[i] : 0.f;
+  for (int i = tid; i < N * T; i += 256) {
+    const int n = i / T, t = i - n * T;
+    const int a1 = n / g.D2, a2 = n - a1 * g.D2, d1 = t / g.KW, d2 = t - d1 * g.KW;
+    s_nb[i] = cb_wrap(a1 + d1 - g.lo, g.D1) * g.D2 + cb_wrap(a2 + d2 - g.lo2, g.D2);
+  }
+  for (int r = blockIdx.x; r < a.rows; r += gridDim.x) {
+    int chain = (int)a.row0 + r, fa = -1, fb = -1;
+    if (a.rowinfo) {
+      const int2 ri = a.rowinfo[a.row0 + r];
+      chain = ri.x;
+      if (ri.y != 0) { const int2 ab = a.bonds[(ri.y > 0 ? ri.y : -ri.y) - 1]; fa = ab.x; fb = ab.y; }
+    }
+    if (a.iup) { fa = a.iup[a.row0 + r]; fb = a.idn[a.row0 + r]; }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) { const float x = a.configs[(long long)chain * N + i]; s_spin[i] = (i == fa || i == fb) ? -x : x; }
+    __syncthreads();
+    float* out = a.out + (long long)r * N * Fp;
+    for (int i = tid; i < N * FQ; i += 256) {
+      const int n = i / FQ, cq = i - n * FQ;
+      f32x4 v = *(const f32x4*)(s_b + 4 * cq);
+      const int* nb = s_nb + n * T;
+      for (int t = 0; t < T; ++t) {
+        const float x = s_spin[nb[t]];
+        const f32x4 w = *(const f32x4*)(s_w + t * Fp + 4 * cq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(x, w[e], v[e]);
+      }
+      if (a.epilogue == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = vmc_act_rt(a.act, v[e]);
+      } else if (a.epilogue == 11) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = cb_selu(v[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = 4 * cq + e < F ? v[e] : 0.f;
+      *(f32x4*)(out + (long long)n * Fp + 4 * cq) = v;
+    }
+  }
+}
+
 template <int K, int KW>
-hipError_t launch_k(hipStream_t s, const CgenBandArgs& a, int num_cus) {
-  const size_t lds = plan_cgen_band_lds_bytes(a.g, a.layer == 0);
-  const int NB = (a.g.D1 + a.band_rows - 1) / a.band_rows;
-  const long long items = (long long)a.rows * NB;
-  // workgroups per CU: what the registers (K KW 4 fragments + ~48) and the LDS allow, at most 4
-  int per_cu = (int)(PLAN_LDS_PER_CU / (lds > 0 ? lds : 1));
+hipError_t launch_k(hipStream_t s, CgenBandArgs a, int num_cus) {
+  // workgroups per CU: what the registers (K KW 4 fragments + ~48) and the LDS of the widest band allow, at most 4
+  int per_cu = (int)(PLAN_LDS_PER_CU / plan_cgen_band_lds_bytes(a.g, a.layer == 0));
   const int by_regs = K * KW <= 9 ? 4 : (K * KW <= 25 ? 2 : 1);
   if (per_cu > by_regs) per_cu = by_regs;
   if (per_cu < 1) per_cu = 1;
+  a.band_rows = plan_cgen_band_rows_for(a.g, a.rows, (long long)num_cus * per_cu);
+  const size_t lds = plan_cgen_band_lds_bytes(a.g, a.layer == 0, a.band_rows);
+  const int NB = (a.g.D1 + a.band_rows - 1) / a.band_rows;
+  const long long items = (long long)a.rows * NB;
   long long grid = (long long)num_cus * per_cu;
   if (grid > items) grid = items;
   if (grid < 1) return hipSuccess;
@@ -186,11 +244,26 @@ hipError_t launch_k(hipStream_t s, const CgenBandArgs& a, int num_cus) {
 int cgen_band_rows(const ConvGeom& g) { return plan_cgen_band_rows(g); }
 bool cgen_band_ok(const ConvGeom& g) { return plan_cgen_band_ok(g); }
 
+// the first convolution of any filter count when the neighbour table fits LDS (epilogues 1 / 4 / 11: no residual add in front)
+bool cgen_first_direct_ok(const ConvGeom& g, int epilogue) {
+  return (epilogue == 1 || epilogue == 4 || epilogue == 11) && plan_cgen_first_direct_lds_bytes(g) <= 64 * 1024;
+}
+hipError_t launch_cgen_first_direct(hipStream_t s, const CgenBandArgs& a, int num_cus) {
+  if (a.rows <= 0) return hipSuccess;
+  if (a.layer != 0 || !cgen_first_direct_ok(a.g, a.epilogue)) return hipErrorInvalidValue;
+  const size_t lds = plan_cgen_first_direct_lds_bytes(a.g);
+  hipError_t e = hipFuncSetAttribute((const void*)k_cgen_first_direct, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  long long grid = (long long)num_cus * 2;
+  if (grid > a.rows) grid = a.rows;
+  hipLaunchKernelGGL(k_cgen_first_direct, dim3((unsigned)grid), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_cgen_band(hipStream_t s, const CgenBandArgs& a_in, int num_cus) {
   if (a_in.rows <= 0) return hipSuccess;
   if (!cgen_band_ok(a_in.g)) return hipErrorInvalidValue;
-  CgenBandArgs a = a_in;
-  a.band_rows = cgen_band_rows(a.g);
+  const CgenBandArgs& a = a_in;
   const bool two_d = a.g.KW == a.g.K;
 #define CB_CASE(KK) case KK: return two_d ? launch_k<KK, KK>(s, a, num_cus) : launch_k<KK, 1>(s, a, num_cus);
   switch (a.g.K) {

@@ -403,6 +403,13 @@ static void conv_grid() {
                   const int nb = (p.cg.D1 + bh - 1) / bh;
                   CHECK((long long)nb * bh >= p.cg.D1 && (long long)(nb - 1) * bh < p.cg.D1);
                   CHECK((long long)(bh + p.cg.K - 1) * (p.cg.D2 + p.cg.KW - 1) * 16 < (1LL << 24));
+                  for (long long rows : {1LL, 7LL, 32LL, 1000LL, 100000LL})       // thinner bands for few rows, never beyond the LDS band
+                    for (long long cap : {256LL, 512LL, 1024LL}) {
+                      const int b2 = plan_cgen_band_rows_for(p.cg, rows, cap);
+                      CHECK(b2 >= 1 && b2 <= bh);
+                      CHECK(plan_cgen_band_lds_bytes(p.cg, false, b2) <= plan_cgen_band_lds_bytes(p.cg, false));
+                      if (rows * ((p.cg.D1 + bh - 1) / bh) >= cap) CHECK(b2 == bh);
+                    }
                 } else {
                   CHECK(F > 16 || K > 7 || K < 2 || plan_cgen_band_rows(p.cg) < 1);
                 }

@@ -111,14 +111,34 @@ inline int plan_cgen_band_rows(const ConvGeom& g) {
   if (bh > g.D1) bh = g.D1;
   return (int)bh;
 }
+// rows per band of ONE launch over `rows` row configurations on a chip that holds `capacity` workgroups: few rows (the
+// sampler's B candidates at a small batch) take thinner bands, so that every CU has an item -- a launch's latency is an
+// item's; many rows (the local energies) take the widest band (least halo re-read)
+inline int plan_cgen_band_rows_for(const ConvGeom& g, long long rows, long long capacity) {
+  const int bh_max = plan_cgen_band_rows(g);
+  if (bh_max < 1 || rows < 1) return bh_max;
+  const long long nb_max = (g.D1 + bh_max - 1) / bh_max;
+  if (rows * nb_max >= capacity) return bh_max;
+  long long nb = (capacity + rows - 1) / rows;
+  if (nb > g.D1) nb = g.D1;
+  long long bh = (g.D1 + nb - 1) / nb;
+  if (bh < 1) bh = 1;
+  return (int)(bh < bh_max ? bh : bh_max);
+}
 // the shapes k_cgen_band takes: up to 16 filters, 2 .. 7 taps per axis (2-D: K x K; 1-D: K x 1)
 inline bool plan_cgen_band_ok(const ConvGeom& g) {
   if (g.F < 1 || g.F > 16 || g.K < 2 || g.K > 7) return false;
   if (!(g.KW == g.K || g.KW == 1)) return false;
   return plan_cgen_band_rows(g) >= 1;
 }
-inline size_t plan_cgen_band_lds_bytes(const ConvGeom& g, bool first) {
-  return (size_t)(plan_cgen_band_rows(g) + g.K - 1) * (size_t)(g.D2 + g.KW - 1) * (first ? 1 : 16) * sizeof(float);
+// k_cgen_first_direct (conv_band.hip): spins [N], weights [taps][Fp], bias [Fp], neighbour table [N][taps]
+inline size_t plan_cgen_first_direct_lds_bytes(const ConvGeom& g) {
+  const size_t fp = (size_t)((g.F + 3) & ~3), t = (size_t)g.K * g.KW;
+  return sizeof(float) * ((size_t)((g.N + 3) & ~3) + t * fp + fp + (size_t)g.N * t);
+}
+inline size_t plan_cgen_band_lds_bytes(const ConvGeom& g, bool first, int band_rows = 0) {
+  const int bh = band_rows > 0 ? band_rows : plan_cgen_band_rows(g);
+  return (size_t)(bh + g.K - 1) * (size_t)(g.D2 + g.KW - 1) * (first ? 1 : 16) * sizeof(float);
 }
 inline size_t plan_conv_rows_lds(const ConvGeom& g, int G) {
   const size_t xs = (size_t)((g.N + 3) & ~3);

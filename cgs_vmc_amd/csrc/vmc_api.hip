@@ -421,7 +421,8 @@ static int cgen_conv(vmc_ctx* c, const ParamSet& p, const float* configs, const 
   else m.epilogue = l == 0 ? 4 : ((l & 1) ? 11 : 8);       // initial convolution; selu(first_conv(h)); h + second_conv(.)
   const int pre = cgen_in_pre(c, l);
   // up to 16 filters: the band kernel (conv_band.hip) -- no im2col matrix, no 64-column tile for 16 columns
-  if (cgen_band_on() && cgen_band_ok(g)) {
+  const bool first_direct = l == 0 && cgen_band_on() && cgen_first_direct_ok(g, m.epilogue);
+  if (cgen_band_on() && (cgen_band_ok(g) || first_direct)) {
     CgenBandArgs b; memset(&b, 0, sizeof(b));
     b.g = g; b.layer = l; b.Fp = Fp; b.w = m.B; b.bias = m.bias; b.in = in; b.out = dst; b.rows = rows;
     b.pre_act = pre; b.epilogue = m.epilogue; b.act = m.act;
@@ -429,7 +430,8 @@ static int cgen_conv(vmc_ctx* c, const ParamSet& p, const float* configs, const 
       b.configs = configs; b.rowinfo = rowinfo; b.row0 = row0; b.bonds = c->bonds ? c->bonds : c->bond_dummy;
       b.iup = iup; b.idn = idn;
     }
-    HIPCHK(c, launch_cgen_band(c->stream, b, c->num_cus));
+    if (cgen_band_ok(g)) HIPCHK(c, launch_cgen_band(c->stream, b, c->num_cus));
+    else HIPCHK(c, launch_cgen_first_direct(c->stream, b, c->num_cus));     // more than 16 filters: the first convolution only
     return VMC_OK;
   }
   // the gather inside the product's A operand (k_gemm_ring<., true>): no im2col matrix for this convolution
