@@ -264,3 +264,32 @@ def test_split_sampler_at_config3_full_size(monkeypatch):
   if same.all():
     a0, a1 = outs[None][3], outs['2'][3]
     assert np.abs(a0 - a1).max() <= 2e-3 * np.abs(a0).max() + 1e-4
+
+
+def test_split_adversarial_operands(monkeypatch):
+  """Round 6: a bound under the experiment on operands chosen to hurt -- weight rows spanning 2^20
+  in magnitude, hidden units in exactly cancelling pairs, the weights after some training epochs -- through
+  tools/split_adversarial.py: both split kernels (CGS_VMC_SPLIT_BF16=2) against the native kernels and the fp64 oracle.
+  The split's error is the native kernels' error (measured worst ratio 1.06, profiles/r6_split_adversarial.txt; bound
+  here: 2), and no Metropolis decision differs from the fp64 decision outside the band the native kernel is allowed."""
+  import importlib.util
+  import os
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  spec = importlib.util.spec_from_file_location('split_adversarial', os.path.join(root, 'tools', 'split_adversarial.py'))
+  tool = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(tool)
+  saved = os.environ.get('CGS_VMC_SPLIT_BF16')
+  try:
+    rng = np.random.default_rng(1)
+    cases = {'range': tool.make_range(rng), 'cancel': tool.make_cancel(rng), 'trained': tool.make_trained(12)[0]}
+    for name, theta in cases.items():
+      nat, ln, en = tool.evaluate(theta, False)
+      spl, ls, es = tool.evaluate(theta, True)
+      assert spl['logit_err'] <= 2e-5 and spl['eloc_err'] <= 2e-4, (name, spl)           # the native kernels' bars
+      assert spl['logit_err'] <= 2 * max(nat['logit_err'], 1e-7) and spl['eloc_err'] <= 2 * max(nat['eloc_err'], 1e-6), (name, nat, spl)
+      assert spl['wrong_decisions'] == 0 and nat['wrong_decisions'] == 0 and spl['decisions'] >= 700, (name, nat, spl)
+  finally:
+    if saved is None:
+      os.environ.pop('CGS_VMC_SPLIT_BF16', None)
+    else:
+      os.environ['CGS_VMC_SPLIT_BF16'] = saved
