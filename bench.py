@@ -248,6 +248,38 @@ def extra_legs(eng, step, n, b, L, h, soak_seconds):
         os.environ.pop('CGS_VMC_SPLIT_BF16', None)
       else:
         os.environ['CGS_VMC_SPLIT_BF16'] = prev
+  # --- BASELINE configs 5 (one of its eight shards) and 2 on fresh engines, with sixteen- and with eight-chain sampler
+  # tiles (round 6: k_sweep8 -- the same chains bit for bit; vmc_create picks eight-chain tiles for these batches), so
+  # that the driver's own run carries their steps; the full lines: --workload heisenberg16x16j1j2_fc6x256_b1024 /
+  # heisenberg6x6_fc3x128_b1024 (profiles/r6_config5_*, r6_config2_*)
+  for tag, wl in (('config5_shard', 'heisenberg16x16j1j2_fc6x256_b1024'), ('config2', 'heisenberg6x6_fc3x128_b1024')):
+    lx, ly, nnn, L2, h2, b2 = WORKLOADS[wl][:6]
+    n2 = lx * ly
+    bonds2 = torus_bonds(lx, ly, nnn)
+    theta2, cfg2 = make_inputs(n2, h2, L2, b2, 0)
+    e2 = VmcEngine(n2, b2, L2, h2, device=eng.device, seed=2024)
+    e2.set_params(theta2); e2.set_bonds(bonds2, -1.0, 1.0)
+    for tile in (16, 8):
+      try:
+        e2.sweep_tile(tile)
+      except Exception:  # pylint: disable=broad-except
+        continue
+      e2.set_configs(cfg2)
+      for _ in range(5):
+        e2.mc_steps(n2, want_accepted=False)
+
+      def step3():
+        e2.reset_accumulators(); e2.accumulate(0); e2.mc_steps(n2, want_accepted=False)
+      for _ in range(4):
+        step3()
+      e2.synchronize()
+      reps3 = 30 if n2 > 100 else 200
+      t0 = time.perf_counter()
+      for _ in range(reps3):
+        step3()
+      e2.synchronize()
+      extra['{}_ms_per_step_tile{}'.format(tag, tile)] = 1e3 * (time.perf_counter() - t0) / reps3
+    e2.close()
   # --- one epoch at the reference's default hparams (a second, small engine)
   dn, dh, dL, db, dnb = 40, 80, 3, 200, 50
   theta, cfg = make_inputs(dn, dh, dL, db, 0)

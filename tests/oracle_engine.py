@@ -4,7 +4,7 @@ wavefunctions.py drive, backed by the numpy oracle (fp64) instead of libcgsvmc_h
 TEST INFRASTRUCTURE ONLY.  It lets the world_size-2 gloo test (no GPU) run the product's Python
 routing for sharded chains -- training.run_optimization_epoch -> engine.epoch_*_dist(collective)
 -> Collective.allreduce_host -- and compare it with the unsharded oracle epoch.  The `_dist`
-methods issue their all-reduces at exactly the points where csrc/vmc_api.hip
+methods issue their all-reduces at exactly the points where csrc/vmc_api_train.hip / vmc_api_sr.hip
 (epoch_energy_gradient_impl / epoch_log_overlap_impl / sr_solve_impl) issues them.
 fully_connected ansatz only."""
 import numpy as np

@@ -56,7 +56,7 @@ def test_500_engine_life_cycles_leak_nothing_and_torch_starts_afterwards():
 def test_one_hip_runtime_whatever_the_import_order():
   """torch bundles its own libamdhip64 / librccl (same sonames as the system ROCm's).  In a fresh
   process that touches this package BEFORE torch, the engine, torch and the library's RCCL binding must
-  still end up on ONE copy of each (cgs_vmc_amd/_hip.py loads torch first; vmc_api.hip takes librccl
+  still end up on ONE copy of each (cgs_vmc_amd/_hip.py loads torch first; vmc_api_coll.hip takes librccl
   from next to the runtime it is bound to)."""
   code = r'''
 import os, sys
