@@ -1286,7 +1286,8 @@ static int gemm_tiling(const GemmArgs& g) {
   const int mode = gemm128_mode();
   // (64 <= N < 128: ONE column tile with its upper columns clamped and masked -- the general convolution path's 65 .. 127
   // filters; the 64 x 64 kernel would read the im2col rows twice.  CGS_VMC_GEMM_NARROW=0: as before round 5's last change)
-  static const bool narrow = !(getenv("CGS_VMC_GEMM_NARROW") && atoi(getenv("CGS_VMC_GEMM_NARROW")) == 0);
+  const char* narrow_env = getenv("CGS_VMC_GEMM_NARROW");       // read per launch (A/B tests in one process), as CGS_VMC_GEMM128
+  const bool narrow = !(narrow_env && atoi(narrow_env) == 0);
   if (mode == 0 || !gemm128_layout_ok(g) || g.N < (narrow ? 64 : G2_TN)) return 0;
   if (mode == 2) return 1;
   if (mode == 5) return gemm_ring_ok(g) ? 2 : 0;

@@ -479,7 +479,7 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     }
     if (const char* e = getenv("CGS_VMC_CONV_GENERAL_BLOCK_ROWS")) { const long long r = atoll(e); if (r >= 1 && r < rows) rows = r; }   // tests: several blocks at small shapes
     c->cg_rows = rows;
-    CA(dalloc(&c->cg_A, rows * cg.N * plan_cgen_lda(cg)));
+    // (cg_A, the im2col matrix: allocated by the first launch that writes one -- cgen_need_A, vmc_api_cgen.hip)
     for (int i = 0; i < 2; ++i) CA(dalloc(&c->cg_fm[i], rows * cg.N * cgen_fp(cg)));
     CA(dalloc(&c->cg_sum, rows)); CA(dalloc(&c->cg_zero, 1)); CA(dalloc(&c->cg_lnew, B));
     CA(hipMemsetAsync(c->cg_zero, 0, sizeof(float), c->stream));

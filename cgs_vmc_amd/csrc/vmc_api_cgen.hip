@@ -19,9 +19,16 @@ static int cgen_in_pre(const vmc_ctx* c, int l) {       // activation applied wh
   if (l == 0 || c->cg.resnet || cgen_post(c)) return -1;
   return c->cg.hact;
 }
-static bool cgen_implicit_on() {
-  static const bool on = !(getenv("CGS_VMC_CONV_GENERAL_IMPLICIT") && atoi(getenv("CGS_VMC_CONV_GENERAL_IMPLICIT")) == 0);
-  return on;
+static bool cgen_implicit_on() {      // read per call: explicit against implicit gathers in one process (tests)
+  const char* e = getenv("CGS_VMC_CONV_GENERAL_IMPLICIT");
+  return !(e && atoi(e) == 0);
+}
+// The im2col matrix [cg_rows * N][plan_cgen_lda] (up to 768 MB) exists from the first launch that writes one: a ctx whose
+// convolutions all take the band kernel or the implicit gather never allocates it for the forward and the sampler.
+static int cgen_need_A(vmc_ctx* c) {
+  if (c->cg_A) return VMC_OK;
+  HIPCHK(c, dalloc(&c->cg_A, c->cg_rows * c->cg.N * plan_cgen_lda(c->cg)));
+  return VMC_OK;
 }
 
 // CGS_VMC_CONV_BAND=0: the im2col + GEMM form for every filter count (read per call: A/B tests in one process)
@@ -59,6 +66,7 @@ static int cgen_conv(vmc_ctx* c, const ParamSet& p, const float* configs, const 
     if (gemm_conv_a_ok(m)) { HIPCHK(c, launch_gemm(c->stream, m)); return VMC_OK; }
     m.conv_a = 0;
   }
+  PROPAGATE(cgen_need_A(c));
   CgenIm2colArgs a;
   memset(&a, 0, sizeof(a));
   a.g = g; a.layer = l; a.Fp = Fp; a.pre_act = pre; a.rows = rows; a.lda = lda; a.A = c->cg_A;
@@ -139,6 +147,7 @@ static float* cgen_gl(vmc_ctx* c, int l) { return c->cg_gl + (long long)l * c->c
 // the input of convolution l gathered into cg_A, as its forward did (from the tape of this block)
 static int cgen_gather_input(vmc_ctx* c, int l, int rows, long long row0, const float* configs) {
   const ConvGeom& g = c->cg;
+  PROPAGATE(cgen_need_A(c));
   CgenIm2colArgs a;
   memset(&a, 0, sizeof(a));
   a.g = g; a.layer = l; a.Fp = cgen_fp(g); a.rows = rows; a.lda = plan_cgen_lda(g); a.A = c->cg_A; a.pre_act = -1;
@@ -151,6 +160,7 @@ static int cgen_gather_input(vmc_ctx* c, int l, int rows, long long row0, const 
 // dst (+)= the transposed convolution l (>= 1) of G: the inverse gather against the transposed weight image
 static int cgen_input_grad(vmc_ctx* c, int l, int rows, const float* G, float* dst, bool accumulate) {
   const ConvGeom& g = c->cg;
+  PROPAGATE(cgen_need_A(c));
   CgenIm2colArgs a;
   memset(&a, 0, sizeof(a));
   a.g = g; a.layer = l; a.Fp = cgen_fp(g); a.rows = rows; a.lda = plan_cgen_lda(g); a.A = c->cg_A; a.pre_act = -1;

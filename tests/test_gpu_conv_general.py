@@ -201,6 +201,50 @@ def test_general_convolution_stochastic_reconfiguration(monkeypatch, ansatz, sx,
   check(ansatz, sx, sy, L, f, k, b, nonlin, n_store)
 
 
+RING_SHAPES = [
+    # the implicit-gather ring GEMM (k_gemm_ring<., true>: filters a multiple of 32, forced wherever it applies with
+    # CGS_VMC_GEMM128=5) beyond the one 128-filter conv_2d case above: residual-block epilogues (selu / accumulate)
+    # on the ring, the 1-D wrap, an even kernel's asymmetric padding, the narrow 64- and 96-column tiles, ragged last row tiles
+    ('res_net_2d', 6, 6, 1, 64, 3, 24, 'relu'),
+    ('conv_1d', 40, 1, 3, 96, 5, 12, 'relu'),
+    ('conv_2d', 8, 6, 2, 64, 4, 10, 'tanh'),
+    ('conv_2d', 6, 6, 2, 96, 3, 14, 'relu'),
+]
+
+
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', RING_SHAPES,
+                         ids=['{}-{}x{}-L{}-F{}-K{}-B{}-{}'.format(*s) for s in RING_SHAPES])
+def test_implicit_gather_ring_agrees_with_explicit_im2col(monkeypatch, ansatz, sx, sy, L, f, k, b, nonlin):
+  """CGS_VMC_CONV_GENERAL_IMPLICIT (read per call since round 6) = 1 / 0 in ONE engine: the gather inside the ring GEMM's A
+  operand against the im2col matrix + the same GEMM -- logits, local energies and gradient sums agree to the
+  summation order, and the implicit results meet the oracle's bars."""
+  from cgs_vmc_amd import _hip
+  monkeypatch.setenv('CGS_VMC_GEMM128', '5')
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')        # (64 filters are within the fused kernels' limits)
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6
+  out = {}
+  for implicit in ('0', '1'):
+    monkeypatch.setenv('CGS_VMC_CONV_GENERAL_IMPLICIT', implicit)
+    eng.set_configs(cfg)
+    logit = eng.amplitude(cfg)[0]
+    eloc = eng.local_energy()[0]
+    eng.reset_accumulators()
+    eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+    out[implicit] = (logit, eloc, eng.get_accumulators())
+  _, scale = vo.conv_forward(theta, cfg, ansatz, geom, L, nonlin, np.float64, return_tape='scale')
+  tol = 1e-6 * scale + 2e-5
+  _logits_close(out['1'][0], theta, cfg, ansatz, geom, L, nonlin)
+  _logits_close(out['0'][0], theta, cfg, ansatz, geom, L, nonlin)
+  assert (np.abs(out['1'][0].astype(np.float64) - out['0'][0]) <= 2 * tol).all()
+  assert np.abs(out['1'][1] - out['0'][1]).max() <= 4e-4 * max(1.0, np.abs(out['0'][1]).max())
+  assert np.abs(out['1'][2] - out['0'][2]).max() <= 4e-3 * np.abs(out['0'][2]).max() + 2e-4
+  psi_fn = vo.ANSATZ[ansatz][0]
+  amp = lambda c: psi_fn(theta, c, geom, L, nonlinearity=nonlin, dtype=np.float64)
+  _close(out['1'][1], vo.local_value(amp, cfg, bonds, -1.0, 1.0, dtype=np.float64), 2e-4)
+  eng.close()
+
+
 BAND_SHAPES = [
     # ansatz, size_x, size_y, layers / blocks, filters, kernel, B, nonlinearity: <= 16 filters, 2 .. 7 taps per axis
     ('conv_2d', 36, 36, 3, 16, 5, 3, 'relu'),       # maps beyond the LDS of the fused kernels: three bands of 12 lattice rows

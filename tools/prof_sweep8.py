@@ -1,4 +1,4 @@
-"""Per-phase s_memtime ticks (100 MHz) of one mc_step of the eight-chain sampler k_sweep8 (its stamped instantiation):
+"""Per-phase s_memtime ticks (shader clocks on gfx950) of one mc_step of the eight-chain sampler k_sweep8 (its stamped instantiation):
   python tools/prof_sweep8.py [N H L chains]     default: config 5's shard, then config 2"""
 import os
 import sys
@@ -17,7 +17,7 @@ def run(n, h, L, b):
   ph = eng.debug_sweep_profile(2 * n)
   eng.close()
   tot = sum(ph.values())
-  print('N={} H={} L={} chains={}: {:.0f} ticks = {:.2f} us per mc_step'.format(n, h, L, b, tot, tot / 100.0))
+  print('N={} H={} L={} chains={}: {:.0f} shader clocks per mc_step (= {:.2f} us at 2.4 GHz)'.format(n, h, L, b, tot, tot / 2400.0))
   for k, v in ph.items():
     if v:
       print('  {:<14s}{:8.1f}  {:5.1f} %'.format(k, v, 100.0 * v / tot))
