@@ -82,6 +82,8 @@ WORKLOADS = {
     'heisenberg10x10_conv3x96k3_b1024': (10, 10, False, 3, 96, 1024, 'conv_2d', 3),     # one column tile, a quarter of it padding
     # a lattice whose feature maps exceed the LDS at the DEFAULT filter count: the general path's weak spot (16 output columns)
     'heisenberg36x36_conv3x16k5_b32': (36, 36, False, 3, 16, 32, 'conv_2d', 5),
+    # round 6: the same lattice at 64 filters 3 x 3 (four channel blocks on the band kernel of conv_band.hip)
+    'heisenberg36x36_conv3x64k3_b32': (36, 36, False, 3, 64, 32, 'conv_2d', 3),
 }
 
 
@@ -981,7 +983,8 @@ def main():
         k_eloc = 'k_tail_lds(eloc)' if h <= 512 else 'wide GEMM rows(eloc)'
       if conv and eng.kernel_path() == 6:     # the general convolution path (conv_general.hip)
         k_sweep, k_eloc = 'k_cgen_im2col + GEMM(sampler)', 'k_cgen_im2col + GEMM(eloc)'
-        if h <= 16 and 2 <= ksz <= 7 and os.environ.get('CGS_VMC_CONV_BAND', '1') != '0':    # conv_band.hip (round 6)
+        kw = ksz if ly > 1 else 1
+        if h <= 64 and 2 <= ksz <= 7 and ksz * kw * 4 * ((h + 15) // 16) <= 208 and os.environ.get('CGS_VMC_CONV_BAND', '1') != '0':    # conv_band.hip (round 6)
           k_sweep, k_eloc = 'k_cgen_band(sampler)', 'k_cgen_band(eloc)'
       if not conv and h > 512:        # the general path: per mc_step one k_wide_step launch + the H x H layers as GEMMs
         k_sweep = 'k_wide_step + k_gemm_ring(sampler)'
@@ -1015,7 +1018,7 @@ def main():
       suffix = {'heisenberg10x10_fc3x256_b4096': '', 'heisenberg10x10_fc3x256_b4096_split3xbf16': '_split', 'heisenberg10x10_fc3x256_b4096_split3xbf16_sampler': '_splits',
                 'heisenberg16x16j1j2_fc6x256_b1024': '_config5', 'heisenberg16x16j1j2_fc6x256_b1024_split3xbf16_sampler': '_config5_splits',
                 'heisenberg6x6_fc3x128_b1024': '_config2', 'heisenberg10x10_fc3x1024_b4096': '_fc3x1024',
-                'heisenberg10x10_conv3x128k3_b1024': '_conv_general', 'heisenberg36x36_conv3x16k5_b32': '_conv_general_36x36',
+                'heisenberg10x10_conv3x128k3_b1024': '_conv_general', 'heisenberg36x36_conv3x16k5_b32': '_conv_general_36x36', 'heisenberg36x36_conv3x64k3_b32': '_conv_general_36x36x64',
                 'heisenberg10x10_conv5x16k5_b4096': '_conv', 'heisenberg16x16j1j2_conv5x16k5_b1024': '_conv16',
                 'heisenberg10x10_fc3x512_b4096': '_fc3x512', 'heisenberg10x10_conv5x32k5_b4096': '_conv32'}.get(args.workload)
       for rnd in ('r6', 'r5', 'r4', 'r3', 'r2'):        # the newest committed profile of this workload

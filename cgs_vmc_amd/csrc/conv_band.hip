@@ -1,5 +1,5 @@
 // k_cgen_band: one periodic convolution of the GENERAL convolution path (conv_general.hip: feature maps in HBM,
-// channel-last [row][site][Fp]) at up to 16 filters, as an implicit GEMM on bands of lattice rows staged through LDS
+// channel-last [row][site][Fp]) at up to 64 filters, as an implicit GEMM on bands of lattice rows staged through LDS
 // (round 6, VERDICT r5 "missing 2" / item 3a: lattices whose maps exceed the LDS at few filters -- the fused kernels of
 // conv_kernels.hpp keep a sample's two maps in LDS and refuse them; the im2col + GEMM form of this path wrote a
 // [rows N][taps F] matrix per convolution and multiplied it into 16 of a tile's 64 columns: 0.04-0.065 of the fp32-MFMA
@@ -32,37 +32,47 @@ __device__ __forceinline__ float cb_pre(int pre, float x) {
 }
 __device__ __forceinline__ int cb_wrap(int v, int d) { v %= d; return v < 0 ? v + d : v; }
 
-template <int K, int KW, bool FIRST>
-__global__ __launch_bounds__(256, (K * KW <= 9 ? 4 : (K * KW <= 25 ? 2 : 1))) void k_cgen_band(CgenBandArgs a) {
+// NCB: channel blocks of 16 (filters <= 16 NCB).  A workgroup owns ONE output block `co` for the whole launch -- its
+// fragments against every input block, K KW 4 NCB registers, stay resident -- and walks the items (row, band) of that
+// block; the NCB workgroups of an item run side by side (consecutive workgroup ids), so the band they all stage comes
+// out of L2.  The staged band is block-major, [input block][site][16 channels]: consecutive positions are 64 contiguous
+// bytes in every block (channel-last with 64 NCB bytes per site would put eight positions on the same banks).
+template <int K, int KW, int NCB, bool FIRST>
+__global__ __launch_bounds__(256, (K * KW * NCB <= 9 ? 4 : (K * KW * NCB <= 50 ? 2 : 1))) void k_cgen_band(CgenBandArgs a) {
   constexpr int T = K * KW;
-  constexpr int NF = FIRST ? (T + 3) / 4 : T * 4;       // weight fragments (one VGPR each)
-  extern __shared__ float s_band[];                     // [SR][SC][FIRST ? 1 : 16]
+  constexpr int NF = FIRST ? (T + 3) / 4 : NCB * T * 4;   // weight fragments (one VGPR each)
+  extern __shared__ float s_band[];                       // FIRST: [SR][SC]; else [NCB][SR][SC][16]
   const ConvGeom g = a.g;
   const int D1 = g.D1, D2 = g.D2, N = g.N, F = g.F, Fp = a.Fp;
   const int BH = a.band_rows, SC = D2 + KW - 1, NB = (D1 + BH - 1) / BH;
+  const int plane = (BH + K - 1) * SC * 16;               // floats of one input block of the staged band
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, gq = lane >> 4;
+  const int co = NCB > 1 ? (int)(blockIdx.x % NCB) : 0;   // this workgroup's output block
+  const int fo = 16 * co + p;                             // output channel of this lane's A rows
 
-  // ---- weight fragments (A operand: lane (cout = p, k slot gq))
+  // ---- weight fragments (A operand: lane (cout = fo, k slot gq))
   float wf[NF];
   if (FIRST) {        // w[tap][0][F]: k index = tap 4 m + gq
 #pragma unroll
     for (int m = 0; m < NF; ++m) {
       const int t = 4 * m + gq;
-      wf[m] = (t < T && p < F) ? a.w[(long long)t * F + p] : 0.f;
+      wf[m] = (t < T && fo < F) ? a.w[(long long)t * F + fo] : 0.f;
     }
-  } else {            // w[tap][cin][F]: MFMA e of a tap contracts channels 4 gq + e
+  } else {            // w[tap][cin][F]: MFMA e of (input block ci, tap) contracts channels 16 ci + 4 gq + e
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int ci = 0; ci < NCB; ++ci)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int ci = 4 * gq + e;
-        wf[4 * t + e] = (ci < F && p < F) ? a.w[((long long)t * F + ci) * F + p] : 0.f;
-      }
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c_in = 16 * ci + 4 * gq + e;
+          wf[(ci * T + t) * 4 + e] = (c_in < F && fo < F) ? a.w[((long long)t * F + c_in) * F + fo] : 0.f;
+        }
   }
   f32x4 bias4;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bias4[r] = 4 * gq + r < F ? a.bias[4 * gq + r] : 0.f;
+  for (int r = 0; r < 4; ++r) bias4[r] = 16 * co + 4 * gq + r < F ? a.bias[16 * co + 4 * gq + r] : 0.f;
   // first convolution: LDS offset of this lane's tap in MFMA m
   int toff[FIRST ? NF : 1];
   if (FIRST) {
@@ -74,7 +84,8 @@ __global__ __launch_bounds__(256, (K * KW <= 9 ? 4 : (K * KW <= 25 ? 2 : 1))) vo
   }
 
   const long long n_items = (long long)a.rows * NB;
-  for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+  const long long stride = NCB > 1 ? (long long)(gridDim.x / NCB) : (long long)gridDim.x;
+  for (long long item = NCB > 1 ? (long long)(blockIdx.x / NCB) : (long long)blockIdx.x; item < n_items; item += stride) {
     const int r = (int)(item / NB), b = (int)(item - (long long)r * NB);
     const int y0 = b * BH, bh = min(BH, D1 - y0);
     __syncthreads();                 // the previous item's readers are done with the band
@@ -96,8 +107,8 @@ __global__ __launch_bounds__(256, (K * KW <= 9 ? 4 : (K * KW <= 25 ? 2 : 1))) vo
       }
     } else {
       const float* src = a.in + (long long)r * N * Fp;
-      for (int i = tid; i < (bh + K - 1) * SC * 4; i += 256) {
-        const int site = i >> 2, cq = i & 3;
+      for (int i = tid; i < (bh + K - 1) * SC * 4 * NCB; i += 256) {
+        const int site = i / (4 * NCB), cq = i - site * (4 * NCB);       // cq: 4-channel quad of the site, 0 .. 4 NCB - 1
         const int sy = site / SC, sx = site - sy * SC;
         const int s = cb_wrap(y0 + sy - g.lo, D1) * D2 + cb_wrap(sx - g.lo2, D2);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256, (K * KW <= 9 ? 4 : (K * KW <= 25 ? 2 : 1))) vo
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = 4 * cq + e < F ? cb_pre(a.pre_act, v[e]) : 0.f;
         }
-        *(f32x4*)(s_band + (long long)site * 16 + 4 * cq) = v;
+        *(f32x4*)(s_band + (cq >> 2) * plane + site * 16 + 4 * (cq & 3)) = v;
       }
     }
     __syncthreads();
@@ -122,18 +133,21 @@ __global__ __launch_bounds__(256, (K * KW <= 9 ? 4 : (K * KW <= 25 ? 2 : 1))) vo
         for (int m = 0; m < NF; ++m)
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[m], base[toff[m]], acc, 0, 0, 0);
       } else {
-        const float* base = s_band + ((long long)(y * SC + x)) * 16 + 4 * gq;
+        const float* base = s_band + (y * SC + x) * 16 + 4 * gq;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const f32x4 bv = *(const f32x4*)(base + ((t / KW) * SC + (t % KW)) * 16);
+        for (int ci = 0; ci < NCB; ++ci)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[4 * t + e], bv[e], acc, 0, 0, 0);
-        }
+          for (int t = 0; t < T; ++t) {
+            const f32x4 bv = *(const f32x4*)(base + ci * plane + ((t / KW) * SC + (t % KW)) * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[(ci * T + t) * 4 + e], bv[e], acc, 0, 0, 0);
+          }
       }
       asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));    // the relu of vmc_act_rt is an asm v_max_f32 (common.hpp: vmc_mfma_settle)
       // ---- epilogue (GemmArgs' ids): 1 f(v + bias), 4 v + bias, 8 C + v + bias, 11 selu(v + bias); bias is in acc
-      if (q < n_pos && 4 * gq < Fp) {
-        float* dst = a.out + ((long long)r * N + (long long)(y0 + y) * D2 + x) * Fp + 4 * gq;
+      const int ch0 = 16 * co + 4 * gq;
+      if (q < n_pos && ch0 < Fp) {
+        float* dst = a.out + ((long long)r * N + (long long)(y0 + y) * D2 + x) * Fp + ch0;
         f32x4 v = acc;
         if (a.epilogue == 8) {
           const f32x4 c = *(const f32x4*)dst;
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(256, (K * KW <= 9 ? 4 : (K * KW <= 25 ? 2 : 1))) vo
           for (int e = 0; e < 4; ++e) v[e] = cb_selu(v[e]);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = 4 * gq + e < F ? v[e] : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = ch0 + e < F ? v[e] : 0.f;
         *(f32x4*)dst = v;
       }
     }
@@ -211,31 +225,44 @@ __global__ __launch_bounds__(256) void k_cgen_first_direct(CgenBandArgs a) {
   }
 }
 
-template <int K, int KW>
+template <int K, int KW, int NCB>
 hipError_t launch_k(hipStream_t s, CgenBandArgs a, int num_cus) {
-  // workgroups per CU: what the registers (K KW 4 fragments + ~48) and the LDS of the widest band allow, at most 4
+  // workgroups per CU: what the registers (K KW 4 NCB fragments + ~48) and the LDS of the widest band allow, at most 4
   int per_cu = (int)(PLAN_LDS_PER_CU / plan_cgen_band_lds_bytes(a.g, a.layer == 0));
-  const int by_regs = K * KW <= 9 ? 4 : (K * KW <= 25 ? 2 : 1);
+  const int by_regs = K * KW * NCB <= 9 ? 4 : (K * KW * NCB <= 50 ? 2 : 1);
   if (per_cu > by_regs) per_cu = by_regs;
   if (per_cu < 1) per_cu = 1;
-  a.band_rows = plan_cgen_band_rows_for(a.g, a.rows, (long long)num_cus * per_cu);
+  a.band_rows = plan_cgen_band_rows_for(a.g, (long long)a.rows * NCB, (long long)num_cus * per_cu);
   const size_t lds = plan_cgen_band_lds_bytes(a.g, a.layer == 0, a.band_rows);
   const int NB = (a.g.D1 + a.band_rows - 1) / a.band_rows;
   const long long items = (long long)a.rows * NB;
-  long long grid = (long long)num_cus * per_cu;
+  long long grid = (long long)num_cus * per_cu / NCB;       // item slots; every slot is NCB workgroups (one per output block)
   if (grid > items) grid = items;
-  if (grid < 1) return hipSuccess;
+  if (grid < 1) grid = 1;
+  grid *= NCB;
 #define CB_LAUNCH(FI)                                                                                       \
   do {                                                                                                      \
-    hipError_t e = hipFuncSetAttribute((const void*)k_cgen_band<K, KW, FI>,                                 \
+    hipError_t e = hipFuncSetAttribute((const void*)k_cgen_band<K, KW, NCB, FI>,                            \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
     if (e != hipSuccess) return e;                                                                          \
-    hipLaunchKernelGGL((k_cgen_band<K, KW, FI>), dim3((unsigned)grid), dim3(256), lds, s, a);               \
+    hipLaunchKernelGGL((k_cgen_band<K, KW, NCB, FI>), dim3((unsigned)grid), dim3(256), lds, s, a);          \
     return hipGetLastError();                                                                               \
   } while (0)
   if (a.layer == 0) CB_LAUNCH(true);
   CB_LAUNCH(false);
 #undef CB_LAUNCH
+}
+
+// NCB by the filter count; the shapes whose fragments fit the registers: plan_cgen_band_ok
+template <int K, int KW>
+hipError_t launch_kk(hipStream_t s, const CgenBandArgs& a, int num_cus) {
+  const int ncb = (a.g.F + 15) / 16;
+  constexpr int T = K * KW;
+  if (ncb == 1) return launch_k<K, KW, 1>(s, a, num_cus);
+  if constexpr (T * 2 <= PLAN_CGEN_BAND_MAX_FRAGS / 4) { if (ncb == 2) return launch_k<K, KW, 2>(s, a, num_cus); }
+  if constexpr (T * 3 <= PLAN_CGEN_BAND_MAX_FRAGS / 4) { if (ncb == 3) return launch_k<K, KW, 3>(s, a, num_cus); }
+  if constexpr (T * 4 <= PLAN_CGEN_BAND_MAX_FRAGS / 4) { if (ncb == 4) return launch_k<K, KW, 4>(s, a, num_cus); }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace
@@ -265,7 +292,7 @@ hipError_t launch_cgen_band(hipStream_t s, const CgenBandArgs& a_in, int num_cus
   if (!cgen_band_ok(a_in.g)) return hipErrorInvalidValue;
   const CgenBandArgs& a = a_in;
   const bool two_d = a.g.KW == a.g.K;
-#define CB_CASE(KK) case KK: return two_d ? launch_k<KK, KK>(s, a, num_cus) : launch_k<KK, 1>(s, a, num_cus);
+#define CB_CASE(KK) case KK: return two_d ? launch_kk<KK, KK>(s, a, num_cus) : launch_kk<KK, 1>(s, a, num_cus);
   switch (a.g.K) {
     CB_CASE(2) CB_CASE(3) CB_CASE(4) CB_CASE(5) CB_CASE(6) CB_CASE(7)
     default: return hipErrorInvalidValue;

@@ -397,12 +397,13 @@ static void conv_grid() {
                 // budget, the bands cover the lattice, the staged index stays in 32 bits
                 if (plan_cgen_band_ok(p.cg)) {
                   const int bh = plan_cgen_band_rows(p.cg);
-                  CHECK(F <= 16 && K >= 2 && K <= 7 && bh >= 1 && bh <= p.cg.D1);
-                  CHECK(plan_cgen_band_lds_bytes(p.cg, false) <= (size_t)PLAN_CGEN_BAND_LDS + 0 &&
+                  CHECK(F <= 64 && K >= 2 && K <= 7 && bh >= 1 && bh <= p.cg.D1);
+                  CHECK(p.cg.K * p.cg.KW * 4 * plan_cgen_band_ncb(p.cg) <= PLAN_CGEN_BAND_MAX_FRAGS && plan_cgen_band_ncb(p.cg) <= 4);
+                  CHECK(plan_cgen_band_lds_bytes(p.cg, false) <= (size_t)(plan_cgen_band_ncb(p.cg) > 1 ? 64 * 1024 : PLAN_CGEN_BAND_LDS) &&
                         plan_cgen_band_lds_bytes(p.cg, true) <= plan_cgen_band_lds_bytes(p.cg, false));
                   const int nb = (p.cg.D1 + bh - 1) / bh;
                   CHECK((long long)nb * bh >= p.cg.D1 && (long long)(nb - 1) * bh < p.cg.D1);
-                  CHECK((long long)(bh + p.cg.K - 1) * (p.cg.D2 + p.cg.KW - 1) * 16 < (1LL << 24));
+                  CHECK((long long)(bh + p.cg.K - 1) * (p.cg.D2 + p.cg.KW - 1) * 16 * plan_cgen_band_ncb(p.cg) < (1LL << 24));
                   for (long long rows : {1LL, 7LL, 32LL, 1000LL, 100000LL})       // thinner bands for few rows, never beyond the LDS band
                     for (long long cap : {256LL, 512LL, 1024LL}) {
                       const int b2 = plan_cgen_band_rows_for(p.cg, rows, cap);
@@ -411,7 +412,8 @@ static void conv_grid() {
                       if (rows * ((p.cg.D1 + bh - 1) / bh) >= cap) CHECK(b2 == bh);
                     }
                 } else {
-                  CHECK(F > 16 || K > 7 || K < 2 || plan_cgen_band_rows(p.cg) < 1);
+                  CHECK(F > 64 || K > 7 || K < 2 || p.cg.K * p.cg.KW * 4 * plan_cgen_band_ncb(p.cg) > PLAN_CGEN_BAND_MAX_FRAGS ||
+                        plan_cgen_band_rows(p.cg) < 1);
                 }
                 ++g_general;
                 continue;

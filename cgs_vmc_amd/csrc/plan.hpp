@@ -105,9 +105,12 @@ PLAN_HD inline int plan_conv_tab(const ConvGeom& g) { return g.K <= 8 ? 8 : 16; 
 // (rows + K - 1) x (D2 + KW - 1) sites x 16 channels, in LDS; rows per band = as many as keep a band within
 // PLAN_CGEN_BAND_LDS bytes (several workgroups per CU); < 1: the lattice is too wide for a band
 #define PLAN_CGEN_BAND_LDS (40 * 1024)
+#define PLAN_CGEN_BAND_MAX_FRAGS 208      // weight fragments (registers) of one output block: K KW 4 NCB
+inline int plan_cgen_band_ncb(const ConvGeom& g) { return (g.F + 15) / 16; }
 inline int plan_cgen_band_rows(const ConvGeom& g) {
-  const long long per_row = (long long)(g.D2 + g.KW - 1) * 16 * (long long)sizeof(float);
-  long long bh = PLAN_CGEN_BAND_LDS / per_row - (g.K - 1);
+  const long long per_row = (long long)(g.D2 + g.KW - 1) * 16 * plan_cgen_band_ncb(g) * (long long)sizeof(float);
+  // one block: 40 KB (several workgroups per CU); more: up to 64 KB (two per CU), the halo of a thin band costs more than the second pair
+  long long bh = (plan_cgen_band_ncb(g) > 1 ? 64 * 1024 : PLAN_CGEN_BAND_LDS) / per_row - (g.K - 1);
   if (bh > g.D1) bh = g.D1;
   return (int)bh;
 }
@@ -125,10 +128,13 @@ inline int plan_cgen_band_rows_for(const ConvGeom& g, long long rows, long long 
   if (bh < 1) bh = 1;
   return (int)(bh < bh_max ? bh : bh_max);
 }
-// the shapes k_cgen_band takes: up to 16 filters, 2 .. 7 taps per axis (2-D: K x K; 1-D: K x 1)
+// the shapes k_cgen_band takes: up to 64 filters (four channel blocks of 16) as long as one output block's fragments
+// against every input block fit the registers (3 x 3: 64 filters; 4 x 4: 48; 5 x 5: 32; 7 x 7: 16), 2 .. 7 taps per
+// axis (2-D: K x K; 1-D: K x 1), a band of at least one lattice row within the LDS budget
 inline bool plan_cgen_band_ok(const ConvGeom& g) {
-  if (g.F < 1 || g.F > 16 || g.K < 2 || g.K > 7) return false;
+  if (g.F < 1 || g.F > 64 || g.K < 2 || g.K > 7) return false;
   if (!(g.KW == g.K || g.KW == 1)) return false;
+  if (g.K * g.KW * 4 * plan_cgen_band_ncb(g) > PLAN_CGEN_BAND_MAX_FRAGS) return false;
   return plan_cgen_band_rows(g) >= 1;
 }
 // k_cgen_first_direct (conv_band.hip): spins [N], weights [taps][Fp], bias [Fp], neighbour table [N][taps]
@@ -138,7 +144,7 @@ inline size_t plan_cgen_first_direct_lds_bytes(const ConvGeom& g) {
 }
 inline size_t plan_cgen_band_lds_bytes(const ConvGeom& g, bool first, int band_rows = 0) {
   const int bh = band_rows > 0 ? band_rows : plan_cgen_band_rows(g);
-  return (size_t)(bh + g.K - 1) * (size_t)(g.D2 + g.KW - 1) * (first ? 1 : 16) * sizeof(float);
+  return (size_t)(bh + g.K - 1) * (size_t)(g.D2 + g.KW - 1) * (first ? 1 : 16 * (size_t)plan_cgen_band_ncb(g)) * sizeof(float);
 }
 inline size_t plan_conv_rows_lds(const ConvGeom& g, int G) {
   const size_t xs = (size_t)((g.N + 3) & ~3);

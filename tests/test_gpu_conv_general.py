@@ -254,13 +254,19 @@ BAND_SHAPES = [
     ('res_net_2d', 24, 24, 2, 16, 5, 4, 'relu'),    # selu / residual-add epilogues
     ('conv_1d', 300, 1, 3, 16, 7, 6, 'sigmoid'),    # 1-D: K x 1 taps
     ('res_net_1d', 64, 1, 1, 9, 2, 8, 'relu'),
+    # more than 16 filters: one workgroup per output channel block, the band block-major in LDS
+    ('conv_2d', 20, 20, 2, 64, 3, 4, 'relu'),       # four blocks, 3 x 3: 144 fragments per output block; maps beyond the LDS
+    ('conv_2d', 16, 16, 2, 32, 5, 4, 'relu'),       # two blocks, 5 x 5: 200 fragments
+    ('conv_2d', 8, 6, 2, 48, 4, 10, 'tanh'),        # three blocks, even kernel
+    ('res_net_2d', 6, 6, 1, 40, 3, 12, 'relu'),     # 40 filters: the third block half empty; residual epilogues
+    ('conv_1d', 50, 1, 2, 64, 7, 6, 'relu'),        # 1-D, four blocks x 7 taps
 ]
 
 
 @pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', BAND_SHAPES,
                          ids=['{}-{}x{}-L{}-F{}-K{}-B{}-{}'.format(*s) for s in BAND_SHAPES])
 def test_band_kernel_agrees_with_im2col_gemm_and_the_oracle(monkeypatch, ansatz, sx, sy, L, f, k, b, nonlin):
-  """Round 6: at <= 16 filters the general path's convolutions run on k_cgen_band (conv_band.hip: bands of lattice rows
+  """Round 6: at <= 64 filters (while one output block's fragments fit the registers) the general path's convolutions run on k_cgen_band (conv_band.hip: bands of lattice rows
   staged through LDS, no im2col matrix).  Same engine, CGS_VMC_CONV_BAND=0 / 1 (read per call): logits, local energies,
   a sampler trajectory and the gradient sums (whose taped forward takes the band kernel too) agree to fp32 summation-order
   differences, and the band results meet tests/test_gpu_conv.py's bars against the fp64 oracle."""
