@@ -32,15 +32,22 @@ __device__ __forceinline__ float cb_pre(int pre, float x) {
 }
 __device__ __forceinline__ int cb_wrap(int v, int d) { v %= d; return v < 0 ? v + d : v; }
 
-// NCB: channel blocks of 16 (filters <= 16 NCB).  A workgroup owns ONE output block `co` for the whole launch -- its
-// fragments against every input block, K KW 4 NCB registers, stay resident -- and walks the items (row, band) of that
-// block; the NCB workgroups of an item run side by side (consecutive workgroup ids), so the band they all stage comes
-// out of L2.  The staged band is block-major, [input block][site][16 channels]: consecutive positions are 64 contiguous
-// bytes in every block (channel-last with 64 NCB bytes per site would put eight positions on the same banks).
+// NCB: channel blocks of 16 (filters <= 16 NCB).  One block: 4 waves, several workgroups per CU.  More: ONE workgroup per
+// CU of NCB x WPC waves (8, 6, 8 at 2, 3, 4 blocks) -- WPC waves per OUTPUT block `co`, each holding that block's fragments
+// against every input block (K KW 4 NCB registers) for the whole launch -- which stages an item's band ONCE, into up to
+// 144 KB of LDS, for all of its output blocks (the first form had a workgroup per output block: every band was staged NCB
+// times, in thin bands with a (K - 1)-row halo each: the L2 -> LDS copies, not the products, bounded it).  The staged band is
+// block-major, [input block][site][16 channels]: consecutive positions are 64 contiguous bytes in every block
+// (channel-last with 64 NCB bytes per site would put eight positions on the same banks).
+template <int NCB> struct BandShape {
+  static constexpr int WPC = NCB == 1 ? 4 : (NCB == 2 ? 4 : 2);     // waves per output block
+  static constexpr int NWV = NCB == 1 ? 4 : NCB * WPC;              // waves per workgroup
+};
 template <int K, int KW, int NCB, bool FIRST>
-__global__ __launch_bounds__(256, (K * KW * NCB <= 9 ? 4 : (K * KW * NCB <= 50 ? 2 : 1))) void k_cgen_band(CgenBandArgs a) {
+__global__ __launch_bounds__(64 * BandShape<NCB>::NWV, (NCB > 1 ? 1 : (K * KW <= 9 ? 4 : (K * KW <= 50 ? 2 : 1)))) void k_cgen_band(CgenBandArgs a) {
   constexpr int T = K * KW;
   constexpr int NF = FIRST ? (T + 3) / 4 : NCB * T * 4;   // weight fragments (one VGPR each)
+  constexpr int WPC = BandShape<NCB>::WPC, NTHR = 64 * BandShape<NCB>::NWV;
   extern __shared__ float s_band[];                       // FIRST: [SR][SC]; else [NCB][SR][SC][16]
   const ConvGeom g = a.g;
   const int D1 = g.D1, D2 = g.D2, N = g.N, F = g.F, Fp = a.Fp;
@@ -48,7 +55,8 @@ __global__ __launch_bounds__(256, (K * KW * NCB <= 9 ? 4 : (K * KW * NCB <= 50 ?
   const int plane = (BH + K - 1) * SC * 16;               // floats of one input block of the staged band
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, gq = lane >> 4;
-  const int co = NCB > 1 ? (int)(blockIdx.x % NCB) : 0;   // this workgroup's output block
+  const int co = NCB > 1 ? wave / WPC : 0;                // this wave's output block
+  const int wl = NCB > 1 ? wave % WPC : wave;             // ... and its place among that block's waves
   const int fo = 16 * co + p;                             // output channel of this lane's A rows
 
   // ---- weight fragments (A operand: lane (cout = fo, k slot gq))
@@ -84,8 +92,7 @@ __global__ __launch_bounds__(256, (K * KW * NCB <= 9 ? 4 : (K * KW * NCB <= 50 ?
   }
 
   const long long n_items = (long long)a.rows * NB;
-  const long long stride = NCB > 1 ? (long long)(gridDim.x / NCB) : (long long)gridDim.x;
-  for (long long item = NCB > 1 ? (long long)(blockIdx.x / NCB) : (long long)blockIdx.x; item < n_items; item += stride) {
+  for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int r = (int)(item / NB), b = (int)(item - (long long)r * NB);
     const int y0 = b * BH, bh = min(BH, D1 - y0);
     __syncthreads();                 // the previous item's readers are done with the band
@@ -99,31 +106,54 @@ __global__ __launch_bounds__(256, (K * KW * NCB <= 9 ? 4 : (K * KW * NCB <= 50 ?
       }
       if (a.iup) { fa = a.iup[a.row0 + r]; fb = a.idn[a.row0 + r]; }
       const float* src = a.configs + (long long)chain * N;
-      for (int i = tid; i < (bh + K - 1) * SC; i += 256) {
-        const int sy = i / SC, sx = i - sy * SC;
-        const int s = cb_wrap(y0 + sy - g.lo, D1) * D2 + cb_wrap(sx - g.lo2, D2);
-        const float x = src[s];
-        s_band[i] = (s == fa || s == fb) ? -x : x;
+      const int total = (bh + K - 1) * SC;
+      for (int i0 = tid; i0 < total; i0 += 4 * NTHR) {      // four loads in flight per thread
+        float xv[4]; int sv[4];
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu) {
+          const int i = min(i0 + uu * NTHR, total - 1);
+          const int sy = i / SC, sx = i - sy * SC;
+          sv[uu] = cb_wrap(y0 + sy - g.lo, D1) * D2 + cb_wrap(sx - g.lo2, D2);
+          xv[uu] = src[sv[uu]];
+        }
+#pragma unroll
+        for (int uu = 0; uu < 4; ++uu)
+          if (i0 + uu * NTHR < total) s_band[i0 + uu * NTHR] = (sv[uu] == fa || sv[uu] == fb) ? -xv[uu] : xv[uu];
       }
     } else {
+      // eight 16-byte loads in flight per thread (a load -> store loop waits one HBM round trip per piece: the staging,
+      // not the products, bounded the first form of this kernel); addresses clamped, stores masked
       const float* src = a.in + (long long)r * N * Fp;
-      for (int i = tid; i < (bh + K - 1) * SC * 4 * NCB; i += 256) {
-        const int site = i / (4 * NCB), cq = i - site * (4 * NCB);       // cq: 4-channel quad of the site, 0 .. 4 NCB - 1
-        const int sy = site / SC, sx = site - sy * SC;
-        const int s = cb_wrap(y0 + sy - g.lo, D1) * D2 + cb_wrap(sx - g.lo2, D2);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (4 * cq < Fp) {
-          v = *(const f32x4*)(src + (long long)s * Fp + 4 * cq);
+      const int total = (bh + K - 1) * SC * 4 * NCB;
+      constexpr int SB = NF > 150 ? 2 : 8;     // loads in flight per thread (fewer where the fragments leave few registers)
+      for (int i0 = tid; i0 < total; i0 += SB * NTHR) {
+        f32x4 v[SB];
+        int dsto[SB], ch[SB];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = 4 * cq + e < F ? cb_pre(a.pre_act, v[e]) : 0.f;
+        for (int uu = 0; uu < SB; ++uu) {
+          const int i = min(i0 + uu * NTHR, total - 1);
+          const int site = i / (4 * NCB), cq = i - site * (4 * NCB);       // cq: 4-channel quad of the site, 0 .. 4 NCB - 1
+          const int sy = site / SC, sx = site - sy * SC;
+          const int sl = cb_wrap(y0 + sy - g.lo, D1) * D2 + cb_wrap(sx - g.lo2, D2);
+          v[uu] = *(const f32x4*)(src + (long long)sl * Fp + (4 * cq < Fp ? 4 * cq : 0));
+          dsto[uu] = (cq >> 2) * plane + site * 16 + 4 * (cq & 3);
+          ch[uu] = 4 * cq;                                                 // first channel of the quad (>= F: zeros)
         }
-        *(f32x4*)(s_band + (cq >> 2) * plane + site * 16 + 4 * (cq & 3)) = v;
+#pragma unroll
+        for (int uu = 0; uu < SB; ++uu) {
+          if (i0 + uu * NTHR < total) {
+            f32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = ch[uu] + e < F ? cb_pre(a.pre_act, v[uu][e]) : 0.f;
+            *(f32x4*)(s_band + dsto[uu]) = w;
+          }
+        }
       }
     }
     __syncthreads();
     // ---- position tiles of the band: 16 consecutive positions (row-major over the band's bh x D2 sites)
     const int n_pos = bh * D2, n_tiles = (n_pos + 15) >> 4;
-    for (int tile = wave; tile < n_tiles; tile += 4) {
+    for (int tile = wl; tile < n_tiles; tile += WPC) {
       const int q = tile * 16 + p, qq = q < n_pos ? q : n_pos - 1;      // (a ragged last tile computes its last position again)
       const int y = qq / D2, x = qq - y * D2;
       f32x4 acc = bias4;
@@ -225,32 +255,32 @@ __global__ __launch_bounds__(256) void k_cgen_first_direct(CgenBandArgs a) {
   }
 }
 
-template <int K, int KW, int NCB>
-hipError_t launch_k(hipStream_t s, CgenBandArgs a, int num_cus) {
-  // workgroups per CU: what the registers (K KW 4 NCB fragments + ~48) and the LDS of the widest band allow, at most 4
-  int per_cu = (int)(PLAN_LDS_PER_CU / plan_cgen_band_lds_bytes(a.g, a.layer == 0));
-  const int by_regs = K * KW * NCB <= 9 ? 4 : (K * KW * NCB <= 50 ? 2 : 1);
-  if (per_cu > by_regs) per_cu = by_regs;
-  if (per_cu < 1) per_cu = 1;
-  a.band_rows = plan_cgen_band_rows_for(a.g, (long long)a.rows * NCB, (long long)num_cus * per_cu);
-  const size_t lds = plan_cgen_band_lds_bytes(a.g, a.layer == 0, a.band_rows);
+template <int K, int KW, int NCB, bool FI>
+hipError_t launch_kf(hipStream_t s, CgenBandArgs a, int num_cus) {
+  constexpr int NTHR = 64 * BandShape<NCB>::NWV;
+  // workgroups per CU: what the runtime says the kernel's registers and the widest band's LDS allow (at most 4; more
+  // than one channel block: one workgroup of 6 or 8 waves per CU)
+  const size_t lds_max = plan_cgen_band_lds_bytes(a.g, FI);
+  hipError_t e = hipFuncSetAttribute((const void*)k_cgen_band<K, KW, NCB, FI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+  if (e != hipSuccess) return e;
+  int per_cu = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_cgen_band<K, KW, NCB, FI>, NTHR, lds_max) != hipSuccess || per_cu < 1)
+    per_cu = 1;
+  if (per_cu > 4) per_cu = 4;
+  a.band_rows = plan_cgen_band_rows_for(a.g, a.rows, (long long)num_cus * per_cu);
+  const size_t lds = plan_cgen_band_lds_bytes(a.g, FI, a.band_rows);
   const int NB = (a.g.D1 + a.band_rows - 1) / a.band_rows;
   const long long items = (long long)a.rows * NB;
-  long long grid = (long long)num_cus * per_cu / NCB;       // item slots; every slot is NCB workgroups (one per output block)
+  long long grid = (long long)num_cus * per_cu;
   if (grid > items) grid = items;
   if (grid < 1) grid = 1;
-  grid *= NCB;
-#define CB_LAUNCH(FI)                                                                                       \
-  do {                                                                                                      \
-    hipError_t e = hipFuncSetAttribute((const void*)k_cgen_band<K, KW, NCB, FI>,                            \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-    if (e != hipSuccess) return e;                                                                          \
-    hipLaunchKernelGGL((k_cgen_band<K, KW, NCB, FI>), dim3((unsigned)grid), dim3(256), lds, s, a);          \
-    return hipGetLastError();                                                                               \
-  } while (0)
-  if (a.layer == 0) CB_LAUNCH(true);
-  CB_LAUNCH(false);
-#undef CB_LAUNCH
+  hipLaunchKernelGGL((k_cgen_band<K, KW, NCB, FI>), dim3((unsigned)grid), dim3(NTHR), lds, s, a);
+  return hipGetLastError();
+}
+template <int K, int KW, int NCB>
+hipError_t launch_k(hipStream_t s, const CgenBandArgs& a, int num_cus) {
+  if (a.layer == 0) return launch_kf<K, KW, NCB, true>(s, a, num_cus);
+  return launch_kf<K, KW, NCB, false>(s, a, num_cus);
 }
 
 // NCB by the filter count; the shapes whose fragments fit the registers: plan_cgen_band_ok

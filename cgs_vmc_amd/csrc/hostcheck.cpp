@@ -399,7 +399,7 @@ static void conv_grid() {
                   const int bh = plan_cgen_band_rows(p.cg);
                   CHECK(F <= 64 && K >= 2 && K <= 7 && bh >= 1 && bh <= p.cg.D1);
                   CHECK(p.cg.K * p.cg.KW * 4 * plan_cgen_band_ncb(p.cg) <= PLAN_CGEN_BAND_MAX_FRAGS && plan_cgen_band_ncb(p.cg) <= 4);
-                  CHECK(plan_cgen_band_lds_bytes(p.cg, false) <= (size_t)(plan_cgen_band_ncb(p.cg) > 1 ? 64 * 1024 : PLAN_CGEN_BAND_LDS) &&
+                  CHECK(plan_cgen_band_lds_bytes(p.cg, false) <= (size_t)(plan_cgen_band_ncb(p.cg) > 1 ? PLAN_CGEN_BAND_LDS_WIDE : PLAN_CGEN_BAND_LDS) &&
                         plan_cgen_band_lds_bytes(p.cg, true) <= plan_cgen_band_lds_bytes(p.cg, false));
                   const int nb = (p.cg.D1 + bh - 1) / bh;
                   CHECK((long long)nb * bh >= p.cg.D1 && (long long)(nb - 1) * bh < p.cg.D1);

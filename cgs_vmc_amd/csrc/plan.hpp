@@ -105,12 +105,13 @@ PLAN_HD inline int plan_conv_tab(const ConvGeom& g) { return g.K <= 8 ? 8 : 16; 
 // (rows + K - 1) x (D2 + KW - 1) sites x 16 channels, in LDS; rows per band = as many as keep a band within
 // PLAN_CGEN_BAND_LDS bytes (several workgroups per CU); < 1: the lattice is too wide for a band
 #define PLAN_CGEN_BAND_LDS (40 * 1024)
+#define PLAN_CGEN_BAND_LDS_WIDE (144 * 1024)
 #define PLAN_CGEN_BAND_MAX_FRAGS 208      // weight fragments (registers) of one output block: K KW 4 NCB
 inline int plan_cgen_band_ncb(const ConvGeom& g) { return (g.F + 15) / 16; }
 inline int plan_cgen_band_rows(const ConvGeom& g) {
   const long long per_row = (long long)(g.D2 + g.KW - 1) * 16 * plan_cgen_band_ncb(g) * (long long)sizeof(float);
-  // one block: 40 KB (several workgroups per CU); more: up to 64 KB (two per CU), the halo of a thin band costs more than the second pair
-  long long bh = (plan_cgen_band_ncb(g) > 1 ? 64 * 1024 : PLAN_CGEN_BAND_LDS) / per_row - (g.K - 1);
+  // one block: 40 KB (several workgroups per CU); more: one workgroup per CU stages a band for all of its output blocks, up to 144 KB
+  long long bh = (plan_cgen_band_ncb(g) > 1 ? PLAN_CGEN_BAND_LDS_WIDE : PLAN_CGEN_BAND_LDS) / per_row - (g.K - 1);
   if (bh > g.D1) bh = g.D1;
   return (int)bh;
 }

@@ -480,8 +480,21 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
     if (const char* e = getenv("CGS_VMC_CONV_GENERAL_BLOCK_ROWS")) { const long long r = atoll(e); if (r >= 1 && r < rows) rows = r; }   // tests: several blocks at small shapes
     c->cg_rows = rows;
     // (cg_A, the im2col matrix: allocated by the first launch that writes one -- cgen_need_A, vmc_api_cgen.hip)
-    for (int i = 0; i < 2; ++i) CA(dalloc(&c->cg_fm[i], rows * cg.N * cgen_fp(cg)));
-    CA(dalloc(&c->cg_sum, rows)); CA(dalloc(&c->cg_zero, 1)); CA(dalloc(&c->cg_lnew, B));
+    // the band kernel (conv_band.hip) needs no im2col matrix: an untaped forward on it runs blocks sized by the two
+    // maps alone, up to 2 GB of them (36 x 36 x 16 filters: 370 rows per im2col block against 12,900 -- the local
+    // energies' 58 k rows were 110 blocks of partly filled launches)
+    long long rows_fwd = rows;
+    if (plan_cgen_band_ok(cg)) {
+      const long long per_row_maps = 2LL * cg.N * cgen_fp(cg) * (long long)sizeof(float);
+      rows_fwd = (2048LL << 20) / per_row_maps;
+      if (rows_fwd > (1LL << 30) / cg.N) rows_fwd = (1LL << 30) / cg.N;
+      if (rows_fwd > 131072) rows_fwd = 131072;
+      if (rows_fwd < rows) rows_fwd = rows;
+      if (getenv("CGS_VMC_CONV_GENERAL_BLOCK_ROWS")) rows_fwd = rows;      // tests: several blocks at small shapes
+    }
+    c->cg_rows_fwd = rows_fwd;
+    for (int i = 0; i < 2; ++i) CA(dalloc(&c->cg_fm[i], rows_fwd * cg.N * cgen_fp(cg)));
+    CA(dalloc(&c->cg_sum, rows_fwd)); CA(dalloc(&c->cg_zero, 1)); CA(dalloc(&c->cg_lnew, B));
     CA(hipMemsetAsync(c->cg_zero, 0, sizeof(float), c->stream));
     CA(dalloc(&c->wide_u, B)); CA(dalloc(&c->wide_iup, B)); CA(dalloc(&c->wide_idn, B));
   } else if (conv) {

@@ -95,9 +95,11 @@ int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2* rowinf
   };
   auto map = [&](int l) { return tape ? tape + (long long)l * tape_stride : c->cg_fm[g.resnet ? (l & 1 ? 1 : 0) : (l & 1)]; };
   if (tape && n_rows > c->cg_rows) return fail(c, VMC_ERR_STATE, "taped forward beyond one block");
-  for (long long blk0 = 0; blk0 < n_rows; blk0 += c->cg_rows) {
+  // block size: the im2col-sized one, or -- untaped, every convolution on the band kernel -- the maps-sized one
+  const long long blk_rows = (!tape && cgen_band_on() && cgen_band_ok(g)) ? c->cg_rows_fwd : c->cg_rows;
+  for (long long blk0 = 0; blk0 < n_rows; blk0 += blk_rows) {
     const long long row0 = first_row + blk0;
-    const int rows = (int)(n_rows - blk0 < c->cg_rows ? n_rows - blk0 : c->cg_rows);
+    const int rows = (int)(n_rows - blk0 < blk_rows ? n_rows - blk0 : blk_rows);
     const float* last;
     PROPAGATE(conv(0, rows, nullptr, map(0), row0));
     if (!g.resnet) {           // Conv2DNetwork (wavefunctions.py:572-575): act between the convolutions, none behind the last

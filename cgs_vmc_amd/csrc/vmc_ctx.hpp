@@ -76,7 +76,8 @@ struct vmc_ctx {
   double* wide_dot = nullptr;          // [ceil(H / 128)][wrows] row-dot partials of the last H x H layer (GemmArgs epilogue 10)
   // general convolution path (conv_general.hip; plan.hpp: conv beyond the fused kernels' limits): block buffers
   bool conv_general = false;
-  long long cg_rows = 0;                   // row configurations per block
+  long long cg_rows = 0;                   // row configurations per block (sized by the im2col matrix: the GEMM form, the gradient path)
+  long long cg_rows_fwd = 0;               // ... of an untaped forward whose convolutions all run on the band kernel (sized by the two maps)
   float* cg_A = nullptr;                   // im2col rows [cg_rows * N][plan_cgen_lda]
   float* cg_fm[2] = {nullptr, nullptr};    // feature maps [cg_rows][N][Fp] (cgen_post: activations; the cosine: pre-activations)
   double* cg_sum = nullptr;                // [cg_rows] sums of the last map
