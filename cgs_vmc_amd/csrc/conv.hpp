@@ -160,6 +160,10 @@ hipError_t launch_cgen_band(hipStream_t s, const CgenBandArgs& a, int num_cus);
 bool cgen_first_direct_ok(const ConvGeom& g, int epilogue);
 hipError_t launch_cgen_first_direct(hipStream_t s, const CgenBandArgs& a, int num_cus);
 hipError_t launch_cgen_rowsum(hipStream_t s, const float* fm, int rows, int N, int F, int Fp, double* out);
+// map sum + candidate logit + Metropolis test / commit + the next step's proposal, one workgroup per chain (k_cgen_step_tail)
+hipError_t launch_cgen_step_tail(hipStream_t s, const float* fm, int N, int F, int Fp, float* configs, float* logit, int B,
+                                 int oact, int* iup, int* idn, float* u, unsigned long long* accepted, uint32_t seed_lo,
+                                 uint32_t seed_hi, int chain_offset, unsigned long long next_step, bool do_propose);
 hipError_t launch_cgen_accept(hipStream_t s, float* configs, float* logit, const float* lnew, const int* iup,
                               const int* idn, const float* u, int B, int N, int oact, unsigned long long* accepted,
                               unsigned char* acc_mask);

@@ -140,6 +140,89 @@ __global__ __launch_bounds__(256) void k_cgen_accept(float* __restrict__ configs
   if (threadIdx.x == 0 && s_n) atomicAdd(accepted, (unsigned long long)s_n);
 }
 
+// The end of one mc_step and the start of the next in ONE launch (round 6): the sum of chain c's last map (k_cgen_rowsum's
+// arithmetic: thread-strided double sums, xor tree per wave, the four waves in order), the candidate's logit
+// (k_wide_out_part with one partial and a zero output bias: (float)sum + 0), the Metropolis test and commit
+// (k_cgen_accept), and the NEXT step's proposal from the chain as it then stands (k_wide_propose's arithmetic: one wave,
+// strict comparisons in site-block order, the lowest index among equal values across lanes) -- four launches of
+// 5 - 10 us each per step where a step's three convolutions take ~35 (36 x 36 sites, 32 chains).  One workgroup per chain.
+__global__ __launch_bounds__(256) void k_cgen_step_tail(const float* __restrict__ fm, int N, int F, int Fp,
+                                                        float* __restrict__ configs, float* __restrict__ logit, int oact,
+                                                        int* __restrict__ iup, int* __restrict__ idn, float* __restrict__ u,
+                                                        unsigned long long* __restrict__ accepted, uint32_t seed_lo,
+                                                        uint32_t seed_hi, int chain_offset, unsigned long long next_step,
+                                                        int do_propose) {
+  __shared__ double s_w[4];
+  __shared__ int s_flip[3];                       // accepted, the site raised, the site lowered
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const float* p = fm + (long long)c * N * Fp;
+  const int q = N * Fp / 4, fq = Fp / 4;
+  double s = 0.0;
+  for (int i = tid; i < q; i += 256) {
+    const f32x4 v = *(const f32x4*)(p + 4 * i);
+    const int c0 = 4 * (i % fq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += c0 + e < F ? (double)v[e] : 0.0;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+  if (lane == 0) s_w[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const double sd = 0.0 + ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+    const float lnew = (float)sd + 0.f;
+    const float uu = u[c];
+    const bool acc = vmc_out_accept(oact, lnew, logit[c], uu, 0.5f * __logf(uu));
+    const int dn = idn[c], up = iup[c];
+    if (acc) {
+      configs[(long long)c * N + dn] += 2.f;      // graph_builders.py:67-71
+      configs[(long long)c * N + up] -= 2.f;
+      logit[c] = lnew;
+      atomicAdd(accepted, 1ull);
+    }
+    s_flip[0] = acc ? 1 : 0; s_flip[1] = dn; s_flip[2] = up;
+  }
+  __syncthreads();
+  if (!do_propose || tid >= 64) return;
+  // the next proposal (graph_builders.py:59-65) from the committed chain: the spins as loaded, the accepted pair patched in
+  const bool acc = s_flip[0] != 0;
+  const int dn = s_flip[1], up = s_flip[2];
+  const float* x = configs + (long long)c * N;
+  const uint2 key = make_uint2(seed_lo, seed_hi);
+  const uint32_t gid = (uint32_t)(chain_offset + c);
+  float best_hi = -INFINITY, best_lo = INFINITY;
+  int idx_hi = 0x7fffffff, idx_lo = 0x7fffffff;
+  const int nblk = (N + 3) >> 2;
+  for (int b = lane; b < nblk; b += 64) {
+    const uint4 r = philox4x32_10(make_uint4((uint32_t)b, gid, (uint32_t)next_step, (uint32_t)(next_step >> 32)), key);
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * b + e;
+      if (i < N) {
+        float xi = x[i];
+        // (thread 0's stores above may or may not have reached this load: the value is taken from before the move and the
+        // move applied here -- spins are +-1, so x +- 2 is exact either way round)
+        if (acc && (i == dn || i == up)) xi = i == dn ? 1.f : -1.f;
+        const float v = xi * u32_to_uniform(rr[e]);
+        if (v > best_hi) { best_hi = v; idx_hi = i; }
+        if (v < best_lo) { best_lo = v; idx_lo = i; }
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float oh = __shfl_xor(best_hi, d); const int ih = __shfl_xor(idx_hi, d);
+    if (oh > best_hi || (oh == best_hi && ih < idx_hi)) { best_hi = oh; idx_hi = ih; }
+    const float ol = __shfl_xor(best_lo, d); const int il = __shfl_xor(idx_lo, d);
+    if (ol < best_lo || (ol == best_lo && il < idx_lo)) { best_lo = ol; idx_lo = il; }
+  }
+  if (lane == 0) {
+    const uint4 ra = philox4x32_10(make_uint4(VMC_ACCEPT_BLOCK, gid, (uint32_t)next_step, (uint32_t)(next_step >> 32)), key);
+    iup[c] = idx_hi; idn[c] = idx_lo; u[c] = u32_to_uniform(ra.x);
+  }
+}
+
 // ---- gradient path
 __device__ __forceinline__ float cg_dpre(int pre, float z) {    // f'(z) of the gather's activation
   if (pre < 0) return 1.f;
@@ -297,6 +380,15 @@ hipError_t launch_cgen_accept(hipStream_t s, float* configs, float* logit, const
                               unsigned char* acc_mask) {
   hipLaunchKernelGGL(k_cgen_accept, dim3((B + 255) / 256), dim3(256), 0, s, configs, logit, lnew, iup, idn, u, B, N,
                      oact, accepted, acc_mask);
+  return hipGetLastError();
+}
+
+hipError_t launch_cgen_step_tail(hipStream_t s, const float* fm, int N, int F, int Fp, float* configs, float* logit, int B,
+                                 int oact, int* iup, int* idn, float* u, unsigned long long* accepted, uint32_t seed_lo,
+                                 uint32_t seed_hi, int chain_offset, unsigned long long next_step, bool do_propose) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cgen_step_tail, dim3(B), dim3(256), 0, s, fm, N, F, Fp, configs, logit, oact, iup, idn, u, accepted,
+                     seed_lo, seed_hi, chain_offset, next_step, do_propose ? 1 : 0);
   return hipGetLastError();
 }
 

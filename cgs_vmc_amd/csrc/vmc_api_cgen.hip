@@ -82,6 +82,15 @@ static int cgen_conv(vmc_ctx* c, const ParamSet& p, const float* configs, const 
   return VMC_OK;
 }
 
+// an untaped forward of n_rows rows is ONE block (its last map is then still in place behind it: cgen_last_map)
+bool cgen_single_block(const vmc_ctx* c, long long n_rows) {
+  const long long blk_rows = (cgen_band_on() && cgen_band_ok(c->cg)) ? c->cg_rows_fwd : c->cg_rows;
+  return n_rows <= blk_rows;
+}
+const float* cgen_last_map(const vmc_ctx* c) {
+  return c->cg.resnet ? c->cg_fm[0] : c->cg_fm[(c->cg.n_conv - 1) & 1];
+}
+
 // tape != nullptr (gradient path, n_rows <= cg_rows): the map of convolution l is kept at tape + l * tape_stride
 // (cgen_post says what it holds; for the second convolution of a residual block the block's output h + v)
 int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2* rowinfo, long long n_rows,

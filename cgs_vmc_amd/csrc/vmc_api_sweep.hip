@@ -122,6 +122,24 @@ static int run_sweep_cgen(vmc_ctx* c, long long n_steps, bool injected, bool dbg
   PROPAGATE(ensure_cache(c, VMC_PSI));
   if (count_accepted) HIPCHK(c, hipMemsetAsync(c->d_accepted, 0, sizeof(unsigned long long), c->stream));
   Timer t(c, "sweep");
+  // One launch closes a step and opens the next (k_cgen_step_tail: map sum, candidate logit, accept, next proposal) where
+  // the candidates are one block of rows whose last map cgen_forward leaves in place; injected proposals (test hook) and
+  // CGS_VMC_CONV_STEP_TAIL=0 take the four separate launches
+  const char* tail_env = getenv("CGS_VMC_CONV_STEP_TAIL");
+  if (!injected && !(tail_env && atoi(tail_env) == 0) && cgen_single_block(c, B)) {
+    const ConvGeom& g = c->cg;
+    HIPCHK(c, launch_wide_propose(c->stream, c->configs, B, N, seed_lo, seed_hi, c->d.chain_offset, step0, nullptr, nullptr,
+                                  nullptr, c->wide_iup, c->wide_idn, c->wide_u));
+    for (long long st = 0; st < n_steps; ++st) {
+      PROPAGATE(cgen_forward(c, VMC_PSI, c->configs, nullptr, B, c->wide_iup, c->wide_idn, false, nullptr));
+      HIPCHK(c, launch_cgen_step_tail(c->stream, cgen_last_map(c), N, g.F, cgen_fp(g), c->configs, p.logit, B, c->oact,
+                                      c->wide_iup, c->wide_idn, c->wide_u, c->d_accepted, seed_lo, seed_hi,
+                                      c->d.chain_offset, step0 + (unsigned long long)st + 1, st + 1 < n_steps));
+    }
+    c->acts_valid = false;
+    c->acc_since_sweep = false;
+    return VMC_OK;
+  }
   for (long long st = 0; st < n_steps; ++st) {
     HIPCHK(c, launch_wide_propose(c->stream, c->configs, B, N, seed_lo, seed_hi, c->d.chain_offset,
                                   step0 + (unsigned long long)st, injected ? c->inj_up : nullptr,

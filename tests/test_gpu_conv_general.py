@@ -299,6 +299,31 @@ def test_band_kernel_agrees_with_im2col_gemm_and_the_oracle(monkeypatch, ansatz,
   eng.close()
 
 
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', [('conv_2d', 12, 12, 2, 16, 5, 9, 'relu'),       # band kernel
+                                                         ('res_net_2d', 4, 4, 2, 96, 3, 8, 'relu'),      # GEMM form, residual blocks
+                                                         ('conv_1d', 30, 1, 3, 100, 5, 9, 'relu')])
+def test_step_tail_launch_gives_the_chains_of_the_four_launches(monkeypatch, ansatz, sx, sy, L, f, k, b, nonlin):
+  """Round 6: k_cgen_step_tail (map sum + candidate logit + accept + next proposal in one launch) against the four
+  launches it replaces (CGS_VMC_CONV_STEP_TAIL=0, read per call): the same arithmetic in the same order, so chains,
+  accept counts and cached logits are the same bits, sweep after sweep."""
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6
+  out = {}
+  for tail in ('0', '1'):
+    monkeypatch.setenv('CGS_VMC_CONV_STEP_TAIL', tail)
+    eng.set_configs(cfg)
+    eng.step_counter = 0
+    acc1 = eng.mc_steps(7)
+    c1 = eng.get_configs()
+    acc2 = eng.mc_steps(2 * sx * sy)
+    out[tail] = (acc1, c1, acc2, eng.get_configs(), eng.amplitude()[0])
+  assert 0 < out['1'][2] <= 2 * sx * sy * b
+  for a, bb in zip(out['0'], out['1']):
+    np.testing.assert_array_equal(a, bb)
+  eng.close()
+
+
 def test_general_convolution_sr_op_by_op_two_phase_matvec():
   """The op-by-op CG loop on the general path (round 6): vmc_sr_matvec_phase1 -> [all-reduce of the buffer's last float]
   -> vmc_sr_matvec_phase2 -> [all-reduce of the buffer] -> vmc_sr_cg_update arrives where the one-call vmc_sr_solve
