@@ -234,6 +234,7 @@ static int cgen_weight_sums(vmc_ctx* c, int l, int rows, long long row0, const f
 // time: taped forward (the map of every convolution), d logit / d z_l of every convolution, then
 // d / d W_l = im2col(x_l)^T G_l with the bias as an implicit row of ones, one product per convolution for both sums.
 int cgen_gradient_sums(vmc_ctx* c, const float* w) {
+  c->cg_sr_tape_rows = 0;                  // (this path overwrites the tapes an SR solve may have left)
   const ConvGeom& g = c->cg;
   ParamSet& p = c->ps[0];
   PROPAGATE(cgen_grad_buffers(c));
@@ -265,10 +266,18 @@ int cgen_gradient_sums(vmc_ctx* c, const float* w) {
 // taped forward and the backward of a block; t_b = sum_l < G_l , im2col(x_l) V_l + v_l > is one more product per
 // convolution against the slice of v (phase 1), then the weight sums with t_b - c as the k-scale (phase 2; several
 // blocks: a second forward / backward pass, the mean needs every t first).
-static int cgen_sr_fwd_bwd(vmc_ctx* c, long long row0, int rows) {
+// (round 6: when the stored chains are ONE block, its tapes and G_l stay valid for every CG iteration of the running solve
+// -- the parameters do not change inside a solve; vmc_sr_begin and the gradient path, which shares the buffers, reset the mark)
+static int cgen_sr_fwd_bwd(vmc_ctx* c, long long row0, int rows, long long n_rows) {
+  const char* keep_env = getenv("CGS_VMC_SR_KEEP_TAPE");                 // 0: recompute every iteration (A/B; read per call)
+  const bool one_block = row0 == 0 && rows == n_rows && !(keep_env && atoi(keep_env) == 0);
+  if (one_block && c->cg_sr_tape_rows == n_rows) return VMC_OK;
+  c->cg_sr_tape_rows = 0;
   const long long map_floats = c->cg_rows * c->cg.N * cgen_fp(c->cg);
   PROPAGATE(cgen_forward(c, VMC_PSI, c->sr_cfg, nullptr, rows, nullptr, nullptr, false, nullptr, c->cg_tape, map_floats, row0));
-  return cgen_backward(c, rows, row0, nullptr);
+  PROPAGATE(cgen_backward(c, rows, row0, nullptr));
+  if (one_block) c->cg_sr_tape_rows = n_rows;
+  return VMC_OK;
 }
 int cgen_sr_phase1(vmc_ctx* c, const float* v, int n_rows) {        // sr_t[b] = O_b . v
   const ConvGeom& g = c->cg;
@@ -280,7 +289,7 @@ int cgen_sr_phase1(vmc_ctx* c, const float* v, int n_rows) {        // sr_t[b] =
     HIPCHK(c, launch_cgen_pack_t(c->stream, p.theta + cgen_off_w(g, l), g.K * g.KW, g.F, c->cg_wt + cgen_off_wt(g, l)));
   for (long long row0 = 0; row0 < n_rows; row0 += c->cg_rows) {
     const int rows = (int)(n_rows - row0 < c->cg_rows ? n_rows - row0 : c->cg_rows);
-    PROPAGATE(cgen_sr_fwd_bwd(c, row0, rows));
+    PROPAGATE(cgen_sr_fwd_bwd(c, row0, rows, n_rows));
     for (int l = 0; l < g.n_conv; ++l) {
       PROPAGATE(cgen_gather_input(c, l, rows, row0, c->sr_cfg));
       GemmArgs m; memset(&m, 0, sizeof(m));
@@ -300,7 +309,7 @@ int cgen_sr_phase2(vmc_ctx* c, int n_rows) {                         // sr_u[0 .
   const bool one_block = n_rows <= c->cg_rows;       // (then the tapes and G_l of phase 1 are still in place)
   for (long long row0 = 0; row0 < n_rows; row0 += c->cg_rows) {
     const int rows = (int)(n_rows - row0 < c->cg_rows ? n_rows - row0 : c->cg_rows);
-    if (!one_block) PROPAGATE(cgen_sr_fwd_bwd(c, row0, rows));
+    if (!one_block) PROPAGATE(cgen_sr_fwd_bwd(c, row0, rows, n_rows));
     HIPCHK(c, launch_cgen_wpos_centred(c->stream, c->sr_t, c->cg_centre, row0, rows, g.N, c->cg_wpos));
     for (int l = g.n_conv - 1; l >= 0; --l)
       PROPAGATE(cgen_weight_sums(c, l, rows, row0, c->sr_cfg, cgen_gl(c, l), nullptr, c->sr_u));

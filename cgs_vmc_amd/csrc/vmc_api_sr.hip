@@ -89,6 +89,7 @@ static int sr_read_rr(vmc_ctx* c, int idx, double* rr) {
 
 int vmc_sr_begin(vmc_ctx* c, double* rr0) {
   ENTER(c);
+  c->cg_sr_tape_rows = 0;        // a new solve: the general convolution path re-runs the stored chains' taped forward once
   if (c->sr_cap <= 0) return fail(c, VMC_ERR_STATE, "vmc_sr_reserve first");
   if (c->sr_n <= 0) return fail(c, VMC_ERR_STATE, "no samples recorded (vmc_accumulate in ENERGY_GRADIENT mode)");
   PROPAGATE(acc_zeros(c));

@@ -88,6 +88,8 @@ struct vmc_ctx {
   float* cg_tape = nullptr; float* cg_gl = nullptr; float* cg_g[2] = {nullptr, nullptr}; float* cg_wpos = nullptr; float* cg_wt = nullptr;
   float* cg_ws = nullptr; long long cg_ws_floats = 0;
   double* cg_td = nullptr;                 // [cg_rows] O_b . v of a block (SR)
+  long long cg_sr_tape_rows = 0;           // > 0: cg_tape / cg_gl hold the taped forward and the backward of the first that many STORED chains
+                                           // at the parameters of the running solve (one block: kept across its CG iterations)
   float* cg_centre = nullptr;              // [1] mean of O_b . v over the stored samples (SR)
   bool sr_centre = false;                  // the SR matvec may centre its weights: a single-rank solve is running
   bool sr_phase1_done = false;             // vmc_sr_matvec_phase1 has run for the current CG direction (general convolution path)

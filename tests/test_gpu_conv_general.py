@@ -324,6 +324,43 @@ def test_step_tail_launch_gives_the_chains_of_the_four_launches(monkeypatch, ans
   eng.close()
 
 
+def test_general_convolution_sr_keeps_the_tape_across_cg_iterations(monkeypatch):
+  """Round 6: with the stored chains in one block the taped forward and the backward run once per solve instead of once
+  per CG iteration (CGS_VMC_SR_KEEP_TAPE=0: every iteration, read per call) -- the same numbers go into every product,
+  so iterations, residual and solution are the same bits; and the solve is faster."""
+  import time
+  from cgs_vmc_amd.engine import VmcEngine
+  ansatz, n, L, f, k, b, n_store = 'conv_1d', 24, 3, 8, 11, 64, 3
+  geom = (f, k, n, 1)
+  rng = np.random.default_rng(0)
+  theta = vo.conv_init_params(ansatz, geom, L, rng)
+  theta += (0.03 * rng.standard_normal(theta.size)).astype(np.float32)
+  eng = VmcEngine(n, b, L, f, nonlinearity='tanh', seed=2024, ansatz=ansatz, kernel_size=k, size_x=n, size_y=1)
+  assert eng.kernel_path() == 6
+  eng.set_params(theta)
+  eng.set_bonds(vo.chain_bonds(n), -1.0, 1.0)
+  eng.sr_reserve(n_store)
+  eng.reset_accumulators()
+  for j in range(n_store):
+    eng.set_configs(vo.random_configurations(n, b, np.random.RandomState(20 + j)))
+    eng.accumulate(0)
+  out, secs = {}, {}
+  for keep in ('0', '1', '0', '1'):
+    monkeypatch.setenv('CGS_VMC_SR_KEEP_TAPE', keep)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    it, res = eng.sr_solve(0.01, 0.0, 40)
+    x = eng.sr_get_solution()
+    secs[keep] = time.perf_counter() - t0
+    out[keep] = (it, res, x)
+  assert out['0'][0] == out['1'][0] == 40 and out['0'][1] == out['1'][1]
+  np.testing.assert_array_equal(out['0'][2], out['1'][2])
+  print('\n40 CG iterations over {} stored chains: {:.1f} ms recomputing the tape, {:.1f} ms keeping it'.format(
+      n_store * b, 1e3 * secs['0'], 1e3 * secs['1']))
+  assert secs['1'] < secs['0']
+  eng.close()
+
+
 def test_general_convolution_sr_op_by_op_two_phase_matvec():
   """The op-by-op CG loop on the general path (round 6): vmc_sr_matvec_phase1 -> [all-reduce of the buffer's last float]
   -> vmc_sr_matvec_phase2 -> [all-reduce of the buffer] -> vmc_sr_cg_update arrives where the one-call vmc_sr_solve
