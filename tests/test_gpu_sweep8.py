@@ -126,3 +126,34 @@ def test_trajectory_follows_oracle_on_either_tile(tile):
     np.testing.assert_array_equal(eng.get_configs()[ok], cur[ok])
   assert ok.sum() > b // 2
   eng.close()
+
+
+def test_sharding_changes_the_tile_not_the_chains():
+  """4,096 chains on one engine take sixteen-chain tiles, the same chains as four shards of 1,024 take eight-chain tiles
+  (vmc_create's rule looks at the LOCAL batch): chains, accept counts and local energies are the same bits -- the
+  property that keeps results independent of the number of GPUs (Philox keyed by the global chain id)."""
+  from cgs_vmc_amd.engine import VmcEngine
+  n, h, L, b, shards = 100, 256, 3, 4096, 4
+  rng = np.random.default_rng(11)
+  theta = vo.init_params(n, h, L, rng)
+  theta += (0.05 * rng.standard_normal(theta.size)).astype(np.float32)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(12))
+  bonds = vo.torus_bonds(10, 10)
+  full = VmcEngine(n, b, L, h, seed=2024)
+  full.set_params(theta); full.set_configs(cfg); full.set_bonds(bonds, -1.0, 1.0)
+  assert full.sweep_tile() == 16
+  acc_full = full.mc_steps(2 * n)
+  cfg_full = full.get_configs()
+  eloc_full = full.local_energy()[0]
+  full.close()
+  lb = b // shards
+  acc_sum = 0
+  for r in range(shards):
+    eng = VmcEngine(n, lb, L, h, seed=2024, chain_offset=r * lb)
+    eng.set_params(theta); eng.set_configs(cfg[r * lb:(r + 1) * lb]); eng.set_bonds(bonds, -1.0, 1.0)
+    assert eng.sweep_tile() == 8
+    acc_sum += eng.mc_steps(2 * n)
+    np.testing.assert_array_equal(eng.get_configs(), cfg_full[r * lb:(r + 1) * lb])
+    np.testing.assert_array_equal(eng.local_energy()[0], eloc_full[r * lb:(r + 1) * lb])
+    eng.close()
+  assert acc_sum == acc_full
