@@ -157,3 +157,31 @@ def test_sharding_changes_the_tile_not_the_chains():
     np.testing.assert_array_equal(eng.local_energy()[0], eloc_full[r * lb:(r + 1) * lb])
     eng.close()
   assert acc_sum == acc_full
+
+
+@pytest.mark.parametrize('oact', ['tanh', 'identity', 'sigmoid'])
+def test_non_exp_output_activations_on_eight_chain_tiles(oact):
+  """psi = g(x) with g != exp: the accept rule is |g(x')| / |g(x)| > sqrt(u) in the linear domain (common.hpp:
+  vmc_out_accept), evaluated by the group that owns the chain in k_sweep8 as by the owning wave in k_sweep16 -- the same
+  chains, accept counts and local energies (tests/test_gpu_activations.py checks the sixteen-chain kernel against the
+  oracle at 64 units, where no eight-chain kernel exists)."""
+  from cgs_vmc_amd.engine import VmcEngine
+  n, h, L, b = 16, 128, 3, 72
+  rng = np.random.default_rng(21)
+  theta = vo.init_params(n, h, L, rng)
+  theta += (0.05 * rng.standard_normal(theta.size)).astype(np.float32)
+  theta[-1] = 0.8                                   # b_out: keeps g(x) away from 0 for the bounded activations
+  cfg = vo.random_configurations(n, b, np.random.RandomState(22))
+  eng = VmcEngine(n, b, L, h, output_activation=oact, seed=2024)
+  eng.set_params(theta); eng.set_bonds(vo.torus_bonds(4, 4), -1.0, 1.0)
+  out = {}
+  for tile in (16, 8):
+    assert eng.sweep_tile(tile) == tile
+    eng.set_configs(cfg)
+    eng.step_counter = 0
+    acc = eng.mc_steps(5 * n)
+    out[tile] = (acc, eng.get_configs(), eng.amplitude()[0], eng.local_energy()[0])
+  assert 0 < out[16][0] < 5 * n * b
+  for a, bb in zip(out[16], out[8]):
+    np.testing.assert_array_equal(a, bb)
+  eng.close()
