@@ -185,3 +185,40 @@ def test_non_exp_output_activations_on_eight_chain_tiles(oact):
   for a, bb in zip(out[16], out[8]):
     np.testing.assert_array_equal(a, bb)
   eng.close()
+
+
+@pytest.mark.parametrize('optimizer', ['EnergyGradient', 'LogOverlapITSWO'])
+def test_training_epochs_do_not_depend_on_the_tile(optimizer):
+  """Two device-resident epochs (vmc_epoch_energy_gradient + Adam / vmc_epoch_log_overlap, whose supervisor refresh is a
+  zero-step sampler launch) from the same start on sixteen- and on eight-chain tiles: the parameters, the Adam moments
+  and the chains afterwards are the same bits (reference defaults' shape: 40 sites, 80 units padded to 128, 200 chains)."""
+  from cgs_vmc_amd.engine import VmcEngine
+  n, h, L, b = 40, 80, 3, 200
+  rng = np.random.default_rng(31)
+  theta = vo.init_params(n, h, L, rng)
+  cfg = vo.random_configurations(n, b, np.random.RandomState(32))
+  eng = VmcEngine(n, b, L, h, seed=2024)
+  eng.set_bonds(vo.chain_bonds(n), -1.0, 1.0)
+  out = {}
+  for tile in (16, 8):
+    assert eng.sweep_tile(tile) == tile
+    eng.set_params(theta)
+    eng.set_adam_state(np.zeros(theta.size, np.float32), np.zeros(theta.size, np.float32), 0)
+    eng.set_shift(-10.0)
+    eng.set_configs(cfg)
+    eng.step_counter = 0
+    energies = []
+    for epoch in range(2):
+      if optimizer == 'EnergyGradient':
+        eng.epoch_energy_gradient(3 * n, 4, n, 1e10)
+        energies.append(eng.apply_adam(0, 1e-3))
+      else:
+        eng.transfer_params()
+        energies.append(eng.epoch_log_overlap(0.12, 3 * n, 4, n, 1e10, 1e-3, 0.9, 0.99, 1e-8))
+    m, v, t = eng.get_adam_state()
+    out[tile] = (np.float64(energies), eng.get_params(), m, v, eng.get_configs())
+    assert t > 0 and np.isfinite(energies).all()
+  assert (out[16][1] != theta).any()
+  for a, bb in zip(out[16], out[8]):
+    np.testing.assert_array_equal(a, bb)
+  eng.close()
