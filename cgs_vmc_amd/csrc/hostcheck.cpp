@@ -452,6 +452,18 @@ static void conv_grid() {
     b.layer_size = 16; b.num_layers = 3; b.size_x = b.size_y = 36; b.n_sites = 1296; b.batch_size = 32;
     CHECK(plan_desc(&b, true, &q, msg, sizeof(msg)) == VMC_OK && q.conv_general && plan_cgen_band_ok(q.cg));
     CHECK(plan_cgen_band_rows(q.cg) == 12 && plan_cgen_band_lds_bytes(q.cg, false) == 16u * 40u * 64u);
+    // the sampler's chain groups: one where the launches are latency, two for the one-workgroup-per-CU band kernel
+    CHECK(plan_cgen_sweep_groups(q.cg, 32, 256) == 1);
+    b.layer_size = 64; b.kernel_size = 3;
+    CHECK(plan_desc(&b, true, &q, msg, sizeof(msg)) == VMC_OK && q.conv_general && plan_cgen_band_ok(q.cg));
+    CHECK(plan_cgen_sweep_groups(q.cg, 32, 256) == 2 && plan_cgen_sweep_groups(q.cg, 1, 256) == 1);
+    // ... and for the GEMM form where the last round of row tiles is mostly empty (800 tiles: 3.125 rounds of 256 CUs)
+    b.layer_size = 128; b.size_x = b.size_y = 10; b.n_sites = 100; b.batch_size = 1024;
+    CHECK(plan_desc(&b, true, &q, msg, sizeof(msg)) == VMC_OK && q.conv_general && !plan_cgen_band_ok(q.cg));
+    CHECK(plan_cgen_sweep_groups(q.cg, 1024, 256) == 2);       // 800 tiles
+    CHECK(plan_cgen_sweep_groups(q.cg, 4096, 256) == 1);       // 3,200 tiles: 12.5 rounds, 0.96 full
+    CHECK(plan_cgen_sweep_groups(q.cg, 256, 256) == 1);        // 200 tiles: less than a round
+    CHECK(plan_cgen_sweep_groups(q.cg, 1280, 256) == 1);       // 1,000 tiles: 3.9 rounds
   }
   d.kernel_size = 10;
   d.kernel_size = 5; d.size_x = 9;

@@ -138,6 +138,21 @@ inline bool plan_cgen_band_ok(const ConvGeom& g) {
   if (g.K * g.KW * 4 * plan_cgen_band_ncb(g) > PLAN_CGEN_BAND_MAX_FRAGS) return false;
   return plan_cgen_band_rows(g) >= 1;
 }
+// Chain groups of the general convolution sampler (run_sweep_cgen: a step of each group on a stream of its own).  Two
+// groups where a launch over the whole batch leaves CUs idle that the next launch of the other group can use: the GEMM
+// form with more than one round of 128-position row tiles whose last round is less than 0.9 full (1,024 chains on a
+// 10 x 10 lattice: 800 tiles on 256 CUs, 3.125 rounds paid as 4), and the one-workgroup-per-CU band kernel from one
+// round of positions on (its tail: measured, 36 x 36 x 64 filters at 32 chains: 161 -> 151 ms per sweep).  One group where
+// the launches are latency (36 x 36 x 16 filters at 32 chains: 68 -> 73 ms with two, 214 with four -- the host's launch rate).
+inline int plan_cgen_sweep_groups(const ConvGeom& g, long long B, int num_cus) {
+  if (B < 2 || num_cus < 1) return 1;
+  const long long positions = B * g.N;
+  if (plan_cgen_band_ok(g)) return (plan_cgen_band_ncb(g) > 1 && positions >= 128LL * num_cus) ? 2 : 1;
+  const long long tiles = ((positions + 127) / 128) * ((g.F + 127) / 128);
+  if (tiles <= num_cus) return 1;
+  const long long rounds = (tiles + num_cus - 1) / num_cus;
+  return tiles * 10 < rounds * num_cus * 9 ? 2 : 1;
+}
 // k_cgen_first_direct (conv_band.hip): spins [N], weights [taps][Fp], bias [Fp], neighbour table [N][taps]
 inline size_t plan_cgen_first_direct_lds_bytes(const ConvGeom& g) {
   const size_t fp = (size_t)((g.F + 3) & ~3), t = (size_t)g.K * g.KW;

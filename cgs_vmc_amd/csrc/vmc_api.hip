@@ -531,6 +531,8 @@ void vmc_destroy(vmc_ctx* c) {
   hipStreamSynchronize(c->stream);
   drain_timings(c);
   if (c->sweep_stream) hipStreamDestroy(c->sweep_stream);
+  for (hipStream_t q : c->cg_grp_stream) if (q) { hipStreamSynchronize(q); hipStreamDestroy(q); }
+  for (hipEvent_t e : c->cg_grp_ev) if (e) hipEventDestroy(e);
   for (hipEvent_t e : {c->ev_mark, c->ev_now, c->ev_sweep_done}) if (e) hipEventDestroy(e);
   for (auto& e : c->event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   for (int w = 0; w < 2; ++w) {

@@ -34,6 +34,9 @@ static int cgen_need_A(vmc_ctx* c) {
 // CGS_VMC_CONV_BAND=0: the im2col + GEMM form for every filter count (read per call: A/B tests in one process)
 static bool cgen_band_on() { const char* e = getenv("CGS_VMC_CONV_BAND"); return !(e && atoi(e) == 0); }
 
+// the stream of the forward launches: `stream`, or the running sampler group's (run_sweep_cgen)
+static hipStream_t cg_s(const vmc_ctx* c) { return c->cg_stream_cur ? c->cg_stream_cur : c->stream; }
+
 static int cgen_conv(vmc_ctx* c, const ParamSet& p, const float* configs, const int2* rowinfo, const int* iup,
                      const int* idn, int l, int rows, const float* in, float* dst, long long row0) {
   const ConvGeom& g = c->cg;
@@ -55,30 +58,30 @@ static int cgen_conv(vmc_ctx* c, const ParamSet& p, const float* configs, const 
       b.configs = configs; b.rowinfo = rowinfo; b.row0 = row0; b.bonds = c->bonds ? c->bonds : c->bond_dummy;
       b.iup = iup; b.idn = idn;
     }
-    if (cgen_band_ok(g)) HIPCHK(c, launch_cgen_band(c->stream, b, c->num_cus));
-    else HIPCHK(c, launch_cgen_first_direct(c->stream, b, c->num_cus));     // more than 16 filters: the first convolution only
+    if (cgen_band_ok(g)) HIPCHK(c, launch_cgen_band(cg_s(c), b, c->num_cus));
+    else HIPCHK(c, launch_cgen_first_direct(cg_s(c), b, c->num_cus));     // more than 16 filters: the first convolution only
     return VMC_OK;
   }
   // the gather inside the product's A operand (k_gemm_ring<., true>): no im2col matrix for this convolution
   if (l > 0 && pre < 0 && cgen_implicit_on()) {
     m.A = in; m.conv_a = 1; m.ca_N = g.N; m.ca_D1 = g.D1; m.ca_D2 = g.D2; m.ca_KW = g.KW; m.ca_lo = g.lo; m.ca_lo2 = g.lo2;
     m.ca_F = g.F; m.ca_Fp = Fp;
-    if (gemm_conv_a_ok(m)) { HIPCHK(c, launch_gemm(c->stream, m)); return VMC_OK; }
+    if (gemm_conv_a_ok(m)) { HIPCHK(c, launch_gemm(cg_s(c), m)); return VMC_OK; }
     m.conv_a = 0;
   }
   PROPAGATE(cgen_need_A(c));
   CgenIm2colArgs a;
   memset(&a, 0, sizeof(a));
-  a.g = g; a.layer = l; a.Fp = Fp; a.pre_act = pre; a.rows = rows; a.lda = lda; a.A = c->cg_A;
+  a.g = g; a.layer = l; a.Fp = Fp; a.pre_act = pre; a.rows = rows; a.lda = lda; a.A = c->cg_A + c->cg_map_row0 * g.N * lda;
   if (l == 0) {
     a.src = configs; a.rowinfo = rowinfo; a.row0 = row0; a.bonds = c->bonds ? c->bonds : c->bond_dummy;
     a.iup = iup; a.idn = idn;
   } else {
     a.src = in;
   }
-  HIPCHK(c, launch_cgen_im2col(c->stream, a));
-  m.A = c->cg_A; m.sam = lda; m.sak = 1;
-  HIPCHK(c, launch_gemm(c->stream, m));
+  HIPCHK(c, launch_cgen_im2col(cg_s(c), a));
+  m.A = c->cg_A + c->cg_map_row0 * g.N * lda; m.sam = lda; m.sak = 1;
+  HIPCHK(c, launch_gemm(cg_s(c), m));
   return VMC_OK;
 }
 
@@ -88,7 +91,7 @@ bool cgen_single_block(const vmc_ctx* c, long long n_rows) {
   return n_rows <= blk_rows;
 }
 const float* cgen_last_map(const vmc_ctx* c) {
-  return c->cg.resnet ? c->cg_fm[0] : c->cg_fm[(c->cg.n_conv - 1) & 1];
+  return (c->cg.resnet ? c->cg_fm[0] : c->cg_fm[(c->cg.n_conv - 1) & 1]) + c->cg_map_row0 * c->cg.N * cgen_fp(c->cg);
 }
 
 // tape != nullptr (gradient path, n_rows <= cg_rows): the map of convolution l is kept at tape + l * tape_stride
@@ -102,7 +105,8 @@ int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2* rowinf
   auto conv = [&](int l, int rows, const float* in, float* dst, long long row0) -> int {
     return cgen_conv(c, p, configs, rowinfo, iup, idn, l, rows, in, dst, row0);
   };
-  auto map = [&](int l) { return tape ? tape + (long long)l * tape_stride : c->cg_fm[g.resnet ? (l & 1 ? 1 : 0) : (l & 1)]; };
+  const long long moff = c->cg_map_row0 * g.N * Fp;      // (a sampler group's slice of the maps; 0 elsewhere)
+  auto map = [&](int l) { return tape ? tape + (long long)l * tape_stride : c->cg_fm[g.resnet ? (l & 1 ? 1 : 0) : (l & 1)] + moff; };
   if (tape && n_rows > c->cg_rows) return fail(c, VMC_ERR_STATE, "taped forward beyond one block");
   // block size: the im2col-sized one, or -- untaped, every convolution on the band kernel -- the maps-sized one
   const long long blk_rows = (!tape && cgen_band_on() && cgen_band_ok(g)) ? c->cg_rows_fwd : c->cg_rows;
@@ -117,19 +121,19 @@ int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2* rowinf
       last = map(g.n_conv - 1);
     } else {                   // ResNet2D (wavefunctions.py:766-772; layers.py:226-228): h += second(selu(first(h)))
       for (int l = 1; l + 1 < g.n_conv; l += 2) {
-        const float* h = tape ? map(l - 1) : c->cg_fm[0];
-        float* u = tape ? map(l) : c->cg_fm[1];
-        float* hn = tape ? map(l + 1) : c->cg_fm[0];
+        const float* h = tape ? map(l - 1) : c->cg_fm[0] + moff;
+        float* u = tape ? map(l) : c->cg_fm[1] + moff;
+        float* hn = tape ? map(l + 1) : c->cg_fm[0] + moff;
         PROPAGATE(conv(l, rows, h, u, row0));
-        if (tape) HIPCHK(c, hipMemcpyAsync(hn, h, (size_t)rows * g.N * Fp * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        if (tape) HIPCHK(c, hipMemcpyAsync(hn, h, (size_t)rows * g.N * Fp * sizeof(float), hipMemcpyDeviceToDevice, cg_s(c)));
         PROPAGATE(conv(l + 1, rows, u, hn, row0));
       }
-      last = tape ? map(g.n_conv - 1) : c->cg_fm[0];
+      last = tape ? map(g.n_conv - 1) : c->cg_fm[0] + moff;
     }
     if (!out) continue;        // (taped forward of the SR matvec: the maps are all that is wanted)
-    HIPCHK(c, launch_cgen_rowsum(c->stream, last, rows, g.N, g.F, Fp, c->cg_sum));
+    HIPCHK(c, launch_cgen_rowsum(cg_s(c), last, rows, g.N, g.F, Fp, c->cg_sum));
     const WideOnsite on{nullptr, nullptr, nullptr, nullptr, nullptr};
-    HIPCHK(c, launch_wide_out_part(c->stream, c->cg_sum, 1, c->cg_zero, rows, rowinfo ? rowinfo : c->rowinfo_id, row0,
+    HIPCHK(c, launch_wide_out_part(cg_s(c), c->cg_sum, 1, c->cg_zero, rows, rowinfo ? rowinfo : c->rowinfo_id, row0,
                                    c->half_jx, p.logit, c->oact, ratio, out, on));
   }
   return VMC_OK;

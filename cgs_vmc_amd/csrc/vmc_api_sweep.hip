@@ -106,6 +106,16 @@ int refresh_cache_by_sampler(vmc_ctx* c, int which) {
   return VMC_OK;
 }
 
+// Chain groups of the general convolution sampler (plan.hpp's rule; CGS_VMC_CONV_GENERAL_GROUPS=1..4 forces, read per call)
+static int cgen_sweep_groups(const vmc_ctx* c) {
+  int G = plan_cgen_sweep_groups(c->cg, c->B, c->num_cus);
+  if (const char* e = getenv("CGS_VMC_CONV_GENERAL_GROUPS")) G = atoi(e);
+  if (G < 1) G = 1;
+  if (G > 4) G = 4;
+  if (G > c->B) G = (int)c->B;
+  return G;
+}
+
 // The sampler of the general convolution path: per mc_step the proposals (k_wide_propose: the Philox streams and the
 // arg-max / arg-min rule of every sampler here), a full forward of the B candidates (the exchanged pair negated as the
 // first convolution gathers its operand), the Metropolis test and commit.  In place on configs / logit.
@@ -130,12 +140,45 @@ static int run_sweep_cgen(vmc_ctx* c, long long n_steps, bool injected, bool dbg
     const ConvGeom& g = c->cg;
     HIPCHK(c, launch_wide_propose(c->stream, c->configs, B, N, seed_lo, seed_hi, c->d.chain_offset, step0, nullptr, nullptr,
                                   nullptr, c->wide_iup, c->wide_idn, c->wide_u));
-    for (long long st = 0; st < n_steps; ++st) {
-      PROPAGATE(cgen_forward(c, VMC_PSI, c->configs, nullptr, B, c->wide_iup, c->wide_idn, false, nullptr));
-      HIPCHK(c, launch_cgen_step_tail(c->stream, cgen_last_map(c), N, g.F, cgen_fp(g), c->configs, p.logit, B, c->oact,
-                                      c->wide_iup, c->wide_idn, c->wide_u, c->d_accepted, seed_lo, seed_hi,
-                                      c->d.chain_offset, step0 + (unsigned long long)st + 1, st + 1 < n_steps));
+    // Chain groups: the chains are independent (graph_builders.py:57-88 maps one update over the batch), so the batch is
+    // cut into G contiguous groups whose steps run on streams of their own.  A launch of one group that leaves CUs idle
+    // (800 row tiles of 128 positions on 256 CUs: the fourth round is one eighth full) then runs beside the next launch
+    // of another group, and launches that are latency (a 36 x 36 lattice at 32 chains) hide each other's.  Every row is
+    // computed by the same kernel in the same k order wherever its tile lies: the chains do not depend on G
+    // (tests/test_gpu_conv_general.py).  How many: plan_cgen_sweep_groups.
+    const int G = cgen_sweep_groups(c);
+    if (G > 1) {
+      for (int i = 0; i < G - 1; ++i)
+        if (!c->cg_grp_stream[i]) HIPCHK(c, hipStreamCreateWithFlags(&c->cg_grp_stream[i], hipStreamNonBlocking));
+      for (int i = 0; i < G; ++i)
+        if (!c->cg_grp_ev[i]) HIPCHK(c, hipEventCreateWithFlags(&c->cg_grp_ev[i], hipEventDisableTiming));
+      HIPCHK(c, hipEventRecord(c->cg_grp_ev[0], c->stream));
+      for (int i = 0; i < G - 1; ++i) HIPCHK(c, hipStreamWaitEvent(c->cg_grp_stream[i], c->cg_grp_ev[0], 0));
     }
+    int rc = VMC_OK;
+    for (long long st = 0; st < n_steps && rc == VMC_OK; ++st) {
+      for (int gi = 0; gi < G && rc == VMC_OK; ++gi) {
+        const long long r0 = (long long)B * gi / G, r1 = (long long)B * (gi + 1) / G;
+        const int rows = (int)(r1 - r0);
+        hipStream_t s = gi ? c->cg_grp_stream[gi - 1] : c->stream;
+        c->cg_stream_cur = s; c->cg_map_row0 = r0;
+        rc = cgen_forward(c, VMC_PSI, c->configs, nullptr, rows, c->wide_iup, c->wide_idn, false, nullptr, nullptr, 0, r0);
+        const float* last = cgen_last_map(c);
+        c->cg_stream_cur = nullptr; c->cg_map_row0 = 0;
+        if (rc != VMC_OK) break;
+        if (launch_cgen_step_tail(s, last, N, g.F, cgen_fp(g), c->configs + r0 * N, p.logit + r0, rows, c->oact,
+                                  c->wide_iup + r0, c->wide_idn + r0, c->wide_u + r0, c->d_accepted, seed_lo, seed_hi,
+                                  c->d.chain_offset + (int)r0, step0 + (unsigned long long)st + 1,
+                                  st + 1 < n_steps) != hipSuccess)
+          rc = fail(c, VMC_ERR_HIP, "k_cgen_step_tail launch");
+      }
+    }
+    // `stream` takes the groups' work back (also behind a failed launch: nothing may be left running on its own)
+    for (int i = 1; i < G; ++i) {
+      HIPCHK(c, hipEventRecord(c->cg_grp_ev[i], c->cg_grp_stream[i - 1]));
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->cg_grp_ev[i], 0));
+    }
+    if (rc != VMC_OK) return rc;
     c->acts_valid = false;
     c->acc_since_sweep = false;
     return VMC_OK;

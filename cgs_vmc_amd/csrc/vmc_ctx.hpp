@@ -83,6 +83,12 @@ struct vmc_ctx {
   double* cg_sum = nullptr;                // [cg_rows] sums of the last map
   float* cg_zero = nullptr;                // one 0.f (the "b_out" of wide_out_finish)
   float* cg_lnew = nullptr;                // [B] candidate logits of the sampler
+  // the sampler's chain groups (run_sweep_cgen): group 0 on `stream`, the others on streams of their own, so that the
+  // partly filled last round of one group's launch runs beside the next launch of another
+  hipStream_t cg_grp_stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t cg_grp_ev[4] = {nullptr, nullptr, nullptr, nullptr};    // [0]: `stream` is ready; [g]: group g has finished
+  hipStream_t cg_stream_cur = nullptr;     // the stream cgen_conv / cgen_forward launch on (null: `stream`)
+  long long cg_map_row0 = 0;               // first row of cg_fm / cg_A an untaped forward writes (a group's slice)
   // ... its gradient path (allocated by the first gradient call): the map of every convolution (the tape), two
   // d logit / d map buffers, per-position weights, the transposed weight images, the split-K workspace
   float* cg_tape = nullptr; float* cg_gl = nullptr; float* cg_g[2] = {nullptr, nullptr}; float* cg_wpos = nullptr; float* cg_wt = nullptr;

@@ -324,6 +324,33 @@ def test_step_tail_launch_gives_the_chains_of_the_four_launches(monkeypatch, ans
   eng.close()
 
 
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', [('conv_2d', 12, 12, 2, 16, 5, 9, 'relu'),       # band kernel
+                                                         ('conv_2d', 10, 10, 3, 128, 3, 37, 'relu'),     # implicit-gather ring, 29 row tiles
+                                                         ('res_net_2d', 4, 4, 2, 96, 3, 8, 'relu'),      # residual blocks
+                                                         ('conv_1d', 30, 1, 3, 100, 5, 3, 'cos')])       # im2col form; 3 chains in 4 groups
+def test_sampler_chain_groups_leave_the_chains_alone(monkeypatch, ansatz, sx, sy, L, f, k, b, nonlin):
+  """Round 6: the general sampler runs its batch as G chain groups on streams of their own (run_sweep_cgen; default 2,
+  CGS_VMC_CONV_GENERAL_GROUPS read per call).  A row's value does not depend on the launch or tile it sits in, so chains,
+  accept counts and cached logits are the same bits for every G -- and the groups' maps are disjoint slices."""
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6
+  out = {}
+  for groups in ('1', '2', '3', '4'):
+    monkeypatch.setenv('CGS_VMC_CONV_GENERAL_GROUPS', groups)
+    eng.set_configs(cfg)
+    eng.step_counter = 0
+    acc1 = eng.mc_steps(5)
+    c1 = eng.get_configs()
+    acc2 = eng.mc_steps(sx * sy)
+    out[groups] = (acc1, c1, acc2, eng.get_configs(), eng.amplitude()[0])
+  assert 0 < out['1'][2] <= sx * sy * b
+  for groups in ('2', '3', '4'):
+    for a, bb in zip(out['1'], out[groups]):
+      np.testing.assert_array_equal(a, bb)
+  eng.close()
+
+
 def test_general_convolution_sr_keeps_the_tape_across_cg_iterations(monkeypatch):
   """Round 6: with the stored chains in one block the taped forward and the backward run once per solve instead of once
   per CG iteration (CGS_VMC_SR_KEEP_TAPE=0: every iteration, read per call) -- the same numbers go into every product,
