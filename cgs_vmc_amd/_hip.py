@@ -147,7 +147,7 @@ _lib = None
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 _STAMP_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libcgsvmc_hip.stamp')
 # the files the library is built from, in the order csrc/Makefile hashes them
-_SOURCES = ('vmc_api.hip', 'vmc_api_cgen.hip', 'vmc_api_sweep.hip', 'vmc_api_train.hip', 'vmc_api_coll.hip', 'vmc_api_sr.hip', 'mlp.hip', 'eloc.hip', 'grad.hip', 'sr.hip', 'srmm.hip', 'conv.hip', 'conv32.hip', 'conv48.hip', 'conv64.hip', 'conv_general.hip', 'conv_band.hip', 'wide.hip', 'tail_split.hip', 'sweep_split.hip', 'sweep8.hip', 'act_tail.hip',
+_SOURCES = ('vmc_api.hip', 'vmc_api_cgen.hip', 'vmc_api_sweep.hip', 'vmc_api_train.hip', 'vmc_api_coll.hip', 'vmc_api_sr.hip', 'mlp.hip', 'eloc.hip', 'grad.hip', 'sr.hip', 'srmm.hip', 'conv.hip', 'conv32.hip', 'conv48.hip', 'conv64.hip', 'conv_general.hip', 'conv_band.hip', 'conv_patch.hip', 'wide.hip', 'tail_split.hip', 'sweep_split.hip', 'sweep8.hip', 'act_tail.hip',
             'act_sweep.hip', 'vmc_ctx.hpp', 'plan.hpp', 'common.hpp', 'tail16.hpp', 'tail_lds.hpp', 'sweep16.hpp', 'conv.hpp', 'conv_kernels.hpp',
             'conv_wide.hpp',
             os.path.join('..', '..', 'include', 'cgsvmc.h'), 'Makefile')

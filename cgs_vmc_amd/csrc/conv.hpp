@@ -160,6 +160,23 @@ hipError_t launch_cgen_band(hipStream_t s, const CgenBandArgs& a, int num_cus);
 bool cgen_first_direct_ok(const ConvGeom& g, int epilogue);
 hipError_t launch_cgen_first_direct(hipStream_t s, const CgenBandArgs& a, int num_cus);
 hipError_t launch_cgen_rowsum(hipStream_t s, const float* fm, int rows, int N, int F, int Fp, double* out);
+// The patch sampler (conv_patch.hip): n_steps exchange steps of every chain in ONE launch, one workgroup per chain; per
+// step the two boxes of every convolution that the exchanged pair reaches are recomputed from the chain's stored maps
+struct CgenPatchArgs {
+  ConvGeom g;
+  int Fp;
+  const float* theta;        // the parameters as they lie: per convolution w[K][KW][Cin][F], b[F]
+  float* maps;               // [n_conv][B][N][Fp]: the maps of the chains as they stand (cgen_post says what a map holds)
+  long long map_stride;      // floats between two convolutions' maps (B N Fp)
+  int post;                  // 1: maps hold activations (the epilogue applies them); 0: pre-activations (applied on the gather)
+  int act, oact;
+  float* configs; float* logit; const int* iup; const int* idn; const float* u;   // the chains; the first step's proposals
+  unsigned long long* accepted;
+  int B;
+  uint32_t seed_lo, seed_hi; int chain_offset; unsigned long long step0; long long n_steps;
+};
+bool cgen_patch_ok(const ConvGeom& g, long long B);
+hipError_t launch_cgen_patch_sweep(hipStream_t s, const CgenPatchArgs& a);
 // map sum + candidate logit + Metropolis test / commit + the next step's proposal, one workgroup per chain (k_cgen_step_tail)
 hipError_t launch_cgen_step_tail(hipStream_t s, const float* fm, int N, int F, int Fp, float* configs, float* logit, int B,
                                  int oact, int* iup, int* idn, float* u, unsigned long long* accepted, uint32_t seed_lo,

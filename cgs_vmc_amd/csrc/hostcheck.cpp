@@ -452,6 +452,21 @@ static void conv_grid() {
     b.layer_size = 16; b.num_layers = 3; b.size_x = b.size_y = 36; b.n_sites = 1296; b.batch_size = 32;
     CHECK(plan_desc(&b, true, &q, msg, sizeof(msg)) == VMC_OK && q.conv_general && plan_cgen_band_ok(q.cg));
     CHECK(plan_cgen_band_rows(q.cg) == 12 && plan_cgen_band_lds_bytes(q.cg, false) == 16u * 40u * 64u);
+    // the patch sampler: boxes of 5, 9, 13 sites per axis; spins 1,296 + fragments 2 x 25 x 256 + biases 48 + boxes
+    // 2 x 16 (25 + 81 + 169) + two windows of 17 x 17 x 16 floats
+    CHECK(plan_cgen_patch_ok(q.cg, 32) && plan_cgen_patch_pays(q.cg) && plan_cgen_patch_side(q.cg, 2, 0) == 13);
+    CHECK(plan_cgen_patch_lds_bytes(q.cg) == 4u * (1296u + 12800u + 48u + 8800u + 2u * 4624u) + 256u);
+    {
+      DescPlan t; vmc_desc s = b;
+      s.size_x = s.size_y = 12; s.n_sites = 144;                       // the last box (13) would meet itself around the torus
+      CHECK(plan_desc(&s, true, &t, msg, sizeof(msg), true) == VMC_OK && t.conv_general && !plan_cgen_patch_ok(t.cg, 32));
+      s.size_x = s.size_y = 13; s.n_sites = 169;                       // fits exactly -- and covers the lattice: does not pay
+      CHECK(plan_desc(&s, true, &t, msg, sizeof(msg), true) == VMC_OK && plan_cgen_patch_ok(t.cg, 32) && !plan_cgen_patch_pays(t.cg));
+      s = b; s.num_layers = 1;                                         // one convolution: nothing to keep
+      CHECK(plan_desc(&s, true, &t, msg, sizeof(msg)) == VMC_OK && !plan_cgen_patch_ok(t.cg, 32));
+      s = b; s.layer_size = 32; s.kernel_size = 3;                     // two channel blocks
+      CHECK(plan_desc(&s, true, &t, msg, sizeof(msg)) == VMC_OK && t.conv_general && !plan_cgen_patch_ok(t.cg, 32));
+    }
     // the sampler's chain groups: one where the launches are latency, two for the one-workgroup-per-CU band kernel
     CHECK(plan_cgen_sweep_groups(q.cg, 32, 256) == 1);
     b.layer_size = 64; b.kernel_size = 3;

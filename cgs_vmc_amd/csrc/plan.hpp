@@ -153,6 +153,42 @@ inline int plan_cgen_sweep_groups(const ConvGeom& g, long long B, int num_cus) {
   const long long rounds = (tiles + num_cus - 1) / num_cus;
   return tiles * 10 < rounds * num_cus * 9 ? 2 : 1;
 }
+// The patch sampler of the general convolution path (k_cgen_patch_sweep, conv_patch.hip): an exchange negates two spins,
+// and convolution l's output changes only in a box of (l + 1)(K - 1) + 1 sites per axis around each of them (the union of
+// the taps' reach: graph_builders.py:67-71 proposes, layers.py:118-160 convolves).  One workgroup per chain keeps the
+// chain's maps of every convolution in HBM and recomputes the two boxes per convolution instead of the lattice.
+// Shapes: Conv2DNetwork / Conv1DNetwork (no residual blocks), the band kernel's single-block shapes (<= 16 filters, so that a box
+// value has k_cgen_band's bits), at least two convolutions, the last box within the lattice along both axes (it must not
+// meet itself around the torus), and the LDS within a CU's.
+inline int plan_cgen_patch_side(const ConvGeom& g, int l, int axis) { return (l + 1) * ((axis ? g.KW : g.K) - 1) + 1; }
+inline size_t plan_cgen_patch_lds_bytes(const ConvGeom& g) {
+  const int L = g.n_conv, T = g.K * g.KW;
+  size_t fl = (size_t)((g.N + 3) & ~3);                           // the chain's spins
+  fl += (size_t)(L - 1) * T * 256;                                 // weight fragments of the convolutions behind the first
+  fl += (size_t)L * 16;                                            // biases
+  size_t win = (size_t)(plan_cgen_patch_side(g, 0, 0) + g.K - 1) * (size_t)(plan_cgen_patch_side(g, 0, 1) + g.KW - 1);   // first: 1 channel
+  for (int l = 0; l < L; ++l) {
+    fl += 2 * (size_t)plan_cgen_patch_side(g, l, 0) * plan_cgen_patch_side(g, l, 1) * 16;          // the two boxes of convolution l
+    if (l > 0) {
+      const size_t w = (size_t)(plan_cgen_patch_side(g, l, 0) + g.K - 1) * (size_t)(plan_cgen_patch_side(g, l, 1) + g.KW - 1) * 16;
+      if (w > win) win = w;
+    }
+  }
+  fl += 2 * win;                                                   // the two staged input windows
+  return fl * sizeof(float) + 256;                                 // + the step's scalars
+}
+#define PLAN_CGEN_PATCH_LDS (156 * 1024)
+inline bool plan_cgen_patch_ok(const ConvGeom& g, long long B) {
+  if (g.resnet || g.n_conv < 2 || g.n_conv > 8 || g.F > 16 || !plan_cgen_band_ok(g)) return false;
+  if (plan_cgen_patch_side(g, g.n_conv - 1, 0) > g.D1 || plan_cgen_patch_side(g, g.n_conv - 1, 1) > g.D2) return false;
+  if (g.N > 16384 || B < 1) return false;
+  if ((long long)g.n_conv * B * g.N * ((g.F + 3) & ~3) * (long long)sizeof(float) > (4LL << 30)) return false;   // the chains' maps
+  return plan_cgen_patch_lds_bytes(g) <= PLAN_CGEN_PATCH_LDS;
+}
+// ... and where it pays: the boxes of the last convolution cover at most half of the lattice
+inline bool plan_cgen_patch_pays(const ConvGeom& g) {
+  return 4LL * plan_cgen_patch_side(g, g.n_conv - 1, 0) * plan_cgen_patch_side(g, g.n_conv - 1, 1) <= g.N;
+}
 // k_cgen_first_direct (conv_band.hip): spins [N], weights [taps][Fp], bias [Fp], neighbour table [N][taps]
 inline size_t plan_cgen_first_direct_lds_bytes(const ConvGeom& g) {
   const size_t fp = (size_t)((g.F + 3) & ~3), t = (size_t)g.K * g.KW;

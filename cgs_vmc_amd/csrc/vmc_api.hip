@@ -548,7 +548,7 @@ void vmc_destroy(vmc_ctx* c) {
                    c->wide_u, c->wide_zero}) if (q) hipFree(q);
   for (int* q : {c->wide_iup, c->wide_idn}) if (q) hipFree(q);
   if (c->wide_dot) hipFree(c->wide_dot);
-  for (float* q : {c->cg_A, c->cg_fm[0], c->cg_fm[1], c->cg_zero, c->cg_lnew, c->cg_tape, c->cg_gl, c->cg_g[0], c->cg_g[1], c->cg_wpos,
+  for (float* q : {c->cg_pmaps, c->cg_A, c->cg_fm[0], c->cg_fm[1], c->cg_zero, c->cg_lnew, c->cg_tape, c->cg_gl, c->cg_g[0], c->cg_g[1], c->cg_wpos,
                    c->cg_wt, c->cg_ws}) if (q) hipFree(q);
   if (c->cg_sum) hipFree(c->cg_sum);
   if (c->cg_td) hipFree(c->cg_td);

@@ -136,6 +136,38 @@ static int run_sweep_cgen(vmc_ctx* c, long long n_steps, bool injected, bool dbg
   // the candidates are one block of rows whose last map cgen_forward leaves in place; injected proposals (test hook) and
   // CGS_VMC_CONV_STEP_TAIL=0 take the four separate launches
   const char* tail_env = getenv("CGS_VMC_CONV_STEP_TAIL");
+  // The patch sampler (conv_patch.hip): on a lattice much larger than the convolutions' reach a step recomputes the two boxes
+  // the exchanged pair touches instead of the lattice, all steps of a chain in one launch -- the same chains bit for bit.
+  // CGS_VMC_CONV_PATCH=0: never; =2: wherever the shape allows (tests: short launches, small lattices); read per call.
+  {
+    const char* pe = getenv("CGS_VMC_CONV_PATCH");
+    const int mode = pe ? atoi(pe) : 1;
+    const bool band = !(getenv("CGS_VMC_CONV_BAND") && atoi(getenv("CGS_VMC_CONV_BAND")) == 0);   // (a box has the BAND kernel's bits)
+    if (!injected && mode != 0 && band && cgen_patch_ok(c->cg, B) &&
+        (mode == 2 || (plan_cgen_patch_pays(c->cg) && n_steps >= 8))) {
+      const ConvGeom& g = c->cg;
+      const long long map_floats = (long long)B * N * cgen_fp(g);
+      if (!c->cg_pmaps) HIPCHK(c, dalloc(&c->cg_pmaps, g.n_conv * map_floats));
+      HIPCHK(c, launch_wide_propose(c->stream, c->configs, B, N, seed_lo, seed_hi, c->d.chain_offset, step0, nullptr, nullptr,
+                                    nullptr, c->wide_iup, c->wide_idn, c->wide_u));
+      // the chains' maps as they stand: one taped full forward (blocks of the im2col-sized rows; the band kernel writes them)
+      for (long long r0 = 0; r0 < B; r0 += c->cg_rows) {
+        const long long rows = B - r0 < c->cg_rows ? B - r0 : c->cg_rows;
+        PROPAGATE(cgen_forward(c, VMC_PSI, c->configs, nullptr, rows, nullptr, nullptr, false, nullptr,
+                               c->cg_pmaps + r0 * N * cgen_fp(g), map_floats, r0));
+      }
+      CgenPatchArgs a; memset(&a, 0, sizeof(a));
+      a.g = g; a.Fp = cgen_fp(g); a.theta = p.theta; a.maps = c->cg_pmaps; a.map_stride = map_floats;
+      a.post = g.hact != VMC_ACT_COS_ ? 1 : 0; a.act = g.hact; a.oact = c->oact;
+      a.configs = c->configs; a.logit = p.logit; a.iup = c->wide_iup; a.idn = c->wide_idn; a.u = c->wide_u;
+      a.accepted = c->d_accepted; a.B = B; a.seed_lo = seed_lo; a.seed_hi = seed_hi; a.chain_offset = c->d.chain_offset;
+      a.step0 = step0; a.n_steps = n_steps;
+      HIPCHK(c, launch_cgen_patch_sweep(c->stream, a));
+      c->acts_valid = false;
+      c->acc_since_sweep = false;
+      return VMC_OK;
+    }
+  }
   if (!injected && !(tail_env && atoi(tail_env) == 0) && cgen_single_block(c, B)) {
     const ConvGeom& g = c->cg;
     HIPCHK(c, launch_wide_propose(c->stream, c->configs, B, N, seed_lo, seed_hi, c->d.chain_offset, step0, nullptr, nullptr,

@@ -89,6 +89,7 @@ struct vmc_ctx {
   hipEvent_t cg_grp_ev[4] = {nullptr, nullptr, nullptr, nullptr};    // [0]: `stream` is ready; [g]: group g has finished
   hipStream_t cg_stream_cur = nullptr;     // the stream cgen_conv / cgen_forward launch on (null: `stream`)
   long long cg_map_row0 = 0;               // first row of cg_fm / cg_A an untaped forward writes (a group's slice)
+  float* cg_pmaps = nullptr;               // [n_conv][B][N][Fp] the chains' maps of every convolution (the patch sampler, conv_patch.hip)
   // ... its gradient path (allocated by the first gradient call): the map of every convolution (the tape), two
   // d logit / d map buffers, per-position weights, the transposed weight images, the split-K workspace
   float* cg_tape = nullptr; float* cg_gl = nullptr; float* cg_g[2] = {nullptr, nullptr}; float* cg_wpos = nullptr; float* cg_wt = nullptr;

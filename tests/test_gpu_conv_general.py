@@ -351,6 +351,59 @@ def test_sampler_chain_groups_leave_the_chains_alone(monkeypatch, ansatz, sx, sy
   eng.close()
 
 
+PATCH_SHAPES = [
+    ('conv_2d', 20, 20, 3, 16, 3, 5, 'relu'),       # boxes of 3, 5, 7 sites per axis
+    ('conv_2d', 36, 36, 3, 16, 5, 3, 'relu'),       # bench workload heisenberg36x36_conv3x16k5_b32: 5, 9, 13
+    ('conv_2d', 14, 18, 2, 12, 4, 4, 'tanh'),       # even kernel (1 in front, 2 behind), 12 filters, a non-square lattice
+    ('conv_2d', 16, 16, 2, 8, 5, 4, 'cos'),         # the cosine: the maps hold pre-activations, applied on the gather
+    ('conv_2d', 7, 9, 3, 16, 3, 4, 'relu'),         # the last box as wide as the lattice along one axis
+    ('conv_2d', 24, 24, 4, 16, 2, 3, 'sigmoid'),    # four convolutions of 2 x 2 taps
+    ('conv_1d', 40, 1, 3, 16, 5, 4, 'relu'),        # 1-D: boxes of 5, 9, 13 sites
+    ('conv_1d', 30, 1, 2, 10, 6, 5, 'tanh'),        # ... even kernel: 3 in front, 2 behind
+]
+
+
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', PATCH_SHAPES, ids=['{}-{}x{}-L{}-F{}-K{}-B{}-{}'.format(*s) for s in PATCH_SHAPES])
+def test_patch_sampler_gives_the_chains_of_the_full_forward(monkeypatch, ansatz, sx, sy, L, f, k, b, nonlin):
+  """Round 6: k_cgen_patch_sweep (conv_patch.hip) recomputes, per step, the two boxes of every convolution that the
+  exchanged pair reaches -- with the band kernel's tile arithmetic and the step tail's sum order -- instead of the whole
+  lattice.  Chains, accept counts and cached logits are the bits of the full-forward sampler (CGS_VMC_CONV_PATCH=0, read
+  per call), over launches long enough for accepted moves to be carried from step to step through the stored maps."""
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6
+  n = sx * sy
+  out = {}
+  for patch in ('0', '2'):
+    monkeypatch.setenv('CGS_VMC_CONV_PATCH', patch)
+    eng.set_configs(cfg)
+    eng.step_counter = 0
+    acc1 = eng.mc_steps(3)
+    c1 = eng.get_configs()
+    acc2 = eng.mc_steps(2 * n)
+    c2 = eng.get_configs()
+    l2 = eng.amplitude()[0]
+    acc3 = eng.mc_steps(n // 2)
+    out[patch] = (acc1, c1, acc2, c2, l2, acc3, eng.get_configs(), eng.amplitude()[0])
+  assert 0 < out['0'][2] <= 2 * n * b
+  for a, bb in zip(out['0'], out['2']):
+    np.testing.assert_array_equal(a, bb)
+  _logits_close(out['2'][7], theta, out['2'][6], ansatz, geom, L, nonlin)      # ... and the oracle's amplitudes of the final chains
+  eng.close()
+
+
+def test_patch_sampler_against_the_oracle_trajectory(monkeypatch):
+  """The oracle checks of every general-path shape (amplitudes, local energies, proposals, injected steps, trajectory)
+  with the patch sampler forced on for the plain launches."""
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')
+  monkeypatch.setenv('CGS_VMC_CONV_PATCH', '2')
+  ansatz, sx, sy, L, f, k, b, nonlin = 'conv_2d', 18, 18, 3, 16, 3, 6, 'relu'
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6
+  _check_forward_and_sampler(eng, theta, cfg, bonds, geom, ansatz, L, nonlin, b, steps=12)
+  eng.close()
+
+
 def test_general_convolution_sr_keeps_the_tape_across_cg_iterations(monkeypatch):
   """Round 6: with the stored chains in one block the taped forward and the backward run once per solve instead of once
   per CG iteration (CGS_VMC_SR_KEEP_TAPE=0: every iteration, read per call) -- the same numbers go into every product,
