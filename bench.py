@@ -986,6 +986,14 @@ def main():
         kw = ksz if ly > 1 else 1
         if h <= 64 and 2 <= ksz <= 7 and ksz * kw * 4 * ((h + 15) // 16) <= 208 and os.environ.get('CGS_VMC_CONV_BAND', '1') != '0':    # conv_band.hip (round 6)
           k_sweep, k_eloc = 'k_cgen_band(sampler)', 'k_cgen_band(eloc)'
+        if eng.conv_patch(n):       # the patch sampler (csrc/conv_patch.hip): per step the two boxes of every convolution, not the lattice
+          k_sweep = 'k_cgen_patch_sweep'
+          taps = ksz * kw
+          per_step = 2 * ((taps + 15) // 16) * ((taps + 3) // 4) * 2048       # first convolution: the taps over the MFMA's k index
+          for l in range(1, L):
+            s1, s2 = (l + 1) * (ksz - 1) + 1, (l + 1) * (kw - 1) + 1
+            per_step += 2 * ((s1 * s2 + 15) // 16) * taps * 4 * 2048           # 16 channels x 16 positions x 4 channels per MFMA
+          exec_sweep = b * n * per_step
       if not conv and h > 512:        # the general path: per mc_step one k_wide_step launch + the H x H layers as GEMMs
         k_sweep = 'k_wide_step + k_gemm_ring(sampler)'
       per_kernel = {
@@ -1045,7 +1053,7 @@ def main():
           # dominant role's shape (tools/summarise_profiles.py: "k_gemm_ring<...> @ grid <threads>"), per launch,
           # next to the bytes that product has to move: A rows x K in (a convolution's implicit gather reads the map,
           # rows x F, once), the weights, rows x columns out.
-          general = (not conv and h > 512) or (conv and eng.kernel_path() == 6 and not key.startswith('k_cgen_band'))
+          general = (not conv and h > 512) or (conv and eng.kernel_path() == 6 and not key.startswith(('k_cgen_band', 'k_cgen_patch')))
           if general and traffic is None:
             shapes = {k2: v2 for k2, v2 in prof.items() if k2.startswith('k_gemm_ring') and ' @ grid ' in k2
                       and v2.get('hbm_read_bytes') is not None}

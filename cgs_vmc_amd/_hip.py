@@ -138,6 +138,7 @@ SIGNATURES = {
     'vmc_last_connected_rows': (C.c_int, [_ctx, C.POINTER(C.c_int64)]),
     'vmc_debug_kernel_path': (C.c_int, [_ctx, C.POINTER(C.c_int32)]),
     'vmc_debug_sweep_tile': (C.c_int, [_ctx, C.c_int32, C.POINTER(C.c_int32)]),
+    'vmc_debug_conv_patch': (C.c_int, [_ctx, C.c_int64, C.POINTER(C.c_int32)]),
     'vmc_synchronize': (C.c_int, [_ctx]),
     'vmc_debug_gemm': (C.c_int, [_ctx, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_int64, C.c_int64,
                                  C.c_int64, _fp, C.c_int64, C.c_int64, C.c_int64, _fp]),

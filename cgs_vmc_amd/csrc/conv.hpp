@@ -174,6 +174,7 @@ struct CgenPatchArgs {
   unsigned long long* accepted;
   int B;
   uint32_t seed_lo, seed_hi; int chain_offset; unsigned long long step0; long long n_steps;
+  unsigned long long* prof;  // diagnostic (CGS_VMC_CONV_PATCH_PROF=1): six phase clocks of chain 0, or nullptr
 };
 bool cgen_patch_ok(const ConvGeom& g, long long B);
 hipError_t launch_cgen_patch_sweep(hipStream_t s, const CgenPatchArgs& a);

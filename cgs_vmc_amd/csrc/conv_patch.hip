@@ -21,20 +21,32 @@
 // Shapes: plan_cgen_patch_ok (plan.hpp).
 #include "conv.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
 
 __device__ __forceinline__ float cp_pre(int pre, float x) { return pre < 0 ? x : vmc_act_rt(pre, x); }
 __device__ __forceinline__ int cp_wrap(int v, int d) { v %= d; return v < 0 ? v + d : v; }
+// v in [0, 3 d): the coordinate of a window site = a wrapped origin + an offset below d + K
+__device__ __forceinline__ int cp_fold(int v, int d) { v -= v >= d ? d : 0; v -= v >= d ? d : 0; return v; }
+// a - b for a, b in [0, d), wrapped
+__device__ __forceinline__ int cp_rel(int a, int b, int d) { const int r = a - b; return r < 0 ? r + d : r; }
+// x / d for 0 <= x < 2^20, 1 <= d <= 2^10 with inv = 1.f / d (exact: the quotient's error stays below half a step of 1 / d)
+__device__ __forceinline__ int cp_div(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
-template <int K, int KW>
-__global__ __launch_bounds__(256, 1) void k_cgen_patch_sweep(CgenPatchArgs a) {
-  constexpr int T = K * KW, NF0 = (T + 3) / 4;
+// NW: waves per workgroup -- 4 (one per SIMD: up to 512 registers, what 6 x 6 and 7 x 7 taps of fragments need) or 8 (two
+// per SIMD: the phases of a step are chains of dependent work -- a second wave fills their gaps).  The map sum is taken
+// by the first four waves either way: its order is k_cgen_step_tail's, 256 threads.
+template <int K, int KW, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a) {
+  constexpr int T = K * KW, NF0 = (T + 3) / 4, NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ double s_w[4];
   __shared__ int s_prop[3];                    // the site raised (iup), the site lowered (idn), accepted
   __shared__ float s_u;
+  __shared__ float s_bv[2][8];                 // the proposal's best values / sites of the waves
+  __shared__ int s_bi[2][8];
   const ConvGeom g = a.g;
   const int D1 = g.D1, D2 = g.D2, N = g.N, F = g.F, Fp = a.Fp, L = g.n_conv, FQ = Fp >> 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, gq = lane >> 4;
@@ -50,18 +62,19 @@ __global__ __launch_bounds__(256, 1) void k_cgen_patch_sweep(CgenPatchArgs a) {
   float* const s_win = s_patch + poff(L);
   int wstride = (2 * K - 1) * (2 * KW - 1);
   for (int l = 1; l < L; ++l) wstride = max(wstride, (side1(l) + K - 1) * (side2(l) + KW - 1) * 16);
+  short* const s_ovl = (short*)(s_win + 2 * wstride);     // [N]: the place of a site in the last convolution's boxes, or -1
 
   // ---- once per launch: the chain, the parameters
   const long long w_base1 = (long long)T * F + F, w_per = (long long)T * F * F + F;     // theta: w_0, b_0, then (w_l, b_l)
-  for (int i = tid; i < N; i += 256) s_x[i] = a.configs[c * N + i];
-  for (int i = tid; i < (L - 1) * T * 256; i += 256) {
+  for (int i = tid; i < N; i += NT) { s_x[i] = a.configs[c * N + i]; s_ovl[i] = -1; }
+  for (int i = tid; i < (L - 1) * T * 256; i += NT) {
     // fragment (l, tap t) of lane ln, MFMA e: the A operand of k_cgen_band -- output channel ln & 15 against input channel 4 (ln >> 4) + e
     const int l1 = i / (T * 256), r = i - l1 * T * 256, t = r >> 8, ln = (r >> 2) & 63, e = r & 3;
     const int c_in = 4 * (ln >> 4) + e, fo = ln & 15;
     const float* w = a.theta + w_base1 + l1 * w_per;
     s_wf[i] = (c_in < F && fo < F) ? w[((long long)t * F + c_in) * F + fo] : 0.f;
   }
-  for (int i = tid; i < L * 16; i += 256) {
+  for (int i = tid; i < L * 16; i += NT) {
     const int l = i >> 4, f = i & 15;
     const float* b = l == 0 ? a.theta + (long long)T * F : a.theta + w_base1 + (l - 1) * w_per + (long long)T * F * F;
     s_bias[i] = f < F ? b[f] : 0.f;
@@ -80,16 +93,26 @@ __global__ __launch_bounds__(256, 1) void k_cgen_patch_sweep(CgenPatchArgs a) {
   __syncthreads();
 
   const int pre = a.post ? -1 : a.act;
+  // phase clocks of chain 0 (diagnostic: CgenPatchArgs.prof; s_memtime ticks summed over the steps): 0 first convolution,
+  // 1 staging of the others, 2 their tiles, 3 the map sum, 4 test + commit, 5 the next proposal
+  unsigned long long t_prev = 0, t_ph[6] = {0, 0, 0, 0, 0, 0};
+  const bool prof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
+  auto stamp = [&](int ph) {
+    if (prof) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_ph[ph] += t - t_prev; t_prev = t; }
+  };
+  if (prof) t_prev = __builtin_amdgcn_s_memtime();
   for (long long st = 0; st < a.n_steps; ++st) {
-    const int up = s_prop[0], dn = s_prop[1];
+    const int up = __builtin_amdgcn_readfirstlane(s_prop[0]), dn = __builtin_amdgcn_readfirstlane(s_prop[1]);   // (uniform: scalar arithmetic below)
     const int q1[2] = {up / D2, dn / D2};
     const int q2[2] = {up - q1[0] * D2, dn - q1[1] * D2};
     // ---- convolution 0: the windows are the candidate's spins (the exchanged pair negated)
     {
       constexpr int SR = 2 * K - 1, SC = 2 * KW - 1, n_win = SR * SC, n_pos = K * KW, n_tiles = (n_pos + 15) >> 4;
-      for (int i = tid; i < 2 * n_win; i += 256) {
+      const int o1[2] = {cp_wrap(q1[0] - g.hi - g.lo, D1), cp_wrap(q1[1] - g.hi - g.lo, D1)};
+      const int o2[2] = {cp_wrap(q2[0] - g.hi2 - g.lo2, D2), cp_wrap(q2[1] - g.hi2 - g.lo2, D2)};
+      for (int i = tid; i < 2 * n_win; i += NT) {
         const int b = i >= n_win, j = i - b * n_win, wy = j / SC, wx = j - wy * SC;
-        const int site = cp_wrap(q1[b] - g.hi - g.lo + wy, D1) * D2 + cp_wrap(q2[b] - g.hi2 - g.lo2 + wx, D2);
+        const int site = cp_fold((b ? o1[1] : o1[0]) + wy, D1) * D2 + cp_fold((b ? o2[1] : o2[0]) + wx, D2);
         const float x = s_x[site];
         s_win[b * wstride + j] = (site == up || site == dn) ? -x : x;
       }
@@ -97,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void k_cgen_patch_sweep(CgenPatchArgs a) {
       f32x4 bias4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) bias4[r] = s_bias[4 * gq + r];
-      for (int tt = wave; tt < 2 * n_tiles; tt += 4) {
+      for (int tt = wave; tt < 2 * n_tiles; tt += NW) {
         const int b = tt >= n_tiles, tile = tt - b * n_tiles;
         const int q = tile * 16 + p, qq = q < n_pos ? q : n_pos - 1;
         const int y = qq / KW, x = qq - y * KW;
@@ -116,51 +139,79 @@ __global__ __launch_bounds__(256, 1) void k_cgen_patch_sweep(CgenPatchArgs a) {
         if (q < n_pos) *(f32x4*)(s_patch + b * n_pos * 16 + q * 16 + 4 * gq) = v;
       }
     }
+    // the first SU quads per thread of the last map are requested before the last convolution's tiles and added behind them
+    constexpr int SU = NW == 8 ? 8 : (T > 25 ? 12 : 24);
+    constexpr bool SUM_AHEAD = NW == 4;      // (eight waves: 256 registers per wave)
+    f32x4 vs[SU];
+    const int nq = N * FQ;
+    const float* const lmap = a.maps + (L - 1) * a.map_stride + c * N * Fp;
     // ---- the convolutions behind it
     for (int l = 1; l < L; ++l) {
       __syncthreads();                 // the boxes of convolution l - 1 are written; the windows' readers are done
+      stamp(l == 1 ? 0 : 2);
       const int s1 = side1(l), s2 = side2(l), SC = s2 + KW - 1, n_win = (s1 + K - 1) * SC;
       const int ps1 = side1(l - 1), ps2 = side2(l - 1), ppos = ps1 * ps2;
       const float* const pp = s_patch + poff(l - 1);
       const float* const mp = a.maps + (l - 1) * a.map_stride + c * N * Fp;
-      const int o1[2] = {q1[0] - (l + 1) * g.hi - g.lo, q1[1] - (l + 1) * g.hi - g.lo};        // window origins
-      const int o2[2] = {q2[0] - (l + 1) * g.hi2 - g.lo2, q2[1] - (l + 1) * g.hi2 - g.lo2};
-      const int b1[2] = {q1[0] - l * g.hi, q1[1] - l * g.hi};                                  // origins of the boxes below
-      const int b2[2] = {q2[0] - l * g.hi2, q2[1] - l * g.hi2};
-      const int total = 2 * n_win * 4;
-      constexpr int SB = 4;            // loads in flight per thread
-      for (int i0 = tid; i0 < total; i0 += SB * 256) {
-        f32x4 v[SB];
-        int dsto[SB], cqs[SB], pat[SB];
+      const int o1[2] = {cp_wrap(q1[0] - (l + 1) * g.hi - g.lo, D1), cp_wrap(q1[1] - (l + 1) * g.hi - g.lo, D1)};       // window origins
+      const int o2[2] = {cp_wrap(q2[0] - (l + 1) * g.hi2 - g.lo2, D2), cp_wrap(q2[1] - (l + 1) * g.hi2 - g.lo2, D2)};
+      const int b1[2] = {cp_wrap(q1[0] - l * g.hi, D1), cp_wrap(q1[1] - l * g.hi, D1)};                                 // origins of the boxes below
+      const int b2[2] = {cp_wrap(q2[0] - l * g.hi2, D2), cp_wrap(q2[1] - l * g.hi2, D2)};
+      const float inv_sc = 1.f / (float)SC;
+      // a thread takes whole window sites (the coordinates and the box test once per site, four 16-byte quads each)
+      const int total = 2 * n_win;
+      constexpr int SB = 3;            // sites in flight per thread: 12 loads
+      for (int i0 = tid; i0 < total; i0 += SB * NT) {
+        f32x4 v[SB][4];
+        int dsto[SB], pat[SB];
 #pragma unroll
         for (int uu = 0; uu < SB; ++uu) {
-          const int i = min(i0 + uu * 256, total - 1);
-          const int b = i >= n_win * 4, r = i - b * n_win * 4, j = r >> 2, cq = r & 3;
-          const int wy = j / SC, wx = j - wy * SC;
-          const int a1 = cp_wrap(o1[b] + wy, D1), a2 = cp_wrap(o2[b] + wx, D2);
-          v[uu] = *(const f32x4*)(mp + (long long)(a1 * D2 + a2) * Fp + (4 * cq < Fp ? 4 * cq : 0));
+          const int i = min(i0 + uu * NT, total - 1);
+          const int b = i >= n_win, j = i - b * n_win;
+          const int wy = cp_div(j, inv_sc), wx = j - wy * SC;
+          const int a1 = cp_fold((b ? o1[1] : o1[0]) + wy, D1), a2 = cp_fold((b ? o2[1] : o2[0]) + wx, D2);
+          const float* src = mp + (long long)(a1 * D2 + a2) * Fp;
+#pragma unroll
+          for (int cq = 0; cq < 4; ++cq) v[uu][cq] = *(const f32x4*)(src + (4 * cq < Fp ? 4 * cq : 0));
           pat[uu] = -1;
 #pragma unroll
           for (int bb = 0; bb < 2; ++bb) {
-            const int r1 = cp_wrap(a1 - b1[bb], D1), r2 = cp_wrap(a2 - b2[bb], D2);
-            if (r1 < ps1 && r2 < ps2) pat[uu] = bb * ppos * 16 + (r1 * ps2 + r2) * 16 + 4 * cq;
+            const int r1 = cp_rel(a1, b1[bb], D1), r2 = cp_rel(a2, b2[bb], D2);
+            if (r1 < ps1 && r2 < ps2) pat[uu] = bb * ppos * 16 + (r1 * ps2 + r2) * 16;
           }
-          dsto[uu] = b * wstride + j * 16 + 4 * cq;
-          cqs[uu] = 4 * cq;
+          dsto[uu] = b * wstride + j * 16;
         }
 #pragma unroll
         for (int uu = 0; uu < SB; ++uu) {
-          if (i0 + uu * 256 < total) {
-            f32x4 x = v[uu];
-            if (pat[uu] >= 0) x = *(const f32x4*)(pp + pat[uu]);
-            f32x4 w;
+          if (i0 + uu * NT < total) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = cqs[uu] + e < F ? cp_pre(pre, x[e]) : 0.f;
-            *(f32x4*)(s_win + dsto[uu]) = w;
+            for (int cq = 0; cq < 4; ++cq) {
+              f32x4 x = v[uu][cq];
+              if (pat[uu] >= 0) x = *(const f32x4*)(pp + pat[uu] + 4 * cq);
+              f32x4 w;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) w[e] = 4 * cq + e < F ? cp_pre(pre, x[e]) : 0.f;
+              *(f32x4*)(s_win + dsto[uu] + 4 * cq) = w;
+            }
           }
         }
       }
       __syncthreads();
+      stamp(1);
+      if (l == L - 1) {
+        if (SUM_AHEAD && tid < 256) {
+#pragma unroll
+          for (int uu = 0; uu < SU; ++uu) vs[uu] = *(const f32x4*)(lmap + 4 * (long long)min(tid + uu * 256, nq - 1));
+        }
+        // ... and the sites of this convolution's boxes are marked for the sum (a site of both boxes: either value, they are equal)
+        const int bo1[2] = {cp_wrap(q1[0] - L * g.hi, D1), cp_wrap(q1[1] - L * g.hi, D1)};
+        const int bo2[2] = {cp_wrap(q2[0] - L * g.hi2, D2), cp_wrap(q2[1] - L * g.hi2, D2)};
+        const float inv = 1.f / (float)s2;
+        for (int i = tid; i < 2 * s1 * s2; i += NT) {
+          const int b = i >= s1 * s2, pos = i - b * s1 * s2, y = cp_div(pos, inv), x = pos - y * s2;
+          s_ovl[cp_fold((b ? bo1[1] : bo1[0]) + y, D1) * D2 + cp_fold((b ? bo2[1] : bo2[0]) + x, D2)] = (short)i;
+        }
+      }
       f32x4 w[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) w[t] = *(const f32x4*)(s_wf + ((l - 1) * T + t) * 256 + lane * 4);
@@ -168,21 +219,20 @@ __global__ __launch_bounds__(256, 1) void k_cgen_patch_sweep(CgenPatchArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) bias4[r] = s_bias[l * 16 + 4 * gq + r];
       const int n_pos = s1 * s2, n_tiles = (n_pos + 15) >> 4;
+      const float inv_s2 = 1.f / (float)s2;
       const bool act_out = l + 1 < L && a.post;
       float* const po = s_patch + poff(l);
-      for (int tt = wave; tt < 2 * n_tiles; tt += 4) {
-        const int b = tt >= n_tiles, tile = tt - b * n_tiles;
-        const int q = tile * 16 + p, qq = q < n_pos ? q : n_pos - 1;
-        const int y = qq / s2, x = qq - y * s2;
-        f32x4 acc = bias4;
-        const float* base = s_win + b * wstride + (y * SC + x) * 16 + 4 * gq;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const f32x4 bv = *(const f32x4*)(base + ((t / KW) * SC + (t % KW)) * 16);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][e], bv[e], acc, 0, 0, 0);
-        }
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
+      // the wave's tiles two at a time: two independent accumulator chains keep the matrix pipe busy where one wave per
+      // SIMD would wait for every MFMA's result (a tile's own chain, and so its bits, are the same)
+      auto locate = [&](int tt, int& b, int& q) {
+        b = tt >= n_tiles;
+        q = (tt - b * n_tiles) * 16 + p;
+        const int qq = q < n_pos ? q : n_pos - 1;
+        const int y = cp_div(qq, inv_s2), x = qq - y * s2;
+        return s_win + b * wstride + (y * SC + x) * 16 + 4 * gq;
+      };
+      auto finish = [&](f32x4 acc, int b, int q) {
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));    // the relu of vmc_act_rt is an asm v_max_f32 (common.hpp: vmc_mfma_settle)
         f32x4 v = acc;
         if (act_out) {
 #pragma unroll
@@ -191,36 +241,79 @@ __global__ __launch_bounds__(256, 1) void k_cgen_patch_sweep(CgenPatchArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = 4 * gq + e < F ? v[e] : 0.f;
         if (q < n_pos) *(f32x4*)(po + b * n_pos * 16 + q * 16 + 4 * gq) = v;
+      };
+      int tt = wave;
+      for (; NW == 4 && tt + NW < 2 * n_tiles; tt += 2 * NW) {      // (eight waves: two per SIMD take turns already)
+        int bA, qA, bB, qB;
+        const float* baseA = locate(tt, bA, qA);
+        const float* baseB = locate(tt + NW, bB, qB);
+        f32x4 accA = bias4, accB = bias4;
+        // the operands of tap t + 1 are requested before the MFMAs of tap t (one wave per SIMD: nobody else covers an LDS round trip)
+        auto off = [&](int t) { return ((t / KW) * SC + (t % KW)) * 16; };
+        f32x4 rA[2], rB[2];
+        rA[0] = *(const f32x4*)(baseA + off(0)); rB[0] = *(const f32x4*)(baseB + off(0));
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          if (t + 1 < T) { rA[(t + 1) & 1] = *(const f32x4*)(baseA + off(t + 1)); rB[(t + 1) & 1] = *(const f32x4*)(baseB + off(t + 1)); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            accA = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][e], rA[t & 1][e], accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][e], rB[t & 1][e], accB, 0, 0, 0);
+          }
+        }
+        finish(accA, bA, qA);
+        finish(accB, bB, qB);
+      }
+      for (; tt < 2 * n_tiles; tt += NW) {
+        int b, q;
+        const float* base = locate(tt, b, q);
+        f32x4 acc = bias4;
+        auto off = [&](int t) { return ((t / KW) * SC + (t % KW)) * 16; };
+        f32x4 r[2];
+        r[0] = *(const f32x4*)(base + off(0));
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          if (t + 1 < T) r[(t + 1) & 1] = *(const f32x4*)(base + off(t + 1));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[t][e], r[t & 1][e], acc, 0, 0, 0);
+        }
+        finish(acc, b, q);
       }
     }
     __syncthreads();
+    stamp(2);
     // ---- the candidate's logit: the sum of the last map with its two boxes overlaid, in k_cgen_step_tail's order
     {
-      const int ls1 = side1(L - 1), ls2 = side2(L - 1), lpos = ls1 * ls2;
-      const float* const lp = s_patch + poff(L - 1);
-      const float* const mp = a.maps + (L - 1) * a.map_stride + c * N * Fp;
-      const int b1[2] = {q1[0] - L * g.hi, q1[1] - L * g.hi};
-      const int b2[2] = {q2[0] - L * g.hi2, q2[1] - L * g.hi2};
-      const int nq = N * FQ;
+      const float* const lp = s_patch + poff(L - 1);        // [2][box positions][16]: s_ovl's index is box * positions + position
+      const float inv_fq = 1.f / (float)FQ;
       double s = 0.0;
-      for (int i = tid; i < nq; i += 256) {
-        const int site = i / FQ, cq = i - site * FQ;
-        f32x4 v = *(const f32x4*)(mp + 4 * (long long)i);
-        const int a1 = site / D2, a2 = site - a1 * D2;
+      for (int i0 = tid; i0 < (tid < 256 ? nq : 0); i0 += SU * 256) {       // (the elements of a thread are added in ascending order)
+        if (!SUM_AHEAD || i0 != tid) {
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          const int r1 = cp_wrap(a1 - b1[bb], D1), r2 = cp_wrap(a2 - b2[bb], D2);
-          if (r1 < ls1 && r2 < ls2) v = *(const f32x4*)(lp + bb * lpos * 16 + (r1 * ls2 + r2) * 16 + 4 * cq);
+          for (int uu = 0; uu < SU; ++uu) vs[uu] = *(const f32x4*)(lmap + 4 * (long long)min(i0 + uu * 256, nq - 1));
         }
-        const int c0 = 4 * cq;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s += c0 + e < F ? (double)v[e] : 0.0;
+        for (int uu = 0; uu < SU; ++uu) {
+          const int i = i0 + uu * 256;
+          if (i < nq) {
+            const int site = cp_div(i, inv_fq), cq = i - site * FQ;
+            const int ov = s_ovl[site];
+            f32x4 x = vs[uu];
+            if (ov >= 0) x = *(const f32x4*)(lp + ov * 16 + 4 * cq);
+            const int c0 = 4 * cq;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += c0 + e < F ? (double)x[e] : 0.0;
+          }
+        }
       }
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-      if (lane == 0) s_w[wave] = s;
+      if (lane == 0 && wave < 4) s_w[wave] = s;
     }
     __syncthreads();
+    stamp(3);
     if (tid == 0) {
       const double sd = 0.0 + ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
       const float lnew = (float)sd + 0.f;
@@ -235,29 +328,45 @@ __global__ __launch_bounds__(256, 1) void k_cgen_patch_sweep(CgenPatchArgs a) {
       s_prop[2] = acc ? 1 : 0;
     }
     __syncthreads();
+    {                                      // the marks of this step's boxes are taken back
+      const int s1 = side1(L - 1), s2 = side2(L - 1);
+      const int bo1[2] = {cp_wrap(q1[0] - L * g.hi, D1), cp_wrap(q1[1] - L * g.hi, D1)};
+      const int bo2[2] = {cp_wrap(q2[0] - L * g.hi2, D2), cp_wrap(q2[1] - L * g.hi2, D2)};
+      const float inv = 1.f / (float)s2;
+      for (int i = tid; i < 2 * s1 * s2; i += NT) {
+        const int b = i >= s1 * s2, pos = i - b * s1 * s2, y = cp_div(pos, inv), x = pos - y * s2;
+        s_ovl[cp_fold((b ? bo1[1] : bo1[0]) + y, D1) * D2 + cp_fold((b ? bo2[1] : bo2[0]) + x, D2)] = -1;
+      }
+    }
     if (s_prop[2]) {
       // ---- accepted: the boxes become part of the chain's maps
       for (int l = 0; l < L; ++l) {
         const int s1 = side1(l), s2 = side2(l), n_pos = s1 * s2;
         const float* const po = s_patch + poff(l);
         float* const mp = a.maps + l * a.map_stride + c * N * Fp;
-        for (int i = tid; i < 2 * n_pos * FQ; i += 256) {
-          const int b = i >= n_pos * FQ, r = i - b * n_pos * FQ, pos = r / FQ, cq = r - pos * FQ;
-          const int y = pos / s2, x = pos - y * s2;
-          const int a1 = cp_wrap(q1[b] - (l + 1) * g.hi + y, D1), a2 = cp_wrap(q2[b] - (l + 1) * g.hi2 + x, D2);
+        const int o1[2] = {cp_wrap(q1[0] - (l + 1) * g.hi, D1), cp_wrap(q1[1] - (l + 1) * g.hi, D1)};
+        const int o2[2] = {cp_wrap(q2[0] - (l + 1) * g.hi2, D2), cp_wrap(q2[1] - (l + 1) * g.hi2, D2)};
+        const float inv_fq = 1.f / (float)FQ, inv_s2 = 1.f / (float)s2;
+        for (int i = tid; i < 2 * n_pos * FQ; i += NT) {
+          const int b = i >= n_pos * FQ, r = i - b * n_pos * FQ, pos = cp_div(r, inv_fq), cq = r - pos * FQ;
+          const int y = cp_div(pos, inv_s2), x = pos - y * s2;
+          const int a1 = cp_fold((b ? o1[1] : o1[0]) + y, D1), a2 = cp_fold((b ? o2[1] : o2[0]) + x, D2);
           *(f32x4*)(mp + (long long)(a1 * D2 + a2) * Fp + 4 * cq) = *(const f32x4*)(po + b * n_pos * 16 + pos * 16 + 4 * cq);
         }
       }
     }
+    stamp(4);
     // ---- the next proposal (k_cgen_step_tail's, k_wide_propose's arithmetic) from the chain as it now stands
-    if (st + 1 < a.n_steps && tid < 64) {
+    // (all four waves: the rule -- the largest / smallest x u, the lowest index among equal values -- does not depend on the
+    // order in which the candidates meet)
+    if (st + 1 < a.n_steps) {
       const unsigned long long next_step = a.step0 + (unsigned long long)st + 1;
       const uint2 key = make_uint2(a.seed_lo, a.seed_hi);
       const uint32_t gid = (uint32_t)(a.chain_offset + (int)c);
       float best_hi = -INFINITY, best_lo = INFINITY;
       int idx_hi = 0x7fffffff, idx_lo = 0x7fffffff;
       const int nblk = (N + 3) >> 2;
-      for (int b = lane; b < nblk; b += 64) {
+      for (int b = tid; b < nblk; b += NT) {
         const uint4 r = philox4x32_10(make_uint4((uint32_t)b, gid, (uint32_t)next_step, (uint32_t)(next_step >> 32)), key);
         const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -277,26 +386,45 @@ __global__ __launch_bounds__(256, 1) void k_cgen_patch_sweep(CgenPatchArgs a) {
         const float ol = __shfl_xor(best_lo, d); const int il = __shfl_xor(idx_lo, d);
         if (ol < best_lo || (ol == best_lo && il < idx_lo)) { best_lo = ol; idx_lo = il; }
       }
-      if (lane == 0) {
+      if (lane == 0) { s_bv[0][wave] = best_hi; s_bi[0][wave] = idx_hi; s_bv[1][wave] = best_lo; s_bi[1][wave] = idx_lo; }
+      __syncthreads();
+      if (tid == 0) {
+        for (int wv = 1; wv < NW; ++wv) {
+          const float oh = s_bv[0][wv]; const int ih = s_bi[0][wv];
+          if (oh > best_hi || (oh == best_hi && ih < idx_hi)) { best_hi = oh; idx_hi = ih; }
+          const float ol = s_bv[1][wv]; const int il = s_bi[1][wv];
+          if (ol < best_lo || (ol == best_lo && il < idx_lo)) { best_lo = ol; idx_lo = il; }
+        }
         const uint4 ra = philox4x32_10(make_uint4(VMC_ACCEPT_BLOCK, gid, (uint32_t)next_step, (uint32_t)(next_step >> 32)), key);
         s_prop[0] = idx_hi; s_prop[1] = idx_lo; s_u = u32_to_uniform(ra.x);
       }
     }
     __syncthreads();      // the proposal; an accepted move's map writes are behind this for every wave of the workgroup
+    stamp(5);
   }
+  if (prof) for (int i = 0; i < 6; ++i) a.prof[i] = t_ph[i];
   if (tid == 0) {
     a.logit[c] = cur_logit;
     if (n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);
   }
 }
 
+template <int K, int KW, int NW>
+hipError_t launch_pw(hipStream_t s, const CgenPatchArgs& a) {
+  const size_t lds = plan_cgen_patch_lds_bytes(a.g);
+  hipError_t e = hipFuncSetAttribute((const void*)k_cgen_patch_sweep<K, KW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_cgen_patch_sweep<K, KW, NW>), dim3((unsigned)a.B), dim3(64 * NW), lds, s, a);
+  return hipGetLastError();
+}
+// eight waves while the fragments of a convolution leave room for two waves per SIMD (CGS_VMC_CONV_PATCH_WAVES=4 forces four)
 template <int K, int KW>
 hipError_t launch_p(hipStream_t s, const CgenPatchArgs& a) {
-  const size_t lds = plan_cgen_patch_lds_bytes(a.g);
-  hipError_t e = hipFuncSetAttribute((const void*)k_cgen_patch_sweep<K, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_cgen_patch_sweep<K, KW>), dim3((unsigned)a.B), dim3(256), lds, s, a);
-  return hipGetLastError();
+  if constexpr (K * KW <= 25) {
+    const char* e = getenv("CGS_VMC_CONV_PATCH_WAVES");
+    if (!(e && atoi(e) == 4)) return launch_pw<K, KW, 8>(s, a);
+  }
+  return launch_pw<K, KW, 4>(s, a);
 }
 
 }  // namespace

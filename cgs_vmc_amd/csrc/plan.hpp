@@ -175,6 +175,7 @@ inline size_t plan_cgen_patch_lds_bytes(const ConvGeom& g) {
     }
   }
   fl += 2 * win;                                                   // the two staged input windows
+  fl += (size_t)((g.N + 1) / 2);                                   // 16-bit marks of the sites inside the last convolution's boxes
   return fl * sizeof(float) + 256;                                 // + the step's scalars
 }
 #define PLAN_CGEN_PATCH_LDS (156 * 1024)

@@ -106,6 +106,17 @@ int refresh_cache_by_sampler(vmc_ctx* c, int which) {
   return VMC_OK;
 }
 
+// Does a plain launch of n_steps steps take the patch sampler (conv_patch.hip)?  CGS_VMC_CONV_PATCH=0: never; =2: wherever the
+// shape allows (tests: short launches, small lattices); read per call.  (A box has the BAND kernel's bits: not with CGS_VMC_CONV_BAND=0.)
+static bool cgen_patch_use(const vmc_ctx* c, long long n_steps) {
+  if (!c->conv_general) return false;
+  const char* pe = getenv("CGS_VMC_CONV_PATCH");
+  const int mode = pe ? atoi(pe) : 1;
+  const bool band = !(getenv("CGS_VMC_CONV_BAND") && atoi(getenv("CGS_VMC_CONV_BAND")) == 0);
+  return mode != 0 && band && n_steps >= 1 && cgen_patch_ok(c->cg, c->B) &&
+         (mode == 2 || (plan_cgen_patch_pays(c->cg) && n_steps >= 8));
+}
+
 // Chain groups of the general convolution sampler (plan.hpp's rule; CGS_VMC_CONV_GENERAL_GROUPS=1..4 forces, read per call)
 static int cgen_sweep_groups(const vmc_ctx* c) {
   int G = plan_cgen_sweep_groups(c->cg, c->B, c->num_cus);
@@ -138,13 +149,9 @@ static int run_sweep_cgen(vmc_ctx* c, long long n_steps, bool injected, bool dbg
   const char* tail_env = getenv("CGS_VMC_CONV_STEP_TAIL");
   // The patch sampler (conv_patch.hip): on a lattice much larger than the convolutions' reach a step recomputes the two boxes
   // the exchanged pair touches instead of the lattice, all steps of a chain in one launch -- the same chains bit for bit.
-  // CGS_VMC_CONV_PATCH=0: never; =2: wherever the shape allows (tests: short launches, small lattices); read per call.
+  // (cgen_patch_use: CGS_VMC_CONV_PATCH)
   {
-    const char* pe = getenv("CGS_VMC_CONV_PATCH");
-    const int mode = pe ? atoi(pe) : 1;
-    const bool band = !(getenv("CGS_VMC_CONV_BAND") && atoi(getenv("CGS_VMC_CONV_BAND")) == 0);   // (a box has the BAND kernel's bits)
-    if (!injected && mode != 0 && band && cgen_patch_ok(c->cg, B) &&
-        (mode == 2 || (plan_cgen_patch_pays(c->cg) && n_steps >= 8))) {
+    if (!injected && cgen_patch_use(c, n_steps)) {
       const ConvGeom& g = c->cg;
       const long long map_floats = (long long)B * N * cgen_fp(g);
       if (!c->cg_pmaps) HIPCHK(c, dalloc(&c->cg_pmaps, g.n_conv * map_floats));
@@ -162,7 +169,21 @@ static int run_sweep_cgen(vmc_ctx* c, long long n_steps, bool injected, bool dbg
       a.configs = c->configs; a.logit = p.logit; a.iup = c->wide_iup; a.idn = c->wide_idn; a.u = c->wide_u;
       a.accepted = c->d_accepted; a.B = B; a.seed_lo = seed_lo; a.seed_hi = seed_hi; a.chain_offset = c->d.chain_offset;
       a.step0 = step0; a.n_steps = n_steps;
+      unsigned long long* d_prof = nullptr;         // diagnostic: the phase clocks of chain 0 to stderr (synchronises)
+      if (getenv("CGS_VMC_CONV_PATCH_PROF") && atoi(getenv("CGS_VMC_CONV_PATCH_PROF")) != 0) {
+        HIPCHK(c, hipMalloc(&d_prof, 6 * sizeof(unsigned long long)));
+        a.prof = d_prof;
+      }
       HIPCHK(c, launch_cgen_patch_sweep(c->stream, a));
+      if (d_prof) {
+        unsigned long long h[6];
+        HIPCHK(c, hipMemcpyAsync(h, d_prof, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(d_prof);
+        fprintf(stderr, "k_cgen_patch_sweep, clocks per step of chain 0: first convolution %.0f, staging %.0f, tiles %.0f, map sum %.0f, "
+                "test + commit %.0f, proposal %.0f\n", (double)h[0] / n_steps, (double)h[1] / n_steps, (double)h[2] / n_steps,
+                (double)h[3] / n_steps, (double)h[4] / n_steps, (double)h[5] / n_steps);
+      }
       c->acts_valid = false;
       c->acc_since_sweep = false;
       return VMC_OK;
@@ -304,6 +325,13 @@ static int run_sweep(vmc_ctx* c, long long n_steps, bool injected, bool dbg, int
 }  // namespace vmcapi
 
 extern "C" {
+
+int vmc_debug_conv_patch(vmc_ctx* c, int64_t n_steps, int32_t* patch) {
+  CHECK_CTX(c);
+  if (!patch) return fail(c, VMC_ERR_INVALID, "null");
+  *patch = cgen_patch_use(c, n_steps) ? 1 : 0;
+  return VMC_OK;
+}
 
 int vmc_mc_steps(vmc_ctx* c, int64_t n_steps, int64_t* accepted) {
   CHECK_CTX(c);

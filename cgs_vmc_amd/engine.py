@@ -494,6 +494,12 @@ class VmcEngine:
     self._check(self._lib.vmc_debug_sweep_tile(self._ctx, int(set_to), C.byref(v)))
     return int(v.value)
 
+  def conv_patch(self, n_steps: int) -> bool:
+    """Would mc_steps(n_steps) run the patch sampler of the general convolution path (csrc/conv_patch.hip)?"""
+    v = C.c_int32()
+    self._check(self._lib.vmc_debug_conv_patch(self._ctx, int(n_steps), C.byref(v)))
+    return bool(v.value)
+
   def synchronize(self):
     self._check(self._lib.vmc_synchronize(self._ctx))
 

@@ -352,6 +352,12 @@ int vmc_debug_kernel_path(vmc_ctx* ctx, int32_t* path);
  * CGS_VMC_SWEEP_TILE=8|16).  Both kernels implement graph_builders.py:38-89 and produce the same chains bit for bit.
  * set = 0 queries, 8 / 16 switches (test hook; 8 is refused where no k_sweep8 exists for the shape). */
 int vmc_debug_sweep_tile(vmc_ctx* ctx, int32_t set, int32_t* chains);
+/* Would vmc_mc_steps(n_steps) run the patch sampler of the general convolution path (k_cgen_patch_sweep,
+ * cgs_vmc_amd/csrc/conv_patch.hip)?  It recomputes, per step, only the two boxes of every convolution that the exchanged
+ * pair of graph_builders.py:67-71 reaches through layers.py:118-160's taps -- Conv2DNetwork / Conv1DNetwork at <= 16
+ * filters on a lattice wider than the last box, launches of >= 8 steps; CGS_VMC_CONV_PATCH=0 never, =2 wherever the shape
+ * allows -- and gives the chains of the full-forward sampler bit for bit.  *patch: 1 / 0. */
+int vmc_debug_conv_patch(vmc_ctx* ctx, int64_t n_steps, int32_t* patch);
 int vmc_synchronize(vmc_ctx* ctx);
 
 /* Test hook: C[M,N] = op(A) op(B) through the library's fp32 MFMA GEMM
