@@ -29,7 +29,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 # kept with the profile carries these counters (roofline.pmc.stale = false), then add the line
 cd "$ROOT" && python3 tools/summarise_profiles.py "$TAG"
 cp "$ROOT/gpurun_out/${TAG}_summary/${TAG}_traffic.json" "$ROOT/profiles/"
-python3 $ROOT/bench.py --workload $WL > $OUT/bench.json 2> $OUT/bench.err
+# (BENCH_ARGS: e.g. "--steps 5 --warmup 1 --warm-sweeps 2 --reps 3 --no-extra --no-cpu-baseline" for a 36 x 36 lattice, whose CPU leg alone outruns the box)
+python3 $ROOT/bench.py --workload $WL ${BENCH_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err
 python3 tools/summarise_profiles.py "$TAG"
 # raw counter dumps are large; the summaries under gpurun_out/<tag>_summary are what is kept.
 # Reached only when every pass and the summary succeeded (set -e): a failed run keeps its dumps.
