@@ -175,9 +175,12 @@ struct CgenPatchArgs {
   int B;
   uint32_t seed_lo, seed_hi; int chain_offset; unsigned long long step0; long long n_steps;
   unsigned long long* prof;  // diagnostic (CGS_VMC_CONV_PATCH_PROF=1): six phase clocks of chain 0, or nullptr
+  // the local energies' form (launch_cgen_patch_rows): rows (chain, +-(bond + 1) or 0) of a row list instead of steps
+  const int2* rowinfo; const int2* bonds; long long row0; long long n_rows; double* out_sum;
 };
 bool cgen_patch_ok(const ConvGeom& g, long long B);
 hipError_t launch_cgen_patch_sweep(hipStream_t s, const CgenPatchArgs& a);
+hipError_t launch_cgen_patch_rows(hipStream_t s, const CgenPatchArgs& a, int num_cus);
 // map sum + candidate logit + Metropolis test / commit + the next step's proposal, one workgroup per chain (k_cgen_step_tail)
 hipError_t launch_cgen_step_tail(hipStream_t s, const float* fm, int N, int F, int Fp, float* configs, float* logit, int B,
                                  int oact, int* iup, int* idn, float* u, unsigned long long* accepted, uint32_t seed_lo,

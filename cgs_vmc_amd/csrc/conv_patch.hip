@@ -38,7 +38,11 @@ __device__ __forceinline__ int cp_div(int x, float inv) { return (int)(((float)x
 // NW: waves per workgroup -- 4 (one per SIMD: up to 512 registers, what 6 x 6 and 7 x 7 taps of fragments need) or 8 (two
 // per SIMD: the phases of a step are chains of dependent work -- a second wave fills their gaps).  The map sum is taken
 // by the first four waves either way: its order is k_cgen_step_tail's, 256 threads.
-template <int K, int KW, int NW>
+// ELOC: the same boxes for the LOCAL ENERGIES (operators.py:162-169: a connected configuration is its chain with one
+// antiparallel bond exchanged -- two spins again).  The workgroups walk the rows of a row list (chain, bond) instead of
+// the steps of one chain: the chain's stored maps are read only, nothing is tested or committed, and the sum of the last
+// map with its boxes overlaid -- k_cgen_rowsum's double, in its order -- goes to out_sum[row].
+template <int K, int KW, int NW, bool ELOC>
 __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a) {
   constexpr int T = K * KW, NF0 = (T + 3) / 4, NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
   const ConvGeom g = a.g;
   const int D1 = g.D1, D2 = g.D2, N = g.N, F = g.F, Fp = a.Fp, L = g.n_conv, FQ = Fp >> 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, gq = lane >> 4;
-  const long long c = blockIdx.x;
+  long long c = blockIdx.x;                    // the chain (ELOC: of the row at hand)
   auto side1 = [&](int l) { return (l + 1) * (K - 1) + 1; };
   auto side2 = [&](int l) { return (l + 1) * (KW - 1) + 1; };
   auto poff = [&](int l) { int o = 0; for (int j = 0; j < l; ++j) o += 2 * side1(j) * side2(j) * 16; return o; };
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
 
   // ---- once per launch: the chain, the parameters
   const long long w_base1 = (long long)T * F + F, w_per = (long long)T * F * F + F;     // theta: w_0, b_0, then (w_l, b_l)
-  for (int i = tid; i < N; i += NT) { s_x[i] = a.configs[c * N + i]; s_ovl[i] = -1; }
+  for (int i = tid; i < N; i += NT) { if (!ELOC) s_x[i] = a.configs[c * N + i]; s_ovl[i] = -1; }
   for (int i = tid; i < (L - 1) * T * 256; i += NT) {
     // fragment (l, tap t) of lane ln, MFMA e: the A operand of k_cgen_band -- output channel ln & 15 against input channel 4 (ln >> 4) + e
     const int l1 = i / (T * 256), r = i - l1 * T * 256, t = r >> 8, ln = (r >> 2) & 63, e = r & 3;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
   }
   float cur_logit = 0.f;
   unsigned n_acc = 0;
-  if (tid == 0) { s_prop[0] = a.iup[c]; s_prop[1] = a.idn[c]; s_u = a.u[c]; cur_logit = a.logit[c]; }
+  if (!ELOC && tid == 0) { s_prop[0] = a.iup[c]; s_prop[1] = a.idn[c]; s_u = a.u[c]; cur_logit = a.logit[c]; }
   __syncthreads();
 
   const int pre = a.post ? -1 : a.act;
@@ -101,8 +105,20 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
     if (prof) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_ph[ph] += t - t_prev; t_prev = t; }
   };
   if (prof) t_prev = __builtin_amdgcn_s_memtime();
-  for (long long st = 0; st < a.n_steps; ++st) {
-    const int up = __builtin_amdgcn_readfirstlane(s_prop[0]), dn = __builtin_amdgcn_readfirstlane(s_prop[1]);   // (uniform: scalar arithmetic below)
+  for (long long st = ELOC ? (long long)blockIdx.x : 0; st < (ELOC ? a.n_rows : a.n_steps); st += ELOC ? (long long)gridDim.x : 1) {
+    int up, dn;
+    bool flip = true;
+    if (ELOC) {       // the row: its chain, and the bond whose two sites are exchanged (0: the chain itself -- its boxes are what is stored)
+      const int2 ri = a.rowinfo[a.row0 + st];
+      c = __builtin_amdgcn_readfirstlane(ri.x);
+      const int bi = __builtin_amdgcn_readfirstlane(ri.y);
+      flip = bi != 0;
+      const int2 ab = a.bonds[(bi > 0 ? bi : -bi) - (flip ? 1 : 0)];
+      up = flip ? __builtin_amdgcn_readfirstlane(ab.x) : 0;
+      dn = flip ? __builtin_amdgcn_readfirstlane(ab.y) : (N > 1 ? 1 : 0);
+    } else {
+      up = __builtin_amdgcn_readfirstlane(s_prop[0]); dn = __builtin_amdgcn_readfirstlane(s_prop[1]);   // (uniform: scalar arithmetic below)
+    }
     const int q1[2] = {up / D2, dn / D2};
     const int q2[2] = {up - q1[0] * D2, dn - q1[1] * D2};
     // ---- convolution 0: the windows are the candidate's spins (the exchanged pair negated)
@@ -113,8 +129,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
       for (int i = tid; i < 2 * n_win; i += NT) {
         const int b = i >= n_win, j = i - b * n_win, wy = j / SC, wx = j - wy * SC;
         const int site = cp_fold((b ? o1[1] : o1[0]) + wy, D1) * D2 + cp_fold((b ? o2[1] : o2[0]) + wx, D2);
-        const float x = s_x[site];
-        s_win[b * wstride + j] = (site == up || site == dn) ? -x : x;
+        const float x = ELOC ? a.configs[c * N + site] : s_x[site];
+        s_win[b * wstride + j] = (flip && (site == up || site == dn)) ? -x : x;
       }
       __syncthreads();
       f32x4 bias4;
@@ -314,7 +330,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
     }
     __syncthreads();
     stamp(3);
-    if (tid == 0) {
+    if (ELOC) {
+      if (tid == 0) a.out_sum[st] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);        // k_cgen_rowsum's value
+    } else if (tid == 0) {
       const double sd = 0.0 + ((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
       const float lnew = (float)sd + 0.f;
       const float uu = s_u;
@@ -338,7 +356,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
         s_ovl[cp_fold((b ? bo1[1] : bo1[0]) + y, D1) * D2 + cp_fold((b ? bo2[1] : bo2[0]) + x, D2)] = -1;
       }
     }
-    if (s_prop[2]) {
+    if (!ELOC && s_prop[2]) {
       // ---- accepted: the boxes become part of the chain's maps
       for (int l = 0; l < L; ++l) {
         const int s1 = side1(l), s2 = side2(l), n_pos = s1 * s2;
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
     // ---- the next proposal (k_cgen_step_tail's, k_wide_propose's arithmetic) from the chain as it now stands
     // (all four waves: the rule -- the largest / smallest x u, the lowest index among equal values -- does not depend on the
     // order in which the candidates meet)
-    if (st + 1 < a.n_steps) {
+    if (!ELOC && st + 1 < a.n_steps) {
       const unsigned long long next_step = a.step0 + (unsigned long long)st + 1;
       const uint2 key = make_uint2(a.seed_lo, a.seed_hi);
       const uint32_t gid = (uint32_t)(a.chain_offset + (int)c);
@@ -403,28 +421,28 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
     stamp(5);
   }
   if (prof) for (int i = 0; i < 6; ++i) a.prof[i] = t_ph[i];
-  if (tid == 0) {
+  if (!ELOC && tid == 0) {
     a.logit[c] = cur_logit;
     if (n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);
   }
 }
 
-template <int K, int KW, int NW>
-hipError_t launch_pw(hipStream_t s, const CgenPatchArgs& a) {
+template <int K, int KW, int NW, bool ELOC>
+hipError_t launch_pw(hipStream_t s, const CgenPatchArgs& a, unsigned grid) {
   const size_t lds = plan_cgen_patch_lds_bytes(a.g);
-  hipError_t e = hipFuncSetAttribute((const void*)k_cgen_patch_sweep<K, KW, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)k_cgen_patch_sweep<K, KW, NW, ELOC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_cgen_patch_sweep<K, KW, NW>), dim3((unsigned)a.B), dim3(64 * NW), lds, s, a);
+  hipLaunchKernelGGL((k_cgen_patch_sweep<K, KW, NW, ELOC>), dim3(grid), dim3(64 * NW), lds, s, a);
   return hipGetLastError();
 }
 // eight waves while the fragments of a convolution leave room for two waves per SIMD (CGS_VMC_CONV_PATCH_WAVES=4 forces four)
-template <int K, int KW>
-hipError_t launch_p(hipStream_t s, const CgenPatchArgs& a) {
+template <int K, int KW, bool ELOC>
+hipError_t launch_p(hipStream_t s, const CgenPatchArgs& a, unsigned grid) {
   if constexpr (K * KW <= 25) {
     const char* e = getenv("CGS_VMC_CONV_PATCH_WAVES");
-    if (!(e && atoi(e) == 4)) return launch_pw<K, KW, 8>(s, a);
+    if (!(e && atoi(e) == 4)) return launch_pw<K, KW, 8, ELOC>(s, a, grid);
   }
-  return launch_pw<K, KW, 4>(s, a);
+  return launch_pw<K, KW, 4, ELOC>(s, a, grid);
 }
 
 }  // namespace
@@ -435,7 +453,22 @@ hipError_t launch_cgen_patch_sweep(hipStream_t s, const CgenPatchArgs& a) {
   if (a.B <= 0 || a.n_steps <= 0) return hipSuccess;
   if (!cgen_patch_ok(a.g, a.B)) return hipErrorInvalidValue;
   const bool two_d = a.g.KW == a.g.K;
-#define CP_CASE(KK) case KK: return two_d ? launch_p<KK, KK>(s, a) : launch_p<KK, 1>(s, a);
+#define CP_CASE(KK) case KK: return two_d ? launch_p<KK, KK, false>(s, a, (unsigned)a.B) : launch_p<KK, 1, false>(s, a, (unsigned)a.B);
+  switch (a.g.K) {
+    CP_CASE(2) CP_CASE(3) CP_CASE(4) CP_CASE(5) CP_CASE(6) CP_CASE(7)
+    default: return hipErrorInvalidValue;
+  }
+#undef CP_CASE
+}
+
+// The sums of the last map of n_rows rows of a row list over the chains whose maps `a.maps` holds: one workgroup per CU walks
+// the rows (the LDS of a workgroup is most of a CU's)
+hipError_t launch_cgen_patch_rows(hipStream_t s, const CgenPatchArgs& a, int num_cus) {
+  if (a.B <= 0 || a.n_rows <= 0) return hipSuccess;
+  if (!cgen_patch_ok(a.g, a.B) || !a.rowinfo || !a.bonds || !a.out_sum) return hipErrorInvalidValue;
+  const bool two_d = a.g.KW == a.g.K;
+  const unsigned grid = (unsigned)(a.n_rows < num_cus ? a.n_rows : num_cus);
+#define CP_CASE(KK) case KK: return two_d ? launch_p<KK, KK, true>(s, a, grid) : launch_p<KK, 1, true>(s, a, grid);
   switch (a.g.K) {
     CP_CASE(2) CP_CASE(3) CP_CASE(4) CP_CASE(5) CP_CASE(6) CP_CASE(7)
     default: return hipErrorInvalidValue;

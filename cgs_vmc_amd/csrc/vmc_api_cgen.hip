@@ -94,6 +94,37 @@ const float* cgen_last_map(const vmc_ctx* c) {
   return (c->cg.resnet ? c->cg_fm[0] : c->cg_fm[(c->cg.n_conv - 1) & 1]) + c->cg_map_row0 * c->cg.N * cgen_fp(c->cg);
 }
 
+// The patch kernels (conv_patch.hip) -- 0: not for this ctx / switched off; 1: where they pay; 2: wherever the shape allows.
+// CGS_VMC_CONV_PATCH=0 | 2, read per call (tests compare the two forms in one process); a box has the BAND kernel's bits, so not
+// with CGS_VMC_CONV_BAND=0.
+int cgen_patch_mode(const vmc_ctx* c) {
+  if (!c->conv_general) return 0;
+  const char* pe = getenv("CGS_VMC_CONV_PATCH");
+  const int mode = pe ? atoi(pe) : 1;
+  if (mode == 0 || !cgen_band_on() || !cgen_patch_ok(c->cg, c->B)) return 0;
+  return mode == 2 ? 2 : 1;
+}
+// the maps of every convolution of the ctx's B chains at parameter set `which`: one taped forward, blocks of the im2col-sized rows
+int cgen_patch_maps(vmc_ctx* c, int which) {
+  const ConvGeom& g = c->cg;
+  const long long map_floats = (long long)c->B * g.N * cgen_fp(g);
+  if (!c->cg_pmaps) HIPCHK(c, dalloc(&c->cg_pmaps, g.n_conv * map_floats));
+  for (long long r0 = 0; r0 < c->B; r0 += c->cg_rows) {
+    const long long rows = c->B - r0 < c->cg_rows ? c->B - r0 : c->cg_rows;
+    PROPAGATE(cgen_forward(c, which, c->configs, nullptr, rows, nullptr, nullptr, false, nullptr,
+                           c->cg_pmaps + r0 * g.N * cgen_fp(g), map_floats, r0));
+  }
+  return VMC_OK;
+}
+void cgen_patch_args(const vmc_ctx* c, int which, CgenPatchArgs* a) {
+  const ConvGeom& g = c->cg;
+  memset(a, 0, sizeof(*a));
+  a->g = g; a->Fp = cgen_fp(g); a->theta = c->ps[which].theta; a->maps = c->cg_pmaps;
+  a->map_stride = (long long)c->B * g.N * cgen_fp(g);
+  a->post = g.hact != VMC_ACT_COS_ ? 1 : 0; a->act = g.hact; a->oact = c->oact;
+  a->configs = c->configs; a->B = c->B;
+}
+
 // tape != nullptr (gradient path, n_rows <= cg_rows): the map of convolution l is kept at tape + l * tape_stride
 // (cgen_post says what it holds; for the second convolution of a residual block the block's output h + v)
 int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2* rowinfo, long long n_rows,
@@ -108,6 +139,29 @@ int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2* rowinf
   const long long moff = c->cg_map_row0 * g.N * Fp;      // (a sampler group's slice of the maps; 0 elsewhere)
   auto map = [&](int l) { return tape ? tape + (long long)l * tape_stride : c->cg_fm[g.resnet ? (l & 1 ? 1 : 0) : (l & 1)] + moff; };
   if (tape && n_rows > c->cg_rows) return fail(c, VMC_ERR_STATE, "taped forward beyond one block");
+  // The rows of a row list over the ctx's chains -- the local energies' connected configurations (operators.py:162-169:
+  // the chain with one antiparallel bond exchanged) -- through the patch kernel: the chains' maps once (B forwards), then
+  // per row the boxes around the bond's two sites and the last map's sum with them overlaid; the sums are k_cgen_rowsum's
+  // bits, the rest of the block is the same (k_wide_out_part).
+  if (!tape && out && !iup && rowinfo && rowinfo != c->rowinfo_id && configs == c->configs && n_rows > 0) {
+    const int mode = cgen_patch_mode(c);
+    if (mode == 2 || (mode == 1 && plan_cgen_patch_pays(g) && n_rows >= 4LL * c->B)) {
+      PROPAGATE(cgen_patch_maps(c, which));
+      CgenPatchArgs a;
+      cgen_patch_args(c, which, &a);
+      a.rowinfo = rowinfo; a.bonds = c->bonds ? c->bonds : c->bond_dummy; a.out_sum = c->cg_sum;
+      const long long blk = c->cg_rows_fwd;
+      for (long long blk0 = 0; blk0 < n_rows; blk0 += blk) {
+        const long long rows = n_rows - blk0 < blk ? n_rows - blk0 : blk;
+        a.row0 = first_row + blk0; a.n_rows = rows;
+        HIPCHK(c, launch_cgen_patch_rows(cg_s(c), a, c->num_cus));
+        const WideOnsite on{nullptr, nullptr, nullptr, nullptr, nullptr};
+        HIPCHK(c, launch_wide_out_part(cg_s(c), c->cg_sum, 1, c->cg_zero, (int)rows, rowinfo, a.row0,
+                                       c->half_jx, p.logit, c->oact, ratio, out, on));
+      }
+      return VMC_OK;
+    }
+  }
   // block size: the im2col-sized one, or -- untaped, every convolution on the band kernel -- the maps-sized one
   const long long blk_rows = (!tape && cgen_band_on() && cgen_band_ok(g)) ? c->cg_rows_fwd : c->cg_rows;
   for (long long blk0 = 0; blk0 < n_rows; blk0 += blk_rows) {

@@ -106,15 +106,10 @@ int refresh_cache_by_sampler(vmc_ctx* c, int which) {
   return VMC_OK;
 }
 
-// Does a plain launch of n_steps steps take the patch sampler (conv_patch.hip)?  CGS_VMC_CONV_PATCH=0: never; =2: wherever the
-// shape allows (tests: short launches, small lattices); read per call.  (A box has the BAND kernel's bits: not with CGS_VMC_CONV_BAND=0.)
+// Does a plain launch of n_steps steps take the patch sampler (conv_patch.hip)?  (cgen_patch_mode: CGS_VMC_CONV_PATCH)
 static bool cgen_patch_use(const vmc_ctx* c, long long n_steps) {
-  if (!c->conv_general) return false;
-  const char* pe = getenv("CGS_VMC_CONV_PATCH");
-  const int mode = pe ? atoi(pe) : 1;
-  const bool band = !(getenv("CGS_VMC_CONV_BAND") && atoi(getenv("CGS_VMC_CONV_BAND")) == 0);
-  return mode != 0 && band && n_steps >= 1 && cgen_patch_ok(c->cg, c->B) &&
-         (mode == 2 || (plan_cgen_patch_pays(c->cg) && n_steps >= 8));
+  const int mode = cgen_patch_mode(c);
+  return n_steps >= 1 && (mode == 2 || (mode == 1 && plan_cgen_patch_pays(c->cg) && n_steps >= 8));
 }
 
 // Chain groups of the general convolution sampler (plan.hpp's rule; CGS_VMC_CONV_GENERAL_GROUPS=1..4 forces, read per call)
@@ -151,23 +146,14 @@ static int run_sweep_cgen(vmc_ctx* c, long long n_steps, bool injected, bool dbg
   // the exchanged pair touches instead of the lattice, all steps of a chain in one launch -- the same chains bit for bit.
   // (cgen_patch_use: CGS_VMC_CONV_PATCH)
   {
-    if (!injected && cgen_patch_use(c, n_steps)) {
-      const ConvGeom& g = c->cg;
-      const long long map_floats = (long long)B * N * cgen_fp(g);
-      if (!c->cg_pmaps) HIPCHK(c, dalloc(&c->cg_pmaps, g.n_conv * map_floats));
+    if (!injected && cgen_patch_use(c, n_steps)) {   // (mc_steps always samples psi: ps[0])
       HIPCHK(c, launch_wide_propose(c->stream, c->configs, B, N, seed_lo, seed_hi, c->d.chain_offset, step0, nullptr, nullptr,
                                     nullptr, c->wide_iup, c->wide_idn, c->wide_u));
-      // the chains' maps as they stand: one taped full forward (blocks of the im2col-sized rows; the band kernel writes them)
-      for (long long r0 = 0; r0 < B; r0 += c->cg_rows) {
-        const long long rows = B - r0 < c->cg_rows ? B - r0 : c->cg_rows;
-        PROPAGATE(cgen_forward(c, VMC_PSI, c->configs, nullptr, rows, nullptr, nullptr, false, nullptr,
-                               c->cg_pmaps + r0 * N * cgen_fp(g), map_floats, r0));
-      }
-      CgenPatchArgs a; memset(&a, 0, sizeof(a));
-      a.g = g; a.Fp = cgen_fp(g); a.theta = p.theta; a.maps = c->cg_pmaps; a.map_stride = map_floats;
-      a.post = g.hact != VMC_ACT_COS_ ? 1 : 0; a.act = g.hact; a.oact = c->oact;
-      a.configs = c->configs; a.logit = p.logit; a.iup = c->wide_iup; a.idn = c->wide_idn; a.u = c->wide_u;
-      a.accepted = c->d_accepted; a.B = B; a.seed_lo = seed_lo; a.seed_hi = seed_hi; a.chain_offset = c->d.chain_offset;
+      PROPAGATE(cgen_patch_maps(c, VMC_PSI));       // the chains' maps as they stand: one taped full forward
+      CgenPatchArgs a;
+      cgen_patch_args(c, VMC_PSI, &a);
+      a.logit = p.logit; a.iup = c->wide_iup; a.idn = c->wide_idn; a.u = c->wide_u;
+      a.accepted = c->d_accepted; a.seed_lo = seed_lo; a.seed_hi = seed_hi; a.chain_offset = c->d.chain_offset;
       a.step0 = step0; a.n_steps = n_steps;
       unsigned long long* d_prof = nullptr;         // diagnostic: the phase clocks of chain 0 to stderr (synchronises)
       if (getenv("CGS_VMC_CONV_PATCH_PROF") && atoi(getenv("CGS_VMC_CONV_PATCH_PROF")) != 0) {

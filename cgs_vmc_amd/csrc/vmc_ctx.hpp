@@ -380,6 +380,9 @@ int grow_tmp(vmc_ctx* c, long long rows);
 int cgen_forward(vmc_ctx* c, int which, const float* configs, const int2* rowinfo, long long n_rows,
                  const int* iup, const int* idn, bool ratio, float* out, float* tape = nullptr,
                  long long tape_stride = 0, long long first_row = 0);
+int cgen_patch_mode(const vmc_ctx* c);
+int cgen_patch_maps(vmc_ctx* c, int which);
+void cgen_patch_args(const vmc_ctx* c, int which, CgenPatchArgs* a);
 bool cgen_single_block(const vmc_ctx* c, long long n_rows);
 const float* cgen_last_map(const vmc_ctx* c);
 int cgen_gradient_sums(vmc_ctx* c, const float* w);

@@ -8,6 +8,7 @@ Tolerances as tests/test_gpu_conv.py."""
 import numpy as np
 import pytest
 
+from cgs_vmc_amd import _hip
 from oracle import vmc_oracle as vo
 from tests.test_gpu_conv import _close, _logits_close, _make
 
@@ -389,6 +390,38 @@ def test_patch_sampler_gives_the_chains_of_the_full_forward(monkeypatch, ansatz,
   for a, bb in zip(out['0'], out['2']):
     np.testing.assert_array_equal(a, bb)
   _logits_close(out['2'][7], theta, out['2'][6], ansatz, geom, L, nonlin)      # ... and the oracle's amplitudes of the final chains
+  eng.close()
+
+
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,b,nonlin', PATCH_SHAPES, ids=['{}-{}x{}-L{}-F{}-K{}-B{}-{}'.format(*s) for s in PATCH_SHAPES])
+def test_patch_rows_give_the_local_energies_of_the_full_forward(monkeypatch, ansatz, sx, sy, L, f, k, b, nonlin):
+  """Round 6: the local energies' connected configurations (operators.py:162-169: the chain with one antiparallel bond
+  exchanged) through the ELOC form of k_cgen_patch_sweep -- the chains' maps once, per row the boxes around the bond's two
+  sites, the last map's sum with them overlaid in k_cgen_rowsum's order -- against a full forward of every row
+  (CGS_VMC_CONV_PATCH=0): local energies, their terms and the gradient accumulators are the same bits; and the oracle's
+  local energies within the path's tolerance."""
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '1')
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6
+  out = {}
+  for jx in (-1.0, 1.0):
+    eng.set_bonds(bonds, jx, 1.0)
+    for patch in ('0', '2'):
+      monkeypatch.setenv('CGS_VMC_CONV_PATCH', patch)
+      eng.set_configs(cfg)
+      eloc, mean = eng.local_energy()
+      diag, off = eng.local_energy_terms()
+      eng.reset_accumulators()
+      eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
+      out[patch] = (eloc, np.float64(mean), diag, off, eng.get_accumulators())
+    assert eng.last_connected_rows() > b
+    for a, bb in zip(out['0'], out['2']):
+      np.testing.assert_array_equal(a, bb)
+    amp = lambda c: vo.ANSATZ[ansatz][0](theta, c, geom, L, nonlinearity=nonlin, dtype=np.float64)
+    with np.errstate(invalid='ignore', over='ignore'):     # (36 x 36 sites at the initialisation's scale: exp overflows on masked rows)
+      ref = vo.local_value(amp, cfg, bonds, jx, 1.0, dtype=np.float64)
+    assert np.isfinite(ref).all()
+    _close(out['2'][0], ref, 2e-4)
   eng.close()
 
 
