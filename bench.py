@@ -994,6 +994,9 @@ def main():
             s1, s2 = (l + 1) * (ksz - 1) + 1, (l + 1) * (kw - 1) + 1
             per_step += 2 * ((s1 * s2 + 15) // 16) * taps * 4 * 2048           # 16 channels x 16 positions x 4 channels per MFMA
           exec_sweep = b * n * per_step
+          if rows >= 4 * b:         # ... and the local energies' rows through its ELOC form (cgen_forward: the same boxes around the exchanged bond)
+            k_eloc = 'k_cgen_patch_sweep<ELOC>(eloc)'
+            exec_eloc = rows * per_step
       if not conv and h > 512:        # the general path: per mc_step one k_wide_step launch + the H x H layers as GEMMs
         k_sweep = 'k_wide_step + k_gemm_ring(sampler)'
       per_kernel = {
@@ -1040,7 +1043,11 @@ def main():
           prof = json.load(open(tpath))
           collected_at = prof.pop('_collected_at_source_hash', None)
           for name, rec in prof.items():
-            if name.startswith(('k_tail16r', 'k_tail16s') if (split and key == k_eloc) else (('k_sweep16s',) if (split_sweep and key == k_sweep) else (key.split('(')[0],))) and rec.get('hbm_read_bytes') is not None:
+            if key.startswith('k_cgen_patch_sweep'):      # one template, two forms: <K, KW, waves, ELOC>
+              hit = name.startswith('k_cgen_patch_sweep') and name.endswith('true>' if 'ELOC' in key else 'false>')
+            else:
+              hit = name.startswith(('k_tail16r', 'k_tail16s') if (split and key == k_eloc) else (('k_sweep16s',) if (split_sweep and key == k_sweep) else (key.split('(')[0],)))
+            if hit and rec.get('hbm_read_bytes') is not None:
               traffic = rec['hbm_read_bytes'] + (rec.get('hbm_write_bytes') or 0)
               pmc = {k: rec[k] for k in ('mfma_util', 'clock_ghz', 'median_us') if k in rec}
               pmc['source'] = 'profiles/{}_traffic.json'.format(tag)
