@@ -84,6 +84,9 @@ WORKLOADS = {
     'heisenberg36x36_conv3x16k5_b32': (36, 36, False, 3, 16, 32, 'conv_2d', 5),
     # round 6: the same lattice at 64 filters 3 x 3 (four channel blocks on the band kernel of conv_band.hip)
     'heisenberg36x36_conv3x64k3_b32': (36, 36, False, 3, 64, 32, 'conv_2d', 3),
+    # a lattice whose maps still fit the fused kernels' LDS but is wider than the network's reach: fused kernels against the general path's patch kernels (CGS_VMC_CONV_GENERAL=1)
+    'heisenberg24x24_conv2x16k5_b256': (24, 24, False, 2, 16, 256, 'conv_2d', 5),
+    'heisenberg20x20_conv3x16k3_b256': (20, 20, False, 3, 16, 256, 'conv_2d', 3),
 }
 
 

@@ -390,8 +390,19 @@ static void conv_grid() {
                 continue;
               }
               CHECK((resnet || L >= 1) && p.conv);
-              if (p.conv_general) {       // beyond the fused kernels: for exactly one of their four reasons
-                CHECK(F > 64 || K > 9 || plan_conv_rows_lds(p.cg, 1) > PLAN_LDS_PER_CU || B * p.cg.CS >= (1LL << 31));
+              if (p.conv_general) {       // beyond the fused kernels for one of their four reasons -- or sent here because the patch kernels beat them
+                const bool refused = F > 64 || K > 9 || plan_conv_rows_lds(p.cg, 1) > PLAN_LDS_PER_CU || B * p.cg.CS >= (1LL << 31);
+                CHECK(refused || plan_cgen_patch_routes(p.cg, B));
+                if (!refused) {           // ... by preference only: CGS_VMC_CONV_GENERAL=0 keeps the fused kernels
+                  DescPlan pf;
+                  CHECK(plan_desc(&d, true, &pf, msg, sizeof(msg), -1) == VMC_OK && !pf.conv_general);
+                }
+                if (plan_cgen_patch_ok(p.cg, B)) {      // the patch kernels' LDS plan: within a CU's, every piece inside it
+                  const size_t lds = plan_cgen_patch_lds_bytes(p.cg);
+                  CHECK(lds <= PLAN_CGEN_PATCH_LDS && !resnet && F <= 16 && L >= 2);
+                  CHECK(plan_cgen_patch_side(p.cg, L - 1, 0) <= p.cg.D1 && plan_cgen_patch_side(p.cg, L - 1, 1) <= p.cg.D2);
+                  CHECK(2LL * plan_cgen_patch_side(p.cg, L - 1, 0) * plan_cgen_patch_side(p.cg, L - 1, 1) <= 32768);   // 16-bit marks: the last index is 2 s1 s2 - 1
+                }
                 CHECK((long long)p.cg.N * plan_cgen_lda(p.cg) < (1LL << 28));
                 // the band kernel of the general path (<= 16 filters, 2 .. 7 taps): a band with its halo fits its LDS
                 // budget, the bands cover the lattice, the staged index stays in 32 bits
@@ -464,6 +475,12 @@ static void conv_grid() {
       CHECK(plan_desc(&s, true, &t, msg, sizeof(msg), true) == VMC_OK && plan_cgen_patch_ok(t.cg, 32) && !plan_cgen_patch_pays(t.cg));
       s = b; s.num_layers = 1;                                         // one convolution: nothing to keep
       CHECK(plan_desc(&s, true, &t, msg, sizeof(msg)) == VMC_OK && !plan_cgen_patch_ok(t.cg, 32));
+      // routing: a shape the fused kernels take goes to the general path where the boxes are at most a fifth of a forward
+      s = b; s.size_x = s.size_y = 24; s.n_sites = 576; s.num_layers = 2; s.batch_size = 256;     // 2 (25 + 81) of 2 x 576: 18 %
+      CHECK(plan_desc(&s, true, &t, msg, sizeof(msg)) == VMC_OK && t.conv_general && plan_cgen_patch_routes(t.cg, 256));
+      CHECK(plan_desc(&s, true, &t, msg, sizeof(msg), -1) == VMC_OK && !t.conv_general);         // CGS_VMC_CONV_GENERAL=0
+      s.size_x = s.size_y = 16; s.n_sites = 256;                                                  // 2 (25 + 81) of 2 x 256: 41 %
+      CHECK(plan_desc(&s, true, &t, msg, sizeof(msg)) == VMC_OK && !t.conv_general && plan_cgen_patch_ok(t.cg, 256) && !plan_cgen_patch_routes(t.cg, 256));
       s = b; s.layer_size = 32; s.kernel_size = 3;                     // two channel blocks
       CHECK(plan_desc(&s, true, &t, msg, sizeof(msg)) == VMC_OK && t.conv_general && !plan_cgen_patch_ok(t.cg, 32));
     }

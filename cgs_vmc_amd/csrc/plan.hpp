@@ -190,6 +190,16 @@ inline bool plan_cgen_patch_ok(const ConvGeom& g, long long B) {
 inline bool plan_cgen_patch_pays(const ConvGeom& g) {
   return 4LL * plan_cgen_patch_side(g, g.n_conv - 1, 0) * plan_cgen_patch_side(g, g.n_conv - 1, 1) <= g.N;
 }
+// ... and where they beat the FUSED kernels (whose maps never leave the LDS): the boxes of all convolutions together at most
+// a fifth of the positions a forward computes.  Whole steps at 256 chains, fused -> general path with the patch kernels:
+// 24 x 24, 2 x 16 filters 5 x 5 (18 %): 36.2 -> 19.8 ms; 20 x 20, 3 x 16 filters 3 x 3 (14 %): 17.6 -> 13.6 ms.  plan_desc sends
+// such a shape to the general path although the fused kernels would take it (CGS_VMC_CONV_GENERAL=0: not by preference).
+inline bool plan_cgen_patch_routes(const ConvGeom& g, long long B) {
+  if (!plan_cgen_patch_ok(g, B) || !plan_cgen_patch_pays(g)) return false;
+  long long boxes = 0;
+  for (int l = 0; l < g.n_conv; ++l) boxes += 2LL * plan_cgen_patch_side(g, l, 0) * plan_cgen_patch_side(g, l, 1);
+  return 5 * boxes <= (long long)g.n_conv * g.N;
+}
 // k_cgen_first_direct (conv_band.hip): spins [N], weights [taps][Fp], bias [Fp], neighbour table [N][taps]
 inline size_t plan_cgen_first_direct_lds_bytes(const ConvGeom& g) {
   const size_t fp = (size_t)((g.F + 3) & ~3), t = (size_t)g.K * g.KW;
@@ -423,8 +433,10 @@ struct DescPlan {
 
 // Everything vmc_create decides before it touches the device.  Returns a vmc_status; `msg` receives the
 // reason.  wide_fast_allowed = false is CGS_VMC_WIDE_FAST=0.
+// conv_general_pref (CGS_VMC_CONV_GENERAL): 1 the general convolution path for every shape, 0 where the fused kernels refuse
+// the shape or the patch kernels beat them (plan_cgen_patch_routes), -1 only where the fused kernels refuse it
 inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, char* msg, size_t msg_len,
-                     bool force_conv_general = false) {
+                     int conv_general_pref = 0) {
   memset(out, 0, sizeof(*out));
 #define PLAN_FAIL(code, text) do { snprintf(msg, msg_len, "%s", text); return code; } while (0)
   if (d->ansatz < VMC_ANSATZ_FULLY_CONNECTED || d->ansatz > VMC_ANSATZ_RES_NET_1D)
@@ -448,7 +460,7 @@ inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, c
     // of conv_general.hip serves: feature maps in HBM, a convolution = im2col (explicit, or in the A operand's address)
     // + one GEMM (round 5: forward, local energies, sampler, the gradient accumulators of both optimizers and
     // stochastic reconfiguration through the one-call solves)
-    bool general = force_conv_general;
+    bool general = conv_general_pref > 0;
     if (d->kernel_size < 1 || d->kernel_size > CONV_GENERAL_MAX_K)
       PLAN_FAIL(VMC_ERR_UNSUPPORTED, "kernel_size 1..31 supported by the convolution kernels");
     if (d->layer_size > CONV_GENERAL_MAX_F)
@@ -472,6 +484,7 @@ inline int plan_desc(const vmc_desc* d, bool wide_fast_allowed, DescPlan* out, c
     if (cg.n_conv > CONV_MAX_LAYERS) PLAN_FAIL(VMC_ERR_UNSUPPORTED, "too many convolutions");
     if ((long long)d->batch_size * cg.CS >= (1LL << 31)) general = true;   // 32-bit tape offsets of the fused kernels
     if (plan_conv_rows_lds(cg, 1) > PLAN_LDS_PER_CU) general = true;       // a sample's maps beyond 160 KiB of LDS
+    if (!general && conv_general_pref == 0 && plan_cgen_patch_routes(cg, d->batch_size)) general = true;   // a lattice much wider than the network's reach
     if (general && (long long)cg.N * plan_cgen_lda(cg) >= (1LL << 28))
       PLAN_FAIL(VMC_ERR_UNSUPPORTED, "lattice x kernel x filters too large for the general convolution path (one sample's im2col rows beyond 1 GiB)");
     out->conv_general = general ? 1 : 0;

@@ -328,8 +328,8 @@ int vmc_create(const vmc_desc* d, vmc_ctx** out) {
   {
     char msg[256];
     const char* wf = getenv("CGS_VMC_WIDE_FAST");
-    const char* fg = getenv("CGS_VMC_CONV_GENERAL");      // =1: the general convolution path for every shape (tests, A/B runs)
-    const int rc = plan_desc(d, !(wf && atoi(wf) == 0), &dp, msg, sizeof(msg), fg && atoi(fg) != 0);
+    const char* fg = getenv("CGS_VMC_CONV_GENERAL");      // =1: the general convolution path for every shape (tests, A/B runs); =0: only where the fused kernels refuse
+    const int rc = plan_desc(d, !(wf && atoi(wf) == 0), &dp, msg, sizeof(msg), fg ? (atoi(fg) != 0 ? 1 : -1) : 0);
     if (rc != VMC_OK) return fail(nullptr, rc, msg);
   }
   const bool rbm = dp.rbm != 0, conv = dp.conv != 0, wide = dp.wide != 0, wide_fast_ok = dp.wide_fast != 0;

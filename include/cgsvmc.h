@@ -356,7 +356,12 @@ int vmc_debug_sweep_tile(vmc_ctx* ctx, int32_t set, int32_t* chains);
  * cgs_vmc_amd/csrc/conv_patch.hip)?  It recomputes, per step, only the two boxes of every convolution that the exchanged
  * pair of graph_builders.py:67-71 reaches through layers.py:118-160's taps -- Conv2DNetwork / Conv1DNetwork at <= 16
  * filters on a lattice wider than the last box, launches of >= 8 steps; CGS_VMC_CONV_PATCH=0 never, =2 wherever the shape
- * allows -- and gives the chains of the full-forward sampler bit for bit.  *patch: 1 / 0. */
+ * allows -- and gives the chains of the full-forward sampler bit for bit.  *patch: 1 / 0.
+ * The local energies' connected configurations (operators.py:162-169) run through the same kernel's second form.
+ * vmc_create sends a convolutional shape that the fused kernels would take to the general path (vmc_debug_kernel_path 6)
+ * when these kernels beat them: the boxes of all convolutions at most a fifth of the lattice x convolutions (e.g. 20 x 20
+ * sites, 3 x 16 filters 3 x 3).  CGS_VMC_CONV_GENERAL=0 keeps the fused kernels there (their gradient and stochastic-
+ * reconfiguration kernels are the faster ones: a solve over many stored samples may prefer them). */
 int vmc_debug_conv_patch(vmc_ctx* ctx, int64_t n_steps, int32_t* patch);
 int vmc_synchronize(vmc_ctx* ctx);
 

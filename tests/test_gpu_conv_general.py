@@ -418,10 +418,33 @@ def test_patch_rows_give_the_local_energies_of_the_full_forward(monkeypatch, ans
     for a, bb in zip(out['0'], out['2']):
       np.testing.assert_array_equal(a, bb)
     amp = lambda c: vo.ANSATZ[ansatz][0](theta, c, geom, L, nonlinearity=nonlin, dtype=np.float64)
-    with np.errstate(invalid='ignore', over='ignore'):     # (36 x 36 sites at the initialisation's scale: exp overflows on masked rows)
-      ref = vo.local_value(amp, cfg, bonds, jx, 1.0, dtype=np.float64)
-    assert np.isfinite(ref).all()
-    _close(out['2'][0], ref, 2e-4)
+    if sx * sy <= 1000:      # (the oracle works on amplitudes: at 36 x 36 sites exp(logit) leaves the doubles -- the bits above are the check there)
+      _close(out['2'][0], vo.local_value(amp, cfg, bonds, jx, 1.0, dtype=np.float64), 2e-4)
+  eng.close()
+
+
+def test_wide_lattice_goes_to_the_patch_kernels_by_itself(monkeypatch):
+  """plan_desc sends a shape the fused kernels would take to the general path where the patch kernels beat them (the boxes at
+  most a fifth of a forward: plan_cgen_patch_routes); CGS_VMC_CONV_GENERAL=0 keeps the fused kernels.  The two agree as the
+  two paths do everywhere, and the routed ctx passes the oracle checks."""
+  ansatz, sx, sy, L, f, k, b, nonlin = 'conv_2d', 20, 20, 3, 16, 3, 6, 'relu'
+  monkeypatch.setenv('CGS_VMC_CONV_GENERAL', '0')
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 3 and not eng.conv_patch(sx * sy)
+  fused = (eng.amplitude()[0], eng.local_energy()[0])
+  eng.close()
+  monkeypatch.delenv('CGS_VMC_CONV_GENERAL')
+  monkeypatch.delenv('CGS_VMC_CONV_PATCH', raising=False)
+  eng, theta, cfg, bonds, geom = _make(ansatz, sx, sy, L, f, k, b, nonlin)
+  assert eng.kernel_path() == 6 and eng.conv_patch(sx * sy) and not eng.conv_patch(4)
+  _, scale = vo.conv_forward(theta, cfg, ansatz, geom, L, nonlin, np.float64, return_tape='scale')
+  assert (np.abs(eng.amplitude()[0].astype(np.float64) - fused[0]) <= 2e-6 * scale + 4e-5).all()
+  _close(eng.local_energy()[0], fused[1], 4e-4)
+  _check_forward_and_sampler(eng, theta, cfg, bonds, geom, ansatz, L, nonlin, b, steps=10)
+  eng.close()
+  # a lattice the network's reach covers stays where it was
+  eng, *_ = _make('conv_2d', 12, 12, 3, 16, 3, 6, 'relu')
+  assert eng.kernel_path() == 3
   eng.close()
 
 
