@@ -435,14 +435,11 @@ hipError_t launch_pw(hipStream_t s, const CgenPatchArgs& a, unsigned grid) {
   hipLaunchKernelGGL((k_cgen_patch_sweep<K, KW, NW, ELOC>), dim3(grid), dim3(64 * NW), lds, s, a);
   return hipGetLastError();
 }
-// eight waves while the fragments of a convolution leave room for two waves per SIMD (CGS_VMC_CONV_PATCH_WAVES=4 forces four)
+// eight waves while the fragments of a convolution leave room for two waves per SIMD (measured at 36 x 36 x 16, 5 x 5: 40.2
+// against 42.2 ms per sweep on four: profiles/r6_conv_patch_bench.txt), four at 6 x 6 and 7 x 7 taps
 template <int K, int KW, bool ELOC>
 hipError_t launch_p(hipStream_t s, const CgenPatchArgs& a, unsigned grid) {
-  if constexpr (K * KW <= 25) {
-    const char* e = getenv("CGS_VMC_CONV_PATCH_WAVES");
-    if (!(e && atoi(e) == 4)) return launch_pw<K, KW, 8, ELOC>(s, a, grid);
-  }
-  return launch_pw<K, KW, 4, ELOC>(s, a, grid);
+  return launch_pw<K, KW, (K * KW <= 25 ? 8 : 4), ELOC>(s, a, grid);
 }
 
 }  // namespace
