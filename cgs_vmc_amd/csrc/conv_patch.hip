@@ -18,6 +18,8 @@
 //   * an accepted move writes the boxes into the stored maps; the next proposal is k_cgen_step_tail's.
 // Work per step: 2 sum_l box_l^2 positions instead of n_conv N -- 36 x 36, 3 convolutions 5 x 5: 550 of 3,888 -- and no
 // launch, no grid-wide hand-over between the convolutions: a chain's step is a workgroup's business.
+// Residual networks (layers.py:226-228, wavefunctions.py:766-772): the initial convolution is linear, a block's first ends in
+// selu, its second adds the block's input h -- read from the map two convolutions below with ITS boxes overlaid.
 // Shapes: plan_cgen_patch_ok (plan.hpp).
 #include "conv.hpp"
 
@@ -27,6 +29,10 @@
 namespace {
 
 __device__ __forceinline__ float cp_pre(int pre, float x) { return pre < 0 ? x : vmc_act_rt(pre, x); }
+__device__ __forceinline__ float cp_selu(float x) {   // layers.py:226 tf.nn.selu (k_cgen_band's form and constants)
+  const float scale = 1.0507009873554805f, alpha = 1.6732632423543772f;
+  return scale * (x > 0.f ? x : alpha * (expf(x) - 1.f));
+}
 __device__ __forceinline__ int cp_wrap(int v, int d) { v %= d; return v < 0 ? v + d : v; }
 // v in [0, 3 d): the coordinate of a window site = a wrapped origin + an offset below d + K
 __device__ __forceinline__ int cp_fold(int v, int d) { v -= v >= d ? d : 0; v -= v >= d ? d : 0; return v; }
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
         for (int m = 0; m < NF0; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf0[m], base[toff0[m]], acc, 0, 0, 0);
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));    // the relu of vmc_act_rt is an asm v_max_f32 (common.hpp: vmc_mfma_settle)
         f32x4 v = acc;
-        if (a.post) {
+        if (a.post && !g.resnet) {          // (ResNet2D: the initial convolution is linear, wavefunctions.py:766)
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = vmc_act_rt(a.act, v[e]);
         }
@@ -236,8 +242,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
       for (int r = 0; r < 4; ++r) bias4[r] = s_bias[l * 16 + 4 * gq + r];
       const int n_pos = s1 * s2, n_tiles = (n_pos + 15) >> 4;
       const float inv_s2 = 1.f / (float)s2;
-      const bool act_out = l + 1 < L && a.post;
+      const bool act_out = !g.resnet && l + 1 < L && a.post;
       float* const po = s_patch + poff(l);
+      // residual blocks (layers.py:226-228, wavefunctions.py:766-772): an odd convolution ends in selu, an even one adds the
+      // block's input h -- the map two convolutions below, with ITS boxes overlaid -- as k_cgen_band's epilogues 11 and 8 do
+      const bool res_selu = g.resnet && (l & 1), res_add = g.resnet && !(l & 1);
+      const int ro1[2] = {cp_wrap(q1[0] - (l + 1) * g.hi, D1), cp_wrap(q1[1] - (l + 1) * g.hi, D1)};        // this convolution's boxes
+      const int ro2[2] = {cp_wrap(q2[0] - (l + 1) * g.hi2, D2), cp_wrap(q2[1] - (l + 1) * g.hi2, D2)};
+      const int hb1[2] = {cp_wrap(q1[0] - (l - 1) * g.hi, D1), cp_wrap(q1[1] - (l - 1) * g.hi, D1)};        // the boxes of h (convolution l - 2)
+      const int hb2[2] = {cp_wrap(q2[0] - (l - 1) * g.hi2, D2), cp_wrap(q2[1] - (l - 1) * g.hi2, D2)};
+      const int hs1 = res_add ? side1(l - 2) : 1, hs2 = res_add ? side2(l - 2) : 1;
+      const float* const hp = res_add ? s_patch + poff(l - 2) : s_patch;
+      const float* const hmap = a.maps + (res_add ? l - 2 : 0) * a.map_stride + c * N * Fp;
       // the wave's tiles two at a time: two independent accumulator chains keep the matrix pipe busy where one wave per
       // SIMD would wait for every MFMA's result (a tile's own chain, and so its bits, are the same)
       auto locate = [&](int tt, int& b, int& q) {
@@ -253,6 +269,24 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
         if (act_out) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = vmc_act_rt(a.act, v[e]);
+        } else if (res_selu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = cp_selu(v[e]);
+        } else if (res_add) {
+          const int qq = q < n_pos ? q : n_pos - 1;
+          const int y = cp_div(qq, inv_s2), x = qq - y * s2;
+          const int a1 = cp_fold((b ? ro1[1] : ro1[0]) + y, D1), a2 = cp_fold((b ? ro2[1] : ro2[0]) + x, D2);
+          f32x4 h = {0.f, 0.f, 0.f, 0.f};
+          if (4 * gq < Fp) {
+            h = *(const f32x4*)(hmap + (long long)(a1 * D2 + a2) * Fp + 4 * gq);
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+              const int r1 = cp_rel(a1, hb1[bb], D1), r2 = cp_rel(a2, hb2[bb], D2);
+              if (r1 < hs1 && r2 < hs2) h = *(const f32x4*)(hp + bb * hs1 * hs2 * 16 + (r1 * hs2 + r2) * 16 + 4 * gq);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += h[e];
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = 4 * gq + e < F ? v[e] : 0.f;

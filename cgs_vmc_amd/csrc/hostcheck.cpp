@@ -399,9 +399,11 @@ static void conv_grid() {
                 }
                 if (plan_cgen_patch_ok(p.cg, B)) {      // the patch kernels' LDS plan: within a CU's, every piece inside it
                   const size_t lds = plan_cgen_patch_lds_bytes(p.cg);
-                  CHECK(lds <= PLAN_CGEN_PATCH_LDS && !resnet && F <= 16 && L >= 2);
-                  CHECK(plan_cgen_patch_side(p.cg, L - 1, 0) <= p.cg.D1 && plan_cgen_patch_side(p.cg, L - 1, 1) <= p.cg.D2);
-                  CHECK(2LL * plan_cgen_patch_side(p.cg, L - 1, 0) * plan_cgen_patch_side(p.cg, L - 1, 1) <= 32768);   // 16-bit marks: the last index is 2 s1 s2 - 1
+                  const int nc = p.cg.n_conv;
+                  CHECK(lds <= PLAN_CGEN_PATCH_LDS && F <= 16 && nc >= 2 && nc <= 9);
+                  CHECK(plan_cgen_patch_side(p.cg, nc - 1, 0) <= p.cg.D1 && plan_cgen_patch_side(p.cg, nc - 1, 1) <= p.cg.D2);
+                  CHECK(2LL * plan_cgen_patch_side(p.cg, nc - 1, 0) * plan_cgen_patch_side(p.cg, nc - 1, 1) <= 32768);   // 16-bit marks: the last index is 2 s1 s2 - 1
+                  CHECK(!resnet || !plan_cgen_patch_routes(p.cg, B));      // residual networks come here only when the fused kernels refuse them
                 }
                 CHECK((long long)p.cg.N * plan_cgen_lda(p.cg) < (1LL << 28));
                 // the band kernel of the general path (<= 16 filters, 2 .. 7 taps): a band with its halo fits its LDS

@@ -157,7 +157,7 @@ inline int plan_cgen_sweep_groups(const ConvGeom& g, long long B, int num_cus) {
 // and convolution l's output changes only in a box of (l + 1)(K - 1) + 1 sites per axis around each of them (the union of
 // the taps' reach: graph_builders.py:67-71 proposes, layers.py:118-160 convolves).  One workgroup per chain keeps the
 // chain's maps of every convolution in HBM and recomputes the two boxes per convolution instead of the lattice.
-// Shapes: Conv2DNetwork / Conv1DNetwork (no residual blocks), the band kernel's single-block shapes (<= 16 filters, so that a box
+// Shapes: Conv2DNetwork / Conv1DNetwork / ResNet2D / ResNet1D, the band kernel's single-block shapes (<= 16 filters, so that a box
 // value has k_cgen_band's bits), at least two convolutions, the last box within the lattice along both axes (it must not
 // meet itself around the torus), and the LDS within a CU's.
 inline int plan_cgen_patch_side(const ConvGeom& g, int l, int axis) { return (l + 1) * ((axis ? g.KW : g.K) - 1) + 1; }
@@ -180,7 +180,7 @@ inline size_t plan_cgen_patch_lds_bytes(const ConvGeom& g) {
 }
 #define PLAN_CGEN_PATCH_LDS (156 * 1024)
 inline bool plan_cgen_patch_ok(const ConvGeom& g, long long B) {
-  if (g.resnet || g.n_conv < 2 || g.n_conv > 8 || g.F > 16 || !plan_cgen_band_ok(g)) return false;
+  if (g.n_conv < 2 || g.n_conv > 9 || g.F > 16 || !plan_cgen_band_ok(g)) return false;       // (residual networks: 1 + 2 blocks convolutions)
   if (plan_cgen_patch_side(g, g.n_conv - 1, 0) > g.D1 || plan_cgen_patch_side(g, g.n_conv - 1, 1) > g.D2) return false;
   if (g.N > 16384 || B < 1) return false;
   if ((long long)g.n_conv * B * g.N * ((g.F + 3) & ~3) * (long long)sizeof(float) > (4LL << 30)) return false;   // the chains' maps
@@ -195,7 +195,7 @@ inline bool plan_cgen_patch_pays(const ConvGeom& g) {
 // 24 x 24, 2 x 16 filters 5 x 5 (18 %): 36.2 -> 19.8 ms; 20 x 20, 3 x 16 filters 3 x 3 (14 %): 17.6 -> 13.6 ms.  plan_desc sends
 // such a shape to the general path although the fused kernels would take it (CGS_VMC_CONV_GENERAL=0: not by preference).
 inline bool plan_cgen_patch_routes(const ConvGeom& g, long long B) {
-  if (!plan_cgen_patch_ok(g, B) || !plan_cgen_patch_pays(g)) return false;
+  if (g.resnet || !plan_cgen_patch_ok(g, B) || !plan_cgen_patch_pays(g)) return false;      // (residual networks: not measured against their fused kernels)
   long long boxes = 0;
   for (int l = 0; l < g.n_conv; ++l) boxes += 2LL * plan_cgen_patch_side(g, l, 0) * plan_cgen_patch_side(g, l, 1);
   return 5 * boxes <= (long long)g.n_conv * g.N;

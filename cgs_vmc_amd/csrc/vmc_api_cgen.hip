@@ -121,7 +121,7 @@ void cgen_patch_args(const vmc_ctx* c, int which, CgenPatchArgs* a) {
   memset(a, 0, sizeof(*a));
   a->g = g; a->Fp = cgen_fp(g); a->theta = c->ps[which].theta; a->maps = c->cg_pmaps;
   a->map_stride = (long long)c->B * g.N * cgen_fp(g);
-  a->post = g.hact != VMC_ACT_COS_ ? 1 : 0; a->act = g.hact; a->oact = c->oact;
+  a->post = (g.resnet || g.hact != VMC_ACT_COS_) ? 1 : 0; a->act = g.hact; a->oact = c->oact;      // cgen_post
   a->configs = c->configs; a->B = c->B;
 }
 

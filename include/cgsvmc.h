@@ -354,7 +354,7 @@ int vmc_debug_kernel_path(vmc_ctx* ctx, int32_t* path);
 int vmc_debug_sweep_tile(vmc_ctx* ctx, int32_t set, int32_t* chains);
 /* Would vmc_mc_steps(n_steps) run the patch sampler of the general convolution path (k_cgen_patch_sweep,
  * cgs_vmc_amd/csrc/conv_patch.hip)?  It recomputes, per step, only the two boxes of every convolution that the exchanged
- * pair of graph_builders.py:67-71 reaches through layers.py:118-160's taps -- Conv2DNetwork / Conv1DNetwork at <= 16
+ * pair of graph_builders.py:67-71 reaches through layers.py:118-160's taps -- the four convolutional ansatz types at <= 16
  * filters on a lattice wider than the last box, launches of >= 8 steps; CGS_VMC_CONV_PATCH=0 never, =2 wherever the shape
  * allows -- and gives the chains of the full-forward sampler bit for bit.  *patch: 1 / 0.
  * The local energies' connected configurations (operators.py:162-169) run through the same kernel's second form.

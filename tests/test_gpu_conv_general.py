@@ -361,6 +361,9 @@ PATCH_SHAPES = [
     ('conv_2d', 24, 24, 4, 16, 2, 3, 'sigmoid'),    # four convolutions of 2 x 2 taps
     ('conv_1d', 40, 1, 3, 16, 5, 4, 'relu'),        # 1-D: boxes of 5, 9, 13 sites
     ('conv_1d', 30, 1, 2, 10, 6, 5, 'tanh'),        # ... even kernel: 3 in front, 2 behind
+    ('res_net_2d', 20, 20, 1, 16, 3, 4, 'relu'),    # one residual block: initial convolution, selu, h + second convolution
+    ('res_net_2d', 24, 22, 2, 12, 3, 3, 'relu'),    # two blocks: five convolutions, boxes up to 11 sites
+    ('res_net_1d', 60, 1, 2, 16, 5, 4, 'relu'),     # 1-D residual network: boxes up to 21 sites
 ]
 
 
@@ -614,14 +617,15 @@ def test_general_convolution_non_exp_output_activation(monkeypatch, oact):
   eng.close()
 
 
-def test_general_convolution_shard_invariance_and_reproducibility():
+@pytest.mark.parametrize('ansatz,sx,sy,L,f,k,patch', [('conv_2d', 6, 6, 2, 72, 3, False),
+                                                      ('conv_2d', 20, 20, 3, 16, 3, True)])     # routed to the patch kernels
+def test_general_convolution_shard_invariance_and_reproducibility(ansatz, sx, sy, L, f, k, patch):
   """Chains [16, 48) of a 64-chain run walk the same trajectory as a 32-chain shard with chain_offset 16 (Philox keyed
   by the global chain id; no float atomics, a fixed order of additions: the energies are the same bits too), two
   identical runs agree bit for bit -- and so do the gradient sums of two identical accumulate calls (split-K partials
-  folded in slice order)."""
-  from cgs_vmc_amd import _hip
+  folded in slice order).  Also on the patch kernels (a chain is a workgroup's business; a row's boxes do not depend on
+  the rows beside it)."""
   from cgs_vmc_amd.engine import VmcEngine
-  ansatz, sx, sy, L, f, k = 'conv_2d', 6, 6, 2, 72, 3
   n, geom = sx * sy, (f, k, sx, sy)
   rng = np.random.default_rng(3)
   theta = (0.5 * vo.conv_init_params(ansatz, geom, L, rng)).astype(np.float32)
@@ -629,8 +633,8 @@ def test_general_convolution_shard_invariance_and_reproducibility():
   outs = []
   for (b, off, rows) in ((64, 0, slice(0, 64)), (64, 0, slice(0, 64)), (32, 16, slice(16, 48))):
     eng = VmcEngine(n, b, L, f, seed=11, ansatz=ansatz, kernel_size=k, size_x=sx, size_y=sy, chain_offset=off)
-    assert eng.kernel_path() == 6
-    eng.set_params(theta); eng.set_configs(cfg[rows]); eng.set_bonds(vo.torus_bonds(6, 6), -1.0, 1.0)
+    assert eng.kernel_path() == 6 and eng.conv_patch(n) == patch
+    eng.set_params(theta); eng.set_configs(cfg[rows]); eng.set_bonds(vo.torus_bonds(sx, sy), -1.0, 1.0)
     eng.mc_steps(n)
     eng.reset_accumulators()
     eng.accumulate(_hip.VMC_MODE_ENERGY_GRADIENT)
