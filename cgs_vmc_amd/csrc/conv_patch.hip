@@ -33,7 +33,8 @@ __device__ __forceinline__ float cp_selu(float x) {   // layers.py:226 tf.nn.sel
   const float scale = 1.0507009873554805f, alpha = 1.6732632423543772f;
   return scale * (x > 0.f ? x : alpha * (expf(x) - 1.f));
 }
-__device__ __forceinline__ int cp_wrap(int v, int d) { v %= d; return v < 0 ? v + d : v; }
+// v in [-2 d, d): a site coordinate minus a box / window offset (at most the last box's side + K - 1 <= 2 d) -- no division
+__device__ __forceinline__ int cp_wrap(int v, int d) { v += v < 0 ? d : 0; v += v < 0 ? d : 0; return v; }
 // v in [0, 3 d): the coordinate of a window site = a wrapped origin + an offset below d + K
 __device__ __forceinline__ int cp_fold(int v, int d) { v -= v >= d ? d : 0; v -= v >= d ? d : 0; return v; }
 // a - b for a, b in [0, d), wrapped
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
   __syncthreads();
 
   const int pre = a.post ? -1 : a.act;
+  const float inv_d2_ = 1.f / (float)D2;
   // phase clocks of chain 0 (diagnostic: CgenPatchArgs.prof; s_memtime ticks summed over the steps): 0 first convolution,
   // 1 staging of the others, 2 their tiles, 3 the map sum, 4 test + commit, 5 the next proposal
   unsigned long long t_prev = 0, t_ph[6] = {0, 0, 0, 0, 0, 0};
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
     } else {
       up = __builtin_amdgcn_readfirstlane(s_prop[0]); dn = __builtin_amdgcn_readfirstlane(s_prop[1]);   // (uniform: scalar arithmetic below)
     }
-    const int q1[2] = {up / D2, dn / D2};
+    const int q1[2] = {cp_div(up, inv_d2_), cp_div(dn, inv_d2_)};
     const int q2[2] = {up - q1[0] * D2, dn - q1[1] * D2};
     // ---- convolution 0: the windows are the candidate's spins (the exchanged pair negated)
     {
@@ -247,13 +249,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
       // residual blocks (layers.py:226-228, wavefunctions.py:766-772): an odd convolution ends in selu, an even one adds the
       // block's input h -- the map two convolutions below, with ITS boxes overlaid -- as k_cgen_band's epilogues 11 and 8 do
       const bool res_selu = g.resnet && (l & 1), res_add = g.resnet && !(l & 1);
-      const int ro1[2] = {cp_wrap(q1[0] - (l + 1) * g.hi, D1), cp_wrap(q1[1] - (l + 1) * g.hi, D1)};        // this convolution's boxes
-      const int ro2[2] = {cp_wrap(q2[0] - (l + 1) * g.hi2, D2), cp_wrap(q2[1] - (l + 1) * g.hi2, D2)};
-      const int hb1[2] = {cp_wrap(q1[0] - (l - 1) * g.hi, D1), cp_wrap(q1[1] - (l - 1) * g.hi, D1)};        // the boxes of h (convolution l - 2)
-      const int hb2[2] = {cp_wrap(q2[0] - (l - 1) * g.hi2, D2), cp_wrap(q2[1] - (l - 1) * g.hi2, D2)};
-      const int hs1 = res_add ? side1(l - 2) : 1, hs2 = res_add ? side2(l - 2) : 1;
-      const float* const hp = res_add ? s_patch + poff(l - 2) : s_patch;
-      const float* const hmap = a.maps + (res_add ? l - 2 : 0) * a.map_stride + c * N * Fp;
+      int ro1[2] = {0, 0}, ro2[2] = {0, 0}, hb1[2] = {0, 0}, hb2[2] = {0, 0}, hs1 = 1, hs2 = 1;     // (plain networks pay nothing for these)
+      const float* hp = s_patch;
+      const float* hmap = a.maps;
+      if (res_add) {
+        for (int bb = 0; bb < 2; ++bb) {
+          ro1[bb] = cp_wrap(q1[bb] - (l + 1) * g.hi, D1); ro2[bb] = cp_wrap(q2[bb] - (l + 1) * g.hi2, D2);      // this convolution's boxes
+          hb1[bb] = cp_wrap(q1[bb] - (l - 1) * g.hi, D1); hb2[bb] = cp_wrap(q2[bb] - (l - 1) * g.hi2, D2);      // the boxes of h (convolution l - 2)
+        }
+        hs1 = side1(l - 2); hs2 = side2(l - 2);
+        hp = s_patch + poff(l - 2);
+        hmap = a.maps + (l - 2) * a.map_stride + c * N * Fp;
+      }
       // the wave's tiles two at a time: two independent accumulator chains keep the matrix pipe busy where one wave per
       // SIMD would wait for every MFMA's result (a tile's own chain, and so its bits, are the same)
       auto locate = [&](int tt, int& b, int& q) {
