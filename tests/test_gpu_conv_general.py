@@ -568,6 +568,38 @@ def test_general_convolution_through_run_training_and_evaluation(tmp_path):
   run_energy_evaluation.main(['--checkpoint_dir', d, '--heisenberg_jx', '-1.0', '--hparams', 'num_evaluation_samples=5'])
 
 
+def test_patch_kernels_through_run_training(tmp_path, monkeypatch):
+  """--wavefunction_type=conv_1d on a 40-site chain, two convolutions of 3 taps: plan_desc routes the shape to the general
+  path's patch kernels.  Six EnergyGradient epochs through the run_training counterpart, with the patch kernels and with
+  full forwards of every candidate and connected configuration (CGS_VMC_CONV_PATCH=0): chains, local energies and gradient
+  sums are the same bits, so the two energy histories are the same numbers."""
+  import os
+  from cgs_vmc_amd import run_training, session as session_lib, wavefunctions
+  hp = ('batch_size=64,num_conv_layers=2,num_conv_filters=8,kernel_size=3,num_equilibration_sweeps=2,'
+        'num_batches_per_epoch=4,learning_rates=[0.002],learning_rate_stops=[]')
+  from cgs_vmc_amd.engine import VmcEngine
+  monkeypatch.delenv('CGS_VMC_CONV_GENERAL', raising=False)
+  probe = VmcEngine(40, 64, 2, 8, ansatz='conv_1d', kernel_size=3)
+  assert probe.kernel_path() == 6 and probe.conv_patch(40)      # (the shape this training runs at)
+  probe.close()
+  histories = []
+  for patch in ('1', '0'):
+    monkeypatch.setenv('CGS_VMC_CONV_PATCH', patch)
+    session_lib.reset_default_graph()
+    wavefunctions.reset_name_scope()
+    os.environ.update(CGS_VMC_SEED='7', CGS_VMC_CONFIG_SEED='5', CGS_VMC_INIT_SEED='3')
+    d = str(tmp_path / ('patch' + patch))
+    os.makedirs(d)
+    run_training.main(['--checkpoint_dir', d, '--num_sites', '40', '--heisenberg_jx', '-1.0',
+                       '--wavefunction_type', 'conv_1d', '--optimizer', 'EnergyGradient',
+                       '--num_epochs', '6', '--hparams', hp])
+    histories.append([float(x) for x in open(os.path.join(d, 'metrics.txt')).read().split()])
+  assert len(histories[0]) == 6 and np.isfinite(histories[0]).all()
+  assert histories[0] == histories[1], histories
+  session_lib.reset_default_graph()
+  wavefunctions.reset_name_scope()
+
+
 @pytest.mark.parametrize('ansatz,f,k', [('conv_2d', 8, 3), ('res_net_2d', 8, 3), ('conv_2d', 80, 3), ('conv_1d', 6, 11)])
 def test_general_convolution_log_overlap_itswo_accumulators(monkeypatch, ansatz, f, k):
   """training.py:655-705 on the general path (forced where the fused kernels would take the shape): the supervisor's
