@@ -62,9 +62,16 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
   const int D1 = g.D1, D2 = g.D2, N = g.N, F = g.F, Fp = a.Fp, L = g.n_conv, FQ = Fp >> 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, gq = lane >> 4;
   long long c = blockIdx.x;                    // the chain (ELOC: of the row at hand)
-  auto side1 = [&](int l) { return (l + 1) * (K - 1) + 1; };
-  auto side2 = [&](int l) { return (l + 1) * (KW - 1) + 1; };
-  auto poff = [&](int l) { int o = 0; for (int j = 0; j < l; ++j) o += 2 * side1(j) * side2(j) * 16; return o; };
+  // ELOC: a bond's two sites are neighbours, their boxes overlap almost entirely -- ONE box per convolution then, the two
+  // boxes' bounding box: e1 x e2 sites larger (the sites' displacement), anchored at the first site along each axis; its
+  // positions outside both boxes recompute what is stored.  It lives in the space of the two (nbx = 1).
+  int e1 = 0, e2 = 0, nbx = 2;
+  auto base1 = [&](int l) { return (l + 1) * (K - 1) + 1; };
+  auto base2 = [&](int l) { return (l + 1) * (KW - 1) + 1; };
+  auto side1 = [&](int l) { return base1(l) + (ELOC ? e1 : 0); };
+  auto side2 = [&](int l) { return base2(l) + (ELOC ? e2 : 0); };
+  auto poff = [&](int l) { int o = 0; for (int j = 0; j < l; ++j) o += 2 * base1(j) * base2(j) * 16; return o; };
+#define NBX (ELOC ? nbx : 2)
   // ---- LDS (plan_cgen_patch_lds_bytes): spins, weight fragments, biases, the boxes of every convolution, two windows
   float* const s_x = sm;
   float* const s_wf = s_x + ((N + 3) & ~3);
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
   float* const s_patch = s_bias + L * 16;
   float* const s_win = s_patch + poff(L);
   int wstride = (2 * K - 1) * (2 * KW - 1);
-  for (int l = 1; l < L; ++l) wstride = max(wstride, (side1(l) + K - 1) * (side2(l) + KW - 1) * 16);
+  for (int l = 1; l < L; ++l) wstride = max(wstride, (base1(l) + K - 1) * (base2(l) + KW - 1) * 16);
   short* const s_ovl = (short*)(s_win + 2 * wstride);     // [N]: the place of a site in the last convolution's boxes, or -1
 
   // ---- once per launch: the chain, the parameters
@@ -91,12 +98,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
     s_bias[i] = f < F ? b[f] : 0.f;
   }
   float wf0[NF0];                              // first convolution: the taps run over the MFMA's k index (k_cgen_band<FIRST>)
-  int toff0[NF0];
+  int tr0[NF0], tc0[NF0];                      // ... this lane's tap of MFMA m: its row and column in the window
 #pragma unroll
   for (int m = 0; m < NF0; ++m) {
     const int t = 4 * m + gq, tt = t < T ? t : 0;
     wf0[m] = (t < T && p < F) ? a.theta[(long long)t * F + p] : 0.f;
-    toff0[m] = (tt / KW) * (2 * KW - 1) + (tt % KW);
+    tr0[m] = tt / KW; tc0[m] = tt % KW;
   }
   float cur_logit = 0.f;
   unsigned n_acc = 0;
@@ -127,15 +134,26 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
     } else {
       up = __builtin_amdgcn_readfirstlane(s_prop[0]); dn = __builtin_amdgcn_readfirstlane(s_prop[1]);   // (uniform: scalar arithmetic below)
     }
-    const int q1[2] = {cp_div(up, inv_d2_), cp_div(dn, inv_d2_)};
-    const int q2[2] = {up - q1[0] * D2, dn - q1[1] * D2};
+    int q1[2] = {cp_div(up, inv_d2_), cp_div(dn, inv_d2_)};
+    int q2[2] = {up - q1[0] * D2, dn - q1[1] * D2};
+    if (ELOC) {
+      int dy = q1[1] - q1[0], dx = q2[1] - q2[0];           // the second site from the first, the shorter way round
+      dy += dy > D1 / 2 ? -D1 : (dy < -((D1 - 1) / 2) ? D1 : 0);
+      dx += dx > D2 / 2 ? -D2 : (dx < -((D2 - 1) / 2) ? D2 : 0);
+      const int ady = dy < 0 ? -dy : dy, adx = dx < 0 ? -dx : dx;
+      const bool merged = ady <= 1 && adx <= 1 && base1(L - 1) + ady <= D1 && base2(L - 1) + adx <= D2 &&
+                          (K + ady) * (KW + adx) <= 2 * K * KW;       // (the first convolution's box is the tightest fit)
+      e1 = merged ? ady : 0; e2 = merged ? adx : 0; nbx = merged ? 1 : 2;
+      if (merged) { q1[0] = dy >= 0 ? q1[0] : q1[1]; q2[0] = dx >= 0 ? q2[0] : q2[1]; }
+    }
     // ---- convolution 0: the windows are the candidate's spins (the exchanged pair negated)
     {
-      constexpr int SR = 2 * K - 1, SC = 2 * KW - 1, n_win = SR * SC, n_pos = K * KW, n_tiles = (n_pos + 15) >> 4;
+      const int s1 = side1(0), s2 = side2(0), SC = s2 + KW - 1, n_win = (s1 + K - 1) * SC, n_pos = s1 * s2, n_tiles = (n_pos + 15) >> 4;
+      const float inv_sc = 1.f / (float)SC, inv_s2 = 1.f / (float)s2;
       const int o1[2] = {cp_wrap(q1[0] - g.hi - g.lo, D1), cp_wrap(q1[1] - g.hi - g.lo, D1)};
       const int o2[2] = {cp_wrap(q2[0] - g.hi2 - g.lo2, D2), cp_wrap(q2[1] - g.hi2 - g.lo2, D2)};
-      for (int i = tid; i < 2 * n_win; i += NT) {
-        const int b = i >= n_win, j = i - b * n_win, wy = j / SC, wx = j - wy * SC;
+      for (int i = tid; i < NBX * n_win; i += NT) {
+        const int b = i >= n_win, j = i - b * n_win, wy = cp_div(j, inv_sc), wx = j - wy * SC;
         const int site = cp_fold((b ? o1[1] : o1[0]) + wy, D1) * D2 + cp_fold((b ? o2[1] : o2[0]) + wx, D2);
         const float x = ELOC ? a.configs[c * N + site] : s_x[site];
         s_win[b * wstride + j] = (flip && (site == up || site == dn)) ? -x : x;
@@ -144,14 +162,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
       f32x4 bias4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) bias4[r] = s_bias[4 * gq + r];
-      for (int tt = wave; tt < 2 * n_tiles; tt += NW) {
+      for (int tt = wave; tt < NBX * n_tiles; tt += NW) {
         const int b = tt >= n_tiles, tile = tt - b * n_tiles;
         const int q = tile * 16 + p, qq = q < n_pos ? q : n_pos - 1;
-        const int y = qq / KW, x = qq - y * KW;
+        const int y = cp_div(qq, inv_s2), x = qq - y * s2;
         f32x4 acc = bias4;
         const float* base = s_win + b * wstride + y * SC + x;
 #pragma unroll
-        for (int m = 0; m < NF0; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf0[m], base[toff0[m]], acc, 0, 0, 0);
+        for (int m = 0; m < NF0; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf0[m], base[tr0[m] * SC + tc0[m]], acc, 0, 0, 0);
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));    // the relu of vmc_act_rt is an asm v_max_f32 (common.hpp: vmc_mfma_settle)
         f32x4 v = acc;
         if (a.post && !g.resnet) {          // (ResNet2D: the initial convolution is linear, wavefunctions.py:766)
@@ -183,7 +201,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
       const int b2[2] = {cp_wrap(q2[0] - l * g.hi2, D2), cp_wrap(q2[1] - l * g.hi2, D2)};
       const float inv_sc = 1.f / (float)SC;
       // a thread takes whole window sites (the coordinates and the box test once per site, four 16-byte quads each)
-      const int total = 2 * n_win;
+      const int total = NBX * n_win;
       constexpr int SB = 3;            // sites in flight per thread: 12 loads
       for (int i0 = tid; i0 < total; i0 += SB * NT) {
         f32x4 v[SB][4];
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
           for (int cq = 0; cq < 4; ++cq) v[uu][cq] = *(const f32x4*)(src + (4 * cq < Fp ? 4 * cq : 0));
           pat[uu] = -1;
 #pragma unroll
-          for (int bb = 0; bb < 2; ++bb) {
+          for (int bb = 0; bb < NBX; ++bb) {
             const int r1 = cp_rel(a1, b1[bb], D1), r2 = cp_rel(a2, b2[bb], D2);
             if (r1 < ps1 && r2 < ps2) pat[uu] = bb * ppos * 16 + (r1 * ps2 + r2) * 16;
           }
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
         const int bo1[2] = {cp_wrap(q1[0] - L * g.hi, D1), cp_wrap(q1[1] - L * g.hi, D1)};
         const int bo2[2] = {cp_wrap(q2[0] - L * g.hi2, D2), cp_wrap(q2[1] - L * g.hi2, D2)};
         const float inv = 1.f / (float)s2;
-        for (int i = tid; i < 2 * s1 * s2; i += NT) {
+        for (int i = tid; i < NBX * s1 * s2; i += NT) {
           const int b = i >= s1 * s2, pos = i - b * s1 * s2, y = cp_div(pos, inv), x = pos - y * s2;
           s_ovl[cp_fold((b ? bo1[1] : bo1[0]) + y, D1) * D2 + cp_fold((b ? bo2[1] : bo2[0]) + x, D2)] = (short)i;
         }
@@ -253,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
       const float* hp = s_patch;
       const float* hmap = a.maps;
       if (res_add) {
-        for (int bb = 0; bb < 2; ++bb) {
+        for (int bb = 0; bb < NBX; ++bb) {
           ro1[bb] = cp_wrap(q1[bb] - (l + 1) * g.hi, D1); ro2[bb] = cp_wrap(q2[bb] - (l + 1) * g.hi2, D2);      // this convolution's boxes
           hb1[bb] = cp_wrap(q1[bb] - (l - 1) * g.hi, D1); hb2[bb] = cp_wrap(q2[bb] - (l - 1) * g.hi2, D2);      // the boxes of h (convolution l - 2)
         }
@@ -287,7 +305,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
           if (4 * gq < Fp) {
             h = *(const f32x4*)(hmap + (long long)(a1 * D2 + a2) * Fp + 4 * gq);
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
+            for (int bb = 0; bb < NBX; ++bb) {
               const int r1 = cp_rel(a1, hb1[bb], D1), r2 = cp_rel(a2, hb2[bb], D2);
               if (r1 < hs1 && r2 < hs2) h = *(const f32x4*)(hp + bb * hs1 * hs2 * 16 + (r1 * hs2 + r2) * 16 + 4 * gq);
             }
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
         if (q < n_pos) *(f32x4*)(po + b * n_pos * 16 + q * 16 + 4 * gq) = v;
       };
       int tt = wave;
-      for (; NW == 4 && tt + NW < 2 * n_tiles; tt += 2 * NW) {      // (eight waves: two per SIMD take turns already)
+      for (; NW == 4 && tt + NW < NBX * n_tiles; tt += 2 * NW) {      // (eight waves: two per SIMD take turns already)
         int bA, qA, bB, qB;
         const float* baseA = locate(tt, bA, qA);
         const float* baseB = locate(tt + NW, bB, qB);
@@ -322,7 +340,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
         finish(accA, bA, qA);
         finish(accB, bB, qB);
       }
-      for (; tt < 2 * n_tiles; tt += NW) {
+      for (; tt < NBX * n_tiles; tt += NW) {
         int b, q;
         const float* base = locate(tt, b, q);
         f32x4 acc = bias4;
@@ -392,7 +410,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
       const int bo1[2] = {cp_wrap(q1[0] - L * g.hi, D1), cp_wrap(q1[1] - L * g.hi, D1)};
       const int bo2[2] = {cp_wrap(q2[0] - L * g.hi2, D2), cp_wrap(q2[1] - L * g.hi2, D2)};
       const float inv = 1.f / (float)s2;
-      for (int i = tid; i < 2 * s1 * s2; i += NT) {
+      for (int i = tid; i < NBX * s1 * s2; i += NT) {
         const int b = i >= s1 * s2, pos = i - b * s1 * s2, y = cp_div(pos, inv), x = pos - y * s2;
         s_ovl[cp_fold((b ? bo1[1] : bo1[0]) + y, D1) * D2 + cp_fold((b ? bo2[1] : bo2[0]) + x, D2)] = -1;
       }
@@ -467,6 +485,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
     if (n_acc) atomicAdd(a.accepted, (unsigned long long)n_acc);
   }
 }
+
+#undef NBX
 
 template <int K, int KW, int NW, bool ELOC>
 hipError_t launch_pw(hipStream_t s, const CgenPatchArgs& a, unsigned grid) {
