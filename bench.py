@@ -999,7 +999,18 @@ def main():
           exec_sweep = b * n * per_step
           if rows >= 4 * b:         # ... and the local energies' rows through its ELOC form (cgen_forward: the same boxes around the exchanged bond)
             k_eloc = 'k_cgen_patch_sweep<ELOC>(eloc)'
-            exec_eloc = rows * per_step
+            # a bond's two sites are neighbours: ONE box per convolution, e1 x e2 sites larger than s1 x s2 (the displacement);
+            # the torus has as many bonds along either axis, and with J2 as many diagonal ones as nearest-neighbour ones
+            kinds = [(1, 0), (0, 1)] + ([(1, 1), (1, 1)] if nnn else [])
+            if ly == 1: kinds = [(1, 0)]
+            per_row = 0.0
+            for e1, e2 in kinds:
+              mf = ((ksz + e1) * (kw + e2) + 15) // 16 * ((taps + 3) // 4)
+              for l in range(1, L):
+                s1, s2 = (l + 1) * (ksz - 1) + 1 + e1, (l + 1) * (kw - 1) + 1 + e2
+                mf += (s1 * s2 + 15) // 16 * taps * 4
+              per_row += mf * 2048 / len(kinds)
+            exec_eloc = rows * per_row
       if not conv and h > 512:        # the general path: per mc_step one k_wide_step launch + the H x H layers as GEMMs
         k_sweep = 'k_wide_step + k_gemm_ring(sampler)'
       per_kernel = {
