@@ -81,6 +81,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
   int wstride = (2 * K - 1) * (2 * KW - 1);
   for (int l = 1; l < L; ++l) wstride = max(wstride, (base1(l) + K - 1) * (base2(l) + KW - 1) * 16);
   short* const s_ovl = (short*)(s_win + 2 * wstride);     // [N]: the place of a site in the last convolution's boxes, or -1
+  float* const s_ru = s_win + 2 * wstride + (N + 7) / 8 * 4;  // [N]: the next step's site uniforms (eight waves: drawn under the map sum)
+  __shared__ float s_unext;                               // ... and its acceptance uniform
 
   // ---- once per launch: the chain, the parameters
   const long long w_base1 = (long long)T * F + F, w_per = (long long)T * F * F + F;     // theta: w_0, b_0, then (w_l, b_l)
@@ -387,6 +389,22 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
       for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
       if (lane == 0 && wave < 4) s_w[wave] = s;
     }
+    if (NW == 8 && !ELOC && tid >= 256 && st + 1 < a.n_steps) {
+      // waves 4 .. 7 have no part in the map sum (its order is 256 threads'): they draw the NEXT step's uniforms meanwhile --
+      // Philox does not depend on how this step ends, only the spins they multiply do
+      const unsigned long long next_step = a.step0 + (unsigned long long)st + 1;
+      const uint2 key = make_uint2(a.seed_lo, a.seed_hi);
+      const uint32_t gid = (uint32_t)(a.chain_offset + (int)c);
+      const int nblk = (N + 3) >> 2;
+      for (int b = tid - 256; b < nblk; b += NT - 256) {
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)b, gid, (uint32_t)next_step, (uint32_t)(next_step >> 32)), key);
+        *(f32x4*)(s_ru + 4 * b) = f32x4{u32_to_uniform(r.x), u32_to_uniform(r.y), u32_to_uniform(r.z), u32_to_uniform(r.w)};
+      }
+      if (tid == 256) {
+        const uint4 ra = philox4x32_10(make_uint4(VMC_ACCEPT_BLOCK, gid, (uint32_t)next_step, (uint32_t)(next_step >> 32)), key);
+        s_unext = u32_to_uniform(ra.x);
+      }
+    }
     __syncthreads();
     stamp(3);
     if (ELOC) {
@@ -444,13 +462,17 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
       int idx_hi = 0x7fffffff, idx_lo = 0x7fffffff;
       const int nblk = (N + 3) >> 2;
       for (int b = tid; b < nblk; b += NT) {
-        const uint4 r = philox4x32_10(make_uint4((uint32_t)b, gid, (uint32_t)next_step, (uint32_t)(next_step >> 32)), key);
-        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+        f32x4 ur;
+        if (NW == 8) ur = *(const f32x4*)(s_ru + 4 * b);
+        else {
+          const uint4 r = philox4x32_10(make_uint4((uint32_t)b, gid, (uint32_t)next_step, (uint32_t)(next_step >> 32)), key);
+          ur = f32x4{u32_to_uniform(r.x), u32_to_uniform(r.y), u32_to_uniform(r.z), u32_to_uniform(r.w)};
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int i = 4 * b + e;
           if (i < N) {
-            const float v = s_x[i] * u32_to_uniform(rr[e]);
+            const float v = s_x[i] * ur[e];
             if (v > best_hi) { best_hi = v; idx_hi = i; }
             if (v < best_lo) { best_lo = v; idx_lo = i; }
           }
@@ -472,8 +494,12 @@ __global__ __launch_bounds__(64 * NW, 1) void k_cgen_patch_sweep(CgenPatchArgs a
           const float ol = s_bv[1][wv]; const int il = s_bi[1][wv];
           if (ol < best_lo || (ol == best_lo && il < idx_lo)) { best_lo = ol; idx_lo = il; }
         }
-        const uint4 ra = philox4x32_10(make_uint4(VMC_ACCEPT_BLOCK, gid, (uint32_t)next_step, (uint32_t)(next_step >> 32)), key);
-        s_prop[0] = idx_hi; s_prop[1] = idx_lo; s_u = u32_to_uniform(ra.x);
+        float un = s_unext;
+        if (NW != 8) {
+          const uint4 ra = philox4x32_10(make_uint4(VMC_ACCEPT_BLOCK, gid, (uint32_t)next_step, (uint32_t)(next_step >> 32)), key);
+          un = u32_to_uniform(ra.x);
+        }
+        s_prop[0] = idx_hi; s_prop[1] = idx_lo; s_u = un;
       }
     }
     __syncthreads();      // the proposal; an accepted move's map writes are behind this for every wave of the workgroup

@@ -466,9 +466,9 @@ static void conv_grid() {
     CHECK(plan_desc(&b, true, &q, msg, sizeof(msg)) == VMC_OK && q.conv_general && plan_cgen_band_ok(q.cg));
     CHECK(plan_cgen_band_rows(q.cg) == 12 && plan_cgen_band_lds_bytes(q.cg, false) == 16u * 40u * 64u);
     // the patch sampler: boxes of 5, 9, 13 sites per axis; spins 1,296 + fragments 2 x 25 x 256 + biases 48 + boxes
-    // 2 x 16 (25 + 81 + 169) + two windows of 17 x 17 x 16 floats + 1,296 16-bit marks
+    // 2 x 16 (25 + 81 + 169) + two windows of 17 x 17 x 16 floats + 1,296 16-bit marks + 1,296 uniforms
     CHECK(plan_cgen_patch_ok(q.cg, 32) && plan_cgen_patch_pays(q.cg) && plan_cgen_patch_side(q.cg, 2, 0) == 13);
-    CHECK(plan_cgen_patch_lds_bytes(q.cg) == 4u * (1296u + 12800u + 48u + 8800u + 2u * 4624u + 648u) + 256u);
+    CHECK(plan_cgen_patch_lds_bytes(q.cg) == 4u * (1296u + 12800u + 48u + 8800u + 2u * 4624u + 648u + 1296u) + 256u);
     {
       DescPlan t; vmc_desc s = b;
       s.size_x = s.size_y = 12; s.n_sites = 144;                       // the last box (13) would meet itself around the torus

@@ -175,7 +175,8 @@ inline size_t plan_cgen_patch_lds_bytes(const ConvGeom& g) {
     }
   }
   fl += 2 * win;                                                   // the two staged input windows
-  fl += (size_t)((g.N + 1) / 2);                                   // 16-bit marks of the sites inside the last convolution's boxes
+  fl += (size_t)((g.N + 7) / 8 * 4);                               // 16-bit marks of the sites inside the last convolution's boxes
+  fl += (size_t)((g.N + 3) & ~3);                                  // the next step's site uniforms
   return fl * sizeof(float) + 256;                                 // + the step's scalars
 }
 #define PLAN_CGEN_PATCH_LDS (156 * 1024)
